@@ -1,0 +1,188 @@
+"""Generate golden fixtures by RUNNING THE REAL REFERENCE (TEST INFRASTRUCTURE; this container only).
+
+Usage (from the repo root, needs /root/reference):   python -m oracle.gen_golden
+Writes small .npz files under tests/golden/ that pin the oracle (tests/test_oracle_golden.py) and the
+HIP path (tests/test_gpu_*.py).  /root/reference does not exist on the GPU box, so nothing else may
+import it; the fixtures travel instead.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def import_reference():
+    for p in (os.path.join(HERE, "stubs"), REF, REF + "/torchlie", REF + "/torchkin"):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    warnings.filterwarnings("ignore")
+    import theseus as th  # noqa
+    import torchlie.functional as lieF  # noqa
+    return th, lieF
+
+
+def special_tangents(dtype, gen):
+    """Angles the reference's own tests sweep (tests/theseus_tests/geometry/test_se3.py:57-62,108-113)
+    plus random ones; exercises near-zero / d-near-zero / near-pi branches."""
+    angles = [0.0, 1e-7, 1e-5, 3e-3, 7e-3, 1.2e-2, 5e-2, 1.5e-1, 2.5e-1, 1.0, 2.0, 3.0,
+              np.pi - 1e-3, np.pi - 1e-5, np.pi - 1e-7, np.pi - 1e-11, np.pi - 0.05, np.pi - 0.12]
+    out = []
+    for a in angles:
+        for _ in range(3):
+            ax = torch.randn(3, dtype=torch.float64, generator=gen)
+            ax = ax / ax.norm()
+            v = torch.randn(3, dtype=torch.float64, generator=gen)
+            out.append(torch.cat([v, ax * a]))
+    rnd = torch.randn(40, 6, dtype=torch.float64, generator=gen)
+    return torch.cat([torch.stack(out), rnd]).to(dtype)
+
+
+def gen_lie(th, lieF):
+    gen = torch.Generator().manual_seed(7)
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        xi = special_tangents(dtype, gen)
+        SE3 = lieF.SE3
+        jl = []
+        X = SE3.exp(xi, jacobians=jl)  # (SE3.jexp() itself trips a reference typo: module.name)
+        jexp = jl[0]
+        Y = SE3.exp(special_tangents(dtype, gen))
+        jl = []
+        log = SE3.log(X, jacobians=jl)
+        jlog = jl[0]
+        np.savez_compressed(
+            os.path.join(OUT, f"lie_se3_{tag}.npz"),
+            xi=xi.numpy(), exp=X.numpy(), jexp=jexp.numpy(), log=log.numpy(), jlog=jlog.numpy(),
+            adj=SE3.adj(X).numpy(), inv=SE3.inv(X).numpy(), Y=Y.numpy(),
+            compose=SE3.compose(X, Y).numpy(),
+        )
+
+
+def make_problem(P, E, B, dtype, seed, th, lieF, batched_weights=False, pose_noise=(0.1, 0.08)):
+    """Small random pose graph in the packed layout of oracle.pose_graph.PGProblem."""
+    gen = torch.Generator().manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    edges = [(i, i + 1) for i in range(P - 1)]
+    while len(edges) < E:
+        i, j = sorted(rng.choice(P, 2, replace=False).tolist())
+        if rng.random() < 0.3:
+            i, j = j, i  # some edges point "backwards"
+        edges.append((i, j))
+    edges = torch.tensor(edges, dtype=torch.long)
+    SE3 = lieF.SE3
+
+    def rnd(n, ts, rs):
+        x = torch.cat([ts * (2 * torch.rand(n, 3, dtype=torch.float64, generator=gen) - 1),
+                       rs * (2 * torch.rand(n, 3, dtype=torch.float64, generator=gen) - 1)], 1)
+        return SE3.exp(x)
+
+    gt = rnd(B * P, 2.0, 1.5).view(B, P, 3, 4)
+    gi, gj = gt[:, edges[:, 0]], gt[:, edges[:, 1]]
+    rel = SE3.compose(SE3.inv(gi.reshape(-1, 3, 4)), gj.reshape(-1, 3, 4))
+    meas = SE3.compose(rel, rnd(B * E, 0.05, 0.02)).view(B, E, 3, 4)
+    poses = SE3.compose(gt.reshape(-1, 3, 4), rnd(B * P, *pose_noise)).view(B, P, 3, 4)
+    if batched_weights:
+        w_between = (0.5 + torch.rand(B, E, 6, dtype=torch.float64, generator=gen)) * 10
+    else:
+        w_between = torch.tensor([[[1 / 0.05] * 3 + [1 / 0.02] * 3]], dtype=torch.float64).repeat(1, E, 1)
+    prior_idx = torch.tensor([0, P // 2], dtype=torch.long)
+    prior_target = SE3.compose(gt[:, prior_idx].reshape(-1, 3, 4), rnd(B * 2, 0.01, 0.01)).view(B, 2, 3, 4)
+    w_prior = torch.tensor([[[1e-1] * 6, [3.0] * 6]], dtype=torch.float64)
+    f = lambda t: t.to(dtype)  # noqa
+    return dict(P=P, edges=edges, meas=f(meas), w_between=f(w_between), prior_idx=prior_idx,
+                prior_target=f(prior_target), w_prior=f(w_prior), poses=f(poses))
+
+
+def build_reference_objective(th, d, dtype):
+    """Between per edge (add order = edge order), then Difference priors: mirrors
+    examples/pose_graph/pose_graph_synthetic.py:130-152."""
+    B = d["poses"].shape[0]
+    obj = th.Objective(dtype=dtype)
+    poses = [th.SE3(tensor=d["poses"][:, k].clone(), name=f"pose_{k}") for k in range(d["P"])]
+    for k in range(d["edges"].shape[0]):
+        i, j = d["edges"][k].tolist()
+        w = d["w_between"][:, k]
+        cw = th.DiagonalCostWeight(th.Variable(w.clone(), name=f"w_{k}"))
+        m = th.SE3(tensor=d["meas"][:, k].clone(), name=f"meas_{k}")
+        obj.add(th.Between(poses[i], poses[j], m, cw, name=f"between_{k}"))
+    for k in range(d["prior_idx"].shape[0]):
+        tgt = th.SE3(tensor=d["prior_target"][:, k].clone(), name=f"prior_target_{k}")
+        sw = th.ScaleCostWeight(th.Variable(d["w_prior"][:, k, :1].clone(), name=f"pw_{k}"))
+        obj.add(th.Difference(poses[int(d["prior_idx"][k])], tgt, sw, name=f"prior_{k}"))
+    obj.update()
+    assert obj.batch_size == B
+    return obj, poses
+
+
+def gen_lm(th, lieF):
+    cases = [
+        ("pg_f64_lm", dict(P=8, E=14, B=3, dtype=torch.float64, seed=11),
+         dict(max_iterations=6, step_size=1.0), dict(damping=1e-3)),
+        ("pg_f32_lm", dict(P=8, E=14, B=3, dtype=torch.float32, seed=11),
+         dict(max_iterations=6, step_size=1.0), dict(damping=1e-3)),
+        ("pg_f64_lm_adaptive_ellips", dict(P=10, E=20, B=4, dtype=torch.float64, seed=5, batched_weights=True),
+         dict(max_iterations=8, step_size=0.75),
+         dict(damping=0.1, adaptive_damping=True, ellipsoidal_damping=True)),
+        ("pg_f64_lm_adaptive", dict(P=6, E=9, B=5, dtype=torch.float64, seed=3),
+         dict(max_iterations=8, step_size=1.0), dict(damping=10.0, adaptive_damping=True)),
+        ("pg_f64_lm_adaptive_rejects", dict(P=9, E=16, B=6, dtype=torch.float64, seed=21, pose_noise=(1.5, 1.6)),
+         dict(max_iterations=12, step_size=1.0), dict(damping=1e-4, adaptive_damping=True, damping_accept=0.9)),
+        ("pg_f64_gn", dict(P=7, E=12, B=2, dtype=torch.float64, seed=9),
+         dict(max_iterations=5, step_size=1.0), None),
+    ]
+    for name, pk, ok, lmk in cases:
+        dtype = pk.pop("dtype")
+        seed = pk.pop("seed")
+        d = make_problem(dtype=dtype, seed=seed, th=th, lieF=lieF, **pk)
+        obj, poses = build_reference_objective(th, d, dtype)
+        cls = th.GaussNewton if lmk is None else th.LevenbergMarquardt
+        opt = cls(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True,
+                  abs_err_tolerance=0.0, rel_err_tolerance=0.0, **ok)
+        taps = dict(AtA=[], Atb=[], delta=[], A=[], b=[], err=[])
+
+        def cb(optimizer, info, delta, it):
+            lin = optimizer.linear_solver.linearization
+            taps["AtA"].append(lin.AtA.clone().numpy())
+            taps["Atb"].append(lin.Atb.clone().numpy())
+            taps["A"].append(lin.A.clone().numpy())
+            taps["b"].append(lin.b.clone().numpy())
+            taps["delta"].append(delta.clone().numpy())
+            taps["err"].append(info.last_err.clone().numpy())
+
+        lin = opt.linear_solver.linearization
+        struct = dict(var_start_cols=np.array(lin.var_start_cols), var_dims=np.array(lin.var_dims),
+                      num_rows=lin.num_rows, num_cols=lin.num_cols)
+        with torch.no_grad():
+            err0 = obj.error_metric().clone().numpy()
+            info = opt.optimize(track_err_history=True, end_iter_callback=cb, **(lmk or {}))
+        final = torch.stack([p.tensor for p in poses], 1).numpy()
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"),
+            P=d["P"], edges=d["edges"].numpy(), meas=d["meas"].numpy(), w_between=d["w_between"].numpy(),
+            prior_idx=d["prior_idx"].numpy(), prior_target=d["prior_target"].numpy(),
+            w_prior=d["w_prior"].numpy(), poses0=d["poses"].numpy(), final=final, err0=err0,
+            err_history=info.err_history.numpy(),
+            AtA=np.stack(taps["AtA"]), Atb=np.stack(taps["Atb"]), A0=taps["A"][0], b0=taps["b"][0],
+            delta=np.stack(taps["delta"]), last_err=np.stack(taps["err"]),
+            opt_kwargs=np.array(repr(dict(ok, **(lmk or {}), gauss_newton=lmk is None))),
+            **struct,
+        )
+        print(name, "err", err0.mean(), "->", info.err_history[:, -1].mean().item())
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    th, lieF = import_reference()
+    torch.manual_seed(0)
+    gen_lie(th, lieF)
+    gen_lm(th, lieF)
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()

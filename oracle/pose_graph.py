@@ -1,0 +1,247 @@
+"""Oracle: dense GN/LM on SE3 pose graphs, restated from the reference (TEST INFRASTRUCTURE).
+
+Follows, on packed tensors instead of per-variable Python objects:
+  Between.jacobians                 theseus/embodied/measurements/between.py:38-45
+  Local/Difference.jacobians        theseus/embodied/misc/local_cost_fn.py:39-61, theseus/geometry/lie_group.py:180-195
+  Diagonal/ScaleCostWeight          theseus/core/cost_weight.py:81-90,125-136
+  DenseLinearization                theseus/optimizer/dense_linearization.py:29-62
+  DenseSolver._apply_damping        theseus/optimizer/linear/dense_solver.py:38-64
+  CholeskyDenseSolver._solve_sytem  theseus/optimizer/linear/dense_solver.py:159-161
+  retract / error_metric            theseus/core/objective.py:37-38,562-641,873-914, theseus/core/variable.py:65-69
+  LM loop                           theseus/optimizer/nonlinear/nonlinear_least_squares.py:100-215,338-365
+                                    theseus/optimizer/nonlinear/levenberg_marquardt.py:114-201
+                                    theseus/optimizer/nonlinear/nonlinear_optimizer.py:110-119
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import lie
+
+MIN_DAMPING, MAX_DAMPING = 1.0e-7, 1.0e7  # levenberg_marquardt.py:52-53
+
+
+@dataclass
+class PGProblem:
+    """Packed pose-graph problem.  Column order = pose index order (VariableOrdering default =
+    insertion order, theseus/optimizer/variable_ordering.py:19-27); row order = ``cost_order``."""
+
+    num_poses: int
+    edges: torch.Tensor          # (E,2) long, (i,j): Between(v0=pose i, v1=pose j)
+    meas: torch.Tensor           # (B,E,3,4)
+    w_between: torch.Tensor      # (1|B, E, 6)  sqrt-information diagonal
+    prior_idx: torch.Tensor      # (K,) long
+    prior_target: torch.Tensor   # (1|B, K, 3, 4)
+    w_prior: torch.Tensor        # (1|B, K, 6)
+    cost_order: Optional[List[Tuple[str, int]]] = None  # [('between',k)|('prior',k)] add order
+
+    def __post_init__(self):
+        if self.cost_order is None:
+            self.cost_order = [("between", k) for k in range(self.edges.shape[0])] + [
+                ("prior", k) for k in range(self.prior_idx.shape[0])
+            ]
+
+    @property
+    def n(self):
+        return 6 * self.num_poses
+
+    @property
+    def m(self):
+        return 6 * len(self.cost_order)
+
+    def row_starts(self):
+        rs = {}
+        for r, c in enumerate(self.cost_order):
+            rs[c] = 6 * r
+        return rs
+
+
+def between_jac_err(v0, v1, meas, w):
+    """between.py:38-45 + cost_weight.py:125-136.  Shapes (...,3,4) x3, w (...,6)."""
+    D = lie.se3_compose(lie.se3_inverse(v0), v1)
+    E = lie.se3_compose(lie.se3_inverse(meas), D)
+    e, Jlog = lie.se3_log_jlog(E)
+    J0 = -Jlog @ lie.se3_adjoint(lie.se3_inverse(D))
+    J1 = Jlog
+    return J0 * w[..., :, None], J1 * w[..., :, None], e * w
+
+
+def local_jac_err(target, var, w):
+    """local_cost_fn.py:58-61 -> lie_group.py:180-195: e = log(target^-1 var), J = Jlog."""
+    D = lie.se3_compose(lie.se3_inverse(target), var)
+    e, Jlog = lie.se3_log_jlog(D)
+    return Jlog * w[..., :, None], e * w
+
+
+def weighted_errors(p: PGProblem, poses):
+    """Weighted residuals of all costs: (e_between (B,E,6), e_prior (B,K,6))."""
+    i, j = p.edges[:, 0], p.edges[:, 1]
+    _, _, eb = between_jac_err(poses[:, i], poses[:, j], p.meas, p.w_between)
+    _, ep = local_jac_err(p.prior_target, poses[:, p.prior_idx], p.w_prior)
+    return eb, ep
+
+
+def error_vector(p: PGProblem, poses):
+    """objective.py:562-613: concatenated weighted error (B,m) in cost add order."""
+    eb, ep = weighted_errors(p, poses)
+    cols = [eb[:, k] if kind == "between" else ep[:, k] for kind, k in p.cost_order]
+    return torch.cat(cols, dim=1)
+
+
+def error_metric(p: PGProblem, poses):
+    """objective.py:37-38,615-641: 0.5 * sum(e^2) per problem."""
+    eb, ep = weighted_errors(p, poses)
+    return 0.5 * ((eb**2).sum((1, 2)) + (ep**2).sum((1, 2)))
+
+
+def dense_linearize(p: PGProblem, poses):
+    """dense_linearization.py:29-56: dense A (B,m,n), b = -err (B,m)."""
+    B = poses.shape[0]
+    i, j = p.edges[:, 0], p.edges[:, 1]
+    J0, J1, eb = between_jac_err(poses[:, i], poses[:, j], p.meas, p.w_between)
+    Jp, ep = local_jac_err(p.prior_target, poses[:, p.prior_idx], p.w_prior)
+    A = torch.zeros(B, p.m, p.n, dtype=poses.dtype)
+    b = torch.zeros(B, p.m, dtype=poses.dtype)
+    for r, (kind, k) in enumerate(p.cost_order):
+        rs = 6 * r
+        if kind == "between":
+            ci, cj = 6 * int(i[k]), 6 * int(j[k])
+            A[:, rs:rs + 6, ci:ci + 6] = J0[:, k]
+            A[:, rs:rs + 6, cj:cj + 6] = J1[:, k]
+            b[:, rs:rs + 6] = -eb[:, k]
+        else:
+            c = 6 * int(p.prior_idx[k])
+            A[:, rs:rs + 6, c:c + 6] = Jp[:, k]
+            b[:, rs:rs + 6] = -ep[:, k]
+    return A, b
+
+
+def hessian(A, b):
+    """dense_linearization.py:58-62: AtA = A^T A, Atb = A^T b (B,n,1)."""
+    At = A.transpose(1, 2)
+    return At.bmm(A), At.bmm(b.unsqueeze(2))
+
+
+def apply_damping(AtA, damping, ellipsoidal, eps):
+    """dense_solver.py:38-64 (out of place)."""
+    damping = torch.as_tensor(damping).to(dtype=AtA.dtype)
+    n = AtA.shape[1]
+    if ellipsoidal:
+        damping = damping.view(-1, 1)
+        D = torch.diag_embed(damping * AtA.diagonal(dim1=1, dim2=2) + eps)
+    else:
+        damping = damping.view(-1, 1, 1)
+        D = damping * torch.eye(n, dtype=AtA.dtype).unsqueeze(0)
+    return AtA + D
+
+
+def cholesky_solve(Atb, AtA):
+    """dense_solver.py:159-161."""
+    L = torch.linalg.cholesky(AtA)
+    return torch.cholesky_solve(Atb, L).squeeze(2)
+
+
+def solve(AtA, Atb, damping=None, ellipsoidal=False, eps=1e-8):
+    """dense_solver.py:66-79,84-123."""
+    if damping is not None:
+        AtA = apply_damping(AtA, damping, ellipsoidal, eps)
+    return cholesky_solve(Atb, AtA)
+
+
+def retract(poses, delta, ignore_mask=None):
+    """objective.py:873-914 / vectorizer.py:410-469 / variable.py:65-69: X.exp(delta), masked rows keep X."""
+    B, P = poses.shape[:2]
+    new = lie.se3_retract(poses, delta.view(B, P, 6))
+    if ignore_mask is not None:
+        new = torch.where(ignore_mask.view(B, 1, 1, 1), poses, new)
+    return new
+
+
+@dataclass
+class LMInfo:
+    err_history: List[torch.Tensor] = field(default_factory=list)  # [(B,)], index 0 = initial
+    deltas: List[torch.Tensor] = field(default_factory=list)
+    AtA: List[torch.Tensor] = field(default_factory=list)
+    Atb: List[torch.Tensor] = field(default_factory=list)
+    dampings: List[torch.Tensor] = field(default_factory=list)
+    iters_done: int = 0
+    converged_iter: Optional[torch.Tensor] = None
+    last_err: Optional[torch.Tensor] = None
+
+
+def check_convergence(err, last_err, abs_tol, rel_tol):
+    """nonlinear_optimizer.py:110-119."""
+    if err.abs().mean() < abs_tol:
+        return torch.ones_like(err).bool()
+    change = last_err - err
+    return (change.abs() < abs_tol) | ((change / last_err).abs() < rel_tol)
+
+
+def lm_optimize(p: PGProblem, poses, max_iterations=20, step_size=1.0, damping=1e-3,
+                adaptive_damping=False, ellipsoidal_damping=False, damping_eps=1e-8,
+                abs_err_tolerance=1e-10, rel_err_tolerance=1e-8,
+                down_damping_ratio=9.0, up_damping_ratio=11.0, damping_accept=0.1,
+                gauss_newton=False, keep_taps=False):
+    """One ``optimize()`` of LevenbergMarquardt (or GaussNewton if ``gauss_newton``) under no_grad.
+
+    nonlinear_least_squares.py:100-215 (loop), :338-365 (_step), levenberg_marquardt.py:114-201,
+    SURVEY Appendix B.  Returns (final poses, LMInfo).
+    """
+    B = poses.shape[0]
+    dtype = poses.dtype
+    info = LMInfo()
+    lam = damping * torch.ones(B, dtype=dtype) if adaptive_damping else damping
+    last_err = error_metric(p, poses)
+    info.err_history.append(last_err.clone())
+    converged = torch.zeros(B, dtype=torch.bool)
+    info.converged_iter = torch.full((B,), -1, dtype=torch.long)
+    it, all_reject_attempts = 0, 0
+    while it < max_iterations:
+        A, b = dense_linearize(p, poses)
+        AtA, Atb = hessian(A, b)
+        if gauss_newton:
+            delta = solve(AtA, Atb)
+        else:
+            delta = solve(AtA, Atb, lam, ellipsoidal_damping, damping_eps)
+        if keep_taps:
+            info.AtA.append(AtA)
+            info.Atb.append(Atb)
+            info.deltas.append(delta)
+            info.dampings.append(torch.as_tensor(lam).clone())
+        d = delta * step_size
+        new_poses = retract(poses, d, ignore_mask=converged)
+        err = error_metric(p, new_poses)
+        reject = None
+        if adaptive_damping and not gauss_newton:
+            dmp = lam.view(-1, 1)
+            if ellipsoidal_damping:
+                dmp = AtA.diagonal(dim1=1, dim2=2) * dmp  # linearization.diagonal_scaling
+            den = (d * (dmp * d + Atb.squeeze(2))).sum(dim=1) / 2
+            rho = (last_err - err) / den
+            reject = rho <= damping_accept
+            lam = torch.where(reject, lam * up_damping_ratio, lam / down_damping_ratio)
+            lam = lam.clamp(MIN_DAMPING, MAX_DAMPING)
+        if reject is not None and bool(reject.all()):
+            all_reject_attempts += 1
+            if all_reject_attempts < 3:  # nonlinear_optimizer.py:88 _MAX_ALL_REJECT_ATTEMPTS
+                continue
+            err = last_err
+        else:
+            if reject is not None:
+                poses = torch.where(reject.view(B, 1, 1, 1), poses, new_poses)
+                if bool(reject.any()):
+                    err = error_metric(p, poses)
+            else:
+                poses = new_poses
+        all_reject_attempts = 0
+        info.err_history.append(err.clone())
+        converged = check_convergence(err, last_err, abs_err_tolerance, rel_err_tolerance)
+        info.converged_iter[converged & (info.converged_iter < 0)] = it + 1
+        if bool(converged.all()):
+            break  # nonlinear_least_squares.py:202-203 (breaks before counting the iteration)
+        last_err = err
+        it += 1
+        info.iters_done = it
+    info.last_err = info.err_history[-1]
+    return poses, info

@@ -1,0 +1,62 @@
+"""Pins the CPU oracle against fixtures produced by the REAL reference (oracle/gen_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lie
+from oracle import pose_graph as opg
+from tests.helpers import golden_problem, load_golden
+
+
+@pytest.mark.parametrize("tag,dtype,tol", [("f32", torch.float32, 2e-5), ("f64", torch.float64, 1e-12)])
+def test_lie_ops_match_reference(tag, dtype, tol):
+    g = load_golden(f"lie_se3_{tag}")
+    xi = torch.from_numpy(g["xi"])
+    X = torch.from_numpy(g["exp"])
+    Y = torch.from_numpy(g["Y"])
+    assert xi.dtype == dtype
+    np.testing.assert_allclose(lie.se3_exp(xi).numpy(), g["exp"], rtol=tol, atol=tol)
+    log, jlog = lie.se3_log_jlog(X)
+    np.testing.assert_allclose(log.numpy(), g["log"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(jlog.numpy(), g["jlog"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(lie.se3_adjoint(X).numpy(), g["adj"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(lie.se3_inverse(X).numpy(), g["inv"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(lie.se3_compose(X, Y).numpy(), g["compose"], rtol=tol, atol=tol)
+
+
+CASES = [("pg_f64_lm", 5e-8), ("pg_f64_gn", 5e-8), ("pg_f64_lm_adaptive", 5e-8),
+         ("pg_f64_lm_adaptive_ellips", 5e-8), ("pg_f64_lm_adaptive_rejects", 5e-8), ("pg_f32_lm", 2e-3)]
+
+
+@pytest.mark.parametrize("name,tol", CASES)
+def test_first_linearization_matches_reference(name, tol):
+    g = load_golden(name)
+    p, poses0, kw = golden_problem(g)
+    A, b = opg.dense_linearize(p, poses0)
+    # structure is bit exact (linearization.py:31-41)
+    assert p.n == int(g["num_cols"]) and p.m == int(g["num_rows"])
+    assert list(g["var_start_cols"]) == [6 * k for k in range(p.num_poses)]
+    scale = np.abs(g["A0"]).max()
+    np.testing.assert_allclose(A.numpy(), g["A0"], atol=tol * scale * 1e-3 if tol < 1e-6 else 1e-4 * scale)
+    np.testing.assert_allclose(b.numpy(), g["b0"], atol=1e-4 if tol > 1e-6 else 1e-10)
+    AtA, Atb = opg.hessian(A, b)
+    np.testing.assert_allclose(AtA.numpy(), g["AtA"][0], rtol=0, atol=np.abs(g["AtA"][0]).max() * (1e-5 if tol > 1e-6 else 1e-12))
+    np.testing.assert_allclose(Atb.numpy(), g["Atb"][0], rtol=0, atol=np.abs(g["Atb"][0]).max() * (1e-5 if tol > 1e-6 else 1e-12))
+    np.testing.assert_allclose(opg.error_metric(p, poses0).numpy(), g["err0"], rtol=1e-5 if tol > 1e-6 else 1e-12)
+
+
+@pytest.mark.parametrize("name,tol", CASES)
+def test_lm_trajectory_matches_reference(name, tol):
+    g = load_golden(name)
+    p, poses0, kw = golden_problem(g)
+    final, info = opg.lm_optimize(p, poses0, abs_err_tolerance=0.0, rel_err_tolerance=0.0, keep_taps=True, **kw)
+    np.testing.assert_allclose(final.numpy(), g["final"], rtol=0, atol=tol)
+    # per-iteration deltas (only comparable when no all-reject retries happened: same count)
+    if len(info.deltas) == g["delta"].shape[0]:
+        for it in range(len(info.deltas)):
+            np.testing.assert_allclose(info.deltas[it].numpy(), g["delta"][it], rtol=0,
+                                       atol=tol * max(1.0, np.abs(g["delta"][it]).max()))
+    hist = torch.stack(info.err_history, 1).numpy()
+    ref = g["err_history"]
+    k = min(hist.shape[1], ref.shape[1])
+    np.testing.assert_allclose(hist[:, :k], ref[:, :k], rtol=2e-5 if tol < 1e-6 else 2e-3)
