@@ -1,0 +1,153 @@
+/* theseus_hip.h -- C ABI of libtheseus_hip.so: the MI355X (gfx950) batched Gauss-Newton /
+ * Levenberg-Marquardt inner loop for Theseus-style SE3 pose graphs.
+ *
+ * The reference (facebookresearch/theseus, /root/reference) has NO C ABI on this path: the
+ * boundary is two Python ABCs, `Linearization` (theseus/optimizer/linearization.py:16-87) and
+ * `LinearSolver` (theseus/optimizer/linear/linear_solver.py:15-37), whose dense implementations
+ * are plain ATen calls (theseus/optimizer/dense_linearization.py:29-62,
+ * theseus/optimizer/linear/dense_solver.py:38-64,159-161).  Each entry point below names the
+ * reference interface it replaces.  Host code (the theseus_amd Python package, or a theseus plugin, see
+ * INTEGRATION.md) binds these with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory;
+ *   - `dtype`: 0 = float32, 1 = float64 (arithmetic and storage type of every floating buffer);
+ *   - `stream`: a hipStream_t (pass torch.cuda.current_stream().cuda_stream); nothing synchronises;
+ *   - return value: 0 on success, negative on a bad argument or launch error
+ *     (thx_last_error() gives the text); no global state besides that thread-local string;
+ *   - batch layouts are "entity major": poses (P, B, 3, 4), measurements (E, Bm, 3, 4) with Bm in
+ *     {1, B}; `*_bstride` is the element stride between consecutive batch items (12 / 6, or 0 when
+ *     the tensor is shared by the whole batch);
+ *   - dense matrices are row major (B, ld, ld) with ld >= n, ld % 32 == 0; only the lower
+ *     triangle of H / L is meaningful to the solver.
+ */
+#ifndef THESEUS_HIP_H_
+#define THESEUS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define THX_F32 0
+#define THX_F64 1
+#define THX_TILE 128 /* Cholesky tile edge; Winv holds ceil(n/THX_TILE) inverse diagonal tiles */
+
+/* Taylor-switch thresholds of torchlie (torchlie/torchlie/global_params.py:44-58), read by the
+ * host at launch time so that runtime changes made through torchlie.set_global_params apply. */
+typedef struct {
+  double near_zero;   /* so3_near_zero_eps   */
+  double d_near_zero; /* so3_d_near_zero_eps */
+  double near_pi;     /* so3_near_pi_eps     */
+} thx_lie_eps;
+
+/* Immutable structure of one pose-graph objective ("problem compiler" output; all device int32).
+ * Column layout = pose index * 6 (Linearization.var_start_cols, linearization.py:31-41). */
+typedef struct {
+  int32_t num_poses;   /* P : SE3 optimisation variables, dof 6 each                    */
+  int32_t num_edges;   /* E : Between costs (v0 = pose edge_i[e], v1 = pose edge_j[e])   */
+  int32_t num_priors;  /* K : Difference/Local costs on pose prior_pose[k]               */
+  const int32_t* edge_i;     /* (E)                                                     */
+  const int32_t* edge_j;     /* (E)                                                     */
+  const int32_t* inc_ptr;    /* (P+1) CSR over poses: incident edge entries             */
+  const int32_t* inc_edge;   /* (2E) edge id, entries of a pose sorted by other endpoint */
+  const int32_t* inc_side;   /* (2E) 0: this pose is v0 of the edge, 1: it is v1        */
+  const int32_t* inc_other;  /* (2E) the other endpoint's pose index                    */
+  const int32_t* prior_pose; /* (K)                                                     */
+  const int32_t* pri_ptr;    /* (P+1) CSR over poses: prior ids                         */
+  const int32_t* pri_id;     /* (K)                                                     */
+} thx_pg_structure;
+
+/* Per-call tensors of the objective. */
+typedef struct {
+  int32_t batch;             /* B */
+  const void* poses;         /* (P, B, 3, 4)                                            */
+  const void* meas;          /* (E, Bm, 3, 4) Between measurements (aux variables)      */
+  int64_t meas_bstride;      /* 12 or 0                                                 */
+  const void* w_between;     /* (E, Bw, 6) sqrt-information diagonal (DiagonalCostWeight;
+                                a ScaleCostWeight is passed expanded)                   */
+  int64_t w_between_bstride; /* 6 or 0                                                  */
+  const void* prior_target;  /* (K, Bt, 3, 4)                                           */
+  int64_t prior_target_bstride;
+  const void* w_prior;       /* (K, Bw, 6)                                              */
+  int64_t w_prior_bstride;
+} thx_pg_data;
+
+const char* thx_last_error(void);
+int thx_abi_version(void);
+
+/* ---- SE3 elementwise ops: torchlie.functional.SE3.{exp,log,compose,inv,adj}
+ *      (torchlie/torchlie/functional/se3_impl.py:178-216,225-310,354-457,531-538,578-581,703-708).
+ *      N independent elements; jac may be NULL; group tensors (N,3,4), tangents (N,6), jac (N,6,6). */
+int thx_se3_exp(const void* xi, void* X, void* jac, int64_t N, int dtype, const thx_lie_eps* eps, void* stream);
+int thx_se3_log(const void* X, void* xi, void* jac, int64_t N, int dtype, const thx_lie_eps* eps, void* stream);
+int thx_se3_compose(const void* X, const void* Y, void* Z, int64_t N, int dtype, void* stream);
+int thx_se3_inverse(const void* X, void* Y, int64_t N, int dtype, void* stream);
+int thx_se3_adjoint(const void* X, void* A, int64_t N, int dtype, void* stream);
+
+/* ---- Linearization.linearize(): replaces DenseLinearization._linearize_jacobian_impl +
+ *      _linearize_hessian_impl (dense_linearization.py:29-62) fused with Between / Local
+ *      Jacobians (embodied/measurements/between.py:38-45, embodied/misc/local_cost_fn.py:58-61)
+ *      and cost weights (core/cost_weight.py:81-90,125-136).  Never materialises A.
+ *      Writes the non-zero 6x6 blocks of the lower triangle of H = A^T A into the dense
+ *      (B, ld, ld) buffer (zero elsewhere must be pre-set once by the caller: the sparsity
+ *      pattern is fixed) and g = A^T b = -J^T e into (B, n). */
+int thx_pg_assemble(const thx_pg_structure* s, const thx_pg_data* d, void* H, int64_t ld, void* g,
+                    int dtype, const thx_lie_eps* eps, void* stream);
+
+/* ---- Objective.error_metric(): 0.5 * ||weighted error||^2 per problem (core/objective.py:37-38,
+ *      562-641).  `partials` is a (B, THX_ERR_CHUNKS) scratch; the reduction order is fixed
+ *      (deterministic).  err is (B). */
+#define THX_ERR_CHUNKS 16
+int thx_pg_error(const thx_pg_structure* s, const thx_pg_data* d, void* partials, void* err, int dtype,
+                 const thx_lie_eps* eps, void* stream);
+
+/* ---- Weighted residuals and Jacobian blocks (what weighted_jacobians_error() returns,
+ *      core/cost_function.py:107-122), for `Linearization.A/.b/.Av` and tests:
+ *      J0,J1 (E,B,6,6), eb (E,B,6), Jp (K,B,6,6), ep (K,B,6); any output may be NULL. */
+int thx_pg_jacobians(const thx_pg_structure* s, const thx_pg_data* d, void* J0, void* J1, void* eb,
+                     void* Jp, void* ep, int dtype, const thx_lie_eps* eps, void* stream);
+
+/* ---- Objective.retract_vars_sequence (core/objective.py:873-914, core/vectorizer.py:410-469,
+ *      core/variable.py:65-69): out[p,b] = ignore[b] ? poses[p,b] : poses[p,b] * exp(step * delta[b, 6p:6p+6]).
+ *      delta is (B, n) with row stride ldd; ignore_mask is (B) uint8 or NULL. */
+int thx_se3_retract(const void* poses, const void* delta, int64_t ldd, double step,
+                    const uint8_t* ignore_mask, void* out, int32_t P, int32_t B, int dtype,
+                    const thx_lie_eps* eps, void* stream);
+
+/* ---- LinearSolver.solve(): replaces DenseSolver._apply_damping + CholeskyDenseSolver._solve_sytem
+ *      (linear/dense_solver.py:38-64,159-161).
+ *      thx_chol_factor: L L^T = H + damping (out of place: H stays undamped, as the reference
+ *      requires for LM's rho test, levenberg_marquardt.py:183-190).
+ *        damping: (B) per-problem lambda or NULL for plain Gauss-Newton;
+ *        ellipsoidal != 0: H + diag(lambda * diag(H) + damping_eps), else H + lambda I;
+ *        L: (B, ld, ld) lower factor; Winv: (B, ceil(n/THX_TILE), THX_TILE, THX_TILE) inverses of
+ *        the diagonal tiles of L (kept for the solves, including the implicit-backward solve);
+ *        info: (B) int32, 0 = ok, k>0 = leading minor k not positive definite (LAPACK potrf
+ *        convention; the host turns any non-zero into the reference's RuntimeError).
+ *      thx_chol_solve: x = (L L^T)^-1 rhs for one right-hand side per problem, rhs/x (B, n) with
+ *        row stride ldv; re-usable with any rhs (the backward pass solves with the cached factor,
+ *        cf. optimizer/autograd/baspacho_sparse_autograd.py:117-168). */
+int thx_chol_factor(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
+                    double damping_eps, void* L, void* Winv, int32_t* info, int dtype, void* stream);
+int thx_chol_solve(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs,
+                   void* x, int64_t ldv, int dtype, void* stream);
+
+/* ---- Linearization.diagonal_scaling support: d[b, i] = H[b, i, i] (linearization.py:85-87). */
+int thx_diag(const void* H, int64_t ld, int32_t n, int32_t B, void* d, int64_t ldv, int dtype, void* stream);
+
+/* ---- LevenbergMarquardt._check_accept (nonlinear/levenberg_marquardt.py:173-201), fused:
+ *      den = sum_j delta_j (lambda D_j delta_j + g_j) / 2, rho = (prev_err - new_err) / den,
+ *      reject = rho <= accept; lambda <- clamp(reject ? lambda*up : lambda/down, 1e-7, 1e7).
+ *      D = diag(H) if ellipsoidal else 1.  delta is the *scaled* step (delta * step_size).
+ *      Outputs reject (B) uint8 and updates damping (B) in place. */
+int thx_lm_accept(const void* delta, const void* g, int64_t ldv, const void* H, int64_t ld, int32_t n,
+                  int32_t B, void* damping, const void* prev_err, const void* new_err, int ellipsoidal,
+                  double accept, double down_ratio, double up_ratio, uint8_t* reject, int dtype,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THESEUS_HIP_H_ */

@@ -1,0 +1,39 @@
+"""Helpers for the -m gpu parity tests: golden fixture / oracle problem -> device layout."""
+import numpy as np
+import torch
+
+from theseus_amd.compiler import PoseGraphStructure
+from theseus_amd.kernels import PGTensors, default_kernels, round_up
+
+
+def to_device_problem(p, poses0, device="cuda"):
+    """oracle PGProblem (batch-major) -> (PoseGraphStructure, PGTensors) in entity-major device layout."""
+    s = PoseGraphStructure.build(p.num_poses, p.edges.tolist(), p.prior_idx.tolist())
+    em = lambda t: t.transpose(0, 1).contiguous().to(device)  # noqa: E731  (B,X,...) -> (X,B,...)
+    t = PGTensors(poses=em(poses0), meas=em(p.meas), w_between=em(p.w_between),
+                  prior_target=em(p.prior_target), w_prior=em(p.w_prior))
+    return s, t
+
+
+def alloc_dense(B, n, dtype, device="cuda"):
+    ld = round_up(n, 32)
+    H = torch.zeros(B, ld, ld, dtype=dtype, device=device)
+    g = torch.zeros(B, n, dtype=dtype, device=device)
+    return H, g, ld
+
+
+def sym_from_lower(H, n):
+    Hl = torch.tril(H[:, :n, :n])
+    return Hl + torch.tril(Hl, -1).transpose(1, 2)
+
+
+def factor_and_solve(K, H, n, rhs, damping=None, ellipsoidal=False, eps=1e-8):
+    B, ld = H.shape[0], H.shape[-1]
+    nt = (n + 127) // 128
+    L = torch.zeros_like(H)
+    diagT = torch.empty(B, nt, 128, 128, dtype=H.dtype, device=H.device)
+    info = torch.empty(B, dtype=torch.int32, device=H.device)
+    K.chol_factor(H, n, damping, ellipsoidal, eps, L, diagT, info)
+    x = torch.empty_like(rhs)
+    K.chol_solve(L, n, diagT, rhs, x)
+    return L, x, info

@@ -1,0 +1,196 @@
+"""-m gpu parity tests of the HIP kernels (through the C ABI) against the oracle / golden fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lie as olie
+from oracle import pose_graph as opg
+from tests.helpers import golden_problem, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from theseus_amd.kernels import default_kernels
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return default_kernels()
+
+
+def _tol(dtype):
+    return 3e-5 if dtype == torch.float32 else 1e-11
+
+
+@pytest.mark.parametrize("tag,dtype", [("f32", torch.float32), ("f64", torch.float64)])
+def test_lie_ops_vs_reference_golden(K, tag, dtype):
+    g = load_golden(f"lie_se3_{tag}")
+    tol = _tol(dtype)
+    xi = torch.from_numpy(g["xi"]).cuda()
+    X, J = K.se3_exp(xi, jac=True)
+    np.testing.assert_allclose(X.cpu().numpy(), g["exp"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(J.cpu().numpy(), g["jexp"], rtol=tol, atol=tol)
+    Xg = torch.from_numpy(g["exp"]).cuda()
+    Yg = torch.from_numpy(g["Y"]).cuda()
+    lg, Jl = K.se3_log(Xg, jac=True)
+    # near pi the log is ill conditioned in fp32: compare through the oracle on identical inputs
+    ref_log, ref_jlog = olie.se3_log_jlog(torch.from_numpy(g["exp"]))
+    scale = 1.0 if dtype == torch.float64 else 40.0
+    np.testing.assert_allclose(lg.cpu().numpy(), g["log"], rtol=tol * scale, atol=tol * scale)
+    np.testing.assert_allclose(Jl.cpu().numpy(), g["jlog"], rtol=tol * scale * 10, atol=tol * scale * 10)
+    np.testing.assert_allclose(K.se3_adjoint(Xg).cpu().numpy(), g["adj"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(K.se3_inverse(Xg).cpu().numpy(), g["inv"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(K.se3_compose(Xg, Yg).cpu().numpy(), g["compose"], rtol=tol, atol=tol)
+
+
+CASES = ["pg_f64_lm", "pg_f32_lm", "pg_f64_lm_adaptive_ellips", "pg_f64_gn"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_assemble_error_jacobians_vs_reference_golden(K, name):
+    from tests.gpu_helpers import alloc_dense, sym_from_lower, to_device_problem
+    g = load_golden(name)
+    p, poses0, kw = golden_problem(g)
+    dtype = poses0.dtype
+    f32 = dtype == torch.float32
+    s, t = to_device_problem(p, poses0)
+    ds = s.on("cuda")
+    B, n = poses0.shape[0], s.num_cols
+    H, gv, ld = alloc_dense(B, n, dtype)
+    K.pg_assemble(ds, t, H, gv)
+    AtA = sym_from_lower(H, n).cpu().numpy()
+    sc = np.abs(g["AtA"][0]).max()
+    np.testing.assert_allclose(AtA, g["AtA"][0], rtol=0, atol=sc * (2e-6 if f32 else 1e-13))
+    np.testing.assert_allclose(gv.cpu().numpy(), g["Atb"][0][..., 0], rtol=0,
+                               atol=np.abs(g["Atb"][0]).max() * (2e-6 if f32 else 1e-13))
+    # untouched entries stay exactly zero (structure): pattern == block pattern
+    pat = np.zeros((n, n), bool)
+    for r, c in s.lower_block_pattern():
+        pat[6 * r:6 * r + 6, 6 * c:6 * c + 6] = True
+    assert not (H[:, :n, :n].cpu().numpy()[:, ~pat] != 0).any()
+    # error metric
+    part = torch.empty(16, B, dtype=dtype, device="cuda")
+    err = torch.empty(B, dtype=dtype, device="cuda")
+    K.pg_error(ds, t, part, err)
+    np.testing.assert_allclose(err.cpu().numpy(), g["err0"], rtol=1e-5 if f32 else 1e-12)
+    # Jacobian blocks against the reference's dense A, b
+    E, Kp = s.num_edges, s.num_priors
+    J0 = torch.empty(E, B, 6, 6, dtype=dtype, device="cuda"); J1 = torch.empty_like(J0)
+    eb = torch.empty(E, B, 6, dtype=dtype, device="cuda")
+    Jp = torch.empty(Kp, B, 6, 6, dtype=dtype, device="cuda"); ep = torch.empty(Kp, B, 6, dtype=dtype, device="cuda")
+    K.pg_jacobians(ds, t, J0, J1, eb, Jp, ep)
+    A = np.zeros((B, s.num_rows, n), dtype=g["A0"].dtype); b = np.zeros((B, s.num_rows), dtype=g["A0"].dtype)
+    for e in range(E):
+        r, i, j = int(s.edge_row_start[e]), int(s.edge_i[e]), int(s.edge_j[e])
+        A[:, r:r + 6, 6 * i:6 * i + 6] = J0[e].cpu().numpy()
+        A[:, r:r + 6, 6 * j:6 * j + 6] = J1[e].cpu().numpy()
+        b[:, r:r + 6] = -eb[e].cpu().numpy()
+    for k in range(Kp):
+        r, i = int(s.prior_row_start[k]), int(s.prior_pose[k])
+        A[:, r:r + 6, 6 * i:6 * i + 6] = Jp[k].cpu().numpy()
+        b[:, r:r + 6] = -ep[k].cpu().numpy()
+    np.testing.assert_allclose(A, g["A0"], rtol=0, atol=np.abs(g["A0"]).max() * (3e-6 if f32 else 1e-13))
+    np.testing.assert_allclose(b, g["b0"], rtol=0, atol=np.abs(g["b0"]).max() * (3e-6 if f32 else 1e-13) + 1e-30)
+
+
+def _random_spd(B, n, dtype, seed, cond=1e3):
+    gen = torch.Generator().manual_seed(seed)
+    A = torch.randn(B, n, n + 8, dtype=torch.float64, generator=gen)
+    M = A @ A.transpose(1, 2) / (n + 8)
+    M = M + (1.0 / cond) * torch.eye(n, dtype=torch.float64)
+    return M.to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n,B", [(6, 3), (48, 5), (126, 4), (128, 9), (132, 3), (258, 8), (390, 17), (1536, 8)])
+def test_chol_factor_solve_vs_lapack(K, dtype, n, B):
+    from tests.gpu_helpers import factor_and_solve
+    from theseus_amd.kernels import round_up
+    M = _random_spd(B, n, dtype, seed=n + B)
+    rhs = torch.randn(B, n, dtype=torch.float64, generator=torch.Generator().manual_seed(1)).to(dtype)
+    ld = round_up(n, 32)
+    H = torch.zeros(B, ld, ld, dtype=dtype)
+    H[:, :n, :n] = torch.tril(M)  # only the lower triangle is meaningful to the solver
+    Hd, rd = H.cuda(), rhs.cuda()
+    L, x, info = factor_and_solve(K, Hd, n, rd)
+    assert int(info.abs().sum()) == 0
+    # reference: dense_solver.py:159-161 on the same (fp) matrix, in float64 as the arbiter
+    M64 = M.double()
+    Lref = torch.linalg.cholesky(M64)
+    xref = torch.cholesky_solve(rhs.double().unsqueeze(2), Lref).squeeze(2)
+    Lg = torch.tril(L[:, :n, :n]).cpu().double()
+    eps = 1.2e-7 if dtype == torch.float32 else 2.3e-16
+    # backward error of the factorisation and forward error of the solve, scaled by conditioning
+    resid = (Lg @ Lg.transpose(1, 2) - M64).abs().max() / M64.abs().max()
+    assert resid < 60 * eps * max(1, n / 64), resid
+    xerr = (x.cpu().double() - xref).abs().max() / xref.abs().max()
+    assert xerr < (5e-3 if dtype == torch.float32 else 1e-10), xerr
+    # H untouched (out-of-place damping contract)
+    assert torch.equal(Hd.cpu(), H)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("ellipsoidal", [False, True])
+def test_chol_damping_matches_reference_semantics(K, dtype, ellipsoidal):
+    from tests.gpu_helpers import factor_and_solve
+    n, B = 132, 6
+    M = _random_spd(B, n, dtype, seed=3)
+    rhs = torch.randn(B, n, dtype=dtype, generator=torch.Generator().manual_seed(5))
+    lam = torch.tensor([1e-3, 1e-1, 1.0, 10.0, 0.0, 5e-2], dtype=dtype)
+    H = torch.zeros(B, 160, 160, dtype=dtype); H[:, :n, :n] = torch.tril(M)
+    _, x, info = factor_and_solve(K, H.cuda(), n, rhs.cuda(), damping=lam.cuda(), ellipsoidal=ellipsoidal, eps=1e-8)
+    xref = opg.solve(M.double(), rhs.double().unsqueeze(2), lam.double(), ellipsoidal, 1e-8)
+    err = (x.cpu().double() - xref).abs().max() / xref.abs().max()
+    assert err < (2e-3 if dtype == torch.float32 else 1e-10), err
+
+
+def test_chol_reports_non_positive_definite(K):
+    from tests.gpu_helpers import factor_and_solve
+    n, B = 260, 4
+    M = _random_spd(B, n, torch.float64, seed=9)
+    M[2, 200, 200] = -1.0  # leading minor 201 fails for problem 2 only
+    H = torch.zeros(B, 288, 288, dtype=torch.float64); H[:, :n, :n] = torch.tril(M)
+    rhs = torch.ones(B, n, dtype=torch.float64)
+    _, _, info = factor_and_solve(K, H.cuda(), n, rhs.cuda())
+    info = info.cpu().tolist()
+    assert info[0] == 0 and info[1] == 0 and info[3] == 0 and info[2] == 201
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_retract_and_mask(K, dtype):
+    gen = torch.Generator().manual_seed(2)
+    P, B = 7, 70
+    poses = olie.se3_exp(torch.randn(B, P, 6, dtype=dtype, generator=gen))
+    delta = 0.3 * torch.randn(B, P * 6, dtype=dtype, generator=gen)
+    mask = torch.rand(B, generator=gen) < 0.3
+    ref = opg.retract(poses, delta * 0.75, ignore_mask=mask)
+    pd = poses.transpose(0, 1).contiguous().cuda()
+    out = torch.empty_like(pd)
+    K.se3_retract(pd, delta.cuda(), 0.75, mask.to(torch.uint8).cuda(), out)
+    got = out.cpu().transpose(0, 1)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=_tol(dtype))
+    assert torch.equal(got[mask], poses[mask])  # masked rows are bit identical (torch.where semantics)
+
+
+@pytest.mark.parametrize("ellipsoidal", [False, True])
+def test_lm_accept_matches_reference_formula(K, ellipsoidal):
+    gen = torch.Generator().manual_seed(4)
+    B, n = 37, 54
+    dtype = torch.float64
+    delta = torch.randn(B, n, dtype=dtype, generator=gen)
+    g = torch.randn(B, n, dtype=dtype, generator=gen)
+    H = torch.zeros(B, 64, 64, dtype=dtype)
+    dg = torch.rand(B, n, dtype=dtype, generator=gen) + 0.5
+    H[:, torch.arange(n), torch.arange(n)] = dg
+    lam = 10.0 ** torch.randint(-8, 8, (B,), generator=gen).to(dtype)
+    prev = torch.rand(B, dtype=dtype, generator=gen) * 10
+    new = prev - torch.randn(B, dtype=dtype, generator=gen)
+    damping = lam.view(-1, 1) * (dg if ellipsoidal else 1.0)
+    den = (delta * (damping * delta + g)).sum(1) / 2
+    rho = (prev - new) / den
+    rej = rho <= 0.1
+    lam_ref = torch.where(rej, lam * 11.0, lam / 9.0).clamp(1e-7, 1e7)
+    lam_d = lam.clone().cuda()
+    rej_d = torch.empty(B, dtype=torch.uint8, device="cuda")
+    K.lm_accept(delta.cuda(), g.cuda(), H.cuda(), n, lam_d, prev.cuda(), new.cuda(), ellipsoidal, 0.1, 9.0, 11.0, rej_d)
+    assert torch.equal(rej_d.cpu().bool(), rej)
+    np.testing.assert_allclose(lam_d.cpu().numpy(), lam_ref.numpy(), rtol=1e-14)

@@ -1,0 +1,123 @@
+"""ctypes binding of libtheseus_hip.so (C ABI: include/theseus_hip.h).
+
+There is NO fallback: if the shared library is missing or a tensor is not on a HIP device the
+calls raise.  ``import torch`` happens first on purpose, so that the HIP runtime torch already
+loaded (same SONAME libamdhip64.so.7) is the one our kernels are registered with -- device
+pointers and streams are then shared with torch.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint8, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtheseus_hip.so")
+
+THX_TILE = 128
+THX_ERR_CHUNKS = 16
+ABI_VERSION = 1
+
+
+class LieEps(Structure):
+    _fields_ = [("near_zero", c_double), ("d_near_zero", c_double), ("near_pi", c_double)]
+
+
+class PGStructure(Structure):
+    _fields_ = [
+        ("num_poses", c_int32), ("num_edges", c_int32), ("num_priors", c_int32),
+        ("edge_i", c_void_p), ("edge_j", c_void_p),
+        ("inc_ptr", c_void_p), ("inc_edge", c_void_p), ("inc_side", c_void_p), ("inc_other", c_void_p),
+        ("prior_pose", c_void_p), ("pri_ptr", c_void_p), ("pri_id", c_void_p),
+    ]
+
+
+class PGData(Structure):
+    _fields_ = [
+        ("batch", c_int32),
+        ("poses", c_void_p),
+        ("meas", c_void_p), ("meas_bstride", c_int64),
+        ("w_between", c_void_p), ("w_between_bstride", c_int64),
+        ("prior_target", c_void_p), ("prior_target_bstride", c_int64),
+        ("w_prior", c_void_p), ("w_prior_bstride", c_int64),
+    ]
+
+
+# name -> (argtypes) ; every entry point returns int (0 = ok)
+_SIGNATURES = {
+    "thx_se3_exp": [c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(LieEps), c_void_p],
+    "thx_se3_log": [c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(LieEps), c_void_p],
+    "thx_se3_compose": [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    "thx_se3_inverse": [c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    "thx_se3_adjoint": [c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    "thx_pg_assemble": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_int64, c_void_p, c_int,
+                        POINTER(LieEps), c_void_p],
+    "thx_pg_error": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
+    "thx_pg_jacobians": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_void_p, c_void_p, c_void_p,
+                         c_void_p, c_int, POINTER(LieEps), c_void_p],
+    "thx_se3_retract": [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p, c_int32, c_int32, c_int,
+                        POINTER(LieEps), c_void_p],
+    "thx_chol_factor": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,
+                        c_void_p, c_int, c_void_p],
+    "thx_chol_solve": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                       c_void_p],
+    "thx_diag": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_int, c_void_p],
+    "thx_lm_accept": [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                      c_void_p, c_int, c_double, c_double, c_double, c_void_p, c_int, c_void_p],
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["thx_last_error", "thx_abi_version"])
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built.  Run "
+            "`python -m theseus_amd.build` (hipcc, gfx950).  There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.thx_last_error.restype = c_char_p
+    lib.thx_last_error.argtypes = []
+    lib.thx_abi_version.restype = c_int
+    lib.thx_abi_version.argtypes = []
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = c_int
+        fn.argtypes = args
+    if lib.thx_abi_version() != ABI_VERSION:
+        raise RuntimeError("libtheseus_hip.so ABI version mismatch: rebuild with python -m theseus_amd.build")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {load().thx_last_error().decode()}")
+
+
+def dtype_code(dtype):
+    if dtype == torch.float32:
+        return 0
+    if dtype == torch.float64:
+        return 1
+    raise TypeError(f"theseus_amd HIP kernels support float32/float64, got {dtype}")
+
+
+def ptr(t, name="tensor"):
+    """Device pointer of a contiguous HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a HIP device (got {t.device}); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

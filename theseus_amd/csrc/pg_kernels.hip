@@ -1,0 +1,525 @@
+// Pose-graph kernels for gfx950: fused Between/Local residual + Jacobian + weight + block J^T J / J^T r
+// assembly, error metric, Jacobian dump, masked SE3 retraction and the elementwise SE3 ops.
+//
+// Mapping: one lane per (entity, batch item) with the batch index fastest across the wavefront, so
+// every wave works on ONE pose / edge for 64 consecutive problems: structure lookups are
+// wave-uniform (scalar loads, no divergence) and pose / measurement reads are 48-byte (f32) records
+// at unit stride across lanes -> fully used 128-B lines.  Assembly is "owner computes": the lane
+// owning (pose p, problem b) walks p's incident edges (CSR sorted by the other endpoint), rebuilds
+// each edge's Jacobians in registers and accumulates its diagonal block, its g segment and the
+// off-diagonal blocks H[p][q] for q < p.  No atomics -> bit-reproducible; the Lie arithmetic is
+// evaluated twice per edge (once per endpoint), which is ~3 MFLOP per problem against an HBM-bound
+// store of the blocks.
+#include "common.cuh"
+
+namespace thx {
+
+std::string& last_error() {
+  static thread_local std::string e;
+  return e;
+}
+
+// 16-byte vector loads of an SE3 record (3x4 row major).
+__device__ __forceinline__ void se3_load_vec(const float* __restrict__ p, SE3<float>& X) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+  float4 r0 = q[0], r1 = q[1], r2 = q[2];
+  X.R[0] = r0.x; X.R[1] = r0.y; X.R[2] = r0.z; X.t[0] = r0.w;
+  X.R[3] = r1.x; X.R[4] = r1.y; X.R[5] = r1.z; X.t[1] = r1.w;
+  X.R[6] = r2.x; X.R[7] = r2.y; X.R[8] = r2.z; X.t[2] = r2.w;
+}
+__device__ __forceinline__ void se3_load_vec(const double* __restrict__ p, SE3<double>& X) {
+  const double2* q = reinterpret_cast<const double2*>(p);
+  double2 a0 = q[0], a1 = q[1], b0 = q[2], b1 = q[3], c0 = q[4], c1 = q[5];
+  X.R[0] = a0.x; X.R[1] = a0.y; X.R[2] = a1.x; X.t[0] = a1.y;
+  X.R[3] = b0.x; X.R[4] = b0.y; X.R[5] = b1.x; X.t[1] = b1.y;
+  X.R[6] = c0.x; X.R[7] = c0.y; X.R[8] = c1.x; X.t[2] = c1.y;
+}
+__device__ __forceinline__ void se3_store_vec(float* __restrict__ p, const SE3<float>& X) {
+  float4* q = reinterpret_cast<float4*>(p);
+  q[0] = make_float4(X.R[0], X.R[1], X.R[2], X.t[0]);
+  q[1] = make_float4(X.R[3], X.R[4], X.R[5], X.t[1]);
+  q[2] = make_float4(X.R[6], X.R[7], X.R[8], X.t[2]);
+}
+__device__ __forceinline__ void se3_store_vec(double* __restrict__ p, const SE3<double>& X) {
+  double2* q = reinterpret_cast<double2*>(p);
+  q[0] = make_double2(X.R[0], X.R[1]); q[1] = make_double2(X.R[2], X.t[0]);
+  q[2] = make_double2(X.R[3], X.R[4]); q[3] = make_double2(X.R[5], X.t[1]);
+  q[4] = make_double2(X.R[6], X.R[7]); q[5] = make_double2(X.R[8], X.t[2]);
+}
+template <typename T>
+__device__ __forceinline__ void load6(const T* __restrict__ p, T* w) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) w[i] = p[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// assembly
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64)
+pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t ld, T* __restrict__ g,
+                   Eps<T> eps) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int p = blockIdx.y;
+  const int B = d.batch;
+  if (b >= B) return;
+  const T* poses = static_cast<const T*>(d.poses);
+  const T* meas = static_cast<const T*>(d.meas);
+  const T* wb = static_cast<const T*>(d.w_between);
+  SE3<T> Xp;
+  se3_load_vec(poses + ((int64_t)p * B + b) * 12, Xp);
+
+  T Dg[36], Off[36], gv[6];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) { Dg[i] = T(0); Off[i] = T(0); }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) gv[i] = T(0);
+
+  T* Hb = H + (int64_t)b * ld * ld;
+  const int beg = s.inc_ptr[p], end = s.inc_ptr[p + 1];
+  int cur_q = -1;
+  for (int k = beg; k < end; ++k) {
+    const int e = s.inc_edge[k], side = s.inc_side[k], q = s.inc_other[k];
+    SE3<T> Xq, M;
+    se3_load_vec(poses + ((int64_t)q * B + b) * 12, Xq);
+    const int64_t mB = d.meas_bstride ? B : 1, wB = d.w_between_bstride ? B : 1;
+    se3_load_vec(meas + ((int64_t)e * mB) * 12 + (int64_t)b * d.meas_bstride, M);
+    T w[6], ev[6];
+    load6(wb + ((int64_t)e * wB) * 6 + (int64_t)b * d.w_between_bstride, w);
+    SJac<T> J0, J1;
+    const bool lower = q < p;
+    if (lower && q != cur_q) {
+      if (cur_q >= 0) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = 0; c < 6; ++c) Hb[(int64_t)(6 * p + r) * ld + 6 * cur_q + c] = Off[6 * r + c];
+      }
+#pragma unroll
+      for (int i = 0; i < 36; ++i) Off[i] = T(0);
+      cur_q = q;
+    }
+    if (side == 0) {  // p is v0: own Jacobian J0, other J1
+      between_eval(Xp, Xq, M, w, eps, ev, &J0, &J1, true);
+      sjac_tmul_acc(J0, J0, Dg);
+      sjac_tvec_sub(J0, ev, gv);
+      if (lower) sjac_tmul_acc(J0, J1, Off);
+    } else {  // p is v1
+      between_eval(Xq, Xp, M, w, eps, ev, &J0, &J1, true);
+      sjac_tmul_acc(J1, J1, Dg);
+      sjac_tvec_sub(J1, ev, gv);
+      if (lower) sjac_tmul_acc(J1, J0, Off);
+    }
+  }
+  if (cur_q >= 0) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Hb[(int64_t)(6 * p + r) * ld + 6 * cur_q + c] = Off[6 * r + c];
+  }
+  // priors on this pose
+  const T* tgt = static_cast<const T*>(d.prior_target);
+  const T* wp = static_cast<const T*>(d.w_prior);
+  for (int k = s.pri_ptr[p]; k < s.pri_ptr[p + 1]; ++k) {
+    const int id = s.pri_id[k];
+    const int64_t tB = d.prior_target_bstride ? B : 1, wB = d.w_prior_bstride ? B : 1;
+    SE3<T> Tg;
+    se3_load_vec(tgt + ((int64_t)id * tB) * 12 + (int64_t)b * d.prior_target_bstride, Tg);
+    T w[6], ev[6];
+    load6(wp + ((int64_t)id * wB) * 6 + (int64_t)b * d.w_prior_bstride, w);
+    SJac<T> J;
+    local_eval(Tg, Xp, w, eps, ev, &J, true);
+    sjac_tmul_acc(J, J, Dg);
+    sjac_tvec_sub(J, ev, gv);
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Hb[(int64_t)(6 * p + r) * ld + 6 * p + c] = Dg[6 * r + c];
+  T* gb = g + (int64_t)b * (6 * s.num_poses) + 6 * p;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) gb[i] = gv[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// error metric: partial sums over a fixed chunking of the costs, then a fixed-order reduction
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64)
+pg_error_partial_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ partials, Eps<T> eps) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int ch = blockIdx.y;
+  const int B = d.batch;
+  if (b >= B) return;
+  const T* poses = static_cast<const T*>(d.poses);
+  const T* meas = static_cast<const T*>(d.meas);
+  const T* wb = static_cast<const T*>(d.w_between);
+  T acc = T(0);
+  const int E = s.num_edges, K = s.num_priors;
+  const int ec = (E + THX_ERR_CHUNKS - 1) / THX_ERR_CHUNKS;
+  const int e1 = min(E, (ch + 1) * ec);
+  const int64_t mB = d.meas_bstride ? B : 1, wB = d.w_between_bstride ? B : 1;
+  for (int e = ch * ec; e < e1; ++e) {
+    const int i = s.edge_i[e], j = s.edge_j[e];
+    SE3<T> Xi, Xj, M;
+    se3_load_vec(poses + ((int64_t)i * B + b) * 12, Xi);
+    se3_load_vec(poses + ((int64_t)j * B + b) * 12, Xj);
+    se3_load_vec(meas + ((int64_t)e * mB) * 12 + (int64_t)b * d.meas_bstride, M);
+    T w[6], ev[6];
+    load6(wb + ((int64_t)e * wB) * 6 + (int64_t)b * d.w_between_bstride, w);
+    between_eval<T>(Xi, Xj, M, w, eps, ev, nullptr, nullptr, false);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc += ev[r] * ev[r];
+  }
+  const T* tgt = static_cast<const T*>(d.prior_target);
+  const T* wp = static_cast<const T*>(d.w_prior);
+  const int kc = (K + THX_ERR_CHUNKS - 1) / THX_ERR_CHUNKS;
+  const int k1 = min(K, (ch + 1) * kc);
+  const int64_t tB = d.prior_target_bstride ? B : 1, wpB = d.w_prior_bstride ? B : 1;
+  for (int k = ch * kc; k < k1; ++k) {
+    const int p = s.prior_pose[k];
+    SE3<T> X, Tg;
+    se3_load_vec(poses + ((int64_t)p * B + b) * 12, X);
+    se3_load_vec(tgt + ((int64_t)k * tB) * 12 + (int64_t)b * d.prior_target_bstride, Tg);
+    T w[6], ev[6];
+    load6(wp + ((int64_t)k * wpB) * 6 + (int64_t)b * d.w_prior_bstride, w);
+    local_eval<T>(Tg, X, w, eps, ev, nullptr, false);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc += ev[r] * ev[r];
+  }
+  partials[(int64_t)ch * B + b] = acc;
+}
+
+template <typename T>
+__global__ void pg_error_reduce_kernel(const T* __restrict__ partials, T* __restrict__ err, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  T acc = T(0);
+#pragma unroll
+  for (int c = 0; c < THX_ERR_CHUNKS; ++c) acc += partials[(int64_t)c * B + b];
+  err[b] = T(0.5) * acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Jacobian / residual dump
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64)
+pg_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* __restrict__ J1o,
+                    T* __restrict__ ebo, T* __restrict__ Jpo, T* __restrict__ epo, Eps<T> eps) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int c = blockIdx.y;
+  const int B = d.batch;
+  if (b >= B) return;
+  const T* poses = static_cast<const T*>(d.poses);
+  T ev[6], M36[36];
+  if (c < s.num_edges) {
+    const int e = c, i = s.edge_i[e], j = s.edge_j[e];
+    const int64_t mB = d.meas_bstride ? B : 1, wB = d.w_between_bstride ? B : 1;
+    SE3<T> Xi, Xj, M;
+    se3_load_vec(poses + ((int64_t)i * B + b) * 12, Xi);
+    se3_load_vec(poses + ((int64_t)j * B + b) * 12, Xj);
+    se3_load_vec(static_cast<const T*>(d.meas) + ((int64_t)e * mB) * 12 + (int64_t)b * d.meas_bstride, M);
+    T w[6];
+    load6(static_cast<const T*>(d.w_between) + ((int64_t)e * wB) * 6 + (int64_t)b * d.w_between_bstride, w);
+    SJac<T> J0, J1;
+    between_eval(Xi, Xj, M, w, eps, ev, &J0, &J1, true);
+    const int64_t o = (int64_t)e * B + b;
+    if (J0o) {
+      sjac_dense(J0, M36);
+#pragma unroll
+      for (int k = 0; k < 36; ++k) J0o[o * 36 + k] = M36[k];
+    }
+    if (J1o) {
+      sjac_dense(J1, M36);
+#pragma unroll
+      for (int k = 0; k < 36; ++k) J1o[o * 36 + k] = M36[k];
+    }
+    if (ebo) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ebo[o * 6 + k] = ev[k];
+    }
+  } else {
+    const int k = c - s.num_edges, p = s.prior_pose[k];
+    const int64_t tB = d.prior_target_bstride ? B : 1, wB = d.w_prior_bstride ? B : 1;
+    SE3<T> X, Tg;
+    se3_load_vec(poses + ((int64_t)p * B + b) * 12, X);
+    se3_load_vec(static_cast<const T*>(d.prior_target) + ((int64_t)k * tB) * 12 + (int64_t)b * d.prior_target_bstride, Tg);
+    T w[6];
+    load6(static_cast<const T*>(d.w_prior) + ((int64_t)k * wB) * 6 + (int64_t)b * d.w_prior_bstride, w);
+    SJac<T> J;
+    local_eval(Tg, X, w, eps, ev, &J, true);
+    const int64_t o = (int64_t)k * B + b;
+    if (Jpo) {
+      sjac_dense(J, M36);
+#pragma unroll
+      for (int q = 0; q < 36; ++q) Jpo[o * 36 + q] = M36[q];
+    }
+    if (epo) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) epo[o * 6 + q] = ev[q];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// retraction
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(64)
+se3_retract_kernel(const T* __restrict__ poses, const T* __restrict__ delta, int64_t ldd, T step,
+                   const uint8_t* __restrict__ ignore, T* __restrict__ out, int P, int B, Eps<T> eps) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int p = blockIdx.y;
+  if (b >= B) return;
+  SE3<T> X, Ex, Y;
+  se3_load_vec(poses + ((int64_t)p * B + b) * 12, X);
+  if (ignore && ignore[b]) {
+    se3_store_vec(out + ((int64_t)p * B + b) * 12, X);
+    return;
+  }
+  T xi[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) xi[i] = delta[(int64_t)b * ldd + 6 * p + i] * step;
+  ExpCoef<T> c;
+  T Ct;
+  se3_exp(xi, eps, Ex, c, Ct);
+  se3_mul(X, Ex, Y);
+  se3_store_vec(out + ((int64_t)p * B + b) * 12, Y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise SE3 ops
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void se3_exp_kernel(const T* __restrict__ xi, T* __restrict__ X, T* __restrict__ jac, int64_t N,
+                               Eps<T> eps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  T v[6];
+  load6(xi + i * 6, v);
+  SE3<T> E;
+  ExpCoef<T> c;
+  T Ct;
+  se3_exp(v, eps, E, c, Ct);
+  se3_store_vec(X + i * 12, E);
+  if (jac) {
+    T J[36];
+    se3_jexp(v, E, c, Ct, J);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) jac[i * 36 + k] = J[k];
+  }
+}
+
+template <typename T>
+__global__ void se3_log_kernel(const T* __restrict__ X, T* __restrict__ xi, T* __restrict__ jac, int64_t N,
+                               Eps<T> eps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  SE3<T> G;
+  se3_load_vec(X + i * 12, G);
+  T v[6], Jr[9], Jt[9];
+  se3_log_jlog(G, eps, v, Jr, Jt, jac != nullptr);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) xi[i * 6 + k] = v[k];
+  if (jac) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        jac[i * 36 + 6 * r + c] = Jr[3 * r + c];
+        jac[i * 36 + 6 * r + 3 + c] = Jt[3 * r + c];
+        jac[i * 36 + 6 * (r + 3) + c] = T(0);
+        jac[i * 36 + 6 * (r + 3) + 3 + c] = Jr[3 * r + c];
+      }
+  }
+}
+
+template <typename T>
+__global__ void se3_compose_kernel(const T* __restrict__ X, const T* __restrict__ Y, T* __restrict__ Z, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  SE3<T> a, b, c;
+  se3_load_vec(X + i * 12, a);
+  se3_load_vec(Y + i * 12, b);
+  se3_mul(a, b, c);
+  se3_store_vec(Z + i * 12, c);
+}
+
+template <typename T>
+__global__ void se3_inverse_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  SE3<T> a, b;
+  se3_load_vec(X + i * 12, a);
+  se3_inv(a, b);
+  se3_store_vec(Y + i * 12, b);
+}
+
+template <typename T>
+__global__ void se3_adjoint_kernel(const T* __restrict__ X, T* __restrict__ A, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  SE3<T> a;
+  se3_load_vec(X + i * 12, a);
+  T Hm[9] = {T(0), -a.t[2], a.t[1], a.t[2], T(0), -a.t[0], -a.t[1], a.t[0], T(0)};
+  T HR[9];
+  mat3_mul(Hm, a.R, HR);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      A[i * 36 + 6 * r + c] = a.R[3 * r + c];
+      A[i * 36 + 6 * r + 3 + c] = HR[3 * r + c];
+      A[i * 36 + 6 * (r + 3) + c] = T(0);
+      A[i * 36 + 6 * (r + 3) + 3 + c] = a.R[3 * r + c];
+    }
+}
+
+static int check_pg(const thx_pg_structure* s, const thx_pg_data* d) {
+  if (!s || !d) return fail("null structure/data");
+  if (s->num_poses <= 0 || d->batch <= 0) return fail("empty problem");
+  if (d->meas_bstride != 0 && d->meas_bstride != 12) return fail("meas_bstride must be 0 or 12");
+  if (d->prior_target_bstride != 0 && d->prior_target_bstride != 12) return fail("prior_target_bstride must be 0 or 12");
+  if (d->w_between_bstride != 0 && d->w_between_bstride != 6) return fail("w_between_bstride must be 0 or 6");
+  if (d->w_prior_bstride != 0 && d->w_prior_bstride != 6) return fail("w_prior_bstride must be 0 or 6");
+  return 0;
+}
+
+}  // namespace thx
+
+using namespace thx;
+
+extern "C" {
+
+const char* thx_last_error(void) { return last_error().c_str(); }
+int thx_abi_version(void) { return 1; }
+
+int thx_pg_assemble(const thx_pg_structure* s, const thx_pg_data* d, void* H, int64_t ld, void* g, int dtype,
+                    const thx_lie_eps* eps, void* stream) {
+  if (int r = check_pg(s, d)) return r;
+  if (!H || !g || !eps) return fail("null output");
+  if (ld < 6 * (int64_t)s->num_poses) return fail("ld < n");
+  dim3 grid((d->batch + 63) / 64, s->num_poses), block(64);
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(pg_assemble_kernel<float>, grid, block, 0, as_stream(stream), *s, *d,
+                                  (float*)H, ld, (float*)g, make_eps<float>(eps)),
+               hipLaunchKernelGGL(pg_assemble_kernel<double>, grid, block, 0, as_stream(stream), *s, *d,
+                                  (double*)H, ld, (double*)g, make_eps<double>(eps)));
+  return check_launch("thx_pg_assemble");
+}
+
+int thx_pg_error(const thx_pg_structure* s, const thx_pg_data* d, void* partials, void* err, int dtype,
+                 const thx_lie_eps* eps, void* stream) {
+  if (int r = check_pg(s, d)) return r;
+  if (!partials || !err || !eps) return fail("null output");
+  dim3 grid((d->batch + 63) / 64, THX_ERR_CHUNKS), block(64);
+  const int B = d->batch;
+  THX_DISPATCH(dtype,
+               {
+                 hipLaunchKernelGGL(pg_error_partial_kernel<float>, grid, block, 0, as_stream(stream), *s, *d,
+                                    (float*)partials, make_eps<float>(eps));
+                 hipLaunchKernelGGL(pg_error_reduce_kernel<float>, dim3((B + 255) / 256), dim3(256), 0,
+                                    as_stream(stream), (const float*)partials, (float*)err, B);
+               },
+               {
+                 hipLaunchKernelGGL(pg_error_partial_kernel<double>, grid, block, 0, as_stream(stream), *s, *d,
+                                    (double*)partials, make_eps<double>(eps));
+                 hipLaunchKernelGGL(pg_error_reduce_kernel<double>, dim3((B + 255) / 256), dim3(256), 0,
+                                    as_stream(stream), (const double*)partials, (double*)err, B);
+               });
+  return check_launch("thx_pg_error");
+}
+
+int thx_pg_jacobians(const thx_pg_structure* s, const thx_pg_data* d, void* J0, void* J1, void* eb, void* Jp,
+                     void* ep, int dtype, const thx_lie_eps* eps, void* stream) {
+  if (int r = check_pg(s, d)) return r;
+  if (!eps) return fail("null eps");
+  dim3 grid((d->batch + 63) / 64, s->num_edges + s->num_priors), block(64);
+  if (grid.y == 0) return 0;
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(pg_jacobians_kernel<float>, grid, block, 0, as_stream(stream), *s, *d,
+                                  (float*)J0, (float*)J1, (float*)eb, (float*)Jp, (float*)ep, make_eps<float>(eps)),
+               hipLaunchKernelGGL(pg_jacobians_kernel<double>, grid, block, 0, as_stream(stream), *s, *d,
+                                  (double*)J0, (double*)J1, (double*)eb, (double*)Jp, (double*)ep,
+                                  make_eps<double>(eps)));
+  return check_launch("thx_pg_jacobians");
+}
+
+int thx_se3_retract(const void* poses, const void* delta, int64_t ldd, double step, const uint8_t* ignore_mask,
+                    void* out, int32_t P, int32_t B, int dtype, const thx_lie_eps* eps, void* stream) {
+  if (!poses || !delta || !out || !eps || P <= 0 || B <= 0) return fail("bad retract args");
+  dim3 grid((B + 63) / 64, P), block(64);
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(se3_retract_kernel<float>, grid, block, 0, as_stream(stream), (const float*)poses,
+                                  (const float*)delta, ldd, (float)step, ignore_mask, (float*)out, P, B,
+                                  make_eps<float>(eps)),
+               hipLaunchKernelGGL(se3_retract_kernel<double>, grid, block, 0, as_stream(stream),
+                                  (const double*)poses, (const double*)delta, ldd, step, ignore_mask, (double*)out,
+                                  P, B, make_eps<double>(eps)));
+  return check_launch("thx_se3_retract");
+}
+
+#define THX_EW_GRID dim3 grid((unsigned)((N + 255) / 256)), block(256)
+
+int thx_se3_exp(const void* xi, void* X, void* jac, int64_t N, int dtype, const thx_lie_eps* eps, void* stream) {
+  if (N <= 0) return 0;
+  if (!xi || !X || !eps) return fail("null arg");
+  THX_EW_GRID;
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(se3_exp_kernel<float>, grid, block, 0, as_stream(stream), (const float*)xi,
+                                  (float*)X, (float*)jac, N, make_eps<float>(eps)),
+               hipLaunchKernelGGL(se3_exp_kernel<double>, grid, block, 0, as_stream(stream), (const double*)xi,
+                                  (double*)X, (double*)jac, N, make_eps<double>(eps)));
+  return check_launch("thx_se3_exp");
+}
+
+int thx_se3_log(const void* X, void* xi, void* jac, int64_t N, int dtype, const thx_lie_eps* eps, void* stream) {
+  if (N <= 0) return 0;
+  if (!xi || !X || !eps) return fail("null arg");
+  THX_EW_GRID;
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(se3_log_kernel<float>, grid, block, 0, as_stream(stream), (const float*)X,
+                                  (float*)xi, (float*)jac, N, make_eps<float>(eps)),
+               hipLaunchKernelGGL(se3_log_kernel<double>, grid, block, 0, as_stream(stream), (const double*)X,
+                                  (double*)xi, (double*)jac, N, make_eps<double>(eps)));
+  return check_launch("thx_se3_log");
+}
+
+int thx_se3_compose(const void* X, const void* Y, void* Z, int64_t N, int dtype, void* stream) {
+  if (N <= 0) return 0;
+  if (!X || !Y || !Z) return fail("null arg");
+  THX_EW_GRID;
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(se3_compose_kernel<float>, grid, block, 0, as_stream(stream), (const float*)X,
+                                  (const float*)Y, (float*)Z, N),
+               hipLaunchKernelGGL(se3_compose_kernel<double>, grid, block, 0, as_stream(stream), (const double*)X,
+                                  (const double*)Y, (double*)Z, N));
+  return check_launch("thx_se3_compose");
+}
+
+int thx_se3_inverse(const void* X, void* Y, int64_t N, int dtype, void* stream) {
+  if (N <= 0) return 0;
+  if (!X || !Y) return fail("null arg");
+  THX_EW_GRID;
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(se3_inverse_kernel<float>, grid, block, 0, as_stream(stream), (const float*)X,
+                                  (float*)Y, N),
+               hipLaunchKernelGGL(se3_inverse_kernel<double>, grid, block, 0, as_stream(stream), (const double*)X,
+                                  (double*)Y, N));
+  return check_launch("thx_se3_inverse");
+}
+
+int thx_se3_adjoint(const void* X, void* A, int64_t N, int dtype, void* stream) {
+  if (N <= 0) return 0;
+  if (!X || !A) return fail("null arg");
+  THX_EW_GRID;
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(se3_adjoint_kernel<float>, grid, block, 0, as_stream(stream), (const float*)X,
+                                  (float*)A, N),
+               hipLaunchKernelGGL(se3_adjoint_kernel<double>, grid, block, 0, as_stream(stream), (const double*)X,
+                                  (double*)A, N));
+  return check_launch("thx_se3_adjoint");
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+"""Kernel backend: torch tensors in, HIP launches out (through the C ABI, on torch's current stream).
+
+``HipKernels`` is the only backend the product ships.  The class boundary exists so that host logic
+that does not depend on a GPU (batch sharding, LM control flow) can be unit-tested on CPU with a
+stand-in injected by tests/; nothing in this package provides such a stand-in.
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .compiler import DeviceStructure
+
+# torchlie/torchlie/global_params.py:44-58 (defaults); runtime settable through set_lie_eps
+_LIE_EPS = {
+    torch.float32: dict(near_zero=1e-2, d_near_zero=2e-1, near_pi=1e-2),
+    torch.float64: dict(near_zero=5e-3, d_near_zero=1e-2, near_pi=1e-7),
+}
+
+
+def set_lie_eps(dtype, **kw):
+    """Mirror of torchlie.set_global_params for the three thresholds the kernels use."""
+    for k, v in kw.items():
+        if k not in _LIE_EPS[dtype]:
+            raise KeyError(k)
+        _LIE_EPS[dtype][k] = float(v)
+
+
+def lie_eps(dtype) -> _lib.LieEps:
+    e = _LIE_EPS[dtype]
+    return _lib.LieEps(e["near_zero"], e["d_near_zero"], e["near_pi"])
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class PGTensors:
+    """Per-call tensors of a pose-graph objective in the entity-major device layout."""
+
+    poses: torch.Tensor          # (P, B, 3, 4)
+    meas: torch.Tensor           # (E, Bm, 3, 4)   Bm in {1, B}
+    w_between: torch.Tensor      # (E, Bw, 6)
+    prior_target: torch.Tensor   # (K, Bt, 3, 4)
+    w_prior: torch.Tensor        # (K, Bw, 6)
+
+    @property
+    def batch(self):
+        return self.poses.shape[1]
+
+    def c_struct(self, poses: Optional[torch.Tensor] = None) -> _lib.PGData:
+        poses = self.poses if poses is None else poses
+        B = poses.shape[1]
+        d = _lib.PGData()
+        d.batch = B
+        d.poses = _lib.ptr(poses, "poses").value
+
+        def put(name, t, width):
+            nb = t.shape[1]
+            if nb not in (1, B):
+                raise ValueError(f"{name}: batch dimension {nb} is neither 1 nor {B}")
+            setattr(d, name, _lib.ptr(t, name).value if t.numel() else None)
+            setattr(d, name + "_bstride", width if nb == B else 0)
+
+        put("meas", self.meas, 12)
+        put("w_between", self.w_between, 6)
+        put("prior_target", self.prior_target, 12)
+        put("w_prior", self.w_prior, 6)
+        return d
+
+
+class HipKernels:
+    """Thin, allocation-free wrappers: every output buffer is supplied by the caller."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    # ---- SE3 elementwise ----------------------------------------------------------------------
+    def se3_exp(self, xi, jac=False):
+        xi = xi.contiguous()
+        N = xi.shape[0]
+        X = xi.new_empty(N, 3, 4)
+        J = xi.new_empty(N, 6, 6) if jac else None
+        e = lie_eps(xi.dtype)
+        _lib.check(self.lib.thx_se3_exp(_lib.ptr(xi), _lib.ptr(X), _lib.ptr(J), N, _lib.dtype_code(xi.dtype), e,
+                                        _lib.stream_ptr(xi.device)), "thx_se3_exp")
+        return (X, J) if jac else X
+
+    def se3_log(self, X, jac=False):
+        X = X.contiguous()
+        N = X.shape[0]
+        xi = X.new_empty(N, 6)
+        J = X.new_empty(N, 6, 6) if jac else None
+        e = lie_eps(X.dtype)
+        _lib.check(self.lib.thx_se3_log(_lib.ptr(X), _lib.ptr(xi), _lib.ptr(J), N, _lib.dtype_code(X.dtype), e,
+                                        _lib.stream_ptr(X.device)), "thx_se3_log")
+        return (xi, J) if jac else xi
+
+    def se3_compose(self, X, Y):
+        X, Y = X.contiguous(), Y.contiguous()
+        Z = torch.empty_like(X)
+        _lib.check(self.lib.thx_se3_compose(_lib.ptr(X), _lib.ptr(Y), _lib.ptr(Z), X.shape[0],
+                                            _lib.dtype_code(X.dtype), _lib.stream_ptr(X.device)), "thx_se3_compose")
+        return Z
+
+    def se3_inverse(self, X):
+        X = X.contiguous()
+        Y = torch.empty_like(X)
+        _lib.check(self.lib.thx_se3_inverse(_lib.ptr(X), _lib.ptr(Y), X.shape[0], _lib.dtype_code(X.dtype),
+                                            _lib.stream_ptr(X.device)), "thx_se3_inverse")
+        return Y
+
+    def se3_adjoint(self, X):
+        X = X.contiguous()
+        A = X.new_empty(X.shape[0], 6, 6)
+        _lib.check(self.lib.thx_se3_adjoint(_lib.ptr(X), _lib.ptr(A), X.shape[0], _lib.dtype_code(X.dtype),
+                                            _lib.stream_ptr(X.device)), "thx_se3_adjoint")
+        return A
+
+    # ---- pose graph -----------------------------------------------------------------------------
+    def pg_assemble(self, s: DeviceStructure, t: PGTensors, H, g, poses=None):
+        d = t.c_struct(poses)
+        dt = H.dtype
+        _lib.check(self.lib.thx_pg_assemble(s.c, d, _lib.ptr(H, "H"), H.shape[-1], _lib.ptr(g, "g"),
+                                            _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(H.device)),
+                   "thx_pg_assemble")
+
+    def pg_error(self, s: DeviceStructure, t: PGTensors, partials, err, poses=None):
+        d = t.c_struct(poses)
+        dt = err.dtype
+        _lib.check(self.lib.thx_pg_error(s.c, d, _lib.ptr(partials), _lib.ptr(err), _lib.dtype_code(dt), lie_eps(dt),
+                                         _lib.stream_ptr(err.device)), "thx_pg_error")
+
+    def pg_jacobians(self, s: DeviceStructure, t: PGTensors, J0, J1, eb, Jp, ep, poses=None):
+        d = t.c_struct(poses)
+        dt = t.poses.dtype
+        _lib.check(self.lib.thx_pg_jacobians(s.c, d, _lib.ptr(J0), _lib.ptr(J1), _lib.ptr(eb), _lib.ptr(Jp),
+                                             _lib.ptr(ep), _lib.dtype_code(dt), lie_eps(dt),
+                                             _lib.stream_ptr(t.poses.device)), "thx_pg_jacobians")
+
+    def se3_retract(self, poses, delta, step, ignore_mask, out):
+        P, B = poses.shape[:2]
+        dt = poses.dtype
+        _lib.check(self.lib.thx_se3_retract(_lib.ptr(poses), _lib.ptr(delta), delta.stride(0), float(step),
+                                            _lib.ptr(ignore_mask), _lib.ptr(out), P, B, _lib.dtype_code(dt),
+                                            lie_eps(dt), _lib.stream_ptr(poses.device)), "thx_se3_retract")
+
+    # ---- dense solver ---------------------------------------------------------------------------
+    def chol_factor(self, H, n, damping, ellipsoidal, damping_eps, L, diagT, info):
+        B, ld = H.shape[0], H.shape[-1]
+        _lib.check(self.lib.thx_chol_factor(_lib.ptr(H), ld, n, B, _lib.ptr(damping), int(bool(ellipsoidal)),
+                                            float(damping_eps), _lib.ptr(L), _lib.ptr(diagT), _lib.ptr(info),
+                                            _lib.dtype_code(H.dtype), _lib.stream_ptr(H.device)), "thx_chol_factor")
+
+    def chol_solve(self, L, n, diagT, rhs, x):
+        B, ld = L.shape[0], L.shape[-1]
+        _lib.check(self.lib.thx_chol_solve(_lib.ptr(L), ld, n, B, _lib.ptr(diagT), _lib.ptr(rhs), _lib.ptr(x),
+                                           rhs.stride(0), _lib.dtype_code(L.dtype), _lib.stream_ptr(L.device)),
+                   "thx_chol_solve")
+
+    def diag(self, H, n, d):
+        B, ld = H.shape[0], H.shape[-1]
+        _lib.check(self.lib.thx_diag(_lib.ptr(H), ld, n, B, _lib.ptr(d), d.stride(0), _lib.dtype_code(H.dtype),
+                                     _lib.stream_ptr(H.device)), "thx_diag")
+
+    def lm_accept(self, delta, g, H, n, damping, prev_err, new_err, ellipsoidal, accept, down, up, reject):
+        B = delta.shape[0]
+        ld = H.shape[-1] if H is not None else 0
+        _lib.check(self.lib.thx_lm_accept(_lib.ptr(delta), _lib.ptr(g), delta.stride(0), _lib.ptr(H), ld, n, B,
+                                          _lib.ptr(damping), _lib.ptr(prev_err), _lib.ptr(new_err),
+                                          int(bool(ellipsoidal)), float(accept), float(down), float(up),
+                                          _lib.ptr(reject), _lib.dtype_code(delta.dtype),
+                                          _lib.stream_ptr(delta.device)), "thx_lm_accept")
+
+
+_default = None
+
+
+def default_kernels() -> HipKernels:
+    global _default
+    if _default is None:
+        _default = HipKernels()
+    return _default
