@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py -- LM problem-iterations/s on the synthetic SE3 pose graph (BASELINE.json configs[1]).
+
+A "step" is ONE Levenberg-Marquardt iteration over the whole batch (linearize -> damp + Cholesky
+factor + solve -> retract -> error), i.e. one pass of the hot path over one batch of synthetic
+input.  `--steps K` LM iterations are run by a single TheseusLayer.forward (max_iterations=K, both
+tolerances 0 so nothing exits early -- same trick as the reference's examples/pose_graph/pose_graph_cube.py:95-96);
+the timed region is bracketed by barrier + torch.cuda.synchronize and the max over ranks is reported.
+value = n_gpus * B * K / time  (problem-iterations per second, whole job).
+
+Multi GPU (launched by torch.distributed.run, one rank per GPU): the batch dimension shards -- every
+rank owns B independent problems (weak scaling) -- and one RCCL all_gather re-collects the solved
+poses on every rank inside the timed region.  No other collective.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK = {"f32": 157.3, "f64": 78.6}  # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+class KernelTimer:
+    """HIP-event timing of every C-ABI call, on the stream the kernels are launched on
+    (torch's current stream: torch.cuda.Event records there)."""
+
+    NAMES = ["pg_assemble", "chol_factor", "chol_solve", "se3_retract", "pg_error", "lm_accept"]
+
+    def __init__(self, K):
+        self.K, self.events, self.enabled = K, {n: [] for n in self.NAMES}, False
+        for n in self.NAMES:
+            setattr(K, n, self._wrap(n, getattr(K, n)))
+
+    def _wrap(self, name, fn):
+        def wrapped(*a, **k):
+            if not self.enabled:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            self.events[name].append((e0, e1))
+            return r
+        return wrapped
+
+    def summary(self):
+        out = {}
+        for n, ev in self.events.items():
+            if ev:
+                ms = [a.elapsed_time(b) for a, b in ev]
+                out[n] = {"calls": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms)}
+        return out
+
+
+def cpu_baseline(tensors, edges, P, dtype, sample, iters):
+    """Oracle (CPU restatement of the reference's dense algorithm, torch-CPU/MKL) on a bounded sample
+    of the same workload.  Returns (problem-iters/s, cores, final poses of the sample, seconds)."""
+    from oracle import pose_graph as opg
+    from theseus_amd.utils import synthetic as syn
+    cpu = lambda t: t[:sample].detach().cpu()  # noqa: E731
+    poses0 = torch.stack([cpu(tensors[f"VERTEX_SE3__{k}"]) for k in range(P)], 1)
+    meas = torch.stack([cpu(tensors[f"EDGE_SE3__{i}_{j}"]) for (i, j) in edges], 1)
+    E = len(edges)
+    w = torch.tensor([1 / syn.TRANSLATION_NOISE] * 3 + [1 / syn.ROTATION_NOISE] * 3, dtype=dtype)
+    prob = opg.PGProblem(num_poses=P, edges=torch.tensor(edges), meas=meas, w_between=w.view(1, 1, 6).expand(1, E, 6),
+                         prior_idx=torch.tensor([0]), prior_target=cpu(tensors["VERTEX_SE3__0__PRIOR"]).unsqueeze(1),
+                         w_prior=torch.full((1, 1, 6), syn.PRIOR_WEIGHT, dtype=dtype))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        final, info = opg.lm_optimize(prob, poses0, max_iterations=iters, damping=1e-3, abs_err_tolerance=0.0,
+                                      rel_err_tolerance=0.0)
+        dt = time.perf_counter() - t0
+    return sample * iters / dt, torch.get_num_threads(), final, dt, torch.stack(info.err_history, 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
+    ap.add_argument("--poses", type=int, default=256)
+    ap.add_argument("--edges", type=int, default=1024)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--damping", type=float, default=1e-3)
+    ap.add_argument("--adaptive", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="problems in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+
+    import theseus_amd as th
+    from theseus_amd.utils import synthetic as syn
+
+    P, E, B, K_iters, W = args.poses, args.edges, args.batch, args.steps, args.warmup
+    n = 6 * P
+    edges = syn.pose_graph_topology(P, E, topology_seed=0)
+    objective = syn.build_pose_graph_objective(edges, P, dtype=dtype, device=device)
+    opt = th.LevenbergMarquardt(objective, linear_solver_cls=th.HipCholeskySolver, max_iterations=K_iters,
+                                abs_err_tolerance=0.0, rel_err_tolerance=0.0, step_size=1.0)
+    layer = th.TheseusLayer(opt)
+    timer = KernelTimer(opt.linear_solver.K)
+    tensors = syn.make_pose_graph_tensors(edges, P, B, dtype=dtype, device=device, seed=1234 + rank)
+    inputs = syn.input_dict(tensors)
+    okw = dict(damping=args.damping, adaptive_damping=args.adaptive)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        if W > 0:
+            opt.set_params(max_iterations=W)
+            layer.forward(inputs, optimizer_kwargs=okw)
+        opt.set_params(max_iterations=K_iters)
+        gathered = None
+        if world > 1:
+            gathered = torch.empty(world, P, B, 3, 4, dtype=dtype, device=device)
+        barrier()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        sol, info = layer.forward(inputs, optimizer_kwargs=dict(track_err_history=True, **okw))
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, opt.linear_solver.linearization.packed.tensors.poses)
+        barrier()
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    iters_done = info.iters_done
+    if rank == 0:
+        phases = timer.summary()
+        fac = phases.get("chol_factor", {"avg_ms": float("nan")})
+        flops_per_launch = B * (n ** 3) / 3.0  # n^3/3 per problem x B problems per factor call
+        achieved = flops_per_launch / (fac["avg_ms"] * 1e-3) / 1e12
+        peak = PEAK[args.dtype]
+        err_hist = info.err_history
+        result = {
+            "metric": "LM iterations/sec (batch x vars) on SE3 pose-graph",
+            "value": world * B * iters_done / dt,
+            "unit": "problem-iterations/s",
+            "n_gpus": world, "steps": K_iters, "warmup": W, "ms_per_step": dt / max(iters_done, 1) * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"SE3 pose-graph {P} poses / {E} Between edges + 1 prior, batch {B} per GPU, "
+                                   f"LM damping {args.damping}{' adaptive' if args.adaptive else ''} + dense Cholesky",
+                       "poses": P, "edges": E, "batch_per_gpu": B, "global_batch": world * B, "n": n,
+                       "parallelism": f"batch-shard x{world}"},
+            "pose_updates_per_s": world * B * iters_done * P / dt,
+            "iters_done": iters_done,
+            "mean_error": [float(err_hist[:, 0].mean()), float(err_hist[:, iters_done].mean())],
+            "roofline": {"bound": "mfma", "kernel": "thx_chol_factor (chol_diag + chol_offdiag launches)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "flops_per_launch": flops_per_launch, "avg_launch_ms": fac["avg_ms"]},
+            "phases_ms_per_call": {k: round(v["avg_ms"], 4) for k, v in phases.items()},
+        }
+        if args.cpu_sample > 0:
+            S, CI = min(args.cpu_sample, B), args.cpu_iters
+            v, cores, cpu_final, cpu_s, cpu_hist = cpu_baseline(tensors, edges, P, dtype, S, CI)
+            # parity of the HIP path against the oracle on exactly that sample
+            sub = {k: t[:S].contiguous() for k, t in inputs.items()}
+            opt.set_params(max_iterations=CI)
+            with torch.no_grad():
+                sol_s, info_s = layer.forward(sub, optimizer_kwargs=dict(track_err_history=True, **okw))
+            got = torch.stack([sol_s[f"VERTEX_SE3__{k}"] for k in range(P)], 1).cpu()
+            result["cpu_baseline"] = {"value": v, "unit": "problem-iterations/s", "cores": cores, "kind": "port",
+                                      "sample": f"first {S} problems of rank 0's batch x {CI} LM iterations "
+                                                f"({cpu_s:.1f} s), oracle.pose_graph.lm_optimize (torch-CPU/MKL "
+                                                f"restatement of DenseLinearization + CholeskyDenseSolver)"}
+            result["parity"] = {"max_abs_pose_err_vs_oracle": float((got - cpu_final).abs().max()),
+                                "rel_err_final_cost": float(((info_s.err_history[:, CI] - cpu_hist[:, CI]).abs()
+                                                            / cpu_hist[:, CI].abs()).max()),
+                                "problems": S, "iters": CI}
+            result["speedup_vs_cpu"] = result["value"] / v
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

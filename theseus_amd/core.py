@@ -1,0 +1,465 @@
+"""Host-side mirror of the part of the Theseus modelling API that feeds the GN/LM hot path.
+
+Same names, argument meaning and error behaviour as the reference so that code written against
+``theseus`` reads the same against ``theseus_amd`` for this path:
+  Variable              theseus/core/variable.py:14-112
+  SE3                   theseus/geometry/se3.py:20-300, theseus/geometry/lie_group.py:19-260
+  Scale/DiagonalCostWeight  theseus/core/cost_weight.py:60-139
+  Between / Difference  theseus/embodied/measurements/between.py:16-60, theseus/embodied/misc/local_cost_fn.py:16-75
+  Objective             theseus/core/objective.py:42-956 (add / update / error / error_metric / retract)
+All arithmetic is done by the HIP kernels (theseus_amd/csrc); nothing here computes on the CPU.
+"""
+import abc
+from collections import OrderedDict
+from itertools import count
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+
+from .kernels import default_kernels
+
+
+class Variable:
+    """Named tensor with a leading batch dimension (theseus/core/variable.py:14-112)."""
+
+    _ids = count(0)
+
+    def __init__(self, tensor: torch.Tensor, name: Optional[str] = None):
+        self._id = next(Variable._ids)
+        self.name = name if name else f"{self.__class__.__name__}__{self._id}"
+        self.tensor = tensor
+        self._num_updates = 0
+
+    def update(self, data: Union[torch.Tensor, "Variable"], batch_ignore_mask: Optional[torch.Tensor] = None):
+        if isinstance(data, Variable):
+            data = data.tensor
+        if data.ndim != self.tensor.ndim or data.shape[1:] != self.tensor.shape[1:]:
+            raise ValueError(
+                f"Tried to update tensor {self.name} with data incompatible with original tensor shape. "
+                f"Given {tuple(data.shape[1:])}. Expected: {tuple(self.tensor.shape[1:])}")
+        if data.dtype != self.dtype:
+            raise ValueError(f"Tried to update used tensor of dtype {data.dtype} but Variable "
+                             f"{self.name} has dtype {self.dtype}.")
+        if batch_ignore_mask is not None and batch_ignore_mask.any():
+            mask = batch_ignore_mask.view([-1] + [1] * (data.ndim - 1))
+            self.tensor = torch.where(mask, self.tensor, data)  # core/variable.py:65-69
+        else:
+            self.tensor = data
+        self._num_updates += 1
+
+    @property
+    def shape(self):
+        return self.tensor.shape
+
+    @property
+    def dtype(self):
+        return self.tensor.dtype
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+    @property
+    def ndim(self):
+        return self.tensor.ndim
+
+    def to(self, *args, **kwargs):
+        self.tensor = self.tensor.to(*args, **kwargs)
+        self._num_updates += 1
+
+    def copy(self, new_name: Optional[str] = None) -> "Variable":
+        return self.__class__(tensor=self.tensor.clone(), name=new_name or f"{self.name}_copy")
+
+    def __getitem__(self, item):
+        return self.tensor[item]
+
+
+class Vector(Variable):
+    """Euclidean variable (theseus/geometry/vector.py); only used as an auxiliary variable here."""
+
+    def __init__(self, dof: Optional[int] = None, tensor: Optional[torch.Tensor] = None,
+                 name: Optional[str] = None, dtype: Optional[torch.dtype] = None):
+        if tensor is None:
+            tensor = torch.zeros(1, dof, dtype=dtype or torch.get_default_dtype())
+        if tensor.ndim == 1:
+            tensor = tensor.view(1, -1)
+        super().__init__(tensor, name)
+
+    def dof(self) -> int:
+        return self.tensor.shape[1]
+
+
+class SE3(Variable):
+    """SE3 group element batch, tensor (B,3,4) = [R | t]; tangent [v, w]; right perturbations."""
+
+    def __init__(self, x_y_z_quaternion: Optional[torch.Tensor] = None, tensor: Optional[torch.Tensor] = None,
+                 name: Optional[str] = None, dtype: Optional[torch.dtype] = None):
+        if x_y_z_quaternion is not None and tensor is not None:
+            raise ValueError("Please provide only one of x_y_z_quaternion or tensor.")
+        if x_y_z_quaternion is not None:
+            tensor = SE3._from_x_y_z_quaternion(x_y_z_quaternion)
+        if tensor is None:
+            tensor = torch.eye(3, 4, dtype=dtype or torch.get_default_dtype()).view(1, 3, 4)
+        if tensor.ndim == 2:
+            tensor = tensor.unsqueeze(0)
+        if tensor.ndim != 3 or tensor.shape[1:] != (3, 4):
+            raise ValueError("SE3 data tensors can only be 3x4 matrices.")
+        if dtype is not None and tensor.dtype != dtype:
+            tensor = tensor.to(dtype)
+        super().__init__(tensor, name)
+
+    @staticmethod
+    def _from_x_y_z_quaternion(q: torch.Tensor) -> torch.Tensor:
+        # theseus/geometry/se3.py:128-145 ; quaternion order (w, x, y, z) after the translation
+        if q.ndim == 1:
+            q = q.unsqueeze(0)
+        t, w, x, y, z = q[:, :3], q[:, 3], q[:, 4], q[:, 5], q[:, 6]
+        R = torch.stack([
+            1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+            2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+            2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=1).view(-1, 3, 3)
+        return torch.cat([R, t.unsqueeze(2)], dim=2)
+
+    @staticmethod
+    def dof() -> int:
+        return 6
+
+    # ---- group operations: all evaluated by the HIP elementwise kernels -------------------------
+    @staticmethod
+    def exp_map(tangent_vector: torch.Tensor, jacobians: Optional[List[torch.Tensor]] = None) -> "SE3":
+        if tangent_vector.ndim != 2 or tangent_vector.shape[1] != 6:
+            raise ValueError("Tangent vectors of SE3 should be 6-D vectors.")
+        K = default_kernels()
+        if jacobians is not None:
+            X, J = K.se3_exp(tangent_vector, jac=True)
+            jacobians.append(J)
+        else:
+            X = K.se3_exp(tangent_vector)
+        return SE3(tensor=X)
+
+    def log_map(self, jacobians: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+        K = default_kernels()
+        if jacobians is not None:
+            xi, J = K.se3_log(self.tensor, jac=True)
+            jacobians.append(J)
+            return xi
+        return K.se3_log(self.tensor)
+
+    def adjoint(self) -> torch.Tensor:
+        return default_kernels().se3_adjoint(self.tensor)
+
+    def inverse(self) -> "SE3":
+        return SE3(tensor=default_kernels().se3_inverse(self.tensor))
+
+    def compose(self, other: "SE3") -> "SE3":
+        a, b = _broadcast_pair(self.tensor, other.tensor)
+        return SE3(tensor=default_kernels().se3_compose(a, b))
+
+    def between(self, other: "SE3") -> "SE3":
+        return self.inverse().compose(other)
+
+    def local(self, other: "SE3") -> torch.Tensor:
+        return self.between(other).log_map()
+
+    def retract(self, delta: torch.Tensor) -> "SE3":
+        return self.compose(SE3.exp_map(delta))
+
+    @staticmethod
+    def rand(*size: int, generator=None, dtype=None, device=None) -> "SE3":
+        # theseus/geometry/se3.py:45-62 (uniform quaternion + uniform translation); here: exp of a
+        # random tangent, adequate for synthetic data
+        if len(size) != 1:
+            raise ValueError("The size should be 1D.")
+        xi = torch.rand(size[0], 6, generator=generator, dtype=dtype, device=device) * 2 - 1
+        xi[:, 3:] *= 3.0
+        return SE3.exp_map(xi)
+
+    def copy(self, new_name: Optional[str] = None) -> "SE3":
+        return SE3(tensor=self.tensor.clone(), name=new_name or f"{self.name}_copy")
+
+
+def _broadcast_pair(a, b):
+    if a.shape[0] != b.shape[0]:
+        if a.shape[0] == 1:
+            a = a.expand_as(b)
+        elif b.shape[0] == 1:
+            b = b.expand_as(a)
+        else:
+            raise ValueError("Batch sizes must match or be 1.")
+    return a.contiguous(), b.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# cost weights
+# ------------------------------------------------------------------------------------------------
+class CostWeight(abc.ABC):
+    def __init__(self, name: Optional[str] = None):
+        self.name = name
+
+    @abc.abstractmethod
+    def diagonal6(self) -> torch.Tensor:
+        """(Bw, 6) sqrt-information diagonal (what the kernels consume)."""
+
+
+class ScaleCostWeight(CostWeight):
+    """e <- e * s, J <- J * s (theseus/core/cost_weight.py:60-90)."""
+
+    def __init__(self, scale: Union[float, torch.Tensor, Variable], name: Optional[str] = None):
+        super().__init__(name)
+        if not isinstance(scale, Variable):
+            if not isinstance(scale, torch.Tensor):
+                scale = torch.tensor(float(scale))
+            scale = Variable(scale.view(-1, 1) if scale.ndim < 2 else scale)
+        if scale.tensor.ndim != 2 or scale.tensor.shape[1] != 1:
+            raise ValueError("ScaleCostWeight only accepts 0-dim or 1-dim tensors, or (batch, 1) tensors.")
+        self.scale = scale
+
+    def aux_vars(self):
+        return [self.scale]
+
+    def diagonal6(self):
+        return self.scale.tensor.expand(-1, 6)
+
+
+class DiagonalCostWeight(CostWeight):
+    """e <- e * w, J <- diag(w) J (theseus/core/cost_weight.py:93-139)."""
+
+    def __init__(self, diagonal: Union[Sequence[float], torch.Tensor, Variable], name: Optional[str] = None):
+        super().__init__(name)
+        if not isinstance(diagonal, Variable):
+            if not isinstance(diagonal, torch.Tensor):
+                diagonal = torch.tensor(diagonal)
+            diagonal = Variable(diagonal.view(1, -1) if diagonal.ndim == 1 else diagonal)
+        if diagonal.tensor.ndim != 2:
+            raise ValueError("DiagonalCostWeight only accepts tensors of shape (batch, dim) or (dim,).")
+        self.diagonal = diagonal
+
+    def aux_vars(self):
+        return [self.diagonal]
+
+    def diagonal6(self):
+        if self.diagonal.tensor.shape[1] != 6:
+            raise ValueError("SE3 costs need a 6-dimensional DiagonalCostWeight.")
+        return self.diagonal.tensor
+
+
+# ------------------------------------------------------------------------------------------------
+# cost functions
+# ------------------------------------------------------------------------------------------------
+class CostFunction(abc.ABC):
+    _ids = count(0)
+
+    def __init__(self, cost_weight: CostWeight, name: Optional[str] = None):
+        self.weight = cost_weight
+        self.name = name if name else f"{self.__class__.__name__}__{next(CostFunction._ids)}"
+
+    @abc.abstractmethod
+    def optim_vars(self) -> List[Variable]:
+        pass
+
+    @abc.abstractmethod
+    def aux_vars(self) -> List[Variable]:
+        pass
+
+    @abc.abstractmethod
+    def error(self) -> torch.Tensor:
+        pass
+
+    @abc.abstractmethod
+    def dim(self) -> int:
+        pass
+
+    def weighted_error(self) -> torch.Tensor:
+        return self.error() * self.weight.diagonal6()
+
+
+class Between(CostFunction):
+    """e = log(meas^-1 (v0^-1 v1)) (theseus/embodied/measurements/between.py:16-60)."""
+
+    def __init__(self, v0: SE3, v1: SE3, measurement: SE3, cost_weight: CostWeight, name: Optional[str] = None):
+        super().__init__(cost_weight, name)
+        if not isinstance(v0, v1.__class__) or not isinstance(v0, measurement.__class__):
+            raise ValueError("Inconsistent types between variables and measurement.")
+        self.v0, self.v1, self.measurement = v0, v1, measurement
+
+    def optim_vars(self):
+        return [self.v0, self.v1]
+
+    def aux_vars(self):
+        return [self.measurement] + self.weight.aux_vars()
+
+    def error(self):
+        return self.measurement.local(self.v0.between(self.v1))
+
+    def dim(self):
+        return 6
+
+
+class Difference(CostFunction):
+    """e = log(target^-1 var) (theseus/embodied/misc/local_cost_fn.py:16-75; ``Local`` is an alias)."""
+
+    def __init__(self, var: SE3, target: SE3, cost_weight: CostWeight, name: Optional[str] = None):
+        super().__init__(cost_weight, name)
+        if not isinstance(var, target.__class__):
+            raise ValueError("Variable for the Local inconsistent with the given target.")
+        self.var, self.target = var, target
+
+    def optim_vars(self):
+        return [self.var]
+
+    def aux_vars(self):
+        return [self.target] + self.weight.aux_vars()
+
+    def error(self):
+        return self.target.local(self.var)
+
+    def dim(self):
+        return 6
+
+
+Local = Difference
+
+
+# ------------------------------------------------------------------------------------------------
+# objective
+# ------------------------------------------------------------------------------------------------
+class Objective:
+    """Container of cost functions and their variables (theseus/core/objective.py:42-956).
+
+    The linearization back end (``HipLinearization``) installs a packed device representation in
+    ``self._packed`` -- the analogue of the reference's vectorisation hooks
+    (core/objective.py:113-146,916-956) -- after which ``error``/``error_metric``/
+    ``retract_vars_sequence``/``update`` run as fused HIP kernels on the packed buffers.
+    """
+
+    def __init__(self, dtype: Optional[torch.dtype] = None):
+        self.dtype = dtype or torch.get_default_dtype()
+        self.device = torch.device("cpu")
+        self.cost_functions: "OrderedDict[str, CostFunction]" = OrderedDict()
+        self.optim_vars: "OrderedDict[str, Variable]" = OrderedDict()
+        self.aux_vars: "OrderedDict[str, Variable]" = OrderedDict()
+        self.batch_size: Optional[int] = None
+        self._packed = None
+        self._num_updates_variables: Dict[str, int] = {}
+        self.current_version = 0
+
+    # theseus/core/objective.py:148-300 (add / registration, name clash checks)
+    def add(self, cost_function: CostFunction):
+        if cost_function.name in self.cost_functions:
+            raise ValueError(f"Two different cost function objects with the same name "
+                             f"({cost_function.name}) are not allowed in the same objective.")
+        for v in cost_function.optim_vars() + cost_function.aux_vars():
+            if v.dtype != self.dtype:
+                raise ValueError(f"Tried to add variable {v.name} with data type {v.dtype} but objective's "
+                                 f"data type is {self.dtype}.")
+        for v in cost_function.optim_vars():
+            if v.name in self.aux_vars:
+                raise ValueError(f"Variable {v.name} is already registered as an auxiliary variable.")
+            if v.name in self.optim_vars and self.optim_vars[v.name] is not v:
+                raise ValueError(f"Two different variable objects with the same name ({v.name}) are not allowed.")
+            self.optim_vars[v.name] = v
+        for v in cost_function.aux_vars():
+            if v.name in self.optim_vars:
+                raise ValueError(f"Variable {v.name} is already registered as an optimization variable.")
+            if v.name in self.aux_vars and self.aux_vars[v.name] is not v:
+                raise ValueError(f"Two different variable objects with the same name ({v.name}) are not allowed.")
+            self.aux_vars[v.name] = v
+        self.cost_functions[cost_function.name] = cost_function
+        self.current_version += 1
+        self._packed = None
+
+    def dim(self) -> int:
+        return sum(c.dim() for c in self.cost_functions.values())
+
+    def size_cost_functions(self) -> int:
+        return len(self.cost_functions)
+
+    def size_variables(self) -> int:
+        return len(self.optim_vars)
+
+    def _all_variables(self):
+        yield from self.optim_vars.values()
+        yield from self.aux_vars.values()
+
+    def get_variable(self, name: str) -> Variable:
+        if name in self.optim_vars:
+            return self.optim_vars[name]
+        if name in self.aux_vars:
+            return self.aux_vars[name]
+        raise ValueError(f"Named variable {name} is not in the objective.")
+
+    # theseus/core/objective.py:708-727
+    def _resolve_batch_size(self):
+        bs = 1
+        for v in self._all_variables():
+            b = v.shape[0]
+            if b != 1:
+                if bs != 1 and b != bs:
+                    raise ValueError("Provided variable tensors must be broadcastable along batch dimension.")
+                bs = b
+        self.batch_size = bs
+
+    # theseus/core/objective.py:729-811
+    def update(self, input_tensors: Optional[Dict[str, torch.Tensor]] = None,
+               batch_ignore_mask: Optional[torch.Tensor] = None):
+        input_tensors = input_tensors or {}
+        for name, t in input_tensors.items():
+            if name in self.optim_vars:
+                self.optim_vars[name].update(t, batch_ignore_mask=batch_ignore_mask)
+            elif name in self.aux_vars:
+                self.aux_vars[name].update(t, batch_ignore_mask=batch_ignore_mask)
+            else:
+                import warnings
+                warnings.warn(f"Attempted to update a tensor with name {name}, which is not associated to any "
+                              f"variable in the objective.")
+        self._resolve_batch_size()
+        devs = {v.device for v in self._all_variables()}
+        if len(devs) == 1:
+            self.device = devs.pop()
+
+    def to(self, *args, **kwargs):
+        for v in self._all_variables():
+            v.to(*args, **kwargs)
+        dev, dtype, *_ = torch._C._nn._parse_to(*args, **kwargs)
+        self.device = dev or self.device
+        self.dtype = dtype or self.dtype
+        self._packed = None
+
+    # theseus/core/objective.py:562-641
+    def error(self, input_tensors: Optional[Dict[str, torch.Tensor]] = None, also_update: bool = False):
+        saved = None
+        if input_tensors is not None:
+            if not also_update:
+                saved = {n: self.get_variable(n).tensor for n in input_tensors}
+            self.update(input_tensors)
+        if self._packed is not None:
+            err = self._packed.error_vector()
+        else:
+            err = torch.cat([c.weighted_error() for c in self.cost_functions.values()], dim=1)
+        if saved is not None:
+            self.update(saved)
+        return err
+
+    def error_metric(self, input_tensors: Optional[Dict[str, torch.Tensor]] = None, also_update: bool = False):
+        """0.5 * squared norm of the weighted error vector, per batch item (objective.py:37-38,615-641)."""
+        if self._packed is not None:
+            saved = None
+            if input_tensors is not None:
+                if not also_update:
+                    saved = {n: self.get_variable(n).tensor for n in input_tensors}
+                self.update(input_tensors)
+            out = self._packed.error_metric()
+            if saved is not None:
+                self.update(saved)
+            return out
+        return (self.error(input_tensors, also_update) ** 2).sum(dim=1) / 2
+
+    # theseus/core/objective.py:873-914
+    def retract_vars_sequence(self, delta: torch.Tensor, ordering, ignore_mask: Optional[torch.Tensor] = None,
+                              force_update: bool = False):
+        var_idx = 0
+        mask = None if force_update else ignore_mask
+        for var in ordering:
+            new_var = var.retract(delta[:, var_idx:var_idx + var.dof()])
+            var.update(new_var.tensor, batch_ignore_mask=mask)
+            var_idx += var.dof()

@@ -1,0 +1,97 @@
+"""`LinearSolver` plugin surface + the HIP dense Cholesky solver.
+
+ABC contract: theseus/optimizer/linear/linear_solver.py:15-37.  ``HipCholeskySolver`` replaces
+``CholeskyDenseSolver`` (theseus/optimizer/linear/dense_solver.py:20-161): damping semantics of
+``DenseSolver._apply_damping`` (:38-64, out of place), ``torch.linalg.cholesky`` +
+``torch.cholesky_solve`` (:159-161) become one batched tiled HIP factorisation + two triangular
+solves; a non positive-definite system raises ``RuntimeError`` like ``torch.linalg.cholesky`` does.
+"""
+import abc
+from typing import Any, Dict, Optional, Type, Union
+
+import torch
+
+from .core import Objective
+from .linearization import HipLinearization, Linearization
+from . import _lib
+
+
+class LinearSolver(abc.ABC):
+    def __init__(self, objective: Objective, linearization_cls: Optional[Type[Linearization]] = None,
+                 linearization_kwargs: Optional[Dict[str, Any]] = None, **kwargs):
+        linearization_kwargs = linearization_kwargs or {}
+        self.linearization: Linearization = linearization_cls(objective, **linearization_kwargs)
+
+    def reset(self, **kwargs):
+        pass
+
+    @abc.abstractmethod
+    def solve(self, damping: Optional[Union[float, torch.Tensor]] = None, **kwargs) -> torch.Tensor:
+        pass
+
+
+class HipCholeskySolver(LinearSolver):
+    def __init__(self, objective: Objective, linearization_cls: Optional[Type[Linearization]] = None,
+                 linearization_kwargs: Optional[Dict[str, Any]] = None, check_singular: bool = False, **kwargs):
+        linearization_cls = linearization_cls or HipLinearization
+        if not (isinstance(linearization_cls, type) and issubclass(linearization_cls, HipLinearization)):
+            raise RuntimeError("HipCholeskySolver only works with theseus_amd.HipLinearization, "
+                               f"but {linearization_cls} was provided.")
+        super().__init__(objective, linearization_cls, linearization_kwargs)
+        self.linearization: HipLinearization = self.linearization
+        self.K = self.linearization.K
+        self.L = self.diagT = self.info = None
+        self._lam = None
+
+    def _ensure_buffers(self):
+        lin = self.linearization
+        H = lin.H
+        if self.L is None or self.L.shape != H.shape or self.L.device != H.device or self.L.dtype != H.dtype:
+            B = H.shape[0]
+            nt = (lin.n + _lib.THX_TILE - 1) // _lib.THX_TILE
+            self.L = torch.zeros_like(H)
+            self.diagT = torch.empty(B, nt, _lib.THX_TILE, _lib.THX_TILE, dtype=H.dtype, device=H.device)
+            self.info = torch.zeros(B, dtype=torch.int32, device=H.device)
+            self._lam = torch.empty(B, dtype=H.dtype, device=H.device)
+
+    def factorize(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
+                  damping_eps: float = 1e-8):
+        """L L^T = AtA (+ damping); keeps L for later solves (the implicit backward re-uses it)."""
+        lin = self.linearization
+        if lin.H is None:
+            raise RuntimeError("linearize() must be called before solve().")
+        self._ensure_buffers()
+        lam = None
+        if damping is not None:
+            lam = self._lam
+            if isinstance(damping, torch.Tensor):
+                lam.copy_(damping.to(lam.dtype).expand(lam.shape[0]) if damping.ndim else damping.to(lam.dtype).expand(lam.shape[0]))
+            else:
+                lam.fill_(float(damping))
+        self.K.chol_factor(lin.H, lin.n, lam, ellipsoidal_damping, damping_eps, self.L, self.diagT, self.info)
+
+    def solve_with_factor(self, rhs: torch.Tensor) -> torch.Tensor:
+        rhs = rhs.contiguous()
+        x = torch.empty_like(rhs)
+        self.K.chol_solve(self.L, self.linearization.n, self.diagT, rhs, x)
+        return x
+
+    def check_info(self):
+        bad = self.info.nonzero()
+        if bad.numel():
+            b = int(bad[0])
+            raise RuntimeError(
+                f"linalg.cholesky: (Batch element {b}): The factorization could not be completed because the "
+                f"input is not positive-definite (the leading minor of order {int(self.info[b])} is not "
+                "positive-definite).")
+
+    # theseus/optimizer/linear/dense_solver.py:84-123
+    def solve(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
+              damping_eps: float = 1e-8, check_info: bool = True, **kwargs) -> torch.Tensor:
+        if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
+            raise ValueError("Damping must be a float or a 1-D tensor.")
+        self.factorize(damping, ellipsoidal_damping, damping_eps)
+        delta = self.solve_with_factor(self.linearization.g)
+        if check_info:
+            self.check_info()
+        return delta

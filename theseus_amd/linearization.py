@@ -1,0 +1,195 @@
+"""`Linearization` plugin surface + the HIP implementation.
+
+ABC contract: theseus/optimizer/linearization.py:16-87.  ``HipLinearization`` replaces
+``DenseLinearization`` (theseus/optimizer/dense_linearization.py:15-77): same attributes
+(``ordering, var_dims, var_start_cols, num_cols, num_rows``), same ``linearize / AtA / Atb / Av /
+diagonal_scaling / hessian_approx`` -- but the dense ``A`` is never built: the fused HIP kernel
+writes the block-sparse lower triangle of H = A^T A straight into a persistent dense (B,ld,ld)
+buffer (zero-filled once; the pattern is fixed) and g = A^T b into (B,n).
+"""
+import abc
+from typing import List, Optional
+
+import torch
+
+from .core import Objective, Variable
+from .packed import packed_for
+
+
+class VariableOrdering:
+    """Default = insertion order of objective.optim_vars (theseus/optimizer/variable_ordering.py:14-60)."""
+
+    def __init__(self, objective: Objective, default_order: bool = True):
+        self.objective = objective
+        self._var_order: List[Variable] = []
+        self._var_name_to_index = {}
+        if default_order:
+            for v in objective.optim_vars.values():
+                self.append(v)
+
+    def append(self, var: Variable):
+        if var.name in self._var_name_to_index:
+            raise ValueError("Tried to add a variable that was already added.")
+        if var.name not in self.objective.optim_vars:
+            raise ValueError("Variable is not an optimization variable for the objective.")
+        self._var_order.append(var)
+        self._var_name_to_index[var.name] = len(self._var_order) - 1
+
+    def index_of(self, key: str) -> int:
+        return self._var_name_to_index[key]
+
+    def __getitem__(self, i) -> Variable:
+        return self._var_order[i]
+
+    def __iter__(self):
+        return iter(self._var_order)
+
+    def __len__(self):
+        return len(self._var_order)
+
+    def complete(self):
+        return len(self._var_order) == self.objective.size_variables()
+
+
+class Linearization(abc.ABC):
+    # theseus/optimizer/linearization.py:18-41
+    def __init__(self, objective: Objective, ordering: Optional[VariableOrdering] = None, **kwargs):
+        self.objective = objective
+        if ordering is None:
+            ordering = VariableOrdering(objective, default_order=True)
+        self.ordering = ordering
+        if not self.ordering.complete():
+            raise ValueError("Given variable ordering is not complete.")
+        self.var_dims: List[int] = []
+        self.var_start_cols: List[int] = []
+        col = 0
+        for var in ordering:
+            self.var_start_cols.append(col)
+            self.var_dims.append(var.dof())
+            col += var.dof()
+        self.num_cols = col
+        self.num_rows = self.objective.dim()
+
+    @abc.abstractmethod
+    def _linearize_jacobian_impl(self):
+        pass
+
+    @abc.abstractmethod
+    def _linearize_hessian_impl(self, _detach_hessian: bool = False):
+        pass
+
+    def linearize(self, _detach_hessian: bool = False):
+        if not self.ordering.complete():
+            raise RuntimeError("Attempted to linearize an objective with an incomplete variable order.")
+        self._linearize_hessian_impl(_detach_hessian=_detach_hessian)
+
+    def hessian_approx(self):
+        return self.AtA
+
+    @property
+    @abc.abstractmethod
+    def AtA(self) -> torch.Tensor:
+        pass
+
+    @property
+    @abc.abstractmethod
+    def Atb(self) -> torch.Tensor:
+        pass
+
+    @abc.abstractmethod
+    def Av(self, v: torch.Tensor) -> torch.Tensor:
+        pass
+
+    @abc.abstractmethod
+    def diagonal_scaling(self, v: torch.Tensor) -> torch.Tensor:
+        pass
+
+
+class HipLinearization(Linearization):
+    def __init__(self, objective: Objective, ordering: Optional[VariableOrdering] = None, kernels=None, **kwargs):
+        super().__init__(objective, ordering)
+        if [v.name for v in self.ordering] != list(objective.optim_vars.keys()):
+            raise NotImplementedError("HipLinearization uses the default (insertion) variable ordering.")
+        self.packed = packed_for(objective, kernels)
+        self.K = self.packed.K
+        self.H: Optional[torch.Tensor] = None   # (B, ld, ld): lower triangle of A^T A (undamped)
+        self.g: Optional[torch.Tensor] = None   # (B, n): A^T b
+        self._AtA_cache = None
+        self._A = self._b = None
+
+    # structure exactly as the reference lays it out
+    @property
+    def n(self):
+        return self.packed.n
+
+    @property
+    def ld(self):
+        return self.packed.ld
+
+    def _ensure_buffers(self):
+        self.packed.sync()
+        B = self.packed.batch
+        dev, dt = self.packed.tensors.poses.device, self.objective.dtype
+        if self.H is None or self.H.shape[0] != B or self.H.device != dev or self.H.dtype != dt:
+            self.H = torch.zeros(B, self.ld, self.ld, dtype=dt, device=dev)  # zero once: fixed pattern
+            self.g = torch.empty(B, self.n, dtype=dt, device=dev)
+
+    def _linearize_jacobian_impl(self):
+        """Materialise dense A (B,m,n) and b (B,m) -- for tests / foreign consumers only
+        (dense_linearization.py:29-56); the optimiser never calls this."""
+        p = self.packed
+        J0, J1, eb, Jp, ep = p.jacobian_blocks()
+        B, s = p.batch, p.structure
+        A = torch.zeros(B, p.m, p.n, dtype=J0.dtype, device=J0.device)
+        b = torch.zeros(B, p.m, dtype=J0.dtype, device=J0.device)
+        for e in range(s.num_edges):
+            r, i, j = int(s.edge_row_start[e]), int(s.edge_i[e]), int(s.edge_j[e])
+            A[:, r:r + 6, 6 * i:6 * i + 6] = J0[e]
+            A[:, r:r + 6, 6 * j:6 * j + 6] = J1[e]
+            b[:, r:r + 6] = -eb[e]
+        for k in range(s.num_priors):
+            r, i = int(s.prior_row_start[k]), int(s.prior_pose[k])
+            A[:, r:r + 6, 6 * i:6 * i + 6] = Jp[k]
+            b[:, r:r + 6] = -ep[k]
+        self._A, self._b = A, b
+
+    def _linearize_hessian_impl(self, _detach_hessian: bool = False):
+        self._ensure_buffers()
+        self.packed.assemble(self.H, self.g)
+        self._AtA_cache = None
+        self._A = self._b = None
+
+    @property
+    def A(self):
+        if self._A is None:
+            self._linearize_jacobian_impl()
+        return self._A
+
+    @property
+    def b(self):
+        if self._b is None:
+            self._linearize_jacobian_impl()
+        return self._b
+
+    @property
+    def AtA(self) -> torch.Tensor:
+        """Full symmetric (B,n,n); materialised only when read (LM needs just Atb / diagonal_scaling)."""
+        if self._AtA_cache is None:
+            Hl = torch.tril(self.H[:, :self.n, :self.n])
+            self._AtA_cache = Hl + torch.tril(Hl, -1).transpose(1, 2)
+        return self._AtA_cache
+
+    @property
+    def Atb(self) -> torch.Tensor:
+        return self.g.unsqueeze(2)
+
+    def Av(self, v: torch.Tensor) -> torch.Tensor:
+        return self.A.bmm(v.unsqueeze(2)).squeeze(2)
+
+    def diagonal(self) -> torch.Tensor:
+        d = torch.empty(self.H.shape[0], self.n, dtype=self.H.dtype, device=self.H.device)
+        self.K.diag(self.H, self.n, d)
+        return d
+
+    def diagonal_scaling(self, v: torch.Tensor) -> torch.Tensor:
+        return self.diagonal() * v

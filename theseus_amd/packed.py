@@ -1,0 +1,193 @@
+"""Packed device representation of an SE3 pose-graph objective.
+
+This is the analogue of the reference's ``Vectorize`` pass (theseus/core/vectorizer.py:112-474): it
+groups the objective's cost functions by schema (Between / Difference on SE3), but instead of
+stacking tensors for batched ATen calls it keeps ONE entity-major buffer per role
+(poses (P,B,3,4), measurements (E,Bm,3,4), weights (E,Bw,6), prior targets, prior weights) that
+the fused HIP kernels index directly.  Variables are tracked by ``_num_updates`` so that the
+buffers are re-packed only when somebody changed a variable behind our back.
+"""
+from typing import List, Optional
+
+import torch
+
+from .compiler import PoseGraphStructure
+from .core import SE3, Between, Difference, Objective
+from .kernels import PGTensors, default_kernels, round_up, _lib
+
+ERR_CHUNKS = _lib.THX_ERR_CHUNKS
+
+
+class UnsupportedObjective(NotImplementedError):
+    pass
+
+
+class PackedPoseGraph:
+    def __init__(self, objective: Objective, kernels=None):
+        self.objective = objective
+        self.K = kernels or default_kernels()
+        self.pose_vars: List[SE3] = []
+        for v in objective.optim_vars.values():
+            if not isinstance(v, SE3):
+                raise UnsupportedObjective(
+                    f"HIP backend supports SE3 optimisation variables; got {type(v).__name__} ({v.name}). "
+                    "There is no CPU/eager fallback.")
+            self.pose_vars.append(v)
+        index = {v.name: k for k, v in enumerate(self.pose_vars)}
+        edges, priors, e_rows, p_rows = [], [], [], []
+        self.edge_costs: List[Between] = []
+        self.prior_costs: List[Difference] = []
+        row = 0
+        for c in objective.cost_functions.values():
+            if isinstance(c, Between):
+                edges.append((index[c.v0.name], index[c.v1.name]))
+                e_rows.append(row)
+                self.edge_costs.append(c)
+            elif isinstance(c, Difference):
+                priors.append(index[c.var.name])
+                p_rows.append(row)
+                self.prior_costs.append(c)
+            else:
+                raise UnsupportedObjective(
+                    f"HIP backend has no fused kernel for cost function {type(c).__name__} ({c.name}); "
+                    "supported: Between, Difference/Local on SE3.  There is no CPU/eager fallback.")
+            row += c.dim()
+        self.structure = PoseGraphStructure.build(len(self.pose_vars), edges, priors, e_rows, p_rows)
+        self.n = self.structure.num_cols
+        self.m = self.structure.num_rows
+        self.ld = round_up(self.n, 32)
+        self.version = objective.current_version
+        self.tensors: Optional[PGTensors] = None
+        self._stamp = None
+        self._scratch = {}
+
+    # ---- packing ----------------------------------------------------------------------------
+    def _tracked(self):
+        for v in self.pose_vars:
+            yield v
+        for c in self.edge_costs:
+            yield c.measurement
+            yield from c.weight.aux_vars()
+        for c in self.prior_costs:
+            yield c.target
+            yield from c.weight.aux_vars()
+
+    def _current_stamp(self):
+        return tuple(v._num_updates for v in self._tracked())
+
+    @staticmethod
+    def _stack(ts, B):
+        """list of (b_k, ...) with b_k in {1,B} -> (len, 1|B, ...) contiguous."""
+        if not ts:
+            return None
+        if all(t.shape[0] == ts[0].shape[0] for t in ts):
+            return torch.stack(ts, dim=0).contiguous()
+        return torch.stack([t.expand(B, *t.shape[1:]) for t in ts], dim=0).contiguous()
+
+    def sync(self, force: bool = False):
+        """(Re)pack the variable tensors into the device buffers if any variable changed."""
+        stamp = self._current_stamp()
+        if not force and self.tensors is not None and stamp == self._stamp:
+            return
+        obj = self.objective
+        obj._resolve_batch_size()
+        B = obj.batch_size
+        dev, dt = self.pose_vars[0].device, obj.dtype
+        poses = self._stack([v.tensor.expand(B, 3, 4) if v.shape[0] != B else v.tensor for v in self.pose_vars], B)
+        E, Kp = self.structure.num_edges, self.structure.num_priors
+        empty = lambda *s: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+        meas = self._stack([c.measurement.tensor for c in self.edge_costs], B) if E else empty(0, 1, 3, 4)
+        wb = self._stack([c.weight.diagonal6() for c in self.edge_costs], B) if E else empty(0, 1, 6)
+        tgt = self._stack([c.target.tensor for c in self.prior_costs], B) if Kp else empty(0, 1, 3, 4)
+        wp = self._stack([c.weight.diagonal6() for c in self.prior_costs], B) if Kp else empty(0, 1, 6)
+        self.tensors = PGTensors(poses=poses, meas=meas, w_between=wb, prior_target=tgt, w_prior=wp)
+        self._repoint_variables()
+
+    def _repoint_variables(self):
+        """Make every optimisation variable's tensor a view of the packed pose buffer."""
+        poses = self.tensors.poses
+        for k, v in enumerate(self.pose_vars):
+            v.tensor = poses[k]
+        self._stamp = self._current_stamp()
+
+    def set_poses(self, poses: torch.Tensor):
+        """Adopt a new packed pose buffer (after an accepted LM step)."""
+        self.tensors.poses = poses
+        self._repoint_variables()
+
+    # ---- scratch ------------------------------------------------------------------------------
+    def _buf(self, key, shape, dtype=None):
+        t = self._scratch.get(key)
+        dt = dtype or self.objective.dtype
+        dev = self.tensors.poses.device
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dt or t.device != dev:
+            t = torch.empty(*shape, dtype=dt, device=dev)
+            self._scratch[key] = t
+        return t
+
+    @property
+    def batch(self):
+        return self.tensors.batch
+
+    @property
+    def dstruct(self):
+        return self.structure.on(self.tensors.poses.device)
+
+    # ---- fused operations ---------------------------------------------------------------------
+    def assemble(self, H: torch.Tensor, g: torch.Tensor):
+        self.sync()
+        self.K.pg_assemble(self.dstruct, self.tensors, H, g)
+
+    def error_metric(self, poses: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+        self.sync()
+        B = self.batch
+        part = self._buf("err_part", (ERR_CHUNKS, B))
+        err = out if out is not None else torch.empty(B, dtype=self.objective.dtype, device=part.device)
+        self.K.pg_error(self.dstruct, self.tensors, part, err, poses=poses)
+        return err
+
+    def retract(self, delta: torch.Tensor, step: float, ignore_mask: Optional[torch.Tensor], out: torch.Tensor):
+        self.sync()
+        m = None
+        if ignore_mask is not None:
+            m = ignore_mask if ignore_mask.dtype == torch.uint8 else ignore_mask.to(torch.uint8)
+        self.K.se3_retract(self.tensors.poses, delta, step, m, out)
+        return out
+
+    def jacobian_blocks(self):
+        """Weighted Jacobian blocks / residuals of every cost: (J0,J1 (E,B,6,6), eb (E,B,6), Jp, ep)."""
+        self.sync()
+        B, E, Kp = self.batch, self.structure.num_edges, self.structure.num_priors
+        dt, dev = self.objective.dtype, self.tensors.poses.device
+        J0 = torch.empty(max(E, 1), B, 6, 6, dtype=dt, device=dev)
+        J1 = torch.empty_like(J0)
+        eb = torch.empty(max(E, 1), B, 6, dtype=dt, device=dev)
+        Jp = torch.empty(max(Kp, 1), B, 6, 6, dtype=dt, device=dev)
+        ep = torch.empty(max(Kp, 1), B, 6, dtype=dt, device=dev)
+        self.K.pg_jacobians(self.dstruct, self.tensors, J0, J1, eb, Jp, ep)
+        return J0[:E], J1[:E], eb[:E], Jp[:Kp], ep[:Kp]
+
+    def error_vector(self):
+        """(B, m) weighted error in cost add order (Objective.error, core/objective.py:562-613)."""
+        _, _, eb, _, ep = self.jacobian_blocks()
+        B = self.batch
+        out = torch.empty(B, self.m, dtype=eb.dtype, device=eb.device)
+        s = self.structure
+        if s.num_edges:
+            rows = torch.from_numpy(s.edge_row_start).to(eb.device)
+            idx = (rows.view(-1, 1) + torch.arange(6, device=eb.device)).view(-1)
+            out[:, idx] = eb.permute(1, 0, 2).reshape(B, -1)
+        if s.num_priors:
+            rows = torch.from_numpy(s.prior_row_start).to(eb.device)
+            idx = (rows.view(-1, 1) + torch.arange(6, device=eb.device)).view(-1)
+            out[:, idx] = ep.permute(1, 0, 2).reshape(B, -1)
+        return out
+
+
+def packed_for(objective: Objective, kernels=None) -> PackedPoseGraph:
+    """Get (or build) the packed representation attached to an objective."""
+    p = objective._packed
+    if p is None or p.version != objective.current_version or (kernels is not None and p.K is not kernels):
+        p = PackedPoseGraph(objective, kernels)
+        objective._packed = p
+    return p
