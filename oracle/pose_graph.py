@@ -165,6 +165,9 @@ class LMInfo:
     AtA: List[torch.Tensor] = field(default_factory=list)
     Atb: List[torch.Tensor] = field(default_factory=list)
     dampings: List[torch.Tensor] = field(default_factory=list)
+    rho: List[torch.Tensor] = field(default_factory=list)            # adaptive LM: gain ratio per step
+    actual_reduction: List[torch.Tensor] = field(default_factory=list)
+    prev_err: List[torch.Tensor] = field(default_factory=list)
     iters_done: int = 0
     converged_iter: Optional[torch.Tensor] = None
     last_err: Optional[torch.Tensor] = None
@@ -220,6 +223,10 @@ def lm_optimize(p: PGProblem, poses, max_iterations=20, step_size=1.0, damping=1
             den = (d * (dmp * d + Atb.squeeze(2))).sum(dim=1) / 2
             rho = (last_err - err) / den
             reject = rho <= damping_accept
+            if keep_taps:
+                info.rho.append(rho.clone())
+                info.actual_reduction.append((last_err - err).clone())
+                info.prev_err.append(last_err.clone())
             lam = torch.where(reject, lam * up_damping_ratio, lam / down_damping_ratio)
             lam = lam.clamp(MIN_DAMPING, MAX_DAMPING)
         if reject is not None and bool(reject.all()):

@@ -24,3 +24,26 @@ def golden_problem(g):
     )
     kw = ast.literal_eval(str(g["opt_kwargs"]))
     return p, t(g["poses0"]), kw
+
+
+def f32_truth_problem(p, poses0):
+    """The fp32 problem widened to fp64 (same values): evaluating the oracle on it, with the fp32
+    Taylor thresholds, gives the exact value of what the reference's fp32 path approximates."""
+    import dataclasses
+    p64 = dataclasses.replace(p, meas=p.meas.double(), w_between=p.w_between.double(),
+                              prior_target=p.prior_target.double(), w_prior=p.w_prior.double())
+    return p64, poses0.double()
+
+
+class f32_thresholds:
+    """Context manager: make the fp64 oracle switch Taylor branches where the fp32 reference does
+    (torchlie/torchlie/global_params.py:44-58 keys the thresholds by dtype)."""
+
+    def __enter__(self):
+        from oracle import lie
+        self._saved = dict(lie.EPS[torch.float64])
+        lie.EPS[torch.float64] = {k: float(np.float32(v)) for k, v in lie.EPS[torch.float32].items()}
+
+    def __exit__(self, *a):
+        from oracle import lie
+        lie.EPS[torch.float64] = self._saved

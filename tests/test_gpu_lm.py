@@ -29,8 +29,39 @@ def build_objective(th, g, device="cuda"):
     return obj, poses
 
 
-CASES = [("pg_f64_lm", 2e-8), ("pg_f64_gn", 2e-8), ("pg_f64_lm_adaptive", 2e-8),
-         ("pg_f64_lm_adaptive_ellips", 2e-8), ("pg_f64_lm_adaptive_rejects", 2e-8), ("pg_f32_lm", 5e-3)]
+# fp64 tolerance: the golden problems are gauge-weak (priors 1e-1 / 3 against edge information ~2.5e3 and LM
+# damping down to 1e-7 when adaptive), cond(H + lambda I) ~ 1e9..1e10, so two correct fp64 Cholesky solves
+# differ by ~cond * 1e-16 * |delta| ~ 1e-8 on the weakly constrained components; 1e-7 absolute on poses.
+CASES = [("pg_f64_lm", 1e-7), ("pg_f64_gn", 1e-7), ("pg_f64_lm_adaptive", 1e-7),
+         ("pg_f64_lm_adaptive_ellips", 1e-7), ("pg_f64_lm_adaptive_rejects", 1e-7)]
+
+
+def well_conditioned_steps(g, n_iters):
+    """(n_iters, B) bool: step `it` of problem b is comparable between two correct implementations.
+
+    Adaptive LM accepts a step iff rho = actual / predicted reduction > damping_accept
+    (levenberg_marquardt.py:173-201).  Once a problem has converged the actual reduction (a difference of
+    two costs) drops below the rounding of the cost itself, rho is noise (|rho| up to 1e11 in this
+    fixture) and accept/reject -- hence lambda and every later delta -- is a coin flip in the reference
+    too.  The oracle (pinned to the reference) supplies rho / reductions; a step is comparable while
+    every EARLIER decision of that problem was resolvable: |actual| > 1e-9 * cost and rho at least
+    1e-6 away from the threshold."""
+    from oracle import pose_graph as opg
+    p, poses0, kw = golden_problem(g)
+    B = poses0.shape[0]
+    ok = np.ones((n_iters, B), bool)
+    if not kw.get("adaptive_damping", False):
+        return ok
+    accept = kw.get("damping_accept", 0.1)
+    _, oi = opg.lm_optimize(p, poses0, abs_err_tolerance=0.0, rel_err_tolerance=0.0, keep_taps=True, **kw)
+    if len(oi.rho) != n_iters:  # all-reject retries: indices do not line up, compare nothing per step
+        return np.zeros((n_iters, B), bool)
+    alive = np.ones(B, bool)
+    for it in range(n_iters):
+        ok[it] = alive
+        act, prev, rho = (x[it].numpy() for x in (oi.actual_reduction, oi.prev_err, oi.rho))
+        alive = alive & (np.abs(act) > 1e-9 * np.abs(prev)) & (np.abs(rho - accept) > 1e-6)
+    return ok
 
 
 @pytest.mark.parametrize("name,tol", CASES)
@@ -55,13 +86,51 @@ def test_lm_trajectory_matches_reference(name, tol):
     final = torch.stack([sol[f"pose_{k}"] for k in range(int(g["P"]))], 1).cpu().numpy()
     np.testing.assert_allclose(final, g["final"], rtol=0, atol=tol)
     if len(deltas) == g["delta"].shape[0]:
+        ok = well_conditioned_steps(g, len(deltas))
         for it, d in enumerate(deltas):
-            np.testing.assert_allclose(d.cpu().numpy(), g["delta"][it], rtol=0,
+            np.testing.assert_allclose(d.cpu().numpy()[ok[it]], g["delta"][it][ok[it]], rtol=0,
                                        atol=tol * max(1.0, np.abs(g["delta"][it]).max()))
     k = min(info.err_history.shape[1], g["err_history"].shape[1])
-    np.testing.assert_allclose(info.err_history[:, :k].numpy(), g["err_history"][:, :k],
-                               rtol=2e-5 if tol < 1e-6 else 3e-3)
+    np.testing.assert_allclose(info.err_history[:, :k].numpy(), g["err_history"][:, :k], rtol=2e-5)
     assert all(s == th.NonlinearOptimizerStatus.MAX_ITERATIONS for s in info.status)
+
+
+@pytest.mark.parametrize("name", ["pg_f32_lm", "pg_f32_lm_b16"])
+def test_lm_trajectory_fp32_inside_reference_band(name):
+    """fp32 parity.  The reference's fp32 path is a noisy evaluation (catastrophic cancellation in the
+    torchlie log coefficients, fp32 potrf): its trajectory sits at a distance dev_ref from the exact
+    trajectory of the same fp32 problem (fp64 oracle, fp32 thresholds).  Bit-level agreement between
+    two fp32 implementations is not defined (the reference's CPU and CUDA back ends differ by the same
+    amount), so the criterion is: the HIP trajectory is at most as far from exact as the reference's
+    (factor 1.5 on the max norm for the tail of 16 problems) -- i.e. inside the reference's band."""
+    import theseus_amd as th
+    from oracle import pose_graph as opg
+    from tests.helpers import f32_thresholds, f32_truth_problem
+    g = load_golden(name)
+    p, poses0, kw = golden_problem(g)
+    p64, poses64 = f32_truth_problem(p, poses0)
+    with f32_thresholds():
+        exact, xinfo = opg.lm_optimize(p64, poses64, abs_err_tolerance=0.0, rel_err_tolerance=0.0, keep_taps=True, **kw)
+    obj, _ = build_objective(th, g)
+    kw.pop("gauss_newton")
+    opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.HipCholeskySolver, max_iterations=kw.pop("max_iterations"),
+                                step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    deltas = []
+    sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(
+        track_err_history=True, end_iter_callback=lambda o, i, d, it: deltas.append(d.clone()), **kw))
+    final = torch.stack([sol[f"pose_{k}"] for k in range(int(g["P"]))], 1).cpu().double()
+    dev = (final - exact).abs().max().item()
+    dev_ref = (torch.from_numpy(g["final"]).double() - exact).abs().max().item()
+    assert dev <= 1.5 * dev_ref, (dev, dev_ref)
+    assert dev <= 2e-4  # and small in absolute terms (poses are O(1))
+    for it, d in enumerate(deltas):
+        dd = (d.cpu().double() - xinfo.deltas[it]).abs().max().item()
+        dr = (torch.from_numpy(g["delta"][it]).double() - xinfo.deltas[it]).abs().max().item()
+        assert dd <= 1.5 * dr + 1e-6, (it, dd, dr)
+    hx = torch.stack(xinfo.err_history, 1)
+    rel = ((info.err_history.double() - hx).abs() / hx).max().item()
+    rel_ref = ((torch.from_numpy(g["err_history"]).double() - hx).abs() / hx).max().item()
+    assert rel <= 1.5 * rel_ref + 1e-6, (rel, rel_ref)
 
 
 def test_first_linearization_properties_match_reference():

@@ -69,11 +69,12 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
   SE3<T> Xp;
   se3_load_vec(poses + ((int64_t)p * B + b) * 12, Xp);
 
-  T Dg[36], Off[36], gv[6];
+  T Dg[36], Off[36];
+  double gv[6];  // g = -J^T e accumulated in fp64 (lie.cuh, "Evaluation precision")
 #pragma unroll
   for (int i = 0; i < 36; ++i) { Dg[i] = T(0); Off[i] = T(0); }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) gv[i] = T(0);
+  for (int i = 0; i < 6; ++i) gv[i] = 0.0;
 
   T* Hb = H + (int64_t)b * ld * ld;
   const int beg = s.inc_ptr[p], end = s.inc_ptr[p + 1];
@@ -84,9 +85,10 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
     se3_load_vec(poses + ((int64_t)q * B + b) * 12, Xq);
     const int64_t mB = d.meas_bstride ? B : 1, wB = d.w_between_bstride ? B : 1;
     se3_load_vec(meas + ((int64_t)e * mB) * 12 + (int64_t)b * d.meas_bstride, M);
-    T w[6], ev[6];
+    T w[6];
+    double ev[6];
     load6(wb + ((int64_t)e * wB) * 6 + (int64_t)b * d.w_between_bstride, w);
-    SJac<T> J0, J1;
+    SJac<double> J0d, J1d;
     const bool lower = q < p;
     if (lower && q != cur_q) {
       if (cur_q >= 0) {
@@ -100,15 +102,17 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
       cur_q = q;
     }
     if (side == 0) {  // p is v0: own Jacobian J0, other J1
-      between_eval(Xp, Xq, M, w, eps, ev, &J0, &J1, true);
+      between_eval_hp(Xp, Xq, M, w, eps, ev, &J0d, &J1d, true);
+      const SJac<T> J0 = narrow<T>(J0d);
       sjac_tmul_acc(J0, J0, Dg);
-      sjac_tvec_sub(J0, ev, gv);
-      if (lower) sjac_tmul_acc(J0, J1, Off);
+      sjac_tvec_sub(J0d, ev, gv);
+      if (lower) sjac_tmul_acc(J0, narrow<T>(J1d), Off);
     } else {  // p is v1
-      between_eval(Xq, Xp, M, w, eps, ev, &J0, &J1, true);
+      between_eval_hp(Xq, Xp, M, w, eps, ev, &J0d, &J1d, true);
+      const SJac<T> J1 = narrow<T>(J1d);
       sjac_tmul_acc(J1, J1, Dg);
-      sjac_tvec_sub(J1, ev, gv);
-      if (lower) sjac_tmul_acc(J1, J0, Off);
+      sjac_tvec_sub(J1d, ev, gv);
+      if (lower) sjac_tmul_acc(J1, narrow<T>(J0d), Off);
     }
   }
   if (cur_q >= 0) {
@@ -125,12 +129,14 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
     const int64_t tB = d.prior_target_bstride ? B : 1, wB = d.w_prior_bstride ? B : 1;
     SE3<T> Tg;
     se3_load_vec(tgt + ((int64_t)id * tB) * 12 + (int64_t)b * d.prior_target_bstride, Tg);
-    T w[6], ev[6];
+    T w[6];
+    double ev[6];
     load6(wp + ((int64_t)id * wB) * 6 + (int64_t)b * d.w_prior_bstride, w);
-    SJac<T> J;
-    local_eval(Tg, Xp, w, eps, ev, &J, true);
+    SJac<double> Jd;
+    local_eval_hp(Tg, Xp, w, eps, ev, &Jd, true);
+    const SJac<T> J = narrow<T>(Jd);
     sjac_tmul_acc(J, J, Dg);
-    sjac_tvec_sub(J, ev, gv);
+    sjac_tvec_sub(Jd, ev, gv);
   }
 #pragma unroll
   for (int r = 0; r < 6; ++r)
@@ -138,7 +144,7 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
     for (int c = 0; c < 6; ++c) Hb[(int64_t)(6 * p + r) * ld + 6 * p + c] = Dg[6 * r + c];
   T* gb = g + (int64_t)b * (6 * s.num_poses) + 6 * p;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) gb[i] = gv[i];
+  for (int i = 0; i < 6; ++i) gb[i] = (T)gv[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -154,7 +160,7 @@ pg_error_partial_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ parti
   const T* poses = static_cast<const T*>(d.poses);
   const T* meas = static_cast<const T*>(d.meas);
   const T* wb = static_cast<const T*>(d.w_between);
-  T acc = T(0);
+  double acc = 0.0;
   const int E = s.num_edges, K = s.num_priors;
   const int ec = (E + THX_ERR_CHUNKS - 1) / THX_ERR_CHUNKS;
   const int e1 = min(E, (ch + 1) * ec);
@@ -165,9 +171,10 @@ pg_error_partial_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ parti
     se3_load_vec(poses + ((int64_t)i * B + b) * 12, Xi);
     se3_load_vec(poses + ((int64_t)j * B + b) * 12, Xj);
     se3_load_vec(meas + ((int64_t)e * mB) * 12 + (int64_t)b * d.meas_bstride, M);
-    T w[6], ev[6];
+    T w[6];
+    double ev[6];
     load6(wb + ((int64_t)e * wB) * 6 + (int64_t)b * d.w_between_bstride, w);
-    between_eval<T>(Xi, Xj, M, w, eps, ev, nullptr, nullptr, false);
+    between_eval_hp<T>(Xi, Xj, M, w, eps, ev, nullptr, nullptr, false);
 #pragma unroll
     for (int r = 0; r < 6; ++r) acc += ev[r] * ev[r];
   }
@@ -181,13 +188,14 @@ pg_error_partial_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ parti
     SE3<T> X, Tg;
     se3_load_vec(poses + ((int64_t)p * B + b) * 12, X);
     se3_load_vec(tgt + ((int64_t)k * tB) * 12 + (int64_t)b * d.prior_target_bstride, Tg);
-    T w[6], ev[6];
+    T w[6];
+    double ev[6];
     load6(wp + ((int64_t)k * wpB) * 6 + (int64_t)b * d.w_prior_bstride, w);
-    local_eval<T>(Tg, X, w, eps, ev, nullptr, false);
+    local_eval_hp<T>(Tg, X, w, eps, ev, nullptr, false);
 #pragma unroll
     for (int r = 0; r < 6; ++r) acc += ev[r] * ev[r];
   }
-  partials[(int64_t)ch * B + b] = acc;
+  partials[(int64_t)ch * B + b] = (T)acc;
 }
 
 template <typename T>
@@ -212,7 +220,8 @@ pg_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* _
   const int B = d.batch;
   if (b >= B) return;
   const T* poses = static_cast<const T*>(d.poses);
-  T ev[6], M36[36];
+  double ev[6];
+  T M36[36];
   if (c < s.num_edges) {
     const int e = c, i = s.edge_i[e], j = s.edge_j[e];
     const int64_t mB = d.meas_bstride ? B : 1, wB = d.w_between_bstride ? B : 1;
@@ -222,8 +231,9 @@ pg_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* _
     se3_load_vec(static_cast<const T*>(d.meas) + ((int64_t)e * mB) * 12 + (int64_t)b * d.meas_bstride, M);
     T w[6];
     load6(static_cast<const T*>(d.w_between) + ((int64_t)e * wB) * 6 + (int64_t)b * d.w_between_bstride, w);
-    SJac<T> J0, J1;
-    between_eval(Xi, Xj, M, w, eps, ev, &J0, &J1, true);
+    SJac<double> J0d, J1d;
+    between_eval_hp(Xi, Xj, M, w, eps, ev, &J0d, &J1d, true);
+    const SJac<T> J0 = narrow<T>(J0d), J1 = narrow<T>(J1d);
     const int64_t o = (int64_t)e * B + b;
     if (J0o) {
       sjac_dense(J0, M36);
@@ -237,7 +247,7 @@ pg_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* _
     }
     if (ebo) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) ebo[o * 6 + k] = ev[k];
+      for (int k = 0; k < 6; ++k) ebo[o * 6 + k] = (T)ev[k];
     }
   } else {
     const int k = c - s.num_edges, p = s.prior_pose[k];
@@ -247,8 +257,9 @@ pg_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* _
     se3_load_vec(static_cast<const T*>(d.prior_target) + ((int64_t)k * tB) * 12 + (int64_t)b * d.prior_target_bstride, Tg);
     T w[6];
     load6(static_cast<const T*>(d.w_prior) + ((int64_t)k * wB) * 6 + (int64_t)b * d.w_prior_bstride, w);
-    SJac<T> J;
-    local_eval(Tg, X, w, eps, ev, &J, true);
+    SJac<double> Jd;
+    local_eval_hp(Tg, X, w, eps, ev, &Jd, true);
+    const SJac<T> J = narrow<T>(Jd);
     const int64_t o = (int64_t)k * B + b;
     if (Jpo) {
       sjac_dense(J, M36);
@@ -257,7 +268,7 @@ pg_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* _
     }
     if (epo) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) epo[o * 6 + q] = ev[q];
+      for (int q = 0; q < 6; ++q) epo[o * 6 + q] = (T)ev[q];
     }
   }
 }
@@ -272,19 +283,22 @@ se3_retract_kernel(const T* __restrict__ poses, const T* __restrict__ delta, int
   const int b = blockIdx.x * 64 + threadIdx.x;
   const int p = blockIdx.y;
   if (b >= B) return;
-  SE3<T> X, Ex, Y;
+  SE3<T> X, Y;
   se3_load_vec(poses + ((int64_t)p * B + b) * 12, X);
   if (ignore && ignore[b]) {
     se3_store_vec(out + ((int64_t)p * B + b) * 12, X);
     return;
   }
-  T xi[6];
+  // the scaled step delta * step_size is formed in T like the reference (nonlinear_least_squares.py:167-175)
+  double xi[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) xi[i] = delta[(int64_t)b * ldd + 6 * p + i] * step;
-  ExpCoef<T> c;
-  T Ct;
-  se3_exp(xi, eps, Ex, c, Ct);
-  se3_mul(X, Ex, Y);
+  for (int i = 0; i < 6; ++i) xi[i] = (double)(delta[(int64_t)b * ldd + 6 * p + i] * step);
+  ExpCoef<double> c;
+  double Ct;
+  SE3<double> Exd, Yd;
+  se3_exp(xi, widen(eps), Exd, c, Ct);
+  se3_mul(widen(X), Exd, Yd);
+  Y = narrow<T>(Yd);
   se3_store_vec(out + ((int64_t)p * B + b) * 12, Y);
 }
 
@@ -296,18 +310,21 @@ __global__ void se3_exp_kernel(const T* __restrict__ xi, T* __restrict__ X, T* _
                                Eps<T> eps) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  T v[6];
-  load6(xi + i * 6, v);
-  SE3<T> E;
-  ExpCoef<T> c;
-  T Ct;
-  se3_exp(v, eps, E, c, Ct);
-  se3_store_vec(X + i * 12, E);
+  T vt[6];
+  load6(xi + i * 6, vt);
+  double v[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[k] = (double)vt[k];
+  SE3<double> E;
+  ExpCoef<double> c;
+  double Ct;
+  se3_exp(v, widen(eps), E, c, Ct);
+  se3_store_vec(X + i * 12, narrow<T>(E));
   if (jac) {
-    T J[36];
+    double J[36];
     se3_jexp(v, E, c, Ct, J);
 #pragma unroll
-    for (int k = 0; k < 36; ++k) jac[i * 36 + k] = J[k];
+    for (int k = 0; k < 36; ++k) jac[i * 36 + k] = (T)J[k];
   }
 }
 
@@ -318,19 +335,19 @@ __global__ void se3_log_kernel(const T* __restrict__ X, T* __restrict__ xi, T* _
   if (i >= N) return;
   SE3<T> G;
   se3_load_vec(X + i * 12, G);
-  T v[6], Jr[9], Jt[9];
-  se3_log_jlog(G, eps, v, Jr, Jt, jac != nullptr);
+  double v[6], Jr[9], Jt[9];
+  se3_log_jlog(widen(G), widen(eps), v, Jr, Jt, jac != nullptr);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) xi[i * 6 + k] = v[k];
+  for (int k = 0; k < 6; ++k) xi[i * 6 + k] = (T)v[k];
   if (jac) {
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        jac[i * 36 + 6 * r + c] = Jr[3 * r + c];
-        jac[i * 36 + 6 * r + 3 + c] = Jt[3 * r + c];
+        jac[i * 36 + 6 * r + c] = (T)Jr[3 * r + c];
+        jac[i * 36 + 6 * r + 3 + c] = (T)Jt[3 * r + c];
         jac[i * 36 + 6 * (r + 3) + c] = T(0);
-        jac[i * 36 + 6 * (r + 3) + 3 + c] = Jr[3 * r + c];
+        jac[i * 36 + 6 * (r + 3) + 3 + c] = (T)Jr[3 * r + c];
       }
   }
 }
