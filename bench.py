@@ -31,7 +31,7 @@ class KernelTimer:
     """HIP-event timing of every C-ABI call, on the stream the kernels are launched on
     (torch's current stream: torch.cuda.Event records there)."""
 
-    NAMES = ["pg_assemble", "chol_factor", "chol_solve", "se3_retract", "pg_error", "lm_accept"]
+    NAMES = ["pg_assemble", "chol_factor", "chol_solve_backward", "chol_solve", "se3_retract", "pg_error", "lm_accept"]
 
     def __init__(self, K):
         self.K, self.events, self.enabled = K, {n: [] for n in self.NAMES}, False
@@ -59,12 +59,10 @@ class KernelTimer:
         return out
 
 
-def cpu_baseline(tensors, edges, P, dtype, sample, iters):
-    """Oracle (CPU restatement of the reference's dense algorithm, torch-CPU/MKL) on a bounded sample
-    of the same workload.  Returns (problem-iters/s, cores, final poses of the sample, seconds)."""
+def oracle_problem(tensors, edges, P, dtype, sample):
     from oracle import pose_graph as opg
     from theseus_amd.utils import synthetic as syn
-    cpu = lambda t: t[:sample].detach().cpu()  # noqa: E731
+    cpu = lambda t: t[:sample].detach().cpu().to(dtype)  # noqa: E731
     poses0 = torch.stack([cpu(tensors[f"VERTEX_SE3__{k}"]) for k in range(P)], 1)
     meas = torch.stack([cpu(tensors[f"EDGE_SE3__{i}_{j}"]) for (i, j) in edges], 1)
     E = len(edges)
@@ -72,12 +70,39 @@ def cpu_baseline(tensors, edges, P, dtype, sample, iters):
     prob = opg.PGProblem(num_poses=P, edges=torch.tensor(edges), meas=meas, w_between=w.view(1, 1, 6).expand(1, E, 6),
                          prior_idx=torch.tensor([0]), prior_target=cpu(tensors["VERTEX_SE3__0__PRIOR"]).unsqueeze(1),
                          w_prior=torch.full((1, 1, 6), syn.PRIOR_WEIGHT, dtype=dtype))
+    return prob, poses0
+
+
+def cpu_baseline(tensors, edges, P, dtype, sample, iters, damping):
+    """Oracle (CPU restatement of the reference's dense algorithm, torch-CPU/MKL) on a bounded sample
+    of the same workload.  Returns (problem-iters/s, cores, final poses of the sample, seconds, cost history)."""
+    from oracle import pose_graph as opg
+    prob, poses0 = oracle_problem(tensors, edges, P, dtype, sample)
     with torch.no_grad():
         t0 = time.perf_counter()
-        final, info = opg.lm_optimize(prob, poses0, max_iterations=iters, damping=1e-3, abs_err_tolerance=0.0,
+        final, info = opg.lm_optimize(prob, poses0, max_iterations=iters, damping=damping, abs_err_tolerance=0.0,
                                       rel_err_tolerance=0.0)
         dt = time.perf_counter() - t0
     return sample * iters / dt, torch.get_num_threads(), final, dt, torch.stack(info.err_history, 1)
+
+
+def exact_reference(tensors, edges, P, dtype, sample, iters, damping):
+    """The same problem evaluated exactly: fp64 oracle on the (fp32- or fp64-valued) inputs with the
+    run dtype's Taylor thresholds -- what both the reference's fp path and ours approximate."""
+    from oracle import lie
+    from oracle import pose_graph as opg
+    prob, poses0 = oracle_problem(tensors, edges, P, torch.float64, sample)
+    saved = dict(lie.EPS[torch.float64])
+    if dtype == torch.float32:
+        import numpy as np
+        lie.EPS[torch.float64] = {k: float(np.float32(v)) for k, v in lie.EPS[torch.float32].items()}
+    try:
+        with torch.no_grad():
+            final, info = opg.lm_optimize(prob, poses0, max_iterations=iters, damping=damping, abs_err_tolerance=0.0,
+                                          rel_err_tolerance=0.0)
+    finally:
+        lie.EPS[torch.float64] = saved
+    return final, torch.stack(info.err_history, 1)
 
 
 def main():
@@ -93,6 +118,7 @@ def main():
     ap.add_argument("--adaptive", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32, help="problems in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--parity-sample", type=int, default=8, help="problems in the exact-parity sub-sample")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -155,7 +181,9 @@ def main():
     if rank == 0:
         phases = timer.summary()
         fac = phases.get("chol_factor", {"avg_ms": float("nan")})
-        flops_per_launch = B * (n ** 3) / 3.0  # n^3/3 per problem x B problems per factor call
+        # n^3/3 flops per problem x B problems per thx_chol_factor_forward call (the 2n^2 of the
+        # fused forward substitution are not counted)
+        flops_per_launch = B * (n ** 3) / 3.0
         achieved = flops_per_launch / (fac["avg_ms"] * 1e-3) / 1e12
         peak = PEAK[args.dtype]
         err_hist = info.err_history
@@ -173,29 +201,35 @@ def main():
             "pose_updates_per_s": world * B * iters_done * P / dt,
             "iters_done": iters_done,
             "mean_error": [float(err_hist[:, 0].mean()), float(err_hist[:, iters_done].mean())],
-            "roofline": {"bound": "mfma", "kernel": "thx_chol_factor (chol_diag + chol_offdiag launches)",
+            "roofline": {"bound": "mfma", "kernel": "thx_chol_factor_forward (chol_diag + chol_offdiag launches per block column)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": None, "flops_per_launch": flops_per_launch, "avg_launch_ms": fac["avg_ms"]},
             "phases_ms_per_call": {k: round(v["avg_ms"], 4) for k, v in phases.items()},
         }
         if args.cpu_sample > 0:
             S, CI = min(args.cpu_sample, B), args.cpu_iters
-            v, cores, cpu_final, cpu_s, cpu_hist = cpu_baseline(tensors, edges, P, dtype, S, CI)
-            # parity of the HIP path against the oracle on exactly that sample
-            sub = {k: t[:S].contiguous() for k, t in inputs.items()}
-            opt.set_params(max_iterations=CI)
-            with torch.no_grad():
-                sol_s, info_s = layer.forward(sub, optimizer_kwargs=dict(track_err_history=True, **okw))
-            got = torch.stack([sol_s[f"VERTEX_SE3__{k}"] for k in range(P)], 1).cpu()
+            v, cores, cpu_final, cpu_s, cpu_hist = cpu_baseline(tensors, edges, P, dtype, S, CI, args.damping)
             result["cpu_baseline"] = {"value": v, "unit": "problem-iterations/s", "cores": cores, "kind": "port",
                                       "sample": f"first {S} problems of rank 0's batch x {CI} LM iterations "
                                                 f"({cpu_s:.1f} s), oracle.pose_graph.lm_optimize (torch-CPU/MKL "
                                                 f"restatement of DenseLinearization + CholeskyDenseSolver)"}
-            result["parity"] = {"max_abs_pose_err_vs_oracle": float((got - cpu_final).abs().max()),
-                                "rel_err_final_cost": float(((info_s.err_history[:, CI] - cpu_hist[:, CI]).abs()
-                                                            / cpu_hist[:, CI].abs()).max()),
-                                "problems": S, "iters": CI}
             result["speedup_vs_cpu"] = result["value"] / v
+            # parity of the HIP path on a sub-sample, against the exact (fp64) evaluation of the same problem;
+            # the CPU port's own distance from exact is printed next to it (the fp32 band)
+            SP = min(args.parity_sample, S)
+            ex_final, ex_hist = exact_reference(tensors, edges, P, dtype, SP, CI, args.damping)
+            sub = {k: t[:SP].contiguous() for k, t in inputs.items()}
+            opt.set_params(max_iterations=CI)
+            with torch.no_grad():
+                sol_s, info_s = layer.forward(sub, optimizer_kwargs=dict(track_err_history=True, **okw))
+            got = torch.stack([sol_s[f"VERTEX_SE3__{k}"] for k in range(P)], 1).cpu().double()
+            rel = lambda h: float(((h.double()[:, CI] - ex_hist[:, CI]).abs() / ex_hist[:, CI].abs()).max())  # noqa
+            result["parity"] = {
+                "reference": "fp64 oracle (exact evaluation of the same inputs)", "problems": SP, "iters": CI,
+                "hip_max_abs_pose_err": float((got - ex_final).abs().max()),
+                "hip_rel_err_final_cost": rel(info_s.err_history),
+                "cpu_port_max_abs_pose_err": float((cpu_final[:SP].double() - ex_final).abs().max()),
+                "cpu_port_rel_err_final_cost": rel(cpu_hist[:SP])}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

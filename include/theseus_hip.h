@@ -32,7 +32,7 @@ extern "C" {
 
 #define THX_F32 0
 #define THX_F64 1
-#define THX_TILE 128 /* Cholesky tile edge; Winv holds ceil(n/THX_TILE) inverse diagonal tiles */
+#define THX_TILE 128 /* Cholesky tile edge; Winv holds ceil(n/THX_TILE) solve panels (see thx_chol_factor) */
 
 /* Taylor-switch thresholds of torchlie (torchlie/torchlie/global_params.py:44-58), read by the
  * host at launch time so that runtime changes made through torchlie.set_global_params apply. */
@@ -122,15 +122,26 @@ int thx_se3_retract(const void* poses, const void* delta, int64_t ldd, double st
  *      requires for LM's rho test, levenberg_marquardt.py:183-190).
  *        damping: (B) per-problem lambda or NULL for plain Gauss-Newton;
  *        ellipsoidal != 0: H + diag(lambda * diag(H) + damping_eps), else H + lambda I;
- *        L: (B, ld, ld) lower factor; Winv: (B, ceil(n/THX_TILE), THX_TILE, THX_TILE) inverses of
- *        the diagonal tiles of L (kept for the solves, including the implicit-backward solve);
+ *        L: (B, ld, ld) lower factor;
+ *        Winv: (B, ceil(n/THX_TILE), THX_TILE, THX_TILE) solve panels, one per diagonal tile of L:
+ *          32x32 diagonal sub-blocks hold (L_ss)^-1, strictly-lower sub-blocks hold -L_st (kept for
+ *          the solves, including the implicit-backward solve);
  *        info: (B) int32, 0 = ok, k>0 = leading minor k not positive definite (LAPACK potrf
  *        convention; the host turns any non-zero into the reference's RuntimeError).
- *      thx_chol_solve: x = (L L^T)^-1 rhs for one right-hand side per problem, rhs/x (B, n) with
- *        row stride ldv; re-usable with any rhs (the backward pass solves with the cached factor,
- *        cf. optimizer/autograd/baspacho_sparse_autograd.py:117-168). */
+ *      thx_chol_factor_forward: the same factorisation with the forward substitution fused in
+ *        (torch.cholesky_solve's first half): y = L^-1 rhs, rhs/y (B, n) with row stride ldv, y must
+ *        not alias rhs.  The panel rows the factorisation streams anyway are re-used, so y costs no
+ *        extra pass over L.
+ *      thx_chol_solve_backward: x = L^-T y (second half; x may alias y).
+ *      thx_chol_solve: x = (L L^T)^-1 rhs with a cached factor, any rhs -- the backward pass solves
+ *        with it (cf. optimizer/autograd/baspacho_sparse_autograd.py:117-168); x may alias rhs. */
 int thx_chol_factor(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
                     double damping_eps, void* L, void* Winv, int32_t* info, int dtype, void* stream);
+int thx_chol_factor_forward(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
+                            double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y,
+                            int64_t ldv, int dtype, void* stream);
+int thx_chol_solve_backward(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* y,
+                            void* x, int64_t ldv, int dtype, void* stream);
 int thx_chol_solve(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs,
                    void* x, int64_t ldv, int dtype, void* stream);
 

@@ -27,13 +27,20 @@ def sym_from_lower(H, n):
     return Hl + torch.tril(Hl, -1).transpose(1, 2)
 
 
-def factor_and_solve(K, H, n, rhs, damping=None, ellipsoidal=False, eps=1e-8):
+def factor_and_solve(K, H, n, rhs, damping=None, ellipsoidal=False, eps=1e-8, fused=False):
+    """fused=False: thx_chol_factor + thx_chol_solve (cached-factor solve);
+    fused=True: thx_chol_factor_forward + thx_chol_solve_backward (what LinearSolver.solve runs)."""
     B, ld = H.shape[0], H.shape[-1]
     nt = (n + 127) // 128
     L = torch.zeros_like(H)
-    diagT = torch.empty(B, nt, 128, 128, dtype=H.dtype, device=H.device)
+    panels = torch.empty(B, nt, 128, 128, dtype=H.dtype, device=H.device)
     info = torch.empty(B, dtype=torch.int32, device=H.device)
-    K.chol_factor(H, n, damping, ellipsoidal, eps, L, diagT, info)
     x = torch.empty_like(rhs)
-    K.chol_solve(L, n, diagT, rhs, x)
+    if fused:
+        y = torch.empty_like(rhs)
+        K.chol_factor(H, n, damping, ellipsoidal, eps, L, panels, info, rhs=rhs, y=y)
+        K.chol_solve_backward(L, n, panels, y, x)
+    else:
+        K.chol_factor(H, n, damping, ellipsoidal, eps, L, panels, info)
+        K.chol_solve(L, n, panels, rhs, x)
     return L, x, info

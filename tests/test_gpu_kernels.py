@@ -142,8 +142,9 @@ def _random_spd(B, n, dtype, seed, cond=1e3):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("n,B", [(6, 3), (48, 5), (126, 4), (128, 9), (132, 3), (258, 8), (390, 17), (1536, 8)])
-def test_chol_factor_solve_vs_lapack(K, dtype, n, B):
+def test_chol_factor_solve_vs_lapack(K, dtype, n, B, fused):
     from tests.gpu_helpers import factor_and_solve
     from theseus_amd.kernels import round_up
     M = _random_spd(B, n, dtype, seed=n + B)
@@ -152,7 +153,7 @@ def test_chol_factor_solve_vs_lapack(K, dtype, n, B):
     H = torch.zeros(B, ld, ld, dtype=dtype)
     H[:, :n, :n] = torch.tril(M)  # only the lower triangle is meaningful to the solver
     Hd, rd = H.cuda(), rhs.cuda()
-    L, x, info = factor_and_solve(K, Hd, n, rd)
+    L, x, info = factor_and_solve(K, Hd, n, rd, fused=fused)
     assert int(info.abs().sum()) == 0
     # reference: dense_solver.py:159-161 on the same (fp) matrix, in float64 as the arbiter
     M64 = M.double()

@@ -84,9 +84,13 @@ def test_lm_trajectory_matches_reference(name, tol):
                                                           end_iter_callback=lambda o, i, d, it: deltas.append(d.clone()),
                                                           **kw))
     final = torch.stack([sol[f"pose_{k}"] for k in range(int(g["P"]))], 1).cpu().numpy()
-    np.testing.assert_allclose(final, g["final"], rtol=0, atol=tol)
+    ok = well_conditioned_steps(g, g["delta"].shape[0])
+    # a problem whose late accept/reject decisions are coin flips (see well_conditioned_steps) may or may
+    # not have taken those steps: its final pose is defined up to the size of the steps in question
+    slack = 2.0 * (np.abs(g["delta"]).max(axis=2) * ~ok).sum(axis=0)          # (B,)
+    assert (np.abs(final - g["final"]).reshape(final.shape[0], -1).max(1) <= tol + slack).all(), \
+        (np.abs(final - g["final"]).reshape(final.shape[0], -1).max(1), slack)
     if len(deltas) == g["delta"].shape[0]:
-        ok = well_conditioned_steps(g, len(deltas))
         for it, d in enumerate(deltas):
             np.testing.assert_allclose(d.cpu().numpy()[ok[it]], g["delta"][it][ok[it]], rtol=0,
                                        atol=tol * max(1.0, np.abs(g["delta"][it]).max()))

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtheseus_hip.so")
 
 THX_TILE = 128
 THX_ERR_CHUNKS = 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class LieEps(Structure):
@@ -59,8 +59,12 @@ _SIGNATURES = {
                         POINTER(LieEps), c_void_p],
     "thx_chol_factor": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,
                         c_void_p, c_int, c_void_p],
+    "thx_chol_factor_forward": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     "thx_chol_solve": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                        c_void_p],
+    "thx_chol_solve_backward": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                c_void_p],
     "thx_diag": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_int, c_void_p],
     "thx_lm_accept": [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                       c_void_p, c_int, c_double, c_double, c_double, c_void_p, c_int, c_void_p],

@@ -6,20 +6,31 @@
 // Algorithm: tiled LEFT-LOOKING Cholesky with 128x128 tiles, one kernel launch pair per block
 // column j (the batch supplies the parallelism: B x (N-j) workgroups per launch, no inter-workgroup
 // communication inside a launch):
-//   chol_diag(j)    : S = H_jj + damping - L_j,0:j L_j,0:j^T   (MFMA K-loop)
+//   chol_diag(j)    : S = H_jj + damping - L_j,0:j L_j,0:j^T   (MFMA K-loop; the same pass over the
+//                     panel also forms L_j,0:j y_0:j for the fused forward substitution)
 //                     L_jj = chol(S)                            (register-resident, row per lane pair)
+//                     panel M_j: 32x32 diagonal sub-blocks W_ss = L_ss^-1 (inverted in fp64), strictly
+//                     lower sub-blocks -L_st;  y_j = L_jj^-1 (g_j - L_j,0:j y)  (blocked, via M_j)
 //   chol_offdiag(j) : P = H_ij - L_i,0:j L_j,0:j^T              (MFMA K-loop)
-//                     L_ij = P L_jj^-T                          (register-resident substitution)
+//                     L_ij = P L_jj^-T as a BLOCKED substitution on the matrix cores:
+//                       for s = 0..3:  P_s += sum_{t<s} X_t (-L_st)^T ;  X_s = P_s W_ss^T
+//                     The accumulator registers are fed straight back as the MFMA B operand (the
+//                     k index of an MFMA is just a pairing of columns, and the pairing the C/D
+//                     layout gives is as good as any), A comes from the panel in LDS: no data
+//                     movement, 160 MFMAs per wave instead of 128 dependent VALU/LDS steps.
 // Left-looking means every tile of L is written exactly once and the trailing matrix is never
-// re-read: per problem the K-loops stream  sum_j (N-j) * 2*128*(128 j)  elements, i.e. algorithmic
-// intensity T/4 = 32 flop/B in fp32 -- above the 157 TF / 8 TB/s ridge -- so the kernel is MFMA bound.
+// re-read: per problem the K-loops stream  sum_j (N-j) * 2*128*(128 j)  elements.
+// Only 32x32 triangles are ever inverted (in fp64, rounded once): the substitution across sub-blocks
+// uses L itself, so the result has the error profile of a blocked TRSM, not of a full inverse.
 //
 // MFMA mapping (f32: v_mfma_f32_32x32x2_f32, f64: v_mfma_f64_16x16x4_f64): a 256-thread workgroup is
 // 4 waves; wave w owns tile rows [32w, 32w+32) x all 128 columns and computes the TRANSPOSED product
-// block D = L_j-rows * L_i-rows^T, so that the MFMA result layout puts matrix row r = 32w + (lane&31)
-// in lane pair (lane, lane^32) -- lane group g = lane>>5 holds columns c with ((c>>2)&1) == g.
-// That "row per lane pair" layout is exactly what the in-register Cholesky / triangular solve need,
-// so the tile never round-trips through LDS in fp32.
+// block D = L_j-rows * L_i-rows^T, so that a lane holds ONE matrix row (f32: row 32w + (lane&31),
+// columns with ((c>>2)&1) == lane>>5; f64: row 32w + 16h + (lane&15), columns c = lane>>4 mod 4).
+//
+// Solves: L y = g is fused into the factorisation (above); L^T x = y is one HBM-bound pass over L
+// (chol_bwd_kernel).  A stand-alone forward kernel serves solves with a cached factor (implicit
+// backward pass).
 #include "common.cuh"
 
 #include <utility>
@@ -47,12 +58,12 @@ template <typename T>
 struct CT;
 template <>
 struct CT<float> {
-  static constexpr int KB = 32, LDT = 36, VEC = 4, LDC = 132;
+  static constexpr int KB = 32, LDT = 36, VEC = 4, LDC = 132, LDM = 132;
   using V = float4;
 };
 template <>
 struct CT<double> {
-  static constexpr int KB = 16, LDT = 18, VEC = 2, LDC = 132;
+  static constexpr int KB = 16, LDT = 18, VEC = 2, LDC = 132, LDM = 130;
   using V = double2;
 };
 
@@ -118,6 +129,47 @@ struct Engine<float> {
       for (int r = 0; r < 16; ++r) a[16 * cb + r] = acc.v[cb][r];
   }
   static constexpr size_t canonical_lds_bytes = 0;
+
+  // ---- native-layout helpers: lane (rl = lane&31, g = lane>>5) of wave w holds tile row 32w + rl,
+  //      register rho of block cb <-> tile column 32cb + 8(rho>>2) + 4g + (rho&3)
+  // acc <- tile - acc   (tile: an H tile staged in LDS, row stride 132)
+  static __device__ __forceinline__ void rsub_lds(Acc& acc, const float* tile, int wave, int lane) {
+    const float* row = tile + (32 * wave + (lane & 31)) * 132 + 4 * (lane >> 5);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 h = *reinterpret_cast<const float4*>(row + 32 * cb + 8 * q);
+        acc.v[cb][4 * q + 0] = h.x - acc.v[cb][4 * q + 0];
+        acc.v[cb][4 * q + 1] = h.y - acc.v[cb][4 * q + 1];
+        acc.v[cb][4 * q + 2] = h.z - acc.v[cb][4 * q + 2];
+        acc.v[cb][4 * q + 3] = h.w - acc.v[cb][4 * q + 3];
+      }
+  }
+  static __device__ __forceinline__ void store_lds(const Acc& acc, float* tile, int wave, int lane) {
+    float* row = tile + (32 * wave + (lane & 31)) * 132 + 4 * (lane >> 5);
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(row + 32 * cb + 8 * q) =
+            make_float4(acc.v[cb][4 * q], acc.v[cb][4 * q + 1], acc.v[cb][4 * q + 2], acc.v[cb][4 * q + 3]);
+  }
+  // D.block(S) += M[rows of sub-block S][cols of sub-block Tt] * Bs.block(Tt)^T, i.e. for every tile row r
+  // this wave owns:  D[r][32S + i] += sum_{c in block Tt} M[32S + i][c] * Bs[r][c].
+  // The B operand is the accumulator itself: MFMA k = 0/1 <-> columns c and c+4 held by lane groups 0/1.
+  template <int S, int Tt>
+  static __device__ __forceinline__ void sub_mma(const float* M, const Acc& Bs, Acc& D, int lane) {
+    const float* arow = M + (32 * S + (lane & 31)) * 132 + 32 * Tt + 4 * (lane >> 5);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 fa = *reinterpret_cast<const float4*>(arow + 8 * q);
+      D.v[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, Bs.v[Tt][4 * q + 0], D.v[S], 0, 0, 0);
+      D.v[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, Bs.v[Tt][4 * q + 1], D.v[S], 0, 0, 0);
+      D.v[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, Bs.v[Tt][4 * q + 2], D.v[S], 0, 0, 0);
+      D.v[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, Bs.v[Tt][4 * q + 3], D.v[S], 0, 0, 0);
+    }
+  }
 };
 
 template <>
@@ -176,13 +228,62 @@ struct Engine<double> {
     __syncthreads();
   }
   static constexpr size_t canonical_lds_bytes = (size_t)128 * 132 * sizeof(double);
+
+  // ---- native-layout helpers: lane (rl = lane&15, kq = lane>>4) of wave w holds tile rows
+  //      32w + 16h + rl (h = 0,1); register rho of block cb <-> tile column 16cb + 4rho + kq
+  static __device__ __forceinline__ void rsub_lds(Acc& acc, const double* tile, int wave, int lane) {
+    const int rl = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho)
+          acc.v[h][cb][rho] = tile[(32 * wave + 16 * h + rl) * 130 + 16 * cb + 4 * rho + kq] - acc.v[h][cb][rho];
+  }
+  static __device__ __forceinline__ void store_lds(const Acc& acc, double* tile, int wave, int lane) {
+    const int rl = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho)
+          tile[(32 * wave + 16 * h + rl) * 130 + 16 * cb + 4 * rho + kq] = acc.v[h][cb][rho];
+  }
+  // as Engine<float>::sub_mma; a 32-column sub-block is two 16-column MFMA blocks, the accumulator
+  // register rho of block cb serves as the B operand for k = kq <-> column 16cb + 4rho + kq.
+  template <int S, int Tt>
+  static __device__ __forceinline__ void sub_mma(const double* M, const Acc& Bs, Acc& D, int lane) {
+    const int rl = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int cp = 2 * S; cp < 2 * S + 2; ++cp)
+#pragma unroll
+      for (int cb = 2 * Tt; cb < 2 * Tt + 2; ++cb)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) {
+          const double a = M[(16 * cp + rl) * 130 + 16 * cb + 4 * rho + kq];
+          D.v[0][cp] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs.v[0][cb][rho], D.v[0][cp], 0, 0, 0);
+          D.v[1][cp] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs.v[1][cb][rho], D.v[1][cp], 0, 0, 0);
+        }
+  }
 };
 
-template <typename T, bool SAME>
+// Optional rider on the SYRK K-loop of chol_diag: the panel rows L_j,0:j pass through LDS anyway, so
+// t[r] = sum_k L[row0+r][k] y[k] (the forward-substitution update) costs 16 VALU FMAs per thread and
+// chunk in the shadow of the MFMAs.  Thread pair (2r, 2r+1) splits the chunk's k range in two.
+template <typename T>
+struct Gemv {
+  const T* y;  // LDS, y[0:K]
+  T part;      // this thread's partial sum
+};
+
+template <typename T, bool SAME, bool GEMV = false>
 __device__ __forceinline__ void kloop(const T* __restrict__ Arows, int validA, const T* __restrict__ Brows,
                                       int validB, int64_t ld, int K, T* sA, T* sB,
-                                      typename Engine<T>::Acc& acc, int tid) {
+                                      typename Engine<T>::Acc& acc, int tid, Gemv<T>* gv = nullptr) {
   using C = CT<T>;
+  using V = typename C::V;
   const int lrow = tid >> 3, lc = tid & 7;
   const int wave = tid >> 6, lane = tid & 63;
   uint4 ra[4], rb[4];
@@ -221,17 +322,138 @@ __device__ __forceinline__ void kloop(const T* __restrict__ Arows, int validA, c
     }
     __syncthreads();
     if (kc + 1 < nk) gload((kc + 1) * C::KB);
+    if constexpr (GEMV) {
+      if (gv) {
+        constexpr int HALF = C::KB / 2;
+        const V* rp = reinterpret_cast<const V*>(sA + (tid >> 1) * C::LDT + (tid & 1) * HALF);
+        const V* yp = reinterpret_cast<const V*>(gv->y + kc * C::KB + (tid & 1) * HALF);
+        T sum = gv->part;
+#pragma unroll
+        for (int i = 0; i < HALF / C::VEC; ++i) {
+          const V a = rp[i], yv = yp[i];
+          if constexpr (sizeof(T) == 4) {
+            sum += a.x * yv.x; sum += a.y * yv.y; sum += a.z * yv.z; sum += a.w * yv.w;
+          } else {
+            sum += a.x * yv.x; sum += a.y * yv.y;
+          }
+        }
+        gv->part = sum;
+      }
+    }
     Engine<T>::chunk(sA, (SAME ? sA : sB) + 32 * wave * C::LDT, acc, lane);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// chol_diag: SYRK + in-register Cholesky of the 128x128 diagonal tile of block column j
+// 128x128 tile <-> LDS (row stride LDM), coalesced 16-byte accesses, zero fill outside the matrix
 // ------------------------------------------------------------------------------------------------
 template <typename T>
+__device__ __forceinline__ void tile_g2l(const T* __restrict__ g, int64_t ld, int vrows, int vcols, T* lds, int tid) {
+  using C = CT<T>;
+  constexpr int CPR = TILE / C::VEC;        // 16-byte chunks per row
+  constexpr int RPP = 256 / CPR;            // rows per pass
+  const int c = (tid % CPR) * C::VEC, r0 = tid / CPR;
+#pragma unroll 4
+  for (int r = r0; r < TILE; r += RPP) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < vrows && c < vcols) v = *reinterpret_cast<const uint4*>(g + (int64_t)r * ld + c);
+    *reinterpret_cast<uint4*>(lds + r * C::LDM + c) = v;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void tile_l2g(const T* lds, T* __restrict__ g, int64_t ld, int vrows, int vcols, int tid) {
+  using C = CT<T>;
+  constexpr int CPR = TILE / C::VEC;
+  constexpr int RPP = 256 / CPR;
+  const int c = (tid % CPR) * C::VEC, r0 = tid / CPR;
+#pragma unroll 4
+  for (int r = r0; r < TILE; r += RPP)
+    if (r < vrows && c < vcols)
+      *reinterpret_cast<uint4*>(g + (int64_t)r * ld + c) = *reinterpret_cast<const uint4*>(lds + r * C::LDM + c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// blocked substitutions with a panel M in LDS (diag sub-blocks W_ss = L_ss^-1, below: -L_st)
+// executed by wave 0 (64 lanes: lane = (row-in-block, half of the column range)); the caller
+// brackets them with __syncthreads().  vec holds the right-hand side on entry, the solution on exit.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float half_sum(float x) { return x + __shfl_xor(x, 32); }
+__device__ __forceinline__ double half_sum(double x) { return x + __shfl_xor(x, 32); }
+
+// y = L_jj^-1 v :  for s: u_s = v_s + sum_{c < 32s} M[r][c] y[c] ;  y_s = W_ss u_s
+template <typename T>
+__device__ __forceinline__ void panel_forward(const T* M, T* vec, T* ubuf, int lane) {
+  using C = CT<T>;
+  const int rl = lane & 31, hf = lane >> 5;
+#pragma unroll
+  for (int sb = 0; sb < 4; ++sb) {
+    const T* row = M + (32 * sb + rl) * C::LDM;
+    T u = T(0);
+    // columns [0, 32 sb) split between the two lane halves in 16-column slabs
+    for (int c = 16 * hf; c < 32 * sb; c += 32)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) u += row[c + i] * vec[c + i];
+    u = half_sum(u) + vec[32 * sb + rl];
+    if (hf == 0) ubuf[rl] = u;
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are visible to its reads
+    __builtin_amdgcn_wave_barrier();
+    T yv = T(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) yv += row[32 * sb + 16 * hf + i] * ubuf[16 * hf + i];
+    yv = half_sum(yv);
+    __builtin_amdgcn_wave_barrier();
+    if (hf == 0) vec[32 * sb + rl] = yv;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// x = L_jj^-T z :  for t = 3..0: a_t = z_t + sum_{r >= 32(t+1)} M[r][c] x[r] ;  x_t = W_tt^T a_t
+template <typename T>
+__device__ __forceinline__ void panel_backward(const T* M, T* vec, T* ubuf, int lane) {
+  using C = CT<T>;
+  const int cl = lane & 31, hf = lane >> 5;
+#pragma unroll
+  for (int tb = 3; tb >= 0; --tb) {
+    const T* col = M + 32 * tb + cl;
+    T a = T(0);
+    for (int r = 32 * (tb + 1) + 16 * hf; r < TILE; r += 32)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a += col[(r + i) * C::LDM] * vec[r + i];
+    a = half_sum(a) + vec[32 * tb + cl];
+    if (hf == 0) ubuf[cl] = a;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    T xv = T(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xv += col[(32 * tb + 16 * hf + i) * C::LDM] * ubuf[16 * hf + i];
+    xv = half_sum(xv);
+    __builtin_amdgcn_wave_barrier();
+    if (hf == 0) vec[32 * tb + cl] = xv;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// chol_diag: SYRK + in-register Cholesky of the 128x128 diagonal tile of block column j, panel M_j,
+// fused forward substitution
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct DiagSmem {
+  static constexpr size_t stage = (size_t)128 * CT<T>::LDT * sizeof(T);
+  static constexpr size_t canon = Engine<T>::canonical_lds_bytes;
+  static constexpr size_t tile = (size_t)128 * CT<T>::LDM * sizeof(T);
+  static constexpr size_t region0 = (stage > canon ? stage : canon) > tile ? (stage > canon ? stage : canon) : tile;
+  // region0 | colbuf [4][128] T | dinv [128] double | vvec [128] T | ubuf [32] T | ybuf [ypad] T
+  static size_t bytes(int ypad) { return region0 + 4 * 128 * sizeof(T) + 128 * sizeof(double) + 160 * sizeof(T) + (size_t)ypad * sizeof(T); }
+};
+
+template <typename T>
 __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1)
-chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ diagT, const T* __restrict__ damping,
-                 int ellipsoidal, T damping_eps, int32_t* __restrict__ info, int n, int64_t ld, int j, int ntiles) {
+chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ panel, const T* __restrict__ damping,
+                 int ellipsoidal, T damping_eps, int32_t* __restrict__ info, int n, int64_t ld, int j, int ntiles,
+                 const T* __restrict__ rhs, T* __restrict__ yout, int64_t ldv) {
   using C = CT<T>;
   using V = typename C::V;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -241,14 +463,22 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ dia
   const int64_t mat = (int64_t)b * ld * ld;
   const int row0 = j * TILE;
   const int valid = min(TILE, n - row0);
-  T* sA = smem;  // [128][LDT]; the f64 canonicalisation tile aliases it
-  const size_t stage_elems = (size_t)128 * C::LDT;
-  const size_t canon_elems = Engine<T>::canonical_lds_bytes / sizeof(T);
-  T* colbuf = smem + (stage_elems > canon_elems ? stage_elems : canon_elems);  // [2][128] + dummy [2][128]
+  T* sA = smem;  // [128][LDT]; the f64 canonicalisation tile and the panel tile alias it
+  T* colbuf = reinterpret_cast<T*>(smem_raw + DiagSmem<T>::region0);  // [2][128] + dummy [2][128]
+  double* dinv = reinterpret_cast<double*>(colbuf + 4 * 128);
+  T* vvec = reinterpret_cast<T*>(dinv + 128);
+  T* ubuf = vvec + 128;
+  T* ybuf = ubuf + 32;
+
+  Gemv<T> gv{ybuf, T(0)};
+  const bool fwd = rhs != nullptr;
+  if (fwd)
+    for (int k = tid; k < row0; k += 256) ybuf[k] = yout[(int64_t)b * ldv + k];  // y_0:j of earlier columns
 
   typename Engine<T>::Acc acc;
   Engine<T>::zero(acc);
-  kloop<T, true>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, row0, sA, nullptr, acc, tid);
+  kloop<T, true, true>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, row0, sA, nullptr, acc, tid,
+                       fwd ? &gv : nullptr);
 
   T a[64];
   Engine<T>::canonical(acc, a, smem, wave, lane);
@@ -338,39 +568,105 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ dia
   });
   if (bad != 0 && tid == 0 && info[b] == 0) info[b] = row0 + bad;  // every thread sees the same `bad`
 
-  // ---- store L_jj (row major, zeros above the diagonal) and its transpose (for the solves) ----
-  T* Lrow = L + mat + (int64_t)(row0 + r) * ld + row0;
-  T* dT = diagT + ((int64_t)b * ntiles + j) * TILE * TILE;
+  // ---- L_jj -> LDS tile (zeros above the diagonal), coalesced store to L ----
+  T* tile = smem;  // [128][LDM]
+  __syncthreads();  // region0 is free (staging / canonical tile no longer read)
 #pragma unroll
   for (int m = 0; m < 16; ++m) {
     const int q0 = 8 * m + 4 * g;
     const int idx = 16 * (m >> 2) + 4 * (m & 3);
     T v[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      v[t] = (q0 + t <= r) ? a[idx + t] : T(0);
-      dT[(int64_t)(q0 + t) * TILE + r] = v[t];
+    for (int t = 0; t < 4; ++t) v[t] = (q0 + t <= r) ? a[idx + t] : T(0);
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<V*>(tile + r * C::LDM + q0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      *reinterpret_cast<V*>(tile + r * C::LDM + q0) = make_double2(v[0], v[1]);
+      *reinterpret_cast<V*>(tile + r * C::LDM + q0 + 2) = make_double2(v[2], v[3]);
     }
-    if (rvalid && q0 < valid) {
+  }
+  if (tid < TILE) vvec[tid] = (fwd && tid < valid) ? rhs[(int64_t)b * ldv + row0 + tid] : T(0);
+  __syncthreads();
+  tile_l2g<T>(tile, L + mat + (int64_t)row0 * ld + row0, ld, valid, valid, tid);
+  if (tid < TILE) dinv[tid] = 1.0 / (double)tile[tid * C::LDM + tid];
+  // g_j - L_j,0:j y : thread pair (2r, 2r+1) holds the two halves of row r's sum
+  {
+    const T tsum = gv.part + __shfl_xor(gv.part, 1);
+    if (fwd && (tid & 1) == 0) vvec[tid >> 1] -= tsum;
+  }
+  __syncthreads();
+
+  // ---- panel: wave s inverts the 32x32 triangle L_ss in fp64 (lane c < 32 owns column c of W_ss:
+  //      forward substitution on e_c, no cross-lane traffic), every thread negates its share of the
+  //      strictly-lower sub-blocks.  In place: a wave's reads of L_ss complete before its writes. ----
+  {
+    const int sb = wave, cc = lane & 31;
+    const T* Ls = tile + (32 * sb) * C::LDM + 32 * sb;
+    double w[32];
+    static_for<32>([&](auto ii) __attribute__((always_inline)) {
+      constexpr int i = decltype(ii)::value;
+      double sacc = (cc == i) ? 1.0 : 0.0;
+      static_for<i>([&](auto kk) __attribute__((always_inline)) {
+        constexpr int k = decltype(kk)::value;
+        sacc -= (double)Ls[i * C::LDM + k] * w[k];
+      });
+      w[i] = sacc * dinv[32 * sb + i];
+      // one row at a time: tie w[i] to a compiler barrier, otherwise all 496 LDS reads are issued first
+      // and the FMA chains sink below them (hundreds of spilled registers)
+      asm volatile("" : "+v"(w[i]) : : "memory");
+    });
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32) {
+      T* Ws = tile + (32 * sb) * C::LDM + 32 * sb + cc;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) Ws[i * C::LDM] = (T)w[i];
+    }
+    // negate: thread (row = tid >> 1, half) over columns [0, 32 * (row >> 5))
+    const int nr = tid >> 1, nh = tid & 1;
+    T* nrow = tile + nr * C::LDM;
+    for (int c = 4 * nh; c < 32 * (nr >> 5); c += 8) {
+      V* vp = reinterpret_cast<V*>(nrow + c);
       if constexpr (sizeof(T) == 4) {
-        *reinterpret_cast<V*>(Lrow + q0) = make_float4(v[0], v[1], v[2], v[3]);
+        V v = vp[0];
+        vp[0] = make_float4(-v.x, -v.y, -v.z, -v.w);
       } else {
-        *reinterpret_cast<V*>(Lrow + q0) = make_double2(v[0], v[1]);
-        *reinterpret_cast<V*>(Lrow + q0 + 2) = make_double2(v[2], v[3]);
+        V v0 = vp[0], v1 = vp[1];
+        vp[0] = make_double2(-v0.x, -v0.y);
+        vp[1] = make_double2(-v1.x, -v1.y);
       }
     }
+  }
+  __syncthreads();
+  {  // panel -> global (full 128 x 128, row stride 128)
+    T* P = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
+    constexpr int CPR = TILE / C::VEC, RPP = 256 / CPR;
+    const int c = (tid % CPR) * C::VEC;
+    for (int rr = tid / CPR; rr < TILE; rr += RPP)
+      *reinterpret_cast<uint4*>(P + rr * TILE + c) = *reinterpret_cast<const uint4*>(tile + rr * C::LDM + c);
+  }
+  if (fwd) {
+    if (wave == 0) panel_forward<T>(tile, vvec, ubuf, lane);
+    __syncthreads();
+    if (tid < valid) yout[(int64_t)b * ldv + row0 + tid] = vvec[tid];
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// chol_offdiag: GEMM K-loop + in-register triangular solve  L_ij = (H_ij - sum) L_jj^-T
+// chol_offdiag: GEMM K-loop + blocked MFMA substitution  L_ij = (H_ij - sum) L_jj^-T
 // ------------------------------------------------------------------------------------------------
 template <typename T>
+struct OffdiagSmem {
+  static constexpr size_t stage = (size_t)2 * 128 * CT<T>::LDT * sizeof(T);
+  static constexpr size_t tile = (size_t)128 * CT<T>::LDM * sizeof(T);
+  static constexpr size_t bytes = stage > tile ? stage : tile;
+};
+
+template <typename T>
 __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1)
-chol_offdiag_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict__ diagT, int n, int64_t ld,
+chol_offdiag_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict__ panel, int n, int64_t ld,
                     int j, int ntiles, int nrow_tiles, int B) {
   using C = CT<T>;
-  using V = typename C::V;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   // XCD-aware mapping: block id -> (problem, tile) so that all row tiles of one problem (which share
@@ -387,98 +683,46 @@ chol_offdiag_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restr
   const int validB = min(TILE, n - row0);
   T* sA = smem;
   T* sB = smem + 128 * C::LDT;
+  T* tile = smem;  // [128][LDM], aliases the staging buffers
 
-  typename Engine<T>::Acc acc;
-  Engine<T>::zero(acc);
-  kloop<T, false>(L + mat + (int64_t)col0 * ld, validA, L + mat + (int64_t)row0 * ld, validB, ld, col0, sA, sB, acc,
+  typename Engine<T>::Acc P;
+  Engine<T>::zero(P);
+  kloop<T, false>(L + mat + (int64_t)col0 * ld, validA, L + mat + (int64_t)row0 * ld, validB, ld, col0, sA, sB, P,
                   tid);
-  T p[64];
-  Engine<T>::canonical(acc, p, smem, wave, lane);
-
-  // L_jj^T tile -> LDS (LT[c][q] = L[col0+q][col0+c]); reciprocal diagonal
+  // P = H_ij - sum  (H tile staged through LDS for coalescing)
   __syncthreads();
-  T* LT = smem;               // [128][128]
-  T* dinv = smem + 128 * 128;  // [128]
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(diagT + ((int64_t)b * ntiles + j) * TILE * TILE);
-    uint4* dst = reinterpret_cast<uint4*>(LT);
-    constexpr int NV = 128 * 128 * sizeof(T) / 16;
-    for (int v = tid; v < NV; v += 256) dst[v] = src[v];
+  tile_g2l<T>(H + mat + (int64_t)row0 * ld + col0, ld, validB, validA, tile, tid);
+  __syncthreads();
+  Engine<T>::rsub_lds(P, tile, wave, lane);
+  __syncthreads();
+  {  // panel M_j (row stride 128 in global) -> LDS
+    const T* Pn = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
+    constexpr int CPR = TILE / C::VEC, RPP = 256 / CPR;
+    const int c = (tid % CPR) * C::VEC;
+#pragma unroll 4
+    for (int rr = tid / CPR; rr < TILE; rr += RPP)
+      *reinterpret_cast<uint4*>(tile + rr * C::LDM + c) = *reinterpret_cast<const uint4*>(Pn + rr * TILE + c);
   }
   __syncthreads();
-  if (tid < 128) dinv[tid] = t_rcp(LT[tid * 128 + tid]);
-
-  const int r = 32 * wave + (lane & 31), g = lane >> 5;
-  const bool rvalid = r < validB;
-  const T* Hrow = H + mat + (int64_t)(row0 + r) * ld + col0;
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    const int q0 = 8 * m + 4 * g;
-    const int idx = 16 * (m >> 2) + 4 * (m & 3);
-    T h[4] = {T(0), T(0), T(0), T(0)};
-    if (rvalid) {
-      if constexpr (sizeof(T) == 4) {
-        const V v = *reinterpret_cast<const V*>(Hrow + q0);
-        h[0] = v.x; h[1] = v.y; h[2] = v.z; h[3] = v.w;
-      } else {
-        const V v0 = *reinterpret_cast<const V*>(Hrow + q0);
-        const V v1 = *reinterpret_cast<const V*>(Hrow + q0 + 2);
-        h[0] = v0.x; h[1] = v0.y; h[2] = v1.x; h[3] = v1.y;
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) p[idx + t] = h[t] - p[idx + t];
-  }
-  __syncthreads();  // dinv visible
-
-  // ---- X L_jj^T = P, right-looking over columns; each row lives in the lane pair (l, l^32) ----
-  const T own0 = g == 0 ? T(1) : T(0), own1 = T(1) - own0;
-  static_for<TILE>([&](auto ic) __attribute__((always_inline)) {
-    constexpr int c = decltype(ic)::value;
-    constexpr int G = (c >> 2) & 1;
-    constexpr int I = 16 * (c >> 5) + 4 * ((c & 31) >> 3) + (c & 3);
-    // arithmetic mask instead of a select: LLVM turns `cond ? p*dinv[c] : 0` back into a branch
-    // around the LDS load, and the branches let it sink the FMA chains and spill every LT read
-    const T mine = p[I] * dinv[c] * (G == 0 ? own0 : own1);
-    const T x = pair_sum(mine);
-    const T* ltc = LT + c * 128;
-#pragma unroll
-    for (int m = (c >> 3); m < 16; ++m) {
-      const V* vp = reinterpret_cast<const V*>(ltc + 8 * m + 4 * g);
-      T v[4];
-      if constexpr (sizeof(T) == 4) {
-        const V y = vp[0];
-        v[0] = y.x; v[1] = y.y; v[2] = y.z; v[3] = y.w;
-      } else {
-        const V y0 = vp[0], y1 = vp[1];
-        v[0] = y0.x; v[1] = y0.y; v[2] = y1.x; v[3] = y1.y;
-      }
-      const int idx = 16 * (m >> 2) + 4 * (m & 3);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) p[idx + t] -= x * v[t];  // LT[c][q] == 0 for q < c
-    }
-    p[I] = (g == G) ? x : p[I];
-    __builtin_amdgcn_sched_barrier(0);
+  // ---- X L_jj^T = P on the matrix cores ----
+  typename Engine<T>::Acc X;
+  Engine<T>::zero(X);
+  static_for<4>([&](auto is) __attribute__((always_inline)) {
+    constexpr int sb = decltype(is)::value;
+    static_for<sb>([&](auto it) __attribute__((always_inline)) {
+      constexpr int tb = decltype(it)::value;
+      Engine<T>::template sub_mma<sb, tb>(tile, X, P, lane);  // P_s += (-L_st) X_t
+    });
+    Engine<T>::template sub_mma<sb, sb>(tile, P, X, lane);    // X_s  = W_ss P_s
   });
-
-  if (rvalid) {
-    T* Lrow = L + mat + (int64_t)(row0 + r) * ld + col0;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const int q0 = 8 * m + 4 * g;
-      const int idx = 16 * (m >> 2) + 4 * (m & 3);
-      if constexpr (sizeof(T) == 4) {
-        *reinterpret_cast<V*>(Lrow + q0) = make_float4(p[idx], p[idx + 1], p[idx + 2], p[idx + 3]);
-      } else {
-        *reinterpret_cast<V*>(Lrow + q0) = make_double2(p[idx], p[idx + 1]);
-        *reinterpret_cast<V*>(Lrow + q0 + 2) = make_double2(p[idx + 2], p[idx + 3]);
-      }
-    }
-  }
+  __syncthreads();
+  Engine<T>::store_lds(X, tile, wave, lane);
+  __syncthreads();
+  tile_l2g<T>(tile, L + mat + (int64_t)row0 * ld + col0, ld, validB, validA, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
-// triangular solves with one right-hand side per problem (v1: one workgroup per problem)
+// triangular solves with one right-hand side per problem, one workgroup per problem, HBM bound
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
@@ -488,89 +732,132 @@ __device__ __forceinline__ T wave_sum(T v) {
 }
 
 template <typename T>
+__device__ __forceinline__ void panel_g2l(const T* __restrict__ Pn, T* tile, int tid) {
+  using C = CT<T>;
+  constexpr int CPR = TILE / C::VEC, RPP = 256 / CPR;
+  const int c = (tid % CPR) * C::VEC;
+#pragma unroll 4
+  for (int rr = tid / CPR; rr < TILE; rr += RPP)
+    *reinterpret_cast<uint4*>(tile + rr * C::LDM + c) = *reinterpret_cast<const uint4*>(Pn + rr * TILE + c);
+}
+
+template <typename T>
+static size_t solve_smem(int npad) {
+  return (size_t)128 * CT<T>::LDM * sizeof(T) + (size_t)(npad + 128 + 32) * sizeof(T);
+}
+
+// L y = rhs (stand-alone; the LM iteration gets y from the factorisation)
+template <typename T>
 __global__ void __launch_bounds__(256)
-chol_solve_kernel(const T* __restrict__ L, const T* __restrict__ diagT, const T* __restrict__ rhs, T* __restrict__ x,
-                  int n, int64_t ld, int64_t ldv, int ntiles) {
+chol_fwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* __restrict__ rhs, T* __restrict__ y,
+                int n, int64_t ld, int64_t ldv, int ntiles) {
+  using C = CT<T>;
+  using V = typename C::V;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* smem = reinterpret_cast<T*>(smem_raw);
-  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  T* tile = reinterpret_cast<T*>(smem_raw);
   const int npad = ntiles * TILE;
-  T* tile = smem;                   // [128][128]
-  T* y = smem + 128 * 128;          // [npad]
-  T* tbuf = y + npad;               // [128]
-  T* cur = tbuf + 128;              // [2]
+  T* yv = tile + 128 * C::LDM;  // [npad]
+  T* tv = yv + npad;            // [128]
+  T* ubuf = tv + 128;           // [32]
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const T* Lb = L + (int64_t)b * ld * ld;
-  const T* dTb = diagT + (int64_t)b * ntiles * TILE * TILE;
-  for (int k = tid; k < npad; k += 256) y[k] = k < n ? rhs[(int64_t)b * ldv + k] : T(0);
+  for (int k = tid; k < npad; k += 256) yv[k] = k < n ? rhs[(int64_t)b * ldv + k] : T(0);
   __syncthreads();
-
-  // ---- forward: L y = g ----
   for (int jb = 0; jb < ntiles; ++jb) {
-    const int row0 = jb * TILE, K = row0;
-    const int valid = min(TILE, n - row0);
-    // t[r] = sum_k L[row0+r][k] y[k], one wave per row (coalesced along k)
-    for (int rr = wave; rr < TILE; rr += 4) {
-      T s = T(0);
-      if (rr < valid) {
-        const T* Lr = Lb + (int64_t)(row0 + rr) * ld;
-        for (int k = lane; k < K; k += 64) s += Lr[k] * y[k];
+    const int row0 = jb * TILE, valid = min(TILE, n - row0);
+    panel_g2l<T>(panel + ((int64_t)b * ntiles + jb) * TILE * TILE, tile, tid);
+    // t[r] = sum_{k < row0} L[row0 + r][k] y[k]: wave w takes rows r = w (mod 4), four rows in flight
+    for (int rr = wave; rr < TILE; rr += 16) {
+      T s[4] = {T(0), T(0), T(0), T(0)};
+      for (int k = lane * C::VEC; k < row0; k += 64 * C::VEC) {
+        const V yk = *reinterpret_cast<const V*>(yv + k);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = rr + 4 * u;
+          if (r < valid) {
+            const V lv = *reinterpret_cast<const V*>(Lb + (int64_t)(row0 + r) * ld + k);
+            if constexpr (sizeof(T) == 4) s[u] += lv.x * yk.x + lv.y * yk.y + lv.z * yk.z + lv.w * yk.w;
+            else s[u] += lv.x * yk.x + lv.y * yk.y;
+          }
+        }
       }
-      s = wave_sum(s);
-      if (lane == 0) tbuf[rr] = s;
-    }
-    {  // LT tile of this diagonal block
-      const uint4* src = reinterpret_cast<const uint4*>(dTb + (int64_t)jb * TILE * TILE);
-      uint4* dst = reinterpret_cast<uint4*>(tile);
-      constexpr int NV = 128 * 128 * sizeof(T) / 16;
-      for (int v = tid; v < NV; v += 256) dst[v] = src[v];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const T t = wave_sum(s[u]);
+        if (lane == 0) tv[rr + 4 * u] = t;
+      }
     }
     __syncthreads();
-    T rq = T(0);
-    if (tid < TILE) rq = y[row0 + tid] - tbuf[tid];
-    for (int c = 0; c < TILE; ++c) {
-      if (tid == c) cur[c & 1] = rq / tile[c * 128 + c];
-      __syncthreads();
-      const T yc = cur[c & 1];
-      if (tid == c) rq = yc;
-      else if (tid > c && tid < TILE) rq -= yc * tile[c * 128 + tid];  // LT[c][q] = L[q][c]
-    }
-    if (tid < TILE) y[row0 + tid] = rq;
+    if (tid < TILE) tv[tid] = yv[row0 + tid] - tv[tid];
+    __syncthreads();
+    if (wave == 0) panel_forward<T>(tile, tv, ubuf, lane);
+    __syncthreads();
+    if (tid < TILE) yv[row0 + tid] = tv[tid];
     __syncthreads();
   }
+  for (int k = tid; k < n; k += 256) y[(int64_t)b * ldv + k] = yv[k];
+}
 
-  // ---- backward: L^T x = y ----
+// L^T x = y : right-looking from the last block row; every block row of L is streamed once
+template <typename T>
+__global__ void __launch_bounds__(256)
+chol_bwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* __restrict__ yin, T* __restrict__ x,
+                int n, int64_t ld, int64_t ldv, int ntiles) {
+  using C = CT<T>;
+  using V = typename C::V;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);
+  const int npad = ntiles * TILE;
+  T* z = tile + 128 * C::LDM;  // [npad]
+  T* xb = z + npad;            // [128] current block
+  T* ubuf = xb + 128;          // [32]
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const T* Lb = L + (int64_t)b * ld * ld;
+  for (int k = tid; k < npad; k += 256) z[k] = k < n ? yin[(int64_t)b * ldv + k] : T(0);
+  __syncthreads();
   for (int jb = ntiles - 1; jb >= 0; --jb) {
-    const int row0 = jb * TILE;
-    const int valid = min(TILE, n - row0);
-    {
-      const uint4* src = reinterpret_cast<const uint4*>(dTb + (int64_t)jb * TILE * TILE);
-      uint4* dst = reinterpret_cast<uint4*>(tile);
-      constexpr int NV = 128 * 128 * sizeof(T) / 16;
-      for (int v = tid; v < NV; v += 256) dst[v] = src[v];
-    }
+    const int row0 = jb * TILE, valid = min(TILE, n - row0);
+    panel_g2l<T>(panel + ((int64_t)b * ntiles + jb) * TILE * TILE, tile, tid);
+    if (tid < TILE) xb[tid] = z[row0 + tid];
     __syncthreads();
-    // x_c = (z_c - sum_{q>c} L[q][c] x_q) / L[c][c] ; column c of L == row c of LT: thread q holds x_q
-    // right-looking in reverse: after x_c is final, z_q -= L[c][q] x_c for q < c, L[c][q] = LT[q][c]
-    T zq = T(0);
-    if (tid < TILE) zq = y[row0 + tid];
-    for (int c = TILE - 1; c >= 0; --c) {
-      if (tid == c) cur[c & 1] = zq / tile[c * 128 + c];
-      __syncthreads();
-      const T xc = cur[c & 1];
-      if (tid == c) zq = xc;
-      else if (tid < c) zq -= xc * tile[tid * 128 + c];
-    }
-    if (tid < TILE) y[row0 + tid] = zq;  // now x for this block
+    if (wave == 0) panel_backward<T>(tile, xb, ubuf, lane);
     __syncthreads();
-    // z[0:row0] -= L[row0: row0+valid, 0:row0]^T x_block   (thread per column, coalesced rows)
-    for (int k = tid; k < row0; k += 256) {
-      T s = T(0);
-      for (int rr = 0; rr < valid; ++rr) s += Lb[(int64_t)(row0 + rr) * ld + k] * y[row0 + rr];
-      y[k] -= s;
+    if (tid < TILE) z[row0 + tid] = xb[tid];
+    // z[0:row0] -= L[row0 : row0 + valid, 0:row0]^T x_block : a thread owns VEC consecutive columns,
+    // rows unrolled by 8 (independent 16-byte loads in flight), x broadcast from LDS
+    for (int k = tid * C::VEC; k < row0; k += 256 * C::VEC) {
+      T s[4] = {T(0), T(0), T(0), T(0)};
+      const T* Lk = Lb + (int64_t)row0 * ld + k;
+      int rr = 0;
+      for (; rr + 8 <= valid; rr += 8) {
+        V lv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lv[u] = *reinterpret_cast<const V*>(Lk + (int64_t)(rr + u) * ld);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const T xv = xb[rr + u];
+          if constexpr (sizeof(T) == 4) {
+            s[0] += lv[u].x * xv; s[1] += lv[u].y * xv; s[2] += lv[u].z * xv; s[3] += lv[u].w * xv;
+          } else {
+            s[0] += lv[u].x * xv; s[1] += lv[u].y * xv;
+          }
+        }
+      }
+      for (; rr < valid; ++rr) {
+        const V lv = *reinterpret_cast<const V*>(Lk + (int64_t)rr * ld);
+        const T xv = xb[rr];
+        if constexpr (sizeof(T) == 4) {
+          s[0] += lv.x * xv; s[1] += lv.y * xv; s[2] += lv.z * xv; s[3] += lv.w * xv;
+        } else {
+          s[0] += lv.x * xv; s[1] += lv.y * xv;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < C::VEC; ++u) z[k + u] -= s[u];
     }
     __syncthreads();
   }
-  for (int k = tid; k < n; k += 256) x[(int64_t)b * ldv + k] = y[k];
+  for (int k = tid; k < n; k += 256) x[(int64_t)b * ldv + k] = z[k];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -608,44 +895,63 @@ lm_accept_kernel(const T* __restrict__ delta, const T* __restrict__ g, int64_t l
   }
 }
 
-template <typename T>
-static size_t diag_smem() {
-  size_t stage = (size_t)128 * CT<T>::LDT * sizeof(T);
-  size_t canon = Engine<T>::canonical_lds_bytes;
-  return (stage > canon ? stage : canon) + 4 * 128 * sizeof(T);
-}
-template <typename T>
-static size_t offdiag_smem() {
-  size_t stage = (size_t)2 * 128 * CT<T>::LDT * sizeof(T);
-  size_t canon = Engine<T>::canonical_lds_bytes;
-  size_t lt = (size_t)(128 * 128 + 128) * sizeof(T);
-  size_t m = stage > canon ? stage : canon;
-  return m > lt ? m : lt;
-}
+constexpr size_t LDS_LIMIT = 160 * 1024;
 
 template <typename T>
 static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damping, int ellipsoidal, double eps,
-                       void* L, void* diagT, int32_t* info, hipStream_t st) {
+                       void* L, void* panel, int32_t* info, const void* rhs, void* y, int64_t ldv, hipStream_t st) {
   const int ntiles = (n + TILE - 1) / TILE;
-  static bool attr_set = false;
-  if (!attr_set) {
+  const size_t dsm = DiagSmem<T>::bytes(rhs ? ntiles * TILE : 0);
+  if (dsm > LDS_LIMIT) return fail("thx_chol_factor: n too large for the fused forward substitution (LDS)");
+  static size_t attr_diag = 0;
+  static bool attr_off = false;
+  if (dsm > attr_diag) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)diag_smem<T>());
+                        (int)dsm);
+    attr_diag = dsm;
+  }
+  if (!attr_off) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_kernel<T>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)offdiag_smem<T>());
-    attr_set = true;
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)OffdiagSmem<T>::bytes);
+    attr_off = true;
   }
   hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)B, st);
   const int Bpad = (B + 7) / 8 * 8;
   for (int j = 0; j < ntiles; ++j) {
-    hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(B), dim3(256), diag_smem<T>(), st, (const T*)H, (T*)L, (T*)diagT,
-                       (const T*)damping, ellipsoidal, (T)eps, info, n, ld, j, ntiles);
+    hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(B), dim3(256), dsm, st, (const T*)H, (T*)L, (T*)panel,
+                       (const T*)damping, ellipsoidal, (T)eps, info, n, ld, j, ntiles, (const T*)rhs, (T*)y, ldv);
     const int nrt = ntiles - 1 - j;
     if (nrt > 0)
-      hipLaunchKernelGGL(chol_offdiag_kernel<T>, dim3(Bpad * nrt), dim3(256), offdiag_smem<T>(), st, (const T*)H,
-                         (T*)L, (const T*)diagT, n, ld, j, ntiles, nrt, B);
+      hipLaunchKernelGGL(chol_offdiag_kernel<T>, dim3(Bpad * nrt), dim3(256), OffdiagSmem<T>::bytes, st, (const T*)H,
+                         (T*)L, (const T*)panel, n, ld, j, ntiles, nrt, B);
   }
   return check_launch("thx_chol_factor");
+}
+
+template <typename T>
+static int solve_impl(const void* L, int64_t ld, int n, int B, const void* panel, const void* rhs, void* x,
+                      int64_t ldv, bool forward, bool backward, hipStream_t st) {
+  const int ntiles = (n + TILE - 1) / TILE;
+  const size_t sm = solve_smem<T>(ntiles * TILE);
+  if (sm > LDS_LIMIT) return fail("thx_chol_solve: n too large for the LDS plan");
+  static size_t attr = 0;
+  if (sm > attr) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)sm);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_bwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)sm);
+    attr = sm;
+  }
+  const T* src = (const T*)rhs;
+  if (forward) {
+    hipLaunchKernelGGL(chol_fwd_kernel<T>, dim3(B), dim3(256), sm, st, (const T*)L, (const T*)panel, src, (T*)x, n, ld,
+                       ldv, ntiles);
+    src = (const T*)x;  // the backward pass then runs in place
+  }
+  if (backward)
+    hipLaunchKernelGGL(chol_bwd_kernel<T>, dim3(B), dim3(256), sm, st, (const T*)L, (const T*)panel, src, (T*)x, n, ld,
+                       ldv, ntiles);
+  return check_launch("thx_chol_solve");
 }
 
 }  // namespace thx
@@ -654,42 +960,56 @@ using namespace thx;
 
 extern "C" {
 
-int thx_chol_factor(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
-                    double damping_eps, void* L, void* diagT, int32_t* info, int dtype, void* stream) {
-  if (!H || !L || !diagT || !info) return fail("thx_chol_factor: null pointer");
+static int check_factor_args(const void* H, const void* L, const void* panel, const void* info, int n, int B,
+                             int64_t ld) {
+  if (!H || !L || !panel || !info) return fail("thx_chol_factor: null pointer");
   if (n <= 0 || B <= 0 || ld < n || (ld % 32) != 0) return fail("thx_chol_factor: need n>0, B>0, ld>=n, ld%32==0");
   if (n % 2) return fail("thx_chol_factor: n must be even");
+  return 0;
+}
+
+int thx_chol_factor(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
+                    double damping_eps, void* L, void* Winv, int32_t* info, int dtype, void* stream) {
+  if (int r = check_factor_args(H, L, Winv, info, n, B, ld)) return r;
   THX_DISPATCH(dtype,
-               return factor_impl<float>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, diagT, info,
+               return factor_impl<float>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, nullptr,
+                                         nullptr, 0, as_stream(stream)),
+               return factor_impl<double>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, nullptr,
+                                          nullptr, 0, as_stream(stream)));
+  return 0;
+}
+
+int thx_chol_factor_forward(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
+                            double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y,
+                            int64_t ldv, int dtype, void* stream) {
+  if (int r = check_factor_args(H, L, Winv, info, n, B, ld)) return r;
+  if (!rhs || !y || ldv < n) return fail("thx_chol_factor_forward: rhs / y / ldv");
+  if (rhs == y) return fail("thx_chol_factor_forward: y must not alias rhs");
+  THX_DISPATCH(dtype,
+               return factor_impl<float>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
                                          as_stream(stream)),
-               return factor_impl<double>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, diagT, info,
+               return factor_impl<double>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
                                           as_stream(stream)));
   return 0;
 }
 
-int thx_chol_solve(const void* L, int64_t ld, int32_t n, int32_t B, const void* diagT, const void* rhs, void* x,
-                   int64_t ldv, int dtype, void* stream) {
-  if (!L || !diagT || !rhs || !x) return fail("thx_chol_solve: null pointer");
+static int solve_dispatch(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs, void* x,
+                          int64_t ldv, bool fwd, bool bwd, int dtype, void* stream) {
+  if (!L || !Winv || !rhs || !x) return fail("thx_chol_solve: null pointer");
   if (n <= 0 || B <= 0 || ld < n || ldv < n) return fail("thx_chol_solve: bad sizes");
-  const int ntiles = (n + TILE - 1) / TILE;
-  THX_DISPATCH(
-      dtype,
-      {
-        const size_t sm = (size_t)(128 * 128 + ntiles * TILE + 128 + 2) * sizeof(float);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(chol_solve_kernel<float>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL(chol_solve_kernel<float>, dim3(B), dim3(256), sm, as_stream(stream), (const float*)L,
-                           (const float*)diagT, (const float*)rhs, (float*)x, n, ld, ldv, ntiles);
-      },
-      {
-        const size_t sm = (size_t)(128 * 128 + ntiles * TILE + 128 + 2) * sizeof(double);
-        if (sm > 160 * 1024) return fail("thx_chol_solve: n too large for the f64 LDS plan");
-        hipFuncSetAttribute(reinterpret_cast<const void*>(chol_solve_kernel<double>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        hipLaunchKernelGGL(chol_solve_kernel<double>, dim3(B), dim3(256), sm, as_stream(stream), (const double*)L,
-                           (const double*)diagT, (const double*)rhs, (double*)x, n, ld, ldv, ntiles);
-      });
-  return check_launch("thx_chol_solve");
+  THX_DISPATCH(dtype, return solve_impl<float>(L, ld, n, B, Winv, rhs, x, ldv, fwd, bwd, as_stream(stream)),
+               return solve_impl<double>(L, ld, n, B, Winv, rhs, x, ldv, fwd, bwd, as_stream(stream)));
+  return 0;
+}
+
+int thx_chol_solve(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs, void* x,
+                   int64_t ldv, int dtype, void* stream) {
+  return solve_dispatch(L, ld, n, B, Winv, rhs, x, ldv, true, true, dtype, stream);
+}
+
+int thx_chol_solve_backward(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* y, void* x,
+                            int64_t ldv, int dtype, void* stream) {
+  return solve_dispatch(L, ld, n, B, Winv, y, x, ldv, false, true, dtype, stream);
 }
 
 int thx_diag(const void* H, int64_t ld, int32_t n, int32_t B, void* d, int64_t ldv, int dtype, void* stream) {

@@ -150,17 +150,30 @@ class HipKernels:
                                             lie_eps(dt), _lib.stream_ptr(poses.device)), "thx_se3_retract")
 
     # ---- dense solver ---------------------------------------------------------------------------
-    def chol_factor(self, H, n, damping, ellipsoidal, damping_eps, L, diagT, info):
+    def chol_factor(self, H, n, damping, ellipsoidal, damping_eps, L, panels, info, rhs=None, y=None):
+        """L L^T = H + damping.  With rhs/y the forward substitution y = L^-1 rhs is fused in."""
         B, ld = H.shape[0], H.shape[-1]
-        _lib.check(self.lib.thx_chol_factor(_lib.ptr(H), ld, n, B, _lib.ptr(damping), int(bool(ellipsoidal)),
-                                            float(damping_eps), _lib.ptr(L), _lib.ptr(diagT), _lib.ptr(info),
-                                            _lib.dtype_code(H.dtype), _lib.stream_ptr(H.device)), "thx_chol_factor")
+        common = (_lib.ptr(H), ld, n, B, _lib.ptr(damping), int(bool(ellipsoidal)), float(damping_eps), _lib.ptr(L),
+                  _lib.ptr(panels), _lib.ptr(info))
+        if rhs is None:
+            _lib.check(self.lib.thx_chol_factor(*common, _lib.dtype_code(H.dtype), _lib.stream_ptr(H.device)),
+                       "thx_chol_factor")
+        else:
+            _lib.check(self.lib.thx_chol_factor_forward(*common, _lib.ptr(rhs), _lib.ptr(y), rhs.stride(0),
+                                                        _lib.dtype_code(H.dtype), _lib.stream_ptr(H.device)),
+                       "thx_chol_factor_forward")
 
-    def chol_solve(self, L, n, diagT, rhs, x):
+    def chol_solve(self, L, n, panels, rhs, x):
         B, ld = L.shape[0], L.shape[-1]
-        _lib.check(self.lib.thx_chol_solve(_lib.ptr(L), ld, n, B, _lib.ptr(diagT), _lib.ptr(rhs), _lib.ptr(x),
+        _lib.check(self.lib.thx_chol_solve(_lib.ptr(L), ld, n, B, _lib.ptr(panels), _lib.ptr(rhs), _lib.ptr(x),
                                            rhs.stride(0), _lib.dtype_code(L.dtype), _lib.stream_ptr(L.device)),
                    "thx_chol_solve")
+
+    def chol_solve_backward(self, L, n, panels, y, x):
+        B, ld = L.shape[0], L.shape[-1]
+        _lib.check(self.lib.thx_chol_solve_backward(_lib.ptr(L), ld, n, B, _lib.ptr(panels), _lib.ptr(y), _lib.ptr(x),
+                                                    y.stride(0), _lib.dtype_code(L.dtype), _lib.stream_ptr(L.device)),
+                   "thx_chol_solve_backward")
 
     def diag(self, H, n, d):
         B, ld = H.shape[0], H.shape[-1]

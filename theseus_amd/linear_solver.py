@@ -40,7 +40,7 @@ class HipCholeskySolver(LinearSolver):
         super().__init__(objective, linearization_cls, linearization_kwargs)
         self.linearization: HipLinearization = self.linearization
         self.K = self.linearization.K
-        self.L = self.diagT = self.info = None
+        self.L = self.panels = self.info = self._y = None
         self._lam = None
 
     def _ensure_buffers(self):
@@ -50,13 +50,16 @@ class HipCholeskySolver(LinearSolver):
             B = H.shape[0]
             nt = (lin.n + _lib.THX_TILE - 1) // _lib.THX_TILE
             self.L = torch.zeros_like(H)
-            self.diagT = torch.empty(B, nt, _lib.THX_TILE, _lib.THX_TILE, dtype=H.dtype, device=H.device)
+            self.panels = torch.empty(B, nt, _lib.THX_TILE, _lib.THX_TILE, dtype=H.dtype, device=H.device)
+            self._y = torch.empty(B, lin.n, dtype=H.dtype, device=H.device)
             self.info = torch.zeros(B, dtype=torch.int32, device=H.device)
             self._lam = torch.empty(B, dtype=H.dtype, device=H.device)
 
     def factorize(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
-                  damping_eps: float = 1e-8):
-        """L L^T = AtA (+ damping); keeps L for later solves (the implicit backward re-uses it)."""
+                  damping_eps: float = 1e-8, rhs: Optional[torch.Tensor] = None):
+        """L L^T = AtA (+ damping); keeps L and the solve panels for later solves (the implicit backward
+        re-uses them).  With ``rhs`` the forward substitution L y = rhs is fused into the factorisation
+        (no extra pass over L) and y is returned."""
         lin = self.linearization
         if lin.H is None:
             raise RuntimeError("linearize() must be called before solve().")
@@ -65,15 +68,19 @@ class HipCholeskySolver(LinearSolver):
         if damping is not None:
             lam = self._lam
             if isinstance(damping, torch.Tensor):
-                lam.copy_(damping.to(lam.dtype).expand(lam.shape[0]) if damping.ndim else damping.to(lam.dtype).expand(lam.shape[0]))
+                lam.copy_(damping.to(lam.dtype).expand(lam.shape[0]))
             else:
                 lam.fill_(float(damping))
-        self.K.chol_factor(lin.H, lin.n, lam, ellipsoidal_damping, damping_eps, self.L, self.diagT, self.info)
+        y = self._y if rhs is not None else None
+        self.K.chol_factor(lin.H, lin.n, lam, ellipsoidal_damping, damping_eps, self.L, self.panels, self.info,
+                           rhs=rhs, y=y)
+        return y
 
     def solve_with_factor(self, rhs: torch.Tensor) -> torch.Tensor:
+        """(L L^T)^-1 rhs with the cached factor (forward + backward substitution kernels)."""
         rhs = rhs.contiguous()
         x = torch.empty_like(rhs)
-        self.K.chol_solve(self.L, self.linearization.n, self.diagT, rhs, x)
+        self.K.chol_solve(self.L, self.linearization.n, self.panels, rhs, x)
         return x
 
     def check_info(self):
@@ -90,8 +97,9 @@ class HipCholeskySolver(LinearSolver):
               damping_eps: float = 1e-8, check_info: bool = True, **kwargs) -> torch.Tensor:
         if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
             raise ValueError("Damping must be a float or a 1-D tensor.")
-        self.factorize(damping, ellipsoidal_damping, damping_eps)
-        delta = self.solve_with_factor(self.linearization.g)
+        y = self.factorize(damping, ellipsoidal_damping, damping_eps, rhs=self.linearization.g)
+        delta = torch.empty_like(y)
+        self.K.chol_solve_backward(self.L, self.linearization.n, self.panels, y, delta)
         if check_info:
             self.check_info()
         return delta

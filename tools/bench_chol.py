@@ -39,6 +39,12 @@ def timed(fn):
 
 fmin, favg = timed(lambda: K.chol_factor(H, n, lam, False, 1e-8, L, diagT, info))
 smin, savg = timed(lambda: K.chol_solve(L, n, diagT, rhs, x))
+y = torch.empty_like(rhs)
+x2 = torch.empty_like(rhs)
+ffmin, ffavg = timed(lambda: K.chol_factor(H, n, lam, False, 1e-8, L, diagT, info, rhs=rhs, y=y))
+bmin, bavg = timed(lambda: K.chol_solve_backward(L, n, diagT, y, x2))
+print(f"fused: factor+forward {ffavg:.2f} ms (min {ffmin:.2f}); backward {bavg:.2f} ms (min {bmin:.2f}) = "
+      f"{B * n * (n + 1) / 2 * dt.itemsize / bavg / 1e6:.0f} GB/s of tril(L); x2 vs x max diff {(x2 - x).abs().max().item():.3e}")
 fl = B * n ** 3 / 3
 print(f"n={n} B={B} {dt}: factor {favg:.2f} ms (min {fmin:.2f}) = {fl / favg / 1e9:.1f} TFLOP/s ; "
       f"solve {savg:.2f} ms (min {smin:.2f}) = {B * n * (n + 1) * dt.itemsize / savg / 1e6:.0f} GB/s of L (2 passes over tril)")
