@@ -12,7 +12,8 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtheseus_hip.so")
+# THESEUS_HIP_LIB overrides the in-tree build (kernel A/B experiments: tools/variants.sh)
+LIB_PATH = os.environ.get("THESEUS_HIP_LIB") or os.path.join(_HERE, "lib", "libtheseus_hip.so")
 
 THX_TILE = 128
 THX_ERR_CHUNKS = 16

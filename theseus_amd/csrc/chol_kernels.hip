@@ -67,25 +67,26 @@ struct CT<double> {
   using V = double2;
 };
 
-// sum of a value over the two lanes (l, l^32) that share a matrix row
-__device__ __forceinline__ float pair_sum(float x) {
-  unsigned u = __float_as_uint(x);
-  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+// 1/sqrt(d) from the hardware estimate + Newton steps (~1 ulp): the pivot scaling of the in-register
+// Cholesky sits on a 128-step latency chain, a correctly rounded sqrt + division is ~40 dependent
+// instructions, this is ~8.  L[c][c] = d * isq and L[r][c] = S[r][c] * isq stay mutually consistent.
+__device__ __forceinline__ float t_rsqrt(float d) {
+  float y = __builtin_amdgcn_rsqf(d);
+  return y * (1.5f - 0.5f * d * y * y);
 }
-__device__ __forceinline__ double pair_sum(double x) {
-  unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
-  auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+__device__ __forceinline__ double t_rsqrt(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * (1.5 - 0.5 * d * y * y);
+  return y * (1.5 - 0.5 * d * y * y);
 }
 
-__device__ __forceinline__ float t_rcp(float x) { return 1.0f / x; }
-__device__ __forceinline__ double t_rcp(double x) { return 1.0 / x; }
-
-// canonical register slot -> tile column: idx in [0,64), lane group g in {0,1}
-__device__ __forceinline__ constexpr int col_of(int idx, int g) {
-  return 32 * (idx >> 4) + 8 * ((idx & 15) >> 2) + 4 * g + (idx & 3);
+// lane broadcast through SGPRs (v_readlane_b32; `l` is wave uniform)
+__device__ __forceinline__ float bcast(float x, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
+__device__ __forceinline__ double bcast(double x, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l),
+                          __builtin_amdgcn_readlane(__double2loint(x), l));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -121,15 +122,6 @@ struct Engine<float> {
       }
     }
   }
-  // MFMA layout == canonical layout: a[16 cb + rho] = acc[cb][rho]
-  static __device__ __forceinline__ void canonical(const Acc& acc, float* a, float* /*lds*/, int /*wave*/, int /*lane*/) {
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a[16 * cb + r] = acc.v[cb][r];
-  }
-  static constexpr size_t canonical_lds_bytes = 0;
-
   // ---- native-layout helpers: lane (rl = lane&31, g = lane>>5) of wave w holds tile row 32w + rl,
   //      register rho of block cb <-> tile column 32cb + 8(rho>>2) + 4g + (rho&3)
   // acc <- tile - acc   (tile: an H tile staged in LDS, row stride 132)
@@ -170,6 +162,42 @@ struct Engine<float> {
       D.v[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, Bs.v[Tt][4 * q + 3], D.v[S], 0, 0, 0);
     }
   }
+
+  // ---- 32x32 block helpers for the diagonal-tile factorisation (operands in the LDS tile, row stride 132).
+  //      Blk D[m][n]: a lane holds ONE row n = lane&31 of the block, register rho <-> column m = 8(rho>>2) + 4g + (rho&3)
+  using Blk = f32x16;
+  static __device__ __forceinline__ void blk_zero(Blk& d) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = 0.f;
+  }
+  static __device__ __forceinline__ void blk_load(Blk& d, const float* blk, int lane) {
+    const float* p = blk + (lane & 31) * 132 + 4 * (lane >> 5);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(p + 8 * q);
+      d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
+    }
+  }
+  static __device__ __forceinline__ void blk_store(const Blk& d, float* blk, int lane, float sign) {
+    float* p = blk + (lane & 31) * 132 + 4 * (lane >> 5);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(p + 8 * q) =
+          make_float4(sign * d[4 * q], sign * d[4 * q + 1], sign * d[4 * q + 2], sign * d[4 * q + 3]);
+  }
+  // D[m][n] += sum_k (asign * A[m][k]) * B[n][k]   (A, B: 32x32 blocks in LDS, rows m / n)
+  static __device__ __forceinline__ void blk_mma(const float* Ablk, const float* Bblk, Blk& d, int lane, float asign) {
+    const int o = (lane & 31) * 132 + 4 * (lane >> 5);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 fa = *reinterpret_cast<const float4*>(Ablk + o + 8 * q);
+      const float4 fb = *reinterpret_cast<const float4*>(Bblk + o + 8 * q);
+      d = __builtin_amdgcn_mfma_f32_32x32x2f32(asign * fa.x, fb.x, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_32x32x2f32(asign * fa.y, fb.y, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_32x32x2f32(asign * fa.z, fb.z, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_32x32x2f32(asign * fa.w, fb.w, d, 0, 0, 0);
+    }
+  }
 };
 
 template <>
@@ -203,32 +231,6 @@ struct Engine<double> {
       }
     }
   }
-  // f64 MFMA layout: D[i = (lane>>4) + 4 rho][j = lane&15]; with D = Arows-block x Brows-block^T this is
-  // C[r = 32w + 16h + (lane&15)][c = 16cb + 4 rho + (lane>>4)].  Re-shape to the canonical
-  // row-per-lane-pair layout through an LDS tile [128][LDC].
-  static __device__ __forceinline__ void canonical(const Acc& acc, double* a, double* lds, int wave, int lane) {
-    const int rl = lane & 15, kq = lane >> 4;
-    __syncthreads();  // staging buffers (aliased) no longer in use
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int cb = 0; cb < 8; ++cb)
-#pragma unroll
-        for (int rho = 0; rho < 4; ++rho)
-          lds[(32 * wave + 16 * h + rl) * 132 + 16 * cb + 4 * rho + kq] = acc.v[h][cb][rho];
-    __syncthreads();
-    const int r = 32 * wave + (lane & 31), g = lane >> 5;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const double2 x0 = *reinterpret_cast<const double2*>(lds + r * 132 + 8 * m + 4 * g);
-      const double2 x1 = *reinterpret_cast<const double2*>(lds + r * 132 + 8 * m + 4 * g + 2);
-      const int idx = 16 * (m >> 2) + 4 * (m & 3);
-      a[idx] = x0.x; a[idx + 1] = x0.y; a[idx + 2] = x1.x; a[idx + 3] = x1.y;
-    }
-    __syncthreads();
-  }
-  static constexpr size_t canonical_lds_bytes = (size_t)128 * 132 * sizeof(double);
-
   // ---- native-layout helpers: lane (rl = lane&15, kq = lane>>4) of wave w holds tile rows
   //      32w + 16h + rl (h = 0,1); register rho of block cb <-> tile column 16cb + 4rho + kq
   static __device__ __forceinline__ void rsub_lds(Acc& acc, const double* tile, int wave, int lane) {
@@ -267,21 +269,60 @@ struct Engine<double> {
           D.v[1][cp] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs.v[1][cb][rho], D.v[1][cp], 0, 0, 0);
         }
   }
+
+  // ---- 32x32 block helpers (see Engine<float>): Blk.v[mh][nh][rho] <-> row n = 16nh + (lane&15),
+  //      column m = 16mh + (lane>>4) + 4rho; LDS row stride 130
+  struct Blk {
+    f64x4 v[2][2];
+  };
+  static __device__ __forceinline__ void blk_zero(Blk& d) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d.v[a][b][i] = 0.0;
+  }
+  static __device__ __forceinline__ void blk_load(Blk& d, const double* blk, int lane) {
+    const int rl = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) d.v[mh][nh][rho] = blk[(16 * nh + rl) * 130 + 16 * mh + kq + 4 * rho];
+  }
+  static __device__ __forceinline__ void blk_store(const Blk& d, double* blk, int lane, double sign) {
+    const int rl = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) blk[(16 * nh + rl) * 130 + 16 * mh + kq + 4 * rho] = sign * d.v[mh][nh][rho];
+  }
+  static __device__ __forceinline__ void blk_mma(const double* Ablk, const double* Bblk, Blk& d, int lane, double asign) {
+    const int rl = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const double a0 = asign * Ablk[rl * 130 + 4 * kk + kq], a1 = asign * Ablk[(16 + rl) * 130 + 4 * kk + kq];
+      const double b0 = Bblk[rl * 130 + 4 * kk + kq], b1 = Bblk[(16 + rl) * 130 + 4 * kk + kq];
+      d.v[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, d.v[0][0], 0, 0, 0);
+      d.v[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, d.v[0][1], 0, 0, 0);
+      d.v[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, d.v[1][0], 0, 0, 0);
+      d.v[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, d.v[1][1], 0, 0, 0);
+    }
+  }
 };
 
 // Optional rider on the SYRK K-loop of chol_diag: the panel rows L_j,0:j pass through LDS anyway, so
 // t[r] = sum_k L[row0+r][k] y[k] (the forward-substitution update) costs 16 VALU FMAs per thread and
 // chunk in the shadow of the MFMAs.  Thread pair (2r, 2r+1) splits the chunk's k range in two.
-template <typename T>
-struct Gemv {
-  const T* y;  // LDS, y[0:K]
-  T part;      // this thread's partial sum
-};
-
 template <typename T, bool SAME, bool GEMV = false>
 __device__ __forceinline__ void kloop(const T* __restrict__ Arows, int validA, const T* __restrict__ Brows,
                                       int validB, int64_t ld, int K, T* sA, T* sB,
-                                      typename Engine<T>::Acc& acc, int tid, Gemv<T>* gv = nullptr) {
+                                      typename Engine<T>::Acc& acc, int tid, const T* gemv_y = nullptr,
+                                      T* gemv_part = nullptr) {
   using C = CT<T>;
   using V = typename C::V;
   const int lrow = tid >> 3, lc = tid & 7;
@@ -311,6 +352,7 @@ __device__ __forceinline__ void kloop(const T* __restrict__ Arows, int validA, c
     }
   };
   const int nk = K / C::KB;
+  T gsum = T(0);
   if (nk > 0) gload(0);
   for (int kc = 0; kc < nk; ++kc) {
     __syncthreads();
@@ -323,24 +365,25 @@ __device__ __forceinline__ void kloop(const T* __restrict__ Arows, int validA, c
     __syncthreads();
     if (kc + 1 < nk) gload((kc + 1) * C::KB);
     if constexpr (GEMV) {
-      if (gv) {
+      if (gemv_y) {
         constexpr int HALF = C::KB / 2;
         const V* rp = reinterpret_cast<const V*>(sA + (tid >> 1) * C::LDT + (tid & 1) * HALF);
-        const V* yp = reinterpret_cast<const V*>(gv->y + kc * C::KB + (tid & 1) * HALF);
-        T sum = gv->part;
+        const V* yp = reinterpret_cast<const V*>(gemv_y + kc * C::KB + (tid & 1) * HALF);
 #pragma unroll
         for (int i = 0; i < HALF / C::VEC; ++i) {
           const V a = rp[i], yv = yp[i];
           if constexpr (sizeof(T) == 4) {
-            sum += a.x * yv.x; sum += a.y * yv.y; sum += a.z * yv.z; sum += a.w * yv.w;
+            gsum += a.x * yv.x; gsum += a.y * yv.y; gsum += a.z * yv.z; gsum += a.w * yv.w;
           } else {
-            sum += a.x * yv.x; sum += a.y * yv.y;
+            gsum += a.x * yv.x; gsum += a.y * yv.y;
           }
         }
-        gv->part = sum;
       }
     }
     Engine<T>::chunk(sA, (SAME ? sA : sB) + 32 * wave * C::LDT, acc, lane);
+  }
+  if constexpr (GEMV) {
+    if (gemv_part) *gemv_part = gsum;
   }
 }
 
@@ -436,17 +479,66 @@ __device__ __forceinline__ void panel_backward(const T* M, T* vec, T* ubuf, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// chol_diag: SYRK + in-register Cholesky of the 128x128 diagonal tile of block column j, panel M_j,
+// 32x32 in-wave kernels of the diagonal-tile factorisation.  Straight-line code is kept SMALL and is
+// re-used by a run-time loop over the four sub-blocks: a fully unrolled 128-step factorisation is
+// ~120 KB of instructions, streams through the 64 KB instruction cache once per workgroup and runs at
+// L2 instruction-fetch latency (measured: 2700 cycles per 120-instruction step).
+// ------------------------------------------------------------------------------------------------
+// lane r (= lane & 31) holds row r: a[c] = S[r][c].  On exit a[c] = L[r][c] for c <= r (columns above the
+// diagonal are garbage).  Broadcasts go through SGPRs (v_readlane), no LDS round trips.  Returns the
+// 1-based index of the first non-positive pivot (0 = positive definite).
+template <typename T>
+__device__ __forceinline__ int potrf32(T (&a)[32]) {
+  int bad = 0;
+  static_for<32>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int c = decltype(ic)::value;
+    T d = bcast(a[c], c);
+    if (!(d > T(0))) {
+      if (bad == 0) bad = c + 1;
+      d = T(1);
+    }
+    const T isq = t_rsqrt(d);
+    a[c] *= isq;  // L[r][c]
+    static_for<31 - c>([&](auto iq) __attribute__((always_inline)) {
+      constexpr int q = c + 1 + decltype(iq)::value;
+      a[q] -= a[c] * bcast(a[c], q);  // S[r][q] -= L[r][c] L[q][c]
+    });
+  });
+  return bad;
+}
+
+// W = L^-1 for the 32x32 triangle held row-per-lane in a[]: lane j (= lane & 31) computes column j of W by
+// forward substitution on e_j, in fp64 whatever T is (the inverse is formed once and multiplies every
+// row tile below it), two interleaved partial sums to shorten the dependent chain.
+template <typename T>
+__device__ __forceinline__ void inv32(const T (&a)[32], double (&w)[32], int lane) {
+  const int j = lane & 31;
+  static_for<32>([&](auto ii) __attribute__((always_inline)) {
+    constexpr int i = decltype(ii)::value;
+    const double lii = (double)bcast(a[i], i);
+    double r = (double)(1.0f / (float)lii);
+    r = r * (2.0 - lii * r);
+    r = r * (2.0 - lii * r);
+    double s0 = (j == i) ? 1.0 : 0.0, s1 = 0.0;
+    static_for<i>([&](auto kk) __attribute__((always_inline)) {
+      constexpr int k = decltype(kk)::value;
+      const double lik = (double)bcast(a[k], i);  // L[i][k]
+      if constexpr (k & 1) s1 -= lik * w[k];
+      else s0 -= lik * w[k];
+    });
+    w[i] = (s0 + s1) * r;
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// chol_diag: SYRK + blocked Cholesky of the 128x128 diagonal tile of block column j, panel M_j,
 // fused forward substitution
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 struct DiagSmem {
-  static constexpr size_t stage = (size_t)128 * CT<T>::LDT * sizeof(T);
-  static constexpr size_t canon = Engine<T>::canonical_lds_bytes;
-  static constexpr size_t tile = (size_t)128 * CT<T>::LDM * sizeof(T);
-  static constexpr size_t region0 = (stage > canon ? stage : canon) > tile ? (stage > canon ? stage : canon) : tile;
-  // region0 | colbuf [4][128] T | dinv [128] double | vvec [128] T | ubuf [32] T | ybuf [ypad] T
-  static size_t bytes(int ypad) { return region0 + 4 * 128 * sizeof(T) + 128 * sizeof(double) + 160 * sizeof(T) + (size_t)ypad * sizeof(T); }
+  static constexpr size_t tile = (size_t)128 * CT<T>::LDM * sizeof(T);  // >= the K-loop staging buffer
+  // tile | vvec [128] T | ubuf [32] T | ybuf [ypad] T
+  static size_t bytes(int ypad) { return tile + 160 * sizeof(T) + (size_t)ypad * sizeof(T); }
 };
 
 template <typename T>
@@ -456,194 +548,149 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
                  const T* __restrict__ rhs, T* __restrict__ yout, int64_t ldv) {
   using C = CT<T>;
   using V = typename C::V;
+  using E = Engine<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* smem = reinterpret_cast<T*>(smem_raw);
+  T* tile = reinterpret_cast<T*>(smem_raw);  // [128][LDM]; its head doubles as the K-loop staging buffer
+  T* vvec = reinterpret_cast<T*>(smem_raw + DiagSmem<T>::tile);
+  T* ubuf = vvec + 128;
+  T* ybuf = ubuf + 32;
   const int b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t mat = (int64_t)b * ld * ld;
   const int row0 = j * TILE;
   const int valid = min(TILE, n - row0);
-  T* sA = smem;  // [128][LDT]; the f64 canonicalisation tile and the panel tile alias it
-  T* colbuf = reinterpret_cast<T*>(smem_raw + DiagSmem<T>::region0);  // [2][128] + dummy [2][128]
-  double* dinv = reinterpret_cast<double*>(colbuf + 4 * 128);
-  T* vvec = reinterpret_cast<T*>(dinv + 128);
-  T* ubuf = vvec + 128;
-  T* ybuf = ubuf + 32;
 
-  Gemv<T> gv{ybuf, T(0)};
   const bool fwd = rhs != nullptr;
   if (fwd)
     for (int k = tid; k < row0; k += 256) ybuf[k] = yout[(int64_t)b * ldv + k];  // y_0:j of earlier columns
 
-  typename Engine<T>::Acc acc;
-  Engine<T>::zero(acc);
-  kloop<T, true, true>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, row0, sA, nullptr, acc, tid,
-                       fwd ? &gv : nullptr);
+  typename E::Acc acc;
+  E::zero(acc);
+  T tpart = T(0);  // this thread's half of (L_j,0:j y)[tid >> 1]
+  kloop<T, true, true>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, row0, tile, nullptr, acc, tid,
+                       fwd ? ybuf : nullptr, &tpart);
 
-  T a[64];
-  Engine<T>::canonical(acc, a, smem, wave, lane);
-
-  const int r = 32 * wave + (lane & 31), g = lane >> 5;
-  const bool rvalid = r < valid;
-  const T* Hrow = H + mat + (int64_t)(row0 + r) * ld + row0;
-  const T lam = damping ? damping[b] : T(0);
-  // S = H_jj (+ damping on the diagonal) - acc ; identity padding outside the matrix
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    const int q0 = 8 * m + 4 * g;
-    const int idx = 16 * (m >> 2) + 4 * (m & 3);
-    T h[4] = {T(0), T(0), T(0), T(0)};
-    if (rvalid && q0 < valid) {  // valid is a multiple of 2 (n = 6P), ld % 32 == 0: the 16-B chunk is in bounds
-      if constexpr (sizeof(T) == 4) {
-        const V v = *reinterpret_cast<const V*>(Hrow + q0);
-        h[0] = v.x; h[1] = v.y; h[2] = v.z; h[3] = v.w;
-      } else {
-        const V v0 = *reinterpret_cast<const V*>(Hrow + q0);
-        const V v1 = *reinterpret_cast<const V*>(Hrow + q0 + 2);
-        h[0] = v0.x; h[1] = v0.y; h[2] = v1.x; h[3] = v1.y;
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int q = q0 + t;
-      T hv = h[t];
-      if (q == r) {
-        if (rvalid) {
-          if (damping) hv = ellipsoidal ? hv + (lam * hv + damping_eps) : hv + lam;
-        } else {
-          hv = T(1);
-        }
-      } else if (!rvalid || q >= valid) {
-        hv = T(0);
-      }
-      a[idx + t] = hv - a[idx + t];
-    }
-  }
-
-  // ---- in-register right-looking Cholesky, one barrier per column ----
-  int bad = 0;
-  static_for<TILE>([&](auto ic) __attribute__((always_inline)) {
-    constexpr int c = decltype(ic)::value;
-    constexpr int G = (c >> 2) & 1;
-    constexpr int I = 16 * (c >> 5) + 4 * ((c & 31) >> 3) + (c & 3);
-    T* cb = colbuf + (c & 1) * TILE;
-    // branch-free publish of column c: the non-owning lane group writes to a scratch half (keeps the
-    // whole factorisation one basic block -- with branches LLVM sinks the FMAs and spills the LDS reads)
-    cb[(g == G ? 0 : 2 * TILE) + r] = a[I];
-    __syncthreads();
-    T d = cb[c];
-    if (!(d > T(0))) {
-      if (bad == 0) bad = c + 1;
-      d = T(1);
-    }
-    const T sq = t_sqrt(d);
-    const T isq = t_rcp(sq);
-    const T lrc = cb[r] * isq;  // L[r][c]
-    const T s = lrc * isq;      // S[r][c] / d
-#pragma unroll
-    for (int m = (c >> 3); m < 16; ++m) {
-      const V* vp = reinterpret_cast<const V*>(cb + 8 * m + 4 * g);
-      T v[4];
-      if constexpr (sizeof(T) == 4) {
-        const V x = vp[0];
-        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-      } else {
-        const V x0 = vp[0], x1 = vp[1];
-        v[0] = x0.x; v[1] = x0.y; v[2] = x1.x; v[3] = x1.y;
-      }
-      const int idx = 16 * (m >> 2) + 4 * (m & 3);
-      if (8 * m > c) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) a[idx + t] -= s * v[t];
-      } else {  // chunk containing column c: only columns q > c
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const T se = (4 * g + t > (c & 7)) ? s : T(0);
-          a[idx + t] -= se * v[t];
-        }
-      }
-    }
-    a[I] = (g == G) ? lrc : a[I];
-    __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting later steps' LDS reads (spills)
-  });
-  if (bad != 0 && tid == 0 && info[b] == 0) info[b] = row0 + bad;  // every thread sees the same `bad`
-
-  // ---- L_jj -> LDS tile (zeros above the diagonal), coalesced store to L ----
-  T* tile = smem;  // [128][LDM]
-  __syncthreads();  // region0 is free (staging / canonical tile no longer read)
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    const int q0 = 8 * m + 4 * g;
-    const int idx = 16 * (m >> 2) + 4 * (m & 3);
-    T v[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = (q0 + t <= r) ? a[idx + t] : T(0);
-    if constexpr (sizeof(T) == 4) {
-      *reinterpret_cast<V*>(tile + r * C::LDM + q0) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-      *reinterpret_cast<V*>(tile + r * C::LDM + q0) = make_double2(v[0], v[1]);
-      *reinterpret_cast<V*>(tile + r * C::LDM + q0 + 2) = make_double2(v[2], v[3]);
-    }
-  }
+  // ---- S = H_jj (+ damping on the diagonal) - acc -> LDS tile; identity padding outside the matrix ----
+  __syncthreads();  // staging buffer is free
+  tile_g2l<T>(H + mat + (int64_t)row0 * ld + row0, ld, valid, valid, tile, tid);
   if (tid < TILE) vvec[tid] = (fwd && tid < valid) ? rhs[(int64_t)b * ldv + row0 + tid] : T(0);
   __syncthreads();
-  tile_l2g<T>(tile, L + mat + (int64_t)row0 * ld + row0, ld, valid, valid, tid);
-  if (tid < TILE) dinv[tid] = 1.0 / (double)tile[tid * C::LDM + tid];
-  // g_j - L_j,0:j y : thread pair (2r, 2r+1) holds the two halves of row r's sum
-  {
-    const T tsum = gv.part + __shfl_xor(gv.part, 1);
+  if (tid < TILE) {
+    T hv = tile[tid * C::LDM + tid];
+    if (tid < valid) {
+      if (damping) {
+        const T lam = damping[b];
+        hv = ellipsoidal ? hv + (lam * hv + damping_eps) : hv + lam;
+      }
+    } else {
+      hv = T(1);
+    }
+    tile[tid * C::LDM + tid] = hv;
+  }
+  {  // g_j - L_j,0:j y : thread pair (2r, 2r+1) holds the two halves of row r's sum
+    const T tsum = tpart + __shfl_xor(tpart, 1);
     if (fwd && (tid & 1) == 0) vvec[tid >> 1] -= tsum;
   }
   __syncthreads();
+  E::rsub_lds(acc, tile, wave, lane);   // acc <- tile - acc
+  E::store_lds(acc, tile, wave, lane);  // same lane, same addresses: no barrier in between
+  __syncthreads();
 
-  // ---- panel: wave s inverts the 32x32 triangle L_ss in fp64 (lane c < 32 owns column c of W_ss:
-  //      forward substitution on e_c, no cross-lane traffic), every thread negates its share of the
-  //      strictly-lower sub-blocks.  In place: a wave's reads of L_ss complete before its writes. ----
-  {
-    const int sb = wave, cc = lane & 31;
-    const T* Ls = tile + (32 * sb) * C::LDM + 32 * sb;
-    double w[32];
-    static_for<32>([&](auto ii) __attribute__((always_inline)) {
-      constexpr int i = decltype(ii)::value;
-      double sacc = (cc == i) ? 1.0 : 0.0;
-      static_for<i>([&](auto kk) __attribute__((always_inline)) {
-        constexpr int k = decltype(kk)::value;
-        sacc -= (double)Ls[i * C::LDM + k] * w[k];
-      });
-      w[i] = sacc * dinv[32 * sb + i];
-      // one row at a time: tie w[i] to a compiler barrier, otherwise all 496 LDS reads are issued first
-      // and the FMA chains sink below them (hundreds of spilled registers)
-      asm volatile("" : "+v"(w[i]) : : "memory");
-    });
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 32) {
-      T* Ws = tile + (32 * sb) * C::LDM + 32 * sb + cc;
+  // ---- blocked right-looking Cholesky on the LDS tile, 32-wide sub-blocks.  Afterwards the tile IS the
+  //      solve panel: W_ss = L_ss^-1 on the diagonal sub-blocks, -L_us below them. ----
+  for (int sb = 0; sb < 4; ++sb) {
+    T* Dss = tile + (32 * sb) * C::LDM + 32 * sb;
+    if (wave == 0) {
+      T a[32];
+      {
+        const V* rp = reinterpret_cast<const V*>(Dss + (lane & 31) * C::LDM);
 #pragma unroll
-      for (int i = 0; i < 32; ++i) Ws[i * C::LDM] = (T)w[i];
-    }
-    // negate: thread (row = tid >> 1, half) over columns [0, 32 * (row >> 5))
-    const int nr = tid >> 1, nh = tid & 1;
-    T* nrow = tile + nr * C::LDM;
-    for (int c = 4 * nh; c < 32 * (nr >> 5); c += 8) {
-      V* vp = reinterpret_cast<V*>(nrow + c);
-      if constexpr (sizeof(T) == 4) {
-        V v = vp[0];
-        vp[0] = make_float4(-v.x, -v.y, -v.z, -v.w);
-      } else {
-        V v0 = vp[0], v1 = vp[1];
-        vp[0] = make_double2(-v0.x, -v0.y);
-        vp[1] = make_double2(-v1.x, -v1.y);
+        for (int q = 0; q < 32 / C::VEC; ++q) {
+          const V v = rp[q];
+          if constexpr (sizeof(T) == 4) {
+            a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+          } else {
+            a[2 * q] = v.x; a[2 * q + 1] = v.y;
+          }
+        }
+      }
+#ifdef THX_X_NOPOTRF
+      const int bad = 0;
+#else
+      const int bad = potrf32<T>(a);
+#endif
+      if (bad != 0 && lane == 0 && info[b] == 0) info[b] = row0 + 32 * sb + bad;
+      // L_ss straight to global memory: one 32-element row per lane, zeros above the diagonal
+      const int lr = lane & 31, grow = 32 * sb + lr;
+      if (lane < 32 && grow < valid) {
+        V* gp = reinterpret_cast<V*>(L + mat + (int64_t)(row0 + grow) * ld + row0 + 32 * sb);
+#pragma unroll
+        for (int q = 0; q < 32 / C::VEC; ++q) {
+          if constexpr (sizeof(T) == 4) {
+            gp[q] = make_float4(4 * q <= lr ? a[4 * q] : 0.f, 4 * q + 1 <= lr ? a[4 * q + 1] : 0.f,
+                                4 * q + 2 <= lr ? a[4 * q + 2] : 0.f, 4 * q + 3 <= lr ? a[4 * q + 3] : 0.f);
+          } else {
+            gp[q] = make_double2(2 * q <= lr ? a[2 * q] : 0.0, 2 * q + 1 <= lr ? a[2 * q + 1] : 0.0);
+          }
+        }
+      }
+      double w[32];
+#ifdef THX_X_NOINV
+#pragma unroll
+      for (int i = 0; i < 32; ++i) w[i] = (double)a[i];
+#else
+      inv32<T>(a, w, lane);
+#endif
+      if (lane < 32) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) Dss[i * C::LDM + lr] = (T)w[i];  // W[i][lr]; zero for i < lr
       }
     }
+    __syncthreads();
+    if (sb == 3) break;
+    // L_us = S_us W_ss^T for the sub-blocks below (one per wave), stored negated
+    {
+      const int u = sb + 1 + wave;
+      if (u < 4) {
+        T* Dus = tile + (32 * u) * C::LDM + 32 * sb;
+        typename E::Blk X;
+        E::blk_zero(X);
+        E::blk_mma(Dss, Dus, X, lane, T(1));
+        E::blk_store(X, Dus, lane, T(-1));
+      }
+    }
+    __syncthreads();
+    // trailing update S_uv -= L_us L_vs^T, sb < v <= u: blocks dealt round-robin to the waves
+    {
+      int idx = 0;
+      for (int u = sb + 1; u < 4; ++u)
+        for (int v = sb + 1; v <= u; ++v, ++idx) {
+          if ((idx & 3) != wave) continue;
+          T* Duv = tile + (32 * u) * C::LDM + 32 * v;
+          typename E::Blk D;
+          E::blk_load(D, Duv, lane);
+          // tile(v,s) = -L_vs is negated on load, tile(u,s) = -L_us:  D += (+L_vs)(-L_us)^T
+          E::blk_mma(tile + (32 * v) * C::LDM + 32 * sb, tile + (32 * u) * C::LDM + 32 * sb, D, lane, T(-1));
+          E::blk_store(D, Duv, lane, T(1));
+        }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  {  // panel -> global (full 128 x 128, row stride 128)
-    T* P = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
+
+  // ---- outputs: strictly-lower sub-blocks of L_jj (= -tile), the panel, y_j ----
+  {
     constexpr int CPR = TILE / C::VEC, RPP = 256 / CPR;
     const int c = (tid % CPR) * C::VEC;
-    for (int rr = tid / CPR; rr < TILE; rr += RPP)
-      *reinterpret_cast<uint4*>(P + rr * TILE + c) = *reinterpret_cast<const uint4*>(tile + rr * C::LDM + c);
+    T* Lt = L + mat + (int64_t)row0 * ld + row0;
+    T* P = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
+    for (int rr = tid / CPR; rr < TILE; rr += RPP) {
+      const V v = *reinterpret_cast<const V*>(tile + rr * C::LDM + c);
+      *reinterpret_cast<V*>(P + rr * TILE + c) = v;
+      if ((rr >> 5) > (c >> 5) && rr < valid) {
+        if constexpr (sizeof(T) == 4) *reinterpret_cast<V*>(Lt + (int64_t)rr * ld + c) = make_float4(-v.x, -v.y, -v.z, -v.w);
+        else *reinterpret_cast<V*>(Lt + (int64_t)rr * ld + c) = make_double2(-v.x, -v.y);
+      }
+    }
   }
   if (fwd) {
     if (wave == 0) panel_forward<T>(tile, vvec, ubuf, lane);
@@ -719,6 +766,114 @@ chol_offdiag_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restr
   Engine<T>::store_lds(X, tile, wave, lane);
   __syncthreads();
   tile_l2g<T>(tile, L + mat + (int64_t)row0 * ld + col0, ld, validB, validA, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// chol_offdiag, fp32 fast path.  Same arithmetic as the generic kernel, but nothing of the epilogue
+// waits on memory: the H tile is prefetched into registers in the accumulator layout and the ten
+// lower sub-blocks of the panel (40 KB, XOR-swizzled so that unpadded 32x32 blocks read conflict
+// free) are copied to LDS BEFORE the K-loop; the result is stored straight from the registers.
+// LDS: staging 36 KB + panel 40 KB -> two workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+constexpr int OFF32_STAGE_FLOATS = 2 * 128 * 36;
+constexpr int OFF32_SMEM = (OFF32_STAGE_FLOATS + 10 * 1024) * 4;
+
+// D.block(S) += Pc[block (S,Tt)] * Bs.block(Tt)^T with the swizzled compact panel
+template <int S, int Tt>
+__device__ __forceinline__ void sub_mma_sw(const float* Pc, const Engine<float>::Acc& Bs, Engine<float>::Acc& D,
+                                           int lane) {
+  const int rl = lane & 31, g = lane >> 5;
+  const float* brow = Pc + (S * (S + 1) / 2 + Tt) * 1024 + rl * 32;
+  const int sw = (rl >> 1) & 7;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 fa = *reinterpret_cast<const float4*>(brow + (((2 * q + g) ^ sw) << 2));
+    D.v[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, Bs.v[Tt][4 * q + 0], D.v[S], 0, 0, 0);
+    D.v[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, Bs.v[Tt][4 * q + 1], D.v[S], 0, 0, 0);
+    D.v[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, Bs.v[Tt][4 * q + 2], D.v[S], 0, 0, 0);
+    D.v[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, Bs.v[Tt][4 * q + 3], D.v[S], 0, 0, 0);
+  }
+}
+
+__global__ void __launch_bounds__(256, 2)
+chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, const float* __restrict__ panel, int n,
+                        int64_t ld, int j, int ntiles, int nrow_tiles, int B) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int b = (slot / nrow_tiles) * 8 + xcd;
+  const int i = j + 1 + (slot % nrow_tiles);
+  if (b >= B) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t mat = (int64_t)b * ld * ld;
+  const int col0 = j * TILE, row0 = i * TILE;
+  const int validB = min(TILE, n - row0);  // j is never the last tile: all 128 columns are inside the matrix
+  float* sA = smem;
+  float* sB = smem + 128 * 36;
+  float* Pc = smem + OFF32_STAGE_FLOATS;
+
+  // ---- prefetch: panel sub-blocks (s,t), t <= s, then the H tile ----
+  uint4 pr[10];
+  {
+    const float* Pn = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
+    const int pi = tid >> 3, pc = tid & 7;
+    constexpr int SB[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3}, TB[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+      pr[k] = *reinterpret_cast<const uint4*>(Pn + (32 * SB[k] + pi) * TILE + 32 * TB[k] + 4 * pc);
+  }
+  const int r = 32 * wave + (lane & 31), g = lane >> 5;
+  const bool rvalid = r < validB;
+  float4 hr[4][4];
+  {
+    const float* Hrow = H + mat + (int64_t)(row0 + (rvalid ? r : 0)) * ld + col0 + 4 * g;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hr[cb][q] = *reinterpret_cast<const float4*>(Hrow + 32 * cb + 8 * q);
+  }
+  {
+    const int pi = tid >> 3, pc = tid & 7;
+    float* dst = Pc + pi * 32 + ((pc ^ ((pi >> 1) & 7)) << 2);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) *reinterpret_cast<uint4*>(dst + k * 1024) = pr[k];
+  }
+
+  Engine<float>::Acc P;
+  Engine<float>::zero(P);
+  kloop<float, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, col0, sA, sB, P, tid);
+  // P = H_ij - sum (rows outside the matrix: zero)
+#pragma unroll
+  for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 h = hr[cb][q];
+      P.v[cb][4 * q + 0] = (rvalid ? h.x : 0.f) - P.v[cb][4 * q + 0];
+      P.v[cb][4 * q + 1] = (rvalid ? h.y : 0.f) - P.v[cb][4 * q + 1];
+      P.v[cb][4 * q + 2] = (rvalid ? h.z : 0.f) - P.v[cb][4 * q + 2];
+      P.v[cb][4 * q + 3] = (rvalid ? h.w : 0.f) - P.v[cb][4 * q + 3];
+    }
+  __syncthreads();  // panel copy visible (also when the K-loop had no iterations)
+  Engine<float>::Acc X;
+  Engine<float>::zero(X);
+  static_for<4>([&](auto is) __attribute__((always_inline)) {
+    constexpr int sb = decltype(is)::value;
+    static_for<sb>([&](auto it) __attribute__((always_inline)) {
+      constexpr int tb = decltype(it)::value;
+      sub_mma_sw<sb, tb>(Pc, X, P, lane);  // P_s += (-L_st) X_t
+    });
+    sub_mma_sw<sb, sb>(Pc, P, X, lane);    // X_s  = W_ss P_s
+  });
+  if (rvalid) {
+    float* Lrow = L + mat + (int64_t)(row0 + r) * ld + col0 + 4 * g;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(Lrow + 32 * cb + 8 * q) =
+            make_float4(X.v[cb][4 * q], X.v[cb][4 * q + 1], X.v[cb][4 * q + 2], X.v[cb][4 * q + 3]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -913,6 +1068,8 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   if (!attr_off) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_kernel<T>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)OffdiagSmem<T>::bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f32_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, OFF32_SMEM);
     attr_off = true;
   }
   hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)B, st);
@@ -921,9 +1078,14 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(B), dim3(256), dsm, st, (const T*)H, (T*)L, (T*)panel,
                        (const T*)damping, ellipsoidal, (T)eps, info, n, ld, j, ntiles, (const T*)rhs, (T*)y, ldv);
     const int nrt = ntiles - 1 - j;
-    if (nrt > 0)
-      hipLaunchKernelGGL(chol_offdiag_kernel<T>, dim3(Bpad * nrt), dim3(256), OffdiagSmem<T>::bytes, st, (const T*)H,
-                         (T*)L, (const T*)panel, n, ld, j, ntiles, nrt, B);
+    if (nrt > 0) {
+      if constexpr (sizeof(T) == 4)
+        hipLaunchKernelGGL(chol_offdiag_f32_kernel, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, st, (const float*)H,
+                           (float*)L, (const float*)panel, n, ld, j, ntiles, nrt, B);
+      else
+        hipLaunchKernelGGL(chol_offdiag_kernel<T>, dim3(Bpad * nrt), dim3(256), OffdiagSmem<T>::bytes, st,
+                           (const T*)H, (T*)L, (const T*)panel, n, ld, j, ntiles, nrt, B);
+    }
   }
   return check_launch("thx_chol_factor");
 }

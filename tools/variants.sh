@@ -1,0 +1,16 @@
+#!/bin/bash
+# Build A/B variants of libtheseus_hip.so with extra -D flags into scratch/variants/<name>.so
+# usage: tools/variants.sh name1:"-DFLAG1 -DFLAG2" name2:"..."
+set -e
+ROOT=$(cd $(dirname $0)/.. && pwd)
+OUT=$ROOT/scratch/variants; mkdir -p $OUT
+for spec in "$@"; do
+  name=${spec%%:*}; flags=${spec#*:}
+  for f in pg_kernels chol_kernels; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-pass-failed $flags -c $ROOT/theseus_amd/csrc/$f.hip -o $OUT/${name}_$f.o &
+  done
+  wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/$name.so $OUT/${name}_pg_kernels.o $OUT/${name}_chol_kernels.o
+  rm -f $OUT/${name}_*.o
+  echo built $OUT/$name.so
+done
