@@ -143,6 +143,9 @@ def main():
     objective = syn.build_pose_graph_objective(edges, P, dtype=dtype, device=device)
     opt = th.LevenbergMarquardt(objective, linear_solver_cls=th.HipCholeskySolver, max_iterations=K_iters,
                                 abs_err_tolerance=0.0, rel_err_tolerance=0.0, step_size=1.0)
+    if world > 1:
+        from theseus_amd.sharding import DistBatchReducer
+        opt.reducer = DistBatchReducer()  # batch-global predicates over all shards (one tiny all-reduce / iteration)
     layer = th.TheseusLayer(opt)
     timer = KernelTimer(opt.linear_solver.K)
     tensors = syn.make_pose_graph_tensors(edges, P, B, dtype=dtype, device=device, seed=1234 + rank)
@@ -160,15 +163,13 @@ def main():
             opt.set_params(max_iterations=W)
             layer.forward(inputs, optimizer_kwargs=okw)
         opt.set_params(max_iterations=K_iters)
-        gathered = None
-        if world > 1:
-            gathered = torch.empty(world, P, B, 3, 4, dtype=dtype, device=device)
         barrier()
         timer.enabled = True
         t0 = time.perf_counter()
         sol, info = layer.forward(inputs, optimizer_kwargs=dict(track_err_history=True, **okw))
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, opt.linear_solver.linearization.packed.tensors.poses)
+        if world > 1:  # the one data-path collective: re-collect the solved poses on every rank (RCCL over xGMI)
+            from theseus_amd.sharding import gather_solution
+            gathered = gather_solution(opt.linear_solver.linearization.packed.tensors.poses)
         barrier()
         dt = time.perf_counter() - t0
         timer.enabled = False

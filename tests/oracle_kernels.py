@@ -1,0 +1,94 @@
+"""TEST-ONLY stand-in for theseus_amd.kernels.HipKernels, built on the CPU oracle.
+
+It exists so that the host logic that does not need a GPU -- batch sharding across ranks, the LM control
+flow with its batch-global predicates -- can run under ``-m "not gpu"`` (gloo, world_size 2).  The product
+never imports this module: theseus_amd has no CPU path (theseus_amd/kernels.py)."""
+import torch
+
+from oracle import lie
+from oracle import pose_graph as opg
+
+
+class OracleKernels:
+    name = "oracle-cpu-standin"
+
+    # ---- helpers -------------------------------------------------------------------------------
+    @staticmethod
+    def _problem(s, t, poses=None):
+        h = s.host
+        bm = lambda x: x.transpose(0, 1)  # noqa: E731  entity-major (X,B,...) -> batch-major (B,X,...)
+        p = opg.PGProblem(num_poses=h.num_poses,
+                          edges=torch.stack([torch.from_numpy(h.edge_i), torch.from_numpy(h.edge_j)], 1).long(),
+                          meas=bm(t.meas), w_between=bm(t.w_between),
+                          prior_idx=torch.from_numpy(h.prior_pose).long(),
+                          prior_target=bm(t.prior_target), w_prior=bm(t.w_prior))
+        return p, bm(t.poses if poses is None else poses)
+
+    # ---- SE3 elementwise -----------------------------------------------------------------------
+    def se3_exp(self, xi, jac=False):
+        assert not jac
+        return lie.se3_exp(xi)
+
+    def se3_log(self, X, jac=False):
+        xi, J = lie.se3_log_jlog(X)
+        return (xi, J) if jac else xi
+
+    def se3_compose(self, X, Y):
+        return lie.se3_compose(X, Y)
+
+    def se3_inverse(self, X):
+        return lie.se3_inverse(X)
+
+    def se3_adjoint(self, X):
+        return lie.se3_adjoint(X)
+
+    # ---- pose graph ------------------------------------------------------------------------------
+    def pg_assemble(self, s, t, H, g, poses=None):
+        p, x = self._problem(s, t, poses)
+        A, b = opg.dense_linearize(p, x)
+        AtA, Atb = opg.hessian(A, b)
+        n = p.n
+        H[:, :n, :n] = torch.tril(AtA)
+        g.copy_(Atb.squeeze(2))
+
+    def pg_error(self, s, t, partials, err, poses=None):
+        p, x = self._problem(s, t, poses)
+        err.copy_(opg.error_metric(p, x))
+
+    def se3_retract(self, poses, delta, step, ignore_mask, out):
+        x = poses.transpose(0, 1)
+        m = ignore_mask.bool() if ignore_mask is not None else None
+        out.copy_(opg.retract(x, delta * step, ignore_mask=m).transpose(0, 1))
+
+    # ---- dense solver ------------------------------------------------------------------------------
+    def chol_factor(self, H, n, damping, ellipsoidal, damping_eps, L, panels, info, rhs=None, y=None):
+        Hl = torch.tril(H[:, :n, :n])
+        A = Hl + torch.tril(Hl, -1).transpose(1, 2)
+        if damping is not None:
+            d = A.diagonal(dim1=1, dim2=2)
+            add = damping.view(-1, 1) * d + damping_eps if ellipsoidal else damping.view(-1, 1).expand_as(d)
+            A = A + torch.diag_embed(add)
+        Lc, inf = torch.linalg.cholesky_ex(A)
+        L[:, :n, :n] = Lc
+        info.copy_(inf.to(info.dtype))
+        if rhs is not None:
+            y.copy_(torch.linalg.solve_triangular(Lc, rhs.unsqueeze(2), upper=False).squeeze(2))
+
+    def chol_solve_backward(self, L, n, panels, y, x):
+        x.copy_(torch.linalg.solve_triangular(L[:, :n, :n].transpose(1, 2), y.unsqueeze(2), upper=True).squeeze(2))
+
+    def chol_solve(self, L, n, panels, rhs, x):
+        x.copy_(torch.cholesky_solve(rhs.unsqueeze(2), L[:, :n, :n]).squeeze(2))
+
+    def diag(self, H, n, d):
+        d.copy_(H[:, :n, :n].diagonal(dim1=1, dim2=2))
+
+    def lm_accept(self, delta, g, H, n, damping, prev_err, new_err, ellipsoidal, accept, down, up, reject):
+        dmp = damping.view(-1, 1)
+        if ellipsoidal:
+            dmp = H[:, :n, :n].diagonal(dim1=1, dim2=2) * dmp
+        den = (delta * (dmp * delta + g)).sum(1) / 2
+        rho = (prev_err - new_err) / den
+        rej = rho <= accept
+        damping.copy_(torch.where(rej, damping * up, damping / down).clamp(opg.MIN_DAMPING, opg.MAX_DAMPING))
+        reject.copy_(rej.to(reject.dtype))

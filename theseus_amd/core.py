@@ -23,6 +23,7 @@ class Variable:
     """Named tensor with a leading batch dimension (theseus/core/variable.py:14-112)."""
 
     _ids = count(0)
+    _global_updates = 0  # bumped by every update()/to(): lets packed buffers skip per-variable stamp scans
 
     def __init__(self, tensor: torch.Tensor, name: Optional[str] = None):
         self._id = next(Variable._ids)
@@ -46,6 +47,7 @@ class Variable:
         else:
             self.tensor = data
         self._num_updates += 1
+        Variable._global_updates += 1
 
     @property
     def shape(self):
@@ -66,6 +68,7 @@ class Variable:
     def to(self, *args, **kwargs):
         self.tensor = self.tensor.to(*args, **kwargs)
         self._num_updates += 1
+        Variable._global_updates += 1
 
     def copy(self, new_name: Optional[str] = None) -> "Variable":
         return self.__class__(tensor=self.tensor.clone(), name=new_name or f"{self.name}_copy")

@@ -23,6 +23,7 @@ import torch
 from .core import Objective
 from .linear_solver import HipCholeskySolver, LinearSolver
 from .linearization import HipLinearization, Linearization
+from .sharding import LocalBatchReducer
 
 
 class NonlinearOptimizerStatus(Enum):
@@ -68,13 +69,6 @@ class NonlinearOptimizerParams:
     rel_err_tolerance: float
     max_iterations: int
     step_size: float
-
-
-class LocalBatchReducer:
-    """The three batch-global predicates of the reference loop, single process."""
-
-    def all_any_mean(self, flags: torch.Tensor) -> torch.Tensor:
-        return flags
 
 
 class NonlinearLeastSquares(abc.ABC):
@@ -188,22 +182,26 @@ class NonlinearLeastSquares(abc.ABC):
                 packed.retract(delta, p.step_size, converged, spare)
                 packed.error_metric(poses=spare, out=err_new)
                 reject = self._complete_step(delta, err_new, last_err, step_size=p.step_size, **kwargs)
-                # ---- the only host sync of the iteration: [solver failed, all rejected, any rejected] ----
-                fl = [self.linear_solver.info.ne(0).any().view(1)]
+                # ---- the only host sync of the iteration: [solver failed | all rejected, any rejected], over
+                #      the GLOBAL batch (self.reducer all-reduces across shards when the batch is sharded) ----
+                any_f = [self.linear_solver.info.ne(0)]
+                all_f = []
                 if reject is not None:
                     rb = reject.bool()
-                    fl += [rb.all().view(1), rb.any().view(1)]
-                fl = torch.cat(fl).tolist()
-                if fl[0]:
+                    any_f.append(rb)
+                    all_f.append(rb)
+                any_r, all_r = self.reducer.decide(any_f, all_f)
+                if any_r[0]:
                     try:
                         self.linear_solver.check_info()
+                        raise RuntimeError("the linear solve failed on another shard of the batch")
                     except RuntimeError as run_err:
                         warnings.warn(f"There was an error while running the linear optimizer. "
                                       f"Original error message: {run_err}.", RuntimeWarning)
                     info.status[:] = NonlinearOptimizerStatus.FAIL
                     break
                 if reject is not None:
-                    all_rej, any_rej = bool(fl[1]), bool(fl[2])
+                    all_rej, any_rej = all_r[0], any_r[1]
                     if all_rej:
                         all_reject_attempts += 1
                         if all_reject_attempts < self._MAX_ALL_REJECT_ATTEMPTS:
@@ -217,12 +215,12 @@ class NonlinearLeastSquares(abc.ABC):
                         else:
                             err = err_new.clone()
                         old = packed.tensors.poses
-                        packed.set_poses(spare)
+                        packed.set_poses(spare, repoint=False)
                         spare = old
                 else:
                     err = err_new.clone()
                     old = packed.tensors.poses
-                    packed.set_poses(spare)
+                    packed.set_poses(spare, repoint=False)
                     spare = old
                 all_reject_attempts = 0
                 if err_hist is not None:
@@ -234,21 +232,23 @@ class NonlinearLeastSquares(abc.ABC):
                 if verbose:
                     print(f"Nonlinear optimizer. Iteration: {it + 1}. Error: {err.mean().item()}")
                 if need_conv:
-                    if bool(err.abs().mean() < p.abs_err_tolerance):
+                    if self.reducer.mean_abs(err) < p.abs_err_tolerance:
                         converged = torch.ones(B, dtype=torch.bool, device=dev)
                     else:
                         converged = self._check_convergence(err, last_err)
                     conv_iter = torch.where(converged & (conv_iter < 0), torch.full_like(conv_iter, it + 1), conv_iter)
-                    if bool(converged.all()):
+                    if self.reducer.decide([], [converged])[1][0]:
                         info.last_err = err
                         break
                 last_err = err
                 info.last_err = err
                 if end_iter_callback is not None:
+                    packed.flush_variables()
                     end_iter_callback(self, info, delta, it)
                 it += 1
                 info.iters_done = it
 
+            packed.flush_variables()
             # ---- bookkeeping, one device->host copy ----
             if converged is not None:
                 cm = converged.cpu().numpy()

@@ -59,6 +59,8 @@ class PackedPoseGraph:
         self.version = objective.current_version
         self.tensors: Optional[PGTensors] = None
         self._stamp = None
+        self._global_stamp = -1
+        self._vars_stale = False
         self._scratch = {}
 
     # ---- packing ----------------------------------------------------------------------------
@@ -86,9 +88,14 @@ class PackedPoseGraph:
 
     def sync(self, force: bool = False):
         """(Re)pack the variable tensors into the device buffers if any variable changed."""
+        from .core import Variable
+        if not force and self.tensors is not None and Variable._global_updates == self._global_stamp:
+            return  # nobody called Variable.update()/to() since the last look: O(1) fast path
         stamp = self._current_stamp()
         if not force and self.tensors is not None and stamp == self._stamp:
+            self._global_stamp = Variable._global_updates
             return
+        self.flush_variables()
         obj = self.objective
         obj._resolve_batch_size()
         B = obj.batch_size
@@ -105,15 +112,27 @@ class PackedPoseGraph:
 
     def _repoint_variables(self):
         """Make every optimisation variable's tensor a view of the packed pose buffer."""
+        from .core import Variable
         poses = self.tensors.poses
         for k, v in enumerate(self.pose_vars):
             v.tensor = poses[k]
         self._stamp = self._current_stamp()
+        self._global_stamp = Variable._global_updates
+        self._vars_stale = False
 
-    def set_poses(self, poses: torch.Tensor):
-        """Adopt a new packed pose buffer (after an accepted LM step)."""
+    def set_poses(self, poses: torch.Tensor, repoint: bool = True):
+        """Adopt a new packed pose buffer (after an accepted LM step).  ``repoint=False`` defers the
+        O(#variables) Python re-pointing of the Variable objects (the optimiser loop flushes before anybody
+        can look: callbacks, loop exit)."""
         self.tensors.poses = poses
-        self._repoint_variables()
+        if repoint:
+            self._repoint_variables()
+        else:
+            self._vars_stale = True
+
+    def flush_variables(self):
+        if self._vars_stale and self.tensors is not None:
+            self._repoint_variables()
 
     # ---- scratch ------------------------------------------------------------------------------
     def _buf(self, key, shape, dtype=None):
