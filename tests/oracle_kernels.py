@@ -55,6 +55,16 @@ class OracleKernels:
         p, x = self._problem(s, t, poses)
         err.copy_(opg.error_metric(p, x))
 
+    def pg_jacobians(self, s, t, J0, J1, eb, Jp, ep, poses=None):
+        p, x = self._problem(s, t, poses)
+        i, j = p.edges[:, 0], p.edges[:, 1]
+        if p.edges.shape[0]:
+            a, b, e = opg.between_jac_err(x[:, i], x[:, j], p.meas, p.w_between)
+            J0.copy_(a.transpose(0, 1)); J1.copy_(b.transpose(0, 1)); eb.copy_(e.transpose(0, 1))
+        if p.prior_idx.shape[0]:
+            a, e = opg.local_jac_err(p.prior_target, x[:, p.prior_idx], p.w_prior)
+            Jp.copy_(a.transpose(0, 1)); ep.copy_(e.transpose(0, 1))
+
     def se3_retract(self, poses, delta, step, ignore_mask, out):
         x = poses.transpose(0, 1)
         m = ignore_mask.bool() if ignore_mask is not None else None

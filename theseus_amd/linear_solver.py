@@ -30,15 +30,11 @@ class LinearSolver(abc.ABC):
         pass
 
 
-class HipCholeskySolver(LinearSolver):
-    def __init__(self, objective: Objective, linearization_cls: Optional[Type[Linearization]] = None,
-                 linearization_kwargs: Optional[Dict[str, Any]] = None, check_singular: bool = False, **kwargs):
-        linearization_cls = linearization_cls or HipLinearization
-        if not (isinstance(linearization_cls, type) and issubclass(linearization_cls, HipLinearization)):
-            raise RuntimeError("HipCholeskySolver only works with theseus_amd.HipLinearization, "
-                               f"but {linearization_cls} was provided.")
-        super().__init__(objective, linearization_cls, linearization_kwargs)
-        self.linearization: HipLinearization = self.linearization
+class HipCholeskyCore:
+    """Back-end half of the solver (buffers, factor, solves), shared by theseus_amd's mirror class below and
+    the adapter for the real ``theseus`` (theseus_amd/plugin.py)."""
+
+    def _core_init(self):
         self.K = self.linearization.K
         self.L = self.panels = self.info = self._y = None
         self._lam = None
@@ -92,9 +88,7 @@ class HipCholeskySolver(LinearSolver):
                 f"input is not positive-definite (the leading minor of order {int(self.info[b])} is not "
                 "positive-definite).")
 
-    # theseus/optimizer/linear/dense_solver.py:84-123
-    def solve(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
-              damping_eps: float = 1e-8, check_info: bool = True, **kwargs) -> torch.Tensor:
+    def _solve(self, damping, ellipsoidal_damping, damping_eps, check_info) -> torch.Tensor:
         if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
             raise ValueError("Damping must be a float or a 1-D tensor.")
         y = self.factorize(damping, ellipsoidal_damping, damping_eps, rhs=self.linearization.g)
@@ -103,3 +97,19 @@ class HipCholeskySolver(LinearSolver):
         if check_info:
             self.check_info()
         return delta
+
+
+class HipCholeskySolver(HipCholeskyCore, LinearSolver):
+    def __init__(self, objective: Objective, linearization_cls: Optional[Type[Linearization]] = None,
+                 linearization_kwargs: Optional[Dict[str, Any]] = None, check_singular: bool = False, **kwargs):
+        linearization_cls = linearization_cls or HipLinearization
+        if not (isinstance(linearization_cls, type) and issubclass(linearization_cls, HipLinearization)):
+            raise RuntimeError("HipCholeskySolver only works with theseus_amd.HipLinearization, "
+                               f"but {linearization_cls} was provided.")
+        LinearSolver.__init__(self, objective, linearization_cls, linearization_kwargs)
+        self._core_init()
+
+    # theseus/optimizer/linear/dense_solver.py:84-123
+    def solve(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
+              damping_eps: float = 1e-8, check_info: bool = True, **kwargs) -> torch.Tensor:
+        return self._solve(damping, ellipsoidal_damping, damping_eps, check_info)

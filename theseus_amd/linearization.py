@@ -105,9 +105,11 @@ class Linearization(abc.ABC):
         pass
 
 
-class HipLinearization(Linearization):
-    def __init__(self, objective: Objective, ordering: Optional[VariableOrdering] = None, kernels=None, **kwargs):
-        super().__init__(objective, ordering)
+class HipLinearizationCore:
+    """Back-end half of the linearization, independent of which ``Linearization`` ABC it is mixed into:
+    theseus_amd's mirror (below) or the real ``theseus.optimizer.Linearization`` (theseus_amd/plugin.py)."""
+
+    def _core_init(self, objective, kernels=None):
         if [v.name for v in self.ordering] != list(objective.optim_vars.keys()):
             raise NotImplementedError("HipLinearization uses the default (insertion) variable ordering.")
         self.packed = packed_for(objective, kernels)
@@ -134,8 +136,8 @@ class HipLinearization(Linearization):
             self.H = torch.zeros(B, self.ld, self.ld, dtype=dt, device=dev)  # zero once: fixed pattern
             self.g = torch.empty(B, self.n, dtype=dt, device=dev)
 
-    def _linearize_jacobian_impl(self):
-        """Materialise dense A (B,m,n) and b (B,m) -- for tests / foreign consumers only
+    def _materialize_A_b(self):
+        """Dense A (B,m,n) and b (B,m) -- for tests / foreign consumers only
         (dense_linearization.py:29-56); the optimiser never calls this."""
         p = self.packed
         J0, J1, eb, Jp, ep = p.jacobian_blocks()
@@ -153,7 +155,7 @@ class HipLinearization(Linearization):
             b[:, r:r + 6] = -ep[k]
         self._A, self._b = A, b
 
-    def _linearize_hessian_impl(self, _detach_hessian: bool = False):
+    def _assemble(self):
         self._ensure_buffers()
         self.packed.assemble(self.H, self.g)
         self._AtA_cache = None
@@ -162,26 +164,21 @@ class HipLinearization(Linearization):
     @property
     def A(self):
         if self._A is None:
-            self._linearize_jacobian_impl()
+            self._materialize_A_b()
         return self._A
 
     @property
     def b(self):
         if self._b is None:
-            self._linearize_jacobian_impl()
+            self._materialize_A_b()
         return self._b
 
-    @property
-    def AtA(self) -> torch.Tensor:
+    def _full_AtA(self) -> torch.Tensor:
         """Full symmetric (B,n,n); materialised only when read (LM needs just Atb / diagonal_scaling)."""
         if self._AtA_cache is None:
             Hl = torch.tril(self.H[:, :self.n, :self.n])
             self._AtA_cache = Hl + torch.tril(Hl, -1).transpose(1, 2)
         return self._AtA_cache
-
-    @property
-    def Atb(self) -> torch.Tensor:
-        return self.g.unsqueeze(2)
 
     def Av(self, v: torch.Tensor) -> torch.Tensor:
         return self.A.bmm(v.unsqueeze(2)).squeeze(2)
@@ -193,3 +190,23 @@ class HipLinearization(Linearization):
 
     def diagonal_scaling(self, v: torch.Tensor) -> torch.Tensor:
         return self.diagonal() * v
+
+
+class HipLinearization(HipLinearizationCore, Linearization):
+    def __init__(self, objective: Objective, ordering: Optional[VariableOrdering] = None, kernels=None, **kwargs):
+        Linearization.__init__(self, objective, ordering)
+        self._core_init(objective, kernels)
+
+    def _linearize_jacobian_impl(self):
+        self._materialize_A_b()
+
+    def _linearize_hessian_impl(self, _detach_hessian: bool = False):
+        self._assemble()
+
+    @property
+    def AtA(self) -> torch.Tensor:
+        return self._full_AtA()
+
+    @property
+    def Atb(self) -> torch.Tensor:
+        return self.g.unsqueeze(2)

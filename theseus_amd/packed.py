@@ -12,7 +12,7 @@ from typing import List, Optional
 import torch
 
 from .compiler import PoseGraphStructure
-from .core import SE3, Between, Difference, Objective
+from .core import Objective, Variable
 from .kernels import PGTensors, default_kernels, round_up, _lib
 
 ERR_CHUNKS = _lib.THX_ERR_CHUNKS
@@ -22,28 +22,63 @@ class UnsupportedObjective(NotImplementedError):
     pass
 
 
+# The packer recognises objects by the reference's CLASS NAMES, so that it accepts theseus_amd's mirror classes
+# and the real ``theseus`` ones alike (theseus_amd/plugin.py plugs this back end into the reference's own loop).
+def _kind(obj) -> str:
+    names = {c.__name__ for c in type(obj).__mro__}
+    for k in ("SE3", "Between"):
+        if k in names:
+            return k
+    if "Local" in names or "Difference" in names:
+        return "Difference"
+    return type(obj).__name__
+
+
+def _weight_diag6(w) -> torch.Tensor:
+    """(Bw, 6) sqrt-information diagonal of a Scale/DiagonalCostWeight (theseus/core/cost_weight.py:60-139)."""
+    if hasattr(w, "diagonal6"):
+        return w.diagonal6()
+    names = {c.__name__ for c in type(w).__mro__}
+    if "ScaleCostWeight" in names:
+        return w.scale.tensor.view(-1, 1).expand(-1, 6)
+    if "DiagonalCostWeight" in names:
+        d = w.diagonal.tensor
+        if d.shape[1] != 6:
+            raise ValueError("SE3 costs need a 6-dimensional DiagonalCostWeight.")
+        return d
+    raise UnsupportedObjective(f"HIP backend supports Scale/DiagonalCostWeight; got {type(w).__name__}. "
+                               "There is no CPU/eager fallback.")
+
+
+def _aux_vars(x):
+    a = x.aux_vars
+    return list(a() if callable(a) else a)
+
+
 class PackedPoseGraph:
     def __init__(self, objective: Objective, kernels=None):
         self.objective = objective
         self.K = kernels or default_kernels()
-        self.pose_vars: List[SE3] = []
+        self.pose_vars = []
         for v in objective.optim_vars.values():
-            if not isinstance(v, SE3):
+            if _kind(v) != "SE3":
                 raise UnsupportedObjective(
                     f"HIP backend supports SE3 optimisation variables; got {type(v).__name__} ({v.name}). "
                     "There is no CPU/eager fallback.")
             self.pose_vars.append(v)
         index = {v.name: k for k, v in enumerate(self.pose_vars)}
         edges, priors, e_rows, p_rows = [], [], [], []
-        self.edge_costs: List[Between] = []
-        self.prior_costs: List[Difference] = []
+        self.edge_costs = []
+        self.prior_costs = []
         row = 0
         for c in objective.cost_functions.values():
-            if isinstance(c, Between):
+            if type(c).__name__ == "RobustCostFunction":
+                raise UnsupportedObjective("HIP backend: RobustCostFunction is not fused yet. No CPU/eager fallback.")
+            if _kind(c) == "Between":
                 edges.append((index[c.v0.name], index[c.v1.name]))
                 e_rows.append(row)
                 self.edge_costs.append(c)
-            elif isinstance(c, Difference):
+            elif _kind(c) == "Difference":
                 priors.append(index[c.var.name])
                 p_rows.append(row)
                 self.prior_costs.append(c)
@@ -58,6 +93,8 @@ class PackedPoseGraph:
         self.ld = round_up(self.n, 32)
         self.version = objective.current_version
         self.tensors: Optional[PGTensors] = None
+        # the O(1) "nothing changed" test relies on theseus_amd.core.Variable's global update counter
+        self._own_variables = all(isinstance(v, Variable) for v in self._tracked())
         self._stamp = None
         self._global_stamp = -1
         self._vars_stale = False
@@ -69,10 +106,10 @@ class PackedPoseGraph:
             yield v
         for c in self.edge_costs:
             yield c.measurement
-            yield from c.weight.aux_vars()
+            yield from _aux_vars(c.weight)
         for c in self.prior_costs:
             yield c.target
-            yield from c.weight.aux_vars()
+            yield from _aux_vars(c.weight)
 
     def _current_stamp(self):
         return tuple(v._num_updates for v in self._tracked())
@@ -88,8 +125,8 @@ class PackedPoseGraph:
 
     def sync(self, force: bool = False):
         """(Re)pack the variable tensors into the device buffers if any variable changed."""
-        from .core import Variable
-        if not force and self.tensors is not None and Variable._global_updates == self._global_stamp:
+        if (not force and self.tensors is not None and self._own_variables
+                and Variable._global_updates == self._global_stamp):
             return  # nobody called Variable.update()/to() since the last look: O(1) fast path
         stamp = self._current_stamp()
         if not force and self.tensors is not None and stamp == self._stamp:
@@ -104,15 +141,14 @@ class PackedPoseGraph:
         E, Kp = self.structure.num_edges, self.structure.num_priors
         empty = lambda *s: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
         meas = self._stack([c.measurement.tensor for c in self.edge_costs], B) if E else empty(0, 1, 3, 4)
-        wb = self._stack([c.weight.diagonal6() for c in self.edge_costs], B) if E else empty(0, 1, 6)
+        wb = self._stack([_weight_diag6(c.weight) for c in self.edge_costs], B) if E else empty(0, 1, 6)
         tgt = self._stack([c.target.tensor for c in self.prior_costs], B) if Kp else empty(0, 1, 3, 4)
-        wp = self._stack([c.weight.diagonal6() for c in self.prior_costs], B) if Kp else empty(0, 1, 6)
+        wp = self._stack([_weight_diag6(c.weight) for c in self.prior_costs], B) if Kp else empty(0, 1, 6)
         self.tensors = PGTensors(poses=poses, meas=meas, w_between=wb, prior_target=tgt, w_prior=wp)
         self._repoint_variables()
 
     def _repoint_variables(self):
         """Make every optimisation variable's tensor a view of the packed pose buffer."""
-        from .core import Variable
         poses = self.tensors.poses
         for k, v in enumerate(self.pose_vars):
             v.tensor = poses[k]
@@ -205,7 +241,7 @@ class PackedPoseGraph:
 
 def packed_for(objective: Objective, kernels=None) -> PackedPoseGraph:
     """Get (or build) the packed representation attached to an objective."""
-    p = objective._packed
+    p = getattr(objective, "_packed", None)
     if p is None or p.version != objective.current_version or (kernels is not None and p.K is not kernels):
         p = PackedPoseGraph(objective, kernels)
         objective._packed = p
