@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32, help="problems in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--parity-sample", type=int, default=8, help="problems in the exact-parity sub-sample")
+    ap.add_argument("--implicit", action="store_true",
+                    help="BASELINE.json configs[4]: forward LM + implicit backward (one backward linear solve) through "
+                         "TheseusLayer; measurement tensors require grad; a step = one LM iteration of the forward")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,15 +161,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    with torch.no_grad():
+    bwd_ms = None
+    if args.implicit:
+        for k, v in inputs.items():
+            if k.startswith("EDGE_SE3__"):
+                v.requires_grad_(True)
+        okw = dict(okw, backward_mode="implicit")
+    with torch.set_grad_enabled(args.implicit):
         if W > 0:
-            opt.set_params(max_iterations=W)
+            opt.set_params(max_iterations=max(W, 2) if args.implicit else W)
             layer.forward(inputs, optimizer_kwargs=okw)
         opt.set_params(max_iterations=K_iters)
         barrier()
         timer.enabled = True
         t0 = time.perf_counter()
         sol, info = layer.forward(inputs, optimizer_kwargs=dict(track_err_history=True, **okw))
+        if args.implicit:  # backward: retract VJP + ONE linear solve with the cached factor + cost VJP
+            loss = sum(v.sum() for v in sol.values())
+            eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            eb0.record()
+            loss.backward()
+            eb1.record()
+            torch.cuda.synchronize()
+            bwd_ms = eb0.elapsed_time(eb1)
         if world > 1:  # the one data-path collective: re-collect the solved poses on every rank (RCCL over xGMI)
             from theseus_amd.sharding import gather_solution
             gathered = gather_solution(opt.linear_solver.linearization.packed.tensors.poses)
@@ -207,7 +224,10 @@ def main():
                          "traffic": None, "flops_per_launch": flops_per_launch, "avg_launch_ms": fac["avg_ms"]},
             "phases_ms_per_call": {k: round(v["avg_ms"], 4) for k, v in phases.items()},
         }
-        if args.cpu_sample > 0:
+        if args.implicit:
+            result["config"]["workload"] += " + implicit backward through TheseusLayer"
+            result["implicit_backward_ms"] = bwd_ms
+        if args.cpu_sample > 0 and not args.implicit:
             S, CI = min(args.cpu_sample, B), args.cpu_iters
             v, cores, cpu_final, cpu_s, cpu_hist = cpu_baseline(tensors, edges, P, dtype, S, CI, args.damping)
             result["cpu_baseline"] = {"value": v, "unit": "problem-iterations/s", "cores": cores, "kind": "port",

@@ -145,6 +145,24 @@ int thx_chol_solve_backward(const void* L, int64_t ld, int32_t n, int32_t B, con
 int thx_chol_solve(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs,
                    void* x, int64_t ldv, int dtype, void* stream);
 
+/* ---- Implicit backward (BackwardMode.IMPLICIT, nonlinear/nonlinear_least_squares.py:121-135,265-292): the
+ *      grad-enabled last step is X_new = X exp(step * delta), delta = H^-1 g(theta) with H detached
+ *      (dense_linearization.py:61).  The backward pass is
+ *        grad_delta = thx_se3_retract_vjp(grad_X_new)      (torchlie Exp/Compose backward, se3_impl.py:313-343,739-747)
+ *        w          = thx_chol_solve(L, grad_delta)         (the backward linear solve, cached factor)
+ *        grad_theta = thx_pg_vjp(w)                         (d(w^T A^T b)/d theta, H detached: what autograd does to
+ *                                                            Between/Local jacobians + errors + cost weights)
+ *      thx_pg_vjp outputs are per problem: grad_meas (E,B,3,4), grad_w_between (E,B,6), grad_prior_target
+ *      (K,B,3,4), grad_w_prior (K,B,6) -- the host reduces over broadcast dimensions; w is (B, n), row stride ldw.
+ *      Gradients w.r.t. raw 3x4 entries follow torchlie's conventions (log: tangent-projected passthrough
+ *      backward, se3_impl.py:487-493; inverse / compose / jlog: plain derivatives). */
+int thx_se3_retract_vjp(const void* poses, const void* delta, int64_t ldd, double step, const void* grad_out,
+                        void* grad_delta, int64_t ldg, int32_t P, int32_t B, int dtype, const thx_lie_eps* eps,
+                        void* stream);
+int thx_pg_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, int64_t ldw, void* grad_meas,
+               void* grad_w_between, void* grad_prior_target, void* grad_w_prior, int dtype, const thx_lie_eps* eps,
+               void* stream);
+
 /* ---- Linearization.diagonal_scaling support: d[b, i] = H[b, i, i] (linearization.py:85-87). */
 int thx_diag(const void* H, int64_t ld, int32_t n, int32_t B, void* d, int64_t ldv, int dtype, void* stream);
 

@@ -182,6 +182,50 @@ def gen_lm(th, lieF, only=None):
         print(name, "err", err0.mean(), "->", info.err_history[:, -1].mean().item())
 
 
+def gen_implicit(th, lieF):
+    """Implicit backward (BackwardMode.IMPLICIT, nonlinear_least_squares.py:265-292): LM under no_grad, one
+    undamped GN step with the Hessian detached and grad enabled; loss = <coef, final poses>; gradients w.r.t.
+    the measurement tensors, the shared DiagonalCostWeight, the prior targets and the prior ScaleCostWeights."""
+    dtype = torch.float64
+    for name, pk, iters in (("pg_f64_implicit", dict(P=8, E=14, B=3, seed=31), 8),
+                            ("pg_f64_implicit_b", dict(P=6, E=10, B=4, seed=33, batched_weights=True), 5)):
+        d = make_problem(dtype=dtype, th=th, lieF=lieF, **pk)
+        B, P = d["poses"].shape[:2]
+        meas = d["meas"].clone().requires_grad_(True)
+        wb = d["w_between"].clone().requires_grad_(True)      # (1|B, E, 6)
+        tgt = d["prior_target"].clone().requires_grad_(True)
+        wp = d["w_prior"][:, :, :1].clone().requires_grad_(True)  # (1, K, 1) scales
+        obj = th.Objective(dtype=dtype)
+        poses = [th.SE3(tensor=d["poses"][:, k].clone(), name=f"pose_{k}") for k in range(P)]
+        for k in range(d["edges"].shape[0]):
+            i, j = d["edges"][k].tolist()
+            cw = th.DiagonalCostWeight(th.Variable(wb[:, k], name=f"w_{k}"))
+            obj.add(th.Between(poses[i], poses[j], th.SE3(tensor=meas[:, k], name=f"meas_{k}"), cw, name=f"between_{k}"))
+        for k in range(d["prior_idx"].shape[0]):
+            sw = th.ScaleCostWeight(th.Variable(wp[:, k], name=f"pw_{k}"))
+            obj.add(th.Difference(poses[int(d["prior_idx"][k])], th.SE3(tensor=tgt[:, k], name=f"prior_target_{k}"), sw,
+                                  name=f"prior_{k}"))
+        opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True,
+                                    max_iterations=iters, step_size=1.0, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+        layer = th.TheseusLayer(opt)
+        sol, info = layer.forward(optimizer_kwargs=dict(backward_mode="implicit", damping=1e-3))
+        gen = torch.Generator().manual_seed(5)
+        coef = torch.randn(B, P, 3, 4, dtype=dtype, generator=gen)
+        final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
+        loss = (coef * final).sum()
+        loss.backward()
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"),
+            P=P, edges=d["edges"].numpy(), meas=d["meas"].numpy(), w_between=d["w_between"].numpy(),
+            prior_idx=d["prior_idx"].numpy(), prior_target=d["prior_target"].numpy(), w_prior=d["w_prior"].numpy(),
+            poses0=d["poses"].numpy(), final=final.detach().numpy(), coef=coef.numpy(), loss=loss.item(),
+            grad_meas=meas.grad.numpy(), grad_w_between=wb.grad.numpy(), grad_prior_target=tgt.grad.numpy(),
+            grad_w_prior=wp.grad.numpy(),
+            opt_kwargs=np.array(repr(dict(max_iterations=iters, step_size=1.0, damping=1e-3, gauss_newton=False))))
+        print(name, "loss", loss.item(), "|grad_meas|", meas.grad.abs().max().item(),
+              "|grad_wb|", wb.grad.abs().max().item())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     th, lieF = import_reference()
@@ -190,6 +234,8 @@ def main():
     if not only:
         gen_lie(th, lieF)
     gen_lm(th, lieF, only)
+    if not only or "implicit" in only:
+        gen_implicit(th, lieF)
     print("wrote", sorted(os.listdir(OUT)))
 
 

@@ -202,3 +202,28 @@ def se3_compose(X0, X1):
 def se3_retract(X, delta):
     """theseus/geometry/lie_group.py:197-198: X . exp(delta)."""
     return se3_compose(X, se3_exp(delta))
+
+
+class _LogPassthrough(torch.autograd.Function):
+    """What autograd sees when the reference asks ``SE3.log(X, jacobians=[...])``
+    (torchlie/functional/lie_group.py:60-84,148-155): the VALUE is the formula's, the BACKWARD is
+    ``_log_backward`` (se3_impl.py:487-493): grad_X = R @ lift(J^T g * [1,1,1,.5,.5,.5]) -- the tangent
+    projection, not the derivative of the closed form; the Jacobian itself keeps its plain autograd graph."""
+
+    @staticmethod
+    def forward(ctx, X, xi, J):
+        ctx.save_for_backward(X, J)
+        return xi.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        X, J = ctx.saved_tensors
+        h = (J.transpose(-1, -2) @ g.unsqueeze(-1)).squeeze(-1)
+        lifted = torch.cat([_hat(0.5 * h[..., 3:]), h[..., :3, None]], -1)  # se3_impl.py:876-882
+        return X[..., :3] @ lifted, None, None
+
+
+def se3_log_jlog_autograd(X):
+    """se3_log_jlog with the reference's autograd semantics (see _LogPassthrough); same values."""
+    xi, J = se3_log_jlog(X)
+    return _LogPassthrough.apply(X, xi, J), J

@@ -61,7 +61,7 @@ def between_jac_err(v0, v1, meas, w):
     """between.py:38-45 + cost_weight.py:125-136.  Shapes (...,3,4) x3, w (...,6)."""
     D = lie.se3_compose(lie.se3_inverse(v0), v1)
     E = lie.se3_compose(lie.se3_inverse(meas), D)
-    e, Jlog = lie.se3_log_jlog(E)
+    e, Jlog = lie.se3_log_jlog_autograd(E)
     J0 = -Jlog @ lie.se3_adjoint(lie.se3_inverse(D))
     J1 = Jlog
     return J0 * w[..., :, None], J1 * w[..., :, None], e * w
@@ -70,7 +70,7 @@ def between_jac_err(v0, v1, meas, w):
 def local_jac_err(target, var, w):
     """local_cost_fn.py:58-61 -> lie_group.py:180-195: e = log(target^-1 var), J = Jlog."""
     D = lie.se3_compose(lie.se3_inverse(target), var)
-    e, Jlog = lie.se3_log_jlog(D)
+    e, Jlog = lie.se3_log_jlog_autograd(D)
     return Jlog * w[..., :, None], e * w
 
 
@@ -252,3 +252,14 @@ def lm_optimize(p: PGProblem, poses, max_iterations=20, step_size=1.0, damping=1
         info.iters_done = it
     info.last_err = info.err_history[-1]
     return poses, info
+
+
+def implicit_final_step(p: PGProblem, poses, step_size=1.0):
+    """The grad-enabled last step of BackwardMode.IMPLICIT (nonlinear_least_squares.py:121-135,265-292): undamped
+    Gauss-Newton with the Hessian detached (dense_linearization.py:61); the autograd graph runs through
+    Atb = A^T b only.  ``poses`` are the (detached) iterates of the no-grad loop; gradients flow to whatever in
+    ``p`` requires grad (measurements, weights, prior targets)."""
+    A, b = dense_linearize(p, poses.detach())
+    AtA, Atb = hessian(A, b)
+    delta = solve(AtA.detach(), Atb)
+    return retract(poses.detach(), delta * step_size), delta

@@ -70,6 +70,31 @@ class OracleKernels:
         m = ignore_mask.bool() if ignore_mask is not None else None
         out.copy_(opg.retract(x, delta * step, ignore_mask=m).transpose(0, 1))
 
+    # ---- implicit backward (torch autograd through the oracle, which mirrors torchlie's backward conventions) ----
+    def se3_retract_vjp(self, poses, delta, step, grad_out, grad_delta):
+        x = poses.transpose(0, 1)
+        with torch.enable_grad():
+            d = delta.detach().clone().requires_grad_(True)
+            y = opg.retract(x, d * step)
+            (g,) = torch.autograd.grad(y, d, grad_out.transpose(0, 1))
+        grad_delta.copy_(g)
+
+    def pg_vjp(self, s, t, w, g_meas, g_wb, g_tgt, g_wp, poses=None):
+        import dataclasses
+        p, x = self._problem(s, t, poses)
+        B = x.shape[0]
+        with torch.enable_grad():
+            full = lambda a: a.detach().expand(B, *a.shape[1:]).clone().requires_grad_(True)  # noqa: E731
+            leaves = [full(p.meas), full(p.w_between), full(p.prior_target), full(p.w_prior)]
+            pg = dataclasses.replace(p, meas=leaves[0], w_between=leaves[1], prior_target=leaves[2], w_prior=leaves[3])
+            A, b = opg.dense_linearize(pg, x)
+            _, Atb = opg.hessian(A, b)
+            phi = (w * Atb.squeeze(2)).sum()
+            grads = torch.autograd.grad(phi, leaves, allow_unused=True)
+        for out, g, leaf in zip((g_meas, g_wb, g_tgt, g_wp), grads, leaves):
+            if leaf.shape[1] > 0:
+                out[:leaf.shape[1]].copy_((g if g is not None else torch.zeros_like(leaf)).transpose(0, 1))
+
     # ---- dense solver ------------------------------------------------------------------------------
     def chol_factor(self, H, n, damping, ellipsoidal, damping_eps, L, panels, info, rhs=None, y=None):
         Hl = torch.tril(H[:, :n, :n])

@@ -60,3 +60,30 @@ def test_lm_trajectory_matches_reference(name, tol):
     ref = g["err_history"]
     k = min(hist.shape[1], ref.shape[1])
     np.testing.assert_allclose(hist[:, :k], ref[:, :k], rtol=2e-5 if tol < 1e-6 else 2e-3)
+
+
+@pytest.mark.parametrize("name", ["pg_f64_implicit", "pg_f64_implicit_b"])
+def test_implicit_backward_gradients_match_reference(name):
+    """Pins the oracle's implicit step (autograd through the restated formulas) to the gradients the REAL
+    reference produced through TheseusLayer(backward_mode="implicit") (torchlie's custom backward passes)."""
+    import dataclasses
+    g = load_golden(name)
+    p, poses0, kw = golden_problem(g)
+    kw.pop("gauss_newton")
+    iters = kw.pop("max_iterations")
+    with torch.no_grad():
+        x, _ = opg.lm_optimize(p, poses0, max_iterations=iters - 1, abs_err_tolerance=0.0, rel_err_tolerance=0.0, **kw)
+    leaves = dict(meas=p.meas.clone().requires_grad_(True), w_between=p.w_between.clone().requires_grad_(True),
+                  prior_target=p.prior_target.clone().requires_grad_(True),
+                  w_scale=p.w_prior[:, :, :1].clone().requires_grad_(True))
+    pg = dataclasses.replace(p, meas=leaves["meas"], w_between=leaves["w_between"], prior_target=leaves["prior_target"],
+                             w_prior=leaves["w_scale"].expand(-1, -1, 6))
+    final, _ = opg.implicit_final_step(pg, x)
+    np.testing.assert_allclose(final.detach().numpy(), g["final"], rtol=0, atol=5e-8)
+    loss = (torch.from_numpy(g["coef"]) * final).sum()
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    for key, ref in (("meas", "grad_meas"), ("w_between", "grad_w_between"), ("prior_target", "grad_prior_target"),
+                     ("w_scale", "grad_w_prior")):
+        got, want = leaves[key].grad.numpy(), g[ref]
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)

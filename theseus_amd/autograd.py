@@ -1,0 +1,69 @@
+"""Autograd glue of the implicit backward mode (theseus/optimizer/nonlinear/nonlinear_least_squares.py:121-135,
+265-292).
+
+Forward: one undamped Gauss-Newton step at the (detached) iterate of the no-grad loop,
+``X_new = X exp(step * delta)``, ``delta = H^-1 g(theta)``, H outside autograd.  Backward: three launches --
+``thx_se3_retract_vjp`` (grad_X_new -> grad_delta), ``thx_chol_solve`` with the factor cached by the forward
+(the "backward linear solve"), ``thx_pg_vjp`` (grad w.r.t. measurements, prior targets and cost weights).
+No torch ops compute anything here except the reductions over broadcast dimensions.
+"""
+import warnings
+
+import torch
+
+from .kernels import PGTensors
+
+
+class ImplicitStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, opt, step, kwargs, meas, w_between, prior_target, w_prior):
+        solver = opt.linear_solver
+        lin = solver.linearization
+        packed = lin.packed
+        lin._assemble()
+        y = solver.factorize(None, rhs=lin.g)  # plain GN; the reference falls back to the damped step if it fails
+        if bool(solver.info.ne(0).any()):
+            if kwargs.get("__strict_implicit_final_gn__", False):
+                solver.check_info()
+            warnings.warn("implicit backward: the undamped Gauss-Newton system is not positive definite, "
+                          "falling back to the optimizer's damped step", RuntimeWarning)
+            delta = opt.compute_delta(**kwargs)
+            solver.check_info()
+        else:
+            delta = torch.empty_like(y)
+            solver.K.chol_solve_backward(solver.L, lin.n, solver.panels, y, delta)
+        X = packed.tensors.poses.detach()
+        X_new = torch.empty_like(X)
+        packed.retract(delta, step, None, X_new)  # force_update: the converged mask is ignored in this step
+        ctx.opt, ctx.step = opt, step
+        ctx.factor_version = solver.factor_version
+        ctx.tensors = PGTensors(poses=X, meas=meas.detach(), w_between=w_between.detach(),
+                                prior_target=prior_target.detach(), w_prior=w_prior.detach())
+        ctx.delta = delta
+        ctx.mark_non_differentiable(delta)
+        return X_new, delta
+
+    @staticmethod
+    def backward(ctx, grad_x, _grad_delta):
+        solver = ctx.opt.linear_solver
+        lin = solver.linearization
+        packed, K = lin.packed, solver.K
+        if solver.factor_version != ctx.factor_version:
+            raise RuntimeError("implicit backward: the cached Cholesky factor of this forward pass was overwritten by "
+                               "a later factorisation on the same optimizer; call backward() before the next forward().")
+        t = ctx.tensors
+        B, n = t.poses.shape[1], lin.n
+        gd = torch.empty(B, n, dtype=t.poses.dtype, device=t.poses.device)
+        K.se3_retract_vjp(t.poses, ctx.delta, ctx.step, grad_x.contiguous(), gd)
+        w = solver.solve_with_factor(gd)  # the backward linear solve
+        E, Kp = packed.structure.num_edges, packed.structure.num_priors
+        new = lambda *s: torch.empty(*s, dtype=gd.dtype, device=gd.device)  # noqa: E731
+        g_meas, g_wb = new(max(E, 1), B, 3, 4), new(max(E, 1), B, 6)
+        g_tgt, g_wp = new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 6)
+        K.pg_vjp(packed.dstruct, t, w, g_meas, g_wb, g_tgt, g_wp)
+
+        def fit(g, count, like):  # (count, B, ...) -> the packed input's shape (count, 1|B, ...)
+            g = g[:count]
+            return g.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else g
+        return (None, None, None, fit(g_meas, E, t.meas), fit(g_wb, E, t.w_between), fit(g_tgt, Kp, t.prior_target),
+                fit(g_wp, Kp, t.w_prior))

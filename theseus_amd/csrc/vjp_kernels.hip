@@ -1,0 +1,254 @@
+// Implicit backward (BackwardMode.IMPLICIT, theseus/optimizer/nonlinear/nonlinear_least_squares.py:121-135,
+// 265-292): the grad-enabled last step is  X_new = X exp(delta),  delta = H^-1 g(theta)  with H detached
+// (dense_linearization.py:61), theta = measurements / prior targets / cost weights.  Backward:
+//   1. thx_se3_retract_vjp : grad_delta = Jexp(delta)^T [ Y_R^T G_t ; vee(Y_R^T G_R) ]   (torchlie Exp.backward,
+//                            se3_impl.py:313-343, after Compose.backward :739-747)
+//   2. thx_chol_solve      : w = H^-1 grad_delta with the cached factor (chol_kernels.hip)
+//   3. thx_pg_vjp          : grad_theta = d(w^T g)/d theta, per cost, by forward-mode differentiation
+// With q = w_j - Ad(D^-1) w_i (edges; q = w_p for priors) the part of w^T g that belongs to one cost is
+//   phi = - sum_r s_r^2 (Jlog(E) q)_r log(E)_r ,   E = Z^-1 C   (Z = measurement, C = v0^-1 v1 | Z = target, C = var)
+// d phi / d s_r is closed form; d phi / d Z_k (12 raw entries) uses dual numbers through inverse / compose / the
+// Jlog closed forms -- the derivative the reference's plain autograd takes -- while log(E)'s own derivative is
+// torchlie's passthrough backward (se3_impl.py:487-493): d log = Jlog [E_R^T dE_t ; vee(E_R^T dE_R)/2].
+#include "common.cuh"
+#include "dual.cuh"
+
+namespace thx {
+
+using D2 = Dual<double>;
+
+template <typename T>
+__device__ __forceinline__ void load_se3_any(const T* __restrict__ p, SE3<double>& X) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    X.R[3 * i] = (double)p[4 * i];
+    X.R[3 * i + 1] = (double)p[4 * i + 1];
+    X.R[3 * i + 2] = (double)p[4 * i + 2];
+    X.t[i] = (double)p[4 * i + 3];
+  }
+}
+
+// grad of phi w.r.t. the 12 entries of Z (row major 3x4) and the 6 weights
+__device__ __forceinline__ void cost_vjp(const SE3<double>& Z, const SE3<double>& C, const double* q, const double* s,
+                                         const Eps<double>& eps, double* gZ, double* gs) {
+  // value pass
+  SE3<double> Zi, E;
+  se3_inv(Z, Zi);
+  se3_mul(Zi, C, E);
+  double xi[6], Jr[9], Jt[9];
+  se3_log_jlog(E, eps, xi, Jr, Jt, true);
+  double a[6];  // Jlog q  (Jlog = [[Jr, Jt],[0, Jr]])
+  {
+    double t0[3], t1[3], t2[3];
+    mat3_vec(Jr, q, t0);
+    mat3_vec(Jt, q + 3, t1);
+    mat3_vec(Jr, q + 3, t2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      a[i] = t0[i] + t1[i];
+      a[3 + i] = t2[i];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) gs[r] = -2.0 * s[r] * a[r] * xi[r];
+  const Eps<D2> epsd{D2(eps.nz), D2(eps.dnz), D2(eps.npi)};
+  SE3<D2> Cd;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Cd.R[i] = D2(C.R[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Cd.t[i] = D2(C.t[i]);
+  for (int k = 0; k < 12; ++k) {  // run-time loop: one dual evaluation per raw entry of Z
+    SE3<D2> Zd, Zid, Ed;
+    const int kr = k >> 2, kc = k & 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Zd.R[3 * i + j] = D2(Z.R[3 * i + j], (i == kr && j == kc) ? 1.0 : 0.0);
+      Zd.t[i] = D2(Z.t[i], (i == kr && kc == 3) ? 1.0 : 0.0);
+    }
+    se3_inv(Zd, Zid);
+    se3_mul(Zid, Cd, Ed);
+    D2 xid[6], Jrd[9], Jtd[9];
+    se3_log_jlog(Ed, epsd, xid, Jrd, Jtd, true);
+    // torchlie's log backward: d xi = Jlog [E_R^T dE_t ; vee(E_R^T dE_R) / 2]
+    double dR[9], dt[3], M[9], u[6], dxi[6];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dR[i] = Ed.R[i].d;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dt[i] = Ed.t[i].d;
+    mat3_tmul(E.R, dR, M);
+    mat3_tvec(E.R, dt, u);
+    u[3] = 0.5 * (M[7] - M[5]);
+    u[4] = 0.5 * (M[2] - M[6]);
+    u[5] = 0.5 * (M[3] - M[1]);
+    {
+      double t0[3], t1[3], t2[3];
+      mat3_vec(Jr, u, t0);
+      mat3_vec(Jt, u + 3, t1);
+      mat3_vec(Jr, u + 3, t2);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        dxi[i] = t0[i] + t1[i];
+        dxi[3 + i] = t2[i];
+      }
+    }
+    // d(Jlog q): dual parts of the Jlog closed forms
+    double da[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double top = 0.0, bot = 0.0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        top += Jrd[3 * i + j].d * q[j] + Jtd[3 * i + j].d * q[3 + j];
+        bot += Jrd[3 * i + j].d * q[3 + j];
+      }
+      da[i] = top;
+      da[3 + i] = bot;
+    }
+    double g = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) g -= s[r] * s[r] * (da[r] * xi[r] + a[r] * dxi[r]);
+    gZ[k] = g;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64)
+pg_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wvec, int64_t ldw, T* __restrict__ g_meas,
+              T* __restrict__ g_wb, T* __restrict__ g_tgt, T* __restrict__ g_wp, Eps<T> eps_t) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int c = blockIdx.y;
+  const int B = d.batch;
+  if (b >= B) return;
+  const Eps<double> eps{(double)eps_t.nz, (double)eps_t.dnz, (double)eps_t.npi};
+  const T* poses = static_cast<const T*>(d.poses);
+  const T* wv = wvec + (int64_t)b * ldw;
+  double q[6], sw[6], gZ[12], gs[6];
+  SE3<double> Z, C;
+  T* outZ;
+  T* outS;
+  if (c < s.num_edges) {
+    const int e = c, i = s.edge_i[e], j = s.edge_j[e];
+    const int64_t mB = d.meas_bstride ? B : 1, wB = d.w_between_bstride ? B : 1;
+    SE3<double> Xi, Xj, Xii, Di;
+    load_se3_any(poses + ((int64_t)i * B + b) * 12, Xi);
+    load_se3_any(poses + ((int64_t)j * B + b) * 12, Xj);
+    load_se3_any(static_cast<const T*>(d.meas) + ((int64_t)e * mB) * 12 + (int64_t)b * d.meas_bstride, Z);
+    const T* wp = static_cast<const T*>(d.w_between) + ((int64_t)e * wB) * 6 + (int64_t)b * d.w_between_bstride;
+    se3_inv(Xi, Xii);
+    se3_mul(Xii, Xj, C);  // D = v0^-1 v1
+    se3_inv(C, Di);
+    // q = w_j - Ad(D^-1) w_i,  Ad = [[R, hat(t) R],[0, R]]
+    double wi[6], wj[6], Rl[3], Ra[3], tx[3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      wi[k] = (double)wv[6 * i + k];
+      wj[k] = (double)wv[6 * j + k];
+      sw[k] = (double)wp[k];
+    }
+    mat3_vec(Di.R, wi, Rl);
+    mat3_vec(Di.R, wi + 3, Ra);
+    cross3(Di.t, Ra, tx);  // hat(t) (R w_ang)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      q[k] = wj[k] - (Rl[k] + tx[k]);
+      q[3 + k] = wj[3 + k] - Ra[k];
+    }
+    outZ = g_meas + ((int64_t)e * B + b) * 12;
+    outS = g_wb + ((int64_t)e * B + b) * 6;
+  } else {
+    const int k = c - s.num_edges, p = s.prior_pose[k];
+    const int64_t tB = d.prior_target_bstride ? B : 1, wB = d.w_prior_bstride ? B : 1;
+    load_se3_any(poses + ((int64_t)p * B + b) * 12, C);
+    load_se3_any(static_cast<const T*>(d.prior_target) + ((int64_t)k * tB) * 12 + (int64_t)b * d.prior_target_bstride, Z);
+    const T* wp = static_cast<const T*>(d.w_prior) + ((int64_t)k * wB) * 6 + (int64_t)b * d.w_prior_bstride;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      q[r] = (double)wv[6 * p + r];
+      sw[r] = (double)wp[r];
+    }
+    outZ = g_tgt + ((int64_t)k * B + b) * 12;
+    outS = g_wp + ((int64_t)k * B + b) * 6;
+  }
+  cost_vjp(Z, C, q, sw, eps, gZ, gs);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) outZ[k] = (T)gZ[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) outS[k] = (T)gs[k];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64)
+se3_retract_vjp_kernel(const T* __restrict__ poses, const T* __restrict__ delta, int64_t ldd, T step,
+                       const T* __restrict__ gout, T* __restrict__ gdelta, int64_t ldg, int P, int B, Eps<T> eps_t) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int p = blockIdx.y;
+  if (b >= B) return;
+  const Eps<double> eps{(double)eps_t.nz, (double)eps_t.dnz, (double)eps_t.npi};
+  SE3<double> X, Ex, Y, G;
+  load_se3_any(poses + ((int64_t)p * B + b) * 12, X);
+  load_se3_any(gout + ((int64_t)p * B + b) * 12, G);
+  double xi[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) xi[i] = (double)(delta[(int64_t)b * ldd + 6 * p + i] * step);
+  ExpCoef<double> c;
+  double Ct, J[36];
+  se3_exp(xi, eps, Ex, c, Ct);
+  se3_jexp(xi, Ex, c, Ct, J);
+  se3_mul(X, Ex, Y);
+  double M[9], u[6];
+  mat3_tmul(Y.R, G.R, M);
+  mat3_tvec(Y.R, G.t, u);
+  u[3] = M[7] - M[5];
+  u[4] = M[2] - M[6];
+  u[5] = M[3] - M[1];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc += J[6 * k + i] * u[k];
+    gdelta[(int64_t)b * ldg + 6 * p + i] = (T)(acc * (double)step);
+  }
+}
+
+}  // namespace thx
+
+using namespace thx;
+
+extern "C" {
+
+int thx_pg_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, int64_t ldw, void* grad_meas,
+               void* grad_w_between, void* grad_prior_target, void* grad_w_prior, int dtype, const thx_lie_eps* eps,
+               void* stream) {
+  if (!s || !d || !w || !eps) return fail("thx_pg_vjp: null argument");
+  if (s->num_edges > 0 && (!grad_meas || !grad_w_between)) return fail("thx_pg_vjp: null edge gradient buffer");
+  if (s->num_priors > 0 && (!grad_prior_target || !grad_w_prior)) return fail("thx_pg_vjp: null prior gradient buffer");
+  if (ldw < 6 * (int64_t)s->num_poses) return fail("thx_pg_vjp: ldw < n");
+  dim3 grid((d->batch + 63) / 64, s->num_edges + s->num_priors), block(64);
+  if (grid.y == 0) return 0;
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(pg_vjp_kernel<float>, grid, block, 0, as_stream(stream), *s, *d, (const float*)w, ldw,
+                                  (float*)grad_meas, (float*)grad_w_between, (float*)grad_prior_target,
+                                  (float*)grad_w_prior, make_eps<float>(eps)),
+               hipLaunchKernelGGL(pg_vjp_kernel<double>, grid, block, 0, as_stream(stream), *s, *d, (const double*)w,
+                                  ldw, (double*)grad_meas, (double*)grad_w_between, (double*)grad_prior_target,
+                                  (double*)grad_w_prior, make_eps<double>(eps)));
+  return check_launch("thx_pg_vjp");
+}
+
+int thx_se3_retract_vjp(const void* poses, const void* delta, int64_t ldd, double step, const void* grad_out,
+                        void* grad_delta, int64_t ldg, int32_t P, int32_t B, int dtype, const thx_lie_eps* eps,
+                        void* stream) {
+  if (!poses || !delta || !grad_out || !grad_delta || !eps || P <= 0 || B <= 0) return fail("bad retract_vjp args");
+  dim3 grid((B + 63) / 64, P), block(64);
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(se3_retract_vjp_kernel<float>, grid, block, 0, as_stream(stream), (const float*)poses,
+                                  (const float*)delta, ldd, (float)step, (const float*)grad_out, (float*)grad_delta,
+                                  ldg, P, B, make_eps<float>(eps)),
+               hipLaunchKernelGGL(se3_retract_vjp_kernel<double>, grid, block, 0, as_stream(stream),
+                                  (const double*)poses, (const double*)delta, ldd, step, (const double*)grad_out,
+                                  (double*)grad_delta, ldg, P, B, make_eps<double>(eps)));
+  return check_launch("thx_se3_retract_vjp");
+}
+
+}  // extern "C"

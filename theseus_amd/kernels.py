@@ -149,6 +149,22 @@ class HipKernels:
                                             _lib.ptr(ignore_mask), _lib.ptr(out), P, B, _lib.dtype_code(dt),
                                             lie_eps(dt), _lib.stream_ptr(poses.device)), "thx_se3_retract")
 
+    # ---- implicit backward ----------------------------------------------------------------------
+    def se3_retract_vjp(self, poses, delta, step, grad_out, grad_delta):
+        P, B = poses.shape[:2]
+        dt = poses.dtype
+        _lib.check(self.lib.thx_se3_retract_vjp(_lib.ptr(poses), _lib.ptr(delta), delta.stride(0), float(step),
+                                                _lib.ptr(grad_out), _lib.ptr(grad_delta), grad_delta.stride(0), P, B,
+                                                _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(poses.device)),
+                   "thx_se3_retract_vjp")
+
+    def pg_vjp(self, s: DeviceStructure, t: PGTensors, w, g_meas, g_wb, g_tgt, g_wp, poses=None):
+        d = t.c_struct(poses)
+        dt = w.dtype
+        _lib.check(self.lib.thx_pg_vjp(s.c, d, _lib.ptr(w), w.stride(0), _lib.ptr(g_meas), _lib.ptr(g_wb),
+                                       _lib.ptr(g_tgt), _lib.ptr(g_wp), _lib.dtype_code(dt), lie_eps(dt),
+                                       _lib.stream_ptr(w.device)), "thx_pg_vjp")
+
     # ---- dense solver ---------------------------------------------------------------------------
     def chol_factor(self, H, n, damping, ellipsoidal, damping_eps, L, panels, info, rhs=None, y=None):
         """L L^T = H + damping.  With rhs/y the forward substitution y = L^-1 rhs is fused in."""

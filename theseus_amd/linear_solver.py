@@ -38,6 +38,7 @@ class HipCholeskyCore:
         self.K = self.linearization.K
         self.L = self.panels = self.info = self._y = None
         self._lam = None
+        self.factor_version = 0  # bumped by every factorisation (the implicit backward checks its factor is current)
 
     def _ensure_buffers(self):
         lin = self.linearization
@@ -68,6 +69,7 @@ class HipCholeskyCore:
             else:
                 lam.fill_(float(damping))
         y = self._y if rhs is not None else None
+        self.factor_version += 1
         self.K.chol_factor(lin.H, lin.n, lam, ellipsoidal_damping, damping_eps, self.L, self.panels, self.info,
                            rhs=rhs, y=y)
         return y

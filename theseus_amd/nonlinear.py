@@ -136,13 +136,20 @@ class NonlinearLeastSquares(abc.ABC):
                        backward_mode: Union[str, BackwardMode] = BackwardMode.UNROLL,
                        end_iter_callback: Optional[Callable] = None, **kwargs) -> NonlinearOptimizerInfo:
         backward_mode = BackwardMode.resolve(backward_mode)
-        if backward_mode != BackwardMode.UNROLL:
+        outer_grad = torch.is_grad_enabled()
+        if backward_mode in (BackwardMode.TRUNCATED, BackwardMode.DLM):
+            raise NotImplementedError(f"backward_mode={backward_mode.name} is not supported by the HIP back end "
+                                      "(supported: 'implicit'; 'unroll' without gradients).")
+        if backward_mode == BackwardMode.UNROLL and outer_grad and self._needs_grad():
             raise NotImplementedError(
-                f"backward_mode={backward_mode.name} is not wired to the HIP back end yet "
-                "(implicit backward solve: use HipCholeskySolver.solve_with_factor).")
+                "Differentiating through the unrolled iterations (backward_mode='unroll') is not supported by the "
+                "HIP back end: the kernels are outside autograd.  Use backward_mode='implicit' (one backward linear "
+                "solve with the cached factor), or call under torch.no_grad().")
+        implicit = backward_mode == BackwardMode.IMPLICIT
         lin: HipLinearization = self.linear_solver.linearization
         packed = lin.packed
         self.reset(**kwargs, backward_mode=backward_mode)
+        _, loop_iters = self._split_backward_iters(backward_mode=backward_mode, **kwargs) if implicit else (0, self.params.max_iterations)
         with torch.no_grad():
             packed.sync()
             B = packed.batch
@@ -169,7 +176,7 @@ class NonlinearLeastSquares(abc.ABC):
             spare = torch.empty_like(packed.tensors.poses)
             err_new = torch.empty(B, dtype=dt, device=dev)
             it, all_reject_attempts = 0, 0
-            while it < p.max_iterations:
+            while it < loop_iters:
                 lin.linearize()
                 try:
                     delta = self.compute_delta(**kwargs)
@@ -248,6 +255,28 @@ class NonlinearLeastSquares(abc.ABC):
                 it += 1
                 info.iters_done = it
 
+            # ---- BackwardMode.IMPLICIT: the last step is an undamped Gauss-Newton step with the Hessian detached,
+            #      executed under the caller's grad mode (nonlinear_least_squares.py:121-135,265-292) ----
+            if implicit and not (info.status == NonlinearOptimizerStatus.FAIL).any():
+                X_new, delta = self._implicit_last_step(packed, outer_grad, kwargs)
+                err = packed.error_metric(poses=X_new.detach())
+                packed.set_poses(X_new, repoint=False)
+                if err_hist is not None:
+                    err_hist[:, it + 1] = err
+                if track_best_solution:
+                    better = err < best_err
+                    torch.where(better.view(1, B, 1, 1), X_new.detach(), best_poses, out=best_poses)
+                    best_err = torch.where(better, err, best_err)
+                if need_conv:
+                    converged = self._check_convergence(err, last_err)
+                    conv_iter = torch.where(converged & (conv_iter < 0), torch.full_like(conv_iter, it + 1), conv_iter)
+                last_err = err
+                info.last_err = err
+                if end_iter_callback is not None:
+                    packed.flush_variables()
+                    end_iter_callback(self, info, delta.detach(), it)
+                it += 1
+                info.iters_done = it
             packed.flush_variables()
             # ---- bookkeeping, one device->host copy ----
             if converged is not None:
@@ -264,7 +293,19 @@ class NonlinearLeastSquares(abc.ABC):
         return info
 
     def _needs_grad(self):
-        return any(v.tensor.requires_grad for v in self.objective._all_variables())
+        return any(v.tensor.requires_grad for v in self.linear_solver.linearization.packed._tracked())
+
+    def _implicit_last_step(self, packed, outer_grad: bool, kwargs):
+        """X_new = X exp(delta), delta = H^-1 g(theta): H is built outside autograd (i.e. detached, as
+        dense_linearization.py:61 does for this step), the graph runs through g only and its backward is one
+        linear solve with the cached factor + the fused VJP kernel (theseus_amd/autograd.py)."""
+        from .autograd import ImplicitStep
+        step = self.params.step_size if kwargs.get("__keep_final_step_size__", False) else 1.0
+        with torch.set_grad_enabled(outer_grad):
+            packed.flush_variables()
+            packed.sync(force=True)  # re-pack the auxiliary tensors WITH their autograd history
+            t = packed.tensors
+            return ImplicitStep.apply(self, float(step), kwargs, t.meas, t.w_between, t.prior_target, t.w_prior)
 
 
 class GaussNewton(NonlinearLeastSquares):

@@ -150,8 +150,11 @@ class PackedPoseGraph:
     def _repoint_variables(self):
         """Make every optimisation variable's tensor a view of the packed pose buffer."""
         poses = self.tensors.poses
-        for k, v in enumerate(self.pose_vars):
-            v.tensor = poses[k]
+        # the optimiser calls this under no_grad; after the implicit last step the pose buffer carries a graph
+        # and the per-variable views must stay attached to it
+        with torch.set_grad_enabled(poses.requires_grad):
+            for k, v in enumerate(self.pose_vars):
+                v.tensor = poses[k]
         self._stamp = self._current_stamp()
         self._global_stamp = Variable._global_updates
         self._vars_stale = False
