@@ -205,6 +205,13 @@ def main():
         achieved = flops_per_launch / (fac["avg_ms"] * 1e-3) / 1e12
         peak = PEAK[args.dtype]
         err_hist = info.err_history
+        traffic, traffic_src = None, None
+        try:  # measured offline with rocprofv3 --pmc (bench.py cannot profile itself): profiles/traffic.json
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"{args.dtype}_n{n}_b{B}")
+            if tj:
+                traffic, traffic_src = tj["bytes_per_factor_call"], tj["source"]
+        except (OSError, ValueError, KeyError):
+            pass
         result = {
             "metric": "LM iterations/sec (batch x vars) on SE3 pose-graph",
             "value": world * B * iters_done / dt,
@@ -221,7 +228,9 @@ def main():
             "mean_error": [float(err_hist[:, 0].mean()), float(err_hist[:, iters_done].mean())],
             "roofline": {"bound": "mfma", "kernel": "thx_chol_factor_forward (chol_diag + chol_offdiag launches per block column)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "flops_per_launch": flops_per_launch, "avg_launch_ms": fac["avg_ms"]},
+                         "traffic": traffic, "traffic_unit": "bytes per thx_chol_factor_forward call (PMC, rocprofv3)",
+                         "traffic_source": traffic_src, "flops_per_launch": flops_per_launch,
+                         "avg_launch_ms": fac["avg_ms"]},
             "phases_ms_per_call": {k: round(v["avg_ms"], 4) for k, v in phases.items()},
         }
         if args.implicit:
