@@ -33,6 +33,7 @@
 // backward pass).
 #include "common.cuh"
 
+#include <cstdlib>
 #include <utility>
 
 namespace thx {
@@ -52,6 +53,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 template <typename T>
@@ -163,12 +165,68 @@ struct Engine<float> {
     }
   }
 
+  // SYRK of the diagonal tile on the 36 lower 16x16 blocks of its 8x8 block grid, nine per wave: wave g owns block
+  // rows 4+g (5+g blocks) and 3-g (4-g blocks) -- equal MFMA counts on all four SIMDs, 56 % of the full tile.
+  // v_mfma_f32_16x16x4_f32; an MFMA's k index <-> staged column 8*(lane>>4) + m (m = 0..7 per 32-wide chunk).
+  using Sy = f32x4;
+  template <int G>
+  static __device__ __forceinline__ void syrk36(const float* sA, f32x4* acc, int lane) {
+    constexpr int UH = 4 + G, UL = 3 - G;
+    const int o = (lane & 15) * 36 + 8 * (lane >> 4);
+    float fbh[8], fbl[8];
+    {
+      const float4 a = *reinterpret_cast<const float4*>(sA + 16 * UH * 36 + o), b = *reinterpret_cast<const float4*>(sA + 16 * UH * 36 + o + 4);
+      const float4 c = *reinterpret_cast<const float4*>(sA + 16 * UL * 36 + o), d = *reinterpret_cast<const float4*>(sA + 16 * UL * 36 + o + 4);
+      fbh[0] = a.x; fbh[1] = a.y; fbh[2] = a.z; fbh[3] = a.w; fbh[4] = b.x; fbh[5] = b.y; fbh[6] = b.z; fbh[7] = b.w;
+      fbl[0] = c.x; fbl[1] = c.y; fbl[2] = c.z; fbl[3] = c.w; fbl[4] = d.x; fbl[5] = d.y; fbl[6] = d.z; fbl[7] = d.w;
+    }
+#pragma unroll
+    for (int v = 0; v <= UH; ++v) {
+      float fa[8];
+      if (v == UH) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) fa[m] = fbh[m];
+      } else if (v == UL) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) fa[m] = fbl[m];
+      } else {
+        const float4 a = *reinterpret_cast<const float4*>(sA + 16 * v * 36 + o), b = *reinterpret_cast<const float4*>(sA + 16 * v * 36 + o + 4);
+        fa[0] = a.x; fa[1] = a.y; fa[2] = a.z; fa[3] = a.w; fa[4] = b.x; fa[5] = b.y; fa[6] = b.z; fa[7] = b.w;
+      }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) acc[v] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m], fbh[m], acc[v], 0, 0, 0);
+      if (v <= UL) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[UH + 1 + v] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m], fbl[m], acc[UH + 1 + v], 0, 0, 0);
+      }
+    }
+  }
+  // tile(u, v) <- tile(u, v) - acc for the blocks of syrk36 (16x16 C layout: lane holds row 16u + (lane&15),
+  // columns 16v + 4(lane>>4) .. +3)
+  template <int G>
+  static __device__ __forceinline__ void syrk36_finish(float* tile, const f32x4* acc, int lane) {
+    constexpr int UH = 4 + G, UL = 3 - G;
+    auto fin = [&](int u, int v, const f32x4& a) __attribute__((always_inline)) {
+      float4* p = reinterpret_cast<float4*>(tile + (16 * u + (lane & 15)) * 132 + 16 * v + 4 * (lane >> 4));
+      float4 h = *p;
+      h.x -= a[0]; h.y -= a[1]; h.z -= a[2]; h.w -= a[3];
+      *p = h;
+    };
+#pragma unroll
+    for (int v = 0; v <= UH; ++v) fin(UH, v, acc[v]);
+#pragma unroll
+    for (int v = 0; v <= UL; ++v) fin(UL, v, acc[UH + 1 + v]);
+  }
   // ---- 32x32 block helpers for the diagonal-tile factorisation (operands in the LDS tile, row stride 132).
   //      Blk D[m][n]: a lane holds ONE row n = lane&31 of the block, register rho <-> column m = 8(rho>>2) + 4g + (rho&3)
   using Blk = f32x16;
   static __device__ __forceinline__ void blk_zero(Blk& d) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) d[i] = 0.f;
+  }
+  static __device__ __forceinline__ void blk_sub(Blk& d, const Blk& a) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] -= a[i];
   }
   static __device__ __forceinline__ void blk_load(Blk& d, const float* blk, int lane) {
     const float* p = blk + (lane & 31) * 132 + 4 * (lane >> 5);
@@ -275,6 +333,54 @@ struct Engine<double> {
   struct Blk {
     f64x4 v[2][2];
   };
+  // see Engine<float>::syrk36; staged rows have stride 18, a k-chunk is 16 wide: k index <-> column 4*(lane>>4) + m
+  using Sy = f64x4;
+  template <int G>
+  static __device__ __forceinline__ void syrk36(const double* sA, f64x4* acc, int lane) {
+    constexpr int UH = 4 + G, UL = 3 - G;
+    const int o = (lane & 15) * 18 + 4 * (lane >> 4);
+    double fbh[4], fbl[4];
+    {
+      const double2 a = *reinterpret_cast<const double2*>(sA + 16 * UH * 18 + o), b = *reinterpret_cast<const double2*>(sA + 16 * UH * 18 + o + 2);
+      const double2 c = *reinterpret_cast<const double2*>(sA + 16 * UL * 18 + o), d = *reinterpret_cast<const double2*>(sA + 16 * UL * 18 + o + 2);
+      fbh[0] = a.x; fbh[1] = a.y; fbh[2] = b.x; fbh[3] = b.y;
+      fbl[0] = c.x; fbl[1] = c.y; fbl[2] = d.x; fbl[3] = d.y;
+    }
+#pragma unroll
+    for (int v = 0; v <= UH; ++v) {
+      double fa[4];
+      if (v == UH) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fa[m] = fbh[m];
+      } else if (v == UL) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fa[m] = fbl[m];
+      } else {
+        const double2 a = *reinterpret_cast<const double2*>(sA + 16 * v * 18 + o), b = *reinterpret_cast<const double2*>(sA + 16 * v * 18 + o + 2);
+        fa[0] = a.x; fa[1] = a.y; fa[2] = b.x; fa[3] = b.y;
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[v] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], fbh[m], acc[v], 0, 0, 0);
+      if (v <= UL) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[UH + 1 + v] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], fbl[m], acc[UH + 1 + v], 0, 0, 0);
+      }
+    }
+  }
+  // f64 16x16 C layout: lane holds row 16u + (lane&15), columns 16v + (lane>>4) + 4 rho
+  template <int G>
+  static __device__ __forceinline__ void syrk36_finish(double* tile, const f64x4* acc, int lane) {
+    constexpr int UH = 4 + G, UL = 3 - G;
+    auto fin = [&](int u, int v, const f64x4& a) __attribute__((always_inline)) {
+      double* p = tile + (16 * u + (lane & 15)) * 130 + 16 * v + (lane >> 4);
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) p[4 * rho] -= a[rho];
+    };
+#pragma unroll
+    for (int v = 0; v <= UH; ++v) fin(UH, v, acc[v]);
+#pragma unroll
+    for (int v = 0; v <= UL; ++v) fin(UL, v, acc[UH + 1 + v]);
+  }
   static __device__ __forceinline__ void blk_zero(Blk& d) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -282,6 +388,14 @@ struct Engine<double> {
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int i = 0; i < 4; ++i) d.v[a][b][i] = 0.0;
+  }
+  static __device__ __forceinline__ void blk_sub(Blk& d, const Blk& a) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d.v[p][q][i] -= a.v[p][q][i];
   }
   static __device__ __forceinline__ void blk_load(Blk& d, const double* blk, int lane) {
     const int rl = lane & 15, kq = lane >> 4;
@@ -318,15 +432,13 @@ struct Engine<double> {
 // Optional rider on the SYRK K-loop of chol_diag: the panel rows L_j,0:j pass through LDS anyway, so
 // t[r] = sum_k L[row0+r][k] y[k] (the forward-substitution update) costs 16 VALU FMAs per thread and
 // chunk in the shadow of the MFMAs.  Thread pair (2r, 2r+1) splits the chunk's k range in two.
-template <typename T, bool SAME, bool GEMV = false>
-__device__ __forceinline__ void kloop(const T* __restrict__ Arows, int validA, const T* __restrict__ Brows,
-                                      int validB, int64_t ld, int K, T* sA, T* sB,
-                                      typename Engine<T>::Acc& acc, int tid, const T* gemv_y = nullptr,
-                                      T* gemv_part = nullptr) {
+template <typename T, bool SAME, bool GEMV, typename Compute>
+__device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA, const T* __restrict__ Brows,
+                                        int validB, int64_t ld, int K, T* sA, T* sB, int tid, const T* gemv_y,
+                                        T* gemv_part, Compute&& compute) {
   using C = CT<T>;
   using V = typename C::V;
   const int lrow = tid >> 3, lc = tid & 7;
-  const int wave = tid >> 6, lane = tid & 63;
   uint4 ra[4], rb[4];
   // rows outside the matrix are read from a clamped (in-bounds) row and zeroed by value: selecting
   // between a global pointer and a local zero makes hipcc emit flat loads through scratch
@@ -380,11 +492,22 @@ __device__ __forceinline__ void kloop(const T* __restrict__ Arows, int validA, c
         }
       }
     }
-    Engine<T>::chunk(sA, (SAME ? sA : sB) + 32 * wave * C::LDT, acc, lane);
+    compute();  // MFMAs on the staged chunk (sA / sB)
   }
   if constexpr (GEMV) {
     if (gemv_part) *gemv_part = gsum;
   }
+}
+
+template <typename T, bool SAME, bool GEMV = false>
+__device__ __forceinline__ void kloop(const T* __restrict__ Arows, int validA, const T* __restrict__ Brows,
+                                      int validB, int64_t ld, int K, T* sA, T* sB,
+                                      typename Engine<T>::Acc& acc, int tid, const T* gemv_y = nullptr,
+                                      T* gemv_part = nullptr) {
+  const int wave = tid >> 6, lane = tid & 63;
+  kloop_f<T, SAME, GEMV>(Arows, validA, Brows, validB, ld, K, sA, sB, tid, gemv_y, gemv_part, [&]() __attribute__((always_inline)) {
+    Engine<T>::chunk(sA, (SAME ? sA : sB) + 32 * wave * CT<T>::LDT, acc, lane);
+  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -564,11 +687,20 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   if (fwd)
     for (int k = tid; k < row0; k += 256) ybuf[k] = yout[(int64_t)b * ldv + k];  // y_0:j of earlier columns
 
-  typename E::Acc acc;
-  E::zero(acc);
+  // SYRK on the 36 lower 16x16 blocks of the tile, nine per wave (Engine<T>::syrk36)
+  typename E::Sy acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[i][k] = T(0);
   T tpart = T(0);  // this thread's half of (L_j,0:j y)[tid >> 1]
-  kloop<T, true, true>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, row0, tile, nullptr, acc, tid,
-                       fwd ? ybuf : nullptr, &tpart);
+  kloop_f<T, true, true>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, row0, tile, nullptr, tid,
+                         fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
+    if (wave == 0) E::template syrk36<0>(tile, acc, lane);
+    else if (wave == 1) E::template syrk36<1>(tile, acc, lane);
+    else if (wave == 2) E::template syrk36<2>(tile, acc, lane);
+    else E::template syrk36<3>(tile, acc, lane);
+  });
 
   // ---- S = H_jj (+ damping on the diagonal) - acc -> LDS tile; identity padding outside the matrix ----
   __syncthreads();  // staging buffer is free
@@ -592,8 +724,11 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
     if (fwd && (tid & 1) == 0) vvec[tid >> 1] -= tsum;
   }
   __syncthreads();
-  E::rsub_lds(acc, tile, wave, lane);   // acc <- tile - acc
-  E::store_lds(acc, tile, wave, lane);  // same lane, same addresses: no barrier in between
+  // own blocks: tile(u,v) <- tile(u,v) - acc (each lane touches only its own elements)
+  if (wave == 0) E::template syrk36_finish<0>(tile, acc, lane);
+  else if (wave == 1) E::template syrk36_finish<1>(tile, acc, lane);
+  else if (wave == 2) E::template syrk36_finish<2>(tile, acc, lane);
+  else E::template syrk36_finish<3>(tile, acc, lane);
   __syncthreads();
 
   // ---- blocked right-looking Cholesky on the LDS tile, 32-wide sub-blocks.  Afterwards the tile IS the
@@ -712,7 +847,7 @@ struct OffdiagSmem {
 template <typename T>
 __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1)
 chol_offdiag_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict__ panel, int n, int64_t ld,
-                    int j, int ntiles, int nrow_tiles, int B) {
+                    int j, int ntiles, int i_first, int nrow_tiles, int B) {
   using C = CT<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -721,7 +856,7 @@ chol_offdiag_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restr
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
   const int b = (slot / nrow_tiles) * 8 + xcd;
-  const int i = j + 1 + (slot % nrow_tiles);
+  const int i = i_first + (slot % nrow_tiles);  // row tiles [i_first, i_first + nrow_tiles) of block column j
   if (b >= B) return;  // batch padded to a multiple of 8 by the launcher (whole block exits)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t mat = (int64_t)b * ld * ld;
@@ -797,13 +932,13 @@ __device__ __forceinline__ void sub_mma_sw(const float* Pc, const Engine<float>:
 
 __global__ void __launch_bounds__(256, 2)
 chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, const float* __restrict__ panel, int n,
-                        int64_t ld, int j, int ntiles, int nrow_tiles, int B) {
+                        int64_t ld, int j, int ntiles, int i_first, int nrow_tiles, int B) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
   const int b = (slot / nrow_tiles) * 8 + xcd;
-  const int i = j + 1 + (slot % nrow_tiles);
+  const int i = i_first + (slot % nrow_tiles);  // row tiles [i_first, i_first + nrow_tiles) of block column j
   if (b >= B) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t mat = (int64_t)b * ld * ld;
@@ -814,6 +949,8 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   float* Pc = smem + OFF32_STAGE_FLOATS;
 
   // ---- prefetch: panel sub-blocks (s,t), t <= s, then the H tile ----
+  // (a "lean" variant without any prefetch -- 40 KB LDS, 168 VGPRs, three workgroups per CU -- measured 1-2 % SLOWER:
+  //  the K-loop's 82 % MFMA-busy is not an occupancy problem)
   uint4 pr[10];
   {
     const float* Pn = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
@@ -1074,18 +1211,23 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   }
   hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)B, st);
   const int Bpad = (B + 7) / 8 * 8;
-  for (int j = 0; j < ntiles; ++j) {
+  auto offdiag = [&](hipStream_t s, int j, int i_first, int nrt) {
+    if constexpr (sizeof(T) == 4)
+      hipLaunchKernelGGL(chol_offdiag_f32_kernel, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, s, (const float*)H, (float*)L,
+                         (const float*)panel, n, ld, j, ntiles, i_first, nrt, B);
+    else
+      hipLaunchKernelGGL(chol_offdiag_kernel<T>, dim3(Bpad * nrt), dim3(256), OffdiagSmem<T>::bytes, s, (const T*)H,
+                         (T*)L, (const T*)panel, n, ld, j, ntiles, i_first, nrt, B);
+  };
+  auto diag = [&](int j) {
     hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(B), dim3(256), dsm, st, (const T*)H, (T*)L, (T*)panel,
                        (const T*)damping, ellipsoidal, (T)eps, info, n, ld, j, ntiles, (const T*)rhs, (T*)y, ldv);
-    const int nrt = ntiles - 1 - j;
-    if (nrt > 0) {
-      if constexpr (sizeof(T) == 4)
-        hipLaunchKernelGGL(chol_offdiag_f32_kernel, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, st, (const float*)H,
-                           (float*)L, (const float*)panel, n, ld, j, ntiles, nrt, B);
-      else
-        hipLaunchKernelGGL(chol_offdiag_kernel<T>, dim3(Bpad * nrt), dim3(256), OffdiagSmem<T>::bytes, st,
-                           (const T*)H, (T*)L, (const T*)panel, n, ld, j, ntiles, nrt, B);
-    }
+  };
+  // (A two-stream schedule -- the rest of column j underneath diag(j+1) on an auxiliary stream -- was measured: the
+  //  kernels do run concurrently, but LDS caps a CU at two workgroups of either kind, so nothing is gained.)
+  for (int j = 0; j < ntiles; ++j) {
+    diag(j);
+    if (ntiles - 1 - j > 0) offdiag(st, j, j + 1, ntiles - 1 - j);
   }
   return check_launch("thx_chol_factor");
 }
