@@ -34,6 +34,7 @@
 #include "common.cuh"
 
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 
 namespace thx {
@@ -630,26 +631,52 @@ __device__ __forceinline__ int potrf32(T (&a)[32]) {
   return bad;
 }
 
-// W = L^-1 for the 32x32 triangle held row-per-lane in a[]: lane j (= lane & 31) computes column j of W by
-// forward substitution on e_j, in fp64 whatever T is (the inverse is formed once and multiplies every
-// row tile below it), two interleaved partial sums to shorten the dependent chain.
-template <typename T>
-__device__ __forceinline__ void inv32(const T (&a)[32], double (&w)[32], int lane) {
+// W = L^-1 for a 32x32 triangle stored row-major in LDS (row stride LDM): lane j (= lane & 31) computes column j of
+// W by forward substitution on e_j.  L[i][k] is wave uniform: it is read with broadcast ds_read_b128 (4 values per
+// instruction, into VGPRs) -- a v_readlane per value does not scale: hipcc hoists all 496 of them, runs out of SGPRs
+// and spills through v_writelane/v_readlane pairs (measured 30 cycles per term).  Row i+1 is loaded while row i is
+// being consumed.  Accumulation in A: fp64 for the fp64 path, float for fp32 -- W then carries the backward error of
+// an fp32 TRSM (columnwise ~32 eps |L|), which is what the sub-block solve it replaces would have.
+template <typename T, typename A, int LDM>
+__device__ __forceinline__ void inv32(const T* Lss, A (&w)[32], int lane) {
+  constexpr int VEC = 16 / sizeof(T);
+  using V = std::conditional_t<sizeof(T) == 4, float4, double2>;
   const int j = lane & 31;
+  V cur[32 / VEC], nxt[32 / VEC];
+  cur[0] = *reinterpret_cast<const V*>(Lss);
   static_for<32>([&](auto ii) __attribute__((always_inline)) {
     constexpr int i = decltype(ii)::value;
-    const double lii = (double)bcast(a[i], i);
-    double r = (double)(1.0f / (float)lii);
-    r = r * (2.0 - lii * r);
-    r = r * (2.0 - lii * r);
-    double s0 = (j == i) ? 1.0 : 0.0, s1 = 0.0;
+    if constexpr (i + 1 < 32) {  // prefetch row i+1: entries 0 .. i+1
+#pragma unroll
+      for (int q = 0; q <= (i + 1) / VEC; ++q) nxt[q] = *reinterpret_cast<const V*>(Lss + (i + 1) * LDM + VEC * q);
+    }
+    auto at = [&](int k) __attribute__((always_inline)) -> A {
+      if constexpr (sizeof(T) == 4) {
+        const float4 v = cur[k >> 2];
+        return (A)((k & 3) == 0 ? v.x : (k & 3) == 1 ? v.y : (k & 3) == 2 ? v.z : v.w);
+      } else {
+        const double2 v = cur[k >> 1];
+        return (A)((k & 1) ? v.y : v.x);
+      }
+    };
+    const A lii = at(i);
+    A r = (A)(1.0f / (float)lii);
+    r = r * (A(2) - lii * r);
+    r = r * (A(2) - lii * r);
+    A s0 = (j == i) ? A(1) : A(0), s1 = A(0);
     static_for<i>([&](auto kk) __attribute__((always_inline)) {
       constexpr int k = decltype(kk)::value;
-      const double lik = (double)bcast(a[k], i);  // L[i][k]
-      if constexpr (k & 1) s1 -= lik * w[k];
-      else s0 -= lik * w[k];
+      if constexpr (k & 1) s1 -= at(k) * w[k];
+      else s0 -= at(k) * w[k];
     });
     w[i] = (s0 + s1) * r;
+    if constexpr (i + 1 < 32) {
+#pragma unroll
+      for (int q = 0; q <= (i + 1) / VEC; ++q) cur[q] = nxt[q];
+    }
+    // keep the rows in order: without this the compiler issues every LDS read first and the FMA chains sink below
+    // them (hundreds of spilled registers)
+    asm volatile("" : "+v"(w[i]) : : "memory");
   });
 }
 
@@ -749,11 +776,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
           }
         }
       }
-#ifdef THX_X_NOPOTRF
-      const int bad = 0;
-#else
       const int bad = potrf32<T>(a);
-#endif
       if (bad != 0 && lane == 0 && info[b] == 0) info[b] = row0 + 32 * sb + bad;
       // L_ss straight to global memory: one 32-element row per lane, zeros above the diagonal
       const int lr = lane & 31, grow = 32 * sb + lr;
@@ -769,13 +792,27 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
           }
         }
       }
-      double w[32];
-#ifdef THX_X_NOINV
+      // L_ss back into its LDS block (zeros above the diagonal), then invert it from there
+      {
+        V* rp = reinterpret_cast<V*>(Dss + lr * C::LDM);
+        if (lane < 32) {
 #pragma unroll
-      for (int i = 0; i < 32; ++i) w[i] = (double)a[i];
-#else
-      inv32<T>(a, w, lane);
-#endif
+          for (int q = 0; q < 32 / C::VEC; ++q) {
+            if constexpr (sizeof(T) == 4) {
+              rp[q] = make_float4(4 * q <= lr ? a[4 * q] : 0.f, 4 * q + 1 <= lr ? a[4 * q + 1] : 0.f,
+                                  4 * q + 2 <= lr ? a[4 * q + 2] : 0.f, 4 * q + 3 <= lr ? a[4 * q + 3] : 0.f);
+            } else {
+              rp[q] = make_double2(2 * q <= lr ? a[2 * q] : 0.0, 2 * q + 1 <= lr ? a[2 * q + 1] : 0.0);
+            }
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's LDS writes are visible to its reads
+        __builtin_amdgcn_wave_barrier();
+      }
+      using WA = std::conditional_t<sizeof(T) == 8, double, float>;
+      WA w[32];
+      inv32<T, WA, C::LDM>(Dss, w, lane);
+      __builtin_amdgcn_wave_barrier();
       if (lane < 32) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) Dss[i * C::LDM + lr] = (T)w[i];  // W[i][lr]; zero for i < lr
