@@ -168,16 +168,19 @@ struct Engine<float> {
 
   // SYRK of the diagonal tile on the 36 lower 16x16 blocks of its 8x8 block grid, nine per wave: wave g owns block
   // rows 4+g (5+g blocks) and 3-g (4-g blocks) -- equal MFMA counts on all four SIMDs, 56 % of the full tile.
-  // v_mfma_f32_16x16x4_f32; an MFMA's k index <-> staged column 8*(lane>>4) + m (m = 0..7 per 32-wide chunk).
+  // v_mfma_f32_16x16x4_f32.  Staged rows have stride SYRK_LDT = 40 words and lane (r, kq) reads the two 16-byte
+  // pieces at words 4kq and 16+4kq (an MFMA's k index is only a pairing of columns): the one (stride, offsets)
+  // combination for which the ds_read_b128 of a 16x16 fragment is bank-conflict free (stride 36: 32 % conflicts).
+  static constexpr int SYRK_LDT = 40;
   using Sy = f32x4;
   template <int G>
   static __device__ __forceinline__ void syrk36(const float* sA, f32x4* acc, int lane) {
     constexpr int UH = 4 + G, UL = 3 - G;
-    const int o = (lane & 15) * 36 + 8 * (lane >> 4);
+    const int o = (lane & 15) * 40 + 4 * (lane >> 4);
     float fbh[8], fbl[8];
     {
-      const float4 a = *reinterpret_cast<const float4*>(sA + 16 * UH * 36 + o), b = *reinterpret_cast<const float4*>(sA + 16 * UH * 36 + o + 4);
-      const float4 c = *reinterpret_cast<const float4*>(sA + 16 * UL * 36 + o), d = *reinterpret_cast<const float4*>(sA + 16 * UL * 36 + o + 4);
+      const float4 a = *reinterpret_cast<const float4*>(sA + 16 * UH * 40 + o), b = *reinterpret_cast<const float4*>(sA + 16 * UH * 40 + o + 16);
+      const float4 c = *reinterpret_cast<const float4*>(sA + 16 * UL * 40 + o), d = *reinterpret_cast<const float4*>(sA + 16 * UL * 40 + o + 16);
       fbh[0] = a.x; fbh[1] = a.y; fbh[2] = a.z; fbh[3] = a.w; fbh[4] = b.x; fbh[5] = b.y; fbh[6] = b.z; fbh[7] = b.w;
       fbl[0] = c.x; fbl[1] = c.y; fbl[2] = c.z; fbl[3] = c.w; fbl[4] = d.x; fbl[5] = d.y; fbl[6] = d.z; fbl[7] = d.w;
     }
@@ -191,7 +194,7 @@ struct Engine<float> {
 #pragma unroll
         for (int m = 0; m < 8; ++m) fa[m] = fbl[m];
       } else {
-        const float4 a = *reinterpret_cast<const float4*>(sA + 16 * v * 36 + o), b = *reinterpret_cast<const float4*>(sA + 16 * v * 36 + o + 4);
+        const float4 a = *reinterpret_cast<const float4*>(sA + 16 * v * 40 + o), b = *reinterpret_cast<const float4*>(sA + 16 * v * 40 + o + 16);
         fa[0] = a.x; fa[1] = a.y; fa[2] = a.z; fa[3] = a.w; fa[4] = b.x; fa[5] = b.y; fa[6] = b.z; fa[7] = b.w;
       }
 #pragma unroll
@@ -334,16 +337,18 @@ struct Engine<double> {
   struct Blk {
     f64x4 v[2][2];
   };
-  // see Engine<float>::syrk36; staged rows have stride 18, a k-chunk is 16 wide: k index <-> column 4*(lane>>4) + m
+  // see Engine<float>::syrk36; staged rows have stride 20 doubles (40 words), a k-chunk is 16 wide, lane (r, kq) reads
+  // doubles 2kq, 2kq+1 and 8+2kq, 9+2kq (words 4kq and 16+4kq): conflict free
+  static constexpr int SYRK_LDT = 20;
   using Sy = f64x4;
   template <int G>
   static __device__ __forceinline__ void syrk36(const double* sA, f64x4* acc, int lane) {
     constexpr int UH = 4 + G, UL = 3 - G;
-    const int o = (lane & 15) * 18 + 4 * (lane >> 4);
+    const int o = (lane & 15) * 20 + 2 * (lane >> 4);
     double fbh[4], fbl[4];
     {
-      const double2 a = *reinterpret_cast<const double2*>(sA + 16 * UH * 18 + o), b = *reinterpret_cast<const double2*>(sA + 16 * UH * 18 + o + 2);
-      const double2 c = *reinterpret_cast<const double2*>(sA + 16 * UL * 18 + o), d = *reinterpret_cast<const double2*>(sA + 16 * UL * 18 + o + 2);
+      const double2 a = *reinterpret_cast<const double2*>(sA + 16 * UH * 20 + o), b = *reinterpret_cast<const double2*>(sA + 16 * UH * 20 + o + 8);
+      const double2 c = *reinterpret_cast<const double2*>(sA + 16 * UL * 20 + o), d = *reinterpret_cast<const double2*>(sA + 16 * UL * 20 + o + 8);
       fbh[0] = a.x; fbh[1] = a.y; fbh[2] = b.x; fbh[3] = b.y;
       fbl[0] = c.x; fbl[1] = c.y; fbl[2] = d.x; fbl[3] = d.y;
     }
@@ -357,7 +362,7 @@ struct Engine<double> {
 #pragma unroll
         for (int m = 0; m < 4; ++m) fa[m] = fbl[m];
       } else {
-        const double2 a = *reinterpret_cast<const double2*>(sA + 16 * v * 18 + o), b = *reinterpret_cast<const double2*>(sA + 16 * v * 18 + o + 2);
+        const double2 a = *reinterpret_cast<const double2*>(sA + 16 * v * 20 + o), b = *reinterpret_cast<const double2*>(sA + 16 * v * 20 + o + 8);
         fa[0] = a.x; fa[1] = a.y; fa[2] = b.x; fa[3] = b.y;
       }
 #pragma unroll
@@ -433,7 +438,7 @@ struct Engine<double> {
 // Optional rider on the SYRK K-loop of chol_diag: the panel rows L_j,0:j pass through LDS anyway, so
 // t[r] = sum_k L[row0+r][k] y[k] (the forward-substitution update) costs 16 VALU FMAs per thread and
 // chunk in the shadow of the MFMAs.  Thread pair (2r, 2r+1) splits the chunk's k range in two.
-template <typename T, bool SAME, bool GEMV, typename Compute>
+template <typename T, bool SAME, bool GEMV, int LDT, typename Compute>
 __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA, const T* __restrict__ Brows,
                                         int validB, int64_t ld, int K, T* sA, T* sB, int tid, const T* gemv_y,
                                         T* gemv_part, Compute&& compute) {
@@ -472,15 +477,15 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int row = lrow + 32 * u;
-      *reinterpret_cast<uint4*>(sA + row * C::LDT + lc * C::VEC) = ra[u];
-      if (!SAME) *reinterpret_cast<uint4*>(sB + row * C::LDT + lc * C::VEC) = rb[u];
+      *reinterpret_cast<uint4*>(sA + row * LDT + lc * C::VEC) = ra[u];
+      if (!SAME) *reinterpret_cast<uint4*>(sB + row * LDT + lc * C::VEC) = rb[u];
     }
     __syncthreads();
     if (kc + 1 < nk) gload((kc + 1) * C::KB);
     if constexpr (GEMV) {
       if (gemv_y) {
         constexpr int HALF = C::KB / 2;
-        const V* rp = reinterpret_cast<const V*>(sA + (tid >> 1) * C::LDT + (tid & 1) * HALF);
+        const V* rp = reinterpret_cast<const V*>(sA + (tid >> 1) * LDT + (tid & 1) * HALF);
         const V* yp = reinterpret_cast<const V*>(gemv_y + kc * C::KB + (tid & 1) * HALF);
 #pragma unroll
         for (int i = 0; i < HALF / C::VEC; ++i) {
@@ -506,7 +511,7 @@ __device__ __forceinline__ void kloop(const T* __restrict__ Arows, int validA, c
                                       typename Engine<T>::Acc& acc, int tid, const T* gemv_y = nullptr,
                                       T* gemv_part = nullptr) {
   const int wave = tid >> 6, lane = tid & 63;
-  kloop_f<T, SAME, GEMV>(Arows, validA, Brows, validB, ld, K, sA, sB, tid, gemv_y, gemv_part, [&]() __attribute__((always_inline)) {
+  kloop_f<T, SAME, GEMV, CT<T>::LDT>(Arows, validA, Brows, validB, ld, K, sA, sB, tid, gemv_y, gemv_part, [&]() __attribute__((always_inline)) {
     Engine<T>::chunk(sA, (SAME ? sA : sB) + 32 * wave * CT<T>::LDT, acc, lane);
   });
 }
@@ -721,7 +726,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[i][k] = T(0);
   T tpart = T(0);  // this thread's half of (L_j,0:j y)[tid >> 1]
-  kloop_f<T, true, true>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, row0, tile, nullptr, tid,
+  kloop_f<T, true, true, E::SYRK_LDT>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, row0, tile, nullptr, tid,
                          fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
     if (wave == 0) E::template syrk36<0>(tile, acc, lane);
     else if (wave == 1) E::template syrk36<1>(tile, acc, lane);
