@@ -96,6 +96,39 @@ int thx_se3_adjoint(const void* X, void* A, int64_t N, int dtype, void* stream);
 int thx_pg_assemble(const thx_pg_structure* s, const thx_pg_data* d, void* H, int64_t ld, void* g,
                     int dtype, const thx_lie_eps* eps, void* stream);
 
+/* ---- Generic assembly for ANY cost function: the same H (lower triangle) and g as thx_pg_assemble, from
+ *      per-cost weighted Jacobian blocks J (B, dim, dof) and weighted errors e (B, dim) supplied as tensors
+ *      (what CostFunction.weighted_jacobians_error returns, core/cost_function.py:107-122); replaces
+ *      DenseLinearization._linearize_jacobian_impl + _linearize_hessian_impl (dense_linearization.py:29-62)
+ *      for objectives the fused pose-graph kernels do not cover.  All tables are DEVICE arrays built by the host:
+ *        h_targets[t]: one non-zero block of tril(H) (row0 >= col0), with its CSR range of terms;
+ *        h_terms[k]  : one J_a^T J_b contribution (device pointers, element batch strides; 0 = shared);
+ *        h_elem2target[e]: owning target of output element e (elements of a target are contiguous from
+ *                          elem_begin, row major dof_a x dof_b).
+ *      Same for g with (J, e) terms.  Deterministic (no atomics), sums carried in fp64. */
+typedef struct {
+  int32_t row0, col0, dof_a, dof_b, term_begin, term_end, elem_begin, pad_;
+} thx_block_target;
+typedef struct {
+  const void* Ja;
+  const void* Jb;
+  int64_t bstride_a, bstride_b;
+  int32_t dim, dof_a, dof_b, pad_;
+} thx_block_term;
+typedef struct {
+  int32_t col0, dof, term_begin, term_end, elem_begin, pad_;
+} thx_grad_target;
+typedef struct {
+  const void* J;
+  const void* e;
+  int64_t bstride_j, bstride_e;
+  int32_t dim, dof;
+} thx_grad_term;
+int thx_block_assemble(const thx_block_target* h_targets, const thx_block_term* h_terms, const int32_t* h_elem2target,
+                       int32_t n_h_elems, const thx_grad_target* g_targets, const thx_grad_term* g_terms,
+                       const int32_t* g_elem2target, int32_t n_g_elems, void* H, int64_t ld, void* g, int64_t ldg,
+                       int32_t B, int dtype, void* stream);
+
 /* ---- Objective.error_metric(): 0.5 * ||weighted error||^2 per problem (core/objective.py:37-38,
  *      562-641).  `partials` is a (B, THX_ERR_CHUNKS) scratch; the reduction order is fixed
  *      (deterministic).  err is (B). */

@@ -70,6 +70,26 @@ class OracleKernels:
         m = ignore_mask.bool() if ignore_mask is not None else None
         out.copy_(opg.retract(x, delta * step, ignore_mask=m).transpose(0, 1))
 
+    # ---- generic block assembly: dense A scatter + A^T A, as DenseLinearization does ----
+    def block_assemble(self, asm, jacobians, errors, H, g):
+        ref = H if H is not None else g
+        B = ref.shape[0]
+        m = sum(asm.cost_dims)
+        A = torch.zeros(B, m, asm.n, dtype=ref.dtype)
+        b = torch.zeros(B, m, dtype=ref.dtype)
+        r = 0
+        for c, (Js, e) in enumerate(zip(jacobians, errors)):
+            d = asm.cost_dims[c]
+            for s, J in enumerate(Js):
+                c0, dof = asm.var_cols[asm.cost_vars[c][s]]
+                A[:, r:r + d, c0:c0 + dof] = J
+            b[:, r:r + d] = -e
+            r += d
+        if H is not None:
+            H[:, :asm.n, :asm.n] = torch.tril(A.transpose(1, 2) @ A)
+        if g is not None:
+            g.copy_((A.transpose(1, 2) @ b.unsqueeze(2)).squeeze(2))
+
     # ---- implicit backward (torch autograd through the oracle, which mirrors torchlie's backward conventions) ----
     def se3_retract_vjp(self, poses, delta, step, grad_out, grad_delta):
         x = poses.transpose(0, 1)

@@ -236,3 +236,58 @@ def test_lm_accept_matches_reference_formula(K, ellipsoidal):
     K.lm_accept(delta.cuda(), g.cuda(), H.cuda(), n, lam_d, prev.cuda(), new.cuda(), ellipsoidal, 0.1, 9.0, 11.0, rej_d)
     assert torch.equal(rej_d.cpu().bool(), rej)
     np.testing.assert_allclose(lam_d.cpu().numpy(), lam_ref.numpy(), rtol=1e-14)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_generic_block_assembly_vs_dense_scatter(K, dtype):
+    """thx_block_assemble against the reference's recipe: scatter the blocks into dense A, b and form A^T A, A^T b
+    (dense_linearization.py:29-62).  Mixed dofs / dims, shared (batch-1) blocks, a variable met by many costs."""
+    from theseus_amd.generic import BlockAssembler
+    from theseus_amd.kernels import round_up
+    gen = torch.Generator().manual_seed(11)
+    dofs = [1, 2, 3, 6, 4, 3]
+    cols, c0 = [], 0
+    for d in dofs:
+        cols.append((c0, d)); c0 += d
+    n = c0
+    cost_vars = [[0, 3], [3], [5, 1, 2], [4, 3], [2, 0], [1], [3, 5], [4, 2, 0, 1]]
+    cost_dims = [2, 6, 3, 4, 1, 2, 6, 5]
+    B = 70
+    Js, es = [], []
+    for c, vs in enumerate(cost_vars):
+        shared = c in (1, 5)  # batch-1 blocks broadcast over the batch
+        Js.append([torch.randn(1 if shared else B, cost_dims[c], dofs[v], dtype=torch.float64, generator=gen).to(dtype).cuda()
+                   for v in vs])
+        es.append(torch.randn(1 if shared else B, cost_dims[c], dtype=torch.float64, generator=gen).to(dtype).cuda())
+    asm = BlockAssembler(cols, cost_vars, cost_dims)
+    ld = round_up(n, 32)
+    H = torch.zeros(B, ld, ld, dtype=dtype, device="cuda")
+    g = torch.zeros(B, n, dtype=dtype, device="cuda")
+    asm.assemble(K, Js, es, H, g)
+    m = sum(cost_dims)
+    A = torch.zeros(B, m, n, dtype=torch.float64)
+    b = torch.zeros(B, m, dtype=torch.float64)
+    r = 0
+    for c, vs in enumerate(cost_vars):
+        for s, v in enumerate(vs):
+            A[:, r:r + cost_dims[c], cols[v][0]:cols[v][0] + dofs[v]] = Js[c][s].cpu().double()
+        b[:, r:r + cost_dims[c]] = -es[c].cpu().double()
+        r += cost_dims[c]
+    AtA, Atb = A.transpose(1, 2) @ A, (A.transpose(1, 2) @ b.unsqueeze(2)).squeeze(2)
+    tol = 1e-6 if dtype == torch.float32 else 1e-13
+    Hl = torch.tril(H[:, :n, :n]).cpu().double()
+    assert (Hl - torch.tril(AtA)).abs().max() <= tol * AtA.abs().max()
+    assert (g.cpu().double() - Atb).abs().max() <= tol * Atb.abs().max()
+    # only the block pattern is written
+    pat = torch.zeros(n, n, dtype=torch.bool)
+    for (r0, c0_, da, db) in asm.lower_block_pattern():
+        pat[r0:r0 + da, c0_:c0_ + db] = True
+    assert not (H[:, :n, :n].cpu()[:, ~pat] != 0).any()
+    # an odd-order system goes through the dense solver (identity padding up to the tile edge)
+    from tests.gpu_helpers import factor_and_solve
+    Hd = H.clone()
+    Hd[:, torch.arange(n), torch.arange(n)] += 1.0
+    L, x, info = factor_and_solve(K, Hd, n, g, fused=True)
+    assert n % 2 == 1 and int(info.abs().sum()) == 0
+    ref = torch.linalg.solve(torch.tril(AtA) + torch.tril(AtA, -1).transpose(1, 2) + torch.eye(n, dtype=torch.float64), Atb)
+    assert (x.cpu().double() - ref).abs().max() <= (2e-4 if dtype == torch.float32 else 1e-11) * ref.abs().max()

@@ -98,10 +98,107 @@ def test_plugin_through_theseus_layer_and_failure_path(ref):
     assert all(s == th.NonlinearOptimizerStatus.FAIL for s in info.status)
 
 
-def test_unsupported_cost_function_is_refused(ref):
+def test_non_pose_graph_objective_takes_the_generic_path(ref):
+    """Vector variables + Difference: not an SE3 pose graph -> generic block assembly, same result as the reference."""
     th, thp = ref
+    from tests.oracle_kernels import OracleKernels
+    out = {}
+    for tag in ("ref", "ours"):
+        obj = th.Objective(dtype=torch.float64)
+        a = th.Vector(tensor=torch.tensor([[1.0, -2.0], [0.5, 3.0]], dtype=torch.float64), name="a")
+        b = th.Vector(tensor=torch.tensor([[0.0, 1.0], [2.0, 2.0]], dtype=torch.float64), name="b")
+        tgt = th.Vector(tensor=torch.tensor([[4.0, 4.0]], dtype=torch.float64), name="t")
+        w = th.ScaleCostWeight(torch.tensor(2.0, dtype=torch.float64))
+        obj.add(th.Difference(a, tgt, w, name="d0"))
+        obj.add(th.Between(a, b, th.Vector(tensor=torch.tensor([[1.0, 1.0]], dtype=torch.float64), name="m"), w, name="d1"))
+        kw = {} if tag == "ref" else dict(linear_solver_cls=thp.HipCholeskySolver,
+                                          linearization_kwargs=dict(kernels=OracleKernels()))
+        opt = th.LevenbergMarquardt(obj, max_iterations=5, **kw)
+        obj.update()
+        with torch.no_grad():
+            opt.optimize(damping=0.1)
+        out[tag] = torch.cat([a.tensor, b.tensor], 1)
+        if tag == "ours":
+            assert not opt.linear_solver.linearization.fused
+    np.testing.assert_allclose(out["ours"].numpy(), out["ref"].numpy(), rtol=1e-12, atol=1e-12)
+
+
+def _quadratic_fit(th, B=16, N=20, seed=0):
+    """examples/simple_example.py (BASELINE.json configs[0]): fit y = v exp(x), AutoDiffCostFunction on a Vector."""
+    gen = torch.Generator().manual_seed(seed)
+    x_true = torch.linspace(-1, 1, N, dtype=torch.float64).view(1, -1).repeat(B, 1)
+    c_true = 0.5 + 0.2 * torch.rand(B, 1, dtype=torch.float64, generator=gen)
+    y = c_true * torch.exp(x_true)
+    x = th.Variable((x_true + 0.05 * torch.randn(B, N, dtype=torch.float64, generator=gen)), name="x")
+    yv = th.Variable(y, name="y")
+    v = th.Vector(1, name="v", dtype=torch.float64)
+
+    def error_fn(optim_vars, aux_vars):
+        xx, yy = aux_vars
+        return yy.tensor - optim_vars[0].tensor * torch.exp(xx.tensor)
+
     obj = th.Objective(dtype=torch.float64)
-    a, b = th.Vector(2, name="a", dtype=torch.float64), th.Vector(2, name="b", dtype=torch.float64)
-    obj.add(th.Difference(a, b, th.ScaleCostWeight(torch.tensor(1.0, dtype=torch.float64)), name="d"))
-    with pytest.raises(NotImplementedError):
-        th.LevenbergMarquardt(obj, linear_solver_cls=thp.HipCholeskySolver)
+    obj.add(th.AutoDiffCostFunction([v], error_fn, N, aux_vars=[x, yv],
+                                    cost_weight=th.ScaleCostWeight(torch.tensor(1.0, dtype=torch.float64))))
+    return obj, x.tensor.clone()
+
+
+def test_generic_path_runs_simple_example_config0(ref):
+    """BASELINE.json configs[0]: quadratic fit, batch 16, GaussNewton + dense Cholesky, implicit backward through
+    TheseusLayer -- the reference's own loop and AutoDiffCostFunction, our Linearization / LinearSolver behind it
+    (generic block assembly; stand-in kernels here, HIP kernels on a GPU)."""
+    th, thp = ref
+    from tests.oracle_kernels import OracleKernels
+    res = {}
+    for tag in ("ref", "ours"):
+        obj, x0 = _quadratic_fit(th)
+        kw = {} if tag == "ref" else dict(linear_solver_cls=thp.HipCholeskySolver,
+                                          linearization_kwargs=dict(kernels=OracleKernels()))
+        layer = th.TheseusLayer(th.GaussNewton(obj, max_iterations=10, **kw))
+        phi = x0.clone().requires_grad_(True)
+        sol, info = layer.forward(input_tensors={"x": phi, "v": torch.ones(16, 1, dtype=torch.float64)},
+                                  optimizer_kwargs={"backward_mode": "implicit"})
+        loss = ((sol["v"] - 0.5) ** 2).mean()
+        loss.backward()
+        res[tag] = (sol["v"].detach(), loss.item(), phi.grad.clone(), info)
+        if tag == "ours":
+            assert not layer.optimizer.linear_solver.linearization.fused
+    np.testing.assert_allclose(res["ours"][0].numpy(), res["ref"][0].numpy(), rtol=1e-10, atol=1e-12)
+    assert abs(res["ours"][1] - res["ref"][1]) < 1e-12
+    np.testing.assert_allclose(res["ours"][2].numpy(), res["ref"][2].numpy(), rtol=1e-8, atol=1e-12)
+
+
+def test_fused_path_is_differentiable_through_the_reference_loop(ref):
+    """backward_mode="implicit" of the REAL loop with the plugin on an SE3 pose graph: Atb's backward is the fused
+    VJP, the solve's backward the cached-factor solve; gradients equal the ones the reference recorded."""
+    th, thp = ref
+    from tests.oracle_kernels import OracleKernels
+    g = load_golden("pg_f64_implicit")
+    t = torch.from_numpy
+    _, _, kw = golden_problem(g)
+    kw.pop("gauss_newton")
+    P = int(g["P"])
+    leaves = dict(meas=t(g["meas"]).requires_grad_(True), w_between=t(g["w_between"]).requires_grad_(True),
+                  prior_target=t(g["prior_target"]).requires_grad_(True),
+                  w_prior=t(g["w_prior"])[:, :, :1].clone().requires_grad_(True))
+    obj = th.Objective(dtype=torch.float64)
+    poses = [th.SE3(tensor=t(g["poses0"])[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    for k in range(g["edges"].shape[0]):
+        i, j = g["edges"][k].tolist()
+        obj.add(th.Between(poses[i], poses[j], th.SE3(tensor=leaves["meas"][:, k], name=f"meas_{k}"),
+                           th.DiagonalCostWeight(th.Variable(leaves["w_between"][:, k], name=f"w_{k}")), name=f"between_{k}"))
+    for k in range(g["prior_idx"].shape[0]):
+        obj.add(th.Difference(poses[int(g["prior_idx"][k])], th.SE3(tensor=leaves["prior_target"][:, k], name=f"tgt_{k}"),
+                              th.ScaleCostWeight(th.Variable(leaves["w_prior"][:, k], name=f"pw_{k}")), name=f"prior_{k}"))
+    opt = th.LevenbergMarquardt(obj, linear_solver_cls=thp.HipCholeskySolver,
+                                linearization_kwargs=dict(kernels=OracleKernels()), max_iterations=kw.pop("max_iterations"),
+                                step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    assert opt.linear_solver.linearization.fused
+    sol, _ = th.TheseusLayer(opt).forward(optimizer_kwargs=dict(backward_mode="implicit", **kw))
+    final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
+    (t(g["coef"]) * final).sum().backward()
+    np.testing.assert_allclose(final.detach().numpy(), g["final"], rtol=0, atol=1e-7)
+    for key, refk in (("meas", "grad_meas"), ("w_between", "grad_w_between"), ("prior_target", "grad_prior_target"),
+                      ("w_prior", "grad_w_prior")):
+        want = g[refk]
+        np.testing.assert_allclose(leaves[key].grad.numpy(), want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)

@@ -1310,7 +1310,6 @@ static int check_factor_args(const void* H, const void* L, const void* panel, co
                              int64_t ld) {
   if (!H || !L || !panel || !info) return fail("thx_chol_factor: null pointer");
   if (n <= 0 || B <= 0 || ld < n || (ld % 32) != 0) return fail("thx_chol_factor: need n>0, B>0, ld>=n, ld%32==0");
-  if (n % 2) return fail("thx_chol_factor: n must be even");
   return 0;
 }
 

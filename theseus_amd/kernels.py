@@ -149,6 +149,29 @@ class HipKernels:
                                             _lib.ptr(ignore_mask), _lib.ptr(out), P, B, _lib.dtype_code(dt),
                                             lie_eps(dt), _lib.stream_ptr(poses.device)), "thx_se3_retract")
 
+    # ---- generic block assembly ------------------------------------------------------------------
+    def block_assemble(self, asm, jacobians, errors, H, g):
+        """asm: theseus_amd.generic.BlockAssembler; jacobians[c][slot] (B|1, dim, dof), errors[c] (B|1, dim)."""
+        import numpy as np
+        for Js in jacobians:
+            for J in Js:
+                _lib.ptr(J, "jacobian block")  # device / contiguity check
+        h_terms, g_terms = asm.term_tables(jacobians, errors)
+        ref = H if H is not None else g
+        dev = ref.device
+        ht_d, he2t_d, gt_d, ge2t_d = asm._static(dev)
+        up = lambda a: torch.from_numpy(a.view(np.uint8).reshape(-1)).to(dev)  # noqa: E731
+        hterm_d, gterm_d = up(h_terms), up(g_terms)
+        B = ref.shape[0]
+        nh = asm.n_h_elems if H is not None else 0
+        ng = asm.n_g_elems if g is not None else 0
+        _lib.check(self.lib.thx_block_assemble(
+            _lib.ptr(ht_d), _lib.ptr(hterm_d), _lib.ptr(he2t_d), nh, _lib.ptr(gt_d), _lib.ptr(gterm_d), _lib.ptr(ge2t_d), ng,
+            _lib.ptr(H), H.shape[-1] if H is not None else 0, _lib.ptr(g), g.stride(0) if g is not None else 0, B,
+            _lib.dtype_code(ref.dtype), _lib.stream_ptr(dev)), "thx_block_assemble")
+        # keep the uploaded tables alive until the stream has consumed them
+        self._keepalive = (hterm_d, gterm_d)
+
     # ---- implicit backward ----------------------------------------------------------------------
     def se3_retract_vjp(self, poses, delta, step, grad_out, grad_delta):
         P, B = poses.shape[:2]

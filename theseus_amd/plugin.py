@@ -8,11 +8,24 @@
 
 The reference's optimiser loop (nonlinear_least_squares.py:100-215) stays untouched and talks to the two ABCs
 ``Linearization`` (theseus/optimizer/linearization.py:16-87) and ``LinearSolver``
-(theseus/optimizer/linear/linear_solver.py:15-37); everything behind them runs in libtheseus_hip.so.
-``theseus`` is imported lazily: this module is only usable where the reference is installed (it is not on the
-GPU box of this build; tests/test_plugin_reference.py exercises it in the container that has /root/reference).
+(theseus/optimizer/linear/linear_solver.py:15-37); everything behind them runs in libtheseus_hip.so:
+
+* SE3 pose graphs (``th.Between`` / ``th.Difference`` with Scale/Diagonal cost weights) take the FUSED path: the
+  cost functions are never evaluated by torch, ``thx_pg_assemble`` builds H and g from the packed variables;
+* every other objective (``th.AutoDiffCostFunction``, user cost functions, any variable type) takes the GENERIC
+  path: the reference evaluates its (vectorised) weighted Jacobians, ``thx_block_assemble`` turns the blocks into
+  H and g without the dense ``A`` of ``DenseLinearization`` (dense_linearization.py:29-62).
+
+Both feed ``thx_chol_factor_forward`` / ``thx_chol_solve_backward``.  Autograd: H is always built outside the graph
+(= ``_detach_hessian=True``, what ``backward_mode="implicit"`` asks for); ``Atb`` and ``solve()`` are
+differentiable -- the solve's backward is one ``thx_chol_solve`` with the cached factor, the fused ``Atb``'s backward
+is ``thx_pg_vjp``, the generic ``Atb`` is formed by torch from the reference's own differentiable Jacobians.
+Unrolled differentiation THROUGH the Hessian is refused.
+
+``theseus`` is imported at module import: this file is only usable where the reference is installed (it is not on
+the GPU box of this build; tests/test_plugin_reference.py exercises it in the container that has /root/reference).
 """
-from typing import Any, Dict, Optional, Type, Union
+from typing import Any, Dict, List, Optional, Type, Union
 
 import torch
 
@@ -21,8 +34,62 @@ from theseus.optimizer import Linearization as _RefLinearization
 from theseus.optimizer.linear import CholeskyDenseSolver as _RefCholeskyDenseSolver
 from theseus.optimizer.linear import LinearSolver as _RefLinearSolver
 
+from .generic import BlockAssembler
+from .kernels import PGTensors, default_kernels, round_up
 from .linear_solver import HipCholeskyCore
 from .linearization import HipLinearizationCore
+from .packed import UnsupportedObjective
+
+
+class _FusedAtb(torch.autograd.Function):
+    """g = A^T b of an SE3 pose graph as a differentiable function of the packed auxiliary tensors: forward is
+    ``thx_pg_assemble`` (which also refreshes H), backward is ``thx_pg_vjp``."""
+
+    @staticmethod
+    def forward(ctx, lin, meas, w_between, prior_target, w_prior):
+        HipLinearizationCore._assemble(lin)
+        t = lin.packed.tensors
+        ctx.lin = lin
+        ctx.tensors = PGTensors(poses=t.poses.detach(), meas=meas.detach(), w_between=w_between.detach(),
+                                prior_target=prior_target.detach(), w_prior=w_prior.detach())
+        return lin.g.clone()
+
+    @staticmethod
+    def backward(ctx, grad_g):
+        lin, t = ctx.lin, ctx.tensors
+        packed = lin.packed
+        B = t.poses.shape[1]
+        E, Kp = packed.structure.num_edges, packed.structure.num_priors
+        new = lambda *s: torch.empty(*s, dtype=grad_g.dtype, device=grad_g.device)  # noqa: E731
+        g_meas, g_wb = new(max(E, 1), B, 3, 4), new(max(E, 1), B, 6)
+        g_tgt, g_wp = new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 6)
+        lin.K.pg_vjp(packed.dstruct, t, grad_g.contiguous(), g_meas, g_wb, g_tgt, g_wp)
+
+        def fit(g, count, like):
+            g = g[:count]
+            return g.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else g
+        return None, fit(g_meas, E, t.meas), fit(g_wb, E, t.w_between), fit(g_tgt, Kp, t.prior_target), fit(g_wp, Kp, t.w_prior)
+
+
+class _CachedFactorSolve(torch.autograd.Function):
+    """delta = (H + damping)^-1 g with H outside autograd: backward = one solve with the cached factor."""
+
+    @staticmethod
+    def forward(ctx, solver, damping, ellipsoidal, eps, g):
+        y = solver.factorize(damping, ellipsoidal, eps, rhs=g.detach().contiguous())
+        delta = torch.empty_like(y)
+        solver.K.chol_solve_backward(solver.L, solver.linearization.n, solver.panels, y, delta)
+        solver.check_info()
+        ctx.solver, ctx.version = solver, solver.factor_version
+        return delta
+
+    @staticmethod
+    def backward(ctx, grad_delta):
+        s = ctx.solver
+        if s.factor_version != ctx.version:
+            raise RuntimeError("implicit backward: the cached Cholesky factor of this forward pass was overwritten by "
+                               "a later factorisation on the same solver; call backward() before the next forward().")
+        return None, None, None, None, s.solve_with_factor(grad_delta.contiguous())
 
 
 class HipLinearization(HipLinearizationCore, _RefLinearization):
@@ -30,15 +97,113 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
 
     def __init__(self, objective: th.Objective, ordering=None, kernels=None, **kwargs):
         _RefLinearization.__init__(self, objective, ordering)
-        self._core_init(objective, kernels)
+        self._g_graph: Optional[torch.Tensor] = None
+        try:
+            self._core_init(objective, kernels)
+            self.fused = True
+        except UnsupportedObjective:
+            self.fused = False
+            self._generic_init(objective, kernels)
 
+    # ---- generic path ------------------------------------------------------------------------------------
+    def _generic_init(self, objective, kernels):
+        if [v.name for v in self.ordering] != list(objective.optim_vars.keys()):
+            raise NotImplementedError("HipLinearization uses the default (insertion) variable ordering.")
+        self.K = kernels or default_kernels()
+        self.packed = None
+        costs = list(objective.cost_functions.values())
+        cost_vars = [[self.ordering.index_of(cf.optim_var_at(i).name) for i in range(cf.num_optim_vars())] for cf in costs]
+        self.asm = BlockAssembler(list(zip(self.var_start_cols, self.var_dims)), cost_vars, [cf.dim() for cf in costs])
+        self._n, self._ld = self.num_cols, round_up(self.num_cols, 32)
+        self.H = self.g = None
+        self._AtA_cache = self._A = self._b = None
+
+    @property
+    def n(self):
+        return self.packed.n if self.fused else self._n
+
+    @property
+    def ld(self):
+        return self.packed.ld if self.fused else self._ld
+
+    def _weighted_blocks(self):
+        Js, es = [], []
+        for cf in self.objective._get_jacobians_iter():  # vectorised when the objective is (objective.py:836-843)
+            jac, err = cf.weighted_jacobians_error()
+            Js.append([j.contiguous() for j in jac])
+            es.append(err.contiguous())
+        return Js, es
+
+    def _assemble_generic(self):
+        Js, es = self._weighted_blocks()
+        B, dev, dt = self.objective.batch_size, self.objective.device, self.objective.dtype
+        if self.H is None or self.H.shape[0] != B or self.H.device != dev or self.H.dtype != dt:
+            self.H = torch.zeros(B, self.ld, self.ld, dtype=dt, device=dev)  # zero once: fixed block pattern
+            self.g = torch.empty(B, self.n, dtype=dt, device=dev)
+        need_graph = torch.is_grad_enabled() and any(t.requires_grad for J in Js for t in J) or \
+            (torch.is_grad_enabled() and any(e.requires_grad for e in es))
+        Jd = [[j.detach() for j in J] for J in Js]
+        ed = [e.detach() for e in es]
+        self.asm.assemble(self.K, Jd, ed, self.H, self.g, gradient=not need_graph)
+        self._blocks = (Jd, ed)  # the launch reads these tensors: keep them alive
+        self._g_graph = None
+        if need_graph:  # Atb = A^T b from the reference's differentiable Jacobians, block by block (no dense A)
+            parts: List[Optional[torch.Tensor]] = [None] * len(self.var_dims)
+            for c, (J, e) in enumerate(zip(Js, es)):
+                for s, v in enumerate(self.asm.cost_vars[c]):
+                    term = -(J[s].transpose(1, 2) @ e.unsqueeze(2)).squeeze(2)
+                    parts[v] = term if parts[v] is None else parts[v] + term
+            zero = lambda d: torch.zeros(B, d, dtype=dt, device=dev)  # noqa: E731
+            self._g_graph = torch.cat([(p.expand(B, -1) if p is not None else zero(d)) for p, d in zip(parts, self.var_dims)], 1)
+            self.g = self._g_graph.detach().contiguous()
+        self._AtA_cache = self._A = self._b = None
+
+    def _materialize_generic_A_b(self):
+        Jd, ed = self._blocks
+        B = self.H.shape[0]
+        A = torch.zeros(B, self.num_rows, self.num_cols, dtype=self.H.dtype, device=self.H.device)
+        b = torch.zeros(B, self.num_rows, dtype=self.H.dtype, device=self.H.device)
+        r = 0
+        for c, (J, e) in enumerate(zip(Jd, ed)):
+            d = self.asm.cost_dims[c]
+            for s, v in enumerate(self.asm.cost_vars[c]):
+                c0, dof = self.asm.var_cols[v]
+                A[:, r:r + d, c0:c0 + dof] = J[s]
+            b[:, r:r + d] = -e
+            r += d
+        self._A, self._b = A, b
+
+    # ---- the ABC ---------------------------------------------------------------------------------------------
     def _linearize_jacobian_impl(self):
-        self._materialize_A_b()
+        if self.fused:
+            self._materialize_A_b()
+        else:
+            self._materialize_generic_A_b()
+
+    def _materialize_A_b(self):  # .A / .b properties of the core
+        if self.fused:
+            HipLinearizationCore._materialize_A_b(self)
+        else:
+            self._materialize_generic_A_b()
 
     def _linearize_hessian_impl(self, _detach_hessian: bool = False):
-        # the Hessian is built by a kernel outside autograd, i.e. it is always "detached"
-        # (dense_linearization.py:61 detaches it in the implicit step; UNROLL backward is not supported)
-        self._assemble()
+        if not self.fused:
+            self._assemble_generic()
+            graph = self._g_graph is not None
+        else:
+            packed = self.packed
+            graph = torch.is_grad_enabled() and any(v.tensor.requires_grad for v in packed._tracked())
+            if graph:
+                packed.sync(force=True)  # re-pack WITH the autograd history of the auxiliary variables
+                t = packed.tensors
+                self._g_graph = _FusedAtb.apply(self, t.meas, t.w_between, t.prior_target, t.w_prior)
+            else:
+                self._g_graph = None
+                self._assemble()
+        if graph and not _detach_hessian:
+            raise NotImplementedError(
+                "theseus_amd builds the Hessian outside autograd: differentiating through it (backward_mode='unroll' "
+                "with gradients) is not supported.  Use backward_mode='implicit', or run under torch.no_grad().")
 
     def hessian_approx(self):
         return self._full_AtA()
@@ -47,7 +212,8 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
         return self._full_AtA()
 
     def _atb_impl(self) -> torch.Tensor:
-        return self.g.unsqueeze(2)
+        g = self._g_graph if self._g_graph is not None else self.g
+        return g.unsqueeze(2)
 
 
 class HipCholeskySolver(HipCholeskyCore, _RefCholeskyDenseSolver):
@@ -72,6 +238,11 @@ class HipCholeskySolver(HipCholeskyCore, _RefCholeskyDenseSolver):
               damping_eps: float = 1e-8, **kwargs) -> torch.Tensor:
         # failure = RuntimeError, which the reference loop turns into FAIL status under no_grad
         # (nonlinear_least_squares.py:138-152)
+        g = self.linearization._g_graph
+        if g is not None and torch.is_grad_enabled():
+            if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
+                raise ValueError("Damping must be a float or a 1-D tensor.")
+            return _CachedFactorSolve.apply(self, damping, ellipsoidal_damping, damping_eps, g)
         return self._solve(damping, ellipsoidal_damping, damping_eps, check_info=True)
 
     def _solve_sytem(self, Atb: torch.Tensor, AtA: torch.Tensor) -> torch.Tensor:  # abstract in DenseSolver
