@@ -471,6 +471,7 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   };
   const int nk = K / C::KB;
   T gsum = T(0);
+  // (a static s_setprio per hardware wave slot, to push the two co-resident workgroups out of lockstep, measured no gain)
   if (nk > 0) gload(0);
   for (int kc = 0; kc < nk; ++kc) {
     __syncthreads();
