@@ -86,6 +86,27 @@ int thx_se3_compose(const void* X, const void* Y, void* Z, int64_t N, int dtype,
 int thx_se3_inverse(const void* X, void* Y, int64_t N, int dtype, void* stream);
 int thx_se3_adjoint(const void* X, void* A, int64_t N, int dtype, void* stream);
 
+/* ---- SE2 (2-D SLAM) twins of the pose-graph entry points: theseus/geometry/se2.py (:165-229 log + Jlog, :239-300
+ *      exp + Jexp, :309-339 adjoint / compose / inverse), tensors [x, y, cos, sin] -> group records of 4, tangents /
+ *      weights of 3, 3x3 blocks, column layout pose * 3.  thx_pg_structure / thx_pg_data are shared (batch strides
+ *      4 / 3 / 0).  thx_se2_op: 0 exp (a = xi (N,3) -> out (N,4), jac (N,3,3) or NULL), 1 log (a = X -> out (N,3),
+ *      jac), 2 compose (a, b -> out), 3 inverse, 4 adjoint (out (N,3,3)).  The solver entry points are group
+ *      agnostic. */
+typedef struct {
+  double near_zero;   /* se2_near_zero_eps   (theseus/global_params.py:46-59) */
+  double d_near_zero; /* se2_d_near_zero_eps */
+} thx_se2_eps;
+int thx_pg2_assemble(const thx_pg_structure* s, const thx_pg_data* d, void* H, int64_t ld, void* g, int dtype,
+                     const thx_se2_eps* eps, void* stream);
+int thx_pg2_error(const thx_pg_structure* s, const thx_pg_data* d, void* partials, void* err, int dtype,
+                  const thx_se2_eps* eps, void* stream);
+int thx_pg2_jacobians(const thx_pg_structure* s, const thx_pg_data* d, void* J0, void* J1, void* eb, void* Jp,
+                      void* ep, int dtype, const thx_se2_eps* eps, void* stream);
+int thx_se2_retract(const void* poses, const void* delta, int64_t ldd, double step, const uint8_t* ignore_mask,
+                    void* out, int32_t P, int32_t B, int dtype, const thx_se2_eps* eps, void* stream);
+int thx_se2_op(int op, const void* a, const void* b, void* out, void* jac, int64_t N, int dtype,
+               const thx_se2_eps* eps, void* stream);
+
 /* ---- Linearization.linearize(): replaces DenseLinearization._linearize_jacobian_impl +
  *      _linearize_hessian_impl (dense_linearization.py:29-62) fused with Between / Local
  *      Jacobians (embodied/measurements/between.py:38-45, embodied/misc/local_cost_fn.py:58-61)

@@ -103,15 +103,16 @@ def build_reference_objective(th, d, dtype):
     examples/pose_graph/pose_graph_synthetic.py:130-152."""
     B = d["poses"].shape[0]
     obj = th.Objective(dtype=dtype)
-    poses = [th.SE3(tensor=d["poses"][:, k].clone(), name=f"pose_{k}") for k in range(d["P"])]
+    G = th.SE2 if d.get("group", "SE3") == "SE2" else th.SE3
+    poses = [G(tensor=d["poses"][:, k].clone(), name=f"pose_{k}") for k in range(d["P"])]
     for k in range(d["edges"].shape[0]):
         i, j = d["edges"][k].tolist()
         w = d["w_between"][:, k]
         cw = th.DiagonalCostWeight(th.Variable(w.clone(), name=f"w_{k}"))
-        m = th.SE3(tensor=d["meas"][:, k].clone(), name=f"meas_{k}")
+        m = G(tensor=d["meas"][:, k].clone(), name=f"meas_{k}")
         obj.add(th.Between(poses[i], poses[j], m, cw, name=f"between_{k}"))
     for k in range(d["prior_idx"].shape[0]):
-        tgt = th.SE3(tensor=d["prior_target"][:, k].clone(), name=f"prior_target_{k}")
+        tgt = G(tensor=d["prior_target"][:, k].clone(), name=f"prior_target_{k}")
         sw = th.ScaleCostWeight(th.Variable(d["w_prior"][:, k, :1].clone(), name=f"pw_{k}"))
         obj.add(th.Difference(poses[int(d["prior_idx"][k])], tgt, sw, name=f"prior_{k}"))
     obj.update()
@@ -182,6 +183,97 @@ def gen_lm(th, lieF, only=None):
         print(name, "err", err0.mean(), "->", info.err_history[:, -1].mean().item())
 
 
+def gen_se2(th):
+    """SE2 (theseus/geometry/se2.py): Lie-op fixtures incl. the near-zero / d-near-zero branches, and LM trajectories
+    of SE2 pose graphs (Between + Difference) with DenseLinearization + CholeskyDenseSolver."""
+    gen = torch.Generator().manual_seed(23)
+    G = th.SE2
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        angles = [0.0, 1e-8, 5e-7, 2e-6, 5e-4, 2e-3, 2e-2, 4e-2, 8e-2, 0.15, 1.0, 2.5, 3.1, -3.1, -1.0, -2e-2, -5e-7]
+        rows = []
+        for a in angles:
+            for _ in range(3):
+                rows.append(torch.cat([torch.randn(2, dtype=torch.float64, generator=gen), torch.tensor([a], dtype=torch.float64)]))
+        xi = torch.cat([torch.stack(rows), torch.randn(30, 3, dtype=torch.float64, generator=gen)]).to(dtype)
+        jl = []
+        X = G.exp_map(xi, jacobians=jl)
+        jexp = jl[0]
+        Y = G.exp_map(torch.randn(xi.shape[0], 3, dtype=torch.float64, generator=gen).to(dtype))
+        jl = []
+        log = X.log_map(jacobians=jl)
+        np.savez_compressed(os.path.join(OUT, f"lie_se2_{tag}.npz"), xi=xi.numpy(), exp=X.tensor.numpy(), jexp=jexp.numpy(),
+                            log=log.numpy(), jlog=jl[0].numpy(), adj=X.adjoint().numpy(), inv=X.inverse().tensor.numpy(),
+                            Y=Y.tensor.numpy(), compose=X.compose(Y).tensor.numpy())
+    cases = [
+        ("pg2_f64_lm", dict(P=9, E=16, B=4, dtype=torch.float64, seed=41), dict(max_iterations=6, step_size=1.0),
+         dict(damping=1e-3)),
+        ("pg2_f32_lm", dict(P=9, E=16, B=8, dtype=torch.float32, seed=41), dict(max_iterations=6, step_size=1.0),
+         dict(damping=1e-3)),
+        ("pg2_f64_lm_adaptive", dict(P=7, E=12, B=5, dtype=torch.float64, seed=43, batched_weights=True),
+         dict(max_iterations=8, step_size=0.8), dict(damping=1.0, adaptive_damping=True, ellipsoidal_damping=True)),
+    ]
+    for name, pk, ok, lmk in cases:
+        dtype, seed, P, E, B = pk["dtype"], pk["seed"], pk["P"], pk["E"], pk["B"]
+        gen = torch.Generator().manual_seed(seed)
+        rng = np.random.default_rng(seed)
+        edges = [(i, i + 1) for i in range(P - 1)]
+        while len(edges) < E:
+            i, j = sorted(rng.choice(P, 2, replace=False).tolist())
+            if rng.random() < 0.3:
+                i, j = j, i
+            edges.append((i, j))
+        edges = torch.tensor(edges, dtype=torch.long)
+
+        def rnd(n, ts, rs):
+            x = torch.cat([ts * (2 * torch.rand(n, 2, dtype=torch.float64, generator=gen) - 1),
+                           rs * (2 * torch.rand(n, 1, dtype=torch.float64, generator=gen) - 1)], 1)
+            return G.exp_map(x)
+        comp = lambda a, b: a.compose(b)  # noqa: E731
+        gt = rnd(B * P, 3.0, 3.0).tensor.view(B, P, 4)
+        gi, gj = G(tensor=gt[:, edges[:, 0]].reshape(-1, 4)), G(tensor=gt[:, edges[:, 1]].reshape(-1, 4))
+        meas = comp(comp(gi.inverse(), gj), rnd(B * E, 0.05, 0.03)).tensor.view(B, E, 4).to(dtype)
+        poses = comp(G(tensor=gt.reshape(-1, 4)), rnd(B * P, 0.3, 0.25)).tensor.view(B, P, 4).to(dtype)
+        if pk.get("batched_weights"):
+            w_between = ((0.5 + torch.rand(B, E, 3, dtype=torch.float64, generator=gen)) * 10).to(dtype)
+        else:
+            w_between = torch.tensor([[[1 / 0.05] * 2 + [1 / 0.03]]], dtype=torch.float64).repeat(1, E, 1).to(dtype)
+        prior_idx = torch.tensor([0, P // 2], dtype=torch.long)
+        prior_target = comp(G(tensor=gt[:, prior_idx].reshape(-1, 4)), rnd(B * 2, 0.01, 0.01)).tensor.view(B, 2, 4).to(dtype)
+        w_prior = torch.tensor([[[1e-1] * 3, [2.0] * 3]], dtype=dtype)
+        obj = th.Objective(dtype=dtype)
+        pv = [G(tensor=poses[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+        for k in range(E):
+            i, j = edges[k].tolist()
+            cw = th.DiagonalCostWeight(th.Variable(w_between[:, k].clone(), name=f"w_{k}"))
+            obj.add(th.Between(pv[i], pv[j], G(tensor=meas[:, k].clone(), name=f"meas_{k}"), cw, name=f"between_{k}"))
+        for k in range(2):
+            sw = th.ScaleCostWeight(th.Variable(w_prior[:, k, :1].clone(), name=f"pw_{k}"))
+            obj.add(th.Difference(pv[int(prior_idx[k])], G(tensor=prior_target[:, k].clone(), name=f"tgt_{k}"), sw, name=f"prior_{k}"))
+        obj.update()
+        opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True,
+                                    abs_err_tolerance=0.0, rel_err_tolerance=0.0, **ok)
+        taps = dict(AtA=[], Atb=[], delta=[], A=[], b=[], err=[])
+
+        def cb(optimizer, info, delta, it):
+            lin = optimizer.linear_solver.linearization
+            for k_, v_ in (("AtA", lin.AtA), ("Atb", lin.Atb), ("A", lin.A), ("b", lin.b), ("delta", delta), ("err", info.last_err)):
+                taps[k_].append(v_.clone().numpy())
+        lin = opt.linear_solver.linearization
+        with torch.no_grad():
+            err0 = obj.error_metric().clone().numpy()
+            info = opt.optimize(track_err_history=True, end_iter_callback=cb, **lmk)
+        final = torch.stack([p_.tensor for p_ in pv], 1).numpy()
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"), group=np.array("SE2"), P=P, edges=edges.numpy(), meas=meas.numpy(),
+            w_between=w_between.numpy(), prior_idx=prior_idx.numpy(), prior_target=prior_target.numpy(),
+            w_prior=w_prior.numpy(), poses0=poses.numpy(), final=final, err0=err0, err_history=info.err_history.numpy(),
+            AtA=np.stack(taps["AtA"][:1]), Atb=np.stack(taps["Atb"]), A0=taps["A"][0], b0=taps["b"][0],
+            delta=np.stack(taps["delta"]), last_err=np.stack(taps["err"]),
+            var_start_cols=np.array(lin.var_start_cols), var_dims=np.array(lin.var_dims), num_rows=lin.num_rows,
+            num_cols=lin.num_cols, opt_kwargs=np.array(repr(dict(ok, **lmk, gauss_newton=False))))
+        print(name, "err", err0.mean(), "->", info.err_history[:, -1].mean().item())
+
+
 def gen_implicit(th, lieF):
     """Implicit backward (BackwardMode.IMPLICIT, nonlinear_least_squares.py:265-292): LM under no_grad, one
     undamped GN step with the Hessian detached and grad enabled; loss = <coef, final poses>; gradients w.r.t.
@@ -236,6 +328,8 @@ def main():
     gen_lm(th, lieF, only)
     if not only or "implicit" in only:
         gen_implicit(th, lieF)
+    if not only or "se2" in only:
+        gen_se2(th)
     print("wrote", sorted(os.listdir(OUT)))
 
 

@@ -17,9 +17,26 @@ from typing import List, Optional, Tuple
 
 import torch
 
-from . import lie
+from . import lie, lie_se2
 
 MIN_DAMPING, MAX_DAMPING = 1.0e-7, 1.0e7  # levenberg_marquardt.py:52-53
+
+
+class _SE3:
+    name, dof = "SE3", 6
+    compose, inverse, adjoint, retract = (staticmethod(lie.se3_compose), staticmethod(lie.se3_inverse),
+                                          staticmethod(lie.se3_adjoint), staticmethod(lie.se3_retract))
+    log_jlog = staticmethod(lie.se3_log_jlog_autograd)
+
+
+class _SE2:
+    name, dof = "SE2", 3
+    compose, inverse, adjoint, retract = (staticmethod(lie_se2.se2_compose), staticmethod(lie_se2.se2_inverse),
+                                          staticmethod(lie_se2.se2_adjoint), staticmethod(lie_se2.se2_retract))
+    log_jlog = staticmethod(lie_se2.se2_log_jlog)
+
+
+GROUPS = {"SE3": _SE3, "SE2": _SE2}
 
 
 @dataclass
@@ -35,6 +52,7 @@ class PGProblem:
     prior_target: torch.Tensor   # (1|B, K, 3, 4)
     w_prior: torch.Tensor        # (1|B, K, 6)
     cost_order: Optional[List[Tuple[str, int]]] = None  # [('between',k)|('prior',k)] add order
+    group: str = "SE3"           # "SE3": tensors (...,3,4), dof 6; "SE2": tensors (...,4) = [x,y,cos,sin], dof 3
 
     def __post_init__(self):
         if self.cost_order is None:
@@ -43,42 +61,50 @@ class PGProblem:
             ]
 
     @property
+    def G(self):
+        return GROUPS[self.group]
+
+    @property
+    def dof(self):
+        return self.G.dof
+
+    @property
     def n(self):
-        return 6 * self.num_poses
+        return self.dof * self.num_poses
 
     @property
     def m(self):
-        return 6 * len(self.cost_order)
+        return self.dof * len(self.cost_order)
 
     def row_starts(self):
         rs = {}
         for r, c in enumerate(self.cost_order):
-            rs[c] = 6 * r
+            rs[c] = self.dof * r
         return rs
 
 
-def between_jac_err(v0, v1, meas, w):
-    """between.py:38-45 + cost_weight.py:125-136.  Shapes (...,3,4) x3, w (...,6)."""
-    D = lie.se3_compose(lie.se3_inverse(v0), v1)
-    E = lie.se3_compose(lie.se3_inverse(meas), D)
-    e, Jlog = lie.se3_log_jlog_autograd(E)
-    J0 = -Jlog @ lie.se3_adjoint(lie.se3_inverse(D))
+def between_jac_err(v0, v1, meas, w, G=_SE3):
+    """between.py:38-45 + cost_weight.py:125-136.  Group tensors x3, w (...,dof)."""
+    D = G.compose(G.inverse(v0), v1)
+    E = G.compose(G.inverse(meas), D)
+    e, Jlog = G.log_jlog(E)
+    J0 = -Jlog @ G.adjoint(G.inverse(D))
     J1 = Jlog
     return J0 * w[..., :, None], J1 * w[..., :, None], e * w
 
 
-def local_jac_err(target, var, w):
+def local_jac_err(target, var, w, G=_SE3):
     """local_cost_fn.py:58-61 -> lie_group.py:180-195: e = log(target^-1 var), J = Jlog."""
-    D = lie.se3_compose(lie.se3_inverse(target), var)
-    e, Jlog = lie.se3_log_jlog_autograd(D)
+    D = G.compose(G.inverse(target), var)
+    e, Jlog = G.log_jlog(D)
     return Jlog * w[..., :, None], e * w
 
 
 def weighted_errors(p: PGProblem, poses):
     """Weighted residuals of all costs: (e_between (B,E,6), e_prior (B,K,6))."""
     i, j = p.edges[:, 0], p.edges[:, 1]
-    _, _, eb = between_jac_err(poses[:, i], poses[:, j], p.meas, p.w_between)
-    _, ep = local_jac_err(p.prior_target, poses[:, p.prior_idx], p.w_prior)
+    _, _, eb = between_jac_err(poses[:, i], poses[:, j], p.meas, p.w_between, p.G)
+    _, ep = local_jac_err(p.prior_target, poses[:, p.prior_idx], p.w_prior, p.G)
     return eb, ep
 
 
@@ -99,21 +125,22 @@ def dense_linearize(p: PGProblem, poses):
     """dense_linearization.py:29-56: dense A (B,m,n), b = -err (B,m)."""
     B = poses.shape[0]
     i, j = p.edges[:, 0], p.edges[:, 1]
-    J0, J1, eb = between_jac_err(poses[:, i], poses[:, j], p.meas, p.w_between)
-    Jp, ep = local_jac_err(p.prior_target, poses[:, p.prior_idx], p.w_prior)
+    J0, J1, eb = between_jac_err(poses[:, i], poses[:, j], p.meas, p.w_between, p.G)
+    Jp, ep = local_jac_err(p.prior_target, poses[:, p.prior_idx], p.w_prior, p.G)
     A = torch.zeros(B, p.m, p.n, dtype=poses.dtype)
     b = torch.zeros(B, p.m, dtype=poses.dtype)
+    d = p.dof
     for r, (kind, k) in enumerate(p.cost_order):
-        rs = 6 * r
+        rs = d * r
         if kind == "between":
-            ci, cj = 6 * int(i[k]), 6 * int(j[k])
-            A[:, rs:rs + 6, ci:ci + 6] = J0[:, k]
-            A[:, rs:rs + 6, cj:cj + 6] = J1[:, k]
-            b[:, rs:rs + 6] = -eb[:, k]
+            ci, cj = d * int(i[k]), d * int(j[k])
+            A[:, rs:rs + d, ci:ci + d] = J0[:, k]
+            A[:, rs:rs + d, cj:cj + d] = J1[:, k]
+            b[:, rs:rs + d] = -eb[:, k]
         else:
-            c = 6 * int(p.prior_idx[k])
-            A[:, rs:rs + 6, c:c + 6] = Jp[:, k]
-            b[:, rs:rs + 6] = -ep[:, k]
+            c = d * int(p.prior_idx[k])
+            A[:, rs:rs + d, c:c + d] = Jp[:, k]
+            b[:, rs:rs + d] = -ep[:, k]
     return A, b
 
 
@@ -149,12 +176,14 @@ def solve(AtA, Atb, damping=None, ellipsoidal=False, eps=1e-8):
     return cholesky_solve(Atb, AtA)
 
 
-def retract(poses, delta, ignore_mask=None):
+def retract(poses, delta, ignore_mask=None, G=None):
     """objective.py:873-914 / vectorizer.py:410-469 / variable.py:65-69: X.exp(delta), masked rows keep X."""
     B, P = poses.shape[:2]
-    new = lie.se3_retract(poses, delta.view(B, P, 6))
+    if G is None:
+        G = _SE3 if poses.ndim == 4 else _SE2
+    new = G.retract(poses, delta.view(B, P, G.dof))
     if ignore_mask is not None:
-        new = torch.where(ignore_mask.view(B, 1, 1, 1), poses, new)
+        new = torch.where(ignore_mask.view([B] + [1] * (poses.ndim - 1)), poses, new)
     return new
 
 
@@ -236,7 +265,7 @@ def lm_optimize(p: PGProblem, poses, max_iterations=20, step_size=1.0, damping=1
             err = last_err
         else:
             if reject is not None:
-                poses = torch.where(reject.view(B, 1, 1, 1), poses, new_poses)
+                poses = torch.where(reject.view([B] + [1] * (poses.ndim - 1)), poses, new_poses)
                 if bool(reject.any()):
                     err = error_metric(p, poses)
             else:

@@ -8,7 +8,7 @@ from theseus_amd.kernels import PGTensors, default_kernels, round_up
 
 def to_device_problem(p, poses0, device="cuda"):
     """oracle PGProblem (batch-major) -> (PoseGraphStructure, PGTensors) in entity-major device layout."""
-    s = PoseGraphStructure.build(p.num_poses, p.edges.tolist(), p.prior_idx.tolist())
+    s = PoseGraphStructure.build(p.num_poses, p.edges.tolist(), p.prior_idx.tolist(), dof=p.dof)
     em = lambda t: t.transpose(0, 1).contiguous().to(device)  # noqa: E731  (B,X,...) -> (X,B,...)
     t = PGTensors(poses=em(poses0), meas=em(p.meas), w_between=em(p.w_between),
                   prior_target=em(p.prior_target), w_prior=em(p.w_prior))

@@ -21,6 +21,7 @@ def golden_problem(g):
     p = opg.PGProblem(
         num_poses=int(g["P"]), edges=t(g["edges"]), meas=t(g["meas"]), w_between=t(g["w_between"]),
         prior_idx=t(g["prior_idx"]), prior_target=t(g["prior_target"]), w_prior=t(g["w_prior"]),
+        group=str(g["group"]) if "group" in g else "SE3",
     )
     kw = ast.literal_eval(str(g["opt_kwargs"]))
     return p, t(g["poses0"]), kw
@@ -40,10 +41,11 @@ class f32_thresholds:
     (torchlie/torchlie/global_params.py:44-58 keys the thresholds by dtype)."""
 
     def __enter__(self):
-        from oracle import lie
-        self._saved = dict(lie.EPS[torch.float64])
-        lie.EPS[torch.float64] = {k: float(np.float32(v)) for k, v in lie.EPS[torch.float32].items()}
+        from oracle import lie, lie_se2
+        self._saved = [(m, dict(m.EPS[torch.float64])) for m in (lie, lie_se2)]
+        for m in (lie, lie_se2):
+            m.EPS[torch.float64] = {k: float(np.float32(v)) for k, v in m.EPS[torch.float32].items()}
 
     def __exit__(self, *a):
-        from oracle import lie
-        lie.EPS[torch.float64] = self._saved
+        for m, saved in self._saved:
+            m.EPS[torch.float64] = saved

@@ -21,7 +21,8 @@ class OracleKernels:
                           edges=torch.stack([torch.from_numpy(h.edge_i), torch.from_numpy(h.edge_j)], 1).long(),
                           meas=bm(t.meas), w_between=bm(t.w_between),
                           prior_idx=torch.from_numpy(h.prior_pose).long(),
-                          prior_target=bm(t.prior_target), w_prior=bm(t.w_prior))
+                          prior_target=bm(t.prior_target), w_prior=bm(t.w_prior),
+                          group="SE2" if t.poses.dim() == 3 else "SE3")
         return p, bm(t.poses if poses is None else poses)
 
     # ---- SE3 elementwise -----------------------------------------------------------------------
@@ -59,16 +60,45 @@ class OracleKernels:
         p, x = self._problem(s, t, poses)
         i, j = p.edges[:, 0], p.edges[:, 1]
         if p.edges.shape[0]:
-            a, b, e = opg.between_jac_err(x[:, i], x[:, j], p.meas, p.w_between)
+            a, b, e = opg.between_jac_err(x[:, i], x[:, j], p.meas, p.w_between, p.G)
             J0.copy_(a.transpose(0, 1)); J1.copy_(b.transpose(0, 1)); eb.copy_(e.transpose(0, 1))
         if p.prior_idx.shape[0]:
-            a, e = opg.local_jac_err(p.prior_target, x[:, p.prior_idx], p.w_prior)
+            a, e = opg.local_jac_err(p.prior_target, x[:, p.prior_idx], p.w_prior, p.G)
             Jp.copy_(a.transpose(0, 1)); ep.copy_(e.transpose(0, 1))
 
     def se3_retract(self, poses, delta, step, ignore_mask, out):
         x = poses.transpose(0, 1)
         m = ignore_mask.bool() if ignore_mask is not None else None
         out.copy_(opg.retract(x, delta * step, ignore_mask=m).transpose(0, 1))
+
+    def retract(self, poses, delta, step, ignore_mask, out):
+        if poses.dim() == 4:
+            return self.se3_retract(poses, delta, step, ignore_mask, out)
+        m = ignore_mask.bool() if ignore_mask is not None else None
+        out.copy_(opg.retract(poses.transpose(0, 1), delta * step, ignore_mask=m).transpose(0, 1))
+
+    # ---- SE2 elementwise -------------------------------------------------------------------------
+    def se2_exp(self, xi, jac=False):
+        from oracle import lie_se2
+        assert not jac
+        return lie_se2.se2_exp(xi)
+
+    def se2_log(self, X, jac=False):
+        from oracle import lie_se2
+        xi, J = lie_se2.se2_log_jlog(X)
+        return (xi, J) if jac else xi
+
+    def se2_compose(self, X, Y):
+        from oracle import lie_se2
+        return lie_se2.se2_compose(X, Y)
+
+    def se2_inverse(self, X):
+        from oracle import lie_se2
+        return lie_se2.se2_inverse(X)
+
+    def se2_adjoint(self, X):
+        from oracle import lie_se2
+        return lie_se2.se2_adjoint(X)
 
     # ---- generic block assembly: dense A scatter + A^T A, as DenseLinearization does ----
     def block_assemble(self, asm, jacobians, errors, H, g):

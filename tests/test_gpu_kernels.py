@@ -57,7 +57,39 @@ def test_lie_ops_vs_reference_golden(K, tag, dtype):
     np.testing.assert_allclose(got["jexp"], g["jexp"], rtol=3e-5, atol=3e-5)
 
 
-CASES = ["pg_f64_lm", "pg_f32_lm", "pg_f32_lm_b16", "pg_f64_lm_adaptive_ellips", "pg_f64_gn"]
+@pytest.mark.parametrize("tag,dtype", [("f32", torch.float32), ("f64", torch.float64)])
+def test_se2_ops_vs_reference_golden(K, tag, dtype):
+    """thx_se2_op against the reference's SE2 outputs (theseus/geometry/se2.py); same criteria as the SE3 test."""
+    from oracle import lie_se2
+    from tests.helpers import f32_thresholds
+    g = load_golden(f"lie_se2_{tag}")
+    xi = torch.from_numpy(g["xi"]).cuda()
+    X, J = K.se2_exp(xi, jac=True)
+    Xg, Yg = torch.from_numpy(g["exp"]).cuda(), torch.from_numpy(g["Y"]).cuda()
+    lg, Jl = K.se2_log(Xg, jac=True)
+    got = dict(exp=X, jexp=J, log=lg, jlog=Jl, adj=K.se2_adjoint(Xg), inv=K.se2_inverse(Xg), compose=K.se2_compose(Xg, Yg))
+    got = {k: v.cpu().numpy() for k, v in got.items()}
+    if dtype == torch.float64:
+        for k, v in got.items():
+            np.testing.assert_allclose(v, g[k], rtol=1e-11, atol=1e-11, err_msg=k)
+        return
+    with f32_thresholds():
+        xi64, X64, Y64 = (torch.from_numpy(g[k]).double() for k in ("xi", "exp", "Y"))
+        exact = dict(exp=lie_se2.se2_exp(xi64), adj=lie_se2.se2_adjoint(X64), inv=lie_se2.se2_inverse(X64),
+                     compose=lie_se2.se2_compose(X64, Y64))
+        exact["log"], exact["jlog"] = lie_se2.se2_log_jlog(X64)
+    for k, ex in exact.items():
+        ex = ex.numpy()
+        rows = lambda a: np.abs(a).reshape(ex.shape[0], -1).max(1)  # noqa: E731
+        scale = np.maximum(1.0, rows(ex))
+        dev, ref_dev = rows(got[k] - ex), rows(g[k] - ex)
+        assert (dev <= 4e-7 * scale).all(), (k, (dev / scale).max())
+        assert (rows(got[k] - g[k]) <= ref_dev + 4e-7 * scale).all(), k
+    np.testing.assert_allclose(got["jexp"], g["jexp"], rtol=3e-5, atol=3e-5)
+
+
+CASES = ["pg_f64_lm", "pg_f32_lm", "pg_f32_lm_b16", "pg_f64_lm_adaptive_ellips", "pg_f64_gn",
+         "pg2_f64_lm", "pg2_f32_lm", "pg2_f64_lm_adaptive"]  # pg2_*: SE2 (thx_pg2_*)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -97,8 +129,9 @@ def test_assemble_error_jacobians_vs_reference_golden(K, name):
         np.testing.assert_allclose(gv.cpu().numpy(), g["Atb"][0][..., 0], rtol=0, atol=np.abs(g["Atb"][0]).max() * 5e-12)
     # untouched entries stay exactly zero (structure): pattern == block pattern
     pat = np.zeros((n, n), bool)
+    d = p.dof
     for r, c in s.lower_block_pattern():
-        pat[6 * r:6 * r + 6, 6 * c:6 * c + 6] = True
+        pat[d * r:d * r + d, d * c:d * c + d] = True
     assert not (H[:, :n, :n].cpu().numpy()[:, ~pat] != 0).any()
     # error metric
     part = torch.empty(16, B, dtype=dtype, device="cuda")
@@ -111,20 +144,20 @@ def test_assemble_error_jacobians_vs_reference_golden(K, name):
         np.testing.assert_allclose(err.cpu().numpy(), g["err0"], rtol=1e-12)
     # Jacobian blocks against the reference's dense A, b
     E, Kp = s.num_edges, s.num_priors
-    J0 = torch.empty(E, B, 6, 6, dtype=dtype, device="cuda"); J1 = torch.empty_like(J0)
-    eb = torch.empty(E, B, 6, dtype=dtype, device="cuda")
-    Jp = torch.empty(Kp, B, 6, 6, dtype=dtype, device="cuda"); ep = torch.empty(Kp, B, 6, dtype=dtype, device="cuda")
+    J0 = torch.empty(E, B, d, d, dtype=dtype, device="cuda"); J1 = torch.empty_like(J0)
+    eb = torch.empty(E, B, d, dtype=dtype, device="cuda")
+    Jp = torch.empty(Kp, B, d, d, dtype=dtype, device="cuda"); ep = torch.empty(Kp, B, d, dtype=dtype, device="cuda")
     K.pg_jacobians(ds, t, J0, J1, eb, Jp, ep)
     A = np.zeros((B, s.num_rows, n), dtype=g["A0"].dtype); b = np.zeros((B, s.num_rows), dtype=g["A0"].dtype)
     for e in range(E):
         r, i, j = int(s.edge_row_start[e]), int(s.edge_i[e]), int(s.edge_j[e])
-        A[:, r:r + 6, 6 * i:6 * i + 6] = J0[e].cpu().numpy()
-        A[:, r:r + 6, 6 * j:6 * j + 6] = J1[e].cpu().numpy()
-        b[:, r:r + 6] = -eb[e].cpu().numpy()
+        A[:, r:r + d, d * i:d * i + d] = J0[e].cpu().numpy()
+        A[:, r:r + d, d * j:d * j + d] = J1[e].cpu().numpy()
+        b[:, r:r + d] = -eb[e].cpu().numpy()
     for k in range(Kp):
         r, i = int(s.prior_row_start[k]), int(s.prior_pose[k])
-        A[:, r:r + 6, 6 * i:6 * i + 6] = Jp[k].cpu().numpy()
-        b[:, r:r + 6] = -ep[k].cpu().numpy()
+        A[:, r:r + d, d * i:d * i + d] = Jp[k].cpu().numpy()
+        b[:, r:r + d] = -ep[k].cpu().numpy()
     if f32:
         in_band(A, g["A0"], A64, 2e-7)
         in_band(b, g["b0"], b64, 2e-7)

@@ -16,14 +16,15 @@ def build_objective(th, g, device="cuda"):
     obj = th.Objective(dtype=dtype)
     P = int(g["P"])
     poses0 = t(g["poses0"])
-    poses = [th.SE3(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    G = th.SE2 if ("group" in g and str(g["group"]) == "SE2") else th.SE3
+    poses = [G(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
     for k in range(g["edges"].shape[0]):
         i, j = g["edges"][k].tolist()
         cw = th.DiagonalCostWeight(th.Variable(t(g["w_between"])[:, k].clone(), name=f"w_{k}"))
-        m = th.SE3(tensor=t(g["meas"])[:, k].clone(), name=f"meas_{k}")
+        m = G(tensor=t(g["meas"])[:, k].clone(), name=f"meas_{k}")
         obj.add(th.Between(poses[i], poses[j], m, cw, name=f"between_{k}"))
     for k in range(g["prior_idx"].shape[0]):
-        tgt = th.SE3(tensor=t(g["prior_target"])[:, k].clone(), name=f"prior_target_{k}")
+        tgt = G(tensor=t(g["prior_target"])[:, k].clone(), name=f"prior_target_{k}")
         sw = th.ScaleCostWeight(th.Variable(t(g["w_prior"])[:, k, :1].clone(), name=f"pw_{k}"))
         obj.add(th.Difference(poses[int(g["prior_idx"][k])], tgt, sw, name=f"prior_{k}"))
     return obj, poses
@@ -33,7 +34,8 @@ def build_objective(th, g, device="cuda"):
 # damping down to 1e-7 when adaptive), cond(H + lambda I) ~ 1e9..1e10, so two correct fp64 Cholesky solves
 # differ by ~cond * 1e-16 * |delta| ~ 1e-8 on the weakly constrained components; 1e-7 absolute on poses.
 CASES = [("pg_f64_lm", 1e-7), ("pg_f64_gn", 1e-7), ("pg_f64_lm_adaptive", 1e-7),
-         ("pg_f64_lm_adaptive_ellips", 1e-7), ("pg_f64_lm_adaptive_rejects", 1e-7)]
+         ("pg_f64_lm_adaptive_ellips", 1e-7), ("pg_f64_lm_adaptive_rejects", 1e-7),
+         ("pg2_f64_lm", 1e-7), ("pg2_f64_lm_adaptive", 1e-7)]  # pg2_*: SE2 pose graphs (theseus/geometry/se2.py)
 
 
 def well_conditioned_steps(g, n_iters):
@@ -70,7 +72,7 @@ def test_lm_trajectory_matches_reference(name, tol):
     g = load_golden(name)
     _, _, kw = golden_problem(g)
     obj, poses = build_objective(th, g)
-    gn = kw.pop("gauss_newton")
+    gn = kw.pop("gauss_newton", False)
     okw = dict(max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"),
                abs_err_tolerance=0.0, rel_err_tolerance=0.0)
     opt = (th.GaussNewton if gn else th.LevenbergMarquardt)(obj, linear_solver_cls=th.HipCholeskySolver, **okw)
@@ -99,7 +101,7 @@ def test_lm_trajectory_matches_reference(name, tol):
     assert all(s == th.NonlinearOptimizerStatus.MAX_ITERATIONS for s in info.status)
 
 
-@pytest.mark.parametrize("name", ["pg_f32_lm", "pg_f32_lm_b16"])
+@pytest.mark.parametrize("name", ["pg_f32_lm", "pg_f32_lm_b16", "pg2_f32_lm"])
 def test_lm_trajectory_fp32_inside_reference_band(name):
     """fp32 parity.  The reference's fp32 path is a noisy evaluation (catastrophic cancellation in the
     torchlie log coefficients, fp32 potrf): its trajectory sits at a distance dev_ref from the exact
@@ -137,9 +139,10 @@ def test_lm_trajectory_fp32_inside_reference_band(name):
     assert rel <= 1.5 * rel_ref + 1e-6, (rel, rel_ref)
 
 
-def test_first_linearization_properties_match_reference():
+@pytest.mark.parametrize("name", ["pg_f64_lm", "pg2_f64_lm"])
+def test_first_linearization_properties_match_reference(name):
     import theseus_amd as th
-    g = load_golden("pg_f64_lm")
+    g = load_golden(name)
     obj, _ = build_objective(th, g)
     opt = th.LevenbergMarquardt(obj, max_iterations=1)
     lin = opt.linear_solver.linearization

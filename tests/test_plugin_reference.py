@@ -35,18 +35,19 @@ def _objective(th, g):
     t = torch.from_numpy
     d = dict(P=int(g["P"]), edges=t(g["edges"]), meas=t(g["meas"]), w_between=t(g["w_between"]),
              prior_idx=t(g["prior_idx"]), prior_target=t(g["prior_target"]), w_prior=t(g["w_prior"]),
-             poses=t(g["poses0"]))
+             poses=t(g["poses0"]), group=str(g["group"]) if "group" in g else "SE3")
     return build_reference_objective(th, d, d["poses"].dtype)
 
 
-@pytest.mark.parametrize("name", ["pg_f64_lm", "pg_f64_lm_adaptive_ellips", "pg_f64_lm_adaptive_rejects", "pg_f64_gn"])
+@pytest.mark.parametrize("name", ["pg_f64_lm", "pg_f64_lm_adaptive_ellips", "pg_f64_lm_adaptive_rejects", "pg_f64_gn",
+                                  "pg2_f64_lm", "pg2_f64_lm_adaptive"])
 def test_reference_loop_drives_the_plugin(ref, name):
     th, thp = ref
     from tests.oracle_kernels import OracleKernels
     g = load_golden(name)
     _, _, kw = golden_problem(g)
     obj, poses = _objective(th, g)
-    gn = kw.pop("gauss_newton")
+    gn = kw.pop("gauss_newton", False)
     okw = dict(max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"))
     cls = th.GaussNewton if gn else th.LevenbergMarquardt
     opt = cls(obj, linear_solver_cls=thp.HipCholeskySolver, linearization_cls=thp.HipLinearization,

@@ -90,6 +90,7 @@ CASES = [
     ("pg_f64_lm_adaptive_rejects", None, dict(abs_err_tolerance=1e-9, rel_err_tolerance=1e-7)),
     ("pg_f64_lm_adaptive", None, dict(abs_err_tolerance=1e-10, rel_err_tolerance=1e-3)),
     ("pg_f64_lm", None, dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0)),
+    ("pg2_f64_lm_adaptive", None, dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0)),   # SE2, uneven shards (B=5)
 ]
 
 
@@ -120,9 +121,10 @@ def test_two_rank_sharded_lm_equals_unsharded(name, perm, overrides):
         np.testing.assert_allclose(o["gathered"].transpose(0, 1).numpy(), ref_final.numpy(), rtol=0, atol=1e-12)
 
 
-def test_reference_trajectory_with_standin_kernels():
+@pytest.mark.parametrize("name", ["pg_f64_lm_adaptive_ellips", "pg2_f64_lm_adaptive", "pg2_f64_lm"])
+def test_reference_trajectory_with_standin_kernels(name):
     """The stand-in + the host LM loop reproduce the REAL reference's recorded trajectory: the host loop is
     the reference's control flow (this is what the GPU tests check with the HIP kernels plugged in)."""
-    g = load_golden("pg_f64_lm_adaptive_ellips")
+    g = load_golden(name)
     final, info, _ = _run_lm(g, dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0))
     np.testing.assert_allclose(final.numpy(), g["final"], rtol=0, atol=5e-8)

@@ -1,11 +1,11 @@
 """theseus_amd -- MI355X-native batched Gauss-Newton / Levenberg-Marquardt inner loop for Theseus.
 
-Host-side mirror of the reference's modelling + optimizer API for the SE3 pose-graph hot path, over
+Host-side mirror of the reference's modelling + optimizer API for the SE3 / SE2 pose-graph hot path, over
 hand-written HIP kernels behind a C ABI (include/theseus_hip.h, theseus_amd/csrc).  No CPU fallback.
 """
 from .core import (Between, CostFunction, CostWeight, DiagonalCostWeight, Difference, Local, Objective,  # noqa: F401
-                   ScaleCostWeight, SE3, Variable, Vector)
-from .kernels import HipKernels, default_kernels, set_lie_eps  # noqa: F401
+                   ScaleCostWeight, SE2, SE3, Variable, Vector)
+from .kernels import HipKernels, default_kernels, set_lie_eps, set_se2_eps  # noqa: F401
 from .layer import TheseusLayer  # noqa: F401
 from .linear_solver import HipCholeskySolver, LinearSolver  # noqa: F401
 from .linearization import HipLinearization, Linearization, VariableOrdering  # noqa: F401

@@ -17,11 +17,15 @@ LIB_PATH = os.environ.get("THESEUS_HIP_LIB") or os.path.join(_HERE, "lib", "libt
 
 THX_TILE = 128
 THX_ERR_CHUNKS = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class LieEps(Structure):
     _fields_ = [("near_zero", c_double), ("d_near_zero", c_double), ("near_pi", c_double)]
+
+
+class SE2Eps(Structure):  # thx_se2_eps (theseus/global_params.py:46-59)
+    _fields_ = [("near_zero", c_double), ("d_near_zero", c_double)]
 
 
 class PGStructure(Structure):
@@ -58,6 +62,14 @@ _SIGNATURES = {
                          c_void_p, c_int, POINTER(LieEps), c_void_p],
     "thx_se3_retract": [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p, c_int32, c_int32, c_int,
                         POINTER(LieEps), c_void_p],
+    "thx_pg2_assemble": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_int64, c_void_p, c_int, POINTER(SE2Eps),
+                         c_void_p],
+    "thx_pg2_error": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_void_p, c_int, POINTER(SE2Eps), c_void_p],
+    "thx_pg2_jacobians": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                          POINTER(SE2Eps), c_void_p],
+    "thx_se2_retract": [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p, c_int32, c_int32, c_int,
+                        POINTER(SE2Eps), c_void_p],
+    "thx_se2_op": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(SE2Eps), c_void_p],
     "thx_chol_factor": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,
                         c_void_p, c_int, c_void_p],
     "thx_chol_factor_forward": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,

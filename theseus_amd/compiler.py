@@ -19,7 +19,7 @@ DOF = 6
 
 @dataclass
 class PoseGraphStructure:
-    """Immutable topology of an SE3 pose graph: P poses, E Between edges, K Difference priors."""
+    """Immutable topology of a pose graph (SE3: dof 6, SE2: dof 3): P poses, E Between edges, K Difference priors."""
 
     num_poses: int
     edge_i: np.ndarray  # (E,) int32  v0 pose of edge e
@@ -36,11 +36,12 @@ class PoseGraphStructure:
     pri_ptr: np.ndarray = field(default=None, repr=False)
     pri_id: np.ndarray = field(default=None, repr=False)
     _dev: dict = field(default_factory=dict, repr=False)
+    dof: int = DOF
 
     @staticmethod
     def build(num_poses: int, edges: Sequence[Tuple[int, int]], priors: Sequence[int],
               edge_row_start: Optional[Sequence[int]] = None,
-              prior_row_start: Optional[Sequence[int]] = None) -> "PoseGraphStructure":
+              prior_row_start: Optional[Sequence[int]] = None, dof: int = DOF) -> "PoseGraphStructure":
         P = int(num_poses)
         e = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
         E = e.shape[0]
@@ -53,9 +54,9 @@ class PoseGraphStructure:
         if E and np.any(e[:, 0] == e[:, 1]):
             raise ValueError("Between cost with v0 is v1 (self loop) is not supported")
         if edge_row_start is None:
-            edge_row_start = DOF * np.arange(E)
+            edge_row_start = dof * np.arange(E)
         if prior_row_start is None:
-            prior_row_start = DOF * (E + np.arange(K))
+            prior_row_start = dof * (E + np.arange(K))
         # incident-edge CSR per pose, entries sorted by (other endpoint, edge id)
         ent_pose = np.concatenate([e[:, 0], e[:, 1]])
         ent_other = np.concatenate([e[:, 1], e[:, 0]])
@@ -74,7 +75,7 @@ class PoseGraphStructure:
             num_poses=P, edge_i=i32(e[:, 0]), edge_j=i32(e[:, 1]), prior_pose=i32(pr),
             edge_row_start=np.asarray(edge_row_start, np.int64), prior_row_start=np.asarray(prior_row_start, np.int64),
             inc_ptr=i32(inc_ptr), inc_edge=i32(ent_edge[order]), inc_side=i32(ent_side[order]),
-            inc_other=i32(ent_other[order]), pri_ptr=i32(pri_ptr), pri_id=i32(porder),
+            inc_other=i32(ent_other[order]), pri_ptr=i32(pri_ptr), pri_id=i32(porder), dof=int(dof),
         )
 
     # ---- sizes -------------------------------------------------------------------------------
@@ -88,15 +89,15 @@ class PoseGraphStructure:
 
     @property
     def num_cols(self) -> int:
-        return DOF * self.num_poses
+        return self.dof * self.num_poses
 
     @property
     def num_rows(self) -> int:
-        return DOF * (self.num_edges + self.num_priors)
+        return self.dof * (self.num_edges + self.num_priors)
 
     @property
     def var_start_cols(self) -> List[int]:
-        return [DOF * k for k in range(self.num_poses)]
+        return [self.dof * k for k in range(self.num_poses)]
 
     def lower_block_pattern(self) -> np.ndarray:
         """(nblocks, 2) sorted unique (row pose, col pose) of the non-zero 6x6 blocks of tril(H)."""

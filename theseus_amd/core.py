@@ -3,7 +3,7 @@
 Same names, argument meaning and error behaviour as the reference so that code written against
 ``theseus`` reads the same against ``theseus_amd`` for this path:
   Variable              theseus/core/variable.py:14-112
-  SE3                   theseus/geometry/se3.py:20-300, theseus/geometry/lie_group.py:19-260
+  SE3 / SE2             theseus/geometry/se3.py:20-300, se2.py:20-340, theseus/geometry/lie_group.py:19-260
   Scale/DiagonalCostWeight  theseus/core/cost_weight.py:60-139
   Between / Difference  theseus/embodied/measurements/between.py:16-60, theseus/embodied/misc/local_cost_fn.py:16-75
   Objective             theseus/core/objective.py:42-956 (add / update / error / error_metric / retract)
@@ -181,6 +181,79 @@ class SE3(Variable):
         return SE3(tensor=self.tensor.clone(), name=new_name or f"{self.name}_copy")
 
 
+class SE2(Variable):
+    """SE2 group element batch, tensor (B,4) = [x, y, cos, sin]; tangent [u_x, u_y, theta]; right perturbations
+    (theseus/geometry/se2.py:20-120)."""
+
+    def __init__(self, x_y_theta: Optional[torch.Tensor] = None, tensor: Optional[torch.Tensor] = None,
+                 name: Optional[str] = None, dtype: Optional[torch.dtype] = None):
+        if x_y_theta is not None and tensor is not None:
+            raise ValueError("Please provide only one of x_y_theta or tensor.")
+        if x_y_theta is not None:
+            if x_y_theta.ndim == 1:
+                x_y_theta = x_y_theta.unsqueeze(0)
+            th = x_y_theta[:, 2:]
+            tensor = torch.cat([x_y_theta[:, :2], th.cos(), th.sin()], dim=1)  # se2.py:40-44,93-106
+        if tensor is None:
+            tensor = torch.tensor([[0.0, 0.0, 1.0, 0.0]], dtype=dtype or torch.get_default_dtype())
+        if tensor.ndim == 1:
+            tensor = tensor.unsqueeze(0)
+        if tensor.ndim != 2 or tensor.shape[1] != 4:
+            raise ValueError("SE2 data tensors can only be 4D vectors.")
+        if dtype is not None and tensor.dtype != dtype:
+            tensor = tensor.to(dtype)
+        super().__init__(tensor, name)
+
+    @staticmethod
+    def dof() -> int:
+        return 3
+
+    @staticmethod
+    def exp_map(tangent_vector: torch.Tensor, jacobians: Optional[List[torch.Tensor]] = None) -> "SE2":
+        if tangent_vector.ndim != 2 or tangent_vector.shape[1] != 3:
+            raise ValueError("Tangent vectors of SE2 should be 3-D vectors.")
+        K = default_kernels()
+        if jacobians is not None:
+            X, J = K.se2_exp(tangent_vector, jac=True)
+            jacobians.append(J)
+        else:
+            X = K.se2_exp(tangent_vector)
+        return SE2(tensor=X)
+
+    def log_map(self, jacobians: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+        K = default_kernels()
+        if jacobians is not None:
+            xi, J = K.se2_log(self.tensor, jac=True)
+            jacobians.append(J)
+            return xi
+        return K.se2_log(self.tensor)
+
+    def adjoint(self) -> torch.Tensor:
+        return default_kernels().se2_adjoint(self.tensor)
+
+    def inverse(self) -> "SE2":
+        return SE2(tensor=default_kernels().se2_inverse(self.tensor))
+
+    def compose(self, other: "SE2") -> "SE2":
+        a, b = _broadcast_pair(self.tensor, other.tensor)
+        return SE2(tensor=default_kernels().se2_compose(a, b))
+
+    def between(self, other: "SE2") -> "SE2":
+        return self.inverse().compose(other)
+
+    def local(self, other: "SE2") -> torch.Tensor:
+        return self.between(other).log_map()
+
+    def retract(self, delta: torch.Tensor) -> "SE2":
+        return self.compose(SE2.exp_map(delta))
+
+    def theta(self) -> torch.Tensor:
+        return torch.atan2(self.tensor[:, 3], self.tensor[:, 2])
+
+    def copy(self, new_name: Optional[str] = None) -> "SE2":
+        return SE2(tensor=self.tensor.clone(), name=new_name or f"{self.name}_copy")
+
+
 def _broadcast_pair(a, b):
     if a.shape[0] != b.shape[0]:
         if a.shape[0] == 1:
@@ -200,8 +273,11 @@ class CostWeight(abc.ABC):
         self.name = name
 
     @abc.abstractmethod
+    def sqrt_diag(self, dim: int) -> torch.Tensor:
+        """(Bw, dim) sqrt-information diagonal (what the kernels consume)."""
+
     def diagonal6(self) -> torch.Tensor:
-        """(Bw, 6) sqrt-information diagonal (what the kernels consume)."""
+        return self.sqrt_diag(6)
 
 
 class ScaleCostWeight(CostWeight):
@@ -220,8 +296,8 @@ class ScaleCostWeight(CostWeight):
     def aux_vars(self):
         return [self.scale]
 
-    def diagonal6(self):
-        return self.scale.tensor.expand(-1, 6)
+    def sqrt_diag(self, dim):
+        return self.scale.tensor.expand(-1, dim)
 
 
 class DiagonalCostWeight(CostWeight):
@@ -240,9 +316,9 @@ class DiagonalCostWeight(CostWeight):
     def aux_vars(self):
         return [self.diagonal]
 
-    def diagonal6(self):
-        if self.diagonal.tensor.shape[1] != 6:
-            raise ValueError("SE3 costs need a 6-dimensional DiagonalCostWeight.")
+    def sqrt_diag(self, dim):
+        if self.diagonal.tensor.shape[1] != dim:
+            raise ValueError(f"This cost needs a {dim}-dimensional DiagonalCostWeight.")
         return self.diagonal.tensor
 
 
@@ -273,7 +349,7 @@ class CostFunction(abc.ABC):
         pass
 
     def weighted_error(self) -> torch.Tensor:
-        return self.error() * self.weight.diagonal6()
+        return self.error() * self.weight.sqrt_diag(self.dim())
 
 
 class Between(CostFunction):
@@ -295,7 +371,7 @@ class Between(CostFunction):
         return self.measurement.local(self.v0.between(self.v1))
 
     def dim(self):
-        return 6
+        return self.v0.dof()
 
 
 class Difference(CostFunction):
@@ -317,7 +393,7 @@ class Difference(CostFunction):
         return self.target.local(self.var)
 
     def dim(self):
-        return 6
+        return self.var.dof()
 
 
 Local = Difference

@@ -32,6 +32,26 @@ def lie_eps(dtype) -> _lib.LieEps:
     return _lib.LieEps(e["near_zero"], e["d_near_zero"], e["near_pi"])
 
 
+# theseus/global_params.py:46-59 (se2 thresholds; the SE2 class is theseus' own, not torchlie's)
+_SE2_EPS = {
+    torch.float32: dict(near_zero=3e-2, d_near_zero=1e-1),
+    torch.float64: dict(near_zero=1e-6, d_near_zero=1e-3),
+}
+
+
+def set_se2_eps(dtype, **kw):
+    """Mirror of theseus.set_global_params for se2_near_zero_eps / se2_d_near_zero_eps."""
+    for k, v in kw.items():
+        if k not in _SE2_EPS[dtype]:
+            raise KeyError(k)
+        _SE2_EPS[dtype][k] = float(v)
+
+
+def se2_eps(dtype) -> _lib.SE2Eps:
+    e = _SE2_EPS[dtype]
+    return _lib.SE2Eps(e["near_zero"], e["d_near_zero"])
+
+
 def round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -40,15 +60,19 @@ def round_up(x, m):
 class PGTensors:
     """Per-call tensors of a pose-graph objective in the entity-major device layout."""
 
-    poses: torch.Tensor          # (P, B, 3, 4)
+    poses: torch.Tensor          # (P, B, 3, 4)     SE2: (P, B, 4)
     meas: torch.Tensor           # (E, Bm, 3, 4)   Bm in {1, B}
-    w_between: torch.Tensor      # (E, Bw, 6)
+    w_between: torch.Tensor      # (E, Bw, 6)       SE2: (E, Bw, 3)
     prior_target: torch.Tensor   # (K, Bt, 3, 4)
     w_prior: torch.Tensor        # (K, Bw, 6)
 
     @property
     def batch(self):
         return self.poses.shape[1]
+
+    @property
+    def se2(self) -> bool:
+        return self.poses.dim() == 3
 
     def c_struct(self, poses: Optional[torch.Tensor] = None) -> _lib.PGData:
         poses = self.poses if poses is None else poses
@@ -64,10 +88,11 @@ class PGTensors:
             setattr(d, name, _lib.ptr(t, name).value if t.numel() else None)
             setattr(d, name + "_bstride", width if nb == B else 0)
 
-        put("meas", self.meas, 12)
-        put("w_between", self.w_between, 6)
-        put("prior_target", self.prior_target, 12)
-        put("w_prior", self.w_prior, 6)
+        gw, dof = (4, 3) if poses.dim() == 3 else (12, 6)
+        put("meas", self.meas, gw)
+        put("w_between", self.w_between, dof)
+        put("prior_target", self.prior_target, gw)
+        put("w_prior", self.w_prior, dof)
         return d
 
 
@@ -121,10 +146,54 @@ class HipKernels:
                                             _lib.stream_ptr(X.device)), "thx_se3_adjoint")
         return A
 
-    # ---- pose graph -----------------------------------------------------------------------------
+    # ---- SE2 elementwise (theseus/geometry/se2.py) ---------------------------------------------
+    def _se2_op(self, op, a, b, out, jac):
+        N = a.shape[0]
+        _lib.check(self.lib.thx_se2_op(op, _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(jac), N,
+                                       _lib.dtype_code(a.dtype), se2_eps(a.dtype), _lib.stream_ptr(a.device)),
+                   "thx_se2_op")
+
+    def se2_exp(self, xi, jac=False):
+        xi = xi.contiguous()
+        X = xi.new_empty(xi.shape[0], 4)
+        J = xi.new_empty(xi.shape[0], 3, 3) if jac else None
+        self._se2_op(0, xi, None, X, J)
+        return (X, J) if jac else X
+
+    def se2_log(self, X, jac=False):
+        X = X.contiguous()
+        xi = X.new_empty(X.shape[0], 3)
+        J = X.new_empty(X.shape[0], 3, 3) if jac else None
+        self._se2_op(1, X, None, xi, J)
+        return (xi, J) if jac else xi
+
+    def se2_compose(self, X, Y):
+        X, Y = X.contiguous(), Y.contiguous()
+        Z = torch.empty_like(X)
+        self._se2_op(2, X, Y, Z, None)
+        return Z
+
+    def se2_inverse(self, X):
+        X = X.contiguous()
+        Y = torch.empty_like(X)
+        self._se2_op(3, X, None, Y, None)
+        return Y
+
+    def se2_adjoint(self, X):
+        X = X.contiguous()
+        A = X.new_empty(X.shape[0], 3, 3)
+        self._se2_op(4, X, None, A, None)
+        return A
+
+    # ---- pose graph (SE3 records (3,4) -> thx_pg_*, SE2 records (4,) -> thx_pg2_*) ---------------
     def pg_assemble(self, s: DeviceStructure, t: PGTensors, H, g, poses=None):
         d = t.c_struct(poses)
         dt = H.dtype
+        if t.se2:
+            _lib.check(self.lib.thx_pg2_assemble(s.c, d, _lib.ptr(H, "H"), H.shape[-1], _lib.ptr(g, "g"),
+                                                 _lib.dtype_code(dt), se2_eps(dt), _lib.stream_ptr(H.device)),
+                       "thx_pg2_assemble")
+            return
         _lib.check(self.lib.thx_pg_assemble(s.c, d, _lib.ptr(H, "H"), H.shape[-1], _lib.ptr(g, "g"),
                                             _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(H.device)),
                    "thx_pg_assemble")
@@ -132,15 +201,34 @@ class HipKernels:
     def pg_error(self, s: DeviceStructure, t: PGTensors, partials, err, poses=None):
         d = t.c_struct(poses)
         dt = err.dtype
+        if t.se2:
+            _lib.check(self.lib.thx_pg2_error(s.c, d, _lib.ptr(partials), _lib.ptr(err), _lib.dtype_code(dt),
+                                              se2_eps(dt), _lib.stream_ptr(err.device)), "thx_pg2_error")
+            return
         _lib.check(self.lib.thx_pg_error(s.c, d, _lib.ptr(partials), _lib.ptr(err), _lib.dtype_code(dt), lie_eps(dt),
                                          _lib.stream_ptr(err.device)), "thx_pg_error")
 
     def pg_jacobians(self, s: DeviceStructure, t: PGTensors, J0, J1, eb, Jp, ep, poses=None):
         d = t.c_struct(poses)
         dt = t.poses.dtype
+        if t.se2:
+            _lib.check(self.lib.thx_pg2_jacobians(s.c, d, _lib.ptr(J0), _lib.ptr(J1), _lib.ptr(eb), _lib.ptr(Jp),
+                                                  _lib.ptr(ep), _lib.dtype_code(dt), se2_eps(dt),
+                                                  _lib.stream_ptr(t.poses.device)), "thx_pg2_jacobians")
+            return
         _lib.check(self.lib.thx_pg_jacobians(s.c, d, _lib.ptr(J0), _lib.ptr(J1), _lib.ptr(eb), _lib.ptr(Jp),
                                              _lib.ptr(ep), _lib.dtype_code(dt), lie_eps(dt),
                                              _lib.stream_ptr(t.poses.device)), "thx_pg_jacobians")
+
+    def retract(self, poses, delta, step, ignore_mask, out):
+        """X <- X exp(step * delta) on the packed pose buffer; the group is read off the record shape."""
+        if poses.dim() == 4:
+            return self.se3_retract(poses, delta, step, ignore_mask, out)
+        P, B = poses.shape[:2]
+        dt = poses.dtype
+        _lib.check(self.lib.thx_se2_retract(_lib.ptr(poses), _lib.ptr(delta), delta.stride(0), float(step),
+                                            _lib.ptr(ignore_mask), _lib.ptr(out), P, B, _lib.dtype_code(dt),
+                                            se2_eps(dt), _lib.stream_ptr(poses.device)), "thx_se2_retract")
 
     def se3_retract(self, poses, delta, step, ignore_mask, out):
         P, B = poses.shape[:2]
@@ -182,6 +270,8 @@ class HipKernels:
                    "thx_se3_retract_vjp")
 
     def pg_vjp(self, s: DeviceStructure, t: PGTensors, w, g_meas, g_wb, g_tgt, g_wp, poses=None):
+        if t.se2:
+            raise NotImplementedError("implicit backward (thx_pg_vjp) is fused for SE3 pose graphs only")
         d = t.c_struct(poses)
         dt = w.dtype
         _lib.check(self.lib.thx_pg_vjp(s.c, d, _lib.ptr(w), w.stride(0), _lib.ptr(g_meas), _lib.ptr(g_wb),

@@ -141,18 +141,18 @@ class HipLinearizationCore:
         (dense_linearization.py:29-56); the optimiser never calls this."""
         p = self.packed
         J0, J1, eb, Jp, ep = p.jacobian_blocks()
-        B, s = p.batch, p.structure
+        B, s, d = p.batch, p.structure, p.dof
         A = torch.zeros(B, p.m, p.n, dtype=J0.dtype, device=J0.device)
         b = torch.zeros(B, p.m, dtype=J0.dtype, device=J0.device)
         for e in range(s.num_edges):
             r, i, j = int(s.edge_row_start[e]), int(s.edge_i[e]), int(s.edge_j[e])
-            A[:, r:r + 6, 6 * i:6 * i + 6] = J0[e]
-            A[:, r:r + 6, 6 * j:6 * j + 6] = J1[e]
-            b[:, r:r + 6] = -eb[e]
+            A[:, r:r + d, d * i:d * i + d] = J0[e]
+            A[:, r:r + d, d * j:d * j + d] = J1[e]
+            b[:, r:r + d] = -eb[e]
         for k in range(s.num_priors):
             r, i = int(s.prior_row_start[k]), int(s.prior_pose[k])
-            A[:, r:r + 6, 6 * i:6 * i + 6] = Jp[k]
-            b[:, r:r + 6] = -ep[k]
+            A[:, r:r + d, d * i:d * i + d] = Jp[k]
+            b[:, r:r + d] = -ep[k]
         self._A, self._b = A, b
 
     def _assemble(self):

@@ -1,9 +1,9 @@
-"""Packed device representation of an SE3 pose-graph objective.
+"""Packed device representation of a pose-graph objective (all poses SE3, or all poses SE2).
 
 This is the analogue of the reference's ``Vectorize`` pass (theseus/core/vectorizer.py:112-474): it
-groups the objective's cost functions by schema (Between / Difference on SE3), but instead of
+groups the objective's cost functions by schema (Between / Difference), but instead of
 stacking tensors for batched ATen calls it keeps ONE entity-major buffer per role
-(poses (P,B,3,4), measurements (E,Bm,3,4), weights (E,Bw,6), prior targets, prior weights) that
+(poses (P,B,3,4 | 4), measurements (E,Bm,3,4 | 4), weights (E,Bw,6 | 3), prior targets, prior weights) that
 the fused HIP kernels index directly.  Variables are tracked by ``_num_updates`` so that the
 buffers are re-packed only when somebody changed a variable behind our back.
 """
@@ -26,7 +26,7 @@ class UnsupportedObjective(NotImplementedError):
 # and the real ``theseus`` ones alike (theseus_amd/plugin.py plugs this back end into the reference's own loop).
 def _kind(obj) -> str:
     names = {c.__name__ for c in type(obj).__mro__}
-    for k in ("SE3", "Between"):
+    for k in ("SE3", "SE2", "Between"):
         if k in names:
             return k
     if "Local" in names or "Difference" in names:
@@ -34,17 +34,21 @@ def _kind(obj) -> str:
     return type(obj).__name__
 
 
-def _weight_diag6(w) -> torch.Tensor:
-    """(Bw, 6) sqrt-information diagonal of a Scale/DiagonalCostWeight (theseus/core/cost_weight.py:60-139)."""
-    if hasattr(w, "diagonal6"):
-        return w.diagonal6()
+GROUP_SHAPE = {"SE3": (3, 4), "SE2": (4,)}
+GROUP_DOF = {"SE3": 6, "SE2": 3}
+
+
+def _weight_diag(w, dof: int) -> torch.Tensor:
+    """(Bw, dof) sqrt-information diagonal of a Scale/DiagonalCostWeight (theseus/core/cost_weight.py:60-139)."""
+    if hasattr(w, "sqrt_diag"):
+        return w.sqrt_diag(dof)
     names = {c.__name__ for c in type(w).__mro__}
     if "ScaleCostWeight" in names:
-        return w.scale.tensor.view(-1, 1).expand(-1, 6)
+        return w.scale.tensor.view(-1, 1).expand(-1, dof)
     if "DiagonalCostWeight" in names:
         d = w.diagonal.tensor
-        if d.shape[1] != 6:
-            raise ValueError("SE3 costs need a 6-dimensional DiagonalCostWeight.")
+        if d.shape[1] != dof:
+            raise ValueError(f"This cost needs a {dof}-dimensional DiagonalCostWeight.")
         return d
     raise UnsupportedObjective(f"HIP backend supports Scale/DiagonalCostWeight; got {type(w).__name__}. "
                                "There is no CPU/eager fallback.")
@@ -60,12 +64,17 @@ class PackedPoseGraph:
         self.objective = objective
         self.K = kernels or default_kernels()
         self.pose_vars = []
+        self.group = None
         for v in objective.optim_vars.values():
-            if _kind(v) != "SE3":
+            kind = _kind(v)
+            if kind not in GROUP_SHAPE or (self.group is not None and kind != self.group):
                 raise UnsupportedObjective(
-                    f"HIP backend supports SE3 optimisation variables; got {type(v).__name__} ({v.name}). "
-                    "There is no CPU/eager fallback.")
+                    f"HIP backend fuses objectives whose optimisation variables are all SE3 or all SE2; got "
+                    f"{type(v).__name__} ({v.name}). There is no CPU/eager fallback.")
+            self.group = kind
             self.pose_vars.append(v)
+        self.gshape = GROUP_SHAPE[self.group]
+        self.dof = GROUP_DOF[self.group]
         index = {v.name: k for k, v in enumerate(self.pose_vars)}
         edges, priors, e_rows, p_rows = [], [], [], []
         self.edge_costs = []
@@ -85,9 +94,9 @@ class PackedPoseGraph:
             else:
                 raise UnsupportedObjective(
                     f"HIP backend has no fused kernel for cost function {type(c).__name__} ({c.name}); "
-                    "supported: Between, Difference/Local on SE3.  There is no CPU/eager fallback.")
+                    "supported: Between, Difference/Local on SE3 / SE2.  There is no CPU/eager fallback.")
             row += c.dim()
-        self.structure = PoseGraphStructure.build(len(self.pose_vars), edges, priors, e_rows, p_rows)
+        self.structure = PoseGraphStructure.build(len(self.pose_vars), edges, priors, e_rows, p_rows, dof=self.dof)
         self.n = self.structure.num_cols
         self.m = self.structure.num_rows
         self.ld = round_up(self.n, 32)
@@ -137,13 +146,14 @@ class PackedPoseGraph:
         obj._resolve_batch_size()
         B = obj.batch_size
         dev, dt = self.pose_vars[0].device, obj.dtype
-        poses = self._stack([v.tensor.expand(B, 3, 4) if v.shape[0] != B else v.tensor for v in self.pose_vars], B)
+        gs, dof = self.gshape, self.dof
+        poses = self._stack([v.tensor.expand(B, *gs) if v.shape[0] != B else v.tensor for v in self.pose_vars], B)
         E, Kp = self.structure.num_edges, self.structure.num_priors
         empty = lambda *s: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
-        meas = self._stack([c.measurement.tensor for c in self.edge_costs], B) if E else empty(0, 1, 3, 4)
-        wb = self._stack([_weight_diag6(c.weight) for c in self.edge_costs], B) if E else empty(0, 1, 6)
-        tgt = self._stack([c.target.tensor for c in self.prior_costs], B) if Kp else empty(0, 1, 3, 4)
-        wp = self._stack([_weight_diag6(c.weight) for c in self.prior_costs], B) if Kp else empty(0, 1, 6)
+        meas = self._stack([c.measurement.tensor for c in self.edge_costs], B) if E else empty(0, 1, *gs)
+        wb = self._stack([_weight_diag(c.weight, dof) for c in self.edge_costs], B) if E else empty(0, 1, dof)
+        tgt = self._stack([c.target.tensor for c in self.prior_costs], B) if Kp else empty(0, 1, *gs)
+        wp = self._stack([_weight_diag(c.weight, dof) for c in self.prior_costs], B) if Kp else empty(0, 1, dof)
         self.tensors = PGTensors(poses=poses, meas=meas, w_between=wb, prior_target=tgt, w_prior=wp)
         self._repoint_variables()
 
@@ -209,19 +219,19 @@ class PackedPoseGraph:
         m = None
         if ignore_mask is not None:
             m = ignore_mask if ignore_mask.dtype == torch.uint8 else ignore_mask.to(torch.uint8)
-        self.K.se3_retract(self.tensors.poses, delta, step, m, out)
+        self.K.retract(self.tensors.poses, delta, step, m, out)
         return out
 
     def jacobian_blocks(self):
-        """Weighted Jacobian blocks / residuals of every cost: (J0,J1 (E,B,6,6), eb (E,B,6), Jp, ep)."""
+        """Weighted Jacobian blocks / residuals of every cost: (J0,J1 (E,B,d,d), eb (E,B,d), Jp, ep), d = dof."""
         self.sync()
-        B, E, Kp = self.batch, self.structure.num_edges, self.structure.num_priors
+        B, E, Kp, d = self.batch, self.structure.num_edges, self.structure.num_priors, self.dof
         dt, dev = self.objective.dtype, self.tensors.poses.device
-        J0 = torch.empty(max(E, 1), B, 6, 6, dtype=dt, device=dev)
+        J0 = torch.empty(max(E, 1), B, d, d, dtype=dt, device=dev)
         J1 = torch.empty_like(J0)
-        eb = torch.empty(max(E, 1), B, 6, dtype=dt, device=dev)
-        Jp = torch.empty(max(Kp, 1), B, 6, 6, dtype=dt, device=dev)
-        ep = torch.empty(max(Kp, 1), B, 6, dtype=dt, device=dev)
+        eb = torch.empty(max(E, 1), B, d, dtype=dt, device=dev)
+        Jp = torch.empty(max(Kp, 1), B, d, d, dtype=dt, device=dev)
+        ep = torch.empty(max(Kp, 1), B, d, dtype=dt, device=dev)
         self.K.pg_jacobians(self.dstruct, self.tensors, J0, J1, eb, Jp, ep)
         return J0[:E], J1[:E], eb[:E], Jp[:Kp], ep[:Kp]
 
@@ -233,11 +243,11 @@ class PackedPoseGraph:
         s = self.structure
         if s.num_edges:
             rows = torch.from_numpy(s.edge_row_start).to(eb.device)
-            idx = (rows.view(-1, 1) + torch.arange(6, device=eb.device)).view(-1)
+            idx = (rows.view(-1, 1) + torch.arange(self.dof, device=eb.device)).view(-1)
             out[:, idx] = eb.permute(1, 0, 2).reshape(B, -1)
         if s.num_priors:
             rows = torch.from_numpy(s.prior_row_start).to(eb.device)
-            idx = (rows.view(-1, 1) + torch.arange(6, device=eb.device)).view(-1)
+            idx = (rows.view(-1, 1) + torch.arange(self.dof, device=eb.device)).view(-1)
             out[:, idx] = ep.permute(1, 0, 2).reshape(B, -1)
         return out
 
