@@ -124,9 +124,15 @@ def test_assemble_error_jacobians_vs_reference_golden(K, name):
         in_band(AtA, g["AtA"][0], H64, 5e-7)            # blocks accumulated in fp32 from fp64-evaluated J
         in_band(gv.cpu().numpy(), g["Atb"][0][..., 0], g64, 2e-7)   # accumulated in fp64, rounded once
     else:
+        # SE2 fp64: the reference's Jlog coefficients half_theta*sine/(1-cosine) and 1/theta - 0.5*sine/(1-cosine)
+        # (se2.py:205-214) amplify a 1-ulp difference of the composed cosine (FMA contraction, summation order) by
+        # 2/theta^2 resp. 1/(theta (1-cosine)); the fixtures hold a residual rotation of 7.8e-3 rad -> 3e-12 resp.
+        # 3e-10 relative: measured here 6e-11 of max|A|, 1.5e-11 of max|AtA|.  Two correct fp64 evaluations of the
+        # reference's formula differ by that much, so SE2 is pinned at 1e-9 of scale (SE3: 5e-12, no such term).
+        r64 = 1e-9 if p.group == "SE2" else 5e-12
         sc = np.abs(g["AtA"][0]).max()
-        np.testing.assert_allclose(AtA, g["AtA"][0], rtol=0, atol=sc * 5e-12)
-        np.testing.assert_allclose(gv.cpu().numpy(), g["Atb"][0][..., 0], rtol=0, atol=np.abs(g["Atb"][0]).max() * 5e-12)
+        np.testing.assert_allclose(AtA, g["AtA"][0], rtol=0, atol=sc * r64)
+        np.testing.assert_allclose(gv.cpu().numpy(), g["Atb"][0][..., 0], rtol=0, atol=np.abs(g["Atb"][0]).max() * r64)
     # untouched entries stay exactly zero (structure): pattern == block pattern
     pat = np.zeros((n, n), bool)
     d = p.dof
@@ -162,7 +168,7 @@ def test_assemble_error_jacobians_vs_reference_golden(K, name):
         in_band(A, g["A0"], A64, 2e-7)
         in_band(b, g["b0"], b64, 2e-7)
     else:
-        np.testing.assert_allclose(A, g["A0"], rtol=0, atol=np.abs(g["A0"]).max() * 1e-11)
+        np.testing.assert_allclose(A, g["A0"], rtol=0, atol=np.abs(g["A0"]).max() * max(r64, 1e-11))
         np.testing.assert_allclose(b, g["b0"], rtol=0, atol=np.abs(g["b0"]).max() * 1e-11 + 1e-30)
 
 
