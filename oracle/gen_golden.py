@@ -318,6 +318,64 @@ def gen_implicit(th, lieF):
               "|grad_wb|", wb.grad.abs().max().item())
 
 
+# the reference's own known-answer test for this path: tests/theseus_tests/test_pgo_benchmark.py:34-39
+PGO_KAT_LOSSES = [-0.29886279606812166, -0.3054215856589109, -0.27485602196709225, -0.3005231105990632]
+
+
+def gen_pgo_kat(th):
+    """Inputs of tests/theseus_tests/test_pgo_benchmark.py::test_pgo_losses[CholeskyDenseSolver] (64 SE3 poses, batch 16,
+    4 outer batches; LM adaptive + Welsch RobustCostFunction + implicit backward + Adam on log_loss_radius), produced by
+    the reference's own generator with the seeding of examples/pose_graph/pose_graph_synthetic.py:88-109, plus the
+    losses the reference computes from them HERE (they reproduce the published constants above to 1e-10)."""
+    import random
+    import logging
+    from omegaconf import OmegaConf
+    import examples.pose_graph.pose_graph_synthetic as pgo
+    import theseus.utils.examples as theg
+    logging.disable(logging.CRITICAL)
+    cfg = OmegaConf.load(REF + "/examples/configs/pose_graph/pose_graph_synthetic.yaml")
+    cfg.outer_optim.num_epochs = 1
+    cfg.outer_optim.max_num_batches = 4
+    cfg.batch_size = 16
+    cfg.num_poses = 64
+    cfg.profile = False
+    cfg.savemat = False
+    cfg.inner_optim.optimizer_kwargs.verbose = False
+    cfg.inner_optim.linear_solver_cls = "CholeskyDenseSolver"
+    cfg.device = "cpu"
+    cfg.inner_optim.reg_w = float(cfg.inner_optim.reg_w)  # the yaml stub reads 1e-3 as a string
+    cwd = os.getcwd()
+    os.chdir("/tmp")  # run() writes nothing with savemat off, but keep the read-only tree out of the cwd
+    try:
+        losses = pgo.run(cfg)[0]
+    finally:
+        os.chdir(cwd)
+    assert np.allclose(losses, PGO_KAT_LOSSES, rtol=1e-10, atol=1e-10), losses
+    # the same dataset again (same seeding as run())
+    torch.manual_seed(cfg.seed)
+    np.random.seed(cfg.seed)
+    random.seed(cfg.seed)
+    rng = torch.Generator()
+    rng.manual_seed(0)
+    pg, _ = theg.PoseGraphDataset.generate_synthetic_3D(
+        num_poses=cfg.num_poses, translation_noise=cfg.translation_noise, rotation_noise=cfg.rotation_noise,
+        loop_closure_ratio=cfg.loop_closure_ratio, loop_closure_outlier_ratio=cfg.loop_closure_outlier_ratio,
+        batch_size=cfg.batch_size, dataset_size=cfg.dataset_size, generator=rng, dtype=torch.float64)
+    gt_idx = [i for i in range(len(pg.poses)) if not (np.random.rand() > cfg.inner_optim.ratio_known_poses)]
+    N = 4 * cfg.batch_size
+    np.savez_compressed(
+        os.path.join(OUT, "pgo_kat.npz"),
+        poses0=torch.stack([p.tensor[:N] for p in pg.poses], 1).numpy(),
+        gt=torch.stack([p.tensor[:N] for p in pg.gt_poses], 1).numpy(),
+        edges=np.array([[e.i, e.j] for e in pg.edges], dtype=np.int64),
+        meas=torch.stack([e.relative_pose.tensor[:N] for e in pg.edges], 1).numpy(),
+        w_between=torch.stack([e.weight.diagonal.tensor for e in pg.edges], 1).numpy(),
+        gt_idx=np.array(gt_idx, dtype=np.int64), reg_w=np.float64(cfg.inner_optim.reg_w), known_w=np.float64(100.0),
+        batch_size=np.int64(cfg.batch_size), max_iters=np.int64(cfg.inner_optim.max_iters),
+        step_size=np.float64(cfg.inner_optim.step_size), lr=np.float64(cfg.outer_optim.lr), log_radius0=np.float64(3.0),
+        losses_published=np.array(PGO_KAT_LOSSES), losses_reference_here=np.array(losses))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     th, lieF = import_reference()
@@ -330,6 +388,8 @@ def main():
         gen_implicit(th, lieF)
     if not only or "se2" in only:
         gen_se2(th)
+    if not only or "pgo_kat" in only:
+        gen_pgo_kat(th)
     print("wrote", sorted(os.listdir(OUT)))
 
 

@@ -7,6 +7,7 @@ Follows, on packed tensors instead of per-variable Python objects:
   DenseLinearization                theseus/optimizer/dense_linearization.py:29-62
   DenseSolver._apply_damping        theseus/optimizer/linear/dense_solver.py:38-64
   CholeskyDenseSolver._solve_sytem  theseus/optimizer/linear/dense_solver.py:159-161
+  RobustCostFunction / Welsch,Huber theseus/core/robust_cost_function.py:87-135, theseus/core/robust_loss.py:13-52
   retract / error_metric            theseus/core/objective.py:37-38,562-641,873-914, theseus/core/variable.py:65-69
   LM loop                           theseus/optimizer/nonlinear/nonlinear_least_squares.py:100-215,338-365
                                     theseus/optimizer/nonlinear/levenberg_marquardt.py:114-201
@@ -53,6 +54,12 @@ class PGProblem:
     w_prior: torch.Tensor        # (1|B, K, 6)
     cost_order: Optional[List[Tuple[str, int]]] = None  # [('between',k)|('prior',k)] add order
     group: str = "SE3"           # "SE3": tensors (...,3,4), dof 6; "SE2": tensors (...,4) = [x,y,cos,sin], dof 3
+    # RobustCostFunction wrappers (robust_cost_function.py): loss kind ("welsch" | "huber" | None) per cost role and
+    # log_loss_radius broadcastable to (B, E|K, 1)
+    robust_between: Optional[str] = None
+    log_radius_between: Optional[torch.Tensor] = None
+    robust_prior: Optional[str] = None
+    log_radius_prior: Optional[torch.Tensor] = None
 
     def __post_init__(self):
         if self.cost_order is None:
@@ -100,12 +107,65 @@ def local_jac_err(target, var, w, G=_SE3):
     return Jlog * w[..., :, None], e * w
 
 
+_LOSS_EPS = 1e-20    # robust_loss.py:10
+_ROBUST_EPS = 1e-20  # robust_cost_function.py:52
+
+
+def loss_evaluate(kind, x, log_radius):
+    """robust_loss.py:13-16,33-36,43-47: rho(x), x = squared norm of the weighted error."""
+    r = log_radius.exp()
+    if kind == "welsch":
+        return r - r * torch.exp(-x / (r + _LOSS_EPS))
+    if kind == "huber":
+        return torch.where(x > r, 2 * torch.sqrt(r * torch.maximum(x, r) + _LOSS_EPS) - r, x)
+    raise ValueError(kind)
+
+
+def loss_linearize(kind, x, log_radius):
+    """robust_loss.py:18-20,38-40,49-52: rho'(x)."""
+    r = log_radius.exp()
+    if kind == "welsch":
+        return torch.exp(-x / (r + _LOSS_EPS))
+    if kind == "huber":
+        return torch.sqrt(r / torch.maximum(x, r) + _LOSS_EPS)
+    raise ValueError(kind)
+
+
+def robust_rescale(jacs, e, kind, log_radius):
+    """robust_cost_function.py:115-135 (flatten_dims=False): J, e <- sqrt(rho'(|e|^2) + eps) * (J, e)."""
+    if kind is None:
+        return jacs, e
+    sqn = (e**2).sum(-1, keepdim=True)
+    rs = (loss_linearize(kind, sqn, log_radius) + _ROBUST_EPS).sqrt()
+    return [rs.unsqueeze(-1) * J for J in jacs], rs * e
+
+
+def robust_weighted_error(e, kind, log_radius):
+    """robust_cost_function.py:87-106: ones * sqrt(rho(|e|^2) / dim + eps), so that |h|^2 = rho (+ dim eps)."""
+    if kind is None:
+        return e
+    sqn = (e**2).sum(-1, keepdim=True)
+    return torch.ones_like(e) * (loss_evaluate(kind, sqn, log_radius) / e.shape[-1] + _ROBUST_EPS).sqrt()
+
+
+def cost_terms(p: PGProblem, poses):
+    """weighted_jacobians_error of every cost (robust ones rescaled): J0, J1, eb, Jp, ep."""
+    i, j = p.edges[:, 0], p.edges[:, 1]
+    J0, J1, eb = between_jac_err(poses[:, i], poses[:, j], p.meas, p.w_between, p.G)
+    (J0, J1), eb = robust_rescale([J0, J1], eb, p.robust_between, p.log_radius_between)
+    Jp, ep = local_jac_err(p.prior_target, poses[:, p.prior_idx], p.w_prior, p.G)
+    (Jp,), ep = robust_rescale([Jp], ep, p.robust_prior, p.log_radius_prior)
+    return J0, J1, eb, Jp, ep
+
+
 def weighted_errors(p: PGProblem, poses):
-    """Weighted residuals of all costs: (e_between (B,E,6), e_prior (B,K,6))."""
+    """weighted_error of all costs: (e_between (B,E,6), e_prior (B,K,6)); robust costs return their
+    sqrt(rho/dim) vector (robust_cost_function.py:87-106)."""
     i, j = p.edges[:, 0], p.edges[:, 1]
     _, _, eb = between_jac_err(poses[:, i], poses[:, j], p.meas, p.w_between, p.G)
     _, ep = local_jac_err(p.prior_target, poses[:, p.prior_idx], p.w_prior, p.G)
-    return eb, ep
+    return (robust_weighted_error(eb, p.robust_between, p.log_radius_between),
+            robust_weighted_error(ep, p.robust_prior, p.log_radius_prior))
 
 
 def error_vector(p: PGProblem, poses):
@@ -125,8 +185,7 @@ def dense_linearize(p: PGProblem, poses):
     """dense_linearization.py:29-56: dense A (B,m,n), b = -err (B,m)."""
     B = poses.shape[0]
     i, j = p.edges[:, 0], p.edges[:, 1]
-    J0, J1, eb = between_jac_err(poses[:, i], poses[:, j], p.meas, p.w_between, p.G)
-    Jp, ep = local_jac_err(p.prior_target, poses[:, p.prior_idx], p.w_prior, p.G)
+    J0, J1, eb, Jp, ep = cost_terms(p, poses)
     A = torch.zeros(B, p.m, p.n, dtype=poses.dtype)
     b = torch.zeros(B, p.m, dtype=poses.dtype)
     d = p.dof

@@ -122,3 +122,32 @@ def test_se2_pose_graph_matches_reference(name, tol):
         for it in range(len(info.deltas)):
             np.testing.assert_allclose(info.deltas[it].numpy(), g["delta"][it], rtol=0,
                                        atol=tol * max(1.0, np.abs(g["delta"][it]).max()))
+
+
+def test_reference_pgo_known_answer_test():
+    """The oracle (Welsch RobustCostFunction, adaptive LM, implicit last step with __keep_final_step_size__) reproduces
+    the four losses PUBLISHED in the reference's tests/theseus_tests/test_pgo_benchmark.py:34-39 at the reference's own
+    tolerance rel = abs = 1e-10."""
+    from tests.pgo_kat_common import kat, outer_loop
+    g = kat()
+    t = torch.from_numpy
+    P, gt_idx = g["poses0"].shape[1], g["gt_idx"]
+
+    def inner(sl, log_radius):
+        poses0 = t(g["poses0"][sl])
+        K = 1 + len(gt_idx)
+        w_prior = torch.cat([torch.full((1, 1, 6), float(g["reg_w"])), torch.full((1, K - 1, 6), float(g["known_w"]))], 1).double()
+        p = opg.PGProblem(
+            num_poses=P, edges=t(g["edges"]), meas=t(g["meas"][sl]), w_between=t(g["w_between"]),
+            prior_idx=torch.cat([torch.zeros(1, dtype=torch.long), t(gt_idx)]),
+            prior_target=torch.cat([poses0[:, :1], t(g["gt"][sl])[:, gt_idx]], 1), w_prior=w_prior,
+            robust_between="welsch", log_radius_between=log_radius.view(1, 1, 1))
+        iters, step = int(g["max_iters"]), float(g["step_size"])
+        with torch.no_grad():
+            x, _ = opg.lm_optimize(p, poses0, max_iterations=iters - 1, step_size=step, damping=1e-3, adaptive_damping=True)
+        final, _ = opg.implicit_final_step(p, x, step_size=step)
+        return final
+
+    losses = outer_loop(g, inner)
+    for got, want in zip(losses, g["losses_published"]):
+        assert got == pytest.approx(want, rel=1e-10, abs=1e-10), (losses, g["losses_published"])

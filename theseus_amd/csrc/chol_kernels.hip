@@ -717,6 +717,14 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   const int valid = min(TILE, n - row0);
 
   const bool fwd = rhs != nullptr;
+#ifdef THX_DIAG_PROF
+  long long stamps[24];
+  int nst = 0;
+#define THX_STAMP() stamps[nst++] = (long long)__builtin_readcyclecounter()
+#else
+#define THX_STAMP()
+#endif
+  THX_STAMP();
   if (fwd)
     for (int k = tid; k < row0; k += 256) ybuf[k] = yout[(int64_t)b * ldv + k];  // y_0:j of earlier columns
 
@@ -737,6 +745,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 
   // ---- S = H_jj (+ damping on the diagonal) - acc -> LDS tile; identity padding outside the matrix ----
   __syncthreads();  // staging buffer is free
+  THX_STAMP();
   tile_g2l<T>(H + mat + (int64_t)row0 * ld + row0, ld, valid, valid, tile, tid);
   if (tid < TILE) vvec[tid] = (fwd && tid < valid) ? rhs[(int64_t)b * ldv + row0 + tid] : T(0);
   __syncthreads();
@@ -763,12 +772,18 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   else if (wave == 2) E::template syrk36_finish<2>(tile, acc, lane);
   else E::template syrk36_finish<3>(tile, acc, lane);
   __syncthreads();
+  THX_STAMP();
 
   // ---- blocked right-looking Cholesky on the LDS tile, 32-wide sub-blocks.  Afterwards the tile IS the
   //      solve panel: W_ss = L_ss^-1 on the diagonal sub-blocks, -L_us below them. ----
+#if defined(THX_SERIAL_WAVE_BID)
+  const int sw = (blockIdx.x >> 8) & 3;
+#else
+  const int sw = 0;
+#endif
   for (int sb = 0; sb < 4; ++sb) {
     T* Dss = tile + (32 * sb) * C::LDM + 32 * sb;
-    if (wave == 0) {
+    if (wave == sw) {
       T a[32];
       {
         const V* rp = reinterpret_cast<const V*>(Dss + (lane & 31) * C::LDM);
@@ -782,7 +797,9 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
           }
         }
       }
+      THX_STAMP();
       const int bad = potrf32<T>(a);
+      THX_STAMP();
       if (bad != 0 && lane == 0 && info[b] == 0) info[b] = row0 + 32 * sb + bad;
       // L_ss straight to global memory: one 32-element row per lane, zeros above the diagonal
       const int lr = lane & 31, grow = 32 * sb + lr;
@@ -817,7 +834,9 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
       }
       using WA = std::conditional_t<sizeof(T) == 8, double, float>;
       WA w[32];
+      THX_STAMP();
       inv32<T, WA, C::LDM>(Dss, w, lane);
+      THX_STAMP();
       __builtin_amdgcn_wave_barrier();
       if (lane < 32) {
 #pragma unroll
@@ -855,6 +874,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
     __syncthreads();
   }
 
+  THX_STAMP();
   // ---- outputs: strictly-lower sub-blocks of L_jj (= -tile), the panel, y_j ----
   {
     constexpr int CPR = TILE / C::VEC, RPP = 256 / CPR;
@@ -875,6 +895,15 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
     __syncthreads();
     if (tid < valid) yout[(int64_t)b * ldv + row0 + tid] = vvec[tid];
   }
+#ifdef THX_DIAG_PROF
+  THX_STAMP();
+  __syncthreads();
+  if (tid == sw * 64) {
+    T* P = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
+    for (int k = 1; k < nst; ++k) P[k] = (T)(stamps[k] - stamps[0]);
+    P[0] = (T)nst;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
