@@ -72,7 +72,20 @@ typedef struct {
   int64_t prior_target_bstride;
   const void* w_prior;       /* (K, Bw, 6)                                              */
   int64_t w_prior_bstride;
+  /* RobustCostFunction wrappers (theseus/core/robust_cost_function.py:52-135, flatten_dims = False): one loss kind per
+   * cost role (THX_LOSS_*), log_loss_radius per cost.  kind THX_LOSS_NONE: the pointer is not read. */
+  int32_t robust_between;
+  const void* log_radius_between;    /* (E, Br, 1), Br in {1, B} */
+  int64_t log_radius_between_bstride; /* 1 or 0 */
+  int32_t robust_prior;
+  const void* log_radius_prior;      /* (K, Br, 1) */
+  int64_t log_radius_prior_bstride;
 } thx_pg_data;
+
+/* theseus/core/robust_loss.py:33-52 */
+#define THX_LOSS_NONE 0
+#define THX_LOSS_WELSCH 1
+#define THX_LOSS_HUBER 2
 
 const char* thx_last_error(void);
 int thx_abi_version(void);
@@ -207,15 +220,16 @@ int thx_chol_solve(const void* L, int64_t ld, int32_t n, int32_t B, const void* 
  *        grad_theta = thx_pg_vjp(w)                         (d(w^T A^T b)/d theta, H detached: what autograd does to
  *                                                            Between/Local jacobians + errors + cost weights)
  *      thx_pg_vjp outputs are per problem: grad_meas (E,B,3,4), grad_w_between (E,B,6), grad_prior_target
- *      (K,B,3,4), grad_w_prior (K,B,6) -- the host reduces over broadcast dimensions; w is (B, n), row stride ldw.
+ *      (K,B,3,4), grad_w_prior (K,B,6), grad_log_radius_between (E,B) / grad_log_radius_prior (K,B) (robust costs
+ *      only, may be NULL) -- the host reduces over broadcast dimensions; w is (B, n), row stride ldw.
  *      Gradients w.r.t. raw 3x4 entries follow torchlie's conventions (log: tangent-projected passthrough
  *      backward, se3_impl.py:487-493; inverse / compose / jlog: plain derivatives). */
 int thx_se3_retract_vjp(const void* poses, const void* delta, int64_t ldd, double step, const void* grad_out,
                         void* grad_delta, int64_t ldg, int32_t P, int32_t B, int dtype, const thx_lie_eps* eps,
                         void* stream);
 int thx_pg_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, int64_t ldw, void* grad_meas,
-               void* grad_w_between, void* grad_prior_target, void* grad_w_prior, int dtype, const thx_lie_eps* eps,
-               void* stream);
+               void* grad_w_between, void* grad_prior_target, void* grad_w_prior, void* grad_log_radius_between,
+               void* grad_log_radius_prior, int dtype, const thx_lie_eps* eps, void* stream);
 
 /* ---- Linearization.diagonal_scaling support: d[b, i] = H[b, i, i] (linearization.py:85-87). */
 int thx_diag(const void* H, int64_t ld, int32_t n, int32_t B, void* d, int64_t ldv, int dtype, void* stream);

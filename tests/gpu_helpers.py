@@ -10,8 +10,13 @@ def to_device_problem(p, poses0, device="cuda"):
     """oracle PGProblem (batch-major) -> (PoseGraphStructure, PGTensors) in entity-major device layout."""
     s = PoseGraphStructure.build(p.num_poses, p.edges.tolist(), p.prior_idx.tolist(), dof=p.dof)
     em = lambda t: t.transpose(0, 1).contiguous().to(device)  # noqa: E731  (B,X,...) -> (X,B,...)
+    kind = {None: 0, "welsch": 1, "huber": 2}
+    E, Kp = p.edges.shape[0], p.prior_idx.shape[0]
+    lr = lambda x, n: None if x is None else em(x.expand(-1, n, 1).to(poses0.dtype))  # noqa: E731
     t = PGTensors(poses=em(poses0), meas=em(p.meas), w_between=em(p.w_between),
-                  prior_target=em(p.prior_target), w_prior=em(p.w_prior))
+                  prior_target=em(p.prior_target), w_prior=em(p.w_prior),
+                  robust_between=kind[p.robust_between], log_radius_between=lr(p.log_radius_between, E),
+                  robust_prior=kind[p.robust_prior], log_radius_prior=lr(p.log_radius_prior, Kp))
     return s, t
 
 

@@ -9,6 +9,9 @@ from oracle import lie
 from oracle import pose_graph as opg
 
 
+LOSS = {0: None, 1: "welsch", 2: "huber"}  # theseus_amd._lib.LOSS_*
+
+
 class OracleKernels:
     name = "oracle-cpu-standin"
 
@@ -22,7 +25,11 @@ class OracleKernels:
                           meas=bm(t.meas), w_between=bm(t.w_between),
                           prior_idx=torch.from_numpy(h.prior_pose).long(),
                           prior_target=bm(t.prior_target), w_prior=bm(t.w_prior),
-                          group="SE2" if t.poses.dim() == 3 else "SE3")
+                          group="SE2" if t.poses.dim() == 3 else "SE3",
+                          robust_between=LOSS[t.robust_between],
+                          log_radius_between=bm(t.log_radius_between) if t.robust_between else None,
+                          robust_prior=LOSS[t.robust_prior],
+                          log_radius_prior=bm(t.log_radius_prior) if t.robust_prior else None)
         return p, bm(t.poses if poses is None else poses)
 
     # ---- SE3 elementwise -----------------------------------------------------------------------
@@ -58,13 +65,11 @@ class OracleKernels:
 
     def pg_jacobians(self, s, t, J0, J1, eb, Jp, ep, poses=None):
         p, x = self._problem(s, t, poses)
-        i, j = p.edges[:, 0], p.edges[:, 1]
+        a, b, e, ap, e2 = opg.cost_terms(p, x)
         if p.edges.shape[0]:
-            a, b, e = opg.between_jac_err(x[:, i], x[:, j], p.meas, p.w_between, p.G)
             J0.copy_(a.transpose(0, 1)); J1.copy_(b.transpose(0, 1)); eb.copy_(e.transpose(0, 1))
         if p.prior_idx.shape[0]:
-            a, e = opg.local_jac_err(p.prior_target, x[:, p.prior_idx], p.w_prior, p.G)
-            Jp.copy_(a.transpose(0, 1)); ep.copy_(e.transpose(0, 1))
+            Jp.copy_(ap.transpose(0, 1)); ep.copy_(e2.transpose(0, 1))
 
     def se3_retract(self, poses, delta, step, ignore_mask, out):
         x = poses.transpose(0, 1)
@@ -129,19 +134,25 @@ class OracleKernels:
             (g,) = torch.autograd.grad(y, d, grad_out.transpose(0, 1))
         grad_delta.copy_(g)
 
-    def pg_vjp(self, s, t, w, g_meas, g_wb, g_tgt, g_wp, poses=None):
+    def pg_vjp(self, s, t, w, g_meas, g_wb, g_tgt, g_wp, poses=None, g_lrb=None, g_lrp=None):
         import dataclasses
         p, x = self._problem(s, t, poses)
         B = x.shape[0]
+        E, Kp = p.edges.shape[0], p.prior_idx.shape[0]
         with torch.enable_grad():
             full = lambda a: a.detach().expand(B, *a.shape[1:]).clone().requires_grad_(True)  # noqa: E731
             leaves = [full(p.meas), full(p.w_between), full(p.prior_target), full(p.w_prior)]
-            pg = dataclasses.replace(p, meas=leaves[0], w_between=leaves[1], prior_target=leaves[2], w_prior=leaves[3])
+            lrb = full(p.log_radius_between.expand(-1, E, 1)) if p.robust_between else None
+            lrp = full(p.log_radius_prior.expand(-1, Kp, 1)) if p.robust_prior else None
+            pg = dataclasses.replace(p, meas=leaves[0], w_between=leaves[1], prior_target=leaves[2], w_prior=leaves[3],
+                                     log_radius_between=lrb, log_radius_prior=lrp)
+            leaves += [l for l in (lrb, lrp) if l is not None]
             A, b = opg.dense_linearize(pg, x)
             _, Atb = opg.hessian(A, b)
             phi = (w * Atb.squeeze(2)).sum()
             grads = torch.autograd.grad(phi, leaves, allow_unused=True)
-        for out, g, leaf in zip((g_meas, g_wb, g_tgt, g_wp), grads, leaves):
+        outs = [g_meas, g_wb, g_tgt, g_wp] + [o for o, l in ((g_lrb, lrb), (g_lrp, lrp)) if l is not None]
+        for out, g, leaf in zip(outs, grads, leaves):
             if leaf.shape[1] > 0:
                 out[:leaf.shape[1]].copy_((g if g is not None else torch.zeros_like(leaf)).transpose(0, 1))
 

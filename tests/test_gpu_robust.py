@@ -1,0 +1,123 @@
+"""-m gpu: RobustCostFunction (Welsch / Huber) fused into the HIP kernels (csrc/robust.cuh): kernel outputs against
+the oracle (pinned to the reference by the PGO known-answer test, tests/test_oracle_golden.py), and the reference's
+PUBLISHED known-answer test itself through the HIP path."""
+import contextlib
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pose_graph as opg
+from tests.helpers import f32_thresholds, golden_problem, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def robust_problem(name, kind, dtype, both_roles):
+    """A golden pose graph with its costs wrapped in a robust loss; radii chosen so that inliers (x << r), the knee
+    (x ~ r) and outliers (x >> r) all occur at the initial iterate.  Values are rounded to ``dtype`` first."""
+    g = load_golden(name)
+    p, poses0, _ = golden_problem(g)
+    B, E, Kp = poses0.shape[0], p.edges.shape[0], p.prior_idx.shape[0]
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        eb, ep = opg.weighted_errors(p, poses0)
+    xb, xp = (eb ** 2).sum(-1, keepdim=True), (ep ** 2).sum(-1, keepdim=True)
+    lrb = (xb.median() * torch.exp(2.0 * torch.randn(B, E, 1, dtype=torch.float64, generator=gen))).log()
+    lrp = (xp.median() * torch.exp(2.0 * torch.randn(1, Kp, 1, dtype=torch.float64, generator=gen))).log()
+    r = lambda x: x.to(dtype).double()  # noqa: E731
+    p = dataclasses.replace(p, meas=r(p.meas), w_between=r(p.w_between), prior_target=r(p.prior_target), w_prior=r(p.w_prior),
+                            robust_between=kind, log_radius_between=r(lrb),
+                            robust_prior=kind if both_roles else None, log_radius_prior=r(lrp) if both_roles else None)
+    return p, r(poses0)
+
+
+def to_dtype(p, dtype):
+    c = lambda x: None if x is None else x.to(dtype)  # noqa: E731
+    return dataclasses.replace(p, meas=c(p.meas), w_between=c(p.w_between), prior_target=c(p.prior_target),
+                               w_prior=c(p.w_prior), log_radius_between=c(p.log_radius_between),
+                               log_radius_prior=c(p.log_radius_prior))
+
+
+@pytest.mark.parametrize("name,kind,dtype,both", [
+    ("pg_f64_lm_adaptive_ellips", "welsch", torch.float64, True), ("pg_f64_lm_adaptive_ellips", "huber", torch.float64, True),
+    ("pg_f64_lm", "welsch", torch.float32, False), ("pg_f64_lm", "huber", torch.float32, True),
+    ("pg2_f64_lm_adaptive", "welsch", torch.float64, True), ("pg2_f64_lm_adaptive", "huber", torch.float32, False)])
+def test_robust_assemble_error_jacobians_vs_oracle(name, kind, dtype, both):
+    from tests.gpu_helpers import alloc_dense, sym_from_lower, to_device_problem
+    from theseus_amd.kernels import default_kernels
+    K = default_kernels()
+    p, poses0 = robust_problem(name, kind, dtype, both)
+    f32 = dtype == torch.float32
+    with (f32_thresholds() if f32 else contextlib.nullcontext()):
+        A, b = opg.dense_linearize(p, poses0)
+        H64, g64 = opg.hessian(A, b)
+        err64 = opg.error_metric(p, poses0)
+        J0r, J1r, ebr, Jpr, epr = opg.cost_terms(p, poses0)
+    s, t = to_device_problem(to_dtype(p, dtype), poses0.to(dtype))
+    ds = s.on("cuda")
+    B, n, d = poses0.shape[0], s.num_cols, p.dof
+    H, gv, _ = alloc_dense(B, n, dtype)
+    K.pg_assemble(ds, t, H, gv)
+    rel = 5e-7 if f32 else (1e-9 if p.group == "SE2" else 5e-12)
+    assert (sym_from_lower(H, n).cpu().double() - H64).abs().max() <= rel * H64.abs().max()
+    assert (gv.cpu().double() - g64[..., 0]).abs().max() <= rel * g64.abs().max()
+    part = torch.empty(16, B, dtype=dtype, device="cuda")
+    err = torch.empty(B, dtype=dtype, device="cuda")
+    K.pg_error(ds, t, part, err)
+    np.testing.assert_allclose(err.cpu().double().numpy(), err64.numpy(), rtol=3e-7 if f32 else 1e-12)
+    E, Kp = s.num_edges, s.num_priors
+    new = lambda *sh: torch.empty(*sh, dtype=dtype, device="cuda")  # noqa: E731
+    J0, J1, eb, Jp, ep = new(E, B, d, d), new(E, B, d, d), new(E, B, d), new(Kp, B, d, d), new(Kp, B, d)
+    K.pg_jacobians(ds, t, J0, J1, eb, Jp, ep)
+    for got, want in ((J0, J0r), (J1, J1r), (eb, ebr), (Jp, Jpr), (ep, epr)):
+        want = want.expand(B, *want.shape[1:]).transpose(0, 1)
+        assert (got.cpu().double() - want).abs().max() <= (3e-7 if f32 else max(rel, 1e-11)) * want.abs().max()
+
+
+@pytest.mark.parametrize("kind,dtype,both", [("welsch", torch.float64, True), ("huber", torch.float64, True),
+                                             ("welsch", torch.float32, False)])
+def test_robust_vjp_vs_oracle_autograd(kind, dtype, both):
+    """thx_pg_vjp with robust costs: gradients w.r.t. measurements, weights, targets AND log_loss_radius against torch
+    autograd through the oracle (rho' is not detached, robust_cost_function.py:115-135)."""
+    from tests.gpu_helpers import to_device_problem
+    from theseus_amd.kernels import default_kernels
+    K = default_kernels()
+    p, poses0 = robust_problem("pg_f64_implicit_b", kind, dtype, both)
+    f32 = dtype == torch.float32
+    B, n = poses0.shape[0], 6 * p.num_poses
+    E, Kp = p.edges.shape[0], p.prior_idx.shape[0]
+    w = torch.randn(B, n, dtype=torch.float64, generator=torch.Generator().manual_seed(3)).to(dtype).double()
+    full = lambda a: a.expand(B, *a.shape[1:]).clone().requires_grad_(True)  # noqa: E731
+    leaves = [full(p.meas), full(p.w_between), full(p.prior_target), full(p.w_prior), full(p.log_radius_between)]
+    if both:
+        leaves.append(full(p.log_radius_prior))
+    pg = dataclasses.replace(p, meas=leaves[0], w_between=leaves[1], prior_target=leaves[2], w_prior=leaves[3],
+                             log_radius_between=leaves[4], log_radius_prior=leaves[5] if both else None)
+    with (f32_thresholds() if f32 else contextlib.nullcontext()):
+        A, b = opg.dense_linearize(pg, poses0)
+        _, Atb = opg.hessian(A, b)
+        ref = torch.autograd.grad((w * Atb.squeeze(2)).sum(), leaves)
+    s, t = to_device_problem(to_dtype(p, dtype), poses0.to(dtype))
+    new = lambda *sh: torch.empty(*sh, dtype=dtype, device="cuda")  # noqa: E731
+    outs = [new(E, B, 3, 4), new(E, B, 6), new(Kp, B, 3, 4), new(Kp, B, 6), new(E, B, 1)] + ([new(Kp, B, 1)] if both else [])
+    K.pg_vjp(s.on("cuda"), t, w.to(dtype).cuda(), *outs[:4], g_lrb=outs[4], g_lrp=outs[5] if both else None)
+    tol = 5e-7 if f32 else 1e-9
+    for k, (got, want) in enumerate(zip(outs, ref)):
+        want = want.transpose(0, 1)
+        assert (got.cpu().double() - want).abs().max() <= tol * want.abs().max(), k
+
+
+def test_reference_pgo_known_answer_through_the_hip_path():
+    """tests/theseus_tests/test_pgo_benchmark.py:34-39 (published losses, rel = abs = 1e-10 in the reference) with the
+    inner optimisation on the GPU: theseus_amd.LevenbergMarquardt + HipCholeskySolver, Welsch costs fused into
+    thx_pg_assemble / thx_pg_error, implicit backward through thx_se3_retract_vjp / thx_chol_solve / thx_pg_vjp.
+    Tolerance: the losses are ratios of sums over 16 x 64 poses after 10 LM iterations on systems whose adaptive
+    damping reaches 1e-7 (cond ~ 1e9); two correct fp64 solvers agree to ~1e-8 on the poses, asserted at 1e-7."""
+    import theseus_amd as th
+    from tests.test_robust_host import run_kat
+    losses, want = run_kat(th, None, device="cuda")
+    print("HIP losses", losses, "published", list(want))
+    for a, b in zip(losses, want):
+        assert a == pytest.approx(b, rel=1e-7, abs=1e-7), (losses, list(want))

@@ -3,8 +3,8 @@
 Host-side mirror of the reference's modelling + optimizer API for the SE3 / SE2 pose-graph hot path, over
 hand-written HIP kernels behind a C ABI (include/theseus_hip.h, theseus_amd/csrc).  No CPU fallback.
 """
-from .core import (Between, CostFunction, CostWeight, DiagonalCostWeight, Difference, Local, Objective,  # noqa: F401
-                   ScaleCostWeight, SE2, SE3, Variable, Vector)
+from .core import (Between, CostFunction, CostWeight, DiagonalCostWeight, Difference, HuberLoss, Local,  # noqa: F401
+                   Objective, RobustCostFunction, RobustLoss, ScaleCostWeight, SE2, SE3, Variable, Vector, WelschLoss)
 from .kernels import HipKernels, default_kernels, set_lie_eps, set_se2_eps  # noqa: F401
 from .layer import TheseusLayer  # noqa: F401
 from .linear_solver import HipCholeskySolver, LinearSolver  # noqa: F401

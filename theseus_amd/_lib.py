@@ -17,7 +17,8 @@ LIB_PATH = os.environ.get("THESEUS_HIP_LIB") or os.path.join(_HERE, "lib", "libt
 
 THX_TILE = 128
 THX_ERR_CHUNKS = 16
-ABI_VERSION = 3
+LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
+ABI_VERSION = 4
 
 
 class LieEps(Structure):
@@ -45,6 +46,9 @@ class PGData(Structure):
         ("w_between", c_void_p), ("w_between_bstride", c_int64),
         ("prior_target", c_void_p), ("prior_target_bstride", c_int64),
         ("w_prior", c_void_p), ("w_prior_bstride", c_int64),
+        # RobustCostFunction wrappers: loss kind (LOSS_*) per cost role + log_loss_radius (E|K, Br, 1)
+        ("robust_between", c_int32), ("log_radius_between", c_void_p), ("log_radius_between_bstride", c_int64),
+        ("robust_prior", c_int32), ("log_radius_prior", c_void_p), ("log_radius_prior_bstride", c_int64),
     ]
 
 
@@ -81,7 +85,7 @@ _SIGNATURES = {
     "thx_se3_retract_vjp": [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int,
                             POINTER(LieEps), c_void_p],
     "thx_pg_vjp": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                   c_int, POINTER(LieEps), c_void_p],
+                   c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
     "thx_block_assemble": [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64,
                            c_void_p, c_int64, c_int32, c_int, c_void_p],
     "thx_diag": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_int, c_void_p],

@@ -400,6 +400,78 @@ Local = Difference
 
 
 # ------------------------------------------------------------------------------------------------
+# robust costs (theseus/core/robust_loss.py:13-52, theseus/core/robust_cost_function.py:52-135)
+# ------------------------------------------------------------------------------------------------
+class RobustLoss(abc.ABC):
+    """rho(x) / rho'(x) of the squared norm x of a weighted error.  The fused kernels evaluate these on device
+    (csrc/robust.cuh); the torch forms below serve ``RobustCostFunction.weighted_error`` outside the packed path."""
+    _LOSS_EPS = 1e-20
+
+    @classmethod
+    def evaluate(cls, x: torch.Tensor, log_radius: torch.Tensor) -> torch.Tensor:
+        return cls._evaluate_impl(x, log_radius.exp())
+
+    @classmethod
+    def linearize(cls, x: torch.Tensor, log_radius: torch.Tensor) -> torch.Tensor:
+        return cls._linearize_impl(x, log_radius.exp())
+
+
+class WelschLoss(RobustLoss):
+    @staticmethod
+    def _evaluate_impl(x, radius):
+        return radius - radius * torch.exp(-x / (radius + RobustLoss._LOSS_EPS))
+
+    @staticmethod
+    def _linearize_impl(x, radius):
+        return torch.exp(-x / (radius + RobustLoss._LOSS_EPS))
+
+
+class HuberLoss(RobustLoss):
+    @staticmethod
+    def _evaluate_impl(x, radius):
+        return torch.where(x > radius, 2 * torch.sqrt(radius * x.max(radius) + RobustLoss._LOSS_EPS) - radius, x)
+
+    @staticmethod
+    def _linearize_impl(x, radius):
+        return torch.sqrt(radius / torch.max(x, radius) + RobustLoss._LOSS_EPS)
+
+
+class RobustCostFunction(CostFunction):
+    """Wraps a cost function: its weighted error / Jacobians are rescaled by sqrt(rho'(|w e|^2) + eps) in the
+    linearization and its contribution to the objective is rho(|w e|^2) (robust_cost_function.py:52-135)."""
+    _EPS = 1e-20
+
+    def __init__(self, cost_function: CostFunction, loss_cls, log_loss_radius: Variable, flatten_dims: bool = False,
+                 name: Optional[str] = None):
+        self.cost_function = cost_function
+        super().__init__(cost_function.weight, name=name)
+        self.log_loss_radius = log_loss_radius
+        self.loss = loss_cls()
+        self.flatten_dims = flatten_dims
+
+    def optim_vars(self):
+        return self.cost_function.optim_vars()
+
+    def aux_vars(self):
+        return self.cost_function.aux_vars() + [self.log_loss_radius]
+
+    def dim(self):
+        return self.cost_function.dim()
+
+    def weighted_error(self):
+        we = self.cost_function.weighted_error()
+        if self.flatten_dims:
+            we = we.reshape(-1, 1)
+        rho = self.loss.evaluate((we ** 2).sum(dim=1, keepdim=True), self.log_loss_radius.tensor)
+        if self.flatten_dims:
+            return (rho.reshape(-1, self.dim()) + RobustCostFunction._EPS).sqrt()
+        return torch.ones_like(we) * (rho / self.dim() + RobustCostFunction._EPS).sqrt()
+
+    def error(self):
+        return self.weighted_error()
+
+
+# ------------------------------------------------------------------------------------------------
 # objective
 # ------------------------------------------------------------------------------------------------
 class Objective:

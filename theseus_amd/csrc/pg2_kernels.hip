@@ -3,6 +3,7 @@
 // 3x3 blocks instead of 6x6, 4-element records instead of 3x4.  All Lie arithmetic in fp64 registers.
 #include "common.cuh"
 #include "lie_se2.cuh"
+#include "robust.cuh"
 
 namespace thx {
 
@@ -21,6 +22,18 @@ __device__ __forceinline__ void m3_tmul_acc(const double* P, const double* Q, do
 __device__ __forceinline__ void m3_tvec_sub(const double* P, const double* e, double* g) {  // g -= P^T e
 #pragma unroll
   for (int i = 0; i < 3; ++i) g[i] -= P[i] * e[0] + P[3 + i] * e[1] + P[6 + i] * e[2];
+}
+template <typename T>
+__device__ __forceinline__ void robustify2(int kind, const void* lr, int64_t lr_bs, int64_t entity, int b, int B,
+                                           double* ev, double* J0, double* J1) {
+  if (kind == THX_LOSS_NONE) return;
+  const double f = robust_rescale<3>(kind, ev, load_log_radius<T>(lr, entity, b, B, lr_bs));
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    if (J0) J0[i] *= f;
+    if (J1) J1[i] *= f;
+  }
+  ev[0] *= f; ev[1] *= f; ev[2] *= f;
 }
 template <typename T>
 __device__ __forceinline__ void load3(const T* __restrict__ p, double* w) {
@@ -66,11 +79,13 @@ pg2_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_
     }
     if (side == 0) {
       between_eval2(Xp, Xq, M, w, eps, ev, J0, J1, true);
+      robustify2<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, J0, J1);
       m3_tmul_acc(J0, J0, Dg);
       m3_tvec_sub(J0, ev, gv);
       if (lower) m3_tmul_acc(J0, J1, Off);
     } else {
       between_eval2(Xq, Xp, M, w, eps, ev, J0, J1, true);
+      robustify2<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, J0, J1);
       m3_tmul_acc(J1, J1, Dg);
       m3_tvec_sub(J1, ev, gv);
       if (lower) m3_tmul_acc(J1, J0, Off);
@@ -86,6 +101,7 @@ pg2_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_
     double w[3], ev[3], J[9];
     load3(wp + ((int64_t)id * wpB) * 3 + (int64_t)b * d.w_prior_bstride, w);
     local_eval2(Tg, Xp, w, eps, ev, J, true);
+    robustify2<T>(d.robust_prior, d.log_radius_prior, d.log_radius_prior_bstride, id, b, B, ev, J, nullptr);
     m3_tmul_acc(J, J, Dg);
     m3_tvec_sub(J, ev, gv);
   }
@@ -116,7 +132,8 @@ pg2_error_partial_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ part
     double w[3], ev[3];
     load3(static_cast<const T*>(d.w_between) + ((int64_t)e * wB) * 3 + (int64_t)b * d.w_between_bstride, w);
     between_eval2<double>(Xi, Xj, M, w, eps, ev, nullptr, nullptr, false);
-    acc += ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2];
+    acc += robust_sq_error<3>(d.robust_between, ev,
+                              d.robust_between ? load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride) : 0.0);
   }
   const int kc = (K + THX_ERR_CHUNKS - 1) / THX_ERR_CHUNKS, k1 = min(K, (ch + 1) * kc);
   const int64_t tB = d.prior_target_bstride ? B : 1, wpB = d.w_prior_bstride ? B : 1;
@@ -126,7 +143,8 @@ pg2_error_partial_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ part
     double w[3], ev[3];
     load3(static_cast<const T*>(d.w_prior) + ((int64_t)k * wpB) * 3 + (int64_t)b * d.w_prior_bstride, w);
     local_eval2<double>(Tg, X, w, eps, ev, nullptr, false);
-    acc += ev[0] * ev[0] + ev[1] * ev[1] + ev[2] * ev[2];
+    acc += robust_sq_error<3>(d.robust_prior, ev,
+                              d.robust_prior ? load_log_radius<T>(d.log_radius_prior, k, b, B, d.log_radius_prior_bstride) : 0.0);
   }
   partials[(int64_t)ch * B + b] = (T)acc;
 }
@@ -159,6 +177,7 @@ pg2_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* 
     const SE2<double> M = se2_load(static_cast<const T*>(d.meas) + ((int64_t)e * mB) * 4 + (int64_t)b * d.meas_bstride);
     load3(static_cast<const T*>(d.w_between) + ((int64_t)e * wB) * 3 + (int64_t)b * d.w_between_bstride, w);
     between_eval2(Xi, Xj, M, w, eps, ev, J0, J1, true);
+    robustify2<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, J0, J1);
     const int64_t o = (int64_t)e * B + b;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -173,6 +192,7 @@ pg2_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* 
     const SE2<double> Tg = se2_load(static_cast<const T*>(d.prior_target) + ((int64_t)k * tB) * 4 + (int64_t)b * d.prior_target_bstride);
     load3(static_cast<const T*>(d.w_prior) + ((int64_t)k * wB) * 3 + (int64_t)b * d.w_prior_bstride, w);
     local_eval2(Tg, X, w, eps, ev, J0, true);
+    robustify2<T>(d.robust_prior, d.log_radius_prior, d.log_radius_prior_bstride, k, b, B, ev, J0, nullptr);
     const int64_t o = (int64_t)k * B + b;
 #pragma unroll
     for (int q = 0; q < 9; ++q)
@@ -245,6 +265,9 @@ static int check_pg2(const thx_pg_structure* s, const thx_pg_data* d) {
   if (d->prior_target_bstride != 0 && d->prior_target_bstride != 4) return fail("SE2: prior_target_bstride must be 0 or 4");
   if (d->w_between_bstride != 0 && d->w_between_bstride != 3) return fail("SE2: w_between_bstride must be 0 or 3");
   if (d->w_prior_bstride != 0 && d->w_prior_bstride != 3) return fail("SE2: w_prior_bstride must be 0 or 3");
+  if ((d->robust_between && !d->log_radius_between) || (d->robust_prior && !d->log_radius_prior))
+    return fail("robust cost without log_loss_radius");
+  if (d->robust_between < 0 || d->robust_between > 2 || d->robust_prior < 0 || d->robust_prior > 2) return fail("bad loss kind");
   return 0;
 }
 

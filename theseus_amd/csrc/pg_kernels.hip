@@ -11,6 +11,25 @@
 // evaluated twice per edge (once per endpoint), which is ~3 MFLOP per problem against an HBM-bound
 // store of the blocks.
 #include "common.cuh"
+#include "robust.cuh"
+
+namespace thx {
+__device__ __forceinline__ void sjac_scale(SJac<double>& J, double f) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { J.a[i] *= f; J.c[i] *= f; J.d[i] *= f; }
+}
+// robust rescale of a Between / Local evaluation (robust_cost_function.py:115-135)
+template <typename T>
+__device__ __forceinline__ void robustify(int kind, const void* lr, int64_t lr_bs, int64_t entity, int b, int B,
+                                          double* ev, SJac<double>* J0, SJac<double>* J1) {
+  if (kind == THX_LOSS_NONE) return;
+  const double f = robust_rescale<6>(kind, ev, load_log_radius<T>(lr, entity, b, B, lr_bs));
+  if (J0) sjac_scale(*J0, f);
+  if (J1) sjac_scale(*J1, f);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) ev[i] *= f;
+}
+}  // namespace thx
 
 namespace thx {
 
@@ -103,12 +122,14 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
     }
     if (side == 0) {  // p is v0: own Jacobian J0, other J1
       between_eval_hp(Xp, Xq, M, w, eps, ev, &J0d, &J1d, true);
+      robustify<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, &J0d, &J1d);
       const SJac<T> J0 = narrow<T>(J0d);
       sjac_tmul_acc(J0, J0, Dg);
       sjac_tvec_sub(J0d, ev, gv);
       if (lower) sjac_tmul_acc(J0, narrow<T>(J1d), Off);
     } else {  // p is v1
       between_eval_hp(Xq, Xp, M, w, eps, ev, &J0d, &J1d, true);
+      robustify<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, &J0d, &J1d);
       const SJac<T> J1 = narrow<T>(J1d);
       sjac_tmul_acc(J1, J1, Dg);
       sjac_tvec_sub(J1d, ev, gv);
@@ -134,6 +155,7 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
     load6(wp + ((int64_t)id * wB) * 6 + (int64_t)b * d.w_prior_bstride, w);
     SJac<double> Jd;
     local_eval_hp(Tg, Xp, w, eps, ev, &Jd, true);
+    robustify<T>(d.robust_prior, d.log_radius_prior, d.log_radius_prior_bstride, id, b, B, ev, &Jd, nullptr);
     const SJac<T> J = narrow<T>(Jd);
     sjac_tmul_acc(J, J, Dg);
     sjac_tvec_sub(Jd, ev, gv);
@@ -175,8 +197,8 @@ pg_error_partial_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ parti
     double ev[6];
     load6(wb + ((int64_t)e * wB) * 6 + (int64_t)b * d.w_between_bstride, w);
     between_eval_hp<T>(Xi, Xj, M, w, eps, ev, nullptr, nullptr, false);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) acc += ev[r] * ev[r];
+    acc += robust_sq_error<6>(d.robust_between, ev,
+                              d.robust_between ? load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride) : 0.0);
   }
   const T* tgt = static_cast<const T*>(d.prior_target);
   const T* wp = static_cast<const T*>(d.w_prior);
@@ -192,8 +214,8 @@ pg_error_partial_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ parti
     double ev[6];
     load6(wp + ((int64_t)k * wpB) * 6 + (int64_t)b * d.w_prior_bstride, w);
     local_eval_hp<T>(Tg, X, w, eps, ev, nullptr, false);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) acc += ev[r] * ev[r];
+    acc += robust_sq_error<6>(d.robust_prior, ev,
+                              d.robust_prior ? load_log_radius<T>(d.log_radius_prior, k, b, B, d.log_radius_prior_bstride) : 0.0);
   }
   partials[(int64_t)ch * B + b] = (T)acc;
 }
@@ -233,6 +255,7 @@ pg_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* _
     load6(static_cast<const T*>(d.w_between) + ((int64_t)e * wB) * 6 + (int64_t)b * d.w_between_bstride, w);
     SJac<double> J0d, J1d;
     between_eval_hp(Xi, Xj, M, w, eps, ev, &J0d, &J1d, true);
+    robustify<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, &J0d, &J1d);
     const SJac<T> J0 = narrow<T>(J0d), J1 = narrow<T>(J1d);
     const int64_t o = (int64_t)e * B + b;
     if (J0o) {
@@ -259,6 +282,7 @@ pg_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* _
     load6(static_cast<const T*>(d.w_prior) + ((int64_t)k * wB) * 6 + (int64_t)b * d.w_prior_bstride, w);
     SJac<double> Jd;
     local_eval_hp(Tg, X, w, eps, ev, &Jd, true);
+    robustify<T>(d.robust_prior, d.log_radius_prior, d.log_radius_prior_bstride, k, b, B, ev, &Jd, nullptr);
     const SJac<T> J = narrow<T>(Jd);
     const int64_t o = (int64_t)k * B + b;
     if (Jpo) {
@@ -400,6 +424,9 @@ static int check_pg(const thx_pg_structure* s, const thx_pg_data* d) {
   if (d->prior_target_bstride != 0 && d->prior_target_bstride != 12) return fail("prior_target_bstride must be 0 or 12");
   if (d->w_between_bstride != 0 && d->w_between_bstride != 6) return fail("w_between_bstride must be 0 or 6");
   if (d->w_prior_bstride != 0 && d->w_prior_bstride != 6) return fail("w_prior_bstride must be 0 or 6");
+  if ((d->robust_between && !d->log_radius_between) || (d->robust_prior && !d->log_radius_prior))
+    return fail("robust cost without log_loss_radius");
+  if (d->robust_between < 0 || d->robust_between > 2 || d->robust_prior < 0 || d->robust_prior > 2) return fail("bad loss kind");
   return 0;
 }
 
@@ -410,7 +437,7 @@ using namespace thx;
 extern "C" {
 
 const char* thx_last_error(void) { return last_error().c_str(); }
-int thx_abi_version(void) { return 3; }
+int thx_abi_version(void) { return 4; }
 
 int thx_pg_assemble(const thx_pg_structure* s, const thx_pg_data* d, void* H, int64_t ld, void* g, int dtype,
                     const thx_lie_eps* eps, void* stream) {

@@ -10,8 +10,11 @@
 // d phi / d s_r is closed form; d phi / d Z_k (12 raw entries) uses dual numbers through inverse / compose / the
 // Jlog closed forms -- the derivative the reference's plain autograd takes -- while log(E)'s own derivative is
 // torchlie's passthrough backward (se3_impl.py:487-493): d log = Jlog [E_R^T dE_t ; vee(E_R^T dE_R)/2].
+// RobustCostFunction (robust_cost_function.py:115-135) multiplies the cost's part by m = rho'(x) + 1e-20,
+// x = sum_r (s_r log(E)_r)^2, which is NOT detached: d(m phi) = m d phi + phi (m_x dx + m_l d log_radius).
 #include "common.cuh"
 #include "dual.cuh"
+#include "robust.cuh"
 
 namespace thx {
 
@@ -30,7 +33,8 @@ __device__ __forceinline__ void load_se3_any(const T* __restrict__ p, SE3<double
 
 // grad of phi w.r.t. the 12 entries of Z (row major 3x4) and the 6 weights
 __device__ __forceinline__ void cost_vjp(const SE3<double>& Z, const SE3<double>& C, const double* q, const double* s,
-                                         const Eps<double>& eps, double* gZ, double* gs) {
+                                         const Eps<double>& eps, int loss, double log_radius, double* gZ, double* gs,
+                                         double* glr) {
   // value pass
   SE3<double> Zi, E;
   se3_inv(Z, Zi);
@@ -49,8 +53,19 @@ __device__ __forceinline__ void cost_vjp(const SE3<double>& Z, const SE3<double>
       a[3 + i] = t2[i];
     }
   }
+  // robust factor m(x, log_radius) and the plain phi
+  double m = 1.0, m_x = 0.0, m_l = 0.0, phi = 0.0;
 #pragma unroll
-  for (int r = 0; r < 6; ++r) gs[r] = -2.0 * s[r] * a[r] * xi[r];
+  for (int r = 0; r < 6; ++r) phi -= s[r] * s[r] * a[r] * xi[r];
+  if (loss != THX_LOSS_NONE) {
+    double x = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) x += (s[r] * xi[r]) * (s[r] * xi[r]);
+    rescale2_partials(loss, x, log_radius, m, m_x, m_l);
+  }
+  *glr = phi * m_l;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) gs[r] = m * (-2.0 * s[r] * a[r] * xi[r]) + phi * m_x * (2.0 * s[r] * xi[r] * xi[r]);
   const Eps<D2> epsd{D2(eps.nz), D2(eps.dnz), D2(eps.npi)};
   SE3<D2> Cd;
 #pragma unroll
@@ -105,17 +120,21 @@ __device__ __forceinline__ void cost_vjp(const SE3<double>& Z, const SE3<double>
       da[i] = top;
       da[3 + i] = bot;
     }
-    double g = 0.0;
+    double g = 0.0, dx = 0.0;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) g -= s[r] * s[r] * (da[r] * xi[r] + a[r] * dxi[r]);
-    gZ[k] = g;
+    for (int r = 0; r < 6; ++r) {
+      g -= s[r] * s[r] * (da[r] * xi[r] + a[r] * dxi[r]);
+      dx += 2.0 * s[r] * s[r] * xi[r] * dxi[r];
+    }
+    gZ[k] = m * g + phi * m_x * dx;
   }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(64)
 pg_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wvec, int64_t ldw, T* __restrict__ g_meas,
-              T* __restrict__ g_wb, T* __restrict__ g_tgt, T* __restrict__ g_wp, Eps<T> eps_t) {
+              T* __restrict__ g_wb, T* __restrict__ g_tgt, T* __restrict__ g_wp, T* __restrict__ g_lrb,
+              T* __restrict__ g_lrp, Eps<T> eps_t) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   const int c = blockIdx.y;
   const int B = d.batch;
@@ -123,10 +142,12 @@ pg_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wvec, int
   const Eps<double> eps{(double)eps_t.nz, (double)eps_t.dnz, (double)eps_t.npi};
   const T* poses = static_cast<const T*>(d.poses);
   const T* wv = wvec + (int64_t)b * ldw;
-  double q[6], sw[6], gZ[12], gs[6];
+  double q[6], sw[6], gZ[12], gs[6], glr = 0.0, lr = 0.0;
+  int loss = THX_LOSS_NONE;
   SE3<double> Z, C;
   T* outZ;
   T* outS;
+  T* outL = nullptr;
   if (c < s.num_edges) {
     const int e = c, i = s.edge_i[e], j = s.edge_j[e];
     const int64_t mB = d.meas_bstride ? B : 1, wB = d.w_between_bstride ? B : 1;
@@ -156,6 +177,11 @@ pg_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wvec, int
     }
     outZ = g_meas + ((int64_t)e * B + b) * 12;
     outS = g_wb + ((int64_t)e * B + b) * 6;
+    loss = d.robust_between;
+    if (loss) {
+      lr = load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride);
+      outL = g_lrb ? g_lrb + (int64_t)e * B + b : nullptr;
+    }
   } else {
     const int k = c - s.num_edges, p = s.prior_pose[k];
     const int64_t tB = d.prior_target_bstride ? B : 1, wB = d.w_prior_bstride ? B : 1;
@@ -169,8 +195,14 @@ pg_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wvec, int
     }
     outZ = g_tgt + ((int64_t)k * B + b) * 12;
     outS = g_wp + ((int64_t)k * B + b) * 6;
+    loss = d.robust_prior;
+    if (loss) {
+      lr = load_log_radius<T>(d.log_radius_prior, k, b, B, d.log_radius_prior_bstride);
+      outL = g_lrp ? g_lrp + (int64_t)k * B + b : nullptr;
+    }
   }
-  cost_vjp(Z, C, q, sw, eps, gZ, gs);
+  cost_vjp(Z, C, q, sw, eps, loss, lr, gZ, gs, &glr);
+  if (outL) *outL = (T)glr;
 #pragma unroll
   for (int k = 0; k < 12; ++k) outZ[k] = (T)gZ[k];
 #pragma unroll
@@ -218,21 +250,25 @@ using namespace thx;
 extern "C" {
 
 int thx_pg_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, int64_t ldw, void* grad_meas,
-               void* grad_w_between, void* grad_prior_target, void* grad_w_prior, int dtype, const thx_lie_eps* eps,
-               void* stream) {
+               void* grad_w_between, void* grad_prior_target, void* grad_w_prior, void* grad_log_radius_between,
+               void* grad_log_radius_prior, int dtype, const thx_lie_eps* eps, void* stream) {
   if (!s || !d || !w || !eps) return fail("thx_pg_vjp: null argument");
   if (s->num_edges > 0 && (!grad_meas || !grad_w_between)) return fail("thx_pg_vjp: null edge gradient buffer");
   if (s->num_priors > 0 && (!grad_prior_target || !grad_w_prior)) return fail("thx_pg_vjp: null prior gradient buffer");
   if (ldw < 6 * (int64_t)s->num_poses) return fail("thx_pg_vjp: ldw < n");
+  if ((d->robust_between && !d->log_radius_between) || (d->robust_prior && !d->log_radius_prior))
+    return fail("thx_pg_vjp: robust cost without log_loss_radius");
   dim3 grid((d->batch + 63) / 64, s->num_edges + s->num_priors), block(64);
   if (grid.y == 0) return 0;
   THX_DISPATCH(dtype,
                hipLaunchKernelGGL(pg_vjp_kernel<float>, grid, block, 0, as_stream(stream), *s, *d, (const float*)w, ldw,
                                   (float*)grad_meas, (float*)grad_w_between, (float*)grad_prior_target,
-                                  (float*)grad_w_prior, make_eps<float>(eps)),
+                                  (float*)grad_w_prior, (float*)grad_log_radius_between, (float*)grad_log_radius_prior,
+                                  make_eps<float>(eps)),
                hipLaunchKernelGGL(pg_vjp_kernel<double>, grid, block, 0, as_stream(stream), *s, *d, (const double*)w,
                                   ldw, (double*)grad_meas, (double*)grad_w_between, (double*)grad_prior_target,
-                                  (double*)grad_w_prior, make_eps<double>(eps)));
+                                  (double*)grad_w_prior, (double*)grad_log_radius_between,
+                                  (double*)grad_log_radius_prior, make_eps<double>(eps)));
   return check_launch("thx_pg_vjp");
 }
 

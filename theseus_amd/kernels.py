@@ -65,6 +65,11 @@ class PGTensors:
     w_between: torch.Tensor      # (E, Bw, 6)       SE2: (E, Bw, 3)
     prior_target: torch.Tensor   # (K, Bt, 3, 4)
     w_prior: torch.Tensor        # (K, Bw, 6)
+    # RobustCostFunction wrappers: loss kind (_lib.LOSS_*) per role and log_loss_radius (E|K, Br, 1)
+    robust_between: int = 0
+    log_radius_between: Optional[torch.Tensor] = None
+    robust_prior: int = 0
+    log_radius_prior: Optional[torch.Tensor] = None
 
     @property
     def batch(self):
@@ -93,6 +98,11 @@ class PGTensors:
         put("w_between", self.w_between, dof)
         put("prior_target", self.prior_target, gw)
         put("w_prior", self.w_prior, dof)
+        for role in ("between", "prior"):
+            kind = getattr(self, "robust_" + role)
+            setattr(d, "robust_" + role, int(kind))
+            if kind:
+                put("log_radius_" + role, getattr(self, "log_radius_" + role), 1)
         return d
 
 
@@ -269,13 +279,14 @@ class HipKernels:
                                                 _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(poses.device)),
                    "thx_se3_retract_vjp")
 
-    def pg_vjp(self, s: DeviceStructure, t: PGTensors, w, g_meas, g_wb, g_tgt, g_wp, poses=None):
+    def pg_vjp(self, s: DeviceStructure, t: PGTensors, w, g_meas, g_wb, g_tgt, g_wp, poses=None, g_lrb=None, g_lrp=None):
         if t.se2:
             raise NotImplementedError("implicit backward (thx_pg_vjp) is fused for SE3 pose graphs only")
         d = t.c_struct(poses)
         dt = w.dtype
         _lib.check(self.lib.thx_pg_vjp(s.c, d, _lib.ptr(w), w.stride(0), _lib.ptr(g_meas), _lib.ptr(g_wb),
-                                       _lib.ptr(g_tgt), _lib.ptr(g_wp), _lib.dtype_code(dt), lie_eps(dt),
+                                       _lib.ptr(g_tgt), _lib.ptr(g_wp), _lib.ptr(g_lrb), _lib.ptr(g_lrp),
+                                       _lib.dtype_code(dt), lie_eps(dt),
                                        _lib.stream_ptr(w.device)), "thx_pg_vjp")
 
     # ---- dense solver ---------------------------------------------------------------------------

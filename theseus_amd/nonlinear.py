@@ -308,7 +308,8 @@ class NonlinearLeastSquares(abc.ABC):
             packed.flush_variables()
             packed.sync(force=True)  # re-pack the auxiliary tensors WITH their autograd history
             t = packed.tensors
-            return ImplicitStep.apply(self, float(step), kwargs, t.meas, t.w_between, t.prior_target, t.w_prior)
+            return ImplicitStep.apply(self, float(step), kwargs, t.meas, t.w_between, t.prior_target, t.w_prior,
+                                      t.log_radius_between, t.log_radius_prior)
 
 
 class GaussNewton(NonlinearLeastSquares):

@@ -7,6 +7,7 @@ stacking tensors for batched ATen calls it keeps ONE entity-major buffer per rol
 the fused HIP kernels index directly.  Variables are tracked by ``_num_updates`` so that the
 buffers are re-packed only when somebody changed a variable behind our back.
 """
+import dataclasses
 from typing import List, Optional
 
 import torch
@@ -54,6 +55,22 @@ def _weight_diag(w, dof: int) -> torch.Tensor:
                                "There is no CPU/eager fallback.")
 
 
+_LOSS_KIND = {"WelschLoss": _lib.LOSS_WELSCH, "HuberLoss": _lib.LOSS_HUBER}
+
+
+def _unwrap_robust(c):
+    """cost -> (base cost, loss kind, log_loss_radius variable | None)  (theseus/core/robust_cost_function.py:52-85)."""
+    if "RobustCostFunction" not in {k.__name__ for k in type(c).__mro__}:
+        return c, _lib.LOSS_NONE, None
+    kind = _LOSS_KIND.get(type(c.loss).__name__)
+    if kind is None:
+        raise UnsupportedObjective(f"HIP backend fuses WelschLoss / HuberLoss; got {type(c.loss).__name__} ({c.name}). "
+                                   "There is no CPU/eager fallback.")
+    if c.flatten_dims:
+        raise UnsupportedObjective(f"HIP backend: RobustCostFunction(flatten_dims=True) is not fused ({c.name}).")
+    return c.cost_function, kind, c.log_loss_radius
+
+
 def _aux_vars(x):
     a = x.aux_vars
     return list(a() if callable(a) else a)
@@ -80,22 +97,32 @@ class PackedPoseGraph:
         self.edge_costs = []
         self.prior_costs = []
         row = 0
-        for c in objective.cost_functions.values():
-            if type(c).__name__ == "RobustCostFunction":
-                raise UnsupportedObjective("HIP backend: RobustCostFunction is not fused yet. No CPU/eager fallback.")
+        self.edge_radius, self.prior_radius = [], []   # log_loss_radius Variable per robust cost
+        kinds = {"Between": set(), "Difference": set()}
+        for wrapped in objective.cost_functions.values():
+            c, loss, radius = _unwrap_robust(wrapped)
             if _kind(c) == "Between":
                 edges.append((index[c.v0.name], index[c.v1.name]))
                 e_rows.append(row)
                 self.edge_costs.append(c)
+                self.edge_radius.append(radius)
+                kinds["Between"].add(loss)
             elif _kind(c) == "Difference":
                 priors.append(index[c.var.name])
                 p_rows.append(row)
                 self.prior_costs.append(c)
+                self.prior_radius.append(radius)
+                kinds["Difference"].add(loss)
             else:
                 raise UnsupportedObjective(
                     f"HIP backend has no fused kernel for cost function {type(c).__name__} ({c.name}); "
                     "supported: Between, Difference/Local on SE3 / SE2.  There is no CPU/eager fallback.")
             row += c.dim()
+        for role, ks in kinds.items():
+            if len(ks) > 1:
+                raise UnsupportedObjective(f"HIP backend: all {role} costs must share one robust loss kind (or none).")
+        self.robust_between = kinds["Between"].pop() if kinds["Between"] else _lib.LOSS_NONE
+        self.robust_prior = kinds["Difference"].pop() if kinds["Difference"] else _lib.LOSS_NONE
         self.structure = PoseGraphStructure.build(len(self.pose_vars), edges, priors, e_rows, p_rows, dof=self.dof)
         self.n = self.structure.num_cols
         self.m = self.structure.num_rows
@@ -119,6 +146,9 @@ class PackedPoseGraph:
         for c in self.prior_costs:
             yield c.target
             yield from _aux_vars(c.weight)
+        for r in self.edge_radius + self.prior_radius:
+            if r is not None:
+                yield r
 
     def _current_stamp(self):
         return tuple(v._num_updates for v in self._tracked())
@@ -154,7 +184,11 @@ class PackedPoseGraph:
         wb = self._stack([_weight_diag(c.weight, dof) for c in self.edge_costs], B) if E else empty(0, 1, dof)
         tgt = self._stack([c.target.tensor for c in self.prior_costs], B) if Kp else empty(0, 1, *gs)
         wp = self._stack([_weight_diag(c.weight, dof) for c in self.prior_costs], B) if Kp else empty(0, 1, dof)
-        self.tensors = PGTensors(poses=poses, meas=meas, w_between=wb, prior_target=tgt, w_prior=wp)
+        lrb = self._stack([r.tensor.view(-1, 1) for r in self.edge_radius], B) if self.robust_between else None
+        lrp = self._stack([r.tensor.view(-1, 1) for r in self.prior_radius], B) if self.robust_prior else None
+        self.tensors = PGTensors(poses=poses, meas=meas, w_between=wb, prior_target=tgt, w_prior=wp,
+                                 robust_between=self.robust_between, log_radius_between=lrb,
+                                 robust_prior=self.robust_prior, log_radius_prior=lrp)
         self._repoint_variables()
 
     def _repoint_variables(self):
@@ -222,8 +256,9 @@ class PackedPoseGraph:
         self.K.retract(self.tensors.poses, delta, step, m, out)
         return out
 
-    def jacobian_blocks(self):
-        """Weighted Jacobian blocks / residuals of every cost: (J0,J1 (E,B,d,d), eb (E,B,d), Jp, ep), d = dof."""
+    def jacobian_blocks(self, robust: bool = True):
+        """Weighted Jacobian blocks / residuals of every cost: (J0,J1 (E,B,d,d), eb (E,B,d), Jp, ep), d = dof;
+        robust costs rescaled as in ``weighted_jacobians_error`` unless ``robust=False``."""
         self.sync()
         B, E, Kp, d = self.batch, self.structure.num_edges, self.structure.num_priors, self.dof
         dt, dev = self.objective.dtype, self.tensors.poses.device
@@ -232,12 +267,28 @@ class PackedPoseGraph:
         eb = torch.empty(max(E, 1), B, d, dtype=dt, device=dev)
         Jp = torch.empty(max(Kp, 1), B, d, d, dtype=dt, device=dev)
         ep = torch.empty(max(Kp, 1), B, d, dtype=dt, device=dev)
-        self.K.pg_jacobians(self.dstruct, self.tensors, J0, J1, eb, Jp, ep)
+        t = self.tensors if robust else dataclasses.replace(self.tensors, robust_between=0, robust_prior=0)
+        self.K.pg_jacobians(self.dstruct, t, J0, J1, eb, Jp, ep)
         return J0[:E], J1[:E], eb[:E], Jp[:Kp], ep[:Kp]
 
     def error_vector(self):
         """(B, m) weighted error in cost add order (Objective.error, core/objective.py:562-613)."""
-        _, _, eb, _, ep = self.jacobian_blocks()
+        _, _, eb, _, ep = self.jacobian_blocks(robust=False)
+        t = self.tensors
+
+        def robust_error(e, kind, lr):
+            # robust_cost_function.py:87-106: ones * sqrt(rho(|e|^2) / dim + eps) -- elementwise torch on the device
+            # the errors live on (Objective.error() is not on the optimiser's path)
+            if not kind:
+                return e
+            x, r = (e ** 2).sum(-1, keepdim=True), lr.exp()
+            if kind == _lib.LOSS_WELSCH:
+                rho = r - r * torch.exp(-x / (r + 1e-20))
+            else:
+                rho = torch.where(x > r, 2 * torch.sqrt(r * torch.maximum(x, r) + 1e-20) - r, x)
+            return torch.ones_like(e) * (rho / e.shape[-1] + 1e-20).sqrt()
+        eb = robust_error(eb, t.robust_between, t.log_radius_between)
+        ep = robust_error(ep, t.robust_prior, t.log_radius_prior)
         B = self.batch
         out = torch.empty(B, self.m, dtype=eb.dtype, device=eb.device)
         s = self.structure

@@ -35,40 +35,29 @@ from theseus.optimizer.linear import CholeskyDenseSolver as _RefCholeskyDenseSol
 from theseus.optimizer.linear import LinearSolver as _RefLinearSolver
 
 from .generic import BlockAssembler
-from .kernels import PGTensors, default_kernels, round_up
+from .autograd import detached_tensors, pg_vjp_grads
+from .kernels import default_kernels, round_up
 from .linear_solver import HipCholeskyCore
 from .linearization import HipLinearizationCore
 from .packed import UnsupportedObjective
 
 
 class _FusedAtb(torch.autograd.Function):
-    """g = A^T b of an SE3 pose graph as a differentiable function of the packed auxiliary tensors: forward is
+    """g = A^T b of a pose graph as a differentiable function of the packed auxiliary tensors: forward is
     ``thx_pg_assemble`` (which also refreshes H), backward is ``thx_pg_vjp``."""
 
     @staticmethod
-    def forward(ctx, lin, meas, w_between, prior_target, w_prior):
+    def forward(ctx, lin, meas, w_between, prior_target, w_prior, lr_between, lr_prior):
         HipLinearizationCore._assemble(lin)
         t = lin.packed.tensors
         ctx.lin = lin
-        ctx.tensors = PGTensors(poses=t.poses.detach(), meas=meas.detach(), w_between=w_between.detach(),
-                                prior_target=prior_target.detach(), w_prior=w_prior.detach())
+        ctx.tensors = detached_tensors(t, t.poses, meas, w_between, prior_target, w_prior, lr_between, lr_prior)
         return lin.g.clone()
 
     @staticmethod
     def backward(ctx, grad_g):
-        lin, t = ctx.lin, ctx.tensors
-        packed = lin.packed
-        B = t.poses.shape[1]
-        E, Kp = packed.structure.num_edges, packed.structure.num_priors
-        new = lambda *s: torch.empty(*s, dtype=grad_g.dtype, device=grad_g.device)  # noqa: E731
-        g_meas, g_wb = new(max(E, 1), B, 3, 4), new(max(E, 1), B, 6)
-        g_tgt, g_wp = new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 6)
-        lin.K.pg_vjp(packed.dstruct, t, grad_g.contiguous(), g_meas, g_wb, g_tgt, g_wp)
-
-        def fit(g, count, like):
-            g = g[:count]
-            return g.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else g
-        return None, fit(g_meas, E, t.meas), fit(g_wb, E, t.w_between), fit(g_tgt, Kp, t.prior_target), fit(g_wp, Kp, t.w_prior)
+        lin = ctx.lin
+        return (None,) + pg_vjp_grads(lin.K, lin.packed, ctx.tensors, grad_g.contiguous())
 
 
 class _CachedFactorSolve(torch.autograd.Function):
@@ -196,7 +185,8 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
             if graph:
                 packed.sync(force=True)  # re-pack WITH the autograd history of the auxiliary variables
                 t = packed.tensors
-                self._g_graph = _FusedAtb.apply(self, t.meas, t.w_between, t.prior_target, t.w_prior)
+                self._g_graph = _FusedAtb.apply(self, t.meas, t.w_between, t.prior_target, t.w_prior, t.log_radius_between,
+                                                t.log_radius_prior)
             else:
                 self._g_graph = None
                 self._assemble()
