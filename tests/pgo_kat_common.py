@@ -19,7 +19,7 @@ def batch_slices(g):
 
 def pose_loss(poses, gt):
     """pose_graph_synthetic.py:58-72: sum over poses and problems of |log(pose^-1 gt)|; poses/gt (B,P,3,4).
-    torch ops (autograd follows torchlie's conventions, oracle/lie.py); runs on whatever device the tensors are."""
+    torch ops on CPU tensors (autograd follows torchlie's conventions, oracle/lie.py)."""
     a, b = poses.reshape(-1, 3, 4), gt.reshape(-1, 3, 4)
     xi, _ = lie.se3_log_jlog_autograd(lie.se3_compose(lie.se3_inverse(a), b))
     return xi.norm(dim=1).sum()
@@ -38,7 +38,7 @@ def outer_loop(g, inner_solve):
             ref = pose_loss(t(g["poses0"][sl]), gt)
         final = inner_solve(sl, param.clone())
         opt.zero_grad()
-        loss = (pose_loss(final, gt.to(final.device)).cpu() - ref) / ref
+        loss = (pose_loss(final.cpu(), gt) - ref) / ref  # the outer loss is the caller's (torch, CPU); .cpu() is differentiable
         loss.backward()
         opt.step()
         losses.append(loss.item())
