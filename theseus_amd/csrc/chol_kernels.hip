@@ -1020,6 +1020,11 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   float* sB = smem + 128 * 36;
   float* Pc = smem + OFF32_STAGE_FLOATS;
 
+#ifdef THX_OFF_PROF  // timing build (tools/prof/off_prof.py): cycle stamps overwrite the head of the output tile
+  long long st[6];
+  st[0] = (long long)__builtin_readcyclecounter();
+  const long long wc0 = (long long)wall_clock64();
+#endif
   // ---- prefetch: panel sub-blocks (s,t), t <= s, then the H tile ----
   // (a "lean" variant without any prefetch -- 40 KB LDS, 168 VGPRs, three workgroups per CU -- measured 1-2 % SLOWER:
   //  the K-loop's 82 % MFMA-busy is not an occupancy problem)
@@ -1051,7 +1056,17 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
 
   Engine<float>::Acc P;
   Engine<float>::zero(P);
+#ifdef THX_OFF_PROF
+  st[1] = (long long)__builtin_readcyclecounter();
+#endif
+  // (two LDS staging buffers with ONE barrier per k-chunk instead of one buffer with two -- panel copy moved behind the
+  //  loop to keep 2 workgroups/CU -- measured the same 9.3-9.4 k cycles per chunk: the barriers are not the K-loop's limit)
   kloop<float, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, col0, sA, sB, P, tid);
+#ifdef THX_OFF_PROF
+  __builtin_amdgcn_sched_barrier(0);
+  st[2] = (long long)__builtin_readcyclecounter();
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   // P = H_ij - sum (rows outside the matrix: zero)
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb)
@@ -1074,6 +1089,11 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
     });
     sub_mma_sw<sb, sb>(Pc, P, X, lane);    // X_s  = W_ss P_s
   });
+#ifdef THX_OFF_PROF
+  __builtin_amdgcn_sched_barrier(0);
+  st[3] = (long long)__builtin_readcyclecounter();
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   if (rvalid) {
     float* Lrow = L + mat + (int64_t)(row0 + r) * ld + col0 + 4 * g;
 #pragma unroll
@@ -1083,6 +1103,16 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
         *reinterpret_cast<float4*>(Lrow + 32 * cb + 8 * q) =
             make_float4(X.v[cb][4 * q], X.v[cb][4 * q + 1], X.v[cb][4 * q + 2], X.v[cb][4 * q + 3]);
   }
+#ifdef THX_OFF_PROF
+  __builtin_amdgcn_s_waitcnt(0);
+  st[4] = (long long)__builtin_readcyclecounter();
+  __syncthreads();
+  if (tid == 0) {
+    float* o = L + mat + (int64_t)row0 * ld + col0;
+    for (int k = 1; k < 5; ++k) o[k] = (float)(st[k] - st[0]);
+    o[5] = (float)((long long)wall_clock64() - wc0);  // 100 MHz ticks
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
