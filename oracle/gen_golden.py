@@ -376,6 +376,109 @@ def gen_pgo_kat(th):
         losses_published=np.array(PGO_KAT_LOSSES), losses_reference_here=np.array(losses))
 
 
+def gen_ba(th):
+    """Small bundle adjustment problems (examples/bundle_adjustment.py:103-160 shape: robust Huber Reprojection costs,
+    Difference regularisers on every camera and point, strong priors on a few cameras) solved by the reference's
+    LevenbergMarquardt + DenseLinearization + CholeskyDenseSolver; geometry from the reference's generator, batch items =
+    independent perturbations of the initial cameras / points and of the feature noise."""
+    import theseus.utils.examples as theg
+    cases = [("ba_f64_lm", torch.float64, 4, dict(max_iterations=8, step_size=1.0), dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True), "huber"),
+             ("ba_f64_gn", torch.float64, 3, dict(max_iterations=6, step_size=0.5), None, None),
+             ("ba_f32_lm", torch.float32, 4, dict(max_iterations=6, step_size=1.0), dict(damping=1e-2), "welsch")]
+    for name, dtype, B, ok, lmk, robust in cases:
+        torch.manual_seed(3)
+        np.random.seed(3)
+        ba = theg.BundleAdjustmentDataset.generate_synthetic(num_cameras=6, num_points=40, average_track_length=4,
+                                                             track_locality=0.3, feat_random=1.5, outlier_feat_random=70)
+        gen = torch.Generator().manual_seed(17)
+        C, Np, O = len(ba.cameras), len(ba.points), len(ba.observations)
+        lieF = __import__("torchlie.functional", fromlist=["SE3"])
+        rnd = lambda *s: 2 * torch.rand(*s, dtype=torch.float64, generator=gen) - 1  # noqa: E731
+        cams0 = torch.stack([c.pose.tensor[0] for c in ba.cameras]).unsqueeze(0).repeat(B, 1, 1, 1)
+        pert = lieF.SE3.exp(torch.cat([0.3 * rnd(B * C, 3), 0.01 * rnd(B * C, 3)], 1)).view(B, C, 3, 4)
+        cams0 = lieF.SE3.compose(cams0.reshape(-1, 3, 4), pert.reshape(-1, 3, 4)).view(B, C, 3, 4).to(dtype)
+        pts0 = (torch.stack([p_.tensor[0] for p_ in ba.points]).unsqueeze(0) + 0.2 * rnd(B, Np, 3)).to(dtype)
+        feat = (torch.stack([o.image_feature_point.tensor[0] for o in ba.observations]).unsqueeze(0) + 0.5 * rnd(B, O, 2)).to(dtype)
+        focal = torch.stack([c.focal_length.tensor[0] for c in ba.cameras]).unsqueeze(0).to(dtype)       # (1,C,1)
+        k1 = torch.stack([c.calib_k1.tensor[0] for c in ba.cameras]).unsqueeze(0).to(dtype)
+        k2 = torch.stack([c.calib_k2.tensor[0] for c in ba.cameras]).unsqueeze(0).to(dtype)
+        gt_c = torch.stack([c.pose.tensor[0] for c in ba.gt_cameras]).unsqueeze(0).to(dtype)
+        obs_cam = np.array([o.camera_index for o in ba.observations], dtype=np.int64)
+        obs_pt = np.array([int(o.point_index) for o in ba.observations], dtype=np.int64)
+        obj = th.Objective(dtype=dtype)
+        cam_v = [th.SE3(tensor=cams0[:, i].clone(), name=f"Cam{i}") for i in range(C)]
+        pt_v = [th.Point3(tensor=pts0[:, i].clone(), name=f"Pt{i}") for i in range(Np)]
+        fl = [th.Vector(tensor=focal[:, i].clone(), name=f"fl{i}") for i in range(C)]
+        k1v = [th.Vector(tensor=k1[:, i].clone(), name=f"k1_{i}") for i in range(C)]
+        k2v = [th.Vector(tensor=k2[:, i].clone(), name=f"k2_{i}") for i in range(C)]
+        w = th.ScaleCostWeight(torch.tensor(1.0, dtype=dtype))
+        log_radius = th.Vector(tensor=torch.tensor([[1.5]], dtype=dtype), name="log_loss_radius")
+        for o in range(O):
+            cf = th.eb.Reprojection(camera_pose=cam_v[obs_cam[o]], world_point=pt_v[obs_pt[o]], focal_length=fl[obs_cam[o]],
+                                    calib_k1=k1v[obs_cam[o]], calib_k2=k2v[obs_cam[o]],
+                                    image_feature_point=th.Point2(tensor=feat[:, o].clone(), name=f"Feat{o}"), weight=w,
+                                    name=f"reproj_{o}")
+            if robust:
+                cf = th.RobustCostFunction(cf, th.HuberLoss if robust == "huber" else th.WelschLoss, log_radius, name=f"robust_{o}")
+            obj.add(cf)
+        reg_w = float(np.sqrt(1e-4))
+        dw = th.ScaleCostWeight(reg_w * torch.ones(1, dtype=dtype))
+        zero_pt, ident = th.Point3(dtype=dtype, name="zero_point"), th.SE3(dtype=dtype, name="zero_se3")
+        var_order, cost_order = [], [("obs", o) for o in range(O)]
+        cam_prior_idx, pt_prior_idx = [], []
+        for vname, var in obj.optim_vars.items():
+            kind, idx = ("cam", int(vname[3:])) if vname.startswith("Cam") else ("pt", int(vname[2:]))
+            var_order.append((kind, idx))
+            if kind == "cam":
+                obj.add(th.Difference(var, ident, dw, name=f"reg_{vname}"))
+                cost_order.append(("cam_prior", len(cam_prior_idx)))
+                cam_prior_idx.append(idx)
+            else:
+                obj.add(th.Difference(var, zero_pt, dw, name=f"reg_{vname}"))
+                cost_order.append(("pt_prior", len(pt_prior_idx)))
+                pt_prior_idx.append(idx)
+        n_reg_cam = len(cam_prior_idx)
+        cw = th.ScaleCostWeight(100 * torch.ones(1, dtype=dtype))
+        for i in (0, C - 1):
+            obj.add(th.Difference(cam_v[i], th.SE3(tensor=gt_c[:, i].clone(), name=f"gt_cam{i}"), cw, name=f"camera_diff_{i}"))
+            cost_order.append(("cam_prior", len(cam_prior_idx)))
+            cam_prior_idx.append(i)
+        obj.update()
+        cls = th.LevenbergMarquardt if lmk is not None else th.GaussNewton
+        opt = cls(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, abs_err_tolerance=0.0, rel_err_tolerance=0.0, **ok)
+        taps = dict(delta=[], AtA=[], Atb=[])
+
+        def cb(optimizer, info, delta, it):
+            lin_ = optimizer.linear_solver.linearization
+            taps["delta"].append(delta.clone().numpy())
+            if it == 0:
+                taps["AtA"].append(lin_.AtA.clone().numpy())
+                taps["Atb"].append(lin_.Atb.clone().numpy())
+        lin = opt.linear_solver.linearization
+        lin.linearize()
+        A0, b0 = lin.A.clone().numpy(), lin.b.clone().numpy()
+        err0 = obj.error_metric().clone().numpy()
+        with torch.no_grad():
+            info = opt.optimize(track_err_history=True, end_iter_callback=cb, **(lmk or {}))
+        Kc = len(cam_prior_idx)
+        cam_prior_target = torch.cat([torch.eye(3, 4, dtype=dtype).view(1, 1, 3, 4).repeat(1, n_reg_cam, 1, 1), gt_c[:, [0, C - 1]]], 1)
+        w_cam_prior = torch.cat([torch.full((1, n_reg_cam, 6), reg_w, dtype=dtype), torch.full((1, 2, 6), 100.0, dtype=dtype)], 1)
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"), C=C, Np=Np, obs_cam=obs_cam, obs_pt=obs_pt, feat=feat.numpy(), focal=focal.numpy(),
+            k1=k1.numpy(), k2=k2.numpy(), cams0=cams0.numpy(), pts0=pts0.numpy(),
+            cam_prior_idx=np.array(cam_prior_idx, dtype=np.int64), cam_prior_target=cam_prior_target.numpy(), w_cam_prior=w_cam_prior.numpy(),
+            pt_prior_idx=np.array(pt_prior_idx, dtype=np.int64), w_pt_prior=np.full((1, len(pt_prior_idx), 3), reg_w, dtype=feat.numpy().dtype),
+            var_kind=np.array([0 if k == "cam" else 1 for k, _ in var_order]), var_idx=np.array([i for _, i in var_order]),
+            cost_kind=np.array([{"obs": 0, "cam_prior": 1, "pt_prior": 2}[k] for k, _ in cost_order]), cost_idx=np.array([i for _, i in cost_order]),
+            robust=np.array(robust or ""), log_radius=np.float64(1.5), A0=A0, b0=b0, err0=err0, AtA=np.stack(taps["AtA"]),
+            Atb=np.stack(taps["Atb"]), delta=np.stack(taps["delta"]), err_history=info.err_history.numpy(),
+            final_cams=torch.stack([v.tensor for v in cam_v], 1).numpy(), final_pts=torch.stack([v.tensor for v in pt_v], 1).numpy(),
+            var_start_cols=np.array(lin.var_start_cols), num_rows=lin.num_rows, num_cols=lin.num_cols,
+            opt_kwargs=np.array(repr(dict(ok, **(lmk or {}), gauss_newton=lmk is None))))
+        print(name, "err", info.err_history[:, 0].numpy(), "->", info.err_history[:, -1].numpy(), "unobserved points:",
+              Np - len(pt_prior_idx))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     th, lieF = import_reference()
@@ -390,6 +493,8 @@ def main():
         gen_se2(th)
     if not only or "pgo_kat" in only:
         gen_pgo_kat(th)
+    if not only or "ba" in only:
+        gen_ba(th)
     print("wrote", sorted(os.listdir(OUT)))
 
 

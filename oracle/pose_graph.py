@@ -269,6 +269,18 @@ def check_convergence(err, last_err, abs_tol, rel_tol):
     return (change.abs() < abs_tol) | ((change / last_err).abs() < rel_tol)
 
 
+def _ops(p):
+    """(dense_linearize, error_metric, retract, keep_where) of a problem: module functions for pose graphs, the
+    problem's own methods for other problem kinds (oracle/ba.py: state = (cameras, points))."""
+    if hasattr(p, "oracle_ops"):
+        return p.oracle_ops()
+
+    def keep_where(mask, old, new):
+        return torch.where(mask.view([old.shape[0]] + [1] * (old.ndim - 1)), old, new)
+    return (lambda x: dense_linearize(p, x), lambda x: error_metric(p, x),
+            lambda x, d, m: retract(x, d, ignore_mask=m), keep_where)
+
+
 def lm_optimize(p: PGProblem, poses, max_iterations=20, step_size=1.0, damping=1e-3,
                 adaptive_damping=False, ellipsoidal_damping=False, damping_eps=1e-8,
                 abs_err_tolerance=1e-10, rel_err_tolerance=1e-8,
@@ -279,17 +291,19 @@ def lm_optimize(p: PGProblem, poses, max_iterations=20, step_size=1.0, damping=1
     nonlinear_least_squares.py:100-215 (loop), :338-365 (_step), levenberg_marquardt.py:114-201,
     SURVEY Appendix B.  Returns (final poses, LMInfo).
     """
-    B = poses.shape[0]
-    dtype = poses.dtype
+    _linearize, _error, _retract, _keep = _ops(p)
+    first = poses[0] if isinstance(poses, (tuple, list)) else poses
+    B = first.shape[0]
+    dtype = first.dtype
     info = LMInfo()
     lam = damping * torch.ones(B, dtype=dtype) if adaptive_damping else damping
-    last_err = error_metric(p, poses)
+    last_err = _error(poses)
     info.err_history.append(last_err.clone())
     converged = torch.zeros(B, dtype=torch.bool)
     info.converged_iter = torch.full((B,), -1, dtype=torch.long)
     it, all_reject_attempts = 0, 0
     while it < max_iterations:
-        A, b = dense_linearize(p, poses)
+        A, b = _linearize(poses)
         AtA, Atb = hessian(A, b)
         if gauss_newton:
             delta = solve(AtA, Atb)
@@ -301,8 +315,8 @@ def lm_optimize(p: PGProblem, poses, max_iterations=20, step_size=1.0, damping=1
             info.deltas.append(delta)
             info.dampings.append(torch.as_tensor(lam).clone())
         d = delta * step_size
-        new_poses = retract(poses, d, ignore_mask=converged)
-        err = error_metric(p, new_poses)
+        new_poses = _retract(poses, d, converged)
+        err = _error(new_poses)
         reject = None
         if adaptive_damping and not gauss_newton:
             dmp = lam.view(-1, 1)
@@ -324,9 +338,9 @@ def lm_optimize(p: PGProblem, poses, max_iterations=20, step_size=1.0, damping=1
             err = last_err
         else:
             if reject is not None:
-                poses = torch.where(reject.view([B] + [1] * (poses.ndim - 1)), poses, new_poses)
+                poses = _keep(reject, poses, new_poses)
                 if bool(reject.any()):
-                    err = error_metric(p, poses)
+                    err = _error(poses)
             else:
                 poses = new_poses
         all_reject_attempts = 0

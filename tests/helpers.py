@@ -49,3 +49,27 @@ class f32_thresholds:
     def __exit__(self, *a):
         for m, saved in self._saved:
             m.EPS[torch.float64] = saved
+
+
+def ba_problem(g):
+    """Bundle-adjustment fixture -> (oracle BAProblem, (cams0, pts0), optimizer kwargs).  Points that no observation
+    touches are not optimisation variables of the reference objective: they are dropped and the rest re-indexed."""
+    from oracle import ba as oba
+    t = torch.from_numpy
+    kinds, idxs = g["var_kind"].tolist(), g["var_idx"].tolist()
+    used = sorted(i for k, i in zip(kinds, idxs) if k == 1)
+    remap = {old: new for new, old in enumerate(used)}
+    var_order = [("cam", i) if k == 0 else ("pt", remap[i]) for k, i in zip(kinds, idxs)]
+    cost_order = [(("obs", "cam_prior", "pt_prior")[k], int(i)) for k, i in zip(g["cost_kind"].tolist(), g["cost_idx"].tolist())]
+    dtype = t(g["cams0"]).dtype
+    robust = str(g["robust"]) or None
+    p = oba.BAProblem(
+        num_cams=int(g["C"]), num_points=len(used), obs_cam=t(g["obs_cam"]), obs_pt=torch.tensor([remap[i] for i in g["obs_pt"].tolist()]),
+        feat=t(g["feat"]), w_obs=torch.ones(1, g["obs_cam"].shape[0], 2, dtype=dtype), focal=t(g["focal"]), k1=t(g["k1"]), k2=t(g["k2"]),
+        cam_prior_idx=t(g["cam_prior_idx"]), cam_prior_target=t(g["cam_prior_target"]), w_cam_prior=t(g["w_cam_prior"]),
+        pt_prior_idx=torch.tensor([remap[i] for i in g["pt_prior_idx"].tolist()]),
+        pt_prior_target=torch.zeros(1, g["pt_prior_idx"].shape[0], 3, dtype=dtype), w_pt_prior=t(g["w_pt_prior"]),
+        var_order=var_order, cost_order=cost_order, robust_obs=robust,
+        log_radius_obs=torch.full((1, 1, 1), float(g["log_radius"]), dtype=dtype) if robust else None)
+    kw = ast.literal_eval(str(g["opt_kwargs"]))
+    return p, (t(g["cams0"]), t(g["pts0"])[:, used]), kw, used

@@ -151,3 +151,29 @@ def test_reference_pgo_known_answer_test():
     losses = outer_loop(g, inner)
     for got, want in zip(losses, g["losses_published"]):
         assert got == pytest.approx(want, rel=1e-10, abs=1e-10), (losses, g["losses_published"])
+
+
+@pytest.mark.parametrize("name,tol", [("ba_f64_lm", 1e-7), ("ba_f64_gn", 1e-7), ("ba_f32_lm", 5e-3)])
+def test_bundle_adjustment_matches_reference(name, tol):
+    """oracle/ba.py (Reprojection + robust loss + SE3 / Point3 Difference priors, mixed variable ordering) against the
+    reference's DenseLinearization + CholeskyDenseSolver run (oracle/gen_golden.py:gen_ba)."""
+    from tests.helpers import ba_problem
+    g = load_golden(name)
+    p, state0, kw, used = ba_problem(g)
+    f32 = tol > 1e-6
+    assert p.n == int(g["num_cols"]) and p.m == int(g["num_rows"])
+    assert [p.col_starts()[v] for v in p.var_order] == list(g["var_start_cols"])
+    A, b = p.dense_linearize(state0)
+    np.testing.assert_allclose(A.numpy(), g["A0"], rtol=0, atol=np.abs(g["A0"]).max() * (2e-5 if f32 else 1e-12))
+    np.testing.assert_allclose(b.numpy(), g["b0"], rtol=0, atol=np.abs(g["b0"]).max() * (2e-5 if f32 else 1e-12))
+    AtA, Atb = opg.hessian(A, b)
+    np.testing.assert_allclose(AtA.numpy(), g["AtA"][0], rtol=0, atol=np.abs(g["AtA"][0]).max() * (2e-5 if f32 else 1e-12))
+    np.testing.assert_allclose(p.error_metric(state0).numpy(), g["err0"], rtol=2e-5 if f32 else 1e-12)
+    (cams, pts), info = opg.lm_optimize(p, state0, abs_err_tolerance=0.0, rel_err_tolerance=0.0, keep_taps=True, **kw)
+    np.testing.assert_allclose(cams.numpy(), g["final_cams"], rtol=0, atol=tol * 10)
+    np.testing.assert_allclose(pts.numpy(), g["final_pts"][:, used], rtol=0, atol=tol * 100)
+    hist = torch.stack(info.err_history, 1).numpy()
+    k = min(hist.shape[1], g["err_history"].shape[1])
+    np.testing.assert_allclose(hist[:, :k], g["err_history"][:, :k], rtol=5e-3 if f32 else 1e-6)
+    if len(info.deltas) == g["delta"].shape[0]:
+        np.testing.assert_allclose(info.deltas[0].numpy(), g["delta"][0], rtol=0, atol=(1e-2 if f32 else 1e-7) * max(1.0, np.abs(g["delta"][0]).max()))

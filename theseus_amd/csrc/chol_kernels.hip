@@ -112,6 +112,23 @@ struct Engine<float> {
   }
   static __device__ __forceinline__ void chunk(const float* sA, const float* sBw, Acc& acc, int lane) {
     const int rl = lane & 31, g = lane >> 5;
+#ifdef THX_CHUNK_INTERLEAVE
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float4 fb = *reinterpret_cast<const float4*>(sBw + rl * 36 + 8 * ks + 4 * g);
+      float4 fa[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) fa[cb] = *reinterpret_cast<const float4*>(sA + (32 * cb + rl) * 36 + 8 * ks + 4 * g);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb].x, fb.x, acc.v[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb].y, fb.y, acc.v[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb].z, fb.z, acc.v[cb], 0, 0, 0);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb].w, fb.w, acc.v[cb], 0, 0, 0);
+    }
+#else
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const float4 fb = *reinterpret_cast<const float4*>(sBw + rl * 36 + 8 * ks + 4 * g);
@@ -124,6 +141,7 @@ struct Engine<float> {
         acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc.v[cb], 0, 0, 0);
       }
     }
+#endif
   }
   // ---- native-layout helpers: lane (rl = lane&31, g = lane>>5) of wave w holds tile row 32w + rl,
   //      register rho of block cb <-> tile column 32cb + 8(rho>>2) + 4g + (rho&3)
