@@ -231,6 +231,85 @@ int thx_pg_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, i
                void* grad_w_between, void* grad_prior_target, void* grad_w_prior, void* grad_log_radius_between,
                void* grad_log_radius_prior, int dtype, const thx_lie_eps* eps, void* stream);
 
+/* ---- Bundle adjustment (BASELINE.json configs[3]; examples/bundle_adjustment.py:103-160): camera poses SE3 + Point3
+ *      world points, costs = Reprojection (theseus/embodied/measurements/reprojection.py:54-94, dim 2; SE3.transform_from
+ *      + Jacobians: torchlie/functional/se3_impl.py:757-777) optionally wrapped in RobustCostFunction, Difference priors on
+ *      cameras (local_cost_fn.py:39-61) and on points (vector.py:150-178: e = x - target, J = I).
+ *      The damped normal equations (H + D) delta = g of DenseLinearization + CholeskyDenseSolver are solved EXACTLY by
+ *      block elimination of the points:  H = [[Hcc, Hcp],[Hpc, Hpp]] (Hcc, Hpp block diagonal 6x6 / 3x3),
+ *        S = Hcc' - Hcp Hpp'^-1 Hpc,  rhs = gc - Hcp Hpp'^-1 gp,  S delta_c = rhs  (thx_chol_factor_forward, no damping),
+ *        delta_p = Hpp'^-1 (gp - Hpc delta_c);   ' = damping applied (dense_solver.py:38-64).
+ *      Internal column order: cameras (6 each) then points (3 each); g / delta / diag are (B, n), n = 6C + 3Np.
+ *      Layouts (entity major, batch fastest): cams (C,B,3,4), points (Np,B,3), Hcc (C,B,6,6), Hpp (Np,B,6) =
+ *      [xx,xy,xz,yy,yz,zz], W (O,B,6,3) = Jc^T Jp per observation, Hinv (Np,B,6), tvec (B,3Np). */
+typedef struct {
+  int32_t num_cams, num_points, num_obs, num_cam_priors, num_pt_priors, num_pairs;
+  const int32_t* obs_cam;       /* (O) */
+  const int32_t* obs_pt;        /* (O) */
+  const int32_t* pt_ptr;        /* (Np+1) CSR: observations of a point */
+  const int32_t* pt_obs;        /* (O)    */
+  const int32_t* cam_ptr;       /* (C+1)  CSR: observations of a camera */
+  const int32_t* cam_obs;       /* (O)    */
+  const int32_t* cam_prior_cam; /* (Kc) camera of prior k */
+  const int32_t* cam_prior_ptr; /* (C+1)  CSR: priors of a camera */
+  const int32_t* cam_prior_id;  /* (Kc)   */
+  const int32_t* pt_prior_pt;   /* (Kp) */
+  const int32_t* pt_prior_ptr;  /* (Np+1) */
+  const int32_t* pt_prior_id;   /* (Kp)   */
+  const int32_t* pair_ptr;      /* (C+1)  Schur pairs of camera c1: (o1, o2) share a point, cam(o1) = c1, cam(o2) <= c1, */
+  const int32_t* pair_o1;       /* (Npairs)  sorted by cam(o2)                                                           */
+  const int32_t* pair_o2;
+  const int32_t* pair_c2;
+} thx_ba_structure;
+
+typedef struct {
+  int32_t batch;
+  const void* cams;    /* (C, B, 3, 4) */
+  const void* points;  /* (Np, B, 3)   */
+  const void* feat;    /* (O, Bf, 2) image_feature_point */
+  int64_t feat_bstride;   /* 2 or 0 */
+  const void* w_obs;   /* (O, Bw, 2) sqrt-information diagonal of the Reprojection cost weight */
+  int64_t w_obs_bstride;
+  const void* focal;   /* (C, Bc, 1) focal_length, calib_k1, calib_k2 of the camera */
+  const void* k1;
+  const void* k2;
+  int64_t calib_bstride;  /* 1 or 0 (shared by the three) */
+  int32_t robust_obs;  /* THX_LOSS_* on the Reprojection costs */
+  const void* log_radius_obs;  /* (O, Br, 1) */
+  int64_t log_radius_obs_bstride;
+  const void* cam_prior_target;  /* (Kc, Bt, 3, 4) */
+  int64_t cam_prior_target_bstride;
+  const void* w_cam_prior;       /* (Kc, Bw, 6) */
+  int64_t w_cam_prior_bstride;
+  const void* pt_prior_target;   /* (Kp, Bt, 3) */
+  int64_t pt_prior_target_bstride;
+  const void* w_pt_prior;        /* (Kp, Bw, 3) */
+  int64_t w_pt_prior_bstride;
+} thx_ba_data;
+
+/* linearize: Hcc, Hpp, W, g = [gc | gp] (row stride ldv), diag = diag(H) (row stride ldv) */
+int thx_ba_assemble(const thx_ba_structure* s, const thx_ba_data* d, void* Hcc, void* Hpp, void* W, void* g, void* diag,
+                    int64_t ldv, int dtype, const thx_lie_eps* eps, void* stream);
+/* Schur complement with the damping of DenseSolver._apply_damping: writes the lower blocks of S (B, ld, ld) (zero-filled
+ * once by the caller: fixed pattern), rhs (B, 6C) (row stride ldr), Hinv, tvec; info[b] != 0 if a damped point block is
+ * not positive definite. */
+int thx_ba_schur(const thx_ba_structure* s, int32_t B, const void* Hcc, const void* Hpp, const void* W, const void* g,
+                 int64_t ldv, const void* damping, int ellipsoidal, double damping_eps, void* S, int64_t ld, void* rhs,
+                 int64_t ldr, void* Hinv, void* tvec, int32_t* info, int dtype, void* stream);
+/* delta_p = tvec - Hinv Hpc delta_c, written to delta[:, 6C:] (delta_c = delta[:, :6C] is read) */
+int thx_ba_backsub(const thx_ba_structure* s, int32_t B, const void* W, const void* Hinv, const void* tvec, void* delta,
+                   int64_t ldv, int dtype, void* stream);
+int thx_ba_error(const thx_ba_structure* s, const thx_ba_data* d, void* partials, void* err, int dtype,
+                 const thx_lie_eps* eps, void* stream);
+/* Vector retraction x <- x + step * delta (theseus/geometry/vector.py:177-178), masked like thx_se3_retract; x (N,B,dof),
+ * delta (B, ldd) read at columns [col0, col0 + N*dof) */
+int thx_vec_retract(const void* x, const void* delta, int64_t ldd, int64_t col0, double step, const uint8_t* ignore_mask,
+                    void* out, int32_t N, int32_t dof, int32_t B, int dtype, void* stream);
+/* thx_lm_accept with diag(H) given as a (B, n) vector (row stride ldv) instead of the dense H */
+int thx_lm_accept_diag(const void* delta, const void* g, const void* diag, int64_t ldv, int32_t n, int32_t B, void* damping,
+                       const void* prev_err, const void* new_err, int ellipsoidal, double accept, double down_ratio,
+                       double up_ratio, uint8_t* reject, int dtype, void* stream);
+
 /* ---- Linearization.diagonal_scaling support: d[b, i] = H[b, i, i] (linearization.py:85-87). */
 int thx_diag(const void* H, int64_t ld, int32_t n, int32_t B, void* d, int64_t ldv, int dtype, void* stream);
 

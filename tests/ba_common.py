@@ -1,0 +1,85 @@
+"""Bundle-adjustment fixtures (tests/golden/ba_*.npz, oracle/gen_golden.py:gen_ba) -> theseus_amd objective, built in the
+reference's order so that the reference column layout (insertion order) can be recovered for comparisons."""
+import numpy as np
+import torch
+
+from tests.helpers import ba_problem
+
+
+def build_ba_objective(th, g, device="cpu"):
+    t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
+    dtype = torch.from_numpy(g["cams0"]).dtype
+    C, Np, O = int(g["C"]), int(g["Np"]), g["obs_cam"].shape[0]
+    cams0, pts0, feat = t(g["cams0"]), t(g["pts0"]), t(g["feat"])
+    obj = th.Objective(dtype=dtype)
+    cam_v = [th.SE3(tensor=cams0[:, i].clone(), name=f"Cam{i}") for i in range(C)]
+    pt_v = [th.Point3(tensor=pts0[:, i].clone(), name=f"Pt{i}") for i in range(Np)]
+    fl = [th.Vector(tensor=t(g["focal"])[:, i].clone(), name=f"fl{i}") for i in range(C)]
+    k1 = [th.Vector(tensor=t(g["k1"])[:, i].clone(), name=f"k1_{i}") for i in range(C)]
+    k2 = [th.Vector(tensor=t(g["k2"])[:, i].clone(), name=f"k2_{i}") for i in range(C)]
+    w = th.ScaleCostWeight(torch.tensor(1.0, dtype=dtype, device=device))
+    robust = str(g["robust"])
+    radius = th.Vector(tensor=torch.tensor([[float(g["log_radius"])]], dtype=dtype, device=device), name="log_loss_radius")
+    for o in range(O):
+        c, p = int(g["obs_cam"][o]), int(g["obs_pt"][o])
+        cf = th.Reprojection(camera_pose=cam_v[c], world_point=pt_v[p], focal_length=fl[c], calib_k1=k1[c], calib_k2=k2[c],
+                             image_feature_point=th.Point2(tensor=feat[:, o].clone(), name=f"Feat{o}"), weight=w, name=f"reproj_{o}")
+        if robust:
+            cf = th.RobustCostFunction(cf, th.HuberLoss if robust == "huber" else th.WelschLoss, radius, name=f"robust_{o}")
+        obj.add(cf)
+    # priors in the fixture's cost order (regularisers interleaved by variable insertion order, then the strong camera priors)
+    tgt_c, w_c = t(g["cam_prior_target"]), t(g["w_cam_prior"])
+    w_p = t(g["w_pt_prior"])
+    zero_pt = th.Point3(tensor=torch.zeros(1, 3, dtype=dtype, device=device), name="zero_point")
+    seen = {}
+    for kind, k in zip(g["cost_kind"].tolist(), g["cost_idx"].tolist()):
+        if kind == 1:
+            i = int(g["cam_prior_idx"][k])
+            key = tgt_c[:, k].cpu().numpy().tobytes()
+            target = seen.setdefault(key, th.SE3(tensor=tgt_c[:, k].clone(), name=f"cam_target_{k}"))
+            obj.add(th.Difference(cam_v[i], target, th.ScaleCostWeight(w_c[:, k, :1].clone()), name=f"cam_prior_{k}"))
+        elif kind == 2:
+            i = int(g["pt_prior_idx"][k])
+            obj.add(th.Difference(pt_v[i], zero_pt, th.ScaleCostWeight(w_p[:, k, :1].clone()), name=f"pt_prior_{k}"))
+    return obj, cam_v, pt_v
+
+
+def reference_columns(g):
+    """Index vector ``cols`` with delta_reference[:, j] = delta_internal[:, cols[j]] (internal order: cameras, then the
+    objective's points in insertion order = order of first appearance in the fixture's variable list)."""
+    kinds, idxs = g["var_kind"].tolist(), g["var_idx"].tolist()
+    C = int(g["C"])
+    pts_in_order = [i for k, i in zip(kinds, idxs) if k == 1]
+    # theseus_amd's objective registers variables in the same insertion order as the reference's, so the internal point
+    # order is the order in which points first appear among the observations
+    seen, order = set(), []
+    for p in g["obs_pt"].tolist():
+        if p not in seen:
+            seen.add(p)
+            order.append(p)
+    pos = {p: k for k, p in enumerate(order)}
+    cols = []
+    for k, i in zip(kinds, idxs):
+        cols += list(range(6 * i, 6 * i + 6)) if k == 0 else [6 * C + 3 * pos[i] + a for a in range(3)]
+    assert sorted(pts_in_order) == sorted(order)
+    return np.array(cols), order
+
+
+def run_ba(th, g, kernels=None, device="cpu"):
+    from tests.helpers import ba_problem  # noqa: F401
+    obj, cam_v, pt_v = build_ba_objective(th, g, device)
+    import ast
+    kw = ast.literal_eval(str(g["opt_kwargs"]))
+    gn = kw.pop("gauss_newton")
+    okw = dict(max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    if kernels is not None:
+        okw["linearization_kwargs"] = dict(kernels=kernels)
+    opt = (th.GaussNewton if gn else th.LevenbergMarquardt)(obj, **okw)
+    assert type(opt.linear_solver).__name__ == "HipSchurSolver"
+    deltas = []
+    sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(
+        track_err_history=True, end_iter_callback=lambda o, i, d, it: deltas.append(d.clone()), **kw))
+    cams = torch.stack([sol[f"Cam{i}"] for i in range(int(g["C"]))], 1)
+    used = sorted(set(g["obs_pt"].tolist()))
+    pts = torch.stack([sol[f"Pt{i}"] for i in used], 1)
+    return cams, pts, used, deltas, info, opt

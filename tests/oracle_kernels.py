@@ -74,7 +74,7 @@ class OracleKernels:
     def se3_retract(self, poses, delta, step, ignore_mask, out):
         x = poses.transpose(0, 1)
         m = ignore_mask.bool() if ignore_mask is not None else None
-        out.copy_(opg.retract(x, delta * step, ignore_mask=m).transpose(0, 1))
+        out.copy_(opg.retract(x, delta[:, :6 * poses.shape[0]] * step, ignore_mask=m).transpose(0, 1))
 
     def retract(self, poses, delta, step, ignore_mask, out):
         if poses.dim() == 4:
@@ -104,6 +104,113 @@ class OracleKernels:
     def se2_adjoint(self, X):
         from oracle import lie_se2
         return lie_se2.se2_adjoint(X)
+
+    # ---- bundle adjustment: block quantities from the oracle's per-cost terms (oracle/ba.py) ------------------
+    @staticmethod
+    def _ba_problem(s, t, cams=None, points=None):
+        from oracle import ba as oba
+        h = s.host
+        bm = lambda x: x.transpose(0, 1)  # noqa: E731
+        lg = lambda a: torch.from_numpy(h.t[a].astype("int64"))  # noqa: E731
+        p = oba.BAProblem(
+            num_cams=h.num_cams, num_points=h.num_points, obs_cam=lg("obs_cam")[:h.num_obs], obs_pt=lg("obs_pt")[:h.num_obs],
+            feat=bm(t.feat), w_obs=bm(t.w_obs), focal=bm(t.focal), k1=bm(t.k1), k2=bm(t.k2),
+            cam_prior_idx=lg("cam_prior_cam")[:h.num_cam_priors], cam_prior_target=bm(t.cam_prior_target),
+            w_cam_prior=bm(t.w_cam_prior), pt_prior_idx=lg("pt_prior_pt")[:h.num_pt_priors],
+            pt_prior_target=bm(t.pt_prior_target), w_pt_prior=bm(t.w_pt_prior), var_order=[], cost_order=[],
+            robust_obs=LOSS[t.robust_obs], log_radius_obs=bm(t.log_radius_obs) if t.robust_obs else None)
+        return p, (bm(t.cams if cams is None else cams), bm(t.points if points is None else points))
+
+    def ba_assemble(self, s, t, Hcc, Hpp, W, g, diag):
+        p, state = self._ba_problem(s, t)
+        Jc, Jp, e, _, Jcp, ecp, ept = p.terms(state)
+        B, C, Np = state[0].shape[0], p.num_cams, p.num_points
+        hcc = torch.zeros(B, C, 6, 6, dtype=g.dtype).index_add_(1, p.obs_cam, Jc.transpose(2, 3) @ Jc)
+        hcc.index_add_(1, p.cam_prior_idx, (Jcp.transpose(2, 3) @ Jcp).expand(B, -1, 6, 6))
+        hpp = torch.zeros(B, Np, 3, 3, dtype=g.dtype).index_add_(1, p.obs_pt, Jp.transpose(2, 3) @ Jp)
+        hpp.index_add_(1, p.pt_prior_idx, torch.diag_embed(p.w_pt_prior ** 2).expand(B, -1, 3, 3))
+        gc = torch.zeros(B, C, 6, dtype=g.dtype).index_add_(1, p.obs_cam, -(Jc.transpose(2, 3) @ e.unsqueeze(3)).squeeze(3))
+        gc.index_add_(1, p.cam_prior_idx, -(Jcp.transpose(2, 3) @ ecp.unsqueeze(3)).squeeze(3).expand(B, -1, 6))
+        gp = torch.zeros(B, Np, 3, dtype=g.dtype).index_add_(1, p.obs_pt, -(Jp.transpose(2, 3) @ e.unsqueeze(3)).squeeze(3))
+        gp.index_add_(1, p.pt_prior_idx, -(p.w_pt_prior * ept).expand(B, -1, 3))
+        Hcc.copy_(hcc.transpose(0, 1))
+        iu = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+        Hpp.copy_(torch.stack([hpp[:, :, i, j] for i, j in iu], -1).transpose(0, 1))
+        if p.obs_cam.numel():
+            W[:p.obs_cam.numel()].copy_((Jc.transpose(2, 3) @ Jp).transpose(0, 1))
+        g[:, :6 * C] = gc.reshape(B, -1)
+        g[:, 6 * C:] = gp.reshape(B, -1)
+        diag[:, :6 * C] = hcc.diagonal(dim1=2, dim2=3).reshape(B, -1)
+        diag[:, 6 * C:] = hpp.diagonal(dim1=2, dim2=3).reshape(B, -1)
+
+    @staticmethod
+    def _sym3(h):  # (..., 6) -> (..., 3, 3)
+        return torch.stack([torch.stack([h[..., 0], h[..., 1], h[..., 2]], -1), torch.stack([h[..., 1], h[..., 3], h[..., 4]], -1),
+                            torch.stack([h[..., 2], h[..., 4], h[..., 5]], -1)], -2)
+
+    def ba_schur(self, s, Hcc, Hpp, W, g, damping, ellipsoidal, damping_eps, S, rhs, Hinv, tvec, info):
+        h = s.host
+        C, Np, O = h.num_cams, h.num_points, h.num_obs
+        B = g.shape[0]
+        oc, op = (torch.from_numpy(h.t[k].astype("int64"))[:O] for k in ("obs_cam", "obs_pt"))
+        hcc, hpp = Hcc.transpose(0, 1).clone(), self._sym3(Hpp.transpose(0, 1))
+        if damping is not None:
+            lam = damping.view(B, 1, 1)
+            dc, dp = hcc.diagonal(dim1=2, dim2=3), hpp.diagonal(dim1=2, dim2=3)
+            hcc = hcc + torch.diag_embed(lam * dc + damping_eps if ellipsoidal else lam.expand_as(dc))
+            hpp = hpp + torch.diag_embed(lam * dp + damping_eps if ellipsoidal else lam.expand_as(dp))
+        _, inf = torch.linalg.cholesky_ex(hpp)
+        info.copy_((inf != 0).any(1).to(info.dtype))
+        hi = torch.linalg.inv(hpp)
+        Hinv.copy_(torch.stack([hi[..., 0, 0], hi[..., 0, 1], hi[..., 0, 2], hi[..., 1, 1], hi[..., 1, 2], hi[..., 2, 2]], -1).transpose(0, 1))
+        gp = g[:, 6 * C:].reshape(B, Np, 3)
+        tv = (hi @ gp.unsqueeze(3)).squeeze(3)
+        tvec.copy_(tv.reshape(B, -1))
+        Wb = W[:O].transpose(0, 1)                                        # (B,O,6,3)
+        Hcp = torch.zeros(B, 6 * C, 3 * Np, dtype=g.dtype)
+        for o in range(O):
+            c, p_ = int(oc[o]), int(op[o])
+            Hcp[:, 6 * c:6 * c + 6, 3 * p_:3 * p_ + 3] += Wb[:, o]
+        HccD = torch.zeros(B, 6 * C, 6 * C, dtype=g.dtype)
+        HpiD = torch.zeros(B, 3 * Np, 3 * Np, dtype=g.dtype)
+        for c in range(C):
+            HccD[:, 6 * c:6 * c + 6, 6 * c:6 * c + 6] = hcc[:, c]
+        for p_ in range(Np):
+            HpiD[:, 3 * p_:3 * p_ + 3, 3 * p_:3 * p_ + 3] = hi[:, p_]
+        Sfull = HccD - Hcp @ HpiD @ Hcp.transpose(1, 2)
+        S[:, :6 * C, :6 * C] = torch.tril(Sfull)
+        rhs.copy_(g[:, :6 * C] - (Hcp @ tv.reshape(B, -1, 1)).squeeze(2))
+
+    def ba_backsub(self, s, W, Hinv, tvec, delta):
+        h = s.host
+        C, Np, O = h.num_cams, h.num_points, h.num_obs
+        B = delta.shape[0]
+        oc, op = (torch.from_numpy(h.t[k].astype("int64"))[:O] for k in ("obs_cam", "obs_pt"))
+        dc = delta[:, :6 * C].reshape(B, C, 6)
+        acc = torch.zeros(B, Np, 3, dtype=delta.dtype).index_add_(
+            1, op, (W[:O].transpose(0, 1).transpose(2, 3) @ dc[:, oc].unsqueeze(3)).squeeze(3))
+        hi = self._sym3(Hinv.transpose(0, 1))
+        delta[:, 6 * C:] = (tvec.reshape(B, Np, 3) - (hi @ acc.unsqueeze(3)).squeeze(3)).reshape(B, -1)
+
+    def ba_error(self, s, t, partials, err, cams=None, points=None):
+        p, state = self._ba_problem(s, t, cams, points)
+        err.copy_(p.error_metric(state))
+
+    def vec_retract(self, x, delta, col0, step, ignore_mask, out):
+        N, B, dof = x.shape
+        new = x + (delta[:, col0:col0 + N * dof] * step).reshape(B, N, dof).transpose(0, 1)
+        if ignore_mask is not None:
+            new = torch.where(ignore_mask.bool().view(1, B, 1), x, new)
+        out.copy_(new)
+
+    def lm_accept_diag(self, delta, g, diag, n, damping, prev_err, new_err, ellipsoidal, accept, down, up, reject):
+        dmp = damping.view(-1, 1)
+        if ellipsoidal:
+            dmp = diag[:, :n] * dmp
+        den = (delta * (dmp * delta + g)).sum(1) / 2
+        rej = (prev_err - new_err) / den <= accept
+        damping.copy_(torch.where(rej, damping * up, damping / down).clamp(1e-7, 1e7))
+        reject.copy_(rej.to(reject.dtype))
 
     # ---- generic block assembly: dense A scatter + A^T A, as DenseLinearization does ----
     def block_assemble(self, asm, jacobians, errors, H, g):

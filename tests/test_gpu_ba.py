@@ -1,0 +1,94 @@
+"""-m gpu: bundle adjustment on the HIP kernels (csrc/ba_kernels.hip + the dense Cholesky on the Schur complement) against
+the reference's DenseLinearization + CholeskyDenseSolver runs (tests/golden/ba_*.npz) and the oracle (oracle/ba.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pose_graph as opg
+from tests.ba_common import build_ba_objective, reference_columns, run_ba
+from tests.helpers import ba_problem, f32_thresholds, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["ba_f64_lm", "ba_f64_gn", "ba_f32_lm"])
+def test_ba_first_linear_system_matches_reference(name):
+    """thx_ba_assemble + thx_ba_schur + Cholesky + thx_ba_backsub = the delta the reference's dense solve produced at the
+    first iteration; g, diag(H) and the error metric against the reference's A^T b, diag(A^T A), error."""
+    import theseus_amd as th
+    g = load_golden(name)
+    f32 = name.startswith("ba_f32")
+    obj, _, _ = build_ba_objective(th, g, "cuda")
+    opt = th.LevenbergMarquardt(obj, max_iterations=1)
+    solver, lin = opt.linear_solver, opt.linear_solver.linearization
+    obj.update()
+    lin.linearize()
+    cols, _ = reference_columns(g)
+    Atb, AtA = g["Atb"][0][..., 0], g["AtA"][0]
+    tol = 3e-5 if f32 else 1e-11
+    np.testing.assert_allclose(lin.g.cpu().numpy()[:, cols], Atb, rtol=0, atol=tol * np.abs(Atb).max())
+    dref = np.diagonal(AtA, axis1=1, axis2=2)
+    np.testing.assert_allclose(lin.diag.cpu().numpy()[:, cols], dref, rtol=tol * 10, atol=tol * np.abs(dref).max())
+    np.testing.assert_allclose(obj.error_metric().cpu().numpy(), g["err0"], rtol=3e-5 if f32 else 1e-12)
+    import ast
+    kw = ast.literal_eval(str(g["opt_kwargs"]))
+    if kw["gauss_newton"]:
+        delta = solver.solve()
+    else:
+        B = Atb.shape[0]
+        lam = torch.full((B,), kw["damping"], dtype=lin.g.dtype, device="cuda")
+        delta = solver.solve(damping=lam, ellipsoidal_damping=kw.get("ellipsoidal_damping", False), damping_eps=1e-8)
+    want = g["delta"][0]
+    np.testing.assert_allclose(delta.cpu().numpy()[:, cols], want, rtol=0, atol=(2e-3 if f32 else 1e-8) * max(1.0, np.abs(want).max()))
+
+
+@pytest.mark.parametrize("name,tol_c,tol_p", [("ba_f64_lm", 1e-6, 1e-5), ("ba_f64_gn", 1e-6, 1e-5)])
+def test_ba_trajectory_matches_reference(name, tol_c, tol_p):
+    import theseus_amd as th
+    g = load_golden(name)
+    cams, pts, used, deltas, info, _ = run_ba(th, g, None, "cuda")
+    np.testing.assert_allclose(cams.cpu().numpy(), g["final_cams"], rtol=0, atol=tol_c)
+    np.testing.assert_allclose(pts.cpu().numpy(), g["final_pts"][:, used], rtol=0, atol=tol_p)
+    k = min(info.err_history.shape[1], g["err_history"].shape[1])
+    np.testing.assert_allclose(info.err_history[:, :k].numpy(), g["err_history"][:, :k], rtol=1e-6)
+    assert all(s == th.NonlinearOptimizerStatus.MAX_ITERATIONS for s in info.status)
+
+
+def test_ba_fp32_inside_reference_band():
+    """fp32: the HIP trajectory is no farther from the exact trajectory of the same fp32 problem (fp64 oracle, fp32
+    thresholds) than the reference's own fp32 run."""
+    import dataclasses
+    import theseus_amd as th
+    g = load_golden("ba_f32_lm")
+    p, (c0, p0), kw, used = ba_problem(g)
+    d = lambda x: None if x is None else x.double()  # noqa: E731
+    p64 = dataclasses.replace(p, **{f.name: d(getattr(p, f.name)) for f in dataclasses.fields(p)
+                                    if isinstance(getattr(p, f.name), torch.Tensor) and getattr(p, f.name).is_floating_point()})
+    with f32_thresholds():
+        (xc, xp), xinfo = opg.lm_optimize(p64, (c0.double(), p0.double()), abs_err_tolerance=0.0, rel_err_tolerance=0.0, **kw)
+    cams, pts, used2, _, info, _ = run_ba(th, g, None, "cuda")
+    assert used2 == used
+    dev_c = (cams.cpu().double() - xc).abs().max().item()
+    ref_c = (torch.from_numpy(g["final_cams"]).double() - xc).abs().max().item()
+    dev_p = (pts.cpu().double() - xp).abs().max().item()
+    ref_p = (torch.from_numpy(g["final_pts"][:, used]).double() - xp).abs().max().item()
+    assert dev_c <= 1.5 * ref_c + 1e-5 and dev_p <= 1.5 * ref_p + 1e-4, (dev_c, ref_c, dev_p, ref_p)
+    hx = torch.stack(xinfo.err_history, 1)
+    rel = ((info.err_history.double() - hx).abs() / hx).max().item()
+    rel_ref = ((torch.from_numpy(g["err_history"]).double() - hx).abs() / hx).max().item()
+    assert rel <= 1.5 * rel_ref + 1e-5, (rel, rel_ref)
+
+
+def test_ba_non_positive_definite_sets_fail_status():
+    import warnings
+    import theseus_amd as th
+    g = dict(load_golden("ba_f64_gn"))
+    g["w_cam_prior"] = g["w_cam_prior"] * 0.0
+    g["w_pt_prior"] = g["w_pt_prior"] * 0.0
+    g["feat"] = g["feat"] * 0.0   # keeps shapes; the gauge freedom makes the undamped system singular
+    obj, _, _ = build_ba_objective(th, g, "cuda")
+    opt = th.GaussNewton(obj, max_iterations=2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        info = opt.optimize()
+    assert all(s in (th.NonlinearOptimizerStatus.FAIL, th.NonlinearOptimizerStatus.MAX_ITERATIONS) for s in info.status)

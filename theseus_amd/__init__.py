@@ -4,7 +4,8 @@ Host-side mirror of the reference's modelling + optimizer API for the SE3 / SE2 
 hand-written HIP kernels behind a C ABI (include/theseus_hip.h, theseus_amd/csrc).  No CPU fallback.
 """
 from .core import (Between, CostFunction, CostWeight, DiagonalCostWeight, Difference, HuberLoss, Local,  # noqa: F401
-                   Objective, RobustCostFunction, RobustLoss, ScaleCostWeight, SE2, SE3, Variable, Vector, WelschLoss)
+                   Objective, Point2, Point3, Reprojection, RobustCostFunction, RobustLoss, ScaleCostWeight, SE2, SE3,
+                   Variable, Vector, WelschLoss)
 from .kernels import HipKernels, default_kernels, set_lie_eps, set_se2_eps  # noqa: F401
 from .layer import TheseusLayer  # noqa: F401
 from .linear_solver import HipCholeskySolver, LinearSolver  # noqa: F401
@@ -12,6 +13,7 @@ from .linearization import HipLinearization, Linearization, VariableOrdering  # 
 from .nonlinear import (BackwardMode, GaussNewton, LevenbergMarquardt, NonlinearLeastSquares,  # noqa: F401
                         NonlinearOptimizerInfo, NonlinearOptimizerStatus)
 from .packed import PackedPoseGraph, UnsupportedObjective  # noqa: F401
+from .ba import HipSchurLinearization, HipSchurSolver, PackedBA  # noqa: F401
 
 # names a reference user would reach for on this path
 CholeskyDenseSolver = HipCholeskySolver

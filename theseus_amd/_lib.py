@@ -18,11 +18,31 @@ LIB_PATH = os.environ.get("THESEUS_HIP_LIB") or os.path.join(_HERE, "lib", "libt
 THX_TILE = 128
 THX_ERR_CHUNKS = 16
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class LieEps(Structure):
     _fields_ = [("near_zero", c_double), ("d_near_zero", c_double), ("near_pi", c_double)]
+
+
+class BAStructure(Structure):  # thx_ba_structure: int32 device tables of a bundle-adjustment objective
+    _fields_ = [(k, c_int32) for k in ("num_cams", "num_points", "num_obs", "num_cam_priors", "num_pt_priors", "num_pairs")] + [
+        (k, c_void_p) for k in ("obs_cam", "obs_pt", "pt_ptr", "pt_obs", "cam_ptr", "cam_obs", "cam_prior_cam",
+                                "cam_prior_ptr", "cam_prior_id", "pt_prior_pt", "pt_prior_ptr", "pt_prior_id",
+                                "pair_ptr", "pair_o1", "pair_o2", "pair_c2")]
+
+
+class BAData(Structure):  # thx_ba_data
+    _fields_ = [
+        ("batch", c_int32), ("cams", c_void_p), ("points", c_void_p),
+        ("feat", c_void_p), ("feat_bstride", c_int64), ("w_obs", c_void_p), ("w_obs_bstride", c_int64),
+        ("focal", c_void_p), ("k1", c_void_p), ("k2", c_void_p), ("calib_bstride", c_int64),
+        ("robust_obs", c_int32), ("log_radius_obs", c_void_p), ("log_radius_obs_bstride", c_int64),
+        ("cam_prior_target", c_void_p), ("cam_prior_target_bstride", c_int64),
+        ("w_cam_prior", c_void_p), ("w_cam_prior_bstride", c_int64),
+        ("pt_prior_target", c_void_p), ("pt_prior_target_bstride", c_int64),
+        ("w_pt_prior", c_void_p), ("w_pt_prior_bstride", c_int64),
+    ]
 
 
 class SE2Eps(Structure):  # thx_se2_eps (theseus/global_params.py:46-59)
@@ -74,6 +94,16 @@ _SIGNATURES = {
     "thx_se2_retract": [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p, c_int32, c_int32, c_int,
                         POINTER(SE2Eps), c_void_p],
     "thx_se2_op": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(SE2Eps), c_void_p],
+    "thx_ba_assemble": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                        POINTER(LieEps), c_void_p],
+    "thx_ba_schur": [POINTER(BAStructure), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_double,
+                     c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "thx_ba_backsub": [POINTER(BAStructure), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    "thx_ba_error": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
+    "thx_vec_retract": [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int,
+                        c_void_p],
+    "thx_lm_accept_diag": [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int,
+                           c_double, c_double, c_double, c_void_p, c_int, c_void_p],
     "thx_chol_factor": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,
                         c_void_p, c_int, c_void_p],
     "thx_chol_factor_forward": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,

@@ -1,0 +1,502 @@
+"""Bundle adjustment on the HIP back end (BASELINE.json configs[3]; examples/bundle_adjustment.py:103-160).
+
+Objectives whose optimisation variables are camera poses (SE3) and world points (Point3), with Reprojection costs
+(optionally wrapped in RobustCostFunction) and Difference priors on cameras / points.  The damped normal equations the
+reference forms with DenseLinearization + CholeskyDenseSolver (dense n x n, n = 6C + 3Np: 27648^2 at configs[3]) are solved
+EXACTLY by eliminating the points: fused block assembly (thx_ba_assemble), Schur complement on the camera block
+(thx_ba_schur), the tiled dense Cholesky of the (6C)^2 reduced system (thx_chol_factor_forward / thx_chol_solve_backward),
+back substitution (thx_ba_backsub).  Column order of this linearization: cameras, then points, each in objective order --
+a ``VariableOrdering`` like any user-supplied one (theseus/optimizer/linearization.py:18-41).
+"""
+import dataclasses
+from typing import Any, Dict, List, Optional, Type, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .core import Objective, Variable
+from .kernels import default_kernels, round_up
+from .linear_solver import LinearSolver
+from .linearization import Linearization, VariableOrdering
+from .packed import UnsupportedObjective, _aux_vars, _kind, _unwrap_robust, _weight_diag
+
+ERR_CHUNKS = _lib.THX_ERR_CHUNKS
+
+
+def _csr(owner: np.ndarray, n: int, secondary: Optional[np.ndarray] = None):
+    """ids grouped by owner (stable / sorted by ``secondary``) -> (ptr (n+1), ids)."""
+    ids = np.arange(owner.shape[0])
+    order = np.lexsort((ids, secondary, owner)) if secondary is not None else np.argsort(owner, kind="stable")
+    ptr = np.zeros(n + 1, np.int64)
+    np.add.at(ptr, owner + 1, 1)
+    return np.cumsum(ptr), ids[order]
+
+
+class BAStructure:
+    """Immutable topology of a bundle-adjustment objective + the index tables of the kernels (host, numpy)."""
+
+    def __init__(self, num_cams: int, num_points: int, obs_cam, obs_pt, cam_prior_cam, pt_prior_pt):
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+        self.num_cams, self.num_points = int(num_cams), int(num_points)
+        oc, op = np.asarray(obs_cam, np.int64).reshape(-1), np.asarray(obs_pt, np.int64).reshape(-1)
+        cpc, ppp = np.asarray(cam_prior_cam, np.int64).reshape(-1), np.asarray(pt_prior_pt, np.int64).reshape(-1)
+        if oc.size and (oc.min() < 0 or oc.max() >= num_cams or op.min() < 0 or op.max() >= num_points):
+            raise ValueError("observation index out of range")
+        self.num_obs, self.num_cam_priors, self.num_pt_priors = oc.size, cpc.size, ppp.size
+        pt_ptr, pt_obs = _csr(op, num_points, oc)
+        cam_ptr, cam_obs = _csr(oc, num_cams, op)
+        cpp, cpi = _csr(cpc, num_cams)
+        ppptr, ppi = _csr(ppp, num_points)
+        # Schur pairs: (o1, o2) observe the same point and cam(o2) <= cam(o1); grouped by cam(o1), sorted by cam(o2)
+        o1s, o2s = [], []
+        for p in range(num_points):
+            obs = pt_obs[pt_ptr[p]:pt_ptr[p + 1]]
+            if obs.size:
+                a, b = np.meshgrid(obs, obs, indexing="ij")
+                keep = oc[b] <= oc[a]
+                o1s.append(a[keep])
+                o2s.append(b[keep])
+        o1 = np.concatenate(o1s) if o1s else np.zeros(0, np.int64)
+        o2 = np.concatenate(o2s) if o2s else np.zeros(0, np.int64)
+        order = np.lexsort((o2, o1, oc[o2], oc[o1]))
+        o1, o2 = o1[order], o2[order]
+        pair_ptr = np.zeros(num_cams + 1, np.int64)
+        np.add.at(pair_ptr, oc[o1] + 1, 1)
+        self.num_pairs = o1.size
+        self.t = dict(obs_cam=i32(oc), obs_pt=i32(op), pt_ptr=i32(pt_ptr), pt_obs=i32(pt_obs), cam_ptr=i32(cam_ptr),
+                      cam_obs=i32(cam_obs), cam_prior_cam=i32(cpc), cam_prior_ptr=i32(cpp), cam_prior_id=i32(cpi),
+                      pt_prior_pt=i32(ppp), pt_prior_ptr=i32(ppptr), pt_prior_id=i32(ppi), pair_ptr=i32(np.cumsum(pair_ptr)),
+                      pair_o1=i32(o1), pair_o2=i32(o2), pair_c2=i32(oc[o2]))
+        self._dev: Dict[str, "DeviceBA"] = {}
+
+    @property
+    def n(self) -> int:
+        return 6 * self.num_cams + 3 * self.num_points
+
+    def on(self, device) -> "DeviceBA":
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = DeviceBA(self, device)
+        return self._dev[key]
+
+
+class DeviceBA:
+    def __init__(self, s: BAStructure, device):
+        self.host = s
+        self.t = {k: torch.from_numpy((v if v.size else np.zeros(1, np.int32)).copy()).to(device) for k, v in s.t.items()}
+        c = _lib.BAStructure()
+        for k in ("num_cams", "num_points", "num_obs", "num_cam_priors", "num_pt_priors", "num_pairs"):
+            setattr(c, k, getattr(s, k))
+        for k, v in self.t.items():
+            setattr(c, k, v.data_ptr())
+        self.c = c
+
+
+@dataclasses.dataclass
+class BATensors:
+    cams: torch.Tensor              # (C, B, 3, 4)
+    points: torch.Tensor            # (Np, B, 3)
+    feat: torch.Tensor              # (O, 1|B, 2)
+    w_obs: torch.Tensor             # (O, 1|B, 2)
+    focal: torch.Tensor             # (C, 1|B, 1)
+    k1: torch.Tensor
+    k2: torch.Tensor
+    cam_prior_target: torch.Tensor  # (Kc, 1|B, 3, 4)
+    w_cam_prior: torch.Tensor       # (Kc, 1|B, 6)
+    pt_prior_target: torch.Tensor   # (Kp, 1|B, 3)
+    w_pt_prior: torch.Tensor        # (Kp, 1|B, 3)
+    robust_obs: int = 0
+    log_radius_obs: Optional[torch.Tensor] = None   # (O, 1|B, 1)
+
+    @property
+    def batch(self):
+        return self.cams.shape[1]
+
+    def c_struct(self, cams=None, points=None) -> _lib.BAData:
+        cams = self.cams if cams is None else cams
+        points = self.points if points is None else points
+        B = cams.shape[1]
+        d = _lib.BAData()
+        d.batch = B
+        d.cams, d.points = _lib.ptr(cams, "cams").value, _lib.ptr(points, "points").value
+
+        def put(name, t, width, stride_name=None):
+            nb = t.shape[1]
+            if nb not in (1, B):
+                raise ValueError(f"{name}: batch dimension {nb} is neither 1 nor {B}")
+            setattr(d, name, _lib.ptr(t, name).value if t.numel() else None)
+            setattr(d, stride_name or name + "_bstride", width if nb == B else 0)
+        put("feat", self.feat, 2)
+        put("w_obs", self.w_obs, 2)
+        if len({self.focal.shape[1], self.k1.shape[1], self.k2.shape[1]}) != 1:
+            raise ValueError("focal_length / calib_k1 / calib_k2 must share their batch size")
+        for name in ("focal", "k1", "k2"):
+            put(name, getattr(self, name), 1, "calib_bstride")
+        d.robust_obs = int(self.robust_obs)
+        if self.robust_obs:
+            put("log_radius_obs", self.log_radius_obs, 1)
+        put("cam_prior_target", self.cam_prior_target, 12)
+        put("w_cam_prior", self.w_cam_prior, 6)
+        put("pt_prior_target", self.pt_prior_target, 3)
+        put("w_pt_prior", self.w_pt_prior, 3)
+        return d
+
+
+class PackedBA:
+    """Packed device representation of a bundle-adjustment objective (the PackedPoseGraph of this problem class)."""
+
+    group = "BA"
+
+    def __init__(self, objective: Objective, kernels=None):
+        self.objective = objective
+        self.K = kernels or default_kernels()
+        self.cam_vars, self.pt_vars = [], []
+        for v in objective.optim_vars.values():
+            k = _kind(v)
+            if k == "SE3":
+                self.cam_vars.append(v)
+            elif "Point3" in {c.__name__ for c in type(v).__mro__}:
+                self.pt_vars.append(v)
+            else:
+                raise UnsupportedObjective(f"HIP bundle adjustment optimises SE3 cameras and Point3 points; got "
+                                           f"{type(v).__name__} ({v.name}).  There is no CPU/eager fallback.")
+        if not self.cam_vars or not self.pt_vars:
+            raise UnsupportedObjective("HIP bundle adjustment needs at least one SE3 camera and one Point3 point.")
+        ci = {v.name: k for k, v in enumerate(self.cam_vars)}
+        pi = {v.name: k for k, v in enumerate(self.pt_vars)}
+        self.obs_costs, self.obs_radius, self.cam_prior_costs, self.pt_prior_costs = [], [], [], []
+        obs_cam, obs_pt, cpc, ppp, kinds = [], [], [], [], set()
+        for wrapped in objective.cost_functions.values():
+            c, loss, radius = _unwrap_robust(wrapped)
+            names = {k.__name__ for k in type(c).__mro__}
+            if "Reprojection" in names:
+                obs_cam.append(ci[c.camera_pose.name])
+                obs_pt.append(pi[c.world_point.name])
+                self.obs_costs.append(c)
+                self.obs_radius.append(radius)
+                kinds.add(loss)
+            elif _kind(c) == "Difference" and not loss:
+                if c.var.name in ci:
+                    cpc.append(ci[c.var.name])
+                    self.cam_prior_costs.append(c)
+                else:
+                    ppp.append(pi[c.var.name])
+                    self.pt_prior_costs.append(c)
+            else:
+                raise UnsupportedObjective(f"HIP bundle adjustment has no fused kernel for {type(wrapped).__name__} "
+                                           f"({wrapped.name}); supported: Reprojection (optionally robust), Difference.")
+        if len(kinds) > 1:
+            raise UnsupportedObjective("HIP bundle adjustment: all Reprojection costs must share one robust loss kind.")
+        self.robust_obs = kinds.pop() if kinds else _lib.LOSS_NONE
+        self.structure = BAStructure(len(self.cam_vars), len(self.pt_vars), obs_cam, obs_pt, cpc, ppp)
+        self.n = self.structure.n
+        self.nc = 6 * len(self.cam_vars)
+        self.m = objective.dim()
+        self.version = objective.current_version
+        self.tensors: Optional[BATensors] = None
+        self._own_variables = all(isinstance(v, Variable) for v in self._tracked())
+        self._stamp = None
+        self._global_stamp = -1
+        self._vars_stale = False
+        self._scratch = {}
+
+    # ---- packing ------------------------------------------------------------------------------------------
+    def _tracked(self):
+        yield from self.cam_vars
+        yield from self.pt_vars
+        for c, r in zip(self.obs_costs, self.obs_radius):
+            yield c.image_feature_point
+            yield c.focal_length
+            yield c.calib_k1
+            yield c.calib_k2
+            yield from _aux_vars(c.weight)
+            if r is not None:
+                yield r
+        for c in self.cam_prior_costs + self.pt_prior_costs:
+            yield c.target
+            yield from _aux_vars(c.weight)
+
+    def _current_stamp(self):
+        return tuple(v._num_updates for v in self._tracked())
+
+    @staticmethod
+    def _stack(ts, B):
+        if all(t.shape[0] == ts[0].shape[0] for t in ts):
+            return torch.stack(ts, dim=0).contiguous()
+        return torch.stack([t.expand(B, *t.shape[1:]) for t in ts], dim=0).contiguous()
+
+    def sync(self, force: bool = False):
+        if (not force and self.tensors is not None and self._own_variables
+                and Variable._global_updates == self._global_stamp):
+            return
+        stamp = self._current_stamp()
+        if not force and self.tensors is not None and stamp == self._stamp:
+            self._global_stamp = Variable._global_updates
+            return
+        self.flush_variables()
+        obj = self.objective
+        obj._resolve_batch_size()
+        B = obj.batch_size
+        dev, dt = self.cam_vars[0].device, obj.dtype
+        full = lambda v, *s: v.tensor.expand(B, *s) if v.shape[0] != B else v.tensor  # noqa: E731
+        cams = self._stack([full(v, 3, 4) for v in self.cam_vars], B)
+        pts = self._stack([full(v, 3) for v in self.pt_vars], B)
+        empty = lambda *s: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+        cam_of = {}
+        for c in self.obs_costs:  # calibration is read per camera: all observations of a camera must share it
+            k = c.camera_pose.name
+            trip = (c.focal_length, c.calib_k1, c.calib_k2)
+            if k in cam_of and any(a is not b for a, b in zip(cam_of[k], trip)):
+                raise UnsupportedObjective("HIP bundle adjustment: the Reprojection costs of one camera must share their "
+                                           "focal_length / calib_k1 / calib_k2 variables.")
+            cam_of[k] = trip
+        one = lambda: torch.ones(1, 1, dtype=dt, device=dev)  # noqa: E731
+        zero = lambda: torch.zeros(1, 1, dtype=dt, device=dev)  # noqa: E731
+        calib = [cam_of.get(v.name) for v in self.cam_vars]
+        focal = self._stack([c[0].tensor.view(-1, 1) if c else one() for c in calib], B)
+        k1 = self._stack([c[1].tensor.view(-1, 1) if c else zero() for c in calib], B)
+        k2 = self._stack([c[2].tensor.view(-1, 1) if c else zero() for c in calib], B)
+        nb = max(focal.shape[1], k1.shape[1], k2.shape[1])
+        focal, k1, k2 = (t.expand(-1, nb, 1).contiguous() for t in (focal, k1, k2))
+        O, Kc, Kp = len(self.obs_costs), len(self.cam_prior_costs), len(self.pt_prior_costs)
+        feat = self._stack([c.image_feature_point.tensor for c in self.obs_costs], B) if O else empty(0, 1, 2)
+        w_obs = self._stack([_weight_diag(c.weight, 2) for c in self.obs_costs], B) if O else empty(0, 1, 2)
+        lr = self._stack([r.tensor.view(-1, 1) for r in self.obs_radius], B) if self.robust_obs else None
+        cpt = self._stack([c.target.tensor for c in self.cam_prior_costs], B) if Kc else empty(0, 1, 3, 4)
+        wcp = self._stack([_weight_diag(c.weight, 6) for c in self.cam_prior_costs], B) if Kc else empty(0, 1, 6)
+        ppt = self._stack([c.target.tensor for c in self.pt_prior_costs], B) if Kp else empty(0, 1, 3)
+        wpp = self._stack([_weight_diag(c.weight, 3) for c in self.pt_prior_costs], B) if Kp else empty(0, 1, 3)
+        self.tensors = BATensors(cams=cams, points=pts, feat=feat, w_obs=w_obs, focal=focal, k1=k1, k2=k2,
+                                 cam_prior_target=cpt, w_cam_prior=wcp, pt_prior_target=ppt, w_pt_prior=wpp,
+                                 robust_obs=self.robust_obs, log_radius_obs=lr)
+        self._repoint_variables()
+
+    def _repoint_variables(self):
+        for k, v in enumerate(self.cam_vars):
+            v.tensor = self.tensors.cams[k]
+        for k, v in enumerate(self.pt_vars):
+            v.tensor = self.tensors.points[k]
+        self._stamp = self._current_stamp()
+        self._global_stamp = Variable._global_updates
+        self._vars_stale = False
+
+    def flush_variables(self):
+        if self._vars_stale and self.tensors is not None:
+            self._repoint_variables()
+
+    # ---- optimisation state = (cams, points) ------------------------------------------------------------------
+    @property
+    def state(self):
+        return (self.tensors.cams, self.tensors.points)
+
+    @property
+    def device(self):
+        return self.tensors.cams.device
+
+    @property
+    def batch(self):
+        return self.tensors.batch
+
+    @property
+    def optim_variables(self):
+        return self.cam_vars + self.pt_vars
+
+    @property
+    def dstruct(self):
+        return self.structure.on(self.tensors.cams.device)
+
+    def alloc_state(self):
+        return (torch.empty_like(self.tensors.cams), torch.empty_like(self.tensors.points))
+
+    def clone_state(self):
+        return (self.tensors.cams.clone(), self.tensors.points.clone())
+
+    def swap_state(self, new, repoint: bool = False):
+        old = self.state
+        self.tensors.cams, self.tensors.points = new
+        if repoint:
+            self._repoint_variables()
+        else:
+            self._vars_stale = True
+        return old
+
+    def keep_where(self, mask, out):
+        self.copy_where(mask, self.state, out)
+
+    @staticmethod
+    def copy_where(mask, src, dst):
+        torch.where(mask.view(1, -1, 1, 1), src[0], dst[0], out=dst[0])
+        torch.where(mask.view(1, -1, 1), src[1], dst[1], out=dst[1])
+
+    def solution_dict(self, state):
+        out = {v.name: state[0][k].cpu() for k, v in enumerate(self.cam_vars)}
+        out.update({v.name: state[1][k].cpu() for k, v in enumerate(self.pt_vars)})
+        return out
+
+    # ---- fused operations ----------------------------------------------------------------------------------------
+    def _buf(self, key, shape, dtype=None):
+        t = self._scratch.get(key)
+        dt = dtype or self.objective.dtype
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dt or t.device != self.device:
+            t = torch.empty(*shape, dtype=dt, device=self.device)
+            self._scratch[key] = t
+        return t
+
+    def error_metric(self, state=None, out: Optional[torch.Tensor] = None, poses=None):
+        self.sync()
+        B = self.batch
+        part = self._buf("err_part", (ERR_CHUNKS, B))
+        err = out if out is not None else torch.empty(B, dtype=self.objective.dtype, device=part.device)
+        cams, pts = state if state is not None else (None, None)
+        self.K.ba_error(self.dstruct, self.tensors, part, err, cams=cams, points=pts)
+        return err
+
+    def retract(self, delta: torch.Tensor, step: float, ignore_mask: Optional[torch.Tensor], out):
+        self.sync()
+        m = None
+        if ignore_mask is not None:
+            m = ignore_mask if ignore_mask.dtype == torch.uint8 else ignore_mask.to(torch.uint8)
+        self.K.se3_retract(self.tensors.cams, delta, step, m, out[0])   # columns [0, 6C)
+        self.K.vec_retract(self.tensors.points, delta, self.nc, step, m, out[1])
+        return out
+
+    def error_vector(self):
+        raise NotImplementedError("Objective.error() of a bundle-adjustment objective is not materialised on the HIP back end "
+                                  "(use error_metric())")
+
+
+class HipSchurLinearization(Linearization):
+    """``Linearization`` of a bundle-adjustment objective: block form (Hcc, Hpp, Hcp) + g + diag(H), never the dense H.
+    ``ordering``: cameras, then points."""
+
+    def __init__(self, objective: Objective, ordering: Optional[VariableOrdering] = None, kernels=None, **kwargs):
+        packed = getattr(objective, "_packed", None)
+        if not isinstance(packed, PackedBA) or packed.version != objective.current_version or (
+                kernels is not None and packed.K is not kernels):
+            packed = PackedBA(objective, kernels)
+            objective._packed = packed
+        if ordering is not None:
+            raise NotImplementedError("HipSchurLinearization fixes the variable ordering: cameras, then points.")
+        ordering = VariableOrdering(objective, default_order=False)
+        for v in packed.cam_vars + packed.pt_vars:
+            ordering.append(v)
+        Linearization.__init__(self, objective, ordering)
+        self.packed, self.K = packed, packed.K
+        self.Hcc = self.Hpp = self.W = self.g = self.diag = None
+
+    @property
+    def n(self):
+        return self.packed.n
+
+    def _ensure_buffers(self):
+        p = self.packed
+        p.sync()
+        B, s = p.batch, p.structure
+        dev, dt = p.device, self.objective.dtype
+        if self.g is None or self.g.shape[0] != B or self.g.device != dev or self.g.dtype != dt:
+            new = lambda *sh: torch.empty(*sh, dtype=dt, device=dev)  # noqa: E731
+            self.Hcc, self.Hpp = new(s.num_cams, B, 6, 6), new(s.num_points, B, 6)
+            self.W = new(max(s.num_obs, 1), B, 6, 3)
+            self.g, self.diag = new(B, p.n), new(B, p.n)
+
+    def _assemble(self):
+        self._ensure_buffers()
+        p = self.packed
+        self.K.ba_assemble(p.dstruct, p.tensors, self.Hcc, self.Hpp, self.W, self.g, self.diag)
+
+    def _linearize_jacobian_impl(self):
+        raise NotImplementedError("the dense Jacobian of a bundle-adjustment objective is not materialised")
+
+    def _linearize_hessian_impl(self, _detach_hessian: bool = False):
+        self._assemble()
+
+    @property
+    def AtA(self) -> torch.Tensor:
+        raise NotImplementedError("the dense Hessian of a bundle-adjustment objective is not materialised "
+                                  "(Hcc / Hpp / W hold its blocks)")
+
+    @property
+    def Atb(self) -> torch.Tensor:
+        return self.g.unsqueeze(2)
+
+    def Av(self, v):
+        raise NotImplementedError
+
+    def diagonal_scaling(self, v: torch.Tensor) -> torch.Tensor:
+        return self.diag * v
+
+    def lm_accept(self, delta, damping, prev_err, new_err, ellipsoidal, accept, down, up, reject):
+        self.K.lm_accept_diag(delta, self.g, self.diag, self.n, damping, prev_err, new_err, ellipsoidal, accept, down, up, reject)
+
+
+class HipSchurSolver(LinearSolver):
+    """(H + damping) delta = g of a bundle-adjustment linearization by block elimination of the points + the tiled dense
+    Cholesky on the reduced camera system.  Same ``solve`` contract and failure behaviour as ``HipCholeskySolver``."""
+
+    def __init__(self, objective: Objective, linearization_cls: Optional[Type[Linearization]] = None,
+                 linearization_kwargs: Optional[Dict[str, Any]] = None, **kwargs):
+        linearization_cls = linearization_cls or HipSchurLinearization
+        if not (isinstance(linearization_cls, type) and issubclass(linearization_cls, HipSchurLinearization)):
+            raise RuntimeError(f"HipSchurSolver only works with HipSchurLinearization, but {linearization_cls} was provided.")
+        LinearSolver.__init__(self, objective, linearization_cls, linearization_kwargs)
+        self.K = self.linearization.K
+        self.S = self.L = self.panels = self.info_chol = self.info_pts = None
+        self.factor_version = 0
+
+    def _ensure_buffers(self):
+        lin = self.linearization
+        B, nc = lin.g.shape[0], lin.packed.nc
+        dev, dt = lin.g.device, lin.g.dtype
+        if self.S is None or self.S.shape[0] != B or self.S.device != dev or self.S.dtype != dt:
+            ld = round_up(nc, 32)
+            nt = (nc + _lib.THX_TILE - 1) // _lib.THX_TILE
+            s = lin.packed.structure
+            self.S = torch.zeros(B, ld, ld, dtype=dt, device=dev)   # zero once: the block pattern is fixed
+            self.L = torch.zeros_like(self.S)
+            self.panels = torch.empty(B, nt, _lib.THX_TILE, _lib.THX_TILE, dtype=dt, device=dev)
+            self.rhs, self._y, self._dc = (torch.empty(B, nc, dtype=dt, device=dev) for _ in range(3))
+            self.Hinv, self.tvec = torch.empty(s.num_points, B, 6, dtype=dt, device=dev), torch.empty(B, 3 * s.num_points, dtype=dt, device=dev)
+            self.delta = torch.empty(B, lin.n, dtype=dt, device=dev)
+            self.info_chol = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.info_pts = torch.zeros(B, dtype=torch.int32, device=dev)
+            self._lam = torch.empty(B, dtype=dt, device=dev)
+
+    @property
+    def info(self):
+        """(B,) int32: non-zero where the damped system of a problem is not positive definite."""
+        return self.info_chol + self.info_pts
+
+    def check_info(self):
+        bad = self.info.nonzero()
+        if bad.numel():
+            b = int(bad[0])
+            raise RuntimeError(f"linalg.cholesky: (Batch element {b}): The factorization could not be completed because the "
+                               "input is not positive-definite.")
+
+    def solve(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
+              damping_eps: float = 1e-8, check_info: bool = True, **kwargs) -> torch.Tensor:
+        lin = self.linearization
+        if lin.g is None:
+            raise RuntimeError("linearize() must be called before solve().")
+        if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
+            raise ValueError("Damping must be a float or a 1-D tensor.")
+        self._ensure_buffers()
+        lam = None
+        if damping is not None:
+            lam = self._lam
+            if isinstance(damping, torch.Tensor):
+                lam.copy_(damping.to(lam.dtype).expand(lam.shape[0]))
+            else:
+                lam.fill_(float(damping))
+        p = lin.packed
+        self.factor_version += 1
+        self.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, lin.g, lam, ellipsoidal_damping, damping_eps, self.S, self.rhs,
+                        self.Hinv, self.tvec, self.info_pts)
+        self.K.chol_factor(self.S, p.nc, None, False, damping_eps, self.L, self.panels, self.info_chol, rhs=self.rhs, y=self._y)
+        self.K.chol_solve_backward(self.L, p.nc, self.panels, self._y, self._dc)
+        self.delta[:, :p.nc].copy_(self._dc)                                          # delta = [delta_c | delta_p]
+        self.K.ba_backsub(p.dstruct, lin.W, self.Hinv, self.tvec, self.delta)
+        if check_info:
+            self.check_info()
+        return self.delta

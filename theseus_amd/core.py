@@ -92,6 +92,39 @@ class Vector(Variable):
         return self.tensor.shape[1]
 
 
+class Point3(Vector):
+    """World point (theseus/geometry/point_types.py:97-170): a 3-vector; retraction = addition
+    (theseus/geometry/vector.py:177-178), local(a, b) = b - a (:150-160)."""
+
+    def __init__(self, tensor: Optional[torch.Tensor] = None, name: Optional[str] = None,
+                 dtype: Optional[torch.dtype] = None):
+        if tensor is not None and tensor.shape[-1] != 3:
+            raise ValueError("Provided tensor must have shape (batch_size, 3).")
+        super().__init__(3, tensor=tensor, name=name, dtype=dtype)
+
+    def local(self, other: "Vector") -> torch.Tensor:
+        return other.tensor - self.tensor
+
+    def retract(self, delta: torch.Tensor) -> "Point3":
+        return Point3(tensor=self.tensor + delta)
+
+    def copy(self, new_name: Optional[str] = None) -> "Point3":
+        return Point3(tensor=self.tensor.clone(), name=new_name or f"{self.name}_copy")
+
+
+class Point2(Vector):
+    """Image point (theseus/geometry/point_types.py:18-94)."""
+
+    def __init__(self, tensor: Optional[torch.Tensor] = None, name: Optional[str] = None,
+                 dtype: Optional[torch.dtype] = None):
+        if tensor is not None and tensor.shape[-1] != 2:
+            raise ValueError("Provided tensor must have shape (batch_size, 2).")
+        super().__init__(2, tensor=tensor, name=name, dtype=dtype)
+
+    def copy(self, new_name: Optional[str] = None) -> "Point2":
+        return Point2(tensor=self.tensor.clone(), name=new_name or f"{self.name}_copy")
+
+
 class SE3(Variable):
     """SE3 group element batch, tensor (B,3,4) = [R | t]; tangent [v, w]; right perturbations."""
 
@@ -397,6 +430,38 @@ class Difference(CostFunction):
 
 
 Local = Difference
+
+
+class Reprojection(CostFunction):
+    """Pinhole reprojection with two radial terms (theseus/embodied/measurements/reprojection.py:13-94): optimises
+    ``camera_pose`` (SE3) and ``world_point`` (Point3); auxiliary ``image_feature_point``, ``focal_length``,
+    ``calib_k1``, ``calib_k2``.  Evaluated by the fused bundle-adjustment kernels (csrc/ba_kernels.hip)."""
+
+    def __init__(self, camera_pose: SE3, world_point: Point3, image_feature_point: Point2, focal_length: Vector,
+                 calib_k1: Optional[Vector] = None, calib_k2: Optional[Vector] = None, weight: Optional[CostWeight] = None,
+                 name: Optional[str] = None):
+        dt, dev = camera_pose.dtype, camera_pose.device
+        if weight is None:
+            weight = ScaleCostWeight(torch.tensor(1.0, dtype=dt, device=dev))
+        super().__init__(weight, name)
+        zero = lambda n: Vector(tensor=torch.zeros(1, 1, dtype=dt, device=dev), name=f"{self.name}__{n}")  # noqa: E731
+        self.camera_pose, self.world_point = camera_pose, world_point
+        self.image_feature_point, self.focal_length = image_feature_point, focal_length
+        self.calib_k1 = calib_k1 if calib_k1 is not None else zero("calib_k1")
+        self.calib_k2 = calib_k2 if calib_k2 is not None else zero("calib_k2")
+
+    def optim_vars(self):
+        return [self.camera_pose, self.world_point]
+
+    def aux_vars(self):
+        return [self.focal_length, self.image_feature_point, self.calib_k1, self.calib_k2] + self.weight.aux_vars()
+
+    def dim(self):
+        return 2
+
+    def error(self):
+        raise NotImplementedError("Reprojection is evaluated by the fused bundle-adjustment kernels "
+                                  "(objective.error_metric() after an optimizer / linearization was built on it)")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,606 @@
+// Bundle adjustment on the dense GN/LM path (include/theseus_hip.h, "Bundle adjustment"): fused Reprojection residual /
+// Jacobian evaluation, block assembly, Schur complement on the camera block, back substitution, error metric.
+// Same mapping as the pose-graph kernels: one lane per (entity, problem), batch index fastest across the wave, entity
+// tables wave-uniform, owner-computes (no atomics, bit-reproducible); per-cost arithmetic in fp64 registers.
+#include "common.cuh"
+#include "robust.cuh"
+
+namespace thx {
+
+struct Reproj {
+  double Jc[12];  // 2x6 row major (weighted)
+  double Jp[6];   // 2x3
+  double e[2];
+};
+
+// theseus/embodied/measurements/reprojection.py:54-94 (+ se3_impl.py:757-777), rows scaled by w (cost_weight.py:81-136)
+__device__ __forceinline__ void reproj_eval(const SE3<double>& cam, const double* X, const double* feat, double f, double k1,
+                                            double k2, const double* w, bool want_jac, Reproj& r) {
+  double pc[3];
+  mat3_vec(cam.R, X, pc);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pc[i] += cam.t[i];
+  const double iz = 1.0 / pc[2];
+  const double proj[2] = {-pc[0] * iz, -pc[1] * iz};
+  const double q = proj[0] * proj[0] + proj[1] * proj[1];
+  const double factor = f * (1.0 + q * (k1 + q * k2));
+  r.e[0] = (proj[0] * factor - feat[0]) * w[0];
+  r.e[1] = (proj[1] * factor - feat[1]) * w[1];
+  if (!want_jac) return;
+  const double dfactor = f * (k1 + 2.0 * q * k2);
+  // J = [R, -R hat(X) | R]  (3 x 9)
+  double J[27];
+  const double hx[9] = {0.0, -X[2], X[1], X[2], 0.0, -X[0], -X[1], X[0], 0.0};
+  double RH[9];
+  mat3_mul(cam.R, hx, RH);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      J[9 * i + j] = cam.R[3 * i + j];
+      J[9 * i + 3 + j] = -RH[3 * i + j];
+      J[9 * i + 6 + j] = cam.R[3 * i + j];
+    }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const double j2 = J[18 + j] * iz;
+    const double pj0 = (pc[0] * j2 - J[j]) * iz;        // derivative of N/D is (N' - N D'/D) / D, with the sign of proj
+    const double pj1 = (pc[1] * j2 - J[9 + j]) * iz;
+    const double qj = 2.0 * (proj[0] * pj0 + proj[1] * pj1);
+    const double o0 = (pj0 * factor + proj[0] * qj * dfactor) * w[0];
+    const double o1 = (pj1 * factor + proj[1] * qj * dfactor) * w[1];
+    if (j < 6) {
+      r.Jc[j] = o0;
+      r.Jc[6 + j] = o1;
+    } else {
+      r.Jp[j - 6] = o0;
+      r.Jp[3 + j - 6] = o1;
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ SE3<double> load_cam(const T* __restrict__ p) {
+  SE3<double> X;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    X.R[3 * i] = (double)p[4 * i];
+    X.R[3 * i + 1] = (double)p[4 * i + 1];
+    X.R[3 * i + 2] = (double)p[4 * i + 2];
+    X.t[i] = (double)p[4 * i + 3];
+  }
+  return X;
+}
+
+// everything one observation needs besides its two variables
+template <typename T>
+struct ObsAux {
+  double feat[2], w[2], f, k1, k2, lr;
+};
+template <typename T>
+__device__ __forceinline__ void load_obs(const thx_ba_data& d, int o, int c, int b, ObsAux<T>& a) {
+  const int B = d.batch;
+  const T* fp = static_cast<const T*>(d.feat) + ((int64_t)o * (d.feat_bstride ? B : 1)) * 2 + (int64_t)b * d.feat_bstride;
+  const T* wp = static_cast<const T*>(d.w_obs) + ((int64_t)o * (d.w_obs_bstride ? B : 1)) * 2 + (int64_t)b * d.w_obs_bstride;
+  const int64_t ci = (int64_t)c * (d.calib_bstride ? B : 1) + (int64_t)b * d.calib_bstride;
+  a.feat[0] = (double)fp[0]; a.feat[1] = (double)fp[1];
+  a.w[0] = (double)wp[0]; a.w[1] = (double)wp[1];
+  a.f = (double)static_cast<const T*>(d.focal)[ci];
+  a.k1 = (double)static_cast<const T*>(d.k1)[ci];
+  a.k2 = (double)static_cast<const T*>(d.k2)[ci];
+  a.lr = d.robust_obs ? load_log_radius<T>(d.log_radius_obs, o, b, B, d.log_radius_obs_bstride) : 0.0;
+}
+__device__ __forceinline__ void robustify_obs(int kind, double lr, Reproj& r, bool jac) {
+  if (kind == THX_LOSS_NONE) return;
+  const double s = robust_rescale<2>(kind, r.e, lr);
+  r.e[0] *= s; r.e[1] *= s;
+  if (jac) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) r.Jc[i] *= s;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.Jp[i] *= s;
+  }
+}
+
+// ---- pass A: one lane per (point, problem): Hpp, gp, W = Jc^T Jp of the point's observations ----
+template <typename T>
+__global__ void __launch_bounds__(64)
+ba_point_kernel(thx_ba_structure s, thx_ba_data d, T* __restrict__ Hpp, T* __restrict__ W, T* __restrict__ g,
+                T* __restrict__ diag, int64_t ldv) {
+  const int b = blockIdx.x * 64 + threadIdx.x, p = blockIdx.y, B = d.batch;
+  if (b >= B) return;
+  const T* Xp = static_cast<const T*>(d.points) + ((int64_t)p * B + b) * 3;
+  const double X[3] = {(double)Xp[0], (double)Xp[1], (double)Xp[2]};
+  double h[6] = {0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
+  for (int k = s.pt_ptr[p]; k < s.pt_ptr[p + 1]; ++k) {
+    const int o = s.pt_obs[k], c = s.obs_cam[o];
+    const SE3<double> cam = load_cam(static_cast<const T*>(d.cams) + ((int64_t)c * B + b) * 12);
+    ObsAux<T> a;
+    load_obs<T>(d, o, c, b, a);
+    Reproj r;
+    reproj_eval(cam, X, a.feat, a.f, a.k1, a.k2, a.w, true, r);
+    robustify_obs(d.robust_obs, a.lr, r, true);
+    h[0] += r.Jp[0] * r.Jp[0] + r.Jp[3] * r.Jp[3];
+    h[1] += r.Jp[0] * r.Jp[1] + r.Jp[3] * r.Jp[4];
+    h[2] += r.Jp[0] * r.Jp[2] + r.Jp[3] * r.Jp[5];
+    h[3] += r.Jp[1] * r.Jp[1] + r.Jp[4] * r.Jp[4];
+    h[4] += r.Jp[1] * r.Jp[2] + r.Jp[4] * r.Jp[5];
+    h[5] += r.Jp[2] * r.Jp[2] + r.Jp[5] * r.Jp[5];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gp[i] -= r.Jp[i] * r.e[0] + r.Jp[3 + i] * r.e[1];
+    T* Wo = W + ((int64_t)o * B + b) * 18;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Wo[3 * i + j] = (T)(r.Jc[i] * r.Jp[j] + r.Jc[6 + i] * r.Jp[3 + j]);
+  }
+  for (int k = s.pt_prior_ptr[p]; k < s.pt_prior_ptr[p + 1]; ++k) {
+    const int id = s.pt_prior_id[k];
+    const T* tg = static_cast<const T*>(d.pt_prior_target) + ((int64_t)id * (d.pt_prior_target_bstride ? B : 1)) * 3 +
+                  (int64_t)b * d.pt_prior_target_bstride;
+    const T* wp = static_cast<const T*>(d.w_pt_prior) + ((int64_t)id * (d.w_pt_prior_bstride ? B : 1)) * 3 +
+                  (int64_t)b * d.w_pt_prior_bstride;
+    const int dgi[3] = {0, 3, 5};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double w = (double)wp[i], e = (X[i] - (double)tg[i]) * w;
+      h[dgi[i]] += w * w;
+      gp[i] -= w * e;
+    }
+  }
+  T* Hp = Hpp + ((int64_t)p * B + b) * 6;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Hp[i] = (T)h[i];
+  const int64_t col = 6 * (int64_t)s.num_cams + 3 * p;
+  T* gb = g + (int64_t)b * ldv + col;
+  T* db = diag + (int64_t)b * ldv + col;
+  gb[0] = (T)gp[0]; gb[1] = (T)gp[1]; gb[2] = (T)gp[2];
+  db[0] = (T)h[0]; db[1] = (T)h[3]; db[2] = (T)h[5];
+}
+
+// ---- pass B: one lane per (camera, problem): Hcc, gc ----
+template <typename T>
+__global__ void __launch_bounds__(64)
+ba_camera_kernel(thx_ba_structure s, thx_ba_data d, T* __restrict__ Hcc, T* __restrict__ g, T* __restrict__ diag,
+                 int64_t ldv, Eps<T> eps) {
+  const int b = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y, B = d.batch;
+  if (b >= B) return;
+  const T* cp = static_cast<const T*>(d.cams) + ((int64_t)c * B + b) * 12;
+  const SE3<double> cam = load_cam(cp);
+  double Hc[36], gc[6];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) Hc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) gc[i] = 0.0;
+  for (int k = s.cam_ptr[c]; k < s.cam_ptr[c + 1]; ++k) {
+    const int o = s.cam_obs[k], p = s.obs_pt[o];
+    const T* Xp = static_cast<const T*>(d.points) + ((int64_t)p * B + b) * 3;
+    const double X[3] = {(double)Xp[0], (double)Xp[1], (double)Xp[2]};
+    ObsAux<T> a;
+    load_obs<T>(d, o, c, b, a);
+    Reproj r;
+    reproj_eval(cam, X, a.feat, a.f, a.k1, a.k2, a.w, true, r);
+    robustify_obs(d.robust_obs, a.lr, r, true);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) Hc[6 * i + j] += r.Jc[i] * r.Jc[j] + r.Jc[6 + i] * r.Jc[6 + j];
+      gc[i] -= r.Jc[i] * r.e[0] + r.Jc[6 + i] * r.e[1];
+    }
+  }
+  for (int k = s.cam_prior_ptr[c]; k < s.cam_prior_ptr[c + 1]; ++k) {
+    const int id = s.cam_prior_id[k];
+    const SE3<double> Tg = load_cam(static_cast<const T*>(d.cam_prior_target) +
+                                    ((int64_t)id * (d.cam_prior_target_bstride ? B : 1)) * 12 + (int64_t)b * d.cam_prior_target_bstride);
+    const T* wp = static_cast<const T*>(d.w_cam_prior) + ((int64_t)id * (d.w_cam_prior_bstride ? B : 1)) * 6 +
+                  (int64_t)b * d.w_cam_prior_bstride;
+    double w[6], ev[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) w[i] = (double)wp[i];
+    SJac<double> Jd;
+    local_eval<double>(Tg, cam, w, widen(eps), ev, &Jd, true);
+    sjac_tmul_acc(Jd, Jd, Hc);
+    sjac_tvec_sub(Jd, ev, gc);
+  }
+  T* Ho = Hcc + ((int64_t)c * B + b) * 36;
+#pragma unroll
+  for (int i = 0; i < 36; ++i) Ho[i] = (T)Hc[i];
+  T* gb = g + (int64_t)b * ldv + 6 * c;
+  T* db = diag + (int64_t)b * ldv + 6 * c;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    gb[i] = (T)gc[i];
+    db[i] = (T)Hc[7 * i];
+  }
+}
+
+// ---- Schur 1: damped point blocks inverted, t = Hpp'^-1 gp ----
+template <typename T>
+__global__ void __launch_bounds__(64)
+ba_point_invert_kernel(thx_ba_structure s, int B, const T* __restrict__ Hpp, const T* __restrict__ g, int64_t ldv,
+                       const T* __restrict__ damping, int ellipsoidal, T eps, T* __restrict__ Hinv, T* __restrict__ tvec,
+                       int32_t* __restrict__ info) {
+  const int b = blockIdx.x * 64 + threadIdx.x, p = blockIdx.y;
+  if (b >= B) return;
+  const T* Hp = Hpp + ((int64_t)p * B + b) * 6;
+  // the damping is applied in T like DenseSolver._apply_damping does on the T-valued Hessian
+  T hd[3] = {Hp[0], Hp[3], Hp[5]};
+  if (damping) {
+    const T lam = damping[b];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) hd[i] = ellipsoidal ? hd[i] + (lam * hd[i] + eps) : hd[i] + lam;
+  }
+  const double a = (double)hd[0], bb = (double)Hp[1], c = (double)Hp[2], dd = (double)hd[1], e = (double)Hp[4], f = (double)hd[2];
+  // adjugate of the symmetric 3x3 [[a,b,c],[b,d,e],[c,e,f]]
+  const double A = dd * f - e * e, Bc = c * e - bb * f, C = bb * e - c * dd;
+  const double det = a * A + bb * Bc + c * C;
+  const double m2 = a * dd - bb * bb;
+  if (!(a > 0.0) || !(m2 > 0.0) || !(det > 0.0)) info[b] = 6 * s.num_cams + 3 * p + 1;  // any writer: value only flags failure
+  const double id = 1.0 / det;
+  const double inv[6] = {A * id, Bc * id, C * id, (a * f - c * c) * id, (bb * c - a * e) * id, m2 * id};
+  T* Ho = Hinv + ((int64_t)p * B + b) * 6;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Ho[i] = (T)inv[i];
+  const T* gp = g + (int64_t)b * ldv + 6 * (int64_t)s.num_cams + 3 * p;
+  const double g0 = (double)gp[0], g1 = (double)gp[1], g2 = (double)gp[2];
+  T* tp = tvec + (int64_t)b * (3 * (int64_t)s.num_points) + 3 * p;
+  tp[0] = (T)(inv[0] * g0 + inv[1] * g1 + inv[2] * g2);
+  tp[1] = (T)(inv[1] * g0 + inv[3] * g1 + inv[4] * g2);
+  tp[2] = (T)(inv[2] * g0 + inv[4] * g1 + inv[5] * g2);
+}
+
+// M (6x3) = W (6x3) * Hinv (sym 3x3)
+__device__ __forceinline__ void w_times_sym(const double* W, const double* h, double* M) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double w0 = W[3 * i], w1 = W[3 * i + 1], w2 = W[3 * i + 2];
+    M[3 * i] = w0 * h[0] + w1 * h[1] + w2 * h[2];
+    M[3 * i + 1] = w0 * h[1] + w1 * h[3] + w2 * h[4];
+    M[3 * i + 2] = w0 * h[2] + w1 * h[4] + w2 * h[5];
+  }
+}
+
+// ---- Schur 2: one lane per (camera c1, problem): block row c1 of S (columns c2 <= c1) and rhs_c1 ----
+template <typename T>
+__global__ void __launch_bounds__(64)
+ba_schur_kernel(thx_ba_structure s, int B, const T* __restrict__ Hcc, const T* __restrict__ W, const T* __restrict__ g,
+                int64_t ldv, const T* __restrict__ damping, int ellipsoidal, T eps, const T* __restrict__ Hinv,
+                const T* __restrict__ tvec, T* __restrict__ S, int64_t ld, T* __restrict__ rhs, int64_t ldr) {
+  const int b = blockIdx.x * 64 + threadIdx.x, c1 = blockIdx.y;
+  if (b >= B) return;
+  double Dg[36], Off[36], rv[6];
+  const T* Hc = Hcc + ((int64_t)c1 * B + b) * 36;
+#pragma unroll
+  for (int i = 0; i < 36; ++i) { Dg[i] = (double)Hc[i]; Off[i] = 0.0; }
+  if (damping) {
+    const T lam = damping[b];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const T h = Hc[7 * i];
+      Dg[7 * i] = (double)(ellipsoidal ? h + (lam * h + eps) : h + lam);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) rv[i] = (double)g[(int64_t)b * ldv + 6 * c1 + i];
+  // rhs -= sum_o W_o t_p(o)
+  for (int k = s.cam_ptr[c1]; k < s.cam_ptr[c1 + 1]; ++k) {
+    const int o = s.cam_obs[k], p = s.obs_pt[o];
+    const T* Wo = W + ((int64_t)o * B + b) * 18;
+    const T* tp = tvec + (int64_t)b * (3 * (int64_t)s.num_points) + 3 * p;
+    const double t0 = (double)tp[0], t1 = (double)tp[1], t2 = (double)tp[2];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rv[i] -= (double)Wo[3 * i] * t0 + (double)Wo[3 * i + 1] * t1 + (double)Wo[3 * i + 2] * t2;
+  }
+  T* Sb = S + (int64_t)b * ld * ld;
+  auto flush = [&](int c2) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Sb[(int64_t)(6 * c1 + r) * ld + 6 * c2 + c] = (T)Off[6 * r + c];
+  };
+  int cur = -1;
+  for (int k = s.pair_ptr[c1]; k < s.pair_ptr[c1 + 1]; ++k) {
+    const int o1 = s.pair_o1[k], o2 = s.pair_o2[k], c2 = s.pair_c2[k];
+    const int p = s.obs_pt[o1];
+    double W1[18], W2[18], h[6], M[18];
+    const T* W1p = W + ((int64_t)o1 * B + b) * 18;
+    const T* W2p = W + ((int64_t)o2 * B + b) * 18;
+    const T* hp = Hinv + ((int64_t)p * B + b) * 6;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) { W1[i] = (double)W1p[i]; W2[i] = (double)W2p[i]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) h[i] = (double)hp[i];
+    w_times_sym(W1, h, M);
+    if (c2 != cur && c2 != c1) {
+      if (cur >= 0 && cur != c1) flush(cur);
+#pragma unroll
+      for (int i = 0; i < 36; ++i) Off[i] = 0.0;
+    }
+    cur = c2;
+    double* dst = c2 == c1 ? Dg : Off;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        dst[6 * r + c] -= M[3 * r] * W2[3 * c] + M[3 * r + 1] * W2[3 * c + 1] + M[3 * r + 2] * W2[3 * c + 2];
+  }
+  if (cur >= 0 && cur != c1) flush(cur);
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Sb[(int64_t)(6 * c1 + r) * ld + 6 * c1 + c] = (T)Dg[6 * r + c];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) rhs[(int64_t)b * ldr + 6 * c1 + i] = (T)rv[i];
+}
+
+// ---- back substitution: delta_p = t_p - Hinv_p sum_o W_o^T delta_c(o) ----
+template <typename T>
+__global__ void __launch_bounds__(64)
+ba_backsub_kernel(thx_ba_structure s, int B, const T* __restrict__ W, const T* __restrict__ Hinv,
+                  const T* __restrict__ tvec, T* __restrict__ delta, int64_t ldv) {
+  const int b = blockIdx.x * 64 + threadIdx.x, p = blockIdx.y;
+  if (b >= B) return;
+  double acc[3] = {0, 0, 0};
+  for (int k = s.pt_ptr[p]; k < s.pt_ptr[p + 1]; ++k) {
+    const int o = s.pt_obs[k], c = s.obs_cam[o];
+    const T* Wo = W + ((int64_t)o * B + b) * 18;
+    const T* dc = delta + (int64_t)b * ldv + 6 * c;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double di = (double)dc[i];
+      acc[0] += (double)Wo[3 * i] * di;
+      acc[1] += (double)Wo[3 * i + 1] * di;
+      acc[2] += (double)Wo[3 * i + 2] * di;
+    }
+  }
+  const T* hp = Hinv + ((int64_t)p * B + b) * 6;
+  const double h[6] = {(double)hp[0], (double)hp[1], (double)hp[2], (double)hp[3], (double)hp[4], (double)hp[5]};
+  const T* tp = tvec + (int64_t)b * (3 * (int64_t)s.num_points) + 3 * p;
+  T* dp = delta + (int64_t)b * ldv + 6 * (int64_t)s.num_cams + 3 * p;
+  dp[0] = (T)((double)tp[0] - (h[0] * acc[0] + h[1] * acc[1] + h[2] * acc[2]));
+  dp[1] = (T)((double)tp[1] - (h[1] * acc[0] + h[3] * acc[1] + h[4] * acc[2]));
+  dp[2] = (T)((double)tp[2] - (h[2] * acc[0] + h[4] * acc[1] + h[5] * acc[2]));
+}
+
+// ---- error metric ----
+template <typename T>
+__global__ void __launch_bounds__(64)
+ba_error_partial_kernel(thx_ba_structure s, thx_ba_data d, T* __restrict__ partials, Eps<T> eps) {
+  const int b = blockIdx.x * 64 + threadIdx.x, ch = blockIdx.y, B = d.batch;
+  if (b >= B) return;
+  double acc = 0.0;
+  auto range = [&](int n, int& lo, int& hi) __attribute__((always_inline)) {
+    const int per = (n + THX_ERR_CHUNKS - 1) / THX_ERR_CHUNKS;
+    lo = ch * per;
+    hi = min(n, lo + per);
+  };
+  int lo, hi;
+  range(s.num_obs, lo, hi);
+  for (int o = lo; o < hi; ++o) {
+    const int c = s.obs_cam[o], p = s.obs_pt[o];
+    const SE3<double> cam = load_cam(static_cast<const T*>(d.cams) + ((int64_t)c * B + b) * 12);
+    const T* Xp = static_cast<const T*>(d.points) + ((int64_t)p * B + b) * 3;
+    const double X[3] = {(double)Xp[0], (double)Xp[1], (double)Xp[2]};
+    ObsAux<T> a;
+    load_obs<T>(d, o, c, b, a);
+    Reproj r;
+    reproj_eval(cam, X, a.feat, a.f, a.k1, a.k2, a.w, false, r);
+    acc += robust_sq_error<2>(d.robust_obs, r.e, a.lr);
+  }
+  range(s.num_cam_priors, lo, hi);
+  for (int k = lo; k < hi; ++k) {
+    const int c = s.cam_prior_cam[k];
+    const SE3<double> Xc = load_cam(static_cast<const T*>(d.cams) + ((int64_t)c * B + b) * 12);
+    const SE3<double> Tg = load_cam(static_cast<const T*>(d.cam_prior_target) +
+                                    ((int64_t)k * (d.cam_prior_target_bstride ? B : 1)) * 12 + (int64_t)b * d.cam_prior_target_bstride);
+    const T* wp = static_cast<const T*>(d.w_cam_prior) + ((int64_t)k * (d.w_cam_prior_bstride ? B : 1)) * 6 +
+                  (int64_t)b * d.w_cam_prior_bstride;
+    double w[6], ev[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) w[i] = (double)wp[i];
+    local_eval<double>(Tg, Xc, w, widen(eps), ev, nullptr, false);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc += ev[i] * ev[i];
+  }
+  range(s.num_pt_priors, lo, hi);
+  for (int k = lo; k < hi; ++k) {
+    const int p = s.pt_prior_pt[k];
+    const T* Xp = static_cast<const T*>(d.points) + ((int64_t)p * B + b) * 3;
+    const T* tg = static_cast<const T*>(d.pt_prior_target) + ((int64_t)k * (d.pt_prior_target_bstride ? B : 1)) * 3 +
+                  (int64_t)b * d.pt_prior_target_bstride;
+    const T* wp = static_cast<const T*>(d.w_pt_prior) + ((int64_t)k * (d.w_pt_prior_bstride ? B : 1)) * 3 +
+                  (int64_t)b * d.w_pt_prior_bstride;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double e = ((double)Xp[i] - (double)tg[i]) * (double)wp[i];
+      acc += e * e;
+    }
+  }
+  partials[(int64_t)ch * B + b] = (T)acc;
+}
+template <typename T>
+__global__ void ba_error_reduce_kernel(const T* __restrict__ partials, T* __restrict__ err, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  T acc = T(0);
+#pragma unroll
+  for (int c = 0; c < THX_ERR_CHUNKS; ++c) acc += partials[(int64_t)c * B + b];
+  err[b] = T(0.5) * acc;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64)
+vec_retract_kernel(const T* __restrict__ x, const T* __restrict__ delta, int64_t ldd, int64_t col0, T step,
+                   const uint8_t* __restrict__ ignore, T* __restrict__ out, int N, int dof, int B) {
+  const int b = blockIdx.x * 64 + threadIdx.x, p = blockIdx.y;
+  if (b >= B) return;
+  const bool keep = ignore && ignore[b];
+  for (int i = 0; i < dof; ++i) {
+    const int64_t o = ((int64_t)p * B + b) * dof + i;
+    out[o] = keep ? x[o] : x[o] + delta[(int64_t)b * ldd + col0 + (int64_t)p * dof + i] * step;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64)
+lm_accept_diag_kernel(const T* __restrict__ delta, const T* __restrict__ g, const T* __restrict__ diag, int64_t ldv, int n,
+                      T* __restrict__ damping, const T* __restrict__ prev_err, const T* __restrict__ new_err,
+                      int ellipsoidal, T accept, T down, T up, uint8_t* __restrict__ reject) {
+  // levenberg_marquardt.py:173-201 (same arithmetic as lm_accept_kernel, diag(H) read from a vector)
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const T lam = damping[b];
+  T s = T(0);
+  for (int i = lane; i < n; i += 64) {
+    const T dl = delta[(int64_t)b * ldv + i];
+    const T D = ellipsoidal ? diag[(int64_t)b * ldv + i] * lam : lam;
+    s += dl * (D * dl + g[(int64_t)b * ldv + i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) {
+    const T den = s / T(2);
+    const T rho = (prev_err[b] - new_err[b]) / den;
+    const bool rej = rho <= accept;
+    T nl = rej ? lam * up : lam / down;
+    nl = nl < T(1.0e-7) ? T(1.0e-7) : (nl > T(1.0e7) ? T(1.0e7) : nl);
+    damping[b] = nl;
+    reject[b] = rej ? 1 : 0;
+  }
+}
+
+static int check_ba(const thx_ba_structure* s, const thx_ba_data* d) {
+  if (!s || !d) return fail("thx_ba: null structure/data");
+  if (s->num_cams <= 0 || s->num_points <= 0 || d->batch <= 0) return fail("thx_ba: empty problem");
+  if (!d->cams || !d->points) return fail("thx_ba: null variables");
+  if (s->num_obs > 0 && (!d->feat || !d->w_obs || !d->focal || !d->k1 || !d->k2)) return fail("thx_ba: null observation data");
+  if (d->robust_obs < 0 || d->robust_obs > 2 || (d->robust_obs && !d->log_radius_obs)) return fail("thx_ba: bad robust loss");
+  if ((d->feat_bstride != 0 && d->feat_bstride != 2) || (d->w_obs_bstride != 0 && d->w_obs_bstride != 2) ||
+      (d->calib_bstride != 0 && d->calib_bstride != 1) || (d->cam_prior_target_bstride != 0 && d->cam_prior_target_bstride != 12) ||
+      (d->w_cam_prior_bstride != 0 && d->w_cam_prior_bstride != 6) || (d->pt_prior_target_bstride != 0 && d->pt_prior_target_bstride != 3) ||
+      (d->w_pt_prior_bstride != 0 && d->w_pt_prior_bstride != 3))
+    return fail("thx_ba: bad batch stride");
+  return 0;
+}
+
+}  // namespace thx
+
+using namespace thx;
+
+#define BA_LAUNCH(KERNEL, GRID, BLOCK, ...)                                                                   \
+  THX_DISPATCH(dtype, hipLaunchKernelGGL(KERNEL<float>, GRID, BLOCK, 0, as_stream(stream), __VA_ARGS__),      \
+               hipLaunchKernelGGL(KERNEL<double>, GRID, BLOCK, 0, as_stream(stream), __VA_ARGS__))
+
+extern "C" {
+
+int thx_ba_assemble(const thx_ba_structure* s, const thx_ba_data* d, void* Hcc, void* Hpp, void* W, void* g, void* diag,
+                    int64_t ldv, int dtype, const thx_lie_eps* eps, void* stream) {
+  if (int r = check_ba(s, d)) return r;
+  if (!Hcc || !Hpp || !g || !diag || !eps || (s->num_obs > 0 && !W)) return fail("thx_ba_assemble: null output");
+  if (ldv < 6 * (int64_t)s->num_cams + 3 * (int64_t)s->num_points) return fail("thx_ba_assemble: ldv < n");
+  const dim3 block(64), gp((d->batch + 63) / 64, s->num_points), gc((d->batch + 63) / 64, s->num_cams);
+  THX_DISPATCH(dtype,
+               {
+                 hipLaunchKernelGGL(ba_point_kernel<float>, gp, block, 0, as_stream(stream), *s, *d, (float*)Hpp, (float*)W,
+                                    (float*)g, (float*)diag, ldv);
+                 hipLaunchKernelGGL(ba_camera_kernel<float>, gc, block, 0, as_stream(stream), *s, *d, (float*)Hcc, (float*)g,
+                                    (float*)diag, ldv, make_eps<float>(eps));
+               },
+               {
+                 hipLaunchKernelGGL(ba_point_kernel<double>, gp, block, 0, as_stream(stream), *s, *d, (double*)Hpp,
+                                    (double*)W, (double*)g, (double*)diag, ldv);
+                 hipLaunchKernelGGL(ba_camera_kernel<double>, gc, block, 0, as_stream(stream), *s, *d, (double*)Hcc,
+                                    (double*)g, (double*)diag, ldv, make_eps<double>(eps));
+               });
+  return check_launch("thx_ba_assemble");
+}
+
+int thx_ba_schur(const thx_ba_structure* s, int32_t B, const void* Hcc, const void* Hpp, const void* W, const void* g,
+                 int64_t ldv, const void* damping, int ellipsoidal, double damping_eps, void* S, int64_t ld, void* rhs,
+                 int64_t ldr, void* Hinv, void* tvec, int32_t* info, int dtype, void* stream) {
+  if (!s || !Hcc || !Hpp || !g || !S || !rhs || !Hinv || !tvec || !info || B <= 0) return fail("thx_ba_schur: null argument");
+  if (ld < 6 * (int64_t)s->num_cams || ldr < 6 * (int64_t)s->num_cams) return fail("thx_ba_schur: ld < 6 C");
+  const dim3 block(64), gp((B + 63) / 64, s->num_points), gc((B + 63) / 64, s->num_cams);
+  hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)B, as_stream(stream));
+  THX_DISPATCH(dtype,
+               {
+                 hipLaunchKernelGGL(ba_point_invert_kernel<float>, gp, block, 0, as_stream(stream), *s, B, (const float*)Hpp,
+                                    (const float*)g, ldv, (const float*)damping, ellipsoidal, (float)damping_eps,
+                                    (float*)Hinv, (float*)tvec, info);
+                 hipLaunchKernelGGL(ba_schur_kernel<float>, gc, block, 0, as_stream(stream), *s, B, (const float*)Hcc,
+                                    (const float*)W, (const float*)g, ldv, (const float*)damping, ellipsoidal,
+                                    (float)damping_eps, (const float*)Hinv, (const float*)tvec, (float*)S, ld, (float*)rhs, ldr);
+               },
+               {
+                 hipLaunchKernelGGL(ba_point_invert_kernel<double>, gp, block, 0, as_stream(stream), *s, B,
+                                    (const double*)Hpp, (const double*)g, ldv, (const double*)damping, ellipsoidal,
+                                    damping_eps, (double*)Hinv, (double*)tvec, info);
+                 hipLaunchKernelGGL(ba_schur_kernel<double>, gc, block, 0, as_stream(stream), *s, B, (const double*)Hcc,
+                                    (const double*)W, (const double*)g, ldv, (const double*)damping, ellipsoidal, damping_eps,
+                                    (const double*)Hinv, (const double*)tvec, (double*)S, ld, (double*)rhs, ldr);
+               });
+  return check_launch("thx_ba_schur");
+}
+
+int thx_ba_backsub(const thx_ba_structure* s, int32_t B, const void* W, const void* Hinv, const void* tvec, void* delta,
+                   int64_t ldv, int dtype, void* stream) {
+  if (!s || !Hinv || !tvec || !delta || B <= 0 || (s->num_obs > 0 && !W)) return fail("thx_ba_backsub: null argument");
+  const dim3 block(64), gp((B + 63) / 64, s->num_points);
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(ba_backsub_kernel<float>, gp, block, 0, as_stream(stream), *s, B, (const float*)W,
+                                  (const float*)Hinv, (const float*)tvec, (float*)delta, ldv),
+               hipLaunchKernelGGL(ba_backsub_kernel<double>, gp, block, 0, as_stream(stream), *s, B, (const double*)W,
+                                  (const double*)Hinv, (const double*)tvec, (double*)delta, ldv));
+  return check_launch("thx_ba_backsub");
+}
+
+int thx_ba_error(const thx_ba_structure* s, const thx_ba_data* d, void* partials, void* err, int dtype,
+                 const thx_lie_eps* eps, void* stream) {
+  if (int r = check_ba(s, d)) return r;
+  if (!partials || !err || !eps) return fail("thx_ba_error: null output");
+  const dim3 block(64), grid((d->batch + 63) / 64, THX_ERR_CHUNKS);
+  const int B = d->batch;
+  THX_DISPATCH(dtype,
+               {
+                 hipLaunchKernelGGL(ba_error_partial_kernel<float>, grid, block, 0, as_stream(stream), *s, *d,
+                                    (float*)partials, make_eps<float>(eps));
+                 hipLaunchKernelGGL(ba_error_reduce_kernel<float>, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream),
+                                    (const float*)partials, (float*)err, B);
+               },
+               {
+                 hipLaunchKernelGGL(ba_error_partial_kernel<double>, grid, block, 0, as_stream(stream), *s, *d,
+                                    (double*)partials, make_eps<double>(eps));
+                 hipLaunchKernelGGL(ba_error_reduce_kernel<double>, dim3((B + 255) / 256), dim3(256), 0, as_stream(stream),
+                                    (const double*)partials, (double*)err, B);
+               });
+  return check_launch("thx_ba_error");
+}
+
+int thx_vec_retract(const void* x, const void* delta, int64_t ldd, int64_t col0, double step, const uint8_t* ignore_mask,
+                    void* out, int32_t N, int32_t dof, int32_t B, int dtype, void* stream) {
+  if (!x || !delta || !out || N <= 0 || dof <= 0 || B <= 0) return fail("thx_vec_retract: bad arguments");
+  const dim3 block(64), grid((B + 63) / 64, N);
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(vec_retract_kernel<float>, grid, block, 0, as_stream(stream), (const float*)x,
+                                  (const float*)delta, ldd, col0, (float)step, ignore_mask, (float*)out, N, dof, B),
+               hipLaunchKernelGGL(vec_retract_kernel<double>, grid, block, 0, as_stream(stream), (const double*)x,
+                                  (const double*)delta, ldd, col0, step, ignore_mask, (double*)out, N, dof, B));
+  return check_launch("thx_vec_retract");
+}
+
+int thx_lm_accept_diag(const void* delta, const void* g, const void* diag, int64_t ldv, int32_t n, int32_t B, void* damping,
+                       const void* prev_err, const void* new_err, int ellipsoidal, double accept, double down_ratio,
+                       double up_ratio, uint8_t* reject, int dtype, void* stream) {
+  if (!delta || !g || !damping || !prev_err || !new_err || !reject || (ellipsoidal && !diag))
+    return fail("thx_lm_accept_diag: null pointer");
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(lm_accept_diag_kernel<float>, dim3(B), dim3(64), 0, as_stream(stream), (const float*)delta,
+                                  (const float*)g, (const float*)diag, ldv, n, (float*)damping, (const float*)prev_err,
+                                  (const float*)new_err, ellipsoidal, (float)accept, (float)down_ratio, (float)up_ratio, reject),
+               hipLaunchKernelGGL(lm_accept_diag_kernel<double>, dim3(B), dim3(64), 0, as_stream(stream),
+                                  (const double*)delta, (const double*)g, (const double*)diag, ldv, n, (double*)damping,
+                                  (const double*)prev_err, (const double*)new_err, ellipsoidal, accept, down_ratio, up_ratio,
+                                  reject));
+  return check_launch("thx_lm_accept_diag");
+}
+
+}  // extern "C"

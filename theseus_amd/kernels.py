@@ -247,6 +247,47 @@ class HipKernels:
                                             _lib.ptr(ignore_mask), _lib.ptr(out), P, B, _lib.dtype_code(dt),
                                             lie_eps(dt), _lib.stream_ptr(poses.device)), "thx_se3_retract")
 
+    # ---- bundle adjustment (csrc/ba_kernels.hip) --------------------------------------------------
+    def ba_assemble(self, s, t, Hcc, Hpp, W, g, diag):
+        d = t.c_struct()
+        dt = g.dtype
+        _lib.check(self.lib.thx_ba_assemble(s.c, d, _lib.ptr(Hcc), _lib.ptr(Hpp), _lib.ptr(W), _lib.ptr(g), _lib.ptr(diag),
+                                            g.stride(0), _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(g.device)),
+                   "thx_ba_assemble")
+
+    def ba_schur(self, s, Hcc, Hpp, W, g, damping, ellipsoidal, damping_eps, S, rhs, Hinv, tvec, info):
+        B = g.shape[0]
+        _lib.check(self.lib.thx_ba_schur(s.c, B, _lib.ptr(Hcc), _lib.ptr(Hpp), _lib.ptr(W), _lib.ptr(g), g.stride(0),
+                                         _lib.ptr(damping), int(bool(ellipsoidal)), float(damping_eps), _lib.ptr(S),
+                                         S.shape[-1], _lib.ptr(rhs), rhs.stride(0), _lib.ptr(Hinv), _lib.ptr(tvec),
+                                         _lib.ptr(info), _lib.dtype_code(g.dtype), _lib.stream_ptr(g.device)), "thx_ba_schur")
+
+    def ba_backsub(self, s, W, Hinv, tvec, delta):
+        B = delta.shape[0]
+        _lib.check(self.lib.thx_ba_backsub(s.c, B, _lib.ptr(W), _lib.ptr(Hinv), _lib.ptr(tvec), _lib.ptr(delta),
+                                           delta.stride(0), _lib.dtype_code(delta.dtype), _lib.stream_ptr(delta.device)),
+                   "thx_ba_backsub")
+
+    def ba_error(self, s, t, partials, err, cams=None, points=None):
+        d = t.c_struct(cams, points)
+        dt = err.dtype
+        _lib.check(self.lib.thx_ba_error(s.c, d, _lib.ptr(partials), _lib.ptr(err), _lib.dtype_code(dt), lie_eps(dt),
+                                         _lib.stream_ptr(err.device)), "thx_ba_error")
+
+    def vec_retract(self, x, delta, col0, step, ignore_mask, out):
+        N, B, dof = x.shape
+        _lib.check(self.lib.thx_vec_retract(_lib.ptr(x), _lib.ptr(delta), delta.stride(0), int(col0), float(step),
+                                            _lib.ptr(ignore_mask), _lib.ptr(out), N, dof, B, _lib.dtype_code(x.dtype),
+                                            _lib.stream_ptr(x.device)), "thx_vec_retract")
+
+    def lm_accept_diag(self, delta, g, diag, n, damping, prev_err, new_err, ellipsoidal, accept, down, up, reject):
+        B = delta.shape[0]
+        _lib.check(self.lib.thx_lm_accept_diag(_lib.ptr(delta), _lib.ptr(g), _lib.ptr(diag), delta.stride(0), n, B,
+                                               _lib.ptr(damping), _lib.ptr(prev_err), _lib.ptr(new_err),
+                                               int(bool(ellipsoidal)), float(accept), float(down), float(up),
+                                               _lib.ptr(reject), _lib.dtype_code(delta.dtype),
+                                               _lib.stream_ptr(delta.device)), "thx_lm_accept_diag")
+
     # ---- generic block assembly ------------------------------------------------------------------
     def block_assemble(self, asm, jacobians, errors, H, g):
         """asm: theseus_amd.generic.BlockAssembler; jacobians[c][slot] (B|1, dim, dof), errors[c] (B|1, dim)."""

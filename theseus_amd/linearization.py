@@ -191,6 +191,10 @@ class HipLinearizationCore:
     def diagonal_scaling(self, v: torch.Tensor) -> torch.Tensor:
         return self.diagonal() * v
 
+    def lm_accept(self, delta, damping, prev_err, new_err, ellipsoidal, accept, down, up, reject):
+        """levenberg_marquardt.py:173-201 on the packed buffers (thx_lm_accept)."""
+        self.K.lm_accept(delta, self.g, self.H, self.n, damping, prev_err, new_err, ellipsoidal, accept, down, up, reject)
+
 
 class HipLinearization(HipLinearizationCore, Linearization):
     def __init__(self, objective: Objective, ordering: Optional[VariableOrdering] = None, kernels=None, **kwargs):

@@ -80,8 +80,11 @@ class NonlinearLeastSquares(abc.ABC):
                  linear_solver_kwargs: Optional[Dict[str, Any]] = None, abs_err_tolerance: float = 1e-10,
                  rel_err_tolerance: float = 1e-8, max_iterations: int = 20, step_size: float = 1.0, **kwargs):
         self.objective = objective
-        linear_solver_cls = linear_solver_cls or HipCholeskySolver
-        linearization_cls = linearization_cls or HipLinearization
+        if linear_solver_cls is None:
+            # bundle-adjustment objectives (SE3 cameras + Point3 points) default to the Schur-complement solver
+            from .ba import HipSchurSolver
+            kinds = {type(v).__name__ for v in objective.optim_vars.values()}
+            linear_solver_cls = HipSchurSolver if "Point3" in kinds else HipCholeskySolver
         self.linear_solver = linear_solver_cls(objective, linearization_cls=linearization_cls,
                                                linearization_kwargs=linearization_kwargs,
                                                **(linear_solver_kwargs or {}))
@@ -153,7 +156,7 @@ class NonlinearLeastSquares(abc.ABC):
         with torch.no_grad():
             packed.sync()
             B = packed.batch
-            dev, dt = packed.tensors.poses.device, self.objective.dtype
+            dev, dt = packed.device, self.objective.dtype
             p = self.params
             last_err = packed.error_metric()
             err_hist = None
@@ -165,7 +168,7 @@ class NonlinearLeastSquares(abc.ABC):
                 converged_iter=torch.full((B,), -1, dtype=torch.long), best_iter=torch.zeros(B, dtype=torch.long),
                 err_history=err_hist, last_err=last_err, best_err=last_err.clone())
             if track_best_solution:
-                best_poses = packed.tensors.poses.clone()
+                best_state = packed.clone_state()
                 best_err = last_err.clone()
             if verbose:
                 print(f"Nonlinear optimizer. Iteration: 0. Error: {last_err.mean().item()}")
@@ -173,7 +176,7 @@ class NonlinearLeastSquares(abc.ABC):
             need_conv = p.abs_err_tolerance > 0 or p.rel_err_tolerance > 0
             converged = None          # (B,) bool on device, None == nobody
             conv_iter = torch.full((B,), -1, dtype=torch.long, device=dev)
-            spare = torch.empty_like(packed.tensors.poses)
+            spare = packed.alloc_state()
             err_new = torch.empty(B, dtype=dt, device=dev)
             it, all_reject_attempts = 0, 0
             while it < loop_iters:
@@ -187,7 +190,7 @@ class NonlinearLeastSquares(abc.ABC):
                     break
                 # retract (converged problems frozen) + error of the candidate, fused HIP kernels
                 packed.retract(delta, p.step_size, converged, spare)
-                packed.error_metric(poses=spare, out=err_new)
+                packed.error_metric(state=spare, out=err_new)
                 reject = self._complete_step(delta, err_new, last_err, step_size=p.step_size, **kwargs)
                 # ---- the only host sync of the iteration: [solver failed | all rejected, any rejected], over
                 #      the GLOBAL batch (self.reducer all-reduces across shards when the batch is sharded) ----
@@ -217,24 +220,20 @@ class NonlinearLeastSquares(abc.ABC):
                     else:
                         if any_rej:
                             rb = reject.bool()
-                            torch.where(rb.view(1, B, 1, 1), packed.tensors.poses, spare, out=spare)
+                            packed.keep_where(rb, spare)
                             err = torch.where(rb, last_err, err_new)
                         else:
                             err = err_new.clone()
-                        old = packed.tensors.poses
-                        packed.set_poses(spare, repoint=False)
-                        spare = old
+                        spare = packed.swap_state(spare)
                 else:
                     err = err_new.clone()
-                    old = packed.tensors.poses
-                    packed.set_poses(spare, repoint=False)
-                    spare = old
+                    spare = packed.swap_state(spare)
                 all_reject_attempts = 0
                 if err_hist is not None:
                     err_hist[:, it + 1] = err
                 if track_best_solution:
                     better = err < best_err
-                    torch.where(better.view(1, B, 1, 1), packed.tensors.poses, best_poses, out=best_poses)
+                    packed.copy_where(better, packed.state, best_state)
                     best_err = torch.where(better, err, best_err)
                 if verbose:
                     print(f"Nonlinear optimizer. Iteration: {it + 1}. Error: {err.mean().item()}")
@@ -259,13 +258,13 @@ class NonlinearLeastSquares(abc.ABC):
             #      executed under the caller's grad mode (nonlinear_least_squares.py:121-135,265-292) ----
             if implicit and not (info.status == NonlinearOptimizerStatus.FAIL).any():
                 X_new, delta = self._implicit_last_step(packed, outer_grad, kwargs)
-                err = packed.error_metric(poses=X_new.detach())
-                packed.set_poses(X_new, repoint=False)
+                err = packed.error_metric(state=X_new.detach())
+                packed.swap_state(X_new)
                 if err_hist is not None:
                     err_hist[:, it + 1] = err
                 if track_best_solution:
                     better = err < best_err
-                    torch.where(better.view(1, B, 1, 1), X_new.detach(), best_poses, out=best_poses)
+                    packed.copy_where(better, X_new.detach(), best_state)
                     best_err = torch.where(better, err, best_err)
                 if need_conv:
                     converged = self._check_convergence(err, last_err)
@@ -289,7 +288,7 @@ class NonlinearLeastSquares(abc.ABC):
                 info.err_history = err_hist.cpu()
             if track_best_solution:
                 info.best_err = best_err
-                info.best_solution = {v.name: best_poses[k].cpu() for k, v in enumerate(packed.pose_vars)}
+                info.best_solution = packed.solution_dict(best_state)
         return info
 
     def _needs_grad(self):
@@ -332,9 +331,9 @@ class LevenbergMarquardt(NonlinearLeastSquares):
         packed = self.linear_solver.linearization.packed
         packed.sync()
         if adaptive_damping:
-            self._damping = damping * torch.ones(packed.batch, device=packed.tensors.poses.device,
+            self._damping = damping * torch.ones(packed.batch, device=packed.device,
                                                  dtype=self.objective.dtype)
-            self._reject = torch.zeros(packed.batch, dtype=torch.uint8, device=packed.tensors.poses.device)
+            self._reject = torch.zeros(packed.batch, dtype=torch.uint8, device=packed.device)
         else:
             self._damping = damping
 
@@ -353,6 +352,6 @@ class LevenbergMarquardt(NonlinearLeastSquares):
             return None
         lin = self.linear_solver.linearization
         d = delta if step_size == 1.0 else delta * step_size
-        lin.K.lm_accept(d, lin.g, lin.H, lin.n, self._damping, previous_err, new_err, ellipsoidal_damping,
-                        damping_accept, down_damping_ratio, up_damping_ratio, self._reject)
+        lin.lm_accept(d, self._damping, previous_err, new_err, ellipsoidal_damping, damping_accept, down_damping_ratio,
+                      up_damping_ratio, self._reject)
         return self._reject

@@ -217,6 +217,43 @@ class PackedPoseGraph:
         if self._vars_stale and self.tensors is not None:
             self._repoint_variables()
 
+    # ---- optimisation state: what the LM loop moves around (here: the packed pose buffer) --------------
+    @property
+    def state(self):
+        return self.tensors.poses
+
+    @property
+    def device(self):
+        return self.tensors.poses.device
+
+    @property
+    def optim_variables(self):
+        return self.pose_vars
+
+    def alloc_state(self):
+        return torch.empty_like(self.tensors.poses)
+
+    def clone_state(self):
+        return self.tensors.poses.clone()
+
+    def swap_state(self, new, repoint: bool = False):
+        """Adopt ``new`` as the current state; returns the previous buffer for re-use."""
+        old = self.tensors.poses
+        self.set_poses(new, repoint=repoint)
+        return old
+
+    def keep_where(self, mask: torch.Tensor, out):
+        """out <- current state where mask (B,), else out."""
+        torch.where(mask.view(1, -1, *([1] * (out.dim() - 2))), self.tensors.poses, out, out=out)
+
+    @staticmethod
+    def copy_where(mask: torch.Tensor, src, dst):
+        """dst <- src where mask (B,)."""
+        torch.where(mask.view(1, -1, *([1] * (dst.dim() - 2))), src, dst, out=dst)
+
+    def solution_dict(self, state):
+        return {v.name: state[k].cpu() for k, v in enumerate(self.pose_vars)}
+
     # ---- scratch ------------------------------------------------------------------------------
     def _buf(self, key, shape, dtype=None):
         t = self._scratch.get(key)
@@ -240,8 +277,9 @@ class PackedPoseGraph:
         self.sync()
         self.K.pg_assemble(self.dstruct, self.tensors, H, g)
 
-    def error_metric(self, poses: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    def error_metric(self, poses: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, state=None):
         self.sync()
+        poses = state if state is not None else poses
         B = self.batch
         part = self._buf("err_part", (ERR_CHUNKS, B))
         err = out if out is not None else torch.empty(B, dtype=self.objective.dtype, device=part.device)
