@@ -241,7 +241,10 @@ int thx_pg_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, i
  *        delta_p = Hpp'^-1 (gp - Hpc delta_c);   ' = damping applied (dense_solver.py:38-64).
  *      Internal column order: cameras (6 each) then points (3 each); g / delta / diag are (B, n), n = 6C + 3Np.
  *      Layouts (entity major, batch fastest): cams (C,B,3,4), points (Np,B,3), Hcc (C,B,6,6), Hpp (Np,B,6) =
- *      [xx,xy,xz,yy,yz,zz], W (O,B,6,3) = Jc^T Jp per observation, Hinv (Np,B,6), tvec (B,3Np). */
+ *      [xx,xy,xz,yy,yz,zz], W (O,B,6,3) = Jc^T Jp per observation, Hinv (Np,B,6), tvec (B,3Np), gd (B,n).
+ *      PRECISION: the block quantities Hcc, Hpp, W, gd, Hinv, tvec are ALWAYS fp64 buffers, whatever `dtype` is: the
+ *      Schur complement subtracts quantities of the size of Hcc from Hcc, so fp32 blocks would put fp32 rounding of
+ *      |Hcc| -- not of |S| -- into S.  S, rhs, g, diag, delta are `dtype` (S feeds the fp32 / fp64 MFMA Cholesky). */
 typedef struct {
   int32_t num_cams, num_points, num_obs, num_cam_priors, num_pt_priors, num_pairs;
   const int32_t* obs_cam;       /* (O) */
@@ -287,13 +290,13 @@ typedef struct {
   int64_t w_pt_prior_bstride;
 } thx_ba_data;
 
-/* linearize: Hcc, Hpp, W, g = [gc | gp] (row stride ldv), diag = diag(H) (row stride ldv) */
-int thx_ba_assemble(const thx_ba_structure* s, const thx_ba_data* d, void* Hcc, void* Hpp, void* W, void* g, void* diag,
-                    int64_t ldv, int dtype, const thx_lie_eps* eps, void* stream);
+/* linearize: Hcc, Hpp, W, gd (fp64) and g = [gc | gp], diag = diag(H) (dtype); row stride ldv for gd, g, diag */
+int thx_ba_assemble(const thx_ba_structure* s, const thx_ba_data* d, void* Hcc, void* Hpp, void* W, void* gd, void* g,
+                    void* diag, int64_t ldv, int dtype, const thx_lie_eps* eps, void* stream);
 /* Schur complement with the damping of DenseSolver._apply_damping: writes the lower blocks of S (B, ld, ld) (zero-filled
  * once by the caller: fixed pattern), rhs (B, 6C) (row stride ldr), Hinv, tvec; info[b] != 0 if a damped point block is
  * not positive definite. */
-int thx_ba_schur(const thx_ba_structure* s, int32_t B, const void* Hcc, const void* Hpp, const void* W, const void* g,
+int thx_ba_schur(const thx_ba_structure* s, int32_t B, const void* Hcc, const void* Hpp, const void* W, const void* gd,
                  int64_t ldv, const void* damping, int ellipsoidal, double damping_eps, void* S, int64_t ld, void* rhs,
                  int64_t ldr, void* Hinv, void* tvec, int32_t* info, int dtype, void* stream);
 /* delta_p = tvec - Hinv Hpc delta_c, written to delta[:, 6C:] (delta_c = delta[:, :6C] is read) */

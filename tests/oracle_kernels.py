@@ -121,7 +121,7 @@ class OracleKernels:
             robust_obs=LOSS[t.robust_obs], log_radius_obs=bm(t.log_radius_obs) if t.robust_obs else None)
         return p, (bm(t.cams if cams is None else cams), bm(t.points if points is None else points))
 
-    def ba_assemble(self, s, t, Hcc, Hpp, W, g, diag):
+    def ba_assemble(self, s, t, Hcc, Hpp, W, gd, g, diag):
         p, state = self._ba_problem(s, t)
         Jc, Jp, e, _, Jcp, ecp, ept = p.terms(state)
         B, C, Np = state[0].shape[0], p.num_cams, p.num_points
@@ -140,6 +140,7 @@ class OracleKernels:
             W[:p.obs_cam.numel()].copy_((Jc.transpose(2, 3) @ Jp).transpose(0, 1))
         g[:, :6 * C] = gc.reshape(B, -1)
         g[:, 6 * C:] = gp.reshape(B, -1)
+        gd.copy_(g)
         diag[:, :6 * C] = hcc.diagonal(dim1=2, dim2=3).reshape(B, -1)
         diag[:, 6 * C:] = hpp.diagonal(dim1=2, dim2=3).reshape(B, -1)
 

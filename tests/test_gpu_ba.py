@@ -25,11 +25,29 @@ def test_ba_first_linear_system_matches_reference(name):
     lin.linearize()
     cols, _ = reference_columns(g)
     Atb, AtA = g["Atb"][0][..., 0], g["AtA"][0]
-    tol = 3e-5 if f32 else 1e-11
-    np.testing.assert_allclose(lin.g.cpu().numpy()[:, cols], Atb, rtol=0, atol=tol * np.abs(Atb).max())
     dref = np.diagonal(AtA, axis1=1, axis2=2)
-    np.testing.assert_allclose(lin.diag.cpu().numpy()[:, cols], dref, rtol=tol * 10, atol=tol * np.abs(dref).max())
-    np.testing.assert_allclose(obj.error_metric().cpu().numpy(), g["err0"], rtol=3e-5 if f32 else 1e-12)
+    got_g, got_d = lin.g.cpu().numpy()[:, cols], lin.diag.cpu().numpy()[:, cols]
+    if f32:
+        # the reference's fp32 evaluation is itself a noisy draw (7e-4 relative on single entries of A^T b here): compare
+        # with the exact values of the same fp32 inputs and require us to be inside the reference's own band
+        import dataclasses
+        p, state0, _, _ = ba_problem(g)
+        p64 = dataclasses.replace(p, **{f.name: getattr(p, f.name).double() for f in dataclasses.fields(p)
+                                        if isinstance(getattr(p, f.name), torch.Tensor) and getattr(p, f.name).is_floating_point()})
+        with f32_thresholds():
+            A, b = p64.dense_linearize((state0[0].double(), state0[1].double()))
+            H64, g64 = opg.hessian(A, b)
+            e64 = p64.error_metric((state0[0].double(), state0[1].double())).numpy()
+        g64, d64 = g64[..., 0].numpy(), H64.diagonal(dim1=1, dim2=2).numpy()
+        for got, ref32, exact in ((got_g, Atb, g64), (got_d, dref, d64)):
+            sc = np.abs(exact).max()
+            assert np.abs(got - exact).max() <= 3e-7 * sc
+            assert np.abs(got - ref32).max() <= np.abs(ref32 - exact).max() + 3e-7 * sc
+        np.testing.assert_allclose(obj.error_metric().cpu().numpy(), e64, rtol=3e-7)
+    else:
+        np.testing.assert_allclose(got_g, Atb, rtol=0, atol=1e-11 * np.abs(Atb).max())
+        np.testing.assert_allclose(got_d, dref, rtol=1e-10, atol=1e-11 * np.abs(dref).max())
+        np.testing.assert_allclose(obj.error_metric().cpu().numpy(), g["err0"], rtol=1e-12)
     import ast
     kw = ast.literal_eval(str(g["opt_kwargs"]))
     if kw["gauss_newton"]:

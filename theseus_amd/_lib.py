@@ -94,8 +94,8 @@ _SIGNATURES = {
     "thx_se2_retract": [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p, c_int32, c_int32, c_int,
                         POINTER(SE2Eps), c_void_p],
     "thx_se2_op": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(SE2Eps), c_void_p],
-    "thx_ba_assemble": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
-                        POINTER(LieEps), c_void_p],
+    "thx_ba_assemble": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                        c_int, POINTER(LieEps), c_void_p],
     "thx_ba_schur": [POINTER(BAStructure), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_double,
                      c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "thx_ba_backsub": [POINTER(BAStructure), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],

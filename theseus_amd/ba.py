@@ -383,7 +383,7 @@ class HipSchurLinearization(Linearization):
             ordering.append(v)
         Linearization.__init__(self, objective, ordering)
         self.packed, self.K = packed, packed.K
-        self.Hcc = self.Hpp = self.W = self.g = self.diag = None
+        self.Hcc = self.Hpp = self.W = self.gd = self.g = self.diag = None
 
     @property
     def n(self):
@@ -396,14 +396,16 @@ class HipSchurLinearization(Linearization):
         dev, dt = p.device, self.objective.dtype
         if self.g is None or self.g.shape[0] != B or self.g.device != dev or self.g.dtype != dt:
             new = lambda *sh: torch.empty(*sh, dtype=dt, device=dev)  # noqa: E731
-            self.Hcc, self.Hpp = new(s.num_cams, B, 6, 6), new(s.num_points, B, 6)
-            self.W = new(max(s.num_obs, 1), B, 6, 3)
+            f64 = lambda *sh: torch.empty(*sh, dtype=torch.float64, device=dev)  # noqa: E731
+            # block quantities in fp64 for every dtype: the Schur complement cancels at the scale of Hcc
+            self.Hcc, self.Hpp = f64(s.num_cams, B, 6, 6), f64(s.num_points, B, 6)
+            self.W, self.gd = f64(max(s.num_obs, 1), B, 6, 3), f64(B, p.n)
             self.g, self.diag = new(B, p.n), new(B, p.n)
 
     def _assemble(self):
         self._ensure_buffers()
         p = self.packed
-        self.K.ba_assemble(p.dstruct, p.tensors, self.Hcc, self.Hpp, self.W, self.g, self.diag)
+        self.K.ba_assemble(p.dstruct, p.tensors, self.Hcc, self.Hpp, self.W, self.gd, self.g, self.diag)
 
     def _linearize_jacobian_impl(self):
         raise NotImplementedError("the dense Jacobian of a bundle-adjustment objective is not materialised")
@@ -456,7 +458,8 @@ class HipSchurSolver(LinearSolver):
             self.L = torch.zeros_like(self.S)
             self.panels = torch.empty(B, nt, _lib.THX_TILE, _lib.THX_TILE, dtype=dt, device=dev)
             self.rhs, self._y, self._dc = (torch.empty(B, nc, dtype=dt, device=dev) for _ in range(3))
-            self.Hinv, self.tvec = torch.empty(s.num_points, B, 6, dtype=dt, device=dev), torch.empty(B, 3 * s.num_points, dtype=dt, device=dev)
+            self.Hinv = torch.empty(s.num_points, B, 6, dtype=torch.float64, device=dev)
+            self.tvec = torch.empty(B, 3 * s.num_points, dtype=torch.float64, device=dev)
             self.delta = torch.empty(B, lin.n, dtype=dt, device=dev)
             self.info_chol = torch.zeros(B, dtype=torch.int32, device=dev)
             self.info_pts = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -491,7 +494,7 @@ class HipSchurSolver(LinearSolver):
                 lam.fill_(float(damping))
         p = lin.packed
         self.factor_version += 1
-        self.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, lin.g, lam, ellipsoidal_damping, damping_eps, self.S, self.rhs,
+        self.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, lin.gd, lam, ellipsoidal_damping, damping_eps, self.S, self.rhs,
                         self.Hinv, self.tvec, self.info_pts)
         self.K.chol_factor(self.S, p.nc, None, False, damping_eps, self.L, self.panels, self.info_chol, rhs=self.rhs, y=self._y)
         self.K.chol_solve_backward(self.L, p.nc, self.panels, self._y, self._dc)

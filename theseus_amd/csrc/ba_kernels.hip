@@ -105,8 +105,8 @@ __device__ __forceinline__ void robustify_obs(int kind, double lr, Reproj& r, bo
 // ---- pass A: one lane per (point, problem): Hpp, gp, W = Jc^T Jp of the point's observations ----
 template <typename T>
 __global__ void __launch_bounds__(64)
-ba_point_kernel(thx_ba_structure s, thx_ba_data d, T* __restrict__ Hpp, T* __restrict__ W, T* __restrict__ g,
-                T* __restrict__ diag, int64_t ldv) {
+ba_point_kernel(thx_ba_structure s, thx_ba_data d, double* __restrict__ Hpp, double* __restrict__ W,
+                double* __restrict__ gd, T* __restrict__ g, T* __restrict__ diag, int64_t ldv) {
   const int b = blockIdx.x * 64 + threadIdx.x, p = blockIdx.y, B = d.batch;
   if (b >= B) return;
   const T* Xp = static_cast<const T*>(d.points) + ((int64_t)p * B + b) * 3;
@@ -128,11 +128,11 @@ ba_point_kernel(thx_ba_structure s, thx_ba_data d, T* __restrict__ Hpp, T* __res
     h[5] += r.Jp[2] * r.Jp[2] + r.Jp[5] * r.Jp[5];
 #pragma unroll
     for (int i = 0; i < 3; ++i) gp[i] -= r.Jp[i] * r.e[0] + r.Jp[3 + i] * r.e[1];
-    T* Wo = W + ((int64_t)o * B + b) * 18;
+    double* Wo = W + ((int64_t)o * B + b) * 18;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) Wo[3 * i + j] = (T)(r.Jc[i] * r.Jp[j] + r.Jc[6 + i] * r.Jp[3 + j]);
+      for (int j = 0; j < 3; ++j) Wo[3 * i + j] = r.Jc[i] * r.Jp[j] + r.Jc[6 + i] * r.Jp[3 + j];
   }
   for (int k = s.pt_prior_ptr[p]; k < s.pt_prior_ptr[p + 1]; ++k) {
     const int id = s.pt_prior_id[k];
@@ -148,12 +148,14 @@ ba_point_kernel(thx_ba_structure s, thx_ba_data d, T* __restrict__ Hpp, T* __res
       gp[i] -= w * e;
     }
   }
-  T* Hp = Hpp + ((int64_t)p * B + b) * 6;
+  double* Hp = Hpp + ((int64_t)p * B + b) * 6;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) Hp[i] = (T)h[i];
+  for (int i = 0; i < 6; ++i) Hp[i] = h[i];
   const int64_t col = 6 * (int64_t)s.num_cams + 3 * p;
   T* gb = g + (int64_t)b * ldv + col;
   T* db = diag + (int64_t)b * ldv + col;
+  double* gdb = gd + (int64_t)b * ldv + col;
+  gdb[0] = gp[0]; gdb[1] = gp[1]; gdb[2] = gp[2];
   gb[0] = (T)gp[0]; gb[1] = (T)gp[1]; gb[2] = (T)gp[2];
   db[0] = (T)h[0]; db[1] = (T)h[3]; db[2] = (T)h[5];
 }
@@ -161,8 +163,8 @@ ba_point_kernel(thx_ba_structure s, thx_ba_data d, T* __restrict__ Hpp, T* __res
 // ---- pass B: one lane per (camera, problem): Hcc, gc ----
 template <typename T>
 __global__ void __launch_bounds__(64)
-ba_camera_kernel(thx_ba_structure s, thx_ba_data d, T* __restrict__ Hcc, T* __restrict__ g, T* __restrict__ diag,
-                 int64_t ldv, Eps<T> eps) {
+ba_camera_kernel(thx_ba_structure s, thx_ba_data d, double* __restrict__ Hcc, double* __restrict__ gd, T* __restrict__ g,
+                 T* __restrict__ diag, int64_t ldv, Eps<T> eps) {
   const int b = blockIdx.x * 64 + threadIdx.x, c = blockIdx.y, B = d.batch;
   if (b >= B) return;
   const T* cp = static_cast<const T*>(d.cams) + ((int64_t)c * B + b) * 12;
@@ -202,13 +204,15 @@ ba_camera_kernel(thx_ba_structure s, thx_ba_data d, T* __restrict__ Hcc, T* __re
     sjac_tmul_acc(Jd, Jd, Hc);
     sjac_tvec_sub(Jd, ev, gc);
   }
-  T* Ho = Hcc + ((int64_t)c * B + b) * 36;
+  double* Ho = Hcc + ((int64_t)c * B + b) * 36;
 #pragma unroll
-  for (int i = 0; i < 36; ++i) Ho[i] = (T)Hc[i];
+  for (int i = 0; i < 36; ++i) Ho[i] = Hc[i];
   T* gb = g + (int64_t)b * ldv + 6 * c;
   T* db = diag + (int64_t)b * ldv + 6 * c;
+  double* gdb = gd + (int64_t)b * ldv + 6 * c;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
+    gdb[i] = gc[i];
     gb[i] = (T)gc[i];
     db[i] = (T)Hc[7 * i];
   }
@@ -217,20 +221,19 @@ ba_camera_kernel(thx_ba_structure s, thx_ba_data d, T* __restrict__ Hcc, T* __re
 // ---- Schur 1: damped point blocks inverted, t = Hpp'^-1 gp ----
 template <typename T>
 __global__ void __launch_bounds__(64)
-ba_point_invert_kernel(thx_ba_structure s, int B, const T* __restrict__ Hpp, const T* __restrict__ g, int64_t ldv,
-                       const T* __restrict__ damping, int ellipsoidal, T eps, T* __restrict__ Hinv, T* __restrict__ tvec,
-                       int32_t* __restrict__ info) {
+ba_point_invert_kernel(thx_ba_structure s, int B, const double* __restrict__ Hpp, const double* __restrict__ g, int64_t ldv,
+                       const T* __restrict__ damping, int ellipsoidal, T eps, double* __restrict__ Hinv,
+                       double* __restrict__ tvec, int32_t* __restrict__ info) {
   const int b = blockIdx.x * 64 + threadIdx.x, p = blockIdx.y;
   if (b >= B) return;
-  const T* Hp = Hpp + ((int64_t)p * B + b) * 6;
-  // the damping is applied in T like DenseSolver._apply_damping does on the T-valued Hessian
-  T hd[3] = {Hp[0], Hp[3], Hp[5]};
-  if (damping) {
-    const T lam = damping[b];
+  const double* Hp = Hpp + ((int64_t)p * B + b) * 6;
+  double hd[3] = {Hp[0], Hp[3], Hp[5]};
+  if (damping) {  // DenseSolver._apply_damping (dense_solver.py:38-64)
+    const double lam = (double)damping[b];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) hd[i] = ellipsoidal ? hd[i] + (lam * hd[i] + eps) : hd[i] + lam;
+    for (int i = 0; i < 3; ++i) hd[i] = ellipsoidal ? hd[i] + (lam * hd[i] + (double)eps) : hd[i] + lam;
   }
-  const double a = (double)hd[0], bb = (double)Hp[1], c = (double)Hp[2], dd = (double)hd[1], e = (double)Hp[4], f = (double)hd[2];
+  const double a = hd[0], bb = Hp[1], c = Hp[2], dd = hd[1], e = Hp[4], f = hd[2];
   // adjugate of the symmetric 3x3 [[a,b,c],[b,d,e],[c,e,f]]
   const double A = dd * f - e * e, Bc = c * e - bb * f, C = bb * e - c * dd;
   const double det = a * A + bb * Bc + c * C;
@@ -238,15 +241,15 @@ ba_point_invert_kernel(thx_ba_structure s, int B, const T* __restrict__ Hpp, con
   if (!(a > 0.0) || !(m2 > 0.0) || !(det > 0.0)) info[b] = 6 * s.num_cams + 3 * p + 1;  // any writer: value only flags failure
   const double id = 1.0 / det;
   const double inv[6] = {A * id, Bc * id, C * id, (a * f - c * c) * id, (bb * c - a * e) * id, m2 * id};
-  T* Ho = Hinv + ((int64_t)p * B + b) * 6;
+  double* Ho = Hinv + ((int64_t)p * B + b) * 6;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) Ho[i] = (T)inv[i];
-  const T* gp = g + (int64_t)b * ldv + 6 * (int64_t)s.num_cams + 3 * p;
-  const double g0 = (double)gp[0], g1 = (double)gp[1], g2 = (double)gp[2];
-  T* tp = tvec + (int64_t)b * (3 * (int64_t)s.num_points) + 3 * p;
-  tp[0] = (T)(inv[0] * g0 + inv[1] * g1 + inv[2] * g2);
-  tp[1] = (T)(inv[1] * g0 + inv[3] * g1 + inv[4] * g2);
-  tp[2] = (T)(inv[2] * g0 + inv[4] * g1 + inv[5] * g2);
+  for (int i = 0; i < 6; ++i) Ho[i] = inv[i];
+  const double* gp = g + (int64_t)b * ldv + 6 * (int64_t)s.num_cams + 3 * p;
+  const double g0 = gp[0], g1 = gp[1], g2 = gp[2];
+  double* tp = tvec + (int64_t)b * (3 * (int64_t)s.num_points) + 3 * p;
+  tp[0] = inv[0] * g0 + inv[1] * g1 + inv[2] * g2;
+  tp[1] = inv[1] * g0 + inv[3] * g1 + inv[4] * g2;
+  tp[2] = inv[2] * g0 + inv[4] * g1 + inv[5] * g2;
 }
 
 // M (6x3) = W (6x3) * Hinv (sym 3x3)
@@ -263,33 +266,34 @@ __device__ __forceinline__ void w_times_sym(const double* W, const double* h, do
 // ---- Schur 2: one lane per (camera c1, problem): block row c1 of S (columns c2 <= c1) and rhs_c1 ----
 template <typename T>
 __global__ void __launch_bounds__(64)
-ba_schur_kernel(thx_ba_structure s, int B, const T* __restrict__ Hcc, const T* __restrict__ W, const T* __restrict__ g,
-                int64_t ldv, const T* __restrict__ damping, int ellipsoidal, T eps, const T* __restrict__ Hinv,
-                const T* __restrict__ tvec, T* __restrict__ S, int64_t ld, T* __restrict__ rhs, int64_t ldr) {
+ba_schur_kernel(thx_ba_structure s, int B, const double* __restrict__ Hcc, const double* __restrict__ W,
+                const double* __restrict__ g, int64_t ldv, const T* __restrict__ damping, int ellipsoidal, T eps,
+                const double* __restrict__ Hinv, const double* __restrict__ tvec, T* __restrict__ S, int64_t ld,
+                T* __restrict__ rhs, int64_t ldr) {
   const int b = blockIdx.x * 64 + threadIdx.x, c1 = blockIdx.y;
   if (b >= B) return;
   double Dg[36], Off[36], rv[6];
-  const T* Hc = Hcc + ((int64_t)c1 * B + b) * 36;
+  const double* Hc = Hcc + ((int64_t)c1 * B + b) * 36;
 #pragma unroll
-  for (int i = 0; i < 36; ++i) { Dg[i] = (double)Hc[i]; Off[i] = 0.0; }
+  for (int i = 0; i < 36; ++i) { Dg[i] = Hc[i]; Off[i] = 0.0; }
   if (damping) {
-    const T lam = damping[b];
+    const double lam = (double)damping[b];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const T h = Hc[7 * i];
-      Dg[7 * i] = (double)(ellipsoidal ? h + (lam * h + eps) : h + lam);
+      const double h = Hc[7 * i];
+      Dg[7 * i] = ellipsoidal ? h + (lam * h + (double)eps) : h + lam;
     }
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) rv[i] = (double)g[(int64_t)b * ldv + 6 * c1 + i];
+  for (int i = 0; i < 6; ++i) rv[i] = g[(int64_t)b * ldv + 6 * c1 + i];
   // rhs -= sum_o W_o t_p(o)
   for (int k = s.cam_ptr[c1]; k < s.cam_ptr[c1 + 1]; ++k) {
     const int o = s.cam_obs[k], p = s.obs_pt[o];
-    const T* Wo = W + ((int64_t)o * B + b) * 18;
-    const T* tp = tvec + (int64_t)b * (3 * (int64_t)s.num_points) + 3 * p;
-    const double t0 = (double)tp[0], t1 = (double)tp[1], t2 = (double)tp[2];
+    const double* Wo = W + ((int64_t)o * B + b) * 18;
+    const double* tp = tvec + (int64_t)b * (3 * (int64_t)s.num_points) + 3 * p;
+    const double t0 = tp[0], t1 = tp[1], t2 = tp[2];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) rv[i] -= (double)Wo[3 * i] * t0 + (double)Wo[3 * i + 1] * t1 + (double)Wo[3 * i + 2] * t2;
+    for (int i = 0; i < 6; ++i) rv[i] -= Wo[3 * i] * t0 + Wo[3 * i + 1] * t1 + Wo[3 * i + 2] * t2;
   }
   T* Sb = S + (int64_t)b * ld * ld;
   auto flush = [&](int c2) __attribute__((always_inline)) {
@@ -303,20 +307,20 @@ ba_schur_kernel(thx_ba_structure s, int B, const T* __restrict__ Hcc, const T* _
     const int o1 = s.pair_o1[k], o2 = s.pair_o2[k], c2 = s.pair_c2[k];
     const int p = s.obs_pt[o1];
     double W1[18], W2[18], h[6], M[18];
-    const T* W1p = W + ((int64_t)o1 * B + b) * 18;
-    const T* W2p = W + ((int64_t)o2 * B + b) * 18;
-    const T* hp = Hinv + ((int64_t)p * B + b) * 6;
+    const double* W1p = W + ((int64_t)o1 * B + b) * 18;
+    const double* W2p = W + ((int64_t)o2 * B + b) * 18;
+    const double* hp = Hinv + ((int64_t)p * B + b) * 6;
 #pragma unroll
-    for (int i = 0; i < 18; ++i) { W1[i] = (double)W1p[i]; W2[i] = (double)W2p[i]; }
+    for (int i = 0; i < 18; ++i) { W1[i] = W1p[i]; W2[i] = W2p[i]; }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) h[i] = (double)hp[i];
+    for (int i = 0; i < 6; ++i) h[i] = hp[i];
     w_times_sym(W1, h, M);
-    if (c2 != cur && c2 != c1) {
-      if (cur >= 0 && cur != c1) flush(cur);
+    if (c2 != c1 && c2 != cur) {  // a new off-diagonal block (pairs are sorted by c2; the diagonal ones come last)
+      if (cur >= 0) flush(cur);
 #pragma unroll
       for (int i = 0; i < 36; ++i) Off[i] = 0.0;
+      cur = c2;
     }
-    cur = c2;
     double* dst = c2 == c1 ? Dg : Off;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
@@ -324,7 +328,7 @@ ba_schur_kernel(thx_ba_structure s, int B, const T* __restrict__ Hcc, const T* _
       for (int c = 0; c < 6; ++c)
         dst[6 * r + c] -= M[3 * r] * W2[3 * c] + M[3 * r + 1] * W2[3 * c + 1] + M[3 * r + 2] * W2[3 * c + 2];
   }
-  if (cur >= 0 && cur != c1) flush(cur);
+  if (cur >= 0) flush(cur);
 #pragma unroll
   for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -336,30 +340,29 @@ ba_schur_kernel(thx_ba_structure s, int B, const T* __restrict__ Hcc, const T* _
 // ---- back substitution: delta_p = t_p - Hinv_p sum_o W_o^T delta_c(o) ----
 template <typename T>
 __global__ void __launch_bounds__(64)
-ba_backsub_kernel(thx_ba_structure s, int B, const T* __restrict__ W, const T* __restrict__ Hinv,
-                  const T* __restrict__ tvec, T* __restrict__ delta, int64_t ldv) {
+ba_backsub_kernel(thx_ba_structure s, int B, const double* __restrict__ W, const double* __restrict__ Hinv,
+                  const double* __restrict__ tvec, T* __restrict__ delta, int64_t ldv) {
   const int b = blockIdx.x * 64 + threadIdx.x, p = blockIdx.y;
   if (b >= B) return;
   double acc[3] = {0, 0, 0};
   for (int k = s.pt_ptr[p]; k < s.pt_ptr[p + 1]; ++k) {
     const int o = s.pt_obs[k], c = s.obs_cam[o];
-    const T* Wo = W + ((int64_t)o * B + b) * 18;
+    const double* Wo = W + ((int64_t)o * B + b) * 18;
     const T* dc = delta + (int64_t)b * ldv + 6 * c;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const double di = (double)dc[i];
-      acc[0] += (double)Wo[3 * i] * di;
-      acc[1] += (double)Wo[3 * i + 1] * di;
-      acc[2] += (double)Wo[3 * i + 2] * di;
+      acc[0] += Wo[3 * i] * di;
+      acc[1] += Wo[3 * i + 1] * di;
+      acc[2] += Wo[3 * i + 2] * di;
     }
   }
-  const T* hp = Hinv + ((int64_t)p * B + b) * 6;
-  const double h[6] = {(double)hp[0], (double)hp[1], (double)hp[2], (double)hp[3], (double)hp[4], (double)hp[5]};
-  const T* tp = tvec + (int64_t)b * (3 * (int64_t)s.num_points) + 3 * p;
+  const double* h = Hinv + ((int64_t)p * B + b) * 6;
+  const double* tp = tvec + (int64_t)b * (3 * (int64_t)s.num_points) + 3 * p;
   T* dp = delta + (int64_t)b * ldv + 6 * (int64_t)s.num_cams + 3 * p;
-  dp[0] = (T)((double)tp[0] - (h[0] * acc[0] + h[1] * acc[1] + h[2] * acc[2]));
-  dp[1] = (T)((double)tp[1] - (h[1] * acc[0] + h[3] * acc[1] + h[4] * acc[2]));
-  dp[2] = (T)((double)tp[2] - (h[2] * acc[0] + h[4] * acc[1] + h[5] * acc[2]));
+  dp[0] = (T)(tp[0] - (h[0] * acc[0] + h[1] * acc[1] + h[2] * acc[2]));
+  dp[1] = (T)(tp[1] - (h[1] * acc[0] + h[3] * acc[1] + h[4] * acc[2]));
+  dp[2] = (T)(tp[2] - (h[2] * acc[0] + h[4] * acc[1] + h[5] * acc[2]));
 }
 
 // ---- error metric ----
@@ -492,50 +495,50 @@ using namespace thx;
 
 extern "C" {
 
-int thx_ba_assemble(const thx_ba_structure* s, const thx_ba_data* d, void* Hcc, void* Hpp, void* W, void* g, void* diag,
-                    int64_t ldv, int dtype, const thx_lie_eps* eps, void* stream) {
+int thx_ba_assemble(const thx_ba_structure* s, const thx_ba_data* d, void* Hcc, void* Hpp, void* W, void* gd, void* g,
+                    void* diag, int64_t ldv, int dtype, const thx_lie_eps* eps, void* stream) {
   if (int r = check_ba(s, d)) return r;
-  if (!Hcc || !Hpp || !g || !diag || !eps || (s->num_obs > 0 && !W)) return fail("thx_ba_assemble: null output");
+  if (!Hcc || !Hpp || !gd || !g || !diag || !eps || (s->num_obs > 0 && !W)) return fail("thx_ba_assemble: null output");
   if (ldv < 6 * (int64_t)s->num_cams + 3 * (int64_t)s->num_points) return fail("thx_ba_assemble: ldv < n");
   const dim3 block(64), gp((d->batch + 63) / 64, s->num_points), gc((d->batch + 63) / 64, s->num_cams);
   THX_DISPATCH(dtype,
                {
-                 hipLaunchKernelGGL(ba_point_kernel<float>, gp, block, 0, as_stream(stream), *s, *d, (float*)Hpp, (float*)W,
-                                    (float*)g, (float*)diag, ldv);
-                 hipLaunchKernelGGL(ba_camera_kernel<float>, gc, block, 0, as_stream(stream), *s, *d, (float*)Hcc, (float*)g,
-                                    (float*)diag, ldv, make_eps<float>(eps));
+                 hipLaunchKernelGGL(ba_point_kernel<float>, gp, block, 0, as_stream(stream), *s, *d, (double*)Hpp, (double*)W,
+                                    (double*)gd, (float*)g, (float*)diag, ldv);
+                 hipLaunchKernelGGL(ba_camera_kernel<float>, gc, block, 0, as_stream(stream), *s, *d, (double*)Hcc,
+                                    (double*)gd, (float*)g, (float*)diag, ldv, make_eps<float>(eps));
                },
                {
                  hipLaunchKernelGGL(ba_point_kernel<double>, gp, block, 0, as_stream(stream), *s, *d, (double*)Hpp,
-                                    (double*)W, (double*)g, (double*)diag, ldv);
+                                    (double*)W, (double*)gd, (double*)g, (double*)diag, ldv);
                  hipLaunchKernelGGL(ba_camera_kernel<double>, gc, block, 0, as_stream(stream), *s, *d, (double*)Hcc,
-                                    (double*)g, (double*)diag, ldv, make_eps<double>(eps));
+                                    (double*)gd, (double*)g, (double*)diag, ldv, make_eps<double>(eps));
                });
   return check_launch("thx_ba_assemble");
 }
 
-int thx_ba_schur(const thx_ba_structure* s, int32_t B, const void* Hcc, const void* Hpp, const void* W, const void* g,
+int thx_ba_schur(const thx_ba_structure* s, int32_t B, const void* Hcc, const void* Hpp, const void* W, const void* gd,
                  int64_t ldv, const void* damping, int ellipsoidal, double damping_eps, void* S, int64_t ld, void* rhs,
                  int64_t ldr, void* Hinv, void* tvec, int32_t* info, int dtype, void* stream) {
-  if (!s || !Hcc || !Hpp || !g || !S || !rhs || !Hinv || !tvec || !info || B <= 0) return fail("thx_ba_schur: null argument");
+  if (!s || !Hcc || !Hpp || !gd || !S || !rhs || !Hinv || !tvec || !info || B <= 0) return fail("thx_ba_schur: null argument");
   if (ld < 6 * (int64_t)s->num_cams || ldr < 6 * (int64_t)s->num_cams) return fail("thx_ba_schur: ld < 6 C");
   const dim3 block(64), gp((B + 63) / 64, s->num_points), gc((B + 63) / 64, s->num_cams);
   hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)B, as_stream(stream));
   THX_DISPATCH(dtype,
                {
-                 hipLaunchKernelGGL(ba_point_invert_kernel<float>, gp, block, 0, as_stream(stream), *s, B, (const float*)Hpp,
-                                    (const float*)g, ldv, (const float*)damping, ellipsoidal, (float)damping_eps,
-                                    (float*)Hinv, (float*)tvec, info);
-                 hipLaunchKernelGGL(ba_schur_kernel<float>, gc, block, 0, as_stream(stream), *s, B, (const float*)Hcc,
-                                    (const float*)W, (const float*)g, ldv, (const float*)damping, ellipsoidal,
-                                    (float)damping_eps, (const float*)Hinv, (const float*)tvec, (float*)S, ld, (float*)rhs, ldr);
+                 hipLaunchKernelGGL(ba_point_invert_kernel<float>, gp, block, 0, as_stream(stream), *s, B, (const double*)Hpp,
+                                    (const double*)gd, ldv, (const float*)damping, ellipsoidal, (float)damping_eps,
+                                    (double*)Hinv, (double*)tvec, info);
+                 hipLaunchKernelGGL(ba_schur_kernel<float>, gc, block, 0, as_stream(stream), *s, B, (const double*)Hcc,
+                                    (const double*)W, (const double*)gd, ldv, (const float*)damping, ellipsoidal,
+                                    (float)damping_eps, (const double*)Hinv, (const double*)tvec, (float*)S, ld, (float*)rhs, ldr);
                },
                {
                  hipLaunchKernelGGL(ba_point_invert_kernel<double>, gp, block, 0, as_stream(stream), *s, B,
-                                    (const double*)Hpp, (const double*)g, ldv, (const double*)damping, ellipsoidal,
+                                    (const double*)Hpp, (const double*)gd, ldv, (const double*)damping, ellipsoidal,
                                     damping_eps, (double*)Hinv, (double*)tvec, info);
                  hipLaunchKernelGGL(ba_schur_kernel<double>, gc, block, 0, as_stream(stream), *s, B, (const double*)Hcc,
-                                    (const double*)W, (const double*)g, ldv, (const double*)damping, ellipsoidal, damping_eps,
+                                    (const double*)W, (const double*)gd, ldv, (const double*)damping, ellipsoidal, damping_eps,
                                     (const double*)Hinv, (const double*)tvec, (double*)S, ld, (double*)rhs, ldr);
                });
   return check_launch("thx_ba_schur");
@@ -546,8 +549,8 @@ int thx_ba_backsub(const thx_ba_structure* s, int32_t B, const void* W, const vo
   if (!s || !Hinv || !tvec || !delta || B <= 0 || (s->num_obs > 0 && !W)) return fail("thx_ba_backsub: null argument");
   const dim3 block(64), gp((B + 63) / 64, s->num_points);
   THX_DISPATCH(dtype,
-               hipLaunchKernelGGL(ba_backsub_kernel<float>, gp, block, 0, as_stream(stream), *s, B, (const float*)W,
-                                  (const float*)Hinv, (const float*)tvec, (float*)delta, ldv),
+               hipLaunchKernelGGL(ba_backsub_kernel<float>, gp, block, 0, as_stream(stream), *s, B, (const double*)W,
+                                  (const double*)Hinv, (const double*)tvec, (float*)delta, ldv),
                hipLaunchKernelGGL(ba_backsub_kernel<double>, gp, block, 0, as_stream(stream), *s, B, (const double*)W,
                                   (const double*)Hinv, (const double*)tvec, (double*)delta, ldv));
   return check_launch("thx_ba_backsub");

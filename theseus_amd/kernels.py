@@ -248,19 +248,22 @@ class HipKernels:
                                             lie_eps(dt), _lib.stream_ptr(poses.device)), "thx_se3_retract")
 
     # ---- bundle adjustment (csrc/ba_kernels.hip) --------------------------------------------------
-    def ba_assemble(self, s, t, Hcc, Hpp, W, g, diag):
+    def ba_assemble(self, s, t, Hcc, Hpp, W, gd, g, diag):
+        """Block quantities Hcc, Hpp, W, gd are fp64 buffers for every dtype (include/theseus_hip.h, PRECISION)."""
         d = t.c_struct()
         dt = g.dtype
-        _lib.check(self.lib.thx_ba_assemble(s.c, d, _lib.ptr(Hcc), _lib.ptr(Hpp), _lib.ptr(W), _lib.ptr(g), _lib.ptr(diag),
-                                            g.stride(0), _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(g.device)),
-                   "thx_ba_assemble")
+        for b in (Hcc, Hpp, W, gd):
+            assert b.dtype == torch.float64
+        _lib.check(self.lib.thx_ba_assemble(s.c, d, _lib.ptr(Hcc), _lib.ptr(Hpp), _lib.ptr(W), _lib.ptr(gd), _lib.ptr(g),
+                                            _lib.ptr(diag), g.stride(0), _lib.dtype_code(dt), lie_eps(dt),
+                                            _lib.stream_ptr(g.device)), "thx_ba_assemble")
 
-    def ba_schur(self, s, Hcc, Hpp, W, g, damping, ellipsoidal, damping_eps, S, rhs, Hinv, tvec, info):
-        B = g.shape[0]
-        _lib.check(self.lib.thx_ba_schur(s.c, B, _lib.ptr(Hcc), _lib.ptr(Hpp), _lib.ptr(W), _lib.ptr(g), g.stride(0),
+    def ba_schur(self, s, Hcc, Hpp, W, gd, damping, ellipsoidal, damping_eps, S, rhs, Hinv, tvec, info):
+        B = gd.shape[0]
+        _lib.check(self.lib.thx_ba_schur(s.c, B, _lib.ptr(Hcc), _lib.ptr(Hpp), _lib.ptr(W), _lib.ptr(gd), gd.stride(0),
                                          _lib.ptr(damping), int(bool(ellipsoidal)), float(damping_eps), _lib.ptr(S),
                                          S.shape[-1], _lib.ptr(rhs), rhs.stride(0), _lib.ptr(Hinv), _lib.ptr(tvec),
-                                         _lib.ptr(info), _lib.dtype_code(g.dtype), _lib.stream_ptr(g.device)), "thx_ba_schur")
+                                         _lib.ptr(info), _lib.dtype_code(S.dtype), _lib.stream_ptr(S.device)), "thx_ba_schur")
 
     def ba_backsub(self, s, W, Hinv, tvec, delta):
         B = delta.shape[0]
