@@ -302,6 +302,8 @@ int thx_ba_schur(const thx_ba_structure* s, int32_t B, const void* Hcc, const vo
 /* delta_p = tvec - Hinv Hpc delta_c, written to delta[:, 6C:] (delta_c = delta[:, :6C] is read) */
 int thx_ba_backsub(const thx_ba_structure* s, int32_t B, const void* W, const void* Hinv, const void* tvec, void* delta,
                    int64_t ldv, int dtype, void* stream);
+/* partials: scratch (THX_BA_ERR_CHUNKS, B) */
+#define THX_BA_ERR_CHUNKS 256
 int thx_ba_error(const thx_ba_structure* s, const thx_ba_data* d, void* partials, void* err, int dtype,
                  const thx_lie_eps* eps, void* stream);
 /* Vector retraction x <- x + step * delta (theseus/geometry/vector.py:177-178), masked like thx_se3_retract; x (N,B,dof),

@@ -247,3 +247,36 @@ def test_unmodified_reference_example_runs_on_the_plugin(ref, monkeypatch):
     for got, want in zip(losses, PGO_KAT_LOSSES):
         assert got == pytest.approx(want, rel=1e-10, abs=1e-10), (losses, PGO_KAT_LOSSES)
     assert calls["pg_assemble"] >= 40 and calls["pg_vjp"] == 4, calls   # the FUSED path ran, once per outer backward
+
+
+@pytest.mark.parametrize("name", ["ba_f64_lm", "ba_f64_gn"])
+def test_reference_loop_drives_the_bundle_adjustment_plugin(ref, name):
+    """The REAL th.LevenbergMarquardt / th.GaussNewton loop with theseus_amd.plugin.HipSchurSolver on a bundle-adjustment
+    objective built from the reference's own classes (th.eb.Reprojection, th.RobustCostFunction, th.Difference on SE3 and
+    Point3) reproduces the trajectory the reference recorded with DenseLinearization + CholeskyDenseSolver."""
+    th, thp = ref
+    import ast
+    from tests.ba_common import build_ba_objective
+    from tests.oracle_kernels import OracleKernels
+
+    class RefNames:  # build_ba_objective speaks theseus_amd's names: map them onto the reference's
+        Objective, SE3, Point3, Point2, Vector, Difference = th.Objective, th.SE3, th.Point3, th.Point2, th.Vector, th.Difference
+        ScaleCostWeight, RobustCostFunction, HuberLoss, WelschLoss = th.ScaleCostWeight, th.RobustCostFunction, th.HuberLoss, th.WelschLoss
+        Reprojection = th.eb.Reprojection
+    g = load_golden(name)
+    obj, cam_v, pt_v = build_ba_objective(RefNames, g)
+    obj.update()   # resolves the batch size (TheseusLayer.forward does this for the user)
+    kw = ast.literal_eval(str(g["opt_kwargs"]))
+    gn = kw.pop("gauss_newton")
+    opt = (th.GaussNewton if gn else th.LevenbergMarquardt)(
+        obj, linear_solver_cls=thp.HipSchurSolver, linearization_kwargs=dict(kernels=OracleKernels()), vectorize=True,
+        abs_err_tolerance=0.0, rel_err_tolerance=0.0, max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"))
+    with torch.no_grad():
+        info = opt.optimize(track_err_history=True, **kw)
+    cams = torch.stack([v.tensor for v in cam_v], 1).numpy()
+    used = sorted(set(g["obs_pt"].tolist()))
+    pts = torch.stack([pt_v[i].tensor for i in used], 1).numpy()
+    np.testing.assert_allclose(cams, g["final_cams"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(pts, g["final_pts"][:, used], rtol=0, atol=1e-5)
+    k = min(info.err_history.shape[1], g["err_history"].shape[1])
+    np.testing.assert_allclose(info.err_history[:, :k].numpy(), g["err_history"][:, :k], rtol=1e-6)

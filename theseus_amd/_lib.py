@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("THESEUS_HIP_LIB") or os.path.join(_HERE, "lib", "libt
 
 THX_TILE = 128
 THX_ERR_CHUNKS = 16
+THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
 ABI_VERSION = 5
 

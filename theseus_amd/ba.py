@@ -21,7 +21,7 @@ from .linear_solver import LinearSolver
 from .linearization import Linearization, VariableOrdering
 from .packed import UnsupportedObjective, _aux_vars, _kind, _unwrap_robust, _weight_diag
 
-ERR_CHUNKS = _lib.THX_ERR_CHUNKS
+ERR_CHUNKS = _lib.THX_BA_ERR_CHUNKS
 
 
 def _csr(owner: np.ndarray, n: int, secondary: Optional[np.ndarray] = None):
@@ -195,7 +195,12 @@ class PackedBA:
         self.m = objective.dim()
         self.version = objective.current_version
         self.tensors: Optional[BATensors] = None
-        self._own_variables = all(isinstance(v, Variable) for v in self._tracked())
+        seen, self._tracked_list = set(), []          # shared calibration / weights / radius appear once
+        for v in self._walk_tracked():
+            if id(v) not in seen:
+                seen.add(id(v))
+                self._tracked_list.append(v)
+        self._own_variables = all(isinstance(v, Variable) for v in self._tracked_list)
         self._stamp = None
         self._global_stamp = -1
         self._vars_stale = False
@@ -203,6 +208,9 @@ class PackedBA:
 
     # ---- packing ------------------------------------------------------------------------------------------
     def _tracked(self):
+        return self._tracked_list
+
+    def _walk_tracked(self):
         yield from self.cam_vars
         yield from self.pt_vars
         for c, r in zip(self.obs_costs, self.obs_radius):
@@ -366,11 +374,13 @@ class PackedBA:
                                   "(use error_metric())")
 
 
-class HipSchurLinearization(Linearization):
-    """``Linearization`` of a bundle-adjustment objective: block form (Hcc, Hpp, Hcp) + g + diag(H), never the dense H.
-    ``ordering``: cameras, then points."""
+class HipSchurLinearizationCore:
+    """Back-end half of the bundle-adjustment linearization, independent of which ``Linearization`` ABC it is mixed into
+    (theseus_amd's mirror below, the real ``theseus.optimizer.Linearization`` in theseus_amd/plugin.py): block form
+    (Hcc, Hpp, Hcp) + g + diag(H), never the dense H.  ``ordering``: cameras, then points."""
 
-    def __init__(self, objective: Objective, ordering: Optional[VariableOrdering] = None, kernels=None, **kwargs):
+    @staticmethod
+    def _schur_setup(objective, ordering, kernels, ordering_cls):
         packed = getattr(objective, "_packed", None)
         if not isinstance(packed, PackedBA) or packed.version != objective.current_version or (
                 kernels is not None and packed.K is not kernels):
@@ -378,10 +388,12 @@ class HipSchurLinearization(Linearization):
             objective._packed = packed
         if ordering is not None:
             raise NotImplementedError("HipSchurLinearization fixes the variable ordering: cameras, then points.")
-        ordering = VariableOrdering(objective, default_order=False)
+        ordering = ordering_cls(objective, default_order=False)
         for v in packed.cam_vars + packed.pt_vars:
             ordering.append(v)
-        Linearization.__init__(self, objective, ordering)
+        return packed, ordering
+
+    def _schur_init(self, packed):
         self.packed, self.K = packed, packed.K
         self.Hcc = self.Hpp = self.W = self.gd = self.g = self.diag = None
 
@@ -413,17 +425,15 @@ class HipSchurLinearization(Linearization):
     def _linearize_hessian_impl(self, _detach_hessian: bool = False):
         self._assemble()
 
-    @property
-    def AtA(self) -> torch.Tensor:
+    def _ata_impl(self) -> torch.Tensor:
         raise NotImplementedError("the dense Hessian of a bundle-adjustment objective is not materialised "
                                   "(Hcc / Hpp / W hold its blocks)")
 
-    @property
-    def Atb(self) -> torch.Tensor:
+    def _atb_impl(self) -> torch.Tensor:
         return self.g.unsqueeze(2)
 
     def Av(self, v):
-        raise NotImplementedError
+        raise NotImplementedError("the dense Jacobian of a bundle-adjustment objective is not materialised")
 
     def diagonal_scaling(self, v: torch.Tensor) -> torch.Tensor:
         return self.diag * v
@@ -432,16 +442,26 @@ class HipSchurLinearization(Linearization):
         self.K.lm_accept_diag(delta, self.g, self.diag, self.n, damping, prev_err, new_err, ellipsoidal, accept, down, up, reject)
 
 
-class HipSchurSolver(LinearSolver):
+class HipSchurLinearization(HipSchurLinearizationCore, Linearization):
+    def __init__(self, objective: Objective, ordering: Optional[VariableOrdering] = None, kernels=None, **kwargs):
+        packed, ordering = self._schur_setup(objective, ordering, kernels, VariableOrdering)
+        Linearization.__init__(self, objective, ordering)
+        self._schur_init(packed)
+
+    @property
+    def AtA(self) -> torch.Tensor:
+        return self._ata_impl()
+
+    @property
+    def Atb(self) -> torch.Tensor:
+        return self._atb_impl()
+
+
+class HipSchurSolverCore:
     """(H + damping) delta = g of a bundle-adjustment linearization by block elimination of the points + the tiled dense
     Cholesky on the reduced camera system.  Same ``solve`` contract and failure behaviour as ``HipCholeskySolver``."""
 
-    def __init__(self, objective: Objective, linearization_cls: Optional[Type[Linearization]] = None,
-                 linearization_kwargs: Optional[Dict[str, Any]] = None, **kwargs):
-        linearization_cls = linearization_cls or HipSchurLinearization
-        if not (isinstance(linearization_cls, type) and issubclass(linearization_cls, HipSchurLinearization)):
-            raise RuntimeError(f"HipSchurSolver only works with HipSchurLinearization, but {linearization_cls} was provided.")
-        LinearSolver.__init__(self, objective, linearization_cls, linearization_kwargs)
+    def _schur_solver_init(self):
         self.K = self.linearization.K
         self.S = self.L = self.panels = self.info_chol = self.info_pts = None
         self.factor_version = 0
@@ -477,8 +497,7 @@ class HipSchurSolver(LinearSolver):
             raise RuntimeError(f"linalg.cholesky: (Batch element {b}): The factorization could not be completed because the "
                                "input is not positive-definite.")
 
-    def solve(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
-              damping_eps: float = 1e-8, check_info: bool = True, **kwargs) -> torch.Tensor:
+    def _solve(self, damping, ellipsoidal_damping, damping_eps, check_info) -> torch.Tensor:
         lin = self.linearization
         if lin.g is None:
             raise RuntimeError("linearize() must be called before solve().")
@@ -503,3 +522,17 @@ class HipSchurSolver(LinearSolver):
         if check_info:
             self.check_info()
         return self.delta
+
+
+class HipSchurSolver(HipSchurSolverCore, LinearSolver):
+    def __init__(self, objective: Objective, linearization_cls: Optional[Type[Linearization]] = None,
+                 linearization_kwargs: Optional[Dict[str, Any]] = None, **kwargs):
+        linearization_cls = linearization_cls or HipSchurLinearization
+        if not (isinstance(linearization_cls, type) and issubclass(linearization_cls, HipSchurLinearization)):
+            raise RuntimeError(f"HipSchurSolver only works with HipSchurLinearization, but {linearization_cls} was provided.")
+        LinearSolver.__init__(self, objective, linearization_cls, linearization_kwargs)
+        self._schur_solver_init()
+
+    def solve(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
+              damping_eps: float = 1e-8, check_info: bool = True, **kwargs) -> torch.Tensor:
+        return self._solve(damping, ellipsoidal_damping, damping_eps, check_info)

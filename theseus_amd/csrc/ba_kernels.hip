@@ -365,7 +365,8 @@ ba_backsub_kernel(thx_ba_structure s, int B, const double* __restrict__ W, const
   dp[2] = (T)(tp[2] - (h[2] * acc[0] + h[4] * acc[1] + h[5] * acc[2]));
 }
 
-// ---- error metric ----
+// ---- error metric: BA_ERR_CHUNKS partial sums per problem (the batch is small, the cost count large) ----
+constexpr int BA_ERR_CHUNKS = THX_BA_ERR_CHUNKS;
 template <typename T>
 __global__ void __launch_bounds__(64)
 ba_error_partial_kernel(thx_ba_structure s, thx_ba_data d, T* __restrict__ partials, Eps<T> eps) {
@@ -373,7 +374,7 @@ ba_error_partial_kernel(thx_ba_structure s, thx_ba_data d, T* __restrict__ parti
   if (b >= B) return;
   double acc = 0.0;
   auto range = [&](int n, int& lo, int& hi) __attribute__((always_inline)) {
-    const int per = (n + THX_ERR_CHUNKS - 1) / THX_ERR_CHUNKS;
+    const int per = (n + BA_ERR_CHUNKS - 1) / BA_ERR_CHUNKS;
     lo = ch * per;
     hi = min(n, lo + per);
   };
@@ -426,8 +427,7 @@ __global__ void ba_error_reduce_kernel(const T* __restrict__ partials, T* __rest
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   T acc = T(0);
-#pragma unroll
-  for (int c = 0; c < THX_ERR_CHUNKS; ++c) acc += partials[(int64_t)c * B + b];
+  for (int c = 0; c < BA_ERR_CHUNKS; ++c) acc += partials[(int64_t)c * B + b];
   err[b] = T(0.5) * acc;
 }
 
@@ -560,7 +560,7 @@ int thx_ba_error(const thx_ba_structure* s, const thx_ba_data* d, void* partials
                  const thx_lie_eps* eps, void* stream) {
   if (int r = check_ba(s, d)) return r;
   if (!partials || !err || !eps) return fail("thx_ba_error: null output");
-  const dim3 block(64), grid((d->batch + 63) / 64, THX_ERR_CHUNKS);
+  const dim3 block(64), grid((d->batch + 63) / 64, BA_ERR_CHUNKS);
   const int B = d->batch;
   THX_DISPATCH(dtype,
                {

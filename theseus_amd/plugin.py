@@ -237,3 +237,45 @@ class HipCholeskySolver(HipCholeskyCore, _RefCholeskyDenseSolver):
 
     def _solve_sytem(self, Atb: torch.Tensor, AtA: torch.Tensor) -> torch.Tensor:  # abstract in DenseSolver
         raise NotImplementedError("HipCholeskySolver.solve() factorises its linearization's packed Hessian")
+
+
+# ---- bundle adjustment (theseus_amd/ba.py): Schur-complement linearization / solver for the REAL theseus loop ----------
+from .ba import HipSchurLinearizationCore, HipSchurSolverCore  # noqa: E402
+
+
+class HipSchurLinearization(HipSchurLinearizationCore, _RefLinearization):
+    """``linearization_cls`` for bundle-adjustment objectives (SE3 cameras + Point3 points, th.eb.Reprojection optionally
+    robust, th.Difference priors).  Sets ``ordering`` = cameras, then points -- the reference retracts and reads ``delta``
+    through ``linearization.ordering`` (nonlinear_least_squares.py:97, objective.py:873-914)."""
+
+    def __init__(self, objective: th.Objective, ordering=None, kernels=None, **kwargs):
+        packed, ordering = self._schur_setup(objective, ordering, kernels, th.optimizer.VariableOrdering)
+        _RefLinearization.__init__(self, objective, ordering)
+        self._schur_init(packed)
+
+    def _linearize_hessian_impl(self, _detach_hessian: bool = False):
+        if torch.is_grad_enabled() and any(v.tensor.requires_grad for v in self.packed._tracked()):
+            raise NotImplementedError("HIP bundle adjustment: differentiating through the linearization is not fused yet")
+        self._assemble()
+
+
+class HipSchurSolver(HipSchurSolverCore, _RefCholeskyDenseSolver):
+    """``linear_solver_cls`` for bundle adjustment.  Subclasses the reference's CholeskyDenseSolver for LevenbergMarquardt's
+    isinstance whitelists (levenberg_marquardt.py:21-48,82-87) but calls ``LinearSolver.__init__`` directly, like
+    HipCholeskySolver above; ``solve`` returns delta in ``linearization.ordering`` (cameras, then points)."""
+
+    def __init__(self, objective: th.Objective, linearization_cls=None, linearization_kwargs=None, check_singular: bool = False,
+                 **kwargs):
+        linearization_cls = linearization_cls or HipSchurLinearization
+        if not (isinstance(linearization_cls, type) and issubclass(linearization_cls, HipSchurLinearization)):
+            raise RuntimeError(f"HipSchurSolver only works with theseus_amd.plugin.HipSchurLinearization, but "
+                               f"{linearization_cls} was provided.")
+        _RefLinearSolver.__init__(self, objective, linearization_cls, linearization_kwargs)
+        self._check_singular = check_singular
+        self._schur_solver_init()
+
+    def solve(self, damping=None, ellipsoidal_damping: bool = True, damping_eps: float = 1e-8, **kwargs) -> torch.Tensor:
+        return self._solve(damping, ellipsoidal_damping, damping_eps, check_info=True).clone()
+
+    def _solve_sytem(self, Atb, AtA):  # abstract in DenseSolver
+        raise NotImplementedError("HipSchurSolver.solve() eliminates the points of its block linearization")

@@ -1,0 +1,63 @@
+"""Bundle adjustment at BASELINE.json configs[3] size on one GPU: LM iterations/s and the per-phase times.
+usage: python tools/bench_ba.py [cams] [points] [batch] [dtype] [iters]"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import theseus_amd as th
+from theseus_amd.utils.synthetic_ba import make_ba_objective
+
+C = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+Np = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+dt = {"f32": torch.float32, "f64": torch.float64}[sys.argv[4] if len(sys.argv) > 4 else "f32"]
+iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+t0 = time.time()
+obj, meta = make_ba_objective(C, Np, B, dtype=dt)
+print(f"objective built in {time.time() - t0:.1f} s: {meta['num_cams']} cams, {meta['num_points']} points, {meta['num_obs']} obs, n = {meta['n']}")
+opt = th.LevenbergMarquardt(obj, max_iterations=iters, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+layer = th.TheseusLayer(opt)
+kw = dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True, track_err_history=True)
+t0 = time.time()
+with torch.no_grad():
+    sol, info = layer.forward(None, optimizer_kwargs=kw)
+torch.cuda.synchronize()
+print(f"first optimize (incl. packing): {time.time() - t0:.2f} s; mean error {info.err_history[:, 0].mean():.1f} -> {info.err_history[:, -1].mean():.3f}")
+solver, lin = opt.linear_solver, opt.linear_solver.linearization
+ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+phases = {}
+lam = torch.full((B,), 1e-2, dtype=dt, device="cuda")
+
+
+def timed(name, fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    phases[name] = e0.elapsed_time(e1) / reps
+
+
+p = lin.packed
+timed("ba_assemble", lambda: lin._assemble())
+timed("ba_schur", lambda: solver.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, lin.gd, lam, True, 1e-8, solver.S, solver.rhs, solver.Hinv, solver.tvec, solver.info_pts))
+timed("chol_factor(S)", lambda: solver.K.chol_factor(solver.S, p.nc, None, False, 1e-8, solver.L, solver.panels, solver.info_chol, rhs=solver.rhs, y=solver._y))
+timed("chol_backward", lambda: solver.K.chol_solve_backward(solver.L, p.nc, solver.panels, solver._y, solver._dc))
+timed("ba_backsub", lambda: solver.K.ba_backsub(p.dstruct, lin.W, solver.Hinv, solver.tvec, solver.delta))
+timed("ba_error", lambda: p.error_metric())
+spare = p.alloc_state()
+timed("retract", lambda: p.retract(solver.delta, 1.0, None, spare))
+e0, e1 = ev(), ev()
+with torch.no_grad():
+    obj.update()
+    e0.record()
+    info = opt.optimize(**kw)
+    e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / max(info.iters_done, 1)
+nc = p.nc
+fl = B * nc ** 3 / 3
+print("phases (ms):", {k: round(v, 3) for k, v in phases.items()})
+print(f"LM iteration {ms:.2f} ms -> {B / ms * 1e3:.0f} problem-iterations/s; Schur system {nc}^2, Cholesky {fl / phases['chol_factor(S)'] / 1e9:.1f} TFLOP/s")
