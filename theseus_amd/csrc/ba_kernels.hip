@@ -426,9 +426,9 @@ template <typename T>
 __global__ void ba_error_reduce_kernel(const T* __restrict__ partials, T* __restrict__ err, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  T acc = T(0);
-  for (int c = 0; c < BA_ERR_CHUNKS; ++c) acc += partials[(int64_t)c * B + b];
-  err[b] = T(0.5) * acc;
+  double acc = 0.0;  // 256 partials: accumulate in fp64 so that the sum carries one fp32 rounding, not 256
+  for (int c = 0; c < BA_ERR_CHUNKS; ++c) acc += (double)partials[(int64_t)c * B + b];
+  err[b] = (T)(0.5 * acc);
 }
 
 template <typename T>

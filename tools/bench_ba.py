@@ -60,4 +60,7 @@ ms = e0.elapsed_time(e1) / max(info.iters_done, 1)
 nc = p.nc
 fl = B * nc ** 3 / 3
 print("phases (ms):", {k: round(v, 3) for k, v in phases.items()})
-print(f"LM iteration {ms:.2f} ms -> {B / ms * 1e3:.0f} problem-iterations/s; Schur system {nc}^2, Cholesky {fl / phases['chol_factor(S)'] / 1e9:.1f} TFLOP/s")
+per_solve = sum(phases.values())
+print(f"one linearize + solve + retract + error: {per_solve:.2f} ms of kernels -> {B / per_solve * 1e3:.0f} problem-iterations/s; "
+      f"LM loop {ms:.2f} ms per ACCEPTED iteration (all-rejected retries re-solve, nonlinear_least_squares.py:358-365); "
+      f"Schur system {nc}^2, Cholesky {fl / phases['chol_factor(S)'] / 1e9:.1f} TFLOP/s")
