@@ -239,6 +239,45 @@ struct Engine<float> {
 #pragma unroll
     for (int v = 0; v <= UL; ++v) fin(UL, v, acc[UH + 1 + v]);
   }
+  // The same nine blocks of H_jj, global -> registers BEFORE the K-loop (row index clamped into the matrix: the caller
+  // masks by value), so that the H tile costs no exposed round trips after it.
+  template <int G>
+  static __device__ __forceinline__ void syrk36_prefetch(const float* __restrict__ Hjj, int64_t ld, int valid, float4* hp,
+                                                        int lane) {
+    constexpr int UH = 4 + G, UL = 3 - G;
+    auto ldb = [&](int u, int v) __attribute__((always_inline)) -> float4 {
+      const int r = min(16 * u + (lane & 15), valid - 1);
+      return *reinterpret_cast<const float4*>(Hjj + (int64_t)r * ld + 16 * v + 4 * (lane >> 4));
+    };
+#pragma unroll
+    for (int v = 0; v <= UH; ++v) hp[v] = ldb(UH, v);
+#pragma unroll
+    for (int v = 0; v <= UL; ++v) hp[UH + 1 + v] = ldb(UL, v);
+  }
+  // tile(u, v) <- S = H (+ damping on the diagonal) - acc; rows / columns outside the matrix: identity
+  template <int G>
+  static __device__ __forceinline__ void syrk36_store(float* tile, const float4* hp, const f32x4* acc, int lane, int valid,
+                                                      bool damp, float lam, int ellipsoidal, float eps) {
+    constexpr int UH = 4 + G, UL = 3 - G;
+    auto st = [&](int u, int v, const float4& h, const f32x4& a) __attribute__((always_inline)) {
+      const int r = 16 * u + (lane & 15), c0 = 16 * v + 4 * (lane >> 4);
+      float hv[4] = {h.x, h.y, h.z, h.w}, o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + k;
+        float x = hv[k];
+        if (u == v && r == c && damp) x = ellipsoidal ? x + (lam * x + eps) : x + lam;
+        x -= a[k];
+        if (r >= valid || c >= valid) x = (r == c) ? 1.f : 0.f;
+        o[k] = x;
+      }
+      *reinterpret_cast<float4*>(tile + r * 132 + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    };
+#pragma unroll
+    for (int v = 0; v <= UH; ++v) st(UH, v, hp[v], acc[v]);
+#pragma unroll
+    for (int v = 0; v <= UL; ++v) st(UL, v, hp[UH + 1 + v], acc[UH + 1 + v]);
+  }
   // ---- 32x32 block helpers for the diagonal-tile factorisation (operands in the LDS tile, row stride 132).
   //      Blk D[m][n]: a lane holds ONE row n = lane&31 of the block, register rho <-> column m = 8(rho>>2) + 4g + (rho&3)
   using Blk = f32x16;
@@ -753,6 +792,14 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[i][k] = T(0);
   T tpart = T(0);  // this thread's half of (L_j,0:j y)[tid >> 1]
+  [[maybe_unused]] float4 hpre[9];
+  if constexpr (sizeof(T) == 4) {  // H_jj blocks in flight during the whole K-loop (fp32 path; fp64 stages through LDS)
+    const float* Hjj = H + mat + (int64_t)row0 * ld + row0;
+    if (wave == 0) E::template syrk36_prefetch<0>(Hjj, ld, valid, hpre, lane);
+    else if (wave == 1) E::template syrk36_prefetch<1>(Hjj, ld, valid, hpre, lane);
+    else if (wave == 2) E::template syrk36_prefetch<2>(Hjj, ld, valid, hpre, lane);
+    else E::template syrk36_prefetch<3>(Hjj, ld, valid, hpre, lane);
+  }
   kloop_f<T, true, true, E::SYRK_LDT>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, row0, tile, nullptr, tid,
                          fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
     if (wave == 0) E::template syrk36<0>(tile, acc, lane);
@@ -764,31 +811,45 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   // ---- S = H_jj (+ damping on the diagonal) - acc -> LDS tile; identity padding outside the matrix ----
   __syncthreads();  // staging buffer is free
   THX_STAMP();
-  tile_g2l<T>(H + mat + (int64_t)row0 * ld + row0, ld, valid, valid, tile, tid);
   if (tid < TILE) vvec[tid] = (fwd && tid < valid) ? rhs[(int64_t)b * ldv + row0 + tid] : T(0);
-  __syncthreads();
-  if (tid < TILE) {
-    T hv = tile[tid * C::LDM + tid];
-    if (tid < valid) {
-      if (damping) {
-        const T lam = damping[b];
-        hv = ellipsoidal ? hv + (lam * hv + damping_eps) : hv + lam;
-      }
-    } else {
-      hv = T(1);
+  if constexpr (sizeof(T) == 4) {
+    const bool damp = damping != nullptr;
+    const float lam = damp ? damping[b] : 0.f;
+    if (wave == 0) E::template syrk36_store<0>(tile, hpre, acc, lane, valid, damp, lam, ellipsoidal, damping_eps);
+    else if (wave == 1) E::template syrk36_store<1>(tile, hpre, acc, lane, valid, damp, lam, ellipsoidal, damping_eps);
+    else if (wave == 2) E::template syrk36_store<2>(tile, hpre, acc, lane, valid, damp, lam, ellipsoidal, damping_eps);
+    else E::template syrk36_store<3>(tile, hpre, acc, lane, valid, damp, lam, ellipsoidal, damping_eps);
+    __syncthreads();  // vvec visible
+    {  // g_j - L_j,0:j y : thread pair (2r, 2r+1) holds the two halves of row r's sum
+      const T tsum = tpart + __shfl_xor(tpart, 1);
+      if (fwd && (tid & 1) == 0) vvec[tid >> 1] -= tsum;
     }
-    tile[tid * C::LDM + tid] = hv;
+  } else {
+    tile_g2l<T>(H + mat + (int64_t)row0 * ld + row0, ld, valid, valid, tile, tid);
+    __syncthreads();
+    if (tid < TILE) {
+      T hv = tile[tid * C::LDM + tid];
+      if (tid < valid) {
+        if (damping) {
+          const T lam = damping[b];
+          hv = ellipsoidal ? hv + (lam * hv + damping_eps) : hv + lam;
+        }
+      } else {
+        hv = T(1);
+      }
+      tile[tid * C::LDM + tid] = hv;
+    }
+    {  // g_j - L_j,0:j y : thread pair (2r, 2r+1) holds the two halves of row r's sum
+      const T tsum = tpart + __shfl_xor(tpart, 1);
+      if (fwd && (tid & 1) == 0) vvec[tid >> 1] -= tsum;
+    }
+    __syncthreads();
+    // own blocks: tile(u,v) <- tile(u,v) - acc (each lane touches only its own elements)
+    if (wave == 0) E::template syrk36_finish<0>(tile, acc, lane);
+    else if (wave == 1) E::template syrk36_finish<1>(tile, acc, lane);
+    else if (wave == 2) E::template syrk36_finish<2>(tile, acc, lane);
+    else E::template syrk36_finish<3>(tile, acc, lane);
   }
-  {  // g_j - L_j,0:j y : thread pair (2r, 2r+1) holds the two halves of row r's sum
-    const T tsum = tpart + __shfl_xor(tpart, 1);
-    if (fwd && (tid & 1) == 0) vvec[tid >> 1] -= tsum;
-  }
-  __syncthreads();
-  // own blocks: tile(u,v) <- tile(u,v) - acc (each lane touches only its own elements)
-  if (wave == 0) E::template syrk36_finish<0>(tile, acc, lane);
-  else if (wave == 1) E::template syrk36_finish<1>(tile, acc, lane);
-  else if (wave == 2) E::template syrk36_finish<2>(tile, acc, lane);
-  else E::template syrk36_finish<3>(tile, acc, lane);
   __syncthreads();
   THX_STAMP();
 
