@@ -1,0 +1,48 @@
+"""The sync-free iteration path of the LM loop (theseus_amd/nonlinear.py: no adaptive damping / convergence test / callback
+/ sharding -> the "a linear solve failed" flag stays on the device) takes the same steps as the path with one host
+decision per iteration, and keeps the reference's failure semantics (nonlinear_least_squares.py:138-152: FAIL status,
+variables untouched).  CPU, TEST stand-in kernels."""
+import warnings
+
+import numpy as np
+import torch
+
+from tests.helpers import golden_problem, load_golden
+
+
+def _run(g, lazy, gauss_newton=False, **okw):
+    import theseus_amd as th
+    from tests.oracle_kernels import OracleKernels
+    from tests.test_gpu_lm import build_objective
+    obj, poses = build_objective(th, g, device="cpu")
+    cls = th.GaussNewton if gauss_newton else th.LevenbergMarquardt
+    opt = cls(obj, linearization_kwargs=dict(kernels=OracleKernels()), abs_err_tolerance=0.0, rel_err_tolerance=0.0, **okw)
+    calls = []
+    kw = dict(track_err_history=True) if gauss_newton else dict(track_err_history=True, damping=1e-3)
+    if not lazy:
+        kw["end_iter_callback"] = lambda o, i, d, it: calls.append(it)   # any callback forces the per-iteration decision
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=kw)
+    return torch.stack([sol[f"pose_{k}"] for k in range(int(g["P"]))], 1), info
+
+
+def test_sync_free_iterations_equal_the_synchronised_loop():
+    g = load_golden("pg_f64_lm")
+    a, ia = _run(g, True, max_iterations=6, step_size=1.0)
+    b, ib = _run(g, False, max_iterations=6, step_size=1.0)
+    assert torch.equal(a, b) and torch.equal(ia.err_history, ib.err_history)
+    np.testing.assert_allclose(a.numpy(), g["final"], rtol=0, atol=5e-8)
+    assert ia.iters_done == ib.iters_done == 6
+
+
+def test_sync_free_iterations_keep_the_failure_semantics():
+    import theseus_amd as th
+    g = dict(load_golden("pg_f64_gn"))
+    g["w_between"] = g["w_between"] * 0.0
+    g["w_prior"] = g["w_prior"] * 0.0          # H = 0: not positive definite (Gauss-Newton: no damping)
+    for lazy in (True, False):
+        a, info = _run(g, lazy, gauss_newton=True, max_iterations=4, step_size=1.0)
+        assert all(s == th.NonlinearOptimizerStatus.FAIL for s in info.status), lazy
+        np.testing.assert_array_equal(a.numpy(), g["poses0"])      # variables keep their values
+        assert info.iters_done == 0 and torch.isinf(info.err_history[:, 1:]).all()

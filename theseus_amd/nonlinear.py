@@ -179,7 +179,53 @@ class NonlinearLeastSquares(abc.ABC):
             spare = packed.alloc_state()
             err_new = torch.empty(B, dtype=dt, device=dev)
             it, all_reject_attempts = 0, 0
-            while it < loop_iters:
+            # ---- sync-free iterations.  Without adaptive damping, convergence tests, callbacks or a
+            #      sharded batch the only host decision of an iteration is "did a linear solve fail?"
+            #      (nonlinear_least_squares.py:138-152: FAIL status, variables keep their values).  That flag stays on
+            #      the device: once raised it freezes every later update through the retraction mask, and it is read
+            #      ONCE after the loop -- the host queues the iterations back to back and the GPU never drains. ----
+            lazy = (type(self.reducer) is LocalBatchReducer and not need_conv and end_iter_callback is None
+                    and not verbose and not kwargs.get("adaptive_damping", False))
+            failed = first_fail = None
+            if lazy:
+                failed = torch.zeros((), dtype=torch.bool, device=dev)
+                first_fail = torch.full((), -1, dtype=torch.long, device=dev)
+            while lazy and it < loop_iters:
+                lin.linearize()
+                try:
+                    delta = self.compute_delta(**kwargs)
+                except RuntimeError as run_err:
+                    msg = f"There was an error while running the linear optimizer. Original error message: {run_err}."
+                    warnings.warn(msg, RuntimeWarning)
+                    info.status[:] = NonlinearOptimizerStatus.FAIL
+                    break
+                now = self.linear_solver.info.ne(0).any()
+                first_fail = torch.where(now & ~failed, torch.full_like(first_fail, it), first_fail)
+                failed = failed | now
+                packed.retract(delta, p.step_size, failed.to(torch.uint8).expand(B).contiguous(), spare)
+                packed.error_metric(state=spare, out=err_new)
+                err = torch.where(failed, last_err, err_new)
+                spare = packed.swap_state(spare)
+                if err_hist is not None:
+                    err_hist[:, it + 1] = torch.where(failed, torch.full_like(err, float("inf")), err)
+                if track_best_solution:
+                    better = (err < best_err) & ~failed
+                    packed.copy_where(better, packed.state, best_state)
+                    best_err = torch.where(better, err, best_err)
+                last_err = err
+                info.last_err = err
+                it += 1
+                info.iters_done = it
+            if lazy and bool(failed):  # the one host sync of the loop
+                try:
+                    self.linear_solver.check_info()
+                    raise RuntimeError("a linear solve failed")
+                except RuntimeError as run_err:
+                    warnings.warn(f"There was an error while running the linear optimizer. "
+                                  f"Original error message: {run_err}.", RuntimeWarning)
+                info.status[:] = NonlinearOptimizerStatus.FAIL
+                info.iters_done = int(first_fail)
+            while not lazy and it < loop_iters:
                 lin.linearize()
                 try:
                     delta = self.compute_delta(**kwargs)
