@@ -119,6 +119,14 @@ int thx_se2_retract(const void* poses, const void* delta, int64_t ldd, double st
                     void* out, int32_t P, int32_t B, int dtype, const thx_se2_eps* eps, void* stream);
 int thx_se2_op(int op, const void* a, const void* b, void* out, void* jac, int64_t N, int dtype,
                const thx_se2_eps* eps, void* stream);
+/* implicit backward on SE2 pose graphs (thx_se3_retract_vjp / thx_pg_vjp below, with 4-element records, 3-vectors): plain
+ * derivatives of the se2.py closed forms (the reference has no custom backward for SE2). */
+int thx_se2_retract_vjp(const void* poses, const void* delta, int64_t ldd, double step, const void* grad_out,
+                        void* grad_delta, int64_t ldg, int32_t P, int32_t B, int dtype, const thx_se2_eps* eps,
+                        void* stream);
+int thx_pg2_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, int64_t ldw, void* grad_meas,
+                void* grad_w_between, void* grad_prior_target, void* grad_w_prior, void* grad_log_radius_between,
+                void* grad_log_radius_prior, int dtype, const thx_se2_eps* eps, void* stream);
 
 /* ---- Linearization.linearize(): replaces DenseLinearization._linearize_jacobian_impl +
  *      _linearize_hessian_impl (dense_linearization.py:29-62) fused with Between / Local

@@ -16,16 +16,17 @@ def run_implicit(th, g, device, kernels=None):
                   w_prior=t(g["w_prior"])[:, :, :1].clone().requires_grad_(True))
     obj = th.Objective(dtype=leaves["meas"].dtype)
     poses0 = t(g["poses0"])
-    poses = [th.SE3(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    G = th.SE2 if ("group" in g and str(g["group"]) == "SE2") else th.SE3
+    poses = [G(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
     for k in range(g["edges"].shape[0]):
         i, j = g["edges"][k].tolist()
         cw = th.DiagonalCostWeight(th.Variable(leaves["w_between"][:, k], name=f"w_{k}"))
-        obj.add(th.Between(poses[i], poses[j], th.SE3(tensor=leaves["meas"][:, k], name=f"meas_{k}"), cw,
+        obj.add(th.Between(poses[i], poses[j], G(tensor=leaves["meas"][:, k], name=f"meas_{k}"), cw,
                            name=f"between_{k}"))
     for k in range(g["prior_idx"].shape[0]):
         sw = th.ScaleCostWeight(th.Variable(leaves["w_prior"][:, k], name=f"pw_{k}"))
         obj.add(th.Difference(poses[int(g["prior_idx"][k])],
-                              th.SE3(tensor=leaves["prior_target"][:, k], name=f"prior_target_{k}"), sw, name=f"prior_{k}"))
+                              G(tensor=leaves["prior_target"][:, k], name=f"prior_target_{k}"), sw, name=f"prior_{k}"))
     lkw = dict(kernels=kernels) if kernels is not None else None
     opt = th.LevenbergMarquardt(obj, linearization_kwargs=lkw, max_iterations=kw.pop("max_iterations"),
                                 step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0)

@@ -242,6 +242,9 @@ class OracleKernels:
             (g,) = torch.autograd.grad(y, d, grad_out.transpose(0, 1))
         grad_delta.copy_(g)
 
+    def retract_vjp(self, poses, delta, step, grad_out, grad_delta):
+        return self.se3_retract_vjp(poses, delta, step, grad_out, grad_delta)   # opg.retract dispatches on the shape
+
     def pg_vjp(self, s, t, w, g_meas, g_wb, g_tgt, g_wp, poses=None, g_lrb=None, g_lrp=None):
         import dataclasses
         p, x = self._problem(s, t, poses)

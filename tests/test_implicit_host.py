@@ -5,17 +5,18 @@ import pytest
 import torch
 
 from tests.helpers import load_golden
+from tests.helpers import golden_problem  # noqa: F401
 from tests.implicit_common import check_against_reference, run_implicit
 
 
-@pytest.mark.parametrize("name", ["pg_f64_implicit", "pg_f64_implicit_b"])
+@pytest.mark.parametrize("name", ["pg_f64_implicit", "pg_f64_implicit_b", "pg2_f64_implicit"])
 def test_implicit_gradients_match_reference(name):
     import theseus_amd as th
     from tests.oracle_kernels import OracleKernels
     g = load_golden(name)
     final, loss, grads, info, _, _ = run_implicit(th, g, "cpu", OracleKernels())
     check_against_reference(g, final, loss, grads)
-    assert info.iters_done == 8 if name == "pg_f64_implicit" else info.iters_done == 5
+    assert info.iters_done == golden_problem(g)[2]["max_iterations"]
 
 
 def test_stale_factor_is_detected_and_unroll_with_grad_refused():

@@ -62,7 +62,7 @@ def test_lm_trajectory_matches_reference(name, tol):
     np.testing.assert_allclose(hist[:, :k], ref[:, :k], rtol=2e-5 if tol < 1e-6 else 2e-3)
 
 
-@pytest.mark.parametrize("name", ["pg_f64_implicit", "pg_f64_implicit_b"])
+@pytest.mark.parametrize("name", ["pg_f64_implicit", "pg_f64_implicit_b", "pg2_f64_implicit"])
 def test_implicit_backward_gradients_match_reference(name):
     """Pins the oracle's implicit step (autograd through the restated formulas) to the gradients the REAL
     reference produced through TheseusLayer(backward_mode="implicit") (torchlie's custom backward passes)."""
@@ -77,7 +77,7 @@ def test_implicit_backward_gradients_match_reference(name):
                   prior_target=p.prior_target.clone().requires_grad_(True),
                   w_scale=p.w_prior[:, :, :1].clone().requires_grad_(True))
     pg = dataclasses.replace(p, meas=leaves["meas"], w_between=leaves["w_between"], prior_target=leaves["prior_target"],
-                             w_prior=leaves["w_scale"].expand(-1, -1, 6))
+                             w_prior=leaves["w_scale"].expand(-1, -1, p.dof))
     final, _ = opg.implicit_final_step(pg, x)
     np.testing.assert_allclose(final.detach().numpy(), g["final"], rtol=0, atol=5e-8)
     loss = (torch.from_numpy(g["coef"]) * final).sum()

@@ -19,7 +19,7 @@ THX_TILE = 128
 THX_ERR_CHUNKS = 16
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class LieEps(Structure):
@@ -105,6 +105,10 @@ _SIGNATURES = {
                         c_void_p],
     "thx_lm_accept_diag": [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int,
                            c_double, c_double, c_double, c_void_p, c_int, c_void_p],
+    "thx_se2_retract_vjp": [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int,
+                            POINTER(SE2Eps), c_void_p],
+    "thx_pg2_vjp": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                    c_void_p, c_void_p, c_int, POINTER(SE2Eps), c_void_p],
     "thx_chol_factor": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,
                         c_void_p, c_int, c_void_p],
     "thx_chol_factor_forward": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,

@@ -27,8 +27,9 @@ def pg_vjp_grads(K, packed, t, w):
     B = t.poses.shape[1]
     E, Kp = packed.structure.num_edges, packed.structure.num_priors
     new = lambda *s: torch.empty(*s, dtype=w.dtype, device=w.device)  # noqa: E731
-    g_meas, g_wb = new(max(E, 1), B, 3, 4), new(max(E, 1), B, 6)
-    g_tgt, g_wp = new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 6)
+    gs, dof = t.poses.shape[2:], (3 if t.se2 else 6)   # group record shape (3,4) | (4,)
+    g_meas, g_wb = new(max(E, 1), B, *gs), new(max(E, 1), B, dof)
+    g_tgt, g_wp = new(max(Kp, 1), B, *gs), new(max(Kp, 1), B, dof)
     g_lrb = new(max(E, 1), B, 1) if t.robust_between else None
     g_lrp = new(max(Kp, 1), B, 1) if t.robust_prior else None
     K.pg_vjp(packed.dstruct, t, w, g_meas, g_wb, g_tgt, g_wp, g_lrb=g_lrb, g_lrp=g_lrp)
@@ -81,6 +82,6 @@ class ImplicitStep(torch.autograd.Function):
         t = ctx.tensors
         B, n = t.poses.shape[1], lin.n
         gd = torch.empty(B, n, dtype=t.poses.dtype, device=t.poses.device)
-        K.se3_retract_vjp(t.poses, ctx.delta, ctx.step, grad_x.contiguous(), gd)
+        K.retract_vjp(t.poses, ctx.delta, ctx.step, grad_x.contiguous(), gd)
         w = solver.solve_with_factor(gd)  # the backward linear solve
         return (None, None, None) + pg_vjp_grads(K, packed, t, w)

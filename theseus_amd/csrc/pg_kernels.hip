@@ -437,7 +437,7 @@ using namespace thx;
 extern "C" {
 
 const char* thx_last_error(void) { return last_error().c_str(); }
-int thx_abi_version(void) { return 5; }
+int thx_abi_version(void) { return 6; }
 
 int thx_pg_assemble(const thx_pg_structure* s, const thx_pg_data* d, void* H, int64_t ld, void* g, int dtype,
                     const thx_lie_eps* eps, void* stream) {

@@ -315,6 +315,17 @@ class HipKernels:
         self._keepalive = (hterm_d, gterm_d)
 
     # ---- implicit backward ----------------------------------------------------------------------
+    def retract_vjp(self, poses, delta, step, grad_out, grad_delta):
+        """grad_X_new -> grad_delta of X exp(step * delta); the group is read off the record shape."""
+        if poses.dim() == 4:
+            return self.se3_retract_vjp(poses, delta, step, grad_out, grad_delta)
+        P, B = poses.shape[:2]
+        dt = poses.dtype
+        _lib.check(self.lib.thx_se2_retract_vjp(_lib.ptr(poses), _lib.ptr(delta), delta.stride(0), float(step),
+                                                _lib.ptr(grad_out), _lib.ptr(grad_delta), grad_delta.stride(0), P, B,
+                                                _lib.dtype_code(dt), se2_eps(dt), _lib.stream_ptr(poses.device)),
+                   "thx_se2_retract_vjp")
+
     def se3_retract_vjp(self, poses, delta, step, grad_out, grad_delta):
         P, B = poses.shape[:2]
         dt = poses.dtype
@@ -324,10 +335,13 @@ class HipKernels:
                    "thx_se3_retract_vjp")
 
     def pg_vjp(self, s: DeviceStructure, t: PGTensors, w, g_meas, g_wb, g_tgt, g_wp, poses=None, g_lrb=None, g_lrp=None):
-        if t.se2:
-            raise NotImplementedError("implicit backward (thx_pg_vjp) is fused for SE3 pose graphs only")
         d = t.c_struct(poses)
         dt = w.dtype
+        if t.se2:
+            _lib.check(self.lib.thx_pg2_vjp(s.c, d, _lib.ptr(w), w.stride(0), _lib.ptr(g_meas), _lib.ptr(g_wb),
+                                            _lib.ptr(g_tgt), _lib.ptr(g_wp), _lib.ptr(g_lrb), _lib.ptr(g_lrp),
+                                            _lib.dtype_code(dt), se2_eps(dt), _lib.stream_ptr(w.device)), "thx_pg2_vjp")
+            return
         _lib.check(self.lib.thx_pg_vjp(s.c, d, _lib.ptr(w), w.stride(0), _lib.ptr(g_meas), _lib.ptr(g_wb),
                                        _lib.ptr(g_tgt), _lib.ptr(g_wp), _lib.ptr(g_lrb), _lib.ptr(g_lrp),
                                        _lib.dtype_code(dt), lie_eps(dt),

@@ -345,8 +345,8 @@ class NonlinearLeastSquares(abc.ABC):
         dense_linearization.py:61 does for this step), the graph runs through g only and its backward is one
         linear solve with the cached factor + the fused VJP kernel (theseus_amd/autograd.py)."""
         from .autograd import ImplicitStep
-        if packed.group != "SE3":
-            raise NotImplementedError("HIP back end: backward_mode='implicit' is fused for SE3 pose graphs only "
+        if packed.group not in ("SE3", "SE2"):
+            raise NotImplementedError("HIP back end: backward_mode='implicit' is fused for SE3 / SE2 pose graphs "
                                       f"(got {packed.group}); there is no autograd/CPU fallback.")
         step = self.params.step_size if kwargs.get("__keep_final_step_size__", False) else 1.0
         with torch.set_grad_enabled(outer_grad):
