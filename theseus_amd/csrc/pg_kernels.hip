@@ -74,7 +74,9 @@ __device__ __forceinline__ void load6(const T* __restrict__ p, T* w) {
 // ------------------------------------------------------------------------------------------------
 // assembly
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// ROBUST = false compiles the rescale away: the plain-cost kernel keeps its registers (with the rescale inlined the
+// fp64 Jacobian chain spilled 440 bytes per lane to scratch: 1.47 -> 1.82 ms and 3x the HBM writes, rocprofv3 PMC)
+template <typename T, bool ROBUST>
 __global__ void __launch_bounds__(64)
 pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t ld, T* __restrict__ g,
                    Eps<T> eps) {
@@ -122,14 +124,16 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
     }
     if (side == 0) {  // p is v0: own Jacobian J0, other J1
       between_eval_hp(Xp, Xq, M, w, eps, ev, &J0d, &J1d, true);
-      robustify<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, &J0d, &J1d);
+      if constexpr (ROBUST)
+        robustify<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, &J0d, &J1d);
       const SJac<T> J0 = narrow<T>(J0d);
       sjac_tmul_acc(J0, J0, Dg);
       sjac_tvec_sub(J0d, ev, gv);
       if (lower) sjac_tmul_acc(J0, narrow<T>(J1d), Off);
     } else {  // p is v1
       between_eval_hp(Xq, Xp, M, w, eps, ev, &J0d, &J1d, true);
-      robustify<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, &J0d, &J1d);
+      if constexpr (ROBUST)
+        robustify<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, &J0d, &J1d);
       const SJac<T> J1 = narrow<T>(J1d);
       sjac_tmul_acc(J1, J1, Dg);
       sjac_tvec_sub(J1d, ev, gv);
@@ -155,7 +159,8 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
     load6(wp + ((int64_t)id * wB) * 6 + (int64_t)b * d.w_prior_bstride, w);
     SJac<double> Jd;
     local_eval_hp(Tg, Xp, w, eps, ev, &Jd, true);
-    robustify<T>(d.robust_prior, d.log_radius_prior, d.log_radius_prior_bstride, id, b, B, ev, &Jd, nullptr);
+    if constexpr (ROBUST)
+      robustify<T>(d.robust_prior, d.log_radius_prior, d.log_radius_prior_bstride, id, b, B, ev, &Jd, nullptr);
     const SJac<T> J = narrow<T>(Jd);
     sjac_tmul_acc(J, J, Dg);
     sjac_tvec_sub(Jd, ev, gv);
@@ -445,11 +450,12 @@ int thx_pg_assemble(const thx_pg_structure* s, const thx_pg_data* d, void* H, in
   if (!H || !g || !eps) return fail("null output");
   if (ld < 6 * (int64_t)s->num_poses) return fail("ld < n");
   dim3 grid((d->batch + 63) / 64, s->num_poses), block(64);
-  THX_DISPATCH(dtype,
-               hipLaunchKernelGGL(pg_assemble_kernel<float>, grid, block, 0, as_stream(stream), *s, *d,
-                                  (float*)H, ld, (float*)g, make_eps<float>(eps)),
-               hipLaunchKernelGGL(pg_assemble_kernel<double>, grid, block, 0, as_stream(stream), *s, *d,
-                                  (double*)H, ld, (double*)g, make_eps<double>(eps)));
+  const bool robust = d->robust_between != THX_LOSS_NONE || d->robust_prior != THX_LOSS_NONE;
+#define THX_ASM(T, R) hipLaunchKernelGGL((pg_assemble_kernel<T, R>), grid, block, 0, as_stream(stream), *s, *d, (T*)H, ld, \
+                                         (T*)g, make_eps<T>(eps))
+  THX_DISPATCH(dtype, { if (robust) THX_ASM(float, true); else THX_ASM(float, false); },
+               { if (robust) THX_ASM(double, true); else THX_ASM(double, false); });
+#undef THX_ASM
   return check_launch("thx_pg_assemble");
 }
 
