@@ -1195,6 +1195,167 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp64 off-diagonal fast path: TWO workgroups per CU.  The generic kernel above keeps the 128x130 panel / H / X tile in
+// LDS (133 KB -> one workgroup per CU, every load phase exposed).  Here:
+//   * H_ij and the result go global <-> registers directly in the accumulator's native layout (a 4-lane group covers 32
+//     contiguous bytes of a row);
+//   * the panel's lower 32x32 sub-blocks are staged compactly (8 KB each, XOR-swizzled: conflict-free ds_read_b64 of the
+//     A fragments) in two phases -- rows 0..2 (48 KB), then row 3 -- over the K-loop's staging buffers;
+//   * the substitution runs IN PLACE: X_s = W_ss P_s goes through a 32-VGPR temporary back into P_s's registers, which
+//     then serve as the B operand of the updates P_u += (-L_us) X_s.  128 + 32 accumulator VGPRs instead of 256.
+// ------------------------------------------------------------------------------------------------
+constexpr int OFF64_SMEM = 6 * 1024 * 8;  // 48 KB >= the K-loop staging buffers (2 x 128 x 18 doubles = 36.9 KB)
+
+// D.block(S) += Pc[block idx] * Bs.block(Tt)^T, Pc block: 32 x 32 doubles, element (r, c) at r * 32 + (c ^ 2 (r & 15))
+template <int S, int Tt, typename DT>
+__device__ __forceinline__ void sub_mma64(const double* blk, const Engine<double>::Acc& Bs, DT& D0, DT& D1, int lane) {
+  // D0 / D1: the two 16-column accumulator blocks [h] of sub-block S: f64x4 (&)[2] each ([h])
+  const int rl = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch) {       // 16-row half of the panel sub-block <-> accumulator block cp = 2S + ch
+#pragma unroll
+    for (int cbh = 0; cbh < 2; ++cbh)    // 16-column half <-> B block cb = 2Tt + cbh
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) {
+        const int r = 16 * ch + rl, c = 16 * cbh + 4 * rho + kq;
+        const double a = blk[r * 32 + (c ^ (2 * rl))];
+        auto& d = ch == 0 ? D0 : D1;
+        d[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs.v[0][2 * Tt + cbh][rho], d[0], 0, 0, 0);
+        d[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs.v[1][2 * Tt + cbh][rho], d[1], 0, 0, 0);
+      }
+  }
+}
+
+__global__ void __launch_bounds__(256, 2)
+chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, const double* __restrict__ panel, int n,
+                        int64_t ld, int j, int ntiles, int i_first, int nrow_tiles, int B) {
+  using E = Engine<double>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* smem = reinterpret_cast<double*>(smem_raw);
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int b = (slot / nrow_tiles) * 8 + xcd;
+  const int i = i_first + (slot % nrow_tiles);
+  if (b >= B) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rl = lane & 15, kq = lane >> 4;
+  const int64_t mat = (int64_t)b * ld * ld;
+  const int col0 = j * TILE, row0 = i * TILE;
+  const int validB = min(TILE, n - row0);
+  double* sA = smem;
+  double* sB = smem + 128 * CT<double>::LDT;
+
+  E::Acc P;
+  E::zero(P);
+  kloop<double, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, col0, sA, sB, P, tid);
+  // ---- P = H_ij - sum, H straight from global memory in the native layout (rows outside the matrix: zero) ----
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = 32 * wave + 16 * h + rl;
+    const bool rv = r < validB;
+    const double* Hrow = H + mat + (int64_t)(row0 + (rv ? r : 0)) * ld + col0 + kq;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) {
+        const double hv = Hrow[16 * cb + 4 * rho];
+        P.v[h][cb][rho] = (rv ? hv : 0.0) - P.v[h][cb][rho];
+      }
+  }
+  // ---- panel sub-blocks -> LDS (swizzled), phase A: block rows 0..2 (six blocks) ----
+  const double* Pn = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
+  auto stage = [&](int first, int count) __attribute__((always_inline)) {
+    constexpr int SB[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3}, TB[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
+    const int pi = tid >> 3, pc = tid & 7;  // row of the sub-block, 32-byte piece (4 doubles) of the row
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < count) {
+        const int blk = first + k;
+        int sbk = 0, tbk = 0;
+#pragma unroll
+        for (int q = 0; q < 10; ++q)
+          if (q == blk) { sbk = SB[q]; tbk = TB[q]; }
+        const double2* src = reinterpret_cast<const double2*>(Pn + (32 * sbk + pi) * TILE + 32 * tbk + 4 * pc);
+        const double2 v0 = src[0], v1 = src[1];
+        double* dst = smem + (size_t)k * 1024 + pi * 32;
+        // columns 4pc, 4pc+1 | 4pc+2, 4pc+3 -> swizzled pairs (2-double pieces stay contiguous: the swizzle is even)
+        *reinterpret_cast<double2*>(dst + ((4 * pc) ^ (2 * (pi & 15)))) = v0;
+        *reinterpret_cast<double2*>(dst + ((4 * pc + 2) ^ (2 * (pi & 15)))) = v1;
+      }
+    }
+  };
+  // (the K-loop ends on a barrier: the staging buffers are free)
+  stage(0, 4);
+  {  // blocks 4, 5 of phase A
+    constexpr int SB2[2] = {2, 2}, TB2[2] = {1, 2};
+    const int pi = tid >> 3, pc = tid & 7;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const double2* src = reinterpret_cast<const double2*>(Pn + (32 * SB2[k] + pi) * TILE + 32 * TB2[k] + 4 * pc);
+      const double2 v0 = src[0], v1 = src[1];
+      double* dst = smem + (size_t)(4 + k) * 1024 + pi * 32;
+      *reinterpret_cast<double2*>(dst + ((4 * pc) ^ (2 * (pi & 15)))) = v0;
+      *reinterpret_cast<double2*>(dst + ((4 * pc + 2) ^ (2 * (pi & 15)))) = v1;
+    }
+  }
+  __syncthreads();
+  // ---- in-place substitution, sub-block columns 0..2 ----
+  auto solve_diag = [&](auto is, const double* Wss) __attribute__((always_inline)) {
+    constexpr int sb = decltype(is)::value;
+    f64x4 T0[2], T1[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) { T0[h][r4] = 0.0; T1[h][r4] = 0.0; }
+    sub_mma64<sb, sb>(Wss, P, T0, T1, lane);  // X_s = W_ss P_s
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      P.v[h][2 * sb] = T0[h];
+      P.v[h][2 * sb + 1] = T1[h];
+    }
+  };
+  auto update = [&](auto is, auto it, const double* Mst) __attribute__((always_inline)) {
+    constexpr int sb = decltype(is)::value, tb = decltype(it)::value;
+    f64x4 D0[2] = {P.v[0][2 * sb], P.v[1][2 * sb]}, D1[2] = {P.v[0][2 * sb + 1], P.v[1][2 * sb + 1]};
+    sub_mma64<sb, tb>(Mst, P, D0, D1, lane);  // P_s += (-L_st) X_t  (X_t lives in P_t's registers)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      P.v[h][2 * sb] = D0[h];
+      P.v[h][2 * sb + 1] = D1[h];
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  solve_diag(I0{}, smem + 0 * 1024);
+  update(I1{}, I0{}, smem + 1 * 1024);
+  solve_diag(I1{}, smem + 2 * 1024);
+  update(I2{}, I0{}, smem + 3 * 1024);
+  update(I2{}, I1{}, smem + 4 * 1024);
+  solve_diag(I2{}, smem + 5 * 1024);
+  __syncthreads();  // phase A blocks consumed
+  stage(6, 4);      // phase B: block row 3
+  __syncthreads();
+  update(I3{}, I0{}, smem + 0 * 1024);
+  update(I3{}, I1{}, smem + 1 * 1024);
+  update(I3{}, I2{}, smem + 2 * 1024);
+  solve_diag(I3{}, smem + 3 * 1024);
+  // ---- store X (in P's registers) ----
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = 32 * wave + 16 * h + rl;
+    if (r < validB) {
+      double* Lrow = L + mat + (int64_t)(row0 + r) * ld + col0 + kq;
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) Lrow[16 * cb + 4 * rho] = P.v[h][cb][rho];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // triangular solves with one right-hand side per problem, one workgroup per problem, HBM bound
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -1388,6 +1549,8 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)OffdiagSmem<T>::bytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f32_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF32_SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
     attr_off = true;
   }
   hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)B, st);
@@ -1397,8 +1560,13 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       hipLaunchKernelGGL(chol_offdiag_f32_kernel, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, s, (const float*)H, (float*)L,
                          (const float*)panel, n, ld, j, ntiles, i_first, nrt, B);
     else
+#ifdef THX_F64_GENERIC_OFFDIAG
       hipLaunchKernelGGL(chol_offdiag_kernel<T>, dim3(Bpad * nrt), dim3(256), OffdiagSmem<T>::bytes, s, (const T*)H,
                          (T*)L, (const T*)panel, n, ld, j, ntiles, i_first, nrt, B);
+#else
+      hipLaunchKernelGGL(chol_offdiag_f64_kernel, dim3(Bpad * nrt), dim3(256), OFF64_SMEM, s, (const double*)H, (double*)L,
+                         (const double*)panel, n, ld, j, ntiles, i_first, nrt, B);
+#endif
   };
   auto diag = [&](int j) {
     hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(B), dim3(256), dsm, st, (const T*)H, (T*)L, (T*)panel,
