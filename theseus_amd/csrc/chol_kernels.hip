@@ -444,6 +444,44 @@ struct Engine<double> {
 #pragma unroll
     for (int v = 0; v <= UL; ++v) fin(UL, v, acc[UH + 1 + v]);
   }
+  // H_jj blocks global -> registers before the K-loop / S = H (+ damping) - acc -> LDS afterwards (see Engine<float>)
+  template <int G>
+  static __device__ __forceinline__ void syrk36_prefetch(const double* __restrict__ Hjj, int64_t ld, int valid, f64x4* hp,
+                                                        int lane) {
+    constexpr int UH = 4 + G, UL = 3 - G;
+    auto ldb = [&](int u, int v) __attribute__((always_inline)) -> f64x4 {
+      const double* p = Hjj + (int64_t)min(16 * u + (lane & 15), valid - 1) * ld + 16 * v + (lane >> 4);
+      f64x4 h;
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) h[rho] = p[4 * rho];
+      return h;
+    };
+#pragma unroll
+    for (int v = 0; v <= UH; ++v) hp[v] = ldb(UH, v);
+#pragma unroll
+    for (int v = 0; v <= UL; ++v) hp[UH + 1 + v] = ldb(UL, v);
+  }
+  template <int G>
+  static __device__ __forceinline__ void syrk36_store(double* tile, const f64x4* hp, const f64x4* acc, int lane, int valid,
+                                                      bool damp, double lam, int ellipsoidal, double eps) {
+    constexpr int UH = 4 + G, UL = 3 - G;
+    auto st = [&](int u, int v, const f64x4& h, const f64x4& a) __attribute__((always_inline)) {
+      const int r = 16 * u + (lane & 15), c0 = 16 * v + (lane >> 4);
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) {
+        const int c = c0 + 4 * rho;
+        double x = h[rho];
+        if (u == v && r == c && damp) x = ellipsoidal ? x + (lam * x + eps) : x + lam;
+        x -= a[rho];
+        if (r >= valid || c >= valid) x = (r == c) ? 1.0 : 0.0;
+        tile[r * 130 + c] = x;
+      }
+    };
+#pragma unroll
+    for (int v = 0; v <= UH; ++v) st(UH, v, hp[v], acc[v]);
+#pragma unroll
+    for (int v = 0; v <= UL; ++v) st(UL, v, hp[UH + 1 + v], acc[UH + 1 + v]);
+  }
   static __device__ __forceinline__ void blk_zero(Blk& d) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -792,9 +830,9 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[i][k] = T(0);
   T tpart = T(0);  // this thread's half of (L_j,0:j y)[tid >> 1]
-  [[maybe_unused]] float4 hpre[9];
-  if constexpr (sizeof(T) == 4) {  // H_jj blocks in flight during the whole K-loop (fp32 path; fp64 stages through LDS)
-    const float* Hjj = H + mat + (int64_t)row0 * ld + row0;
+  std::conditional_t<sizeof(T) == 4, float4, f64x4> hpre[9];
+  {  // H_jj blocks in flight during the whole K-loop
+    const T* Hjj = H + mat + (int64_t)row0 * ld + row0;
     if (wave == 0) E::template syrk36_prefetch<0>(Hjj, ld, valid, hpre, lane);
     else if (wave == 1) E::template syrk36_prefetch<1>(Hjj, ld, valid, hpre, lane);
     else if (wave == 2) E::template syrk36_prefetch<2>(Hjj, ld, valid, hpre, lane);
@@ -812,9 +850,9 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   __syncthreads();  // staging buffer is free
   THX_STAMP();
   if (tid < TILE) vvec[tid] = (fwd && tid < valid) ? rhs[(int64_t)b * ldv + row0 + tid] : T(0);
-  if constexpr (sizeof(T) == 4) {
+  {
     const bool damp = damping != nullptr;
-    const float lam = damp ? damping[b] : 0.f;
+    const T lam = damp ? damping[b] : T(0);
     if (wave == 0) E::template syrk36_store<0>(tile, hpre, acc, lane, valid, damp, lam, ellipsoidal, damping_eps);
     else if (wave == 1) E::template syrk36_store<1>(tile, hpre, acc, lane, valid, damp, lam, ellipsoidal, damping_eps);
     else if (wave == 2) E::template syrk36_store<2>(tile, hpre, acc, lane, valid, damp, lam, ellipsoidal, damping_eps);
@@ -824,31 +862,6 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
       const T tsum = tpart + __shfl_xor(tpart, 1);
       if (fwd && (tid & 1) == 0) vvec[tid >> 1] -= tsum;
     }
-  } else {
-    tile_g2l<T>(H + mat + (int64_t)row0 * ld + row0, ld, valid, valid, tile, tid);
-    __syncthreads();
-    if (tid < TILE) {
-      T hv = tile[tid * C::LDM + tid];
-      if (tid < valid) {
-        if (damping) {
-          const T lam = damping[b];
-          hv = ellipsoidal ? hv + (lam * hv + damping_eps) : hv + lam;
-        }
-      } else {
-        hv = T(1);
-      }
-      tile[tid * C::LDM + tid] = hv;
-    }
-    {  // g_j - L_j,0:j y : thread pair (2r, 2r+1) holds the two halves of row r's sum
-      const T tsum = tpart + __shfl_xor(tpart, 1);
-      if (fwd && (tid & 1) == 0) vvec[tid >> 1] -= tsum;
-    }
-    __syncthreads();
-    // own blocks: tile(u,v) <- tile(u,v) - acc (each lane touches only its own elements)
-    if (wave == 0) E::template syrk36_finish<0>(tile, acc, lane);
-    else if (wave == 1) E::template syrk36_finish<1>(tile, acc, lane);
-    else if (wave == 2) E::template syrk36_finish<2>(tile, acc, lane);
-    else E::template syrk36_finish<3>(tile, acc, lane);
   }
   __syncthreads();
   THX_STAMP();
