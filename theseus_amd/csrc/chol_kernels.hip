@@ -541,26 +541,27 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   using V = typename C::V;
   const int lrow = tid >> 3, lc = tid & 7;
   uint4 ra[4], rb[4];
-  // rows outside the matrix are read from a clamped (in-bounds) row and zeroed by value: selecting
-  // between a global pointer and a local zero makes hipcc emit flat loads through scratch
-  int64_t offA[4], offB[4];
-  bool okA[4], okB[4];
+  // Operand rows through BUFFER loads: base pointer + extent live in a 4-SGPR resource, each lane contributes a 32-bit
+  // byte offset, the k-chunk offset is a scalar -- no 64-bit per-row addresses in VGPRs (the fp64 kernels, two
+  // workgroups per CU = 256 VGPRs, spilled them, and every reload put an s_waitcnt vmcnt(0) into the prefetch), and rows
+  // outside the matrix are zeroed by the hardware bounds check (extent = valid rows) instead of v_cndmask / exec branches.
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(Arows), 0, (int)((int64_t)validA * ld * (int64_t)sizeof(T)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(SAME ? Arows : Brows), 0, (int)((int64_t)(SAME ? validA : validB) * ld * (int64_t)sizeof(T)), 0x00020000);
+  unsigned voff[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int row = lrow + 32 * u;
-    okA[u] = row < validA;
-    okB[u] = row < validB;
-    offA[u] = (int64_t)(okA[u] ? row : 0) * ld + lc * C::VEC;
-    offB[u] = (int64_t)(okB[u] ? row : 0) * ld + lc * C::VEC;
-  }
+  for (int u = 0; u < 4; ++u) voff[u] = (unsigned)(((lrow + 32 * u) * (int)ld + lc * C::VEC) * (int)sizeof(T));
   auto gload = [&](int k0) __attribute__((always_inline)) {
+    const int so = k0 * (int)sizeof(T);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      uint4 va = *reinterpret_cast<const uint4*>(Arows + offA[u] + k0);
-      ra[u] = okA[u] ? va : make_uint4(0, 0, 0, 0);
+      const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], so, 0);
+      ra[u] = make_uint4(va.x, va.y, va.z, va.w);
       if (!SAME) {
-        uint4 vb = *reinterpret_cast<const uint4*>(Brows + offB[u] + k0);
-        rb[u] = okB[u] ? vb : make_uint4(0, 0, 0, 0);
+        const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff[u], so, 0);
+        rb[u] = make_uint4(vb.x, vb.y, vb.z, vb.w);
       }
     }
   };
