@@ -578,7 +578,11 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
       if (!SAME) *reinterpret_cast<uint4*>(sB + row * LDT + lc * C::VEC) = rb[u];
     }
     __syncthreads();
+#ifdef THX_EXP_NOLOAD
+    if (kc == 0 && kc + 1 < nk) gload((kc + 1) * C::KB);   // timing experiment: operands are not streamed (garbage results)
+#else
     if (kc + 1 < nk) gload((kc + 1) * C::KB);
+#endif
     if constexpr (GEMV) {
       if (gemv_y) {
         constexpr int HALF = C::KB / 2;
@@ -595,7 +599,11 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
         }
       }
     }
+#ifdef THX_EXP_NOMFMA
+    if (K < 0) compute();  // timing experiment: no MFMAs (garbage results)
+#else
     compute();  // MFMAs on the staged chunk (sA / sB)
+#endif
   }
   if constexpr (GEMV) {
     if (gemv_part) *gemv_part = gsum;
