@@ -1,9 +1,8 @@
 """Helpers for the -m gpu parity tests: golden fixture / oracle problem -> device layout."""
-import numpy as np
 import torch
 
 from theseus_amd.compiler import PoseGraphStructure
-from theseus_amd.kernels import PGTensors, default_kernels, round_up
+from theseus_amd.kernels import PGTensors, round_up
 
 
 def to_device_problem(p, poses0, device="cuda"):

@@ -3,7 +3,7 @@ implicit golden fixture with requires_grad leaves, run TheseusLayer(backward_mod
 import numpy as np
 import torch
 
-from tests.helpers import golden_problem, load_golden
+from tests.helpers import golden_problem
 
 
 def run_implicit(th, g, device, kernels=None):

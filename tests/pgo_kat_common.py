@@ -1,7 +1,6 @@
 """The reference's own known-answer test for this path -- tests/theseus_tests/test_pgo_benchmark.py:34-39 (four outer
 losses of examples/pose_graph/pose_graph_synthetic.py at rel=abs=1e-10) -- restated on the committed inputs
 (tests/golden/pgo_kat.npz, produced by the reference's generator: oracle/gen_golden.py:gen_pgo_kat)."""
-import numpy as np
 import torch
 
 from oracle import lie

@@ -3,7 +3,6 @@
 CholeskyDenseSolver trajectories.  GPU twin: tests/test_gpu_ba.py."""
 import numpy as np
 import pytest
-import torch
 
 from tests.ba_common import reference_columns, run_ba
 from tests.helpers import load_golden

@@ -4,7 +4,6 @@ import ctypes
 import os
 import re
 
-import numpy as np
 import pytest
 
 from tests.conftest import ROOT

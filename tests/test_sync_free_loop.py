@@ -7,7 +7,7 @@ import warnings
 import numpy as np
 import torch
 
-from tests.helpers import golden_problem, load_golden
+from tests.helpers import load_golden
 
 
 def _run(g, lazy, gauss_newton=False, **okw):

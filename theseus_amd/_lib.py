@@ -7,7 +7,7 @@ pointers and streams are then shared with torch.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint8, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
 
 import torch
 

@@ -9,7 +9,7 @@ back substitution (thx_ba_backsub).  Column order of this linearization: cameras
 a ``VariableOrdering`` like any user-supplied one (theseus/optimizer/linearization.py:18-41).
 """
 import dataclasses
-from typing import Any, Dict, List, Optional, Type, Union
+from typing import Any, Dict, Optional, Type, Union
 
 import numpy as np
 import torch

@@ -11,8 +11,6 @@ from typing import List, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import _lib
-
 H_TARGET = np.dtype([("row0", "<i4"), ("col0", "<i4"), ("dof_a", "<i4"), ("dof_b", "<i4"), ("term_begin", "<i4"),
                      ("term_end", "<i4"), ("elem_begin", "<i4"), ("pad", "<i4")])
 H_TERM = np.dtype([("Ja", "<u8"), ("Jb", "<u8"), ("bstride_a", "<i8"), ("bstride_b", "<i8"), ("dim", "<i4"),

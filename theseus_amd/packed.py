@@ -8,7 +8,7 @@ the fused HIP kernels index directly.  Variables are tracked by ``_num_updates``
 buffers are re-packed only when somebody changed a variable behind our back.
 """
 import dataclasses
-from typing import List, Optional
+from typing import Optional
 
 import torch
 

@@ -6,7 +6,7 @@ small radial terms, pixel noise) and of the example objective (examples/bundle_a
 Reprojection costs, Difference regularisers on every variable, strong priors on a few cameras), with ONE topology shared
 by the batch; batch items = independent draws of the feature noise and of the initial perturbations.
 """
-from typing import Dict, List, Tuple
+from typing import List, Tuple
 
 import numpy as np
 import torch
