@@ -112,23 +112,6 @@ struct Engine<float> {
   }
   static __device__ __forceinline__ void chunk(const float* sA, const float* sBw, Acc& acc, int lane) {
     const int rl = lane & 31, g = lane >> 5;
-#ifdef THX_CHUNK_INTERLEAVE
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const float4 fb = *reinterpret_cast<const float4*>(sBw + rl * 36 + 8 * ks + 4 * g);
-      float4 fa[4];
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) fa[cb] = *reinterpret_cast<const float4*>(sA + (32 * cb + rl) * 36 + 8 * ks + 4 * g);
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb].x, fb.x, acc.v[cb], 0, 0, 0);
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb].y, fb.y, acc.v[cb], 0, 0, 0);
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb].z, fb.z, acc.v[cb], 0, 0, 0);
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb].w, fb.w, acc.v[cb], 0, 0, 0);
-    }
-#else
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const float4 fb = *reinterpret_cast<const float4*>(sBw + rl * 36 + 8 * ks + 4 * g);
@@ -140,47 +123,6 @@ struct Engine<float> {
         acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc.v[cb], 0, 0, 0);
         acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc.v[cb], 0, 0, 0);
       }
-    }
-#endif
-  }
-  // ---- native-layout helpers: lane (rl = lane&31, g = lane>>5) of wave w holds tile row 32w + rl,
-  //      register rho of block cb <-> tile column 32cb + 8(rho>>2) + 4g + (rho&3)
-  // acc <- tile - acc   (tile: an H tile staged in LDS, row stride 132)
-  static __device__ __forceinline__ void rsub_lds(Acc& acc, const float* tile, int wave, int lane) {
-    const float* row = tile + (32 * wave + (lane & 31)) * 132 + 4 * (lane >> 5);
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 h = *reinterpret_cast<const float4*>(row + 32 * cb + 8 * q);
-        acc.v[cb][4 * q + 0] = h.x - acc.v[cb][4 * q + 0];
-        acc.v[cb][4 * q + 1] = h.y - acc.v[cb][4 * q + 1];
-        acc.v[cb][4 * q + 2] = h.z - acc.v[cb][4 * q + 2];
-        acc.v[cb][4 * q + 3] = h.w - acc.v[cb][4 * q + 3];
-      }
-  }
-  static __device__ __forceinline__ void store_lds(const Acc& acc, float* tile, int wave, int lane) {
-    float* row = tile + (32 * wave + (lane & 31)) * 132 + 4 * (lane >> 5);
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(row + 32 * cb + 8 * q) =
-            make_float4(acc.v[cb][4 * q], acc.v[cb][4 * q + 1], acc.v[cb][4 * q + 2], acc.v[cb][4 * q + 3]);
-  }
-  // D.block(S) += M[rows of sub-block S][cols of sub-block Tt] * Bs.block(Tt)^T, i.e. for every tile row r
-  // this wave owns:  D[r][32S + i] += sum_{c in block Tt} M[32S + i][c] * Bs[r][c].
-  // The B operand is the accumulator itself: MFMA k = 0/1 <-> columns c and c+4 held by lane groups 0/1.
-  template <int S, int Tt>
-  static __device__ __forceinline__ void sub_mma(const float* M, const Acc& Bs, Acc& D, int lane) {
-    const float* arow = M + (32 * S + (lane & 31)) * 132 + 32 * Tt + 4 * (lane >> 5);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 fa = *reinterpret_cast<const float4*>(arow + 8 * q);
-      D.v[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, Bs.v[Tt][4 * q + 0], D.v[S], 0, 0, 0);
-      D.v[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, Bs.v[Tt][4 * q + 1], D.v[S], 0, 0, 0);
-      D.v[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, Bs.v[Tt][4 * q + 2], D.v[S], 0, 0, 0);
-      D.v[S] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, Bs.v[Tt][4 * q + 3], D.v[S], 0, 0, 0);
     }
   }
 
@@ -222,22 +164,6 @@ struct Engine<float> {
         for (int m = 0; m < 8; ++m) acc[UH + 1 + v] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m], fbl[m], acc[UH + 1 + v], 0, 0, 0);
       }
     }
-  }
-  // tile(u, v) <- tile(u, v) - acc for the blocks of syrk36 (16x16 C layout: lane holds row 16u + (lane&15),
-  // columns 16v + 4(lane>>4) .. +3)
-  template <int G>
-  static __device__ __forceinline__ void syrk36_finish(float* tile, const f32x4* acc, int lane) {
-    constexpr int UH = 4 + G, UL = 3 - G;
-    auto fin = [&](int u, int v, const f32x4& a) __attribute__((always_inline)) {
-      float4* p = reinterpret_cast<float4*>(tile + (16 * u + (lane & 15)) * 132 + 16 * v + 4 * (lane >> 4));
-      float4 h = *p;
-      h.x -= a[0]; h.y -= a[1]; h.z -= a[2]; h.w -= a[3];
-      *p = h;
-    };
-#pragma unroll
-    for (int v = 0; v <= UH; ++v) fin(UH, v, acc[v]);
-#pragma unroll
-    for (int v = 0; v <= UL; ++v) fin(UL, v, acc[UH + 1 + v]);
   }
   // The same nine blocks of H_jj, global -> registers BEFORE the K-loop (row index clamped into the matrix: the caller
   // masks by value), so that the H tile costs no exposed round trips after it.
@@ -350,44 +276,6 @@ struct Engine<double> {
       }
     }
   }
-  // ---- native-layout helpers: lane (rl = lane&15, kq = lane>>4) of wave w holds tile rows
-  //      32w + 16h + rl (h = 0,1); register rho of block cb <-> tile column 16cb + 4rho + kq
-  static __device__ __forceinline__ void rsub_lds(Acc& acc, const double* tile, int wave, int lane) {
-    const int rl = lane & 15, kq = lane >> 4;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int cb = 0; cb < 8; ++cb)
-#pragma unroll
-        for (int rho = 0; rho < 4; ++rho)
-          acc.v[h][cb][rho] = tile[(32 * wave + 16 * h + rl) * 130 + 16 * cb + 4 * rho + kq] - acc.v[h][cb][rho];
-  }
-  static __device__ __forceinline__ void store_lds(const Acc& acc, double* tile, int wave, int lane) {
-    const int rl = lane & 15, kq = lane >> 4;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int cb = 0; cb < 8; ++cb)
-#pragma unroll
-        for (int rho = 0; rho < 4; ++rho)
-          tile[(32 * wave + 16 * h + rl) * 130 + 16 * cb + 4 * rho + kq] = acc.v[h][cb][rho];
-  }
-  // as Engine<float>::sub_mma; a 32-column sub-block is two 16-column MFMA blocks, the accumulator
-  // register rho of block cb serves as the B operand for k = kq <-> column 16cb + 4rho + kq.
-  template <int S, int Tt>
-  static __device__ __forceinline__ void sub_mma(const double* M, const Acc& Bs, Acc& D, int lane) {
-    const int rl = lane & 15, kq = lane >> 4;
-#pragma unroll
-    for (int cp = 2 * S; cp < 2 * S + 2; ++cp)
-#pragma unroll
-      for (int cb = 2 * Tt; cb < 2 * Tt + 2; ++cb)
-#pragma unroll
-        for (int rho = 0; rho < 4; ++rho) {
-          const double a = M[(16 * cp + rl) * 130 + 16 * cb + 4 * rho + kq];
-          D.v[0][cp] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs.v[0][cb][rho], D.v[0][cp], 0, 0, 0);
-          D.v[1][cp] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs.v[1][cb][rho], D.v[1][cp], 0, 0, 0);
-        }
-  }
 
   // ---- 32x32 block helpers (see Engine<float>): Blk.v[mh][nh][rho] <-> row n = 16nh + (lane&15),
   //      column m = 16mh + (lane>>4) + 4rho; LDS row stride 130
@@ -429,20 +317,6 @@ struct Engine<double> {
         for (int m = 0; m < 4; ++m) acc[UH + 1 + v] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], fbl[m], acc[UH + 1 + v], 0, 0, 0);
       }
     }
-  }
-  // f64 16x16 C layout: lane holds row 16u + (lane&15), columns 16v + (lane>>4) + 4 rho
-  template <int G>
-  static __device__ __forceinline__ void syrk36_finish(double* tile, const f64x4* acc, int lane) {
-    constexpr int UH = 4 + G, UL = 3 - G;
-    auto fin = [&](int u, int v, const f64x4& a) __attribute__((always_inline)) {
-      double* p = tile + (16 * u + (lane & 15)) * 130 + 16 * v + (lane >> 4);
-#pragma unroll
-      for (int rho = 0; rho < 4; ++rho) p[4 * rho] -= a[rho];
-    };
-#pragma unroll
-    for (int v = 0; v <= UH; ++v) fin(UH, v, acc[v]);
-#pragma unroll
-    for (int v = 0; v <= UL; ++v) fin(UL, v, acc[UH + 1 + v]);
   }
   // H_jj blocks global -> registers before the K-loop / S = H (+ damping) - acc -> LDS afterwards (see Engine<float>)
   template <int G>
@@ -621,33 +495,6 @@ __device__ __forceinline__ void kloop(const T* __restrict__ Arows, int validA, c
   });
 }
 
-// ------------------------------------------------------------------------------------------------
-// 128x128 tile <-> LDS (row stride LDM), coalesced 16-byte accesses, zero fill outside the matrix
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void tile_g2l(const T* __restrict__ g, int64_t ld, int vrows, int vcols, T* lds, int tid) {
-  using C = CT<T>;
-  constexpr int CPR = TILE / C::VEC;        // 16-byte chunks per row
-  constexpr int RPP = 256 / CPR;            // rows per pass
-  const int c = (tid % CPR) * C::VEC, r0 = tid / CPR;
-#pragma unroll 4
-  for (int r = r0; r < TILE; r += RPP) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r < vrows && c < vcols) v = *reinterpret_cast<const uint4*>(g + (int64_t)r * ld + c);
-    *reinterpret_cast<uint4*>(lds + r * C::LDM + c) = v;
-  }
-}
-template <typename T>
-__device__ __forceinline__ void tile_l2g(const T* lds, T* __restrict__ g, int64_t ld, int vrows, int vcols, int tid) {
-  using C = CT<T>;
-  constexpr int CPR = TILE / C::VEC;
-  constexpr int RPP = 256 / CPR;
-  const int c = (tid % CPR) * C::VEC, r0 = tid / CPR;
-#pragma unroll 4
-  for (int r = r0; r < TILE; r += RPP)
-    if (r < vrows && c < vcols)
-      *reinterpret_cast<uint4*>(g + (int64_t)r * ld + c) = *reinterpret_cast<const uint4*>(lds + r * C::LDM + c);
-}
 
 // ------------------------------------------------------------------------------------------------
 // blocked substitutions with a panel M in LDS (diag sub-blocks W_ss = L_ss^-1, below: -L_st)
@@ -1008,77 +855,13 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 }
 
 // ------------------------------------------------------------------------------------------------
-// chol_offdiag: GEMM K-loop + blocked MFMA substitution  L_ij = (H_ij - sum) L_jj^-T
+// chol_offdiag: GEMM K-loop + blocked MFMA substitution  L_ij = (H_ij - sum) L_jj^-T.
+// Two kernels, one per dtype; both keep two workgroups per CU resident and move H / the result between global memory and
+// registers directly.  (The first version of this kernel staged H, the full 128x130 panel and the result through one LDS
+// tile: 67 / 133 KB, every load phase exposed; it is gone.)
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-struct OffdiagSmem {
-  static constexpr size_t stage = (size_t)2 * 128 * CT<T>::LDT * sizeof(T);
-  static constexpr size_t tile = (size_t)128 * CT<T>::LDM * sizeof(T);
-  static constexpr size_t bytes = stage > tile ? stage : tile;
-};
-
-template <typename T>
-__global__ void __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1)
-chol_offdiag_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict__ panel, int n, int64_t ld,
-                    int j, int ntiles, int i_first, int nrow_tiles, int B) {
-  using C = CT<T>;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* smem = reinterpret_cast<T*>(smem_raw);
-  // XCD-aware mapping: block id -> (problem, tile) so that all row tiles of one problem (which share
-  // the L_j panel) run on the same XCD (blocks are dealt round-robin over the 8 XCDs).
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, slot = bid >> 3;
-  const int b = (slot / nrow_tiles) * 8 + xcd;
-  const int i = i_first + (slot % nrow_tiles);  // row tiles [i_first, i_first + nrow_tiles) of block column j
-  if (b >= B) return;  // batch padded to a multiple of 8 by the launcher (whole block exits)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t mat = (int64_t)b * ld * ld;
-  const int col0 = j * TILE, row0 = i * TILE;
-  const int validA = min(TILE, n - col0);  // == TILE (j is not the last tile)
-  const int validB = min(TILE, n - row0);
-  T* sA = smem;
-  T* sB = smem + 128 * C::LDT;
-  T* tile = smem;  // [128][LDM], aliases the staging buffers
-
-  typename Engine<T>::Acc P;
-  Engine<T>::zero(P);
-  kloop<T, false>(L + mat + (int64_t)col0 * ld, validA, L + mat + (int64_t)row0 * ld, validB, ld, col0, sA, sB, P,
-                  tid);
-  // P = H_ij - sum  (H tile staged through LDS for coalescing)
-  __syncthreads();
-  tile_g2l<T>(H + mat + (int64_t)row0 * ld + col0, ld, validB, validA, tile, tid);
-  __syncthreads();
-  Engine<T>::rsub_lds(P, tile, wave, lane);
-  __syncthreads();
-  {  // panel M_j (row stride 128 in global) -> LDS
-    const T* Pn = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
-    constexpr int CPR = TILE / C::VEC, RPP = 256 / CPR;
-    const int c = (tid % CPR) * C::VEC;
-#pragma unroll 4
-    for (int rr = tid / CPR; rr < TILE; rr += RPP)
-      *reinterpret_cast<uint4*>(tile + rr * C::LDM + c) = *reinterpret_cast<const uint4*>(Pn + rr * TILE + c);
-  }
-  __syncthreads();
-  // ---- X L_jj^T = P on the matrix cores ----
-  typename Engine<T>::Acc X;
-  Engine<T>::zero(X);
-  static_for<4>([&](auto is) __attribute__((always_inline)) {
-    constexpr int sb = decltype(is)::value;
-    static_for<sb>([&](auto it) __attribute__((always_inline)) {
-      constexpr int tb = decltype(it)::value;
-      Engine<T>::template sub_mma<sb, tb>(tile, X, P, lane);  // P_s += (-L_st) X_t
-    });
-    Engine<T>::template sub_mma<sb, sb>(tile, P, X, lane);    // X_s  = W_ss P_s
-  });
-  __syncthreads();
-  Engine<T>::store_lds(X, tile, wave, lane);
-  __syncthreads();
-  tile_l2g<T>(tile, L + mat + (int64_t)row0 * ld + col0, ld, validB, validA, tid);
-}
-
 // ------------------------------------------------------------------------------------------------
-// chol_offdiag, fp32 fast path.  Same arithmetic as the generic kernel, but nothing of the epilogue
-// waits on memory: the H tile is prefetched into registers in the accumulator layout and the ten
+// chol_offdiag, fp32.  Nothing of the epilogue waits on memory: the H tile is prefetched into registers in the accumulator layout and the ten
 // lower sub-blocks of the panel (40 KB, XOR-swizzled so that unpadded 32x32 blocks read conflict
 // free) are copied to LDS BEFORE the K-loop; the result is stored straight from the registers.
 // LDS: staging 36 KB + panel 40 KB -> two workgroups per CU.
@@ -1086,7 +869,9 @@ chol_offdiag_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restr
 constexpr int OFF32_STAGE_FLOATS = 2 * 128 * 36;
 constexpr int OFF32_SMEM = (OFF32_STAGE_FLOATS + 10 * 1024) * 4;
 
-// D.block(S) += Pc[block (S,Tt)] * Bs.block(Tt)^T with the swizzled compact panel
+// D.block(S) += Pc[block (S,Tt)] * Bs.block(Tt)^T with the swizzled compact panel, i.e. for every tile row r this wave
+// owns:  D[r][32S + i] += sum_{c in block Tt} M[32S + i][c] * Bs[r][c].  The B operand is the accumulator itself: an MFMA's
+// k index is only a pairing of columns (k = 0/1 <-> columns c and c+4 held by lane groups 0/1).
 template <int S, int Tt>
 __device__ __forceinline__ void sub_mma_sw(const float* Pc, const Engine<float>::Acc& Bs, Engine<float>::Acc& D,
                                            int lane) {
@@ -1217,8 +1002,7 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// fp64 off-diagonal fast path: TWO workgroups per CU.  The generic kernel above keeps the 128x130 panel / H / X tile in
-// LDS (133 KB -> one workgroup per CU, every load phase exposed).  Here:
+// chol_offdiag, fp64: two workgroups per CU (a full 128x130 fp64 panel tile in LDS would be 133 KB):
 //   * H_ij and the result go global <-> registers directly in the accumulator's native layout (a 4-lane group covers 32
 //     contiguous bytes of a row);
 //   * the panel's lower 32x32 sub-blocks are staged compactly (8 KB each, XOR-swizzled: conflict-free ds_read_b64 of the
@@ -1567,8 +1351,6 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     attr_diag = dsm;
   }
   if (!attr_off) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_kernel<T>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)OffdiagSmem<T>::bytes);
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f32_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF32_SMEM);
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel),
@@ -1582,13 +1364,8 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       hipLaunchKernelGGL(chol_offdiag_f32_kernel, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, s, (const float*)H, (float*)L,
                          (const float*)panel, n, ld, j, ntiles, i_first, nrt, B);
     else
-#ifdef THX_F64_GENERIC_OFFDIAG
-      hipLaunchKernelGGL(chol_offdiag_kernel<T>, dim3(Bpad * nrt), dim3(256), OffdiagSmem<T>::bytes, s, (const T*)H,
-                         (T*)L, (const T*)panel, n, ld, j, ntiles, i_first, nrt, B);
-#else
       hipLaunchKernelGGL(chol_offdiag_f64_kernel, dim3(Bpad * nrt), dim3(256), OFF64_SMEM, s, (const double*)H, (double*)L,
                          (const double*)panel, n, ld, j, ntiles, i_first, nrt, B);
-#endif
   };
   auto diag = [&](int j) {
     hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(B), dim3(256), dsm, st, (const T*)H, (T*)L, (T*)panel,
