@@ -128,3 +128,44 @@ def test_reference_trajectory_with_standin_kernels(name):
     g = load_golden(name)
     final, info, _ = _run_lm(g, dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0))
     np.testing.assert_allclose(final.numpy(), g["final"], rtol=0, atol=5e-8)
+
+
+def _fail_worker(rank, world, port, outdir):
+    """Gauss-Newton (sync-free loop): the problems of rank 1 are singular from the start, rank 0's are fine."""
+    import warnings
+    import torch.distributed as dist
+    import theseus_amd as th
+    from tests.oracle_kernels import OracleKernels
+    from tests.test_gpu_lm import build_objective
+    from theseus_amd.sharding import DistBatchReducer, shard_bounds
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = dict(load_golden("pg_f64_gn"))
+        lo, hi = shard_bounds(g["poses0"].shape[0], rank, world)
+        g = _take(g, slice(lo, hi))
+        if rank == 1:
+            g["w_between"], g["w_prior"] = g["w_between"] * 0.0, g["w_prior"] * 0.0
+        obj, _ = build_objective(th, g, device="cpu")
+        opt = th.GaussNewton(obj, linearization_kwargs=dict(kernels=OracleKernels()), max_iterations=3,
+                             abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+        opt.reducer = DistBatchReducer()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs={})
+        final = torch.stack([sol[f"pose_{k}"] for k in range(int(g["P"]))], 1)
+        torch.save(dict(final=final, start=torch.from_numpy(g["poses0"]), status=[s.name for s in info.status],
+                        iters=info.iters_done), os.path.join(outdir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failure_on_one_shard_freezes_every_shard():
+    """nonlinear_least_squares.py:138-152 on a sharded batch, sync-free loop: the solve of ONE shard fails at the first
+    iteration -> every rank reports FAIL and no rank has moved its variables (what the unsharded reference run does)."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_fail_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        outs = [torch.load(os.path.join(d, f"r{r}.pt"), weights_only=False) for r in range(2)]
+    for o in outs:
+        assert all(s == "FAIL" for s in o["status"]) and o["iters"] == 0
+        assert torch.equal(o["final"], o["start"])

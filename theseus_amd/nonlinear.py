@@ -182,9 +182,10 @@ class NonlinearLeastSquares(abc.ABC):
             # ---- sync-free iterations.  Without adaptive damping, convergence tests, callbacks or a
             #      sharded batch the only host decision of an iteration is "did a linear solve fail?"
             #      (nonlinear_least_squares.py:138-152: FAIL status, variables keep their values).  That flag stays on
-            #      the device: once raised it freezes every later update through the retraction mask, and it is read
-            #      ONCE after the loop -- the host queues the iterations back to back and the GPU never drains. ----
-            lazy = (type(self.reducer) is LocalBatchReducer and not need_conv and end_iter_callback is None
+            #      the device (OR-ed over the shards by a stream-ordered all-reduce when the batch is sharded): once
+            #      raised it freezes every later update through the retraction mask, and it is read ONCE after the loop
+            #      -- the host queues the iterations back to back and the GPU never drains. ----
+            lazy = (isinstance(self.reducer, LocalBatchReducer) and not need_conv and end_iter_callback is None
                     and not verbose and not kwargs.get("adaptive_damping", False))
             failed = first_fail = None
             if lazy:
@@ -199,7 +200,7 @@ class NonlinearLeastSquares(abc.ABC):
                     warnings.warn(msg, RuntimeWarning)
                     info.status[:] = NonlinearOptimizerStatus.FAIL
                     break
-                now = self.linear_solver.info.ne(0).any()
+                now = self.reducer.device_any(self.linear_solver.info.ne(0).any())
                 first_fail = torch.where(now & ~failed, torch.full_like(first_fail, it), first_fail)
                 failed = failed | now
                 packed.retract(delta, p.step_size, failed.to(torch.uint8).expand(B).contiguous(), spare)
@@ -219,7 +220,7 @@ class NonlinearLeastSquares(abc.ABC):
             if lazy and bool(failed):  # the one host sync of the loop
                 try:
                     self.linear_solver.check_info()
-                    raise RuntimeError("a linear solve failed")
+                    raise RuntimeError("the linear solve failed on another shard of the batch")
                 except RuntimeError as run_err:
                     warnings.warn(f"There was an error while running the linear optimizer. "
                                   f"Original error message: {run_err}.", RuntimeWarning)

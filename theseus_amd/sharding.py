@@ -54,6 +54,10 @@ class LocalBatchReducer:
         s = s.tolist()
         return s[0] / s[1]
 
+    def device_any(self, flag: torch.Tensor) -> torch.Tensor:
+        """OR of a 0-dim bool tensor over the global batch, result stays on the device (no host sync)."""
+        return flag
+
     def _max(self, t):
         return t
 
@@ -71,6 +75,11 @@ class DistBatchReducer(LocalBatchReducer):
             raise RuntimeError("DistBatchReducer needs an initialised torch.distributed process group")
         self.dist, self.group = dist, group
         self.world_size = dist.get_world_size(group)
+
+    def device_any(self, flag):
+        t = flag.to(torch.int32).view(1)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)   # stream-ordered: the host does not wait
+        return t.bool().view(())
 
     def _max(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
