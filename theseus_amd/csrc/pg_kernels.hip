@@ -29,6 +29,17 @@ __device__ __forceinline__ void robustify(int kind, const void* lr, int64_t lr_b
 #pragma unroll
   for (int i = 0; i < 6; ++i) ev[i] *= f;
 }
+// Robust costs in the assembly kernel: the rescale factor f = sqrt(rho'(|w e|^2) + eps) only needs the residual, so it is
+// computed from a residual-only evaluation FIRST and folded into the weights (J' = f J, e' = f e  <=>  w' = f w) -- the
+// Jacobian pass then runs exactly as for plain costs and nothing but six weights is live across the exp() of the loss
+// (rescaling the finished fp64 Jacobians spilled 440 bytes per lane).
+template <typename T>
+__device__ __forceinline__ void robust_weights(int kind, const void* lr, int64_t lr_bs, int64_t entity, int b, int B,
+                                               const double* ev, T* w) {
+  const double f = robust_rescale<6>(kind, ev, load_log_radius<T>(lr, entity, b, B, lr_bs));
+#pragma unroll
+  for (int i = 0; i < 6; ++i) w[i] = (T)((double)w[i] * f);
+}
 }  // namespace thx
 
 namespace thx {
@@ -123,17 +134,25 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
       cur_q = q;
     }
     if (side == 0) {  // p is v0: own Jacobian J0, other J1
+      if constexpr (ROBUST) {
+        if (d.robust_between) {
+          between_eval_hp<T>(Xp, Xq, M, w, eps, ev, nullptr, nullptr, false);
+          robust_weights<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, w);
+        }
+      }
       between_eval_hp(Xp, Xq, M, w, eps, ev, &J0d, &J1d, true);
-      if constexpr (ROBUST)
-        robustify<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, &J0d, &J1d);
       const SJac<T> J0 = narrow<T>(J0d);
       sjac_tmul_acc(J0, J0, Dg);
       sjac_tvec_sub(J0d, ev, gv);
       if (lower) sjac_tmul_acc(J0, narrow<T>(J1d), Off);
     } else {  // p is v1
+      if constexpr (ROBUST) {
+        if (d.robust_between) {
+          between_eval_hp<T>(Xq, Xp, M, w, eps, ev, nullptr, nullptr, false);
+          robust_weights<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, w);
+        }
+      }
       between_eval_hp(Xq, Xp, M, w, eps, ev, &J0d, &J1d, true);
-      if constexpr (ROBUST)
-        robustify<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, &J0d, &J1d);
       const SJac<T> J1 = narrow<T>(J1d);
       sjac_tmul_acc(J1, J1, Dg);
       sjac_tvec_sub(J1d, ev, gv);
@@ -158,9 +177,13 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
     double ev[6];
     load6(wp + ((int64_t)id * wB) * 6 + (int64_t)b * d.w_prior_bstride, w);
     SJac<double> Jd;
+    if constexpr (ROBUST) {
+      if (d.robust_prior) {
+        local_eval_hp<T>(Tg, Xp, w, eps, ev, nullptr, false);
+        robust_weights<T>(d.robust_prior, d.log_radius_prior, d.log_radius_prior_bstride, id, b, B, ev, w);
+      }
+    }
     local_eval_hp(Tg, Xp, w, eps, ev, &Jd, true);
-    if constexpr (ROBUST)
-      robustify<T>(d.robust_prior, d.log_radius_prior, d.log_radius_prior_bstride, id, b, B, ev, &Jd, nullptr);
     const SJac<T> J = narrow<T>(Jd);
     sjac_tmul_acc(J, J, Dg);
     sjac_tvec_sub(Jd, ev, gv);
