@@ -1358,24 +1358,65 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     attr_off = true;
   }
   hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)B, st);
-  const int Bpad = (B + 7) / 8 * 8;
-  auto offdiag = [&](hipStream_t s, int j, int i_first, int nrt) {
+  // One half of the batch per stream, the second half one diagonal phase behind the first: the latency-bound serial part
+  // of chol_diag (one wave per workgroup busy, §4.1) and the tail of every launch of one half run underneath the MFMA-bound
+  // chol_offdiag of the other half.  The halves touch disjoint memory; the auxiliary stream forks from / joins the
+  // caller's stream through events.  (Overlapping diag(j+1) with the rest of column j of the SAME problems had gained
+  // nothing: column j+1 needs all of column j, so there is no slack to fill.)
+  struct Half {
+    hipStream_t s;
+    int b0, nb;
+  };
+  static hipStream_t aux = nullptr;
+  static hipEvent_t ev_fork = nullptr, ev_lag = nullptr, ev_join = nullptr;
+  static const int split_min = [] {
+    const char* e = getenv("THX_CHOL_SPLIT_MIN");  // batch size from which the two-stream schedule is used (0: never)
+    return e ? atoi(e) : 1024;
+  }();
+  const bool split = split_min > 0 && B >= split_min && ntiles > 1;
+  Half halves[2] = {{st, 0, B}, {st, 0, 0}};
+  if (split) {
+    if (!aux) {
+      hipStreamCreateWithFlags(&aux, hipStreamNonBlocking);
+      hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+      hipEventCreateWithFlags(&ev_lag, hipEventDisableTiming);
+      hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
+    }
+    const int b_half = min((B / 2 + 7) / 8 * 8, B);  // (multiple of 8: the XCD-aware block map of chol_offdiag)
+    halves[0] = {st, 0, b_half};
+    halves[1] = {aux, b_half, B - b_half};
+    hipEventRecord(ev_fork, st);
+    hipStreamWaitEvent(aux, ev_fork, 0);
+  }
+  auto launch_off = [&](const Half& h, int j, int i_first, int nrt) {
+    const int Bpad = (h.nb + 7) / 8 * 8;
+    const int64_t mo = (int64_t)h.b0 * ld * ld, po = (int64_t)h.b0 * ntiles * TILE * TILE;
     if constexpr (sizeof(T) == 4)
-      hipLaunchKernelGGL(chol_offdiag_f32_kernel, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, s, (const float*)H, (float*)L,
-                         (const float*)panel, n, ld, j, ntiles, i_first, nrt, B);
+      hipLaunchKernelGGL(chol_offdiag_f32_kernel, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, h.s, (const float*)H + mo,
+                         (float*)L + mo, (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb);
     else
-      hipLaunchKernelGGL(chol_offdiag_f64_kernel, dim3(Bpad * nrt), dim3(256), OFF64_SMEM, s, (const double*)H, (double*)L,
-                         (const double*)panel, n, ld, j, ntiles, i_first, nrt, B);
+      hipLaunchKernelGGL(chol_offdiag_f64_kernel, dim3(Bpad * nrt), dim3(256), OFF64_SMEM, h.s, (const double*)H + mo,
+                         (double*)L + mo, (const double*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb);
   };
-  auto diag = [&](int j) {
-    hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(B), dim3(256), dsm, st, (const T*)H, (T*)L, (T*)panel,
-                       (const T*)damping, ellipsoidal, (T)eps, info, n, ld, j, ntiles, (const T*)rhs, (T*)y, ldv);
+  auto launch_diag = [&](const Half& h, int j) {
+    const int64_t mo = (int64_t)h.b0 * ld * ld, po = (int64_t)h.b0 * ntiles * TILE * TILE;
+    hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(h.nb), dim3(256), dsm, h.s, (const T*)H + mo, (T*)L + mo, (T*)panel + po,
+                       damping ? (const T*)damping + h.b0 : nullptr, ellipsoidal, (T)eps, info + h.b0, n, ld, j, ntiles,
+                       rhs ? (const T*)rhs + (int64_t)h.b0 * ldv : nullptr, y ? (T*)y + (int64_t)h.b0 * ldv : nullptr, ldv);
   };
-  // (A two-stream schedule -- the rest of column j underneath diag(j+1) on an auxiliary stream -- was measured: the
-  //  kernels do run concurrently, but LDS caps a CU at two workgroups of either kind, so nothing is gained.)
   for (int j = 0; j < ntiles; ++j) {
-    diag(j);
-    if (ntiles - 1 - j > 0) offdiag(st, j, j + 1, ntiles - 1 - j);
+    for (int k = 0; k < 2; ++k) {
+      const Half& h = halves[k];
+      if (h.nb <= 0) continue;
+      if (split && k == 1 && j == 0) hipStreamWaitEvent(aux, ev_lag, 0);  // second half: one diagonal phase behind
+      launch_diag(h, j);
+      if (split && k == 0 && j == 0) hipEventRecord(ev_lag, st);
+      if (ntiles - 1 - j > 0) launch_off(h, j, j + 1, ntiles - 1 - j);
+    }
+  }
+  if (split) {
+    hipEventRecord(ev_join, aux);
+    hipStreamWaitEvent(st, ev_join, 0);
   }
   return check_launch("thx_chol_factor");
 }
