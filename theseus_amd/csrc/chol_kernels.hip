@@ -414,7 +414,6 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   using C = CT<T>;
   using V = typename C::V;
   const int lrow = tid >> 3, lc = tid & 7;
-  uint4 ra[4], rb[4];
   // Operand rows through BUFFER loads: base pointer + extent live in a 4-SGPR resource, each lane contributes a 32-bit
   // byte offset, the k-chunk offset is a scalar -- no 64-bit per-row addresses in VGPRs (the fp64 kernels, two
   // workgroups per CU = 256 VGPRs, spilled them, and every reload put an s_waitcnt vmcnt(0) into the prefetch), and rows
@@ -427,35 +426,40 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   unsigned voff[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) voff[u] = (unsigned)(((lrow + 32 * u) * (int)ld + lc * C::VEC) * (int)sizeof(T));
-  auto gload = [&](int k0) __attribute__((always_inline)) {
+  // Register prefetch, AHEAD k-chunks deep.  fp32: one (a second register set measured no gain: 47.3-47.7 ms either way);
+  // fp64: two -- a 16-column chunk is half the MFMA time of an fp32 one, one chunk ahead does not cover the load latency
+  // (factor -2.9 %).
+  constexpr int AHEAD = sizeof(T) == 8 ? 2 : 1;
+  uint4 ra[AHEAD][4], rb[AHEAD][4];
+  auto gload = [&](uint4 (&xa)[4], uint4 (&xb)[4], int k0) __attribute__((always_inline)) {
     const int so = k0 * (int)sizeof(T);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], so, 0);
-      ra[u] = make_uint4(va.x, va.y, va.z, va.w);
+      xa[u] = make_uint4(va.x, va.y, va.z, va.w);
       if (!SAME) {
         const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff[u], so, 0);
-        rb[u] = make_uint4(vb.x, vb.y, vb.z, vb.w);
+        xb[u] = make_uint4(vb.x, vb.y, vb.z, vb.w);
       }
     }
   };
   const int nk = K / C::KB;
   T gsum = T(0);
+  // one k-chunk: registers -> LDS, refill the registers with the chunk AHEAD steps on, MFMAs on the staged chunk
   // (a static s_setprio per hardware wave slot, to push the two co-resident workgroups out of lockstep, measured no gain)
-  if (nk > 0) gload(0);
-  for (int kc = 0; kc < nk; ++kc) {
+  auto step = [&](uint4 (&xa)[4], uint4 (&xb)[4], int kc) __attribute__((always_inline)) {
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int row = lrow + 32 * u;
-      *reinterpret_cast<uint4*>(sA + row * LDT + lc * C::VEC) = ra[u];
-      if (!SAME) *reinterpret_cast<uint4*>(sB + row * LDT + lc * C::VEC) = rb[u];
+      *reinterpret_cast<uint4*>(sA + row * LDT + lc * C::VEC) = xa[u];
+      if (!SAME) *reinterpret_cast<uint4*>(sB + row * LDT + lc * C::VEC) = xb[u];
     }
     __syncthreads();
 #ifdef THX_EXP_NOLOAD
-    if (kc == 0 && kc + 1 < nk) gload((kc + 1) * C::KB);   // timing experiment: operands are not streamed (garbage results)
+    if (kc == 0 && kc + AHEAD < nk) gload(xa, xb, (kc + AHEAD) * C::KB);  // timing experiment: operands are not streamed
 #else
-    if (kc + 1 < nk) gload((kc + 1) * C::KB);
+    if (kc + AHEAD < nk) gload(xa, xb, (kc + AHEAD) * C::KB);
 #endif
     if constexpr (GEMV) {
       if (gemv_y) {
@@ -478,6 +482,15 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
 #else
     compute();  // MFMAs on the staged chunk (sA / sB)
 #endif
+  };
+#pragma unroll
+  for (int a = 0; a < AHEAD; ++a)
+    if (a < nk) gload(ra[a], rb[a], a * C::KB);
+  for (int kc = 0; kc < nk; kc += AHEAD) {
+    step(ra[0], rb[0], kc);
+    if constexpr (AHEAD == 2) {
+      if (kc + 1 < nk) step(ra[1], rb[1], kc + 1);
+    }
   }
   if constexpr (GEMV) {
     if (gemv_part) *gemv_part = gsum;
