@@ -531,6 +531,43 @@ def gen_ba(th):
               Np - len(pt_prior_idx))
 
 
+def gen_g2o(th):
+    """A small SLAM-3D g2o file written by the reference's own writer (PoseGraphDataset.write_3D_g2o,
+    theseus/utils/examples/pose_graph/dataset.py:367-399) from its synthetic generator (:238-365), what the reference's
+    reader (:35-104) returns for it in fp64, and the LM trajectory of examples/pose_graph/pose_graph_benchmark.py's
+    objective (:45-63; DenseLinearization + CholeskyDenseSolver here) on it."""
+    import theseus.utils.examples as theg
+    torch.manual_seed(5)
+    np.random.seed(5)
+    ds, _ = theg.pose_graph.PoseGraphDataset.generate_synthetic_3D(
+        num_poses=20, translation_noise=0.05, rotation_noise=0.02, loop_closure_ratio=0.5,
+        loop_closure_outlier_ratio=0.0, max_num_loop_closures=3, dataset_size=1, dtype=torch.float64)
+    # per-edge information that differs from edge to edge (the generator's is shared)
+    for k, e in enumerate(ds.edges):
+        e.weight.diagonal.tensor = e.weight.diagonal.tensor * (1.0 + 0.05 * (k % 7))
+    ds.write_3D_g2o(os.path.join(OUT, "g2o_small"))   # -> g2o_small_0.g2o
+    path = os.path.join(OUT, "g2o_small_0.g2o")
+    nv, verts, edges = theg.pose_graph.read_3D_g2o_file(path, dtype=torch.float64)
+    objective = th.Objective(torch.float64)
+    for edge in edges:
+        objective.add(th.Between(verts[edge.i], verts[edge.j], edge.relative_pose, edge.weight))
+    objective.add(th.Difference(var=verts[0], cost_weight=th.ScaleCostWeight(torch.tensor(1e-6, dtype=torch.float64)),
+                                target=verts[0].copy(new_name=verts[0].name + "PRIOR")))
+    poses0 = torch.stack([v.tensor.clone() for v in verts], 1)
+    opt = th.LevenbergMarquardt(objective, max_iterations=8, step_size=1, linear_solver_cls=th.CholeskyDenseSolver,
+                                vectorize=True, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    objective.update({v.name: v.tensor for v in verts})
+    with torch.no_grad():
+        info = opt.optimize(track_err_history=True)
+    np.savez_compressed(
+        os.path.join(OUT, "g2o_small.npz"), num_vertices=nv, poses0=poses0.numpy(),
+        edge_ij=np.array([[e.i, e.j] for e in edges]), meas=torch.stack([e.relative_pose.tensor for e in edges], 1).numpy(),
+        weights=torch.stack([e.weight.diagonal.tensor for e in edges], 1).numpy(),
+        final=torch.stack([v.tensor for v in verts], 1).numpy(), err_history=info.err_history.numpy())
+    print("g2o_small: poses", nv, "edges", len(edges), "err", info.err_history[0, 0].item(), "->",
+          info.err_history[0, -1].item())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     th, lieF = import_reference()
@@ -549,6 +586,8 @@ def main():
         gen_pgo_kat(th)
     if not only or "ba" in only:
         gen_ba(th)
+    if not only or "g2o" in only:
+        gen_g2o(th)
     print("wrote", sorted(os.listdir(OUT)))
 
 

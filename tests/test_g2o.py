@@ -1,0 +1,150 @@
+"""g2o reader / writer / dataset batching (theseus_amd/utils/g2o.py) against what the REFERENCE's reader returned for a
+file the reference's own writer produced (tests/golden/g2o_small_0.g2o + g2o_small.npz, oracle/gen_golden.py::gen_g2o), and
+the LM run of examples/pose_graph/pose_graph_benchmark.py's objective on that file: host path on CPU with the test stand-in
+kernels, HIP path under -m gpu."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import theseus_amd as th
+from theseus_amd.utils import g2o
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+G2O_FILE = os.path.join(GOLDEN, "g2o_small_0.g2o")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLDEN, "g2o_small.npz"))
+
+
+def stacked(verts, edges):
+    return (torch.stack([v.tensor for v in verts], 1), torch.stack([e.relative_pose.tensor for e in edges], 1),
+            torch.stack([e.weight.diagonal.tensor for e in edges], 1))
+
+
+def test_read_3d_matches_reference_reader(golden):
+    nv, verts, edges = g2o.read_3D_g2o_file(G2O_FILE, dtype=torch.float64)
+    assert nv == int(golden["num_vertices"]) == len(verts)
+    assert [[e.i, e.j] for e in edges] == golden["edge_ij"].tolist()
+    assert [v.name for v in verts] == [f"VERTEX_SE3__{i}" for i in range(nv)]
+    assert edges[3].relative_pose.name == "EDGE_SE3__3" and edges[3].weight.name == "EDGE_WEIGHT__3"
+    poses, meas, w = stacked(verts, edges)
+    # quaternion -> rotation is 2-3 fp64 roundings of products of unit-quaternion entries: a few ulp of 1
+    assert np.abs(poses.numpy() - golden["poses0"]).max() < 1e-15 * 8
+    assert np.abs(meas.numpy() - golden["meas"]).max() < 1e-15 * 8
+    assert np.array_equal(w.numpy(), golden["weights"])  # sqrt of the information diagonal: bit-exact
+
+
+def test_read_3d_fp32_and_missing_vertices(tmp_path):
+    _, verts, edges = g2o.read_3D_g2o_file(G2O_FILE, dtype=torch.float32)
+    assert verts[0].dtype == torch.float32 and edges[0].weight.diagonal.dtype == torch.float32
+    # a file with edges only: vertex count from the edge indices, no initial values (dataset.py:96-104)
+    p = tmp_path / "edges_only.g2o"
+    with open(G2O_FILE) as f:
+        p.write_text("".join(line for line in f if line.startswith("EDGE")) + "\n")
+    nv, verts, edges = g2o.read_3D_g2o_file(str(p), dtype=torch.float64)
+    assert nv == 20 and verts == [] and len(edges) == 31
+    bad = tmp_path / "short.g2o"
+    bad.write_text("EDGE_SE3:QUAT 0 1 0 0 0 0 0 0 1 1 0 0\n")
+    with pytest.raises(ValueError):
+        g2o.read_3D_g2o_file(str(bad), dtype=torch.float64)
+
+
+def test_write_read_round_trip(tmp_path):
+    _, verts, edges = g2o.read_3D_g2o_file(G2O_FILE, dtype=torch.float64)
+    ds = g2o.PoseGraphDataset(verts, edges)
+    ds.write_3D_g2o(str(tmp_path / "rt"))
+    nv, verts2, edges2 = g2o.read_3D_g2o_file(str(tmp_path / "rt_0.g2o"), dtype=torch.float64)
+    assert nv == len(verts)
+    for a, b in zip(stacked(verts, edges), stacked(verts2, edges2)):
+        assert (a - b).abs().max().item() < 1e-14
+
+
+def test_rotation_to_quaternion_all_branches():
+    # rotations by ~pi about each axis (trace ~ -1: the three non-trace branches) and small ones (trace branch)
+    xi = torch.zeros(7, 6, dtype=torch.float64)
+    for k in range(3):
+        xi[k, 3 + k] = np.pi - 1e-3
+        xi[3 + k, 3 + k] = 0.3 * (k + 1)
+    xi[6, 3:] = torch.tensor([2.0, -2.2, 0.9])
+    from oracle import lie
+    X = lie.se3_exp(xi)
+    q = g2o.rotation_to_quaternion(X[:, :, :3])
+    assert (q[:, 0] >= 0).all() and (q.norm(dim=1) - 1).abs().max() < 1e-15
+    back = th.SE3(x_y_z_quaternion=torch.cat([X[:, :, 3], q], 1)).tensor
+    assert (back - X).abs().max().item() < 1e-14
+
+
+def test_read_2d(tmp_path):
+    p = tmp_path / "tiny2d.g2o"
+    p.write_text("VERTEX_SE2 0 0.0 0.0 0.0\nVERTEX_SE2 1 1.0 0.5 0.3\nVERTEX_SE2 2 2.0 -0.5 -1.2\n"
+                 "EDGE_SE2 0 1 1.01 0.49 0.31 100.0 1.0 2.0 400.0 3.0 900.0\n"
+                 "EDGE_SE2 1 2 0.9 -1.1 -1.5 25.0 0.0 0.0 36.0 0.0 49.0\n\n")
+    nv, verts, edges = g2o.read_2D_g2o_file(str(p), dtype=torch.float64)
+    assert nv == 3 and len(verts) == 3 and [(e.i, e.j) for e in edges] == [(0, 1), (1, 2)]
+    assert torch.allclose(verts[1].tensor, torch.tensor([[1.0, 0.5, np.cos(0.3), np.sin(0.3)]], dtype=torch.float64))
+    assert torch.equal(edges[0].weight.diagonal.tensor, torch.tensor([[10.0, 20.0, 30.0]], dtype=torch.float64))
+    assert torch.equal(edges[1].weight.diagonal.tensor, torch.tensor([[5.0, 6.0, 7.0]], dtype=torch.float64))
+    assert edges[1].relative_pose.name == "EDGE_SE2__1" and verts[2].name == "VERTEX_SE2__2"
+
+
+def test_dataset_batching():
+    _, verts, edges = g2o.read_3D_g2o_file(G2O_FILE, dtype=torch.float64)
+    rep = lambda v, n: th.SE3(tensor=torch.cat([v.tensor + 0.01 * k for k in range(n)]), name=v.name)  # noqa: E731
+    verts5 = [rep(v, 5) for v in verts]
+    edges5 = [g2o.PoseGraphEdge(e.i, e.j, rep(e.relative_pose, 5), e.weight) for e in edges]
+    ds = g2o.PoseGraphDataset(verts5, edges5, batch_size=2)
+    assert ds.dataset_size == 5 and ds.num_batches == 3
+    b2 = ds.get_batch_dataset(2)
+    assert b2.dataset_size == 1 and b2.poses[4].name == "VERTEX_SE3__4__batch"
+    assert torch.equal(b2.poses[4].tensor, verts5[4].tensor[4:5])
+    b0 = ds.get_batch_dataset(0)
+    assert torch.equal(b0.edges[7].relative_pose.tensor, edges5[7].relative_pose.tensor[0:2])
+    assert b0.edges[7].weight is edges5[7].weight
+    with pytest.raises(ValueError):
+        g2o.PoseGraphDataset(verts5[:-1] + [verts[-1]], edges5)
+
+
+def run_lm(golden, dtype, device, kernels=None):
+    _, verts, edges = g2o.read_3D_g2o_file(G2O_FILE, dtype=torch.float64)
+    ds = g2o.PoseGraphDataset(verts, edges)
+    ds.to(device=device, dtype=dtype)
+    obj = g2o.pose_graph_objective(verts, edges, dtype=dtype)
+    kw = dict(linearization_kwargs=dict(kernels=kernels)) if kernels is not None else {}
+    opt = th.LevenbergMarquardt(obj, max_iterations=8, step_size=1.0, linear_solver_cls=th.HipCholeskySolver,
+                                abs_err_tolerance=0.0, rel_err_tolerance=0.0, **kw)
+    with torch.no_grad():
+        info = opt.optimize(track_err_history=True)
+    return torch.stack([v.tensor for v in verts], 1).cpu(), info.err_history.cpu()
+
+
+def test_benchmark_objective_lm_host_path(golden):
+    from tests.oracle_kernels import OracleKernels
+    final, hist = run_lm(golden, torch.float64, "cpu", OracleKernels())
+    # (the reference keeps info.err_history in fp32 whatever the objective's dtype: the history pins 1e-7 relative, the
+    #  final poses pin the fp64 path)
+    assert np.abs(hist.numpy() / golden["err_history"] - 1).max() < 2e-7
+    assert np.abs(final.numpy() - golden["final"]).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_benchmark_objective_lm_hip_f64(golden):
+    final, hist = run_lm(golden, torch.float64, "cuda")
+    assert np.abs(hist.numpy() / golden["err_history"] - 1).max() < 2e-7
+    assert np.abs(final.numpy() - golden["final"]).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_benchmark_objective_lm_hip_f32(golden):
+    """fp32: the prior on pose 0 has weight 1e-6, so the gauge (a common rigid motion of all poses) is free at fp32
+    resolution; the objective and the RELATIVE poses are what the data determines."""
+    from oracle import lie
+    final, hist = run_lm(golden, torch.float32, "cuda")
+    assert np.abs(hist.double().numpy() / golden["err_history"] - 1).max() < 5e-4
+    want = torch.from_numpy(golden["final"])[0]
+    got = final.double()[0]
+    rel = lambda X: lie.se3_compose(lie.se3_inverse(X[:-1]), X[1:])  # noqa: E731
+    assert (rel(got) - rel(want)).abs().max().item() < 2e-3

@@ -312,6 +312,10 @@ class CostWeight(abc.ABC):
     def diagonal6(self) -> torch.Tensor:
         return self.sqrt_diag(6)
 
+    def to(self, *args, **kwargs):  # theseus/core/theseus_function.py:74-77
+        for v in self.aux_vars():
+            v.to(*args, **kwargs)
+
 
 class ScaleCostWeight(CostWeight):
     """e <- e * s, J <- J * s (theseus/core/cost_weight.py:60-90)."""
