@@ -61,14 +61,21 @@ template <typename T>
 struct CT;
 template <>
 struct CT<float> {
-  static constexpr int KB = 32, LDT = 36, VEC = 4, LDC = 132, LDM = 132;
+  static constexpr int KB = 32, LDT = 36, VEC = 4, LDM = 132, LDB = 36;
   using V = float4;
 };
 template <>
 struct CT<double> {
-  static constexpr int KB = 16, LDT = 18, VEC = 2, LDC = 132, LDM = 130;
+  static constexpr int KB = 16, LDT = 18, VEC = 2, LDM = 130, LDB = 34;
   using V = double2;
 };
+
+// The diagonal tile in LDS (chol_diag): only its ten lower 32x32 sub-blocks, each stored row-major with row stride LDB
+// (= 4 banks mod 32, like the 128-wide rows they replace: 46 KB instead of 68 KB in fp32 -> three workgroups per CU).
+template <typename T>
+__device__ __forceinline__ constexpr int tblk(int u, int v) {
+  return (u * (u + 1) / 2 + v) * 32 * CT<T>::LDB;
+}
 
 // 1/sqrt(d) from the hardware estimate + Newton steps (~1 ulp): the pivot scaling of the in-register
 // Cholesky sits on a 128-step latency chain, a correctly rounded sqrt + division is ~40 dependent
@@ -197,14 +204,15 @@ struct Engine<float> {
         if (r >= valid || c >= valid) x = (r == c) ? 1.f : 0.f;
         o[k] = x;
       }
-      *reinterpret_cast<float4*>(tile + r * 132 + c0) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(tile + tblk<float>(u >> 1, v >> 1) + (r & 31) * 36 + (c0 & 31)) =
+          make_float4(o[0], o[1], o[2], o[3]);
     };
 #pragma unroll
     for (int v = 0; v <= UH; ++v) st(UH, v, hp[v], acc[v]);
 #pragma unroll
     for (int v = 0; v <= UL; ++v) st(UL, v, hp[UH + 1 + v], acc[UH + 1 + v]);
   }
-  // ---- 32x32 block helpers for the diagonal-tile factorisation (operands in the LDS tile, row stride 132).
+  // ---- 32x32 block helpers for the diagonal-tile factorisation (operands: sub-blocks of the LDS tile, row stride 36).
   //      Blk D[m][n]: a lane holds ONE row n = lane&31 of the block, register rho <-> column m = 8(rho>>2) + 4g + (rho&3)
   using Blk = f32x16;
   static __device__ __forceinline__ void blk_zero(Blk& d) {
@@ -216,7 +224,7 @@ struct Engine<float> {
     for (int i = 0; i < 16; ++i) d[i] -= a[i];
   }
   static __device__ __forceinline__ void blk_load(Blk& d, const float* blk, int lane) {
-    const float* p = blk + (lane & 31) * 132 + 4 * (lane >> 5);
+    const float* p = blk + (lane & 31) * 36 + 4 * (lane >> 5);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 v = *reinterpret_cast<const float4*>(p + 8 * q);
@@ -224,7 +232,7 @@ struct Engine<float> {
     }
   }
   static __device__ __forceinline__ void blk_store(const Blk& d, float* blk, int lane, float sign) {
-    float* p = blk + (lane & 31) * 132 + 4 * (lane >> 5);
+    float* p = blk + (lane & 31) * 36 + 4 * (lane >> 5);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       *reinterpret_cast<float4*>(p + 8 * q) =
@@ -232,7 +240,7 @@ struct Engine<float> {
   }
   // D[m][n] += sum_k (asign * A[m][k]) * B[n][k]   (A, B: 32x32 blocks in LDS, rows m / n)
   static __device__ __forceinline__ void blk_mma(const float* Ablk, const float* Bblk, Blk& d, int lane, float asign) {
-    const int o = (lane & 31) * 132 + 4 * (lane >> 5);
+    const int o = (lane & 31) * 36 + 4 * (lane >> 5);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 fa = *reinterpret_cast<const float4*>(Ablk + o + 8 * q);
@@ -278,7 +286,7 @@ struct Engine<double> {
   }
 
   // ---- 32x32 block helpers (see Engine<float>): Blk.v[mh][nh][rho] <-> row n = 16nh + (lane&15),
-  //      column m = 16mh + (lane>>4) + 4rho; LDS row stride 130
+  //      column m = 16mh + (lane>>4) + 4rho; LDS row stride 34
   struct Blk {
     f64x4 v[2][2];
   };
@@ -348,7 +356,7 @@ struct Engine<double> {
         if (u == v && r == c && damp) x = ellipsoidal ? x + (lam * x + eps) : x + lam;
         x -= a[rho];
         if (r >= valid || c >= valid) x = (r == c) ? 1.0 : 0.0;
-        tile[r * 130 + c] = x;
+        tile[tblk<double>(u >> 1, v >> 1) + (r & 31) * 34 + (c & 31)] = x;
       }
     };
 #pragma unroll
@@ -379,7 +387,7 @@ struct Engine<double> {
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-        for (int rho = 0; rho < 4; ++rho) d.v[mh][nh][rho] = blk[(16 * nh + rl) * 130 + 16 * mh + kq + 4 * rho];
+        for (int rho = 0; rho < 4; ++rho) d.v[mh][nh][rho] = blk[(16 * nh + rl) * 34 + 16 * mh + kq + 4 * rho];
   }
   static __device__ __forceinline__ void blk_store(const Blk& d, double* blk, int lane, double sign) {
     const int rl = lane & 15, kq = lane >> 4;
@@ -388,14 +396,14 @@ struct Engine<double> {
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-        for (int rho = 0; rho < 4; ++rho) blk[(16 * nh + rl) * 130 + 16 * mh + kq + 4 * rho] = sign * d.v[mh][nh][rho];
+        for (int rho = 0; rho < 4; ++rho) blk[(16 * nh + rl) * 34 + 16 * mh + kq + 4 * rho] = sign * d.v[mh][nh][rho];
   }
   static __device__ __forceinline__ void blk_mma(const double* Ablk, const double* Bblk, Blk& d, int lane, double asign) {
     const int rl = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      const double a0 = asign * Ablk[rl * 130 + 4 * kk + kq], a1 = asign * Ablk[(16 + rl) * 130 + 4 * kk + kq];
-      const double b0 = Bblk[rl * 130 + 4 * kk + kq], b1 = Bblk[(16 + rl) * 130 + 4 * kk + kq];
+      const double a0 = asign * Ablk[rl * 34 + 4 * kk + kq], a1 = asign * Ablk[(16 + rl) * 34 + 4 * kk + kq];
+      const double b0 = Bblk[rl * 34 + 4 * kk + kq], b1 = Bblk[(16 + rl) * 34 + 4 * kk + kq];
       d.v[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, d.v[0][0], 0, 0, 0);
       d.v[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, d.v[0][1], 0, 0, 0);
       d.v[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, d.v[1][0], 0, 0, 0);
@@ -545,6 +553,36 @@ __device__ __forceinline__ void panel_forward(const T* M, T* vec, T* ubuf, int l
   }
 }
 
+// the same on the block-compact LDS tile of chol_diag (sub-block (s,t) at tblk(s,t), row stride LDB)
+template <typename T>
+__device__ __forceinline__ void panel_forward_blk(const T* M, T* vec, T* ubuf, int lane) {
+  using C = CT<T>;
+  const int rl = lane & 31, hf = lane >> 5;
+#pragma unroll
+  for (int sb = 0; sb < 4; ++sb) {
+    T u = T(0);
+#pragma unroll
+    for (int tb = 0; tb < sb; ++tb) {  // columns of sub-block tb, 16 per lane half
+      const T* row = M + tblk<T>(sb, tb) + rl * C::LDB + 16 * hf;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) u += row[i] * vec[32 * tb + 16 * hf + i];
+    }
+    u = half_sum(u) + vec[32 * sb + rl];
+    if (hf == 0) ubuf[rl] = u;
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are visible to its reads
+    __builtin_amdgcn_wave_barrier();
+    const T* wrow = M + tblk<T>(sb, sb) + rl * C::LDB + 16 * hf;
+    T yv = T(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) yv += wrow[i] * ubuf[16 * hf + i];
+    yv = half_sum(yv);
+    __builtin_amdgcn_wave_barrier();
+    if (hf == 0) vec[32 * sb + rl] = yv;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // x = L_jj^-T z :  for t = 3..0: a_t = z_t + sum_{r >= 32(t+1)} M[r][c] x[r] ;  x_t = W_tt^T a_t
 template <typename T>
 __device__ __forceinline__ void panel_backward(const T* M, T* vec, T* ubuf, int lane) {
@@ -656,13 +694,15 @@ __device__ __forceinline__ void inv32(const T* Lss, A (&w)[32], int lane) {
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 struct DiagSmem {
-  static constexpr size_t tile = (size_t)128 * CT<T>::LDM * sizeof(T);  // >= the K-loop staging buffer
+  // ten 32 x LDB sub-blocks; the K-loop's staging buffer (128 x SYRK_LDT) lives in its head
+  static constexpr size_t tile = (size_t)10 * 32 * CT<T>::LDB * sizeof(T);
+  static_assert(10 * 32 * CT<T>::LDB >= 128 * Engine<T>::SYRK_LDT, "staging buffer must fit in the tile");
   // tile | vvec [128] T | ubuf [32] T | ybuf [ypad] T
   static size_t bytes(int ypad) { return tile + 160 * sizeof(T) + (size_t)ypad * sizeof(T); }
 };
 
 template <typename T>
-__global__ void __launch_bounds__(256, sizeof(T) == 4 ? 2 : 1)
+__global__ void __launch_bounds__(256, sizeof(T) == 4 ? 3 : 1)
 chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ panel, const T* __restrict__ damping,
                  int ellipsoidal, T damping_eps, int32_t* __restrict__ info, int n, int64_t ld, int j, int ntiles,
                  const T* __restrict__ rhs, T* __restrict__ yout, int64_t ldv) {
@@ -670,7 +710,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   using V = typename C::V;
   using E = Engine<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* tile = reinterpret_cast<T*>(smem_raw);  // [128][LDM]; its head doubles as the K-loop staging buffer
+  T* tile = reinterpret_cast<T*>(smem_raw);  // lower sub-blocks (tblk); its head doubles as the K-loop staging buffer
   T* vvec = reinterpret_cast<T*>(smem_raw + DiagSmem<T>::tile);
   T* ubuf = vvec + 128;
   T* ybuf = ubuf + 32;
@@ -743,11 +783,11 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   const int sw = 0;
 #endif
   for (int sb = 0; sb < 4; ++sb) {
-    T* Dss = tile + (32 * sb) * C::LDM + 32 * sb;
+    T* Dss = tile + tblk<T>(sb, sb);
     if (wave == sw) {
       T a[32];
       {
-        const V* rp = reinterpret_cast<const V*>(Dss + (lane & 31) * C::LDM);
+        const V* rp = reinterpret_cast<const V*>(Dss + (lane & 31) * C::LDB);
 #pragma unroll
         for (int q = 0; q < 32 / C::VEC; ++q) {
           const V v = rp[q];
@@ -778,7 +818,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
       }
       // L_ss back into its LDS block (zeros above the diagonal), then invert it from there
       {
-        V* rp = reinterpret_cast<V*>(Dss + lr * C::LDM);
+        V* rp = reinterpret_cast<V*>(Dss + lr * C::LDB);
         if (lane < 32) {
 #pragma unroll
           for (int q = 0; q < 32 / C::VEC; ++q) {
@@ -796,12 +836,12 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
       using WA = std::conditional_t<sizeof(T) == 8, double, float>;
       WA w[32];
       THX_STAMP();
-      inv32<T, WA, C::LDM>(Dss, w, lane);
+      inv32<T, WA, C::LDB>(Dss, w, lane);
       THX_STAMP();
       __builtin_amdgcn_wave_barrier();
       if (lane < 32) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) Dss[i * C::LDM + lr] = (T)w[i];  // W[i][lr]; zero for i < lr
+        for (int i = 0; i < 32; ++i) Dss[i * C::LDB + lr] = (T)w[i];  // W[i][lr]; zero for i < lr
       }
     }
     __syncthreads();
@@ -810,7 +850,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
     {
       const int u = sb + 1 + wave;
       if (u < 4) {
-        T* Dus = tile + (32 * u) * C::LDM + 32 * sb;
+        T* Dus = tile + tblk<T>(u, sb);
         typename E::Blk X;
         E::blk_zero(X);
         E::blk_mma(Dss, Dus, X, lane, T(1));
@@ -824,11 +864,11 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
       for (int u = sb + 1; u < 4; ++u)
         for (int v = sb + 1; v <= u; ++v, ++idx) {
           if ((idx & 3) != wave) continue;
-          T* Duv = tile + (32 * u) * C::LDM + 32 * v;
+          T* Duv = tile + tblk<T>(u, v);
           typename E::Blk D;
           E::blk_load(D, Duv, lane);
           // tile(v,s) = -L_vs is negated on load, tile(u,s) = -L_us:  D += (+L_vs)(-L_us)^T
-          E::blk_mma(tile + (32 * v) * C::LDM + 32 * sb, tile + (32 * u) * C::LDM + 32 * sb, D, lane, T(-1));
+          E::blk_mma(tile + tblk<T>(v, sb), tile + tblk<T>(u, sb), D, lane, T(-1));
           E::blk_store(D, Duv, lane, T(1));
         }
     }
@@ -837,22 +877,29 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 
   THX_STAMP();
   // ---- outputs: strictly-lower sub-blocks of L_jj (= -tile), the panel, y_j ----
-  {
-    constexpr int CPR = TILE / C::VEC, RPP = 256 / CPR;
-    const int c = (tid % CPR) * C::VEC;
+  {  // (the panel's sub-blocks above the diagonal are never read -- chol_offdiag and the solves use the lower ten -- and
+     //  are not written)
+    constexpr int VPR = 32 / C::VEC;  // vectors per sub-block row
     T* Lt = L + mat + (int64_t)row0 * ld + row0;
     T* P = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
-    for (int rr = tid / CPR; rr < TILE; rr += RPP) {
-      const V v = *reinterpret_cast<const V*>(tile + rr * C::LDM + c);
-      *reinterpret_cast<V*>(P + rr * TILE + c) = v;
-      if ((rr >> 5) > (c >> 5) && rr < valid) {
-        if constexpr (sizeof(T) == 4) *reinterpret_cast<V*>(Lt + (int64_t)rr * ld + c) = make_float4(-v.x, -v.y, -v.z, -v.w);
-        else *reinterpret_cast<V*>(Lt + (int64_t)rr * ld + c) = make_double2(-v.x, -v.y);
+    for (int u = 0; u < 4; ++u)
+      for (int v = 0; v <= u; ++v) {
+        const T* blk = tile + tblk<T>(u, v);
+#pragma unroll
+        for (int idx = tid; idx < 32 * VPR; idx += 256) {
+          const int rr = idx / VPR, c = (idx % VPR) * C::VEC;
+          const V val = *reinterpret_cast<const V*>(blk + rr * C::LDB + c);
+          *reinterpret_cast<V*>(P + (32 * u + rr) * TILE + 32 * v + c) = val;
+          if (u > v && 32 * u + rr < valid) {
+            V* dst = reinterpret_cast<V*>(Lt + (int64_t)(32 * u + rr) * ld + 32 * v + c);
+            if constexpr (sizeof(T) == 4) *dst = make_float4(-val.x, -val.y, -val.z, -val.w);
+            else *dst = make_double2(-val.x, -val.y);
+          }
+        }
       }
-    }
   }
   if (fwd) {
-    if (wave == 0) panel_forward<T>(tile, vvec, ubuf, lane);
+    if (wave == 0) panel_forward_blk<T>(tile, vvec, ubuf, lane);
     __syncthreads();
     if (tid < valid) yout[(int64_t)b * ldv + row0 + tid] = vvec[tid];
   }

@@ -27,6 +27,33 @@ if st:
     for r in csv.DictReader(open(st)):
         print(f"{short(r['Name']):70s} {int(r['Calls']):7d} {float(r['TotalDurationNs'])/1e6:10.3f} "
               f"{float(r['AverageNs'])/1e3:10.2f} {float(r['Percentage']):6.2f}")
+tr = find("trace/**/*kernel_trace.csv")
+if tr:
+    # thx_chol_factor[_forward] runs the two halves of the batch on two streams: kernel durations overlap, so the call's
+    # time is the SPAN first start -> last end of its chol_diag / chol_offdiag launches (bench.py measures the same span
+    # with HIP events on the caller's stream), not the sum of the per-kernel averages above.
+    rows = sorted(csv.DictReader(open(tr)), key=lambda r: int(r["Start_Timestamp"]))
+    calls, cur = [], None
+    for r in rows:
+        name = r["Kernel_Name"]
+        if "chol_diag_kernel" in name or "chol_offdiag" in name:
+            t0, t1 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            if cur is None:
+                cur = [t0, t1, 0, 0]
+            cur[1] = max(cur[1], t1)
+            cur[2] += t1 - t0
+            cur[3] += 1
+        elif cur is not None and "fillBuffer" not in name:
+            calls.append(cur)
+            cur = None
+    if cur is not None:
+        calls.append(cur)
+    if calls:
+        span = [(c[1] - c[0]) / 1e6 for c in calls]
+        print("== thx_chol_factor_forward: span of each call's chol_diag + chol_offdiag launches (kernel trace) ==")
+        print(f"calls {len(calls)}  launches/call {calls[0][3]}  span avg {sum(span) / len(span):.3f} ms  "
+              f"min {min(span):.3f}  max {max(span):.3f}   (sum of kernel durations per call "
+              f"{sum(c[2] for c in calls) / len(calls) / 1e6:.3f} ms: the half-batch streams overlap)")
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = find(f"pmc_{c}/**/*counter_collection.csv")
     if not f:
