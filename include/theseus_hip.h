@@ -323,6 +323,12 @@ int thx_lm_accept_diag(const void* delta, const void* g, const void* diag, int64
                        const void* prev_err, const void* new_err, int ellipsoidal, double accept, double down_ratio,
                        double up_ratio, uint8_t* reject, int dtype, void* stream);
 
+/* ---- Per-problem selection on entity-major state buffers (N, B, record): dst[k, b, :] = src[k, b, :] where mask[b] != 0.
+ *      The `torch.where(mask, new, old)` of Variable.update(batch_ignore_mask) (theseus/core/variable.py:65-69) and of the
+ *      rejected-step / best-solution bookkeeping (nonlinear_least_squares.py:320, nonlinear_optimizer.py:160-172) applied to
+ *      the packed state in place: no temporary, no allocation.  record_bytes must be a multiple of 4. */
+int thx_copy_where(const uint8_t* mask, const void* src, void* dst, int64_t N, int32_t B, int32_t record_bytes, void* stream);
+
 /* ---- Linearization.diagonal_scaling support: d[b, i] = H[b, i, i] (linearization.py:85-87). */
 int thx_diag(const void* H, int64_t ld, int32_t n, int32_t B, void* d, int64_t ldv, int dtype, void* stream);
 

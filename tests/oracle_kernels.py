@@ -197,6 +197,10 @@ class OracleKernels:
         p, state = self._ba_problem(s, t, cams, points)
         err.copy_(p.error_metric(state))
 
+    def copy_where(self, mask, src, dst):
+        m = mask.bool().view(1, -1, *([1] * (dst.dim() - 2)))
+        dst.copy_(torch.where(m, src, dst))
+
     def vec_retract(self, x, delta, col0, step, ignore_mask, out):
         N, B, dof = x.shape
         new = x + (delta[:, col0:col0 + N * dof] * step).reshape(B, N, dof).transpose(0, 1)

@@ -356,3 +356,24 @@ def test_generic_block_assembly_vs_dense_scatter(K, dtype):
     assert n % 2 == 1 and int(info.abs().sum()) == 0
     ref = torch.linalg.solve(torch.tril(AtA) + torch.tril(AtA, -1).transpose(1, 2) + torch.eye(n, dtype=torch.float64), Atb)
     assert (x.cpu().double() - ref).abs().max() <= (2e-4 if dtype == torch.float32 else 1e-11) * ref.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dtype", [((5, 7, 3, 4), torch.float32), ((9, 33, 3), torch.float64), ((1, 2, 4), torch.float32),
+                                         ((300, 129, 3), torch.float32)])
+def test_copy_where(shape, dtype):
+    """thx_copy_where: dst[k, b] <- src[k, b] where mask[b], in place, bit-exact."""
+    from theseus_amd.kernels import default_kernels
+    K = default_kernels()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    src = torch.randn(*shape, dtype=dtype, device="cuda", generator=gen)
+    dst = torch.randn(*shape, dtype=dtype, device="cuda", generator=gen)
+    mask = torch.rand(shape[1], device="cuda", generator=gen) < 0.4
+    want = torch.where(mask.view(1, -1, *([1] * (len(shape) - 2))), src, dst)
+    K.copy_where(mask, src, dst)
+    assert torch.equal(dst, want)
+    dst2 = want.clone()
+    K.copy_where(torch.zeros_like(mask), src, dst2)       # nothing selected: untouched
+    assert torch.equal(dst2, want)
+    K.copy_where(torch.ones_like(mask).view(torch.uint8), src, dst2)  # uint8 mask, everything selected
+    assert torch.equal(dst2, src)

@@ -281,10 +281,10 @@ class PackedBA:
         self._repoint_variables()
 
     def _repoint_variables(self):
-        for k, v in enumerate(self.cam_vars):
-            v.tensor = self.tensors.cams[k]
-        for k, v in enumerate(self.pt_vars):
-            v.tensor = self.tensors.points[k]
+        for v, t in zip(self.cam_vars, self.tensors.cams.unbind(0)):  # one call builds all the views
+            v.tensor = t
+        for v, t in zip(self.pt_vars, self.tensors.points.unbind(0)):
+            v.tensor = t
         self._stamp = self._current_stamp()
         self._global_stamp = Variable._global_updates
         self._vars_stale = False
@@ -332,10 +332,9 @@ class PackedBA:
     def keep_where(self, mask, out):
         self.copy_where(mask, self.state, out)
 
-    @staticmethod
-    def copy_where(mask, src, dst):
-        torch.where(mask.view(1, -1, 1, 1), src[0], dst[0], out=dst[0])
-        torch.where(mask.view(1, -1, 1), src[1], dst[1], out=dst[1])
+    def copy_where(self, mask, src, dst):
+        self.K.copy_where(mask, src[0], dst[0])
+        self.K.copy_where(mask, src[1], dst[1])
 
     def solution_dict(self, state):
         out = {v.name: state[0][k].cpu() for k, v in enumerate(self.cam_vars)}

@@ -458,6 +458,16 @@ static int check_pg(const thx_pg_structure* s, const thx_pg_data* d) {
   return 0;
 }
 
+// dst word w of record (k, b) <- src word w where mask[b] (grid-stride over 4-byte words: HBM-bound, coalesced)
+__global__ void __launch_bounds__(256)
+copy_where_kernel(const uint8_t* __restrict__ mask, const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                  int64_t words, int B, int wpr) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)((i / wpr) % B);
+    if (mask[b]) dst[i] = src[i];
+  }
+}
+
 }  // namespace thx
 
 using namespace thx;
@@ -465,7 +475,18 @@ using namespace thx;
 extern "C" {
 
 const char* thx_last_error(void) { return last_error().c_str(); }
-int thx_abi_version(void) { return 6; }
+int thx_abi_version(void) { return 7; }
+
+int thx_copy_where(const uint8_t* mask, const void* src, void* dst, int64_t N, int32_t B, int32_t record_bytes, void* stream) {
+  if (!mask || !src || !dst || N < 0 || B <= 0 || record_bytes <= 0 || (record_bytes & 3))
+    return fail("thx_copy_where: bad arguments");
+  const int64_t words = N * (int64_t)B * (record_bytes / 4);
+  if (words == 0) return 0;
+  const int64_t blocks = (words + 255) / 256;
+  hipLaunchKernelGGL(copy_where_kernel, dim3((unsigned)(blocks < 65536 * 16 ? blocks : 65536 * 16)), dim3(256), 0,
+                     as_stream(stream), mask, (const uint32_t*)src, (uint32_t*)dst, words, B, record_bytes / 4);
+  return check_launch("thx_copy_where");
+}
 
 int thx_pg_assemble(const thx_pg_structure* s, const thx_pg_data* d, void* H, int64_t ld, void* g, int dtype,
                     const thx_lie_eps* eps, void* stream) {

@@ -277,6 +277,17 @@ class HipKernels:
         _lib.check(self.lib.thx_ba_error(s.c, d, _lib.ptr(partials), _lib.ptr(err), _lib.dtype_code(dt), lie_eps(dt),
                                          _lib.stream_ptr(err.device)), "thx_ba_error")
 
+    def copy_where(self, mask, src, dst):
+        """dst[k, b] <- src[k, b] where mask[b]; src / dst (N, B, ...) contiguous, mask (B,) bool or uint8."""
+        if src.shape != dst.shape or src.dtype != dst.dtype or not (src.is_contiguous() and dst.is_contiguous()):
+            raise ValueError("copy_where: src and dst must be contiguous tensors of one shape and dtype")
+        N, B = dst.shape[0], dst.shape[1]
+        if mask.dtype == torch.bool:
+            mask = mask.view(torch.uint8)
+        rec = dst[0, 0].numel() * dst.element_size()
+        _lib.check(self.lib.thx_copy_where(_lib.ptr(mask), _lib.ptr(src), _lib.ptr(dst), N, B, rec,
+                                           _lib.stream_ptr(dst.device)), "thx_copy_where")
+
     def vec_retract(self, x, delta, col0, step, ignore_mask, out):
         N, B, dof = x.shape
         _lib.check(self.lib.thx_vec_retract(_lib.ptr(x), _lib.ptr(delta), delta.stride(0), int(col0), float(step),

@@ -268,7 +268,8 @@ class NonlinearLeastSquares(abc.ABC):
                         if any_rej:
                             rb = reject.bool()
                             packed.keep_where(rb, spare)
-                            err = torch.where(rb, last_err, err_new)
+                            packed.K.copy_where(rb, last_err.view(1, -1, 1), err_new.view(1, -1, 1))
+                            err = err_new.clone()
                         else:
                             err = err_new.clone()
                         spare = packed.swap_state(spare)

@@ -197,8 +197,8 @@ class PackedPoseGraph:
         # the optimiser calls this under no_grad; after the implicit last step the pose buffer carries a graph
         # and the per-variable views must stay attached to it
         with torch.set_grad_enabled(poses.requires_grad):
-            for k, v in enumerate(self.pose_vars):
-                v.tensor = poses[k]
+            for v, t in zip(self.pose_vars, poses.unbind(0)):  # one call builds all the views
+                v.tensor = t
         self._stamp = self._current_stamp()
         self._global_stamp = Variable._global_updates
         self._vars_stale = False
@@ -244,12 +244,12 @@ class PackedPoseGraph:
 
     def keep_where(self, mask: torch.Tensor, out):
         """out <- current state where mask (B,), else out."""
-        torch.where(mask.view(1, -1, *([1] * (out.dim() - 2))), self.tensors.poses, out, out=out)
+        self.K.copy_where(mask, self.tensors.poses, out)
 
-    @staticmethod
-    def copy_where(mask: torch.Tensor, src, dst):
-        """dst <- src where mask (B,)."""
-        torch.where(mask.view(1, -1, *([1] * (dst.dim() - 2))), src, dst, out=dst)
+    def copy_where(self, mask: torch.Tensor, src, dst):
+        """dst <- src where mask (B,): thx_copy_where, in place (torch.where(..., out=dst) with dst among the inputs
+        allocates a state-sized temporary -- a hipMalloc stall of tens of ms at bundle-adjustment sizes)."""
+        self.K.copy_where(mask, src, dst)
 
     def solution_dict(self, state):
         return {v.name: state[k].cpu() for k, v in enumerate(self.pose_vars)}

@@ -49,14 +49,33 @@ timed("ba_backsub", lambda: solver.K.ba_backsub(p.dstruct, lin.W, solver.Hinv, s
 timed("ba_error", lambda: p.error_metric())
 spare = p.alloc_state()
 timed("retract", lambda: p.retract(solver.delta, 1.0, None, spare))
+if os.environ.get("BENCH_BA_NOGC"):
+    import gc
+    gc.disable()
 e0, e1 = ev(), ev()
 with torch.no_grad():
     obj.update()
+    torch.cuda.synchronize()
+    fv0, w0 = solver.factor_version, time.perf_counter()
     e0.record()
-    info = opt.optimize(**kw)
+    if os.environ.get("BENCH_BA_CPROFILE"):  # where the host time of optimize() goes
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        info = opt.optimize(**kw)
+        pr.disable()
+        pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+    else:
+        info = opt.optimize(**kw)
     e1.record()
+    host_ms = (time.perf_counter() - w0) * 1e3   # host time until optimize() returns (launches may still be queued)
 torch.cuda.synchronize()
+wall_ms = (time.perf_counter() - w0) * 1e3
+solves = solver.factor_version - fv0
 ms = e0.elapsed_time(e1) / max(info.iters_done, 1)
+print(f"optimize(): {info.iters_done} accepted iterations, {solves} linear solves; device span {e0.elapsed_time(e1):.1f} ms, "
+      f"host returned after {host_ms:.1f} ms, wall {wall_ms:.1f} ms -> {e0.elapsed_time(e1) / max(solves, 1):.2f} ms per solve")
 nc = p.nc
 fl = B * nc ** 3 / 3
 print("phases (ms):", {k: round(v, 3) for k, v in phases.items()})
