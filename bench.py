@@ -110,7 +110,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU (weak scaling), or per sub-batch")
+    ap.add_argument("--total-batch", type=int, default=0,
+                    help="STRONG scaling (BASELINE.json configs[2]: 32768 problems sharded over the GPUs): total problems of "
+                         "the job; each rank solves its share in sub-batches of at most --batch problems, one after the "
+                         "other, with persistent workspaces.  0 (default) = weak scaling, --batch problems per GPU")
     ap.add_argument("--poses", type=int, default=256)
     ap.add_argument("--edges", type=int, default=1024)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
@@ -151,8 +155,26 @@ def main():
         opt.reducer = DistBatchReducer()  # batch-global predicates over all shards (one tiny all-reduce / iteration)
     layer = th.TheseusLayer(opt)
     timer = KernelTimer(opt.linear_solver.K)
-    tensors = syn.make_pose_graph_tensors(edges, P, B, dtype=dtype, device=device, seed=1234 + rank)
-    inputs = syn.input_dict(tensors)
+    strong = args.total_batch > 0
+    if strong:
+        from theseus_amd.sharding import shard_bounds
+        if args.implicit:
+            raise SystemExit("--total-batch is the forward configuration (configs[2]); not combined with --implicit")
+        lo, hi = shard_bounds(args.total_batch, rank, world)
+        if (hi - lo) % B and hi - lo > B:
+            raise SystemExit(f"rank share {hi - lo} is not a multiple of the sub-batch {B}")
+        B = min(B, hi - lo)
+        n_sub = (hi - lo) // B
+    else:
+        n_sub = 1
+    # every sub-batch's inputs are resident in HBM before the timed region (synthetic, one seed per rank and sub-batch)
+    sub_inputs = []
+    for c in range(n_sub):
+        tensors_c = syn.make_pose_graph_tensors(edges, P, B, dtype=dtype, device=device, seed=1234 + rank + 1000 * c)
+        sub_inputs.append(syn.input_dict(tensors_c))
+        if c == 0:
+            tensors = tensors_c
+    inputs = sub_inputs[0]
     okw = dict(damping=args.damping, adaptive_damping=args.adaptive)
 
     def barrier():
@@ -176,6 +198,8 @@ def main():
         timer.enabled = True
         t0 = time.perf_counter()
         sol, info = layer.forward(inputs, optimizer_kwargs=dict(track_err_history=True, **okw))
+        for more in sub_inputs[1:]:  # strong scaling: the rank's remaining sub-batches through the same workspaces
+            layer.forward(more, optimizer_kwargs=okw)
         if args.implicit:  # backward: retract VJP + ONE linear solve with the cached factor + cost VJP
             loss = sum(v.sum() for v in sol.values())
             eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -214,16 +238,16 @@ def main():
             pass
         result = {
             "metric": "LM iterations/sec (batch x vars) on SE3 pose-graph",
-            "value": world * B * iters_done / dt,
+            "value": world * n_sub * B * iters_done / dt,
             "unit": "problem-iterations/s",
             "n_gpus": world, "steps": K_iters, "warmup": W, "ms_per_step": dt / max(iters_done, 1) * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"SE3 pose-graph {P} poses / {E} Between edges + 1 prior, batch {B} per GPU, "
+            "config": {"workload": f"SE3 pose-graph {P} poses / {E} Between edges + 1 prior, batch {n_sub * B} per GPU, "
                                    f"LM damping {args.damping}{' adaptive' if args.adaptive else ''} + dense Cholesky",
-                       "poses": P, "edges": E, "batch_per_gpu": B, "global_batch": world * B, "n": n,
-                       "parallelism": f"batch-shard x{world}"},
-            "pose_updates_per_s": world * B * iters_done * P / dt,
+                       "poses": P, "edges": E, "batch_per_gpu": n_sub * B, "global_batch": world * n_sub * B, "n": n,
+                       "parallelism": f"batch-shard x{world}" + (f", {n_sub} sub-batches of {B} per GPU" if strong else "")},
+            "pose_updates_per_s": world * n_sub * B * iters_done * P / dt,
             "iters_done": iters_done,
             "mean_error": [float(err_hist[:, 0].mean()), float(err_hist[:, iters_done].mean())],
             "roofline": {"bound": "mfma", "kernel": "thx_chol_factor_forward (chol_diag + chol_offdiag launches per block column)",
