@@ -151,7 +151,12 @@ class PackedPoseGraph:
                 yield r
 
     def _current_stamp(self):
-        return tuple(v._num_updates for v in self._tracked())
+        # the objective is frozen once an optimizer holds it (Optimizer.optimize checks its version): the walk over the cost
+        # functions is done once, later stamps are one pass over the cached list (7 k variables at the headline size)
+        tracked = self.__dict__.get("_tracked_list")
+        if tracked is None:
+            tracked = self._tracked_list = list(self._tracked())
+        return tuple([v._num_updates for v in tracked])
 
     @staticmethod
     def _stack(ts, B):
