@@ -456,6 +456,20 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   // one k-chunk: registers -> LDS, refill the registers with the chunk AHEAD steps on, MFMAs on the staged chunk
   // (a static s_setprio per hardware wave slot, to push the two co-resident workgroups out of lockstep, measured no gain)
   auto step = [&](uint4 (&xa)[4], uint4 (&xb)[4], int kc) __attribute__((always_inline)) {
+#ifdef THX_EXP_NOSTAGE  // timing experiment: no register -> LDS staging and only one barrier per chunk (garbage results)
+    if (kc == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = lrow + 32 * u;
+        *reinterpret_cast<uint4*>(sA + row * LDT + lc * C::VEC) = xa[u];
+        if (!SAME) *reinterpret_cast<uint4*>(sB + row * LDT + lc * C::VEC) = xb[u];
+      }
+    } else {
+      asm volatile("" ::"v"(xa[0].x), "v"(xa[1].x), "v"(xa[2].x), "v"(xa[3].x));  // the loads must still complete
+      if (!SAME) asm volatile("" ::"v"(xb[0].x), "v"(xb[1].x), "v"(xb[2].x), "v"(xb[3].x));
+    }
+    __syncthreads();
+#else
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -464,6 +478,7 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
       if (!SAME) *reinterpret_cast<uint4*>(sB + row * LDT + lc * C::VEC) = xb[u];
     }
     __syncthreads();
+#endif
 #ifdef THX_EXP_NOLOAD
     if (kc == 0 && kc + AHEAD < nk) gload(xa, xb, (kc + AHEAD) * C::KB);  // timing experiment: operands are not streamed
 #else
