@@ -634,10 +634,10 @@ __device__ __forceinline__ void panel_backward(const T* M, T* vec, T* ubuf, int 
 // lane r (= lane & 31) holds row r: a[c] = S[r][c].  On exit a[c] = L[r][c] for c <= r (columns above the
 // diagonal are garbage).  Broadcasts go through SGPRs (v_readlane), no LDS round trips.  Returns the
 // 1-based index of the first non-positive pivot (0 = positive definite).
-template <typename T>
-__device__ __forceinline__ int potrf32(T (&a)[32]) {
+template <typename T, int N>
+__device__ __forceinline__ int potrf_reg(T (&a)[N]) {
   int bad = 0;
-  static_for<32>([&](auto ic) __attribute__((always_inline)) {
+  static_for<N>([&](auto ic) __attribute__((always_inline)) {
     constexpr int c = decltype(ic)::value;
     T d = bcast(a[c], c);
     if (!(d > T(0))) {
@@ -646,12 +646,16 @@ __device__ __forceinline__ int potrf32(T (&a)[32]) {
     }
     const T isq = t_rsqrt(d);
     a[c] *= isq;  // L[r][c]
-    static_for<31 - c>([&](auto iq) __attribute__((always_inline)) {
+    static_for<N - 1 - c>([&](auto iq) __attribute__((always_inline)) {
       constexpr int q = c + 1 + decltype(iq)::value;
       a[q] -= a[c] * bcast(a[c], q);  // S[r][q] -= L[r][c] L[q][c]
     });
   });
   return bad;
+}
+template <typename T>
+__device__ __forceinline__ int potrf32(T (&a)[32]) {
+  return potrf_reg<T, 32>(a);
 }
 
 // W = L^-1 for a 32x32 triangle stored row-major in LDS (row stride LDM): lane j (= lane & 31) computes column j of
@@ -660,16 +664,16 @@ __device__ __forceinline__ int potrf32(T (&a)[32]) {
 // and spills through v_writelane/v_readlane pairs (measured 30 cycles per term).  Row i+1 is loaded while row i is
 // being consumed.  Accumulation in A: fp64 for the fp64 path, float for fp32 -- W then carries the backward error of
 // an fp32 TRSM (columnwise ~32 eps |L|), which is what the sub-block solve it replaces would have.
-template <typename T, typename A, int LDM>
-__device__ __forceinline__ void inv32(const T* Lss, A (&w)[32], int lane) {
+template <typename T, typename A, int LDM, int N>
+__device__ __forceinline__ void inv_tri(const T* Lss, A (&w)[N], int lane) {
   constexpr int VEC = 16 / sizeof(T);
   using V = std::conditional_t<sizeof(T) == 4, float4, double2>;
-  const int j = lane & 31;
-  V cur[32 / VEC], nxt[32 / VEC];
+  const int j = lane & (N - 1);
+  V cur[N / VEC], nxt[N / VEC];
   cur[0] = *reinterpret_cast<const V*>(Lss);
-  static_for<32>([&](auto ii) __attribute__((always_inline)) {
+  static_for<N>([&](auto ii) __attribute__((always_inline)) {
     constexpr int i = decltype(ii)::value;
-    if constexpr (i + 1 < 32) {  // prefetch row i+1: entries 0 .. i+1
+    if constexpr (i + 1 < N) {  // prefetch row i+1: entries 0 .. i+1
 #pragma unroll
       for (int q = 0; q <= (i + 1) / VEC; ++q) nxt[q] = *reinterpret_cast<const V*>(Lss + (i + 1) * LDM + VEC * q);
     }
@@ -693,7 +697,7 @@ __device__ __forceinline__ void inv32(const T* Lss, A (&w)[32], int lane) {
       else s0 -= at(k) * w[k];
     });
     w[i] = (s0 + s1) * r;
-    if constexpr (i + 1 < 32) {
+    if constexpr (i + 1 < N) {
 #pragma unroll
       for (int q = 0; q <= (i + 1) / VEC; ++q) cur[q] = nxt[q];
     }
@@ -701,6 +705,198 @@ __device__ __forceinline__ void inv32(const T* Lss, A (&w)[32], int lane) {
     // them (hundreds of spilled registers)
     asm volatile("" : "+v"(w[i]) : : "memory");
   });
+}
+template <typename T, typename A, int LDM>
+__device__ __forceinline__ void inv32(const T* Lss, A (&w)[32], int lane) {
+  inv_tri<T, A, LDM, 32>(Lss, w, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One 32x32 diagonal sub-block, blocked 16 + 16 (executed by ONE wave): the in-register factorisation and the
+// substitution for the inverse cost ~N^2 dependent readlane/FMA steps each, so halving N and doing the coupling
+// with 16x16x16 MFMA products on the LDS block halves the serial chain of chol_diag:
+//   L00 = chol(S00), W00 = L00^-1, L10 = S10 W00^T, S11 -= L10 L10^T, L11 = chol(S11), W11 = L11^-1,
+//   W10 = -W11 (L10 W00);   on exit the block holds W_ss = [[W00, 0], [W10, W11]] and L_ss has gone to global memory.
+// 16x16 MFMA convention (both dtypes):  acc(n, m) += sum_k Aop[m][k] * B[n][k],  n = lane & 15 (row of the B block),
+// m = m_of(lane, i) for accumulator element i (fp32: 4 (lane >> 4) + i; fp64: (lane >> 4) + 4 i); TA reads A transposed.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct Mma16;
+template <>
+struct Mma16<float> {
+  using Acc = f32x4;
+  static __device__ __forceinline__ int m_of(int lane, int i) { return 4 * (lane >> 4) + i; }
+  template <bool TA>
+  static __device__ __forceinline__ void mma(const float* A, const float* B, Acc& acc, int lane, float asign) {
+    constexpr int LDB = CT<float>::LDB;
+    const int x = lane & 15, kq = lane >> 4;
+    const float4 fb = *reinterpret_cast<const float4*>(B + x * LDB + 4 * kq);
+    float fa[4];
+    if constexpr (TA) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) fa[e] = A[(4 * kq + e) * LDB + x];
+    } else {
+      const float4 v = *reinterpret_cast<const float4*>(A + x * LDB + 4 * kq);
+      fa[0] = v.x; fa[1] = v.y; fa[2] = v.z; fa[3] = v.w;
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(asign * fa[0], fb.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(asign * fa[1], fb.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(asign * fa[2], fb.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(asign * fa[3], fb.w, acc, 0, 0, 0);
+  }
+};
+template <>
+struct Mma16<double> {
+  using Acc = f64x4;
+  static __device__ __forceinline__ int m_of(int lane, int i) { return (lane >> 4) + 4 * i; }
+  template <bool TA>
+  static __device__ __forceinline__ void mma(const double* A, const double* B, Acc& acc, int lane, double asign) {
+    constexpr int LDB = CT<double>::LDB;
+    const int x = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double fa = TA ? A[(4 * e + kq) * LDB + x] : A[x * LDB + 4 * e + kq];
+      const double fb = B[x * LDB + 4 * e + kq];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(asign * fa, fb, acc, 0, 0, 0);
+    }
+  }
+};
+
+// the wave's own LDS writes become visible to its reads
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Dss: the 32 x LDB block in LDS (S_ss on entry, W_ss on exit); Lg: global address of L's element (first row of the
+// sub-block, first column of the sub-block), rows_valid = number of the sub-block's rows inside the matrix.
+// Returns the 1-based index (within the sub-block) of the first non-positive pivot, 0 if none.
+template <typename T>
+__device__ __forceinline__ int potrf_inv32_blocked(T* Dss, T* Lg, int64_t ld, int rows_valid, int lane) {
+  using C = CT<T>;
+  using V = typename C::V;
+  using M = Mma16<T>;
+  using WA = std::conditional_t<sizeof(T) == 8, double, float>;
+  constexpr int LDB = C::LDB;
+  T* Q00 = Dss;
+  T* Q01 = Dss + 16;
+  T* Q10 = Dss + 16 * LDB;
+  T* Q11 = Dss + 16 * LDB + 16;
+  const int r = lane & 15;
+  int bad = 0;
+  // row r of a 16x16 LDS quadrant -> registers
+  auto load_row = [&](const T* Q, T (&a)[16]) __attribute__((always_inline)) {
+    const V* rp = reinterpret_cast<const V*>(Q + r * LDB);
+#pragma unroll
+    for (int q = 0; q < 16 / C::VEC; ++q) {
+      const V v = rp[q];
+      if constexpr (sizeof(T) == 4) {
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+      } else {
+        a[2 * q] = v.x; a[2 * q + 1] = v.y;
+      }
+    }
+  };
+  // lower-triangular rows (zeros above the diagonal) -> the LDS quadrant and -> global memory (rows inside the matrix)
+  auto store_tri = [&](T* Q, T* G, int row_in_block, const T (&a)[16]) __attribute__((always_inline)) {
+    if (lane < 16) {
+      V* rp = reinterpret_cast<V*>(Q + r * LDB);
+      V* gp = reinterpret_cast<V*>(G + (int64_t)r * ld);
+      const bool g = row_in_block + r < rows_valid;
+#pragma unroll
+      for (int q = 0; q < 16 / C::VEC; ++q) {
+        V v;
+        if constexpr (sizeof(T) == 4)
+          v = make_float4(4 * q <= r ? a[4 * q] : 0.f, 4 * q + 1 <= r ? a[4 * q + 1] : 0.f,
+                          4 * q + 2 <= r ? a[4 * q + 2] : 0.f, 4 * q + 3 <= r ? a[4 * q + 3] : 0.f);
+        else
+          v = make_double2(2 * q <= r ? a[2 * q] : 0.0, 2 * q + 1 <= r ? a[2 * q + 1] : 0.0);
+        rp[q] = v;
+        if (g) gp[q] = v;
+      }
+    }
+  };
+  // column j = r of W (w[i] = W[i][j], zero above the diagonal) -> row-major into the quadrant
+  auto store_cols = [&](T* Q, const WA (&w)[16]) __attribute__((always_inline)) {
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Q[i * LDB + r] = (T)w[i];
+    }
+  };
+  auto acc_zero = [&](typename M::Acc& acc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = T(0);
+  };
+  auto acc_store = [&](const typename M::Acc& acc, T* Q) __attribute__((always_inline)) {
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(Q + r * LDB + 4 * (lane >> 4)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Q[r * LDB + M::m_of(lane, i)] = acc[i];
+    }
+  };
+
+  T a[16];
+  WA w[16];
+  typename M::Acc acc;
+  // ---- L00, W00 ----
+  load_row(Q00, a);
+  bad = potrf_reg<T, 16>(a);
+  store_tri(Q00, Lg, 0, a);
+  wave_lds_fence();
+  inv_tri<T, WA, LDB, 16>(Q00, w, lane);
+  __builtin_amdgcn_wave_barrier();
+  store_cols(Q00, w);
+  wave_lds_fence();
+  // ---- L10 = S10 W00^T ----
+  acc_zero(acc);
+  M::template mma<false>(Q00, Q10, acc, lane, T(1));
+  acc_store(acc, Q10);
+  if (16 + r < rows_valid) {  // L10 -> global
+    T* gp = Lg + (int64_t)(16 + r) * ld;
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(gp + 4 * (lane >> 4)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gp[M::m_of(lane, i)] = acc[i];
+    }
+  }
+  wave_lds_fence();
+  // ---- S11 -= L10 L10^T ----
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = Q11[r * LDB + M::m_of(lane, i)];
+  M::template mma<false>(Q10, Q10, acc, lane, T(-1));
+  acc_store(acc, Q11);
+  wave_lds_fence();
+  // ---- L11, W11 ----
+  load_row(Q11, a);
+  {
+    const int bad1 = potrf_reg<T, 16>(a);
+    if (bad == 0 && bad1 != 0) bad = 16 + bad1;
+  }
+  store_tri(Q11, Lg + 16 * ld + 16, 16, a);
+  wave_lds_fence();
+  inv_tri<T, WA, LDB, 16>(Q11, w, lane);
+  __builtin_amdgcn_wave_barrier();
+  store_cols(Q11, w);
+  wave_lds_fence();
+  // ---- W10 = -W11 (L10 W00): T1 = L10 W00 through the (otherwise zero) upper-right quadrant ----
+  acc_zero(acc);
+  M::template mma<true>(Q00, Q10, acc, lane, T(1));   // T1(n = row of L10, m = c) = sum_k W00[k][c] L10[n][k]
+  acc_store(acc, Q01);
+  wave_lds_fence();
+  acc_zero(acc);
+  M::template mma<true>(Q01, Q11, acc, lane, T(-1));  // W10(n, c) = -sum_k T1[k][c] W11[n][k]
+  acc_store(acc, Q10);
+  if (lane < 16) {  // upper-right quadrant back to zero: W_ss is used as a full 32x32 operand
+    V* rp = reinterpret_cast<V*>(Q01 + r * LDB);
+#pragma unroll
+    for (int q = 0; q < 16 / C::VEC; ++q) {
+      if constexpr (sizeof(T) == 4) rp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      else rp[q] = make_double2(0.0, 0.0);
+    }
+  }
+  return bad;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -799,6 +995,17 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 #endif
   for (int sb = 0; sb < 4; ++sb) {
     T* Dss = tile + tblk<T>(sb, sb);
+#ifndef THX_POTRF_FLAT
+    if (wave == sw) {
+      THX_STAMP();
+      THX_STAMP();
+      THX_STAMP();
+      const int bad = potrf_inv32_blocked<T>(Dss, L + mat + (int64_t)(row0 + 32 * sb) * ld + row0 + 32 * sb, ld,
+                                             valid - 32 * sb, lane);
+      if (bad != 0 && lane == 0 && info[b] == 0) info[b] = row0 + 32 * sb + bad;
+      THX_STAMP();
+    }
+#else  // the unblocked 32-step chain (kept for A/B timing)
     if (wave == sw) {
       T a[32];
       {
@@ -859,6 +1066,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
         for (int i = 0; i < 32; ++i) Dss[i * C::LDB + lr] = (T)w[i];  // W[i][lr]; zero for i < lr
       }
     }
+#endif
     __syncthreads();
     if (sb == 3) break;
     // L_us = S_us W_ss^T for the sub-blocks below (one per wave), stored negated
