@@ -68,7 +68,12 @@ def test_factor_and_solve_residuals_of_the_last_linear_system(full_run):
     y = torch.empty_like(lin.g)
     solver.K.chol_solve(solver.L, n, solver.panels, lin.g, delta)   # cached-factor two-pass solve on the whole batch
     r = (H @ delta[idx].double().unsqueeze(2)).squeeze(2) - g
-    assert (r.norm(dim=1) / g.norm(dim=1)).max().item() < 2e-4     # cond(H) ~ 1e7 at prior weight 1e-3: fp32 solve
+    # normwise backward error of the fp32 solve (Higham, Accuracy and Stability, eq. 7.2): a few sqrt(n) eps; relative to
+    # the right-hand side alone -- tiny at the converged iterate -- the residual is ~1e-4
+    d64 = delta[idx].double()
+    eta = r.abs().amax(dim=1) / (H.abs().sum(dim=2).amax(dim=1) * d64.abs().amax(dim=1) + g.abs().amax(dim=1))
+    assert eta.max().item() < 2e-5, eta
+    assert (r.norm(dim=1) / g.norm(dim=1)).max().item() < 1e-3
     # the fused path (forward substitution inside the factorisation + backward kernel) gives the same solution
     lamv = torch.full((B,), lam, dtype=lin.g.dtype, device="cuda")
     solver.K.chol_factor(lin.H, n, lamv, False, 1e-8, solver.L, solver.panels, solver.info, rhs=lin.g, y=y)
