@@ -998,8 +998,6 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 #ifndef THX_POTRF_FLAT
     if (wave == sw) {
       THX_STAMP();
-      THX_STAMP();
-      THX_STAMP();
       const int bad = potrf_inv32_blocked<T>(Dss, L + mat + (int64_t)(row0 + 32 * sb) * ld + row0 + 32 * sb, ld,
                                              valid - 32 * sb, lane);
       if (bad != 0 && lane == 0 && info[b] == 0) info[b] = row0 + 32 * sb + bad;

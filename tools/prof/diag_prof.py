@@ -14,10 +14,12 @@ info = torch.empty(B, dtype=torch.int32, device="cuda"); lam = torch.full((B,), 
 for _ in range(2):
     K.chol_factor(H, n, lam, False, 1e-8, L, P, info)
 torch.cuda.synchronize()
-names = ["start", "kloop", "S done"] + sum([[f"sb{s} pre", f"sb{s} potrf", f"sb{s} st", f"sb{s} inv"] for s in range(4)], []) + ["chol done", "end"]
+flat = ["start", "kloop", "S done"] + sum([[f"sb{s} pre", f"sb{s} potrf", f"sb{s} st", f"sb{s} inv"] for s in range(4)], []) + ["chol done", "end"]
+blocked = ["start", "kloop", "S done"] + sum([[f"sb{s} enter", f"sb{s} potrf+inv"] for s in range(4)], []) + ["chol done", "end"]
 for j in (0, 5, 11):
     st = P[:, j, 0, :24].double().cpu()   # (B, 24)
     nst = int(st[0, 0].item())
+    names = flat if nst == len(flat) else blocked   # -DTHX_POTRF_FLAT stamps four phases per sub-block, the default two
     d = st[:, 1:nst]
     med = d.median(0).values
     print(f"j={j} nst={nst}: median cycle stamps (delta from previous)")
