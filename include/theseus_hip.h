@@ -254,7 +254,7 @@ int thx_pg_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, i
  *      Schur complement subtracts quantities of the size of Hcc from Hcc, so fp32 blocks would put fp32 rounding of
  *      |Hcc| -- not of |S| -- into S.  S, rhs, g, diag, delta are `dtype` (S feeds the fp32 / fp64 MFMA Cholesky). */
 typedef struct {
-  int32_t num_cams, num_points, num_obs, num_cam_priors, num_pt_priors, num_pairs;
+  int32_t num_cams, num_points, num_obs, num_cam_priors, num_pt_priors, num_pairs, num_blocks;
   const int32_t* obs_cam;       /* (O) */
   const int32_t* obs_pt;        /* (O) */
   const int32_t* pt_ptr;        /* (Np+1) CSR: observations of a point */
@@ -271,6 +271,10 @@ typedef struct {
   const int32_t* pair_o1;       /* (Npairs)  sorted by cam(o2)                                                           */
   const int32_t* pair_o2;
   const int32_t* pair_c2;
+  const int32_t* pair_dptr;     /* (C)  first pair of camera c1 with cam(o2) = c1 (its diagonal pairs run to pair_ptr[c1+1]) */
+  const int32_t* blk_ptr;       /* (Nblocks, 2) [begin, end) pair range of every off-diagonal block (c1, c2 < c1) of S   */
+  const int32_t* blk_c1;        /* (Nblocks) */
+  const int32_t* blk_c2;        /* (Nblocks) */
 } thx_ba_structure;
 
 typedef struct {

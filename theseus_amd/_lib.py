@@ -19,7 +19,7 @@ THX_TILE = 128
 THX_ERR_CHUNKS = 16
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class LieEps(Structure):
@@ -27,10 +27,10 @@ class LieEps(Structure):
 
 
 class BAStructure(Structure):  # thx_ba_structure: int32 device tables of a bundle-adjustment objective
-    _fields_ = [(k, c_int32) for k in ("num_cams", "num_points", "num_obs", "num_cam_priors", "num_pt_priors", "num_pairs")] + [
+    _fields_ = [(k, c_int32) for k in ("num_cams", "num_points", "num_obs", "num_cam_priors", "num_pt_priors", "num_pairs", "num_blocks")] + [
         (k, c_void_p) for k in ("obs_cam", "obs_pt", "pt_ptr", "pt_obs", "cam_ptr", "cam_obs", "cam_prior_cam",
                                 "cam_prior_ptr", "cam_prior_id", "pt_prior_pt", "pt_prior_ptr", "pt_prior_id",
-                                "pair_ptr", "pair_o1", "pair_o2", "pair_c2")]
+                                "pair_ptr", "pair_o1", "pair_o2", "pair_c2", "pair_dptr", "blk_ptr", "blk_c1", "blk_c2")]
 
 
 class BAData(Structure):  # thx_ba_data

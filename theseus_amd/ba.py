@@ -64,10 +64,28 @@ class BAStructure:
         pair_ptr = np.zeros(num_cams + 1, np.int64)
         np.add.at(pair_ptr, oc[o1] + 1, 1)
         self.num_pairs = o1.size
+        # off-diagonal blocks (c1, c2 < c1) of the reduced system: runs of the sorted pair list (a camera's diagonal pairs,
+        # c2 = c1, close its range, so the runs are given as [begin, end) and not as one CSR array)
+        pc1, pc2 = oc[o1], oc[o2]
+        ndiag = np.zeros(num_cams, np.int64)
+        np.add.at(ndiag, pc1[pc1 == pc2], 1)
+        pair_dptr = np.cumsum(pair_ptr)[1:] - ndiag
+        off = np.flatnonzero(pc2 < pc1)
+        if off.size:
+            start = np.ones(off.size, bool)
+            start[1:] = (pc1[off][1:] != pc1[off][:-1]) | (pc2[off][1:] != pc2[off][:-1])
+            starts = np.flatnonzero(start)
+            blk_begin = off[starts]
+            blk_end = off[np.append(starts[1:] - 1, off.size - 1)] + 1
+            blk_c1, blk_c2 = pc1[blk_begin], pc2[blk_begin]
+        else:
+            blk_begin = blk_end = blk_c1 = blk_c2 = np.zeros(0, np.int64)
+        self.num_blocks = int(blk_begin.size)
         self.t = dict(obs_cam=i32(oc), obs_pt=i32(op), pt_ptr=i32(pt_ptr), pt_obs=i32(pt_obs), cam_ptr=i32(cam_ptr),
                       cam_obs=i32(cam_obs), cam_prior_cam=i32(cpc), cam_prior_ptr=i32(cpp), cam_prior_id=i32(cpi),
                       pt_prior_pt=i32(ppp), pt_prior_ptr=i32(ppptr), pt_prior_id=i32(ppi), pair_ptr=i32(np.cumsum(pair_ptr)),
-                      pair_o1=i32(o1), pair_o2=i32(o2), pair_c2=i32(oc[o2]))
+                      pair_o1=i32(o1), pair_o2=i32(o2), pair_c2=i32(oc[o2]), pair_dptr=i32(pair_dptr),
+                      blk_ptr=i32(np.stack([blk_begin, blk_end], 1).reshape(-1)), blk_c1=i32(blk_c1), blk_c2=i32(blk_c2))
         self._dev: Dict[str, "DeviceBA"] = {}
 
     @property
@@ -86,7 +104,7 @@ class DeviceBA:
         self.host = s
         self.t = {k: torch.from_numpy((v if v.size else np.zeros(1, np.int32)).copy()).to(device) for k, v in s.t.items()}
         c = _lib.BAStructure()
-        for k in ("num_cams", "num_points", "num_obs", "num_cam_priors", "num_pt_priors", "num_pairs"):
+        for k in ("num_cams", "num_points", "num_obs", "num_cam_priors", "num_pt_priors", "num_pairs", "num_blocks"):
             setattr(c, k, getattr(s, k))
         for k, v in self.t.items():
             setattr(c, k, v.data_ptr())

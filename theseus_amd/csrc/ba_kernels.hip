@@ -263,7 +263,45 @@ __device__ __forceinline__ void w_times_sym(const double* W, const double* h, do
   }
 }
 
-// ---- Schur 2: one lane per (camera c1, problem): block row c1 of S (columns c2 <= c1) and rhs_c1 ----
+// ---- Schur 2a: one lane per (off-diagonal block (c1, c2 < c1), problem): S_c1c2 = -sum_pairs W_o1 Hpp'^-1 W_o2^T.
+//      (One lane per block ROW left 8 waves per CU walking ~175 pairs each: 3.8 ms at 512 cameras / 32768 observations;
+//      per block there are ~40x more lanes with a handful of pairs each.)
+template <typename T>
+__global__ void __launch_bounds__(64)
+ba_schur_block_kernel(thx_ba_structure s, int B, const double* __restrict__ W, const double* __restrict__ Hinv,
+                      T* __restrict__ S, int64_t ld) {
+  const int b = blockIdx.y * 64 + threadIdx.x, k = blockIdx.x;  // blocks along x: their number can exceed 65535
+  if (b >= B) return;
+  const int c1 = s.blk_c1[k], c2 = s.blk_c2[k];
+  double Off[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) Off[i] = 0.0;
+  for (int q = s.blk_ptr[2 * k]; q < s.blk_ptr[2 * k + 1]; ++q) {
+    const int o1 = s.pair_o1[q], o2 = s.pair_o2[q];
+    const int p = s.obs_pt[o1];
+    double W1[18], W2[18], h[6], M[18];
+    const double* W1p = W + ((int64_t)o1 * B + b) * 18;
+    const double* W2p = W + ((int64_t)o2 * B + b) * 18;
+    const double* hp = Hinv + ((int64_t)p * B + b) * 6;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) { W1[i] = W1p[i]; W2[i] = W2p[i]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) h[i] = hp[i];
+    w_times_sym(W1, h, M);
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+        Off[6 * r + c] -= M[3 * r] * W2[3 * c] + M[3 * r + 1] * W2[3 * c + 1] + M[3 * r + 2] * W2[3 * c + 2];
+  }
+  T* Sb = S + (int64_t)b * ld * ld;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Sb[(int64_t)(6 * c1 + r) * ld + 6 * c2 + c] = (T)Off[6 * r + c];
+}
+
+// ---- Schur 2b: one lane per (camera c1, problem): the diagonal block S_c1c1 (Hcc' - its pairs) and rhs_c1 ----
 template <typename T>
 __global__ void __launch_bounds__(64)
 ba_schur_kernel(thx_ba_structure s, int B, const double* __restrict__ Hcc, const double* __restrict__ W,
@@ -272,10 +310,10 @@ ba_schur_kernel(thx_ba_structure s, int B, const double* __restrict__ Hcc, const
                 T* __restrict__ rhs, int64_t ldr) {
   const int b = blockIdx.x * 64 + threadIdx.x, c1 = blockIdx.y;
   if (b >= B) return;
-  double Dg[36], Off[36], rv[6];
+  double Dg[36], rv[6];
   const double* Hc = Hcc + ((int64_t)c1 * B + b) * 36;
 #pragma unroll
-  for (int i = 0; i < 36; ++i) { Dg[i] = Hc[i]; Off[i] = 0.0; }
+  for (int i = 0; i < 36; ++i) Dg[i] = Hc[i];
   if (damping) {
     const double lam = (double)damping[b];
 #pragma unroll
@@ -296,15 +334,8 @@ ba_schur_kernel(thx_ba_structure s, int B, const double* __restrict__ Hcc, const
     for (int i = 0; i < 6; ++i) rv[i] -= Wo[3 * i] * t0 + Wo[3 * i + 1] * t1 + Wo[3 * i + 2] * t2;
   }
   T* Sb = S + (int64_t)b * ld * ld;
-  auto flush = [&](int c2) __attribute__((always_inline)) {
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = 0; c < 6; ++c) Sb[(int64_t)(6 * c1 + r) * ld + 6 * c2 + c] = (T)Off[6 * r + c];
-  };
-  int cur = -1;
-  for (int k = s.pair_ptr[c1]; k < s.pair_ptr[c1 + 1]; ++k) {
-    const int o1 = s.pair_o1[k], o2 = s.pair_o2[k], c2 = s.pair_c2[k];
+  for (int k = s.pair_dptr[c1]; k < s.pair_ptr[c1 + 1]; ++k) {  // the pairs with cam(o2) = c1
+    const int o1 = s.pair_o1[k], o2 = s.pair_o2[k];
     const int p = s.obs_pt[o1];
     double W1[18], W2[18], h[6], M[18];
     const double* W1p = W + ((int64_t)o1 * B + b) * 18;
@@ -315,20 +346,12 @@ ba_schur_kernel(thx_ba_structure s, int B, const double* __restrict__ Hcc, const
 #pragma unroll
     for (int i = 0; i < 6; ++i) h[i] = hp[i];
     w_times_sym(W1, h, M);
-    if (c2 != c1 && c2 != cur) {  // a new off-diagonal block (pairs are sorted by c2; the diagonal ones come last)
-      if (cur >= 0) flush(cur);
-#pragma unroll
-      for (int i = 0; i < 36; ++i) Off[i] = 0.0;
-      cur = c2;
-    }
-    double* dst = c2 == c1 ? Dg : Off;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
       for (int c = 0; c < 6; ++c)
-        dst[6 * r + c] -= M[3 * r] * W2[3 * c] + M[3 * r + 1] * W2[3 * c + 1] + M[3 * r + 2] * W2[3 * c + 2];
+        Dg[6 * r + c] -= M[3 * r] * W2[3 * c] + M[3 * r + 1] * W2[3 * c + 1] + M[3 * r + 2] * W2[3 * c + 2];
   }
-  if (cur >= 0) flush(cur);
 #pragma unroll
   for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -529,6 +552,9 @@ int thx_ba_schur(const thx_ba_structure* s, int32_t B, const void* Hcc, const vo
                  hipLaunchKernelGGL(ba_point_invert_kernel<float>, gp, block, 0, as_stream(stream), *s, B, (const double*)Hpp,
                                     (const double*)gd, ldv, (const float*)damping, ellipsoidal, (float)damping_eps,
                                     (double*)Hinv, (double*)tvec, info);
+                 if (s->num_blocks > 0)
+                   hipLaunchKernelGGL(ba_schur_block_kernel<float>, dim3(s->num_blocks, (B + 63) / 64), block, 0,
+                                      as_stream(stream), *s, B, (const double*)W, (const double*)Hinv, (float*)S, ld);
                  hipLaunchKernelGGL(ba_schur_kernel<float>, gc, block, 0, as_stream(stream), *s, B, (const double*)Hcc,
                                     (const double*)W, (const double*)gd, ldv, (const float*)damping, ellipsoidal,
                                     (float)damping_eps, (const double*)Hinv, (const double*)tvec, (float*)S, ld, (float*)rhs, ldr);
@@ -537,6 +563,9 @@ int thx_ba_schur(const thx_ba_structure* s, int32_t B, const void* Hcc, const vo
                  hipLaunchKernelGGL(ba_point_invert_kernel<double>, gp, block, 0, as_stream(stream), *s, B,
                                     (const double*)Hpp, (const double*)gd, ldv, (const double*)damping, ellipsoidal,
                                     damping_eps, (double*)Hinv, (double*)tvec, info);
+                 if (s->num_blocks > 0)
+                   hipLaunchKernelGGL(ba_schur_block_kernel<double>, dim3(s->num_blocks, (B + 63) / 64), block, 0,
+                                      as_stream(stream), *s, B, (const double*)W, (const double*)Hinv, (double*)S, ld);
                  hipLaunchKernelGGL(ba_schur_kernel<double>, gc, block, 0, as_stream(stream), *s, B, (const double*)Hcc,
                                     (const double*)W, (const double*)gd, ldv, (const double*)damping, ellipsoidal, damping_eps,
                                     (const double*)Hinv, (const double*)tvec, (double*)S, ld, (double*)rhs, ldr);
