@@ -15,7 +15,7 @@ for f in glob.glob(os.path.join(out, "p*/**/*counter_collection.csv"), recursive
         a[1] += float(r["Counter_Value"])
 for k, cs in sorted(tab.items()):
     n = max(v[0] for v in cs.values())
-    if not ("chol" in k or "pg_" in k or "se3_retract" in k):
+    if not ("chol" in k or "pg_" in k or "se3_retract" in k or "ba_" in k):
         continue
     print(f"## {k}  ({n} launches) per-launch averages")
     for c, (m, v) in sorted(cs.items()):
