@@ -22,3 +22,32 @@ def test_ba_host_path_matches_reference(name):
     np.testing.assert_allclose(deltas[0].numpy()[:, cols], g["delta"][0], rtol=0, atol=1e-7 * max(1.0, np.abs(g["delta"][0]).max()))
     lin = opt.linear_solver.linearization
     assert lin.num_cols == int(g["num_cols"]) and lin.num_rows == int(g["num_rows"])
+
+
+def test_schur_block_tables_partition_the_pair_list():
+    """BAStructure's tables for thx_ba_schur: every off-diagonal pair (cam(o2) < cam(o1)) lies in exactly one block run
+    [begin, end) of constant (c1, c2), the diagonal pairs close each camera's range, blocks are unique."""
+    import numpy as np
+    from theseus_amd.ba import BAStructure
+    rng = np.random.default_rng(0)
+    C, Np = 9, 40
+    u = np.unique(np.stack([rng.integers(0, C, 160), rng.integers(0, Np, 160)], 1), axis=0)
+    oc, op = u[:, 0], u[:, 1]
+    s = BAStructure(C, Np, oc, op, np.arange(C), np.arange(Np))
+    t = s.t
+    pc1, pc2 = oc[t["pair_o1"]], t["pair_c2"]
+    assert (op[t["pair_o1"]] == op[t["pair_o2"]]).all() and (pc2 <= pc1).all()
+    runs = t["blk_ptr"].reshape(-1, 2)
+    assert runs.shape[0] == s.num_blocks == len(set(zip(t["blk_c1"].tolist(), t["blk_c2"].tolist())))
+    covered = np.zeros(s.num_pairs, bool)
+    for k, (a, b) in enumerate(runs):
+        assert b > a and (pc1[a:b] == t["blk_c1"][k]).all() and (pc2[a:b] == t["blk_c2"][k]).all()
+        assert not covered[a:b].any()
+        covered[a:b] = True
+    assert (covered == (pc2 < pc1)).all()
+    for c in range(C):
+        a, b = t["pair_dptr"][c], t["pair_ptr"][c + 1]
+        assert (pc1[a:b] == c).all() and (pc2[a:b] == c).all() and (pc2[t["pair_ptr"][c]:a] < c).all()
+    # every pair of observations of a common point appears once (lower triangle incl. the diagonal)
+    want = sum(k * (k + 1) // 2 for k in np.bincount(op, minlength=Np))
+    assert s.num_pairs == want
