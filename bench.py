@@ -157,14 +157,13 @@ def main():
     timer = KernelTimer(opt.linear_solver.K)
     strong = args.total_batch > 0
     if strong:
-        from theseus_amd.sharding import shard_bounds
+        from theseus_amd.sharding import plan_sub_batches
         if args.implicit:
             raise SystemExit("--total-batch is the forward configuration (configs[2]); not combined with --implicit")
-        lo, hi = shard_bounds(args.total_batch, rank, world)
-        if (hi - lo) % B and hi - lo > B:
-            raise SystemExit(f"rank share {hi - lo} is not a multiple of the sub-batch {B}")
-        B = min(B, hi - lo)
-        n_sub = (hi - lo) // B
+        try:
+            B, n_sub = plan_sub_batches(args.total_batch, rank, world, B)
+        except ValueError as e:
+            raise SystemExit(str(e))
     else:
         n_sub = 1
     # every sub-batch's inputs are resident in HBM before the timed region (synthetic, one seed per rank and sub-batch)

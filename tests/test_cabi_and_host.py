@@ -85,3 +85,20 @@ def test_shard_bounds_cover_the_batch():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_bounds(8, 2, 2)
+
+
+def test_plan_sub_batches_strong_scaling():
+    """bench.py --total-batch: configs[2] = 32768 problems over 1/2/4/8 ranks in sub-batches of 4096."""
+    import pytest
+    from theseus_amd.sharding import plan_sub_batches, shard_bounds
+    for world in (1, 2, 4, 8):
+        plans = [plan_sub_batches(32768, r, world, 4096) for r in range(world)]
+        assert plans == [(4096, 8 // world)] * world
+        assert sum(b * n for b, n in plans) == 32768
+    assert plan_sub_batches(8192, 0, 1, 4096) == (4096, 2)
+    assert plan_sub_batches(1000, 1, 2, 4096) == (500, 1)          # a share below the sub-batch is one batch
+    assert plan_sub_batches(10, 2, 3, 4) == (3, 1) and shard_bounds(10, 2, 3) == (7, 10)
+    with pytest.raises(ValueError):
+        plan_sub_batches(12288 + 8, 0, 1, 4096)                    # share not a multiple of the sub-batch
+    with pytest.raises(ValueError):
+        plan_sub_batches(2, 2, 3, 4096)                            # more ranks than problems

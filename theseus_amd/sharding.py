@@ -26,6 +26,21 @@ def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def plan_sub_batches(total: int, rank: int, world: int, max_batch: int) -> Tuple[int, int]:
+    """Strong scaling of a job of ``total`` problems (BASELINE.json configs[2]): this rank's share (``shard_bounds``) is
+    solved as ``n_sub`` consecutive sub-batches of ``batch`` problems through one set of persistent workspaces.
+    Returns (batch, n_sub); the share must be at most ``max_batch`` or a multiple of it."""
+    lo, hi = shard_bounds(total, rank, world)
+    share = hi - lo
+    if share <= 0:
+        raise ValueError(f"rank {rank} of {world} has no problems in a job of {total}")
+    if share <= max_batch:
+        return share, 1
+    if share % max_batch:
+        raise ValueError(f"rank share {share} is not a multiple of the sub-batch {max_batch}")
+    return max_batch, share // max_batch
+
+
 def shard_tensors(tensors, rank: int, world: int):
     """name -> tensor dict with batch-leading tensors -> this rank's slice (batch-1 tensors are shared)."""
     B = max(t.shape[0] for t in tensors.values())
