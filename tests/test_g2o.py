@@ -148,3 +148,56 @@ def test_benchmark_objective_lm_hip_f32(golden):
     got = final.double()[0]
     rel = lambda X: lie.se3_compose(lie.se3_inverse(X[:-1]), X[1:])  # noqa: E731
     assert (rel(got) - rel(want)).abs().max().item() < 2e-3
+
+
+def test_2d_file_lm_host_path_matches_oracle(tmp_path):
+    """A SLAM-2D file (the reference's own 2-D reader cannot parse EDGE_SE2 lines, see theseus_amd/utils/g2o.py): read it,
+    build the benchmark objective on SE2, run LM through the host path (test stand-in kernels) and compare with the oracle's
+    dense SE2 restatement evaluated on the tensors the reader produced."""
+    from oracle import pose_graph as opg
+    from tests.oracle_kernels import OracleKernels
+    rng = np.random.default_rng(4)
+    P = 7
+    gt = np.cumsum(rng.uniform(-0.6, 0.6, (P, 3)), 0)
+    gt[0] = 0
+    lines = []
+    pairs = [(k, k + 1) for k in range(P - 1)] + [(0, 3), (2, 6), (1, 5)]
+
+    def rel(a, b):  # inv(a) * b for [x, y, theta]
+        c, s = np.cos(a[2]), np.sin(a[2])
+        d = b[:2] - a[:2]
+        return np.array([c * d[0] + s * d[1], -s * d[0] + c * d[1], b[2] - a[2]])
+    for k, (i, j) in enumerate(pairs):
+        m = rel(gt[i], gt[j]) + rng.normal(0, 0.02, 3)
+        info = [100.0 + 7 * k, 0.0, 0.0, 144.0 + 3 * k, 0.0, 400.0 + 11 * k]
+        lines.append("EDGE_SE2 %d %d %r %r %r " % (i, j, float(m[0]), float(m[1]), float(m[2])) +
+                     " ".join(repr(x) for x in info))
+    for i in range(P):
+        v = gt[i] + rng.normal(0, 0.05, 3)
+        lines.append("VERTEX_SE2 %d %r %r %r" % (i, float(v[0]), float(v[1]), float(v[2])))
+    path = tmp_path / "loop2d.g2o"
+    path.write_text("\n".join(lines) + "\n")
+
+    nv, verts, edges = g2o.read_2D_g2o_file(str(path), dtype=torch.float64)
+    assert nv == P and len(edges) == len(pairs)
+    poses0 = torch.stack([v.tensor.clone() for v in verts], 1)
+    prob = opg.PGProblem(
+        num_poses=P, edges=torch.tensor([[e.i, e.j] for e in edges]),
+        meas=torch.stack([e.relative_pose.tensor for e in edges], 1),
+        w_between=torch.stack([e.weight.diagonal.tensor for e in edges], 1),
+        prior_idx=torch.tensor([0]), prior_target=poses0[:, :1].clone(),
+        w_prior=torch.full((1, 1, 3), 1e-6, dtype=torch.float64), group="SE2")
+    with torch.no_grad():
+        want, winfo = opg.lm_optimize(prob, poses0.clone(), max_iterations=6, damping=1e-3, abs_err_tolerance=0.0,
+                                      rel_err_tolerance=0.0)
+    obj = g2o.pose_graph_objective(verts, edges, dtype=torch.float64)
+    opt = th.LevenbergMarquardt(obj, max_iterations=6, step_size=1.0, linear_solver_cls=th.HipCholeskySolver,
+                                abs_err_tolerance=0.0, rel_err_tolerance=0.0,
+                                linearization_kwargs=dict(kernels=OracleKernels()))
+    with torch.no_grad():
+        info = opt.optimize(track_err_history=True, damping=1e-3)
+    got = torch.stack([v.tensor for v in verts], 1)
+    want_hist = torch.stack(winfo.err_history, 1)
+    assert (info.err_history.double() / want_hist - 1).abs().max().item() < 1e-9
+    assert want_hist[0, -1] < 0.05 * want_hist[0, 0]
+    assert (got - want).abs().max().item() < 1e-8
