@@ -102,3 +102,16 @@ def test_plan_sub_batches_strong_scaling():
         plan_sub_batches(12288 + 8, 0, 1, 4096)                    # share not a multiple of the sub-batch
     with pytest.raises(ValueError):
         plan_sub_batches(2, 2, 3, 4096)                            # more ranks than problems
+
+
+def test_integration_doc_lists_every_entry_point():
+    """INTEGRATION.md is the binding a maintainer reads: every function include/theseus_hip.h declares appears in it."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "theseus_hip.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\b(thx_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) > 30
+    missing = [n for n in names if n not in doc]
+    assert not missing, missing
