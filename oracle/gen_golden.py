@@ -183,6 +183,67 @@ def gen_lm(th, lieF, only=None):
         print(name, "err", err0.mean(), "->", info.err_history[:, -1].mean().item())
 
 
+def gen_pg_full(th, lieF, only=None):
+    """BASELINE.json configs[1] at FULL size through the REAL reference: 256 SE3 poses, 1024 Between edges (the benchmark's
+    fixed topology, theseus_amd/utils/synthetic.py:pose_graph_topology(256, 1024, 0)) + the Difference prior on pose 0 with
+    ScaleCostWeight(1e-3) (examples/pose_graph/pose_graph_synthetic.py:130-152), LM damping 1e-3, 3 iterations,
+    DenseLinearization + CholeskyDenseSolver.  Data model of the benchmark (random-walk ground truth, noisy measurements and
+    initial poses: dataset.py:238-365), drawn here on the CPU with the reference's own SE3 ops.  Dense A is 75.6 MB per
+    problem in fp64: the fixture keeps Atb, the steps, the errors and the solution (no A / AtA)."""
+    from theseus_amd.utils.synthetic import PRIOR_WEIGHT, ROTATION_NOISE, TRANSLATION_NOISE, pose_graph_topology
+    P, E, ITERS = 256, 1024, 3
+    SE3 = lieF.SE3
+    for name, dtype, B, seed in (("pg_full_f64_lm", torch.float64, 2, 101), ("pg_full_f32_lm", torch.float32, 4, 102)):
+        if only and name not in only:
+            continue
+        gen = torch.Generator().manual_seed(seed)
+        edges = torch.tensor(pose_graph_topology(P, E, topology_seed=0), dtype=torch.long)
+
+        def noise(n):
+            u = 2.0 * torch.rand(n, 6, dtype=torch.float64, generator=gen) - 1.0
+            u[:, :3] *= TRANSLATION_NOISE
+            u[:, 3:] *= ROTATION_NOISE
+            return SE3.exp(u)
+        gt = [torch.eye(3, 4, dtype=torch.float64).expand(B, 3, 4).contiguous()]
+        for k in range(1, P):
+            u = torch.rand(B, 6, dtype=torch.float64, generator=gen)
+            u[:, :3] -= 0.5
+            u[:, 3:] = 2.0 * u[:, 3:] - 1.0
+            gt.append(SE3.compose(gt[-1], SE3.exp(u)))
+        gt = torch.stack(gt, 1)                                                            # (B, P, 3, 4)
+        poses0 = SE3.compose(gt.reshape(-1, 3, 4), noise(B * P)).view(B, P, 3, 4)
+        gi, gj = gt[:, edges[:, 0]].reshape(-1, 3, 4), gt[:, edges[:, 1]].reshape(-1, 3, 4)
+        meas = SE3.compose(SE3.compose(SE3.inv(gi), gj), noise(B * E)).view(B, E, 3, 4)
+        f = lambda t: t.to(dtype)  # noqa: E731
+        d = dict(P=P, edges=edges, meas=f(meas), poses=f(poses0),
+                 w_between=f(torch.tensor([[[1 / TRANSLATION_NOISE] * 3 + [1 / ROTATION_NOISE] * 3]], dtype=torch.float64).repeat(1, E, 1)),
+                 prior_idx=torch.tensor([0]), prior_target=f(poses0[:, :1]).clone(),
+                 w_prior=torch.full((1, 1, 6), PRIOR_WEIGHT, dtype=dtype))
+        obj, poses = build_reference_objective(th, d, dtype)
+        opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, abs_err_tolerance=0.0,
+                                    rel_err_tolerance=0.0, max_iterations=ITERS, step_size=1.0)
+        taps = dict(Atb=[], delta=[], err=[])
+
+        def cb(optimizer, info, delta, it):
+            lin = optimizer.linear_solver.linearization
+            taps["Atb"].append(lin.Atb.clone().numpy())
+            taps["delta"].append(delta.clone().numpy())
+            taps["err"].append(info.last_err.clone().numpy())
+        lin = opt.linear_solver.linearization
+        with torch.no_grad():
+            err0 = obj.error_metric().clone().numpy()
+            info = opt.optimize(track_err_history=True, end_iter_callback=cb, damping=1e-3)
+        final = torch.stack([p.tensor for p in poses], 1).numpy()
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"), P=P, edges=edges.numpy(), meas=d["meas"].numpy(), w_between=d["w_between"].numpy(),
+            prior_idx=d["prior_idx"].numpy(), prior_target=d["prior_target"].numpy(), w_prior=d["w_prior"].numpy(),
+            poses0=d["poses"].numpy(), final=final, err0=err0, err_history=info.err_history.numpy(), Atb=np.stack(taps["Atb"]),
+            delta=np.stack(taps["delta"]), last_err=np.stack(taps["err"]), var_start_cols=np.array(lin.var_start_cols),
+            var_dims=np.array(lin.var_dims), num_rows=lin.num_rows, num_cols=lin.num_cols,
+            opt_kwargs=np.array(repr(dict(max_iterations=ITERS, step_size=1.0, damping=1e-3, gauss_newton=False))))
+        print(name, "err", err0.mean(), "->", info.err_history[:, -1].mean().item())
+
+
 def gen_se2(th):
     """SE2 (theseus/geometry/se2.py): Lie-op fixtures incl. the near-zero / d-near-zero branches, and LM trajectories
     of SE2 pose graphs (Between + Difference) with DenseLinearization + CholeskyDenseSolver."""
@@ -428,20 +489,33 @@ def gen_pgo_kat(th):
         losses_published=np.array(PGO_KAT_LOSSES), losses_reference_here=np.array(losses))
 
 
-def gen_ba(th):
+def gen_ba(th, only=None):
     """Small bundle adjustment problems (examples/bundle_adjustment.py:103-160 shape: robust Huber Reprojection costs,
     Difference regularisers on every camera and point, strong priors on a few cameras) solved by the reference's
     LevenbergMarquardt + DenseLinearization + CholeskyDenseSolver; geometry from the reference's generator, batch items =
     independent perturbations of the initial cameras / points and of the feature noise."""
     import theseus.utils.examples as theg
-    cases = [("ba_f64_lm", torch.float64, 4, dict(max_iterations=8, step_size=1.0), dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True), "huber"),
-             ("ba_f64_gn", torch.float64, 3, dict(max_iterations=6, step_size=0.5), None, None),
-             ("ba_f32_lm", torch.float32, 4, dict(max_iterations=6, step_size=1.0), dict(damping=1e-2), "welsch")]
-    for name, dtype, B, ok, lmk, robust in cases:
+    small = dict(num_cameras=6, num_points=40, average_track_length=4, track_locality=0.3)
+    cases = [("ba_f64_lm", torch.float64, 4, dict(max_iterations=8, step_size=1.0), dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True), "huber", small),
+             ("ba_f64_gn", torch.float64, 3, dict(max_iterations=6, step_size=0.5), None, None, small),
+             ("ba_f32_lm", torch.float32, 4, dict(max_iterations=6, step_size=1.0), dict(damping=1e-2), "welsch", small),
+             # reduced camera system 192 x 192 (two 128-tiles of the Cholesky, multi-row Schur tables), 512 points
+             ("ba_mid_f64_lm", torch.float64, 2, dict(max_iterations=4, step_size=1.0),
+              dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True), "huber",
+              dict(num_cameras=32, num_points=512, average_track_length=4, track_locality=0.2)),
+             ("ba_mid_f32_lm", torch.float32, 2, dict(max_iterations=3, step_size=1.0), dict(damping=1e-2), None,
+              dict(num_cameras=32, num_points=512, average_track_length=4, track_locality=0.2)),
+             # BASELINE.json configs[3] at FULL size, one problem, fp64: dense A is 20.6 GB, A^T A 6.1 GB (SURVEY 8c)
+             ("ba_full_f64_lm", torch.float64, 1, dict(max_iterations=2, step_size=1.0),
+              dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True), "huber",
+              dict(num_cameras=512, num_points=8192, average_track_length=4, track_locality=0.2))]
+    for name, dtype, B, ok, lmk, robust, dims in cases:
+        if only is not None and name not in only:
+            continue
+        big = dims["num_cameras"] > 6
         torch.manual_seed(3)
         np.random.seed(3)
-        ba = theg.BundleAdjustmentDataset.generate_synthetic(num_cameras=6, num_points=40, average_track_length=4,
-                                                             track_locality=0.3, feat_random=1.5, outlier_feat_random=70)
+        ba = theg.BundleAdjustmentDataset.generate_synthetic(feat_random=1.5, outlier_feat_random=70, **dims)
         gen = torch.Generator().manual_seed(17)
         C, Np, O = len(ba.cameras), len(ba.points), len(ba.observations)
         lieF = __import__("torchlie.functional", fromlist=["SE3"])
@@ -504,11 +578,17 @@ def gen_ba(th):
             lin_ = optimizer.linear_solver.linearization
             taps["delta"].append(delta.clone().numpy())
             if it == 0:
-                taps["AtA"].append(lin_.AtA.clone().numpy())
+                if not big:
+                    taps["AtA"].append(lin_.AtA.clone().numpy())
                 taps["Atb"].append(lin_.Atb.clone().numpy())
+            print(f"  {name}: iteration {it} done, err {info.last_err.tolist()}", flush=True)
         lin = opt.linear_solver.linearization
-        lin.linearize()
-        A0, b0 = lin.A.clone().numpy(), lin.b.clone().numpy()
+        if big:   # the dense taps (A0, b0, AtA) would be GBs: the big cases pin Atb, the steps, the errors and the solution
+            A0 = b0 = np.zeros(0)
+            taps["AtA"].append(np.zeros(0))
+        else:
+            lin.linearize()
+            A0, b0 = lin.A.clone().numpy(), lin.b.clone().numpy()
         err0 = obj.error_metric().clone().numpy()
         with torch.no_grad():
             info = opt.optimize(track_err_history=True, end_iter_callback=cb, **(lmk or {}))
@@ -584,8 +664,12 @@ def main():
         gen_se2_implicit(th)
     if not only or "pgo_kat" in only:
         gen_pgo_kat(th)
-    if not only or "ba" in only:
-        gen_ba(th)
+    if not only or "ba" in only:   # (the small cases; the multi-tile and full-size ones are asked for by name)
+        gen_ba(th, {"ba_f64_lm", "ba_f64_gn", "ba_f32_lm"})
+    if only & {"ba_mid_f64_lm", "ba_mid_f32_lm", "ba_full_f64_lm"}:
+        gen_ba(th, only)
+    if not only or only & {"pg_full_f64_lm", "pg_full_f32_lm"}:
+        gen_pg_full(th, lieF, only & {"pg_full_f64_lm", "pg_full_f32_lm"})
     if not only or "g2o" in only:
         gen_g2o(th)
     print("wrote", sorted(os.listdir(OUT)))

@@ -1,0 +1,47 @@
+"""bench.py's launcher / sharding / reporting logic without a GPU: `python bench.py --gpus 2` must START two ranks by itself
+(torch.distributed.run, 127.0.0.1 rendezvous), shard the batch, run the one all_gather and print ONE JSON line that says so.
+The kernels are the TEST stand-in (tests/oracle_kernels.py) over gloo -- the line is marked "data": "TEST-STANDIN"; on the GPU
+box the same command runs libtheseus_hip.so over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEAM = ["--backend", "gloo", "--test-kernels", "tests.oracle_kernels:OracleKernels", "--poses", "6", "--edges", "8",
+        "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--parity-sample", "0", "--dtype", "f64"]
+
+
+def _bench(*argv):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv, *SEAM], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout          # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_gpus_2_starts_two_ranks_weak_scaling():
+    r = _bench("--gpus", "2", "--batch", "3")
+    assert r["n_gpus"] == 2 and r["ranks"] == 2 and r["collective_backend"] == "gloo"
+    assert r["scaling"] == "weak" and r["config"]["global_batch"] == 6 and r["config"]["batch_per_gpu"] == 3
+    assert r["all_gather_ms"] is not None and r["all_gather_ms"] >= 0.0
+    assert r["rank_ms_per_step"]["min"] <= r["rank_ms_per_step"]["max"] <= r["ms_per_step"] * 1.001
+    assert r["iters_done"] == 2 and r["data"] == "TEST-STANDIN" and "roofline" not in r
+    assert r["value"] == pytest.approx(6 * 2 / (r["ms_per_step"] * 2 * 1e-3), rel=1e-6)
+    assert r["mean_error"][1] < r["mean_error"][0]
+
+
+def test_gpus_2_strong_scaling_in_sub_batches():
+    r = _bench("--gpus", "2", "--total-batch", "8", "--batch", "2")
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong"
+    assert r["config"]["global_batch"] == 8 and r["config"]["batch_per_gpu"] == 4 and "2 sub-batches of 2" in r["config"]["parallelism"]
+
+
+def test_single_rank_default():
+    r = _bench("--batch", "2")
+    assert r["n_gpus"] == 1 and r["ranks"] == 1 and r["all_gather_ms"] is None and r["collective_backend"] is None

@@ -119,3 +119,77 @@ def test_sample_agrees_with_exact_evaluation_of_the_same_inputs(full_run):
     got = full_run["poses"][idx].double().cpu()
     rel = lambda X: lie.se3_compose(lie.se3_inverse(X[:, :-1].reshape(-1, 3, 4)), X[:, 1:].reshape(-1, 3, 4))  # noqa: E731
     assert (rel(got) - rel(final)).abs().max().item() < 5e-3   # relative poses: the gauge is weakly pinned (prior 1e-3)
+
+
+# ---- the same size against the REAL reference (tests/golden/pg_full_*.npz, oracle/gen_golden.py:gen_pg_full) ----------------
+def _run_fixture(name):
+    import theseus_amd as th
+    from tests.helpers import golden_problem, load_golden
+    from tests.test_gpu_lm import build_objective
+    g = load_golden(name)
+    _, _, kw = golden_problem(g)
+    obj, _ = build_objective(th, g)
+    kw.pop("gauss_newton")
+    opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.HipCholeskySolver, max_iterations=kw.pop("max_iterations"),
+                                step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    lin = opt.linear_solver.linearization
+    assert lin.var_start_cols == list(g["var_start_cols"]) and lin.var_dims == list(g["var_dims"])   # structure: bit exact
+    assert lin.num_rows == int(g["num_rows"]) and lin.num_cols == int(g["num_cols"]) == 6 * P
+    deltas, atbs = [], []
+
+    def cb(o, i, d, it):
+        deltas.append(d.clone())
+        atbs.append(o.linear_solver.linearization.Atb.clone())
+    sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(track_err_history=True, end_iter_callback=cb, **kw))
+    final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1).cpu()
+    return g, final, deltas, atbs, info
+
+
+def _relative_poses(X):
+    """Gauge-free view of a solution: X_k^-1 X_{k+1} along the odometry chain (B, P-1, 3, 4)."""
+    from oracle import lie
+    B = X.shape[0]
+    return lie.se3_compose(lie.se3_inverse(X[:, :-1].reshape(-1, 3, 4)), X[:, 1:].reshape(-1, 3, 4)).view(B, -1, 3, 4)
+
+
+def test_fp64_matches_the_reference_run_at_full_size():
+    """north_star: "solution error <= 1e-5 vs reference" -- carried by the fp64 path at the size the metric is quoted on
+    (n = 1536, 12 Cholesky tiles): final poses of the reference's own DenseLinearization + CholeskyDenseSolver LM run."""
+    import numpy as np
+    g, final, deltas, atbs, info = _run_fixture("pg_full_f64_lm")
+    err = (final - torch.from_numpy(g["final"])).abs().max().item()
+    rel = (_relative_poses(final) - _relative_poses(torch.from_numpy(g["final"]))).abs().max().item()
+    print(f"[full size fp64] max |pose - reference| = {err:.3e}, gauge-free (relative poses) = {rel:.3e}")
+    assert err <= 1e-5, err            # the bar north_star states
+    assert err <= 2e-7 and rel <= 2e-8, (err, rel)   # what this path actually delivers (gauge-weak: cond ~ 1e10)
+    for it in range(g["delta"].shape[0]):
+        np.testing.assert_allclose(atbs[it].cpu().numpy(), g["Atb"][it], rtol=0, atol=1e-9 * np.abs(g["Atb"][it]).max())
+        np.testing.assert_allclose(deltas[it].cpu().numpy(), g["delta"][it], rtol=0, atol=2e-7 * max(1.0, np.abs(g["delta"][it]).max()))
+    np.testing.assert_allclose(info.err_history.numpy()[:, 1:].T, g["last_err"], rtol=1e-9)
+    np.testing.assert_allclose(info.err_history.numpy()[:, 0], g["err0"], rtol=1e-12)
+
+
+def test_fp32_inside_the_reference_band_at_full_size():
+    """fp32 at n = 1536: the HIP trajectory is no farther from the exact trajectory of the same fp32 problem (fp64 oracle,
+    fp32 thresholds) than the REFERENCE's own fp32 run -- in absolute pose terms (gauge included) and gauge-free."""
+    from oracle import pose_graph as opg
+    from tests.helpers import f32_thresholds, f32_truth_problem, golden_problem
+    g, final, deltas, atbs, info = _run_fixture("pg_full_f32_lm")
+    p, poses0, kw = golden_problem(g)
+    p64, poses64 = f32_truth_problem(p, poses0)
+    with f32_thresholds(), torch.no_grad():
+        exact, xinfo = opg.lm_optimize(p64, poses64, abs_err_tolerance=0.0, rel_err_tolerance=0.0, keep_taps=True, **kw)
+    ref = torch.from_numpy(g["final"]).double()
+    dev, dev_ref = (final.double() - exact).abs().max().item(), (ref - exact).abs().max().item()
+    rel = (_relative_poses(final.double()) - _relative_poses(exact)).abs().max().item()
+    rel_ref = (_relative_poses(ref) - _relative_poses(exact)).abs().max().item()
+    print(f"[full size fp32] |pose - exact|: hip {dev:.3e}, reference {dev_ref:.3e}; gauge-free: hip {rel:.3e}, reference {rel_ref:.3e}")
+    assert dev <= 1.5 * dev_ref and rel <= 1.5 * rel_ref + 1e-6, (dev, dev_ref, rel, rel_ref)
+    hx = torch.stack(xinfo.err_history, 1)
+    e = ((info.err_history.double() - hx).abs() / hx).max().item()
+    e_ref = ((torch.from_numpy(g["err_history"]).double() - hx).abs() / hx).max().item()
+    assert e <= 1.5 * e_ref + 1e-6, (e, e_ref)
+    for it, d in enumerate(deltas):
+        dd = (d.cpu().double() - xinfo.deltas[it]).abs().max().item()
+        dr = (torch.from_numpy(g["delta"][it]).double() - xinfo.deltas[it]).abs().max().item()
+        assert dd <= 1.5 * dr + 1e-6, (it, dd, dr)

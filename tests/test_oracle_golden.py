@@ -177,3 +177,48 @@ def test_bundle_adjustment_matches_reference(name, tol):
     np.testing.assert_allclose(hist[:, :k], g["err_history"][:, :k], rtol=5e-3 if f32 else 1e-6)
     if len(info.deltas) == g["delta"].shape[0]:
         np.testing.assert_allclose(info.deltas[0].numpy(), g["delta"][0], rtol=0, atol=(1e-2 if f32 else 1e-7) * max(1.0, np.abs(g["delta"][0]).max()))
+
+
+# ---- fixtures at the sizes BASELINE.json names (oracle/gen_golden.py: gen_pg_full, gen_ba cases ba_mid_* / ba_full_*) ----
+@pytest.mark.parametrize("name,tol", [("pg_full_f64_lm", 5e-8), ("pg_full_f32_lm", 5e-2)])
+def test_full_size_pose_graph_matches_reference(name, tol):
+    """256 SE3 poses / 1024 Between edges + prior (configs[1]'s shape, n = 1536): the oracle against the REAL reference's
+    DenseLinearization + CholeskyDenseSolver LM run -- A^T b of every iteration, every step, the errors, the solution."""
+    g = load_golden(name)
+    p, poses0, kw = golden_problem(g)
+    f32 = tol > 1e-6
+    assert p.n == int(g["num_cols"]) == 1536 and p.m == int(g["num_rows"]) == 6 * 1025
+    final, info = opg.lm_optimize(p, poses0, abs_err_tolerance=0.0, rel_err_tolerance=0.0, keep_taps=True, **kw)
+    A, b = opg.dense_linearize(p, poses0)
+    _, Atb = opg.hessian(A, b)
+    np.testing.assert_allclose(Atb.numpy(), g["Atb"][0], rtol=0, atol=np.abs(g["Atb"][0]).max() * (2e-5 if f32 else 1e-12))
+    np.testing.assert_allclose(opg.error_metric(p, poses0).numpy(), g["err0"], rtol=1e-5 if f32 else 1e-12)
+    hist = torch.stack(info.err_history, 1).numpy()
+    np.testing.assert_allclose(hist, g["err_history"], rtol=5e-3 if f32 else 2e-7)   # (the reference keeps err_history in fp32)
+    np.testing.assert_allclose(hist[:, 1:].T, g["last_err"], rtol=5e-3 if f32 else 1e-9)   # info.last_err per iteration, fp64
+    # fp32: the reference's own fp32 run is a noisy draw at this size (gauge-weak: prior 1e-3, lambda 1e-3); the fp32 oracle
+    # is another draw of the same band -- the tight fp32 statement is the in-band test on the GPU (tests/test_gpu_full_size.py)
+    np.testing.assert_allclose(final.numpy(), g["final"], rtol=0, atol=tol)
+    for it in range(len(info.deltas)):
+        np.testing.assert_allclose(info.deltas[it].numpy(), g["delta"][it], rtol=0, atol=tol * max(1.0, np.abs(g["delta"][it]).max()))
+
+
+@pytest.mark.parametrize("name,tol", [("ba_mid_f64_lm", 1e-7), ("ba_mid_f32_lm", 5e-2)])
+def test_multi_tile_bundle_adjustment_matches_reference(name, tol):
+    """32 cameras / 471 observed points / 2048 observations (reduced camera system 192 x 192 = two Cholesky tiles)."""
+    from tests.helpers import ba_problem
+    g = load_golden(name)
+    p, state0, kw, used = ba_problem(g)
+    f32 = tol > 1e-6
+    assert p.n == int(g["num_cols"]) and p.m == int(g["num_rows"]) and p.num_cams == 32
+    A, b = p.dense_linearize(state0)
+    _, Atb = opg.hessian(A, b)
+    np.testing.assert_allclose(Atb.numpy(), g["Atb"][0], rtol=0, atol=np.abs(g["Atb"][0]).max() * (5e-5 if f32 else 1e-12))
+    np.testing.assert_allclose(p.error_metric(state0).numpy(), g["err0"], rtol=2e-5 if f32 else 1e-12)
+    (cams, pts), info = opg.lm_optimize(p, state0, abs_err_tolerance=0.0, rel_err_tolerance=0.0, keep_taps=True, **kw)
+    hist = torch.stack(info.err_history, 1).numpy()
+    k = min(hist.shape[1], g["err_history"].shape[1])
+    np.testing.assert_allclose(hist[:, :k], g["err_history"][:, :k], rtol=5e-3 if f32 else 1e-7)
+    np.testing.assert_allclose(cams.numpy(), g["final_cams"], rtol=0, atol=tol * 10)
+    np.testing.assert_allclose(pts.numpy(), g["final_pts"][:, used], rtol=0, atol=tol * 100)
+    np.testing.assert_allclose(info.deltas[0].numpy(), g["delta"][0], rtol=0, atol=(1e-2 if f32 else 1e-7) * max(1.0, np.abs(g["delta"][0]).max()))
