@@ -173,3 +173,23 @@ def test_ba_multi_tile_fp32_inside_reference_band():
     rel = ((info.err_history.double() - hx).abs() / hx).max().item()
     rel_ref = ((torch.from_numpy(g["err_history"]).double() - hx).abs() / hx).max().item()
     assert rel <= 1.5 * rel_ref + 1e-5, (rel, rel_ref)
+
+
+def test_ba_full_size_matches_the_reference_run():
+    """BASELINE.json configs[3] at FULL size -- 512 SE3 cameras / 8192 Point3 (7481 observed) / 32768 robust Reprojection
+    costs, one problem, fp64 -- against the REAL reference's DenseLinearization + CholeskyDenseSolver run (dense A 20.6 GB,
+    A^T A 6.1 GB: oracle/gen_golden.py case ba_full_f64_lm): A^T b, the first linear solve, two adaptive ellipsoidal LM
+    iterations, the solution.  The reduced camera system is 3072 x 3072 (24 Cholesky tiles)."""
+    import theseus_amd as th
+    g = load_golden("ba_full_f64_lm")
+    assert int(g["C"]) == 512 and g["obs_cam"].shape[0] == 32768
+    err, solver = _ba_first_system(th, g)
+    assert solver.S.shape[-1] == 3072 and err <= 1e-7, err
+    cams, pts, used, deltas, info, _ = run_ba(th, g, None, "cuda")
+    dc = np.abs(cams.cpu().numpy() - g["final_cams"]).max()
+    dp = np.abs(pts.cpu().numpy() - g["final_pts"][:, used]).max()
+    print(f"[BA 512 cams] first solve: max |delta - reference| / |delta| = {err:.2e}; after 2 LM iterations: "
+          f"max |cam - reference| = {dc:.2e}, max |point - reference| = {dp:.2e}")
+    assert dc <= 1e-5 and dp <= 1e-5, (dc, dp)      # north_star's 1e-5, on a 27648-column problem
+    k = min(info.err_history.shape[1], g["err_history"].shape[1])
+    np.testing.assert_allclose(info.err_history[:, :k].numpy(), g["err_history"][:, :k], rtol=1e-6)

@@ -220,8 +220,10 @@ class PackedBA:
                 self._tracked_list.append(v)
         self._own_variables = all(isinstance(v, Variable) for v in self._tracked_list)
         self._stamp = None
+        self._deep_stamp = None
         self._global_stamp = -1
         self._vars_stale = False
+        self._state_exposed = False
         self._scratch = {}
 
     # ---- packing ------------------------------------------------------------------------------------------
@@ -243,12 +245,14 @@ class PackedBA:
             yield c.target
             yield from _aux_vars(c.weight)
 
-    def _current_stamp(self):
+    def _current_stamp(self, deep: bool = False):
         # the objective is frozen once an optimizer holds it (Optimizer.optimize checks its version): the walk over the cost
         # functions is done once, later stamps are one pass over the cached list (7 k variables at the headline size)
         tracked = self.__dict__.get("_tracked_list")
         if tracked is None:
             tracked = self._tracked_list = list(self._tracked())
+        if deep:  # in-place edits of a variable's tensor (see PackedPoseGraph._current_stamp)
+            return tuple([(t.data_ptr(), t._version) for t in (v.tensor for v in tracked)])
         return tuple([v._num_updates for v in tracked])
 
     @staticmethod
@@ -257,12 +261,14 @@ class PackedBA:
             return torch.stack(ts, dim=0).contiguous()
         return torch.stack([t.expand(B, *t.shape[1:]) for t in ts], dim=0).contiguous()
 
-    def sync(self, force: bool = False):
-        if (not force and self.tensors is not None and self._own_variables
+    def sync(self, force: bool = False, deep: bool = False):
+        deep = deep or not self._own_variables   # see PackedPoseGraph.sync
+        if (not force and not deep and self.tensors is not None
                 and Variable._global_updates == self._global_stamp):
             return
         stamp = self._current_stamp()
-        if not force and self.tensors is not None and stamp == self._stamp:
+        if (not force and self.tensors is not None and stamp == self._stamp
+                and (not deep or self._current_stamp(deep=True) == self._deep_stamp)):
             self._global_stamp = Variable._global_updates
             return
         self.flush_variables()
@@ -309,8 +315,19 @@ class PackedBA:
         for v, t in zip(self.pt_vars, self.tensors.points.unbind(0)):
             v.tensor = t
         self._stamp = self._current_stamp()
+        self._deep_stamp = self._current_stamp(deep=True)
         self._global_stamp = Variable._global_updates
         self._vars_stale = False
+        self._state_exposed = True
+
+    def privatize_state(self):
+        """See PackedPoseGraph.privatize_state: never recycle a state buffer the variables' tensors view."""
+        if self._state_exposed:
+            with torch.no_grad():
+                self.tensors.cams = self.tensors.cams.detach().clone()
+                self.tensors.points = self.tensors.points.detach().clone()
+            self._state_exposed = False
+            self._vars_stale = True
 
     def flush_variables(self):
         if self._vars_stale and self.tensors is not None:

@@ -148,13 +148,19 @@ class NonlinearLeastSquares(abc.ABC):
                 "Differentiating through the unrolled iterations (backward_mode='unroll') is not supported by the "
                 "HIP back end: the kernels are outside autograd.  Use backward_mode='implicit' (one backward linear "
                 "solve with the cached factor), or call under torch.no_grad().")
+        if track_state_history:
+            raise NotImplementedError("track_state_history is not supported by the HIP back end (the iterates live in two "
+                                      "recycled device buffers); use end_iter_callback to copy the states you need.")
         implicit = backward_mode == BackwardMode.IMPLICIT
         lin: HipLinearization = self.linear_solver.linearization
         packed = lin.packed
+        with torch.no_grad():
+            packed.sync(deep=True)   # once per optimize(): also catches in-place edits of the variables' tensors
         self.reset(**kwargs, backward_mode=backward_mode)
         _, loop_iters = self._split_backward_iters(backward_mode=backward_mode, **kwargs) if implicit else (0, self.params.max_iterations)
         with torch.no_grad():
             packed.sync()
+            packed.privatize_state()   # never recycle the buffer the previous optimize() handed to the user
             B = packed.batch
             dev, dt = packed.device, self.objective.dtype
             p = self.params
@@ -170,6 +176,7 @@ class NonlinearLeastSquares(abc.ABC):
             if track_best_solution:
                 best_state = packed.clone_state()
                 best_err = last_err.clone()
+                best_iter = torch.zeros(B, dtype=torch.long, device=dev)
             if verbose:
                 print(f"Nonlinear optimizer. Iteration: 0. Error: {last_err.mean().item()}")
 
@@ -184,23 +191,30 @@ class NonlinearLeastSquares(abc.ABC):
             #      (nonlinear_least_squares.py:138-152: FAIL status, variables keep their values).  That flag stays on
             #      the device (OR-ed over the shards by a stream-ordered all-reduce when the batch is sharded): once
             #      raised it freezes every later update through the retraction mask, and it is read ONCE after the loop
-            #      -- the host queues the iterations back to back and the GPU never drains. ----
+            #      -- the host queues the iterations back to back and the GPU never drains.  (Local AND sharded batches:
+            #      DistBatchReducer is a LocalBatchReducer whose device_any() all-reduces.) ----
             lazy = (isinstance(self.reducer, LocalBatchReducer) and not need_conv and end_iter_callback is None
                     and not verbose and not kwargs.get("adaptive_damping", False))
             failed = first_fail = None
             if lazy:
                 failed = torch.zeros((), dtype=torch.bool, device=dev)
                 first_fail = torch.full((), -1, dtype=torch.long, device=dev)
+            raised = None
             while lazy and it < loop_iters:
-                lin.linearize()
-                try:
-                    delta = self.compute_delta(**kwargs)
-                except RuntimeError as run_err:
-                    msg = f"There was an error while running the linear optimizer. Original error message: {run_err}."
-                    warnings.warn(msg, RuntimeWarning)
-                    info.status[:] = NonlinearOptimizerStatus.FAIL
-                    break
-                now = self.reducer.device_any(self.linear_solver.info.ne(0).any())
+                local_fail = None
+                if raised is None:
+                    lin.linearize()
+                    try:
+                        delta = self.compute_delta(**kwargs)
+                        local_fail = self.linear_solver.info.ne(0).any()
+                    except RuntimeError as run_err:
+                        # a host-side error on THIS rank: the other shards are (or will be) waiting in device_any()'s
+                        # all-reduce -- keep taking part in it with the flag raised instead of leaving the loop
+                        raised = run_err
+                if raised is not None:
+                    delta = torch.zeros(B, lin.num_cols, dtype=dt, device=dev)
+                    local_fail = torch.ones((), dtype=torch.bool, device=dev)
+                now = self.reducer.device_any(local_fail)
                 first_fail = torch.where(now & ~failed, torch.full_like(first_fail, it), first_fail)
                 failed = failed | now
                 packed.retract(delta, p.step_size, failed.to(torch.uint8).expand(B).contiguous(), spare)
@@ -213,12 +227,15 @@ class NonlinearLeastSquares(abc.ABC):
                     better = (err < best_err) & ~failed
                     packed.copy_where(better, packed.state, best_state)
                     best_err = torch.where(better, err, best_err)
+                    best_iter = torch.where(better, torch.full_like(best_iter, it), best_iter)  # nonlinear_optimizer.py:202
                 last_err = err
                 info.last_err = err
                 it += 1
                 info.iters_done = it
             if lazy and bool(failed):  # the one host sync of the loop
                 try:
+                    if raised is not None:
+                        raise raised
                     self.linear_solver.check_info()
                     raise RuntimeError("the linear solve failed on another shard of the batch")
                 except RuntimeError as run_err:
@@ -283,6 +300,7 @@ class NonlinearLeastSquares(abc.ABC):
                     better = err < best_err
                     packed.copy_where(better, packed.state, best_state)
                     best_err = torch.where(better, err, best_err)
+                    best_iter = torch.where(better, torch.full_like(best_iter, it), best_iter)  # nonlinear_optimizer.py:202
                 if verbose:
                     print(f"Nonlinear optimizer. Iteration: {it + 1}. Error: {err.mean().item()}")
                 if need_conv:
@@ -314,8 +332,12 @@ class NonlinearLeastSquares(abc.ABC):
                     better = err < best_err
                     packed.copy_where(better, X_new.detach(), best_state)
                     best_err = torch.where(better, err, best_err)
+                    best_iter = torch.where(better, torch.full_like(best_iter, it), best_iter)  # nonlinear_optimizer.py:202
                 if need_conv:
-                    converged = self._check_convergence(err, last_err)
+                    # _merge_infos (nonlinear_least_squares.py:216-263): a problem that converged in the no-grad loop stays
+                    # CONVERGED whatever the final Gauss-Newton step does
+                    last_step = self._check_convergence(err, last_err)
+                    converged = last_step if converged is None else (converged | last_step)
                     conv_iter = torch.where(converged & (conv_iter < 0), torch.full_like(conv_iter, it + 1), conv_iter)
                 last_err = err
                 info.last_err = err
@@ -336,6 +358,7 @@ class NonlinearLeastSquares(abc.ABC):
                 info.err_history = err_hist.cpu()
             if track_best_solution:
                 info.best_err = best_err
+                info.best_iter = best_iter.cpu()
                 info.best_solution = packed.solution_dict(best_state)
         return info
 

@@ -132,8 +132,10 @@ class PackedPoseGraph:
         # the O(1) "nothing changed" test relies on theseus_amd.core.Variable's global update counter
         self._own_variables = all(isinstance(v, Variable) for v in self._tracked())
         self._stamp = None
+        self._deep_stamp = None
         self._global_stamp = -1
         self._vars_stale = False
+        self._state_exposed = False
         self._scratch = {}
 
     # ---- packing ----------------------------------------------------------------------------
@@ -150,12 +152,17 @@ class PackedPoseGraph:
             if r is not None:
                 yield r
 
-    def _current_stamp(self):
+    def _current_stamp(self, deep: bool = False):
         # the objective is frozen once an optimizer holds it (Optimizer.optimize checks its version): the walk over the cost
         # functions is done once, later stamps are one pass over the cached list (7 k variables at the headline size)
         tracked = self.__dict__.get("_tracked_list")
         if tracked is None:
             tracked = self._tracked_list = list(self._tracked())
+        if deep:
+            # storage identity + autograd version counter: catches IN-PLACE edits of a variable's tensor that never go
+            # through Variable.update() (an nn.Parameter stepped by a torch optimizer, ``var.tensor.mul_()``) -- the reference
+            # re-reads ``var.tensor`` at every evaluation (core/objective.py:813-830) and sees those
+            return tuple([(t.data_ptr(), t._version) for t in (v.tensor for v in tracked)])
         return tuple([v._num_updates for v in tracked])
 
     @staticmethod
@@ -167,13 +174,18 @@ class PackedPoseGraph:
             return torch.stack(ts, dim=0).contiguous()
         return torch.stack([t.expand(B, *t.shape[1:]) for t in ts], dim=0).contiguous()
 
-    def sync(self, force: bool = False):
-        """(Re)pack the variable tensors into the device buffers if any variable changed."""
-        if (not force and self.tensors is not None and self._own_variables
+    def sync(self, force: bool = False, deep: bool = False):
+        """(Re)pack the variable tensors into the device buffers if any variable changed.  ``deep`` also looks for in-place
+        edits of the variables' tensors (storage pointer + version counter): the optimizers ask for it once per
+        ``optimize()``, the inner-loop calls keep the O(1) test; with the reference's own Variable class (theseus_amd/
+        plugin.py) every call is deep -- there is no global update counter to lean on."""
+        deep = deep or not self._own_variables
+        if (not force and not deep and self.tensors is not None
                 and Variable._global_updates == self._global_stamp):
             return  # nobody called Variable.update()/to() since the last look: O(1) fast path
         stamp = self._current_stamp()
-        if not force and self.tensors is not None and stamp == self._stamp:
+        if (not force and self.tensors is not None and stamp == self._stamp
+                and (not deep or self._current_stamp(deep=True) == self._deep_stamp)):
             self._global_stamp = Variable._global_updates
             return
         self.flush_variables()
@@ -205,8 +217,21 @@ class PackedPoseGraph:
             for v, t in zip(self.pose_vars, poses.unbind(0)):  # one call builds all the views
                 v.tensor = t
         self._stamp = self._current_stamp()
+        self._deep_stamp = self._current_stamp(deep=True)
         self._global_stamp = Variable._global_updates
         self._vars_stale = False
+        self._state_exposed = True   # the variables (and whoever holds their tensors) now view the state buffer
+
+    def privatize_state(self):
+        """Called at the start of ``optimize()``: if the state buffer is the one the variables' tensors view (i.e. what the
+        previous ``optimize()`` / ``forward()`` handed to the user, possibly carrying an autograd graph), continue on a
+        private copy -- the loop recycles its two state buffers through raw-pointer kernels and must never write into a
+        tensor somebody else holds."""
+        if self._state_exposed:
+            with torch.no_grad():
+                self.tensors.poses = self.tensors.poses.detach().clone()
+            self._state_exposed = False
+            self._vars_stale = True
 
     def set_poses(self, poses: torch.Tensor, repoint: bool = True):
         """Adopt a new packed pose buffer (after an accepted LM step).  ``repoint=False`` defers the
