@@ -14,7 +14,10 @@
  *   - `dtype`: 0 = float32, 1 = float64 (arithmetic and storage type of every floating buffer);
  *   - `stream`: a hipStream_t (pass torch.cuda.current_stream().cuda_stream); nothing synchronises;
  *   - return value: 0 on success, negative on a bad argument or launch error
- *     (thx_last_error() gives the text); no global state besides that thread-local string;
+ *     (thx_last_error() gives the text); no global state besides that thread-local string and, per device, the
+ *     launch-side state of the dense solver (raised dynamic-LDS limits, the auxiliary stream + events of
+ *     thx_chol_factor's two-stream schedule): the entry points act on the CURRENT device (hipGetDevice), may be called
+ *     for several devices and from several threads (thx_chol_* enqueues are serialised by a mutex);
  *   - batch layouts are "entity major": poses (P, B, 3, 4), measurements (E, Bm, 3, 4) with Bm in
  *     {1, B}; `*_bstride` is the element stride between consecutive batch items (12 / 6, or 0 when
  *     the tensor is shared by the whole batch);

@@ -67,9 +67,13 @@ class OracleKernels:
         p, x = self._problem(s, t, poses)
         a, b, e, ap, e2 = opg.cost_terms(p, x)
         if p.edges.shape[0]:
-            J0.copy_(a.transpose(0, 1)); J1.copy_(b.transpose(0, 1)); eb.copy_(e.transpose(0, 1))
+            eb.copy_(e.transpose(0, 1))
+            if J0 is not None:
+                J0.copy_(a.transpose(0, 1)); J1.copy_(b.transpose(0, 1))
         if p.prior_idx.shape[0]:
-            Jp.copy_(ap.transpose(0, 1)); ep.copy_(e2.transpose(0, 1))
+            ep.copy_(e2.transpose(0, 1))
+            if Jp is not None:
+                Jp.copy_(ap.transpose(0, 1))
 
     def se3_retract(self, poses, delta, step, ignore_mask, out):
         x = poses.transpose(0, 1)

@@ -1,0 +1,117 @@
+"""Host-side state handling of the packed representation and the LM loop (-m "not gpu", TEST stand-in kernels):
+in-place edits of variable tensors are seen, result buffers handed to the user are never recycled, Info bookkeeping."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import golden_problem, load_golden
+
+
+def _layer(name="pg_f64_lm", iters=4, **okw):
+    import theseus_amd as th
+    from tests.oracle_kernels import OracleKernels
+    from tests.test_gpu_lm import build_objective
+    g = load_golden(name)
+    obj, poses = build_objective(th, g, device="cpu")
+    opt = th.LevenbergMarquardt(obj, linearization_kwargs=dict(kernels=OracleKernels()), max_iterations=iters,
+                                abs_err_tolerance=0.0, rel_err_tolerance=0.0, **okw)
+    return th, g, obj, opt, th.TheseusLayer(opt)
+
+
+def test_in_place_edit_of_an_auxiliary_tensor_is_seen():
+    """A cost weight held by a Variable and scaled IN PLACE (what a torch optimizer does to an nn.Parameter) must change the
+    next forward(): the reference re-reads var.tensor at every evaluation (core/objective.py:813-830)."""
+    th, g, obj, opt, layer = _layer(iters=1)
+    w_vars = [c.weight.diagonal for c in obj.cost_functions.values() if hasattr(c.weight, "diagonal")]
+    start = {k: v.tensor.clone() for k, v in obj.optim_vars.items()}
+    _, info1 = layer.forward(None, optimizer_kwargs=dict(track_err_history=True, damping=1e-3))
+    with torch.no_grad():
+        for w in w_vars:
+            w.tensor.mul_(3.0)          # no Variable.update(): only the tensor's version counter moves
+    _, info2 = layer.forward(start, optimizer_kwargs=dict(track_err_history=True, damping=1e-3))
+    e1, e2 = info1.err_history[:, 0], info2.err_history[:, 0]
+    assert (e2 > 5.0 * e1).all(), (e1, e2)   # Between errors carry w^2 = 9x; the priors keep theirs
+
+
+def test_in_place_edit_without_any_update_is_seen():
+    th, g, obj, opt, layer = _layer(iters=1)
+    layer.forward(None, optimizer_kwargs=dict(damping=1e-3))
+    packed = opt.linear_solver.linearization.packed
+    e0 = packed.error_metric().clone()
+    with torch.no_grad():
+        for c in obj.cost_functions.values():
+            if hasattr(c.weight, "diagonal"):
+                c.weight.diagonal.tensor.mul_(2.0)
+    info = opt.optimize(track_err_history=True, damping=1e-3)   # nobody called update(): the deep stamp must catch it
+    assert (info.err_history[:, 0] > 2.0 * e0).all()
+
+
+def test_a_second_forward_does_not_overwrite_the_first_solution():
+    th, g, obj, opt, layer = _layer(iters=4)
+    sol1, _ = layer.forward(None, optimizer_kwargs=dict(damping=1e-3))
+    keep = {k: v.clone() for k, v in sol1.items()}
+    sol2, _ = layer.forward(None, optimizer_kwargs=dict(damping=1e-3))   # continues from sol1, no update() in between
+    for k in keep:
+        assert torch.equal(sol1[k], keep[k]), k                           # sol1's tensors were not used as scratch
+    assert any(not torch.equal(sol2[k], keep[k]) for k in keep)
+
+
+def test_best_iter_and_state_history():
+    th, g, obj, opt, layer = _layer("pg_f64_lm_adaptive_rejects", iters=6)
+    _, kw_ = None, None
+    _, _, kw = golden_problem(g)
+    kw = {k: v for k, v in kw.items() if k not in ("gauss_newton", "max_iterations", "step_size")}
+    _, info = layer.forward(None, optimizer_kwargs=dict(track_best_solution=True, track_err_history=True, **kw))
+    h = info.err_history[:, :info.iters_done + 1]
+    # nonlinear_optimizer.py:200-202: best_iter = index of the iteration whose error first reached the minimum (0 if never improved)
+    for b in range(h.shape[0]):
+        best, bi = h[b, 0].item(), 0
+        for it in range(info.iters_done):
+            if h[b, it + 1].item() < best:
+                best, bi = h[b, it + 1].item(), it
+        assert int(info.best_iter[b]) == bi
+        assert float(info.best_err[b]) == pytest.approx(best)
+    with pytest.raises(NotImplementedError):
+        layer.forward(None, optimizer_kwargs=dict(track_state_history=True, **kw))
+
+
+def test_global_params_mirror():
+    """theseus_amd.set_global_params takes the reference's option names (theseus/global_params.py:46-80,
+    torchlie/global_params.py:44-68) for the thresholds this path reads; fast_approx_local_jacobians is refused loudly."""
+    import theseus_amd as th
+    import theseus_amd.kernels as tk
+    try:
+        th.set_global_params({"so3_near_zero_eps_float32": 0.5, "so3_d_near_zero_eps_float64": 0.25, "se2_d_near_zero_eps_float32": 0.75})
+        assert tk.lie_eps(torch.float32).near_zero == 0.5 and tk.lie_eps(torch.float64).d_near_zero == 0.25
+        assert tk.se2_eps(torch.float32).d_near_zero == 0.75 and tk.lie_eps(torch.float32).near_pi == 1e-2
+        with pytest.raises(ValueError):
+            th.set_global_params({"so3_quat_eps_float32": 1.0})     # a reference option this path never reads
+        th.set_global_params({"fast_approx_local_jacobians": True})
+        with pytest.raises(NotImplementedError, match="fast_approx_local_jacobians"):
+            _layer()
+    finally:
+        th.reset_global_params()
+    assert tk.lie_eps(torch.float32).near_zero == 1e-2 and not tk.fast_approx_local_jacobians()
+    _layer()
+
+
+def test_check_singular_zeroes_the_singular_items():
+    import theseus_amd as th
+    from tests.oracle_kernels import OracleKernels
+    from tests.test_gpu_lm import build_objective
+    g = dict(load_golden("pg_f64_lm_adaptive_ellips"))     # batched DiagonalCostWeights
+    B = g["poses0"].shape[0]
+    g["w_between"] = g["w_between"].copy()
+    g["w_prior"] = np.repeat(g["w_prior"], B, axis=0).copy()
+    g["w_between"][2] = 0.0
+    g["w_prior"][2] = 0.0
+    obj, _ = build_objective(th, g, device="cpu")
+    solver = th.HipCholeskySolver(obj, linearization_kwargs=dict(kernels=OracleKernels()), check_singular=True)
+    obj.update()
+    solver.linearization.linearize()
+    with pytest.warns(RuntimeWarning, match="Singular matrix found in batch"):
+        delta = solver.solve(damping=0.1, ellipsoidal_damping=False)
+    assert (delta[2] == 0).all() and all((delta[b] != 0).any() for b in (0, 1, 3))
+    plain = th.HipCholeskySolver(obj, linearization_kwargs=dict(kernels=OracleKernels()))
+    plain.linearization.linearize()
+    np.testing.assert_allclose(plain.solve(damping=0.1, ellipsoidal_damping=False)[[0, 1, 3]].numpy(), delta[[0, 1, 3]].numpy())

@@ -280,3 +280,160 @@ def test_reference_loop_drives_the_bundle_adjustment_plugin(ref, name):
     np.testing.assert_allclose(pts, g["final_pts"][:, used], rtol=0, atol=1e-5)
     k = min(info.err_history.shape[1], g["err_history"].shape[1])
     np.testing.assert_allclose(info.err_history[:, :k].numpy(), g["err_history"][:, :k], rtol=1e-6)
+
+
+# ---- the third hook set (Objective vectorization callbacks) -------------------------------------------------
+def _counting(standin, names):
+    calls = {n: 0 for n in names}
+    for name in names:
+        def spy(*a, _f=getattr(standin, name), _n=name, **k):
+            calls[_n] += 1
+            return _f(*a, **k)
+        setattr(standin, name, spy)
+    return calls
+
+
+@pytest.mark.parametrize("name", ["pg_f64_lm_adaptive_rejects", "pg2_f64_lm"])
+def test_objective_hooks_keep_the_reference_loop_off_aten(ref, name):
+    """With theseus_amd.plugin the REAL loop's retract_vars_sequence / error_metric / update go through the kernels: the
+    reference's vectorized torch Jacobian pass (Vectorize._vectorize, run by every Objective.update) never runs, its torch
+    retraction never runs, and the trajectory is still the recorded one."""
+    th, thp = ref
+    from tests.oracle_kernels import OracleKernels
+    g = load_golden(name)
+    _, _, kw = golden_problem(g)
+    obj, poses = _objective(th, g)
+    kw.pop("gauss_newton", False)
+    standin = OracleKernels()
+    calls = _counting(standin, ["pg_assemble", "retract", "pg_jacobians", "chol_factor"])
+    opt = th.LevenbergMarquardt(obj, linear_solver_cls=thp.HipCholeskySolver, linearization_kwargs=dict(kernels=standin),
+                                vectorize=True, abs_err_tolerance=0.0, rel_err_tolerance=0.0,
+                                max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"))
+    hooks = opt.linear_solver.linearization.hooks
+    assert hooks is not None and obj.vectorized and obj._retract_method == hooks.retract
+    ref_calls = {"run": 0, "retract": 0, "err_iter": 0}
+    for key in ref_calls:
+        def spy(*a, _f=hooks.ref[key], _k=key, **k):
+            ref_calls[_k] += 1
+            return _f(*a, **k)
+        hooks.ref[key] = spy
+    with torch.no_grad():
+        info = opt.optimize(track_err_history=True, **kw)
+    assert ref_calls == {"run": 0, "retract": 0, "err_iter": 0}, ref_calls
+    solves = calls["chol_factor"]
+    assert calls["pg_assemble"] == solves and calls["retract"] == solves and calls["pg_jacobians"] >= solves
+    final = torch.stack([p.tensor for p in poses], 1).numpy()
+    from tests.test_gpu_lm import well_conditioned_steps
+    ok = well_conditioned_steps(g, g["delta"].shape[0])
+    slack = 2.0 * (np.abs(g["delta"]).max(axis=2) * ~ok).sum(axis=0)
+    assert (np.abs(final - g["final"]).reshape(final.shape[0], -1).max(1) <= 5e-8 + slack).all()
+    k = min(info.err_history.shape[1], g["err_history"].shape[1])
+    np.testing.assert_allclose(info.err_history[:, :k].numpy(), g["err_history"][:, :k], rtol=2e-5)
+    # Objective.error() / error_metric() as a user calls them: the (B, m) weighted error vector in cost add order
+    ref_obj, _ = _objective(th, g)
+    ref_obj.update({p.name: p.tensor for p in poses})
+    np.testing.assert_allclose(obj.error().numpy(), ref_obj.error().numpy(), rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(obj.error_metric().numpy(), ref_obj.error_metric().numpy(), rtol=1e-10)
+    # somebody else's Linearization on the hooked objective is served Jacobians through the reference's own wrappers
+    other = th.optimizer.DenseLinearization(obj)
+    other.linearize()
+    mine = opt.linear_solver.linearization
+    mine.linearize()
+    np.testing.assert_allclose(other.AtA.numpy(), mine.AtA.numpy(), rtol=1e-9, atol=1e-9)
+    # disable_vectorization() (objective.py:945-951) takes the hooks out again
+    obj.disable_vectorization()
+    assert not obj.vectorized and obj._retract_method == th.Objective._retract_base
+
+
+def test_hooks_can_be_left_out(ref):
+    th, thp = ref
+    from tests.oracle_kernels import OracleKernels
+    g = load_golden("pg_f64_lm")
+    obj, poses = _objective(th, g)
+    opt = th.LevenbergMarquardt(obj, linear_solver_cls=thp.HipCholeskySolver, vectorize=True, max_iterations=6,
+                                linearization_kwargs=dict(kernels=OracleKernels(), objective_hooks=False),
+                                abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    assert opt.linear_solver.linearization.hooks is None and type(obj._vectorization_run.__self__).__name__ == "Vectorize"
+    with torch.no_grad():
+        opt.optimize(damping=1e-3)
+    np.testing.assert_allclose(torch.stack([p.tensor for p in poses], 1).numpy(), g["final"], rtol=0, atol=5e-8)
+
+
+# ---- the reference's knobs ----------------------------------------------------------------------------------------------------
+def test_global_params_of_the_reference_reach_the_kernels(ref):
+    """torchlie.set_global_params / theseus.set_global_params (torchlie/global_params.py:61-68, theseus/global_params.py:
+    63-80) are read at every launch once the plugin is imported."""
+    th, thp = ref
+    import torchlie
+    import theseus_amd.kernels as tk
+    try:
+        torchlie.set_global_params({"so3_near_zero_eps_float64": 0.25, "so3_near_pi_eps_float32": 0.5})
+        th.set_global_params({"se2_near_zero_eps_float64": 0.125})
+        e = tk.lie_eps(torch.float64)
+        assert (e.near_zero, e.d_near_zero, e.near_pi) == (0.25, 1e-2, 1e-7)
+        assert tk.lie_eps(torch.float32).near_pi == 0.5 and tk.se2_eps(torch.float64).near_zero == 0.125
+    finally:
+        torchlie.reset_global_params()
+        th.global_params._THESEUS_GLOBAL_PARAMS.reset()
+    assert tk.lie_eps(torch.float64).near_zero == 5e-3 and tk.se2_eps(torch.float64).near_zero == 1e-6
+    # a threshold change moves the result exactly as it moves the reference's: force the Taylor branch of log everywhere
+    from tests.oracle_kernels import OracleKernels  # noqa: F401  (the stand-in reads oracle.lie.EPS, not these: host-side check only)
+
+
+def test_fast_approx_local_jacobians_is_honoured_through_the_generic_path(ref):
+    """theseus/embodied/misc/local_cost_fn.py:43-57.  Set before construction: the plugin takes the generic block path, where
+    the reference evaluates its own (identity) Jacobians; toggled afterwards on a fused linearization: a loud error."""
+    th, thp = ref
+    from tests.oracle_kernels import OracleKernels
+    g = load_golden("pg_f64_lm")
+    try:
+        th.set_global_params({"fast_approx_local_jacobians": True})
+        obj, _ = _objective(th, g)
+        lin = thp.HipLinearization(obj, kernels=OracleKernels())
+        assert not lin.fused
+        lin.linearize()
+        ref_lin = th.optimizer.DenseLinearization(obj)
+        ref_lin.linearize()
+        np.testing.assert_allclose(lin.AtA.numpy(), ref_lin.AtA.numpy(), rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(lin.Atb.numpy(), ref_lin.Atb.numpy(), rtol=1e-10, atol=1e-9)
+        th.set_global_params({"fast_approx_local_jacobians": False})
+        exact = th.optimizer.DenseLinearization(obj)
+        exact.linearize()
+        assert not np.allclose(exact.AtA.numpy(), ref_lin.AtA.numpy(), rtol=1e-6)   # the option does change the Hessian
+        obj2, _ = _objective(th, g)
+        fused = thp.HipLinearization(obj2, kernels=OracleKernels())
+        assert fused.fused
+        th.set_global_params({"fast_approx_local_jacobians": True})
+        with pytest.raises(NotImplementedError, match="fast_approx_local_jacobians"):
+            fused.linearize()
+    finally:
+        th.global_params._THESEUS_GLOBAL_PARAMS.reset()
+
+
+def test_check_singular_matches_the_reference(ref):
+    """dense_solver.py:91-114: batch items whose (undamped) AtA is singular get an all-zero step and a RuntimeWarning, the
+    others are solved."""
+    th, thp = ref
+    from tests.oracle_kernels import OracleKernels
+    # fp32: the reference's check_singular path only runs in fp32 (its output buffer is torch.zeros(...) of the default dtype,
+    # dense_solver.py:95, and the index_put of an fp64 solution into it raises)
+    g = dict(load_golden("pg_f32_lm"))
+    B = g["poses0"].shape[0]
+    g["w_between"] = np.repeat(g["w_between"], B, axis=0).copy()
+    g["w_prior"] = np.repeat(g["w_prior"], B, axis=0).copy()
+    g["w_between"][1] = 0.0          # item 1: every cost weight zero -> A = 0 -> singular AtA
+    g["w_prior"][1] = 0.0
+    out = {}
+    for tag in ("ref", "ours"):
+        obj, _ = _objective(th, g)
+        if tag == "ref":
+            solver = th.CholeskyDenseSolver(obj, check_singular=True)
+        else:
+            solver = thp.HipCholeskySolver(obj, linearization_kwargs=dict(kernels=OracleKernels()), check_singular=True)
+        solver.linearization.linearize()
+        with pytest.warns(RuntimeWarning, match="Singular matrix found in batch"):
+            out[tag] = solver.solve(damping=0.1, ellipsoidal_damping=False).double()
+    assert (out["ours"][1] == 0).all() and (out["ref"][1] == 0).all()
+    good = [0, 2]
+    np.testing.assert_allclose(out["ours"][good].numpy(), out["ref"][good].numpy(), rtol=0,
+                               atol=2e-3 * np.abs(out["ref"][good].numpy()).max())

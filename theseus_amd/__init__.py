@@ -6,7 +6,8 @@ hand-written HIP kernels behind a C ABI (include/theseus_hip.h, theseus_amd/csrc
 from .core import (Between, CostFunction, CostWeight, DiagonalCostWeight, Difference, HuberLoss, Local,  # noqa: F401
                    Objective, Point2, Point3, Reprojection, RobustCostFunction, RobustLoss, ScaleCostWeight, SE2, SE3,
                    Variable, Vector, WelschLoss)
-from .kernels import HipKernels, default_kernels, set_lie_eps, set_se2_eps  # noqa: F401
+from .kernels import (HipKernels, default_kernels, reset_global_params, set_global_params, set_lie_eps,  # noqa: F401
+                      set_se2_eps)
 from .layer import TheseusLayer  # noqa: F401
 from .linear_solver import HipCholeskySolver, LinearSolver  # noqa: F401
 from .linearization import HipLinearization, Linearization, VariableOrdering  # noqa: F401

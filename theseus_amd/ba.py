@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from .core import Objective, Variable
-from .kernels import default_kernels, round_up
+from .kernels import default_kernels, fast_approx_local_jacobians, round_up
 from .linear_solver import LinearSolver
 from .linearization import Linearization, VariableOrdering
 from .packed import UnsupportedObjective, _aux_vars, _kind, _unwrap_robust, _weight_diag
@@ -207,6 +207,7 @@ class PackedBA:
         if len(kinds) > 1:
             raise UnsupportedObjective("HIP bundle adjustment: all Reprojection costs must share one robust loss kind.")
         self.robust_obs = kinds.pop() if kinds else _lib.LOSS_NONE
+        self._refuse_fast_approx(UnsupportedObjective)
         self.structure = BAStructure(len(self.cam_vars), len(self.pt_vars), obs_cam, obs_pt, cpc, ppp)
         self.n = self.structure.n
         self.nc = 6 * len(self.cam_vars)
@@ -225,6 +226,12 @@ class PackedBA:
         self._vars_stale = False
         self._state_exposed = False
         self._scratch = {}
+
+    def _refuse_fast_approx(self, exc=NotImplementedError):
+        """See PackedPoseGraph._refuse_fast_approx (the SE3 camera priors would silently get their exact Jacobian)."""
+        if self.cam_prior_costs and fast_approx_local_jacobians():
+            raise exc("HIP bundle adjustment: the global option fast_approx_local_jacobians=True is not fused into the "
+                      "kernels (camera Difference/Local costs); there is no CPU/eager fallback.")
 
     # ---- packing ------------------------------------------------------------------------------------------
     def _tracked(self):
@@ -456,6 +463,7 @@ class HipSchurLinearizationCore:
     def _assemble(self):
         self._ensure_buffers()
         p = self.packed
+        p._refuse_fast_approx()
         self.K.ba_assemble(p.dstruct, p.tensors, self.Hcc, self.Hpp, self.W, self.gd, self.g, self.diag)
 
     def _linearize_jacobian_impl(self):

@@ -34,6 +34,7 @@
 #include "common.cuh"
 
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -1618,25 +1619,44 @@ lm_accept_kernel(const T* __restrict__ delta, const T* __restrict__ g, int64_t l
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
+// Launch-side state is kept PER DEVICE (a process may drive several GPUs, from several threads): the dynamic-LDS limits
+// raised with hipFuncSetAttribute, and the auxiliary stream + events of the two-stream schedule, which belong to the device
+// they were created on.
+constexpr int MAX_DEVICES = 64;
+struct DeviceLaunchState {
+  size_t attr_diag[2] = {0, 0}, attr_solve[2] = {0, 0};   // [0] float, [1] double
+  bool attr_off = false;
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_lag = nullptr, ev_join = nullptr;
+};
+static std::mutex g_launch_mutex;
+static DeviceLaunchState& launch_state() {
+  static DeviceLaunchState st[MAX_DEVICES];
+  int dev = 0;
+  hipGetDevice(&dev);
+  return st[(dev >= 0 && dev < MAX_DEVICES) ? dev : 0];
+}
+
 template <typename T>
 static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damping, int ellipsoidal, double eps,
                        void* L, void* panel, int32_t* info, const void* rhs, void* y, int64_t ldv, hipStream_t st) {
   const int ntiles = (n + TILE - 1) / TILE;
   const size_t dsm = DiagSmem<T>::bytes(rhs ? ntiles * TILE : 0);
   if (dsm > LDS_LIMIT) return fail("thx_chol_factor: n too large for the fused forward substitution (LDS)");
-  static size_t attr_diag = 0;
-  static bool attr_off = false;
-  if (dsm > attr_diag) {
+  std::lock_guard<std::mutex> guard(g_launch_mutex);   // (the whole enqueue: the auxiliary stream / events are shared)
+  DeviceLaunchState& ds = launch_state();
+  constexpr int ti = sizeof(T) == 8;
+  if (dsm > ds.attr_diag[ti]) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)dsm);
-    attr_diag = dsm;
+    ds.attr_diag[ti] = dsm;
   }
-  if (!attr_off) {
+  if (!ds.attr_off) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f32_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF32_SMEM);
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
-    attr_off = true;
+    ds.attr_off = true;
   }
   hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)B, st);
   // One half of the batch per stream, the second half one diagonal phase behind the first: the latency-bound serial part
@@ -1648,8 +1668,8 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     hipStream_t s;
     int b0, nb;
   };
-  static hipStream_t aux = nullptr;
-  static hipEvent_t ev_fork = nullptr, ev_lag = nullptr, ev_join = nullptr;
+  hipStream_t& aux = ds.aux;
+  hipEvent_t &ev_fork = ds.ev_fork, &ev_lag = ds.ev_lag, &ev_join = ds.ev_join;
   static const int split_min = [] {
     const char* e = getenv("THX_CHOL_SPLIT_MIN");  // batch size from which the two-stream schedule is used (0: never)
     return e ? atoi(e) : 1024;
@@ -1708,13 +1728,16 @@ static int solve_impl(const void* L, int64_t ld, int n, int B, const void* panel
   const int ntiles = (n + TILE - 1) / TILE;
   const size_t sm = solve_smem<T>(ntiles * TILE);
   if (sm > LDS_LIMIT) return fail("thx_chol_solve: n too large for the LDS plan");
-  static size_t attr = 0;
-  if (sm > attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)sm);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_bwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)sm);
-    attr = sm;
+  {
+    std::lock_guard<std::mutex> guard(g_launch_mutex);
+    size_t& attr = launch_state().attr_solve[sizeof(T) == 8];
+    if (sm > attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)sm);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(chol_bwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)sm);
+      attr = sm;
+    }
   }
   const T* src = (const T*)rhs;
   if (forward) {

@@ -12,44 +12,100 @@ import torch
 from . import _lib
 from .compiler import DeviceStructure
 
-# torchlie/torchlie/global_params.py:44-58 (defaults); runtime settable through set_lie_eps
+# ---- Taylor-switch thresholds and the one behavioural switch of the reference's global parameters ------------------------
+# torchlie/torchlie/global_params.py:44-58 and theseus/global_params.py:46-80 (defaults).  They are read AT EVERY LAUNCH:
+#   * stand-alone (this package's own mirror classes): from the tables below, set through ``set_global_params`` with the
+#     reference's option names (``so3_near_zero_eps_float32`` ..., ``se2_near_zero_eps_float64`` ..., ``fast_approx_local_jacobians``);
+#   * plugged into the real ``theseus`` (theseus_amd/plugin.py): from the reference's own ``_THESEUS_GLOBAL_PARAMS`` /
+#     ``_TORCHLIE_GLOBAL_PARAMS`` objects (``use_reference_global_params``), so that ``torchlie.set_global_params`` /
+#     ``theseus.set_global_params`` calls made by the user apply to the HIP kernels too.
 _LIE_EPS = {
     torch.float32: dict(near_zero=1e-2, d_near_zero=2e-1, near_pi=1e-2),
     torch.float64: dict(near_zero=5e-3, d_near_zero=1e-2, near_pi=1e-7),
 }
+_SE2_EPS = {
+    torch.float32: dict(near_zero=3e-2, d_near_zero=1e-1),
+    torch.float64: dict(near_zero=1e-6, d_near_zero=1e-3),
+}
+_FLAGS = dict(fast_approx_local_jacobians=False)
+_REFERENCE_PARAMS = None   # the reference's _THESEUS_GLOBAL_PARAMS (its get_eps falls through to torchlie's for so3_*)
+
+
+def use_reference_global_params(theseus_params) -> None:
+    global _REFERENCE_PARAMS
+    _REFERENCE_PARAMS = theseus_params
+
+
+def _option(key: str):
+    """'so3_d_near_zero_eps_float32' -> (table, dtype, 'd_near_zero')."""
+    for group, table in (("so3", _LIE_EPS), ("se2", _SE2_EPS)):
+        for dt, tag in ((torch.float32, "float32"), (torch.float64, "float64")):
+            if key.startswith(group + "_") and key.endswith("_eps_" + tag):
+                attr = key[len(group) + 1:-len("_eps_" + tag)]
+                if attr in table[dt]:
+                    return table, dt, attr
+    return None
+
+
+def set_global_params(options) -> None:
+    """Mirror of ``theseus.set_global_params`` + ``torchlie.set_global_params`` for the options this path reads."""
+    for k, v in options.items():
+        if k in _FLAGS:
+            _FLAGS[k] = bool(v)
+            continue
+        hit = _option(k)
+        if hit is None:
+            raise ValueError(f"{k} is not a valid global option for theseus_amd (this path reads the so3_* / se2_* "
+                             f"near_zero / d_near_zero / near_pi thresholds and fast_approx_local_jacobians).")
+        table, dt, attr = hit
+        table[dt][attr] = float(v)
+
+
+def reset_global_params() -> None:
+    _LIE_EPS[torch.float32].update(near_zero=1e-2, d_near_zero=2e-1, near_pi=1e-2)
+    _LIE_EPS[torch.float64].update(near_zero=5e-3, d_near_zero=1e-2, near_pi=1e-7)
+    _SE2_EPS[torch.float32].update(near_zero=3e-2, d_near_zero=1e-1)
+    _SE2_EPS[torch.float64].update(near_zero=1e-6, d_near_zero=1e-3)
+    _FLAGS["fast_approx_local_jacobians"] = False
 
 
 def set_lie_eps(dtype, **kw):
-    """Mirror of torchlie.set_global_params for the three thresholds the kernels use."""
+    """Short form of set_global_params for the three so3 thresholds."""
     for k, v in kw.items():
         if k not in _LIE_EPS[dtype]:
             raise KeyError(k)
         _LIE_EPS[dtype][k] = float(v)
 
 
-def lie_eps(dtype) -> _lib.LieEps:
-    e = _LIE_EPS[dtype]
-    return _lib.LieEps(e["near_zero"], e["d_near_zero"], e["near_pi"])
-
-
-# theseus/global_params.py:46-59 (se2 thresholds; the SE2 class is theseus' own, not torchlie's)
-_SE2_EPS = {
-    torch.float32: dict(near_zero=3e-2, d_near_zero=1e-1),
-    torch.float64: dict(near_zero=1e-6, d_near_zero=1e-3),
-}
-
-
 def set_se2_eps(dtype, **kw):
-    """Mirror of theseus.set_global_params for se2_near_zero_eps / se2_d_near_zero_eps."""
+    """Short form of set_global_params for se2_near_zero_eps / se2_d_near_zero_eps."""
     for k, v in kw.items():
         if k not in _SE2_EPS[dtype]:
             raise KeyError(k)
         _SE2_EPS[dtype][k] = float(v)
 
 
+def lie_eps(dtype) -> _lib.LieEps:
+    r = _REFERENCE_PARAMS
+    if r is not None:
+        return _lib.LieEps(r.get_eps("so3", "near_zero", dtype), r.get_eps("so3", "d_near_zero", dtype),
+                           r.get_eps("so3", "near_pi", dtype))
+    e = _LIE_EPS[dtype]
+    return _lib.LieEps(e["near_zero"], e["d_near_zero"], e["near_pi"])
+
+
 def se2_eps(dtype) -> _lib.SE2Eps:
+    r = _REFERENCE_PARAMS
+    if r is not None:
+        return _lib.SE2Eps(r.get_eps("se2", "near_zero", dtype), r.get_eps("se2", "d_near_zero", dtype))
     e = _SE2_EPS[dtype]
     return _lib.SE2Eps(e["near_zero"], e["d_near_zero"])
+
+
+def fast_approx_local_jacobians() -> bool:
+    """theseus/embodied/misc/local_cost_fn.py:43-57: Local/Difference costs then use the identity as their Jacobian."""
+    r = _REFERENCE_PARAMS
+    return bool(r.fast_approx_local_jacobians) if r is not None else _FLAGS["fast_approx_local_jacobians"]
 
 
 def round_up(x, m):

@@ -7,6 +7,7 @@ ABC contract: theseus/optimizer/linear/linear_solver.py:15-37.  ``HipCholeskySol
 solves; a non positive-definite system raises ``RuntimeError`` like ``torch.linalg.cholesky`` does.
 """
 import abc
+import warnings
 from typing import Any, Dict, Optional, Type, Union
 
 import torch
@@ -90,12 +91,27 @@ class HipCholeskyCore:
                 f"input is not positive-definite (the leading minor of order {int(self.info[b])} is not "
                 "positive-definite).")
 
+    def singular_mask(self) -> torch.Tensor:
+        """(B,) bool -- ``check_singular=True`` (dense_solver.py:91-103): the reference runs ``torch.lu`` on the UNDAMPED
+        ``AtA`` and drops the batch items whose factorisation hits an exactly zero pivot.  For ``AtA = A^T A`` that is the
+        case of an all-zero column of ``A`` (a variable every cost of which has zero weight): a zero on the diagonal of
+        ``AtA``.  Rank deficiency that leaves a non-zero rounding residue (a gauge freedom) passes the reference's LU test
+        too, and is solved here as it is there."""
+        return (self.linearization.diagonal() == 0).any(dim=1)
+
     def _solve(self, damping, ellipsoidal_damping, damping_eps, check_info) -> torch.Tensor:
         if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
             raise ValueError("Damping must be a float or a 1-D tensor.")
         y = self.factorize(damping, ellipsoidal_damping, damping_eps, rhs=self.linearization.g)
         delta = torch.empty_like(y)
         self.K.chol_solve_backward(self.L, self.linearization.n, self.panels, y, delta)
+        if getattr(self, "_check_singular", False):
+            singular = self.singular_mask()
+            if bool(singular.any()):   # (one host sync, as the reference's ``good_idx.all()``)
+                warnings.warn("Singular matrix found in batch, solution will be set to all 0 for all singular matrices.",
+                              RuntimeWarning)
+                delta.masked_fill_(singular.unsqueeze(1), 0.0)
+                self.info.masked_fill_(singular, 0)   # a dropped item is not a failed solve
         if check_info:
             self.check_info()
         return delta
@@ -109,6 +125,7 @@ class HipCholeskySolver(HipCholeskyCore, LinearSolver):
             raise RuntimeError("HipCholeskySolver only works with theseus_amd.HipLinearization, "
                                f"but {linearization_cls} was provided.")
         LinearSolver.__init__(self, objective, linearization_cls, linearization_kwargs)
+        self._check_singular = check_singular
         self._core_init()
 
     # theseus/optimizer/linear/dense_solver.py:84-123

@@ -14,7 +14,7 @@ import torch
 
 from .compiler import PoseGraphStructure
 from .core import Objective, Variable
-from .kernels import PGTensors, default_kernels, round_up, _lib
+from .kernels import PGTensors, default_kernels, fast_approx_local_jacobians, round_up, _lib
 
 ERR_CHUNKS = _lib.THX_ERR_CHUNKS
 
@@ -121,6 +121,7 @@ class PackedPoseGraph:
         for role, ks in kinds.items():
             if len(ks) > 1:
                 raise UnsupportedObjective(f"HIP backend: all {role} costs must share one robust loss kind (or none).")
+        self._refuse_fast_approx(UnsupportedObjective)
         self.robust_between = kinds["Between"].pop() if kinds["Between"] else _lib.LOSS_NONE
         self.robust_prior = kinds["Difference"].pop() if kinds["Difference"] else _lib.LOSS_NONE
         self.structure = PoseGraphStructure.build(len(self.pose_vars), edges, priors, e_rows, p_rows, dof=self.dof)
@@ -136,7 +137,19 @@ class PackedPoseGraph:
         self._global_stamp = -1
         self._vars_stale = False
         self._state_exposed = False
+        self._known = []
         self._scratch = {}
+
+    def _refuse_fast_approx(self, exc=NotImplementedError):
+        """``fast_approx_local_jacobians`` (theseus/embodied/misc/local_cost_fn.py:43-57: identity Jacobians for Local /
+        Difference costs) is not fused into the kernels: refuse loudly instead of silently computing the exact Jacobian.
+        (At construction the plugin for the real ``theseus`` catches this and takes its generic block path, where the
+        reference evaluates its own -- approximate -- Jacobians.)"""
+        if self.prior_costs and fast_approx_local_jacobians():
+            raise exc("HIP backend: the global option fast_approx_local_jacobians=True is not fused into the pose-graph "
+                      "kernels (Difference/Local costs would silently get their exact Jacobian).  There is no CPU/eager "
+                      "fallback; unset it, or set it BEFORE constructing the optimizer when running the real theseus "
+                      "through theseus_amd.plugin (generic block path).")
 
     # ---- packing ----------------------------------------------------------------------------
     def _tracked(self):
@@ -157,7 +170,7 @@ class PackedPoseGraph:
         # functions is done once, later stamps are one pass over the cached list (7 k variables at the headline size)
         tracked = self.__dict__.get("_tracked_list")
         if tracked is None:
-            tracked = self._tracked_list = list(self._tracked())
+            tracked = self._tracked_list = list(self._tracked())   # the optimisation variables (poses) come first
         if deep:
             # storage identity + autograd version counter: catches IN-PLACE edits of a variable's tensor that never go
             # through Variable.update() (an nn.Parameter stepped by a torch optimizer, ``var.tensor.mul_()``) -- the reference
@@ -178,14 +191,21 @@ class PackedPoseGraph:
         """(Re)pack the variable tensors into the device buffers if any variable changed.  ``deep`` also looks for in-place
         edits of the variables' tensors (storage pointer + version counter): the optimizers ask for it once per
         ``optimize()``, the inner-loop calls keep the O(1) test; with the reference's own Variable class (theseus_amd/
-        plugin.py) every call is deep -- there is no global update counter to lean on."""
+        plugin.py) every call is deep -- there is no global update counter to lean on.  Poses and auxiliary tensors are
+        re-packed independently (the reference's loop replaces the pose tensors every iteration, the measurements never)."""
         deep = deep or not self._own_variables
         if (not force and not deep and self.tensors is not None
                 and Variable._global_updates == self._global_stamp):
             return  # nobody called Variable.update()/to() since the last look: O(1) fast path
         stamp = self._current_stamp()
-        if (not force and self.tensors is not None and stamp == self._stamp
-                and (not deep or self._current_stamp(deep=True) == self._deep_stamp)):
+        dstamp = self._current_stamp(deep=True) if deep else None
+        nP = len(self.pose_vars)
+        if force or self.tensors is None:
+            poses_changed = aux_changed = True
+        else:
+            poses_changed = stamp[:nP] != self._stamp[:nP] or (deep and dstamp[:nP] != self._deep_stamp[:nP])
+            aux_changed = stamp[nP:] != self._stamp[nP:] or (deep and dstamp[nP:] != self._deep_stamp[nP:])
+        if not (poses_changed or aux_changed):
             self._global_stamp = Variable._global_updates
             return
         self.flush_variables()
@@ -194,19 +214,46 @@ class PackedPoseGraph:
         B = obj.batch_size
         dev, dt = self.pose_vars[0].device, obj.dtype
         gs, dof = self.gshape, self.dof
-        poses = self._stack([v.tensor.expand(B, *gs) if v.shape[0] != B else v.tensor for v in self.pose_vars], B)
-        E, Kp = self.structure.num_edges, self.structure.num_priors
-        empty = lambda *s: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
-        meas = self._stack([c.measurement.tensor for c in self.edge_costs], B) if E else empty(0, 1, *gs)
-        wb = self._stack([_weight_diag(c.weight, dof) for c in self.edge_costs], B) if E else empty(0, 1, dof)
-        tgt = self._stack([c.target.tensor for c in self.prior_costs], B) if Kp else empty(0, 1, *gs)
-        wp = self._stack([_weight_diag(c.weight, dof) for c in self.prior_costs], B) if Kp else empty(0, 1, dof)
-        lrb = self._stack([r.tensor.view(-1, 1) for r in self.edge_radius], B) if self.robust_between else None
-        lrp = self._stack([r.tensor.view(-1, 1) for r in self.prior_radius], B) if self.robust_prior else None
-        self.tensors = PGTensors(poses=poses, meas=meas, w_between=wb, prior_target=tgt, w_prior=wp,
-                                 robust_between=self.robust_between, log_radius_between=lrb,
-                                 robust_prior=self.robust_prior, log_radius_prior=lrp)
-        self._repoint_variables()
+        adopted = False
+        if poses_changed or self.tensors.poses.shape[1] != B:
+            ts = [v.tensor for v in self.pose_vars]
+            poses = self.buffer_of(ts)   # the variables already view ONE packed buffer (a kernel's output): no copy
+            adopted = poses is not None
+            if poses is None:
+                poses = self._stack([t.expand(B, *gs) if t.shape[0] != B else t for t in ts], B)
+        else:
+            poses = self.tensors.poses
+        if aux_changed or self.tensors.batch != B:
+            E, Kp = self.structure.num_edges, self.structure.num_priors
+            empty = lambda *s: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+            meas = self._stack([c.measurement.tensor for c in self.edge_costs], B) if E else empty(0, 1, *gs)
+            wb = self._stack([_weight_diag(c.weight, dof) for c in self.edge_costs], B) if E else empty(0, 1, dof)
+            tgt = self._stack([c.target.tensor for c in self.prior_costs], B) if Kp else empty(0, 1, *gs)
+            wp = self._stack([_weight_diag(c.weight, dof) for c in self.prior_costs], B) if Kp else empty(0, 1, dof)
+            lrb = self._stack([r.tensor.view(-1, 1) for r in self.edge_radius], B) if self.robust_between else None
+            lrp = self._stack([r.tensor.view(-1, 1) for r in self.prior_radius], B) if self.robust_prior else None
+            self.tensors = PGTensors(poses=poses, meas=meas, w_between=wb, prior_target=tgt, w_prior=wp,
+                                     robust_between=self.robust_between, log_radius_between=lrb,
+                                     robust_prior=self.robust_prior, log_radius_prior=lrp)
+        else:
+            self.tensors.poses = poses
+        if adopted:   # the variables hold these very views already: only the stamps move
+            self._stamp, self._deep_stamp = stamp, self._current_stamp(deep=True)
+            self._global_stamp = Variable._global_updates
+            self._vars_stale = False
+            self._state_exposed = True
+        else:
+            self._repoint_variables()
+
+    # ---- buffers whose per-pose views are known (so that a list of variable tensors can be recognised as one buffer) ----
+    def remember_views(self, buf: torch.Tensor, views):
+        self._known = [(buf, tuple(views))] + self._known[:3]
+
+    def buffer_of(self, tensors):
+        for buf, views in self._known:
+            if len(views) == len(tensors) and all(a is b for a, b in zip(tensors, views)):
+                return buf
+        return None
 
     def _repoint_variables(self):
         """Make every optimisation variable's tensor a view of the packed pose buffer."""
@@ -214,8 +261,10 @@ class PackedPoseGraph:
         # the optimiser calls this under no_grad; after the implicit last step the pose buffer carries a graph
         # and the per-variable views must stay attached to it
         with torch.set_grad_enabled(poses.requires_grad):
-            for v, t in zip(self.pose_vars, poses.unbind(0)):  # one call builds all the views
+            views = poses.unbind(0)  # one call builds all the views
+            for v, t in zip(self.pose_vars, views):
                 v.tensor = t
+        self.remember_views(poses, views)
         self._stamp = self._current_stamp()
         self._deep_stamp = self._current_stamp(deep=True)
         self._global_stamp = Variable._global_updates
@@ -304,6 +353,7 @@ class PackedPoseGraph:
 
     # ---- fused operations ---------------------------------------------------------------------
     def assemble(self, H: torch.Tensor, g: torch.Tensor):
+        self._refuse_fast_approx()
         self.sync()
         self.K.pg_assemble(self.dstruct, self.tensors, H, g)
 
@@ -324,24 +374,29 @@ class PackedPoseGraph:
         self.K.retract(self.tensors.poses, delta, step, m, out)
         return out
 
-    def jacobian_blocks(self, robust: bool = True):
+    def jacobian_blocks(self, robust: bool = True, jacobians: bool = True):
         """Weighted Jacobian blocks / residuals of every cost: (J0,J1 (E,B,d,d), eb (E,B,d), Jp, ep), d = dof;
-        robust costs rescaled as in ``weighted_jacobians_error`` unless ``robust=False``."""
+        robust costs rescaled as in ``weighted_jacobians_error`` unless ``robust=False``; ``jacobians=False`` writes the
+        residuals only (J0 = J1 = Jp = None)."""
         self.sync()
         B, E, Kp, d = self.batch, self.structure.num_edges, self.structure.num_priors, self.dof
         dt, dev = self.objective.dtype, self.tensors.poses.device
-        J0 = torch.empty(max(E, 1), B, d, d, dtype=dt, device=dev)
-        J1 = torch.empty_like(J0)
+        J0 = J1 = Jp = None
+        if jacobians:
+            J0 = torch.empty(max(E, 1), B, d, d, dtype=dt, device=dev)
+            J1 = torch.empty_like(J0)
+            Jp = torch.empty(max(Kp, 1), B, d, d, dtype=dt, device=dev)
         eb = torch.empty(max(E, 1), B, d, dtype=dt, device=dev)
-        Jp = torch.empty(max(Kp, 1), B, d, d, dtype=dt, device=dev)
         ep = torch.empty(max(Kp, 1), B, d, dtype=dt, device=dev)
         t = self.tensors if robust else dataclasses.replace(self.tensors, robust_between=0, robust_prior=0)
         self.K.pg_jacobians(self.dstruct, t, J0, J1, eb, Jp, ep)
+        if not jacobians:
+            return None, None, eb[:E], None, ep[:Kp]
         return J0[:E], J1[:E], eb[:E], Jp[:Kp], ep[:Kp]
 
     def error_vector(self):
         """(B, m) weighted error in cost add order (Objective.error, core/objective.py:562-613)."""
-        _, _, eb, _, ep = self.jacobian_blocks(robust=False)
+        _, _, eb, _, ep = self.jacobian_blocks(robust=False, jacobians=False)
         t = self.tensors
 
         def robust_error(e, kind, lr):

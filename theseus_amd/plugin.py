@@ -34,12 +34,20 @@ from theseus.optimizer import Linearization as _RefLinearization
 from theseus.optimizer.linear import CholeskyDenseSolver as _RefCholeskyDenseSolver
 from theseus.optimizer.linear import LinearSolver as _RefLinearSolver
 
+from theseus.global_params import _THESEUS_GLOBAL_PARAMS as _REF_GLOBAL_PARAMS
+
 from .generic import BlockAssembler
 from .autograd import detached_tensors, pg_vjp_grads
 from .kernels import default_kernels, round_up
 from .linear_solver import HipCholeskyCore
 from .linearization import HipLinearizationCore
 from .packed import UnsupportedObjective
+from . import kernels as _kernels
+
+# The Taylor-switch thresholds and fast_approx_local_jacobians are the REFERENCE's from here on: every launch reads
+# theseus' / torchlie's own global-parameter objects (torchlie/global_params.py:44-68, theseus/global_params.py:46-80), so
+# torchlie.set_global_params(...) / theseus.set_global_params(...) made by the user reach the HIP kernels.
+_kernels.use_reference_global_params(_REF_GLOBAL_PARAMS)
 
 
 class _FusedAtb(torch.autograd.Function):
@@ -81,10 +89,159 @@ class _CachedFactorSolve(torch.autograd.Function):
         return None, None, None, None, s.solve_with_factor(grad_delta.contiguous())
 
 
-class HipLinearization(HipLinearizationCore, _RefLinearization):
-    """Replaces ``th.DenseLinearization`` (theseus/optimizer/dense_linearization.py:15-77)."""
+class _HipRetract(torch.autograd.Function):
+    """X_new = X exp(delta) on the packed pose buffer (thx_se3_retract / thx_se2_retract), differentiable w.r.t. delta:
+    the backward is thx_se3_retract_vjp / thx_se2_retract_vjp.  (X itself is the detached iterate of the no-grad loop.)"""
 
-    def __init__(self, objective: th.Objective, ordering=None, kernels=None, **kwargs):
+    @staticmethod
+    def forward(ctx, packed, poses, delta, mask):
+        out = torch.empty_like(poses)
+        d = delta.detach().contiguous()
+        packed.K.retract(poses, d, 1.0, mask, out)
+        ctx.packed, ctx.mask = packed, mask
+        ctx.save_for_backward(poses, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        poses, d = ctx.saved_tensors
+        gd = torch.empty_like(d)
+        ctx.packed.K.retract_vjp(poses, d, 1.0, grad_out.contiguous(), gd)
+        if ctx.mask is not None:
+            gd = gd * (ctx.mask == 0).to(gd.dtype).unsqueeze(1)
+        return None, None, gd, None
+
+
+class _FusedWeightedError:
+    """What ``Objective.error()`` concatenates (core/objective.py:587-613): ONE item whose ``weighted_error()`` is the whole
+    (B, m) weighted error vector in cost add order, from thx_pg_jacobians (residuals only)."""
+
+    def __init__(self, packed):
+        self.packed = packed
+
+    def weighted_error(self) -> torch.Tensor:
+        return self.packed.error_vector()
+
+
+class _LazyJacobians:
+    """``Objective._vectorized_jacobians_iter``: served on demand (``Objective._get_jacobians_iter``, objective.py:836-843).
+    The fused linearization never asks; anybody else (another Linearization on the same objective, ``.A`` / ``.b``) gets the
+    reference's own wrappers filled from thx_pg_jacobians -- or, when autograd history is needed, from the reference's
+    differentiable vectorization."""
+
+    def __init__(self, hooks):
+        self.hooks = hooks
+
+    def __iter__(self):
+        h = self.hooks
+        if h.needs_graph():
+            h.ref["run"]()
+            return iter(h.ref["jac_iter"])
+        J0, J1, eb, Jp, ep = h.packed.jacobian_blocks()
+        for w, (kind, k) in zip(h.ref["jac_iter"], h.slots):
+            if kind == "e":
+                w._cached_jacobians, w._cached_error = [J0[k], J1[k]], eb[k]
+            else:
+                w._cached_jacobians, w._cached_error = [Jp[k]], ep[k]
+        return iter(h.ref["jac_iter"])
+
+
+class HipObjectiveHooks:
+    """The THIRD hook set of the boundary: the six swappable vectorization callbacks of ``th.Objective``
+    (core/objective.py:128-138, installed like ``_enable_vectorization`` :916-943 does, undone by ``disable_vectorization``
+    :945-951), called by the reference's loop from ``retract_vars_sequence`` / ``error_metric`` / ``update``
+    (nonlinear_least_squares.py:315-325,361-364).  With them one iteration of the REAL ``th.LevenbergMarquardt`` on a
+    pose graph is: thx_pg_assemble, thx_chol_factor_forward + thx_chol_solve_backward, thx_se3_retract, thx_pg_jacobians
+    (residuals) -- no per-update torch Jacobian pass (``_vectorization_run`` becomes a no-op: the fused linearization reads
+    the variables when it linearizes), no ATen retract, no ATen error evaluation.
+
+    The reference's own ``Vectorize`` stays underneath: evaluations that must record autograd history (grad enabled and
+    some tensor requires grad -- e.g. a user differentiating ``objective.error()``) are its differentiable torch ops; the
+    grad-enabled retraction of ``backward_mode="implicit"``'s last step is the HIP kernel with its VJP kernel."""
+
+    def __init__(self, objective, packed):
+        from theseus.core.vectorizer import Vectorize
+        if not objective.vectorized:
+            Vectorize(objective)
+        self.objective, self.packed = objective, packed
+        self.ref = dict(jac_iter=objective._vectorized_jacobians_iter, run=objective._vectorization_run,
+                        to=objective._vectorization_to, retract=objective._retract_method,
+                        err_iter=objective._get_error_iter)
+        self.pose_names = [v.name for v in packed.pose_vars]
+        index_e = {id(c): k for k, c in enumerate(packed.edge_costs)}
+        index_p = {id(c): k for k, c in enumerate(packed.prior_costs)}
+        self.slots = []
+        for wrapped in objective.cost_functions.values():
+            c = getattr(wrapped, "cost_function", wrapped) if type(wrapped).__name__ == "RobustCostFunction" else wrapped
+            self.slots.append(("e", index_e[id(c)]) if id(c) in index_e else ("p", index_p[id(c)]))
+        objective._vectorized_jacobians_iter = _LazyJacobians(self)
+        objective._vectorization_run = self.run
+        objective._vectorization_to = self.to
+        objective._retract_method = self.retract
+        objective._get_error_iter = self.error_iter
+        objective._vectorized = True
+        objective._thx_hooks = self
+
+    @staticmethod
+    def install(objective, packed):
+        h = getattr(objective, "_thx_hooks", None)
+        if (isinstance(h, HipObjectiveHooks) and h.packed is packed and objective._vectorized
+                and objective._retract_method == h.retract):
+            return h
+        return HipObjectiveHooks(objective, packed)
+
+    def needs_graph(self) -> bool:
+        return torch.is_grad_enabled() and any(v.tensor.requires_grad for v in self.packed._tracked())
+
+    # ---- _vectorization_run: nothing to precompute (the reference's version is a full torch Jacobian pass per update) ----
+    def run(self, *args, **kwargs):
+        return None
+
+    def to(self, *args, **kwargs):
+        self.ref["to"](*args, **kwargs)
+        self.packed.tensors = None      # re-packed on the new device / dtype at the next launch
+        self.packed._known = []
+
+    # ---- _retract_method (objective.py:873-914) ----
+    def retract(self, delta, ordering, ignore_mask=None, force_update: bool = False):
+        vars_ = list(ordering)
+        packed = self.packed
+        ts = [v.tensor for v in vars_]
+        grad = torch.is_grad_enabled()
+        if ([v.name for v in vars_] != self.pose_names or not delta.is_cuda and packed.K.name == "hip"
+                or (grad and any(t.requires_grad for t in ts))):
+            # not the packed pose order / differentiation w.r.t. the iterate itself: the reference's retraction
+            return self.ref["retract"](delta, vars_, ignore_mask=ignore_mask, force_update=force_update)
+        B = delta.shape[0]
+        poses = packed.buffer_of(ts)
+        if poses is None:
+            poses = packed._stack([t.expand(B, *packed.gshape) if t.shape[0] != B else t for t in ts], B)
+        mask = None
+        if ignore_mask is not None and not force_update:
+            mask = ignore_mask.to(torch.uint8).contiguous()
+        if grad and delta.requires_grad:
+            out = _HipRetract.apply(packed, poses.detach(), delta, mask)
+        else:
+            out = torch.empty_like(poses)
+            packed.K.retract(poses, delta.detach().contiguous(), 1.0, mask, out)
+        with torch.set_grad_enabled(grad and out.requires_grad):
+            views = out.unbind(0)
+        packed.remember_views(out, views)
+        for v, t in zip(vars_, views):
+            v.update(t)
+
+    # ---- _get_error_iter (objective.py:587-613) ----
+    def error_iter(self):
+        if self.needs_graph():
+            return self.ref["err_iter"]()
+        return iter([_FusedWeightedError(self.packed)])
+
+
+class HipLinearization(HipLinearizationCore, _RefLinearization):
+    """Replaces ``th.DenseLinearization`` (theseus/optimizer/dense_linearization.py:15-77).  ``objective_hooks=False``
+    keeps the reference's own vectorization callbacks (only ``Linearization`` + ``LinearSolver`` are replaced then)."""
+
+    def __init__(self, objective: th.Objective, ordering=None, kernels=None, objective_hooks: bool = True, **kwargs):
         _RefLinearization.__init__(self, objective, ordering)
         self._g_graph: Optional[torch.Tensor] = None
         try:
@@ -93,6 +250,7 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
         except UnsupportedObjective:
             self.fused = False
             self._generic_init(objective, kernels)
+        self.hooks = HipObjectiveHooks.install(objective, self.packed) if (self.fused and objective_hooks) else None
 
     # ---- generic path ------------------------------------------------------------------------------------
     def _generic_init(self, objective, kernels):
