@@ -162,8 +162,9 @@ def test_fp64_matches_the_reference_run_at_full_size():
     print(f"[full size fp64] max |pose - reference| = {err:.3e}, gauge-free (relative poses) = {rel:.3e}")
     assert err <= 1e-5, err            # the bar north_star states
     assert err <= 2e-7 and rel <= 2e-8, (err, rel)   # what this path actually delivers (gauge-weak: cond ~ 1e10)
+    scale = np.abs(g["Atb"][0]).max()   # A^T b shrinks towards zero along the run: its rounding level is set by |A|^T |b|
     for it in range(g["delta"].shape[0]):
-        np.testing.assert_allclose(atbs[it].cpu().numpy(), g["Atb"][it], rtol=0, atol=1e-9 * np.abs(g["Atb"][it]).max())
+        np.testing.assert_allclose(atbs[it].cpu().numpy(), g["Atb"][it], rtol=0, atol=1e-10 * scale)
         np.testing.assert_allclose(deltas[it].cpu().numpy(), g["delta"][it], rtol=0, atol=2e-7 * max(1.0, np.abs(g["delta"][it]).max()))
     np.testing.assert_allclose(info.err_history.numpy()[:, 1:].T, g["last_err"], rtol=1e-9)
     np.testing.assert_allclose(info.err_history.numpy()[:, 0], g["err0"], rtol=1e-12)

@@ -14,8 +14,20 @@ import torch
 from tests.conftest import ROOT
 from tests.helpers import golden_problem, load_golden
 
-REF = "/root/reference"
+# THX_REFERENCE_ROOT / THX_PLUGIN_DEVICE=cuda: the same tests with the REAL HIP kernels behind the plugin, on a GPU box that
+# was handed a scratch copy of the reference for the occasion (tools/dropin_gpu.sh; the copy is never committed).
+REF = os.environ.get("THX_REFERENCE_ROOT", "/root/reference")
+DEVICE = os.environ.get("THX_PLUGIN_DEVICE", "cpu")
 pytestmark = [pytest.mark.reference, pytest.mark.skipif(not os.path.isdir(REF), reason="needs /root/reference")]
+cpu_only = pytest.mark.skipif(DEVICE != "cpu", reason="builds its tensors on the CPU / spies on the stand-in")
+
+
+def _kernels():
+    """linearization_kwargs: the TEST stand-in on the CPU, libtheseus_hip.so (the default) on a GPU."""
+    if DEVICE == "cpu":
+        from tests.oracle_kernels import OracleKernels
+        return dict(kernels=OracleKernels())
+    return {}
 
 
 @pytest.fixture(scope="module")
@@ -36,7 +48,10 @@ def _objective(th, g):
     d = dict(P=int(g["P"]), edges=t(g["edges"]), meas=t(g["meas"]), w_between=t(g["w_between"]),
              prior_idx=t(g["prior_idx"]), prior_target=t(g["prior_target"]), w_prior=t(g["w_prior"]),
              poses=t(g["poses0"]), group=str(g["group"]) if "group" in g else "SE3")
-    return build_reference_objective(th, d, d["poses"].dtype)
+    obj, poses = build_reference_objective(th, d, d["poses"].dtype)
+    if DEVICE != "cpu":
+        obj.to(DEVICE)
+    return obj, poses
 
 
 @pytest.mark.parametrize("name", ["pg_f64_lm", "pg_f64_lm_adaptive_ellips", "pg_f64_lm_adaptive_rejects", "pg_f64_gn",
@@ -51,13 +66,13 @@ def test_reference_loop_drives_the_plugin(ref, name):
     okw = dict(max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"))
     cls = th.GaussNewton if gn else th.LevenbergMarquardt
     opt = cls(obj, linear_solver_cls=thp.HipCholeskySolver, linearization_cls=thp.HipLinearization,
-              linearization_kwargs=dict(kernels=OracleKernels()), vectorize=True,
+              linearization_kwargs=_kernels(), vectorize=True,
               abs_err_tolerance=0.0, rel_err_tolerance=0.0, **okw)
     lin = opt.linear_solver.linearization
     assert lin.var_start_cols == list(g["var_start_cols"]) and lin.num_rows == int(g["num_rows"])
     with torch.no_grad():
         info = opt.optimize(track_err_history=True, **kw)
-    final = torch.stack([p.tensor for p in poses], 1).numpy()
+    final = torch.stack([p.tensor for p in poses], 1).detach().cpu().numpy()
     # converged problems' late accept/reject decisions are coin flips (tests/test_gpu_lm.py:well_conditioned_steps)
     from tests.test_gpu_lm import well_conditioned_steps
     ok = well_conditioned_steps(g, g["delta"].shape[0])
@@ -68,12 +83,12 @@ def test_reference_loop_drives_the_plugin(ref, name):
     lin.linearize()
     ref_lin = th.optimizer.DenseLinearization(obj)
     ref_lin.linearize()
-    np.testing.assert_allclose(lin.AtA.numpy(), ref_lin.AtA.numpy(), rtol=1e-10, atol=1e-9)
-    np.testing.assert_allclose(lin.Atb.numpy(), ref_lin.Atb.numpy(), rtol=1e-10, atol=1e-9)
-    np.testing.assert_allclose(lin.A.numpy(), ref_lin.A.numpy(), rtol=1e-10, atol=1e-10)
-    v = torch.randn(lin.AtA.shape[0], lin.num_cols, dtype=torch.float64)
-    np.testing.assert_allclose(lin.diagonal_scaling(v).numpy(), ref_lin.diagonal_scaling(v).numpy(), rtol=1e-10)
-    np.testing.assert_allclose(lin.Av(v).numpy(), ref_lin.Av(v).numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(lin.AtA.detach().cpu().numpy(), ref_lin.AtA.detach().cpu().numpy(), rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(lin.Atb.detach().cpu().numpy(), ref_lin.Atb.detach().cpu().numpy(), rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(lin.A.detach().cpu().numpy(), ref_lin.A.detach().cpu().numpy(), rtol=1e-10, atol=1e-10)
+    v = torch.randn(lin.AtA.shape[0], lin.num_cols, dtype=torch.float64).to(DEVICE)
+    np.testing.assert_allclose(lin.diagonal_scaling(v).detach().cpu().numpy(), ref_lin.diagonal_scaling(v).detach().cpu().numpy(), rtol=1e-10)
+    np.testing.assert_allclose(lin.Av(v).detach().cpu().numpy(), ref_lin.Av(v).detach().cpu().numpy(), rtol=1e-9, atol=1e-9)
 
 
 def test_plugin_through_theseus_layer_and_failure_path(ref):
@@ -82,12 +97,12 @@ def test_plugin_through_theseus_layer_and_failure_path(ref):
     g = load_golden("pg_f64_lm")
     obj, poses = _objective(th, g)
     opt = th.LevenbergMarquardt(obj, linear_solver_cls=thp.HipCholeskySolver,
-                                linearization_kwargs=dict(kernels=OracleKernels()), max_iterations=6,
+                                linearization_kwargs=_kernels(), max_iterations=6,
                                 abs_err_tolerance=0.0, rel_err_tolerance=0.0)
     layer = th.TheseusLayer(opt)
     with torch.no_grad():
         sol, info = layer.forward(optimizer_kwargs=dict(damping=1e-3))
-    final = torch.stack([sol[f"pose_{k}"] for k in range(int(g["P"]))], 1).numpy()
+    final = torch.stack([sol[f"pose_{k}"] for k in range(int(g["P"]))], 1).detach().cpu().numpy()
     np.testing.assert_allclose(final, g["final"], rtol=0, atol=5e-8)
     # non positive definite system -> RuntimeError from solve() -> the reference loop reports FAIL
     for cf in obj.cost_functions.values():
@@ -95,10 +110,11 @@ def test_plugin_through_theseus_layer_and_failure_path(ref):
             v.update(torch.zeros_like(v.tensor))
     with torch.no_grad(), pytest.warns(RuntimeWarning):
         info = th.GaussNewton(obj, linear_solver_cls=thp.HipCholeskySolver,
-                              linearization_kwargs=dict(kernels=OracleKernels()), max_iterations=3).optimize()
+                              linearization_kwargs=_kernels(), max_iterations=3).optimize()
     assert all(s == th.NonlinearOptimizerStatus.FAIL for s in info.status)
 
 
+@cpu_only
 def test_non_pose_graph_objective_takes_the_generic_path(ref):
     """Vector variables + Difference: not an SE3 pose graph -> generic block assembly, same result as the reference."""
     th, thp = ref
@@ -113,7 +129,7 @@ def test_non_pose_graph_objective_takes_the_generic_path(ref):
         obj.add(th.Difference(a, tgt, w, name="d0"))
         obj.add(th.Between(a, b, th.Vector(tensor=torch.tensor([[1.0, 1.0]], dtype=torch.float64), name="m"), w, name="d1"))
         kw = {} if tag == "ref" else dict(linear_solver_cls=thp.HipCholeskySolver,
-                                          linearization_kwargs=dict(kernels=OracleKernels()))
+                                          linearization_kwargs=_kernels())
         opt = th.LevenbergMarquardt(obj, max_iterations=5, **kw)
         obj.update()
         with torch.no_grad():
@@ -121,7 +137,7 @@ def test_non_pose_graph_objective_takes_the_generic_path(ref):
         out[tag] = torch.cat([a.tensor, b.tensor], 1)
         if tag == "ours":
             assert not opt.linear_solver.linearization.fused
-    np.testing.assert_allclose(out["ours"].numpy(), out["ref"].numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out["ours"].detach().cpu().numpy(), out["ref"].detach().cpu().numpy(), rtol=1e-12, atol=1e-12)
 
 
 def _quadratic_fit(th, B=16, N=20, seed=0):
@@ -144,6 +160,7 @@ def _quadratic_fit(th, B=16, N=20, seed=0):
     return obj, x.tensor.clone()
 
 
+@cpu_only
 def test_generic_path_runs_simple_example_config0(ref):
     """BASELINE.json configs[0]: quadratic fit, batch 16, GaussNewton + dense Cholesky, implicit backward through
     TheseusLayer -- the reference's own loop and AutoDiffCostFunction, our Linearization / LinearSolver behind it
@@ -154,7 +171,7 @@ def test_generic_path_runs_simple_example_config0(ref):
     for tag in ("ref", "ours"):
         obj, x0 = _quadratic_fit(th)
         kw = {} if tag == "ref" else dict(linear_solver_cls=thp.HipCholeskySolver,
-                                          linearization_kwargs=dict(kernels=OracleKernels()))
+                                          linearization_kwargs=_kernels())
         layer = th.TheseusLayer(th.GaussNewton(obj, max_iterations=10, **kw))
         phi = x0.clone().requires_grad_(True)
         sol, info = layer.forward(input_tensors={"x": phi, "v": torch.ones(16, 1, dtype=torch.float64)},
@@ -164,11 +181,12 @@ def test_generic_path_runs_simple_example_config0(ref):
         res[tag] = (sol["v"].detach(), loss.item(), phi.grad.clone(), info)
         if tag == "ours":
             assert not layer.optimizer.linear_solver.linearization.fused
-    np.testing.assert_allclose(res["ours"][0].numpy(), res["ref"][0].numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(res["ours"][0].detach().cpu().numpy(), res["ref"][0].detach().cpu().numpy(), rtol=1e-10, atol=1e-12)
     assert abs(res["ours"][1] - res["ref"][1]) < 1e-12
-    np.testing.assert_allclose(res["ours"][2].numpy(), res["ref"][2].numpy(), rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(res["ours"][2].detach().cpu().numpy(), res["ref"][2].detach().cpu().numpy(), rtol=1e-8, atol=1e-12)
 
 
+@cpu_only
 def test_fused_path_is_differentiable_through_the_reference_loop(ref):
     """backward_mode="implicit" of the REAL loop with the plugin on an SE3 pose graph: Atb's backward is the fused
     VJP, the solve's backward the cached-factor solve; gradients equal the ones the reference recorded."""
@@ -192,19 +210,20 @@ def test_fused_path_is_differentiable_through_the_reference_loop(ref):
         obj.add(th.Difference(poses[int(g["prior_idx"][k])], th.SE3(tensor=leaves["prior_target"][:, k], name=f"tgt_{k}"),
                               th.ScaleCostWeight(th.Variable(leaves["w_prior"][:, k], name=f"pw_{k}")), name=f"prior_{k}"))
     opt = th.LevenbergMarquardt(obj, linear_solver_cls=thp.HipCholeskySolver,
-                                linearization_kwargs=dict(kernels=OracleKernels()), max_iterations=kw.pop("max_iterations"),
+                                linearization_kwargs=_kernels(), max_iterations=kw.pop("max_iterations"),
                                 step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0)
     assert opt.linear_solver.linearization.fused
     sol, _ = th.TheseusLayer(opt).forward(optimizer_kwargs=dict(backward_mode="implicit", **kw))
     final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
     (t(g["coef"]) * final).sum().backward()
-    np.testing.assert_allclose(final.detach().numpy(), g["final"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(final.detach().detach().cpu().numpy(), g["final"], rtol=0, atol=1e-7)
     for key, refk in (("meas", "grad_meas"), ("w_between", "grad_w_between"), ("prior_target", "grad_prior_target"),
                       ("w_prior", "grad_w_prior")):
         want = g[refk]
-        np.testing.assert_allclose(leaves[key].grad.numpy(), want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
+        np.testing.assert_allclose(leaves[key].grad.detach().cpu().numpy(), want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
 
 
+@cpu_only
 def test_unmodified_reference_example_runs_on_the_plugin(ref, monkeypatch):
     """examples/pose_graph/pose_graph_synthetic.py -- UNMODIFIED, imported from /root/reference -- with
     ``inner_optim.linear_solver_cls = HipCholeskySolver`` (the one name a user changes): Welsch RobustCostFunction,
@@ -264,22 +283,24 @@ def test_reference_loop_drives_the_bundle_adjustment_plugin(ref, name):
         ScaleCostWeight, RobustCostFunction, HuberLoss, WelschLoss = th.ScaleCostWeight, th.RobustCostFunction, th.HuberLoss, th.WelschLoss
         Reprojection = th.eb.Reprojection
     g = load_golden(name)
-    obj, cam_v, pt_v = build_ba_objective(RefNames, g)
+    obj, cam_v, pt_v = build_ba_objective(RefNames, g, DEVICE)
+    if DEVICE != "cpu":
+        obj.to(DEVICE)
     obj.update()   # resolves the batch size (TheseusLayer.forward does this for the user)
     kw = ast.literal_eval(str(g["opt_kwargs"]))
     gn = kw.pop("gauss_newton")
     opt = (th.GaussNewton if gn else th.LevenbergMarquardt)(
-        obj, linear_solver_cls=thp.HipSchurSolver, linearization_kwargs=dict(kernels=OracleKernels()), vectorize=True,
+        obj, linear_solver_cls=thp.HipSchurSolver, linearization_kwargs=_kernels(), vectorize=True,
         abs_err_tolerance=0.0, rel_err_tolerance=0.0, max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"))
     with torch.no_grad():
         info = opt.optimize(track_err_history=True, **kw)
-    cams = torch.stack([v.tensor for v in cam_v], 1).numpy()
+    cams = torch.stack([v.tensor for v in cam_v], 1).detach().cpu().numpy()
     used = sorted(set(g["obs_pt"].tolist()))
-    pts = torch.stack([pt_v[i].tensor for i in used], 1).numpy()
+    pts = torch.stack([pt_v[i].tensor for i in used], 1).detach().cpu().numpy()
     np.testing.assert_allclose(cams, g["final_cams"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(pts, g["final_pts"][:, used], rtol=0, atol=1e-5)
     k = min(info.err_history.shape[1], g["err_history"].shape[1])
-    np.testing.assert_allclose(info.err_history[:, :k].numpy(), g["err_history"][:, :k], rtol=1e-6)
+    np.testing.assert_allclose(info.err_history[:, :k].detach().cpu().numpy(), g["err_history"][:, :k], rtol=1e-6)
 
 
 # ---- the third hook set (Objective vectorization callbacks) -------------------------------------------------
@@ -293,6 +314,7 @@ def _counting(standin, names):
     return calls
 
 
+@cpu_only
 @pytest.mark.parametrize("name", ["pg_f64_lm_adaptive_rejects", "pg2_f64_lm"])
 def test_objective_hooks_keep_the_reference_loop_off_aten(ref, name):
     """With theseus_amd.plugin the REAL loop's retract_vars_sequence / error_metric / update go through the kernels: the
@@ -322,29 +344,30 @@ def test_objective_hooks_keep_the_reference_loop_off_aten(ref, name):
     assert ref_calls == {"run": 0, "retract": 0, "err_iter": 0}, ref_calls
     solves = calls["chol_factor"]
     assert calls["pg_assemble"] == solves and calls["retract"] == solves and calls["pg_jacobians"] >= solves
-    final = torch.stack([p.tensor for p in poses], 1).numpy()
+    final = torch.stack([p.tensor for p in poses], 1).detach().cpu().numpy()
     from tests.test_gpu_lm import well_conditioned_steps
     ok = well_conditioned_steps(g, g["delta"].shape[0])
     slack = 2.0 * (np.abs(g["delta"]).max(axis=2) * ~ok).sum(axis=0)
     assert (np.abs(final - g["final"]).reshape(final.shape[0], -1).max(1) <= 5e-8 + slack).all()
     k = min(info.err_history.shape[1], g["err_history"].shape[1])
-    np.testing.assert_allclose(info.err_history[:, :k].numpy(), g["err_history"][:, :k], rtol=2e-5)
+    np.testing.assert_allclose(info.err_history[:, :k].detach().cpu().numpy(), g["err_history"][:, :k], rtol=2e-5)
     # Objective.error() / error_metric() as a user calls them: the (B, m) weighted error vector in cost add order
     ref_obj, _ = _objective(th, g)
     ref_obj.update({p.name: p.tensor for p in poses})
-    np.testing.assert_allclose(obj.error().numpy(), ref_obj.error().numpy(), rtol=1e-9, atol=1e-10)
-    np.testing.assert_allclose(obj.error_metric().numpy(), ref_obj.error_metric().numpy(), rtol=1e-10)
+    np.testing.assert_allclose(obj.error().detach().cpu().numpy(), ref_obj.error().detach().cpu().numpy(), rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(obj.error_metric().detach().cpu().numpy(), ref_obj.error_metric().detach().cpu().numpy(), rtol=1e-10)
     # somebody else's Linearization on the hooked objective is served Jacobians through the reference's own wrappers
     other = th.optimizer.DenseLinearization(obj)
     other.linearize()
     mine = opt.linear_solver.linearization
     mine.linearize()
-    np.testing.assert_allclose(other.AtA.numpy(), mine.AtA.numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(other.AtA.detach().cpu().numpy(), mine.AtA.detach().cpu().numpy(), rtol=1e-9, atol=1e-9)
     # disable_vectorization() (objective.py:945-951) takes the hooks out again
     obj.disable_vectorization()
     assert not obj.vectorized and obj._retract_method == th.Objective._retract_base
 
 
+@cpu_only
 def test_hooks_can_be_left_out(ref):
     th, thp = ref
     from tests.oracle_kernels import OracleKernels
@@ -356,7 +379,7 @@ def test_hooks_can_be_left_out(ref):
     assert opt.linear_solver.linearization.hooks is None and type(obj._vectorization_run.__self__).__name__ == "Vectorize"
     with torch.no_grad():
         opt.optimize(damping=1e-3)
-    np.testing.assert_allclose(torch.stack([p.tensor for p in poses], 1).numpy(), g["final"], rtol=0, atol=5e-8)
+    np.testing.assert_allclose(torch.stack([p.tensor for p in poses], 1).detach().cpu().numpy(), g["final"], rtol=0, atol=5e-8)
 
 
 # ---- the reference's knobs ----------------------------------------------------------------------------------------------------
@@ -380,6 +403,7 @@ def test_global_params_of_the_reference_reach_the_kernels(ref):
     from tests.oracle_kernels import OracleKernels  # noqa: F401  (the stand-in reads oracle.lie.EPS, not these: host-side check only)
 
 
+@cpu_only
 def test_fast_approx_local_jacobians_is_honoured_through_the_generic_path(ref):
     """theseus/embodied/misc/local_cost_fn.py:43-57.  Set before construction: the plugin takes the generic block path, where
     the reference evaluates its own (identity) Jacobians; toggled afterwards on a fused linearization: a loud error."""
@@ -394,12 +418,12 @@ def test_fast_approx_local_jacobians_is_honoured_through_the_generic_path(ref):
         lin.linearize()
         ref_lin = th.optimizer.DenseLinearization(obj)
         ref_lin.linearize()
-        np.testing.assert_allclose(lin.AtA.numpy(), ref_lin.AtA.numpy(), rtol=1e-10, atol=1e-9)
-        np.testing.assert_allclose(lin.Atb.numpy(), ref_lin.Atb.numpy(), rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(lin.AtA.detach().cpu().numpy(), ref_lin.AtA.detach().cpu().numpy(), rtol=1e-10, atol=1e-9)
+        np.testing.assert_allclose(lin.Atb.detach().cpu().numpy(), ref_lin.Atb.detach().cpu().numpy(), rtol=1e-10, atol=1e-9)
         th.set_global_params({"fast_approx_local_jacobians": False})
         exact = th.optimizer.DenseLinearization(obj)
         exact.linearize()
-        assert not np.allclose(exact.AtA.numpy(), ref_lin.AtA.numpy(), rtol=1e-6)   # the option does change the Hessian
+        assert not np.allclose(exact.AtA.detach().cpu().numpy(), ref_lin.AtA.detach().cpu().numpy(), rtol=1e-6)   # the option does change the Hessian
         obj2, _ = _objective(th, g)
         fused = thp.HipLinearization(obj2, kernels=OracleKernels())
         assert fused.fused
@@ -410,6 +434,7 @@ def test_fast_approx_local_jacobians_is_honoured_through_the_generic_path(ref):
         th.global_params._THESEUS_GLOBAL_PARAMS.reset()
 
 
+@cpu_only
 def test_check_singular_matches_the_reference(ref):
     """dense_solver.py:91-114: batch items whose (undamped) AtA is singular get an all-zero step and a RuntimeWarning, the
     others are solved."""
@@ -429,11 +454,11 @@ def test_check_singular_matches_the_reference(ref):
         if tag == "ref":
             solver = th.CholeskyDenseSolver(obj, check_singular=True)
         else:
-            solver = thp.HipCholeskySolver(obj, linearization_kwargs=dict(kernels=OracleKernels()), check_singular=True)
+            solver = thp.HipCholeskySolver(obj, linearization_kwargs=_kernels(), check_singular=True)
         solver.linearization.linearize()
         with pytest.warns(RuntimeWarning, match="Singular matrix found in batch"):
             out[tag] = solver.solve(damping=0.1, ellipsoidal_damping=False).double()
     assert (out["ours"][1] == 0).all() and (out["ref"][1] == 0).all()
     good = [0, 2]
-    np.testing.assert_allclose(out["ours"][good].numpy(), out["ref"][good].numpy(), rtol=0,
-                               atol=2e-3 * np.abs(out["ref"][good].numpy()).max())
+    np.testing.assert_allclose(out["ours"][good].detach().cpu().numpy(), out["ref"][good].detach().cpu().numpy(), rtol=0,
+                               atol=2e-3 * np.abs(out["ref"][good].detach().cpu().numpy()).max())

@@ -57,6 +57,13 @@ def _run_lm(g, opt_overrides, reducer=None, spy=None):
             spy.append(([bool(f.any()) for f in any_f], [bool(f.all()) for f in all_f], r))
             return r
         opt.reducer.decide = decide
+        inner_all = opt.reducer.device_all
+
+        def device_all(flag):   # the sync-free loop's form of the same predicate (0-dim device bool)
+            r = inner_all(flag)
+            spy.append(([], [bool(flag)], ([], [bool(r)])))
+            return r
+        opt.reducer.device_all = device_all
     sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(track_err_history=True, **kw))
     packed = opt.linear_solver.linearization.packed
     final = torch.stack([sol[f"pose_{k}"] for k in range(int(g["P"]))], 1)

@@ -71,6 +71,35 @@ class NonlinearOptimizerParams:
     step_size: float
 
 
+class _LaggedFlag:
+    """A device-side bool looked at WITHOUT stalling the queue: ``post`` copies it to pinned host memory behind the work
+    already queued and records an event; ``seen`` is True once a posted copy has landed with the flag raised.  On a CPU
+    device (tests) the look is immediate."""
+
+    def __init__(self, device):
+        self.cuda = device.type == "cuda"
+        self.pending, self.value = [], False
+        self.host = torch.zeros(8, dtype=torch.bool).pin_memory() if self.cuda else None
+        self.slot = 0
+
+    def post(self, flag: torch.Tensor):
+        if not self.cuda:
+            self.value = self.value or bool(flag)
+            return
+        k = self.slot % 8
+        self.slot += 1
+        self.host[k:k + 1].copy_(flag.view(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((ev, k))
+
+    def seen(self) -> bool:
+        while self.pending and self.pending[0][0].query():
+            _, k = self.pending.pop(0)
+            self.value = self.value or bool(self.host[k])
+        return self.value
+
+
 class NonlinearLeastSquares(abc.ABC):
     _MAX_ALL_REJECT_ATTEMPTS = 3  # nonlinear_optimizer.py:88
 
@@ -164,15 +193,22 @@ class NonlinearLeastSquares(abc.ABC):
             B = packed.batch
             dev, dt = packed.device, self.objective.dtype
             p = self.params
-            last_err = packed.error_metric()
-            err_hist = None
-            if track_err_history:
-                err_hist = torch.full((B, p.max_iterations + 1), float("inf"), dtype=dt, device=dev)
-                err_hist[:, 0] = last_err
-            info = NonlinearOptimizerInfo(
-                best_solution=None, status=np.array([NonlinearOptimizerStatus.START] * B),
-                converged_iter=torch.full((B,), -1, dtype=torch.long), best_iter=torch.zeros(B, dtype=torch.long),
-                err_history=err_hist, last_err=last_err, best_err=last_err.clone())
+            need_conv = p.abs_err_tolerance > 0 or p.rel_err_tolerance > 0
+            adaptive = bool(kwargs.get("adaptive_damping", False))
+            inf = float("inf")
+
+            def fresh_info():
+                last = packed.error_metric()
+                hist = None
+                if track_err_history:
+                    hist = torch.full((B, p.max_iterations + 1), inf, dtype=dt, device=dev)
+                    hist[:, 0] = last
+                return last, hist, NonlinearOptimizerInfo(
+                    best_solution=None, status=np.array([NonlinearOptimizerStatus.START] * B),
+                    converged_iter=torch.full((B,), -1, dtype=torch.long), best_iter=torch.zeros(B, dtype=torch.long),
+                    err_history=hist, last_err=last, best_err=last.clone())
+
+            last_err, err_hist, info = fresh_info()
             if track_best_solution:
                 best_state = packed.clone_state()
                 best_err = last_err.clone()
@@ -180,76 +216,133 @@ class NonlinearLeastSquares(abc.ABC):
             if verbose:
                 print(f"Nonlinear optimizer. Iteration: 0. Error: {last_err.mean().item()}")
 
-            need_conv = p.abs_err_tolerance > 0 or p.rel_err_tolerance > 0
             converged = None          # (B,) bool on device, None == nobody
             conv_iter = torch.full((B,), -1, dtype=torch.long, device=dev)
             spare = packed.alloc_state()
             err_new = torch.empty(B, dtype=dt, device=dev)
             it, all_reject_attempts = 0, 0
-            # ---- sync-free iterations.  Without adaptive damping, convergence tests, callbacks or a
-            #      sharded batch the only host decision of an iteration is "did a linear solve fail?"
-            #      (nonlinear_least_squares.py:138-152: FAIL status, variables keep their values).  That flag stays on
-            #      the device (OR-ed over the shards by a stream-ordered all-reduce when the batch is sharded): once
-            #      raised it freezes every later update through the retraction mask, and it is read ONCE after the loop
-            #      -- the host queues the iterations back to back and the GPU never drains.  (Local AND sharded batches:
-            #      DistBatchReducer is a LocalBatchReducer whose device_any() all-reduces.) ----
-            lazy = (isinstance(self.reducer, LocalBatchReducer) and not need_conv and end_iter_callback is None
-                    and not verbose and not kwargs.get("adaptive_damping", False))
-            failed = first_fail = None
-            if lazy:
+
+            def warn_failed(run_err):
+                warnings.warn(f"There was an error while running the linear optimizer. Original error message: {run_err}.",
+                              RuntimeWarning)
+
+            # ---- SYNC-FREE iterations.  The host decisions of the reference's iteration -- "did a linear
+            #      solve fail?" (nonlinear_least_squares.py:138-152), "were ALL steps rejected?" (:358-359, the retry that
+            #      does not count as an iteration), "has EVERY problem converged?" (:202) -- are evaluated on the device
+            #      (all-reduced over the shards when the batch is sharded) and kept there as three flags; everything else
+            #      of the iteration is per-problem masked work: rejected problems keep their state and error
+            #      (thx_copy_where), converged / failed ones are frozen through the retraction mask, lambda lives in a device
+            #      vector (thx_lm_accept).  The iterations are queued back to back and the flags are read ONCE after the loop:
+            #        * a failed solve froze every later update on the device: FAIL status, iters_done = the failing iteration;
+            #        * everybody converged at iteration k: later iterations were no-ops on frozen problems, the bookkeeping
+            #          is cut at k (a lagged, non-blocking poll of the flag stops the queueing a couple of iterations later);
+            #        * an ALL-rejected step (rare at any real batch size): the loop is REPLAYED from the saved start on the
+            #          synchronous path below, which takes the reference's retry branch exactly.
+            #      Callbacks and verbose printing need the host every iteration: synchronous path. ----
+            sync_free = (isinstance(self.reducer, LocalBatchReducer) and end_iter_callback is None and not verbose
+                         and loop_iters > 0)
+            replay = False
+            if sync_free:
+                start_state = packed.clone_state() if adaptive else None
+                flag = lambda v: torch.full((), v, dtype=torch.long, device=dev)  # noqa: E731
                 failed = torch.zeros((), dtype=torch.bool, device=dev)
-                first_fail = torch.full((), -1, dtype=torch.long, device=dev)
-            raised = None
-            while lazy and it < loop_iters:
-                local_fail = None
-                if raised is None:
-                    lin.linearize()
-                    try:
-                        delta = self.compute_delta(**kwargs)
-                        local_fail = self.linear_solver.info.ne(0).any()
-                    except RuntimeError as run_err:
-                        # a host-side error on THIS rank: the other shards are (or will be) waiting in device_any()'s
-                        # all-reduce -- keep taking part in it with the flag raised instead of leaving the loop
-                        raised = run_err
-                if raised is not None:
-                    delta = torch.zeros(B, lin.num_cols, dtype=dt, device=dev)
-                    local_fail = torch.ones((), dtype=torch.bool, device=dev)
-                now = self.reducer.device_any(local_fail)
-                first_fail = torch.where(now & ~failed, torch.full_like(first_fail, it), first_fail)
-                failed = failed | now
-                packed.retract(delta, p.step_size, failed.to(torch.uint8).expand(B).contiguous(), spare)
-                packed.error_metric(state=spare, out=err_new)
-                err = torch.where(failed, last_err, err_new)
-                spare = packed.swap_state(spare)
-                if err_hist is not None:
-                    err_hist[:, it + 1] = torch.where(failed, torch.full_like(err, float("inf")), err)
-                if track_best_solution:
-                    better = (err < best_err) & ~failed
-                    packed.copy_where(better, packed.state, best_state)
-                    best_err = torch.where(better, err, best_err)
-                    best_iter = torch.where(better, torch.full_like(best_iter, it), best_iter)  # nonlinear_optimizer.py:202
-                last_err = err
-                info.last_err = err
-                it += 1
-                info.iters_done = it
-            if lazy and bool(failed):  # the one host sync of the loop
-                try:
+                first_fail, first_all_rej, first_all_conv = flag(-1), flag(-1), flag(-1)
+                # (the lagged poll is a per-process decision: a sharded batch runs all its iterations, so that every rank
+                #  issues the same all-reduces)
+                poll = _LaggedFlag(dev) if (need_conv and self.reducer.world_size == 1) else None
+                raised = None
+                while it < loop_iters:
+                    if poll is not None and poll.seen():
+                        break   # everybody converged a moment ago: stop queueing (the cut below is exact)
+                    local_fail = None
+                    if raised is None:
+                        lin.linearize()
+                        try:
+                            delta = self.compute_delta(**kwargs)
+                            local_fail = self.linear_solver.info.ne(0).any()
+                        except RuntimeError as run_err:
+                            # a host-side error on THIS rank: the other shards are (or will be) waiting in device_any()'s
+                            # all-reduce -- keep taking part in it with the flag raised instead of leaving the loop
+                            raised = run_err
                     if raised is not None:
-                        raise raised
-                    self.linear_solver.check_info()
-                    raise RuntimeError("the linear solve failed on another shard of the batch")
-                except RuntimeError as run_err:
-                    warnings.warn(f"There was an error while running the linear optimizer. "
-                                  f"Original error message: {run_err}.", RuntimeWarning)
-                info.status[:] = NonlinearOptimizerStatus.FAIL
-                info.iters_done = int(first_fail)
-            while not lazy and it < loop_iters:
+                        delta = torch.zeros(B, lin.num_cols, dtype=dt, device=dev)
+                        local_fail = torch.ones((), dtype=torch.bool, device=dev)
+                    now = self.reducer.device_any(local_fail)
+                    first_fail = torch.where(now & ~failed, torch.full_like(first_fail, it), first_fail)
+                    failed = failed | now
+                    frozen = failed.expand(B) if converged is None else (converged | failed)
+                    packed.retract(delta, p.step_size, frozen.to(torch.uint8).contiguous(), spare)
+                    packed.error_metric(state=spare, out=err_new)
+                    reject = self._complete_step(delta, err_new, last_err, step_size=p.step_size, **kwargs)
+                    if reject is not None:
+                        rb = reject.bool()
+                        all_rej = self.reducer.device_all(rb.all())
+                        first_all_rej = torch.where(all_rej & (first_all_rej < 0) & ~failed,
+                                                    torch.full_like(first_all_rej, it), first_all_rej)
+                        packed.keep_where(rb, spare)                                   # rejected problems keep their state
+                        packed.K.copy_where(rb, last_err.view(1, -1, 1), err_new.view(1, -1, 1))   # ... and their error
+                    err = torch.where(failed, last_err, err_new)
+                    spare = packed.swap_state(spare)
+                    if err_hist is not None:
+                        err_hist[:, it + 1] = torch.where(failed, torch.full_like(err, inf), err)
+                    if track_best_solution:
+                        better = (err < best_err) & ~failed
+                        packed.copy_where(better, packed.state, best_state)
+                        best_err = torch.where(better, err, best_err)
+                        best_iter = torch.where(better, torch.full_like(best_iter, it), best_iter)  # nonlinear_optimizer.py:202
+                    if need_conv:
+                        small = self.reducer.device_mean_abs_below(err, p.abs_err_tolerance)
+                        converged = self._check_convergence(err, last_err) | small
+                        conv_iter = torch.where(converged & (conv_iter < 0), torch.full_like(conv_iter, it + 1), conv_iter)
+                        all_conv = self.reducer.device_all(converged.all()) & ~failed
+                        first_all_conv = torch.where(all_conv & (first_all_conv < 0),
+                                                     torch.full_like(first_all_conv, it + 1), first_all_conv)
+                        if poll is not None:
+                            poll.post(first_all_conv >= 0)
+                    last_err = err
+                    it += 1
+                # ---- the one host sync of the loop ----
+                f_fail, f_rej, f_conv = torch.stack([first_fail, first_all_rej, first_all_conv]).tolist()
+                before = lambda a, b: a >= 0 and (b < 0 or a < b)  # noqa: E731
+                if f_rej >= 0 and not before(f_fail, f_rej + 1) and not before(f_conv, f_rej + 1):
+                    replay = True      # the reference would have retried without counting the iteration
+                elif f_fail >= 0 and not before(f_conv, f_fail + 1):
+                    try:
+                        if raised is not None:
+                            raise raised
+                        self.linear_solver.check_info()
+                        raise RuntimeError("the linear solve failed on another shard of the batch")
+                    except RuntimeError as run_err:
+                        warn_failed(run_err)
+                    info.status[:] = NonlinearOptimizerStatus.FAIL   # (overrides every status: nonlinear_least_squares.py:147)
+                    it = f_fail
+                elif f_conv >= 0:
+                    it = f_conv        # the reference broke out of its loop here (:202-203)
+                    if err_hist is not None:
+                        err_hist[:, it + 1:] = inf
+                    converged = conv_iter.ge(0) & conv_iter.le(it)   # (later iterations only re-marked frozen problems)
+                    conv_iter = torch.where(converged, conv_iter, torch.full_like(conv_iter, -1))
+                if not replay:
+                    info.last_err = last_err   # (frozen / failed problems kept their error: this is the error AT ``it``)
+                    info.iters_done = it
+                else:
+                    # back to the start: state, lambda, bookkeeping -- then the synchronous path
+                    spare = packed.swap_state(start_state)
+                    self.reset(**kwargs, backward_mode=backward_mode)
+                    last_err, err_hist, info = fresh_info()
+                    if track_best_solution:
+                        packed.copy_where(torch.ones(B, dtype=torch.bool, device=dev), packed.state, best_state)
+                        best_err = last_err.clone()
+                        best_iter = torch.zeros(B, dtype=torch.long, device=dev)
+                    converged = None
+                    conv_iter = torch.full((B,), -1, dtype=torch.long, device=dev)
+                    it = 0
+            while (not sync_free or replay) and it < loop_iters:
                 lin.linearize()
                 try:
                     delta = self.compute_delta(**kwargs)
                 except RuntimeError as run_err:
-                    msg = f"There was an error while running the linear optimizer. Original error message: {run_err}."
-                    warnings.warn(msg, RuntimeWarning)
+                    warn_failed(run_err)
                     info.status[:] = NonlinearOptimizerStatus.FAIL
                     break
                 # retract (converged problems frozen) + error of the candidate, fused HIP kernels
@@ -270,8 +363,7 @@ class NonlinearLeastSquares(abc.ABC):
                         self.linear_solver.check_info()
                         raise RuntimeError("the linear solve failed on another shard of the batch")
                     except RuntimeError as run_err:
-                        warnings.warn(f"There was an error while running the linear optimizer. "
-                                      f"Original error message: {run_err}.", RuntimeWarning)
+                        warn_failed(run_err)
                     info.status[:] = NonlinearOptimizerStatus.FAIL
                     break
                 if reject is not None:
@@ -348,7 +440,7 @@ class NonlinearLeastSquares(abc.ABC):
                 info.iters_done = it
             packed.flush_variables()
             # ---- bookkeeping, one device->host copy ----
-            if converged is not None:
+            if converged is not None and not (info.status == NonlinearOptimizerStatus.FAIL).any():
                 cm = converged.cpu().numpy()
                 info.status[cm] = NonlinearOptimizerStatus.CONVERGED
                 info.converged_iter = conv_iter.cpu()

@@ -73,6 +73,19 @@ class LocalBatchReducer:
         """OR of a 0-dim bool tensor over the global batch, result stays on the device (no host sync)."""
         return flag
 
+    def device_all(self, flag: torch.Tensor) -> torch.Tensor:
+        """AND of a 0-dim bool tensor over the global batch, on the device."""
+        return ~self.device_any(~flag)
+
+    def device_mean_abs_below(self, err: torch.Tensor, tol: float) -> torch.Tensor:
+        """0-dim bool on the device: mean(|err|) over the GLOBAL batch < tol (nonlinear_optimizer.py:111)."""
+        s = self._sum_device(torch.stack([err.abs().sum().double(),
+                                          torch.tensor(float(err.numel()), dtype=torch.float64, device=err.device)]))
+        return (s[0] / s[1]) < tol
+
+    def _sum_device(self, t):
+        return t
+
     def _max(self, t):
         return t
 
@@ -95,6 +108,10 @@ class DistBatchReducer(LocalBatchReducer):
         t = flag.to(torch.int32).view(1)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)   # stream-ordered: the host does not wait
         return t.bool().view(())
+
+    def _sum_device(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)   # stream-ordered, no host wait
+        return t
 
     def _max(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)

@@ -3,7 +3,7 @@
 # usage: tools/variants.sh name1:"-DFLAG1 -DFLAG2" name2:"..."
 set -e
 ROOT=$(cd $(dirname $0)/.. && pwd)
-OUT=$ROOT/scratch/variants; mkdir -p $OUT
+OUT=${THX_VARIANT_DIR:-$ROOT/theseus_amd/lib/variants}; mkdir -p $OUT   # (theseus_amd/lib travels to the GPU box; scratch/ does not)
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   for f in pg_kernels chol_kernels vjp_kernels block_kernels pg2_kernels ba_kernels vjp2_kernels; do
