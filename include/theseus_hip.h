@@ -131,6 +131,23 @@ int thx_pg2_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, 
                 void* grad_w_between, void* grad_prior_target, void* grad_w_prior, void* grad_log_radius_between,
                 void* grad_log_radius_prior, int dtype, const thx_se2_eps* eps, void* stream);
 
+/* ---- SO3 variables (rotation-only graphs): theseus/geometry/so3.py over torchlie's SO3 closed forms
+ *      (torchlie/torchlie/functional/so3_impl.py:220-261 exp, :270-320 Jexp, :390-433 log, :442-479 Jlog; adjoint = R,
+ *      inverse = R^T, compose = R0 R1), group records of 9 (3x3 row major), tangents / weights of 3, 3x3 blocks, column
+ *      layout pose * 3; thx_pg_structure / thx_pg_data are shared (batch strides 9 / 3 / 0), thresholds = the so3_* ones of
+ *      thx_lie_eps.  thx_so3_op: 0 exp (a = w (N,3) -> out (N,3,3), jac (N,3,3) or NULL), 1 log (a = R -> out (N,3), jac),
+ *      2 compose (a, b -> out), 3 inverse, 4 adjoint (out (N,3,3)). */
+int thx_pgso3_assemble(const thx_pg_structure* s, const thx_pg_data* d, void* H, int64_t ld, void* g, int dtype,
+                       const thx_lie_eps* eps, void* stream);
+int thx_pgso3_error(const thx_pg_structure* s, const thx_pg_data* d, void* partials, void* err, int dtype,
+                    const thx_lie_eps* eps, void* stream);
+int thx_pgso3_jacobians(const thx_pg_structure* s, const thx_pg_data* d, void* J0, void* J1, void* eb, void* Jp,
+                        void* ep, int dtype, const thx_lie_eps* eps, void* stream);
+int thx_so3_retract(const void* poses, const void* delta, int64_t ldd, double step, const uint8_t* ignore_mask,
+                    void* out, int32_t P, int32_t B, int dtype, const thx_lie_eps* eps, void* stream);
+int thx_so3_op(int op, const void* a, const void* b, void* out, void* jac, int64_t N, int dtype,
+               const thx_lie_eps* eps, void* stream);
+
 /* ---- Linearization.linearize(): replaces DenseLinearization._linearize_jacobian_impl +
  *      _linearize_hessian_impl (dense_linearization.py:29-62) fused with Between / Local
  *      Jacobians (embodied/measurements/between.py:38-45, embodied/misc/local_cost_fn.py:58-61)

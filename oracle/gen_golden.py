@@ -103,7 +103,7 @@ def build_reference_objective(th, d, dtype):
     examples/pose_graph/pose_graph_synthetic.py:130-152."""
     B = d["poses"].shape[0]
     obj = th.Objective(dtype=dtype)
-    G = th.SE2 if d.get("group", "SE3") == "SE2" else th.SE3
+    G = {"SE2": th.SE2, "SO3": th.SO3}.get(d.get("group", "SE3"), th.SE3)
     poses = [G(tensor=d["poses"][:, k].clone(), name=f"pose_{k}") for k in range(d["P"])]
     for k in range(d["edges"].shape[0]):
         i, j = d["edges"][k].tolist()
@@ -326,6 +326,83 @@ def gen_se2(th):
         final = torch.stack([p_.tensor for p_ in pv], 1).numpy()
         np.savez_compressed(
             os.path.join(OUT, name + ".npz"), group=np.array("SE2"), P=P, edges=edges.numpy(), meas=meas.numpy(),
+            w_between=w_between.numpy(), prior_idx=prior_idx.numpy(), prior_target=prior_target.numpy(),
+            w_prior=w_prior.numpy(), poses0=poses.numpy(), final=final, err0=err0, err_history=info.err_history.numpy(),
+            AtA=np.stack(taps["AtA"][:1]), Atb=np.stack(taps["Atb"]), A0=taps["A"][0], b0=taps["b"][0],
+            delta=np.stack(taps["delta"]), last_err=np.stack(taps["err"]),
+            var_start_cols=np.array(lin.var_start_cols), var_dims=np.array(lin.var_dims), num_rows=lin.num_rows,
+            num_cols=lin.num_cols, opt_kwargs=np.array(repr(dict(ok, **lmk, gauss_newton=False))))
+        print(name, "err", err0.mean(), "->", info.err_history[:, -1].mean().item())
+
+
+def gen_so3(th, lieF):
+    """SO3 as a variable type of its own (theseus/geometry/so3.py over torchlie/functional/so3_impl.py): Lie-op fixtures incl. the
+    near-zero / d-near-zero / near-pi branches, and LM trajectories of rotation-only graphs (Between + Difference on th.SO3)
+    with DenseLinearization + CholeskyDenseSolver."""
+    gen = torch.Generator().manual_seed(29)
+    G = lieF.SO3
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        w = special_tangents(dtype, gen)[:, 3:].contiguous()          # the angle sweep of the SE3 fixtures, rotation part
+        jl = []
+        X = G.exp(w, jacobians=jl)
+        jexp = jl[0]
+        Y = G.exp(special_tangents(dtype, gen)[:, 3:].contiguous())
+        jl = []
+        log = G.log(X, jacobians=jl)
+        np.savez_compressed(os.path.join(OUT, f"lie_so3_{tag}.npz"), xi=w.numpy(), exp=X.numpy(), jexp=jexp.numpy(), log=log.numpy(),
+                            jlog=jl[0].numpy(), adj=G.adj(X).numpy(), inv=G.inv(X).numpy(), Y=Y.numpy(), compose=G.compose(X, Y).numpy())
+    cases = [
+        ("pg3_f64_lm", dict(P=9, E=16, B=4, dtype=torch.float64, seed=51), dict(max_iterations=6, step_size=1.0), dict(damping=1e-3)),
+        ("pg3_f32_lm", dict(P=9, E=16, B=8, dtype=torch.float32, seed=51), dict(max_iterations=6, step_size=1.0), dict(damping=1e-3)),
+        ("pg3_f64_lm_adaptive", dict(P=7, E=12, B=5, dtype=torch.float64, seed=53, batched_weights=True),
+         dict(max_iterations=8, step_size=0.8), dict(damping=1.0, adaptive_damping=True, ellipsoidal_damping=True)),
+    ]
+    for name, pk, ok, lmk in cases:
+        dtype, seed, P, E, B = pk["dtype"], pk["seed"], pk["P"], pk["E"], pk["B"]
+        gen = torch.Generator().manual_seed(seed)
+        rng = np.random.default_rng(seed)
+        edges = [(i, i + 1) for i in range(P - 1)]
+        while len(edges) < E:
+            i, j = sorted(rng.choice(P, 2, replace=False).tolist())
+            edges.append((j, i) if rng.random() < 0.3 else (i, j))
+        edges = torch.tensor(edges, dtype=torch.long)
+        rnd = lambda n, rs: G.exp(rs * (2 * torch.rand(n, 3, dtype=torch.float64, generator=gen) - 1))  # noqa: E731
+        gt = rnd(B * P, 2.5).view(B, P, 3, 3)
+        gi, gj = gt[:, edges[:, 0]].reshape(-1, 3, 3), gt[:, edges[:, 1]].reshape(-1, 3, 3)
+        meas = G.compose(G.compose(G.inv(gi), gj), rnd(B * E, 0.03)).view(B, E, 3, 3).to(dtype)
+        poses = G.compose(gt.reshape(-1, 3, 3), rnd(B * P, 0.25)).view(B, P, 3, 3).to(dtype)
+        if pk.get("batched_weights"):
+            w_between = ((0.5 + torch.rand(B, E, 3, dtype=torch.float64, generator=gen)) * 10).to(dtype)
+        else:
+            w_between = torch.tensor([[[1 / 0.03] * 3]], dtype=torch.float64).repeat(1, E, 1).to(dtype)
+        prior_idx = torch.tensor([0, P // 2], dtype=torch.long)
+        prior_target = G.compose(gt[:, prior_idx].reshape(-1, 3, 3), rnd(B * 2, 0.01)).view(B, 2, 3, 3).to(dtype)
+        w_prior = torch.tensor([[[1e-1] * 3, [2.0] * 3]], dtype=dtype)
+        obj = th.Objective(dtype=dtype)
+        pv = [th.SO3(tensor=poses[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+        for k in range(E):
+            i, j = edges[k].tolist()
+            cw = th.DiagonalCostWeight(th.Variable(w_between[:, k].clone(), name=f"w_{k}"))
+            obj.add(th.Between(pv[i], pv[j], th.SO3(tensor=meas[:, k].clone(), name=f"meas_{k}"), cw, name=f"between_{k}"))
+        for k in range(2):
+            sw = th.ScaleCostWeight(th.Variable(w_prior[:, k, :1].clone(), name=f"pw_{k}"))
+            obj.add(th.Difference(pv[int(prior_idx[k])], th.SO3(tensor=prior_target[:, k].clone(), name=f"tgt_{k}"), sw, name=f"prior_{k}"))
+        obj.update()
+        opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True,
+                                    abs_err_tolerance=0.0, rel_err_tolerance=0.0, **ok)
+        taps = dict(AtA=[], Atb=[], delta=[], A=[], b=[], err=[])
+
+        def cb(optimizer, info, delta, it):
+            lin = optimizer.linear_solver.linearization
+            for k_, v_ in (("AtA", lin.AtA), ("Atb", lin.Atb), ("A", lin.A), ("b", lin.b), ("delta", delta), ("err", info.last_err)):
+                taps[k_].append(v_.clone().numpy())
+        lin = opt.linear_solver.linearization
+        with torch.no_grad():
+            err0 = obj.error_metric().clone().numpy()
+            info = opt.optimize(track_err_history=True, end_iter_callback=cb, **lmk)
+        final = torch.stack([p_.tensor for p_ in pv], 1).numpy()
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"), group=np.array("SO3"), P=P, edges=edges.numpy(), meas=meas.numpy(),
             w_between=w_between.numpy(), prior_idx=prior_idx.numpy(), prior_target=prior_target.numpy(),
             w_prior=w_prior.numpy(), poses0=poses.numpy(), final=final, err0=err0, err_history=info.err_history.numpy(),
             AtA=np.stack(taps["AtA"][:1]), Atb=np.stack(taps["Atb"]), A0=taps["A"][0], b0=taps["b"][0],
@@ -660,6 +737,8 @@ def main():
         gen_implicit(th, lieF)
     if not only or "se2" in only:
         gen_se2(th)
+    if not only or "so3" in only:
+        gen_so3(th, lieF)
     if not only or "se2_implicit" in only:
         gen_se2_implicit(th)
     if not only or "pgo_kat" in only:

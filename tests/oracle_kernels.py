@@ -25,7 +25,7 @@ class OracleKernels:
                           meas=bm(t.meas), w_between=bm(t.w_between),
                           prior_idx=torch.from_numpy(h.prior_pose).long(),
                           prior_target=bm(t.prior_target), w_prior=bm(t.w_prior),
-                          group="SE2" if t.poses.dim() == 3 else "SE3",
+                          group="SE2" if t.poses.dim() == 3 else ("SO3" if t.poses.shape[-1] == 3 else "SE3"),
                           robust_between=LOSS[t.robust_between],
                           log_radius_between=bm(t.log_radius_between) if t.robust_between else None,
                           robust_prior=LOSS[t.robust_prior],
@@ -81,10 +81,30 @@ class OracleKernels:
         out.copy_(opg.retract(x, delta[:, :6 * poses.shape[0]] * step, ignore_mask=m).transpose(0, 1))
 
     def retract(self, poses, delta, step, ignore_mask, out):
-        if poses.dim() == 4:
+        if poses.dim() == 4 and poses.shape[-1] == 4:
             return self.se3_retract(poses, delta, step, ignore_mask, out)
         m = ignore_mask.bool() if ignore_mask is not None else None
         out.copy_(opg.retract(poses.transpose(0, 1), delta * step, ignore_mask=m).transpose(0, 1))
+
+    # ---- SO3 elementwise -------------------------------------------------------------------------
+    def so3_exp(self, w, jac=False):
+        from oracle import lie_so3
+        R, J = lie_so3.so3_exp_jexp(w)
+        return (R, J) if jac else R
+
+    def so3_log(self, R, jac=False):
+        from oracle import lie_so3
+        w, J = lie_so3.so3_log_jlog(R)
+        return (w, J) if jac else w
+
+    def so3_compose(self, X, Y):
+        return X @ Y
+
+    def so3_inverse(self, X):
+        return X.transpose(-1, -2).contiguous()
+
+    def so3_adjoint(self, X):
+        return X.clone()
 
     # ---- SE2 elementwise -------------------------------------------------------------------------
     def se2_exp(self, xi, jac=False):

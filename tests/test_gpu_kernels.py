@@ -88,8 +88,40 @@ def test_se2_ops_vs_reference_golden(K, tag, dtype):
     np.testing.assert_allclose(got["jexp"], g["jexp"], rtol=3e-5, atol=3e-5)
 
 
+@pytest.mark.parametrize("tag,dtype", [("f32", torch.float32), ("f64", torch.float64)])
+def test_so3_ops_vs_reference_golden(K, tag, dtype):
+    """thx_so3_op against the reference's SO3 outputs (torchlie so3_impl.py under theseus/geometry/so3.py), incl. the
+    near-zero / d-near-zero / near-pi branches; same criteria as the SE3 test."""
+    from oracle import lie_so3
+    from tests.helpers import f32_thresholds
+    g = load_golden(f"lie_so3_{tag}")
+    w = torch.from_numpy(g["xi"]).cuda()
+    X, J = K.so3_exp(w, jac=True)
+    Xg, Yg = torch.from_numpy(g["exp"]).cuda(), torch.from_numpy(g["Y"]).cuda()
+    lg, Jl = K.so3_log(Xg, jac=True)
+    got = dict(exp=X, jexp=J, log=lg, jlog=Jl, adj=K.so3_adjoint(Xg), inv=K.so3_inverse(Xg), compose=K.so3_compose(Xg, Yg))
+    got = {k: v.cpu().numpy() for k, v in got.items()}
+    if dtype == torch.float64:
+        for k, v in got.items():
+            np.testing.assert_allclose(v, g[k], rtol=1e-11, atol=1e-11, err_msg=k)
+        return
+    with f32_thresholds():
+        w64, X64, Y64 = (torch.from_numpy(g[k]).double() for k in ("xi", "exp", "Y"))
+        exact = dict(adj=lie_so3.so3_adjoint(X64), inv=lie_so3.so3_inverse(X64), compose=lie_so3.so3_compose(X64, Y64))
+        exact["exp"], exact["jexp"] = lie_so3.so3_exp_jexp(w64)
+        exact["log"], exact["jlog"] = lie_so3.so3_log_jlog(X64)
+    for k, ex in exact.items():
+        ex = ex.numpy()
+        rows = lambda a: np.abs(a).reshape(ex.shape[0], -1).max(1)  # noqa: E731
+        scale = np.maximum(1.0, rows(ex))
+        dev, ref_dev = rows(got[k] - ex), rows(g[k] - ex)
+        assert (dev <= 4e-7 * scale).all(), (k, (dev / scale).max())
+        assert (rows(got[k] - g[k]) <= ref_dev + 4e-7 * scale).all(), k
+
+
 CASES = ["pg_f64_lm", "pg_f32_lm", "pg_f32_lm_b16", "pg_f64_lm_adaptive_ellips", "pg_f64_gn",
-         "pg2_f64_lm", "pg2_f32_lm", "pg2_f64_lm_adaptive"]  # pg2_*: SE2 (thx_pg2_*)
+         "pg2_f64_lm", "pg2_f32_lm", "pg2_f64_lm_adaptive",   # pg2_*: SE2 (thx_pg2_*)
+         "pg3_f64_lm", "pg3_f32_lm", "pg3_f64_lm_adaptive"]   # pg3_*: SO3 (thx_pgso3_*)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -129,7 +161,7 @@ def test_assemble_error_jacobians_vs_reference_golden(K, name):
         # 2/theta^2 resp. 1/(theta (1-cosine)); the fixtures hold a residual rotation of 7.8e-3 rad -> 3e-12 resp.
         # 3e-10 relative: measured here 6e-11 of max|A|, 1.5e-11 of max|AtA|.  Two correct fp64 evaluations of the
         # reference's formula differ by that much, so SE2 is pinned at 1e-9 of scale (SE3: 5e-12, no such term).
-        r64 = 1e-9 if p.group == "SE2" else 5e-12
+        r64 = {"SE2": 1e-9, "SO3": 5e-11}.get(p.group, 5e-12)
         sc = np.abs(g["AtA"][0]).max()
         np.testing.assert_allclose(AtA, g["AtA"][0], rtol=0, atol=sc * r64)
         np.testing.assert_allclose(gv.cpu().numpy(), g["Atb"][0][..., 0], rtol=0, atol=np.abs(g["Atb"][0]).max() * r64)

@@ -16,7 +16,7 @@ def build_objective(th, g, device="cuda"):
     obj = th.Objective(dtype=dtype)
     P = int(g["P"])
     poses0 = t(g["poses0"])
-    G = th.SE2 if ("group" in g and str(g["group"]) == "SE2") else th.SE3
+    G = {"SE2": th.SE2, "SO3": th.SO3}.get(str(g["group"]) if "group" in g else "SE3", th.SE3)
     poses = [G(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
     for k in range(g["edges"].shape[0]):
         i, j = g["edges"][k].tolist()
@@ -35,7 +35,8 @@ def build_objective(th, g, device="cuda"):
 # differ by ~cond * 1e-16 * |delta| ~ 1e-8 on the weakly constrained components; 1e-7 absolute on poses.
 CASES = [("pg_f64_lm", 1e-7), ("pg_f64_gn", 1e-7), ("pg_f64_lm_adaptive", 1e-7),
          ("pg_f64_lm_adaptive_ellips", 1e-7), ("pg_f64_lm_adaptive_rejects", 1e-7),
-         ("pg2_f64_lm", 1e-7), ("pg2_f64_lm_adaptive", 1e-7)]  # pg2_*: SE2 pose graphs (theseus/geometry/se2.py)
+         ("pg2_f64_lm", 1e-7), ("pg2_f64_lm_adaptive", 1e-7),   # pg2_*: SE2 pose graphs (theseus/geometry/se2.py)
+         ("pg3_f64_lm", 1e-7), ("pg3_f64_lm_adaptive", 1e-7)]   # pg3_*: SO3 rotation graphs (theseus/geometry/so3.py)
 
 
 def well_conditioned_steps(g, n_iters):
@@ -101,7 +102,7 @@ def test_lm_trajectory_matches_reference(name, tol):
     assert all(s == th.NonlinearOptimizerStatus.MAX_ITERATIONS for s in info.status)
 
 
-@pytest.mark.parametrize("name", ["pg_f32_lm", "pg_f32_lm_b16", "pg2_f32_lm"])
+@pytest.mark.parametrize("name", ["pg_f32_lm", "pg_f32_lm_b16", "pg2_f32_lm", "pg3_f32_lm"])
 def test_lm_trajectory_fp32_inside_reference_band(name):
     """fp32 parity.  The reference's fp32 path is a noisy evaluation (catastrophic cancellation in the
     torchlie log coefficients, fp32 potrf): its trajectory sits at a distance dev_ref from the exact
@@ -139,7 +140,7 @@ def test_lm_trajectory_fp32_inside_reference_band(name):
     assert rel <= 1.5 * rel_ref + 1e-6, (rel, rel_ref)
 
 
-@pytest.mark.parametrize("name", ["pg_f64_lm", "pg2_f64_lm"])
+@pytest.mark.parametrize("name", ["pg_f64_lm", "pg2_f64_lm", "pg3_f64_lm"])
 def test_first_linearization_properties_match_reference(name):
     import theseus_amd as th
     g = load_golden(name)
@@ -149,7 +150,7 @@ def test_first_linearization_properties_match_reference(name):
     obj.update()
     lin.linearize()
     sc = np.abs(g["AtA"][0]).max()
-    r64 = 1e-9 if name.startswith("pg2") else 5e-12   # SE2: see tests/test_gpu_kernels.py (Jlog conditioning)
+    r64 = 1e-9 if name.startswith("pg2") else (5e-11 if name.startswith("pg3") else 5e-12)   # SE2: see tests/test_gpu_kernels.py (Jlog conditioning)
     np.testing.assert_allclose(lin.AtA.cpu().numpy(), g["AtA"][0], rtol=0, atol=sc * r64)
     np.testing.assert_allclose(lin.Atb.cpu().numpy(), g["Atb"][0], rtol=0, atol=np.abs(g["Atb"][0]).max() * r64)
     np.testing.assert_allclose(lin.A.cpu().numpy(), g["A0"], rtol=0, atol=np.abs(g["A0"]).max() * max(r64, 1e-11))

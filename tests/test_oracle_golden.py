@@ -222,3 +222,40 @@ def test_multi_tile_bundle_adjustment_matches_reference(name, tol):
     np.testing.assert_allclose(cams.numpy(), g["final_cams"], rtol=0, atol=tol * 10)
     np.testing.assert_allclose(pts.numpy(), g["final_pts"][:, used], rtol=0, atol=tol * 100)
     np.testing.assert_allclose(info.deltas[0].numpy(), g["delta"][0], rtol=0, atol=(1e-2 if f32 else 1e-7) * max(1.0, np.abs(g["delta"][0]).max()))
+
+
+@pytest.mark.parametrize("tag,dtype,tol", [("f32", torch.float32, 3e-5), ("f64", torch.float64, 1e-12)])
+def test_so3_ops_match_reference(tag, dtype, tol):
+    from oracle import lie_so3
+    g = load_golden(f"lie_so3_{tag}")
+    w, X, Y = (torch.from_numpy(g[k]) for k in ("xi", "exp", "Y"))
+    assert w.dtype == dtype
+    R, J = lie_so3.so3_exp_jexp(w)
+    np.testing.assert_allclose(R.numpy(), g["exp"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(J.numpy(), g["jexp"], rtol=tol, atol=tol)
+    log, jlog = lie_so3.so3_log_jlog(X)
+    np.testing.assert_allclose(log.numpy(), g["log"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(jlog.numpy(), g["jlog"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(lie_so3.so3_adjoint(X).numpy(), g["adj"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(lie_so3.so3_inverse(X).numpy(), g["inv"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(lie_so3.so3_compose(X, Y).numpy(), g["compose"], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("name,tol", [("pg3_f64_lm", 5e-8), ("pg3_f64_lm_adaptive", 5e-8), ("pg3_f32_lm", 2e-3)])
+def test_so3_pose_graph_matches_reference(name, tol):
+    g = load_golden(name)
+    p, poses0, kw = golden_problem(g)
+    assert p.group == "SO3" and p.n == int(g["num_cols"]) and p.m == int(g["num_rows"])
+    A, b = opg.dense_linearize(p, poses0)
+    f32 = tol > 1e-6
+    np.testing.assert_allclose(A.numpy(), g["A0"], atol=np.abs(g["A0"]).max() * (1e-5 if f32 else 1e-12))
+    np.testing.assert_allclose(b.numpy(), g["b0"], atol=np.abs(g["b0"]).max() * (1e-5 if f32 else 1e-12))
+    AtA, Atb = opg.hessian(A, b)
+    np.testing.assert_allclose(AtA.numpy(), g["AtA"][0], rtol=0, atol=np.abs(g["AtA"][0]).max() * (1e-5 if f32 else 1e-12))
+    np.testing.assert_allclose(opg.error_metric(p, poses0).numpy(), g["err0"], rtol=1e-5 if f32 else 1e-12)
+    final, info = opg.lm_optimize(p, poses0, abs_err_tolerance=0.0, rel_err_tolerance=0.0, keep_taps=True, **kw)
+    np.testing.assert_allclose(final.numpy(), g["final"], rtol=0, atol=tol)
+    if len(info.deltas) == g["delta"].shape[0]:
+        for it in range(len(info.deltas)):
+            np.testing.assert_allclose(info.deltas[it].numpy(), g["delta"][it], rtol=0,
+                                       atol=tol * max(1.0, np.abs(g["delta"][it]).max()))

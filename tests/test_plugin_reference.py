@@ -55,7 +55,7 @@ def _objective(th, g):
 
 
 @pytest.mark.parametrize("name", ["pg_f64_lm", "pg_f64_lm_adaptive_ellips", "pg_f64_lm_adaptive_rejects", "pg_f64_gn",
-                                  "pg2_f64_lm", "pg2_f64_lm_adaptive"])
+                                  "pg2_f64_lm", "pg2_f64_lm_adaptive", "pg3_f64_lm", "pg3_f64_lm_adaptive"])
 def test_reference_loop_drives_the_plugin(ref, name):
     th, thp = ref
     from tests.oracle_kernels import OracleKernels

@@ -128,7 +128,7 @@ def test_two_rank_sharded_lm_equals_unsharded(name, perm, overrides):
         np.testing.assert_allclose(o["gathered"].transpose(0, 1).numpy(), ref_final.numpy(), rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("name", ["pg_f64_lm_adaptive_ellips", "pg2_f64_lm_adaptive", "pg2_f64_lm"])
+@pytest.mark.parametrize("name", ["pg_f64_lm_adaptive_ellips", "pg2_f64_lm_adaptive", "pg2_f64_lm", "pg3_f64_lm", "pg3_f64_lm_adaptive"])
 def test_reference_trajectory_with_standin_kernels(name):
     """The stand-in + the host LM loop reproduce the REAL reference's recorded trajectory: the host loop is
     the reference's control flow (this is what the GPU tests check with the HIP kernels plugged in)."""

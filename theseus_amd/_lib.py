@@ -19,7 +19,7 @@ THX_TILE = 128
 THX_ERR_CHUNKS = 16
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class LieEps(Structure):
@@ -95,6 +95,14 @@ _SIGNATURES = {
     "thx_se2_retract": [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p, c_int32, c_int32, c_int,
                         POINTER(SE2Eps), c_void_p],
     "thx_se2_op": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(SE2Eps), c_void_p],
+    "thx_pgso3_assemble": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_int64, c_void_p, c_int, POINTER(LieEps),
+                           c_void_p],
+    "thx_pgso3_error": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
+    "thx_pgso3_jacobians": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                            POINTER(LieEps), c_void_p],
+    "thx_so3_retract": [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p, c_int32, c_int32, c_int,
+                        POINTER(LieEps), c_void_p],
+    "thx_so3_op": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(LieEps), c_void_p],
     "thx_ba_assemble": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                         c_int, POINTER(LieEps), c_void_p],
     "thx_ba_schur": [POINTER(BAStructure), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_double,

@@ -287,6 +287,75 @@ class SE2(Variable):
         return SE2(tensor=self.tensor.clone(), name=new_name or f"{self.name}_copy")
 
 
+class SO3(Variable):
+    """SO3 group element batch, tensor (B,3,3); tangent w (3); right perturbations (theseus/geometry/so3.py:20-186 over
+    torchlie/torchlie/functional/so3_impl.py)."""
+
+    def __init__(self, quaternion: Optional[torch.Tensor] = None, tensor: Optional[torch.Tensor] = None,
+                 name: Optional[str] = None, dtype: Optional[torch.dtype] = None):
+        if quaternion is not None and tensor is not None:
+            raise ValueError("Please provide only one of quaternion or tensor.")
+        if quaternion is not None:
+            if quaternion.ndim == 1:
+                quaternion = quaternion.unsqueeze(0)
+            tensor = SE3._from_x_y_z_quaternion(torch.cat([quaternion.new_zeros(quaternion.shape[0], 3), quaternion], 1))[:, :, :3]
+        if tensor is None:
+            tensor = torch.eye(3, dtype=dtype or torch.get_default_dtype()).unsqueeze(0)
+        if tensor.ndim == 2:
+            tensor = tensor.unsqueeze(0)
+        if tensor.ndim != 3 or tensor.shape[1:] != (3, 3):
+            raise ValueError("SO3 data tensors can only be 3x3 matrices.")
+        if dtype is not None and tensor.dtype != dtype:
+            tensor = tensor.to(dtype)
+        super().__init__(tensor, name)
+
+    @staticmethod
+    def dof() -> int:
+        return 3
+
+    @staticmethod
+    def exp_map(tangent_vector: torch.Tensor, jacobians: Optional[List[torch.Tensor]] = None) -> "SO3":
+        if tangent_vector.ndim != 2 or tangent_vector.shape[1] != 3:
+            raise ValueError("Tangent vectors of SO3 should be 3-D vectors.")
+        K = default_kernels()
+        if jacobians is not None:
+            X, J = K.so3_exp(tangent_vector, jac=True)
+            jacobians.append(J)
+        else:
+            X = K.so3_exp(tangent_vector)
+        return SO3(tensor=X)
+
+    def log_map(self, jacobians: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+        K = default_kernels()
+        if jacobians is not None:
+            w, J = K.so3_log(self.tensor, jac=True)
+            jacobians.append(J)
+            return w
+        return K.so3_log(self.tensor)
+
+    def adjoint(self) -> torch.Tensor:
+        return self.tensor.clone()   # so3.py:99-100
+
+    def inverse(self) -> "SO3":
+        return SO3(tensor=default_kernels().so3_inverse(self.tensor))
+
+    def compose(self, other: "SO3") -> "SO3":
+        a, b = _broadcast_pair(self.tensor, other.tensor)
+        return SO3(tensor=default_kernels().so3_compose(a, b))
+
+    def between(self, other: "SO3") -> "SO3":
+        return self.inverse().compose(other)
+
+    def local(self, other: "SO3") -> torch.Tensor:
+        return self.between(other).log_map()
+
+    def retract(self, delta: torch.Tensor) -> "SO3":
+        return self.compose(SO3.exp_map(delta))
+
+    def copy(self, new_name: Optional[str] = None) -> "SO3":
+        return SO3(tensor=self.tensor.clone(), name=new_name or f"{self.name}_copy")
+
+
 def _broadcast_pair(a, b):
     if a.shape[0] != b.shape[0]:
         if a.shape[0] == 1:

@@ -416,10 +416,17 @@ struct Engine<double> {
 // Optional rider on the SYRK K-loop of chol_diag: the panel rows L_j,0:j pass through LDS anyway, so
 // t[r] = sum_k L[row0+r][k] y[k] (the forward-substitution update) costs 16 VALU FMAs per thread and
 // chunk in the shadow of the MFMAs.  Thread pair (2r, 2r+1) splits the chunk's k range in two.
-template <typename T, bool SAME, bool GEMV, int LDT, typename Compute>
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// ``after_issue`` runs right after the loads of the first k-chunk(s) have been ISSUED: whatever else a kernel wants in
+// flight before its K-loop (H tile, solve panel) goes there, so that its latency overlaps the first chunk's instead of
+// preceding it.
+template <typename T, bool SAME, bool GEMV, int LDT, typename Compute, typename Hook = NoHook>
 __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA, const T* __restrict__ Brows,
                                         int validB, int64_t ld, int K, T* sA, T* sB, int tid, const T* gemv_y,
-                                        T* gemv_part, Compute&& compute) {
+                                        T* gemv_part, Compute&& compute, Hook&& after_issue = NoHook{}) {
   using C = CT<T>;
   using V = typename C::V;
   const int lrow = tid >> 3, lc = tid & 7;
@@ -510,6 +517,7 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
 #pragma unroll
   for (int a = 0; a < AHEAD; ++a)
     if (a < nk) gload(ra[a], rb[a], a * C::KB);
+  after_issue();
   for (int kc = 0; kc < nk; kc += AHEAD) {
     step(ra[0], rb[0], kc);
     if constexpr (AHEAD == 2) {
@@ -521,15 +529,15 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   }
 }
 
-template <typename T, bool SAME, bool GEMV = false>
+template <typename T, bool SAME, bool GEMV = false, typename Hook = NoHook>
 __device__ __forceinline__ void kloop(const T* __restrict__ Arows, int validA, const T* __restrict__ Brows,
                                       int validB, int64_t ld, int K, T* sA, T* sB,
                                       typename Engine<T>::Acc& acc, int tid, const T* gemv_y = nullptr,
-                                      T* gemv_part = nullptr) {
+                                      T* gemv_part = nullptr, Hook&& after_issue = NoHook{}) {
   const int wave = tid >> 6, lane = tid & 63;
   kloop_f<T, SAME, GEMV, CT<T>::LDT>(Arows, validA, Brows, validB, ld, K, sA, sB, tid, gemv_y, gemv_part, [&]() __attribute__((always_inline)) {
     Engine<T>::chunk(sA, (SAME ? sA : sB) + 32 * wave * CT<T>::LDT, acc, lane);
-  });
+  }, after_issue);
 }
 
 
@@ -941,8 +949,6 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 #define THX_STAMP()
 #endif
   THX_STAMP();
-  if (fwd)
-    for (int k = tid; k < row0; k += 256) ybuf[k] = yout[(int64_t)b * ldv + k];  // y_0:j of earlier columns
 
   // SYRK on the 36 lower 16x16 blocks of the tile, nine per wave (Engine<T>::syrk36)
   typename E::Sy acc[9];
@@ -952,20 +958,32 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
     for (int k = 0; k < 4; ++k) acc[i][k] = T(0);
   T tpart = T(0);  // this thread's half of (L_j,0:j y)[tid >> 1]
   std::conditional_t<sizeof(T) == 4, float4, f64x4> hpre[9];
-  {  // H_jj blocks in flight during the whole K-loop
+  // issued behind the loads of the first k-chunk (kloop_f's after_issue hook): y_0:j of the earlier columns -> LDS, and the
+  // H_jj blocks, in flight during the whole K-loop
+  auto prologue = [&]() __attribute__((always_inline)) {
+    if (fwd)
+      for (int k = tid; k < row0; k += 256) ybuf[k] = yout[(int64_t)b * ldv + k];
     const T* Hjj = H + mat + (int64_t)row0 * ld + row0;
     if (wave == 0) E::template syrk36_prefetch<0>(Hjj, ld, valid, hpre, lane);
     else if (wave == 1) E::template syrk36_prefetch<1>(Hjj, ld, valid, hpre, lane);
     else if (wave == 2) E::template syrk36_prefetch<2>(Hjj, ld, valid, hpre, lane);
     else E::template syrk36_prefetch<3>(Hjj, ld, valid, hpre, lane);
-  }
+  };
+#ifdef THX_OFF_PROLOGUE_FIRST   // the round-1 order (A/B timing)
+  prologue();
+#endif
   kloop_f<T, true, true, E::SYRK_LDT>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, row0, tile, nullptr, tid,
                          fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
     if (wave == 0) E::template syrk36<0>(tile, acc, lane);
     else if (wave == 1) E::template syrk36<1>(tile, acc, lane);
     else if (wave == 2) E::template syrk36<2>(tile, acc, lane);
     else E::template syrk36<3>(tile, acc, lane);
-  });
+  },
+#ifdef THX_OFF_PROLOGUE_FIRST
+  NoHook{});
+#else
+  prologue);
+#endif
 
   // ---- S = H_jj (+ damping on the diagonal) - acc -> LDS tile; identity padding outside the matrix ----
   __syncthreads();  // staging buffer is free
@@ -1193,34 +1211,40 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   st[0] = (long long)__builtin_readcyclecounter();
   const long long wc0 = (long long)wall_clock64();
 #endif
-  // ---- prefetch: panel sub-blocks (s,t), t <= s, then the H tile ----
+  // ---- prefetch: panel sub-blocks (s,t), t <= s, then the H tile.  Issued from inside the K-loop's prologue, AFTER the
+  //      loads of the first k-chunk: one exposed memory latency per workgroup instead of two (in-kernel stamps: 8.8-11.2 k
+  //      cycles from kernel entry to the first MFMA, profiles/r2/a_offdiag_stamps.txt) ----
   // (a "lean" variant without any prefetch -- 40 KB LDS, 168 VGPRs, three workgroups per CU -- measured 1-2 % SLOWER:
   //  the K-loop's 82 % MFMA-busy is not an occupancy problem)
-  uint4 pr[10];
-  {
-    const float* Pn = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
-    const int pi = tid >> 3, pc = tid & 7;
-    constexpr int SB[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3}, TB[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
-#pragma unroll
-    for (int k = 0; k < 10; ++k)
-      pr[k] = *reinterpret_cast<const uint4*>(Pn + (32 * SB[k] + pi) * TILE + 32 * TB[k] + 4 * pc);
-  }
   const int r = 32 * wave + (lane & 31), g = lane >> 5;
   const bool rvalid = r < validB;
   float4 hr[4][4];
-  {
-    const float* Hrow = H + mat + (int64_t)(row0 + (rvalid ? r : 0)) * ld + col0 + 4 * g;
+  auto prologue = [&]() __attribute__((always_inline)) {
+    {
+      const float* Hrow = H + mat + (int64_t)(row0 + (rvalid ? r : 0)) * ld + col0 + 4 * g;
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+      for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) hr[cb][q] = *reinterpret_cast<const float4*>(Hrow + 32 * cb + 8 * q);
-  }
-  {
-    const int pi = tid >> 3, pc = tid & 7;
-    float* dst = Pc + pi * 32 + ((pc ^ ((pi >> 1) & 7)) << 2);
-#pragma unroll
-    for (int k = 0; k < 10; ++k) *reinterpret_cast<uint4*>(dst + k * 1024) = pr[k];
-  }
+        for (int q = 0; q < 4; ++q) hr[cb][q] = *reinterpret_cast<const float4*>(Hrow + 32 * cb + 8 * q);
+    }
+    {  // panel: global -> LDS (swizzled), one 16-byte piece of each of the ten sub-blocks per thread
+      const float* Pn = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
+      const int pi = tid >> 3, pc = tid & 7;
+      float* dst = Pc + pi * 32 + ((pc ^ ((pi >> 1) & 7)) << 2);
+      const float* src = Pn + pi * TILE + 4 * pc;
+      static_for<4>([&](auto is) __attribute__((always_inline)) {
+        constexpr int sb = decltype(is)::value;
+        static_for<sb + 1>([&](auto it) __attribute__((always_inline)) {
+          constexpr int tb = decltype(it)::value;
+          *reinterpret_cast<uint4*>(dst + (sb * (sb + 1) / 2 + tb) * 1024) =
+              *reinterpret_cast<const uint4*>(src + 32 * sb * TILE + 32 * tb);
+        });
+      });
+    }
+  };
+#ifdef THX_OFF_PROLOGUE_FIRST   // the round-1 order (A/B timing): panel + H loads and the panel copy BEFORE the first chunk's loads
+  prologue();
+#endif
 
   Engine<float>::Acc P;
   Engine<float>::zero(P);
@@ -1229,7 +1253,12 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
 #endif
   // (two LDS staging buffers with ONE barrier per k-chunk instead of one buffer with two -- panel copy moved behind the
   //  loop to keep 2 workgroups/CU -- measured the same 9.3-9.4 k cycles per chunk: the barriers are not the K-loop's limit)
+#ifdef THX_OFF_PROLOGUE_FIRST
   kloop<float, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, col0, sA, sB, P, tid);
+#else
+  kloop<float, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, col0, sA, sB, P, tid,
+                      nullptr, nullptr, prologue);
+#endif
 #ifdef THX_OFF_PROF
   __builtin_amdgcn_sched_barrier(0);
   st[2] = (long long)__builtin_readcyclecounter();

@@ -1,274 +1,32 @@
-// SE2 pose-graph kernels (2-D SLAM): the SE3 kernels of pg_kernels.hip with the SE2 group functor of lie_se2.cuh --
-// same mapping (one lane per (pose | edge, problem), batch index fastest, owner-computes assembly, no atomics),
-// 3x3 blocks instead of 6x6, 4-element records instead of 3x4.  All Lie arithmetic in fp64 registers.
+// SE2 pose-graph kernels (2-D SLAM): the generic 3-dof kernels of pg3_generic.cuh instantiated with the SE2 group functor
+// of lie_se2.cuh (4-element records [x, y, cos, sin], 3x3 blocks).
 #include "common.cuh"
 #include "lie_se2.cuh"
-#include "robust.cuh"
+#include "pg3_generic.cuh"
 
 namespace thx {
 
-using E2 = Eps2<double>;
-static inline E2 make_eps2(const thx_se2_eps* e, int dtype) {
+struct GroupSE2 {
+  static constexpr int REC = 4;
+  using X = SE2<double>;
+  using Eps = Eps2<double>;
+  template <typename T>
+  static __device__ __forceinline__ X load(const T* __restrict__ p) { return se2_load(p); }
+  template <typename T>
+  static __device__ __forceinline__ void store(T* __restrict__ p, const X& x) { se2_store(p, x); }
+  static __device__ __forceinline__ void inv(const X& a, X& y) { se2_inv(a, y); }
+  static __device__ __forceinline__ void mul(const X& a, const X& b, X& z) { se2_mul(a, b, z); }
+  static __device__ __forceinline__ void exp(const double* xi, const Eps& eps, X& x, double* J) { se2_exp<double>(xi, eps, x, J); }
+  static __device__ __forceinline__ void log_jlog(const X& x, const Eps& eps, double* xi, double* J, bool want_jac) {
+    se2_log_jlog(x, eps, xi, J, want_jac);
+  }
+  static __device__ __forceinline__ void adjoint(const X& x, double* A) { se2_adjoint(x, A); }
+};
+
+static inline Eps2<double> make_eps2(const thx_se2_eps* e, int dtype) {
   // the reference compares an fp32 angle with the fp32-rounded threshold
-  return dtype == THX_F32 ? E2{(double)(float)e->near_zero, (double)(float)e->d_near_zero} : E2{e->near_zero, e->d_near_zero};
-}
-
-__device__ __forceinline__ void m3_tmul_acc(const double* P, const double* Q, double* B) {  // B += P^T Q
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) B[3 * i + j] += P[i] * Q[j] + P[3 + i] * Q[3 + j] + P[6 + i] * Q[6 + j];
-}
-__device__ __forceinline__ void m3_tvec_sub(const double* P, const double* e, double* g) {  // g -= P^T e
-#pragma unroll
-  for (int i = 0; i < 3; ++i) g[i] -= P[i] * e[0] + P[3 + i] * e[1] + P[6 + i] * e[2];
-}
-template <typename T>
-__device__ __forceinline__ void robustify2(int kind, const void* lr, int64_t lr_bs, int64_t entity, int b, int B,
-                                           double* ev, double* J0, double* J1) {
-  if (kind == THX_LOSS_NONE) return;
-  const double f = robust_rescale<3>(kind, ev, load_log_radius<T>(lr, entity, b, B, lr_bs));
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    if (J0) J0[i] *= f;
-    if (J1) J1[i] *= f;
-  }
-  ev[0] *= f; ev[1] *= f; ev[2] *= f;
-}
-template <typename T>
-__device__ __forceinline__ void load3(const T* __restrict__ p, double* w) {
-  w[0] = (double)p[0]; w[1] = (double)p[1]; w[2] = (double)p[2];
-}
-
-template <typename T>
-__global__ void __launch_bounds__(64)
-pg2_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t ld, T* __restrict__ g, E2 eps) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  const int p = blockIdx.y;
-  const int B = d.batch;
-  if (b >= B) return;
-  const T* poses = static_cast<const T*>(d.poses);
-  const T* meas = static_cast<const T*>(d.meas);
-  const T* wb = static_cast<const T*>(d.w_between);
-  const SE2<double> Xp = se2_load(poses + ((int64_t)p * B + b) * 4);
-  double Dg[9], Off[9], gv[3];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) { Dg[i] = 0.0; Off[i] = 0.0; }
-  gv[0] = gv[1] = gv[2] = 0.0;
-  T* Hb = H + (int64_t)b * ld * ld;
-  auto flush = [&](int q) __attribute__((always_inline)) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) Hb[(int64_t)(3 * p + r) * ld + 3 * q + c] = (T)Off[3 * r + c];
-  };
-  const int64_t mB = d.meas_bstride ? B : 1, wB = d.w_between_bstride ? B : 1;
-  int cur_q = -1;
-  for (int k = s.inc_ptr[p]; k < s.inc_ptr[p + 1]; ++k) {
-    const int e = s.inc_edge[k], side = s.inc_side[k], q = s.inc_other[k];
-    const SE2<double> Xq = se2_load(poses + ((int64_t)q * B + b) * 4);
-    const SE2<double> M = se2_load(meas + ((int64_t)e * mB) * 4 + (int64_t)b * d.meas_bstride);
-    double w[3], ev[3], J0[9], J1[9];
-    load3(wb + ((int64_t)e * wB) * 3 + (int64_t)b * d.w_between_bstride, w);
-    const bool lower = q < p;
-    if (lower && q != cur_q) {
-      if (cur_q >= 0) flush(cur_q);
-#pragma unroll
-      for (int i = 0; i < 9; ++i) Off[i] = 0.0;
-      cur_q = q;
-    }
-    if (side == 0) {
-      between_eval2(Xp, Xq, M, w, eps, ev, J0, J1, true);
-      robustify2<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, J0, J1);
-      m3_tmul_acc(J0, J0, Dg);
-      m3_tvec_sub(J0, ev, gv);
-      if (lower) m3_tmul_acc(J0, J1, Off);
-    } else {
-      between_eval2(Xq, Xp, M, w, eps, ev, J0, J1, true);
-      robustify2<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, J0, J1);
-      m3_tmul_acc(J1, J1, Dg);
-      m3_tvec_sub(J1, ev, gv);
-      if (lower) m3_tmul_acc(J1, J0, Off);
-    }
-  }
-  if (cur_q >= 0) flush(cur_q);
-  const T* tgt = static_cast<const T*>(d.prior_target);
-  const T* wp = static_cast<const T*>(d.w_prior);
-  const int64_t tB = d.prior_target_bstride ? B : 1, wpB = d.w_prior_bstride ? B : 1;
-  for (int k = s.pri_ptr[p]; k < s.pri_ptr[p + 1]; ++k) {
-    const int id = s.pri_id[k];
-    const SE2<double> Tg = se2_load(tgt + ((int64_t)id * tB) * 4 + (int64_t)b * d.prior_target_bstride);
-    double w[3], ev[3], J[9];
-    load3(wp + ((int64_t)id * wpB) * 3 + (int64_t)b * d.w_prior_bstride, w);
-    local_eval2(Tg, Xp, w, eps, ev, J, true);
-    robustify2<T>(d.robust_prior, d.log_radius_prior, d.log_radius_prior_bstride, id, b, B, ev, J, nullptr);
-    m3_tmul_acc(J, J, Dg);
-    m3_tvec_sub(J, ev, gv);
-  }
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) Hb[(int64_t)(3 * p + r) * ld + 3 * p + c] = (T)Dg[3 * r + c];
-  T* gb = g + (int64_t)b * (3 * s.num_poses) + 3 * p;
-  gb[0] = (T)gv[0]; gb[1] = (T)gv[1]; gb[2] = (T)gv[2];
-}
-
-template <typename T>
-__global__ void __launch_bounds__(64)
-pg2_error_partial_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ partials, E2 eps) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  const int ch = blockIdx.y;
-  const int B = d.batch;
-  if (b >= B) return;
-  const T* poses = static_cast<const T*>(d.poses);
-  double acc = 0.0;
-  const int E = s.num_edges, K = s.num_priors;
-  const int ec = (E + THX_ERR_CHUNKS - 1) / THX_ERR_CHUNKS, e1 = min(E, (ch + 1) * ec);
-  const int64_t mB = d.meas_bstride ? B : 1, wB = d.w_between_bstride ? B : 1;
-  for (int e = ch * ec; e < e1; ++e) {
-    const SE2<double> Xi = se2_load(poses + ((int64_t)s.edge_i[e] * B + b) * 4);
-    const SE2<double> Xj = se2_load(poses + ((int64_t)s.edge_j[e] * B + b) * 4);
-    const SE2<double> M = se2_load(static_cast<const T*>(d.meas) + ((int64_t)e * mB) * 4 + (int64_t)b * d.meas_bstride);
-    double w[3], ev[3];
-    load3(static_cast<const T*>(d.w_between) + ((int64_t)e * wB) * 3 + (int64_t)b * d.w_between_bstride, w);
-    between_eval2<double>(Xi, Xj, M, w, eps, ev, nullptr, nullptr, false);
-    acc += robust_sq_error<3>(d.robust_between, ev,
-                              d.robust_between ? load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride) : 0.0);
-  }
-  const int kc = (K + THX_ERR_CHUNKS - 1) / THX_ERR_CHUNKS, k1 = min(K, (ch + 1) * kc);
-  const int64_t tB = d.prior_target_bstride ? B : 1, wpB = d.w_prior_bstride ? B : 1;
-  for (int k = ch * kc; k < k1; ++k) {
-    const SE2<double> X = se2_load(poses + ((int64_t)s.prior_pose[k] * B + b) * 4);
-    const SE2<double> Tg = se2_load(static_cast<const T*>(d.prior_target) + ((int64_t)k * tB) * 4 + (int64_t)b * d.prior_target_bstride);
-    double w[3], ev[3];
-    load3(static_cast<const T*>(d.w_prior) + ((int64_t)k * wpB) * 3 + (int64_t)b * d.w_prior_bstride, w);
-    local_eval2<double>(Tg, X, w, eps, ev, nullptr, false);
-    acc += robust_sq_error<3>(d.robust_prior, ev,
-                              d.robust_prior ? load_log_radius<T>(d.log_radius_prior, k, b, B, d.log_radius_prior_bstride) : 0.0);
-  }
-  partials[(int64_t)ch * B + b] = (T)acc;
-}
-
-template <typename T>
-__global__ void pg2_error_reduce_kernel(const T* __restrict__ partials, T* __restrict__ err, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  T acc = T(0);
-#pragma unroll
-  for (int c = 0; c < THX_ERR_CHUNKS; ++c) acc += partials[(int64_t)c * B + b];
-  err[b] = T(0.5) * acc;
-}
-
-template <typename T>
-__global__ void __launch_bounds__(64)
-pg2_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* __restrict__ J1o, T* __restrict__ ebo,
-                     T* __restrict__ Jpo, T* __restrict__ epo, E2 eps) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  const int c = blockIdx.y;
-  const int B = d.batch;
-  if (b >= B) return;
-  const T* poses = static_cast<const T*>(d.poses);
-  double ev[3], J0[9], J1[9], w[3];
-  if (c < s.num_edges) {
-    const int e = c;
-    const int64_t mB = d.meas_bstride ? B : 1, wB = d.w_between_bstride ? B : 1;
-    const SE2<double> Xi = se2_load(poses + ((int64_t)s.edge_i[e] * B + b) * 4);
-    const SE2<double> Xj = se2_load(poses + ((int64_t)s.edge_j[e] * B + b) * 4);
-    const SE2<double> M = se2_load(static_cast<const T*>(d.meas) + ((int64_t)e * mB) * 4 + (int64_t)b * d.meas_bstride);
-    load3(static_cast<const T*>(d.w_between) + ((int64_t)e * wB) * 3 + (int64_t)b * d.w_between_bstride, w);
-    between_eval2(Xi, Xj, M, w, eps, ev, J0, J1, true);
-    robustify2<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, J0, J1);
-    const int64_t o = (int64_t)e * B + b;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      if (J0o) J0o[o * 9 + k] = (T)J0[k];
-      if (J1o) J1o[o * 9 + k] = (T)J1[k];
-    }
-    if (ebo) { ebo[o * 3] = (T)ev[0]; ebo[o * 3 + 1] = (T)ev[1]; ebo[o * 3 + 2] = (T)ev[2]; }
-  } else {
-    const int k = c - s.num_edges;
-    const int64_t tB = d.prior_target_bstride ? B : 1, wB = d.w_prior_bstride ? B : 1;
-    const SE2<double> X = se2_load(poses + ((int64_t)s.prior_pose[k] * B + b) * 4);
-    const SE2<double> Tg = se2_load(static_cast<const T*>(d.prior_target) + ((int64_t)k * tB) * 4 + (int64_t)b * d.prior_target_bstride);
-    load3(static_cast<const T*>(d.w_prior) + ((int64_t)k * wB) * 3 + (int64_t)b * d.w_prior_bstride, w);
-    local_eval2(Tg, X, w, eps, ev, J0, true);
-    robustify2<T>(d.robust_prior, d.log_radius_prior, d.log_radius_prior_bstride, k, b, B, ev, J0, nullptr);
-    const int64_t o = (int64_t)k * B + b;
-#pragma unroll
-    for (int q = 0; q < 9; ++q)
-      if (Jpo) Jpo[o * 9 + q] = (T)J0[q];
-    if (epo) { epo[o * 3] = (T)ev[0]; epo[o * 3 + 1] = (T)ev[1]; epo[o * 3 + 2] = (T)ev[2]; }
-  }
-}
-
-template <typename T>
-__global__ void __launch_bounds__(64)
-se2_retract_kernel(const T* __restrict__ poses, const T* __restrict__ delta, int64_t ldd, T step,
-                   const uint8_t* __restrict__ ignore, T* __restrict__ out, int P, int B, E2 eps) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  const int p = blockIdx.y;
-  if (b >= B) return;
-  const T* src = poses + ((int64_t)p * B + b) * 4;
-  T* dst = out + ((int64_t)p * B + b) * 4;
-  if (ignore && ignore[b]) {
-    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
-    return;
-  }
-  double xi[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) xi[i] = (double)(delta[(int64_t)b * ldd + 3 * p + i] * step);
-  SE2<double> Ex, Y;
-  se2_exp<double>(xi, eps, Ex, nullptr);
-  se2_mul(se2_load(src), Ex, Y);
-  se2_store(dst, Y);
-}
-
-// elementwise ops: op 0 exp (xi -> X [, J]), 1 log (X -> xi [, J]), 2 compose, 3 inverse, 4 adjoint
-template <typename T>
-__global__ void se2_elementwise_kernel(int op, const T* __restrict__ a, const T* __restrict__ bb, T* __restrict__ o,
-                                       T* __restrict__ jac, int64_t N, E2 eps) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  double J[9];
-  if (op == 0) {
-    double xi[3] = {(double)a[i * 3], (double)a[i * 3 + 1], (double)a[i * 3 + 2]};
-    SE2<double> X;
-    se2_exp<double>(xi, eps, X, jac ? J : nullptr);
-    se2_store(o + i * 4, X);
-  } else if (op == 1) {
-    double xi[3];
-    se2_log_jlog(se2_load(a + i * 4), eps, xi, J, jac != nullptr);
-    o[i * 3] = (T)xi[0]; o[i * 3 + 1] = (T)xi[1]; o[i * 3 + 2] = (T)xi[2];
-  } else if (op == 2) {
-    SE2<double> Z;
-    se2_mul(se2_load(a + i * 4), se2_load(bb + i * 4), Z);
-    se2_store(o + i * 4, Z);
-  } else if (op == 3) {
-    SE2<double> Z;
-    se2_inv(se2_load(a + i * 4), Z);
-    se2_store(o + i * 4, Z);
-  } else {
-    se2_adjoint(se2_load(a + i * 4), J);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) o[i * 9 + k] = (T)J[k];
-  }
-  if (jac && op <= 1) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) jac[i * 9 + k] = (T)J[k];
-  }
-}
-
-static int check_pg2(const thx_pg_structure* s, const thx_pg_data* d) {
-  if (!s || !d) return fail("null structure/data");
-  if (s->num_poses <= 0 || d->batch <= 0) return fail("empty problem");
-  if (d->meas_bstride != 0 && d->meas_bstride != 4) return fail("SE2: meas_bstride must be 0 or 4");
-  if (d->prior_target_bstride != 0 && d->prior_target_bstride != 4) return fail("SE2: prior_target_bstride must be 0 or 4");
-  if (d->w_between_bstride != 0 && d->w_between_bstride != 3) return fail("SE2: w_between_bstride must be 0 or 3");
-  if (d->w_prior_bstride != 0 && d->w_prior_bstride != 3) return fail("SE2: w_prior_bstride must be 0 or 3");
-  if ((d->robust_between && !d->log_radius_between) || (d->robust_prior && !d->log_radius_prior))
-    return fail("robust cost without log_loss_radius");
-  if (d->robust_between < 0 || d->robust_between > 2 || d->robust_prior < 0 || d->robust_prior > 2) return fail("bad loss kind");
-  return 0;
+  return dtype == THX_F32 ? Eps2<double>{(double)(float)e->near_zero, (double)(float)e->d_near_zero}
+                          : Eps2<double>{e->near_zero, e->d_near_zero};
 }
 
 }  // namespace thx
@@ -279,80 +37,33 @@ extern "C" {
 
 int thx_pg2_assemble(const thx_pg_structure* s, const thx_pg_data* d, void* H, int64_t ld, void* g, int dtype,
                      const thx_se2_eps* eps, void* stream) {
-  if (int r = check_pg2(s, d)) return r;
-  if (!H || !g || !eps) return fail("null output");
-  if (ld < 3 * (int64_t)s->num_poses) return fail("ld < n");
-  dim3 grid((d->batch + 63) / 64, s->num_poses), block(64);
-  THX_DISPATCH(dtype,
-               hipLaunchKernelGGL(pg2_assemble_kernel<float>, grid, block, 0, as_stream(stream), *s, *d, (float*)H, ld,
-                                  (float*)g, make_eps2(eps, dtype)),
-               hipLaunchKernelGGL(pg2_assemble_kernel<double>, grid, block, 0, as_stream(stream), *s, *d, (double*)H,
-                                  ld, (double*)g, make_eps2(eps, dtype)));
-  return check_launch("thx_pg2_assemble");
+  if (!eps) return fail("null eps");
+  return pg3_assemble<GroupSE2>(s, d, H, ld, g, dtype, make_eps2(eps, dtype), stream, "thx_pg2_assemble");
 }
 
 int thx_pg2_error(const thx_pg_structure* s, const thx_pg_data* d, void* partials, void* err, int dtype,
                   const thx_se2_eps* eps, void* stream) {
-  if (int r = check_pg2(s, d)) return r;
-  if (!partials || !err || !eps) return fail("null output");
-  dim3 grid((d->batch + 63) / 64, THX_ERR_CHUNKS), block(64);
-  const int B = d->batch;
-  THX_DISPATCH(dtype,
-               {
-                 hipLaunchKernelGGL(pg2_error_partial_kernel<float>, grid, block, 0, as_stream(stream), *s, *d,
-                                    (float*)partials, make_eps2(eps, dtype));
-                 hipLaunchKernelGGL(pg2_error_reduce_kernel<float>, dim3((B + 255) / 256), dim3(256), 0,
-                                    as_stream(stream), (const float*)partials, (float*)err, B);
-               },
-               {
-                 hipLaunchKernelGGL(pg2_error_partial_kernel<double>, grid, block, 0, as_stream(stream), *s, *d,
-                                    (double*)partials, make_eps2(eps, dtype));
-                 hipLaunchKernelGGL(pg2_error_reduce_kernel<double>, dim3((B + 255) / 256), dim3(256), 0,
-                                    as_stream(stream), (const double*)partials, (double*)err, B);
-               });
-  return check_launch("thx_pg2_error");
+  if (!eps) return fail("null eps");
+  return pg3_error<GroupSE2>(s, d, partials, err, dtype, make_eps2(eps, dtype), stream, "thx_pg2_error");
 }
 
 int thx_pg2_jacobians(const thx_pg_structure* s, const thx_pg_data* d, void* J0, void* J1, void* eb, void* Jp, void* ep,
                       int dtype, const thx_se2_eps* eps, void* stream) {
-  if (int r = check_pg2(s, d)) return r;
   if (!eps) return fail("null eps");
-  dim3 grid((d->batch + 63) / 64, s->num_edges + s->num_priors), block(64);
-  if (grid.y == 0) return 0;
-  THX_DISPATCH(dtype,
-               hipLaunchKernelGGL(pg2_jacobians_kernel<float>, grid, block, 0, as_stream(stream), *s, *d, (float*)J0,
-                                  (float*)J1, (float*)eb, (float*)Jp, (float*)ep, make_eps2(eps, dtype)),
-               hipLaunchKernelGGL(pg2_jacobians_kernel<double>, grid, block, 0, as_stream(stream), *s, *d, (double*)J0,
-                                  (double*)J1, (double*)eb, (double*)Jp, (double*)ep, make_eps2(eps, dtype)));
-  return check_launch("thx_pg2_jacobians");
+  return pg3_jacobians<GroupSE2>(s, d, J0, J1, eb, Jp, ep, dtype, make_eps2(eps, dtype), stream, "thx_pg2_jacobians");
 }
 
 int thx_se2_retract(const void* poses, const void* delta, int64_t ldd, double step, const uint8_t* ignore_mask, void* out,
                     int32_t P, int32_t B, int dtype, const thx_se2_eps* eps, void* stream) {
-  if (!poses || !delta || !out || !eps || P <= 0 || B <= 0) return fail("bad retract args");
-  dim3 grid((B + 63) / 64, P), block(64);
-  THX_DISPATCH(dtype,
-               hipLaunchKernelGGL(se2_retract_kernel<float>, grid, block, 0, as_stream(stream), (const float*)poses,
-                                  (const float*)delta, ldd, (float)step, ignore_mask, (float*)out, P, B,
-                                  make_eps2(eps, dtype)),
-               hipLaunchKernelGGL(se2_retract_kernel<double>, grid, block, 0, as_stream(stream), (const double*)poses,
-                                  (const double*)delta, ldd, step, ignore_mask, (double*)out, P, B,
-                                  make_eps2(eps, dtype)));
-  return check_launch("thx_se2_retract");
+  if (!eps) return fail("bad retract args");
+  return g3_retract<GroupSE2>(poses, delta, ldd, step, ignore_mask, out, P, B, dtype, make_eps2(eps, dtype), stream,
+                              "thx_se2_retract");
 }
 
 int thx_se2_op(int op, const void* a, const void* b, void* out, void* jac, int64_t N, int dtype, const thx_se2_eps* eps,
                void* stream) {
-  if (N <= 0) return 0;
-  if (op < 0 || op > 4 || !a || !out || !eps || (op == 2 && !b)) return fail("thx_se2_op: bad arguments");
-  dim3 grid((unsigned)((N + 255) / 256)), block(256);
-  THX_DISPATCH(dtype,
-               hipLaunchKernelGGL(se2_elementwise_kernel<float>, grid, block, 0, as_stream(stream), op, (const float*)a,
-                                  (const float*)b, (float*)out, (float*)jac, N, make_eps2(eps, dtype)),
-               hipLaunchKernelGGL(se2_elementwise_kernel<double>, grid, block, 0, as_stream(stream), op,
-                                  (const double*)a, (const double*)b, (double*)out, (double*)jac, N,
-                                  make_eps2(eps, dtype)));
-  return check_launch("thx_se2_op");
+  if (N > 0 && !eps) return fail("thx_se2_op: bad arguments");
+  return g3_op<GroupSE2>(op, a, b, out, jac, N, dtype, N > 0 ? make_eps2(eps, dtype) : Eps2<double>{0, 0}, stream, "thx_se2_op");
 }
 
 }  // extern "C"

@@ -112,6 +112,15 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
+GROUP_RECORD = {"SE3": (12, 6), "SO3": (9, 3), "SE2": (4, 3)}   # (scalars per record, dof)
+
+
+def group_of(poses: torch.Tensor) -> str:
+    if poses.dim() == 3:
+        return "SE2"
+    return "SO3" if poses.shape[-1] == 3 else "SE3"
+
+
 @dataclass
 class PGTensors:
     """Per-call tensors of a pose-graph objective in the entity-major device layout."""
@@ -135,6 +144,11 @@ class PGTensors:
     def se2(self) -> bool:
         return self.poses.dim() == 3
 
+    @property
+    def group(self) -> str:
+        """Read off the record shape: SE3 (3,4), SO3 (3,3), SE2 (4,)."""
+        return group_of(self.poses)
+
     def c_struct(self, poses: Optional[torch.Tensor] = None) -> _lib.PGData:
         poses = self.poses if poses is None else poses
         B = poses.shape[1]
@@ -149,7 +163,7 @@ class PGTensors:
             setattr(d, name, _lib.ptr(t, name).value if t.numel() else None)
             setattr(d, name + "_bstride", width if nb == B else 0)
 
-        gw, dof = (4, 3) if poses.dim() == 3 else (12, 6)
+        gw, dof = GROUP_RECORD[group_of(poses)]
         put("meas", self.meas, gw)
         put("w_between", self.w_between, dof)
         put("prior_target", self.prior_target, gw)
@@ -251,10 +265,53 @@ class HipKernels:
         self._se2_op(4, X, None, A, None)
         return A
 
-    # ---- pose graph (SE3 records (3,4) -> thx_pg_*, SE2 records (4,) -> thx_pg2_*) ---------------
+    # ---- SO3 elementwise (theseus/geometry/so3.py over torchlie's so3_impl.py) -------------------
+    def _so3_op(self, op, a, b, out, jac):
+        _lib.check(self.lib.thx_so3_op(op, _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(jac), a.shape[0],
+                                       _lib.dtype_code(a.dtype), lie_eps(a.dtype), _lib.stream_ptr(a.device)),
+                   "thx_so3_op")
+
+    def so3_exp(self, w, jac=False):
+        w = w.contiguous()
+        R = w.new_empty(w.shape[0], 3, 3)
+        J = w.new_empty(w.shape[0], 3, 3) if jac else None
+        self._so3_op(0, w, None, R, J)
+        return (R, J) if jac else R
+
+    def so3_log(self, R, jac=False):
+        R = R.contiguous()
+        w = R.new_empty(R.shape[0], 3)
+        J = R.new_empty(R.shape[0], 3, 3) if jac else None
+        self._so3_op(1, R, None, w, J)
+        return (w, J) if jac else w
+
+    def so3_compose(self, X, Y):
+        X, Y = X.contiguous(), Y.contiguous()
+        Z = torch.empty_like(X)
+        self._so3_op(2, X, Y, Z, None)
+        return Z
+
+    def so3_inverse(self, X):
+        X = X.contiguous()
+        Y = torch.empty_like(X)
+        self._so3_op(3, X, None, Y, None)
+        return Y
+
+    def so3_adjoint(self, X):
+        X = X.contiguous()
+        A = torch.empty_like(X)
+        self._so3_op(4, X, None, A, None)
+        return A
+
+    # ---- pose graph (SE3 records (3,4) -> thx_pg_*, SE2 records (4,) -> thx_pg2_*, SO3 records (3,3) -> thx_pgso3_*) ----
     def pg_assemble(self, s: DeviceStructure, t: PGTensors, H, g, poses=None):
         d = t.c_struct(poses)
         dt = H.dtype
+        if t.group == "SO3":
+            _lib.check(self.lib.thx_pgso3_assemble(s.c, d, _lib.ptr(H, "H"), H.shape[-1], _lib.ptr(g, "g"),
+                                                   _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(H.device)),
+                       "thx_pgso3_assemble")
+            return
         if t.se2:
             _lib.check(self.lib.thx_pg2_assemble(s.c, d, _lib.ptr(H, "H"), H.shape[-1], _lib.ptr(g, "g"),
                                                  _lib.dtype_code(dt), se2_eps(dt), _lib.stream_ptr(H.device)),
@@ -267,6 +324,10 @@ class HipKernels:
     def pg_error(self, s: DeviceStructure, t: PGTensors, partials, err, poses=None):
         d = t.c_struct(poses)
         dt = err.dtype
+        if t.group == "SO3":
+            _lib.check(self.lib.thx_pgso3_error(s.c, d, _lib.ptr(partials), _lib.ptr(err), _lib.dtype_code(dt),
+                                                lie_eps(dt), _lib.stream_ptr(err.device)), "thx_pgso3_error")
+            return
         if t.se2:
             _lib.check(self.lib.thx_pg2_error(s.c, d, _lib.ptr(partials), _lib.ptr(err), _lib.dtype_code(dt),
                                               se2_eps(dt), _lib.stream_ptr(err.device)), "thx_pg2_error")
@@ -277,6 +338,11 @@ class HipKernels:
     def pg_jacobians(self, s: DeviceStructure, t: PGTensors, J0, J1, eb, Jp, ep, poses=None):
         d = t.c_struct(poses)
         dt = t.poses.dtype
+        if t.group == "SO3":
+            _lib.check(self.lib.thx_pgso3_jacobians(s.c, d, _lib.ptr(J0), _lib.ptr(J1), _lib.ptr(eb), _lib.ptr(Jp),
+                                                    _lib.ptr(ep), _lib.dtype_code(dt), lie_eps(dt),
+                                                    _lib.stream_ptr(t.poses.device)), "thx_pgso3_jacobians")
+            return
         if t.se2:
             _lib.check(self.lib.thx_pg2_jacobians(s.c, d, _lib.ptr(J0), _lib.ptr(J1), _lib.ptr(eb), _lib.ptr(Jp),
                                                   _lib.ptr(ep), _lib.dtype_code(dt), se2_eps(dt),
@@ -288,10 +354,16 @@ class HipKernels:
 
     def retract(self, poses, delta, step, ignore_mask, out):
         """X <- X exp(step * delta) on the packed pose buffer; the group is read off the record shape."""
-        if poses.dim() == 4:
+        grp = group_of(poses)
+        if grp == "SE3":
             return self.se3_retract(poses, delta, step, ignore_mask, out)
         P, B = poses.shape[:2]
         dt = poses.dtype
+        if grp == "SO3":
+            _lib.check(self.lib.thx_so3_retract(_lib.ptr(poses), _lib.ptr(delta), delta.stride(0), float(step),
+                                                _lib.ptr(ignore_mask), _lib.ptr(out), P, B, _lib.dtype_code(dt),
+                                                lie_eps(dt), _lib.stream_ptr(poses.device)), "thx_so3_retract")
+            return
         _lib.check(self.lib.thx_se2_retract(_lib.ptr(poses), _lib.ptr(delta), delta.stride(0), float(step),
                                             _lib.ptr(ignore_mask), _lib.ptr(out), P, B, _lib.dtype_code(dt),
                                             se2_eps(dt), _lib.stream_ptr(poses.device)), "thx_se2_retract")
@@ -384,6 +456,8 @@ class HipKernels:
     # ---- implicit backward ----------------------------------------------------------------------
     def retract_vjp(self, poses, delta, step, grad_out, grad_delta):
         """grad_X_new -> grad_delta of X exp(step * delta); the group is read off the record shape."""
+        if group_of(poses) == "SO3":
+            raise NotImplementedError("HIP back end: the implicit backward pass is fused for SE3 / SE2 pose graphs, not SO3.")
         if poses.dim() == 4:
             return self.se3_retract_vjp(poses, delta, step, grad_out, grad_delta)
         P, B = poses.shape[:2]
@@ -402,6 +476,8 @@ class HipKernels:
                    "thx_se3_retract_vjp")
 
     def pg_vjp(self, s: DeviceStructure, t: PGTensors, w, g_meas, g_wb, g_tgt, g_wp, poses=None, g_lrb=None, g_lrp=None):
+        if t.group == "SO3":
+            raise NotImplementedError("HIP back end: the implicit backward pass is fused for SE3 / SE2 pose graphs, not SO3.")
         d = t.c_struct(poses)
         dt = w.dtype
         if t.se2:

@@ -463,7 +463,7 @@ class NonlinearLeastSquares(abc.ABC):
         linear solve with the cached factor + the fused VJP kernel (theseus_amd/autograd.py)."""
         from .autograd import ImplicitStep
         if packed.group not in ("SE3", "SE2"):
-            raise NotImplementedError("HIP back end: backward_mode='implicit' is fused for SE3 / SE2 pose graphs "
+            raise NotImplementedError("HIP back end: backward_mode='implicit' is fused for SE3 / SE2 pose graphs (not SO3, not BA) "
                                       f"(got {packed.group}); there is no autograd/CPU fallback.")
         step = self.params.step_size if kwargs.get("__keep_final_step_size__", False) else 1.0
         with torch.set_grad_enabled(outer_grad):

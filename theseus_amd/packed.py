@@ -27,7 +27,7 @@ class UnsupportedObjective(NotImplementedError):
 # and the real ``theseus`` ones alike (theseus_amd/plugin.py plugs this back end into the reference's own loop).
 def _kind(obj) -> str:
     names = {c.__name__ for c in type(obj).__mro__}
-    for k in ("SE3", "SE2", "Between"):
+    for k in ("SE3", "SE2", "SO3", "Between"):
         if k in names:
             return k
     if "Local" in names or "Difference" in names:
@@ -35,8 +35,8 @@ def _kind(obj) -> str:
     return type(obj).__name__
 
 
-GROUP_SHAPE = {"SE3": (3, 4), "SE2": (4,)}
-GROUP_DOF = {"SE3": 6, "SE2": 3}
+GROUP_SHAPE = {"SE3": (3, 4), "SE2": (4,), "SO3": (3, 3)}
+GROUP_DOF = {"SE3": 6, "SE2": 3, "SO3": 3}
 
 
 def _weight_diag(w, dof: int) -> torch.Tensor:
@@ -86,7 +86,7 @@ class PackedPoseGraph:
             kind = _kind(v)
             if kind not in GROUP_SHAPE or (self.group is not None and kind != self.group):
                 raise UnsupportedObjective(
-                    f"HIP backend fuses objectives whose optimisation variables are all SE3 or all SE2; got "
+                    f"HIP backend fuses objectives whose optimisation variables are all SE3, all SE2 or all SO3; got "
                     f"{type(v).__name__} ({v.name}). There is no CPU/eager fallback.")
             self.group = kind
             self.pose_vars.append(v)
@@ -116,7 +116,7 @@ class PackedPoseGraph:
             else:
                 raise UnsupportedObjective(
                     f"HIP backend has no fused kernel for cost function {type(c).__name__} ({c.name}); "
-                    "supported: Between, Difference/Local on SE3 / SE2.  There is no CPU/eager fallback.")
+                    "supported: Between, Difference/Local on SE3 / SE2 / SO3.  There is no CPU/eager fallback.")
             row += c.dim()
         for role, ks in kinds.items():
             if len(ks) > 1:
