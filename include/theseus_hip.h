@@ -322,6 +322,17 @@ typedef struct {
   int64_t w_pt_prior_bstride;
 } thx_ba_data;
 
+/* implicit backward of a bundle-adjustment objective (nonlinear_least_squares.py:121-135,265-292; examples/bundle_adjustment.py:
+ * 184-215 learns log_loss_radius through it): gradients of phi = w^T g(theta), w (B, ldw) = H^-1 grad_delta in the internal
+ * column order [cameras | points], w.r.t. the image features (O,B,2), the Reprojection cost weights (O,B,2), the calibration
+ * (PER OBSERVATION (O,B): the host sums the observations of a camera), log_loss_radius (O,B), the SE3 Difference priors' targets
+ * (Kc,B,3,4) / weights (Kc,B,6) and the Point3 Difference priors' targets / weights (Kp,B,3).  Any output may be NULL
+ * (grad_focal / grad_k1 / grad_k2 together). */
+int thx_ba_vjp(const thx_ba_structure* s, const thx_ba_data* d, const void* w, int64_t ldw, void* grad_feat, void* grad_w_obs,
+               void* grad_focal, void* grad_k1, void* grad_k2, void* grad_log_radius_obs, void* grad_cam_prior_target,
+               void* grad_w_cam_prior, void* grad_pt_prior_target, void* grad_w_pt_prior, int dtype, const thx_lie_eps* eps,
+               void* stream);
+
 /* linearize: Hcc, Hpp, W, gd (fp64) and g = [gc | gp], diag = diag(H) (dtype); row stride ldv for gd, g, diag */
 int thx_ba_assemble(const thx_ba_structure* s, const thx_ba_data* d, void* Hcc, void* Hpp, void* W, void* gd, void* g,
                     void* diag, int64_t ldv, int dtype, const thx_lie_eps* eps, void* stream);

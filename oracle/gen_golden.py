@@ -688,6 +688,101 @@ def gen_ba(th, only=None):
               Np - len(pt_prior_idx))
 
 
+def gen_ba_implicit(th):
+    """Implicit backward through a bundle-adjustment objective (examples/bundle_adjustment.py:184-215 learns log_loss_radius this
+    way): LM under no_grad, one undamped GN step with the Hessian detached and grad enabled; loss = <coef, final cameras> +
+    <coef, final points>; gradients w.r.t. log_loss_radius, the image features, the calibration (focal, k1, k2), the
+    observation weight, the strong camera priors' targets and weight, the regularisers' weight."""
+    import theseus.utils.examples as theg
+    dtype, B, iters, robust = torch.float64, 3, 5, "huber"
+    torch.manual_seed(3)
+    np.random.seed(3)
+    ba = theg.BundleAdjustmentDataset.generate_synthetic(num_cameras=6, num_points=40, average_track_length=4, track_locality=0.3,
+                                                         feat_random=1.5, outlier_feat_random=70)
+    gen = torch.Generator().manual_seed(19)
+    C, Np, O = len(ba.cameras), len(ba.points), len(ba.observations)
+    lieF = __import__("torchlie.functional", fromlist=["SE3"])
+    rnd = lambda *s_: 2 * torch.rand(*s_, dtype=torch.float64, generator=gen) - 1  # noqa: E731
+    cams0 = torch.stack([c.pose.tensor[0] for c in ba.cameras]).unsqueeze(0).repeat(B, 1, 1, 1)
+    pert = lieF.SE3.exp(torch.cat([0.3 * rnd(B * C, 3), 0.01 * rnd(B * C, 3)], 1)).view(B, C, 3, 4)
+    cams0 = lieF.SE3.compose(cams0.reshape(-1, 3, 4), pert.reshape(-1, 3, 4)).view(B, C, 3, 4)
+    pts0 = torch.stack([p_.tensor[0] for p_ in ba.points]).unsqueeze(0) + 0.2 * rnd(B, Np, 3)
+    leaves = dict(
+        feat=(torch.stack([o.image_feature_point.tensor[0] for o in ba.observations]).unsqueeze(0) + 0.5 * rnd(B, O, 2)),
+        focal=torch.stack([c.focal_length.tensor[0] for c in ba.cameras]).unsqueeze(0),       # (1,C,1)
+        k1=torch.stack([c.calib_k1.tensor[0] for c in ba.cameras]).unsqueeze(0),
+        k2=torch.stack([c.calib_k2.tensor[0] for c in ba.cameras]).unsqueeze(0),
+        log_radius=torch.tensor([[1.5]], dtype=dtype), w_obs=torch.tensor(1.0, dtype=dtype),
+        gt_cams=torch.stack([c.pose.tensor[0] for c in ba.gt_cameras]).unsqueeze(0)[:, [0, C - 1]].clone(),   # (1,2,3,4)
+        w_strong=100 * torch.ones(1, dtype=dtype), w_reg=float(np.sqrt(1e-4)) * torch.ones(1, dtype=dtype))
+    leaves = {k: v.to(dtype).clone().requires_grad_(True) for k, v in leaves.items()}
+    obs_cam = np.array([o.camera_index for o in ba.observations], dtype=np.int64)
+    obs_pt = np.array([int(o.point_index) for o in ba.observations], dtype=np.int64)
+    obj = th.Objective(dtype=dtype)
+    cam_v = [th.SE3(tensor=cams0[:, i].clone(), name=f"Cam{i}") for i in range(C)]
+    pt_v = [th.Point3(tensor=pts0[:, i].clone(), name=f"Pt{i}") for i in range(Np)]
+    fl = [th.Vector(tensor=leaves["focal"][:, i], name=f"fl{i}") for i in range(C)]
+    k1v = [th.Vector(tensor=leaves["k1"][:, i], name=f"k1_{i}") for i in range(C)]
+    k2v = [th.Vector(tensor=leaves["k2"][:, i], name=f"k2_{i}") for i in range(C)]
+    w = th.ScaleCostWeight(th.Variable(leaves["w_obs"].view(1, 1), name="w_obs"))
+    log_radius = th.Vector(tensor=leaves["log_radius"], name="log_loss_radius")
+    for o in range(O):
+        cf = th.eb.Reprojection(camera_pose=cam_v[obs_cam[o]], world_point=pt_v[obs_pt[o]], focal_length=fl[obs_cam[o]],
+                                calib_k1=k1v[obs_cam[o]], calib_k2=k2v[obs_cam[o]],
+                                image_feature_point=th.Point2(tensor=leaves["feat"][:, o], name=f"Feat{o}"), weight=w,
+                                name=f"reproj_{o}")
+        obj.add(th.RobustCostFunction(cf, th.HuberLoss, log_radius, name=f"robust_{o}"))
+    dw = th.ScaleCostWeight(th.Variable(leaves["w_reg"].view(1, 1), name="w_reg"))
+    zero_pt, ident = th.Point3(dtype=dtype, name="zero_point"), th.SE3(dtype=dtype, name="zero_se3")
+    var_order, cost_order = [], [("obs", o) for o in range(O)]
+    cam_prior_idx, pt_prior_idx = [], []
+    for vname, var in obj.optim_vars.items():
+        kind, idx = ("cam", int(vname[3:])) if vname.startswith("Cam") else ("pt", int(vname[2:]))
+        var_order.append((kind, idx))
+        if kind == "cam":
+            obj.add(th.Difference(var, ident, dw, name=f"reg_{vname}"))
+            cost_order.append(("cam_prior", len(cam_prior_idx)))
+            cam_prior_idx.append(idx)
+        else:
+            obj.add(th.Difference(var, zero_pt, dw, name=f"reg_{vname}"))
+            cost_order.append(("pt_prior", len(pt_prior_idx)))
+            pt_prior_idx.append(idx)
+    n_reg_cam = len(cam_prior_idx)
+    cw = th.ScaleCostWeight(th.Variable(leaves["w_strong"].view(1, 1), name="w_strong"))
+    for k, i in enumerate((0, C - 1)):
+        obj.add(th.Difference(cam_v[i], th.SE3(tensor=leaves["gt_cams"][:, k], name=f"gt_cam{i}"), cw, name=f"camera_diff_{i}"))
+        cost_order.append(("cam_prior", len(cam_prior_idx)))
+        cam_prior_idx.append(i)
+    opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, abs_err_tolerance=0.0,
+                                rel_err_tolerance=0.0, max_iterations=iters, step_size=1.0)
+    sol, info = th.TheseusLayer(opt).forward(optimizer_kwargs=dict(backward_mode="implicit", damping=1e-2))
+    used = sorted(set(obs_pt.tolist()))
+    final_c = torch.stack([sol[f"Cam{i}"] for i in range(C)], 1)
+    final_p = torch.stack([sol[f"Pt{i}"] for i in used], 1)
+    gen2 = torch.Generator().manual_seed(5)
+    coef_c = torch.randn(B, C, 3, 4, dtype=dtype, generator=gen2)
+    coef_p = torch.randn(B, len(used), 3, dtype=dtype, generator=gen2)
+    loss = (coef_c * final_c).sum() + (coef_p * final_p).sum()
+    loss.backward()
+    d = lambda t: t.detach().numpy()  # noqa: E731
+    cam_prior_target = torch.cat([torch.eye(3, 4, dtype=dtype).view(1, 1, 3, 4).repeat(1, n_reg_cam, 1, 1), leaves["gt_cams"].detach()], 1)
+    w_cam_prior = torch.cat([torch.full((1, n_reg_cam, 6), float(leaves["w_reg"]), dtype=dtype), torch.full((1, 2, 6), 100.0, dtype=dtype)], 1)
+    np.savez_compressed(
+        os.path.join(OUT, "ba_f64_implicit.npz"), C=C, Np=Np, obs_cam=obs_cam, obs_pt=obs_pt, feat=d(leaves["feat"]),
+        focal=d(leaves["focal"]), k1=d(leaves["k1"]), k2=d(leaves["k2"]), cams0=cams0.numpy(), pts0=pts0.numpy(),
+        cam_prior_idx=np.array(cam_prior_idx, dtype=np.int64), cam_prior_target=cam_prior_target.numpy(), w_cam_prior=w_cam_prior.numpy(),
+        pt_prior_idx=np.array(pt_prior_idx, dtype=np.int64), w_pt_prior=np.full((1, len(pt_prior_idx), 3), float(leaves["w_reg"])),
+        var_kind=np.array([0 if k == "cam" else 1 for k, _ in var_order]), var_idx=np.array([i for _, i in var_order]),
+        cost_kind=np.array([{"obs": 0, "cam_prior": 1, "pt_prior": 2}[k] for k, _ in cost_order]), cost_idx=np.array([i for _, i in cost_order]),
+        robust=np.array(robust), log_radius=np.float64(1.5), final_cams=d(final_c), final_pts=d(final_p), coef_c=coef_c.numpy(),
+        coef_p=coef_p.numpy(), loss=loss.item(), n_reg_cam=n_reg_cam,
+        grad_log_radius=d(leaves["log_radius"].grad), grad_feat=d(leaves["feat"].grad), grad_focal=d(leaves["focal"].grad),
+        grad_k1=d(leaves["k1"].grad), grad_k2=d(leaves["k2"].grad), grad_w_obs=d(leaves["w_obs"].grad),
+        grad_gt_cams=d(leaves["gt_cams"].grad), grad_w_strong=d(leaves["w_strong"].grad), grad_w_reg=d(leaves["w_reg"].grad),
+        opt_kwargs=np.array(repr(dict(max_iterations=iters, step_size=1.0, damping=1e-2, gauss_newton=False))))
+    print("ba_f64_implicit loss", loss.item(), {k: float(v.grad.abs().max()) for k, v in leaves.items()})
+
+
 def gen_g2o(th):
     """A small SLAM-3D g2o file written by the reference's own writer (PoseGraphDataset.write_3D_g2o,
     theseus/utils/examples/pose_graph/dataset.py:367-399) from its synthetic generator (:238-365), what the reference's
@@ -749,6 +844,8 @@ def main():
         gen_ba(th, only)
     if not only or only & {"pg_full_f64_lm", "pg_full_f32_lm"}:
         gen_pg_full(th, lieF, only & {"pg_full_f64_lm", "pg_full_f32_lm"})
+    if not only or "ba_implicit" in only:
+        gen_ba_implicit(th)
     if not only or "g2o" in only:
         gen_g2o(th)
     print("wrote", sorted(os.listdir(OUT)))

@@ -83,3 +83,60 @@ def run_ba(th, g, kernels=None, device="cpu"):
     used = sorted(set(g["obs_pt"].tolist()))
     pts = torch.stack([sol[f"Pt{i}"] for i in used], 1)
     return cams, pts, used, deltas, info, opt
+
+
+def run_ba_implicit(th, g, kernels=None, device="cpu"):
+    """The objective of oracle/gen_golden.py:gen_ba_implicit on theseus_amd's classes with the differentiable leaves of that
+    fixture; LM + backward_mode="implicit"; returns the solution, the loss and the gradients as numpy arrays."""
+    import ast
+    t = lambda a: torch.from_numpy(np.asarray(a)).to(device)  # noqa: E731
+    dtype = torch.float64
+    C, Np, O = int(g["C"]), int(g["Np"]), g["obs_cam"].shape[0]
+    n_reg = int(g["n_reg_cam"])
+    leaves = dict(feat=t(g["feat"]), focal=t(g["focal"]), k1=t(g["k1"]), k2=t(g["k2"]),
+                  log_radius=torch.tensor([[float(g["log_radius"])]], dtype=dtype, device=device),
+                  w_obs=torch.tensor(1.0, dtype=dtype, device=device), gt_cams=t(g["cam_prior_target"])[:, n_reg:].clone(),
+                  w_strong=100 * torch.ones(1, dtype=dtype, device=device),
+                  w_reg=t(g["w_cam_prior"])[0, 0, :1].clone())
+    leaves = {k: v.clone().requires_grad_(True) for k, v in leaves.items()}
+    cams0, pts0 = t(g["cams0"]), t(g["pts0"])
+    obj = th.Objective(dtype=dtype)
+    cam_v = [th.SE3(tensor=cams0[:, i].clone(), name=f"Cam{i}") for i in range(C)]
+    pt_v = [th.Point3(tensor=pts0[:, i].clone(), name=f"Pt{i}") for i in range(Np)]
+    fl = [th.Vector(tensor=leaves["focal"][:, i], name=f"fl{i}") for i in range(C)]
+    k1 = [th.Vector(tensor=leaves["k1"][:, i], name=f"k1_{i}") for i in range(C)]
+    k2 = [th.Vector(tensor=leaves["k2"][:, i], name=f"k2_{i}") for i in range(C)]
+    w = th.ScaleCostWeight(th.Variable(leaves["w_obs"].view(1, 1), name="w_obs"))
+    radius = th.Vector(tensor=leaves["log_radius"], name="log_loss_radius")
+    for o in range(O):
+        c, p = int(g["obs_cam"][o]), int(g["obs_pt"][o])
+        cf = th.Reprojection(camera_pose=cam_v[c], world_point=pt_v[p], focal_length=fl[c], calib_k1=k1[c], calib_k2=k2[c],
+                             image_feature_point=th.Point2(tensor=leaves["feat"][:, o], name=f"Feat{o}"), weight=w, name=f"reproj_{o}")
+        obj.add(th.RobustCostFunction(cf, th.HuberLoss, radius, name=f"robust_{o}"))
+    dw = th.ScaleCostWeight(th.Variable(leaves["w_reg"].view(1, 1), name="w_reg"))
+    ident = th.SE3(tensor=torch.eye(3, 4, dtype=dtype, device=device).unsqueeze(0), name="zero_se3")
+    zero_pt = th.Point3(tensor=torch.zeros(1, 3, dtype=dtype, device=device), name="zero_point")
+    for kind, k in zip(g["cost_kind"].tolist(), g["cost_idx"].tolist()):   # regularisers in the fixture's cost order
+        if kind == 1 and k < n_reg:
+            obj.add(th.Difference(cam_v[int(g["cam_prior_idx"][k])], ident, dw, name=f"reg_cam_{k}"))
+        elif kind == 2:
+            obj.add(th.Difference(pt_v[int(g["pt_prior_idx"][k])], zero_pt, dw, name=f"reg_pt_{k}"))
+    cw = th.ScaleCostWeight(th.Variable(leaves["w_strong"].view(1, 1), name="w_strong"))
+    for k, i in enumerate((0, C - 1)):
+        obj.add(th.Difference(cam_v[i], th.SE3(tensor=leaves["gt_cams"][:, k], name=f"gt_cam{i}"), cw, name=f"camera_diff_{i}"))
+    kw = ast.literal_eval(str(g["opt_kwargs"]))
+    kw.pop("gauss_newton")
+    okw = dict(max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    if kernels is not None:
+        okw["linearization_kwargs"] = dict(kernels=kernels)
+    opt = th.LevenbergMarquardt(obj, **okw)
+    sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode="implicit", **kw))
+    used = sorted(set(g["obs_pt"].tolist()))
+    final_c = torch.stack([sol[f"Cam{i}"] for i in range(C)], 1)
+    final_p = torch.stack([sol[f"Pt{i}"] for i in used], 1)
+    loss = (t(g["coef_c"]) * final_c).sum() + (t(g["coef_p"]) * final_p).sum()
+    loss.backward()
+    out = dict(final_cams=final_c.detach().cpu().numpy(), final_pts=final_p.detach().cpu().numpy(), loss=float(loss))
+    for k, v in leaves.items():
+        out["grad_" + k] = v.grad.detach().cpu().numpy()
+    return out

@@ -168,6 +168,45 @@ class OracleKernels:
         diag[:, :6 * C] = hcc.diagonal(dim1=2, dim2=3).reshape(B, -1)
         diag[:, 6 * C:] = hpp.diagonal(dim1=2, dim2=3).reshape(B, -1)
 
+    def ba_vjp(self, s, t, w, grads):
+        """d(w^T g)/d theta by torch autograd through the oracle's restatement of the cost terms."""
+        import dataclasses
+        p, state = self._ba_problem(s, t)
+        B, C, Np, O = state[0].shape[0], p.num_cams, p.num_points, p.obs_cam.numel()
+        with torch.enable_grad():
+            full = lambda a: a.detach().expand(B, *a.shape[1:]).clone().requires_grad_(True)  # noqa: E731
+            lv = dict(feat=full(p.feat), w_obs=full(p.w_obs), focal=full(p.focal), k1=full(p.k1), k2=full(p.k2),
+                      cam_prior_target=full(p.cam_prior_target), w_cam_prior=full(p.w_cam_prior),
+                      pt_prior_target=full(p.pt_prior_target), w_pt_prior=full(p.w_pt_prior))
+            if p.robust_obs:
+                lv["log_radius"] = full(p.log_radius_obs.expand(-1, O, 1))
+            pg = dataclasses.replace(p, feat=lv["feat"], w_obs=lv["w_obs"], focal=lv["focal"], k1=lv["k1"], k2=lv["k2"],
+                                     cam_prior_target=lv["cam_prior_target"], w_cam_prior=lv["w_cam_prior"],
+                                     pt_prior_target=lv["pt_prior_target"], w_pt_prior=lv["w_pt_prior"],
+                                     log_radius_obs=lv.get("log_radius"))
+            Jc, Jp, e, _, Jcp, ecp, ept = pg.terms(state)
+            gc = torch.zeros(B, C, 6, dtype=w.dtype).index_add(1, p.obs_cam, -(Jc.transpose(2, 3) @ e.unsqueeze(3)).squeeze(3))
+            gc = gc.index_add(1, p.cam_prior_idx, -(Jcp.transpose(2, 3) @ ecp.unsqueeze(3)).squeeze(3).expand(B, -1, 6))
+            gp = torch.zeros(B, Np, 3, dtype=w.dtype).index_add(1, p.obs_pt, -(Jp.transpose(2, 3) @ e.unsqueeze(3)).squeeze(3))
+            gp = gp.index_add(1, p.pt_prior_idx, -(pg.w_pt_prior * ept).expand(B, -1, 3))
+            phi = (w[:, :6 * C] * gc.reshape(B, -1)).sum() + (w[:, 6 * C:] * gp.reshape(B, -1)).sum()
+            names = list(lv)
+            gr = dict(zip(names, torch.autograd.grad(phi, [lv[k] for k in names], allow_unused=True)))
+        for k, out in grads.items():
+            if out is None or k not in gr:
+                continue
+            g = gr[k] if gr[k] is not None else torch.zeros_like(lv[k])
+            if k in ("focal", "k1", "k2"):
+                # the kernel reports calibration gradients PER OBSERVATION; any split that sums to the camera's works
+                first = {}
+                for o, c in enumerate(p.obs_cam.tolist()):
+                    first.setdefault(c, o)
+                out.zero_()
+                for c, o in first.items():
+                    out[o] = g[:, c, 0]
+            elif g.shape[1] > 0:
+                out[:g.shape[1]].copy_(g.transpose(0, 1))
+
     @staticmethod
     def _sym3(h):  # (..., 6) -> (..., 3, 3)
         return torch.stack([torch.stack([h[..., 0], h[..., 1], h[..., 2]], -1), torch.stack([h[..., 1], h[..., 3], h[..., 4]], -1),
@@ -264,11 +303,12 @@ class OracleKernels:
     # ---- implicit backward (torch autograd through the oracle, which mirrors torchlie's backward conventions) ----
     def se3_retract_vjp(self, poses, delta, step, grad_out, grad_delta):
         x = poses.transpose(0, 1)
+        ncol = (6 if poses.dim() == 4 and poses.shape[-1] == 4 else 3) * poses.shape[0]   # (bundle adjustment: camera columns)
         with torch.enable_grad():
-            d = delta.detach().clone().requires_grad_(True)
+            d = delta[:, :ncol].detach().clone().requires_grad_(True)
             y = opg.retract(x, d * step)
             (g,) = torch.autograd.grad(y, d, grad_out.transpose(0, 1))
-        grad_delta.copy_(g)
+        grad_delta[:, :ncol].copy_(g)
 
     def retract_vjp(self, poses, delta, step, grad_out, grad_delta):
         return self.se3_retract_vjp(poses, delta, step, grad_out, grad_delta)   # opg.retract dispatches on the shape

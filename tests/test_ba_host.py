@@ -51,3 +51,25 @@ def test_schur_block_tables_partition_the_pair_list():
     # every pair of observations of a common point appears once (lower triangle incl. the diagonal)
     want = sum(k * (k + 1) // 2 for k in np.bincount(op, minlength=Np))
     assert s.num_pairs == want
+
+
+def test_ba_implicit_backward_matches_reference_gradients():
+    """backward_mode="implicit" on a bundle-adjustment objective through theseus_amd's host path (BAImplicitStep: retract VJP ->
+    solve with the cached Schur factor -> thx_ba_vjp; TEST stand-in kernels here, HIP kernels in tests/test_gpu_ba.py): the
+    gradients the REAL reference produced (oracle/gen_golden.py:gen_ba_implicit) w.r.t. log_loss_radius, the image features,
+    the calibration, the observation weight, the strong camera priors' targets / weight and the regularisers' weight."""
+    import ast
+    import numpy as np
+    import torch
+    import theseus_amd as th
+    from tests.ba_common import run_ba_implicit
+    from tests.helpers import load_golden
+    from tests.oracle_kernels import OracleKernels
+    g = load_golden("ba_f64_implicit")
+    got = run_ba_implicit(th, g, OracleKernels(), "cpu")
+    np.testing.assert_allclose(got["final_cams"], g["final_cams"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(got["final_pts"], g["final_pts"], rtol=0, atol=1e-6)
+    assert abs(got["loss"] - float(g["loss"])) < 1e-5
+    for k in ("log_radius", "feat", "focal", "k1", "k2", "w_obs", "gt_cams", "w_strong", "w_reg"):
+        want = g["grad_" + k]
+        np.testing.assert_allclose(got["grad_" + k], want, rtol=0, atol=5e-6 * max(np.abs(want).max(), 1e-12), err_msg=k)

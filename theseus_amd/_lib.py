@@ -19,7 +19,7 @@ THX_TILE = 128
 THX_ERR_CHUNKS = 16
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class LieEps(Structure):
@@ -109,6 +109,8 @@ _SIGNATURES = {
                      c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "thx_ba_backsub": [POINTER(BAStructure), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     "thx_ba_error": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
+    "thx_ba_vjp": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
     "thx_copy_where": [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p],
     "thx_vec_retract": [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int,
                         c_void_p],

@@ -166,6 +166,8 @@ class PackedBA:
 
     group = "BA"
 
+    group = "BA"
+
     def __init__(self, objective: Objective, kernels=None):
         self.objective = objective
         self.K = kernels or default_kernels()
@@ -317,10 +319,12 @@ class PackedBA:
         self._repoint_variables()
 
     def _repoint_variables(self):
-        for v, t in zip(self.cam_vars, self.tensors.cams.unbind(0)):  # one call builds all the views
-            v.tensor = t
-        for v, t in zip(self.pt_vars, self.tensors.points.unbind(0)):
-            v.tensor = t
+        # (after the implicit last step the state carries an autograd graph: the per-variable views stay attached to it)
+        with torch.set_grad_enabled(self.tensors.cams.requires_grad or self.tensors.points.requires_grad):
+            for v, t in zip(self.cam_vars, self.tensors.cams.unbind(0)):  # one call builds all the views
+                v.tensor = t
+            for v, t in zip(self.pt_vars, self.tensors.points.unbind(0)):
+                v.tensor = t
         self._stamp = self._current_stamp()
         self._deep_stamp = self._current_stamp(deep=True)
         self._global_stamp = Variable._global_updates
@@ -560,6 +564,7 @@ class HipSchurSolverCore:
                 lam.fill_(float(damping))
         p = lin.packed
         self.factor_version += 1
+        self._factor_args = (lam.clone() if lam is not None else None, ellipsoidal_damping, damping_eps)
         self.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, lin.gd, lam, ellipsoidal_damping, damping_eps, self.S, self.rhs,
                         self.Hinv, self.tvec, self.info_pts)
         self.K.chol_factor(self.S, p.nc, None, False, damping_eps, self.L, self.panels, self.info_chol, rhs=self.rhs, y=self._y)
@@ -569,6 +574,114 @@ class HipSchurSolverCore:
         if check_info:
             self.check_info()
         return self.delta
+
+
+    def solve_with_factor(self, rhs: torch.Tensor) -> torch.Tensor:
+        """(H + damping)^-1 rhs for another right-hand side (B, n) = [r_c | r_p] with the CACHED factor of the reduced camera
+        system (the backward linear solve of the implicit mode): point elimination of rhs (thx_ba_schur re-run with rhs in
+        place of g -- it rebuilds the same S, which is not factorised again), the two triangular solves with the cached L,
+        back substitution."""
+        lin = self.linearization
+        p = lin.packed
+        lam, ell, eps = self._factor_args
+        gd = rhs.to(torch.float64).contiguous()
+        rc = torch.empty_like(self.rhs)
+        tv = torch.empty_like(self.tvec)
+        scratch_info = torch.zeros_like(self.info_pts)
+        self.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, gd, lam, ell, eps, self.S, rc, self.Hinv, tv, scratch_info)
+        dc = torch.empty_like(rc)
+        self.K.chol_solve(self.L, p.nc, self.panels, rc, dc)
+        out = torch.empty(rhs.shape[0], lin.n, dtype=self.S.dtype, device=rhs.device)
+        out[:, :p.nc].copy_(dc)
+        self.K.ba_backsub(p.dstruct, lin.W, self.Hinv, tv, out)
+        return out
+
+
+class BAImplicitStep(torch.autograd.Function):
+    """The grad-enabled last step of backward_mode="implicit" on a bundle-adjustment objective: one undamped Gauss-Newton step
+    with the block Hessian built outside autograd (dense_linearization.py:61); backward = thx_se3_retract_vjp (cameras) /
+    identity (points) -> one solve with the cached Schur factor -> thx_ba_vjp."""
+
+    NAMES = ("feat", "w_obs", "focal", "k1", "k2", "log_radius", "cam_prior_target", "w_cam_prior", "pt_prior_target",
+             "w_pt_prior")
+
+    @staticmethod
+    def forward(ctx, opt, packed, step, kwargs, *aux):
+        import warnings
+        solver = opt.linear_solver
+        lin = solver.linearization
+        lin._assemble()
+        delta = solver._solve(None, False, 1e-8, check_info=False)   # plain GN; damped step of the optimizer if it fails
+        if bool(solver.info.ne(0).any()):
+            if kwargs.get("__strict_implicit_final_gn__", False):
+                solver.check_info()
+            warnings.warn("implicit backward: the undamped Gauss-Newton system is not positive definite, "
+                          "falling back to the optimizer's damped step", RuntimeWarning)
+            delta = opt.compute_delta(**kwargs)
+            solver.check_info()
+        delta = delta.clone()
+        cams, pts = packed.tensors.cams.detach(), packed.tensors.points.detach()
+        new = (torch.empty_like(cams), torch.empty_like(pts))
+        packed.retract(delta, step, None, new)
+        ctx.opt, ctx.packed, ctx.step, ctx.factor_version = opt, packed, step, solver.factor_version
+        ctx.tensors = dataclasses.replace(packed.tensors, cams=cams, points=pts,
+                                          **{k: (None if a is None else a.detach()) for k, a in zip(
+                                              ("feat", "w_obs", "focal", "k1", "k2", "log_radius_obs", "cam_prior_target",
+                                               "w_cam_prior", "pt_prior_target", "w_pt_prior"), aux)})
+        ctx.delta = delta
+        ctx.mark_non_differentiable(delta)
+        return new[0], new[1], delta
+
+    @staticmethod
+    def backward(ctx, g_cams, g_pts, _g_delta):
+        packed, solver = ctx.packed, ctx.opt.linear_solver
+        lin, K, t = solver.linearization, solver.K, ctx.tensors
+        if solver.factor_version != ctx.factor_version:
+            raise RuntimeError("implicit backward: the cached factor of this forward pass was overwritten by a later "
+                               "factorisation on the same optimizer; call backward() before the next forward().")
+        B, n, nc = t.cams.shape[1], lin.n, packed.nc
+        dt, dev = t.cams.dtype, t.cams.device
+        gd = torch.zeros(B, n, dtype=dt, device=dev)
+        if g_cams is not None:
+            K.se3_retract_vjp(t.cams, ctx.delta, ctx.step, g_cams.contiguous(), gd)        # camera columns [0, 6C)
+        if g_pts is not None:
+            gd[:, nc:] = g_pts.permute(1, 0, 2).reshape(B, -1) * ctx.step                   # X + step * delta
+        w = solver.solve_with_factor(gd)   # the backward linear solve
+        s = packed.structure
+        O, Kc, Kp = s.num_obs, s.num_cam_priors, s.num_pt_priors
+        new = lambda *sh: torch.empty(*sh, dtype=dt, device=dev)  # noqa: E731
+        g = dict(feat=new(max(O, 1), B, 2), w_obs=new(max(O, 1), B, 2), focal=new(max(O, 1), B), k1=new(max(O, 1), B),
+                 k2=new(max(O, 1), B), log_radius=new(max(O, 1), B, 1) if t.robust_obs else None,
+                 cam_prior_target=new(max(Kc, 1), B, 3, 4), w_cam_prior=new(max(Kc, 1), B, 6),
+                 pt_prior_target=new(max(Kp, 1), B, 3), w_pt_prior=new(max(Kp, 1), B, 3))
+        K.ba_vjp(packed.dstruct, t, w, g)
+        # calibration: per observation -> per camera
+        oc = torch.from_numpy(np.asarray(s.t["obs_cam"][:O], dtype=np.int64)).to(dev)
+        C = s.num_cams
+        for k in ("focal", "k1", "k2"):
+            g[k] = torch.zeros(C, B, dtype=dt, device=dev).index_add_(0, oc, g[k][:O]).unsqueeze(2)
+
+        def fit(grad, count, like):   # (count, B, ...) -> the packed input's shape (count, 1|B, ...)
+            if grad is None or like is None:
+                return None
+            grad = grad[:count]
+            return grad.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else grad
+        counts = dict(feat=O, w_obs=O, focal=C, k1=C, k2=C, log_radius=O, cam_prior_target=Kc, w_cam_prior=Kc,
+                      pt_prior_target=Kp, w_pt_prior=Kp)
+        likes = dict(feat=t.feat, w_obs=t.w_obs, focal=t.focal, k1=t.k1, k2=t.k2, log_radius=t.log_radius_obs,
+                     cam_prior_target=t.cam_prior_target, w_cam_prior=t.w_cam_prior, pt_prior_target=t.pt_prior_target,
+                     w_pt_prior=t.w_pt_prior)
+        return (None, None, None, None) + tuple(fit(g[k], counts[k], likes[k]) for k in BAImplicitStep.NAMES)
+
+
+def ba_implicit_step(opt, packed, step: float, kwargs):
+    """-> ((cams_new, points_new), delta): called by NonlinearLeastSquares._implicit_last_step under the caller's grad mode."""
+    packed.flush_variables()
+    packed.sync(force=True)   # re-pack the auxiliary tensors WITH their autograd history
+    t = packed.tensors
+    cams, pts, delta = BAImplicitStep.apply(opt, packed, step, kwargs, t.feat, t.w_obs, t.focal, t.k1, t.k2, t.log_radius_obs,
+                                            t.cam_prior_target, t.w_cam_prior, t.pt_prior_target, t.w_pt_prior)
+    return (cams, pts), delta
 
 
 class HipSchurSolver(HipSchurSolverCore, LinearSolver):

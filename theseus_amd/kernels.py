@@ -405,6 +405,16 @@ class HipKernels:
         _lib.check(self.lib.thx_ba_error(s.c, d, _lib.ptr(partials), _lib.ptr(err), _lib.dtype_code(dt), lie_eps(dt),
                                          _lib.stream_ptr(err.device)), "thx_ba_error")
 
+    def ba_vjp(self, s, t, w, grads):
+        """grads: dict name -> preallocated tensor | None for feat, w_obs, focal, k1, k2, log_radius, cam_prior_target,
+        w_cam_prior, pt_prior_target, w_pt_prior (thx_ba_vjp's outputs, in that order)."""
+        d = t.c_struct()
+        dt = w.dtype
+        order = ("feat", "w_obs", "focal", "k1", "k2", "log_radius", "cam_prior_target", "w_cam_prior", "pt_prior_target",
+                 "w_pt_prior")
+        _lib.check(self.lib.thx_ba_vjp(s.c, d, _lib.ptr(w), w.stride(0), *[_lib.ptr(grads.get(k)) for k in order],
+                                       _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(w.device)), "thx_ba_vjp")
+
     def copy_where(self, mask, src, dst):
         """dst[k, b] <- src[k, b] where mask[b]; src / dst (N, B, ...) contiguous, mask (B,) bool or uint8."""
         if src.shape != dst.shape or src.dtype != dst.dtype or not (src.is_contiguous() and dst.is_contiguous()):

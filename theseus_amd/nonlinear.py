@@ -416,13 +416,14 @@ class NonlinearLeastSquares(abc.ABC):
             #      executed under the caller's grad mode (nonlinear_least_squares.py:121-135,265-292) ----
             if implicit and not (info.status == NonlinearOptimizerStatus.FAIL).any():
                 X_new, delta = self._implicit_last_step(packed, outer_grad, kwargs)
-                err = packed.error_metric(state=X_new.detach())
+                X_det = tuple(x.detach() for x in X_new) if isinstance(X_new, tuple) else X_new.detach()
+                err = packed.error_metric(state=X_det)
                 packed.swap_state(X_new)
                 if err_hist is not None:
                     err_hist[:, it + 1] = err
                 if track_best_solution:
                     better = err < best_err
-                    packed.copy_where(better, X_new.detach(), best_state)
+                    packed.copy_where(better, X_det, best_state)
                     best_err = torch.where(better, err, best_err)
                     best_iter = torch.where(better, torch.full_like(best_iter, it), best_iter)  # nonlinear_optimizer.py:202
                 if need_conv:
@@ -462,10 +463,14 @@ class NonlinearLeastSquares(abc.ABC):
         dense_linearization.py:61 does for this step), the graph runs through g only and its backward is one
         linear solve with the cached factor + the fused VJP kernel (theseus_amd/autograd.py)."""
         from .autograd import ImplicitStep
-        if packed.group not in ("SE3", "SE2"):
-            raise NotImplementedError("HIP back end: backward_mode='implicit' is fused for SE3 / SE2 pose graphs (not SO3, not BA) "
-                                      f"(got {packed.group}); there is no autograd/CPU fallback.")
         step = self.params.step_size if kwargs.get("__keep_final_step_size__", False) else 1.0
+        if getattr(packed, "group", None) == "BA":   # bundle adjustment: theseus_amd/ba.py (thx_ba_vjp)
+            from .ba import ba_implicit_step
+            with torch.set_grad_enabled(outer_grad):
+                return ba_implicit_step(self, packed, float(step), kwargs)
+        if packed.group not in ("SE3", "SE2"):
+            raise NotImplementedError("HIP back end: backward_mode='implicit' is fused for SE3 / SE2 pose graphs and bundle "
+                                      f"adjustment (got {packed.group}); there is no autograd/CPU fallback.")
         with torch.set_grad_enabled(outer_grad):
             packed.flush_variables()
             packed.sync(force=True)  # re-pack the auxiliary tensors WITH their autograd history
