@@ -75,11 +75,12 @@ def test_best_iter_and_state_history():
         layer.forward(None, optimizer_kwargs=dict(track_state_history=True, **kw))
 
 
-def test_global_params_mirror():
+def test_global_params_mirror(monkeypatch):
     """theseus_amd.set_global_params takes the reference's option names (theseus/global_params.py:46-80,
     torchlie/global_params.py:44-68) for the thresholds this path reads; fast_approx_local_jacobians is refused loudly."""
     import theseus_amd as th
     import theseus_amd.kernels as tk
+    monkeypatch.setattr(tk, "_REFERENCE_PARAMS", None)   # (stand-alone use: theseus_amd.plugin, if imported, reads the reference's)
     try:
         th.set_global_params({"so3_near_zero_eps_float32": 0.5, "so3_d_near_zero_eps_float64": 0.25, "se2_d_near_zero_eps_float32": 0.75})
         assert tk.lie_eps(torch.float32).near_zero == 0.5 and tk.lie_eps(torch.float64).d_near_zero == 0.25

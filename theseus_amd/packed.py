@@ -8,6 +8,7 @@ the fused HIP kernels index directly.  Variables are tracked by ``_num_updates``
 buffers are re-packed only when somebody changed a variable behind our back.
 """
 import dataclasses
+import weakref
 from typing import Optional
 
 import torch
@@ -247,11 +248,14 @@ class PackedPoseGraph:
 
     # ---- buffers whose per-pose views are known (so that a list of variable tensors can be recognised as one buffer) ----
     def remember_views(self, buf: torch.Tensor, views):
-        self._known = [(buf, tuple(views))] + self._known[:3]
+        # WEAK references: remembering a buffer must not keep it (50 MB at the headline size) alive -- the caching allocator
+        # would have to hipMalloc fresh state buffers in every optimize() (measured: +20 ms per optimize)
+        self._known = [(weakref.ref(buf), tuple(weakref.ref(v) for v in views))] + self._known[:1]
 
     def buffer_of(self, tensors):
-        for buf, views in self._known:
-            if len(views) == len(tensors) and all(a is b for a, b in zip(tensors, views)):
+        for wbuf, views in self._known:
+            buf = wbuf()
+            if buf is not None and len(views) == len(tensors) and all(a is r() for a, r in zip(tensors, views)):
                 return buf
         return None
 
