@@ -211,6 +211,28 @@ int thx_se3_retract(const void* poses, const void* delta, int64_t ldd, double st
                     const uint8_t* ignore_mask, void* out, int32_t P, int32_t B, int dtype,
                     const thx_lie_eps* eps, void* stream);
 
+/* ---- tile-sparse Cholesky for LARGE pose graphs -- the functional analogue of BaspachoSparseSolver
+ *      (theseus/optimizer/linear/baspacho_sparse_solver.py:23-148; symbolic analysis once, numeric factorisation per iteration).
+ *      Same kernels and storage as thx_chol_factor[_forward] (dense row-major H / L frames), but only the 128x128 tiles of L
+ *      that are STRUCTURALLY non-zero are computed, and every tile's K-loop visits only the block columns in which both of
+ *      its row panels are non-zero: the work follows the fill of the (fill-reducing ordered) block pattern instead of n^3/3.
+ *      Tiles outside the pattern are never written: L must be zero-initialised once.  The pattern is the host's symbolic
+ *      factorisation at tile granularity (theseus_amd/sparse.py:tile_pattern); all tables int32, device pointers except
+ *      col_count_host.  rhs / y may both be NULL (no fused forward substitution).  The solves are thx_chol_solve*. */
+typedef struct {
+  int32_t ntiles;                 /* ceil(n / THX_TILE) */
+  const int32_t* col_ptr;         /* (ntiles + 1) off-diagonal non-zero tiles of block column j: entries [col_ptr[j], col_ptr[j+1]) */
+  const int32_t* col_row;         /* (entries) row tile of every entry, ascending within a column */
+  const int32_t* tile_kptr;       /* (entries + 1) K-list of entry e: */
+  const int32_t* tile_k;          /*   block columns k < j in which L_ik and L_jk are both non-zero */
+  const int32_t* diag_kptr;       /* (ntiles + 1) K-list of diagonal tile j: */
+  const int32_t* diag_k;          /*   block columns k < j in which L_jk is non-zero */
+  const int32_t* col_count_host;  /* (ntiles) HOST copy of col_ptr[j+1] - col_ptr[j] (launch sizes) */
+} thx_tile_pattern;
+int thx_chol_factor_sparse(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
+                           double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y, int64_t ldv,
+                           const thx_tile_pattern* pattern, int dtype, void* stream);
+
 /* ---- LinearSolver.solve(): replaces DenseSolver._apply_damping + CholeskyDenseSolver._solve_sytem
  *      (linear/dense_solver.py:38-64,159-161).
  *      thx_chol_factor: L L^T = H + damping (out of place: H stays undamped, as the reference

@@ -349,6 +349,15 @@ class OracleKernels:
         if rhs is not None:
             y.copy_(torch.linalg.solve_triangular(Lc, rhs.unsqueeze(2), upper=False).squeeze(2))
 
+    def chol_factor_sparse(self, H, n, damping, ellipsoidal, damping_eps, L, panels, info, pattern, rhs=None, y=None):
+        """Dense factorisation + the check that makes the CPU run meaningful: the numeric factor has no entry outside the
+        symbolic tile pattern the HIP kernels would have been launched over."""
+        self.chol_factor(H, n, damping, ellipsoidal, damping_eps, L, panels, info, rhs=rhs, y=y)
+        nt = pattern.ntiles
+        Lp = torch.nn.functional.pad(L[:, :n, :n], (0, nt * 128 - n, 0, nt * 128 - n))
+        tiles = Lp.view(L.shape[0], nt, 128, nt, 128).abs().amax(dim=(0, 2, 4)) > 0
+        assert not (tiles & ~torch.from_numpy(pattern.lower)).any(), "numeric fill outside the symbolic tile pattern"
+
     def chol_solve_backward(self, L, n, panels, y, x):
         x.copy_(torch.linalg.solve_triangular(L[:, :n, :n].transpose(1, 2), y.unsqueeze(2), upper=True).squeeze(2))
 

@@ -1,0 +1,94 @@
+"""-m gpu: thx_chol_factor_sparse (tile-sparse Cholesky, BaspachoSparseSolver's role) on the HIP kernels: bit-identical to the
+dense factorisation of the same banded matrices (skipped tiles are exact zeros), and LM on a large chain-like pose graph
+with HipSparseCholeskySolver == the dense solver."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _banded_spd(B, n, bw_tiles, dtype, seed):
+    """block-banded SPD matrices: 6x6 blocks within ``bw_tiles`` tiles of the diagonal (+ a few far blocks -> fill)."""
+    from theseus_amd.sparse import TilePattern
+    P = n // 6
+    rng = np.random.default_rng(seed)
+    reach = bw_tiles * 21
+    blocks = {(p, p) for p in range(P)} | {(p, p - 1) for p in range(1, P)}
+    blocks |= {(p, max(0, p - int(rng.integers(2, reach)))) for p in range(2, P, 3)}
+    blocks |= {(P - 5, 10)}                                    # one long-range block: fill along the last block rows
+    blocks = np.array(sorted(blocks))
+    gen = torch.Generator().manual_seed(seed)
+    H = torch.zeros(B, n, n, dtype=torch.float64)
+    for r, c in blocks:
+        H[:, 6 * r:6 * r + 6, 6 * c:6 * c + 6] = torch.randn(B, 6, 6, dtype=torch.float64, generator=gen)
+    H = torch.tril(H) + torch.tril(H, -1).transpose(1, 2) + 60.0 * torch.eye(n, dtype=torch.float64)
+    return H.to(dtype), TilePattern(n, blocks, 6)
+
+
+@pytest.mark.parametrize("dtype,n,B", [(torch.float32, 3072, 24), (torch.float64, 1536, 8), (torch.float32, 1530, 1100)])
+def test_sparse_factorisation_is_bit_identical_to_dense(dtype, n, B):
+    from theseus_amd.kernels import default_kernels, round_up
+    K = default_kernels()
+    Hc, pat = _banded_spd(B, n, 2, dtype, seed=n)
+    assert pat.l_tiles < pat.ntiles * (pat.ntiles + 1) // 2
+    ld = round_up(n, 32)
+    H = torch.zeros(B, ld, ld, dtype=dtype, device="cuda")
+    H[:, :n, :n] = Hc.cuda()
+    lam = torch.full((B,), 0.5, dtype=dtype, device="cuda")
+    rhs = torch.randn(B, n, dtype=dtype, device="cuda")
+    nt = (n + 127) // 128
+    out = []
+    for sparse in (False, True):
+        L = torch.zeros_like(H)
+        panels = torch.zeros(B, nt, 128, 128, dtype=dtype, device="cuda")
+        info = torch.empty(B, dtype=torch.int32, device="cuda")
+        y, x = torch.empty_like(rhs), torch.empty_like(rhs)
+        if sparse:
+            K.chol_factor_sparse(H, n, lam, True, 1e-8, L, panels, info, pat, rhs=rhs, y=y)
+        else:
+            K.chol_factor(H, n, lam, True, 1e-8, L, panels, info, rhs=rhs, y=y)
+        K.chol_solve_backward(L, n, panels, y, x)
+        assert int(info.abs().sum()) == 0
+        out.append((torch.tril(L[:, :n, :n]).clone(), y.clone(), x.clone()))
+    (Ld, yd, xd), (Ls, ys, xs) = out
+    assert torch.equal(Ld, Ls) and torch.equal(yd, ys) and torch.equal(xd, xs)
+    # and it IS the factor: residual against fp64
+    Hd = Hc[:2].double().cuda()
+    Hd = Hd + torch.diag_embed(0.5 * Hd.diagonal(dim1=1, dim2=2) + 1e-8)
+    Lc = Ls[:2].double()
+    assert ((Lc @ Lc.transpose(1, 2) - Hd).abs().max() / Hd.abs().max()).item() < (5e-6 if dtype == torch.float32 else 1e-13)
+
+
+def test_lm_on_a_large_chain_graph_sparse_equals_dense():
+    """600 SE3 poses (n = 3600, 29 tiles), shuffled labels: the sparse solver (RCM ordering + tile pattern) reproduces the dense
+    solver's LM run; the pattern prunes most of the tile products."""
+    import theseus_amd as th
+    from tests.test_sparse_solver import chain_graph
+    P, B, dtype = 600, 4, torch.float64
+    edges = chain_graph(P, stride=7, span=5, seed=2)
+    K = th.default_kernels()
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    rnd = lambda nn, s: K.se3_exp(s * (2 * torch.rand(nn, 6, dtype=dtype, device="cuda", generator=gen) - 1))  # noqa: E731
+    gt = rnd(B * P, 1.5).view(B, P, 3, 4)
+    poses0 = K.se3_compose(gt.reshape(-1, 3, 4), rnd(B * P, 0.05)).view(B, P, 3, 4)
+    meas = [K.se3_compose(K.se3_compose(K.se3_inverse(gt[:, i].contiguous()), gt[:, j].contiguous()), rnd(B, 0.01)) for (i, j) in edges]
+
+    def run(solver_cls):
+        obj = th.Objective(dtype=dtype)
+        pv = [th.SE3(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+        w = th.ScaleCostWeight(torch.tensor(5.0, dtype=dtype, device="cuda"))
+        for k, (i, j) in enumerate(edges):
+            obj.add(th.Between(pv[i], pv[j], th.SE3(tensor=meas[k].clone(), name=f"m_{k}"), w, name=f"b_{k}"))
+        obj.add(th.Difference(pv[edges[0][0]], th.SE3(tensor=gt[:, edges[0][0]].clone(), name="anchor"), w, name="prior"))
+        opt = th.LevenbergMarquardt(obj, linear_solver_cls=solver_cls, max_iterations=5, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+        sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(damping=1e-2, track_err_history=True))
+        return torch.stack([sol[f"pose_{k}"] for k in range(P)], 1), info, opt
+    dense, dinfo, _ = run(th.HipCholeskySolver)
+    sparse, sinfo, opt = run(th.HipSparseCholeskySolver)
+    pat = opt.linear_solver.pattern
+    print(f"[sparse LM] tiles of L: {pat.l_tiles} of {pat.ntiles * (pat.ntiles + 1) // 2}; tile products {pat.tile_products} vs dense {pat.dense_tile_products}")
+    assert pat.tile_products * 5 < pat.dense_tile_products
+    np.testing.assert_allclose(sparse.cpu().numpy(), dense.cpu().numpy(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(sinfo.err_history.numpy(), dinfo.err_history.numpy(), rtol=1e-9)
+    assert sinfo.err_history[:, -1].mean() < 0.05 * sinfo.err_history[:, 0].mean()

@@ -1,0 +1,99 @@
+"""Tile-sparse Cholesky solver (theseus_amd/sparse.py): symbolic tile pattern, fill-reducing variable ordering, and the host
+path end to end on a chain-like pose graph (TEST stand-in kernels here; the HIP kernels in tests/test_gpu_sparse.py)."""
+import numpy as np
+import pytest
+import torch
+
+
+def chain_graph(P, stride=7, span=5, seed=0, shuffle=True):
+    """odometry chain + local loop closures; pose NAMES are shuffled so that insertion order is far from banded."""
+    rng = np.random.default_rng(seed)
+    edges = [(i, i + 1) for i in range(P - 1)] + [(i, i + span) for i in range(0, P - span, stride)]
+    label = rng.permutation(P) if shuffle else np.arange(P)
+    return [(int(label[a]), int(label[b])) for a, b in edges]
+
+
+def test_tile_pattern_covers_the_numeric_fill():
+    from theseus_amd.sparse import TilePattern
+    rng = np.random.default_rng(3)
+    P, dof = 120, 6
+    n = P * dof
+    blocks = {(p, p) for p in range(P)} | {(p, p - 1) for p in range(1, P)} | {(p, p - 9) for p in range(9, P, 4)} | {(77, 3), (110, 40)}
+    blocks = np.array(sorted(blocks))
+    tp = TilePattern(n, blocks, dof)
+    A = np.zeros((n, n))
+    for r, c in blocks:
+        A[dof * r:dof * r + dof, dof * c:dof * c + dof] = rng.standard_normal((dof, dof))
+    A = np.tril(A) + np.tril(A, -1).T + 40 * np.eye(n)
+    L = np.linalg.cholesky(A)
+    nt = tp.ntiles
+    Lp = np.zeros((nt * 128, nt * 128))
+    Lp[:n, :n] = L
+    tiles = np.abs(Lp.reshape(nt, 128, nt, 128)).max(axis=(1, 3)) > 0
+    assert not (tiles & ~tp.lower).any()                       # the symbolic pattern covers every numeric non-zero tile
+    assert tp.l_tiles < nt * (nt + 1) // 2                     # ... and is sparser than the dense lower triangle
+    t = tp.tables
+    for j in range(nt):                                        # tables: CSR over columns, K-lists = row-pattern intersections
+        rows = t["col_row"][t["col_ptr"][j]:t["col_ptr"][j + 1]].tolist()
+        assert rows == (np.nonzero(tp.lower[j + 1:, j])[0] + j + 1).tolist() and tp.col_count[j] == len(rows)
+        assert t["diag_k"][t["diag_kptr"][j]:t["diag_kptr"][j + 1]].tolist() == np.nonzero(tp.lower[j, :j])[0].tolist()
+        for e, i in zip(range(t["col_ptr"][j], t["col_ptr"][j + 1]), rows):
+            want = np.nonzero(tp.lower[i, :j] & tp.lower[j, :j])[0].tolist()
+            assert t["tile_k"][t["tile_kptr"][e]:t["tile_kptr"][e + 1]].tolist() == want
+
+
+def test_rcm_ordering_makes_a_shuffled_chain_banded():
+    from theseus_amd.sparse import TilePattern, rcm_order
+    P = 600
+    edges = chain_graph(P)
+    blocks0 = np.array(sorted({(p, p) for p in range(P)} | {(max(a, b), min(a, b)) for a, b in edges}))
+    perm = rcm_order(P, edges)
+    pos = np.empty(P, dtype=np.int64)
+    pos[perm] = np.arange(P)
+    blocks1 = np.array(sorted({(p, p) for p in range(P)} | {(max(pos[a], pos[b]), min(pos[a], pos[b])) for a, b in edges}))
+    t0, t1 = TilePattern(6 * P, blocks0, 6), TilePattern(6 * P, blocks1, 6)
+    assert sorted(perm) == list(range(P))
+    assert t1.tile_products * 8 < t0.tile_products             # shuffled labels: (almost) dense fill; RCM: a narrow band
+    assert t1.tile_products * 10 < t1.dense_tile_products
+
+
+@pytest.mark.parametrize("group", ["SE3", "SE2"])
+def test_sparse_solver_equals_dense_solver_through_the_host_path(group):
+    """LM on a shuffled chain graph: HipSparseCholeskySolver (fill-reducing VariableOrdering -> permuted packed poses, permuted
+    Hessian columns, tile pattern) gives the dense solver's solution; the stand-in asserts that the numeric factor stays inside
+    the symbolic pattern."""
+    import theseus_amd as th
+    from oracle import lie, lie_se2
+    from tests.oracle_kernels import OracleKernels
+    P, B, dtype = 90, 2, torch.float64
+    edges = chain_graph(P, stride=5, span=4, seed=1)
+    gen = torch.Generator().manual_seed(4)
+    if group == "SE3":
+        G, exp, comp, inv, dof = th.SE3, lie.se3_exp, lie.se3_compose, lie.se3_inverse, 6
+    else:
+        G, exp, comp, inv, dof = th.SE2, lie_se2.se2_exp, lie_se2.se2_compose, lie_se2.se2_inverse, 3
+    gt = exp(1.5 * (2 * torch.rand(B * P, dof, dtype=dtype, generator=gen) - 1)).view(B, P, *G().tensor.shape[1:])
+    noise = lambda n, s: exp(s * (2 * torch.rand(n, dof, dtype=dtype, generator=gen) - 1))  # noqa: E731
+    rec = gt.shape[2:]
+    poses0 = comp(gt.reshape(-1, *rec), noise(B * P, 0.05)).view(B, P, *rec)
+    meas = [comp(comp(inv(gt[:, i]), gt[:, j]), noise(B, 0.01)) for (i, j) in edges]
+
+    def run(solver_cls):
+        obj = th.Objective(dtype=dtype)
+        pv = [G(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+        w = th.ScaleCostWeight(torch.tensor(5.0, dtype=dtype))
+        for k, (i, j) in enumerate(edges):
+            obj.add(th.Between(pv[i], pv[j], G(tensor=meas[k].clone(), name=f"m_{k}"), w, name=f"b_{k}"))
+        obj.add(th.Difference(pv[edges[0][0]], G(tensor=gt[:, edges[0][0]].clone(), name="anchor"), w, name="prior"))
+        opt = th.LevenbergMarquardt(obj, linear_solver_cls=solver_cls, linearization_kwargs=dict(kernels=OracleKernels()),
+                                    max_iterations=5, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+        sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(damping=1e-2, track_err_history=True))
+        return torch.stack([sol[f"pose_{k}"] for k in range(P)], 1), info, opt
+    dense, dinfo, _ = run(th.HipCholeskySolver)
+    sparse, sinfo, opt = run(th.HipSparseCholeskySolver)
+    lin = opt.linear_solver.linearization
+    assert [v.name for v in lin.ordering] != [f"pose_{k}" for k in range(P)]          # a genuinely permuted column order
+    assert opt.linear_solver.pattern.tile_products < opt.linear_solver.pattern.dense_tile_products
+    np.testing.assert_allclose(sparse.numpy(), dense.numpy(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(sinfo.err_history.numpy(), dinfo.err_history.numpy(), rtol=1e-9)
+    assert sinfo.err_history[:, -1].mean() < 0.05 * sinfo.err_history[:, 0].mean()

@@ -10,6 +10,7 @@ from .kernels import (HipKernels, default_kernels, reset_global_params, set_glob
                       set_se2_eps)
 from .layer import TheseusLayer  # noqa: F401
 from .linear_solver import HipCholeskySolver, LinearSolver  # noqa: F401
+from .sparse import HipSparseCholeskySolver, fill_reducing_ordering  # noqa: F401
 from .linearization import HipLinearization, Linearization, VariableOrdering  # noqa: F401
 from .nonlinear import (BackwardMode, GaussNewton, LevenbergMarquardt, NonlinearLeastSquares,  # noqa: F401
                         NonlinearOptimizerInfo, NonlinearOptimizerStatus)

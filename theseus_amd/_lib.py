@@ -19,7 +19,7 @@ THX_TILE = 128
 THX_ERR_CHUNKS = 16
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class LieEps(Structure):
@@ -44,6 +44,11 @@ class BAData(Structure):  # thx_ba_data
         ("pt_prior_target", c_void_p), ("pt_prior_target_bstride", c_int64),
         ("w_pt_prior", c_void_p), ("w_pt_prior_bstride", c_int64),
     ]
+
+
+class TilePattern(Structure):  # thx_tile_pattern: tile-level symbolic factorisation (device int32 tables + one host table)
+    _fields_ = [("ntiles", c_int32)] + [(k, c_void_p) for k in ("col_ptr", "col_row", "tile_kptr", "tile_k", "diag_kptr", "diag_k",
+                                                               "col_count_host")]
 
 
 class SE2Eps(Structure):  # thx_se2_eps (theseus/global_params.py:46-59)
@@ -124,6 +129,8 @@ _SIGNATURES = {
                         c_void_p, c_int, c_void_p],
     "thx_chol_factor_forward": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    "thx_chol_factor_sparse": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_int64, POINTER(TilePattern), c_int, c_void_p],
     "thx_chol_solve": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                        c_void_p],
     "thx_chol_solve_backward": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,

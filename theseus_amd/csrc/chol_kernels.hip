@@ -423,10 +423,15 @@ struct NoHook {
 // ``after_issue`` runs right after the loads of the first k-chunk(s) have been ISSUED: whatever else a kernel wants in
 // flight before its K-loop (H tile, solve panel) goes there, so that its latency overlaps the first chunk's instead of
 // preceding it.
+//
+// ``ktiles`` (tile-sparse factorisation, thx_chol_factor_sparse): instead of the contiguous range [0, K) the loop visits the
+// TILE-wide column blocks ktiles[0 .. K / TILE) -- the block columns in which BOTH operand row panels are structurally
+// non-zero.  The list is wave uniform (scalar loads); skipping a block of exact zeros leaves every accumulator bit unchanged.
 template <typename T, bool SAME, bool GEMV, int LDT, typename Compute, typename Hook = NoHook>
 __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA, const T* __restrict__ Brows,
                                         int validB, int64_t ld, int K, T* sA, T* sB, int tid, const T* gemv_y,
-                                        T* gemv_part, Compute&& compute, Hook&& after_issue = NoHook{}) {
+                                        T* gemv_part, Compute&& compute, Hook&& after_issue = NoHook{},
+                                        const int32_t* __restrict__ ktiles = nullptr) {
   using C = CT<T>;
   using V = typename C::V;
   const int lrow = tid >> 3, lc = tid & 7;
@@ -460,6 +465,11 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
     }
   };
   const int nk = K / C::KB;
+  constexpr int CPT = TILE / C::KB;   // k-chunks per tile
+  // first column of k-chunk kc
+  auto kof = [&](int kc) __attribute__((always_inline)) -> int {
+    return ktiles ? ktiles[kc / CPT] * TILE + (kc % CPT) * C::KB : kc * C::KB;
+  };
   T gsum = T(0);
   // one k-chunk: registers -> LDS, refill the registers with the chunk AHEAD steps on, MFMAs on the staged chunk
   // (a static s_setprio per hardware wave slot, to push the two co-resident workgroups out of lockstep, measured no gain)
@@ -488,15 +498,15 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
     __syncthreads();
 #endif
 #ifdef THX_EXP_NOLOAD
-    if (kc == 0 && kc + AHEAD < nk) gload(xa, xb, (kc + AHEAD) * C::KB);  // timing experiment: operands are not streamed
+    if (kc == 0 && kc + AHEAD < nk) gload(xa, xb, kof(kc + AHEAD));  // timing experiment: operands are not streamed
 #else
-    if (kc + AHEAD < nk) gload(xa, xb, (kc + AHEAD) * C::KB);
+    if (kc + AHEAD < nk) gload(xa, xb, kof(kc + AHEAD));
 #endif
     if constexpr (GEMV) {
       if (gemv_y) {
         constexpr int HALF = C::KB / 2;
         const V* rp = reinterpret_cast<const V*>(sA + (tid >> 1) * LDT + (tid & 1) * HALF);
-        const V* yp = reinterpret_cast<const V*>(gemv_y + kc * C::KB + (tid & 1) * HALF);
+        const V* yp = reinterpret_cast<const V*>(gemv_y + kof(kc) + (tid & 1) * HALF);
 #pragma unroll
         for (int i = 0; i < HALF / C::VEC; ++i) {
           const V a = rp[i], yv = yp[i];
@@ -516,7 +526,7 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   };
 #pragma unroll
   for (int a = 0; a < AHEAD; ++a)
-    if (a < nk) gload(ra[a], rb[a], a * C::KB);
+    if (a < nk) gload(ra[a], rb[a], kof(a));
   after_issue();
   for (int kc = 0; kc < nk; kc += AHEAD) {
     step(ra[0], rb[0], kc);
@@ -533,11 +543,12 @@ template <typename T, bool SAME, bool GEMV = false, typename Hook = NoHook>
 __device__ __forceinline__ void kloop(const T* __restrict__ Arows, int validA, const T* __restrict__ Brows,
                                       int validB, int64_t ld, int K, T* sA, T* sB,
                                       typename Engine<T>::Acc& acc, int tid, const T* gemv_y = nullptr,
-                                      T* gemv_part = nullptr, Hook&& after_issue = NoHook{}) {
+                                      T* gemv_part = nullptr, Hook&& after_issue = NoHook{},
+                                      const int32_t* __restrict__ ktiles = nullptr) {
   const int wave = tid >> 6, lane = tid & 63;
   kloop_f<T, SAME, GEMV, CT<T>::LDT>(Arows, validA, Brows, validB, ld, K, sA, sB, tid, gemv_y, gemv_part, [&]() __attribute__((always_inline)) {
     Engine<T>::chunk(sA, (SAME ? sA : sB) + 32 * wave * CT<T>::LDT, acc, lane);
-  }, after_issue);
+  }, after_issue, ktiles);
 }
 
 
@@ -912,6 +923,16 @@ __device__ __forceinline__ int potrf_inv32_blocked(T* Dss, T* Lg, int64_t ld, in
 // chol_diag: SYRK + blocked Cholesky of the 128x128 diagonal tile of block column j, panel M_j,
 // fused forward substitution
 // ------------------------------------------------------------------------------------------------
+// device view of thx_tile_pattern (include/theseus_hip.h): which 128x128 tiles of L are structurally non-zero
+struct TilePat {
+  const int32_t* col_ptr;    // (ntiles + 1) entries of block column j: [col_ptr[j], col_ptr[j + 1])
+  const int32_t* col_row;    // row tile of every entry (ascending within a column)
+  const int32_t* tile_kptr;  // (entries + 1) K-list of entry e ...
+  const int32_t* tile_k;     // ... block columns k < j in which L_ik and L_jk are both non-zero
+  const int32_t* diag_kptr;  // (ntiles + 1) K-list of diagonal tile j ...
+  const int32_t* diag_k;     // ... block columns k < j with L_jk non-zero
+};
+
 template <typename T>
 struct DiagSmem {
   // ten 32 x LDB sub-blocks; the K-loop's staging buffer (128 x SYRK_LDT) lives in its head
@@ -925,7 +946,7 @@ template <typename T>
 __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 3 : 1)
 chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ panel, const T* __restrict__ damping,
                  int ellipsoidal, T damping_eps, int32_t* __restrict__ info, int n, int64_t ld, int j, int ntiles,
-                 const T* __restrict__ rhs, T* __restrict__ yout, int64_t ldv) {
+                 const T* __restrict__ rhs, T* __restrict__ yout, int64_t ldv, TilePat pat) {
   using C = CT<T>;
   using V = typename C::V;
   using E = Engine<T>;
@@ -972,7 +993,10 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 #ifdef THX_OFF_PROLOGUE_FIRST   // the round-1 order (A/B timing)
   prologue();
 #endif
-  kloop_f<T, true, true, E::SYRK_LDT>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, row0, tile, nullptr, tid,
+  // tile-sparse: only the block columns k < j in which row panel j is non-zero
+  const int32_t* klist = pat.diag_k ? pat.diag_k + pat.diag_kptr[j] : nullptr;
+  const int Kspan = pat.diag_k ? (pat.diag_kptr[j + 1] - pat.diag_kptr[j]) * TILE : row0;
+  kloop_f<T, true, true, E::SYRK_LDT>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, Kspan, tile, nullptr, tid,
                          fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
     if (wave == 0) E::template syrk36<0>(tile, acc, lane);
     else if (wave == 1) E::template syrk36<1>(tile, acc, lane);
@@ -980,9 +1004,9 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
     else E::template syrk36<3>(tile, acc, lane);
   },
 #ifdef THX_OFF_PROLOGUE_FIRST
-  NoHook{});
+  NoHook{}, klist);
 #else
-  prologue);
+  prologue, klist);
 #endif
 
   // ---- S = H_jj (+ damping on the diagonal) - acc -> LDS tile; identity padding outside the matrix ----
@@ -1190,13 +1214,17 @@ __device__ __forceinline__ void sub_mma_sw(const float* Pc, const Engine<float>:
 
 __global__ void __launch_bounds__(256, 2)
 chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, const float* __restrict__ panel, int n,
-                        int64_t ld, int j, int ntiles, int i_first, int nrow_tiles, int B) {
+                        int64_t ld, int j, int ntiles, int i_first, int nrow_tiles, int B, TilePat pat) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
   const int b = (slot / nrow_tiles) * 8 + xcd;
-  const int i = i_first + (slot % nrow_tiles);  // row tiles [i_first, i_first + nrow_tiles) of block column j
+  // row tiles [i_first, i_first + nrow_tiles) of block column j -- or, tile-sparse, the column's non-zero row tiles
+  const int ent = pat.col_row ? pat.col_ptr[j] + (slot % nrow_tiles) : 0;
+  const int i = pat.col_row ? pat.col_row[ent] : i_first + (slot % nrow_tiles);
+  const int32_t* klist = pat.col_row ? pat.tile_k + pat.tile_kptr[ent] : nullptr;
+  const int Kspan = pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE;
   if (b >= B) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t mat = (int64_t)b * ld * ld;
@@ -1254,10 +1282,11 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   // (two LDS staging buffers with ONE barrier per k-chunk instead of one buffer with two -- panel copy moved behind the
   //  loop to keep 2 workgroups/CU -- measured the same 9.3-9.4 k cycles per chunk: the barriers are not the K-loop's limit)
 #ifdef THX_OFF_PROLOGUE_FIRST
-  kloop<float, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, col0, sA, sB, P, tid);
+  kloop<float, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, Kspan, sA, sB, P, tid,
+                      nullptr, nullptr, NoHook{}, klist);
 #else
-  kloop<float, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, col0, sA, sB, P, tid,
-                      nullptr, nullptr, prologue);
+  kloop<float, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, Kspan, sA, sB, P, tid,
+                      nullptr, nullptr, prologue, klist);
 #endif
 #ifdef THX_OFF_PROF
   __builtin_amdgcn_sched_barrier(0);
@@ -1345,14 +1374,17 @@ __device__ __forceinline__ void sub_mma64(const double* blk, const Engine<double
 
 __global__ void __launch_bounds__(256, 2)
 chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, const double* __restrict__ panel, int n,
-                        int64_t ld, int j, int ntiles, int i_first, int nrow_tiles, int B) {
+                        int64_t ld, int j, int ntiles, int i_first, int nrow_tiles, int B, TilePat pat) {
   using E = Engine<double>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* smem = reinterpret_cast<double*>(smem_raw);
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
   const int b = (slot / nrow_tiles) * 8 + xcd;
-  const int i = i_first + (slot % nrow_tiles);
+  const int ent = pat.col_row ? pat.col_ptr[j] + (slot % nrow_tiles) : 0;
+  const int i = pat.col_row ? pat.col_row[ent] : i_first + (slot % nrow_tiles);
+  const int32_t* klist = pat.col_row ? pat.tile_k + pat.tile_kptr[ent] : nullptr;
+  const int Kspan = pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE;
   if (b >= B) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int rl = lane & 15, kq = lane >> 4;
@@ -1364,7 +1396,8 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
 
   E::Acc P;
   E::zero(P);
-  kloop<double, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, col0, sA, sB, P, tid);
+  kloop<double, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, Kspan, sA, sB, P, tid,
+                       nullptr, nullptr, NoHook{}, klist);
   // ---- P = H_ij - sum, H straight from global memory in the native layout (rows outside the matrix: zero) ----
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -1668,8 +1701,14 @@ static DeviceLaunchState& launch_state() {
 
 template <typename T>
 static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damping, int ellipsoidal, double eps,
-                       void* L, void* panel, int32_t* info, const void* rhs, void* y, int64_t ldv, hipStream_t st) {
+                       void* L, void* panel, int32_t* info, const void* rhs, void* y, int64_t ldv, hipStream_t st,
+                       const thx_tile_pattern* tp = nullptr) {
   const int ntiles = (n + TILE - 1) / TILE;
+  TilePat pat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (tp) {
+    if (tp->ntiles != ntiles) return fail("thx_chol_factor_sparse: the tile pattern was built for another matrix order");
+    pat = TilePat{tp->col_ptr, tp->col_row, tp->tile_kptr, tp->tile_k, tp->diag_kptr, tp->diag_k};
+  }
   const size_t dsm = DiagSmem<T>::bytes(rhs ? ntiles * TILE : 0);
   if (dsm > LDS_LIMIT) return fail("thx_chol_factor: n too large for the fused forward substitution (LDS)");
   std::lock_guard<std::mutex> guard(g_launch_mutex);   // (the whole enqueue: the auxiliary stream / events are shared)
@@ -1723,16 +1762,16 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     const int64_t mo = (int64_t)h.b0 * ld * ld, po = (int64_t)h.b0 * ntiles * TILE * TILE;
     if constexpr (sizeof(T) == 4)
       hipLaunchKernelGGL(chol_offdiag_f32_kernel, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, h.s, (const float*)H + mo,
-                         (float*)L + mo, (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb);
+                         (float*)L + mo, (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat);
     else
       hipLaunchKernelGGL(chol_offdiag_f64_kernel, dim3(Bpad * nrt), dim3(256), OFF64_SMEM, h.s, (const double*)H + mo,
-                         (double*)L + mo, (const double*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb);
+                         (double*)L + mo, (const double*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat);
   };
   auto launch_diag = [&](const Half& h, int j) {
     const int64_t mo = (int64_t)h.b0 * ld * ld, po = (int64_t)h.b0 * ntiles * TILE * TILE;
     hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(h.nb), dim3(256), dsm, h.s, (const T*)H + mo, (T*)L + mo, (T*)panel + po,
                        damping ? (const T*)damping + h.b0 : nullptr, ellipsoidal, (T)eps, info + h.b0, n, ld, j, ntiles,
-                       rhs ? (const T*)rhs + (int64_t)h.b0 * ldv : nullptr, y ? (T*)y + (int64_t)h.b0 * ldv : nullptr, ldv);
+                       rhs ? (const T*)rhs + (int64_t)h.b0 * ldv : nullptr, y ? (T*)y + (int64_t)h.b0 * ldv : nullptr, ldv, pat);
   };
   for (int j = 0; j < ntiles; ++j) {
     for (int k = 0; k < 2; ++k) {
@@ -1741,7 +1780,8 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       if (split && k == 1 && j == 0) hipStreamWaitEvent(aux, ev_lag, 0);  // second half: one diagonal phase behind
       launch_diag(h, j);
       if (split && k == 0 && j == 0) hipEventRecord(ev_lag, st);
-      if (ntiles - 1 - j > 0) launch_off(h, j, j + 1, ntiles - 1 - j);
+      const int nrt = tp ? tp->col_count_host[j] : ntiles - 1 - j;   // (tile-sparse: the column's non-zero row tiles)
+      if (nrt > 0) launch_off(h, j, j + 1, nrt);
     }
   }
   if (split) {
@@ -1815,6 +1855,23 @@ int thx_chol_factor_forward(const void* H, int64_t ld, int32_t n, int32_t B, con
                                          as_stream(stream)),
                return factor_impl<double>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
                                           as_stream(stream)));
+  return 0;
+}
+
+int thx_chol_factor_sparse(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
+                           double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y, int64_t ldv,
+                           const thx_tile_pattern* pattern, int dtype, void* stream) {
+  if (int r = check_factor_args(H, L, Winv, info, n, B, ld)) return r;
+  if (!pattern || !pattern->col_ptr || !pattern->col_row || !pattern->tile_kptr || !pattern->tile_k || !pattern->diag_kptr ||
+      !pattern->diag_k || !pattern->col_count_host)
+    return fail("thx_chol_factor_sparse: incomplete tile pattern");
+  if ((rhs == nullptr) != (y == nullptr) || (rhs && ldv < n)) return fail("thx_chol_factor_sparse: rhs / y / ldv");
+  if (rhs && rhs == y) return fail("thx_chol_factor_sparse: y must not alias rhs");
+  THX_DISPATCH(dtype,
+               return factor_impl<float>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
+                                         as_stream(stream), pattern),
+               return factor_impl<double>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
+                                          as_stream(stream), pattern));
   return 0;
 }
 

@@ -514,6 +514,16 @@ class HipKernels:
                                                         _lib.dtype_code(H.dtype), _lib.stream_ptr(H.device)),
                        "thx_chol_factor_forward")
 
+    def chol_factor_sparse(self, H, n, damping, ellipsoidal, damping_eps, L, panels, info, pattern, rhs=None, y=None):
+        """thx_chol_factor_sparse: ``pattern`` is a theseus_amd.sparse.TilePattern (device tables of the symbolic tile
+        factorisation); otherwise as chol_factor."""
+        B, ld = H.shape[0], H.shape[-1]
+        _lib.check(self.lib.thx_chol_factor_sparse(_lib.ptr(H), ld, n, B, _lib.ptr(damping), int(bool(ellipsoidal)),
+                                                   float(damping_eps), _lib.ptr(L), _lib.ptr(panels), _lib.ptr(info),
+                                                   _lib.ptr(rhs), _lib.ptr(y), rhs.stride(0) if rhs is not None else 0,
+                                                   pattern.c_struct(H.device), _lib.dtype_code(H.dtype),
+                                                   _lib.stream_ptr(H.device)), "thx_chol_factor_sparse")
+
     def chol_solve(self, L, n, panels, rhs, x):
         B, ld = L.shape[0], L.shape[-1]
         _lib.check(self.lib.thx_chol_solve(_lib.ptr(L), ld, n, B, _lib.ptr(panels), _lib.ptr(rhs), _lib.ptr(x),

@@ -110,9 +110,9 @@ class HipLinearizationCore:
     theseus_amd's mirror (below) or the real ``theseus.optimizer.Linearization`` (theseus_amd/plugin.py)."""
 
     def _core_init(self, objective, kernels=None):
-        if [v.name for v in self.ordering] != list(objective.optim_vars.keys()):
-            raise NotImplementedError("HipLinearization uses the default (insertion) variable ordering.")
-        self.packed = packed_for(objective, kernels)
+        # the column order is the linearization's VariableOrdering (default: insertion order; theseus_amd/sparse.py passes a
+        # fill-reducing one) -- the packed pose buffer is laid out in that order, so delta / retract / Jacobian columns agree
+        self.packed = packed_for(objective, kernels, [v.name for v in self.ordering])
         self.K = self.packed.K
         self.H: Optional[torch.Tensor] = None   # (B, ld, ld): lower triangle of A^T A (undamped)
         self.g: Optional[torch.Tensor] = None   # (B, n): A^T b

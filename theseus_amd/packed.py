@@ -78,12 +78,17 @@ def _aux_vars(x):
 
 
 class PackedPoseGraph:
-    def __init__(self, objective: Objective, kernels=None):
+    def __init__(self, objective: Objective, kernels=None, order=None):
+        """``order``: names of the optimisation variables in COLUMN order (a VariableOrdering -- e.g. the fill-reducing one of
+        theseus_amd/sparse.py); default = insertion order (theseus/optimizer/variable_ordering.py:19-27)."""
         self.objective = objective
         self.K = kernels or default_kernels()
         self.pose_vars = []
         self.group = None
-        for v in objective.optim_vars.values():
+        self.order = tuple(order) if order is not None else tuple(objective.optim_vars.keys())
+        if sorted(self.order) != sorted(objective.optim_vars.keys()):
+            raise ValueError("the variable ordering must hold every optimisation variable of the objective exactly once")
+        for v in (objective.optim_vars[name] for name in self.order):
             kind = _kind(v)
             if kind not in GROUP_SHAPE or (self.group is not None and kind != self.group):
                 raise UnsupportedObjective(
@@ -430,10 +435,12 @@ class PackedPoseGraph:
         return out
 
 
-def packed_for(objective: Objective, kernels=None) -> PackedPoseGraph:
-    """Get (or build) the packed representation attached to an objective."""
+def packed_for(objective: Objective, kernels=None, order=None) -> PackedPoseGraph:
+    """Get (or build) the packed representation attached to an objective (``order``: variable names in column order)."""
     p = getattr(objective, "_packed", None)
-    if p is None or p.version != objective.current_version or (kernels is not None and p.K is not kernels):
-        p = PackedPoseGraph(objective, kernels)
+    order = tuple(order) if order is not None else tuple(objective.optim_vars.keys())
+    if (p is None or not isinstance(p, PackedPoseGraph) or p.version != objective.current_version
+            or (kernels is not None and p.K is not kernels) or p.order != order):
+        p = PackedPoseGraph(objective, kernels, order)
         objective._packed = p
     return p

@@ -397,6 +397,43 @@ class HipCholeskySolver(HipCholeskyCore, _RefCholeskyDenseSolver):
         raise NotImplementedError("HipCholeskySolver.solve() factorises its linearization's packed Hessian")
 
 
+# ---- large pose graphs (theseus_amd/sparse.py): tile-sparse Cholesky under a fill-reducing ordering ----------------------------
+from .sparse import HipSparseCholeskyCore, fill_reducing_ordering  # noqa: E402
+
+
+class HipSparseCholeskySolver(HipSparseCholeskyCore, _RefCholeskyDenseSolver):
+    """``linear_solver_cls`` for the REAL theseus loop in BaspachoSparseSolver's role (baspacho_sparse_solver.py:23-148) on
+    SE3 / SE2 / SO3 pose graphs.  The fill-reducing ordering is a ``th.optimizer.VariableOrdering`` given to the linearization:
+    the reference loop retracts and reads ``delta`` through it (nonlinear_least_squares.py:97)."""
+
+    def __init__(self, objective: th.Objective, linearization_cls: Optional[Type[_RefLinearization]] = None,
+                 linearization_kwargs: Optional[Dict[str, Any]] = None, check_singular: bool = False, **kwargs):
+        linearization_cls = linearization_cls or HipLinearization
+        if not (isinstance(linearization_cls, type) and issubclass(linearization_cls, HipLinearization)):
+            raise RuntimeError(f"HipSparseCholeskySolver only works with theseus_amd.plugin.HipLinearization, but "
+                               f"{linearization_cls} was provided.")
+        linearization_kwargs = dict(linearization_kwargs or {})
+        if linearization_kwargs.get("ordering") is None:
+            linearization_kwargs["ordering"] = fill_reducing_ordering(objective, th.optimizer.VariableOrdering)
+        _RefLinearSolver.__init__(self, objective, linearization_cls, linearization_kwargs)
+        if not self.linearization.fused:
+            raise NotImplementedError("HipSparseCholeskySolver: the tile pattern is derived from a fused pose-graph linearization")
+        self._check_singular = check_singular
+        self._sparse_init()
+
+    def solve(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
+              damping_eps: float = 1e-8, **kwargs) -> torch.Tensor:
+        g = self.linearization._g_graph
+        if g is not None and torch.is_grad_enabled():
+            if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
+                raise ValueError("Damping must be a float or a 1-D tensor.")
+            return _CachedFactorSolve.apply(self, damping, ellipsoidal_damping, damping_eps, g)
+        return self._solve(damping, ellipsoidal_damping, damping_eps, check_info=True)
+
+    def _solve_sytem(self, Atb: torch.Tensor, AtA: torch.Tensor) -> torch.Tensor:  # abstract in DenseSolver
+        raise NotImplementedError("HipSparseCholeskySolver.solve() factorises its linearization's packed Hessian")
+
+
 # ---- bundle adjustment (theseus_amd/ba.py): Schur-complement linearization / solver for the REAL theseus loop ----------
 from .ba import HipSchurLinearizationCore, HipSchurSolverCore  # noqa: E402
 

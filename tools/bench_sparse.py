@@ -1,0 +1,53 @@
+"""Tile-sparse vs dense Cholesky on a large chain-like SE3 pose graph (odometry + local loop closures, shuffled labels):
+LM iterations/s with HipSparseCholeskySolver and with HipCholeskySolver on the same problem.
+usage: python tools/bench_sparse.py [poses] [batch] [dtype] [iters]"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import theseus_amd as th
+from tests.test_sparse_solver import chain_graph
+
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+dtype = {"f32": torch.float32, "f64": torch.float64}[sys.argv[3] if len(sys.argv) > 3 else "f32"]
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+edges = chain_graph(P, stride=7, span=5, seed=2)
+K = th.default_kernels()
+gen = torch.Generator(device="cuda").manual_seed(7)
+rnd = lambda nn, s: K.se3_exp(s * (2 * torch.rand(nn, 6, dtype=dtype, device="cuda", generator=gen) - 1))  # noqa: E731
+gt = rnd(B * P, 1.5).view(B, P, 3, 4)
+poses0 = K.se3_compose(gt.reshape(-1, 3, 4), rnd(B * P, 0.05)).view(B, P, 3, 4)
+meas = [K.se3_compose(K.se3_compose(K.se3_inverse(gt[:, i].contiguous()), gt[:, j].contiguous()), rnd(B, 0.01)) for (i, j) in edges]
+
+
+def run(solver_cls):
+    obj = th.Objective(dtype=dtype)
+    pv = [th.SE3(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    w = th.ScaleCostWeight(torch.tensor(5.0, dtype=dtype, device="cuda"))
+    for k, (i, j) in enumerate(edges):
+        obj.add(th.Between(pv[i], pv[j], th.SE3(tensor=meas[k].clone(), name=f"m_{k}"), w, name=f"b_{k}"))
+    obj.add(th.Difference(pv[edges[0][0]], th.SE3(tensor=gt[:, edges[0][0]].clone(), name="anchor"), w, name="prior"))
+    opt = th.LevenbergMarquardt(obj, linear_solver_cls=solver_cls, max_iterations=iters, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    layer = th.TheseusLayer(opt)
+    start = {f"pose_{k}": poses0[:, k].clone() for k in range(P)}
+    with torch.no_grad():
+        layer.forward(start, optimizer_kwargs=dict(damping=1e-2))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sol, info = layer.forward(start, optimizer_kwargs=dict(damping=1e-2, track_err_history=True))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return dt, info, opt, torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
+
+
+ds, si, so, xs = run(th.HipSparseCholeskySolver)
+pat = so.linear_solver.pattern
+print(f"{P} poses / {len(edges)} edges, n = {6 * P} ({pat.ntiles} tiles), batch {B}, {dtype}: L tiles {pat.l_tiles} of "
+      f"{pat.ntiles * (pat.ntiles + 1) // 2}, tile products {pat.tile_products} vs dense {pat.dense_tile_products}")
+print(f"sparse: {ds / iters * 1e3:.2f} ms / LM iteration = {B * iters / ds:.0f} problem-iterations/s; error {si.err_history[:, 0].mean():.1f} -> {si.err_history[:, -1].mean():.4f}")
+if os.environ.get("BENCH_SPARSE_DENSE", "1") == "1":
+    dd, di, _, xd = run(th.HipCholeskySolver)
+    print(f"dense : {dd / iters * 1e3:.2f} ms / LM iteration = {B * iters / dd:.0f} problem-iterations/s; speed-up {dd / ds:.1f}x; "
+          f"max |pose difference| {float((xs - xd).abs().max()):.2e}")
