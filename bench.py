@@ -34,7 +34,7 @@ class KernelTimer:
     """HIP-event timing of every C-ABI call, on the stream the kernels are launched on
     (torch's current stream: torch.cuda.Event records there)."""
 
-    NAMES = ["pg_assemble", "chol_factor", "chol_solve_backward", "chol_solve", "se3_retract", "pg_error", "lm_accept"]
+    NAMES = ["pg_assemble", "chol_factor", "chol_factor_sparse", "chol_solve_backward", "chol_solve", "se3_retract", "pg_error", "lm_accept"]
 
     def __init__(self, K):
         self.K, self.events, self.enabled = K, {n: [] for n in self.NAMES}, False
@@ -160,10 +160,17 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--damping", type=float, default=1e-3)
     ap.add_argument("--adaptive", action="store_true")
+    ap.add_argument("--solver", default="dense", choices=["dense", "sparse"],
+                    help="dense: HipCholeskySolver (n^3/3 per problem); sparse: HipSparseCholeskySolver -- the same tile kernels "
+                         "under a reverse Cuthill-McKee variable ordering, skipping the tiles of L (and the K-loop blocks) that "
+                         "are structurally zero")
     ap.add_argument("--cpu-sample", type=int, default=128, help="problems in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-chunk", type=int, default=32, help="problems per CPU-baseline chunk")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--parity-sample", type=int, default=8, help="problems in the exact-parity sub-sample (0 = skip)")
+    ap.add_argument("--no-sparse-leg", action="store_true",
+                    help="skip the second measurement of the same workload with the tile-sparse solver (reported under "
+                         "'tile_sparse' next to the dense headline)")
     ap.add_argument("--implicit", action="store_true",
                     help="BASELINE.json configs[4]: forward LM + implicit backward (one backward linear solve) through "
                          "TheseusLayer; measurement tensors require grad; a step = one LM iteration of the forward")
@@ -205,7 +212,8 @@ def main():
     n = 6 * P
     edges = syn.pose_graph_topology(P, E, topology_seed=0)
     objective = syn.build_pose_graph_objective(edges, P, dtype=dtype, device=device)
-    opt = th.LevenbergMarquardt(objective, linear_solver_cls=th.HipCholeskySolver, max_iterations=K_iters,
+    solver_cls = th.HipSparseCholeskySolver if args.solver == "sparse" else th.HipCholeskySolver
+    opt = th.LevenbergMarquardt(objective, linear_solver_cls=solver_cls, max_iterations=K_iters,
                                 abs_err_tolerance=0.0, rel_err_tolerance=0.0, step_size=1.0,
                                 linearization_kwargs=dict(kernels=kernels) if standin else None)
     if world > 1:
@@ -305,7 +313,8 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic" if on_gpu else "TEST-STANDIN",
             "config": {"workload": f"SE3 pose-graph {P} poses / {E} Between edges + 1 prior, batch {n_sub * B} per GPU, "
-                                   f"LM damping {args.damping}{' adaptive' if args.adaptive else ''} + dense Cholesky",
+                                   f"LM damping {args.damping}{' adaptive' if args.adaptive else ''} + "
+                                   f"{'tile-sparse Cholesky (RCM ordering)' if args.solver == 'sparse' else 'dense Cholesky'}",
                        "poses": P, "edges": E, "batch_per_gpu": n_sub * B, "global_batch": world * n_sub * B, "n": n,
                        "parallelism": f"batch-shard x{world}" + (f", {n_sub} sub-batches of {B} per GPU" if strong else "")},
             "ranks": world if world == 1 else dist.get_world_size(),
@@ -317,7 +326,7 @@ def main():
             "mean_error": [float(err_hist[:, 0].mean()), float(err_hist[:, iters_done].mean())],
         }
         if on_gpu:
-            fac = phases.get("chol_factor", {"avg_ms": float("nan")})
+            fac = phases.get("chol_factor_sparse" if args.solver == "sparse" else "chol_factor", {"avg_ms": float("nan")})
             # n^3/3 flops per problem x B problems per thx_chol_factor_forward call (the 2n^2 of the
             # fused forward substitution are not counted)
             flops_per_launch = B * (n ** 3) / 3.0
@@ -346,6 +355,14 @@ def main():
                 "traffic": traffic, "traffic_unit": "bytes per thx_chol_factor_forward call (PMC, rocprofv3)",
                 "traffic_source": traffic_src, "flops_per_launch": flops_per_launch, "avg_launch_ms": fac["avg_ms"],
                 "hbm_bound_kernels": hbm,
+                # "achieved" above is the contract's figure: ALGORITHMIC flops (dense n^3 / 3 per problem) / time.  The tile-sparse
+                # solver executes fewer: the matrix cores' own utilisation is executed flops / time / peak.
+                "executed": None if args.solver != "sparse" else {
+                    "flops_per_launch": B * opt.linear_solver.pattern.flops,
+                    "of_dense": opt.linear_solver.pattern.flops / opt.linear_solver.pattern.dense_flops,
+                    "tiles_of_L": [opt.linear_solver.pattern.l_tiles, opt.linear_solver.pattern.ntiles * (opt.linear_solver.pattern.ntiles + 1) // 2],
+                    "TFLOPs": B * opt.linear_solver.pattern.flops / (fac["avg_ms"] * 1e-3) / 1e12,
+                    "frac": B * opt.linear_solver.pattern.flops / (fac["avg_ms"] * 1e-3) / 1e12 / peak},
                 "iteration": {"floor_ms": {"mfma": round(t_mfma, 3), "hbm": round(t_hbm, 3)},
                               "ms_per_step": dt / max(iters_done, 1) * 1e3 / n_sub,
                               "frac": max(t_mfma, t_hbm) / (dt / max(iters_done, 1) * 1e3 / n_sub)}}
@@ -386,6 +403,41 @@ def main():
                     "cpu_port_max_abs_pose_err": float((c - ex_final).abs().max()),
                     "cpu_port_max_rel_pose_err": float((relative_poses(c) - relative_poses(ex_final)).abs().max()),
                     "cpu_port_rel_err_final_cost": rel(cpu_hist[:SP])})
+        if (on_gpu and world == 1 and args.solver == "dense" and not args.no_sparse_leg and not args.implicit and not strong):
+            # ---- the same workload once more with HipSparseCholeskySolver (theseus_amd/sparse.py): same kernels, reverse
+            #      Cuthill-McKee variable ordering, structurally zero tiles of L and K-loop blocks skipped.  Reported NEXT TO the
+            #      dense headline (value / roofline above are the dense solver's).  The dense solver's workspaces are freed first.
+            import gc
+            del sol, info, layer, opt, objective, timer
+            gc.collect()
+            torch.cuda.empty_cache()
+            obj2 = syn.build_pose_graph_objective(edges, P, dtype=dtype, device=device)
+            opt2 = th.LevenbergMarquardt(obj2, linear_solver_cls=th.HipSparseCholeskySolver, max_iterations=K_iters,
+                                         abs_err_tolerance=0.0, rel_err_tolerance=0.0, step_size=1.0)
+            layer2 = th.TheseusLayer(opt2)
+            timer2 = KernelTimer(opt2.linear_solver.K)
+            with torch.no_grad():
+                if W > 0:
+                    opt2.set_params(max_iterations=W)
+                    layer2.forward(inputs, optimizer_kwargs=okw)
+                opt2.set_params(max_iterations=K_iters)
+                torch.cuda.synchronize()
+                timer2.enabled = True
+                t0 = time.perf_counter()
+                sol2, info2 = layer2.forward(inputs, optimizer_kwargs=dict(track_err_history=True, **okw))
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t0
+                timer2.enabled = False
+            pat = opt2.linear_solver.pattern
+            fms = timer2.summary()["chol_factor_sparse"]["avg_ms"]
+            result["tile_sparse"] = {
+                "solver": "HipSparseCholeskySolver (reverse Cuthill-McKee ordering, tile pattern of L)",
+                "value": B * info2.iters_done / dt2, "unit": "problem-iterations/s", "ms_per_step": dt2 / info2.iters_done * 1e3,
+                "factor_ms": fms, "tiles_of_L": [pat.l_tiles, pat.ntiles * (pat.ntiles + 1) // 2],
+                "executed_flops_of_dense": pat.flops / pat.dense_flops,
+                "executed_TFLOPs": B * pat.flops / (fms * 1e-3) / 1e12,
+                "executed_frac_of_peak": B * pat.flops / (fms * 1e-3) / 1e12 / PEAK[args.dtype],
+                "mean_error": [float(info2.err_history[:, 0].mean()), float(info2.err_history[:, info2.iters_done].mean())]}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

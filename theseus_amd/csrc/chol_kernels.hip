@@ -1341,6 +1341,11 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
 #endif
 }
 
+// (A variant computing TWO row tiles per workgroup -- the column panel streamed once for both products, 3 staged operand
+//  tiles per 2 tile products, half the workgroups, H / panel loaded after the K-loop, 240 VGPRs, 54 KB LDS -- measured
+//  48.5 ms against 48.3 ms for this kernel on the same box at n = 1536, batch 4096, and the same at n = 3072 / batch 256 and
+//  batch 1024: what it saves per tile in the prologue and the K-loop it gives back in the exposed loads and the longer
+//  substitution phase.  Not kept; profiles/r2/f_pair_kernel_ab.txt.)
 // ------------------------------------------------------------------------------------------------
 // chol_offdiag, fp64: two workgroups per CU (a full 128x130 fp64 panel tile in LDS would be 133 KB):
 //   * H_ij and the result go global <-> registers directly in the accumulator's native layout (a 4-lane group covers 32

@@ -91,6 +91,12 @@ class TilePattern:
         # tile products the numeric factorisation executes (K-loop tiles + one TRSM / POTRF per tile) vs the dense count
         self.tile_products = len(tile_k) + len(diag_k) + self.l_tiles
         self.dense_tile_products = sum(j * (nt - j) + (nt - j) for j in range(nt))
+        # flops of the numeric factorisation per problem (tile granularity: 2 t^3 per K-loop tile product of an off-diagonal tile,
+        # t^3 per one of a diagonal tile (lower half), t^3 per substitution, t^3 / 3 per diagonal factorisation; t = 128) and
+        # of the dense factorisation of the same frame -- the latter is n^3 / 3 up to the padding of the last tile
+        t3 = float(TILE) ** 3
+        self.flops = 2 * t3 * len(tile_k) + t3 * len(diag_k) + t3 * len(col_row) + t3 / 3 * nt
+        self.dense_flops = sum((nt - 1 - j) * (2 * t3 * j + t3) + t3 * j + t3 / 3 for j in range(nt))
         self._dev: Dict[str, Any] = {}
 
     def c_struct(self, device) -> _lib.TilePattern:
