@@ -222,7 +222,7 @@ int thx_se3_retract(const void* poses, const void* delta, int64_t ldd, double st
 typedef struct {
   int32_t ntiles;                 /* ceil(n / THX_TILE) */
   const int32_t* col_ptr;         /* (ntiles + 1) off-diagonal non-zero tiles of block column j: entries [col_ptr[j], col_ptr[j+1]) */
-  const int32_t* col_row;         /* (entries) row tile of every entry, ascending within a column */
+  const int32_t* col_row;         /* (entries) row tile of every entry (any order within a column; the host sorts by K-list length) */
   const int32_t* tile_kptr;       /* (entries + 1) K-list of entry e: */
   const int32_t* tile_k;          /*   block columns k < j in which L_ik and L_jk are both non-zero */
   const int32_t* diag_kptr;       /* (ntiles + 1) K-list of diagonal tile j: */

@@ -78,9 +78,13 @@ class TilePattern:
             dk = np.nonzero(lp[j, :j])[0]
             diag_k += dk.tolist()
             diag_kptr.append(len(diag_k))
-            for i in (np.nonzero(lp[j + 1:, j])[0] + j + 1).tolist():
+            rows = (np.nonzero(lp[j + 1:, j])[0] + j + 1).tolist()
+            klists = {i: np.nonzero(lp[i, :j] & lp[j, :j])[0].tolist() for i in rows}
+            # longest K-loop first: the workgroups of a launch are dispatched in entry order, so the long ones start early and
+            # the short ones fill the tail (LPT scheduling)
+            for i in sorted(rows, key=lambda r: (-len(klists[r]), r)):
                 col_row.append(i)
-                tile_k += np.nonzero(lp[i, :j] & lp[j, :j])[0].tolist()
+                tile_k += klists[i]
                 tile_kptr.append(len(tile_k))
             col_ptr.append(len(col_row))
         i32 = lambda a: np.asarray(a if len(a) else [0], dtype=np.int32)  # noqa: E731
