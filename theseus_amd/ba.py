@@ -254,12 +254,14 @@ class PackedBA:
             yield c.target
             yield from _aux_vars(c.weight)
 
-    def _current_stamp(self, deep: bool = False):
+    def _current_stamp(self, deep: bool = False, count: Optional[int] = None):
         # the objective is frozen once an optimizer holds it (Optimizer.optimize checks its version): the walk over the cost
         # functions is done once, later stamps are one pass over the cached list (7 k variables at the headline size)
         tracked = self.__dict__.get("_tracked_list")
         if tracked is None:
             tracked = self._tracked_list = list(self._tracked())
+        if count is not None:
+            tracked = tracked[:count]
         if deep:  # in-place edits of a variable's tensor (see PackedPoseGraph._current_stamp)
             return tuple([(t.data_ptr(), t._version) for t in (v.tensor for v in tracked)])
         return tuple([v._num_updates for v in tracked])
@@ -276,10 +278,11 @@ class PackedBA:
                 and Variable._global_updates == self._global_stamp):
             return
         stamp = self._current_stamp()
-        if (not force and self.tensors is not None and stamp == self._stamp
-                and (not deep or self._current_stamp(deep=True) == self._deep_stamp)):
+        dstamp = self._current_stamp(deep=True) if deep else None
+        if (not force and self.tensors is not None and stamp == self._stamp and (not deep or dstamp == self._deep_stamp)):
             self._global_stamp = Variable._global_updates
             return
+        self._deep_stamp = dstamp if dstamp is not None else self._current_stamp(deep=True)
         self.flush_variables()
         obj = self.objective
         obj._resolve_batch_size()
@@ -326,7 +329,14 @@ class PackedBA:
             for v, t in zip(self.pt_vars, self.tensors.points.unbind(0)):
                 v.tensor = t
         self._stamp = self._current_stamp()
-        self._deep_stamp = self._current_stamp(deep=True)
+        # deep stamp: only the optimisation variables were re-pointed here -- the auxiliary variables' entries (the bulk: 1 k
+        # measurements of a pose graph, 33 k features of a bundle-adjustment problem) are still the ones sync() looked at
+        n_opt = len(self.cam_vars) + len(self.pt_vars)
+        old = self._deep_stamp
+        if old is not None and len(old) == len(self._stamp):
+            self._deep_stamp = self._current_stamp(deep=True, count=n_opt) + old[n_opt:]
+        else:
+            self._deep_stamp = self._current_stamp(deep=True)
         self._global_stamp = Variable._global_updates
         self._vars_stale = False
         self._state_exposed = True

@@ -171,12 +171,14 @@ class PackedPoseGraph:
             if r is not None:
                 yield r
 
-    def _current_stamp(self, deep: bool = False):
+    def _current_stamp(self, deep: bool = False, count: Optional[int] = None):
         # the objective is frozen once an optimizer holds it (Optimizer.optimize checks its version): the walk over the cost
         # functions is done once, later stamps are one pass over the cached list (7 k variables at the headline size)
         tracked = self.__dict__.get("_tracked_list")
         if tracked is None:
             tracked = self._tracked_list = list(self._tracked())   # the optimisation variables (poses) come first
+        if count is not None:
+            tracked = tracked[:count]
         if deep:
             # storage identity + autograd version counter: catches IN-PLACE edits of a variable's tensor that never go
             # through Variable.update() (an nn.Parameter stepped by a torch optimizer, ``var.tensor.mul_()``) -- the reference
@@ -243,8 +245,10 @@ class PackedPoseGraph:
                                      robust_prior=self.robust_prior, log_radius_prior=lrp)
         else:
             self.tensors.poses = poses
+        # (the auxiliary entries of the deep stamp: what this call saw -- _repoint_variables patches the poses' entries)
+        self._deep_stamp = dstamp if dstamp is not None else self._current_stamp(deep=True)
         if adopted:   # the variables hold these very views already: only the stamps move
-            self._stamp, self._deep_stamp = stamp, self._current_stamp(deep=True)
+            self._stamp = stamp
             self._global_stamp = Variable._global_updates
             self._vars_stale = False
             self._state_exposed = True
@@ -275,7 +279,14 @@ class PackedPoseGraph:
                 v.tensor = t
         self.remember_views(poses, views)
         self._stamp = self._current_stamp()
-        self._deep_stamp = self._current_stamp(deep=True)
+        # deep stamp: only the optimisation variables were re-pointed here -- the auxiliary variables' entries (the bulk: 1 k
+        # measurements of a pose graph, 33 k features of a bundle-adjustment problem) are still the ones sync() looked at
+        n_opt = len(self.pose_vars)
+        old = self._deep_stamp
+        if old is not None and len(old) == len(self._stamp):
+            self._deep_stamp = self._current_stamp(deep=True, count=n_opt) + old[n_opt:]
+        else:
+            self._deep_stamp = self._current_stamp(deep=True)
         self._global_stamp = Variable._global_updates
         self._vars_stale = False
         self._state_exposed = True   # the variables (and whoever holds their tensors) now view the state buffer
