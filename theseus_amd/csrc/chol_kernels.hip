@@ -467,13 +467,21 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   const int nk = K / C::KB;
   constexpr int CPT = TILE / C::KB;   // k-chunks per tile
   // first column of k-chunk kc
+  // (the list is read through the constant address space: a SCALAR load.  As a plain global load the compiler issued a vector
+  // load + s_waitcnt vmcnt(0) in front of every chunk's prefetch and wrapped each buffer load in a waterfall loop, since it
+  // could not prove the offset wave uniform.)
+  typedef const int32_t __attribute__((address_space(4))) * klist_t;
+  const klist_t kl = (klist_t)(uintptr_t)ktiles;
   auto kof = [&](int kc) __attribute__((always_inline)) -> int {
-    return ktiles ? ktiles[kc / CPT] * TILE + (kc % CPT) * C::KB : kc * C::KB;
+    const int k0 = kl ? kl[kc / CPT] * TILE + (kc % CPT) * C::KB : kc * C::KB;
+    return __builtin_amdgcn_readfirstlane(k0);
   };
   T gsum = T(0);
   // one k-chunk: registers -> LDS, refill the registers with the chunk AHEAD steps on, MFMAs on the staged chunk
   // (a static s_setprio per hardware wave slot, to push the two co-resident workgroups out of lockstep, measured no gain)
   auto step = [&](uint4 (&xa)[4], uint4 (&xb)[4], int kc) __attribute__((always_inline)) {
+    // column of the chunk to prefetch: the K-list entry is fetched here so that its (scalar) load completes under the staging
+    const int knext = kc + AHEAD < nk ? kof(kc + AHEAD) : 0;
 #ifdef THX_EXP_NOSTAGE  // timing experiment: no register -> LDS staging and only one barrier per chunk (garbage results)
     if (kc == 0) {
 #pragma unroll
@@ -498,9 +506,9 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
     __syncthreads();
 #endif
 #ifdef THX_EXP_NOLOAD
-    if (kc == 0 && kc + AHEAD < nk) gload(xa, xb, kof(kc + AHEAD));  // timing experiment: operands are not streamed
+    if (kc == 0 && kc + AHEAD < nk) gload(xa, xb, knext);  // timing experiment: operands are not streamed
 #else
-    if (kc + AHEAD < nk) gload(xa, xb, kof(kc + AHEAD));
+    if (kc + AHEAD < nk) gload(xa, xb, knext);
 #endif
     if constexpr (GEMV) {
       if (gemv_y) {
