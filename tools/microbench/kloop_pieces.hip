@@ -102,18 +102,70 @@ __global__ void __launch_bounds__(256, 2) k(const float* __restrict__ mats, floa
   out[blockIdx.x * 256 + tid] = t + ra[0].x + rb[3].w;
 }
 
+// mode 7: the operand stream lands in LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write), two 32 KB
+// chunk buffers, rows unpadded with the 16-byte quads XOR-swizzled by (row >> 1) & 7 on both sides, ONE barrier per chunk.
+template <int PIN>
+__global__ void __launch_bounds__(256, 2) k_glds(const float* __restrict__ mats, float* out, int chunks) {
+  const float* mat = mats + (size_t)(blockIdx.x % 512) * (LD + 32) * LD;
+  __shared__ float4 buf0[2048], buf1[2048];   // each: A 128 rows x 8 quads, B 128 rows x 8 quads
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rl = lane & 31, g = lane >> 5;
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  auto issue = [&](float4* buf, int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = 32 * u + 8 * wave + (lane >> 3), q = (lane & 7) ^ ((r >> 1) & 7);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mat + (size_t)(128 * (1 + (kc / 44) % 11) + r) * LD + (kc % 44) * 32 + 4 * q),
+                                       (__attribute__((address_space(3))) void*)(buf + (32 * u + 8 * wave) * 8), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mat + (size_t)r * LD + (kc % 44) * 32 + 4 * q),
+                                       (__attribute__((address_space(3))) void*)(buf + 1024 + (32 * u + 8 * wave) * 8), 16, 0, 0);
+    }
+  };
+  auto compute = [&](const float4* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int rb = 32 * wave + rl;
+      const float4 fb = buf[1024 + rb * 8 + ((2 * ks + g) ^ ((rb >> 1) & 7))];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const int ra = 32 * cb + rl;
+        const float4 fa = buf[ra * 8 + ((2 * ks + g) ^ ((ra >> 1) & 7))];
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[cb], 0, 0, 0);
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[cb], 0, 0, 0);
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc[cb], 0, 0, 0);
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc[cb], 0, 0, 0);
+      }
+    }
+  };
+  issue(buf0, 0);
+  __syncthreads();
+  for (int kc = 0; kc < chunks; kc += 2) {
+    issue(buf1, kc + 1);
+    if (PIN) __builtin_amdgcn_sched_barrier(0);
+    compute(buf0);
+    __syncthreads();
+    issue(buf0, kc + 2);
+    if (PIN) __builtin_amdgcn_sched_barrier(0);
+    compute(buf1);
+    __syncthreads();
+  }
+  float t = 0;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) t += acc[i][j];
+  out[blockIdx.x * 256 + tid] = t;
+}
+
 template <int MODE, int PAD>
 void run(const char* name, const float* mats, float* out) {
   const int wgs = PAD ? 256 : 512, chunks = 8000;
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  k<MODE, PAD><<<wgs, 256>>>(mats, out, 64);
+  if (MODE >= 7) k_glds<MODE - 7><<<wgs, 256>>>(mats, out, 64); else k<MODE >= 7 ? 0 : MODE, PAD><<<wgs, 256>>>(mats, out, 64);
   hipDeviceSynchronize();
   float best = 1e30f, sum = 0;
   for (int r = 0; r < 4; ++r) {
     hipEventRecord(e0);
-    k<MODE, PAD><<<wgs, 256>>>(mats, out, chunks);
+    if (MODE >= 7) k_glds<MODE - 7><<<wgs, 256>>>(mats, out, chunks); else k<MODE >= 7 ? 0 : MODE, PAD><<<wgs, 256>>>(mats, out, chunks);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -139,6 +191,8 @@ int main() {
   run<4, 0>("4 = 3 + operand stream from HBM (the whole K-loop)", mats, out);
   run<5, 0>("5 = 4, leading dimension 1536 + 32", mats, out);
   run<6, 0>("6 = 4, chunks contiguous (tile-packed operands)", mats, out);
+  run<7, 0>("7 = direct-to-LDS operand stream, double buffered", mats, out);
+  run<8, 0>("8 = 7 with the loads pinned in front of the MFMAs", mats, out);
   run<0, 1>("0 reads + MFMAs (4 dependent MFMAs in a row)", mats, out);
   run<1, 1>("1 reads + MFMAs (accumulators interleaved)", mats, out);
   run<2, 1>("2 = 0 + two barriers per chunk", mats, out);
