@@ -7,6 +7,7 @@
 //   mode 3: mode 2 + the register -> LDS staging stores (8 ds_write_b128 per thread and chunk)
 //   mode 4: mode 3 + the operand stream from HBM (2 x 128 rows x 32 columns per chunk through buffer-less global loads,
 //           one chunk ahead), i.e. the whole K-loop: row-major matrix, leading dimension 1536 (a chunk = 256 pieces of 128 B)
+//   mode 9: mode 4 with the fragment reads software-pipelined one k-step ahead (the compiler requests them 4 MFMAs ahead)
 //   mode 5: mode 4 with the leading dimension padded to 1536 + 32 words (HBM channel camping?)
 //   mode 6: mode 4 with every 128 x 32 chunk CONTIGUOUS in memory (16 KB, tile-packed operand layout)
 // each at 2 workgroups per CU (512 workgroups) and at 1 per CU (256 workgroups, LDS padded to force it).
@@ -68,6 +69,31 @@ __global__ void __launch_bounds__(256, 2) k(const float* __restrict__ mats, floa
     if (MODE >= 4) {
       gload(kc + 1);
       __builtin_amdgcn_sched_barrier(0);   // the loads are issued BEFORE the MFMAs (the compiler sinks them below otherwise)
+    }
+    if (MODE == 9) {   // fragments of k-step ks+1 are requested before the 16 MFMAs of k-step ks
+      float4 fbq[2], faq[2][4];
+      auto frag = [&](int ks, float4& fb, float4 (&fa)[4]) __attribute__((always_inline)) {
+        fb = *reinterpret_cast<const float4*>(sBw + rl * LDT + 8 * ks + 4 * g);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) fa[cb] = *reinterpret_cast<const float4*>(sA + (32 * cb + rl) * LDT + 8 * ks + 4 * g);
+      };
+      frag(0, fbq[0], faq[0]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) frag(ks + 1, fbq[(ks + 1) & 1], faq[(ks + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 fb = fbq[ks & 1];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          const float4 fa = faq[ks & 1][cb];
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc[cb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      continue;
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -160,12 +186,12 @@ void run(const char* name, const float* mats, float* out) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  if (MODE >= 7) k_glds<MODE - 7><<<wgs, 256>>>(mats, out, 64); else k<MODE >= 7 ? 0 : MODE, PAD><<<wgs, 256>>>(mats, out, 64);
+  if (MODE == 7 || MODE == 8) k_glds<MODE - 7><<<wgs, 256>>>(mats, out, 64); else k<(MODE == 7 || MODE == 8) ? 0 : MODE, PAD><<<wgs, 256>>>(mats, out, 64);
   hipDeviceSynchronize();
   float best = 1e30f, sum = 0;
   for (int r = 0; r < 4; ++r) {
     hipEventRecord(e0);
-    if (MODE >= 7) k_glds<MODE - 7><<<wgs, 256>>>(mats, out, chunks); else k<MODE >= 7 ? 0 : MODE, PAD><<<wgs, 256>>>(mats, out, chunks);
+    if (MODE == 7 || MODE == 8) k_glds<MODE - 7><<<wgs, 256>>>(mats, out, chunks); else k<(MODE == 7 || MODE == 8) ? 0 : MODE, PAD><<<wgs, 256>>>(mats, out, chunks);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -191,6 +217,7 @@ int main() {
   run<4, 0>("4 = 3 + operand stream from HBM (the whole K-loop)", mats, out);
   run<5, 0>("5 = 4, leading dimension 1536 + 32", mats, out);
   run<6, 0>("6 = 4, chunks contiguous (tile-packed operands)", mats, out);
+  run<9, 0>("9 = 4 with the fragment reads one k-step (16 MFMAs) ahead", mats, out);
   run<7, 0>("7 = direct-to-LDS operand stream, double buffered", mats, out);
   run<8, 0>("8 = 7 with the loads pinned in front of the MFMAs", mats, out);
   run<0, 1>("0 reads + MFMAs (4 dependent MFMAs in a row)", mats, out);
