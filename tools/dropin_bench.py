@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--adaptive", action="store_true")
     ap.add_argument("--no-hooks", action="store_true", help="only Linearization + LinearSolver replaced (round-1 boundary)")
+    ap.add_argument("--profile", action="store_true", help="cProfile of the drop-in's optimize() (host side), top functions to stderr")
     ap.add_argument("--test-kernels", default="", help=argparse.SUPPRESS)   # dry run of this script without a GPU
     args = ap.parse_args()
     import warnings
@@ -79,6 +80,16 @@ def main():
         return sol, info, time.perf_counter() - t0
 
     run(layer, 2)
+    if args.profile:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        run(layer, K)
+        pr.disable()
+        st = pstats.Stats(pr, stream=sys.stderr)
+        st.sort_stats("cumulative").print_stats(45)
+        st.sort_stats("tottime").print_stats(25)
     sol, info, dt = run(layer, K)
     iters = int(info.err_history.shape[1] - 1)
     # ---- theseus_amd's own loop on the same inputs ----
