@@ -139,6 +139,15 @@ def gen_lm(th, lieF, only=None):
         # path must sit inside the reference's own fp32 rounding band around the exact values
         ("pg_f32_lm_b16", dict(P=12, E=26, B=16, dtype=torch.float32, seed=17),
          dict(max_iterations=5, step_size=1.0), dict(damping=1e-3)),
+        # Dogleg (theseus/optimizer/nonlinear/dogleg.py): the third NonlinearLeastSquares optimizer behind the same
+        # Linearization + LinearSolver boundary.  Boundary / interior / rejected steps in one batch.
+        ("pg_f64_dogleg", dict(P=8, E=14, B=5, dtype=torch.float64, seed=61, pose_noise=(0.4, 0.5)),
+         dict(max_iterations=5, step_size=1.0), dict(dogleg=True)),   # (stops before the iterates stagnate at the optimum:
+                                                                      #  from there on accept / reject is rounding noise)
+        ("pg_f64_dogleg_rejects", dict(P=9, E=16, B=6, dtype=torch.float64, seed=66, pose_noise=(2.5, 2.5)),
+         dict(max_iterations=5, step_size=1.0), dict(dogleg=True, trust_region_init=100.0)),   # overshooting first steps
+        ("pg_f32_dogleg", dict(P=8, E=14, B=5, dtype=torch.float32, seed=61, pose_noise=(0.4, 0.5)),
+         dict(max_iterations=4, step_size=1.0), dict(dogleg=True)),
     ]
     for name, pk, ok, lmk in cases:
         if only and name not in only:
@@ -147,10 +156,11 @@ def gen_lm(th, lieF, only=None):
         seed = pk.pop("seed")
         d = make_problem(dtype=dtype, seed=seed, th=th, lieF=lieF, **pk)
         obj, poses = build_reference_objective(th, d, dtype)
-        cls = th.GaussNewton if lmk is None else th.LevenbergMarquardt
+        is_dogleg = bool(lmk and lmk.get("dogleg"))
+        cls = th.GaussNewton if lmk is None else (th.Dogleg if is_dogleg else th.LevenbergMarquardt)
         opt = cls(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True,
                   abs_err_tolerance=0.0, rel_err_tolerance=0.0, **ok)
-        taps = dict(AtA=[], Atb=[], delta=[], A=[], b=[], err=[])
+        taps = dict(AtA=[], Atb=[], delta=[], A=[], b=[], err=[], tr=[])
 
         def cb(optimizer, info, delta, it):
             lin = optimizer.linear_solver.linearization
@@ -160,14 +170,19 @@ def gen_lm(th, lieF, only=None):
             taps["b"].append(lin.b.clone().numpy())
             taps["delta"].append(delta.clone().numpy())
             taps["err"].append(info.last_err.clone().numpy())
+            if is_dogleg:
+                taps["tr"].append(optimizer._trust_region.clone().view(-1).numpy())
 
         lin = opt.linear_solver.linearization
         struct = dict(var_start_cols=np.array(lin.var_start_cols), var_dims=np.array(lin.var_dims),
                       num_rows=lin.num_rows, num_cols=lin.num_cols)
         with torch.no_grad():
             err0 = obj.error_metric().clone().numpy()
-            info = opt.optimize(track_err_history=True, end_iter_callback=cb, **(lmk or {}))
+            info = opt.optimize(track_err_history=True, end_iter_callback=cb,
+                                **{k: v for k, v in (lmk or {}).items() if k != "dogleg"})
         final = torch.stack([p.tensor for p in poses], 1).numpy()
+        if is_dogleg:
+            struct["trust_region"] = np.stack(taps["tr"])
         np.savez_compressed(
             os.path.join(OUT, name + ".npz"),
             P=d["P"], edges=d["edges"].numpy(), meas=d["meas"].numpy(), w_between=d["w_between"].numpy(),

@@ -263,6 +263,7 @@ class LMInfo:
     rho: List[torch.Tensor] = field(default_factory=list)            # adaptive LM: gain ratio per step
     actual_reduction: List[torch.Tensor] = field(default_factory=list)
     prev_err: List[torch.Tensor] = field(default_factory=list)
+    trust_regions: List[torch.Tensor] = field(default_factory=list)  # Dogleg: radius after every counted iteration
     iters_done: int = 0
     converged_iter: Optional[torch.Tensor] = None
     last_err: Optional[torch.Tensor] = None
@@ -292,11 +293,13 @@ def lm_optimize(p: PGProblem, poses, max_iterations=20, step_size=1.0, damping=1
                 adaptive_damping=False, ellipsoidal_damping=False, damping_eps=1e-8,
                 abs_err_tolerance=1e-10, rel_err_tolerance=1e-8,
                 down_damping_ratio=9.0, up_damping_ratio=11.0, damping_accept=0.1,
-                gauss_newton=False, keep_taps=False):
-    """One ``optimize()`` of LevenbergMarquardt (or GaussNewton if ``gauss_newton``) under no_grad.
+                gauss_newton=False, keep_taps=False, dogleg=False, trust_region_init=0.5, accept_threshold=0.0,
+                shrink_threshold=0.25, expand_threshold=0.75, shrink_ratio=0.25, expand_ratio=2.0,
+                min_trust_region=1.0e-5, max_trust_region=1.0e5):
+    """One ``optimize()`` of LevenbergMarquardt (GaussNewton if ``gauss_newton``, Dogleg if ``dogleg``) under no_grad.
 
-    nonlinear_least_squares.py:100-215 (loop), :338-365 (_step), levenberg_marquardt.py:114-201,
-    SURVEY Appendix B.  Returns (final poses, LMInfo).
+    nonlinear_least_squares.py:100-215 (loop), :338-365 (_step), levenberg_marquardt.py:114-201, dogleg.py:52-116,
+    trust_region.py:65-151, SURVEY Appendix B.  Returns (final poses, LMInfo).
     """
     _linearize, _error, _retract, _keep = _ops(p)
     first = poses[0] if isinstance(poses, (tuple, list)) else poses
@@ -304,6 +307,7 @@ def lm_optimize(p: PGProblem, poses, max_iterations=20, step_size=1.0, damping=1
     dtype = first.dtype
     info = LMInfo()
     lam = damping * torch.ones(B, dtype=dtype) if adaptive_damping else damping
+    trust_region = trust_region_init * torch.ones(B, 1, dtype=dtype)   # trust_region.py:65-76
     last_err = _error(poses)
     info.err_history.append(last_err.clone())
     converged = torch.zeros(B, dtype=torch.bool)
@@ -312,7 +316,9 @@ def lm_optimize(p: PGProblem, poses, max_iterations=20, step_size=1.0, damping=1
     while it < max_iterations:
         A, b = _linearize(poses)
         AtA, Atb = hessian(A, b)
-        if gauss_newton:
+        if dogleg:
+            delta = dogleg_step(A, AtA, Atb, trust_region)
+        elif gauss_newton:
             delta = solve(AtA, Atb)
         else:
             delta = solve(AtA, Atb, lam, ellipsoidal_damping, damping_eps)
@@ -338,6 +344,17 @@ def lm_optimize(p: PGProblem, poses, max_iterations=20, step_size=1.0, damping=1
                 info.prev_err.append(last_err.clone())
             lam = torch.where(reject, lam * up_damping_ratio, lam / down_damping_ratio)
             lam = lam.clamp(MIN_DAMPING, MAX_DAMPING)
+        if dogleg:
+            # trust_region.py:91-151: rho against the quadratic model m(d) = err + d.grad + |A d|^2 / 2, grad = -Atb
+            Ad = A.bmm(d.unsqueeze(2)).squeeze(2)
+            pred = last_err + (d * -Atb.squeeze(2)).sum(dim=1) + 0.5 * (Ad ** 2).sum(dim=1)
+            rho = ((last_err - err) / (last_err - pred)).view(-1, 1)
+            trust_region = torch.where(rho < shrink_threshold, trust_region * shrink_ratio, trust_region)
+            trust_region = torch.where(rho > expand_threshold, trust_region * expand_ratio, trust_region)
+            trust_region = trust_region.clamp(min_trust_region, max_trust_region)
+            reject = (rho < accept_threshold).view(-1)
+            if keep_taps:
+                info.rho.append(rho.view(-1).clone())
         if reject is not None and bool(reject.all()):
             all_reject_attempts += 1
             if all_reject_attempts < 3:  # nonlinear_optimizer.py:88 _MAX_ALL_REJECT_ATTEMPTS
@@ -357,10 +374,38 @@ def lm_optimize(p: PGProblem, poses, max_iterations=20, step_size=1.0, damping=1
         if bool(converged.all()):
             break  # nonlinear_least_squares.py:202-203 (breaks before counting the iteration)
         last_err = err
+        if dogleg and keep_taps:   # (where the reference's end_iter_callback sees optimizer._trust_region)
+            info.trust_regions.append(trust_region.view(-1).clone())
         it += 1
         info.iters_done = it
     info.last_err = info.err_history[-1]
     return poses, info
+
+
+def dogleg_step(A, AtA, Atb, trust_region, eps=1e-7):
+    """Dogleg._compute_delta_impl (dogleg.py:52-116; Nocedal & Wright pp. 73-77): the Gauss-Newton step where it lies inside
+    the trust region of EVERY problem of the batch, otherwise per problem the Cauchy step (truncated to the region) extended
+    towards the Gauss-Newton step up to the boundary.  ``trust_region``: (B, 1)."""
+    sq = lambda t: (t ** 2).sum(dim=1, keepdim=True)  # noqa: E731   (TrustRegion._squared_norm)
+    tr2 = trust_region ** 2
+    delta_gn = solve(AtA, Atb)
+    if bool((sq(delta_gn) < tr2).all()):
+        return delta_gn
+    delta_sd = Atb.squeeze(2)
+    Asd2 = sq(A.bmm(delta_sd.unsqueeze(2)).squeeze(2))
+    g2 = sq(delta_sd)
+    cauchy = g2 / (Asd2 + eps)
+    delta_c = delta_sd * cauchy
+    c2 = g2 * cauchy ** 2
+    inside = c2 <= tr2
+    out = torch.where(inside, delta_c, delta_c * trust_region / (c2 + eps).sqrt())
+    diff = delta_gn - delta_c
+    a = sq(diff)
+    b = (2 * delta_c * diff).sum(dim=1, keepdim=True)
+    c = c2 - tr2
+    disc = (b ** 2 - 4 * a * c).clamp(eps)
+    tau = ((-b + disc.sqrt()) / (2 * a + eps)).clamp(max=1.0)
+    return torch.where(inside, delta_c + tau * diff, out)
 
 
 def implicit_final_step(p: PGProblem, poses, step_size=1.0):

@@ -25,7 +25,8 @@ def test_lie_ops_match_reference(tag, dtype, tol):
 
 
 CASES = [("pg_f64_lm", 5e-8), ("pg_f64_gn", 5e-8), ("pg_f64_lm_adaptive", 5e-8),
-         ("pg_f64_lm_adaptive_ellips", 5e-8), ("pg_f64_lm_adaptive_rejects", 5e-8), ("pg_f32_lm", 2e-3)]
+         ("pg_f64_lm_adaptive_ellips", 5e-8), ("pg_f64_lm_adaptive_rejects", 5e-8), ("pg_f32_lm", 2e-3),
+         ("pg_f64_dogleg", 5e-8), ("pg_f64_dogleg_rejects", 5e-8), ("pg_f32_dogleg", 2e-3)]
 
 
 @pytest.mark.parametrize("name,tol", CASES)
@@ -60,6 +61,11 @@ def test_lm_trajectory_matches_reference(name, tol):
     ref = g["err_history"]
     k = min(hist.shape[1], ref.shape[1])
     np.testing.assert_allclose(hist[:, :k], ref[:, :k], rtol=2e-5 if tol < 1e-6 else 2e-3)
+    if kw.get("dogleg"):   # the trust-region radii after every iteration (trust_region.py:139-150), bit for bit in fp64
+        tr = torch.stack(info.trust_regions).numpy()
+        assert tr.shape == g["trust_region"].shape
+        np.testing.assert_allclose(tr, g["trust_region"], rtol=0 if tol < 1e-6 else 1e-6, atol=0)
+        assert (tr != tr[0]).any()   # the fixture exercises shrinking / expanding
 
 
 @pytest.mark.parametrize("name", ["pg_f64_implicit", "pg_f64_implicit_b", "pg2_f64_implicit"])

@@ -55,7 +55,8 @@ def _objective(th, g):
 
 
 @pytest.mark.parametrize("name", ["pg_f64_lm", "pg_f64_lm_adaptive_ellips", "pg_f64_lm_adaptive_rejects", "pg_f64_gn",
-                                  "pg2_f64_lm", "pg2_f64_lm_adaptive", "pg3_f64_lm", "pg3_f64_lm_adaptive"])
+                                  "pg2_f64_lm", "pg2_f64_lm_adaptive", "pg3_f64_lm", "pg3_f64_lm_adaptive",
+                                  "pg_f64_dogleg", "pg_f64_dogleg_rejects"])   # th.Dogleg: Av() from the Jacobian blocks
 def test_reference_loop_drives_the_plugin(ref, name):
     th, thp = ref
     from tests.oracle_kernels import OracleKernels
@@ -64,7 +65,7 @@ def test_reference_loop_drives_the_plugin(ref, name):
     obj, poses = _objective(th, g)
     gn = kw.pop("gauss_newton", False)
     okw = dict(max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"))
-    cls = th.GaussNewton if gn else th.LevenbergMarquardt
+    cls = th.Dogleg if kw.pop("dogleg", False) else (th.GaussNewton if gn else th.LevenbergMarquardt)
     opt = cls(obj, linear_solver_cls=thp.HipCholeskySolver, linearization_cls=thp.HipLinearization,
               linearization_kwargs=_kernels(), vectorize=True,
               abs_err_tolerance=0.0, rel_err_tolerance=0.0, **okw)
@@ -79,6 +80,8 @@ def test_reference_loop_drives_the_plugin(ref, name):
     slack = 2.0 * (np.abs(g["delta"]).max(axis=2) * ~ok).sum(axis=0)
     assert (np.abs(final - g["final"]).reshape(final.shape[0], -1).max(1) <= 5e-8 + slack).all()
     assert all(s == th.NonlinearOptimizerStatus.MAX_ITERATIONS for s in info.status)
+    if "trust_region" in g:
+        np.testing.assert_array_equal(opt._trust_region.view(-1).cpu().numpy(), g["trust_region"][-1])
     # the properties the reference reads from a linearization
     lin.linearize()
     ref_lin = th.optimizer.DenseLinearization(obj)
@@ -115,8 +118,10 @@ def test_plugin_through_theseus_layer_and_failure_path(ref):
 
 
 @cpu_only
-def test_non_pose_graph_objective_takes_the_generic_path(ref):
-    """Vector variables + Difference: not an SE3 pose graph -> generic block assembly, same result as the reference."""
+@pytest.mark.parametrize("optimizer", ["LevenbergMarquardt", "Dogleg"])
+def test_non_pose_graph_objective_takes_the_generic_path(ref, optimizer):
+    """Vector variables + Difference: not an SE3 pose graph -> generic block assembly, same result as the reference
+    (th.Dogleg also reads ``Av`` of the generic path: block-wise, no dense Jacobian)."""
     th, thp = ref
     from tests.oracle_kernels import OracleKernels
     out = {}
@@ -130,10 +135,10 @@ def test_non_pose_graph_objective_takes_the_generic_path(ref):
         obj.add(th.Between(a, b, th.Vector(tensor=torch.tensor([[1.0, 1.0]], dtype=torch.float64), name="m"), w, name="d1"))
         kw = {} if tag == "ref" else dict(linear_solver_cls=thp.HipCholeskySolver,
                                           linearization_kwargs=_kernels())
-        opt = th.LevenbergMarquardt(obj, max_iterations=5, **kw)
+        opt = getattr(th, optimizer)(obj, max_iterations=5, **kw)
         obj.update()
         with torch.no_grad():
-            opt.optimize(damping=0.1)
+            opt.optimize(**(dict(damping=0.1) if optimizer == "LevenbergMarquardt" else dict(trust_region_init=1.0)))
         out[tag] = torch.cat([a.tensor, b.tensor], 1)
         if tag == "ours":
             assert not opt.linear_solver.linearization.fused

@@ -46,7 +46,8 @@ def _run_lm(g, opt_overrides, reducer=None, spy=None):
     obj, _ = build_objective(th, g, device="cpu")
     okw = dict(max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"))
     okw.update(opt_overrides)
-    opt = th.LevenbergMarquardt(obj, linearization_kwargs=dict(kernels=OracleKernels()), **okw)
+    cls = th.Dogleg if kw.pop("dogleg", False) else th.LevenbergMarquardt
+    opt = cls(obj, linearization_kwargs=dict(kernels=OracleKernels()), **okw)
     if reducer is not None:
         opt.reducer = reducer
     if spy is not None:
@@ -98,6 +99,9 @@ CASES = [
     ("pg_f64_lm_adaptive", None, dict(abs_err_tolerance=1e-10, rel_err_tolerance=1e-3)),
     ("pg_f64_lm", None, dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0)),
     ("pg2_f64_lm_adaptive", None, dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0)),   # SE2, uneven shards (B=5)
+    # Dogleg: "every Gauss-Newton step lies inside its trust region" (dogleg.py:55-58) is a batch-global predicate too
+    ("pg_f64_dogleg", None, dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0)),
+    ("pg_f64_dogleg_rejects", None, dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0)),
 ]
 
 

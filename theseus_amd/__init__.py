@@ -12,8 +12,8 @@ from .layer import TheseusLayer  # noqa: F401
 from .linear_solver import HipCholeskySolver, LinearSolver  # noqa: F401
 from .sparse import HipSparseCholeskySolver, fill_reducing_ordering  # noqa: F401
 from .linearization import HipLinearization, Linearization, VariableOrdering  # noqa: F401
-from .nonlinear import (BackwardMode, GaussNewton, LevenbergMarquardt, NonlinearLeastSquares,  # noqa: F401
-                        NonlinearOptimizerInfo, NonlinearOptimizerStatus)
+from .nonlinear import (BackwardMode, Dogleg, GaussNewton, LevenbergMarquardt, NonlinearLeastSquares,  # noqa: F401
+                        NonlinearOptimizerInfo, NonlinearOptimizerStatus, TrustRegion)
 from .packed import PackedPoseGraph, UnsupportedObjective  # noqa: F401
 from .ba import HipSchurLinearization, HipSchurSolver, PackedBA  # noqa: F401
 

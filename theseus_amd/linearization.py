@@ -118,6 +118,7 @@ class HipLinearizationCore:
         self.g: Optional[torch.Tensor] = None   # (B, n): A^T b
         self._AtA_cache = None
         self._A = self._b = None
+        self._Jblocks = None   # weighted Jacobian blocks of the current linearization (Av), on demand
 
     # structure exactly as the reference lays it out
     @property
@@ -160,6 +161,7 @@ class HipLinearizationCore:
         self.packed.assemble(self.H, self.g)
         self._AtA_cache = None
         self._A = self._b = None
+        self._Jblocks = None
 
     @property
     def A(self):
@@ -181,7 +183,13 @@ class HipLinearizationCore:
         return self._AtA_cache
 
     def Av(self, v: torch.Tensor) -> torch.Tensor:
-        return self.A.bmm(v.unsqueeze(2)).squeeze(2)
+        """(B, n) -> (B, m), dense_linearization.py:73-74 -- from the per-cost Jacobian blocks of this linearization
+        (thx_pg_jacobians, evaluated once per ``linearize()`` on first use: the variables still hold the values the
+        linearization was taken at, as they do wherever the reference's optimizers call ``Av``: dogleg.py:66,
+        trust_region.py:97), never through the dense ``A``."""
+        if self._Jblocks is None:
+            self._Jblocks = self.packed.jacobian_blocks()
+        return self.packed.jacobian_times(self._Jblocks, v)
 
     def diagonal(self) -> torch.Tensor:
         d = torch.empty(self.H.shape[0], self.n, dtype=self.H.dtype, device=self.H.device)

@@ -139,6 +139,15 @@ class NonlinearLeastSquares(abc.ABC):
     def _complete_step(self, delta, new_err, previous_err, **kwargs) -> Optional[torch.Tensor]:
         return None
 
+    def _may_reject(self, kwargs) -> bool:
+        """Can ``_complete_step`` reject steps with these optimizer kwargs?  (The sync-free loop then keeps the start state
+        for the replay of an all-rejected iteration.)"""
+        return False
+
+    def _join_compute_delta(self):
+        """Called INSTEAD of ``compute_delta`` on a rank that cannot run it (host-side error): take part in whatever
+        collectives ``compute_delta`` issues, so that the other shards are not left waiting."""
+
     # ---- public entry (theseus/optimizer/optimizer.py:40-53) -------------------------------------
     def optimize(self, **kwargs) -> NonlinearOptimizerInfo:
         if self._objective_version != self.objective.current_version:
@@ -243,7 +252,7 @@ class NonlinearLeastSquares(abc.ABC):
                          and loop_iters > 0)
             replay = False
             if sync_free:
-                start_state = packed.clone_state() if adaptive else None
+                start_state = packed.clone_state() if self._may_reject(kwargs) else None
                 flag = lambda v: torch.full((), v, dtype=torch.long, device=dev)  # noqa: E731
                 failed = torch.zeros((), dtype=torch.bool, device=dev)
                 first_fail, first_all_rej, first_all_conv = flag(-1), flag(-1), flag(-1)
@@ -265,6 +274,7 @@ class NonlinearLeastSquares(abc.ABC):
                             # all-reduce -- keep taking part in it with the flag raised instead of leaving the loop
                             raised = run_err
                     if raised is not None:
+                        self._join_compute_delta()
                         delta = torch.zeros(B, lin.num_cols, dtype=dt, device=dev)
                         local_fail = torch.ones((), dtype=torch.bool, device=dev)
                     now = self.reducer.device_any(local_fail)
@@ -505,6 +515,9 @@ class LevenbergMarquardt(NonlinearLeastSquares):
         else:
             self._damping = damping
 
+    def _may_reject(self, kwargs) -> bool:
+        return bool(kwargs.get("adaptive_damping", False))
+
     # levenberg_marquardt.py:114-137
     def compute_delta(self, ellipsoidal_damping: bool = False, damping_eps: Optional[float] = None,
                       **kwargs) -> torch.Tensor:
@@ -523,3 +536,96 @@ class LevenbergMarquardt(NonlinearLeastSquares):
         lin.lm_accept(d, self._damping, previous_err, new_err, ellipsoidal_damping, damping_accept, down_damping_ratio,
                       up_damping_ratio, self._reject)
         return self._reject
+
+
+class TrustRegion(NonlinearLeastSquares, abc.ABC):
+    """theseus/optimizer/nonlinear/trust_region.py:35-151: per-problem trust-region radius, gain ratio against the quadratic
+    model, shrink / expand / reject.  Everything stays on the device (no host decision)."""
+
+    def __init__(self, objective: Objective, *args, **kwargs):
+        super().__init__(objective, *args, **kwargs)
+        self._trust_region: Optional[torch.Tensor] = None
+
+    # trust_region.py:65-76
+    def reset(self, trust_region_init: float = 0.5, **kwargs) -> None:
+        super().reset(**kwargs)
+        packed = self.linear_solver.linearization.packed
+        packed.sync()
+        self._trust_region = trust_region_init * torch.ones(packed.batch, 1, device=packed.device, dtype=self.objective.dtype)
+
+    def _may_reject(self, kwargs) -> bool:
+        return True
+
+    @abc.abstractmethod
+    def _compute_delta_impl(self) -> torch.Tensor:
+        pass
+
+    def compute_delta(self, **kwargs) -> torch.Tensor:
+        return self._compute_delta_impl()
+
+    @staticmethod
+    def _squared_norm(tensor: torch.Tensor, keepdim: bool = True) -> torch.Tensor:
+        return (tensor ** 2).sum(dim=1, keepdim=keepdim)
+
+    # trust_region.py:91-105: m(delta) = err + delta . grad + |A delta|^2 / 2 with grad = -Atb
+    def _predicted_error(self, previous_error: torch.Tensor, delta: torch.Tensor) -> torch.Tensor:
+        lin = self.linear_solver.linearization
+        Adelta = lin.Av(delta)
+        grad = -lin.Atb.squeeze(2)
+        return previous_error + (delta * grad).sum(dim=1) + 0.5 * TrustRegion._squared_norm(Adelta, keepdim=False)
+
+    # trust_region.py:113-151
+    def _complete_step(self, delta, new_err, previous_err, step_size: float = 1.0, accept_threshold: float = 0.0,
+                       shrink_threshold: float = 0.25, expand_threshold: float = 0.75, shrink_ratio: float = 0.25,
+                       expand_ratio: float = 2.0, min_trust_region: float = 1.0e-5, max_trust_region: float = 1.0e5,
+                       **kwargs) -> Optional[torch.Tensor]:
+        good_params = (0.0 < shrink_ratio <= 1.0) and (expand_ratio >= 1.0)
+        good_params &= (shrink_threshold < expand_threshold) and (accept_threshold < shrink_threshold)
+        if not good_params:
+            raise ValueError("Invalid parameters for TrustRegionMethod. Values must satisfy <accept/shrink>_threshold < "
+                             "expand_threshold, shrink_ratio in (0, 1], and expand_ratio > 1.0.")
+        d = delta if step_size == 1.0 else delta * step_size
+        pred_err = self._predicted_error(previous_err, d)
+        rho = ((previous_err - new_err) / (previous_err - pred_err)).view(-1, 1)
+        tr = self._trust_region
+        tr = torch.where(rho < shrink_threshold, tr * shrink_ratio, tr)
+        tr = torch.where(rho > expand_threshold, tr * expand_ratio, tr)
+        self._trust_region = tr.clamp(min_trust_region, max_trust_region)
+        return (rho < accept_threshold).view(-1)
+
+
+class Dogleg(TrustRegion):
+    """theseus/optimizer/nonlinear/dogleg.py:18-116 (Nocedal & Wright, pp. 73-77)."""
+    EPS = 1e-7
+
+    def _join_compute_delta(self):
+        one = torch.ones((), dtype=torch.bool, device=self._trust_region.device)
+        self.reducer.device_all(one)
+
+    def _compute_delta_impl(self) -> torch.Tensor:
+        sq = TrustRegion._squared_norm
+        tr = self._trust_region
+        tr2 = tr ** 2
+        delta_gn = self.linear_solver.solve(check_info=False)
+        # dogleg.py:55-58 returns the Gauss-Newton steps untouched when ALL of them (the whole batch, every shard) are inside
+        # their regions -- a batch-global predicate, kept on the device and applied as a select
+        all_inside = self.reducer.device_all((sq(delta_gn) < tr2).all())
+        lin = self.linear_solver.linearization
+        delta_sd = lin.Atb.squeeze(2)
+        Asd2 = sq(lin.Av(delta_sd))
+        g2 = sq(delta_sd)
+        cauchy = g2 / (Asd2 + Dogleg.EPS)
+        delta_c = delta_sd * cauchy
+        c2 = g2 * cauchy ** 2
+        inside = c2 <= tr2
+        # steps beyond the region are truncated (dogleg.py:75-82) ...
+        out = torch.where(inside, delta_c, delta_c * tr / (c2 + Dogleg.EPS).sqrt())
+        # ... Cauchy steps inside it are extended towards the Gauss-Newton step up to the boundary (:84-101)
+        diff = delta_gn - delta_c
+        a = sq(diff)
+        b = (2 * delta_c * diff).sum(dim=1, keepdim=True)
+        c = c2 - tr2
+        disc = (b ** 2 - 4 * a * c).clamp(Dogleg.EPS)
+        tau = ((-b + disc.sqrt()) / (2 * a + Dogleg.EPS)).clamp(max=1.0)
+        out = torch.where(inside, delta_c + tau * diff, out)
+        return torch.where(all_inside, delta_gn, out)

@@ -446,6 +446,31 @@ class PackedPoseGraph:
         return out
 
 
+    def jacobian_times(self, blocks, v: torch.Tensor) -> torch.Tensor:
+        """A v (B, m) from the weighted Jacobian BLOCKS of ``jacobian_blocks()`` -- the product the reference takes with its
+        dense (B, m, n) Jacobian (dense_linearization.py:73-74), which at the headline size would be 155 GB.  Rows in cost
+        add order, columns in the packed (= the linearization's) variable order."""
+        J0, J1, _, Jp, _ = blocks
+        s, d, B = self.structure, self.dof, v.shape[0]
+        vb = v.reshape(B, -1, d)
+        out = torch.zeros(B, self.m, dtype=v.dtype, device=v.device)
+        dev = v.device
+        if s.num_edges:
+            vi = vb[:, torch.from_numpy(s.edge_i).long().to(dev)].permute(1, 0, 2).unsqueeze(-1)   # (E, B, d, 1)
+            vj = vb[:, torch.from_numpy(s.edge_j).long().to(dev)].permute(1, 0, 2).unsqueeze(-1)
+            r = (J0 @ vi + J1 @ vj).squeeze(-1)                                                    # (E, B, d)
+            rows = torch.from_numpy(s.edge_row_start).to(dev)
+            idx = (rows.view(-1, 1) + torch.arange(d, device=dev)).view(-1)
+            out[:, idx] = r.permute(1, 0, 2).reshape(B, -1)
+        if s.num_priors:
+            vp = vb[:, torch.from_numpy(s.prior_pose).long().to(dev)].permute(1, 0, 2).unsqueeze(-1)
+            r = (Jp @ vp).squeeze(-1)
+            rows = torch.from_numpy(s.prior_row_start).to(dev)
+            idx = (rows.view(-1, 1) + torch.arange(d, device=dev)).view(-1)
+            out[:, idx] = r.permute(1, 0, 2).reshape(B, -1)
+        return out
+
+
 def packed_for(objective: Objective, kernels=None, order=None) -> PackedPoseGraph:
     """Get (or build) the packed representation attached to an objective (``order``: variable names in column order)."""
     p = getattr(objective, "_packed", None)

@@ -353,6 +353,20 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
                 "theseus_amd builds the Hessian outside autograd: differentiating through it (backward_mode='unroll' "
                 "with gradients) is not supported.  Use backward_mode='implicit', or run under torch.no_grad().")
 
+    def Av(self, v: torch.Tensor) -> torch.Tensor:
+        if self.fused:
+            return HipLinearizationCore.Av(self, v)
+        Jd, _ = self._blocks   # generic path: the reference's weighted Jacobian blocks of this linearization
+        out = torch.zeros(v.shape[0], self.num_rows, dtype=v.dtype, device=v.device)
+        r = 0
+        for c, J in enumerate(Jd):
+            d = self.asm.cost_dims[c]
+            for s, k in enumerate(self.asm.cost_vars[c]):
+                c0, dof = self.asm.var_cols[k]
+                out[:, r:r + d] += (J[s] @ v[:, c0:c0 + dof].unsqueeze(2)).squeeze(2)
+            r += d
+        return out
+
     def hessian_approx(self):
         return self._full_AtA()
 
