@@ -3,6 +3,7 @@
 CholeskyDenseSolver trajectories.  GPU twin: tests/test_gpu_ba.py."""
 import numpy as np
 import pytest
+import torch
 
 from tests.ba_common import reference_columns, run_ba
 from tests.helpers import load_golden
@@ -73,3 +74,32 @@ def test_ba_implicit_backward_matches_reference_gradients():
     for k in ("log_radius", "feat", "focal", "k1", "k2", "w_obs", "gt_cams", "w_strong", "w_reg"):
         want = g["grad_" + k]
         np.testing.assert_allclose(got["grad_" + k], want, rtol=0, atol=5e-6 * max(np.abs(want).max(), 1e-12), err_msg=k)
+
+
+def test_banded_reduced_system_is_factorised_along_its_tile_pattern():
+    """Cameras on a line with local tracks (the reference's generator): the reduced camera system S is banded, the Schur solver
+    hands thx_chol_factor_sparse the tile pattern of its Cholesky factor (the stand-in asserts that the numeric fill stays inside
+    it) and the steps equal those of the dense factorisation of the same S."""
+    import theseus_amd as th
+    from tests.oracle_kernels import OracleKernels
+    from theseus_amd.utils.synthetic_ba import make_ba_objective
+    out = {}
+    for sparse in (True, False):
+        K = OracleKernels()
+        calls = {"sparse": 0}
+        fs = K.chol_factor_sparse   # (the stand-in factorises densely and checks the fill against the pattern)
+        K.chol_factor_sparse = lambda *a, **k: (calls.__setitem__("sparse", calls["sparse"] + 1), fs(*a, **k))[1]
+        obj, meta = make_ba_objective(96, 768, 2, track_length=4, dtype=torch.float64, device="cpu", seed=1, kernels=K)
+        opt = th.LevenbergMarquardt(obj, max_iterations=2, abs_err_tolerance=0.0, rel_err_tolerance=0.0,
+                                    linearization_kwargs=dict(kernels=K),
+                                    linear_solver_kwargs=dict(sparse_reduced_system=sparse))
+        solver = opt.linear_solver
+        with torch.no_grad():
+            info = opt.optimize(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True, track_err_history=True)
+        pat = solver.pattern
+        assert pat.ntiles == 5 and pat.l_tiles < 15            # 96 cameras = 576 columns: the far corner of S is empty
+        assert solver.sparse == sparse and (calls["sparse"] > 0) == sparse
+        out[sparse] = (solver.delta.clone(), info.err_history.clone())
+    np.testing.assert_allclose(out[True][0].numpy(), out[False][0].numpy(), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(out[True][1].numpy(), out[False][1].numpy(), rtol=1e-12)
+    assert (out[True][1][:, -1] < out[True][1][:, 0]).all()

@@ -522,9 +522,10 @@ class HipSchurSolverCore:
     """(H + damping) delta = g of a bundle-adjustment linearization by block elimination of the points + the tiled dense
     Cholesky on the reduced camera system.  Same ``solve`` contract and failure behaviour as ``HipCholeskySolver``."""
 
-    def _schur_solver_init(self):
+    def _schur_solver_init(self, sparse_reduced_system: bool = True):
         self.K = self.linearization.K
         self.S = self.L = self.panels = self.info_chol = self.info_pts = None
+        self.pattern, self.sparse, self._want_sparse = None, False, bool(sparse_reduced_system)
         self.factor_version = 0
 
     def _ensure_buffers(self):
@@ -545,6 +546,18 @@ class HipSchurSolverCore:
             self.info_chol = torch.zeros(B, dtype=torch.int32, device=dev)
             self.info_pts = torch.zeros(B, dtype=torch.int32, device=dev)
             self._lam = torch.empty(B, dtype=dt, device=dev)
+        if self.pattern is None:
+            # Tile pattern of the reduced camera system: S has a block (c1, c2) where two cameras see a common point.  With the
+            # reference's generator (cameras on a line, tracks local: data.py:311-320) S is BANDED -- at 512 cameras 158 of 300
+            # lower tiles, 21 % of the dense tile products -- and the factorisation visits the structurally non-zero tiles only
+            # (thx_chol_factor_sparse, bit-identical to the dense one on the same matrix).  A dense pattern keeps the dense call.
+            from .sparse import TilePattern
+            t = lin.packed.structure.t
+            cams = np.arange(lin.packed.structure.num_cams, dtype=np.int64)
+            blocks = np.concatenate([np.stack([cams, cams], 1),
+                                     np.stack([t["blk_c1"].astype(np.int64), t["blk_c2"].astype(np.int64)], 1)], 0)
+            self.pattern = TilePattern(nc, blocks, 6)
+            self.sparse = self._want_sparse and self.pattern.l_tiles < self.pattern.ntiles * (self.pattern.ntiles + 1) // 2
 
     @property
     def info(self):
@@ -577,7 +590,12 @@ class HipSchurSolverCore:
         self._factor_args = (lam.clone() if lam is not None else None, ellipsoidal_damping, damping_eps)
         self.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, lin.gd, lam, ellipsoidal_damping, damping_eps, self.S, self.rhs,
                         self.Hinv, self.tvec, self.info_pts)
-        self.K.chol_factor(self.S, p.nc, None, False, damping_eps, self.L, self.panels, self.info_chol, rhs=self.rhs, y=self._y)
+        if self.sparse:
+            self.K.chol_factor_sparse(self.S, p.nc, None, False, damping_eps, self.L, self.panels, self.info_chol, self.pattern,
+                                      rhs=self.rhs, y=self._y)
+        else:
+            self.K.chol_factor(self.S, p.nc, None, False, damping_eps, self.L, self.panels, self.info_chol, rhs=self.rhs,
+                               y=self._y)
         self.K.chol_solve_backward(self.L, p.nc, self.panels, self._y, self._dc)
         self.delta[:, :p.nc].copy_(self._dc)                                          # delta = [delta_c | delta_p]
         self.K.ba_backsub(p.dstruct, lin.W, self.Hinv, self.tvec, self.delta)
@@ -696,12 +714,14 @@ def ba_implicit_step(opt, packed, step: float, kwargs):
 
 class HipSchurSolver(HipSchurSolverCore, LinearSolver):
     def __init__(self, objective: Objective, linearization_cls: Optional[Type[Linearization]] = None,
-                 linearization_kwargs: Optional[Dict[str, Any]] = None, **kwargs):
+                 linearization_kwargs: Optional[Dict[str, Any]] = None, sparse_reduced_system: bool = True, **kwargs):
+        """``sparse_reduced_system=False``: factorise the reduced camera system as a dense matrix even where its tile pattern
+        has holes (for comparisons; the result is the same bit for bit)."""
         linearization_cls = linearization_cls or HipSchurLinearization
         if not (isinstance(linearization_cls, type) and issubclass(linearization_cls, HipSchurLinearization)):
             raise RuntimeError(f"HipSchurSolver only works with HipSchurLinearization, but {linearization_cls} was provided.")
         LinearSolver.__init__(self, objective, linearization_cls, linearization_kwargs)
-        self._schur_solver_init()
+        self._schur_solver_init(sparse_reduced_system)
 
     def solve(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
               damping_eps: float = 1e-8, check_info: bool = True, **kwargs) -> torch.Tensor:

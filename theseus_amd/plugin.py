@@ -474,14 +474,14 @@ class HipSchurSolver(HipSchurSolverCore, _RefCholeskyDenseSolver):
     HipCholeskySolver above; ``solve`` returns delta in ``linearization.ordering`` (cameras, then points)."""
 
     def __init__(self, objective: th.Objective, linearization_cls=None, linearization_kwargs=None, check_singular: bool = False,
-                 **kwargs):
+                 sparse_reduced_system: bool = True, **kwargs):
         linearization_cls = linearization_cls or HipSchurLinearization
         if not (isinstance(linearization_cls, type) and issubclass(linearization_cls, HipSchurLinearization)):
             raise RuntimeError(f"HipSchurSolver only works with theseus_amd.plugin.HipSchurLinearization, but "
                                f"{linearization_cls} was provided.")
         _RefLinearSolver.__init__(self, objective, linearization_cls, linearization_kwargs)
         self._check_singular = check_singular
-        self._schur_solver_init()
+        self._schur_solver_init(sparse_reduced_system)
 
     def solve(self, damping=None, ellipsoidal_damping: bool = True, damping_eps: float = 1e-8, **kwargs) -> torch.Tensor:
         return self._solve(damping, ellipsoidal_damping, damping_eps, check_info=True).clone()

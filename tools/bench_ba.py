@@ -43,7 +43,12 @@ def timed(name, fn, reps=3):
 p = lin.packed
 timed("ba_assemble", lambda: lin._assemble())
 timed("ba_schur", lambda: solver.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, lin.gd, lam, True, 1e-8, solver.S, solver.rhs, solver.Hinv, solver.tvec, solver.info_pts))
-timed("chol_factor(S)", lambda: solver.K.chol_factor(solver.S, p.nc, None, False, 1e-8, solver.L, solver.panels, solver.info_chol, rhs=solver.rhs, y=solver._y))
+timed("chol_factor(S) dense", lambda: solver.K.chol_factor(solver.S, p.nc, None, False, 1e-8, solver.L, solver.panels, solver.info_chol, rhs=solver.rhs, y=solver._y))
+dense_ms = phases.pop("chol_factor(S) dense")   # for comparison only: the solver factorises along the tile pattern of S
+if solver.sparse:
+    timed("chol_factor(S)", lambda: solver.K.chol_factor_sparse(solver.S, p.nc, None, False, 1e-8, solver.L, solver.panels, solver.info_chol, solver.pattern, rhs=solver.rhs, y=solver._y))
+else:
+    phases["chol_factor(S)"] = dense_ms
 timed("chol_backward", lambda: solver.K.chol_solve_backward(solver.L, p.nc, solver.panels, solver._y, solver._dc))
 timed("ba_backsub", lambda: solver.K.ba_backsub(p.dstruct, lin.W, solver.Hinv, solver.tvec, solver.delta))
 timed("ba_error", lambda: p.error_metric())
@@ -82,4 +87,7 @@ print("phases (ms):", {k: round(v, 3) for k, v in phases.items()})
 per_solve = sum(phases.values())
 print(f"one linearize + solve + retract + error: {per_solve:.2f} ms of kernels -> {B / per_solve * 1e3:.0f} problem-iterations/s; "
       f"LM loop {ms:.2f} ms per ACCEPTED iteration (all-rejected retries re-solve, nonlinear_least_squares.py:358-365); "
-      f"Schur system {nc}^2, Cholesky {fl / phases['chol_factor(S)'] / 1e9:.1f} TFLOP/s")
+      f"Schur system {nc}^2: L has {solver.pattern.l_tiles} of {solver.pattern.ntiles * (solver.pattern.ntiles + 1) // 2} tiles, "
+      f"{solver.pattern.flops / solver.pattern.dense_flops:.3f} of the dense flops; tile-sparse Cholesky "
+      f"{B * solver.pattern.flops / phases['chol_factor(S)'] / 1e9:.1f} TFLOP/s executed; the dense factorisation of the same S: "
+      f"{dense_ms:.2f} ms = {fl / dense_ms / 1e9:.1f} TFLOP/s")
