@@ -218,7 +218,8 @@ int thx_se3_retract(const void* poses, const void* delta, int64_t ldd, double st
  *      its row panels are non-zero: the work follows the fill of the (fill-reducing ordered) block pattern instead of n^3/3.
  *      Tiles outside the pattern are never written: L must be zero-initialised once.  The pattern is the host's symbolic
  *      factorisation at tile granularity (theseus_amd/sparse.py:tile_pattern); all tables int32, device pointers except
- *      col_count_host.  rhs / y may both be NULL (no fused forward substitution).  The solves are thx_chol_solve*. */
+ *      col_count_host.  rhs / y may both be NULL (no fused forward substitution).  The solves are thx_chol_solve_sparse (or the dense-frame
+ *      thx_chol_solve*). */
 typedef struct {
   int32_t ntiles;                 /* ceil(n / THX_TILE) */
   const int32_t* col_ptr;         /* (ntiles + 1) off-diagonal non-zero tiles of block column j: entries [col_ptr[j], col_ptr[j+1]) */
@@ -228,10 +229,19 @@ typedef struct {
   const int32_t* diag_kptr;       /* (ntiles + 1) K-list of diagonal tile j: */
   const int32_t* diag_k;          /*   block columns k < j in which L_jk is non-zero */
   const int32_t* col_count_host;  /* (ntiles) HOST copy of col_ptr[j+1] - col_ptr[j] (launch sizes) */
+  const int32_t* row_ptr;         /* (ntiles + 1) the same pattern by ROWS, for the list-driven solves: the non-zero off-diagonal */
+  const int32_t* row_tile;        /*   tiles of block row i are the block columns row_tile[row_ptr[i] .. row_ptr[i+1]) (< i) */
 } thx_tile_pattern;
 int thx_chol_factor_sparse(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
                            double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y, int64_t ldv,
                            const thx_tile_pattern* pattern, int dtype, void* stream);
+/*      thx_chol_solve_sparse: x = (L L^T)^-1 rhs (backward_only != 0: x = L^-T rhs, the second half after the fused forward
+ *      substitution of thx_chol_factor_sparse) streaming only the structurally non-zero tiles of L (row lists of the pattern)
+ *      -- where the dense-frame solves read ntiles^2 / 2 tiles per problem, the dominant cost of a large sparse graph's
+ *      iteration.  The working vector stays in global memory: no limit on n (the dense-frame thx_chol_solve* keep it in LDS).
+ *      Bit-identical to thx_chol_solve* on the same factor.  x may alias rhs. */
+int thx_chol_solve_sparse(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs, void* x,
+                          int64_t ldv, int backward_only, const thx_tile_pattern* pattern, int dtype, void* stream);
 
 /* ---- LinearSolver.solve(): replaces DenseSolver._apply_damping + CholeskyDenseSolver._solve_sytem
  *      (linear/dense_solver.py:38-64,159-161).

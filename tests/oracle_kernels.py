@@ -3,6 +3,7 @@
 It exists so that the host logic that does not need a GPU -- batch sharding across ranks, the LM control
 flow with its batch-global predicates -- can run under ``-m "not gpu"`` (gloo, world_size 2).  The product
 never imports this module: theseus_amd has no CPU path (theseus_amd/kernels.py)."""
+import numpy as np
 import torch
 
 from oracle import lie
@@ -357,6 +358,23 @@ class OracleKernels:
         Lp = torch.nn.functional.pad(L[:, :n, :n], (0, nt * 128 - n, 0, nt * 128 - n))
         tiles = Lp.view(L.shape[0], nt, 128, nt, 128).abs().amax(dim=(0, 2, 4)) > 0
         assert not (tiles & ~torch.from_numpy(pattern.lower)).any(), "numeric fill outside the symbolic tile pattern"
+
+    def chol_solve_sparse(self, L, n, panels, rhs, x, pattern, backward_only=False):
+        """The list-driven solves read ONLY the tiles of the row lists: emulate that by masking L to the pattern (a factor with
+        fill outside it would give a different answer here, as it would on the GPU)."""
+        nt = pattern.ntiles
+        rows = np.zeros((nt, nt), dtype=bool)
+        rp, rt = pattern.tables["row_ptr"], pattern.tables["row_tile"]
+        for i in range(nt):
+            rows[i, rt[rp[i]:rp[i + 1]]] = True
+            rows[i, i] = True
+        assert (rows == pattern.lower).all(), "row lists disagree with the column tables"
+        mask = torch.from_numpy(np.kron(rows, np.ones((128, 128), dtype=bool))[:n, :n])
+        Lm = torch.where(mask, L[:, :n, :n], torch.zeros((), dtype=L.dtype))
+        if backward_only:
+            x.copy_(torch.linalg.solve_triangular(Lm.transpose(1, 2), rhs.unsqueeze(2), upper=True).squeeze(2))
+        else:
+            x.copy_(torch.cholesky_solve(rhs.unsqueeze(2), Lm).squeeze(2))
 
     def chol_solve_backward(self, L, n, panels, y, x):
         x.copy_(torch.linalg.solve_triangular(L[:, :n, :n].transpose(1, 2), y.unsqueeze(2), upper=True).squeeze(2))

@@ -48,11 +48,20 @@ def test_sparse_factorisation_is_bit_identical_to_dense(dtype, n, B):
             K.chol_factor_sparse(H, n, lam, True, 1e-8, L, panels, info, pat, rhs=rhs, y=y)
         else:
             K.chol_factor(H, n, lam, True, 1e-8, L, panels, info, rhs=rhs, y=y)
-        K.chol_solve_backward(L, n, panels, y, x)
+        x2 = torch.empty_like(rhs)
+        if sparse:   # the list-driven solves (thx_chol_solve_sparse): second half after the fused forward, and both halves
+            K.chol_solve_sparse(L, n, panels, y, x, pat, backward_only=True)
+            K.chol_solve_sparse(L, n, panels, rhs, x2, pat)
+        else:
+            K.chol_solve_backward(L, n, panels, y, x)
+            K.chol_solve(L, n, panels, rhs, x2)
         assert int(info.abs().sum()) == 0
-        out.append((torch.tril(L[:, :n, :n]).clone(), y.clone(), x.clone()))
-    (Ld, yd, xd), (Ls, ys, xs) = out
-    assert torch.equal(Ld, Ls) and torch.equal(yd, ys) and torch.equal(xd, xs)
+        out.append((torch.tril(L[:, :n, :n]).clone(), y.clone(), x.clone(), x2.clone()))
+    (Ld, yd, xd, x2d), (Ls, ys, xs, x2s) = out
+    assert torch.equal(Ld, Ls) and torch.equal(yd, ys) and torch.equal(xd, xs) and torch.equal(x2d, x2s)
+    x3 = rhs.clone()          # in place
+    K.chol_solve_sparse(L, n, panels, x3, x3, pat)
+    assert torch.equal(x3, x2s)
     # and it IS the factor: residual against fp64
     Hd = Hc[:2].double().cuda()
     Hd = Hd + torch.diag_embed(0.5 * Hd.diagonal(dim1=1, dim2=2) + 1e-8)
@@ -61,9 +70,9 @@ def test_sparse_factorisation_is_bit_identical_to_dense(dtype, n, B):
 
 
 def test_lm_on_a_large_chain_graph_sparse_equals_dense():
-    """560 SE3 poses (n = 3360, 27 tiles; fp64 -- the triangular-solve kernels keep the right-hand side in LDS, which bounds
-    fp64 at n <= 3680, fp32 at n <= ~23000), shuffled labels: the sparse solver (RCM ordering + tile pattern) reproduces the
-    dense solver's LM run; the pattern prunes most of the tile products."""
+    """560 SE3 poses (n = 3360, 27 tiles; fp64 -- the DENSE solver's triangular-solve kernels keep the right-hand side in LDS,
+    which bounds fp64 at n <= 3680, fp32 at n <= ~23000), shuffled labels: the sparse solver (RCM ordering + tile pattern)
+    reproduces the dense solver's LM run; the pattern prunes most of the tile products."""
     import theseus_amd as th
     from tests.test_sparse_solver import chain_graph
     P, B, dtype = 560, 4, torch.float64
@@ -93,3 +102,36 @@ def test_lm_on_a_large_chain_graph_sparse_equals_dense():
     np.testing.assert_allclose(sparse.cpu().numpy(), dense.cpu().numpy(), rtol=0, atol=1e-9)
     np.testing.assert_allclose(sinfo.err_history.numpy(), dinfo.err_history.numpy(), rtol=1e-9)
     assert sinfo.err_history[:, -1].mean() < 0.05 * sinfo.err_history[:, 0].mean()
+
+
+def test_sparse_solver_has_no_size_limit_in_fp64():
+    """1000 SE3 poses in fp64 (n = 6000): beyond the LDS plan of the dense-frame triangular solves (n <= 3680 in fp64), which the
+    list-driven solves do not have.  LM converges; the linear solve of the last iteration satisfies H delta = g."""
+    import theseus_amd as th
+    from tests.test_sparse_solver import chain_graph
+    P, B, dtype = 1000, 2, torch.float64
+    edges = chain_graph(P, stride=7, span=5, seed=3)
+    K = th.default_kernels()
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    rnd = lambda nn, s: K.se3_exp(s * (2 * torch.rand(nn, 6, dtype=dtype, device="cuda", generator=gen) - 1))  # noqa: E731
+    gt = rnd(B * P, 1.5).view(B, P, 3, 4)
+    poses0 = K.se3_compose(gt.reshape(-1, 3, 4), rnd(B * P, 0.05)).view(B, P, 3, 4)
+    meas = [K.se3_compose(K.se3_compose(K.se3_inverse(gt[:, i].contiguous()), gt[:, j].contiguous()), rnd(B, 0.01)) for (i, j) in edges]
+    obj = th.Objective(dtype=dtype)
+    pv = [th.SE3(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    w = th.ScaleCostWeight(torch.tensor(5.0, dtype=dtype, device="cuda"))
+    for k, (i, j) in enumerate(edges):
+        obj.add(th.Between(pv[i], pv[j], th.SE3(tensor=meas[k].clone(), name=f"m_{k}"), w, name=f"b_{k}"))
+    obj.add(th.Difference(pv[edges[0][0]], th.SE3(tensor=gt[:, edges[0][0]].clone(), name="anchor"), w, name="prior"))
+    opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.HipSparseCholeskySolver, max_iterations=4, abs_err_tolerance=0.0,
+                                rel_err_tolerance=0.0)
+    sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(damping=1e-2, track_err_history=True))
+    assert info.err_history[:, -1].mean() < 0.05 * info.err_history[:, 0].mean()
+    solver, lin = opt.linear_solver, opt.linear_solver.linearization
+    lin.linearize()
+    delta = solver.solve(damping=1e-2, ellipsoidal_damping=False)
+    Hf = lin.AtA + 1e-2 * torch.eye(lin.n, dtype=dtype, device="cuda")
+    r = (Hf @ delta.unsqueeze(2)).squeeze(2) - lin.Atb.squeeze(2)
+    assert (r.abs().max() / lin.Atb.abs().max()).item() < 1e-10
+    x = solver.solve_with_factor(lin.Atb.squeeze(2).contiguous())       # both halves with the cached factor
+    np.testing.assert_allclose(x.cpu().numpy(), delta.cpu().numpy(), rtol=0, atol=1e-9 * float(delta.abs().max()))

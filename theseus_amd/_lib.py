@@ -19,7 +19,7 @@ THX_TILE = 128
 THX_ERR_CHUNKS = 16
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class LieEps(Structure):
@@ -48,7 +48,7 @@ class BAData(Structure):  # thx_ba_data
 
 class TilePattern(Structure):  # thx_tile_pattern: tile-level symbolic factorisation (device int32 tables + one host table)
     _fields_ = [("ntiles", c_int32)] + [(k, c_void_p) for k in ("col_ptr", "col_row", "tile_kptr", "tile_k", "diag_kptr", "diag_k",
-                                                               "col_count_host")]
+                                                               "col_count_host", "row_ptr", "row_tile")]
 
 
 class SE2Eps(Structure):  # thx_se2_eps (theseus/global_params.py:46-59)
@@ -131,6 +131,8 @@ _SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     "thx_chol_factor_sparse": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_int64, POINTER(TilePattern), c_int, c_void_p],
+    "thx_chol_solve_sparse": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                              POINTER(TilePattern), c_int, c_void_p],
     "thx_chol_solve": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                        c_void_p],
     "thx_chol_solve_backward": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,

@@ -596,7 +596,10 @@ class HipSchurSolverCore:
         else:
             self.K.chol_factor(self.S, p.nc, None, False, damping_eps, self.L, self.panels, self.info_chol, rhs=self.rhs,
                                y=self._y)
-        self.K.chol_solve_backward(self.L, p.nc, self.panels, self._y, self._dc)
+        if self.sparse:
+            self.K.chol_solve_sparse(self.L, p.nc, self.panels, self._y, self._dc, self.pattern, backward_only=True)
+        else:
+            self.K.chol_solve_backward(self.L, p.nc, self.panels, self._y, self._dc)
         self.delta[:, :p.nc].copy_(self._dc)                                          # delta = [delta_c | delta_p]
         self.K.ba_backsub(p.dstruct, lin.W, self.Hinv, self.tvec, self.delta)
         if check_info:
@@ -618,7 +621,10 @@ class HipSchurSolverCore:
         scratch_info = torch.zeros_like(self.info_pts)
         self.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, gd, lam, ell, eps, self.S, rc, self.Hinv, tv, scratch_info)
         dc = torch.empty_like(rc)
-        self.K.chol_solve(self.L, p.nc, self.panels, rc, dc)
+        if self.sparse:
+            self.K.chol_solve_sparse(self.L, p.nc, self.panels, rc, dc, self.pattern)
+        else:
+            self.K.chol_solve(self.L, p.nc, self.panels, rc, dc)
         out = torch.empty(rhs.shape[0], lin.n, dtype=self.S.dtype, device=rhs.device)
         out[:, :p.nc].copy_(dc)
         self.K.ba_backsub(p.dstruct, lin.W, self.Hinv, tv, out)

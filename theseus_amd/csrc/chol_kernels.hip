@@ -1543,31 +1543,54 @@ static size_t solve_smem(int npad) {
   return (size_t)128 * CT<T>::LDM * sizeof(T) + (size_t)(npad + 128 + 32) * sizeof(T);
 }
 
-// L y = rhs (stand-alone; the LM iteration gets y from the factorisation)
-template <typename T>
+// Row-wise tile pattern of L for the list-driven solves (thx_chol_solve_sparse): for block row i the column tiles j < i with
+// L_ij structurally non-zero.  Null pointers = dense.
+struct RowPat {
+  const int32_t* __restrict__ row_ptr;   // [ntiles + 1]
+  const int32_t* __restrict__ row_tile;  // [row_ptr[ntiles]]
+};
+
+// L y = rhs (stand-alone; the LM iteration gets y from the factorisation).
+// LIST = false: the whole solution vector lives in LDS (n <= ~23 k fp32 / 3.4 k fp64) and every tile of a block row is streamed.
+// LIST = true : the tiles of the row's list only, and the vector stays in global memory (L2) -- no limit on n.
+template <typename T, bool LIST>
 __global__ void __launch_bounds__(256)
 chol_fwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* __restrict__ rhs, T* __restrict__ y,
-                int n, int64_t ld, int64_t ldv, int ntiles) {
+                int n, int64_t ld, int64_t ldv, int ntiles, RowPat rp) {
   using C = CT<T>;
   using V = typename C::V;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
-  const int npad = ntiles * TILE;
+  const int npad = LIST ? 0 : ntiles * TILE;
   T* yv = tile + 128 * C::LDM;  // [npad]
   T* tv = yv + npad;            // [128]
   T* ubuf = tv + 128;           // [32]
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const T* Lb = L + (int64_t)b * ld * ld;
-  for (int k = tid; k < npad; k += 256) yv[k] = k < n ? rhs[(int64_t)b * ldv + k] : T(0);
-  __syncthreads();
+  const T* rb = rhs + (int64_t)b * ldv;
+  T* yb = y + (int64_t)b * ldv;
+  if constexpr (!LIST) {
+    for (int k = tid; k < npad; k += 256) yv[k] = k < n ? rb[k] : T(0);
+    __syncthreads();
+  }
+  constexpr int QPT = TILE / C::VEC;   // VEC-wide column groups per tile
   for (int jb = 0; jb < ntiles; ++jb) {
     const int row0 = jb * TILE, valid = min(TILE, n - row0);
     panel_g2l<T>(panel + ((int64_t)b * ntiles + jb) * TILE * TILE, tile, tid);
     // t[r] = sum_{k < row0} L[row0 + r][k] y[k]: wave w takes rows r = w (mod 4), four rows in flight
+    const int l0 = LIST ? rp.row_ptr[jb] : 0;
+    const int items = LIST ? (rp.row_ptr[jb + 1] - l0) * QPT : row0 / C::VEC;
     for (int rr = wave; rr < TILE; rr += 16) {
       T s[4] = {T(0), T(0), T(0), T(0)};
-      for (int k = lane * C::VEC; k < row0; k += 64 * C::VEC) {
-        const V yk = *reinterpret_cast<const V*>(yv + k);
+      for (int it = lane; it < items; it += 64) {
+        const int k = LIST ? rp.row_tile[l0 + it / QPT] * TILE + (it % QPT) * C::VEC : it * C::VEC;
+        V yk;
+        if constexpr (LIST) {   // (scalar loads: a row of the vector need not be 16-byte aligned)
+          if constexpr (sizeof(T) == 4) yk = V{yb[k], yb[k + 1], yb[k + 2], yb[k + 3]};
+          else yk = V{yb[k], yb[k + 1]};
+        } else {
+          yk = *reinterpret_cast<const V*>(yv + k);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int r = rr + 4 * u;
@@ -1585,44 +1608,70 @@ chol_fwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* _
       }
     }
     __syncthreads();
-    if (tid < TILE) tv[tid] = yv[row0 + tid] - tv[tid];
+    if (tid < TILE) {
+      if constexpr (LIST) tv[tid] = (tid < valid ? rb[row0 + tid] : T(0)) - tv[tid];
+      else tv[tid] = yv[row0 + tid] - tv[tid];
+    }
     __syncthreads();
     if (wave == 0) panel_forward<T>(tile, tv, ubuf, lane);
     __syncthreads();
-    if (tid < TILE) yv[row0 + tid] = tv[tid];
-    __syncthreads();
+    if (tid < TILE) {
+      if constexpr (LIST) {
+        if (tid < valid) yb[row0 + tid] = tv[tid];
+      } else {
+        yv[row0 + tid] = tv[tid];
+      }
+    }
+    __syncthreads();   // (LIST: also makes the block of y visible to the whole workgroup before the next row reads it)
   }
-  for (int k = tid; k < n; k += 256) y[(int64_t)b * ldv + k] = yv[k];
+  if constexpr (!LIST)
+    for (int k = tid; k < n; k += 256) yb[k] = yv[k];
 }
 
-// L^T x = y : right-looking from the last block row; every block row of L is streamed once
-template <typename T>
+// L^T x = y : right-looking from the last block row; every (LIST: every structurally non-zero) tile of L is streamed once
+template <typename T, bool LIST>
 __global__ void __launch_bounds__(256)
 chol_bwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* __restrict__ yin, T* __restrict__ x,
-                int n, int64_t ld, int64_t ldv, int ntiles) {
+                int n, int64_t ld, int64_t ldv, int ntiles, RowPat rp) {
   using C = CT<T>;
   using V = typename C::V;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);
-  const int npad = ntiles * TILE;
+  const int npad = LIST ? 0 : ntiles * TILE;
   T* z = tile + 128 * C::LDM;  // [npad]
   T* xb = z + npad;            // [128] current block
   T* ubuf = xb + 128;          // [32]
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const T* Lb = L + (int64_t)b * ld * ld;
-  for (int k = tid; k < npad; k += 256) z[k] = k < n ? yin[(int64_t)b * ldv + k] : T(0);
+  T* zg = x + (int64_t)b * ldv;   // LIST: the working vector IS the output (global, L2 resident)
+  if constexpr (LIST) {
+    if (yin != x)
+      for (int k = tid; k < n; k += 256) zg[k] = yin[(int64_t)b * ldv + k];
+  } else {
+    for (int k = tid; k < npad; k += 256) z[k] = k < n ? yin[(int64_t)b * ldv + k] : T(0);
+  }
   __syncthreads();
+  constexpr int QPT = TILE / C::VEC;
   for (int jb = ntiles - 1; jb >= 0; --jb) {
     const int row0 = jb * TILE, valid = min(TILE, n - row0);
     panel_g2l<T>(panel + ((int64_t)b * ntiles + jb) * TILE * TILE, tile, tid);
-    if (tid < TILE) xb[tid] = z[row0 + tid];
+    if (tid < TILE) xb[tid] = LIST ? (tid < valid ? zg[row0 + tid] : T(0)) : z[row0 + tid];
     __syncthreads();
     if (wave == 0) panel_backward<T>(tile, xb, ubuf, lane);
     __syncthreads();
-    if (tid < TILE) z[row0 + tid] = xb[tid];
+    if (tid < TILE) {
+      if constexpr (LIST) {
+        if (tid < valid) zg[row0 + tid] = xb[tid];
+      } else {
+        z[row0 + tid] = xb[tid];
+      }
+    }
     // z[0:row0] -= L[row0 : row0 + valid, 0:row0]^T x_block : a thread owns VEC consecutive columns,
     // rows unrolled by 8 (independent 16-byte loads in flight), x broadcast from LDS
-    for (int k = tid * C::VEC; k < row0; k += 256 * C::VEC) {
+    const int l0 = LIST ? rp.row_ptr[jb] : 0;
+    const int items = LIST ? (rp.row_ptr[jb + 1] - l0) * QPT : row0 / C::VEC;
+    for (int it = tid; it < items; it += 256) {
+      const int k = LIST ? rp.row_tile[l0 + it / QPT] * TILE + (it % QPT) * C::VEC : it * C::VEC;
       T s[4] = {T(0), T(0), T(0), T(0)};
       const T* Lk = Lb + (int64_t)row0 * ld + k;
       int rr = 0;
@@ -1649,12 +1698,18 @@ chol_bwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* _
           s[0] += lv.x * xv; s[1] += lv.y * xv;
         }
       }
+      if constexpr (LIST) {   // (scalar accesses: a row of the vector need not be 16-byte aligned, ldv = n = 6 P)
 #pragma unroll
-      for (int u = 0; u < C::VEC; ++u) z[k + u] -= s[u];
+        for (int u = 0; u < C::VEC; ++u) zg[k + u] -= s[u];
+      } else {
+#pragma unroll
+        for (int u = 0; u < C::VEC; ++u) z[k + u] -= s[u];
+      }
     }
     __syncthreads();
   }
-  for (int k = tid; k < n; k += 256) x[(int64_t)b * ldv + k] = z[k];
+  if constexpr (!LIST)
+    for (int k = tid; k < n; k += 256) x[(int64_t)b * ldv + k] = z[k];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1806,30 +1861,45 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
 
 template <typename T>
 static int solve_impl(const void* L, int64_t ld, int n, int B, const void* panel, const void* rhs, void* x,
-                      int64_t ldv, bool forward, bool backward, hipStream_t st) {
+                      int64_t ldv, bool forward, bool backward, hipStream_t st, const thx_tile_pattern* tp = nullptr) {
   const int ntiles = (n + TILE - 1) / TILE;
-  const size_t sm = solve_smem<T>(ntiles * TILE);
-  if (sm > LDS_LIMIT) return fail("thx_chol_solve: n too large for the LDS plan");
+  const bool list = tp != nullptr;
+  const size_t sm = solve_smem<T>(list ? 0 : ntiles * TILE);
+  if (sm > LDS_LIMIT) return fail("thx_chol_solve: n too large for the LDS plan (thx_chol_solve_sparse has no limit)");
   {
     std::lock_guard<std::mutex> guard(g_launch_mutex);
     size_t& attr = launch_state().attr_solve[sizeof(T) == 8];
     if (sm > attr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fwd_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)sm);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(chol_bwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      hipFuncSetAttribute(reinterpret_cast<const void*>(chol_bwd_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)sm);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(chol_fwd_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)sm);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(chol_bwd_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)sm);
       attr = sm;
     }
   }
+  const RowPat rp{list ? tp->row_ptr : nullptr, list ? tp->row_tile : nullptr};
   const T* src = (const T*)rhs;
   if (forward) {
-    hipLaunchKernelGGL(chol_fwd_kernel<T>, dim3(B), dim3(256), sm, st, (const T*)L, (const T*)panel, src, (T*)x, n, ld,
-                       ldv, ntiles);
+    if (list)
+      hipLaunchKernelGGL((chol_fwd_kernel<T, true>), dim3(B), dim3(256), sm, st, (const T*)L, (const T*)panel, src, (T*)x, n,
+                         ld, ldv, ntiles, rp);
+    else
+      hipLaunchKernelGGL((chol_fwd_kernel<T, false>), dim3(B), dim3(256), sm, st, (const T*)L, (const T*)panel, src, (T*)x, n,
+                         ld, ldv, ntiles, rp);
     src = (const T*)x;  // the backward pass then runs in place
   }
-  if (backward)
-    hipLaunchKernelGGL(chol_bwd_kernel<T>, dim3(B), dim3(256), sm, st, (const T*)L, (const T*)panel, src, (T*)x, n, ld,
-                       ldv, ntiles);
+  if (backward) {
+    if (list)
+      hipLaunchKernelGGL((chol_bwd_kernel<T, true>), dim3(B), dim3(256), sm, st, (const T*)L, (const T*)panel, src, (T*)x, n,
+                         ld, ldv, ntiles, rp);
+    else
+      hipLaunchKernelGGL((chol_bwd_kernel<T, false>), dim3(B), dim3(256), sm, st, (const T*)L, (const T*)panel, src, (T*)x, n,
+                         ld, ldv, ntiles, rp);
+  }
   return check_launch("thx_chol_solve");
 }
 
@@ -1889,12 +1959,19 @@ int thx_chol_factor_sparse(const void* H, int64_t ld, int32_t n, int32_t B, cons
 }
 
 static int solve_dispatch(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs, void* x,
-                          int64_t ldv, bool fwd, bool bwd, int dtype, void* stream) {
+                          int64_t ldv, bool fwd, bool bwd, int dtype, void* stream, const thx_tile_pattern* tp = nullptr) {
   if (!L || !Winv || !rhs || !x) return fail("thx_chol_solve: null pointer");
   if (n <= 0 || B <= 0 || ld < n || ldv < n) return fail("thx_chol_solve: bad sizes");
-  THX_DISPATCH(dtype, return solve_impl<float>(L, ld, n, B, Winv, rhs, x, ldv, fwd, bwd, as_stream(stream)),
-               return solve_impl<double>(L, ld, n, B, Winv, rhs, x, ldv, fwd, bwd, as_stream(stream)));
+  THX_DISPATCH(dtype, return solve_impl<float>(L, ld, n, B, Winv, rhs, x, ldv, fwd, bwd, as_stream(stream), tp),
+               return solve_impl<double>(L, ld, n, B, Winv, rhs, x, ldv, fwd, bwd, as_stream(stream), tp));
   return 0;
+}
+
+int thx_chol_solve_sparse(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs, void* x,
+                          int64_t ldv, int backward_only, const thx_tile_pattern* pattern, int dtype, void* stream) {
+  if (!pattern || !pattern->row_ptr || !pattern->row_tile) return fail("thx_chol_solve_sparse: incomplete tile pattern");
+  if (pattern->ntiles != (n + TILE - 1) / TILE) return fail("thx_chol_solve_sparse: the pattern is not this matrix's");
+  return solve_dispatch(L, ld, n, B, Winv, rhs, x, ldv, !backward_only, true, dtype, stream, pattern);
 }
 
 int thx_chol_solve(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs, void* x,

@@ -530,6 +530,14 @@ class HipKernels:
                                            rhs.stride(0), _lib.dtype_code(L.dtype), _lib.stream_ptr(L.device)),
                    "thx_chol_solve")
 
+    def chol_solve_sparse(self, L, n, panels, rhs, x, pattern, backward_only=False):
+        """thx_chol_solve_sparse: the triangular solves over the structurally non-zero tiles of L only (``pattern``: a
+        theseus_amd.sparse.TilePattern); ``backward_only``: x = L^-T rhs."""
+        B, ld = L.shape[0], L.shape[-1]
+        _lib.check(self.lib.thx_chol_solve_sparse(_lib.ptr(L), ld, n, B, _lib.ptr(panels), _lib.ptr(rhs), _lib.ptr(x),
+                                                  rhs.stride(0), int(bool(backward_only)), pattern.c_struct(L.device),
+                                                  _lib.dtype_code(L.dtype), _lib.stream_ptr(L.device)), "thx_chol_solve_sparse")
+
     def chol_solve_backward(self, L, n, panels, y, x):
         B, ld = L.shape[0], L.shape[-1]
         _lib.check(self.lib.thx_chol_solve_backward(_lib.ptr(L), ld, n, B, _lib.ptr(panels), _lib.ptr(y), _lib.ptr(x),

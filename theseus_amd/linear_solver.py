@@ -79,8 +79,15 @@ class HipCholeskyCore:
         """(L L^T)^-1 rhs with the cached factor (forward + backward substitution kernels)."""
         rhs = rhs.contiguous()
         x = torch.empty_like(rhs)
-        self.K.chol_solve(self.L, self.linearization.n, self.panels, rhs, x)
+        self._substitute(rhs, x, backward_only=False)
         return x
+
+    def _substitute(self, rhs, x, backward_only: bool):
+        """x = L^-T rhs (``backward_only``) or (L L^T)^-1 rhs with the current factor (dense frame: every tile of L)."""
+        if backward_only:
+            self.K.chol_solve_backward(self.L, self.linearization.n, self.panels, rhs, x)
+        else:
+            self.K.chol_solve(self.L, self.linearization.n, self.panels, rhs, x)
 
     def check_info(self):
         bad = self.info.nonzero()
@@ -104,7 +111,7 @@ class HipCholeskyCore:
             raise ValueError("Damping must be a float or a 1-D tensor.")
         y = self.factorize(damping, ellipsoidal_damping, damping_eps, rhs=self.linearization.g)
         delta = torch.empty_like(y)
-        self.K.chol_solve_backward(self.L, self.linearization.n, self.panels, y, delta)
+        self._substitute(y, delta, backward_only=True)
         if getattr(self, "_check_singular", False):
             singular = self.singular_mask()
             if bool(singular.any()):   # (one host sync, as the reference's ``good_idx.all()``)

@@ -87,9 +87,13 @@ class TilePattern:
                 tile_k += klists[i]
                 tile_kptr.append(len(tile_k))
             col_ptr.append(len(col_row))
+        row_ptr, row_tile = [0], []     # the same pattern by rows (list-driven triangular solves)
+        for i in range(nt):
+            row_tile += np.nonzero(lp[i, :i])[0].tolist()
+            row_ptr.append(len(row_tile))
         i32 = lambda a: np.asarray(a if len(a) else [0], dtype=np.int32)  # noqa: E731
         self.tables = dict(col_ptr=i32(col_ptr), col_row=i32(col_row), tile_kptr=i32(tile_kptr), tile_k=i32(tile_k),
-                           diag_kptr=i32(diag_kptr), diag_k=i32(diag_k))
+                           diag_kptr=i32(diag_kptr), diag_k=i32(diag_k), row_ptr=i32(row_ptr), row_tile=i32(row_tile))
         self.col_count = np.ascontiguousarray(np.diff(np.asarray(col_ptr, dtype=np.int64)).astype(np.int32))
         self.l_tiles = int(lp.sum())
         # tile products the numeric factorisation executes (K-loop tiles + one TRSM / POTRF per tile) vs the dense count
@@ -147,6 +151,10 @@ class HipSparseCholeskyCore(HipCholeskyCore):
         self.K.chol_factor_sparse(lin.H, lin.n, lam, ellipsoidal_damping, damping_eps, self.L, self.panels, self.info,
                                   self.pattern, rhs=rhs, y=y)
         return y
+
+    def _substitute(self, rhs, x, backward_only: bool):
+        """The triangular solves over the non-zero tiles of L only (thx_chol_solve_sparse; no limit on n)."""
+        self.K.chol_solve_sparse(self.L, self.linearization.n, self.panels, rhs, x, self.pattern, backward_only=backward_only)
 
 
 class HipSparseCholeskySolver(HipSparseCholeskyCore, LinearSolver):

@@ -49,7 +49,10 @@ if solver.sparse:
     timed("chol_factor(S)", lambda: solver.K.chol_factor_sparse(solver.S, p.nc, None, False, 1e-8, solver.L, solver.panels, solver.info_chol, solver.pattern, rhs=solver.rhs, y=solver._y))
 else:
     phases["chol_factor(S)"] = dense_ms
-timed("chol_backward", lambda: solver.K.chol_solve_backward(solver.L, p.nc, solver.panels, solver._y, solver._dc))
+if solver.sparse:
+    timed("chol_backward", lambda: solver.K.chol_solve_sparse(solver.L, p.nc, solver.panels, solver._y, solver._dc, solver.pattern, backward_only=True))
+else:
+    timed("chol_backward", lambda: solver.K.chol_solve_backward(solver.L, p.nc, solver.panels, solver._y, solver._dc))
 timed("ba_backsub", lambda: solver.K.ba_backsub(p.dstruct, lin.W, solver.Hinv, solver.tvec, solver.delta))
 timed("ba_error", lambda: p.error_metric())
 spare = p.alloc_state()
