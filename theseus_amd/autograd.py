@@ -60,7 +60,7 @@ class ImplicitStep(torch.autograd.Function):
             solver.check_info()
         else:
             delta = torch.empty_like(y)
-            solver.K.chol_solve_backward(solver.L, lin.n, solver.panels, y, delta)
+            solver._substitute(y, delta, backward_only=True)
         X = packed.tensors.poses.detach()
         X_new = torch.empty_like(X)
         packed.retract(delta, step, None, X_new)  # force_update: the converged mask is ignored in this step

@@ -75,7 +75,7 @@ class _CachedFactorSolve(torch.autograd.Function):
     def forward(ctx, solver, damping, ellipsoidal, eps, g):
         y = solver.factorize(damping, ellipsoidal, eps, rhs=g.detach().contiguous())
         delta = torch.empty_like(y)
-        solver.K.chol_solve_backward(solver.L, solver.linearization.n, solver.panels, y, delta)
+        solver._substitute(y, delta, backward_only=True)   # (tile-sparse solver: the list-driven solve)
         solver.check_info()
         ctx.solver, ctx.version = solver, solver.factor_version
         return delta
