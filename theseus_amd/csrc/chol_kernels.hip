@@ -1315,6 +1315,16 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   __syncthreads();  // panel copy visible (also when the K-loop had no iterations)
   Engine<float>::Acc X;
   Engine<float>::zero(X);
+#ifdef THX_EXP_FULLINV   // timing experiment: the dataflow of a FULL 128 x 128 inverse in the panel, X_s = sum_{t <= s} W_st P_t --
+                         // the same ten block products without the dependent chain (garbage results with today's panel)
+  static_for<4>([&](auto is) __attribute__((always_inline)) {
+    constexpr int sb = decltype(is)::value;
+    static_for<sb + 1>([&](auto it) __attribute__((always_inline)) {
+      constexpr int tb = decltype(it)::value;
+      sub_mma_sw<sb, tb>(Pc, P, X, lane);
+    });
+  });
+#else
   static_for<4>([&](auto is) __attribute__((always_inline)) {
     constexpr int sb = decltype(is)::value;
     static_for<sb>([&](auto it) __attribute__((always_inline)) {
@@ -1323,6 +1333,7 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
     });
     sub_mma_sw<sb, sb>(Pc, P, X, lane);    // X_s  = W_ss P_s
   });
+#endif
 #ifdef THX_OFF_PROF
   __builtin_amdgcn_sched_barrier(0);
   st[3] = (long long)__builtin_readcyclecounter();
