@@ -85,7 +85,7 @@ def run_ba(th, g, kernels=None, device="cpu"):
     return cams, pts, used, deltas, info, opt
 
 
-def run_ba_implicit(th, g, kernels=None, device="cpu"):
+def run_ba_implicit(th, g, kernels=None, device="cpu", opt_kwargs=None):
     """The objective of oracle/gen_golden.py:gen_ba_implicit on theseus_amd's classes with the differentiable leaves of that
     fixture; LM + backward_mode="implicit"; returns the solution, the loss and the gradients as numpy arrays."""
     import ast
@@ -129,6 +129,7 @@ def run_ba_implicit(th, g, kernels=None, device="cpu"):
     okw = dict(max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0)
     if kernels is not None:
         okw["linearization_kwargs"] = dict(kernels=kernels)
+    okw.update(opt_kwargs or {})
     opt = th.LevenbergMarquardt(obj, **okw)
     sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode="implicit", **kw))
     used = sorted(set(g["obs_pt"].tolist()))

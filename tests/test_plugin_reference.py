@@ -308,6 +308,31 @@ def test_reference_loop_drives_the_bundle_adjustment_plugin(ref, name):
     np.testing.assert_allclose(info.err_history[:, :k].detach().cpu().numpy(), g["err_history"][:, :k], rtol=1e-6)
 
 
+def test_bundle_adjustment_implicit_backward_through_the_reference_loop(ref):
+    """examples/bundle_adjustment.py:184-215 learns log_loss_radius through backward_mode="implicit": the REAL TheseusLayer /
+    LevenbergMarquardt with theseus_amd.plugin.HipSchurSolver -- forward iterations under no_grad, the grad-enabled last
+    Gauss-Newton step with ``Atb`` differentiable (thx_ba_vjp) and the solve's backward on the cached Schur factor, the
+    reference's own retraction in between -- reproduces the gradients the reference recorded with its dense path, all nine
+    groups (features, calibration, radius, weights, prior targets)."""
+    th, thp = ref
+    from tests.ba_common import run_ba_implicit
+
+    class RefNames:
+        Objective, SE3, Point3, Point2, Vector, Variable, Difference = (th.Objective, th.SE3, th.Point3, th.Point2, th.Vector,
+                                                                       th.Variable, th.Difference)
+        ScaleCostWeight, RobustCostFunction, HuberLoss, WelschLoss = th.ScaleCostWeight, th.RobustCostFunction, th.HuberLoss, th.WelschLoss
+        Reprojection = th.eb.Reprojection
+        LevenbergMarquardt, TheseusLayer = th.LevenbergMarquardt, th.TheseusLayer
+    g = load_golden("ba_f64_implicit")
+    out = run_ba_implicit(RefNames, g, device=DEVICE,
+                          opt_kwargs=dict(linear_solver_cls=thp.HipSchurSolver, linearization_kwargs=_kernels(), vectorize=True))
+    np.testing.assert_allclose(out["final_cams"], g["final_cams"], rtol=0, atol=1e-8)
+    assert abs(out["loss"] - float(g["loss"])) <= 1e-8 * abs(float(g["loss"]))
+    for k in ("feat", "focal", "k1", "k2", "log_radius", "w_obs", "gt_cams", "w_strong", "w_reg"):
+        ref_g = g["grad_" + k]
+        np.testing.assert_allclose(out["grad_" + k].reshape(ref_g.shape), ref_g, rtol=5e-6, atol=5e-6 * np.abs(ref_g).max(), err_msg=k)
+
+
 # ---- the third hook set (Objective vectorization callbacks, SURVEY.md §8b) -------------------------------------------------
 def _counting(standin, names):
     calls = {n: 0 for n in names}

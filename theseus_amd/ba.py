@@ -658,10 +658,7 @@ class BAImplicitStep(torch.autograd.Function):
         new = (torch.empty_like(cams), torch.empty_like(pts))
         packed.retract(delta, step, None, new)
         ctx.opt, ctx.packed, ctx.step, ctx.factor_version = opt, packed, step, solver.factor_version
-        ctx.tensors = dataclasses.replace(packed.tensors, cams=cams, points=pts,
-                                          **{k: (None if a is None else a.detach()) for k, a in zip(
-                                              ("feat", "w_obs", "focal", "k1", "k2", "log_radius_obs", "cam_prior_target",
-                                               "w_cam_prior", "pt_prior_target", "w_pt_prior"), aux)})
+        ctx.tensors = detached_ba_tensors(packed.tensors, cams, pts, aux)
         ctx.delta = delta
         ctx.mark_non_differentiable(delta)
         return new[0], new[1], delta
@@ -681,31 +678,48 @@ class BAImplicitStep(torch.autograd.Function):
         if g_pts is not None:
             gd[:, nc:] = g_pts.permute(1, 0, 2).reshape(B, -1) * ctx.step                   # X + step * delta
         w = solver.solve_with_factor(gd)   # the backward linear solve
-        s = packed.structure
-        O, Kc, Kp = s.num_obs, s.num_cam_priors, s.num_pt_priors
-        new = lambda *sh: torch.empty(*sh, dtype=dt, device=dev)  # noqa: E731
-        g = dict(feat=new(max(O, 1), B, 2), w_obs=new(max(O, 1), B, 2), focal=new(max(O, 1), B), k1=new(max(O, 1), B),
-                 k2=new(max(O, 1), B), log_radius=new(max(O, 1), B, 1) if t.robust_obs else None,
-                 cam_prior_target=new(max(Kc, 1), B, 3, 4), w_cam_prior=new(max(Kc, 1), B, 6),
-                 pt_prior_target=new(max(Kp, 1), B, 3), w_pt_prior=new(max(Kp, 1), B, 3))
-        K.ba_vjp(packed.dstruct, t, w, g)
-        # calibration: per observation -> per camera
-        oc = torch.from_numpy(np.asarray(s.t["obs_cam"][:O], dtype=np.int64)).to(dev)
-        C = s.num_cams
-        for k in ("focal", "k1", "k2"):
-            g[k] = torch.zeros(C, B, dtype=dt, device=dev).index_add_(0, oc, g[k][:O]).unsqueeze(2)
+        return (None, None, None, None) + ba_vjp_grads(K, packed, t, w)
 
-        def fit(grad, count, like):   # (count, B, ...) -> the packed input's shape (count, 1|B, ...)
-            if grad is None or like is None:
-                return None
-            grad = grad[:count]
-            return grad.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else grad
-        counts = dict(feat=O, w_obs=O, focal=C, k1=C, k2=C, log_radius=O, cam_prior_target=Kc, w_cam_prior=Kc,
-                      pt_prior_target=Kp, w_pt_prior=Kp)
-        likes = dict(feat=t.feat, w_obs=t.w_obs, focal=t.focal, k1=t.k1, k2=t.k2, log_radius=t.log_radius_obs,
-                     cam_prior_target=t.cam_prior_target, w_cam_prior=t.w_cam_prior, pt_prior_target=t.pt_prior_target,
-                     w_pt_prior=t.w_pt_prior)
-        return (None, None, None, None) + tuple(fit(g[k], counts[k], likes[k]) for k in BAImplicitStep.NAMES)
+
+def ba_vjp_grads(K, packed, t, w):
+    """Gradients of phi = w^T g(theta) (g = A^T b of the bundle-adjustment linearization at the tensors ``t``, Hessian
+    detached) w.r.t. the packed auxiliary tensors, in ``BAImplicitStep.NAMES`` order and in the shapes they were packed in:
+    thx_ba_vjp + the per-observation -> per-camera reduction of the calibration gradients."""
+    s = packed.structure
+    B = t.cams.shape[1]
+    dt, dev = t.cams.dtype, t.cams.device
+    O, Kc, Kp = s.num_obs, s.num_cam_priors, s.num_pt_priors
+    new = lambda *sh: torch.empty(*sh, dtype=dt, device=dev)  # noqa: E731
+    g = dict(feat=new(max(O, 1), B, 2), w_obs=new(max(O, 1), B, 2), focal=new(max(O, 1), B), k1=new(max(O, 1), B),
+             k2=new(max(O, 1), B), log_radius=new(max(O, 1), B, 1) if t.robust_obs else None,
+             cam_prior_target=new(max(Kc, 1), B, 3, 4), w_cam_prior=new(max(Kc, 1), B, 6),
+             pt_prior_target=new(max(Kp, 1), B, 3), w_pt_prior=new(max(Kp, 1), B, 3))
+    K.ba_vjp(packed.dstruct, t, w.contiguous(), g)
+    # calibration: per observation -> per camera
+    oc = torch.from_numpy(np.asarray(s.t["obs_cam"][:O], dtype=np.int64)).to(dev)
+    C = s.num_cams
+    for k in ("focal", "k1", "k2"):
+        g[k] = torch.zeros(C, B, dtype=dt, device=dev).index_add_(0, oc, g[k][:O]).unsqueeze(2)
+
+    def fit(grad, count, like):   # (count, B, ...) -> the packed input's shape (count, 1|B, ...)
+        if grad is None or like is None:
+            return None
+        grad = grad[:count]
+        return grad.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else grad
+    counts = dict(feat=O, w_obs=O, focal=C, k1=C, k2=C, log_radius=O, cam_prior_target=Kc, w_cam_prior=Kc,
+                  pt_prior_target=Kp, w_pt_prior=Kp)
+    likes = dict(feat=t.feat, w_obs=t.w_obs, focal=t.focal, k1=t.k1, k2=t.k2, log_radius=t.log_radius_obs,
+                 cam_prior_target=t.cam_prior_target, w_cam_prior=t.w_cam_prior, pt_prior_target=t.pt_prior_target,
+                 w_pt_prior=t.w_pt_prior)
+    return tuple(fit(g[k], counts[k], likes[k]) for k in BAImplicitStep.NAMES)
+
+
+def detached_ba_tensors(tensors, cams, points, aux):
+    """The packed tensors with cams / points replaced and the auxiliary tensors (BAImplicitStep.NAMES order) detached."""
+    keys = ("feat", "w_obs", "focal", "k1", "k2", "log_radius_obs", "cam_prior_target", "w_cam_prior", "pt_prior_target",
+            "w_pt_prior")
+    return dataclasses.replace(tensors, cams=cams, points=points,
+                               **{k: (None if a is None else a.detach()) for k, a in zip(keys, aux)})
 
 
 def ba_implicit_step(opt, packed, step: float, kwargs):

@@ -449,23 +449,81 @@ class HipSparseCholeskySolver(HipSparseCholeskyCore, _RefCholeskyDenseSolver):
 
 
 # ---- bundle adjustment (theseus_amd/ba.py): Schur-complement linearization / solver for the REAL theseus loop ----------
-from .ba import HipSchurLinearizationCore, HipSchurSolverCore  # noqa: E402
+from .ba import HipSchurLinearizationCore, HipSchurSolverCore, ba_vjp_grads, detached_ba_tensors  # noqa: E402
+
+
+class _FusedAtbBA(torch.autograd.Function):
+    """g = A^T b of a bundle-adjustment objective as a differentiable function of the packed auxiliary tensors (features,
+    weights, calibration, log_loss_radius, prior targets): forward is ``thx_ba_assemble`` (which also refreshes the block
+    Hessian, outside autograd), backward is ``thx_ba_vjp``."""
+
+    @staticmethod
+    def forward(ctx, lin, *aux):
+        HipSchurLinearizationCore._assemble(lin)
+        t = lin.packed.tensors
+        ctx.lin = lin
+        ctx.tensors = detached_ba_tensors(t, t.cams.detach(), t.points.detach(), aux)
+        return lin.g.clone()
+
+    @staticmethod
+    def backward(ctx, grad_g):
+        lin = ctx.lin
+        return (None,) + ba_vjp_grads(lin.K, lin.packed, ctx.tensors, grad_g.contiguous())
+
+
+class _CachedSchurSolve(torch.autograd.Function):
+    """delta = (H + damping)^-1 g by point elimination, H outside autograd: backward = one solve with the cached factor of the
+    reduced camera system (``HipSchurSolverCore.solve_with_factor``)."""
+
+    @staticmethod
+    def forward(ctx, solver, damping, ellipsoidal, eps, g):
+        delta = solver._solve(damping, ellipsoidal, eps, check_info=True).clone()
+        ctx.solver, ctx.version = solver, solver.factor_version
+        return delta
+
+    @staticmethod
+    def backward(ctx, grad_delta):
+        solver = ctx.solver
+        if solver.factor_version != ctx.version:
+            raise RuntimeError("backward of HipSchurSolver.solve(): the cached factor was overwritten by a later solve; "
+                               "call backward() before the next forward().")
+        return None, None, None, None, solver.solve_with_factor(grad_delta.contiguous())
 
 
 class HipSchurLinearization(HipSchurLinearizationCore, _RefLinearization):
     """``linearization_cls`` for bundle-adjustment objectives (SE3 cameras + Point3 points, th.eb.Reprojection optionally
     robust, th.Difference priors).  Sets ``ordering`` = cameras, then points -- the reference retracts and reads ``delta``
-    through ``linearization.ordering`` (nonlinear_least_squares.py:97, objective.py:873-914)."""
+    through ``linearization.ordering`` (nonlinear_least_squares.py:97, objective.py:873-914).
+
+    Under grad (the last step of ``backward_mode="implicit"``, examples/bundle_adjustment.py:184-215 learns
+    ``log_loss_radius`` this way): ``Atb`` carries the graph (``_FusedAtbBA``), the block Hessian is built outside autograd --
+    which is what the reference asks for in that step (``_detach_hessian=True``, dense_linearization.py:61)."""
 
     def __init__(self, objective: th.Objective, ordering=None, kernels=None, **kwargs):
         packed, ordering = self._schur_setup(objective, ordering, kernels, th.optimizer.VariableOrdering)
         _RefLinearization.__init__(self, objective, ordering)
         self._schur_init(packed)
+        self._g_graph: Optional[torch.Tensor] = None
 
     def _linearize_hessian_impl(self, _detach_hessian: bool = False):
-        if torch.is_grad_enabled() and any(v.tensor.requires_grad for v in self.packed._tracked()):
-            raise NotImplementedError("HIP bundle adjustment: differentiating through the linearization is not fused yet")
-        self._assemble()
+        packed = self.packed
+        graph = torch.is_grad_enabled() and any(v.tensor.requires_grad for v in packed._tracked())
+        if graph and not _detach_hessian:
+            raise NotImplementedError(
+                "theseus_amd builds the Hessian outside autograd: differentiating through it (backward_mode='unroll' "
+                "with gradients) is not supported.  Use backward_mode='implicit', or run under torch.no_grad().")
+        if graph:
+            packed.sync(force=True)   # re-pack WITH the autograd history of the auxiliary variables
+            t = packed.tensors
+            self._g_graph = _FusedAtbBA.apply(self, t.feat, t.w_obs, t.focal, t.k1, t.k2, t.log_radius_obs,
+                                              t.cam_prior_target, t.w_cam_prior, t.pt_prior_target, t.w_pt_prior)
+        else:
+            self._g_graph = None
+            self._assemble()
+
+    def _atb_impl(self) -> torch.Tensor:
+        g = self._g_graph if self._g_graph is not None else self.g
+        return g.unsqueeze(2)
 
 
 class HipSchurSolver(HipSchurSolverCore, _RefCholeskyDenseSolver):
@@ -484,6 +542,11 @@ class HipSchurSolver(HipSchurSolverCore, _RefCholeskyDenseSolver):
         self._schur_solver_init(sparse_reduced_system)
 
     def solve(self, damping=None, ellipsoidal_damping: bool = True, damping_eps: float = 1e-8, **kwargs) -> torch.Tensor:
+        g = self.linearization._g_graph
+        if g is not None and torch.is_grad_enabled():
+            if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
+                raise ValueError("Damping must be a float or a 1-D tensor.")
+            return _CachedSchurSolve.apply(self, damping, ellipsoidal_damping, damping_eps, g)
         return self._solve(damping, ellipsoidal_damping, damping_eps, check_info=True).clone()
 
     def _solve_sytem(self, Atb, AtA):  # abstract in DenseSolver
