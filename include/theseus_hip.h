@@ -147,6 +147,15 @@ int thx_so3_retract(const void* poses, const void* delta, int64_t ldd, double st
                     void* out, int32_t P, int32_t B, int dtype, const thx_lie_eps* eps, void* stream);
 int thx_so3_op(int op, const void* a, const void* b, void* out, void* jac, int64_t N, int dtype,
                const thx_lie_eps* eps, void* stream);
+/* implicit backward on SO3 rotation graphs (thx_se3_retract_vjp / thx_pg_vjp below, with 9-element records, 3-vectors), with
+ * torchlie's SO3 backward semantics: Exp.backward (so3_impl.py:336-353), Log's passthrough backward (:489-496: the tangent
+ * projection R lift(Jlog^T g / 2)), plain matrix derivatives for Inverse / Compose (:576-577, :702-707), plain autograd through
+ * the Jlog closed forms. */
+int thx_so3_retract_vjp(const void* poses, const void* delta, int64_t ldd, double step, const void* grad_out,
+                        void* grad_delta, int64_t ldg, int32_t P, int32_t B, int dtype, const thx_lie_eps* eps, void* stream);
+int thx_pgso3_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, int64_t ldw, void* grad_meas,
+                  void* grad_w_between, void* grad_prior_target, void* grad_w_prior, void* grad_log_radius_between,
+                  void* grad_log_radius_prior, int dtype, const thx_lie_eps* eps, void* stream);
 
 /* ---- Linearization.linearize(): replaces DenseLinearization._linearize_jacobian_impl +
  *      _linearize_hessian_impl (dense_linearization.py:29-62) fused with Between / Local

@@ -523,6 +523,58 @@ def gen_se2_implicit(th):
     print("pg2_f64_implicit loss", loss.item(), "|grad_meas|", meas.grad.abs().max().item())
 
 
+def gen_so3_implicit(th):
+    """SO3 twin of gen_implicit: gradients the reference's TheseusLayer(backward_mode="implicit") produces on a rotation graph
+    (theseus/geometry/so3.py over torchlie's SO3 ops: custom backward for Exp / Log / Compose / Inverse, so3_impl.py:336-353,
+    489-514,576-577,702-707; plain autograd through the Jlog closed forms)."""
+    dtype, G = torch.float64, th.SO3
+    P, E, B, iters = 7, 12, 4, 6
+    gen = torch.Generator().manual_seed(57)
+    rng = np.random.default_rng(57)
+    edges = [(i, i + 1) for i in range(P - 1)]
+    while len(edges) < E:
+        i, j = sorted(rng.choice(P, 2, replace=False).tolist())
+        edges.append((j, i) if rng.random() < 0.3 else (i, j))
+    edges = torch.tensor(edges, dtype=torch.long)
+
+    def rnd(n, rs):
+        return G.exp_map(rs * (2 * torch.rand(n, 3, dtype=dtype, generator=gen) - 1))
+    gt = rnd(B * P, 2.0).tensor.view(B, P, 3, 3)
+    gi, gj = G(tensor=gt[:, edges[:, 0]].reshape(-1, 3, 3)), G(tensor=gt[:, edges[:, 1]].reshape(-1, 3, 3))
+    meas0 = gi.inverse().compose(gj).compose(rnd(B * E, 0.03)).tensor.view(B, E, 3, 3)
+    poses0 = G(tensor=gt.reshape(-1, 3, 3)).compose(rnd(B * P, 0.15)).tensor.view(B, P, 3, 3)
+    prior_idx = torch.tensor([0, P // 2], dtype=torch.long)
+    tgt0 = G(tensor=gt[:, prior_idx].reshape(-1, 3, 3)).compose(rnd(B * 2, 0.01)).tensor.view(B, 2, 3, 3)
+    meas = meas0.clone().requires_grad_(True)
+    wb = ((0.5 + torch.rand(B, E, 3, dtype=dtype, generator=gen)) * 10).requires_grad_(True)
+    tgt = tgt0.clone().requires_grad_(True)
+    wp = torch.tensor([[[1e-1], [2.0]]], dtype=dtype).requires_grad_(True)
+    obj = th.Objective(dtype=dtype)
+    pv = [G(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    for k in range(E):
+        i, j = edges[k].tolist()
+        obj.add(th.Between(pv[i], pv[j], G(tensor=meas[:, k], name=f"meas_{k}"),
+                           th.DiagonalCostWeight(th.Variable(wb[:, k], name=f"w_{k}")), name=f"between_{k}"))
+    for k in range(2):
+        obj.add(th.Difference(pv[int(prior_idx[k])], G(tensor=tgt[:, k], name=f"tgt_{k}"),
+                              th.ScaleCostWeight(th.Variable(wp[:, k], name=f"pw_{k}")), name=f"prior_{k}"))
+    opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, max_iterations=iters,
+                                step_size=1.0, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    sol, info = th.TheseusLayer(opt).forward(optimizer_kwargs=dict(backward_mode="implicit", damping=1e-3))
+    coef = torch.randn(B, P, 3, 3, dtype=dtype, generator=torch.Generator().manual_seed(5))
+    final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
+    loss = (coef * final).sum()
+    loss.backward()
+    np.savez_compressed(
+        os.path.join(OUT, "pg3_f64_implicit.npz"), group=np.array("SO3"), P=P, edges=edges.numpy(), meas=meas0.numpy(),
+        w_between=wb.detach().numpy(), prior_idx=prior_idx.numpy(), prior_target=tgt0.numpy(),
+        w_prior=wp.detach().expand(1, 2, 3).numpy().copy(), poses0=poses0.numpy(), final=final.detach().numpy(), coef=coef.numpy(),
+        loss=loss.item(), grad_meas=meas.grad.numpy(), grad_w_between=wb.grad.numpy(), grad_prior_target=tgt.grad.numpy(),
+        grad_w_prior=wp.grad.numpy(),
+        opt_kwargs=np.array(repr(dict(max_iterations=iters, step_size=1.0, damping=1e-3, gauss_newton=False))))
+    print("pg3_f64_implicit loss", loss.item(), "|grad_meas|", meas.grad.abs().max().item())
+
+
 # the reference's own known-answer test for this path: tests/theseus_tests/test_pgo_benchmark.py:34-39
 PGO_KAT_LOSSES = [-0.29886279606812166, -0.3054215856589109, -0.27485602196709225, -0.3005231105990632]
 
@@ -851,6 +903,8 @@ def main():
         gen_so3(th, lieF)
     if not only or "se2_implicit" in only:
         gen_se2_implicit(th)
+    if not only or "so3_implicit" in only:
+        gen_so3_implicit(th)
     if not only or "pgo_kat" in only:
         gen_pgo_kat(th)
     if not only or "ba" in only:   # (the small cases; the multi-tile and full-size ones are asked for by name)

@@ -30,6 +30,30 @@ def so3_log_jlog(R):
     return w, J
 
 
+class _LogPassthrough(torch.autograd.Function):
+    """What autograd sees when the reference asks ``SO3.log(R, jacobians=[...])`` (torchlie/functional/lie_group.py:60-84,
+    148-155): the VALUE is the formula's, the BACKWARD is ``_log_backward`` (so3_impl.py:489-496):
+    grad_R = R @ lift(J^T g / 2) -- the tangent projection, not the derivative of the closed form; the Jacobian itself
+    keeps its plain autograd graph."""
+
+    @staticmethod
+    def forward(ctx, R, w, J):
+        ctx.save_for_backward(R, J)
+        return w.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        R, J = ctx.saved_tensors
+        h = 0.5 * (J.transpose(-1, -2) @ g.unsqueeze(-1)).squeeze(-1)
+        return R @ lie._hat(h), None, None
+
+
+def so3_log_jlog_autograd(R):
+    """so3_log_jlog with the reference's autograd semantics (see _LogPassthrough); same values."""
+    w, J = so3_log_jlog(R)
+    return _LogPassthrough.apply(R, w, J), J
+
+
 def so3_adjoint(R):
     return R.clone()
 

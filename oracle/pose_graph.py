@@ -41,7 +41,7 @@ class _SO3:
     name, dof = "SO3", 3
     compose, inverse, adjoint, retract = (staticmethod(lie_so3.so3_compose), staticmethod(lie_so3.so3_inverse),
                                           staticmethod(lie_so3.so3_adjoint), staticmethod(lie_so3.so3_retract))
-    log_jlog = staticmethod(lie_so3.so3_log_jlog)
+    log_jlog = staticmethod(lie_so3.so3_log_jlog_autograd)
 
 
 GROUPS = {"SE3": _SE3, "SE2": _SE2, "SO3": _SO3}

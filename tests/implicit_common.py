@@ -16,7 +16,7 @@ def run_implicit(th, g, device, kernels=None):
                   w_prior=t(g["w_prior"])[:, :, :1].clone().requires_grad_(True))
     obj = th.Objective(dtype=leaves["meas"].dtype)
     poses0 = t(g["poses0"])
-    G = th.SE2 if ("group" in g and str(g["group"]) == "SE2") else th.SE3
+    G = {"SE2": th.SE2, "SO3": th.SO3}.get(str(g["group"]) if "group" in g else "SE3", th.SE3)
     poses = [G(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
     for k in range(g["edges"].shape[0]):
         i, j = g["edges"][k].tolist()

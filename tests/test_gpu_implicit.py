@@ -13,7 +13,7 @@ from tests.implicit_common import check_against_reference, run_implicit
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["pg_f64_implicit", "pg_f64_implicit_b", "pg2_f64_implicit"])
+@pytest.mark.parametrize("name", ["pg_f64_implicit", "pg_f64_implicit_b", "pg2_f64_implicit", "pg3_f64_implicit"])
 def test_implicit_gradients_match_reference(name):
     import theseus_amd as th
     g = load_golden(name)

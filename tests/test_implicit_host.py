@@ -9,7 +9,7 @@ from tests.helpers import golden_problem  # noqa: F401
 from tests.implicit_common import check_against_reference, run_implicit
 
 
-@pytest.mark.parametrize("name", ["pg_f64_implicit", "pg_f64_implicit_b", "pg2_f64_implicit"])
+@pytest.mark.parametrize("name", ["pg_f64_implicit", "pg_f64_implicit_b", "pg2_f64_implicit", "pg3_f64_implicit"])
 def test_implicit_gradients_match_reference(name):
     import theseus_amd as th
     from tests.oracle_kernels import OracleKernels

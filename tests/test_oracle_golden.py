@@ -68,7 +68,7 @@ def test_lm_trajectory_matches_reference(name, tol):
         assert (tr != tr[0]).any()   # the fixture exercises shrinking / expanding
 
 
-@pytest.mark.parametrize("name", ["pg_f64_implicit", "pg_f64_implicit_b", "pg2_f64_implicit"])
+@pytest.mark.parametrize("name", ["pg_f64_implicit", "pg_f64_implicit_b", "pg2_f64_implicit", "pg3_f64_implicit"])
 def test_implicit_backward_gradients_match_reference(name):
     """Pins the oracle's implicit step (autograd through the restated formulas) to the gradients the REAL
     reference produced through TheseusLayer(backward_mode="implicit") (torchlie's custom backward passes)."""

@@ -19,7 +19,7 @@ THX_TILE = 128
 THX_ERR_CHUNKS = 16
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class LieEps(Structure):
@@ -125,6 +125,10 @@ _SIGNATURES = {
                             POINTER(SE2Eps), c_void_p],
     "thx_pg2_vjp": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                     c_void_p, c_void_p, c_int, POINTER(SE2Eps), c_void_p],
+    "thx_so3_retract_vjp": [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int,
+                            POINTER(LieEps), c_void_p],
+    "thx_pgso3_vjp": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                      c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
     "thx_chol_factor": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,
                         c_void_p, c_int, c_void_p],
     "thx_chol_factor_forward": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,

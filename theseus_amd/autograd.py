@@ -27,7 +27,7 @@ def pg_vjp_grads(K, packed, t, w):
     B = t.poses.shape[1]
     E, Kp = packed.structure.num_edges, packed.structure.num_priors
     new = lambda *s: torch.empty(*s, dtype=w.dtype, device=w.device)  # noqa: E731
-    gs, dof = t.poses.shape[2:], (3 if t.se2 else 6)   # group record shape (3,4) | (4,)
+    gs, dof = t.poses.shape[2:], packed.dof   # group record shape (3,4) | (4,) | (3,3), tangent size 6 | 3 | 3
     g_meas, g_wb = new(max(E, 1), B, *gs), new(max(E, 1), B, dof)
     g_tgt, g_wp = new(max(Kp, 1), B, *gs), new(max(Kp, 1), B, dof)
     g_lrb = new(max(E, 1), B, 1) if t.robust_between else None

@@ -14,6 +14,28 @@ struct SO3m {
   T R[9];
 };
 
+// log (+ Jlog = b w w^T + a I + hat(w)/2, sine / cosine taken from the matrix, d_near_zero switch): so3_impl.py:390-479.
+// On any scalar type: the implicit backward evaluates it on dual numbers (vjpso3_kernels.hip).
+template <typename S>
+__device__ __forceinline__ void so3_log_jlog(const S* R, const thx::Eps<S>& eps, S* w, S* J, bool want_jac) {
+  S theta, sine, cosine;
+  so3_log(R, eps, w, theta, sine, cosine);
+  if (!want_jac) return;
+  const bool dnz = theta < eps.dnz;
+  const S theta2 = theta * theta, st = sine * theta, tcm2 = S(2.0) * cosine - S(2.0);
+  const S tcm2_d = dnz ? S(1.0) : tcm2, theta2_d = dnz ? S(1.0) : theta2;
+  const S a = dnz ? S(1.0) - theta2 / S(12.0) : -st / tcm2_d;
+  const S b = dnz ? S(1.0 / 12.0) + theta2 / S(720.0) : (st + tcm2) / (theta2_d * tcm2_d);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) J[3 * i + j] = (b * w[i]) * w[j];
+  add_hat(J, w, S(0.5));
+  J[0] += a;
+  J[4] += a;
+  J[8] += a;
+}
+
 struct GroupSO3 {
   static constexpr int REC = 9;
   using X = SO3m<double>;
@@ -54,29 +76,16 @@ struct GroupSO3 {
     J[8] += c.A;
     add_hat(J, w, -c.B);
   }
-  // log (+ Jlog = b w w^T + a I + hat(w)/2, sine / cosine taken from the matrix, d_near_zero switch): so3_impl.py:390-479
-  static __device__ __forceinline__ void log_jlog(const X& x, const Eps& eps, double* w, double* J, bool want_jac) {
-    double theta, sine, cosine;
-    so3_log(x.R, eps, w, theta, sine, cosine);
-    if (!want_jac) return;
-    const bool dnz = theta < eps.dnz;
-    const double theta2 = theta * theta, st = sine * theta, tcm2 = 2.0 * cosine - 2.0;
-    const double tcm2_d = dnz ? 1.0 : tcm2, theta2_d = dnz ? 1.0 : theta2;
-    const double a = dnz ? 1.0 - theta2 / 12.0 : -st / tcm2_d;
-    const double b = dnz ? 1.0 / 12.0 + theta2 / 720.0 : (st + tcm2) / (theta2_d * tcm2_d);
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) J[3 * i + j] = (b * w[i]) * w[j];
-    add_hat(J, w, 0.5);
-    J[0] += a;
-    J[4] += a;
-    J[8] += a;
-  }
+  // log (+ Jlog): so3_log_jlog below on doubles
+  static __device__ __forceinline__ void log_jlog(const X& x, const Eps& eps, double* w, double* J, bool want_jac);
   static __device__ __forceinline__ void adjoint(const X& x, double* A) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) A[k] = x.R[k];
   }
 };
+
+__device__ __forceinline__ void GroupSO3::log_jlog(const X& x, const Eps& eps, double* w, double* J, bool want_jac) {
+  so3_log_jlog<double>(x.R, eps, w, J, want_jac);
+}
 
 }  // namespace thx

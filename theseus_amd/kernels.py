@@ -467,7 +467,13 @@ class HipKernels:
     def retract_vjp(self, poses, delta, step, grad_out, grad_delta):
         """grad_X_new -> grad_delta of X exp(step * delta); the group is read off the record shape."""
         if group_of(poses) == "SO3":
-            raise NotImplementedError("HIP back end: the implicit backward pass is fused for SE3 / SE2 pose graphs, not SO3.")
+            P, B = poses.shape[:2]
+            dt = poses.dtype
+            _lib.check(self.lib.thx_so3_retract_vjp(_lib.ptr(poses), _lib.ptr(delta), delta.stride(0), float(step),
+                                                    _lib.ptr(grad_out), _lib.ptr(grad_delta), grad_delta.stride(0), P, B,
+                                                    _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(poses.device)),
+                       "thx_so3_retract_vjp")
+            return
         if poses.dim() == 4:
             return self.se3_retract_vjp(poses, delta, step, grad_out, grad_delta)
         P, B = poses.shape[:2]
@@ -486,10 +492,13 @@ class HipKernels:
                    "thx_se3_retract_vjp")
 
     def pg_vjp(self, s: DeviceStructure, t: PGTensors, w, g_meas, g_wb, g_tgt, g_wp, poses=None, g_lrb=None, g_lrp=None):
-        if t.group == "SO3":
-            raise NotImplementedError("HIP back end: the implicit backward pass is fused for SE3 / SE2 pose graphs, not SO3.")
         d = t.c_struct(poses)
         dt = w.dtype
+        if t.group == "SO3":
+            _lib.check(self.lib.thx_pgso3_vjp(s.c, d, _lib.ptr(w), w.stride(0), _lib.ptr(g_meas), _lib.ptr(g_wb),
+                                              _lib.ptr(g_tgt), _lib.ptr(g_wp), _lib.ptr(g_lrb), _lib.ptr(g_lrp),
+                                              _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(w.device)), "thx_pgso3_vjp")
+            return
         if t.se2:
             _lib.check(self.lib.thx_pg2_vjp(s.c, d, _lib.ptr(w), w.stride(0), _lib.ptr(g_meas), _lib.ptr(g_wb),
                                             _lib.ptr(g_tgt), _lib.ptr(g_wp), _lib.ptr(g_lrb), _lib.ptr(g_lrp),

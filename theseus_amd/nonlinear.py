@@ -478,9 +478,9 @@ class NonlinearLeastSquares(abc.ABC):
             from .ba import ba_implicit_step
             with torch.set_grad_enabled(outer_grad):
                 return ba_implicit_step(self, packed, float(step), kwargs)
-        if packed.group not in ("SE3", "SE2"):
-            raise NotImplementedError("HIP back end: backward_mode='implicit' is fused for SE3 / SE2 pose graphs and bundle "
-                                      f"adjustment (got {packed.group}); there is no autograd/CPU fallback.")
+        if packed.group not in ("SE3", "SE2", "SO3"):
+            raise NotImplementedError("HIP back end: backward_mode='implicit' is fused for SE3 / SE2 / SO3 pose graphs and "
+                                      f"bundle adjustment (got {packed.group}); there is no autograd/CPU fallback.")
         with torch.set_grad_enabled(outer_grad):
             packed.flush_variables()
             packed.sync(force=True)  # re-pack the auxiliary tensors WITH their autograd history
