@@ -372,6 +372,11 @@ def main():
             result["implicit_backward_ms"] = bwd_ms
         S, CI = min(args.cpu_sample, B), args.cpu_iters
         cpu_final = cpu_hist = None
+        if world > 1:
+            # the CPU baseline and the parity sub-sample are rank-0-only legs: at N > 1 the other ranks are already waiting in the
+            # final barrier, and the parity run would issue the sharded loop's all-reduces alone.  They belong to the N = 1 line.
+            S = 0
+            args.parity_sample = 0
         if S > 0 and not args.implicit:
             v, cores, cpu_final, cpu_s, cpu_hist = cpu_baseline(tensors, edges, P, dtype, S, CI, args.damping, args.cpu_chunk)
             result["cpu_baseline"] = {"value": v, "unit": "problem-iterations/s", "cores": cores, "kind": "port",

@@ -14,10 +14,10 @@ SEAM = ["--backend", "gloo", "--test-kernels", "tests.oracle_kernels:OracleKerne
         "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--parity-sample", "0", "--dtype", "f64"]
 
 
-def _bench(*argv):
+def _bench(*argv, seam=None):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv, *SEAM], cwd=ROOT, env=env, capture_output=True,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv, *(SEAM if seam is None else seam)], cwd=ROOT, env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -45,3 +45,14 @@ def test_gpus_2_strong_scaling_in_sub_batches():
 def test_single_rank_default():
     r = _bench("--batch", "2")
     assert r["n_gpus"] == 1 and r["ranks"] == 1 and r["all_gather_ms"] is None and r["collective_backend"] is None
+
+
+def test_gpus_2_with_the_default_rank0_legs_does_not_hang():
+    """The driver runs `bench.py --gpus N --steps K --warmup W` with nothing else: the rank-0-only legs (CPU baseline, parity
+    sub-sample) must not run the sharded loop's collectives on rank 0 alone while the other ranks sit in the final barrier --
+    at N > 1 they are skipped (they belong to the N = 1 line)."""
+    seam = [a for a in SEAM if a not in ("--cpu-sample", "--parity-sample", "0")] + ["--cpu-iters", "1"]
+    r = _bench("--gpus", "2", "--batch", "3", seam=seam)
+    assert r["n_gpus"] == 2 and "cpu_baseline" not in r and "parity" not in r
+    r1 = _bench("--batch", "3", seam=seam)
+    assert r1["n_gpus"] == 1 and r1["cpu_baseline"]["kind"] == "port" and "parity" in r1
