@@ -10,6 +10,6 @@ python bench.py --dtype f64 --steps 5 --cpu-sample 32 > $OUT/bench_f64.json 2> $
 python bench.py --implicit --batch 1024 > $OUT/bench_implicit_b1024.json 2> $OUT/bench_implicit.err; head -c 300 $OUT/bench_implicit_b1024.json; echo
 python bench.py --adaptive --cpu-sample 0 --parity-sample 0 --no-sparse-leg > $OUT/bench_f32_adaptive.json 2> $OUT/bench_adaptive.err; head -c 300 $OUT/bench_f32_adaptive.json; echo
 python tools/bench_ba.py 512 8192 256 f32 5 > $OUT/ba_bench_f32.log 2>&1; tail -4 $OUT/ba_bench_f32.log
-python tools/bench_sparse.py 1024 64 f32 5 > $OUT/sparse_bench.txt 2>&1; tail -3 $OUT/sparse_bench.txt
+python tools/bench_sparse.py 1024 64 f32 5 > $OUT/sparse_bench.txt 2>&1; python tools/bench_sparse.py 2048 64 f32 5 >> $OUT/sparse_bench.txt 2>&1; grep -v amdgpu $OUT/sparse_bench.txt | tail -6
 tools/gpu_profile.sh $TAG --steps 3 --warmup 1 --cpu-sample 0 --parity-sample 0 --no-sparse-leg > $OUT/profile.log 2>&1; head -12 $OUT/profile.log
 tools/pmc.sh ${TAG}_chol "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVES" -- python $(pwd)/tools/bench_chol.py 1536 4096 f32 2 > $OUT/chol_pmc.txt 2>&1; tail -30 $OUT/chol_pmc.txt
