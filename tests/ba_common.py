@@ -131,7 +131,10 @@ def run_ba_implicit(th, g, kernels=None, device="cpu", opt_kwargs=None):
         okw["linearization_kwargs"] = dict(kernels=kernels)
     okw.update(opt_kwargs or {})
     opt = th.LevenbergMarquardt(obj, **okw)
-    sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode="implicit", **kw))
+    layer = th.TheseusLayer(opt)
+    if device != "cpu" and opt_kwargs is not None:   # (the REAL theseus keeps Objective.device separately from its tensors')
+        layer.to(device)
+    sol, info = layer.forward(None, optimizer_kwargs=dict(backward_mode="implicit", **kw))
     used = sorted(set(g["obs_pt"].tolist()))
     final_c = torch.stack([sol[f"Cam{i}"] for i in range(C)], 1)
     final_p = torch.stack([sol[f"Pt{i}"] for i in used], 1)

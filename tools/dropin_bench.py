@@ -30,6 +30,11 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--adaptive", action="store_true")
     ap.add_argument("--no-hooks", action="store_true", help="only Linearization + LinearSolver replaced (round-1 boundary)")
+    ap.add_argument("--reference-gpu-batch", type=int, default=0,
+                    help="also run the UNMODIFIED reference (DenseLinearization + CholeskyDenseSolver through PyTorch-ROCm) on the "
+                         "same GPU at this batch size (its dense A is 37.8 MB per problem in fp32).  OFF by default: on this image "
+                         "(torch 2.10.0+rocm7.0) its linear solve ends in 'HIP error: unspecified launch failure' at n = 1536 in "
+                         "both dtypes (profiles/r2/r_dropin_bench_*_with_reference_on_gpu.json) -- do not put it in a routine run")
     ap.add_argument("--profile", action="store_true", help="cProfile of the drop-in's optimize() (host side), top functions to stderr")
     ap.add_argument("--test-kernels", default="", help=argparse.SUPPRESS)   # dry run of this script without a GPU
     args = ap.parse_args()
@@ -70,12 +75,12 @@ def main():
     layer.to(dev)
     okw = dict(damping=1e-3, adaptive_damping=args.adaptive)
 
-    def run(l, iters):
+    def run(l, iters, inp=None):
         l.optimizer.set_params(max_iterations=iters)
         sync()
         t0 = time.perf_counter()
         with torch.no_grad():
-            sol, info = l.forward(inputs, optimizer_kwargs=dict(track_err_history=True, **okw))
+            sol, info = l.forward(inputs if inp is None else inp, optimizer_kwargs=dict(track_err_history=True, **okw))
         sync()
         return sol, info, time.perf_counter() - t0
 
@@ -100,6 +105,53 @@ def main():
     mlayer.optimizer = mopt
     run(mlayer, 2)
     msol, minfo, mdt = run(mlayer, K)
+    ref_gpu = None
+    if args.reference_gpu_batch > 0:
+        # ---- the reference as it is, on the same device: its own vectorised torch cost functions, dense A / AtA, and
+        #      torch.linalg.cholesky / cholesky_solve of PyTorch-ROCm ----
+        Br, Kr = args.reference_gpu_batch, 3
+        del layer, opt, obj, mlayer, mopt, mobj   # their Hessian / factor frames (2 x 38.6 GB each at the headline size)
+        import gc
+        gc.collect()
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
+        robj = th.Objective(dtype=dtype)
+        rposes = [th.SE3(tensor=eye.clone(), name=f"VERTEX_SE3__{k}") for k in range(P)]
+        rw = th.DiagonalCostWeight(th.Variable(torch.tensor([[1 / syn.TRANSLATION_NOISE] * 3 + [1 / syn.ROTATION_NOISE] * 3], dtype=dtype),
+                                               name="EDGE_WEIGHT"))
+        for (i, j) in edges:
+            robj.add(th.Between(rposes[i], rposes[j], th.SE3(tensor=eye.clone(), name=f"EDGE_SE3__{i}_{j}"), rw, name=f"between_{i}_{j}"))
+        robj.add(th.Difference(rposes[0], th.SE3(tensor=eye.clone(), name="VERTEX_SE3__0__PRIOR"),
+                               th.ScaleCostWeight(th.Variable(torch.tensor([[syn.PRIOR_WEIGHT]], dtype=dtype), name="PRIOR_WEIGHT")),
+                               name="pose_prior"))
+        ropt = th.LevenbergMarquardt(robj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, max_iterations=Kr,
+                                     abs_err_tolerance=0.0, rel_err_tolerance=0.0, step_size=1.0)
+        rlayer = th.TheseusLayer(ropt)
+        rlayer.to(dev)
+        rin = {k: (v[:Br].contiguous() if v.shape[0] == B else v) for k, v in inputs.items()}
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            run(rlayer, 1, rin)
+            torch.cuda.reset_peak_memory_stats() if dev.type == "cuda" else None
+            rsol, rinfo, rdt = run(rlayer, Kr, rin)
+        ref_warn = sorted({str(w.message)[:400] for w in caught if "linear optimizer" in str(w.message)})
+        if ref_warn:   # what torch.linalg.cholesky said, and how far from positive definite the reference's AtA is
+            lin = ropt.linear_solver.linearization
+            try:
+                ev = torch.linalg.eigvalsh(lin.AtA[:4].double().cpu())
+                ref_warn.append(f"eigenvalues of its AtA (first 4 problems, fp64 on the host): min {ev.min().item():.3e}, max {ev.max().item():.3e}")
+            except Exception as e:   # noqa: BLE001
+                ref_warn.append(f"(eigvalsh of its AtA failed: {e})")
+        # iterations the reference actually completed: a failed linear solve (torch.linalg.cholesky raising on a matrix that
+        # is not positive definite in this precision) ends its loop with status FAIL and leaves inf in err_history
+        riters = int(torch.isfinite(rinfo.err_history).all(dim=0).sum()) - 1
+        ref_gpu = {"batch": Br, "lm_iterations_requested": Kr, "lm_iterations": riters,
+                   "status": sorted({str(x).split(".")[-1] for x in rinfo.status.tolist()}), "warnings": ref_warn,
+                   "problem_iterations_per_s": (Br * riters / rdt) if riters > 0 else None,
+                   "ms_per_iteration": (rdt / riters * 1e3) if riters > 0 else None, "wall_ms": rdt * 1e3,
+                   "peak_memory_GB": (torch.cuda.max_memory_allocated() / 1e9) if dev.type == "cuda" else None,
+                   "mean_error": [float(rinfo.err_history[:, 0].mean()), float(rinfo.err_history[:, -1].mean())]}
+        del rsol, rlayer, ropt, robj
     a = torch.stack([sol[f"VERTEX_SE3__{k}"] for k in range(P)], 1)
     b = torch.stack([msol[f"VERTEX_SE3__{k}"] for k in range(P)], 1)
     print(json.dumps({
@@ -109,7 +161,8 @@ def main():
         "mirror_problem_iterations_per_s": B * minfo.iters_done / mdt, "mirror_ms_per_iteration": mdt / minfo.iters_done * 1e3,
         "max_abs_pose_difference": float((a - b).abs().max()),
         "dropin_mean_error": [float(info.err_history[:, 0].mean()), float(info.err_history[:, -1].mean())],
-        "mirror_mean_error": [float(minfo.err_history[:, 0].mean()), float(minfo.err_history[:, minfo.iters_done].mean())]}))
+        "mirror_mean_error": [float(minfo.err_history[:, 0].mean()), float(minfo.err_history[:, minfo.iters_done].mean())],
+        "reference_on_this_gpu": ref_gpu}))
 
 
 if __name__ == "__main__":
