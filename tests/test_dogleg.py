@@ -123,3 +123,71 @@ def test_dogleg_fp32_on_the_gpu_inside_the_reference_band():
     rel = ((info.err_history.double() - hx).abs() / hx).max().item()
     rel_ref = ((torch.from_numpy(g["err_history"]).double() - hx).abs() / hx).max().item()
     assert rel <= 1.5 * rel_ref + 1e-6, (rel, rel_ref)
+
+
+@pytest.mark.parametrize("name", ["pg2_f64_lm", "pg3_f64_lm"])
+def test_dogleg_on_se2_and_so3_graphs_matches_the_oracle(name):
+    """The trust-region logic is group independent; the oracle's Dogleg (pinned to the reference on SE3 above) on the SE2 / SO3
+    fixtures against theseus_amd.Dogleg with the stand-in kernels, incl. a convergence tolerance (the device-side flags)."""
+    import theseus_amd as th
+    from oracle import pose_graph as opg
+    from tests.helpers import golden_problem
+    from tests.oracle_kernels import OracleKernels
+    from tests.test_gpu_lm import build_objective
+    g = load_golden(name)
+    p, poses0, _ = golden_problem(g)
+    kw = dict(max_iterations=12, step_size=1.0, abs_err_tolerance=1e-9, rel_err_tolerance=1e-5)
+    fo, io = opg.lm_optimize(p, poses0, dogleg=True, trust_region_init=0.3, **kw)
+    obj, _ = build_objective(th, g, device="cpu")
+    opt = th.Dogleg(obj, linear_solver_cls=th.HipCholeskySolver, linearization_kwargs=dict(kernels=OracleKernels()), **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(trust_region_init=0.3, track_err_history=True))
+    final = torch.stack([sol[f"pose_{k}"] for k in range(int(g["P"]))], 1)
+    np.testing.assert_allclose(final.numpy(), fo.numpy(), rtol=0, atol=1e-9)
+    assert info.iters_done == io.iters_done and info.iters_done < 12        # stopped by the tolerance, at the same iteration
+    np.testing.assert_array_equal(info.converged_iter.numpy(), io.converged_iter.numpy())
+    hist = torch.stack(io.err_history, 1)
+    np.testing.assert_allclose(info.err_history[:, :hist.shape[1]].numpy(), hist.numpy(), rtol=1e-9)
+
+
+def test_dogleg_with_implicit_backward():
+    """backward_mode="implicit" is optimizer independent (the last step is an undamped Gauss-Newton step,
+    nonlinear_least_squares.py:121-135): Dogleg forward iterations + the fused implicit step, gradients against autograd through
+    the oracle's implicit step from the same iterate."""
+    import dataclasses
+    import theseus_amd as th
+    from oracle import pose_graph as opg
+    from tests.helpers import golden_problem
+    from tests.oracle_kernels import OracleKernels
+    g = load_golden("pg_f64_implicit")
+    p, poses0, kw = golden_problem(g)
+    iters = 4
+    t = torch.from_numpy
+    meas = t(g["meas"]).clone().requires_grad_(True)
+    obj = th.Objective(dtype=torch.float64)
+    P = int(g["P"])
+    poses = [th.SE3(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    for k in range(g["edges"].shape[0]):
+        i, j = g["edges"][k].tolist()
+        cw = th.DiagonalCostWeight(th.Variable(t(g["w_between"])[:, k].clone(), name=f"w_{k}"))
+        obj.add(th.Between(poses[i], poses[j], th.SE3(tensor=meas[:, k], name=f"meas_{k}"), cw, name=f"between_{k}"))
+    for k in range(g["prior_idx"].shape[0]):
+        sw = th.ScaleCostWeight(th.Variable(t(g["w_prior"])[:, k, :1].clone(), name=f"pw_{k}"))
+        obj.add(th.Difference(poses[int(g["prior_idx"][k])], th.SE3(tensor=t(g["prior_target"])[:, k].clone(), name=f"tgt_{k}"), sw,
+                              name=f"prior_{k}"))
+    opt = th.Dogleg(obj, linearization_kwargs=dict(kernels=OracleKernels()), max_iterations=iters, step_size=1.0,
+                    abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode="implicit", trust_region_init=1.0))
+    final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
+    coef = t(g["coef"])
+    (coef * final).sum().backward()
+    # the oracle: Dogleg for iters - 1 iterations under no_grad, then the implicit step with grad
+    with torch.no_grad():
+        x, _ = opg.lm_optimize(p, poses0, max_iterations=iters - 1, abs_err_tolerance=0.0, rel_err_tolerance=0.0, dogleg=True,
+                               trust_region_init=1.0)
+    m2 = p.meas.clone().requires_grad_(True)
+    fo, _ = opg.implicit_final_step(dataclasses.replace(p, meas=m2), x)
+    (coef * fo).sum().backward()
+    np.testing.assert_allclose(final.detach().numpy(), fo.detach().numpy(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(meas.grad.numpy(), m2.grad.numpy(), rtol=0, atol=1e-7 * float(m2.grad.abs().max()))

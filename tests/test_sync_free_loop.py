@@ -10,13 +10,13 @@ import torch
 from tests.helpers import load_golden
 
 
-def _run(g, lazy, gauss_newton=False, **okw):
+def _run(g, lazy, gauss_newton=False, tol=(0.0, 0.0), **okw):
     import theseus_amd as th
     from tests.oracle_kernels import OracleKernels
     from tests.test_gpu_lm import build_objective
     obj, poses = build_objective(th, g, device="cpu")
     cls = th.GaussNewton if gauss_newton else th.LevenbergMarquardt
-    opt = cls(obj, linearization_kwargs=dict(kernels=OracleKernels()), abs_err_tolerance=0.0, rel_err_tolerance=0.0, **okw)
+    opt = cls(obj, linearization_kwargs=dict(kernels=OracleKernels()), abs_err_tolerance=tol[0], rel_err_tolerance=tol[1], **okw)
     calls = []
     kw = dict(track_err_history=True) if gauss_newton else dict(track_err_history=True, damping=1e-3)
     if not lazy:
@@ -46,3 +46,27 @@ def test_sync_free_iterations_keep_the_failure_semantics():
         assert all(s == th.NonlinearOptimizerStatus.FAIL for s in info.status), lazy
         np.testing.assert_array_equal(a.numpy(), g["poses0"])      # variables keep their values
         assert info.iters_done == 0 and torch.isinf(info.err_history[:, 1:]).all()
+
+
+def test_convergence_is_counted_like_the_reference_on_both_paths():
+    """Every problem converges at iteration k: the reference breaks out of its loop BEFORE counting that iteration
+    (nonlinear_least_squares.py:202-203) -- err_history holds its error at [k + 1], converged_iter = k + 1, the iteration count
+    stays k.  Same on the sync-free path (flags read once after the loop, lagged poll), the synchronous one and the oracle."""
+    import theseus_amd as th
+    from oracle import pose_graph as opg
+    from tests.helpers import golden_problem
+    g = load_golden("pg_f64_lm")
+    tol = (1e-10, 1e-4)
+    a, ia = _run(g, True, tol=tol, max_iterations=15, step_size=1.0)
+    b, ib = _run(g, False, tol=tol, max_iterations=15, step_size=1.0)
+    p, poses0, _ = golden_problem(g)
+    fo, io = opg.lm_optimize(p, poses0, max_iterations=15, step_size=1.0, damping=1e-3, abs_err_tolerance=tol[0],
+                             rel_err_tolerance=tol[1])
+    assert 0 < io.iters_done < 14
+    assert ia.iters_done == ib.iters_done == io.iters_done
+    assert torch.equal(a, b) and torch.equal(ia.err_history, ib.err_history)
+    assert torch.equal(ia.converged_iter, ib.converged_iter) and torch.equal(ia.converged_iter, io.converged_iter)
+    k = io.iters_done
+    assert torch.isfinite(ia.err_history[:, :k + 2]).all() and torch.isinf(ia.err_history[:, k + 2:]).all()
+    np.testing.assert_allclose(a.numpy(), fo.numpy(), rtol=0, atol=1e-9)
+    assert all(s == th.NonlinearOptimizerStatus.CONVERGED for s in ia.status) and list(ia.status) == list(ib.status)

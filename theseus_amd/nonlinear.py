@@ -327,10 +327,13 @@ class NonlinearLeastSquares(abc.ABC):
                     info.status[:] = NonlinearOptimizerStatus.FAIL   # (overrides every status: nonlinear_least_squares.py:147)
                     it = f_fail
                 elif f_conv >= 0:
-                    it = f_conv        # the reference broke out of its loop here (:202-203)
+                    # the reference broke out of its loop here, BEFORE counting the converging iteration (:202-203): its error
+                    # is in err_history[:, f_conv], the iteration count stays at f_conv - 1 (the synchronous path below and
+                    # the implicit epilogue -- which writes its error at [iters_done + 1], as _merge_infos does -- agree)
+                    it = f_conv - 1
                     if err_hist is not None:
-                        err_hist[:, it + 1:] = inf
-                    converged = conv_iter.ge(0) & conv_iter.le(it)   # (later iterations only re-marked frozen problems)
+                        err_hist[:, f_conv + 1:] = inf
+                    converged = conv_iter.ge(0) & conv_iter.le(f_conv)   # (later iterations only re-marked frozen problems)
                     conv_iter = torch.where(converged, conv_iter, torch.full_like(conv_iter, -1))
                 if not replay:
                     info.last_err = last_err   # (frozen / failed problems kept their error: this is the error AT ``it``)
