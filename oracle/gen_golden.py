@@ -148,6 +148,12 @@ def gen_lm(th, lieF, only=None):
          dict(max_iterations=5, step_size=1.0), dict(dogleg=True, trust_region_init=100.0)),   # overshooting first steps
         ("pg_f32_dogleg", dict(P=8, E=14, B=5, dtype=torch.float32, seed=61, pose_noise=(0.4, 0.5)),
          dict(max_iterations=4, step_size=1.0), dict(dogleg=True)),
+        # convergence tests switched ON (nonlinear_optimizer.py:110-119, nonlinear_least_squares.py:196-203): problems converge
+        # at different iterations, the loop stops when all have; status / converged_iter / the inf tail of err_history recorded
+        ("pg_f64_lm_converges", dict(P=8, E=14, B=5, dtype=torch.float64, seed=71, pose_noise=(0.3, 0.3)),
+         dict(max_iterations=20, step_size=1.0, abs_err_tolerance=1e-10, rel_err_tolerance=1e-3), dict(damping=1e-3)),
+        ("pg_f64_lm_partly_converges", dict(P=8, E=14, B=5, dtype=torch.float64, seed=71, pose_noise=(0.3, 0.3)),
+         dict(max_iterations=3, step_size=1.0, abs_err_tolerance=1e-10, rel_err_tolerance=1e-3), dict(damping=1e-3)),
     ]
     for name, pk, ok, lmk in cases:
         if only and name not in only:
@@ -158,8 +164,7 @@ def gen_lm(th, lieF, only=None):
         obj, poses = build_reference_objective(th, d, dtype)
         is_dogleg = bool(lmk and lmk.get("dogleg"))
         cls = th.GaussNewton if lmk is None else (th.Dogleg if is_dogleg else th.LevenbergMarquardt)
-        opt = cls(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True,
-                  abs_err_tolerance=0.0, rel_err_tolerance=0.0, **ok)
+        opt = cls(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, **dict(dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0), **ok))
         taps = dict(AtA=[], Atb=[], delta=[], A=[], b=[], err=[], tr=[])
 
         def cb(optimizer, info, delta, it):
@@ -183,6 +188,9 @@ def gen_lm(th, lieF, only=None):
         final = torch.stack([p.tensor for p in poses], 1).numpy()
         if is_dogleg:
             struct["trust_region"] = np.stack(taps["tr"])
+        struct["status"] = np.array([int(x.value) for x in info.status])      # NonlinearOptimizerStatus values
+        struct["converged_iter"] = info.converged_iter.numpy()
+        struct["best_iter"] = info.best_iter.numpy() if info.best_iter is not None else np.zeros(0)
         np.savez_compressed(
             os.path.join(OUT, name + ".npz"),
             P=d["P"], edges=d["edges"].numpy(), meas=d["meas"].numpy(), w_between=d["w_between"].numpy(),
