@@ -152,6 +152,10 @@ def gen_lm(th, lieF, only=None):
         # at different iterations, the loop stops when all have; status / converged_iter / the inf tail of err_history recorded
         ("pg_f64_lm_converges", dict(P=8, E=14, B=5, dtype=torch.float64, seed=71, pose_noise=(0.3, 0.3)),
          dict(max_iterations=20, step_size=1.0, abs_err_tolerance=1e-10, rel_err_tolerance=1e-3), dict(damping=1e-3)),
+        # track_best_solution (nonlinear_optimizer.py:184-213): plain Gauss-Newton from far away overshoots, the best iterate
+        # of a problem is not its last one
+        ("pg_f64_gn_best", dict(P=9, E=16, B=6, dtype=torch.float64, seed=66, pose_noise=(2.5, 2.5)),
+         dict(max_iterations=1, step_size=1.0), None),   # (one step: two of the six problems end ABOVE their starting error)
         ("pg_f64_lm_partly_converges", dict(P=8, E=14, B=5, dtype=torch.float64, seed=71, pose_noise=(0.3, 0.3)),
          dict(max_iterations=3, step_size=1.0, abs_err_tolerance=1e-10, rel_err_tolerance=1e-3), dict(damping=1e-3)),
     ]
@@ -183,7 +187,7 @@ def gen_lm(th, lieF, only=None):
                       num_rows=lin.num_rows, num_cols=lin.num_cols)
         with torch.no_grad():
             err0 = obj.error_metric().clone().numpy()
-            info = opt.optimize(track_err_history=True, end_iter_callback=cb,
+            info = opt.optimize(track_err_history=True, end_iter_callback=cb, track_best_solution=name.endswith("_best"),
                                 **{k: v for k, v in (lmk or {}).items() if k != "dogleg"})
         final = torch.stack([p.tensor for p in poses], 1).numpy()
         if is_dogleg:
@@ -191,6 +195,9 @@ def gen_lm(th, lieF, only=None):
         struct["status"] = np.array([int(x.value) for x in info.status])      # NonlinearOptimizerStatus values
         struct["converged_iter"] = info.converged_iter.numpy()
         struct["best_iter"] = info.best_iter.numpy() if info.best_iter is not None else np.zeros(0)
+        if info.best_solution is not None:
+            struct["best_solution"] = torch.stack([info.best_solution[p.name] for p in poses], 1).numpy()
+            struct["best_err"] = info.best_err.numpy()
         np.savez_compressed(
             os.path.join(OUT, name + ".npz"),
             P=d["P"], edges=d["edges"].numpy(), meas=d["meas"].numpy(), w_between=d["w_between"].numpy(),

@@ -80,3 +80,39 @@ def test_host_loop_matches_the_reference(name, callback):
 def test_gpu_loop_matches_the_reference(name, callback):
     g, final, info, calls = _run(name, "cuda", None, callback)
     _check(g, final, info, calls, callback)
+
+
+def _run_best(device, kernels):
+    import theseus_amd as th
+    from tests.test_gpu_lm import build_objective
+    g = load_golden("pg_f64_gn_best")
+    obj, _ = build_objective(th, g, device=device)
+    opt = th.GaussNewton(obj, linear_solver_cls=th.HipCholeskySolver, max_iterations=1, step_size=1.0, abs_err_tolerance=0.0,
+                         rel_err_tolerance=0.0, linearization_kwargs=dict(kernels=kernels) if kernels is not None else None)
+    sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(track_best_solution=True, track_err_history=True))
+    P = int(g["P"])
+    final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1).cpu()
+    best = torch.stack([info.best_solution[f"pose_{k}"] for k in range(P)], 1).cpu()
+    return g, final, best, info
+
+
+def _check_best(g, final, best, info):
+    """track_best_solution (nonlinear_optimizer.py:184-213): one Gauss-Newton step from far away leaves two of the six problems
+    ABOVE their starting error -- their best solution is the start, the others' is the new iterate."""
+    np.testing.assert_allclose(final.numpy(), g["final"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(best.numpy(), g["best_solution"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(info.best_err.cpu().numpy(), g["best_err"], rtol=2e-5)
+    np.testing.assert_array_equal(info.best_iter.numpy(), g["best_iter"])
+    worse = g["err_history"][:, 1] > g["err_history"][:, 0]
+    assert worse.sum() == 2
+    np.testing.assert_array_equal(best.numpy()[worse], g["poses0"][worse])      # bit for bit the starting values
+
+
+def test_best_solution_matches_the_reference():
+    from tests.oracle_kernels import OracleKernels
+    _check_best(*_run_best("cpu", OracleKernels()))
+
+
+@pytest.mark.gpu
+def test_best_solution_on_the_gpu_matches_the_reference():
+    _check_best(*_run_best("cuda", None))
