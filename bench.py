@@ -187,12 +187,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     standin = bool(args.test_kernels)
     on_gpu = not standin
-    device = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    # (THX_BENCH_ONE_DEVICE=1: every rank on cuda:0 -- a pre-flight of the sharded path with the real kernels on a 1-GPU box,
+    #  over gloo; the driver's multi-GPU runs use one device per rank and RCCL)
+    one_device = os.environ.get("THX_BENCH_ONE_DEVICE") == "1"
+    device = torch.device("cuda", 0 if one_device else local_rank) if on_gpu else torch.device("cpu")
     if on_gpu:
         torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
-        if on_gpu:
+        if on_gpu and args.backend == "nccl":
             dist.init_process_group(args.backend, device_id=device)
         else:
             dist.init_process_group(args.backend)
