@@ -273,6 +273,57 @@ def test_unmodified_reference_example_runs_on_the_plugin(ref, monkeypatch):
     assert calls["pg_assemble"] >= 40 and calls["pg_vjp"] == 4, calls   # the FUSED path ran, once per outer backward
 
 
+@cpu_only
+def test_unmodified_reference_bundle_adjustment_example_runs_on_the_plugin(ref, monkeypatch, tmp_path):
+    """examples/bundle_adjustment.py -- UNMODIFIED, imported from /root/reference, its own config -- learns ``log_loss_radius``
+    through ``backward_mode="implicit"`` (Adam on the outer loss, :184-215).  The example builds its optimizer as
+    ``getattr(th, cfg.inner_optim.optimizer_cls)(objective, max_iterations=..., step_size=...)``; the one thing a user adds is
+    ``linear_solver_cls`` -- injected here through the name the config resolves.  Same outer losses and the same learned radius,
+    epoch by epoch, as the example on the reference's own dense path."""
+    th, thp = ref
+    import functools
+    import logging
+    import random
+    import theseus_amd.kernels as tk
+    from omegaconf import OmegaConf
+    from tests.oracle_kernels import OracleKernels
+    import examples.bundle_adjustment as ba_ex
+    cfg = OmegaConf.load(REF + "/examples/configs/bundle_adjustment.yaml")
+    cfg.outer_optim.num_epochs = 2
+    cfg.inner_optim.verbose = False
+    cfg.inner_optim.max_iters = 3
+    cfg.inner_optim.reg_w = float(cfg.inner_optim.reg_w)
+    standin = OracleKernels()
+    calls = {"ba_assemble": 0, "ba_vjp": 0}
+    for name in calls:
+        def spy(*a, _f=getattr(standin, name), _n=name, **k):
+            calls[_n] += 1
+            return _f(*a, **k)
+        setattr(standin, name, spy)
+
+    def run(tag, plugin):
+        torch.manual_seed(cfg.seed), np.random.seed(cfg.seed), random.seed(cfg.seed)   # what the example's main() does
+        out = tmp_path / tag
+        out.mkdir()
+        with monkeypatch.context() as m:
+            if plugin:
+                m.setattr(tk, "_default", standin)                  # no GPU here: the TEST stand-in
+                m.setattr(th, "GaussNewton", functools.partial(th.GaussNewton, linear_solver_cls=thp.HipSchurSolver))
+            ba_ex.run(cfg, out)
+        res = [torch.load(out / f"results_epoch{e}.pt", weights_only=False) for e in range(cfg.outer_optim.num_epochs)]
+        return [r["loss"] for r in res], [float(r["log_loss_radius"]) for r in res]
+    logging.disable(logging.CRITICAL)
+    try:
+        ref_losses, ref_radius = run("reference", False)
+        losses, radius = run("plugin", True)
+    finally:
+        logging.disable(logging.NOTSET)
+    assert calls["ba_assemble"] >= 2 * 3 and calls["ba_vjp"] == 2, calls      # the fused BA path ran, one VJP per outer backward
+    assert len(set(ref_radius)) == 2                                          # the radius is being learned
+    np.testing.assert_allclose(losses, ref_losses, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(radius, ref_radius, rtol=1e-9)
+
+
 @pytest.mark.parametrize("name", ["ba_f64_lm", "ba_f64_gn"])
 def test_reference_loop_drives_the_bundle_adjustment_plugin(ref, name):
     """The REAL th.LevenbergMarquardt / th.GaussNewton loop with theseus_amd.plugin.HipSchurSolver on a bundle-adjustment
