@@ -390,6 +390,13 @@ int thx_ba_backsub(const thx_ba_structure* s, int32_t B, const void* W, const vo
 #define THX_BA_ERR_CHUNKS 256
 int thx_ba_error(const thx_ba_structure* s, const thx_ba_data* d, void* partials, void* err, int dtype,
                  const thx_lie_eps* eps, void* stream);
+/* Linearization.Av (theseus/optimizer/dense_linearization.py:73-74; read by Dogleg / TrustRegion, nonlinear/dogleg.py:66,
+ * trust_region.py:97) for the block linearization: out_t (m, B) = (A v)^T with the weighted (and robust-rescaled) Jacobian
+ * blocks recomputed per cost, never the dense A.  v (B, ldv) in the linearization's column order (cameras, then points); rows
+ * in cost ADD order: obs_row / cam_prior_row / pt_prior_row (device int32) give the first row of every cost. */
+int thx_ba_av(const thx_ba_structure* s, const thx_ba_data* d, const void* v, int64_t ldv, const int32_t* obs_row,
+              const int32_t* cam_prior_row, const int32_t* pt_prior_row, void* out_t, int dtype, const thx_lie_eps* eps,
+              void* stream);
 /* Vector retraction x <- x + step * delta (theseus/geometry/vector.py:177-178), masked like thx_se3_retract; x (N,B,dof),
  * delta (B, ldd) read at columns [col0, col0 + N*dof) */
 int thx_vec_retract(const void* x, const void* delta, int64_t ldd, int64_t col0, double step, const uint8_t* ignore_mask,

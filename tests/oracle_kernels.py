@@ -169,6 +169,25 @@ class OracleKernels:
         diag[:, :6 * C] = hcc.diagonal(dim1=2, dim2=3).reshape(B, -1)
         diag[:, 6 * C:] = hpp.diagonal(dim1=2, dim2=3).reshape(B, -1)
 
+    def ba_av(self, s, t, v, rows, out_t):
+        p, state = self._ba_problem(s, t)
+        Jc, Jp, _, _, Jcp, _, _ = p.terms(state)
+        B, C, Np = state[0].shape[0], p.num_cams, p.num_points
+        vc, vp = v[:, :6 * C].reshape(B, C, 6), v[:, 6 * C:].reshape(B, Np, 3)
+        out = torch.zeros(B, out_t.shape[0], dtype=v.dtype)
+
+        def put(first_rows, vals):   # vals (B, K, d) -> rows first_rows[k] + [0, d)
+            K, d = vals.shape[1], vals.shape[2]
+            idx = (first_rows[:K].long().view(-1, 1) + torch.arange(d)).view(-1)
+            out[:, idx] = vals.reshape(B, -1)
+        if p.obs_cam.numel():
+            put(rows[0], (Jc @ vc[:, p.obs_cam].unsqueeze(3) + Jp @ vp[:, p.obs_pt].unsqueeze(3)).squeeze(3))
+        if p.cam_prior_idx.numel():
+            put(rows[1], (Jcp @ vc[:, p.cam_prior_idx].unsqueeze(3)).squeeze(3))
+        if p.pt_prior_idx.numel():
+            put(rows[2], p.w_pt_prior * vp[:, p.pt_prior_idx])
+        out_t.copy_(out.t())
+
     def ba_vjp(self, s, t, w, grads):
         """d(w^T g)/d theta by torch autograd through the oracle's restatement of the cost terms."""
         import dataclasses

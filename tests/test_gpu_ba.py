@@ -210,3 +210,33 @@ def test_ba_implicit_backward_matches_reference_gradients():
     for k in ("log_radius", "feat", "focal", "k1", "k2", "w_obs", "gt_cams", "w_strong", "w_reg"):
         want = g["grad_" + k]
         np.testing.assert_allclose(got["grad_" + k], want, rtol=0, atol=5e-6 * max(np.abs(want).max(), 1e-12), err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["ba_f64_lm", "ba_f32_lm"])
+def test_ba_av_and_dogleg_on_the_gpu(name):
+    """thx_ba_av (Linearization.Av for the block linearization: what th.Dogleg / TrustRegion read) against the CPU stand-in built
+    on the oracle's Jacobian blocks, and theseus_amd.Dogleg on a bundle-adjustment objective: GPU run == host run."""
+    import theseus_amd as th
+    from tests.oracle_kernels import OracleKernels
+    g = load_golden(name)
+    f64 = g["cams0"].dtype == np.float64
+    res = {}
+    for dev in ("cuda", "cpu"):
+        obj, cam_v, pt_v = build_ba_objective(th, g, dev)
+        opt = th.Dogleg(obj, max_iterations=4, step_size=1.0, abs_err_tolerance=0.0, rel_err_tolerance=0.0,
+                        linearization_kwargs=dict(kernels=OracleKernels()) if dev == "cpu" else None)
+        lin = opt.linear_solver.linearization
+        lin.linearize()
+        v = torch.randn(lin.g.shape[0], lin.n, dtype=lin.g.dtype, generator=torch.Generator().manual_seed(2)).to(dev)
+        av = lin.Av(v).cpu()
+        assert av.shape == (lin.g.shape[0], lin.packed.m)
+        sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(track_err_history=True, trust_region_init=2.0))
+        res[dev] = (av, torch.stack([sol[v_.name] for v_ in cam_v], 1).cpu(), info.err_history, opt._trust_region.view(-1).cpu())
+    a, b = res["cuda"], res["cpu"]
+    scale = float(b[0].abs().max())
+    np.testing.assert_allclose(a[0].numpy(), b[0].numpy(), rtol=0, atol=(1e-10 if f64 else 2e-5) * scale)
+    np.testing.assert_allclose(a[1].numpy(), b[1].numpy(), rtol=0, atol=1e-7 if f64 else 5e-3)
+    np.testing.assert_allclose(a[2].numpy(), b[2].numpy(), rtol=1e-6 if f64 else 5e-3)
+    if f64:
+        np.testing.assert_array_equal(a[3].numpy(), b[3].numpy())
+    assert (a[2][:, -1] < a[2][:, 0]).all()

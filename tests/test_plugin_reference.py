@@ -384,6 +384,48 @@ def test_bundle_adjustment_implicit_backward_through_the_reference_loop(ref):
         np.testing.assert_allclose(out["grad_" + k].reshape(ref_g.shape), ref_g, rtol=5e-6, atol=5e-6 * np.abs(ref_g).max(), err_msg=k)
 
 
+def test_dogleg_on_bundle_adjustment_through_the_plugin(ref):
+    """th.Dogleg needs ``linearization.Av``: for bundle adjustment the plugin answers from thx_ba_av (per-cost Jacobian blocks,
+    no dense Jacobian).  Av against the reference's DenseLinearization under the same variable ordering, then the REAL
+    th.Dogleg with HipSchurSolver against th.Dogleg on the reference's dense path: same trajectory and trust-region radii."""
+    th, thp = ref
+    from tests.ba_common import build_ba_objective
+
+    class RefNames:
+        Objective, SE3, Point3, Point2, Vector, Difference = th.Objective, th.SE3, th.Point3, th.Point2, th.Vector, th.Difference
+        ScaleCostWeight, RobustCostFunction, HuberLoss, WelschLoss = th.ScaleCostWeight, th.RobustCostFunction, th.HuberLoss, th.WelschLoss
+        Reprojection = th.eb.Reprojection
+    g = load_golden("ba_f64_lm")
+    out = {}
+    for tag in ("plugin", "reference"):
+        obj, cam_v, pt_v = build_ba_objective(RefNames, g, DEVICE)
+        if DEVICE != "cpu":
+            obj.to(DEVICE)
+        obj.update()
+        kw = dict(linear_solver_cls=thp.HipSchurSolver, linearization_kwargs=_kernels()) if tag == "plugin" else dict(
+            linear_solver_cls=th.CholeskyDenseSolver)
+        opt = th.Dogleg(obj, vectorize=True, abs_err_tolerance=0.0, rel_err_tolerance=0.0, max_iterations=4, step_size=1.0, **kw)
+        lin = opt.linear_solver.linearization
+        if tag == "plugin":
+            lin.linearize()
+            ref_lin = th.optimizer.DenseLinearization(obj, ordering=lin.ordering)
+            ref_lin.linearize()
+            v = torch.randn(obj.batch_size, lin.num_cols, dtype=torch.float64, generator=torch.Generator().manual_seed(1)).to(DEVICE)
+            want = ref_lin.Av(v).detach().cpu().numpy()
+            np.testing.assert_allclose(lin.Av(v).detach().cpu().numpy(), want, rtol=0, atol=1e-9 * np.abs(want).max())
+        with torch.no_grad():
+            info = opt.optimize(track_err_history=True, trust_region_init=2.0)
+        used = sorted(set(g["obs_pt"].tolist()))
+        out[tag] = (torch.stack([v.tensor for v in cam_v], 1).cpu(), torch.stack([pt_v[i].tensor for i in used], 1).cpu(),
+                    info.err_history.cpu(), opt._trust_region.view(-1).cpu())
+    a, b = out["plugin"], out["reference"]
+    np.testing.assert_allclose(a[0].numpy(), b[0].numpy(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(a[1].numpy(), b[1].numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(a[2].numpy(), b[2].numpy(), rtol=1e-6)
+    np.testing.assert_array_equal(a[3].numpy(), b[3].numpy())
+    assert (b[2][:, -1] < b[2][:, 0]).all()
+
+
 # ---- the third hook set (Objective vectorization callbacks, SURVEY.md §8b) -------------------------------------------------
 def _counting(standin, names):
     calls = {n: 0 for n in names}

@@ -19,7 +19,7 @@ THX_TILE = 128
 THX_ERR_CHUNKS = 16
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class LieEps(Structure):
@@ -114,6 +114,8 @@ _SIGNATURES = {
                      c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "thx_ba_backsub": [POINTER(BAStructure), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     "thx_ba_error": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
+    "thx_ba_av": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                  POINTER(LieEps), c_void_p],
     "thx_ba_vjp": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
     "thx_copy_where": [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p],

@@ -187,6 +187,7 @@ class PackedBA:
         pi = {v.name: k for k, v in enumerate(self.pt_vars)}
         self.obs_costs, self.obs_radius, self.cam_prior_costs, self.pt_prior_costs = [], [], [], []
         obs_cam, obs_pt, cpc, ppp, kinds = [], [], [], [], set()
+        row, rows = 0, ([], [], [])   # first row of every cost in the reference's (B, m) layouts: cost ADD order
         for wrapped in objective.cost_functions.values():
             c, loss, radius = _unwrap_robust(wrapped)
             names = {k.__name__ for k in type(c).__mro__}
@@ -196,13 +197,19 @@ class PackedBA:
                 self.obs_costs.append(c)
                 self.obs_radius.append(radius)
                 kinds.add(loss)
+                rows[0].append(row)
+                row += 2
             elif _kind(c) == "Difference" and not loss:
                 if c.var.name in ci:
                     cpc.append(ci[c.var.name])
                     self.cam_prior_costs.append(c)
+                    rows[1].append(row)
+                    row += 6
                 else:
                     ppp.append(pi[c.var.name])
                     self.pt_prior_costs.append(c)
+                    rows[2].append(row)
+                    row += 3
             else:
                 raise UnsupportedObjective(f"HIP bundle adjustment has no fused kernel for {type(wrapped).__name__} "
                                            f"({wrapped.name}); supported: Reprojection (optionally robust), Difference.")
@@ -214,6 +221,8 @@ class PackedBA:
         self.n = self.structure.n
         self.nc = 6 * len(self.cam_vars)
         self.m = objective.dim()
+        self.cost_rows = tuple(np.asarray(r if r else [0], dtype=np.int32) for r in rows)
+        self._cost_rows_dev: Dict[str, Any] = {}
         self.version = objective.current_version
         self.tensors: Optional[BATensors] = None
         seen, self._tracked_list = set(), []          # shared calibration / weights / radius appear once
@@ -493,8 +502,19 @@ class HipSchurLinearizationCore:
     def _atb_impl(self) -> torch.Tensor:
         return self.g.unsqueeze(2)
 
-    def Av(self, v):
-        raise NotImplementedError("the dense Jacobian of a bundle-adjustment objective is not materialised")
+    def Av(self, v: torch.Tensor) -> torch.Tensor:
+        """(B, n) -> (B, m), dense_linearization.py:73-74: per-cost Jacobian blocks recomputed by thx_ba_av at the variables'
+        current values (those of this linearization wherever the reference's optimizers call it: dogleg.py:66,
+        trust_region.py:97), never the dense Jacobian.  Rows in cost add order, columns cameras then points."""
+        p = self.packed
+        p.sync()
+        key = str(v.device)
+        if key not in p._cost_rows_dev:
+            p._cost_rows_dev[key] = tuple(torch.from_numpy(r).to(v.device) for r in p.cost_rows)
+        v = v.to(self.objective.dtype).contiguous()
+        out_t = torch.empty(p.m, v.shape[0], dtype=v.dtype, device=v.device)
+        self.K.ba_av(p.dstruct, p.tensors, v, p._cost_rows_dev[key], out_t)
+        return out_t.t().contiguous()
 
     def diagonal_scaling(self, v: torch.Tensor) -> torch.Tensor:
         return self.diag * v

@@ -494,6 +494,77 @@ lm_accept_diag_kernel(const T* __restrict__ delta, const T* __restrict__ g, cons
   }
 }
 
+// ---- A v : the product the reference takes with its dense Jacobian (dense_linearization.py:73-74; read by Dogleg /
+//      TrustRegion, dogleg.py:66, trust_region.py:97), one lane per (cost, problem), Jacobian blocks recomputed on the fly.
+//      Rows in cost ADD order (row tables from the host), output transposed (m, B): coalesced over the batch. ----
+template <typename T>
+__global__ void __launch_bounds__(64)
+ba_av_kernel(thx_ba_structure s, thx_ba_data d, const T* __restrict__ v, int64_t ldv, const int32_t* __restrict__ obs_row,
+             const int32_t* __restrict__ cam_prior_row, const int32_t* __restrict__ pt_prior_row, T* __restrict__ out_t,
+             Eps<T> eps) {
+  const int b = blockIdx.x * 64 + threadIdx.x, B = d.batch;
+  int c = blockIdx.y;
+  if (b >= B) return;
+  const T* vb = v + (int64_t)b * ldv;
+  const int64_t pcol = 6 * (int64_t)s.num_cams;
+  if (c < s.num_obs) {
+    const int o = c, cam_i = s.obs_cam[o], p = s.obs_pt[o];
+    const SE3<double> cam = load_cam(static_cast<const T*>(d.cams) + ((int64_t)cam_i * B + b) * 12);
+    const T* Xp = static_cast<const T*>(d.points) + ((int64_t)p * B + b) * 3;
+    const double X[3] = {(double)Xp[0], (double)Xp[1], (double)Xp[2]};
+    ObsAux<T> a;
+    load_obs<T>(d, o, cam_i, b, a);
+    Reproj r;
+    reproj_eval(cam, X, a.feat, a.f, a.k1, a.k2, a.w, true, r);
+    robustify_obs(d.robust_obs, a.lr, r, true);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc += r.Jc[6 * i + k] * (double)vb[6 * cam_i + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc += r.Jp[3 * i + k] * (double)vb[pcol + 3 * p + k];
+      out_t[(int64_t)(obs_row[o] + i) * B + b] = (T)acc;
+    }
+    return;
+  }
+  c -= s.num_obs;
+  if (c < s.num_cam_priors) {
+    const int k = c, cam_i = s.cam_prior_cam[k];
+    const SE3<double> Xc = load_cam(static_cast<const T*>(d.cams) + ((int64_t)cam_i * B + b) * 12);
+    const SE3<double> Tg = load_cam(static_cast<const T*>(d.cam_prior_target) +
+                                    ((int64_t)k * (d.cam_prior_target_bstride ? B : 1)) * 12 + (int64_t)b * d.cam_prior_target_bstride);
+    const T* wp = static_cast<const T*>(d.w_cam_prior) + ((int64_t)k * (d.w_cam_prior_bstride ? B : 1)) * 6 +
+                  (int64_t)b * d.w_cam_prior_bstride;
+    double w[6], ev[6], x[6], y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      w[i] = (double)wp[i];
+      x[i] = (double)vb[6 * cam_i + i];
+    }
+    SJac<double> J;
+    local_eval<double>(Tg, Xc, w, widen(eps), ev, &J, true);
+    // J = [[a, c], [0, d]] (3x3 blocks, rows already weighted)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      y[i] = J.a[3 * i] * x[0] + J.a[3 * i + 1] * x[1] + J.a[3 * i + 2] * x[2] + J.c[3 * i] * x[3] + J.c[3 * i + 1] * x[4] +
+             J.c[3 * i + 2] * x[5];
+      y[3 + i] = J.d[3 * i] * x[3] + J.d[3 * i + 1] * x[4] + J.d[3 * i + 2] * x[5];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) out_t[(int64_t)(cam_prior_row[k] + i) * B + b] = (T)y[i];
+    return;
+  }
+  c -= s.num_cam_priors;
+  {
+    const int k = c, p = s.pt_prior_pt[k];
+    const T* wp = static_cast<const T*>(d.w_pt_prior) + ((int64_t)k * (d.w_pt_prior_bstride ? B : 1)) * 3 +
+                  (int64_t)b * d.w_pt_prior_bstride;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out_t[(int64_t)(pt_prior_row[k] + i) * B + b] = (T)((double)wp[i] * (double)vb[pcol + 3 * p + i]);
+  }
+}
+
 static int check_ba(const thx_ba_structure* s, const thx_ba_data* d) {
   if (!s || !d) return fail("thx_ba: null structure/data");
   if (s->num_cams <= 0 || s->num_points <= 0 || d->batch <= 0) return fail("thx_ba: empty problem");
@@ -605,6 +676,25 @@ int thx_ba_error(const thx_ba_structure* s, const thx_ba_data* d, void* partials
                                     (const double*)partials, (double*)err, B);
                });
   return check_launch("thx_ba_error");
+}
+
+int thx_ba_av(const thx_ba_structure* s, const thx_ba_data* d, const void* v, int64_t ldv, const int32_t* obs_row,
+              const int32_t* cam_prior_row, const int32_t* pt_prior_row, void* out_t, int dtype, const thx_lie_eps* eps,
+              void* stream) {
+  if (int r = check_ba(s, d)) return r;
+  if (!v || !out_t || !eps) return fail("thx_ba_av: null argument");
+  if ((s->num_obs > 0 && !obs_row) || (s->num_cam_priors > 0 && !cam_prior_row) || (s->num_pt_priors > 0 && !pt_prior_row))
+    return fail("thx_ba_av: null row table");
+  if (ldv < 6 * (int64_t)s->num_cams + 3 * (int64_t)s->num_points) return fail("thx_ba_av: ldv < n");
+  const int costs = s->num_obs + s->num_cam_priors + s->num_pt_priors;
+  if (costs == 0) return 0;
+  const dim3 block(64), grid((d->batch + 63) / 64, costs);
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(ba_av_kernel<float>, grid, block, 0, as_stream(stream), *s, *d, (const float*)v, ldv, obs_row,
+                                  cam_prior_row, pt_prior_row, (float*)out_t, make_eps<float>(eps)),
+               hipLaunchKernelGGL(ba_av_kernel<double>, grid, block, 0, as_stream(stream), *s, *d, (const double*)v, ldv, obs_row,
+                                  cam_prior_row, pt_prior_row, (double*)out_t, make_eps<double>(eps)));
+  return check_launch("thx_ba_av");
 }
 
 int thx_vec_retract(const void* x, const void* delta, int64_t ldd, int64_t col0, double step, const uint8_t* ignore_mask,

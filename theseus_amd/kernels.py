@@ -405,6 +405,13 @@ class HipKernels:
         _lib.check(self.lib.thx_ba_error(s.c, d, _lib.ptr(partials), _lib.ptr(err), _lib.dtype_code(dt), lie_eps(dt),
                                          _lib.stream_ptr(err.device)), "thx_ba_error")
 
+    def ba_av(self, s, t, v, rows, out_t):
+        """thx_ba_av: out_t (m, B) = (A v)^T; ``rows`` = (obs_row, cam_prior_row, pt_prior_row) device int32 tensors."""
+        d = t.c_struct()
+        dt = v.dtype
+        _lib.check(self.lib.thx_ba_av(s.c, d, _lib.ptr(v), v.stride(0), _lib.ptr(rows[0]), _lib.ptr(rows[1]), _lib.ptr(rows[2]),
+                                      _lib.ptr(out_t), _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(v.device)), "thx_ba_av")
+
     def ba_vjp(self, s, t, w, grads):
         """grads: dict name -> preallocated tensor | None for feat, w_obs, focal, k1, k2, log_radius, cam_prior_target,
         w_cam_prior, pt_prior_target, w_pt_prior (thx_ba_vjp's outputs, in that order)."""
