@@ -221,20 +221,28 @@ def test_ba_av_and_dogleg_on_the_gpu(name):
     g = load_golden(name)
     f64 = g["cams0"].dtype == np.float64
     res = {}
+    # (the host leg runs in fp64 on the same data: the stand-in kernels do not model the fp32 path's fp64 block buffers)
+    g64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in g.items()}
     for dev in ("cuda", "cpu"):
-        obj, cam_v, pt_v = build_ba_objective(th, g, dev)
+        obj, cam_v, pt_v = build_ba_objective(th, g if dev == "cuda" else g64, dev)
         opt = th.Dogleg(obj, max_iterations=4, step_size=1.0, abs_err_tolerance=0.0, rel_err_tolerance=0.0,
                         linearization_kwargs=dict(kernels=OracleKernels()) if dev == "cpu" else None)
         lin = opt.linear_solver.linearization
         lin.linearize()
-        v = torch.randn(lin.g.shape[0], lin.n, dtype=lin.g.dtype, generator=torch.Generator().manual_seed(2)).to(dev)
-        av = lin.Av(v).cpu()
+        v = torch.randn(lin.g.shape[0], lin.n, dtype=torch.float64, generator=torch.Generator().manual_seed(2)).to(lin.g.dtype).to(dev)
+        av = lin.Av(v).cpu().double()
         assert av.shape == (lin.g.shape[0], lin.packed.m)
         sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(track_err_history=True, trust_region_init=2.0))
-        res[dev] = (av, torch.stack([sol[v_.name] for v_ in cam_v], 1).cpu(), info.err_history, opt._trust_region.view(-1).cpu())
+        res[dev] = (av, torch.stack([sol[v_.name] for v_ in cam_v], 1).cpu().double(), info.err_history.double(),
+                    opt._trust_region.view(-1).cpu().double())
     a, b = res["cuda"], res["cpu"]
     scale = float(b[0].abs().max())
-    np.testing.assert_allclose(a[0].numpy(), b[0].numpy(), rtol=0, atol=(1e-10 if f64 else 2e-5) * scale)
+    if f64:
+        np.testing.assert_allclose(a[0].numpy(), b[0].numpy(), rtol=0, atol=1e-10 * scale)
+    else:   # fp32 against the fp64 evaluation: rounding, except for the few observations that sit at the Huber kink (the
+            # rescale switches branch between the two precisions: a relative step of the size of the residual's rounding)
+        diff = (a[0] - b[0]).abs().numpy()
+        assert (diff > 2e-5 * scale).mean() < 0.01 and diff.max() < 1e-2 * scale, (diff.max(), scale)
     np.testing.assert_allclose(a[1].numpy(), b[1].numpy(), rtol=0, atol=1e-7 if f64 else 5e-3)
     np.testing.assert_allclose(a[2].numpy(), b[2].numpy(), rtol=1e-6 if f64 else 5e-3)
     if f64:
