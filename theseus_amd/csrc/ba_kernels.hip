@@ -468,22 +468,41 @@ vec_retract_kernel(const T* __restrict__ x, const T* __restrict__ delta, int64_t
 }
 
 template <typename T>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 lm_accept_diag_kernel(const T* __restrict__ delta, const T* __restrict__ g, const T* __restrict__ diag, int64_t ldv, int n,
                       T* __restrict__ damping, const T* __restrict__ prev_err, const T* __restrict__ new_err,
                       int ellipsoidal, T accept, T down, T up, uint8_t* __restrict__ reject) {
-  // levenberg_marquardt.py:173-201 (same arithmetic as lm_accept_kernel, diag(H) read from a vector)
-  const int b = blockIdx.x, lane = threadIdx.x;
+  // levenberg_marquardt.py:173-201 (same arithmetic as lm_accept_kernel, diag(H) read from a vector).  n is 25 k at the
+  // bundle-adjustment size: four waves per problem, four independent element groups in flight per thread (one wave with one
+  // element per trip was 0.31 ms at batch 256 -- latency, not bytes)
+  __shared__ T part[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const T lam = damping[b];
-  T s = T(0);
-  for (int i = lane; i < n; i += 64) {
-    const T dl = delta[(int64_t)b * ldv + i];
-    const T D = ellipsoidal ? diag[(int64_t)b * ldv + i] * lam : lam;
-    s += dl * (D * dl + g[(int64_t)b * ldv + i]);
+  const T* db = delta + (int64_t)b * ldv;
+  const T* gb = g + (int64_t)b * ldv;
+  const T* hb = diag + (int64_t)b * ldv;
+  T s4[4] = {T(0), T(0), T(0), T(0)};
+  int i = tid;
+  for (; i + 768 < n; i += 1024) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const T dl = db[i + 256 * u];
+      const T D = ellipsoidal ? hb[i + 256 * u] * lam : lam;
+      s4[u] += dl * (D * dl + gb[i + 256 * u]);
+    }
   }
+  for (; i < n; i += 256) {
+    const T dl = db[i];
+    const T D = ellipsoidal ? hb[i] * lam : lam;
+    s4[0] += dl * (D * dl + gb[i]);
+  }
+  T s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0) {
+  if (lane == 0) part[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    s = (part[0] + part[1]) + (part[2] + part[3]);
     const T den = s / T(2);
     const T rho = (prev_err[b] - new_err[b]) / den;
     const bool rej = rho <= accept;
@@ -715,10 +734,10 @@ int thx_lm_accept_diag(const void* delta, const void* g, const void* diag, int64
   if (!delta || !g || !damping || !prev_err || !new_err || !reject || (ellipsoidal && !diag))
     return fail("thx_lm_accept_diag: null pointer");
   THX_DISPATCH(dtype,
-               hipLaunchKernelGGL(lm_accept_diag_kernel<float>, dim3(B), dim3(64), 0, as_stream(stream), (const float*)delta,
+               hipLaunchKernelGGL(lm_accept_diag_kernel<float>, dim3(B), dim3(256), 0, as_stream(stream), (const float*)delta,
                                   (const float*)g, (const float*)diag, ldv, n, (float*)damping, (const float*)prev_err,
                                   (const float*)new_err, ellipsoidal, (float)accept, (float)down_ratio, (float)up_ratio, reject),
-               hipLaunchKernelGGL(lm_accept_diag_kernel<double>, dim3(B), dim3(64), 0, as_stream(stream),
+               hipLaunchKernelGGL(lm_accept_diag_kernel<double>, dim3(B), dim3(256), 0, as_stream(stream),
                                   (const double*)delta, (const double*)g, (const double*)diag, ldv, n, (double*)damping,
                                   (const double*)prev_err, (const double*)new_err, ellipsoidal, accept, down_ratio, up_ratio,
                                   reject));
