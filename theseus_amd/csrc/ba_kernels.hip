@@ -324,15 +324,8 @@ ba_schur_kernel(thx_ba_structure s, int B, const double* __restrict__ Hcc, const
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i) rv[i] = g[(int64_t)b * ldv + 6 * c1 + i];
-  // rhs -= sum_o W_o t_p(o)
-  for (int k = s.cam_ptr[c1]; k < s.cam_ptr[c1 + 1]; ++k) {
-    const int o = s.cam_obs[k], p = s.obs_pt[o];
-    const double* Wo = W + ((int64_t)o * B + b) * 18;
-    const double* tp = tvec + (int64_t)b * (3 * (int64_t)s.num_points) + 3 * p;
-    const double t0 = tp[0], t1 = tp[1], t2 = tp[2];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) rv[i] -= Wo[3 * i] * t0 + Wo[3 * i + 1] * t1 + Wo[3 * i + 2] * t2;
-  }
+  // rhs -= sum_o W_o t_p(o): every observation o of the camera is its own diagonal pair (o, o) -- done inside the pair loop
+  // below, on the W block that loop has loaded anyway
   T* Sb = S + (int64_t)b * ld * ld;
   for (int k = s.pair_dptr[c1]; k < s.pair_ptr[c1 + 1]; ++k) {  // the pairs with cam(o2) = c1
     const int o1 = s.pair_o1[k], o2 = s.pair_o2[k];
@@ -342,7 +335,18 @@ ba_schur_kernel(thx_ba_structure s, int B, const double* __restrict__ Hcc, const
     const double* W2p = W + ((int64_t)o2 * B + b) * 18;
     const double* hp = Hinv + ((int64_t)p * B + b) * 6;
 #pragma unroll
-    for (int i = 0; i < 18; ++i) { W1[i] = W1p[i]; W2[i] = W2p[i]; }
+    for (int i = 0; i < 18; ++i) W1[i] = W1p[i];
+    if (o1 == o2) {   // (block uniform: the structure is shared by the batch) a camera sees a point once -- the usual case
+#pragma unroll
+      for (int i = 0; i < 18; ++i) W2[i] = W1[i];
+      const double* tp = tvec + (int64_t)b * (3 * (int64_t)s.num_points) + 3 * p;
+      const double t0 = tp[0], t1 = tp[1], t2 = tp[2];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) rv[i] -= W1[3 * i] * t0 + W1[3 * i + 1] * t1 + W1[3 * i + 2] * t2;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 18; ++i) W2[i] = W2p[i];
+    }
 #pragma unroll
     for (int i = 0; i < 6; ++i) h[i] = hp[i];
     w_times_sym(W1, h, M);
