@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""bench.py -- LM problem-iterations/s on the synthetic SE3 pose graph (BASELINE.json configs[1]).
+"""bench.py -- LM problem-iterations/s on the synthetic SE3 pose graph (BASELINE.json configs[1]) + every other BASELINE config
+as a leg of the same JSON line.
 
 A "step" is ONE Levenberg-Marquardt iteration over the whole batch (linearize -> damp + Cholesky
 factor + solve -> retract -> error), i.e. one pass of the hot path over one batch of synthetic
@@ -8,11 +9,21 @@ tolerances 0 so nothing exits early -- same trick as the reference's examples/po
 the timed region is bracketed by barrier + torch.cuda.synchronize and the max over ranks is reported.
 value = n_gpus * B * K / time  (problem-iterations per second, whole job).
 
+The headline (`metric` / `value` / `roofline` / `cpu_baseline` / `parity` at the top level) is BASELINE.json configs[1]:
+256 poses / 1024 edges, batch 4096 per GPU, fp32, LM + dense Cholesky.  Under `"configs"` the same line carries
+  N = 1 : "fp64_b4096"       configs[2]'s dtype and per-GPU share (32768 / 8 problems) on one GPU,
+          "ba_512_8192_32768_b256"   configs[3] (bundle adjustment, Schur complement + tile-sparse Cholesky),
+          "implicit_b1024"   configs[4] (forward LM + implicit backward through TheseusLayer),
+  N > 1 : "strong_f64_32768" configs[2] itself: 32768 fp64 problems sharded over the N GPUs (strong scaling), each rank's
+          share solved in sub-batches of 4096, one all_gather of the solved poses,
+each with its own value / ms_per_step / roofline / parity / cpu_baseline (`--legs none` skips them).
+
 Multi GPU (one rank per GPU; `python bench.py --gpus N` re-executes itself under torch.distributed.run when it was not
 launched by it): the batch dimension shards -- every rank owns B independent problems (weak scaling) -- and one RCCL
 all_gather re-collects the solved poses on every rank inside the timed region.  No other collective.
 """
 import argparse
+import gc
 import importlib
 import json
 import os
@@ -20,6 +31,7 @@ import socket
 import subprocess
 import sys
 import time
+from types import SimpleNamespace
 
 import torch
 
@@ -34,12 +46,15 @@ class KernelTimer:
     """HIP-event timing of every C-ABI call, on the stream the kernels are launched on
     (torch's current stream: torch.cuda.Event records there)."""
 
-    NAMES = ["pg_assemble", "chol_factor", "chol_factor_sparse", "chol_solve_backward", "chol_solve", "se3_retract", "pg_error", "lm_accept"]
+    NAMES = ["pg_assemble", "chol_factor", "chol_factor_sparse", "chol_solve_backward", "chol_solve", "chol_solve_sparse",
+             "se3_retract", "pg_error", "lm_accept", "ba_assemble", "ba_schur", "ba_backsub", "ba_error", "ba_retract"]
 
     def __init__(self, K):
-        self.K, self.events, self.enabled = K, {n: [] for n in self.NAMES}, False
+        self.K, self.events, self.enabled = K, {}, False
         for n in self.NAMES:
-            setattr(K, n, self._wrap(n, getattr(K, n)))
+            if hasattr(K, n):
+                self.events[n] = []
+                setattr(K, n, self._wrap(n, getattr(K, n)))
 
     def _wrap(self, name, fn):
         def wrapped(*a, **k):
@@ -112,23 +127,74 @@ def respawn_under_torchrun(n):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+class exact_thresholds:
+    """Context: the fp64 oracle evaluates with the RUN dtype's Taylor thresholds -- the exact evaluation of what an fp32 run
+    (the reference's or ours) approximates."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        from oracle import lie
+        self.saved = dict(lie.EPS[torch.float64])
+        if self.dtype == torch.float32:
+            import numpy as np
+            lie.EPS[torch.float64] = {k: float(np.float32(v)) for k, v in lie.EPS[torch.float32].items()}
+
+    def __exit__(self, *a):
+        from oracle import lie
+        lie.EPS[torch.float64] = self.saved
+
+
 def exact_reference(tensors, edges, P, dtype, sample, iters, damping):
     """The same problem evaluated exactly: fp64 oracle on the (fp32- or fp64-valued) inputs with the
     run dtype's Taylor thresholds -- what both the reference's fp path and ours approximate."""
-    from oracle import lie
     from oracle import pose_graph as opg
     prob, poses0 = oracle_problem(tensors, edges, P, torch.float64, sample)
-    saved = dict(lie.EPS[torch.float64])
-    if dtype == torch.float32:
-        import numpy as np
-        lie.EPS[torch.float64] = {k: float(np.float32(v)) for k, v in lie.EPS[torch.float32].items()}
-    try:
-        with torch.no_grad():
-            final, info = opg.lm_optimize(prob, poses0, max_iterations=iters, damping=damping, abs_err_tolerance=0.0,
-                                          rel_err_tolerance=0.0)
-    finally:
-        lie.EPS[torch.float64] = saved
+    with exact_thresholds(dtype), torch.no_grad():
+        final, info = opg.lm_optimize(prob, poses0, max_iterations=iters, damping=damping, abs_err_tolerance=0.0,
+                                      rel_err_tolerance=0.0)
     return final, torch.stack(info.err_history, 1)
+
+
+def riemannian(X, G):
+    """Tangent projection of a gradient w.r.t. the raw 3x4 entries of X: [R skew(R^T G_R) | G_t] -- the component normal to
+    SO(3) depends on how a closed form extends off the manifold (Taylor vs exact branch), so only the projected gradient
+    compares across dtypes (tests/test_gpu_implicit.py)."""
+    R = X[..., :3]
+    M = R.transpose(-1, -2) @ G[..., :3]
+    return torch.cat([R @ (0.5 * (M - M.transpose(-1, -2))), G[..., 3:]], -1)
+
+
+def chain_relative(X):
+    """(B, P, 3, 4) -> X_k^-1 X_{k+1} (B, P-1, 3, 4) in plain differentiable torch ops (any device): the gauge-free view of a
+    solution.  The parity gradients are taken of sum(chain_relative(final)): at this size the undamped Gauss-Newton system of
+    the implicit step has cond ~ 6e14 (the prior of weight 1e-3 is all that pins the gauge), so a loss that sees the gauge
+    has gradients no two evaluations agree on (tests/implicit_common.py:check_full_size_implicit)."""
+    R0, t0, R1, t1 = X[:, :-1, :, :3], X[:, :-1, :, 3:], X[:, 1:, :, :3], X[:, 1:, :, 3:]
+    Rt = R0.transpose(-1, -2)
+    return torch.cat([Rt @ R1, Rt @ (t1 - t0)], -1)
+
+
+def oracle_implicit(tensors, edges, P, dtype, sample, iters, damping, exact):
+    """Forward LM (iters - 1 iterations, no grad) + the grad-enabled Gauss-Newton step + backward of the gauge-free loss
+    sum(chain_relative(final poses)) through the oracle (oracle.pose_graph.implicit_final_step: autograd through the restated formulas, pinned to the
+    reference's implicit gradients by tests/test_oracle_golden.py).  ``exact``: fp64 with the run dtype's thresholds.
+    Returns (final poses, d loss / d measurements, seconds)."""
+    import contextlib
+    import dataclasses
+    from oracle import pose_graph as opg
+    prob, poses0 = oracle_problem(tensors, edges, P, torch.float64 if exact else dtype, sample)
+    ctx = exact_thresholds(dtype) if exact else contextlib.nullcontext()
+    t0 = time.perf_counter()
+    with ctx:
+        with torch.no_grad():
+            x, _ = opg.lm_optimize(prob, poses0, max_iterations=iters - 1, damping=damping, abs_err_tolerance=0.0,
+                                   rel_err_tolerance=0.0)
+        meas = prob.meas.clone().requires_grad_(True)
+        final, _ = opg.implicit_final_step(dataclasses.replace(prob, meas=meas), x)
+        chain_relative(final).sum().backward()
+    return final.detach(), meas.grad, time.perf_counter() - t0
 
 
 # Algorithmic HBM bytes per problem of the HBM-bound kernels (DESIGN.md §4): n = 6 P columns, E edges, element size es.
@@ -143,6 +209,420 @@ def algorithmic_bytes(P, E, es):
         "se3_retract": 2 * P * rec + n * es,
         "chol_solve_backward": n * (n + 1) // 2 * es + 2 * n * es,   # tril(L) once + y + x
     }
+
+
+def free_device_memory():
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+
+
+def pg_run(cfg, ctx):
+    """One pose-graph measurement (the headline, or a leg): build the objective, W warm-up + K timed LM iterations, the one
+    all_gather at N > 1; on rank 0: the result dict with roofline / cpu_baseline / parity.  Returns None on other ranks."""
+    import theseus_amd as th
+    from theseus_amd.utils import synthetic as syn
+    world, rank, device, on_gpu, kernels, dist = ctx.world, ctx.rank, ctx.device, ctx.on_gpu, ctx.kernels, ctx.dist
+    standin = kernels is not None
+    dtype = torch.float32 if cfg.dtype == "f32" else torch.float64
+    P, E, B, K_iters, W = cfg.poses, cfg.edges, cfg.batch, cfg.steps, cfg.warmup
+    n = 6 * P
+    edges = syn.pose_graph_topology(P, E, topology_seed=0)
+    objective = syn.build_pose_graph_objective(edges, P, dtype=dtype, device=device)
+    solver_cls = th.HipSparseCholeskySolver if cfg.solver == "sparse" else th.HipCholeskySolver
+    opt = th.LevenbergMarquardt(objective, linear_solver_cls=solver_cls, max_iterations=K_iters,
+                                abs_err_tolerance=0.0, rel_err_tolerance=0.0, step_size=1.0,
+                                linearization_kwargs=dict(kernels=kernels) if standin else None)
+    if world > 1:
+        from theseus_amd.sharding import DistBatchReducer
+        opt.reducer = DistBatchReducer()  # batch-global predicates over all shards (one tiny all-reduce / iteration)
+    layer = th.TheseusLayer(opt)
+    timer = KernelTimer(opt.linear_solver.K)
+    strong = cfg.total_batch > 0
+    if strong:
+        from theseus_amd.sharding import plan_sub_batches
+        if cfg.implicit:
+            raise SystemExit("--total-batch is the forward configuration (configs[2]); not combined with --implicit")
+        try:
+            B, n_sub = plan_sub_batches(cfg.total_batch, rank, world, B)
+        except ValueError as e:
+            raise SystemExit(str(e))
+    else:
+        n_sub = 1
+    # every sub-batch's inputs are resident in HBM before the timed region (synthetic, one seed per rank and sub-batch)
+    sub_inputs = []
+    for c in range(n_sub):
+        tensors_c = syn.make_pose_graph_tensors(edges, P, B, dtype=dtype, device=device, seed=1234 + rank + 1000 * c,
+                                                kernels=kernels)
+        sub_inputs.append(syn.input_dict(tensors_c))
+        if c == 0:
+            tensors = tensors_c
+    inputs = sub_inputs[0]
+    okw = dict(damping=cfg.damping, adaptive_damping=cfg.adaptive)
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    def barrier():
+        sync()
+        if world > 1:
+            dist.barrier()
+            sync()
+
+    bwd_ms, gather_ms = None, None
+    if cfg.implicit:
+        for k, v in inputs.items():
+            if k.startswith("EDGE_SE3__"):
+                v.requires_grad_(True)
+        okw = dict(okw, backward_mode="implicit")
+    with torch.set_grad_enabled(cfg.implicit):
+        if W > 0:
+            opt.set_params(max_iterations=max(W, 2) if cfg.implicit else W)
+            layer.forward(inputs, optimizer_kwargs=okw)
+        opt.set_params(max_iterations=K_iters)
+        barrier()
+        timer.enabled = on_gpu
+        t0 = time.perf_counter()
+        sol, info = layer.forward(inputs, optimizer_kwargs=dict(track_err_history=True, **okw))
+        for more in sub_inputs[1:]:  # strong scaling: the rank's remaining sub-batches through the same workspaces
+            layer.forward(more, optimizer_kwargs=okw)
+        if cfg.implicit:  # backward: retract VJP + ONE linear solve with the cached factor + cost VJP
+            loss = torch.stack(list(sol.values())).sum()   # (one reduction over all poses; 256 separate .sum() calls were
+                                                            #  1.6 ms of 6 us kernels in the timed backward)
+            eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            eb0.record()
+            loss.backward()
+            eb1.record()
+            torch.cuda.synchronize()
+            bwd_ms = eb0.elapsed_time(eb1)
+        if world > 1:  # the one data-path collective: re-collect the solved poses on every rank (RCCL over xGMI)
+            from theseus_amd.sharding import gather_solution
+            sync()
+            tg0 = time.perf_counter()
+            gathered = gather_solution(opt.linear_solver.linearization.packed.tensors.poses)
+            sync()
+            gather_ms = (time.perf_counter() - tg0) * 1e3
+            assert gathered.shape[1] == world * B
+            del gathered
+        local_dt = time.perf_counter() - t0   # this rank's own work, before it waits for the others
+        barrier()
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+    rank_ms = [local_dt * 1e3]
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        every = [None] * world
+        dist.all_gather_object(every, (local_dt * 1e3, gather_ms))
+        rank_ms = [e[0] for e in every]
+        gather_ms = max(e[1] for e in every)
+
+    iters_done = info.iters_done
+    result = None
+    if rank == 0:
+        phases = timer.summary()
+        es = 4 if cfg.dtype == "f32" else 8
+        err_hist = info.err_history
+        result = {
+            "metric": "LM iterations/sec (batch x vars) on SE3 pose-graph",
+            "value": world * n_sub * B * iters_done / dt,
+            "unit": "problem-iterations/s",
+            "n_gpus": world, "steps": K_iters, "warmup": W, "ms_per_step": dt / max(iters_done, 1) * 1e3,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": cfg.dtype, "data": "synthetic" if on_gpu else "TEST-STANDIN",
+            "config": {"workload": f"SE3 pose-graph {P} poses / {E} Between edges + 1 prior, batch {n_sub * B} per GPU, "
+                                   f"LM damping {cfg.damping}{' adaptive' if cfg.adaptive else ''} + "
+                                   f"{'tile-sparse Cholesky (RCM ordering)' if cfg.solver == 'sparse' else 'dense Cholesky'}",
+                       "poses": P, "edges": E, "batch_per_gpu": n_sub * B, "global_batch": world * n_sub * B, "n": n,
+                       "parallelism": f"batch-shard x{world}" + (f", {n_sub} sub-batches of {B} per GPU" if strong else "")},
+            "ranks": world if world == 1 else dist.get_world_size(),
+            "collective_backend": None if world == 1 else dist.get_backend(),
+            "rank_ms_per_step": {"min": min(rank_ms) / max(iters_done, 1), "max": max(rank_ms) / max(iters_done, 1)},
+            "all_gather_ms": gather_ms,
+            "pose_updates_per_s": world * n_sub * B * iters_done * P / dt,
+            "iters_done": iters_done,
+            "mean_error": [float(err_hist[:, 0].mean()), float(err_hist[:, iters_done].mean())],
+        }
+        if on_gpu:
+            sparse = cfg.solver == "sparse"
+            fac = phases.get("chol_factor_sparse" if sparse else "chol_factor", {"avg_ms": float("nan")})
+            # SURVEY §8(d): n^3/3 flops per problem x B problems per thx_chol_factor_forward call (the 2n^2 of the
+            # fused forward substitution are not counted)
+            dense_flops = B * (n ** 3) / 3.0
+            peak = PEAK[cfg.dtype]
+            # the tile-sparse solver EXECUTES fewer flops than the dense count: its matrix-core utilisation is executed flops /
+            # time / peak (``achieved`` / ``frac``); the dense-equivalent figure is reported beside it, not as the fraction
+            pat = opt.linear_solver.pattern if sparse else None
+            flops_per_launch = B * pat.flops if sparse else dense_flops
+            achieved = flops_per_launch / (fac["avg_ms"] * 1e-3) / 1e12
+            traffic, traffic_src = None, None
+            try:  # measured offline with rocprofv3 --pmc (bench.py cannot profile itself): profiles/traffic.json
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(
+                    f"{cfg.dtype}_n{n}_b{B}" + ("_sparse" if sparse else ""))
+                if tj:
+                    traffic, traffic_src = tj["bytes_per_factor_call"], tj["source"]
+            except (OSError, ValueError, KeyError):
+                pass
+            # the HBM-bound kernels of the iteration: algorithmic bytes / HIP-event time
+            hbm = {}
+            for name, per_problem in algorithmic_bytes(P, E, es).items():
+                if name in phases:
+                    gbs = per_problem * B / (phases[name]["avg_ms"] * 1e-3) / 1e9
+                    hbm[name] = {"avg_ms": round(phases[name]["avg_ms"], 4), "algorithmic_GBps": round(gbs, 1),
+                                 "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+            # SURVEY §8(d) per problem-iteration totals: n^3/3 + 2n^2 flops, 5 n^2/2-ish bytes (23.7 MB fp32 at n = 1536)
+            t_mfma = B * (n ** 3 / 3.0 + 2.0 * n * n) / (peak * 1e12) * 1e3
+            t_hbm = B * (4 * n * (n + 1) / 2 * es + (P + E + 1) * 12 * es + 2 * n * es) / (HBM_PEAK_GBS * 1e9) * 1e3
+            step_ms = dt / max(iters_done, 1) * 1e3 / n_sub
+            result["roofline"] = {
+                "bound": "mfma", "kernel": ("thx_chol_factor_sparse" if sparse else "thx_chol_factor_forward") +
+                                           " (chol_diag + chol_offdiag launches per block column)",
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": traffic, "traffic_unit": "bytes per factor call (PMC, rocprofv3)",
+                "traffic_source": traffic_src, "flops_per_launch": flops_per_launch, "avg_launch_ms": fac["avg_ms"],
+                "hbm_bound_kernels": hbm,
+                "executed": None if not sparse else {
+                    "of_dense": pat.flops / pat.dense_flops,
+                    "tiles_of_L": [pat.l_tiles, pat.ntiles * (pat.ntiles + 1) // 2],
+                    "dense_equivalent_TFLOPs": dense_flops / (fac["avg_ms"] * 1e-3) / 1e12},
+                "iteration": {"floor_ms": {"mfma": round(t_mfma, 3), "hbm": round(t_hbm, 3)}, "ms_per_step": step_ms,
+                              "frac": max(t_mfma, t_hbm) / step_ms}}
+            result["phases_ms_per_call"] = {k: round(v["avg_ms"], 4) for k, v in phases.items()}
+        S, CI = min(cfg.cpu_sample, B), cfg.cpu_iters
+        SP = min(cfg.parity_sample, B)
+        if world > 1:
+            # the CPU baseline and the parity sub-sample are rank-0-only legs: at N > 1 the other ranks are already waiting in the
+            # final barrier, and the parity run would issue the sharded loop's all-reduces alone.  They belong to the N = 1 line.
+            S = SP = 0
+        cpu_final = cpu_hist = None
+        if cfg.implicit:
+            result["config"]["workload"] += " + implicit backward through TheseusLayer"
+            result["implicit_backward_ms"] = bwd_ms
+            if on_gpu:
+                result["roofline"]["note"] = ("a step = one forward LM iteration; the grad-enabled Gauss-Newton step and the "
+                                              "backward (retract VJP + one solve with the cached factor + cost VJP) are inside the "
+                                              "timed region and divided over the forward iterations")
+            if S > 0:
+                _, _, cpu_s = oracle_implicit(tensors, edges, P, dtype, S, CI, cfg.damping, exact=False)
+                v = S * CI / cpu_s
+                result["cpu_baseline"] = {"value": v, "unit": "problem-iterations/s", "cores": torch.get_num_threads(),
+                                          "kind": "port",
+                                          "sample": f"first {S} problems of the batch, {CI - 1} LM iterations + the implicit "
+                                                    f"Gauss-Newton step + backward ({cpu_s:.1f} s), oracle.pose_graph (torch-CPU "
+                                                    f"autograd through the restated formulas)"}
+                result["speedup_vs_cpu"] = result["value"] / v
+            if SP > 0:
+                ex_final, ex_grad, _ = oracle_implicit(tensors, edges, P, dtype, SP, CI, cfg.damping, exact=True)
+                sub = {k: t[:SP].detach().clone().requires_grad_(k.startswith("EDGE_SE3__")) for k, t in inputs.items()}
+                opt.set_params(max_iterations=CI)
+                with torch.enable_grad():
+                    sol_s, _ = layer.forward(sub, optimizer_kwargs=okw)
+                    final_s = torch.stack([sol_s[f"VERTEX_SE3__{k}"] for k in range(P)], 1)
+                    chain_relative(final_s).sum().backward()
+                got = final_s.detach().cpu().double()
+                ggrad = torch.stack([sub[f"EDGE_SE3__{i}_{j}"].grad for (i, j) in edges], 1).cpu().double()
+                X = torch.stack([sub[f"EDGE_SE3__{i}_{j}"].detach() for (i, j) in edges], 1).cpu().double()
+                gr, er = riemannian(X, ggrad), riemannian(X, ex_grad)
+                result["parity"] = {
+                    "reference": "fp64 oracle (exact evaluation of the same inputs): forward + implicit step + autograd backward "
+                                 "of the gauge-free loss sum(X_k^-1 X_{k+1}); gradients compared in the tangent projection",
+                    "problems": SP, "iters": CI,
+                    "hip_max_abs_pose_err": float((got - ex_final).abs().max()),
+                    "hip_max_rel_pose_err": float((relative_poses(got) - relative_poses(ex_final)).abs().max()),
+                    "hip_grad_meas_rel_err": float((gr - er).abs().max() / er.abs().max()),
+                    "grad_scale": float(er.abs().max())}
+                del sub, sol_s, final_s
+        else:
+            if S > 0:
+                v, cores, cpu_final, cpu_s, cpu_hist = cpu_baseline(tensors, edges, P, dtype, S, CI, cfg.damping, cfg.cpu_chunk)
+                result["cpu_baseline"] = {"value": v, "unit": "problem-iterations/s", "cores": cores, "kind": "port",
+                                          "sample": f"first {S} problems of rank 0's batch in chunks of {min(cfg.cpu_chunk, S)} x "
+                                                    f"{CI} LM iterations ({cpu_s:.1f} s), oracle.pose_graph.lm_optimize (torch-CPU/"
+                                                    f"MKL restatement of DenseLinearization + CholeskyDenseSolver)"}
+                result["speedup_vs_cpu"] = result["value"] / v
+            if SP > 0:
+                # parity of the HIP path on a sub-sample, against the exact (fp64) evaluation of the same problem -- for the
+                # fp64 path that is the oracle itself (pinned to the reference at this size: tests/golden/pg_full_f64_lm.npz),
+                # for fp32 the CPU port's own distance from exact is printed next to it (the fp32 band, see DESIGN.md).
+                # *_rel_pose_err is gauge-free (relative poses along the chain): the prior of weight 1e-3 pins the gauge weakly.
+                ex_final, ex_hist = exact_reference(tensors, edges, P, dtype, SP, CI, cfg.damping)
+                sub = {k: t[:SP].contiguous() for k, t in inputs.items()}
+                opt.set_params(max_iterations=CI)
+                with torch.no_grad():
+                    sol_s, info_s = layer.forward(sub, optimizer_kwargs=dict(track_err_history=True, **okw))
+                got = torch.stack([sol_s[f"VERTEX_SE3__{k}"] for k in range(P)], 1).cpu().double()
+                rel = lambda h: float(((h.double()[:, CI] - ex_hist[:, CI]).abs() / ex_hist[:, CI].abs()).max())  # noqa
+                result["parity"] = {
+                    "reference": "fp64 oracle (exact evaluation of the same inputs)", "problems": SP, "iters": CI,
+                    "hip_max_abs_pose_err": float((got - ex_final).abs().max()),
+                    "hip_max_rel_pose_err": float((relative_poses(got) - relative_poses(ex_final)).abs().max()),
+                    "hip_rel_err_final_cost": rel(info_s.err_history)}
+                if cpu_final is not None and S >= SP:
+                    c = cpu_final[:SP].double()
+                    result["parity"].update({
+                        "cpu_port_max_abs_pose_err": float((c - ex_final).abs().max()),
+                        "cpu_port_max_rel_pose_err": float((relative_poses(c) - relative_poses(ex_final)).abs().max()),
+                        "cpu_port_rel_err_final_cost": rel(cpu_hist[:SP])})
+                del sub, sol_s
+    want_sparse_leg = (on_gpu and world == 1 and cfg.solver == "dense" and cfg.sparse_leg and not cfg.implicit and not strong)
+    del sol, info, layer, opt, objective, timer, sub_inputs
+    if not want_sparse_leg:
+        del inputs, tensors
+    free_device_memory()
+    if want_sparse_leg:
+        # ---- the same workload once more with HipSparseCholeskySolver (theseus_amd/sparse.py): same kernels, reverse
+        #      Cuthill-McKee variable ordering, structurally zero tiles of L and K-loop blocks skipped.  Reported NEXT TO the
+        #      dense headline (value / roofline above are the dense solver's).
+        obj2 = syn.build_pose_graph_objective(edges, P, dtype=dtype, device=device)
+        opt2 = th.LevenbergMarquardt(obj2, linear_solver_cls=th.HipSparseCholeskySolver, max_iterations=K_iters,
+                                     abs_err_tolerance=0.0, rel_err_tolerance=0.0, step_size=1.0)
+        layer2 = th.TheseusLayer(opt2)
+        timer2 = KernelTimer(opt2.linear_solver.K)
+        with torch.no_grad():
+            if W > 0:
+                opt2.set_params(max_iterations=W)
+                layer2.forward(inputs, optimizer_kwargs=okw)
+            opt2.set_params(max_iterations=K_iters)
+            torch.cuda.synchronize()
+            timer2.enabled = True
+            t0 = time.perf_counter()
+            sol2, info2 = layer2.forward(inputs, optimizer_kwargs=dict(track_err_history=True, **okw))
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            timer2.enabled = False
+        pat = opt2.linear_solver.pattern
+        fms = timer2.summary()["chol_factor_sparse"]["avg_ms"]
+        result["tile_sparse"] = {
+            "solver": "HipSparseCholeskySolver (reverse Cuthill-McKee ordering, tile pattern of L)",
+            "value": B * info2.iters_done / dt2, "unit": "problem-iterations/s", "ms_per_step": dt2 / info2.iters_done * 1e3,
+            "factor_ms": fms, "tiles_of_L": [pat.l_tiles, pat.ntiles * (pat.ntiles + 1) // 2],
+            "executed_flops_of_dense": pat.flops / pat.dense_flops,
+            "executed_TFLOPs": B * pat.flops / (fms * 1e-3) / 1e12,
+            "executed_frac_of_peak": B * pat.flops / (fms * 1e-3) / 1e12 / PEAK[cfg.dtype],
+            "mean_error": [float(info2.err_history[:, 0].mean()), float(info2.err_history[:, info2.iters_done].mean())]}
+        del sol2, info2, layer2, opt2, obj2, timer2, inputs, tensors
+        free_device_memory()
+    return result
+
+
+def ba_run(cfg, ctx):
+    """BASELINE.json configs[3]: bundle adjustment, 512 SE3 cameras / 8192 Point3 / 32768 robust Reprojection costs, batch 256,
+    adaptive ellipsoidal LM; the reduced camera system (Schur complement, 3072 x 3072) goes through the tile-sparse MFMA
+    Cholesky along its band.  One GPU, rank 0."""
+    import numpy as np
+    import theseus_amd as th
+    from theseus_amd.utils.synthetic_ba import make_ba_objective
+    C, Np, B, K_iters, W = cfg.cams, cfg.points, cfg.batch, cfg.steps, cfg.warmup
+    dtype = torch.float32 if cfg.dtype == "f32" else torch.float64
+    obj, meta = make_ba_objective(C, Np, B, dtype=dtype, device=ctx.device)
+    opt = th.LevenbergMarquardt(obj, max_iterations=K_iters, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    layer = th.TheseusLayer(opt)
+    solver = opt.linear_solver
+    timer = KernelTimer(solver.K)
+    kw = dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True)
+    start = {v.name: v.tensor.clone() for v in obj.optim_vars.values()}
+    with torch.no_grad():
+        if W > 0:
+            opt.set_params(max_iterations=W)
+            layer.forward(None, optimizer_kwargs=kw)
+        opt.set_params(max_iterations=K_iters)
+        for name, t in start.items():       # the timed run starts from the same initial state as the warm-up did
+            obj.optim_vars[name].update(t)
+        torch.cuda.synchronize()
+        fv0 = solver.factor_version
+        timer.enabled = True
+        t0 = time.perf_counter()
+        sol, info = layer.forward(None, optimizer_kwargs=dict(track_err_history=True, **kw))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+    solves = solver.factor_version - fv0
+    iters = max(info.iters_done, 1)
+    phases = timer.summary()
+    pat = getattr(solver, "pattern", None) if getattr(solver, "sparse", False) else None
+    nc = 6 * meta["num_cams"]
+    fname = "chol_factor_sparse" if pat is not None else "chol_factor"
+    fac = phases.get(fname, {"avg_ms": float("nan")})
+    peak = PEAK[cfg.dtype]
+    dense_flops = B * nc ** 3 / 3.0
+    executed = B * pat.flops if pat is not None else dense_flops
+    kernel_ms = sum(v["total_ms"] for v in phases.values()) / max(solves, 1)
+    result = {
+        "metric": "LM iterations/sec (batch x vars) on bundle adjustment", "value": B * iters / dt,
+        "unit": "problem-iterations/s", "ms_per_step": dt / iters * 1e3, "dtype": cfg.dtype, "steps": K_iters, "warmup": W,
+        "iters_done": info.iters_done, "linear_solves": solves,
+        "config": {"workload": f"bundle adjustment {meta['num_cams']} SE3 cameras / {Np} Point3 ({meta['num_points']} observed) / "
+                               f"{meta['num_obs']} Huber-robust Reprojection costs + Difference regularisers, batch {B}, adaptive "
+                               f"ellipsoidal LM (damping 1e-2) + Schur complement + tile-sparse Cholesky of the {nc} x {nc} "
+                               f"reduced camera system",
+                   "cameras": meta["num_cams"], "points": meta["num_points"], "observations": meta["num_obs"], "batch": B,
+                   "n": meta["n"], "n_reduced": nc},
+        "mean_error": [float(info.err_history[:, 0].mean()), float(info.err_history[:, info.iters_done].mean())],
+        "roofline": {
+            "bound": "mfma", "kernel": f"thx_{fname} on the reduced camera system (chol_diag + chol_offdiag launches per block "
+                                       f"column, non-zero tiles only)",
+            # EXECUTED flops (the band of the reduced system: structurally zero tiles are skipped) / HIP-event time
+            "achieved": executed / (fac["avg_ms"] * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+            "frac": executed / (fac["avg_ms"] * 1e-3) / 1e12 / peak, "traffic": None,
+            "flops_per_launch": executed, "avg_launch_ms": fac["avg_ms"],
+            "executed": None if pat is None else {
+                "of_dense": pat.flops / pat.dense_flops, "tiles_of_L": [pat.l_tiles, pat.ntiles * (pat.ntiles + 1) // 2],
+                "dense_equivalent_TFLOPs": dense_flops / (fac["avg_ms"] * 1e-3) / 1e12},
+            # SURVEY §8(d): the MFMA floor of one linear solve on executed flops, against the measured time per linear solve
+            "iteration": {"floor_ms": {"mfma_executed": round(executed / (peak * 1e12) * 1e3, 3)},
+                          "kernel_ms_per_solve": round(kernel_ms, 3), "ms_per_solve": dt / max(solves, 1) * 1e3,
+                          "device_gap_frac": round(1.0 - kernel_ms / (dt / max(solves, 1) * 1e3), 4),
+                          "frac": executed / (peak * 1e12) * 1e3 / (dt / max(solves, 1) * 1e3)}},
+        "phases_ms_per_call": {k: round(v["avg_ms"], 4) for k, v in phases.items()},
+    }
+    del sol, info, layer, opt, obj, timer, solver, start
+    free_device_memory()
+    # ---- parity: the HIP path in fp64 at THIS size against the REAL reference's dense run (tests/golden/ba_full_f64_lm.npz:
+    #      512 cameras / 8192 points / 32768 observations, one problem, two adaptive LM iterations; oracle/gen_golden.py) ----
+    if cfg.parity:
+        try:
+            from tests.ba_common import run_ba
+            from tests.helpers import load_golden
+            g = load_golden("ba_full_f64_lm")
+            cams, pts, used, _, pinfo, _ = run_ba(th, g, None, str(ctx.device))
+            k = min(pinfo.err_history.shape[1], g["err_history"].shape[1])
+            result["parity"] = {
+                "reference": "the reference's DenseLinearization + CholeskyDenseSolver run at 512 / 8192 / 32768, fp64, one "
+                             "problem, 2 adaptive LM iterations (tests/golden/ba_full_f64_lm.npz); HIP path in fp64",
+                "hip_max_abs_camera_err": float(np.abs(cams.cpu().numpy() - g["final_cams"]).max()),
+                "hip_max_abs_point_err": float(np.abs(pts.cpu().numpy() - g["final_pts"][:, used]).max()),
+                "hip_rel_err_cost_history": float(np.abs(pinfo.err_history[:, :k].numpy() / g["err_history"][:, :k] - 1).max())}
+            del cams, pts, pinfo
+        except FileNotFoundError as e:
+            result["parity"] = {"error": f"fixture missing: {e}"}
+        free_device_memory()
+    # ---- CPU baseline: the dense oracle (oracle/ba.py + oracle.pose_graph.lm_optimize: DenseLinearization + CholeskyDenseSolver
+    #      restated) at the 32-CAMERA size of tests/golden/ba_mid_f64_lm.npz -- at 512 cameras the dense A is 20.6 GB per
+    #      problem (one reference iteration there: ~5 min on 6 cores, DESIGN.md §4.3), not a bounded sample ----
+    if cfg.cpu_baseline:
+        try:
+            import ast
+            from oracle import pose_graph as opg
+            from tests.helpers import ba_problem, load_golden
+            g = load_golden("ba_mid_f64_lm")
+            p, state0, kwm, _ = ba_problem(g)
+            kwm = dict(kwm)
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                _, oinfo = opg.lm_optimize(p, state0, abs_err_tolerance=0.0, rel_err_tolerance=0.0, **kwm)
+            cpu_s = time.perf_counter() - t0
+            Bm = state0[0].shape[0]
+            result["cpu_baseline"] = {
+                "value": Bm * max(oinfo.iters_done, 1) / cpu_s, "unit": "problem-iterations/s", "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": f"REDUCED SIZE: {int(g['C'])} cameras / {int(g['Np'])} points / {g['obs_cam'].shape[0]} observations, "
+                          f"{Bm} problems x {oinfo.iters_done} LM iterations ({cpu_s:.1f} s), dense oracle (n = "
+                          f"{6 * int(g['C'])} + 3 x points); the 512-camera dense formulation is 20.6 GB of A per problem"}
+        except FileNotFoundError as e:
+            result["cpu_baseline"] = {"error": f"fixture missing: {e}"}
+    return result
 
 
 def main():
@@ -174,10 +654,14 @@ def main():
     ap.add_argument("--implicit", action="store_true",
                     help="BASELINE.json configs[4]: forward LM + implicit backward (one backward linear solve) through "
                          "TheseusLayer; measurement tensors require grad; a step = one LM iteration of the forward")
+    ap.add_argument("--legs", default="auto",
+                    help="the other BASELINE configs under 'configs' in the same line: 'auto' (default: all of them when the "
+                         "headline configuration is run unmodified), 'none', or a comma list of fp64,ba,implicit,strong")
     # TEST SEAM (tests/test_bench_cli.py): run the launcher / sharding / reporting logic without a GPU.  The numbers of such
     # a run are not measurements: the line says "data": "TEST-STANDIN" and carries no roofline.
     ap.add_argument("--test-kernels", default="", help=argparse.SUPPRESS)   # "module:Class" of a stand-in kernels class
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
+    ap.add_argument("--strong-total", type=int, default=32768, help=argparse.SUPPRESS)   # (the strong leg's job size; tests)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -193,6 +677,7 @@ def main():
     device = torch.device("cuda", 0 if one_device else local_rank) if on_gpu else torch.device("cpu")
     if on_gpu:
         torch.cuda.set_device(device)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if on_gpu and args.backend == "nccl":
@@ -201,252 +686,67 @@ def main():
             dist.init_process_group(args.backend)
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    dtype = torch.float32 if args.dtype == "f32" else torch.float64
-
-    import theseus_amd as th
-    from theseus_amd.utils import synthetic as syn
 
     kernels = None
     if standin:
         mod, cls = args.test_kernels.split(":")
         kernels = getattr(importlib.import_module(mod), cls)()
+    ctx = SimpleNamespace(world=world, rank=rank, device=device, on_gpu=on_gpu, kernels=kernels, dist=dist)
+    head = SimpleNamespace(poses=args.poses, edges=args.edges, batch=args.batch, total_batch=args.total_batch, steps=args.steps,
+                           warmup=args.warmup, dtype=args.dtype, damping=args.damping, adaptive=args.adaptive,
+                           solver=args.solver, implicit=args.implicit, cpu_sample=args.cpu_sample, cpu_chunk=args.cpu_chunk,
+                           cpu_iters=args.cpu_iters, parity_sample=args.parity_sample, sparse_leg=not args.no_sparse_leg)
+    result = pg_run(head, ctx)
 
-    P, E, B, K_iters, W = args.poses, args.edges, args.batch, args.steps, args.warmup
-    n = 6 * P
-    edges = syn.pose_graph_topology(P, E, topology_seed=0)
-    objective = syn.build_pose_graph_objective(edges, P, dtype=dtype, device=device)
-    solver_cls = th.HipSparseCholeskySolver if args.solver == "sparse" else th.HipCholeskySolver
-    opt = th.LevenbergMarquardt(objective, linear_solver_cls=solver_cls, max_iterations=K_iters,
-                                abs_err_tolerance=0.0, rel_err_tolerance=0.0, step_size=1.0,
-                                linearization_kwargs=dict(kernels=kernels) if standin else None)
-    if world > 1:
-        from theseus_amd.sharding import DistBatchReducer
-        opt.reducer = DistBatchReducer()  # batch-global predicates over all shards (one tiny all-reduce / iteration)
-    layer = th.TheseusLayer(opt)
-    timer = KernelTimer(opt.linear_solver.K)
-    strong = args.total_batch > 0
-    if strong:
-        from theseus_amd.sharding import plan_sub_batches
-        if args.implicit:
-            raise SystemExit("--total-batch is the forward configuration (configs[2]); not combined with --implicit")
-        try:
-            B, n_sub = plan_sub_batches(args.total_batch, rank, world, B)
-        except ValueError as e:
-            raise SystemExit(str(e))
+    # ---- the other BASELINE configs, as legs of the same line ----
+    unmodified = (args.dtype == "f32" and args.solver == "dense" and not args.implicit and args.total_batch == 0
+                  and not args.adaptive and args.poses == 256 and args.edges == 1024 and args.batch == 4096)
+    if args.legs == "auto":
+        legs = (["fp64", "ba", "implicit"] if world == 1 else ["strong"]) if (unmodified and on_gpu) else []
+    elif args.legs == "none":
+        legs = []
     else:
-        n_sub = 1
-    # every sub-batch's inputs are resident in HBM before the timed region (synthetic, one seed per rank and sub-batch)
-    sub_inputs = []
-    for c in range(n_sub):
-        tensors_c = syn.make_pose_graph_tensors(edges, P, B, dtype=dtype, device=device, seed=1234 + rank + 1000 * c,
-                                                kernels=kernels)
-        sub_inputs.append(syn.input_dict(tensors_c))
-        if c == 0:
-            tensors = tensors_c
-    inputs = sub_inputs[0]
-    okw = dict(damping=args.damping, adaptive_damping=args.adaptive)
+        legs = [x for x in args.legs.split(",") if x]
+    configs = {}
 
-    def sync():
-        if on_gpu:
-            torch.cuda.synchronize()
-
-    def barrier():
-        sync()
-        if world > 1:
-            dist.barrier()
-            sync()
-
-    bwd_ms, gather_ms = None, None
-    if args.implicit:
-        for k, v in inputs.items():
-            if k.startswith("EDGE_SE3__"):
-                v.requires_grad_(True)
-        okw = dict(okw, backward_mode="implicit")
-    with torch.set_grad_enabled(args.implicit):
-        if W > 0:
-            opt.set_params(max_iterations=max(W, 2) if args.implicit else W)
-            layer.forward(inputs, optimizer_kwargs=okw)
-        opt.set_params(max_iterations=K_iters)
-        barrier()
-        timer.enabled = on_gpu
+    def leg(name, fn):
         t0 = time.perf_counter()
-        sol, info = layer.forward(inputs, optimizer_kwargs=dict(track_err_history=True, **okw))
-        for more in sub_inputs[1:]:  # strong scaling: the rank's remaining sub-batches through the same workspaces
-            layer.forward(more, optimizer_kwargs=okw)
-        if args.implicit:  # backward: retract VJP + ONE linear solve with the cached factor + cost VJP
-            loss = torch.stack(list(sol.values())).sum()   # (one reduction over all poses; 256 separate .sum() calls were
-                                                            #  1.6 ms of 6 us kernels in the timed backward)
-            eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            eb0.record()
-            loss.backward()
-            eb1.record()
-            torch.cuda.synchronize()
-            bwd_ms = eb0.elapsed_time(eb1)
-        if world > 1:  # the one data-path collective: re-collect the solved poses on every rank (RCCL over xGMI)
-            from theseus_amd.sharding import gather_solution
-            sync()
-            tg0 = time.perf_counter()
-            gathered = gather_solution(opt.linear_solver.linearization.packed.tensors.poses)
-            sync()
-            gather_ms = (time.perf_counter() - tg0) * 1e3
-            assert gathered.shape[1] == world * B
-        local_dt = time.perf_counter() - t0   # this rank's own work, before it waits for the others
-        barrier()
-        dt = time.perf_counter() - t0
-        timer.enabled = False
-    rank_ms = [local_dt * 1e3]
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        every = [None] * world
-        dist.all_gather_object(every, (local_dt * 1e3, gather_ms))
-        rank_ms = [e[0] for e in every]
-        gather_ms = max(e[1] for e in every)
+        try:
+            r = fn()
+        except Exception as e:   # a leg must not take the headline down with it; the line says what happened
+            import traceback
+            traceback.print_exc()
+            if world > 1:
+                raise            # (collectives in flight: the other ranks cannot be left waiting)
+            r = {"error": f"{type(e).__name__}: {e}"}
+            free_device_memory()
+        if r is not None:
+            r["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+            configs[name] = r
 
-    iters_done = info.iters_done
+    def variant(**kw):
+        d = dict(vars(head))
+        d.update(kw)
+        return SimpleNamespace(**d)
+
+    if "fp64" in legs and world == 1:
+        leg("fp64_b4096", lambda: pg_run(variant(dtype="f64", cpu_sample=min(args.cpu_sample, 32), sparse_leg=False), ctx))
+    if "ba" in legs and world == 1 and not standin:
+        leg("ba_512_8192_32768_b256", lambda: ba_run(SimpleNamespace(cams=512, points=8192, batch=256, dtype="f32", steps=5,
+                                                                     warmup=2, parity=args.parity_sample > 0,
+                                                                     cpu_baseline=args.cpu_sample > 0), ctx))
+    if "implicit" in legs and world == 1:
+        leg("implicit_b1024", lambda: pg_run(variant(implicit=True, batch=min(1024, args.batch), sparse_leg=False,
+                                                     cpu_sample=min(args.cpu_sample, 16), parity_sample=min(args.parity_sample, 4)),
+                                             ctx))
+    if "strong" in legs:
+        # BASELINE.json configs[2]: 32768 fp64 problems over the N GPUs of the node, each rank's share in sub-batches of 4096
+        leg("strong_f64_32768" if args.strong_total == 32768 else f"strong_{args.dtype if standin else 'f64'}_{args.strong_total}",
+            lambda: pg_run(variant(dtype=args.dtype if standin else "f64", total_batch=args.strong_total,
+                                   batch=min(4096, args.batch), sparse_leg=False), ctx))
     if rank == 0:
-        phases = timer.summary()
-        es = 4 if args.dtype == "f32" else 8
-        err_hist = info.err_history
-        result = {
-            "metric": "LM iterations/sec (batch x vars) on SE3 pose-graph",
-            "value": world * n_sub * B * iters_done / dt,
-            "unit": "problem-iterations/s",
-            "n_gpus": world, "steps": K_iters, "warmup": W, "ms_per_step": dt / max(iters_done, 1) * 1e3,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic" if on_gpu else "TEST-STANDIN",
-            "config": {"workload": f"SE3 pose-graph {P} poses / {E} Between edges + 1 prior, batch {n_sub * B} per GPU, "
-                                   f"LM damping {args.damping}{' adaptive' if args.adaptive else ''} + "
-                                   f"{'tile-sparse Cholesky (RCM ordering)' if args.solver == 'sparse' else 'dense Cholesky'}",
-                       "poses": P, "edges": E, "batch_per_gpu": n_sub * B, "global_batch": world * n_sub * B, "n": n,
-                       "parallelism": f"batch-shard x{world}" + (f", {n_sub} sub-batches of {B} per GPU" if strong else "")},
-            "ranks": world if world == 1 else dist.get_world_size(),
-            "collective_backend": None if world == 1 else dist.get_backend(),
-            "rank_ms_per_step": {"min": min(rank_ms) / max(iters_done, 1), "max": max(rank_ms) / max(iters_done, 1)},
-            "all_gather_ms": gather_ms,
-            "pose_updates_per_s": world * n_sub * B * iters_done * P / dt,
-            "iters_done": iters_done,
-            "mean_error": [float(err_hist[:, 0].mean()), float(err_hist[:, iters_done].mean())],
-        }
-        if on_gpu:
-            fac = phases.get("chol_factor_sparse" if args.solver == "sparse" else "chol_factor", {"avg_ms": float("nan")})
-            # n^3/3 flops per problem x B problems per thx_chol_factor_forward call (the 2n^2 of the
-            # fused forward substitution are not counted)
-            flops_per_launch = B * (n ** 3) / 3.0
-            achieved = flops_per_launch / (fac["avg_ms"] * 1e-3) / 1e12
-            peak = PEAK[args.dtype]
-            traffic, traffic_src = None, None
-            try:  # measured offline with rocprofv3 --pmc (bench.py cannot profile itself): profiles/traffic.json
-                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"{args.dtype}_n{n}_b{B}")
-                if tj:
-                    traffic, traffic_src = tj["bytes_per_factor_call"], tj["source"]
-            except (OSError, ValueError, KeyError):
-                pass
-            # the HBM-bound kernels of the iteration: algorithmic bytes / HIP-event time
-            hbm = {}
-            for name, per_problem in algorithmic_bytes(P, E, es).items():
-                if name in phases:
-                    gbs = per_problem * B / (phases[name]["avg_ms"] * 1e-3) / 1e9
-                    hbm[name] = {"avg_ms": round(phases[name]["avg_ms"], 4), "algorithmic_GBps": round(gbs, 1),
-                                 "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
-            # SURVEY §8(d) per problem-iteration totals: n^3/3 + 2n^2 flops, 5 n^2/2-ish bytes (23.7 MB fp32 at n = 1536)
-            t_mfma = B * (n ** 3 / 3.0 + 2.0 * n * n) / (peak * 1e12) * 1e3
-            t_hbm = B * (4 * n * (n + 1) / 2 * es + (P + E + 1) * 12 * es + 2 * n * es) / (HBM_PEAK_GBS * 1e9) * 1e3
-            result["roofline"] = {
-                "bound": "mfma", "kernel": "thx_chol_factor_forward (chol_diag + chol_offdiag launches per block column)",
-                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": traffic, "traffic_unit": "bytes per thx_chol_factor_forward call (PMC, rocprofv3)",
-                "traffic_source": traffic_src, "flops_per_launch": flops_per_launch, "avg_launch_ms": fac["avg_ms"],
-                "hbm_bound_kernels": hbm,
-                # "achieved" above is the contract's figure: ALGORITHMIC flops (dense n^3 / 3 per problem) / time.  The tile-sparse
-                # solver executes fewer: the matrix cores' own utilisation is executed flops / time / peak.
-                "executed": None if args.solver != "sparse" else {
-                    "flops_per_launch": B * opt.linear_solver.pattern.flops,
-                    "of_dense": opt.linear_solver.pattern.flops / opt.linear_solver.pattern.dense_flops,
-                    "tiles_of_L": [opt.linear_solver.pattern.l_tiles, opt.linear_solver.pattern.ntiles * (opt.linear_solver.pattern.ntiles + 1) // 2],
-                    "TFLOPs": B * opt.linear_solver.pattern.flops / (fac["avg_ms"] * 1e-3) / 1e12,
-                    "frac": B * opt.linear_solver.pattern.flops / (fac["avg_ms"] * 1e-3) / 1e12 / peak},
-                "iteration": {"floor_ms": {"mfma": round(t_mfma, 3), "hbm": round(t_hbm, 3)},
-                              "ms_per_step": dt / max(iters_done, 1) * 1e3 / n_sub,
-                              "frac": max(t_mfma, t_hbm) / (dt / max(iters_done, 1) * 1e3 / n_sub)}}
-            result["phases_ms_per_call"] = {k: round(v["avg_ms"], 4) for k, v in phases.items()}
-        if args.implicit:
-            result["config"]["workload"] += " + implicit backward through TheseusLayer"
-            result["implicit_backward_ms"] = bwd_ms
-        S, CI = min(args.cpu_sample, B), args.cpu_iters
-        cpu_final = cpu_hist = None
-        if world > 1:
-            # the CPU baseline and the parity sub-sample are rank-0-only legs: at N > 1 the other ranks are already waiting in the
-            # final barrier, and the parity run would issue the sharded loop's all-reduces alone.  They belong to the N = 1 line.
-            S = 0
-            args.parity_sample = 0
-        if S > 0 and not args.implicit:
-            v, cores, cpu_final, cpu_s, cpu_hist = cpu_baseline(tensors, edges, P, dtype, S, CI, args.damping, args.cpu_chunk)
-            result["cpu_baseline"] = {"value": v, "unit": "problem-iterations/s", "cores": cores, "kind": "port",
-                                      "sample": f"first {S} problems of rank 0's batch in chunks of {min(args.cpu_chunk, S)} x "
-                                                f"{CI} LM iterations ({cpu_s:.1f} s), oracle.pose_graph.lm_optimize (torch-CPU/"
-                                                f"MKL restatement of DenseLinearization + CholeskyDenseSolver)"}
-            result["speedup_vs_cpu"] = result["value"] / v
-        SP = min(args.parity_sample, B)
-        if SP > 0 and not args.implicit:
-            # parity of the HIP path on a sub-sample, against the exact (fp64) evaluation of the same problem -- for the
-            # fp64 path that is the oracle itself (pinned to the reference at this size: tests/golden/pg_full_f64_lm.npz),
-            # for fp32 the CPU port's own distance from exact is printed next to it (the fp32 band).
-            # *_rel_pose_err is gauge-free (relative poses along the chain): the prior of weight 1e-3 pins the gauge weakly.
-            ex_final, ex_hist = exact_reference(tensors, edges, P, dtype, SP, CI, args.damping)
-            sub = {k: t[:SP].contiguous() for k, t in inputs.items()}
-            opt.set_params(max_iterations=CI)
-            with torch.no_grad():
-                sol_s, info_s = layer.forward(sub, optimizer_kwargs=dict(track_err_history=True, **okw))
-            got = torch.stack([sol_s[f"VERTEX_SE3__{k}"] for k in range(P)], 1).cpu().double()
-            rel = lambda h: float(((h.double()[:, CI] - ex_hist[:, CI]).abs() / ex_hist[:, CI].abs()).max())  # noqa
-            result["parity"] = {
-                "reference": "fp64 oracle (exact evaluation of the same inputs)", "problems": SP, "iters": CI,
-                "hip_max_abs_pose_err": float((got - ex_final).abs().max()),
-                "hip_max_rel_pose_err": float((relative_poses(got) - relative_poses(ex_final)).abs().max()),
-                "hip_rel_err_final_cost": rel(info_s.err_history)}
-            if cpu_final is not None and S >= SP:
-                c = cpu_final[:SP].double()
-                result["parity"].update({
-                    "cpu_port_max_abs_pose_err": float((c - ex_final).abs().max()),
-                    "cpu_port_max_rel_pose_err": float((relative_poses(c) - relative_poses(ex_final)).abs().max()),
-                    "cpu_port_rel_err_final_cost": rel(cpu_hist[:SP])})
-        if (on_gpu and world == 1 and args.solver == "dense" and not args.no_sparse_leg and not args.implicit and not strong):
-            # ---- the same workload once more with HipSparseCholeskySolver (theseus_amd/sparse.py): same kernels, reverse
-            #      Cuthill-McKee variable ordering, structurally zero tiles of L and K-loop blocks skipped.  Reported NEXT TO the
-            #      dense headline (value / roofline above are the dense solver's).  The dense solver's workspaces are freed first.
-            import gc
-            del sol, info, layer, opt, objective, timer
-            gc.collect()
-            torch.cuda.empty_cache()
-            obj2 = syn.build_pose_graph_objective(edges, P, dtype=dtype, device=device)
-            opt2 = th.LevenbergMarquardt(obj2, linear_solver_cls=th.HipSparseCholeskySolver, max_iterations=K_iters,
-                                         abs_err_tolerance=0.0, rel_err_tolerance=0.0, step_size=1.0)
-            layer2 = th.TheseusLayer(opt2)
-            timer2 = KernelTimer(opt2.linear_solver.K)
-            with torch.no_grad():
-                if W > 0:
-                    opt2.set_params(max_iterations=W)
-                    layer2.forward(inputs, optimizer_kwargs=okw)
-                opt2.set_params(max_iterations=K_iters)
-                torch.cuda.synchronize()
-                timer2.enabled = True
-                t0 = time.perf_counter()
-                sol2, info2 = layer2.forward(inputs, optimizer_kwargs=dict(track_err_history=True, **okw))
-                torch.cuda.synchronize()
-                dt2 = time.perf_counter() - t0
-                timer2.enabled = False
-            pat = opt2.linear_solver.pattern
-            fms = timer2.summary()["chol_factor_sparse"]["avg_ms"]
-            result["tile_sparse"] = {
-                "solver": "HipSparseCholeskySolver (reverse Cuthill-McKee ordering, tile pattern of L)",
-                "value": B * info2.iters_done / dt2, "unit": "problem-iterations/s", "ms_per_step": dt2 / info2.iters_done * 1e3,
-                "factor_ms": fms, "tiles_of_L": [pat.l_tiles, pat.ntiles * (pat.ntiles + 1) // 2],
-                "executed_flops_of_dense": pat.flops / pat.dense_flops,
-                "executed_TFLOPs": B * pat.flops / (fms * 1e-3) / 1e12,
-                "executed_frac_of_peak": B * pat.flops / (fms * 1e-3) / 1e12 / PEAK[args.dtype],
-                "mean_error": [float(info2.err_history[:, 0].mean()), float(info2.err_history[:, info2.iters_done].mean())]}
+        if configs:
+            result["configs"] = configs
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -220,35 +220,12 @@ def gen_pg_full(th, lieF, only=None):
     DenseLinearization + CholeskyDenseSolver.  Data model of the benchmark (random-walk ground truth, noisy measurements and
     initial poses: dataset.py:238-365), drawn here on the CPU with the reference's own SE3 ops.  Dense A is 75.6 MB per
     problem in fp64: the fixture keeps Atb, the steps, the errors and the solution (no A / AtA)."""
-    from theseus_amd.utils.synthetic import PRIOR_WEIGHT, ROTATION_NOISE, TRANSLATION_NOISE, pose_graph_topology
     P, E, ITERS = 256, 1024, 3
-    SE3 = lieF.SE3
     for name, dtype, B, seed in (("pg_full_f64_lm", torch.float64, 2, 101), ("pg_full_f32_lm", torch.float32, 4, 102)):
         if only and name not in only:
             continue
-        gen = torch.Generator().manual_seed(seed)
-        edges = torch.tensor(pose_graph_topology(P, E, topology_seed=0), dtype=torch.long)
-
-        def noise(n):
-            u = 2.0 * torch.rand(n, 6, dtype=torch.float64, generator=gen) - 1.0
-            u[:, :3] *= TRANSLATION_NOISE
-            u[:, 3:] *= ROTATION_NOISE
-            return SE3.exp(u)
-        gt = [torch.eye(3, 4, dtype=torch.float64).expand(B, 3, 4).contiguous()]
-        for k in range(1, P):
-            u = torch.rand(B, 6, dtype=torch.float64, generator=gen)
-            u[:, :3] -= 0.5
-            u[:, 3:] = 2.0 * u[:, 3:] - 1.0
-            gt.append(SE3.compose(gt[-1], SE3.exp(u)))
-        gt = torch.stack(gt, 1)                                                            # (B, P, 3, 4)
-        poses0 = SE3.compose(gt.reshape(-1, 3, 4), noise(B * P)).view(B, P, 3, 4)
-        gi, gj = gt[:, edges[:, 0]].reshape(-1, 3, 4), gt[:, edges[:, 1]].reshape(-1, 3, 4)
-        meas = SE3.compose(SE3.compose(SE3.inv(gi), gj), noise(B * E)).view(B, E, 3, 4)
-        f = lambda t: t.to(dtype)  # noqa: E731
-        d = dict(P=P, edges=edges, meas=f(meas), poses=f(poses0),
-                 w_between=f(torch.tensor([[[1 / TRANSLATION_NOISE] * 3 + [1 / ROTATION_NOISE] * 3]], dtype=torch.float64).repeat(1, E, 1)),
-                 prior_idx=torch.tensor([0]), prior_target=f(poses0[:, :1]).clone(),
-                 w_prior=torch.full((1, 1, 6), PRIOR_WEIGHT, dtype=dtype))
+        d = full_size_data(lieF, B, seed, dtype)
+        edges = d["edges"]
         obj, poses = build_reference_objective(th, d, dtype)
         opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, abs_err_tolerance=0.0,
                                     rel_err_tolerance=0.0, max_iterations=ITERS, step_size=1.0)
@@ -440,6 +417,96 @@ def gen_so3(th, lieF):
             var_start_cols=np.array(lin.var_start_cols), var_dims=np.array(lin.var_dims), num_rows=lin.num_rows,
             num_cols=lin.num_cols, opt_kwargs=np.array(repr(dict(ok, **lmk, gauss_newton=False))))
         print(name, "err", err0.mean(), "->", info.err_history[:, -1].mean().item())
+
+
+def full_size_data(lieF, B, seed, dtype):
+    """The benchmark's data model at 256 poses / 1024 edges (see gen_pg_full)."""
+    from theseus_amd.utils.synthetic import PRIOR_WEIGHT, ROTATION_NOISE, TRANSLATION_NOISE, pose_graph_topology
+    P, E = 256, 1024
+    SE3 = lieF.SE3
+    gen = torch.Generator().manual_seed(seed)
+    edges = torch.tensor(pose_graph_topology(P, E, topology_seed=0), dtype=torch.long)
+
+    def noise(n):
+        u = 2.0 * torch.rand(n, 6, dtype=torch.float64, generator=gen) - 1.0
+        u[:, :3] *= TRANSLATION_NOISE
+        u[:, 3:] *= ROTATION_NOISE
+        return SE3.exp(u)
+    gt = [torch.eye(3, 4, dtype=torch.float64).expand(B, 3, 4).contiguous()]
+    for k in range(1, P):
+        u = torch.rand(B, 6, dtype=torch.float64, generator=gen)
+        u[:, :3] -= 0.5
+        u[:, 3:] = 2.0 * u[:, 3:] - 1.0
+        gt.append(SE3.compose(gt[-1], SE3.exp(u)))
+    gt = torch.stack(gt, 1)
+    poses0 = SE3.compose(gt.reshape(-1, 3, 4), noise(B * P)).view(B, P, 3, 4)
+    gi, gj = gt[:, edges[:, 0]].reshape(-1, 3, 4), gt[:, edges[:, 1]].reshape(-1, 3, 4)
+    meas = SE3.compose(SE3.compose(SE3.inv(gi), gj), noise(B * E)).view(B, E, 3, 4)
+    f = lambda t: t.to(dtype)  # noqa: E731
+    return dict(P=P, edges=edges, meas=f(meas), poses=f(poses0),
+                w_between=f(torch.tensor([[[1 / TRANSLATION_NOISE] * 3 + [1 / ROTATION_NOISE] * 3]], dtype=torch.float64).repeat(1, E, 1)),
+                prior_idx=torch.tensor([0]), prior_target=f(poses0[:, :1]).clone(),
+                w_prior=torch.full((1, 1, 6), PRIOR_WEIGHT, dtype=dtype))
+
+
+def gen_pg_full_implicit(th, lieF):
+    """BASELINE.json configs[4] at the size it names: 256 SE3 poses / 1024 Between edges + the 1e-3 prior (the benchmark's
+    topology and data model), TheseusLayer(backward_mode="implicit") through the REAL reference's LevenbergMarquardt +
+    DenseLinearization + CholeskyDenseSolver (nonlinear_least_squares.py:121-135,265-292): LM iterations under no_grad, one
+    undamped Gauss-Newton step with the Hessian detached and grad enabled; loss = <coef, final poses>; gradients w.r.t. the
+    1024 measurements, the shared DiagonalCostWeight, the prior target and the prior's ScaleCostWeight.  fp64, B = 2."""
+    dtype, B, iters = torch.float64, 2, 3
+    d = full_size_data(lieF, B, 201, dtype)
+    P = d["P"]
+    meas = d["meas"].clone().requires_grad_(True)
+    wb = d["w_between"].clone().requires_grad_(True)
+    tgt = d["prior_target"].clone().requires_grad_(True)
+    wp = d["w_prior"][:, :, :1].clone().requires_grad_(True)
+    obj = th.Objective(dtype=dtype)
+    poses = [th.SE3(tensor=d["poses"][:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    for k in range(d["edges"].shape[0]):
+        i, j = d["edges"][k].tolist()
+        cw = th.DiagonalCostWeight(th.Variable(wb[:, k], name=f"w_{k}"))
+        obj.add(th.Between(poses[i], poses[j], th.SE3(tensor=meas[:, k], name=f"meas_{k}"), cw, name=f"between_{k}"))
+    sw = th.ScaleCostWeight(th.Variable(wp[:, 0], name="pw_0"))
+    obj.add(th.Difference(poses[0], th.SE3(tensor=tgt[:, 0], name="prior_target_0"), sw, name="prior_0"))
+    opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, max_iterations=iters,
+                                step_size=1.0, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    sol, info = th.TheseusLayer(opt).forward(optimizer_kwargs=dict(backward_mode="implicit", damping=1e-3))
+    gen5 = torch.Generator().manual_seed(5)
+    coef = torch.randn(B, P, 3, 4, dtype=dtype, generator=gen5)
+    coef_rel = torch.randn(B, P - 1, 3, 4, dtype=dtype, generator=gen5)
+    final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
+    leaves = dict(meas=meas, w_between=wb, prior_target=tgt, w_prior=wp)
+    # (1) the loss of the small fixtures, <coef, final poses>.  At this size the undamped Gauss-Newton system of the last step has
+    #     cond ~ 6e14 (the prior of weight 1e-3 is all that pins the gauge): the gauge component of the step -- and of these
+    #     gradients -- carries eps * cond ~ 1e-2 relative rounding in ANY fp64 evaluation (the oracle's differ from these by 4e-4 ...
+    #     5e-3).  Kept as the loose pin.
+    loss = (coef * final).sum()
+    loss.backward(retain_graph=True)
+    grads = {k: v.grad.clone() for k, v in leaves.items()}
+    for v in leaves.values():
+        v.grad = None
+    # (2) a GAUGE-FREE loss, <coef_rel, X_k^-1 X_{k+1}> along the odometry chain (the reference's own differentiable SE3 ops):
+    #     its gradients do not excite the gauge mode and are reproducible to rounding -- the tight pin.
+    SE3 = lieF.SE3
+    relp = SE3.compose(SE3.inv(final[:, :-1].reshape(-1, 3, 4)), final[:, 1:].reshape(-1, 3, 4)).view(B, P - 1, 3, 4)
+    loss_rel = (coef_rel * relp).sum()
+    loss_rel.backward()
+    np.savez_compressed(
+        os.path.join(OUT, "pg_full_f64_implicit.npz"),
+        P=P, edges=d["edges"].numpy(), meas=d["meas"].numpy(), w_between=d["w_between"].numpy(),
+        prior_idx=d["prior_idx"].numpy(), prior_target=d["prior_target"].numpy(), w_prior=d["w_prior"].numpy(),
+        poses0=d["poses"].numpy(), final=final.detach().numpy(), coef=coef.numpy(), loss=loss.item(),
+        grad_meas=grads["meas"].numpy(), grad_w_between=grads["w_between"].numpy(),
+        grad_prior_target=grads["prior_target"].numpy(), grad_w_prior=grads["w_prior"].numpy(),
+        coef_rel=coef_rel.numpy(), loss_rel=loss_rel.item(), rel_final=relp.detach().numpy(),
+        grad_rel_meas=meas.grad.numpy(), grad_rel_w_between=wb.grad.numpy(), grad_rel_prior_target=tgt.grad.numpy(),
+        grad_rel_w_prior=wp.grad.numpy(),
+        opt_kwargs=np.array(repr(dict(max_iterations=iters, step_size=1.0, damping=1e-3, gauss_newton=False))))
+    print("pg_full_f64_implicit loss", loss.item(), "gauge-free loss", loss_rel.item(), "|grad_rel_meas|", meas.grad.abs().max().item(),
+          "|grad_rel_wb|", wb.grad.abs().max().item(), "|grad_rel_tgt|", tgt.grad.abs().max().item(),
+          "|grad_rel_wp|", wp.grad.abs().max().item())
 
 
 def gen_implicit(th, lieF):
@@ -770,17 +837,17 @@ def gen_ba(th, only=None):
               Np - len(pt_prior_idx))
 
 
-def gen_ba_implicit(th):
+def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5):
     """Implicit backward through a bundle-adjustment objective (examples/bundle_adjustment.py:184-215 learns log_loss_radius this
     way): LM under no_grad, one undamped GN step with the Hessian detached and grad enabled; loss = <coef, final cameras> +
     <coef, final points>; gradients w.r.t. log_loss_radius, the image features, the calibration (focal, k1, k2), the
     observation weight, the strong camera priors' targets and weight, the regularisers' weight."""
     import theseus.utils.examples as theg
-    dtype, B, iters, robust = torch.float64, 3, 5, "huber"
+    dtype, robust = torch.float64, "huber"
+    dims = dims or dict(num_cameras=6, num_points=40, average_track_length=4, track_locality=0.3)
     torch.manual_seed(3)
     np.random.seed(3)
-    ba = theg.BundleAdjustmentDataset.generate_synthetic(num_cameras=6, num_points=40, average_track_length=4, track_locality=0.3,
-                                                         feat_random=1.5, outlier_feat_random=70)
+    ba = theg.BundleAdjustmentDataset.generate_synthetic(feat_random=1.5, outlier_feat_random=70, **dims)
     gen = torch.Generator().manual_seed(19)
     C, Np, O = len(ba.cameras), len(ba.points), len(ba.observations)
     lieF = __import__("torchlie.functional", fromlist=["SE3"])
@@ -850,7 +917,7 @@ def gen_ba_implicit(th):
     cam_prior_target = torch.cat([torch.eye(3, 4, dtype=dtype).view(1, 1, 3, 4).repeat(1, n_reg_cam, 1, 1), leaves["gt_cams"].detach()], 1)
     w_cam_prior = torch.cat([torch.full((1, n_reg_cam, 6), float(leaves["w_reg"]), dtype=dtype), torch.full((1, 2, 6), 100.0, dtype=dtype)], 1)
     np.savez_compressed(
-        os.path.join(OUT, "ba_f64_implicit.npz"), C=C, Np=Np, obs_cam=obs_cam, obs_pt=obs_pt, feat=d(leaves["feat"]),
+        os.path.join(OUT, name + ".npz"), C=C, Np=Np, obs_cam=obs_cam, obs_pt=obs_pt, feat=d(leaves["feat"]),
         focal=d(leaves["focal"]), k1=d(leaves["k1"]), k2=d(leaves["k2"]), cams0=cams0.numpy(), pts0=pts0.numpy(),
         cam_prior_idx=np.array(cam_prior_idx, dtype=np.int64), cam_prior_target=cam_prior_target.numpy(), w_cam_prior=w_cam_prior.numpy(),
         pt_prior_idx=np.array(pt_prior_idx, dtype=np.int64), w_pt_prior=np.full((1, len(pt_prior_idx), 3), float(leaves["w_reg"])),
@@ -862,7 +929,7 @@ def gen_ba_implicit(th):
         grad_k1=d(leaves["k1"].grad), grad_k2=d(leaves["k2"].grad), grad_w_obs=d(leaves["w_obs"].grad),
         grad_gt_cams=d(leaves["gt_cams"].grad), grad_w_strong=d(leaves["w_strong"].grad), grad_w_reg=d(leaves["w_reg"].grad),
         opt_kwargs=np.array(repr(dict(max_iterations=iters, step_size=1.0, damping=1e-2, gauss_newton=False))))
-    print("ba_f64_implicit loss", loss.item(), {k: float(v.grad.abs().max()) for k, v in leaves.items()})
+    print(name, "loss", loss.item(), {k: float(v.grad.abs().max()) for k, v in leaves.items()})
 
 
 def gen_g2o(th):
@@ -930,6 +997,11 @@ def main():
         gen_pg_full(th, lieF, only & {"pg_full_f64_lm", "pg_full_f32_lm"})
     if not only or "ba_implicit" in only:
         gen_ba_implicit(th)
+    if "pg_full_f64_implicit" in only:     # (full size: asked for by name, ~1 min)
+        gen_pg_full_implicit(th, lieF)
+    if "ba_mid_f64_implicit" in only:      # 32 cameras: the reduced camera system takes two Cholesky tiles
+        gen_ba_implicit(th, name="ba_mid_f64_implicit", B=2, iters=3,
+                        dims=dict(num_cameras=32, num_points=512, average_track_length=4, track_locality=0.2))
     if not only or "g2o" in only:
         gen_g2o(th)
     print("wrote", sorted(os.listdir(OUT)))

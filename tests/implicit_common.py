@@ -6,7 +6,14 @@ import torch
 from tests.helpers import golden_problem
 
 
-def run_implicit(th, g, device, kernels=None):
+def relative_poses(X):
+    """(B, P, 3, 4) -> X_k^-1 X_{k+1} (B, P-1, 3, 4): plain differentiable torch ops on any device (gauge-free view)."""
+    R0, t0, R1, t1 = X[:, :-1, :, :3], X[:, :-1, :, 3:], X[:, 1:, :, :3], X[:, 1:, :, 3:]
+    Rt = R0.transpose(-1, -2)
+    return torch.cat([Rt @ R1, Rt @ (t1 - t0)], -1)
+
+
+def run_implicit(th, g, device, kernels=None, gauge_free=False):
     t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
     _, _, kw = golden_problem(g)
     kw.pop("gauss_newton")
@@ -34,8 +41,43 @@ def run_implicit(th, g, device, kernels=None):
     sol, info = layer.forward(None, optimizer_kwargs=dict(backward_mode="implicit", track_err_history=True, **kw))
     final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
     loss = (t(g["coef"]) * final).sum()
-    loss.backward()
-    return final.detach().cpu(), float(loss.detach()), {k: v.grad.detach().cpu() for k, v in leaves.items()}, info, opt, layer
+    loss.backward(retain_graph=gauge_free)
+    grads = {k: v.grad.detach().cpu() for k, v in leaves.items()}
+    if gauge_free:   # second loss of the full-size fixture: <coef_rel, relative poses along the chain>
+        for v in leaves.values():
+            v.grad = None
+        loss_rel = (t(g["coef_rel"]) * relative_poses(final)).sum()
+        loss_rel.backward()
+        grads["gauge_free"] = {k: v.grad.detach().cpu() for k, v in leaves.items()}
+        grads["loss_rel"] = float(loss_rel.detach())
+    return final.detach().cpu(), float(loss.detach()), grads, info, opt, layer
+
+
+def check_full_size_implicit(g, final, loss, grads, tag):
+    """tests/golden/pg_full_f64_implicit.npz (256 poses / 1024 edges, the REAL reference's implicit backward).  The undamped
+    Gauss-Newton system of the last step has cond ~ 6e14 at this size (prior weight 1e-3): gauge-sensitive quantities are
+    reproducible to eps * cond only, gauge-free ones to rounding."""
+    ref = torch.from_numpy(g["final"])
+    d_abs = (final - ref).abs().max().item()
+    d_rel = (relative_poses(final) - torch.from_numpy(g["rel_final"])).abs().max().item()
+    print(f"[{tag}] max |pose - reference| = {d_abs:.2e} (gauge included), relative poses {d_rel:.2e}")
+    assert d_abs <= 5e-4 and d_rel <= 1e-9, (d_abs, d_rel)
+    # the fixture's <coef, final poses> loss: the loose pin
+    assert abs(loss - float(g["loss"])) <= 1e-3 * abs(float(g["loss"]))
+    for key, ref_key in (("meas", "grad_meas"), ("w_between", "grad_w_between"), ("prior_target", "grad_prior_target"),
+                         ("w_prior", "grad_w_prior")):
+        want = g[ref_key]
+        d = np.abs(grads[key].numpy() - want).max() / np.abs(want).max()
+        print(f"[{tag}] gauge-sensitive loss, grad {key}: {d:.2e}")
+        assert d <= 3e-2, (key, d)
+    # the gauge-free loss: the tight pin
+    assert abs(grads["loss_rel"] - float(g["loss_rel"])) <= 1e-8 * max(1.0, abs(float(g["loss_rel"])))
+    for key, ref_key, tol in (("meas", "grad_rel_meas", 2e-5), ("w_between", "grad_rel_w_between", 2e-5),
+                              ("prior_target", "grad_rel_prior_target", 2e-3), ("w_prior", "grad_rel_w_prior", 2e-3)):
+        want = g[ref_key]
+        d = np.abs(grads["gauge_free"][key].numpy() - want).max() / np.abs(want).max()
+        print(f"[{tag}] gauge-free loss, grad {key}: {d:.2e}")
+        assert d <= tol, (key, d)
 
 
 def check_against_reference(g, final, loss, grads, rel=2e-6):

@@ -56,3 +56,21 @@ def test_gpus_2_with_the_default_rank0_legs_does_not_hang():
     assert r["n_gpus"] == 2 and "cpu_baseline" not in r and "parity" not in r
     r1 = _bench("--batch", "3", seam=seam)
     assert r1["n_gpus"] == 1 and r1["cpu_baseline"]["kind"] == "port" and "parity" in r1
+
+
+def test_gpus_2_emits_the_strong_scaling_leg_in_the_same_line():
+    """At N > 1 the driver's ONE command must also yield BASELINE.json configs[2] (a fixed job sharded over the ranks, sub-batches,
+    all_gather): the leg rides under "configs" next to the weak-scaling headline, every rank takes part in it."""
+    r = _bench("--gpus", "2", "--batch", "2", "--legs", "strong", "--strong-total", "8")
+    assert r["scaling"] == "weak" and r["config"]["global_batch"] == 4
+    leg = r["configs"]["strong_f64_8"]
+    assert leg["scaling"] == "strong" and leg["n_gpus"] == 2 and leg["config"]["global_batch"] == 8
+    assert leg["config"]["batch_per_gpu"] == 4 and "2 sub-batches of 2" in leg["config"]["parallelism"]
+    assert leg["all_gather_ms"] is not None and leg["iters_done"] == 2
+    assert leg["rank_ms_per_step"]["min"] <= leg["rank_ms_per_step"]["max"]
+
+
+def test_single_rank_legs_ride_in_the_same_line():
+    r = _bench("--batch", "2", "--legs", "fp64")
+    assert r["n_gpus"] == 1 and r["configs"]["fp64_b4096"]["dtype"] == "f64" and r["configs"]["fp64_b4096"]["iters_done"] == 2
+    assert "configs" not in _bench("--batch", "2")          # a modified headline run carries no legs by default

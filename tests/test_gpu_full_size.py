@@ -194,3 +194,18 @@ def test_fp32_inside_the_reference_band_at_full_size():
         dd = (d.cpu().double() - xinfo.deltas[it]).abs().max().item()
         dr = (torch.from_numpy(g["delta"][it]).double() - xinfo.deltas[it]).abs().max().item()
         assert dd <= 1.5 * dr + 1e-6, (it, dd, dr)
+
+
+# ---- config 4 at the size it names: implicit-backward gradients of the REAL reference at 256 poses / 1024 edges ---------------
+def test_implicit_gradients_match_the_reference_at_full_size():
+    """BASELINE.json configs[4]'s path -- forward LM, the grad-enabled Gauss-Newton step, backward = thx_se3_retract_vjp -> ONE
+    thx_chol_solve with the cached 12-tile factor -> thx_pg_vjp over 1024 edges -- against the gradients the reference's
+    TheseusLayer(backward_mode="implicit") produced at this size (oracle/gen_golden.py:gen_pg_full_implicit, fp64, B = 2)."""
+    import theseus_amd as th
+    from tests.helpers import load_golden
+    from tests.implicit_common import check_full_size_implicit, run_implicit
+    g = load_golden("pg_full_f64_implicit")
+    assert int(g["P"]) == P and g["edges"].shape[0] == E
+    final, loss, grads, info, opt, _ = run_implicit(th, g, "cuda", gauge_free=True)
+    assert opt.linear_solver.L.shape[-1] >= 1536        # the dense 12-tile factor
+    check_full_size_implicit(g, final, loss, grads, "full size implicit fp64, HIP")

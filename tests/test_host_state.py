@@ -56,6 +56,30 @@ def test_a_second_forward_does_not_overwrite_the_first_solution():
     assert any(not torch.equal(sol2[k], keep[k]) for k in keep)
 
 
+def test_exception_inside_optimize_does_not_poison_the_next_forward():
+    """an exception after privatize_state() used to leave ``_vars_stale`` set; the next forward(new_inputs) then
+    flushed the stale private buffer over the user's new tensors and optimised the OLD problem."""
+    th, g, obj, opt, layer = _layer(iters=3)
+    start = {k: v.tensor.clone() for k, v in obj.optim_vars.items()}
+    layer.forward(None, optimizer_kwargs=dict(damping=1e-3))          # state buffer handed out -> next optimize privatizes
+    boom = RuntimeError("kernel error stand-in")
+
+    def raising_complete_step(*a, **k):
+        raise boom
+    orig = opt._complete_step
+    opt._complete_step = raising_complete_step
+    with pytest.raises(RuntimeError):
+        layer.forward(None, optimizer_kwargs=dict(damping=1e-3))
+    opt._complete_step = orig
+    packed = opt.linear_solver.linearization.packed
+    assert not packed._vars_stale
+    # new inputs: the start poses again -- the first error of the history must be the START problem's, as a fresh optimizer sees it
+    _, info = layer.forward(start, optimizer_kwargs=dict(track_err_history=True, damping=1e-3))
+    th2, g2, obj2, opt2, layer2 = _layer(iters=3)
+    _, fresh = layer2.forward(None, optimizer_kwargs=dict(track_err_history=True, damping=1e-3))
+    assert torch.allclose(info.err_history, fresh.err_history, rtol=1e-12, atol=0)
+
+
 def test_best_iter_and_state_history():
     th, g, obj, opt, layer = _layer("pg_f64_lm_adaptive_rejects", iters=6)
     _, kw_ = None, None

@@ -68,6 +68,35 @@ def test_lm_trajectory_matches_reference(name, tol):
         assert (tr != tr[0]).any()   # the fixture exercises shrinking / expanding
 
 
+def test_implicit_backward_at_full_size_matches_reference():
+    """The oracle's implicit step at 256 poses / 1024 edges against the REAL reference's (tests/golden/pg_full_f64_implicit.npz):
+    gauge-free gradients to rounding, gauge-sensitive ones to eps * cond (tests/implicit_common.py)."""
+    import dataclasses
+    from tests.implicit_common import check_full_size_implicit, relative_poses
+    g = load_golden("pg_full_f64_implicit")
+    p, poses0, kw = golden_problem(g)
+    kw.pop("gauss_newton")
+    iters = kw.pop("max_iterations")
+    with torch.no_grad():
+        x, _ = opg.lm_optimize(p, poses0, max_iterations=iters - 1, abs_err_tolerance=0.0, rel_err_tolerance=0.0, **kw)
+    leaves = dict(meas=p.meas.clone().requires_grad_(True), w_between=p.w_between.clone().requires_grad_(True),
+                  prior_target=p.prior_target.clone().requires_grad_(True),
+                  w_prior=p.w_prior[:, :, :1].clone().requires_grad_(True))
+    pg = dataclasses.replace(p, meas=leaves["meas"], w_between=leaves["w_between"], prior_target=leaves["prior_target"],
+                             w_prior=leaves["w_prior"].expand(-1, -1, p.dof))
+    final, _ = opg.implicit_final_step(pg, x)
+    loss = (torch.from_numpy(g["coef"]) * final).sum()
+    loss.backward(retain_graph=True)
+    grads = {k: v.grad.clone() for k, v in leaves.items()}
+    for v in leaves.values():
+        v.grad = None
+    loss_rel = (torch.from_numpy(g["coef_rel"]) * relative_poses(final)).sum()
+    loss_rel.backward()
+    grads["gauge_free"] = {k: v.grad.clone() for k, v in leaves.items()}
+    grads["loss_rel"] = loss_rel.item()
+    check_full_size_implicit(g, final.detach(), loss.item(), grads, "full size implicit fp64, oracle")
+
+
 @pytest.mark.parametrize("name", ["pg_f64_implicit", "pg_f64_implicit_b", "pg2_f64_implicit", "pg3_f64_implicit"])
 def test_implicit_backward_gradients_match_reference(name):
     """Pins the oracle's implicit step (autograd through the restated formulas) to the gradients the REAL

@@ -180,3 +180,21 @@ def test_a_failure_on_one_shard_freezes_every_shard():
     for o in outs:
         assert all(s == "FAIL" for s in o["status"]) and o["iters"] == 0
         assert torch.equal(o["final"], o["start"])
+
+
+def test_rccl_smoke_script_logic_over_gloo():
+    """tests/rccl_smoke.py is what the >= 2-GPU test runs over RCCL; here the same script over gloo on the CPU (uneven shards
+    through gather_solution, the reducer's predicates)."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(THX_SMOKE_BACKEND="gloo", PYTHONPATH=root + os.pathsep + env.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "rccl_smoke.py")],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL-SMOKE-OK" in out.stdout, out.stderr[-3000:]

@@ -166,8 +166,6 @@ class PackedBA:
 
     group = "BA"
 
-    group = "BA"
-
     def __init__(self, objective: Objective, kernels=None):
         self.objective = objective
         self.K = kernels or default_kernels()

@@ -47,8 +47,28 @@ def _option(key: str):
     return None
 
 
+def _forward_to_reference(options) -> None:
+    """theseus_amd.plugin is loaded: every launch reads the REFERENCE's parameter objects, so a setter of this package must
+    reach them (the local tables are no longer read -- silently updating them would make the call a no-op)."""
+    import theseus
+    import torchlie
+    lie_opts = {k: v for k, v in options.items() if k.startswith("so3_")}
+    rest = {k: v for k, v in options.items() if not k.startswith("so3_")}
+    if lie_opts:
+        torchlie.set_global_params(lie_opts)
+    if rest:
+        theseus.set_global_params(rest)
+
+
 def set_global_params(options) -> None:
-    """Mirror of ``theseus.set_global_params`` + ``torchlie.set_global_params`` for the options this path reads."""
+    """Mirror of ``theseus.set_global_params`` + ``torchlie.set_global_params`` for the options this path reads.
+    Once ``theseus_amd.plugin`` redirected the look-ups to the reference's own objects the call is forwarded there."""
+    if _REFERENCE_PARAMS is not None:
+        for k in options:
+            if k not in _FLAGS and _option(k) is None:
+                raise ValueError(f"{k} is not a valid global option for theseus_amd.")
+        _forward_to_reference(dict(options))
+        return
     for k, v in options.items():
         if k in _FLAGS:
             _FLAGS[k] = bool(v)
@@ -62,6 +82,13 @@ def set_global_params(options) -> None:
 
 
 def reset_global_params() -> None:
+    if _REFERENCE_PARAMS is not None:
+        import torchlie
+        import theseus
+        torchlie.reset_global_params()
+        theseus.set_global_params(dict(fast_approx_local_jacobians=False, se2_near_zero_eps_float32=3e-2,
+                                       se2_d_near_zero_eps_float32=1e-1, se2_near_zero_eps_float64=1e-6,
+                                       se2_d_near_zero_eps_float64=1e-3))
     _LIE_EPS[torch.float32].update(near_zero=1e-2, d_near_zero=2e-1, near_pi=1e-2)
     _LIE_EPS[torch.float64].update(near_zero=5e-3, d_near_zero=1e-2, near_pi=1e-7)
     _SE2_EPS[torch.float32].update(near_zero=3e-2, d_near_zero=1e-1)
@@ -71,17 +98,23 @@ def reset_global_params() -> None:
 
 def set_lie_eps(dtype, **kw):
     """Short form of set_global_params for the three so3 thresholds."""
+    tag = "float32" if dtype == torch.float32 else "float64"
     for k, v in kw.items():
         if k not in _LIE_EPS[dtype]:
             raise KeyError(k)
+        if _REFERENCE_PARAMS is not None:
+            _forward_to_reference({f"so3_{k}_eps_{tag}": float(v)})
         _LIE_EPS[dtype][k] = float(v)
 
 
 def set_se2_eps(dtype, **kw):
     """Short form of set_global_params for se2_near_zero_eps / se2_d_near_zero_eps."""
+    tag = "float32" if dtype == torch.float32 else "float64"
     for k, v in kw.items():
         if k not in _SE2_EPS[dtype]:
             raise KeyError(k)
+        if _REFERENCE_PARAMS is not None:
+            _forward_to_reference({f"se2_{k}_eps_{tag}": float(v)})
         _SE2_EPS[dtype][k] = float(v)
 
 

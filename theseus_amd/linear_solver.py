@@ -113,12 +113,21 @@ class HipCholeskyCore:
         delta = torch.empty_like(y)
         self._substitute(y, delta, backward_only=True)
         if getattr(self, "_check_singular", False):
+            # dense_solver.py:91-103: items whose UNDAMPED AtA hits a zero LU pivot are dropped (zero step, no failure).  Here:
+            # a zero on diag(AtA) (an all-zero column of A), and -- for an undamped solve -- any item whose Cholesky
+            # factorisation broke down (exactly dependent columns: the reference's LU meets the same zero pivot).  With
+            # damping the reference still tests the undamped matrix; a rank-deficient item with a non-zero diagonal is then
+            # STEPPED here (its damped system is positive definite) where the reference zeroes it -- documented divergence.
+            # Device-side select, no host sync (the loop's sync-free path stays sync-free); the reference's warning is
+            # raised where the host looks at the solve anyway (check_info=True).
             singular = self.singular_mask()
-            if bool(singular.any()):   # (one host sync, as the reference's ``good_idx.all()``)
+            if damping is None:
+                singular = singular | self.info.ne(0)
+            delta.masked_fill_(singular.unsqueeze(1), 0.0)
+            self.info.masked_fill_(singular, 0)   # a dropped item is not a failed solve
+            if check_info and bool(singular.any()):
                 warnings.warn("Singular matrix found in batch, solution will be set to all 0 for all singular matrices.",
                               RuntimeWarning)
-                delta.masked_fill_(singular.unsqueeze(1), 0.0)
-                self.info.masked_fill_(singular, 0)   # a dropped item is not a failed solve
         if check_info:
             self.check_info()
         return delta

@@ -141,8 +141,9 @@ class NonlinearLeastSquares(abc.ABC):
 
     def _may_reject(self, kwargs) -> bool:
         """Can ``_complete_step`` reject steps with these optimizer kwargs?  (The sync-free loop then keeps the start state
-        for the replay of an all-rejected iteration.)"""
-        return False
+        for the replay of an all-rejected iteration.)  A subclass that overrides ``_complete_step`` may reject unless it says
+        otherwise."""
+        return type(self)._complete_step is not NonlinearLeastSquares._complete_step
 
     def _join_compute_delta(self):
         """Called INSTEAD of ``compute_delta`` on a rank that cannot run it (host-side error): take part in whatever
@@ -172,7 +173,22 @@ class NonlinearLeastSquares(abc.ABC):
             (change / last_err).abs() < self.params.rel_err_tolerance)
         return conv
 
-    def _optimize_impl(self, track_best_solution: bool = False, track_err_history: bool = False,
+    def _optimize_impl(self, **kwargs) -> NonlinearOptimizerInfo:
+        """The loop moves the state through private, recycled buffers and re-points the Variable objects only at the end
+        (``_vars_stale``).  If anything raises in between -- bad optimizer kwargs, a kernel error, KeyboardInterrupt -- the
+        variables are re-pointed at the state reached so far BEFORE the exception leaves: otherwise the next
+        ``forward(new_inputs)`` would see the stale flag, flush the old private buffer over the user's new tensors and
+        silently optimise the previous problem."""
+        try:
+            return self._optimize_loop(**kwargs)
+        except BaseException:
+            packed = self.linear_solver.linearization.packed
+            if getattr(packed, "tensors", None) is not None:
+                with torch.no_grad():
+                    packed.flush_variables()
+            raise
+
+    def _optimize_loop(self, track_best_solution: bool = False, track_err_history: bool = False,
                        track_state_history: bool = False, verbose: bool = False,
                        backward_mode: Union[str, BackwardMode] = BackwardMode.UNROLL,
                        end_iter_callback: Optional[Callable] = None, **kwargs) -> NonlinearOptimizerInfo:
@@ -355,6 +371,13 @@ class NonlinearLeastSquares(abc.ABC):
                 try:
                     delta = self.compute_delta(**kwargs)
                 except RuntimeError as run_err:
+                    if self.reducer.world_size > 1:
+                        # the other shards are (or will be) waiting in compute_delta's collectives and in this iteration's
+                        # decide(): take part in both with the failure flag raised, so that EVERY rank leaves the loop here
+                        self._join_compute_delta()
+                        one = torch.ones(1, dtype=torch.bool, device=dev)
+                        rej = [one] if self._may_reject(kwargs) else []
+                        self.reducer.decide([one] + rej, rej)
                     warn_failed(run_err)
                     info.status[:] = NonlinearOptimizerStatus.FAIL
                     break
