@@ -408,12 +408,20 @@ def dogleg_step(A, AtA, Atb, trust_region, eps=1e-7):
     return torch.where(inside, delta_c + tau * diff, out)
 
 
-def implicit_final_step(p: PGProblem, poses, step_size=1.0):
+def implicit_final_step(p: PGProblem, poses, step_size=1.0, fallback_damping=None, ellipsoidal_damping=False,
+                        damping_eps=1e-8):
     """The grad-enabled last step of BackwardMode.IMPLICIT (nonlinear_least_squares.py:121-135,265-292): undamped
     Gauss-Newton with the Hessian detached (dense_linearization.py:61); the autograd graph runs through
     Atb = A^T b only.  ``poses`` are the (detached) iterates of the no-grad loop; gradients flow to whatever in
-    ``p`` requires grad (measurements, weights, prior targets)."""
+    ``p`` requires grad (measurements, weights, prior targets).  If the undamped factorisation fails the reference falls
+    back to the optimizer's regular (damped) step (nonlinear_least_squares.py:130-135): ``fallback_damping``, the LM damping
+    (None: the error propagates, as with ``__strict_implicit_final_gn__``)."""
     A, b = dense_linearize(p, poses.detach())
     AtA, Atb = hessian(A, b)
-    delta = solve(AtA.detach(), Atb)
+    try:
+        delta = solve(AtA.detach(), Atb)
+    except RuntimeError:
+        if fallback_damping is None:
+            raise
+        delta = solve(AtA.detach(), Atb, fallback_damping, ellipsoidal_damping, damping_eps)
     return retract(poses.detach(), delta * step_size), delta

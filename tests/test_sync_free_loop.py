@@ -70,3 +70,41 @@ def test_convergence_is_counted_like_the_reference_on_both_paths():
     assert torch.isfinite(ia.err_history[:, :k + 2]).all() and torch.isinf(ia.err_history[:, k + 2:]).all()
     np.testing.assert_allclose(a.numpy(), fo.numpy(), rtol=0, atol=1e-9)
     assert all(s == th.NonlinearOptimizerStatus.CONVERGED for s in ia.status) and list(ia.status) == list(ib.status)
+
+
+def test_all_rejected_iteration_is_replayed_from_its_own_start():
+    """an all-rejected step used to throw the whole sync-free pass away and replay optimize() from iteration 0 on the
+    synchronous path.  Now the device keeps a snapshot of the start of the first all-rejected iteration (state, error, damping);
+    only that iteration is replayed (the reference's retry branch) and the queueing resumes.  Problem 4 of the fixture rejects
+    every step from iteration 6 on (rho = noise / noise once converged): as a batch of one, each of those is an ALL-rejection."""
+    import theseus_amd as th
+    from tests.oracle_kernels import OracleKernels
+    from tests.test_gpu_lm import build_objective
+    g = dict(load_golden("pg_f64_lm_adaptive_rejects"))
+    for k in ("poses0", "meas", "prior_target"):
+        g[k] = g[k][4:5].copy()
+    for k in ("w_between", "w_prior"):
+        if g[k].shape[0] > 1:
+            g[k] = g[k][4:5].copy()
+    out = {}
+    for lazy in (True, False):
+        obj, _ = build_objective(th, g, device="cpu")
+        K = OracleKernels()
+        solves = []
+        fac = K.chol_factor
+        K.chol_factor = lambda *a, **k: (solves.append(1), fac(*a, **k))[1]
+        opt = th.LevenbergMarquardt(obj, linearization_kwargs=dict(kernels=K), max_iterations=10, step_size=1.0,
+                                    abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+        kw = dict(track_err_history=True, track_best_solution=True, damping=1e-4, adaptive_damping=True, damping_accept=0.9)
+        if not lazy:
+            kw["end_iter_callback"] = lambda o, i, d, it: None
+        sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=kw)
+        out[lazy] = (torch.stack([sol[f"pose_{k}"] for k in range(int(g["P"]))], 1), info, len(solves), opt._damping.clone())
+    (a, ia, na, da), (b, ib, nb, db) = out[True], out[False]
+    assert torch.equal(a, b) and torch.equal(ia.err_history, ib.err_history) and ia.iters_done == ib.iters_done == 10
+    assert torch.equal(da, db) and torch.equal(ia.best_iter, ib.best_iter) and torch.equal(ia.best_err, ib.best_err)
+    for k in ia.best_solution:
+        assert torch.equal(ia.best_solution[k], ib.best_solution[k])
+    assert nb > 10            # the synchronous run retried all-rejected steps (nonlinear_least_squares.py:358-359)
+    # the sync-free run makes exactly the same attempts (the iteration counter lives on the device: nothing is replayed)
+    assert na == nb, (na, nb)

@@ -140,9 +140,8 @@ class NonlinearLeastSquares(abc.ABC):
         return None
 
     def _may_reject(self, kwargs) -> bool:
-        """Can ``_complete_step`` reject steps with these optimizer kwargs?  (The sync-free loop then keeps the start state
-        for the replay of an all-rejected iteration.)  A subclass that overrides ``_complete_step`` may reject unless it says
-        otherwise."""
+        """Can ``_complete_step`` reject steps with these optimizer kwargs?  A subclass that overrides ``_complete_step`` may
+        reject unless it says otherwise."""
         return type(self)._complete_step is not NonlinearLeastSquares._complete_step
 
     def _join_compute_delta(self):
@@ -261,192 +260,201 @@ class NonlinearLeastSquares(abc.ABC):
             #        * a failed solve froze every later update on the device: FAIL status, iters_done = the failing iteration;
             #        * everybody converged at iteration k: later iterations were no-ops on frozen problems, the bookkeeping
             #          is cut at k (a lagged, non-blocking poll of the flag stops the queueing a couple of iterations later);
-            #        * an ALL-rejected step (rare at any real batch size): the loop is REPLAYED from the saved start on the
-            #          synchronous path below, which takes the reference's retry branch exactly.
+            #        * an ALL-rejected step is the reference's uncounted retry: the iteration counter itself lives on the
+            #          device (see below), nothing is replayed.
             #      Callbacks and verbose printing need the host every iteration: synchronous path. ----
             sync_free = (isinstance(self.reducer, LocalBatchReducer) and end_iter_callback is None and not verbose
                          and loop_iters > 0)
-            replay = False
+            halt = False
             if sync_free:
-                start_state = packed.clone_state() if self._may_reject(kwargs) else None
+                # What the host queues are ATTEMPTS.  An all-rejected attempt leaves every problem's state and error where they
+                # were and has already moved lambda / the trust region -- which is precisely the reference's retry
+                # (nonlinear_least_squares.py:358-359: ``continue`` without counting the iteration; the third all-rejected attempt
+                # in a row is counted with err = last_err, nonlinear_optimizer.py:88).  So nothing is replayed: the ITERATION
+                # COUNTER lives on the device (``it_dev``), the histories are written at device-side column indices, and after the
+                # queued attempts the host reads the counter and queues what is missing (no all-rejection: one round, one sync).
                 flag = lambda v: torch.full((), v, dtype=torch.long, device=dev)  # noqa: E731
                 failed = torch.zeros((), dtype=torch.bool, device=dev)
-                first_fail, first_all_rej, first_all_conv = flag(-1), flag(-1), flag(-1)
-                # (the lagged poll is a per-process decision: a sharded batch runs all its iterations, so that every rank
+                first_fail, first_all_conv = flag(-1), flag(-1)
+                it_dev, attempts_dev = flag(0), flag(0)
+                true0 = torch.ones((), dtype=torch.bool, device=dev)
+                # (the lagged poll is a per-process decision: a sharded batch runs all its attempts, so that every rank
                 #  issues the same all-reduces)
                 poll = _LaggedFlag(dev) if (need_conv and self.reducer.world_size == 1) else None
                 raised = None
-                while it < loop_iters:
-                    if poll is not None and poll.seen():
-                        break   # everybody converged a moment ago: stop queueing (the cut below is exact)
-                    local_fail = None
-                    if raised is None:
-                        lin.linearize()
+                while True:
+                    for _ in range(loop_iters - it):
+                        if poll is not None and poll.seen():
+                            break   # everybody converged a moment ago: stop queueing (the cut below is exact)
+                        local_fail = None
+                        if raised is None:
+                            lin.linearize()
+                            try:
+                                delta = self.compute_delta(**kwargs)
+                                local_fail = self.linear_solver.info.ne(0).any()
+                            except RuntimeError as run_err:
+                                # a host-side error on THIS rank: the other shards are (or will be) waiting in device_any()'s
+                                # all-reduce -- keep taking part in it with the flag raised instead of leaving the loop
+                                raised = run_err
+                        if raised is not None:
+                            self._join_compute_delta()
+                            delta = torch.zeros(B, lin.num_cols, dtype=dt, device=dev)
+                            local_fail = torch.ones((), dtype=torch.bool, device=dev)
+                        now = self.reducer.device_any(local_fail)
+                        first_fail = torch.where(now & ~failed, it_dev, first_fail)
+                        failed = failed | now
+                        stop = failed | it_dev.ge(loop_iters)        # nothing moves after a failure / beyond the last iteration
+                        frozen = stop.expand(B) if converged is None else (converged | stop)
+                        packed.retract(delta, p.step_size, frozen.to(torch.uint8).contiguous(), spare)
+                        packed.error_metric(state=spare, out=err_new)
+                        reject = self._complete_step(delta, err_new, last_err, step_size=p.step_size, **kwargs)
+                        counted = ~stop
+                        if reject is not None:
+                            rb = reject.bool()
+                            all_rej = self.reducer.device_all(rb.all())
+                            forced = attempts_dev.ge(self._MAX_ALL_REJECT_ATTEMPTS - 1)
+                            counted = counted & (~all_rej | forced)
+                            attempts_dev = torch.where(all_rej & ~forced & ~stop, attempts_dev + 1, torch.zeros_like(attempts_dev))
+                            packed.keep_where(rb, spare)                                   # rejected problems keep their state
+                            packed.K.copy_where(rb, last_err.view(1, -1, 1), err_new.view(1, -1, 1))   # ... and their error
+                        err = torch.where(stop, last_err, err_new)
+                        spare = packed.swap_state(spare)
+                        if err_hist is not None:
+                            col = (it_dev + 1).clamp(max=p.max_iterations).view(1)
+                            cur = err_hist.index_select(1, col)
+                            err_hist.index_copy_(1, col, torch.where(counted, err.unsqueeze(1), cur))
+                        if track_best_solution:
+                            better = (err < best_err) & counted
+                            packed.copy_where(better, packed.state, best_state)
+                            best_err = torch.where(better, err, best_err)
+                            best_iter = torch.where(better, it_dev, best_iter)  # nonlinear_optimizer.py:202
+                        if need_conv:
+                            small = self.reducer.device_mean_abs_below(err, p.abs_err_tolerance)
+                            conv_now = self._check_convergence(err, last_err) | small
+                            # (an uncounted attempt -- all rejected, err == last_err everywhere -- converges nobody)
+                            converged = (conv_now & counted) if converged is None else torch.where(counted, conv_now, converged)
+                            conv_iter = torch.where(converged & (conv_iter < 0) & counted, it_dev + 1, conv_iter)
+                            all_conv = self.reducer.device_all(converged.all()) & counted
+                            first_all_conv = torch.where(all_conv & (first_all_conv < 0), it_dev + 1, first_all_conv)
+                            if poll is not None:
+                                poll.post(first_all_conv >= 0)
+                        last_err = err
+                        it_dev = it_dev + counted.long()
+                    # ---- the one host sync of the round ----
+                    f_fail, f_conv, it_now = torch.stack([first_fail, first_all_conv, it_dev]).tolist()
+                    if f_fail >= 0 and not (f_conv >= 0 and f_conv < f_fail + 1):
                         try:
-                            delta = self.compute_delta(**kwargs)
-                            local_fail = self.linear_solver.info.ne(0).any()
+                            if raised is not None:
+                                raise raised
+                            self.linear_solver.check_info()
+                            raise RuntimeError("the linear solve failed on another shard of the batch")
                         except RuntimeError as run_err:
-                            # a host-side error on THIS rank: the other shards are (or will be) waiting in device_any()'s
-                            # all-reduce -- keep taking part in it with the flag raised instead of leaving the loop
-                            raised = run_err
-                    if raised is not None:
-                        self._join_compute_delta()
-                        delta = torch.zeros(B, lin.num_cols, dtype=dt, device=dev)
-                        local_fail = torch.ones((), dtype=torch.bool, device=dev)
-                    now = self.reducer.device_any(local_fail)
-                    first_fail = torch.where(now & ~failed, torch.full_like(first_fail, it), first_fail)
-                    failed = failed | now
-                    frozen = failed.expand(B) if converged is None else (converged | failed)
-                    packed.retract(delta, p.step_size, frozen.to(torch.uint8).contiguous(), spare)
+                            warn_failed(run_err)
+                        info.status[:] = NonlinearOptimizerStatus.FAIL   # (overrides every status: nonlinear_least_squares.py:147)
+                        it = f_fail
+                        halt = True
+                    elif f_conv >= 0:
+                        # the reference broke out of its loop here, BEFORE counting the converging iteration (:202-203): its error
+                        # is in err_history[:, f_conv], the iteration count stays at f_conv - 1 (the synchronous path below and
+                        # the implicit epilogue -- which writes its error at [iters_done + 1], as _merge_infos does -- agree)
+                        it = f_conv - 1
+                        if err_hist is not None:
+                            err_hist[:, f_conv + 1:] = inf
+                        converged = conv_iter.ge(0) & conv_iter.le(f_conv)   # (later iterations only re-marked frozen problems)
+                        conv_iter = torch.where(converged, conv_iter, torch.full_like(conv_iter, -1))
+                        halt = True
+                    else:
+                        it = it_now
+                    if halt or it >= loop_iters:
+                        break
+                info.last_err = last_err   # (frozen / failed problems kept their error: this is the error AT ``it``)
+                info.iters_done = it
+            else:
+                # ---- synchronous path (callbacks, verbose): one host decision per iteration ----
+                while it < loop_iters:
+                    lin.linearize()
+                    try:
+                        delta = self.compute_delta(**kwargs)
+                    except RuntimeError as run_err:
+                        if self.reducer.world_size > 1:
+                            # the other shards are (or will be) waiting in compute_delta's collectives and in this iteration's
+                            # decide(): take part in both with the failure flag raised, so that EVERY rank leaves the loop here
+                            self._join_compute_delta()
+                            one = torch.ones(1, dtype=torch.bool, device=dev)
+                            rej = [one] if self._may_reject(kwargs) else []
+                            self.reducer.decide([one] + rej, rej)
+                        warn_failed(run_err)
+                        info.status[:] = NonlinearOptimizerStatus.FAIL
+                        halt = True
+                        break
+                    # retract (converged problems frozen) + error of the candidate, fused HIP kernels
+                    packed.retract(delta, p.step_size, converged, spare)
                     packed.error_metric(state=spare, out=err_new)
                     reject = self._complete_step(delta, err_new, last_err, step_size=p.step_size, **kwargs)
+                    # ---- the only host sync of the iteration: [solver failed | all rejected, any rejected], over
+                    #      the GLOBAL batch (self.reducer all-reduces across shards when the batch is sharded) ----
+                    any_f = [self.linear_solver.info.ne(0)]
+                    all_f = []
                     if reject is not None:
                         rb = reject.bool()
-                        all_rej = self.reducer.device_all(rb.all())
-                        first_all_rej = torch.where(all_rej & (first_all_rej < 0) & ~failed,
-                                                    torch.full_like(first_all_rej, it), first_all_rej)
-                        packed.keep_where(rb, spare)                                   # rejected problems keep their state
-                        packed.K.copy_where(rb, last_err.view(1, -1, 1), err_new.view(1, -1, 1))   # ... and their error
-                    err = torch.where(failed, last_err, err_new)
-                    spare = packed.swap_state(spare)
+                        any_f.append(rb)
+                        all_f.append(rb)
+                    any_r, all_r = self.reducer.decide(any_f, all_f)
+                    if any_r[0]:
+                        try:
+                            self.linear_solver.check_info()
+                            raise RuntimeError("the linear solve failed on another shard of the batch")
+                        except RuntimeError as run_err:
+                            warn_failed(run_err)
+                        info.status[:] = NonlinearOptimizerStatus.FAIL
+                        halt = True
+                        break
+                    if reject is not None:
+                        all_rej, any_rej = all_r[0], any_r[1]
+                        if all_rej:
+                            all_reject_attempts += 1
+                            if all_reject_attempts < self._MAX_ALL_REJECT_ATTEMPTS:
+                                continue
+                            err = last_err
+                        else:
+                            if any_rej:
+                                rb = reject.bool()
+                                packed.keep_where(rb, spare)
+                                packed.K.copy_where(rb, last_err.view(1, -1, 1), err_new.view(1, -1, 1))
+                                err = err_new.clone()
+                            else:
+                                err = err_new.clone()
+                            spare = packed.swap_state(spare)
+                    else:
+                        err = err_new.clone()
+                        spare = packed.swap_state(spare)
+                    all_reject_attempts = 0
                     if err_hist is not None:
-                        err_hist[:, it + 1] = torch.where(failed, torch.full_like(err, inf), err)
+                        err_hist[:, it + 1] = err
                     if track_best_solution:
-                        better = (err < best_err) & ~failed
+                        better = err < best_err
                         packed.copy_where(better, packed.state, best_state)
                         best_err = torch.where(better, err, best_err)
                         best_iter = torch.where(better, torch.full_like(best_iter, it), best_iter)  # nonlinear_optimizer.py:202
+                    if verbose:
+                        print(f"Nonlinear optimizer. Iteration: {it + 1}. Error: {err.mean().item()}")
                     if need_conv:
-                        small = self.reducer.device_mean_abs_below(err, p.abs_err_tolerance)
-                        converged = self._check_convergence(err, last_err) | small
-                        conv_iter = torch.where(converged & (conv_iter < 0), torch.full_like(conv_iter, it + 1), conv_iter)
-                        all_conv = self.reducer.device_all(converged.all()) & ~failed
-                        first_all_conv = torch.where(all_conv & (first_all_conv < 0),
-                                                     torch.full_like(first_all_conv, it + 1), first_all_conv)
-                        if poll is not None:
-                            poll.post(first_all_conv >= 0)
-                    last_err = err
-                    it += 1
-                # ---- the one host sync of the loop ----
-                f_fail, f_rej, f_conv = torch.stack([first_fail, first_all_rej, first_all_conv]).tolist()
-                before = lambda a, b: a >= 0 and (b < 0 or a < b)  # noqa: E731
-                if f_rej >= 0 and not before(f_fail, f_rej + 1) and not before(f_conv, f_rej + 1):
-                    replay = True      # the reference would have retried without counting the iteration
-                elif f_fail >= 0 and not before(f_conv, f_fail + 1):
-                    try:
-                        if raised is not None:
-                            raise raised
-                        self.linear_solver.check_info()
-                        raise RuntimeError("the linear solve failed on another shard of the batch")
-                    except RuntimeError as run_err:
-                        warn_failed(run_err)
-                    info.status[:] = NonlinearOptimizerStatus.FAIL   # (overrides every status: nonlinear_least_squares.py:147)
-                    it = f_fail
-                elif f_conv >= 0:
-                    # the reference broke out of its loop here, BEFORE counting the converging iteration (:202-203): its error
-                    # is in err_history[:, f_conv], the iteration count stays at f_conv - 1 (the synchronous path below and
-                    # the implicit epilogue -- which writes its error at [iters_done + 1], as _merge_infos does -- agree)
-                    it = f_conv - 1
-                    if err_hist is not None:
-                        err_hist[:, f_conv + 1:] = inf
-                    converged = conv_iter.ge(0) & conv_iter.le(f_conv)   # (later iterations only re-marked frozen problems)
-                    conv_iter = torch.where(converged, conv_iter, torch.full_like(conv_iter, -1))
-                if not replay:
-                    info.last_err = last_err   # (frozen / failed problems kept their error: this is the error AT ``it``)
-                    info.iters_done = it
-                else:
-                    # back to the start: state, lambda, bookkeeping -- then the synchronous path
-                    spare = packed.swap_state(start_state)
-                    self.reset(**kwargs, backward_mode=backward_mode)
-                    last_err, err_hist, info = fresh_info()
-                    if track_best_solution:
-                        packed.copy_where(torch.ones(B, dtype=torch.bool, device=dev), packed.state, best_state)
-                        best_err = last_err.clone()
-                        best_iter = torch.zeros(B, dtype=torch.long, device=dev)
-                    converged = None
-                    conv_iter = torch.full((B,), -1, dtype=torch.long, device=dev)
-                    it = 0
-            while (not sync_free or replay) and it < loop_iters:
-                lin.linearize()
-                try:
-                    delta = self.compute_delta(**kwargs)
-                except RuntimeError as run_err:
-                    if self.reducer.world_size > 1:
-                        # the other shards are (or will be) waiting in compute_delta's collectives and in this iteration's
-                        # decide(): take part in both with the failure flag raised, so that EVERY rank leaves the loop here
-                        self._join_compute_delta()
-                        one = torch.ones(1, dtype=torch.bool, device=dev)
-                        rej = [one] if self._may_reject(kwargs) else []
-                        self.reducer.decide([one] + rej, rej)
-                    warn_failed(run_err)
-                    info.status[:] = NonlinearOptimizerStatus.FAIL
-                    break
-                # retract (converged problems frozen) + error of the candidate, fused HIP kernels
-                packed.retract(delta, p.step_size, converged, spare)
-                packed.error_metric(state=spare, out=err_new)
-                reject = self._complete_step(delta, err_new, last_err, step_size=p.step_size, **kwargs)
-                # ---- the only host sync of the iteration: [solver failed | all rejected, any rejected], over
-                #      the GLOBAL batch (self.reducer all-reduces across shards when the batch is sharded) ----
-                any_f = [self.linear_solver.info.ne(0)]
-                all_f = []
-                if reject is not None:
-                    rb = reject.bool()
-                    any_f.append(rb)
-                    all_f.append(rb)
-                any_r, all_r = self.reducer.decide(any_f, all_f)
-                if any_r[0]:
-                    try:
-                        self.linear_solver.check_info()
-                        raise RuntimeError("the linear solve failed on another shard of the batch")
-                    except RuntimeError as run_err:
-                        warn_failed(run_err)
-                    info.status[:] = NonlinearOptimizerStatus.FAIL
-                    break
-                if reject is not None:
-                    all_rej, any_rej = all_r[0], any_r[1]
-                    if all_rej:
-                        all_reject_attempts += 1
-                        if all_reject_attempts < self._MAX_ALL_REJECT_ATTEMPTS:
-                            continue
-                        err = last_err
-                    else:
-                        if any_rej:
-                            rb = reject.bool()
-                            packed.keep_where(rb, spare)
-                            packed.K.copy_where(rb, last_err.view(1, -1, 1), err_new.view(1, -1, 1))
-                            err = err_new.clone()
+                        if self.reducer.mean_abs(err) < p.abs_err_tolerance:
+                            converged = torch.ones(B, dtype=torch.bool, device=dev)
                         else:
-                            err = err_new.clone()
-                        spare = packed.swap_state(spare)
-                else:
-                    err = err_new.clone()
-                    spare = packed.swap_state(spare)
-                all_reject_attempts = 0
-                if err_hist is not None:
-                    err_hist[:, it + 1] = err
-                if track_best_solution:
-                    better = err < best_err
-                    packed.copy_where(better, packed.state, best_state)
-                    best_err = torch.where(better, err, best_err)
-                    best_iter = torch.where(better, torch.full_like(best_iter, it), best_iter)  # nonlinear_optimizer.py:202
-                if verbose:
-                    print(f"Nonlinear optimizer. Iteration: {it + 1}. Error: {err.mean().item()}")
-                if need_conv:
-                    if self.reducer.mean_abs(err) < p.abs_err_tolerance:
-                        converged = torch.ones(B, dtype=torch.bool, device=dev)
-                    else:
-                        converged = self._check_convergence(err, last_err)
-                    conv_iter = torch.where(converged & (conv_iter < 0), torch.full_like(conv_iter, it + 1), conv_iter)
-                    if self.reducer.decide([], [converged])[1][0]:
-                        info.last_err = err
-                        break
-                last_err = err
-                info.last_err = err
-                if end_iter_callback is not None:
-                    packed.flush_variables()
-                    end_iter_callback(self, info, delta, it)
-                it += 1
-                info.iters_done = it
+                            converged = self._check_convergence(err, last_err)
+                        conv_iter = torch.where(converged & (conv_iter < 0), torch.full_like(conv_iter, it + 1), conv_iter)
+                        if self.reducer.decide([], [converged])[1][0]:
+                            info.last_err = err
+                            halt = True
+                            break
+                    last_err = err
+                    info.last_err = err
+                    if end_iter_callback is not None:
+                        packed.flush_variables()
+                        end_iter_callback(self, info, delta, it)
+                    it += 1
+                    info.iters_done = it
 
             # ---- BackwardMode.IMPLICIT: the last step is an undamped Gauss-Newton step with the Hessian detached,
             #      executed under the caller's grad mode (nonlinear_least_squares.py:121-135,265-292) ----
@@ -623,6 +631,24 @@ class TrustRegion(NonlinearLeastSquares, abc.ABC):
 class Dogleg(TrustRegion):
     """theseus/optimizer/nonlinear/dogleg.py:18-116 (Nocedal & Wright, pp. 73-77)."""
     EPS = 1e-7
+
+    def _step_state(self):
+        """Per-problem tensors that ``_complete_step`` carries from one iteration to the next (LM: the damping vector;
+        trust-region methods: the radii).  The sync-free loop snapshots them on the device so that an all-rejected iteration
+        can be replayed from its own start."""
+        return []
+
+    def _set_step_state(self, tensors) -> None:
+        pass
+
+    def _has_step_state_hooks(self) -> bool:
+        """True when this class's ``_complete_step`` is covered by ``_step_state`` / ``_set_step_state`` -- i.e. for the
+        optimizers of this package; a user subclass that overrides ``_complete_step`` must override the hooks too (or this)."""
+        cls = type(self)
+        for base in cls.__mro__:
+            if "_complete_step" in base.__dict__:
+                return "_step_state" in base.__dict__ or base is NonlinearLeastSquares
+        return True
 
     def _join_compute_delta(self):
         one = torch.ones((), dtype=torch.bool, device=self._trust_region.device)
