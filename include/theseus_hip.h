@@ -167,6 +167,42 @@ int thx_pgso3_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w
 int thx_pg_assemble(const thx_pg_structure* s, const thx_pg_data* d, void* H, int64_t ld, void* g,
                     int dtype, const thx_lie_eps* eps, void* stream);
 
+/* ---- BLOCK-COMPACT Hessian.  The same lower triangle of H = A^T A (dense_linearization.py:55-62), stored as what it is: the
+ *      list of its non-zero bd x bd blocks (SE3 pose graph: 6 x 6; P diagonal + one per connected pose pair), (B, nblocks, bd*bd)
+ *      with problem stride `bstride` elements -- 184 KB per problem at 256 poses / 1024 edges where the dense frame's lower
+ *      triangle is 4.7 MB of mostly zeros.  Blocks are ordered by the 128 x 128 Cholesky tile of their top-left element, so the
+ *      blocks of a tile are one contiguous run.  All tables are DEVICE int32 arrays built once by the host
+ *      (theseus_amd/compiler.py:HessianBlocks):
+ *        diag_blk[k]          block id of the diagonal block of variable k;
+ *        inc_blk[e]           for entry e of thx_pg_structure's incidence lists (inc_edge / inc_side / inc_other): the id of the
+ *                             off-diagonal block it accumulates into when inc_other < the pose (lower triangle), else -1;
+ *        tile_ptr / piece_*   per lower tile t = i (i + 1) / 2 + j (i >= j): the pieces [tile_ptr[t], tile_ptr[t + 1]) that fall
+ *                             into it -- piece_blk: block id, piece_rc: position of the block's top-left element relative to the
+ *                             tile origin, (int16 row) << 16 | (uint16) (int16 col), negative when the block starts in the tile
+ *                             above / to the left (128 is not a multiple of 6: a block may straddle up to four tiles).
+ *      thx_pg_assemble_blocks: thx_pg_assemble writing the block list (every block is written in full, 16-byte pieces: no
+ *        zero-fill, no partial-sector stores) and g.
+ *      thx_hblocks_expand: the block list -> the dense (B, ld, ld) frame of thx_pg_assemble (caller zero-fills once) -- for
+ *        consumers of Linearization.AtA; the optimiser never calls it.
+ *      thx_hblocks_diag: diag(H) -> d (B, nvars * bd), row stride ldv  (Linearization.diagonal_scaling, LM's rho test).
+ *      thx_chol_factor_hblocks: thx_chol_factor_forward / thx_chol_factor_sparse (pattern != NULL) reading H from the block
+ *        list: every Cholesky tile gathers its pieces into LDS / adds them to its Schur update instead of streaming a dense
+ *        tile of zeros.  rhs / y may both be NULL (no fused forward substitution). */
+typedef struct {
+  int32_t nblocks, bd, nvars, ntiles;
+  const int32_t* diag_blk;
+  const int32_t* inc_blk;
+  const int32_t* tile_ptr;
+  const int32_t* piece_blk;
+  const int32_t* piece_rc;
+} thx_hblock_layout;
+int thx_pg_assemble_blocks(const thx_pg_structure* s, const thx_pg_data* d, const thx_hblock_layout* layout, void* Hc,
+                           int64_t bstride, void* g, int dtype, const thx_lie_eps* eps, void* stream);
+int thx_hblocks_expand(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t B, void* H, int64_t ld,
+                       int dtype, void* stream);
+int thx_hblocks_diag(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t B, void* d, int64_t ldv,
+                     int dtype, void* stream);
+
 /* ---- Generic assembly for ANY cost function: the same H (lower triangle) and g as thx_pg_assemble, from
  *      per-cost weighted Jacobian blocks J (B, dim, dof) and weighted errors e (B, dim) supplied as tensors
  *      (what CostFunction.weighted_jacobians_error returns, core/cost_function.py:107-122); replaces
@@ -280,6 +316,17 @@ int thx_chol_solve_backward(const void* L, int64_t ld, int32_t n, int32_t B, con
                             void* x, int64_t ldv, int dtype, void* stream);
 int thx_chol_solve(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs,
                    void* x, int64_t ldv, int dtype, void* stream);
+/*      Schedule knob of thx_chol_factor* (process-wide; results are the same factorisation either way).  The diagonal
+ *      phase of a block column runs either as ONE kernel (SYRK + the serial tile factorisation in the same workgroup) or SPLIT
+ *      into an MFMA-only SYRK kernel and a one-wave-per-tile kernel that keeps the tile in registers (eight tiles per CU in
+ *      their pivot chains instead of three).  The split pays from `min_batch` problems per call on (default 2048; 0 = always
+ *      split, INT32_MAX = never); `previous` (may be NULL) receives the old value. */
+int thx_chol_set_split_diag_min_batch(int32_t min_batch, int32_t* previous);
+/*      (block-compact Hessian, see thx_hblock_layout) */
+int thx_chol_factor_hblocks(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t n, int32_t B,
+                            const void* damping, int ellipsoidal, double damping_eps, void* L, int64_t ld, void* Winv,
+                            int32_t* info, const void* rhs, void* y, int64_t ldv, const thx_tile_pattern* pattern, int dtype,
+                            void* stream);
 
 /* ---- Implicit backward (BackwardMode.IMPLICIT, nonlinear/nonlinear_least_squares.py:121-135,265-292): the
  *      grad-enabled last step is X_new = X exp(step * delta), delta = H^-1 g(theta) with H detached

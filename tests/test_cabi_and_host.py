@@ -115,3 +115,35 @@ def test_integration_doc_lists_every_entry_point():
     assert len(names) > 30
     missing = [n for n in names if n not in doc]
     assert not missing, missing
+
+
+def test_hessian_block_layout_round_trip():
+    """theseus_amd/compiler.py:HessianBlocks -- the block-compact layout of tril(H) the device kernels read: every lower tile's
+    piece list, applied the way the kernels gather it, reproduces the dense lower frame (blocks straddling tile boundaries
+    included), for dof 6 and 3, natural and permuted variable orders."""
+    import numpy as np
+    from theseus_amd.compiler import PoseGraphStructure
+    from theseus_amd.utils.synthetic import pose_graph_topology
+    rng = np.random.default_rng(0)
+    for P, E, d, shuffle in ((256, 1024, 6, False), (70, 200, 6, True), (50, 120, 3, False)):
+        edges = pose_graph_topology(P, E, 0)
+        if shuffle:
+            perm = rng.permutation(P)
+            edges = [(int(perm[i]), int(perm[j])) for i, j in edges]
+        s = PoseGraphStructure.build(P, edges, [0], dof=d)
+        hb = s.hessian_blocks()
+        assert hb.nblocks == P + len({(max(i, j), min(i, j)) for i, j in edges})
+        assert (hb.inc_blk >= 0).sum() == len(edges) and hb.bstride % 4 == 0 and hb.bstride >= hb.nblocks * d * d
+        n = d * P
+        ld = (n + 31) // 32 * 32
+        H = np.zeros((2, ld, ld))
+        for a, b in hb.blocks.tolist():
+            H[:, d * a:d * a + d, d * b:d * b + d] = rng.normal(size=(2, d, d))
+        tiles = np.zeros((ld, ld), dtype=bool)
+        for ti in range(hb.ntiles):
+            for tj in range(ti + 1):
+                tiles[128 * ti:128 * ti + 128, 128 * tj:128 * tj + 128] = True
+        assert np.array_equal(hb.expand(hb.pack_dense(H), ld) * tiles, H * tiles)
+        # the blocks of a tile form one contiguous run (top-left ownership): ids ascend tile by tile
+        own = [(d * a // 128, d * b // 128) for a, b in hb.blocks.tolist()]
+        assert own == sorted(own)

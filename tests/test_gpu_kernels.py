@@ -212,10 +212,70 @@ def _random_spd(B, n, dtype, seed, cond=1e3):
     return M.to(dtype)
 
 
+@pytest.fixture
+def split_diag(K):
+    """The diagonal phase as chol_syrk_kernel + chol_potrf_kernel at ANY batch size (default: from 2048 problems on)."""
+    prev = K.chol_split_diag_min_batch(0)
+    yield
+    K.chol_split_diag_min_batch(prev)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("n,B", [(6, 3), (48, 5), (126, 4), (128, 9), (132, 3), (258, 8), (390, 17), (1536, 8)])
 def test_chol_factor_solve_vs_lapack(K, dtype, n, B, fused):
+    _chol_vs_lapack(K, dtype, n, B, fused)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("n,B", [(6, 3), (48, 5), (126, 4), (128, 9), (132, 3), (258, 8), (390, 17), (1536, 8)])
+def test_chol_split_diagonal_phase_vs_lapack(K, split_diag, dtype, n, B, fused):
+    """The same matrices through the SPLIT diagonal phase: MFMA-only SYRK kernel + the one-wave-per-tile kernel that keeps the
+    128 x 128 tile in registers (register x register MFMAs), incl. tiles that straddle the matrix edge (n = 6 ... 390)."""
+    _chol_vs_lapack(K, dtype, n, B, fused)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_chol_split_and_fused_diagonal_phase_agree(K, dtype):
+    """Both schedules run the same arithmetic on the tile (same MFMA pairings, same 32 x 32 pivot chains): L and the solve panels
+    come out BIT-identical; the fused forward substitution sums in a different order (rounding only)."""
+    from tests.gpu_helpers import factor_and_solve
+    from theseus_amd.kernels import round_up
+    n, B = 700, 12
+    M = _random_spd(B, n, dtype, seed=77)
+    rhs = torch.randn(B, n, dtype=torch.float64, generator=torch.Generator().manual_seed(1)).to(dtype).cuda()
+    ld = round_up(n, 32)
+    H = torch.zeros(B, ld, ld, dtype=dtype)
+    H[:, :n, :n] = torch.tril(M)
+    H = H.cuda()
+    lam = torch.full((B,), 0.05, dtype=dtype, device="cuda")
+    out = {}
+    for split in (True, False):
+        prev = K.chol_split_diag_min_batch(0 if split else 2 ** 31 - 1)
+        try:
+            out[split] = factor_and_solve(K, H, n, rhs, damping=lam, ellipsoidal=True, eps=1e-8, fused=True)
+        finally:
+            K.chol_split_diag_min_batch(prev)
+    (La, xa, ia), (Lb, xb, ib) = out[True], out[False]
+    assert int(ia.abs().sum()) == 0 and int(ib.abs().sum()) == 0
+    assert torch.equal(torch.tril(La[:, :n, :n]), torch.tril(Lb[:, :n, :n]))
+    assert (xa - xb).abs().max() <= (2e-5 if dtype == torch.float32 else 1e-13) * xb.abs().max()
+
+
+def test_chol_split_diagonal_phase_reports_non_positive_definite(K, split_diag):
+    from tests.gpu_helpers import factor_and_solve
+    n, B = 260, 4
+    M = _random_spd(B, n, torch.float64, seed=9)
+    M[2, 200, 200] = -1.0  # leading minor 201 fails for problem 2 only
+    H = torch.zeros(B, 288, 288, dtype=torch.float64); H[:, :n, :n] = torch.tril(M)
+    rhs = torch.ones(B, n, dtype=torch.float64)
+    _, _, info = factor_and_solve(K, H.cuda(), n, rhs.cuda())
+    info = info.cpu().tolist()
+    assert info[0] == 0 and info[1] == 0 and info[3] == 0 and info[2] == 201
+
+
+def _chol_vs_lapack(K, dtype, n, B, fused):
     from tests.gpu_helpers import factor_and_solve
     from theseus_amd.kernels import round_up
     M = _random_spd(B, n, dtype, seed=n + B)

@@ -26,8 +26,18 @@ def _banded_spd(B, n, bw_tiles, dtype, seed):
     return H.to(dtype), TilePattern(n, blocks, 6)
 
 
+@pytest.mark.parametrize("split_diag", [False, True])
 @pytest.mark.parametrize("dtype,n,B", [(torch.float32, 3072, 24), (torch.float64, 1536, 8), (torch.float32, 1530, 1100)])
-def test_sparse_factorisation_is_bit_identical_to_dense(dtype, n, B):
+def test_sparse_factorisation_is_bit_identical_to_dense(dtype, n, B, split_diag):
+    from theseus_amd.kernels import default_kernels
+    prev = default_kernels().chol_split_diag_min_batch(0 if split_diag else 2 ** 31 - 1)
+    try:
+        _sparse_vs_dense(dtype, n, B)
+    finally:
+        default_kernels().chol_split_diag_min_batch(prev)
+
+
+def _sparse_vs_dense(dtype, n, B):
     from theseus_amd.kernels import default_kernels, round_up
     K = default_kernels()
     Hc, pat = _banded_spd(B, n, 2, dtype, seed=n)

@@ -19,7 +19,7 @@ THX_TILE = 128
 THX_ERR_CHUNKS = 16
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
-ABI_VERSION = 14
+ABI_VERSION = 16
 
 
 class LieEps(Structure):
@@ -49,6 +49,11 @@ class BAData(Structure):  # thx_ba_data
 class TilePattern(Structure):  # thx_tile_pattern: tile-level symbolic factorisation (device int32 tables + one host table)
     _fields_ = [("ntiles", c_int32)] + [(k, c_void_p) for k in ("col_ptr", "col_row", "tile_kptr", "tile_k", "diag_kptr", "diag_k",
                                                                "col_count_host", "row_ptr", "row_tile")]
+
+
+class HBlockLayout(Structure):  # thx_hblock_layout: block-compact Hessian (device int32 tables)
+    _fields_ = [(k, c_int32) for k in ("nblocks", "bd", "nvars", "ntiles")] + [
+        (k, c_void_p) for k in ("diag_blk", "inc_blk", "tile_ptr", "piece_blk", "piece_rc")]
 
 
 class SE2Eps(Structure):  # thx_se2_eps (theseus/global_params.py:46-59)
@@ -139,6 +144,13 @@ _SIGNATURES = {
                                c_void_p, c_void_p, c_int64, POINTER(TilePattern), c_int, c_void_p],
     "thx_chol_solve_sparse": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                               POINTER(TilePattern), c_int, c_void_p],
+    "thx_chol_set_split_diag_min_batch": [c_int32, POINTER(c_int32)],
+    "thx_pg_assemble_blocks": [POINTER(PGStructure), POINTER(PGData), POINTER(HBlockLayout), c_void_p, c_int64, c_void_p, c_int,
+                               POINTER(LieEps), c_void_p],
+    "thx_hblocks_expand": [POINTER(HBlockLayout), c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int, c_void_p],
+    "thx_hblocks_diag": [POINTER(HBlockLayout), c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int, c_void_p],
+    "thx_chol_factor_hblocks": [POINTER(HBlockLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p,
+                                c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(TilePattern), c_int, c_void_p],
     "thx_chol_solve": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                        c_void_p],
     "thx_chol_solve_backward": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,

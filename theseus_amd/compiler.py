@@ -106,6 +106,13 @@ class PoseGraphStructure:
             blocks.add((max(i, j), min(i, j)))
         return np.array(sorted(blocks), dtype=np.int64)
 
+    def hessian_blocks(self) -> "HessianBlocks":
+        """Block-compact layout of tril(H) for this structure (built once)."""
+        hb = self._dev.get("__hblocks__")
+        if hb is None:
+            hb = self._dev["__hblocks__"] = HessianBlocks(self)
+        return hb
+
     # ---- device side ---------------------------------------------------------------------------
     def on(self, device) -> "DeviceStructure":
         key = str(device)
@@ -130,6 +137,97 @@ class DeviceStructure:
             self.t[f] = torch.from_numpy(a.copy()).to(self.device)
         c = _lib.PGStructure()
         c.num_poses, c.num_edges, c.num_priors = s.num_poses, s.num_edges, s.num_priors
+        for f in self._FIELDS:
+            setattr(c, f, self.t[f].data_ptr())
+        self.c = c
+
+
+TILE = _lib.THX_TILE
+
+
+class HessianBlocks:
+    """Block-compact storage of tril(H) (include/theseus_hip.h: thx_hblock_layout): the non-zero dof x dof blocks -- one per
+    variable (diagonal) and one per connected variable pair -- ordered by the 128 x 128 Cholesky tile of their top-left element,
+    then by (row variable, column variable), so that the blocks of a tile are one contiguous run of the list; per lower tile the
+    PIECES that fall into it (a block straddles up to four tiles: 128 is not a multiple of 6)."""
+
+    def __init__(self, s: PoseGraphStructure):
+        d, P = s.dof, s.num_poses
+        pat = s.lower_block_pattern()                                   # (nb, 2) sorted by (p, q), q <= p
+        p, q = pat[:, 0], pat[:, 1]
+        order = np.lexsort((q, p, (d * q) // TILE, (d * p) // TILE))    # by (tile row, tile col, p, q)
+        self.blocks = pat[order]
+        self.nblocks, self.bd, self.nvars = int(pat.shape[0]), d, P
+        self.ntiles = (d * P + TILE - 1) // TILE
+        ident = {(int(a), int(b)): k for k, (a, b) in enumerate(self.blocks.tolist())}
+        self.diag_blk = np.array([ident[(k, k)] for k in range(P)], dtype=np.int32)
+        pose_of_entry = np.repeat(np.arange(P), np.diff(s.inc_ptr))
+        self.inc_blk = np.array([ident[(int(a), int(o))] if o < a else -1 for a, o in zip(pose_of_entry.tolist(), s.inc_other.tolist())],
+                                dtype=np.int32)
+        # pieces per lower tile t = i (i + 1) / 2 + j
+        per_tile = [[] for _ in range(self.ntiles * (self.ntiles + 1) // 2)]
+        for k, (a, b) in enumerate(self.blocks.tolist()):
+            r, c = d * a, d * b
+            for ti in sorted({r // TILE, (r + d - 1) // TILE}):
+                for tj in sorted({c // TILE, (c + d - 1) // TILE}):
+                    if tj > ti:
+                        continue   # (the part of a straddling DIAGONAL block above the tile diagonal: never read)
+                    per_tile[ti * (ti + 1) // 2 + tj].append((k, r - TILE * ti, c - TILE * tj))
+        self.tile_ptr = np.zeros(len(per_tile) + 1, dtype=np.int32)
+        self.tile_ptr[1:] = np.cumsum([len(x) for x in per_tile])
+        flat = [x for lst in per_tile for x in lst]
+        self.piece_blk = np.array([x[0] for x in flat], dtype=np.int32)
+        self.piece_rc = np.array([((x[1] & 0xFFFF) << 16) | (x[2] & 0xFFFF) for x in flat], dtype=np.int64).astype(np.uint32).view(np.int32)
+        self.elems = self.nblocks * d * d
+        self.bstride = (self.elems + 3) // 4 * 4     # elements per problem (16-byte aligned in fp32)
+        self._dev = {}
+
+    def on(self, device) -> "DeviceHessianBlocks":
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = DeviceHessianBlocks(self, device)
+        return self._dev[key]
+
+    # ---- host-side reference of the layout (tests) ---------------------------------------------------------------
+    def pack_dense(self, H: np.ndarray) -> np.ndarray:
+        """(B, >= n, >= n) dense (lower) -> (B, bstride) block list."""
+        B, d = H.shape[0], self.bd
+        out = np.zeros((B, self.bstride), dtype=H.dtype)
+        for k, (a, b) in enumerate(self.blocks.tolist()):
+            out[:, k * d * d:(k + 1) * d * d] = H[:, d * a:d * a + d, d * b:d * b + d].reshape(B, -1)
+        return out
+
+    def expand(self, Hc: np.ndarray, ld: int) -> np.ndarray:
+        """(B, bstride) -> dense (B, ld, ld) the way the device kernels gather it: tile by tile, piece by piece."""
+        B, d = Hc.shape[0], self.bd
+        H = np.zeros((B, ld, ld), dtype=Hc.dtype)
+        for ti in range(self.ntiles):
+            for tj in range(ti + 1):
+                t = ti * (ti + 1) // 2 + tj
+                for pc in range(self.tile_ptr[t], self.tile_ptr[t + 1]):
+                    rc = int(self.piece_rc[pc]) & 0xFFFFFFFF
+                    r0, c0 = np.array(rc >> 16, dtype=np.uint16).view(np.int16), np.array(rc & 0xFFFF, dtype=np.uint16).view(np.int16)
+                    blk = Hc[:, self.piece_blk[pc] * d * d:(self.piece_blk[pc] + 1) * d * d].reshape(B, d, d)
+                    for e in range(d * d):
+                        r, c = int(r0) + e // d, int(c0) + e % d
+                        if 0 <= r < TILE and 0 <= c < TILE and TILE * ti + r < ld and TILE * tj + c < ld:
+                            H[:, TILE * ti + r, TILE * tj + c] = blk[:, e // d, e % d]
+        return H
+
+
+class DeviceHessianBlocks:
+    _FIELDS = ["diag_blk", "inc_blk", "tile_ptr", "piece_blk", "piece_rc"]
+
+    def __init__(self, hb: HessianBlocks, device):
+        self.host = hb
+        self.t = {}
+        for f in self._FIELDS:
+            a = getattr(hb, f)
+            if a.size == 0:
+                a = np.zeros(1, np.int32)
+            self.t[f] = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        c = _lib.HBlockLayout()
+        c.nblocks, c.bd, c.nvars, c.ntiles = hb.nblocks, hb.bd, hb.nvars, hb.ntiles
         for f in self._FIELDS:
             setattr(c, f, self.t[f].data_ptr())
         self.c = c

@@ -33,6 +33,7 @@
 // backward pass).
 #include "common.cuh"
 
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -252,6 +253,86 @@ struct Engine<float> {
       d = __builtin_amdgcn_mfma_f32_32x32x2f32(asign * fa.w, fb.w, d, 0, 0, 0);
     }
   }
+
+  // ---- register-resident blocks (chol_potrf_kernel: the whole diagonal tile lives in ONE wave's registers) ----
+  // D[m][n] += sum_k (asign * A[m][k]) * B[n][k] with A, B AND D in the C/D layout (lane = the block's own row, registers =
+  // columns): an MFMA's k index is only a pairing of columns, and two blocks in this layout pair theirs identically
+  // (register rho of lane group g <-> column 8(rho>>2) + 4g + (rho&3)).  No LDS, no data movement.
+  static __device__ __forceinline__ void blk_mma_rr(const Blk& A, const Blk& B, Blk& d, float asign) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d = __builtin_amdgcn_mfma_f32_32x32x2f32(asign * A[i], B[i], d, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void blk_neg(Blk& d) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = -d[i];
+  }
+  // 32x32 block of a row-major global matrix -> registers; rows >= rv / columns >= cv (outside the matrix): identity on a
+  // diagonal block, zero elsewhere
+  static __device__ __forceinline__ void blk_load_global(Blk& d, const float* blk, const float* safe, int64_t ld, int rv, int cv,
+                                                         bool diag, int lane) {
+    const int r = lane & 31, g = lane >> 5;
+    // (a sub-block wholly outside the matrix may lie outside the FRAME too: its lanes read ``safe`` -- 32 valid elements)
+    const float* p = (r < rv ? blk + (int64_t)r * ld : safe) + 4 * g;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(p + 8 * q);
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = 8 * q + 4 * g + k;
+        d[4 * q + k] = (r < rv && c < cv) ? e[k] : ((diag && r == c) ? 1.f : 0.f);
+      }
+    }
+  }
+  // registers -> global (rows < rv only), scaled by sign
+  static __device__ __forceinline__ void blk_store_global(const Blk& d, float* blk, int64_t ld, int rv, int lane, float sign) {
+    const int r = lane & 31, g = lane >> 5;
+    if (r < rv) {
+      float* p = blk + (int64_t)r * ld + 4 * g;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(p + 8 * q) =
+            make_float4(sign * d[4 * q], sign * d[4 * q + 1], sign * d[4 * q + 2], sign * d[4 * q + 3]);
+    }
+  }
+  // rows of a 32-vector a lane is responsible for: NR of them, row blk_row(lane, i); the lanes with row_owner() write
+  static constexpr int NR = 1;
+  static __device__ __forceinline__ int blk_row(int lane, int) { return lane & 31; }
+  static __device__ __forceinline__ bool row_owner(int lane) { return lane < 32; }
+  // out[0] = sum_c X[row][c] * vec[c] for this lane's row (vec: 32 values in LDS); valid in every lane
+  static __device__ __forceinline__ void blk_rowdot(const Blk& X, const float* vec, int lane, float (&out)[1]) {
+    const int g = lane >> 5;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(vec + 8 * q + 4 * g);
+      s += X[4 * q] * v.x + X[4 * q + 1] * v.y + X[4 * q + 2] * v.z + X[4 * q + 3] * v.w;
+    }
+    out[0] = s + __shfl_xor(s, 32);
+  }
+  // S = H (+ damping on the diagonal) - acc of the 36 lower 16x16 blocks -> the diagonal tile's place in the GLOBAL factor
+  // (rows inside the matrix only; chol_potrf_kernel pads on load)
+  template <int G>
+  static __device__ __forceinline__ void syrk36_store_global(float* Lt, int64_t ld, const float4* hp, const f32x4* acc, int lane,
+                                                             int valid, bool damp, float lam, int ellipsoidal, float eps) {
+    constexpr int UH = 4 + G, UL = 3 - G;
+    auto st = [&](int u, int v, const float4& h, const f32x4& a) __attribute__((always_inline)) {
+      const int r = 16 * u + (lane & 15), c0 = 16 * v + 4 * (lane >> 4);
+      if (r >= valid) return;
+      float hv[4] = {h.x, h.y, h.z, h.w}, o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float x = hv[k];
+        if (u == v && r == c0 + k && damp) x = ellipsoidal ? x + (lam * x + eps) : x + lam;
+        o[k] = x - a[k];
+      }
+      *reinterpret_cast<float4*>(Lt + (int64_t)r * ld + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    };
+#pragma unroll
+    for (int v = 0; v <= UH; ++v) st(UH, v, hp[v], acc[v]);
+#pragma unroll
+    for (int v = 0; v <= UL; ++v) st(UL, v, hp[UH + 1 + v], acc[UH + 1 + v]);
+  }
 };
 
 template <>
@@ -410,6 +491,97 @@ struct Engine<double> {
       d.v[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, d.v[1][0], 0, 0, 0);
       d.v[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, d.v[1][1], 0, 0, 0);
     }
+  }
+
+  // ---- register-resident blocks (see Engine<float>): Blk.v[kh][rowhalf][rho] = X[16 rowhalf + (lane&15)][16 kh + (lane>>4) + 4 rho],
+  //      so MFMA (kh, rho) contracts the four consecutive columns 16 kh + 4 rho + {0..3} of both operands ----
+  static __device__ __forceinline__ void blk_mma_rr(const Blk& A, const Blk& B, Blk& d, double asign) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) {
+        const double a0 = asign * A.v[kh][0][rho], a1 = asign * A.v[kh][1][rho];
+        const double b0 = B.v[kh][0][rho], b1 = B.v[kh][1][rho];
+        d.v[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, d.v[0][0], 0, 0, 0);
+        d.v[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, d.v[0][1], 0, 0, 0);
+        d.v[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, d.v[1][0], 0, 0, 0);
+        d.v[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, d.v[1][1], 0, 0, 0);
+      }
+  }
+  static __device__ __forceinline__ void blk_neg(Blk& d) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d.v[a][b][i] = -d.v[a][b][i];
+  }
+  static __device__ __forceinline__ void blk_load_global(Blk& d, const double* blk, const double* safe, int64_t ld, int rv, int cv,
+                                                         bool diag, int lane) {
+    const int rl = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      const int r = 16 * nh + rl;
+      const double* p = (r < rv ? blk + (int64_t)r * ld : safe) + kq;
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) {
+          const int c = 16 * mh + kq + 4 * rho;
+          const double x = p[16 * mh + 4 * rho];
+          d.v[mh][nh][rho] = (r < rv && c < cv) ? x : ((diag && r == c) ? 1.0 : 0.0);
+        }
+    }
+  }
+  static __device__ __forceinline__ void blk_store_global(const Blk& d, double* blk, int64_t ld, int rv, int lane, double sign) {
+    const int rl = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      const int r = 16 * nh + rl;
+      if (r < rv) {
+        double* p = blk + (int64_t)r * ld + kq;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+          for (int rho = 0; rho < 4; ++rho) p[16 * mh + 4 * rho] = sign * d.v[mh][nh][rho];
+      }
+    }
+  }
+  static constexpr int NR = 2;
+  static __device__ __forceinline__ int blk_row(int lane, int i) { return 16 * i + (lane & 15); }
+  static __device__ __forceinline__ bool row_owner(int lane) { return lane < 16; }
+  static __device__ __forceinline__ void blk_rowdot(const Blk& X, const double* vec, int lane, double (&out)[2]) {
+    const int kq = lane >> 4;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      double s = 0.0;
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) s += X.v[mh][nh][rho] * vec[16 * mh + kq + 4 * rho];
+      s += __shfl_xor(s, 16);
+      out[nh] = s + __shfl_xor(s, 32);
+    }
+  }
+  template <int G>
+  static __device__ __forceinline__ void syrk36_store_global(double* Lt, int64_t ld, const f64x4* hp, const f64x4* acc, int lane,
+                                                             int valid, bool damp, double lam, int ellipsoidal, double eps) {
+    constexpr int UH = 4 + G, UL = 3 - G;
+    auto st = [&](int u, int v, const f64x4& h, const f64x4& a) __attribute__((always_inline)) {
+      const int r = 16 * u + (lane & 15), c0 = 16 * v + (lane >> 4);
+      if (r >= valid) return;
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) {
+        const int c = c0 + 4 * rho;
+        double x = h[rho];
+        if (u == v && r == c && damp) x = ellipsoidal ? x + (lam * x + eps) : x + lam;
+        Lt[(int64_t)r * ld + c] = x - a[rho];
+      }
+    };
+#pragma unroll
+    for (int v = 0; v <= UH; ++v) st(UH, v, hp[v], acc[v]);
+#pragma unroll
+    for (int v = 0; v <= UL; ++v) st(UL, v, hp[UH + 1 + v], acc[UH + 1 + v]);
   }
 };
 
@@ -588,36 +760,6 @@ __device__ __forceinline__ void panel_forward(const T* M, T* vec, T* ubuf, int l
     T yv = T(0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) yv += row[32 * sb + 16 * hf + i] * ubuf[16 * hf + i];
-    yv = half_sum(yv);
-    __builtin_amdgcn_wave_barrier();
-    if (hf == 0) vec[32 * sb + rl] = yv;
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// the same on the block-compact LDS tile of chol_diag (sub-block (s,t) at tblk(s,t), row stride LDB)
-template <typename T>
-__device__ __forceinline__ void panel_forward_blk(const T* M, T* vec, T* ubuf, int lane) {
-  using C = CT<T>;
-  const int rl = lane & 31, hf = lane >> 5;
-#pragma unroll
-  for (int sb = 0; sb < 4; ++sb) {
-    T u = T(0);
-#pragma unroll
-    for (int tb = 0; tb < sb; ++tb) {  // columns of sub-block tb, 16 per lane half
-      const T* row = M + tblk<T>(sb, tb) + rl * C::LDB + 16 * hf;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) u += row[i] * vec[32 * tb + 16 * hf + i];
-    }
-    u = half_sum(u) + vec[32 * sb + rl];
-    if (hf == 0) ubuf[rl] = u;
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are visible to its reads
-    __builtin_amdgcn_wave_barrier();
-    const T* wrow = M + tblk<T>(sb, sb) + rl * C::LDB + 16 * hf;
-    T yv = T(0);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) yv += wrow[i] * ubuf[16 * hf + i];
     yv = half_sum(yv);
     __builtin_amdgcn_wave_barrier();
     if (hf == 0) vec[32 * sb + rl] = yv;
@@ -941,6 +1083,60 @@ struct TilePat {
   const int32_t* diag_k;     // ... block columns k < j with L_jk non-zero
 };
 
+// Fused forward substitution through a finished panel column (sub-block column sb of the diagonal tile), on blocks in the
+// register layout of Engine::Blk:  y_s = W_ss u_s ;  u_u += (-L_us) y_s  for the sub-blocks below.  ONE implementation for both
+// schedules of the diagonal phase (chol_diag_kernel loads the blocks from its LDS tile, chol_potrf_kernel has them in
+// registers): the same sums in the same order, so y -- and with it every LM trajectory -- does not depend on which schedule a
+// batch size selects (tests/test_gpu_full_size.py: any slice of a batch solved alone is bit-identical).
+template <typename T>
+__device__ __forceinline__ void fwd_diag_block(const typename Engine<T>::Blk& W, T* vvec, int sb, int lane) {
+  using E = Engine<T>;
+  T y[E::NR];
+  E::blk_rowdot(W, vvec + 32 * sb, lane, y);
+  wave_lds_fence();   // every lane has read u_s
+  if (E::row_owner(lane)) {
+#pragma unroll
+    for (int i = 0; i < E::NR; ++i) vvec[32 * sb + E::blk_row(lane, i)] = y[i];
+  }
+  wave_lds_fence();
+}
+template <typename T>
+__device__ __forceinline__ void fwd_below_block(const typename Engine<T>::Blk& X, T* vvec, int sb, int u, int lane) {
+  using E = Engine<T>;
+  T part[E::NR];
+  E::blk_rowdot(X, vvec + 32 * sb, lane, part);
+  if (E::row_owner(lane)) {
+#pragma unroll
+    for (int i = 0; i < E::NR; ++i) vvec[32 * u + E::blk_row(lane, i)] += part[i];
+  }
+}
+
+// device view of a block-compact Hessian (include/theseus_hip.h: thx_hblock_layout + the value buffer); blocks == nullptr:
+// H is the dense frame
+struct HBlk {
+  const void* blocks;
+  int64_t bstride;
+  int bd;
+  const int32_t* tile_ptr;
+  const int32_t* piece_blk;
+  const int32_t* piece_rc;
+};
+
+// every element of the pieces of lower tile (ti, tj) of problem b: f(r, c, value), (r, c) relative to the tile origin and inside
+// the tile.  The blocks of a tile are one contiguous run of the list (straddlers from the neighbours aside): coalesced reads.
+template <typename T, typename F>
+__device__ __forceinline__ void hb_foreach(const HBlk& hb, int b, int ti, int tj, int tid, int nthreads, F&& f) {
+  const T* base = static_cast<const T*>(hb.blocks) + (int64_t)b * hb.bstride;
+  const int bd = hb.bd, bb = bd * bd, t = ti * (ti + 1) / 2 + tj;
+  const int p0 = hb.tile_ptr[t], cnt = (hb.tile_ptr[t + 1] - p0) * bb;
+  for (int idx = tid; idx < cnt; idx += nthreads) {
+    const int pc = p0 + idx / bb, e = idx % bb;
+    const int rc = hb.piece_rc[pc];
+    const int r = (int)(short)(rc >> 16) + e / bd, c = (int)(short)(rc & 0xffff) + e % bd;
+    if (r >= 0 && r < TILE && c >= 0 && c < TILE) f(r, c, base[(int64_t)hb.piece_blk[pc] * bb + e]);
+  }
+}
+
 template <typename T>
 struct DiagSmem {
   // ten 32 x LDB sub-blocks; the K-loop's staging buffer (128 x SYRK_LDT) lives in its head
@@ -950,11 +1146,11 @@ struct DiagSmem {
   static size_t bytes(int ypad) { return tile + 160 * sizeof(T) + (size_t)ypad * sizeof(T); }
 };
 
-template <typename T>
+template <typename T, bool HB>
 __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 3 : 1)
 chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ panel, const T* __restrict__ damping,
                  int ellipsoidal, T damping_eps, int32_t* __restrict__ info, int n, int64_t ld, int j, int ntiles,
-                 const T* __restrict__ rhs, T* __restrict__ yout, int64_t ldv, TilePat pat) {
+                 const T* __restrict__ rhs, T* __restrict__ yout, int64_t ldv, TilePat pat, HBlk hb) {
   using C = CT<T>;
   using V = typename C::V;
   using E = Engine<T>;
@@ -992,11 +1188,18 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   auto prologue = [&]() __attribute__((always_inline)) {
     if (fwd)
       for (int k = tid; k < row0; k += 256) ybuf[k] = yout[(int64_t)b * ldv + k];
-    const T* Hjj = H + mat + (int64_t)row0 * ld + row0;
-    if (wave == 0) E::template syrk36_prefetch<0>(Hjj, ld, valid, hpre, lane);
-    else if (wave == 1) E::template syrk36_prefetch<1>(Hjj, ld, valid, hpre, lane);
-    else if (wave == 2) E::template syrk36_prefetch<2>(Hjj, ld, valid, hpre, lane);
-    else E::template syrk36_prefetch<3>(Hjj, ld, valid, hpre, lane);
+    if constexpr (!HB) {
+      const T* Hjj = H + mat + (int64_t)row0 * ld + row0;
+      if (wave == 0) E::template syrk36_prefetch<0>(Hjj, ld, valid, hpre, lane);
+      else if (wave == 1) E::template syrk36_prefetch<1>(Hjj, ld, valid, hpre, lane);
+      else if (wave == 2) E::template syrk36_prefetch<2>(Hjj, ld, valid, hpre, lane);
+      else E::template syrk36_prefetch<3>(Hjj, ld, valid, hpre, lane);
+    } else {   // block-compact H: the tile's blocks are ADDED after the SYRK (below); the "H" of the store is zero
+#pragma unroll
+      for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) reinterpret_cast<T*>(&hpre[i])[k] = T(0);
+    }
   };
 #ifdef THX_OFF_PROLOGUE_FIRST   // the round-1 order (A/B timing)
   prologue();
@@ -1024,14 +1227,22 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   {
     const bool damp = damping != nullptr;
     const T lam = damp ? damping[b] : T(0);
-    if (wave == 0) E::template syrk36_store<0>(tile, hpre, acc, lane, valid, damp, lam, ellipsoidal, damping_eps);
-    else if (wave == 1) E::template syrk36_store<1>(tile, hpre, acc, lane, valid, damp, lam, ellipsoidal, damping_eps);
-    else if (wave == 2) E::template syrk36_store<2>(tile, hpre, acc, lane, valid, damp, lam, ellipsoidal, damping_eps);
-    else E::template syrk36_store<3>(tile, hpre, acc, lane, valid, damp, lam, ellipsoidal, damping_eps);
+    const bool sd = damp && !HB;   // (block-compact H: the damping rides on the diagonal elements of the gathered blocks)
+    if (wave == 0) E::template syrk36_store<0>(tile, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
+    else if (wave == 1) E::template syrk36_store<1>(tile, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
+    else if (wave == 2) E::template syrk36_store<2>(tile, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
+    else E::template syrk36_store<3>(tile, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
     __syncthreads();  // vvec visible
     {  // g_j - L_j,0:j y : thread pair (2r, 2r+1) holds the two halves of row r's sum
       const T tsum = tpart + __shfl_xor(tpart, 1);
       if (fwd && (tid & 1) == 0) vvec[tid >> 1] -= tsum;
+    }
+    if constexpr (HB) {   // S += H_jj (+ damping): each element of the tile's lower triangle belongs to at most one piece
+      hb_foreach<T>(hb, b, j, j, tid, 256, [&](int r, int c, T v) __attribute__((always_inline)) {
+        if (c > r) return;
+        if (r == c && damp) v = ellipsoidal ? v + (lam * v + damping_eps) : v + lam;
+        tile[tblk<T>(r >> 5, c >> 5) + (r & 31) * C::LDB + (c & 31)] += v;
+      });
     }
   }
   __syncthreads();
@@ -1171,7 +1382,19 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
       }
   }
   if (fwd) {
-    if (wave == 0) panel_forward_blk<T>(tile, vvec, ubuf, lane);
+    if (wave == 0) {   // (the shared column-by-column substitution: same rounding as chol_potrf_kernel's)
+      for (int sb = 0; sb < 4; ++sb) {
+        typename E::Blk Wb;
+        E::blk_load(Wb, tile + tblk<T>(sb, sb), lane);
+        fwd_diag_block<T>(Wb, vvec, sb, lane);
+        for (int u = sb + 1; u < 4; ++u) {
+          typename E::Blk Xb;
+          E::blk_load(Xb, tile + tblk<T>(u, sb), lane);
+          fwd_below_block<T>(Xb, vvec, sb, u, lane);
+        }
+        wave_lds_fence();
+      }
+    }
     __syncthreads();
     if (tid < valid) yout[(int64_t)b * ldv + row0 + tid] = vvec[tid];
   }
@@ -1184,6 +1407,190 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
     P[0] = (T)nst;
   }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// The diagonal phase SPLIT in two kernels (default; THX_CHOL_FUSED_DIAG=1 selects chol_diag_kernel above):
+//   chol_syrk_kernel : the MFMA half of chol_diag -- S = H_jj + damping - L_j,0:j L_j,0:j^T (36 lower 16x16 blocks, nine per wave),
+//                      riding on it g_j - L_j,0:j y -- written to the diagonal tile's place in the global factor / to y_j.
+//                      No serial phase: all four waves of all three resident workgroups issue MFMAs for the kernel's whole life.
+//   chol_potrf_kernel: the serial half, ONE WAVE per tile.  The tile's ten lower 32x32 sub-blocks live in that wave's registers in
+//                      the MFMA C/D layout (160 VGPRs in fp32); the sub-block TRSMs and trailing updates are register x register
+//                      MFMAs (Engine::blk_mma_rr: no LDS traffic at all), only the 32x32 diagonal sub-block being factorised and
+//                      inverted passes through a 4.6 KB LDS block (potrf_inv32_blocked).  5 KB of LDS and <= 256 VGPRs per tile:
+//                      EIGHT tiles per CU are in their latency-bound pivot chains at once, against three with chol_diag -- whose
+//                      workgroup pinned 53 KB of LDS and three idle waves' registers for the 126 k cycles of its chain, i.e. kept
+//                      a third of a CU from anything else.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct SyrkSmem {
+  static size_t bytes(int ypad) { return (size_t)128 * Engine<T>::SYRK_LDT * sizeof(T) + (size_t)ypad * sizeof(T); }
+};
+
+template <typename T, bool HB>
+__global__ void __launch_bounds__(256, 3)
+chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict__ damping, int ellipsoidal, T damping_eps,
+                 int n, int64_t ld, int j, const T* __restrict__ rhs, T* __restrict__ yout, int64_t ldv, TilePat pat, HBlk hb) {
+  using E = Engine<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* stage = reinterpret_cast<T*>(smem_raw);                 // K-loop staging buffer, 128 x SYRK_LDT
+  T* ybuf = stage + 128 * E::SYRK_LDT;                       // y_0:j of the earlier columns
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t mat = (int64_t)b * ld * ld;
+  const int row0 = j * TILE;
+  const int valid = min(TILE, n - row0);
+  const bool fwd = rhs != nullptr;
+
+  typename E::Sy acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[i][k] = T(0);
+  T tpart = T(0);  // this thread's half of (L_j,0:j y)[tid >> 1]
+  std::conditional_t<sizeof(T) == 4, float4, f64x4> hpre[9];
+  auto prologue = [&]() __attribute__((always_inline)) {
+    if (fwd)
+      for (int k = tid; k < row0; k += 256) ybuf[k] = yout[(int64_t)b * ldv + k];
+    if constexpr (!HB) {
+      const T* Hjj = H + mat + (int64_t)row0 * ld + row0;
+      if (wave == 0) E::template syrk36_prefetch<0>(Hjj, ld, valid, hpre, lane);
+      else if (wave == 1) E::template syrk36_prefetch<1>(Hjj, ld, valid, hpre, lane);
+      else if (wave == 2) E::template syrk36_prefetch<2>(Hjj, ld, valid, hpre, lane);
+      else E::template syrk36_prefetch<3>(Hjj, ld, valid, hpre, lane);
+    } else {   // block-compact H: the tile's blocks are ADDED after the SYRK (below); the "H" of the store is zero
+#pragma unroll
+      for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) reinterpret_cast<T*>(&hpre[i])[k] = T(0);
+    }
+  };
+  const int32_t* klist = pat.diag_k ? pat.diag_k + pat.diag_kptr[j] : nullptr;
+  const int Kspan = pat.diag_k ? (pat.diag_kptr[j + 1] - pat.diag_kptr[j]) * TILE : row0;
+  kloop_f<T, true, true, E::SYRK_LDT>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, Kspan, stage, nullptr, tid,
+                                      fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
+    if (wave == 0) E::template syrk36<0>(stage, acc, lane);
+    else if (wave == 1) E::template syrk36<1>(stage, acc, lane);
+    else if (wave == 2) E::template syrk36<2>(stage, acc, lane);
+    else E::template syrk36<3>(stage, acc, lane);
+  }, prologue, klist);
+
+  {
+    const bool damp = damping != nullptr;
+    const T lam = damp ? damping[b] : T(0);
+    T* Lt = L + mat + (int64_t)row0 * ld + row0;
+    const bool sd = damp && !HB;
+    if (wave == 0) E::template syrk36_store_global<0>(Lt, ld, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
+    else if (wave == 1) E::template syrk36_store_global<1>(Lt, ld, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
+    else if (wave == 2) E::template syrk36_store_global<2>(Lt, ld, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
+    else E::template syrk36_store_global<3>(Lt, ld, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
+    if constexpr (HB) {
+      // block-compact H: the tile now holds -L_j L_j^T; its pieces of H (+ damping on the diagonal) are added in place.  The
+      // stores above are this workgroup's own: visible to all its threads after the fence + barrier.
+      __threadfence_block();
+      __syncthreads();
+      hb_foreach<T>(hb, b, j, j, tid, 256, [&](int r, int c, T v) __attribute__((always_inline)) {
+        if (c > r || r >= valid) return;
+        if (r == c && damp) v = ellipsoidal ? v + (lam * v + damping_eps) : v + lam;
+        Lt[(int64_t)r * ld + c] += v;
+      });
+    }
+  }
+  if (fwd) {  // g_j - L_j,0:j y -> y_j's place (chol_potrf_kernel finishes it): thread pair (2r, 2r+1) holds the halves of row r
+    const T tsum = tpart + __shfl_xor(tpart, 1);
+    const int r = tid >> 1;
+    if ((tid & 1) == 0 && r < valid) yout[(int64_t)b * ldv + row0 + r] = rhs[(int64_t)b * ldv + row0 + r] - tsum;
+  }
+}
+
+__device__ __forceinline__ constexpr int bidx(int u, int v) { return u * (u + 1) / 2 + v; }
+
+template <typename T>
+__global__ void __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1)
+chol_potrf_kernel(T* __restrict__ L, T* __restrict__ panel, int32_t* __restrict__ info, int n, int64_t ld, int j, int ntiles,
+                  T* __restrict__ yout, int64_t ldv) {
+  using C = CT<T>;
+  using E = Engine<T>;
+  using Blk = typename E::Blk;
+  __shared__ __attribute__((aligned(16))) T Dss[32 * C::LDB];   // the diagonal sub-block being factorised / inverted
+  __shared__ __attribute__((aligned(16))) T vvec[TILE];         // right-hand side / solution of the fused forward substitution
+  // fp32, two waves per SIMD (256 VGPRs): while the FIRST diagonal sub-block is factorised -- nine other sub-blocks live next to
+  // the temporaries of potrf_inv32_blocked -- the last block row waits in LDS instead of in spilled registers
+  constexpr int PARK = sizeof(T) == 4 ? 3 : 0;
+  __shared__ __attribute__((aligned(16))) T park[PARK > 0 ? PARK * 32 * C::LDB : 4];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int64_t mat = (int64_t)b * ld * ld;
+  const int row0 = j * TILE, valid = min(TILE, n - row0);
+  T* Lt = L + mat + (int64_t)row0 * ld + row0;
+  const bool fwd = yout != nullptr;
+
+  // the tile: S (written by chol_syrk_kernel) -> registers; identity outside the matrix
+  Blk Tb[10];
+  static_for<4>([&](auto iu) __attribute__((always_inline)) {
+    constexpr int u = decltype(iu)::value;
+    static_for<u + 1>([&](auto iv) __attribute__((always_inline)) {
+      constexpr int v = decltype(iv)::value;
+      E::blk_load_global(Tb[bidx(u, v)], Lt + (int64_t)(32 * u) * ld + 32 * v, Lt, ld, valid - 32 * u, valid - 32 * v, u == v, lane);
+    });
+  });
+  if (fwd) {
+#pragma unroll
+    for (int k = lane; k < TILE; k += 64) vvec[k] = k < valid ? yout[(int64_t)b * ldv + row0 + k] : T(0);
+  }
+
+  // blocked right-looking Cholesky over the four 32-wide sub-block columns.  A finished column -- W_ss = L_ss^-1 on the diagonal
+  // sub-block, -L_us below it: the solve panel's column -- is used at once for the fused forward substitution and stored, so
+  // its registers are free for the rest of the factorisation.
+  T* P = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
+  static_for<4>([&](auto isb) __attribute__((always_inline)) {
+    constexpr int sb = decltype(isb)::value;
+    E::blk_store(Tb[bidx(sb, sb)], Dss, lane, T(1));
+    if constexpr (sb == 0 && PARK > 0) {
+      static_for<PARK>([&](auto ik) __attribute__((always_inline)) {
+        constexpr int k = decltype(ik)::value;
+        E::blk_store(Tb[bidx(3, 1 + k)], park + k * 32 * C::LDB, lane, T(1));
+      });
+    }
+    wave_lds_fence();
+    const int bad = potrf_inv32_blocked<T>(Dss, Lt + (int64_t)(32 * sb) * ld + 32 * sb, ld, valid - 32 * sb, lane);
+    if (bad != 0 && lane == 0 && info[b] == 0) info[b] = row0 + 32 * sb + bad;
+    wave_lds_fence();
+    E::blk_load(Tb[bidx(sb, sb)], Dss, lane);   // W_ss (full 32 x 32, zero above the diagonal)
+    if constexpr (sb == 0 && PARK > 0) {
+      static_for<PARK>([&](auto ik) __attribute__((always_inline)) {
+        constexpr int k = decltype(ik)::value;
+        E::blk_load(Tb[bidx(3, 1 + k)], park + k * 32 * C::LDB, lane);
+      });
+    }
+    E::blk_store_global(Tb[bidx(sb, sb)], P + (32 * sb) * TILE + 32 * sb, TILE, 32, lane, T(1));
+    if (fwd) fwd_diag_block<T>(Tb[bidx(sb, sb)], vvec, sb, lane);   // y_s = W_ss u_s (u_s: what the earlier columns left)
+    // L_us = S_us W_ss^T for the sub-blocks below, kept negated; u_u += (-L_us) y_s
+    static_for<3 - sb>([&](auto iu) __attribute__((always_inline)) {
+      constexpr int u = sb + 1 + decltype(iu)::value;
+      Blk X;
+      E::blk_zero(X);
+      E::blk_mma_rr(Tb[bidx(sb, sb)], Tb[bidx(u, sb)], X, T(1));
+      E::blk_neg(X);
+      Tb[bidx(u, sb)] = X;
+      E::blk_store_global(X, P + (32 * u) * TILE + 32 * sb, TILE, 32, lane, T(1));
+      E::blk_store_global(X, Lt + (int64_t)(32 * u) * ld + 32 * sb, ld, valid - 32 * u, lane, T(-1));
+      if (fwd) fwd_below_block<T>(X, vvec, sb, u, lane);
+    });
+    // trailing update S_uv -= L_us L_vs^T, sb < v <= u  (Tb(v,sb) = -L_vs is negated back, Tb(u,sb) = -L_us)
+    static_for<3 - sb>([&](auto iu) __attribute__((always_inline)) {
+      constexpr int u = sb + 1 + decltype(iu)::value;
+      static_for<u - sb>([&](auto iv) __attribute__((always_inline)) {
+        constexpr int v = sb + 1 + decltype(iv)::value;
+        E::blk_mma_rr(Tb[bidx(v, sb)], Tb[bidx(u, sb)], Tb[bidx(u, v)], T(-1));
+      });
+    });
+    if (fwd) wave_lds_fence();   // the vvec updates of this column before the next column reads them
+  });
+  if (fwd) {
+#pragma unroll
+    for (int k = lane; k < TILE; k += 64)
+      if (k < valid) yout[(int64_t)b * ldv + row0 + k] = vvec[k];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1220,9 +1627,10 @@ __device__ __forceinline__ void sub_mma_sw(const float* Pc, const Engine<float>:
   }
 }
 
+template <bool HB>
 __global__ void __launch_bounds__(256, 2)
 chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, const float* __restrict__ panel, int n,
-                        int64_t ld, int j, int ntiles, int i_first, int nrow_tiles, int B, TilePat pat) {
+                        int64_t ld, int j, int ntiles, int i_first, int nrow_tiles, int B, TilePat pat, HBlk hb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int bid = blockIdx.x;
@@ -1256,7 +1664,7 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   const bool rvalid = r < validB;
   float4 hr[4][4];
   auto prologue = [&]() __attribute__((always_inline)) {
-    {
+    if constexpr (!HB) {
       const float* Hrow = H + mat + (int64_t)(row0 + (rvalid ? r : 0)) * ld + col0 + 4 * g;
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb)
@@ -1301,18 +1709,49 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   st[2] = (long long)__builtin_readcyclecounter();
   __builtin_amdgcn_sched_barrier(0);
 #endif
-  // P = H_ij - sum (rows outside the matrix: zero)
+  if constexpr (HB) {
+    // block-compact H: the tile's pieces are gathered into the (now free) staging buffers, 64 rows at a time, and read back in
+    // the accumulator layout -- a few hundred elements instead of a 64 KB tile of zeros from HBM
+    constexpr int LDH = 132;
+    static_assert(64 * LDH <= OFF32_STAGE_FLOATS, "half an H tile must fit in the staging buffers");
+    __syncthreads();   // the K-loop's last chunk has been consumed
 #pragma unroll
-  for (int cb = 0; cb < 4; ++cb)
+    for (int half = 0; half < 2; ++half) {
+      for (int k = tid; k < 64 * LDH / 4; k += 256) reinterpret_cast<float4*>(smem)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      __syncthreads();
+      hb_foreach<float>(hb, b, i, j, tid, 256, [&](int rr, int cc, float v) __attribute__((always_inline)) {
+        if ((rr >> 6) == half) smem[(rr & 63) * LDH + cc] = v;
+      });
+      __syncthreads();
+      if ((wave >> 1) == half) {
+        const float* hrow = smem + (r & 63) * LDH + 4 * g;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 h = hr[cb][q];
-      P.v[cb][4 * q + 0] = (rvalid ? h.x : 0.f) - P.v[cb][4 * q + 0];
-      P.v[cb][4 * q + 1] = (rvalid ? h.y : 0.f) - P.v[cb][4 * q + 1];
-      P.v[cb][4 * q + 2] = (rvalid ? h.z : 0.f) - P.v[cb][4 * q + 2];
-      P.v[cb][4 * q + 3] = (rvalid ? h.w : 0.f) - P.v[cb][4 * q + 3];
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 h = *reinterpret_cast<const float4*>(hrow + 32 * cb + 8 * q);
+            P.v[cb][4 * q + 0] = h.x - P.v[cb][4 * q + 0];
+            P.v[cb][4 * q + 1] = h.y - P.v[cb][4 * q + 1];
+            P.v[cb][4 * q + 2] = h.z - P.v[cb][4 * q + 2];
+            P.v[cb][4 * q + 3] = h.w - P.v[cb][4 * q + 3];
+          }
+      }
+      __syncthreads();
     }
-  __syncthreads();  // panel copy visible (also when the K-loop had no iterations)
+  } else {
+    // P = H_ij - sum (rows outside the matrix: zero)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 h = hr[cb][q];
+        P.v[cb][4 * q + 0] = (rvalid ? h.x : 0.f) - P.v[cb][4 * q + 0];
+        P.v[cb][4 * q + 1] = (rvalid ? h.y : 0.f) - P.v[cb][4 * q + 1];
+        P.v[cb][4 * q + 2] = (rvalid ? h.z : 0.f) - P.v[cb][4 * q + 2];
+        P.v[cb][4 * q + 3] = (rvalid ? h.w : 0.f) - P.v[cb][4 * q + 3];
+      }
+    __syncthreads();  // panel copy visible (also when the K-loop had no iterations)
+  }
   Engine<float>::Acc X;
   Engine<float>::zero(X);
 #ifdef THX_EXP_FULLINV   // timing experiment: the dataflow of a FULL 128 x 128 inverse in the panel, X_s = sum_{t <= s} W_st P_t --
@@ -1396,9 +1835,10 @@ __device__ __forceinline__ void sub_mma64(const double* blk, const Engine<double
   }
 }
 
+template <bool HB>
 __global__ void __launch_bounds__(256, 2)
 chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, const double* __restrict__ panel, int n,
-                        int64_t ld, int j, int ntiles, int i_first, int nrow_tiles, int B, TilePat pat) {
+                        int64_t ld, int j, int ntiles, int i_first, int nrow_tiles, int B, TilePat pat, HBlk hb) {
   using E = Engine<double>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* smem = reinterpret_cast<double*>(smem_raw);
@@ -1422,6 +1862,32 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   E::zero(P);
   kloop<double, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, Kspan, sA, sB, P, tid,
                        nullptr, nullptr, NoHook{}, klist);
+  if constexpr (HB) {
+    // block-compact H: the tile's pieces through the (free) staging buffers, 32 rows -- one wave's -- at a time
+    constexpr int LDH = 130;
+    static_assert(32 * LDH * 8 <= OFF64_SMEM, "a quarter of an H tile must fit in the staging buffers");
+    __syncthreads();
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+      for (int k = tid; k < 32 * LDH / 2; k += 256) reinterpret_cast<double2*>(smem)[k] = make_double2(0.0, 0.0);
+      __syncthreads();
+      hb_foreach<double>(hb, b, i, j, tid, 256, [&](int rr, int cc, double v) __attribute__((always_inline)) {
+        if ((rr >> 5) == rd) smem[(rr & 31) * LDH + cc] = v;
+      });
+      __syncthreads();
+      if (wave == rd) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const double* hrow = smem + (16 * h + rl) * LDH + kq;
+#pragma unroll
+          for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int rho = 0; rho < 4; ++rho) P.v[h][cb][rho] = hrow[16 * cb + 4 * rho] - P.v[h][cb][rho];
+        }
+      }
+      __syncthreads();
+    }
+  } else {
   // ---- P = H_ij - sum, H straight from global memory in the native layout (rows outside the matrix: zero) ----
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -1435,6 +1901,7 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
         const double hv = Hrow[16 * cb + 4 * rho];
         P.v[h][cb][rho] = (rv ? hv : 0.0) - P.v[h][cb][rho];
       }
+  }
   }
   // ---- panel sub-blocks -> LDS (swizzled), phase A: block rows 0..2 (six blocks) ----
   const double* Pn = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
@@ -1760,12 +2227,17 @@ lm_accept_kernel(const T* __restrict__ delta, const T* __restrict__ g, int64_t l
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
+static std::atomic<int> g_split_diag_min{[] {
+  const char* e = getenv("THX_CHOL_SPLIT_DIAG_MIN");   // (initial value of thx_chol_set_split_diag_min_batch's knob)
+  return e ? atoi(e) : 2048;
+}()};
+
 // Launch-side state is kept PER DEVICE (a process may drive several GPUs, from several threads): the dynamic-LDS limits
 // raised with hipFuncSetAttribute, and the auxiliary stream + events of the two-stream schedule, which belong to the device
 // they were created on.
 constexpr int MAX_DEVICES = 64;
 struct DeviceLaunchState {
-  size_t attr_diag[2] = {0, 0}, attr_solve[2] = {0, 0};   // [0] float, [1] double
+  size_t attr_diag[2][2] = {{0, 0}, {0, 0}}, attr_syrk[2][2] = {{0, 0}, {0, 0}}, attr_solve[2] = {0, 0};   // [0] float, [1] double (x HB)
   bool attr_off = false;
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_lag = nullptr, ev_join = nullptr;
@@ -1781,27 +2253,44 @@ static DeviceLaunchState& launch_state() {
 template <typename T>
 static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damping, int ellipsoidal, double eps,
                        void* L, void* panel, int32_t* info, const void* rhs, void* y, int64_t ldv, hipStream_t st,
-                       const thx_tile_pattern* tp = nullptr) {
+                       const thx_tile_pattern* tp = nullptr, const HBlk* hbp = nullptr) {
+  const bool use_hb = hbp != nullptr;
+  const HBlk hb = use_hb ? *hbp : HBlk{nullptr, 0, 0, nullptr, nullptr, nullptr};
   const int ntiles = (n + TILE - 1) / TILE;
   TilePat pat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (tp) {
     if (tp->ntiles != ntiles) return fail("thx_chol_factor_sparse: the tile pattern was built for another matrix order");
     pat = TilePat{tp->col_ptr, tp->col_row, tp->tile_kptr, tp->tile_k, tp->diag_kptr, tp->diag_k};
   }
-  const size_t dsm = DiagSmem<T>::bytes(rhs ? ntiles * TILE : 0);
+  // diagonal phase: chol_syrk_kernel + chol_potrf_kernel from g_split_diag_min problems per call on (measured, n = 1536: fp32
+  // 45.1 vs 46.0 ms at batch 4096, fp64 101.6 vs 105.2 ms; equal at batch 1024; 3.74 vs 3.51 ms at batch 256 -- the second
+  // launch per column costs more than the chain there), else the fused chol_diag_kernel
+  const bool fused_diag = B < g_split_diag_min.load();
+  const size_t dsm = fused_diag ? DiagSmem<T>::bytes(rhs ? ntiles * TILE : 0) : SyrkSmem<T>::bytes(rhs ? ntiles * TILE : 0);
   if (dsm > LDS_LIMIT) return fail("thx_chol_factor: n too large for the fused forward substitution (LDS)");
   std::lock_guard<std::mutex> guard(g_launch_mutex);   // (the whole enqueue: the auxiliary stream / events are shared)
   DeviceLaunchState& ds = launch_state();
   constexpr int ti = sizeof(T) == 8;
-  if (dsm > ds.attr_diag[ti]) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)dsm);
-    ds.attr_diag[ti] = dsm;
+  if (fused_diag && dsm > ds.attr_diag[ti][use_hb]) {
+    hipFuncSetAttribute(use_hb ? reinterpret_cast<const void*>(chol_diag_kernel<T, true>)
+                               : reinterpret_cast<const void*>(chol_diag_kernel<T, false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsm);
+    ds.attr_diag[ti][use_hb] = dsm;
+  }
+  if (!fused_diag && dsm > ds.attr_syrk[ti][use_hb]) {
+    hipFuncSetAttribute(use_hb ? reinterpret_cast<const void*>(chol_syrk_kernel<T, true>)
+                               : reinterpret_cast<const void*>(chol_syrk_kernel<T, false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsm);
+    ds.attr_syrk[ti][use_hb] = dsm;
   }
   if (!ds.attr_off) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f32_kernel),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f32_kernel<false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF32_SMEM);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f32_kernel<true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, OFF32_SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
     ds.attr_off = true;
   }
@@ -1836,21 +2325,55 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     hipEventRecord(ev_fork, st);
     hipStreamWaitEvent(aux, ev_fork, 0);
   }
+  // (block-compact H: the half's problems start at h.b0 of the block list; H itself is not dereferenced)
+  auto hb_of = [&](const Half& h) {
+    HBlk x = hb;
+    if (use_hb) x.blocks = static_cast<const T*>(hb.blocks) + (int64_t)h.b0 * hb.bstride;
+    return x;
+  };
   auto launch_off = [&](const Half& h, int j, int i_first, int nrt) {
     const int Bpad = (h.nb + 7) / 8 * 8;
     const int64_t mo = (int64_t)h.b0 * ld * ld, po = (int64_t)h.b0 * ntiles * TILE * TILE;
-    if constexpr (sizeof(T) == 4)
-      hipLaunchKernelGGL(chol_offdiag_f32_kernel, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, h.s, (const float*)H + mo,
-                         (float*)L + mo, (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat);
-    else
-      hipLaunchKernelGGL(chol_offdiag_f64_kernel, dim3(Bpad * nrt), dim3(256), OFF64_SMEM, h.s, (const double*)H + mo,
-                         (double*)L + mo, (const double*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat);
+    const T* Hh = use_hb ? nullptr : (const T*)H + mo;
+    if constexpr (sizeof(T) == 4) {
+      if (use_hb)
+        hipLaunchKernelGGL(chol_offdiag_f32_kernel<true>, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, h.s, Hh, (float*)L + mo,
+                           (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));
+      else
+        hipLaunchKernelGGL(chol_offdiag_f32_kernel<false>, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, h.s, Hh, (float*)L + mo,
+                           (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));
+    } else {
+      if (use_hb)
+        hipLaunchKernelGGL(chol_offdiag_f64_kernel<true>, dim3(Bpad * nrt), dim3(256), OFF64_SMEM, h.s, Hh, (double*)L + mo,
+                           (const double*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));
+      else
+        hipLaunchKernelGGL(chol_offdiag_f64_kernel<false>, dim3(Bpad * nrt), dim3(256), OFF64_SMEM, h.s, Hh, (double*)L + mo,
+                           (const double*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));
+    }
   };
   auto launch_diag = [&](const Half& h, int j) {
     const int64_t mo = (int64_t)h.b0 * ld * ld, po = (int64_t)h.b0 * ntiles * TILE * TILE;
-    hipLaunchKernelGGL(chol_diag_kernel<T>, dim3(h.nb), dim3(256), dsm, h.s, (const T*)H + mo, (T*)L + mo, (T*)panel + po,
-                       damping ? (const T*)damping + h.b0 : nullptr, ellipsoidal, (T)eps, info + h.b0, n, ld, j, ntiles,
-                       rhs ? (const T*)rhs + (int64_t)h.b0 * ldv : nullptr, y ? (T*)y + (int64_t)h.b0 * ldv : nullptr, ldv, pat);
+    const T* rh = rhs ? (const T*)rhs + (int64_t)h.b0 * ldv : nullptr;
+    T* yh = y ? (T*)y + (int64_t)h.b0 * ldv : nullptr;
+    const T* dh = damping ? (const T*)damping + h.b0 : nullptr;
+    const T* Hh = use_hb ? nullptr : (const T*)H + mo;
+    if (fused_diag) {
+      if (use_hb)
+        hipLaunchKernelGGL((chol_diag_kernel<T, true>), dim3(h.nb), dim3(256), dsm, h.s, Hh, (T*)L + mo, (T*)panel + po,
+                           dh, ellipsoidal, (T)eps, info + h.b0, n, ld, j, ntiles, rh, yh, ldv, pat, hb_of(h));
+      else
+        hipLaunchKernelGGL((chol_diag_kernel<T, false>), dim3(h.nb), dim3(256), dsm, h.s, Hh, (T*)L + mo, (T*)panel + po,
+                           dh, ellipsoidal, (T)eps, info + h.b0, n, ld, j, ntiles, rh, yh, ldv, pat, hb_of(h));
+    } else {
+      if (use_hb)
+        hipLaunchKernelGGL((chol_syrk_kernel<T, true>), dim3(h.nb), dim3(256), dsm, h.s, Hh, (T*)L + mo, dh, ellipsoidal,
+                           (T)eps, n, ld, j, rh, yh, ldv, pat, hb_of(h));
+      else
+        hipLaunchKernelGGL((chol_syrk_kernel<T, false>), dim3(h.nb), dim3(256), dsm, h.s, Hh, (T*)L + mo, dh, ellipsoidal,
+                           (T)eps, n, ld, j, rh, yh, ldv, pat, hb_of(h));
+      hipLaunchKernelGGL(chol_potrf_kernel<T>, dim3(h.nb), dim3(64), 0, h.s, (T*)L + mo, (T*)panel + po, info + h.b0, n, ld, j,
+                         ntiles, rh ? yh : nullptr, ldv);
+    }
   };
   for (int j = 0; j < ntiles; ++j) {
     for (int k = 0; k < 2; ++k) {
@@ -1983,6 +2506,36 @@ int thx_chol_solve_sparse(const void* L, int64_t ld, int32_t n, int32_t B, const
   if (!pattern || !pattern->row_ptr || !pattern->row_tile) return fail("thx_chol_solve_sparse: incomplete tile pattern");
   if (pattern->ntiles != (n + TILE - 1) / TILE) return fail("thx_chol_solve_sparse: the pattern is not this matrix's");
   return solve_dispatch(L, ld, n, B, Winv, rhs, x, ldv, !backward_only, true, dtype, stream, pattern);
+}
+
+int thx_chol_factor_hblocks(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t n, int32_t B,
+                            const void* damping, int ellipsoidal, double damping_eps, void* L, int64_t ld, void* Winv,
+                            int32_t* info, const void* rhs, void* y, int64_t ldv, const thx_tile_pattern* pattern, int dtype,
+                            void* stream) {
+  if (!layout || !layout->tile_ptr || !layout->piece_blk || !layout->piece_rc || !Hc)
+    return fail("thx_chol_factor_hblocks: incomplete block layout");
+  if (int r = check_factor_args(Hc, L, Winv, info, n, B, ld)) return r;
+  if (layout->ntiles != (n + TILE - 1) / TILE || layout->nvars * layout->bd != n || bstride < (int64_t)layout->nblocks * layout->bd * layout->bd)
+    return fail("thx_chol_factor_hblocks: the block layout is not this matrix's");
+  if (pattern && (!pattern->col_ptr || !pattern->col_row || !pattern->tile_kptr || !pattern->tile_k || !pattern->diag_kptr ||
+                  !pattern->diag_k || !pattern->col_count_host))
+    return fail("thx_chol_factor_hblocks: incomplete tile pattern");
+  if ((rhs == nullptr) != (y == nullptr) || (rhs && ldv < n)) return fail("thx_chol_factor_hblocks: rhs / y / ldv");
+  if (rhs && rhs == y) return fail("thx_chol_factor_hblocks: y must not alias rhs");
+  const HBlk hb{Hc, bstride, layout->bd, layout->tile_ptr, layout->piece_blk, layout->piece_rc};
+  THX_DISPATCH(dtype,
+               return factor_impl<float>(nullptr, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
+                                         as_stream(stream), pattern, &hb),
+               return factor_impl<double>(nullptr, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
+                                          as_stream(stream), pattern, &hb));
+  return 0;
+}
+
+int thx_chol_set_split_diag_min_batch(int32_t min_batch, int32_t* previous) {
+  if (min_batch < 0) return fail("thx_chol_set_split_diag_min_batch: min_batch < 0");
+  const int old = g_split_diag_min.exchange(min_batch);
+  if (previous) *previous = old;
+  return 0;
 }
 
 int thx_chol_solve(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs, void* x,

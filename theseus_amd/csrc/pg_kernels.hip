@@ -87,10 +87,26 @@ __device__ __forceinline__ void load6(const T* __restrict__ p, T* w) {
 // ------------------------------------------------------------------------------------------------
 // ROBUST = false compiles the rescale away: the plain-cost kernel keeps its registers (with the rescale inlined the
 // fp64 Jacobian chain spilled 440 bytes per lane to scratch: 1.47 -> 1.82 ms and 3x the HBM writes, rocprofv3 PMC)
-template <typename T, bool ROBUST>
+// one 6x6 block -> its 36 consecutive elements of the block list, 16-byte pieces
+template <typename T>
+__device__ __forceinline__ void store_block36(T* __restrict__ dst, const T* v) {
+  if constexpr (sizeof(T) == 4) {
+    float4* q = reinterpret_cast<float4*>(dst);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) q[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+  } else {
+    double2* q = reinterpret_cast<double2*>(dst);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) q[i] = make_double2(v[2 * i], v[2 * i + 1]);
+  }
+}
+
+// COMPACT: H is the block list (B, nblocks, 36) with problem stride ``ld`` elements (include/theseus_hip.h: thx_hblock_layout),
+// a lane writes each of its blocks as 144 (288) contiguous bytes; else the dense (B, ld, ld) frame.
+template <typename T, bool ROBUST, bool COMPACT>
 __global__ void __launch_bounds__(64)
 pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t ld, T* __restrict__ g,
-                   Eps<T> eps) {
+                   Eps<T> eps, const int32_t* __restrict__ diag_blk, const int32_t* __restrict__ inc_blk) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   const int p = blockIdx.y;
   const int B = d.batch;
@@ -108,9 +124,9 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
 #pragma unroll
   for (int i = 0; i < 6; ++i) gv[i] = 0.0;
 
-  T* Hb = H + (int64_t)b * ld * ld;
+  T* Hb = H + (int64_t)b * (COMPACT ? ld : ld * ld);
   const int beg = s.inc_ptr[p], end = s.inc_ptr[p + 1];
-  int cur_q = -1;
+  int cur_q = -1, cur_blk = -1;
   for (int k = beg; k < end; ++k) {
     const int e = s.inc_edge[k], side = s.inc_side[k], q = s.inc_other[k];
     SE3<T> Xq, M;
@@ -124,14 +140,19 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
     const bool lower = q < p;
     if (lower && q != cur_q) {
       if (cur_q >= 0) {
+        if constexpr (COMPACT) {
+          store_block36(Hb + (int64_t)cur_blk * 36, Off);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+          for (int r = 0; r < 6; ++r)
 #pragma unroll
-          for (int c = 0; c < 6; ++c) Hb[(int64_t)(6 * p + r) * ld + 6 * cur_q + c] = Off[6 * r + c];
+            for (int c = 0; c < 6; ++c) Hb[(int64_t)(6 * p + r) * ld + 6 * cur_q + c] = Off[6 * r + c];
+        }
       }
 #pragma unroll
       for (int i = 0; i < 36; ++i) Off[i] = T(0);
       cur_q = q;
+      if constexpr (COMPACT) cur_blk = inc_blk[k];
     }
     if (side == 0) {  // p is v0: own Jacobian J0, other J1
       if constexpr (ROBUST) {
@@ -160,10 +181,14 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
     }
   }
   if (cur_q >= 0) {
+    if constexpr (COMPACT) {
+      store_block36(Hb + (int64_t)cur_blk * 36, Off);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+      for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) Hb[(int64_t)(6 * p + r) * ld + 6 * cur_q + c] = Off[6 * r + c];
+        for (int c = 0; c < 6; ++c) Hb[(int64_t)(6 * p + r) * ld + 6 * cur_q + c] = Off[6 * r + c];
+    }
   }
   // priors on this pose
   const T* tgt = static_cast<const T*>(d.prior_target);
@@ -188,10 +213,14 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
     sjac_tmul_acc(J, J, Dg);
     sjac_tvec_sub(Jd, ev, gv);
   }
+  if constexpr (COMPACT) {
+    store_block36(Hb + (int64_t)diag_blk[p] * 36, Dg);
+  } else {
 #pragma unroll
-  for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < 6; ++r)
 #pragma unroll
-    for (int c = 0; c < 6; ++c) Hb[(int64_t)(6 * p + r) * ld + 6 * p + c] = Dg[6 * r + c];
+      for (int c = 0; c < 6; ++c) Hb[(int64_t)(6 * p + r) * ld + 6 * p + c] = Dg[6 * r + c];
+  }
   T* gb = g + (int64_t)b * (6 * s.num_poses) + 6 * p;
 #pragma unroll
   for (int i = 0; i < 6; ++i) gb[i] = (T)gv[i];
@@ -468,6 +497,42 @@ copy_where_kernel(const uint8_t* __restrict__ mask, const uint32_t* __restrict__
   }
 }
 
+// block list -> dense frame: one thread per (problem, piece element); the expansion walks the tile pieces -- every element of
+// every piece that lies inside its tile is written exactly once.
+template <typename T>
+__global__ void __launch_bounds__(256)
+hblocks_expand_kernel(thx_hblock_layout lay, const T* __restrict__ Hc, int64_t bstride, T* __restrict__ H, int64_t ld, int npieces) {
+  const int b = blockIdx.y;
+  const int bb = lay.bd * lay.bd;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= npieces * bb) return;
+  const int pc = idx / bb, e = idx % bb;
+  // tile of piece pc: binary search in tile_ptr
+  int lo = 0, hi = lay.ntiles * (lay.ntiles + 1) / 2;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (lay.tile_ptr[mid] <= pc) lo = mid; else hi = mid;
+  }
+  int ti = 0;
+  while ((ti + 1) * (ti + 2) / 2 <= lo) ++ti;
+  const int tj = lo - ti * (ti + 1) / 2;
+  const int rc = lay.piece_rc[pc];
+  const int r = (int)(short)(rc >> 16) + e / lay.bd, c = (int)(short)(rc & 0xffff) + e % lay.bd;
+  if (r < 0 || r >= THX_TILE || c < 0 || c >= THX_TILE) return;
+  H[(int64_t)b * ld * ld + (int64_t)(ti * THX_TILE + r) * ld + tj * THX_TILE + c] =
+      Hc[(int64_t)b * bstride + (int64_t)lay.piece_blk[pc] * bb + e];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+hblocks_diag_kernel(thx_hblock_layout lay, const T* __restrict__ Hc, int64_t bstride, T* __restrict__ d, int64_t ldv) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= lay.nvars * lay.bd) return;
+  const int k = i / lay.bd, r = i % lay.bd;
+  d[(int64_t)b * ldv + i] = Hc[(int64_t)b * bstride + (int64_t)lay.diag_blk[k] * lay.bd * lay.bd + r * (lay.bd + 1)];
+}
+
 }  // namespace thx
 
 using namespace thx;
@@ -475,7 +540,7 @@ using namespace thx;
 extern "C" {
 
 const char* thx_last_error(void) { return last_error().c_str(); }
-int thx_abi_version(void) { return 14; }
+int thx_abi_version(void) { return 16; }
 
 int thx_copy_where(const uint8_t* mask, const void* src, void* dst, int64_t N, int32_t B, int32_t record_bytes, void* stream) {
   if (!mask || !src || !dst || N < 0 || B <= 0 || record_bytes <= 0 || (record_bytes & 3))
@@ -495,12 +560,67 @@ int thx_pg_assemble(const thx_pg_structure* s, const thx_pg_data* d, void* H, in
   if (ld < 6 * (int64_t)s->num_poses) return fail("ld < n");
   dim3 grid((d->batch + 63) / 64, s->num_poses), block(64);
   const bool robust = d->robust_between != THX_LOSS_NONE || d->robust_prior != THX_LOSS_NONE;
-#define THX_ASM(T, R) hipLaunchKernelGGL((pg_assemble_kernel<T, R>), grid, block, 0, as_stream(stream), *s, *d, (T*)H, ld, \
-                                         (T*)g, make_eps<T>(eps))
+#define THX_ASM(T, R) hipLaunchKernelGGL((pg_assemble_kernel<T, R, false>), grid, block, 0, as_stream(stream), *s, *d, (T*)H, ld, \
+                                         (T*)g, make_eps<T>(eps), (const int32_t*)nullptr, (const int32_t*)nullptr)
   THX_DISPATCH(dtype, { if (robust) THX_ASM(float, true); else THX_ASM(float, false); },
                { if (robust) THX_ASM(double, true); else THX_ASM(double, false); });
 #undef THX_ASM
   return check_launch("thx_pg_assemble");
+}
+
+int thx_pg_assemble_blocks(const thx_pg_structure* s, const thx_pg_data* d, const thx_hblock_layout* layout, void* Hc,
+                           int64_t bstride, void* g, int dtype, const thx_lie_eps* eps, void* stream) {
+  if (int r = check_pg(s, d)) return r;
+  if (!Hc || !g || !eps || !layout || !layout->diag_blk || !layout->inc_blk) return fail("thx_pg_assemble_blocks: null pointer");
+  if (layout->bd != 6 || layout->nvars != s->num_poses) return fail("thx_pg_assemble_blocks: the block layout is not this (SE3) graph's");
+  if (bstride < 36 * (int64_t)layout->nblocks || (bstride % 4) != 0) return fail("thx_pg_assemble_blocks: bstride");
+  dim3 grid((d->batch + 63) / 64, s->num_poses), block(64);
+  const bool robust = d->robust_between != THX_LOSS_NONE || d->robust_prior != THX_LOSS_NONE;
+#define THX_ASM(T, R) hipLaunchKernelGGL((pg_assemble_kernel<T, R, true>), grid, block, 0, as_stream(stream), *s, *d, (T*)Hc, bstride, \
+                                         (T*)g, make_eps<T>(eps), layout->diag_blk, layout->inc_blk)
+  THX_DISPATCH(dtype, { if (robust) THX_ASM(float, true); else THX_ASM(float, false); },
+               { if (robust) THX_ASM(double, true); else THX_ASM(double, false); });
+#undef THX_ASM
+  return check_launch("thx_pg_assemble_blocks");
+}
+
+static int check_layout(const thx_hblock_layout* l, const char* who) {
+  if (!l || !l->diag_blk || !l->tile_ptr || !l->piece_blk || !l->piece_rc || l->nblocks <= 0 || l->bd <= 0 || l->nvars <= 0 ||
+      l->ntiles != (l->nvars * l->bd + THX_TILE - 1) / THX_TILE) {
+    last_error() = std::string(who) + ": incomplete / inconsistent block layout";
+    return -1;
+  }
+  return 0;
+}
+
+int thx_hblocks_expand(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t B, void* H, int64_t ld,
+                       int dtype, void* stream) {
+  if (int r = check_layout(layout, "thx_hblocks_expand")) return r;
+  if (!Hc || !H || B <= 0 || ld < (int64_t)layout->nvars * layout->bd) return fail("thx_hblocks_expand: bad arguments");
+  int npieces = 0;   // (host copy of the last tile_ptr entry: one small synchronous read; this entry point is off the hot path)
+  const int ntl = layout->ntiles * (layout->ntiles + 1) / 2;
+  if (hipMemcpy(&npieces, layout->tile_ptr + ntl, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+    return fail("thx_hblocks_expand: cannot read the piece count");
+  dim3 grid((npieces * layout->bd * layout->bd + 255) / 256, B), block(256);
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(hblocks_expand_kernel<float>, grid, block, 0, as_stream(stream), *layout, (const float*)Hc,
+                                  bstride, (float*)H, ld, npieces),
+               hipLaunchKernelGGL(hblocks_expand_kernel<double>, grid, block, 0, as_stream(stream), *layout, (const double*)Hc,
+                                  bstride, (double*)H, ld, npieces));
+  return check_launch("thx_hblocks_expand");
+}
+
+int thx_hblocks_diag(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t B, void* d, int64_t ldv,
+                     int dtype, void* stream) {
+  if (int r = check_layout(layout, "thx_hblocks_diag")) return r;
+  if (!Hc || !d || B <= 0 || ldv < (int64_t)layout->nvars * layout->bd) return fail("thx_hblocks_diag: bad arguments");
+  dim3 grid((layout->nvars * layout->bd + 255) / 256, B), block(256);
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(hblocks_diag_kernel<float>, grid, block, 0, as_stream(stream), *layout, (const float*)Hc, bstride,
+                                  (float*)d, ldv),
+               hipLaunchKernelGGL(hblocks_diag_kernel<double>, grid, block, 0, as_stream(stream), *layout, (const double*)Hc,
+                                  bstride, (double*)d, ldv));
+  return check_launch("thx_hblocks_diag");
 }
 
 int thx_pg_error(const thx_pg_structure* s, const thx_pg_data* d, void* partials, void* err, int dtype,

@@ -354,6 +354,34 @@ class HipKernels:
                                             _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(H.device)),
                    "thx_pg_assemble")
 
+    # ---- block-compact Hessian (include/theseus_hip.h: thx_hblock_layout; theseus_amd/compiler.py:HessianBlocks) ----
+    def pg_assemble_blocks(self, s: DeviceStructure, t: PGTensors, hb, Hc, g, poses=None):
+        """thx_pg_assemble writing the block list ``Hc`` (B, bstride) instead of the dense frame (SE3 pose graphs)."""
+        if t.group != "SE3":
+            raise RuntimeError("the block-compact Hessian is implemented for SE3 pose graphs")
+        dt = Hc.dtype
+        _lib.check(self.lib.thx_pg_assemble_blocks(s.c, t.c_struct(poses), hb.c, _lib.ptr(Hc, "Hc"), Hc.stride(0), _lib.ptr(g, "g"),
+                                                   _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(Hc.device)),
+                   "thx_pg_assemble_blocks")
+
+    def hblocks_expand(self, hb, Hc, H):
+        """Block list -> the dense (B, ld, ld) frame (H must be zero where no block lies)."""
+        _lib.check(self.lib.thx_hblocks_expand(hb.c, _lib.ptr(Hc), Hc.stride(0), Hc.shape[0], _lib.ptr(H), H.shape[-1],
+                                               _lib.dtype_code(Hc.dtype), _lib.stream_ptr(Hc.device)), "thx_hblocks_expand")
+
+    def hblocks_diag(self, hb, Hc, d):
+        _lib.check(self.lib.thx_hblocks_diag(hb.c, _lib.ptr(Hc), Hc.stride(0), Hc.shape[0], _lib.ptr(d), d.stride(0),
+                                             _lib.dtype_code(Hc.dtype), _lib.stream_ptr(Hc.device)), "thx_hblocks_diag")
+
+    def chol_factor_hblocks(self, hb, Hc, n, damping, ellipsoidal, damping_eps, L, panels, info, pattern=None, rhs=None, y=None):
+        """thx_chol_factor_forward / thx_chol_factor_sparse (``pattern``) with H read from the block list."""
+        B, ld = L.shape[0], L.shape[-1]
+        _lib.check(self.lib.thx_chol_factor_hblocks(
+            hb.c, _lib.ptr(Hc), Hc.stride(0), n, B, _lib.ptr(damping), int(bool(ellipsoidal)), float(damping_eps), _lib.ptr(L), ld,
+            _lib.ptr(panels), _lib.ptr(info), _lib.ptr(rhs), _lib.ptr(y), rhs.stride(0) if rhs is not None else n,
+            pattern.c_struct(L.device) if pattern is not None else None, _lib.dtype_code(L.dtype), _lib.stream_ptr(L.device)),
+            "thx_chol_factor_hblocks")
+
     def pg_error(self, s: DeviceStructure, t: PGTensors, partials, err, poses=None):
         d = t.c_struct(poses)
         dt = err.dtype
@@ -572,6 +600,14 @@ class HipKernels:
                                                    _lib.ptr(rhs), _lib.ptr(y), rhs.stride(0) if rhs is not None else 0,
                                                    pattern.c_struct(H.device), _lib.dtype_code(H.dtype),
                                                    _lib.stream_ptr(H.device)), "thx_chol_factor_sparse")
+
+    def chol_split_diag_min_batch(self, min_batch: int) -> int:
+        """Schedule knob of the factorisation (include/theseus_hip.h: thx_chol_set_split_diag_min_batch): batches of at least
+        ``min_batch`` problems run the diagonal phase as SYRK kernel + one-wave-per-tile kernel.  Returns the previous value."""
+        import ctypes
+        prev = ctypes.c_int32(0)
+        _lib.check(self.lib.thx_chol_set_split_diag_min_batch(int(min_batch), ctypes.byref(prev)), "thx_chol_set_split_diag_min_batch")
+        return int(prev.value)
 
     def chol_solve(self, L, n, panels, rhs, x):
         B, ld = L.shape[0], L.shape[-1]

@@ -43,23 +43,39 @@ class HipCholeskyCore:
 
     def _ensure_buffers(self):
         lin = self.linearization
-        H = lin.H
-        if self.L is None or self.L.shape != H.shape or self.L.device != H.device or self.L.dtype != H.dtype:
-            B = H.shape[0]
+        g = lin.g     # (B, n): shape / dtype / device of the system (lin.H may be block-compact: never touched here)
+        shape = (g.shape[0], lin.ld, lin.ld)
+        if self.L is None or tuple(self.L.shape) != shape or self.L.device != g.device or self.L.dtype != g.dtype:
+            B = g.shape[0]
             nt = (lin.n + _lib.THX_TILE - 1) // _lib.THX_TILE
-            self.L = torch.zeros_like(H)
-            self.panels = torch.empty(B, nt, _lib.THX_TILE, _lib.THX_TILE, dtype=H.dtype, device=H.device)
-            self._y = torch.empty(B, lin.n, dtype=H.dtype, device=H.device)
-            self.info = torch.zeros(B, dtype=torch.int32, device=H.device)
-            self._lam = torch.empty(B, dtype=H.dtype, device=H.device)
+            self.L = torch.zeros(shape, dtype=g.dtype, device=g.device)
+            self.panels = torch.empty(B, nt, _lib.THX_TILE, _lib.THX_TILE, dtype=g.dtype, device=g.device)
+            self._y = torch.empty(B, lin.n, dtype=g.dtype, device=g.device)
+            self.info = torch.zeros(B, dtype=torch.int32, device=g.device)
+            self._lam = torch.empty(B, dtype=g.dtype, device=g.device)
+
+    def _linearized(self) -> bool:
+        lin = self.linearization
+        return lin.linearized if hasattr(lin, "linearized") else lin.H is not None
+
+    def _factor_call(self, lam, ellipsoidal_damping, damping_eps, rhs, y, pattern=None):
+        """One factorisation launch sequence: H from the block list when the linearization keeps it compact."""
+        lin = self.linearization
+        if getattr(lin, "_compact", False):
+            self.K.chol_factor_hblocks(lin.hblocks, lin.Hc, lin.n, lam, ellipsoidal_damping, damping_eps, self.L, self.panels,
+                                       self.info, pattern=pattern, rhs=rhs, y=y)
+        elif pattern is not None:
+            self.K.chol_factor_sparse(lin.H, lin.n, lam, ellipsoidal_damping, damping_eps, self.L, self.panels, self.info,
+                                      pattern, rhs=rhs, y=y)
+        else:
+            self.K.chol_factor(lin.H, lin.n, lam, ellipsoidal_damping, damping_eps, self.L, self.panels, self.info, rhs=rhs, y=y)
 
     def factorize(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
                   damping_eps: float = 1e-8, rhs: Optional[torch.Tensor] = None):
         """L L^T = AtA (+ damping); keeps L and the solve panels for later solves (the implicit backward
         re-uses them).  With ``rhs`` the forward substitution L y = rhs is fused into the factorisation
         (no extra pass over L) and y is returned."""
-        lin = self.linearization
-        if lin.H is None:
+        if not self._linearized():
             raise RuntimeError("linearize() must be called before solve().")
         self._ensure_buffers()
         lam = None
@@ -71,8 +87,7 @@ class HipCholeskyCore:
                 lam.fill_(float(damping))
         y = self._y if rhs is not None else None
         self.factor_version += 1
-        self.K.chol_factor(lin.H, lin.n, lam, ellipsoidal_damping, damping_eps, self.L, self.panels, self.info,
-                           rhs=rhs, y=y)
+        self._factor_call(lam, ellipsoidal_damping, damping_eps, rhs, y)
         return y
 
     def solve_with_factor(self, rhs: torch.Tensor) -> torch.Tensor:

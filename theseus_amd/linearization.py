@@ -8,6 +8,7 @@ writes the block-sparse lower triangle of H = A^T A straight into a persistent d
 buffer (zero-filled once; the pattern is fixed) and g = A^T b into (B,n).
 """
 import abc
+import os
 from typing import List, Optional
 
 import torch
@@ -109,13 +110,27 @@ class HipLinearizationCore:
     """Back-end half of the linearization, independent of which ``Linearization`` ABC it is mixed into:
     theseus_amd's mirror (below) or the real ``theseus.optimizer.Linearization`` (theseus_amd/plugin.py)."""
 
-    def _core_init(self, objective, kernels=None):
+    # (defaults for subclasses that take a generic path without _core_init: theseus_amd/plugin.py)
+    _compact = False
+    _H: Optional[torch.Tensor] = None
+    Hc: Optional[torch.Tensor] = None
+    hblocks = None
+
+    def _core_init(self, objective, kernels=None, block_hessian: Optional[bool] = None):
         # the column order is the linearization's VariableOrdering (default: insertion order; theseus_amd/sparse.py passes a
         # fill-reducing one) -- the packed pose buffer is laid out in that order, so delta / retract / Jacobian columns agree
         self.packed = packed_for(objective, kernels, [v.name for v in self.ordering])
         self.K = self.packed.K
-        self.H: Optional[torch.Tensor] = None   # (B, ld, ld): lower triangle of A^T A (undamped)
+        # A^T A (undamped, lower triangle).  SE3 pose graphs on the HIP kernels keep it BLOCK-COMPACT: ``Hc`` (B, bstride), the
+        # list of its non-zero 6 x 6 blocks (184 KB per problem at 256 poses / 1024 edges; the dense frame: 9.4 MB) -- assembly
+        # writes whole 144-byte blocks, the Cholesky tiles gather their pieces.  ``H`` (B, ld, ld) is then materialised only if
+        # somebody reads it (``AtA``).  Everything else (SE2 / SO3, the test stand-in kernels, THX_DENSE_HESSIAN=1): dense frame.
+        self._H: Optional[torch.Tensor] = None
+        self.Hc: Optional[torch.Tensor] = None
+        self.hblocks = None                      # compiler.DeviceHessianBlocks when compact
         self.g: Optional[torch.Tensor] = None   # (B, n): A^T b
+        want = block_hessian if block_hessian is not None else os.environ.get("THX_DENSE_HESSIAN", "0") != "1"
+        self._compact = bool(want) and getattr(self.packed, "supports_block_hessian", lambda: False)()
         self._AtA_cache = None
         self._A = self._b = None
         self._Jblocks = None   # weighted Jacobian blocks of the current linearization (Av), on demand
@@ -129,12 +144,36 @@ class HipLinearizationCore:
     def ld(self):
         return self.packed.ld
 
+    @property
+    def H(self) -> Optional[torch.Tensor]:
+        """(B, ld, ld) dense frame of the lower triangle.  With block-compact storage it is expanded on first use after a
+        ``linearize()`` (thx_hblocks_expand) -- the optimiser never asks for it."""
+        if self._compact and self.Hc is not None and self._H is None:
+            self._H = torch.zeros(self.Hc.shape[0], self.ld, self.ld, dtype=self.Hc.dtype, device=self.Hc.device)
+            self.K.hblocks_expand(self.hblocks, self.Hc, self._H)
+        return self._H
+
+    @H.setter
+    def H(self, value):
+        self._H = value
+
+    @property
+    def linearized(self) -> bool:
+        return (self.Hc if self._compact else self._H) is not None
+
     def _ensure_buffers(self):
         self.packed.sync()
         B = self.packed.batch
         dev, dt = self.packed.tensors.poses.device, self.objective.dtype
-        if self.H is None or self.H.shape[0] != B or self.H.device != dev or self.H.dtype != dt:
-            self.H = torch.zeros(B, self.ld, self.ld, dtype=dt, device=dev)  # zero once: fixed pattern
+        if self._compact:
+            if self.Hc is None or self.Hc.shape[0] != B or self.Hc.device != dev or self.Hc.dtype != dt:
+                hb = self.packed.structure.hessian_blocks()
+                self.hblocks = hb.on(dev)
+                self.Hc = torch.empty(B, hb.bstride, dtype=dt, device=dev)   # every block is written in full by the assembly
+                self.g = torch.empty(B, self.n, dtype=dt, device=dev)
+            return
+        if self._H is None or self._H.shape[0] != B or self._H.device != dev or self._H.dtype != dt:
+            self._H = torch.zeros(B, self.ld, self.ld, dtype=dt, device=dev)  # zero once: fixed pattern
             self.g = torch.empty(B, self.n, dtype=dt, device=dev)
 
     def _materialize_A_b(self):
@@ -158,7 +197,11 @@ class HipLinearizationCore:
 
     def _assemble(self):
         self._ensure_buffers()
-        self.packed.assemble(self.H, self.g)
+        if self._compact:
+            self.packed.assemble_blocks(self.Hc, self.g)
+            self._H = None      # (a dense expansion of the previous linearization is stale)
+        else:
+            self.packed.assemble(self._H, self.g)
         self._AtA_cache = None
         self._A = self._b = None
         self._Jblocks = None
@@ -192,8 +235,11 @@ class HipLinearizationCore:
         return self.packed.jacobian_times(self._Jblocks, v)
 
     def diagonal(self) -> torch.Tensor:
-        d = torch.empty(self.H.shape[0], self.n, dtype=self.H.dtype, device=self.H.device)
-        self.K.diag(self.H, self.n, d)
+        d = torch.empty(self.g.shape[0], self.n, dtype=self.g.dtype, device=self.g.device)
+        if self._compact:
+            self.K.hblocks_diag(self.hblocks, self.Hc, d)
+        else:
+            self.K.diag(self._H, self.n, d)
         return d
 
     def diagonal_scaling(self, v: torch.Tensor) -> torch.Tensor:
@@ -201,13 +247,23 @@ class HipLinearizationCore:
 
     def lm_accept(self, delta, damping, prev_err, new_err, ellipsoidal, accept, down, up, reject):
         """levenberg_marquardt.py:173-201 on the packed buffers (thx_lm_accept)."""
-        self.K.lm_accept(delta, self.g, self.H, self.n, damping, prev_err, new_err, ellipsoidal, accept, down, up, reject)
+        if self._compact:
+            if ellipsoidal:
+                self.K.lm_accept_diag(delta, self.g, self.diagonal(), self.n, damping, prev_err, new_err, ellipsoidal, accept, down,
+                                      up, reject)
+            else:
+                self.K.lm_accept(delta, self.g, None, self.n, damping, prev_err, new_err, False, accept, down, up, reject)
+            return
+        self.K.lm_accept(delta, self.g, self._H, self.n, damping, prev_err, new_err, ellipsoidal, accept, down, up, reject)
 
 
 class HipLinearization(HipLinearizationCore, Linearization):
-    def __init__(self, objective: Objective, ordering: Optional[VariableOrdering] = None, kernels=None, **kwargs):
+    def __init__(self, objective: Objective, ordering: Optional[VariableOrdering] = None, kernels=None,
+                 block_hessian: Optional[bool] = None, **kwargs):
+        """``block_hessian``: keep A^T A as the list of its non-zero blocks (default for SE3 pose graphs on the HIP kernels;
+        False: the dense (B, ld, ld) frame)."""
         Linearization.__init__(self, objective, ordering)
-        self._core_init(objective, kernels)
+        self._core_init(objective, kernels, block_hessian)
 
     def _linearize_jacobian_impl(self):
         self._materialize_A_b()

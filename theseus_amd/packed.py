@@ -377,6 +377,15 @@ class PackedPoseGraph:
         self.sync()
         self.K.pg_assemble(self.dstruct, self.tensors, H, g)
 
+    def supports_block_hessian(self) -> bool:
+        """Block-compact storage of H (include/theseus_hip.h: thx_hblock_layout): SE3 pose graphs on the HIP kernels."""
+        return self.group == "SE3" and hasattr(self.K, "pg_assemble_blocks")
+
+    def assemble_blocks(self, Hc: torch.Tensor, g: torch.Tensor):
+        self._refuse_fast_approx()
+        self.sync()
+        self.K.pg_assemble_blocks(self.dstruct, self.tensors, self.structure.hessian_blocks().on(Hc.device), Hc, g)
+
     def error_metric(self, poses: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, state=None):
         self.sync()
         poses = state if state is not None else poses

@@ -241,11 +241,12 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
     """Replaces ``th.DenseLinearization`` (theseus/optimizer/dense_linearization.py:15-77).  ``objective_hooks=False``
     keeps the reference's own vectorization callbacks (only ``Linearization`` + ``LinearSolver`` are replaced then)."""
 
-    def __init__(self, objective: th.Objective, ordering=None, kernels=None, objective_hooks: bool = True, **kwargs):
+    def __init__(self, objective: th.Objective, ordering=None, kernels=None, objective_hooks: bool = True,
+                 block_hessian: Optional[bool] = None, **kwargs):
         _RefLinearization.__init__(self, objective, ordering)
         self._g_graph: Optional[torch.Tensor] = None
         try:
-            self._core_init(objective, kernels)
+            self._core_init(objective, kernels, block_hessian)
             self.fused = True
         except UnsupportedObjective:
             self.fused = False

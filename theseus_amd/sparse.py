@@ -135,8 +135,7 @@ class HipSparseCholeskyCore(HipCholeskyCore):
 
     def factorize(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
                   damping_eps: float = 1e-8, rhs: Optional[torch.Tensor] = None):
-        lin = self.linearization
-        if lin.H is None:
+        if not self._linearized():
             raise RuntimeError("linearize() must be called before solve().")
         self._ensure_buffers()
         lam = None
@@ -148,8 +147,7 @@ class HipSparseCholeskyCore(HipCholeskyCore):
                 lam.fill_(float(damping))
         y = self._y if rhs is not None else None
         self.factor_version += 1
-        self.K.chol_factor_sparse(lin.H, lin.n, lam, ellipsoidal_damping, damping_eps, self.L, self.panels, self.info,
-                                  self.pattern, rhs=rhs, y=y)
+        self._factor_call(lam, ellipsoidal_damping, damping_eps, rhs, y, pattern=self.pattern)
         return y
 
     def _substitute(self, rhs, x, backward_only: bool):

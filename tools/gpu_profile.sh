@@ -4,7 +4,7 @@
 # usage: tools/gpu_profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-r1}; shift || true
-ARGS=${@:-"--steps 3 --warmup 1 --cpu-sample 0"}
+ARGS=${@:-"--steps 3 --warmup 1 --cpu-sample 0 --parity-sample 0 --no-sparse-leg --legs none"}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT

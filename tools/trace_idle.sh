@@ -5,7 +5,7 @@ set -u
 TAG=$1; shift
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/trace_idle_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT -o run -- python $ROOT/bench.py --steps 10 --warmup 2 --cpu-sample 0 --parity-sample 0 --no-sparse-leg "$@" > $OUT/run.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT -o run -- python $ROOT/bench.py --steps 10 --warmup 2 --cpu-sample 0 --parity-sample 0 --no-sparse-leg --legs none "$@" > $OUT/run.log 2>&1)
 grep '"metric"' $OUT/run.log | python -c "import sys,json; r=json.loads(sys.stdin.readline()); print('bench under the profiler: ms_per_step', round(r['ms_per_step'], 3), 'value', round(r['value']))"
 python - <<PY
 import csv, glob
