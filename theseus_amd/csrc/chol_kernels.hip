@@ -302,11 +302,16 @@ struct Engine<float> {
   // out[0] = sum_c X[row][c] * vec[c] for this lane's row (vec: 32 values in LDS); valid in every lane
   static __device__ __forceinline__ void blk_rowdot(const Blk& X, const float* vec, int lane, float (&out)[1]) {
     const int g = lane >> 5;
+    // (explicit FMA chain: the function is inlined into two kernels whose results must agree bit for bit -- fwd_diag_block --
+    //  and the compiler's contraction of a * b + c * d + ... depends on the surrounding code)
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float4 v = *reinterpret_cast<const float4*>(vec + 8 * q + 4 * g);
-      s += X[4 * q] * v.x + X[4 * q + 1] * v.y + X[4 * q + 2] * v.z + X[4 * q + 3] * v.w;
+      s = __builtin_fmaf(X[4 * q], v.x, s);
+      s = __builtin_fmaf(X[4 * q + 1], v.y, s);
+      s = __builtin_fmaf(X[4 * q + 2], v.z, s);
+      s = __builtin_fmaf(X[4 * q + 3], v.w, s);
     }
     out[0] = s + __shfl_xor(s, 32);
   }
@@ -558,7 +563,7 @@ struct Engine<double> {
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-        for (int rho = 0; rho < 4; ++rho) s += X.v[mh][nh][rho] * vec[16 * mh + kq + 4 * rho];
+        for (int rho = 0; rho < 4; ++rho) s = __builtin_fma(X.v[mh][nh][rho], vec[16 * mh + kq + 4 * rho], s);
       s += __shfl_xor(s, 16);
       out[nh] = s + __shfl_xor(s, 32);
     }

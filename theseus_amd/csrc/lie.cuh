@@ -398,8 +398,21 @@ __device__ __forceinline__ void sjac_dense(const SJac<T>& J, T* M) {
 
 // Blk(6x6 row major) += P^T Q for structured P, Q:
 //   [[Pa^T Qa, Pa^T Qc],[Pc^T Qa, Pc^T Qc + Pd^T Qd]]
+// (C = A^T B with an EXPLICIT fma chain: the Hessian blocks are accumulated by several instantiations of the assembly kernel --
+//  dense frame / block list -- whose values must agree bit for bit, and the compiler's contraction of a*b + c*d + e*f depends
+//  on the surrounding code)
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <typename T>
+__device__ __forceinline__ void mat3_tmul_fma(const T* A, const T* B, T* C) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[3 * i + j] = fma_t(A[6 + i], B[6 + j], fma_t(A[3 + i], B[3 + j], A[i] * B[j]));
+}
 template <typename T>
 __device__ __forceinline__ void sjac_tmul_acc(const SJac<T>& P, const SJac<T>& Q, T* Blk) {
+#define mat3_tmul mat3_tmul_fma
   T m[9];
   mat3_tmul(P.a, Q.a, m);
 #pragma unroll
@@ -423,6 +436,7 @@ __device__ __forceinline__ void sjac_tmul_acc(const SJac<T>& P, const SJac<T>& Q
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) Blk[6 * (i + 3) + 3 + j] += m[3 * i + j] + m2[3 * i + j];
+#undef mat3_tmul
 }
 
 // g(6) -= P^T e     (Atb = A^T b with b = -err, theseus/optimizer/dense_linearization.py:55)

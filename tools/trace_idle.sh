@@ -27,5 +27,13 @@ for a, b in zip(idx[:-1], idx[1:]):
     tot_span += span; tot_busy += busy
 n = len(idx) - 1
 print(f"per LM iteration ({n} iterations, {idx[1] - idx[0]} kernels each): span {tot_span / n / 1e6:.3f} ms, device busy {tot_busy / n / 1e6:.3f} ms, idle {(tot_span - tot_busy) / n / 1e6:.3f} ms = {(1 - tot_busy / tot_span) * 100:.1f} %")
+# where the busy time goes: kernel time per iteration by kernel name (sum of durations; launches on two streams overlap)
+agg = {}
+for r in rows[idx[0]:idx[-1]]:
+    k = r["Kernel_Name"].split("(")[0][:90]
+    a = agg.setdefault(k, [0, 0])
+    a[0] += 1; a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
+    print(f"  {t / n / 1e6:9.4f} ms/iter  {c / n:6.1f} launches/iter  {t / c / 1e3:9.2f} us avg  {k}")
 PY
 find $OUT -name "*.csv" -size +2M -delete
