@@ -1127,20 +1127,56 @@ struct HBlk {
   const int32_t* piece_rc;
 };
 
-// every element of the pieces of lower tile (ti, tj) of problem b: f(r, c, value), (r, c) relative to the tile origin and inside
-// the tile.  The blocks of a tile are one contiguous run of the list (straddlers from the neighbours aside): coalesced reads.
-template <typename T, typename F>
-__device__ __forceinline__ void hb_foreach(const HBlk& hb, int b, int ti, int tj, int tid, int nthreads, F&& f) {
-  const T* base = static_cast<const T*>(hb.blocks) + (int64_t)b * hb.bstride;
-  const int bd = hb.bd, bb = bd * bd, t = ti * (ti + 1) / 2 + tj;
-  const int p0 = hb.tile_ptr[t], cnt = (hb.tile_ptr[t + 1] - p0) * bb;
-  for (int idx = tid; idx < cnt; idx += nthreads) {
-    const int pc = p0 + idx / bb, e = idx % bb;
-    const int rc = hb.piece_rc[pc];
-    const int r = (int)(short)(rc >> 16) + e / bd, c = (int)(short)(rc & 0xffff) + e % bd;
-    if (r >= 0 && r < TILE && c >= 0 && c < TILE) f(r, c, base[(int64_t)hb.piece_blk[pc] * bb + e]);
+// The pieces of lower tile (ti, tj) of problem b -- f(r, c, value), (r, c) relative to the tile origin and inside the tile; the
+// blocks of a tile are one contiguous run of the list (straddlers from the neighbours aside): coalesced reads -- fetched EARLY:
+// the first NPRE x 256 elements of the tile go global -> registers in the kernel's prologue (two
+// dependent loads each -- table, then value: ~2 us if left to the epilogue, measured as +1.3 ms per factorisation), the K-loop
+// hides them; ``foreach`` then replays them from registers (and walks whatever is beyond NPRE x 256 from memory).
+template <typename T, int NPRE>
+struct HBPre {
+  T v[NPRE];
+  int rc[NPRE];   // (r << 8) | c inside the tile, -1: nothing
+  int p0, cnt;
+  __device__ __forceinline__ void load(const HBlk& hb, int b, int ti, int tj, int tid) {
+    const T* base = static_cast<const T*>(hb.blocks) + (int64_t)b * hb.bstride;
+    const int bd = hb.bd, bb = bd * bd, t = ti * (ti + 1) / 2 + tj;
+    p0 = hb.tile_ptr[t];
+    cnt = (hb.tile_ptr[t + 1] - p0) * bb;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int idx = tid + 256 * k;
+      rc[k] = -1;
+      v[k] = T(0);
+      if (idx < cnt) {
+        const int pc = p0 + idx / bb, e = idx % bb;
+        const int w = hb.piece_rc[pc];
+        const int r = (int)(short)(w >> 16) + e / bd, c = (int)(short)(w & 0xffff) + e % bd;
+        if (r >= 0 && r < TILE && c >= 0 && c < TILE) {
+          rc[k] = (r << 8) | c;
+          v[k] = base[(int64_t)hb.piece_blk[pc] * bb + e];
+        }
+      }
+    }
   }
-}
+  template <typename F>
+  __device__ __forceinline__ void foreach(const HBlk& hb, int b, int tid, F&& f) const {
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k)
+      if (rc[k] >= 0) f(rc[k] >> 8, rc[k] & 255, v[k]);
+    if (cnt > 256 * NPRE) {   // (rare: a tile with more pieces than the registers hold)
+      const T* base = static_cast<const T*>(hb.blocks) + (int64_t)b * hb.bstride;
+      const int bd = hb.bd, bb = bd * bd;
+      for (int idx = tid + 256 * NPRE; idx < cnt; idx += 256) {
+        const int pc = p0 + idx / bb, e = idx % bb;
+        const int w = hb.piece_rc[pc];
+        const int r = (int)(short)(w >> 16) + e / bd, c = (int)(short)(w & 0xffff) + e % bd;
+        if (r >= 0 && r < TILE && c >= 0 && c < TILE) f(r, c, base[(int64_t)hb.piece_blk[pc] * bb + e]);
+      }
+    }
+  }
+};
+constexpr int HB_NPRE_OFF = 3;    // off-diagonal tiles of a pose graph: <= ~20 pieces (720 elements)
+constexpr int HB_NPRE_DIAG = 7;   // diagonal tiles: ~21 diagonal blocks + their chain / loop-closure neighbours (~49 pieces)
 
 template <typename T>
 struct DiagSmem {
@@ -1190,6 +1226,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   std::conditional_t<sizeof(T) == 4, float4, f64x4> hpre[9];
   // issued behind the loads of the first k-chunk (kloop_f's after_issue hook): y_0:j of the earlier columns -> LDS, and the
   // H_jj blocks, in flight during the whole K-loop
+  HBPre<T, HB ? HB_NPRE_DIAG : 1> hbp;
   auto prologue = [&]() __attribute__((always_inline)) {
     if (fwd)
       for (int k = tid; k < row0; k += 256) ybuf[k] = yout[(int64_t)b * ldv + k];
@@ -1204,6 +1241,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
       for (int i = 0; i < 9; ++i)
 #pragma unroll
         for (int k = 0; k < 4; ++k) reinterpret_cast<T*>(&hpre[i])[k] = T(0);
+      hbp.load(hb, b, j, j, tid);
     }
   };
 #ifdef THX_OFF_PROLOGUE_FIRST   // the round-1 order (A/B timing)
@@ -1243,7 +1281,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
       if (fwd && (tid & 1) == 0) vvec[tid >> 1] -= tsum;
     }
     if constexpr (HB) {   // S += H_jj (+ damping): each element of the tile's lower triangle belongs to at most one piece
-      hb_foreach<T>(hb, b, j, j, tid, 256, [&](int r, int c, T v) __attribute__((always_inline)) {
+      hbp.foreach(hb, b, tid, [&](int r, int c, T v) __attribute__((always_inline)) {
         if (c > r) return;
         if (r == c && damp) v = ellipsoidal ? v + (lam * v + damping_eps) : v + lam;
         tile[tblk<T>(r >> 5, c >> 5) + (r & 31) * C::LDB + (c & 31)] += v;
@@ -1433,7 +1471,7 @@ struct SyrkSmem {
 };
 
 template <typename T, bool HB>
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2)
 chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict__ damping, int ellipsoidal, T damping_eps,
                  int n, int64_t ld, int j, const T* __restrict__ rhs, T* __restrict__ yout, int64_t ldv, TilePat pat, HBlk hb) {
   using E = Engine<T>;
@@ -1454,6 +1492,7 @@ chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict
     for (int k = 0; k < 4; ++k) acc[i][k] = T(0);
   T tpart = T(0);  // this thread's half of (L_j,0:j y)[tid >> 1]
   std::conditional_t<sizeof(T) == 4, float4, f64x4> hpre[9];
+  HBPre<T, HB ? HB_NPRE_DIAG : 1> hbp;
   auto prologue = [&]() __attribute__((always_inline)) {
     if (fwd)
       for (int k = tid; k < row0; k += 256) ybuf[k] = yout[(int64_t)b * ldv + k];
@@ -1468,6 +1507,7 @@ chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict
       for (int i = 0; i < 9; ++i)
 #pragma unroll
         for (int k = 0; k < 4; ++k) reinterpret_cast<T*>(&hpre[i])[k] = T(0);
+      hbp.load(hb, b, j, j, tid);
     }
   };
   const int32_t* klist = pat.diag_k ? pat.diag_k + pat.diag_kptr[j] : nullptr;
@@ -1494,7 +1534,7 @@ chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict
       // stores above are this workgroup's own: visible to all its threads after the fence + barrier.
       __threadfence_block();
       __syncthreads();
-      hb_foreach<T>(hb, b, j, j, tid, 256, [&](int r, int c, T v) __attribute__((always_inline)) {
+      hbp.foreach(hb, b, tid, [&](int r, int c, T v) __attribute__((always_inline)) {
         if (c > r || r >= valid) return;
         if (r == c && damp) v = ellipsoidal ? v + (lam * v + damping_eps) : v + lam;
         Lt[(int64_t)r * ld + c] += v;
@@ -1668,7 +1708,9 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   const int r = 32 * wave + (lane & 31), g = lane >> 5;
   const bool rvalid = r < validB;
   float4 hr[4][4];
+  HBPre<float, HB ? HB_NPRE_OFF : 1> hbp;
   auto prologue = [&]() __attribute__((always_inline)) {
+    if constexpr (HB) hbp.load(hb, b, i, j, tid);
     if constexpr (!HB) {
       const float* Hrow = H + mat + (int64_t)(row0 + (rvalid ? r : 0)) * ld + col0 + 4 * g;
 #pragma unroll
@@ -1724,7 +1766,7 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
     for (int half = 0; half < 2; ++half) {
       for (int k = tid; k < 64 * LDH / 4; k += 256) reinterpret_cast<float4*>(smem)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       __syncthreads();
-      hb_foreach<float>(hb, b, i, j, tid, 256, [&](int rr, int cc, float v) __attribute__((always_inline)) {
+      hbp.foreach(hb, b, tid, [&](int rr, int cc, float v) __attribute__((always_inline)) {
         if ((rr >> 6) == half) smem[(rr & 63) * LDH + cc] = v;
       });
       __syncthreads();
@@ -1865,6 +1907,8 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
 
   E::Acc P;
   E::zero(P);
+  HBPre<double, HB ? HB_NPRE_OFF : 1> hbp;
+  if constexpr (HB) hbp.load(hb, b, i, j, tid);
   kloop<double, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, Kspan, sA, sB, P, tid,
                        nullptr, nullptr, NoHook{}, klist);
   if constexpr (HB) {
@@ -1876,7 +1920,7 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
     for (int rd = 0; rd < 4; ++rd) {
       for (int k = tid; k < 32 * LDH / 2; k += 256) reinterpret_cast<double2*>(smem)[k] = make_double2(0.0, 0.0);
       __syncthreads();
-      hb_foreach<double>(hb, b, i, j, tid, 256, [&](int rr, int cc, double v) __attribute__((always_inline)) {
+      hbp.foreach(hb, b, tid, [&](int rr, int cc, double v) __attribute__((always_inline)) {
         if ((rr >> 5) == rd) smem[(rr & 31) * LDH + cc] = v;
       });
       __syncthreads();

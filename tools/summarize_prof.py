@@ -36,7 +36,7 @@ if tr:
     calls, cur = [], None
     for r in rows:
         name = r["Kernel_Name"]
-        if "chol_diag_kernel" in name or "chol_offdiag" in name:
+        if any(k in name for k in ("chol_diag_kernel", "chol_offdiag", "chol_syrk_kernel", "chol_potrf_kernel")):
             t0, t1 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
             if cur is None:
                 cur = [t0, t1, 0, 0]
@@ -50,7 +50,7 @@ if tr:
         calls.append(cur)
     if calls:
         span = [(c[1] - c[0]) / 1e6 for c in calls]
-        print("== thx_chol_factor_forward: span of each call's chol_diag + chol_offdiag launches (kernel trace) ==")
+        print("== thx_chol_factor_*: span of each call's chol_syrk + chol_potrf (or chol_diag) + chol_offdiag launches (kernel trace) ==")
         print(f"calls {len(calls)}  launches/call {calls[0][3]}  span avg {sum(span) / len(span):.3f} ms  "
               f"min {min(span):.3f}  max {max(span):.3f}   (sum of kernel durations per call "
               f"{sum(c[2] for c in calls) / len(calls) / 1e6:.3f} ms: the half-batch streams overlap)")
@@ -67,5 +67,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         a[1] += float(r["Counter_Value"])
     corr = 2.0 if c == "FETCH_SIZE" else 1.0
     print(f"== {c} per launch (KiB x 1024{' x 2 (gfx950 read correction)' if corr == 2 else ''}) ==")
+    tot_chol = 0.0
     for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"{k:70s} launches {n:6d}  avg {v / n * 1024 * corr / 1e6:12.3f} MB/launch  total {v * 1024 * corr / 1e9:10.3f} GB")
+        if k.startswith("chol_") and not k.startswith("chol_bwd") and not k.startswith("chol_fwd"):
+            tot_chol += v * 1024 * corr
+    ncalls = max(1, sum(n for k, (n, v) in agg.items() if k.startswith("pg_assemble")))
+    print(f"   factorisation kernels (chol_syrk / chol_potrf / chol_diag / chol_offdiag): {tot_chol / ncalls / 1e9:.3f} GB per factor call "
+          f"({ncalls} calls)")
