@@ -68,6 +68,11 @@ struct CT<float> {
 };
 template <>
 struct CT<double> {
+  // k-chunks of 16 columns, two of them in flight (kloop_f: AHEAD).  32-column chunks -- KB = 32, LDT = 34: everything below is
+  // written for either -- halve the barriers and staging round trips per flop and measured SLOWER: factor 111.2 vs 108.8 ms at
+  // n = 1536 / batch 4096, 27.8 vs 26.3 ms at batch 1024, 44.7 vs 43.6 ms at n = 3072 / batch 256 on one box
+  // (profiles/r3/j_ab_f64_kchunk32_vs_16.txt): the fp64 K-loop is not barrier-bound; with 70 KB of staging per workgroup the two
+  // workgroups of a CU leave no LDS slack and one 32-column chunk in flight hides less latency than two 16-column ones.
   static constexpr int KB = 16, LDT = 18, VEC = 2, LDM = 130, LDB = 34;
   using V = double2;
 };
@@ -141,6 +146,7 @@ struct Engine<float> {
   // pieces at words 4kq and 16+4kq (an MFMA's k index is only a pairing of columns): the one (stride, offsets)
   // combination for which the ds_read_b128 of a 16x16 fragment is bank-conflict free (stride 36: 32 % conflicts).
   static constexpr int SYRK_LDT = 40;
+  static constexpr int SYRK_STAGE = 128 * SYRK_LDT;   // elements of the SYRK K-loop's staging buffer
   using Sy = f32x4;
   template <int G>
   static __device__ __forceinline__ void syrk36(const float* sA, f32x4* acc, int lane) {
@@ -355,14 +361,15 @@ struct Engine<double> {
   }
   static __device__ __forceinline__ void chunk(const double* sA, const double* sBw, Acc& acc, int lane) {
     const int rl = lane & 15, kq = lane >> 4;
+    constexpr int LDT = CT<double>::LDT;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < CT<double>::KB / 8; ++ks) {
       double2 fb[2];
-      fb[0] = *reinterpret_cast<const double2*>(sBw + rl * 18 + 8 * ks + 2 * kq);
-      fb[1] = *reinterpret_cast<const double2*>(sBw + (16 + rl) * 18 + 8 * ks + 2 * kq);
+      fb[0] = *reinterpret_cast<const double2*>(sBw + rl * LDT + 8 * ks + 2 * kq);
+      fb[1] = *reinterpret_cast<const double2*>(sBw + (16 + rl) * LDT + 8 * ks + 2 * kq);
 #pragma unroll
       for (int cb = 0; cb < 8; ++cb) {
-        const double2 fa = *reinterpret_cast<const double2*>(sA + (16 * cb + rl) * 18 + 8 * ks + 2 * kq);
+        const double2 fa = *reinterpret_cast<const double2*>(sA + (16 * cb + rl) * LDT + 8 * ks + 2 * kq);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           acc.v[h][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa.x, fb[h].x, acc.v[h][cb], 0, 0, 0);
@@ -380,9 +387,18 @@ struct Engine<double> {
   // see Engine<float>::syrk36; staged rows have stride 20 doubles (40 words), a k-chunk is 16 wide, lane (r, kq) reads
   // doubles 2kq, 2kq+1 and 8+2kq, 9+2kq (words 4kq and 16+4kq): conflict free
   static constexpr int SYRK_LDT = 20;
+  // (a 32-column k-chunk would be staged as TWO 16-wide sub-chunks of 128 x SYRK_LDT -- kloop_f's SPLIT16 layout -- so that each
+  //  keeps the conflict-free stride; syrk36 runs once per sub-chunk)
+  static constexpr int SYRK_SUBS = CT<double>::KB / 16;
+  static constexpr int SYRK_STAGE = SYRK_SUBS * 128 * SYRK_LDT;
   using Sy = f64x4;
   template <int G>
   static __device__ __forceinline__ void syrk36(const double* sA, f64x4* acc, int lane) {
+#pragma unroll
+    for (int h = 0; h < SYRK_SUBS; ++h) syrk36_sub<G>(sA + h * 128 * SYRK_LDT, acc, lane);
+  }
+  template <int G>
+  static __device__ __forceinline__ void syrk36_sub(const double* sA, f64x4* acc, int lane) {
     constexpr int UH = 4 + G, UL = 3 - G;
     const int o = (lane & 15) * 20 + 2 * (lane >> 4);
     double fbh[4], fbl[4];
@@ -604,14 +620,20 @@ struct NoHook {
 // ``ktiles`` (tile-sparse factorisation, thx_chol_factor_sparse): instead of the contiguous range [0, K) the loop visits the
 // TILE-wide column blocks ktiles[0 .. K / TILE) -- the block columns in which BOTH operand row panels are structurally
 // non-zero.  The list is wave uniform (scalar loads); skipping a block of exact zeros leaves every accumulator bit unchanged.
-template <typename T, bool SAME, bool GEMV, int LDT, typename Compute, typename Hook = NoHook>
+// SPLIT16 (fp64 SYRK): the chunk's columns [16 h, 16 h + 16) are staged as sub-chunk h at sA + h * 128 * LDT, row stride LDT.
+template <typename T, bool SAME, bool GEMV, int LDT, bool SPLIT16 = false, typename Compute, typename Hook = NoHook>
 __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA, const T* __restrict__ Brows,
                                         int validB, int64_t ld, int K, T* sA, T* sB, int tid, const T* gemv_y,
                                         T* gemv_part, Compute&& compute, Hook&& after_issue = NoHook{},
                                         const int32_t* __restrict__ ktiles = nullptr) {
   using C = CT<T>;
   using V = typename C::V;
-  const int lrow = tid >> 3, lc = tid & 7;
+  constexpr int TPR = C::KB / C::VEC;   // threads per staged row (16 bytes each)
+  constexpr int RPP = 256 / TPR;        // rows per pass of the 256 threads
+  constexpr int NP = TILE / RPP;        // passes: fp32 4 x 32 rows, fp64 8 x 16 rows
+  const int lrow = tid / TPR, lc = tid % TPR;
+  // element offset of this thread's 16-byte piece inside a staged row (set)
+  const int scol = SPLIT16 ? ((lc * C::VEC) >> 4) * 128 * LDT + ((lc * C::VEC) & 15) : lc * C::VEC;
   // Operand rows through BUFFER loads: base pointer + extent live in a 4-SGPR resource, each lane contributes a 32-bit
   // byte offset, the k-chunk offset is a scalar -- no 64-bit per-row addresses in VGPRs (the fp64 kernels, two
   // workgroups per CU = 256 VGPRs, spilled them, and every reload put an s_waitcnt vmcnt(0) into the prefetch), and rows
@@ -621,18 +643,18 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
       const_cast<T*>(Arows), 0, (int)((int64_t)validA * ld * (int64_t)sizeof(T)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<T*>(SAME ? Arows : Brows), 0, (int)((int64_t)(SAME ? validA : validB) * ld * (int64_t)sizeof(T)), 0x00020000);
-  unsigned voff[4];
+  unsigned voff[NP];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) voff[u] = (unsigned)(((lrow + 32 * u) * (int)ld + lc * C::VEC) * (int)sizeof(T));
-  // Register prefetch, AHEAD k-chunks deep.  fp32: one (a second register set measured no gain: 47.3-47.7 ms either way);
-  // fp64: two -- a 16-column chunk is half the MFMA time of an fp32 one, one chunk ahead does not cover the load latency
-  // (factor -2.9 %).
-  constexpr int AHEAD = sizeof(T) == 8 ? 2 : 1;
-  uint4 ra[AHEAD][4], rb[AHEAD][4];
-  auto gload = [&](uint4 (&xa)[4], uint4 (&xb)[4], int k0) __attribute__((always_inline)) {
+  for (int u = 0; u < NP; ++u) voff[u] = (unsigned)(((lrow + RPP * u) * (int)ld + lc * C::VEC) * (int)sizeof(T));
+  // Register prefetch, AHEAD k-chunks deep: 128 bytes per staged row in flight.  fp32: one 32-column chunk (a second register
+  // set measured no gain: 47.3-47.7 ms either way); fp64: two 16-column chunks -- a 16-column chunk is half the MFMA time of an
+  // fp32 one, one chunk ahead does not cover the load latency (factor -2.9 %).
+  constexpr int AHEAD = C::KB * (int)sizeof(T) <= 128 ? 2 : 1;
+  uint4 ra[AHEAD][NP], rb[AHEAD][NP];
+  auto gload = [&](uint4 (&xa)[NP], uint4 (&xb)[NP], int k0) __attribute__((always_inline)) {
     const int so = k0 * (int)sizeof(T);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NP; ++u) {
       const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], so, 0);
       xa[u] = make_uint4(va.x, va.y, va.z, va.w);
       if (!SAME) {
@@ -656,29 +678,32 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   T gsum = T(0);
   // one k-chunk: registers -> LDS, refill the registers with the chunk AHEAD steps on, MFMAs on the staged chunk
   // (a static s_setprio per hardware wave slot, to push the two co-resident workgroups out of lockstep, measured no gain)
-  auto step = [&](uint4 (&xa)[4], uint4 (&xb)[4], int kc) __attribute__((always_inline)) {
+  auto step = [&](uint4 (&xa)[NP], uint4 (&xb)[NP], int kc) __attribute__((always_inline)) {
     // column of the chunk to prefetch: the K-list entry is fetched here so that its (scalar) load completes under the staging
     const int knext = kc + AHEAD < nk ? kof(kc + AHEAD) : 0;
 #ifdef THX_EXP_NOSTAGE  // timing experiment: no register -> LDS staging and only one barrier per chunk (garbage results)
     if (kc == 0) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int row = lrow + 32 * u;
-        *reinterpret_cast<uint4*>(sA + row * LDT + lc * C::VEC) = xa[u];
-        if (!SAME) *reinterpret_cast<uint4*>(sB + row * LDT + lc * C::VEC) = xb[u];
+      for (int u = 0; u < NP; ++u) {
+        const int row = lrow + RPP * u;
+        *reinterpret_cast<uint4*>(sA + row * LDT + scol) = xa[u];
+        if (!SAME) *reinterpret_cast<uint4*>(sB + row * LDT + scol) = xb[u];
       }
     } else {
-      asm volatile("" ::"v"(xa[0].x), "v"(xa[1].x), "v"(xa[2].x), "v"(xa[3].x));  // the loads must still complete
-      if (!SAME) asm volatile("" ::"v"(xb[0].x), "v"(xb[1].x), "v"(xb[2].x), "v"(xb[3].x));
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        asm volatile("" ::"v"(xa[u].x));  // the loads must still complete
+        if (!SAME) asm volatile("" ::"v"(xb[u].x));
+      }
     }
     __syncthreads();
 #else
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int row = lrow + 32 * u;
-      *reinterpret_cast<uint4*>(sA + row * LDT + lc * C::VEC) = xa[u];
-      if (!SAME) *reinterpret_cast<uint4*>(sB + row * LDT + lc * C::VEC) = xb[u];
+    for (int u = 0; u < NP; ++u) {
+      const int row = lrow + RPP * u;
+      *reinterpret_cast<uint4*>(sA + row * LDT + scol) = xa[u];
+      if (!SAME) *reinterpret_cast<uint4*>(sB + row * LDT + scol) = xb[u];
     }
     __syncthreads();
 #endif
@@ -690,7 +715,8 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
     if constexpr (GEMV) {
       if (gemv_y) {
         constexpr int HALF = C::KB / 2;
-        const V* rp = reinterpret_cast<const V*>(sA + (tid >> 1) * LDT + (tid & 1) * HALF);
+        // (thread pair (2r, 2r+1): the two 16-column halves of row r -- with SPLIT16 the two sub-chunks)
+        const V* rp = reinterpret_cast<const V*>(sA + (tid >> 1) * LDT + (SPLIT16 ? (tid & 1) * 128 * LDT : (tid & 1) * HALF));
         const V* yp = reinterpret_cast<const V*>(gemv_y + kof(kc) + (tid & 1) * HALF);
 #pragma unroll
         for (int i = 0; i < HALF / C::VEC; ++i) {
@@ -1182,7 +1208,7 @@ template <typename T>
 struct DiagSmem {
   // ten 32 x LDB sub-blocks; the K-loop's staging buffer (128 x SYRK_LDT) lives in its head
   static constexpr size_t tile = (size_t)10 * 32 * CT<T>::LDB * sizeof(T);
-  static_assert(10 * 32 * CT<T>::LDB >= 128 * Engine<T>::SYRK_LDT, "staging buffer must fit in the tile");
+  static_assert(10 * 32 * CT<T>::LDB >= Engine<T>::SYRK_STAGE, "staging buffer must fit in the tile");
   // tile | vvec [128] T | ubuf [32] T | ybuf [ypad] T
   static size_t bytes(int ypad) { return tile + 160 * sizeof(T) + (size_t)ypad * sizeof(T); }
 };
@@ -1250,7 +1276,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   // tile-sparse: only the block columns k < j in which row panel j is non-zero
   const int32_t* klist = pat.diag_k ? pat.diag_k + pat.diag_kptr[j] : nullptr;
   const int Kspan = pat.diag_k ? (pat.diag_kptr[j + 1] - pat.diag_kptr[j]) * TILE : row0;
-  kloop_f<T, true, true, E::SYRK_LDT>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, Kspan, tile, nullptr, tid,
+  kloop_f<T, true, true, E::SYRK_LDT, (sizeof(T) == 8 && CT<T>::KB == 32)>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, Kspan, tile, nullptr, tid,
                          fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
     if (wave == 0) E::template syrk36<0>(tile, acc, lane);
     else if (wave == 1) E::template syrk36<1>(tile, acc, lane);
@@ -1467,7 +1493,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 struct SyrkSmem {
-  static size_t bytes(int ypad) { return (size_t)128 * Engine<T>::SYRK_LDT * sizeof(T) + (size_t)ypad * sizeof(T); }
+  static size_t bytes(int ypad) { return (size_t)Engine<T>::SYRK_STAGE * sizeof(T) + (size_t)ypad * sizeof(T); }
 };
 
 template <typename T, bool HB>
@@ -1477,7 +1503,7 @@ chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict
   using E = Engine<T>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* stage = reinterpret_cast<T*>(smem_raw);                 // K-loop staging buffer, 128 x SYRK_LDT
-  T* ybuf = stage + 128 * E::SYRK_LDT;                       // y_0:j of the earlier columns
+  T* ybuf = stage + E::SYRK_STAGE;                           // y_0:j of the earlier columns
   const int b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t mat = (int64_t)b * ld * ld;
@@ -1512,7 +1538,7 @@ chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict
   };
   const int32_t* klist = pat.diag_k ? pat.diag_k + pat.diag_kptr[j] : nullptr;
   const int Kspan = pat.diag_k ? (pat.diag_kptr[j + 1] - pat.diag_kptr[j]) * TILE : row0;
-  kloop_f<T, true, true, E::SYRK_LDT>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, Kspan, stage, nullptr, tid,
+  kloop_f<T, true, true, E::SYRK_LDT, (sizeof(T) == 8 && CT<T>::KB == 32)>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, Kspan, stage, nullptr, tid,
                                       fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
     if (wave == 0) E::template syrk36<0>(stage, acc, lane);
     else if (wave == 1) E::template syrk36<1>(stage, acc, lane);
@@ -1860,7 +1886,8 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
 //   * the substitution runs IN PLACE: X_s = W_ss P_s goes through a 32-VGPR temporary back into P_s's registers, which
 //     then serve as the B operand of the updates P_u += (-L_us) X_s.  128 + 32 accumulator VGPRs instead of 256.
 // ------------------------------------------------------------------------------------------------
-constexpr int OFF64_SMEM = 6 * 1024 * 8;  // 48 KB >= the K-loop staging buffers (2 x 128 x 18 doubles = 36.9 KB)
+// 48 KB: panel phase A (six 8 KB sub-blocks), staged over the K-loop buffers (2 x 128 x LDT doubles = 36.9 KB with 16-column chunks)
+constexpr int OFF64_SMEM = (2 * 128 * CT<double>::LDT * 8 > 6 * 1024 * 8) ? 2 * 128 * CT<double>::LDT * 8 : 6 * 1024 * 8;
 
 // D.block(S) += Pc[block idx] * Bs.block(Tt)^T, Pc block: 32 x 32 doubles, element (r, c) at r * 32 + (c ^ 2 (r & 15))
 template <int S, int Tt, typename DT>
