@@ -95,8 +95,43 @@ def test_best_iter_and_state_history():
                 best, bi = h[b, it + 1].item(), it
         assert int(info.best_iter[b]) == bi
         assert float(info.best_err[b]) == pytest.approx(best)
-    with pytest.raises(NotImplementedError):
-        layer.forward(None, optimizer_kwargs=dict(track_state_history=True, **kw))
+
+
+@pytest.mark.parametrize("name", ["pg_f64_lm", "pg_f64_lm_adaptive_rejects", "pg_f64_lm_converges"])
+def test_state_history_matches_the_iterates(name):
+    """track_state_history (nonlinear_optimizer.py:150-163,174-178): name -> (B, 3, 4, max_iterations + 1), slot 0 the initial
+    value, slot k the variable after counted iteration k, unreached slots inf -- recorded on the device by the sync-free loop
+    (device-side slot index: all-rejected attempts are not counted) and by the synchronous loop alike; checked against the
+    iterates an end_iter_callback sees."""
+    import theseus_amd as th
+    from tests.oracle_kernels import OracleKernels
+    from tests.test_gpu_lm import build_objective
+    g = load_golden(name)
+    _, _, kw = golden_problem(g)
+    kw = {k: v for k, v in kw.items() if k not in ("gauss_newton", "max_iterations", "step_size")}
+    tol = dict(abs_err_tolerance=1e-10, rel_err_tolerance=1e-4) if "converges" in name else dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    out = {}
+    for lazy in (True, False):
+        obj, _ = build_objective(th, g, device="cpu")
+        opt = th.LevenbergMarquardt(obj, linearization_kwargs=dict(kernels=OracleKernels()), max_iterations=8, **tol)
+        seen = []
+        okw = dict(track_state_history=True, track_err_history=True, **kw)
+        if not lazy:
+            okw["end_iter_callback"] = lambda o, i, d, it: seen.append({k: v.tensor.clone() for k, v in o.objective.optim_vars.items()})
+        start = {k: v.tensor.clone() for k, v in obj.optim_vars.items()}
+        _, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=okw)
+        out[lazy] = (info, seen, start)
+    (ia, _, start), (ib, seen, _) = out[True], out[False]
+    K = 8
+    for k_, h in ia.state_history.items():
+        assert h.shape == start[k_].shape + (K + 1,) and h.dtype == torch.get_default_dtype()
+        assert torch.equal(h, ib.state_history[k_])                                    # sync-free == synchronous
+        np.testing.assert_allclose(h[..., 0].numpy(), start[k_].numpy(), rtol=0, atol=1e-6)
+        for it, st in enumerate(seen):                                                  # what the callback saw after iteration it
+            np.testing.assert_allclose(h[..., it + 1].numpy(), st[k_].numpy(), rtol=0, atol=1e-6)
+        last = ia.iters_done + (1 if "converges" in name else 0)    # (the converging iteration is recorded, not counted: :202-203)
+        assert torch.isfinite(h[..., :last + 1]).all() and torch.isinf(h[..., last + 1:]).all()
+    assert ia.iters_done == ib.iters_done
 
 
 def test_global_params_mirror(monkeypatch):

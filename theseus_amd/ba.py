@@ -404,6 +404,12 @@ class PackedBA:
         self.K.copy_where(mask, src[0], dst[0])
         self.K.copy_where(mask, src[1], dst[1])
 
+    def history_dict(self, hist, dtype):
+        hc, hp = hist[0].to(dtype).cpu(), hist[1].to(dtype).cpu()
+        out = {v.name: hc[:, k].movedim(0, -1).contiguous() for k, v in enumerate(self.cam_vars)}
+        out.update({v.name: hp[:, k].movedim(0, -1).contiguous() for k, v in enumerate(self.pt_vars)})
+        return out
+
     def solution_dict(self, state):
         out = {v.name: state[0][k].cpu() for k, v in enumerate(self.cam_vars)}
         out.update({v.name: state[1][k].cpu() for k, v in enumerate(self.pt_vars)})

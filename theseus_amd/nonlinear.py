@@ -61,6 +61,7 @@ class NonlinearOptimizerInfo:
     last_err: torch.Tensor
     best_err: torch.Tensor
     iters_done: int = 0
+    state_history: Optional[Dict[str, torch.Tensor]] = None  # variable name -> (B, ..., max_iterations + 1)
 
 
 @dataclass
@@ -98,6 +99,41 @@ class _LaggedFlag:
             _, k = self.pending.pop(0)
             self.value = self.value or bool(self.host[k])
         return self.value
+
+
+class _StateHistory:
+    """``track_state_history`` (nonlinear_optimizer.py:150-163,174-178): the iterate after every counted iteration.  The states
+    are kept on the DEVICE in the packed layout -- slot k of a (K + 1, ...) buffer per state tensor, written at a device-side
+    index so that the sync-free loop stays sync-free -- and turned into the reference's name -> (B, ..., K + 1) host tensors
+    once, after the loop.  Slots never reached stay at inf, like the reference's."""
+
+    def __init__(self, state, slots: int):
+        self.tuple = isinstance(state, tuple)
+        ts = state if self.tuple else (state,)
+        self.bufs = tuple(torch.full((slots,) + tuple(t.shape), float("inf"), dtype=t.dtype, device=t.device) for t in ts)
+        self.slots = slots
+        self.record(0, state)
+
+    def record(self, slot, state, counted=None):
+        """``slot``: int, or a 0-dim device tensor (clamped to the buffer); ``counted``: 0-dim device bool -- write only if set."""
+        ts = state if self.tuple else (state,)
+        for buf, t in zip(self.bufs, ts):
+            t = t.detach()
+            if isinstance(slot, int):
+                buf[slot].copy_(t)
+                continue
+            idx = slot.clamp(max=self.slots - 1).view(1)
+            if counted is not None:
+                t = torch.where(counted, t, buf.index_select(0, idx)[0])
+            buf.index_copy_(0, idx, t.unsqueeze(0))
+
+    def cut(self, first_unused: int):
+        for buf in self.bufs:
+            buf[first_unused:] = float("inf")
+
+    def to_dict(self, packed):
+        hist = self.bufs if self.tuple else self.bufs[0]
+        return packed.history_dict(hist, torch.get_default_dtype())   # (the reference allocates it with torch.ones(...): default dtype)
 
 
 class NonlinearLeastSquares(abc.ABC):
@@ -201,9 +237,6 @@ class NonlinearLeastSquares(abc.ABC):
                 "Differentiating through the unrolled iterations (backward_mode='unroll') is not supported by the "
                 "HIP back end: the kernels are outside autograd.  Use backward_mode='implicit' (one backward linear "
                 "solve with the cached factor), or call under torch.no_grad().")
-        if track_state_history:
-            raise NotImplementedError("track_state_history is not supported by the HIP back end (the iterates live in two "
-                                      "recycled device buffers); use end_iter_callback to copy the states you need.")
         implicit = backward_mode == BackwardMode.IMPLICIT
         lin: HipLinearization = self.linear_solver.linearization
         packed = lin.packed
@@ -233,6 +266,7 @@ class NonlinearLeastSquares(abc.ABC):
                     err_history=hist, last_err=last, best_err=last.clone())
 
             last_err, err_hist, info = fresh_info()
+            state_hist = _StateHistory(packed.state, p.max_iterations + 1) if track_state_history else None
             if track_best_solution:
                 best_state = packed.clone_state()
                 best_err = last_err.clone()
@@ -323,6 +357,8 @@ class NonlinearLeastSquares(abc.ABC):
                             col = (it_dev + 1).clamp(max=p.max_iterations).view(1)
                             cur = err_hist.index_select(1, col)
                             err_hist.index_copy_(1, col, torch.where(counted, err.unsqueeze(1), cur))
+                        if state_hist is not None:
+                            state_hist.record(it_dev + 1, packed.state, counted)
                         if track_best_solution:
                             better = (err < best_err) & counted
                             packed.copy_where(better, packed.state, best_state)
@@ -360,6 +396,8 @@ class NonlinearLeastSquares(abc.ABC):
                         it = f_conv - 1
                         if err_hist is not None:
                             err_hist[:, f_conv + 1:] = inf
+                        if state_hist is not None:
+                            state_hist.cut(f_conv + 1)
                         converged = conv_iter.ge(0) & conv_iter.le(f_conv)   # (later iterations only re-marked frozen problems)
                         conv_iter = torch.where(converged, conv_iter, torch.full_like(conv_iter, -1))
                         halt = True
@@ -431,6 +469,8 @@ class NonlinearLeastSquares(abc.ABC):
                     all_reject_attempts = 0
                     if err_hist is not None:
                         err_hist[:, it + 1] = err
+                    if state_hist is not None:
+                        state_hist.record(it + 1, packed.state)
                     if track_best_solution:
                         better = err < best_err
                         packed.copy_where(better, packed.state, best_state)
@@ -465,6 +505,8 @@ class NonlinearLeastSquares(abc.ABC):
                 packed.swap_state(X_new)
                 if err_hist is not None:
                     err_hist[:, it + 1] = err
+                if state_hist is not None:
+                    state_hist.record(it + 1, X_det)
                 if track_best_solution:
                     better = err < best_err
                     packed.copy_where(better, X_det, best_state)
@@ -493,6 +535,8 @@ class NonlinearLeastSquares(abc.ABC):
             info.converged_iter[torch.from_numpy(info.status == NonlinearOptimizerStatus.MAX_ITERATIONS)] = -1
             if err_hist is not None:
                 info.err_history = err_hist.cpu()
+            if state_hist is not None:
+                info.state_history = state_hist.to_dict(packed)
             if track_best_solution:
                 info.best_err = best_err
                 info.best_iter = best_iter.cpu()

@@ -353,6 +353,12 @@ class PackedPoseGraph:
     def solution_dict(self, state):
         return {v.name: state[k].cpu() for k, v in enumerate(self.pose_vars)}
 
+    def history_dict(self, hist, dtype):
+        """``hist``: (K + 1, P, B, ...) packed states per iteration -> the reference's ``info.state_history`` layout
+        (nonlinear_optimizer.py:150-163): name -> (B, ..., K + 1) on the host."""
+        h = hist.to(dtype).cpu()
+        return {v.name: h[:, k].movedim(0, -1).contiguous() for k, v in enumerate(self.pose_vars)}
+
     # ---- scratch ------------------------------------------------------------------------------
     def _buf(self, key, shape, dtype=None):
         t = self._scratch.get(key)
