@@ -730,7 +730,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=128, help="problems in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-chunk", type=int, default=32, help="problems per CPU-baseline chunk")
     ap.add_argument("--cpu-iters", type=int, default=3)
-    ap.add_argument("--parity-sample", type=int, default=8, help="problems in the exact-parity sub-sample (0 = skip)")
+    ap.add_argument("--parity-sample", type=int, default=32, help="problems in the exact-parity sub-sample (0 = skip)")
     ap.add_argument("--no-sparse-leg", action="store_true",
                     help="skip the second measurement of the same workload with the tile-sparse solver (reported under "
                          "'tile_sparse' next to the dense headline)")
