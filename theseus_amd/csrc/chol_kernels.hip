@@ -2315,8 +2315,8 @@ constexpr int MAX_DEVICES = 64;
 struct DeviceLaunchState {
   size_t attr_diag[2][2] = {{0, 0}, {0, 0}}, attr_syrk[2][2] = {{0, 0}, {0, 0}}, attr_solve[2] = {0, 0};   // [0] float, [1] double (x HB)
   bool attr_off = false;
-  hipStream_t aux = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_lag = nullptr, ev_join = nullptr;
+  hipStream_t aux[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_lag[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
 };
 static std::mutex g_launch_mutex;
 static DeviceLaunchState& launch_state() {
@@ -2380,26 +2380,36 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     hipStream_t s;
     int b0, nb;
   };
-  hipStream_t& aux = ds.aux;
-  hipEvent_t &ev_fork = ds.ev_fork, &ev_lag = ds.ev_lag, &ev_join = ds.ev_join;
   static const int split_min = [] {
-    const char* e = getenv("THX_CHOL_SPLIT_MIN");  // batch size from which the two-stream schedule is used (0: never)
+    const char* e = getenv("THX_CHOL_SPLIT_MIN");  // batch size from which the multi-stream schedule is used (0: never)
     return e ? atoi(e) : 1024;
   }();
+  // number of parts (streams): 2; THX_CHOL_PARTS=3 staggers three thirds (measured)
+  static const int nparts_cfg = [] {
+    const char* e = getenv("THX_CHOL_PARTS");
+    const int v = e ? atoi(e) : 2;
+    return v < 2 ? 2 : (v > 3 ? 3 : v);
+  }();
   const bool split = split_min > 0 && B >= split_min && ntiles > 1;
-  Half halves[2] = {{st, 0, B}, {st, 0, 0}};
+  const int nparts = split ? nparts_cfg : 1;
+  Half halves[3] = {{st, 0, B}, {st, 0, 0}, {st, 0, 0}};
   if (split) {
-    if (!aux) {
-      hipStreamCreateWithFlags(&aux, hipStreamNonBlocking);
-      hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
-      hipEventCreateWithFlags(&ev_lag, hipEventDisableTiming);
-      hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
+    if (!ds.ev_fork) hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming);
+    for (int k = 0; k + 1 < nparts; ++k)
+      if (!ds.aux[k]) {
+        hipStreamCreateWithFlags(&ds.aux[k], hipStreamNonBlocking);
+        hipEventCreateWithFlags(&ds.ev_lag[k], hipEventDisableTiming);
+        hipEventCreateWithFlags(&ds.ev_join[k], hipEventDisableTiming);
+      }
+    const int per = min((B / nparts + 7) / 8 * 8, B);  // (multiple of 8: the XCD-aware block map of chol_offdiag)
+    int b0 = 0;
+    for (int k = 0; k < nparts; ++k) {
+      const int nb = k + 1 < nparts ? min(per, B - b0) : B - b0;
+      halves[k] = {k == 0 ? st : ds.aux[k - 1], b0, nb};
+      b0 += nb;
     }
-    const int b_half = min((B / 2 + 7) / 8 * 8, B);  // (multiple of 8: the XCD-aware block map of chol_offdiag)
-    halves[0] = {st, 0, b_half};
-    halves[1] = {aux, b_half, B - b_half};
-    hipEventRecord(ev_fork, st);
-    hipStreamWaitEvent(aux, ev_fork, 0);
+    hipEventRecord(ds.ev_fork, st);
+    for (int k = 0; k + 1 < nparts; ++k) hipStreamWaitEvent(ds.aux[k], ds.ev_fork, 0);
   }
   // (block-compact H: the half's problems start at h.b0 of the block list; H itself is not dereferenced)
   auto hb_of = [&](const Half& h) {
@@ -2452,19 +2462,21 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     }
   };
   for (int j = 0; j < ntiles; ++j) {
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < nparts; ++k) {
       const Half& h = halves[k];
       if (h.nb <= 0) continue;
-      if (split && k == 1 && j == 0) hipStreamWaitEvent(aux, ev_lag, 0);  // second half: one diagonal phase behind
+      if (split && k > 0 && j == 0) hipStreamWaitEvent(h.s, ds.ev_lag[k - 1], 0);  // part k: one diagonal phase behind part k-1
       launch_diag(h, j);
-      if (split && k == 0 && j == 0) hipEventRecord(ev_lag, st);
+      if (split && k + 1 < nparts && j == 0) hipEventRecord(ds.ev_lag[k], h.s);
       const int nrt = tp ? tp->col_count_host[j] : ntiles - 1 - j;   // (tile-sparse: the column's non-zero row tiles)
       if (nrt > 0) launch_off(h, j, j + 1, nrt);
     }
   }
   if (split) {
-    hipEventRecord(ev_join, aux);
-    hipStreamWaitEvent(st, ev_join, 0);
+    for (int k = 0; k + 1 < nparts; ++k) {
+      hipEventRecord(ds.ev_join[k], ds.aux[k]);
+      hipStreamWaitEvent(st, ds.ev_join[k], 0);
+    }
   }
   return check_launch("thx_chol_factor");
 }
