@@ -187,7 +187,8 @@ int thx_pg_assemble(const thx_pg_structure* s, const thx_pg_data* d, void* H, in
  *      thx_hblocks_diag: diag(H) -> d (B, nvars * bd), row stride ldv  (Linearization.diagonal_scaling, LM's rho test).
  *      thx_chol_factor_hblocks: thx_chol_factor_forward / thx_chol_factor_sparse (pattern != NULL) reading H from the block
  *        list: every Cholesky tile gathers its pieces into LDS / adds them to its Schur update instead of streaming a dense
- *        tile of zeros.  rhs / y may both be NULL (no fused forward substitution). */
+ *        tile of zeros.  rhs / y may both be NULL (no fused forward substitution).  ld = 0 (with a pattern): L is the
+ *        TILE-PACKED factor (see thx_tile_pattern) -- neither H nor L is a dense frame then. */
 typedef struct {
   int32_t nblocks, bd, nvars, ntiles;
   const int32_t* diag_blk;
@@ -276,6 +277,15 @@ typedef struct {
   const int32_t* col_count_host;  /* (ntiles) HOST copy of col_ptr[j+1] - col_ptr[j] (launch sizes) */
   const int32_t* row_ptr;         /* (ntiles + 1) the same pattern by ROWS, for the list-driven solves: the non-zero off-diagonal */
   const int32_t* row_tile;        /*   tiles of block row i are the block columns row_tile[row_ptr[i] .. row_ptr[i+1]) (< i) */
+  /* TILE-PACKED factor (thx_chol_factor_hblocks / thx_chol_solve_sparse with ld = 0): L is (B, nslots, THX_TILE, THX_TILE), only
+   * the tiles of the pattern exist -- slot j = diagonal tile j, slot ntiles + e = off-diagonal entry e (tile (col_row[e], j)) --
+   * instead of a dense (B, ld, ld) frame that is mostly zeros (n = 12288: 604 MB per problem in fp32 against ~12 MB).  The
+   * role of BaspachoSparseSolver's packed factor data (baspacho_sparse_solver.py:58-148).  Zero-initialise once. */
+  const int32_t* tile_sa;         /* (per tile_k element) slot of L_jk, the K-loop's A operand tile */
+  const int32_t* tile_sb;         /* (per tile_k element) slot of L_ik, its B operand tile */
+  const int32_t* diag_s;          /* (per diag_k element) slot of L_jk */
+  const int32_t* row_slot;        /* (per row_tile element) slot of that tile */
+  int32_t nslots;                 /* ntiles + entries */
 } thx_tile_pattern;
 int thx_chol_factor_sparse(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
                            double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y, int64_t ldv,

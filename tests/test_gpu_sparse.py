@@ -145,3 +145,76 @@ def test_sparse_solver_has_no_size_limit_in_fp64():
     assert (r.abs().max() / lin.Atb.abs().max()).item() < 1e-10
     x = solver.solve_with_factor(lin.Atb.squeeze(2).contiguous())       # both halves with the cached factor
     np.testing.assert_allclose(x.cpu().numpy(), delta.cpu().numpy(), rtol=0, atol=1e-9 * float(delta.abs().max()))
+
+
+def _chain_problem(th, P, B, dtype, seed=7):
+    from tests.test_sparse_solver import chain_graph
+    edges = chain_graph(P, stride=7, span=5, seed=2)
+    K = th.default_kernels()
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    rnd = lambda nn, s: K.se3_exp(s * (2 * torch.rand(nn, 6, dtype=dtype, device="cuda", generator=gen) - 1))  # noqa: E731
+    gt = rnd(B * P, 1.5).view(B, P, 3, 4)
+    poses0 = K.se3_compose(gt.reshape(-1, 3, 4), rnd(B * P, 0.05)).view(B, P, 3, 4)
+    meas = [K.se3_compose(K.se3_compose(K.se3_inverse(gt[:, i].contiguous()), gt[:, j].contiguous()), rnd(B, 0.01)) for (i, j) in edges]
+
+    def build(**solver_kw):
+        obj = th.Objective(dtype=dtype)
+        pv = [th.SE3(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+        w = th.ScaleCostWeight(torch.tensor(5.0, dtype=dtype, device="cuda"))
+        for k, (i, j) in enumerate(edges):
+            obj.add(th.Between(pv[i], pv[j], th.SE3(tensor=meas[k].clone(), name=f"m_{k}"), w, name=f"b_{k}"))
+        obj.add(th.Difference(pv[edges[0][0]], th.SE3(tensor=gt[:, edges[0][0]].clone(), name="anchor"), w, name="prior"))
+        return th.LevenbergMarquardt(obj, linear_solver_cls=th.HipSparseCholeskySolver, max_iterations=4, abs_err_tolerance=0.0,
+                                     rel_err_tolerance=0.0, linear_solver_kwargs=solver_kw)
+    return build
+
+
+@pytest.mark.parametrize("dtype,P", [(torch.float32, 700), (torch.float64, 300)])
+def test_tile_packed_factor_is_bit_identical_to_the_dense_frame(dtype, P):
+    """HipSparseCholeskySolver keeps L TILE-PACKED by default -- (B, nslots, 128, 128): only the tiles of the pattern exist -- when
+    the Hessian is block-compact.  Same kernels, same arithmetic: the LM run, the factor (unpacked) and a cached-factor solve are
+    bit-identical to the dense-frame factor of the same pattern."""
+    import theseus_amd as th
+    B = 6
+    build = _chain_problem(th, P, B, dtype)
+    out = {}
+    for packed in (True, False):
+        opt = build(packed_factor=packed)
+        solver = opt.linear_solver
+        assert solver.packed_factor == packed
+        sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(damping=1e-2, adaptive_damping=True, track_err_history=True))
+        x = solver.solve_with_factor(solver.linearization.g.clone())
+        out[packed] = (torch.stack([sol[f"pose_{k}"] for k in range(P)], 1), info.err_history, solver.dense_factor().clone(), x, solver)
+    (xa, ha, La, sa, solver), (xb, hb, Lb, sb, dsolver) = out[True], out[False]
+    pat = solver.pattern
+    assert solver.L.dim() == 4 and solver.L.shape[1] == pat.nslots == pat.ntiles + len(pat.tables["col_row"])
+    n = solver.linearization.n
+    assert torch.equal(torch.tril(La[:, :n, :n]), torch.tril(Lb[:, :n, :n]))
+    assert torch.equal(xa, xb) and torch.equal(ha, hb) and torch.equal(sa, sb)
+    assert ha[:, -1].mean() < 0.05 * ha[:, 0].mean()
+    print(f"[packed factor] n = {n}: {pat.nslots} tiles of 128 x 128 = {pat.nslots * 65536 * xa.element_size() / 4 / 1e6:.1f} MB per problem "
+          f"against {dsolver.L[0].numel() * xa.element_size() / 1e6:.1f} MB of dense frame")
+
+
+def test_tile_packed_factor_runs_a_4096_pose_graph_at_the_reference_sweeps_batch_size():
+    """evaluations/pose_graph_synthetic.sh sweeps to 4096 poses at batch sizes up to 256: n = 24576 -- a dense (B, ld, ld) frame
+    of L would be 2.4 GB per problem in fp32 (batch 256: 618 GB, twice the HBM of an MI355X; H another 618 GB before round 3).
+    Block-compact H + tile-packed L: a few tens of MB per problem."""
+    import theseus_amd as th
+    P, B, dtype = 4096, 256, torch.float32
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    build = _chain_problem(th, P, B, dtype)
+    opt = build()
+    solver = opt.linear_solver
+    with torch.no_grad():
+        sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(damping=1e-2, track_err_history=True))
+    assert solver.packed_factor and solver.linearization._compact and solver.linearization._H is None
+    peak = torch.cuda.max_memory_allocated() / 1e9
+    pat = solver.pattern
+    print(f"[4096 poses, batch 256] L: {pat.nslots} tiles = {solver.L[0].numel() * 4 / 1e6:.1f} MB per problem (dense frame: "
+          f"{(6 * P) ** 2 * 4 / 1e6:.0f} MB); peak device memory of the run {peak:.1f} GB; cost {info.err_history[:, 0].mean():.1f} -> "
+          f"{info.err_history[:, -1].mean():.4f}")
+    assert int(solver.info.abs().sum()) == 0
+    assert info.err_history[:, -1].mean() < 0.05 * info.err_history[:, 0].mean()
+    assert peak < 60.0

@@ -97,3 +97,30 @@ def test_sparse_solver_equals_dense_solver_through_the_host_path(group):
     np.testing.assert_allclose(sparse.numpy(), dense.numpy(), rtol=0, atol=1e-9)
     np.testing.assert_allclose(sinfo.err_history.numpy(), dinfo.err_history.numpy(), rtol=1e-9)
     assert sinfo.err_history[:, -1].mean() < 0.05 * sinfo.err_history[:, 0].mean()
+
+
+def test_slot_tables_of_the_tile_packed_factor():
+    """TilePattern's slot tables (include/theseus_hip.h: thx_tile_pattern, tile-packed factor): slot j = diagonal tile j, slot
+    ntiles + e = off-diagonal entry e; every K-list element names the slots of its two operand tiles, every row-list element the
+    slot of its tile -- and all of them are tiles of the pattern."""
+    import numpy as np
+    from theseus_amd.compiler import PoseGraphStructure
+    from theseus_amd.sparse import tile_pattern
+    s = PoseGraphStructure.build(400, chain_graph(400, stride=7, span=5, seed=2), [0])
+    pat = tile_pattern(s, 6)
+    t, nt = pat.tables, pat.ntiles
+    assert pat.nslots == nt + len(t["col_row"]) == pat.l_tiles
+    tiles = {v: k for k, v in pat.slot.items()}
+    assert len(tiles) == pat.nslots and all(pat.lower[i, j] for (i, j) in pat.slot)
+    for j in range(nt):
+        for e in range(t["col_ptr"][j], t["col_ptr"][j + 1]):
+            i = int(t["col_row"][e])
+            assert pat.slot[(i, j)] == nt + e
+            for q in range(t["tile_kptr"][e], t["tile_kptr"][e + 1]):
+                k = int(t["tile_k"][q])
+                assert tiles[int(t["tile_sa"][q])] == (j, k) and tiles[int(t["tile_sb"][q])] == (i, k)
+        for q in range(t["diag_kptr"][j], t["diag_kptr"][j + 1]):
+            assert tiles[int(t["diag_s"][q])] == (j, int(t["diag_k"][q]))
+    for i in range(nt):
+        for q in range(t["row_ptr"][i], t["row_ptr"][i + 1]):
+            assert tiles[int(t["row_slot"][q])] == (i, int(t["row_tile"][q]))

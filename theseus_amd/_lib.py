@@ -19,7 +19,7 @@ THX_TILE = 128
 THX_ERR_CHUNKS = 16
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class LieEps(Structure):
@@ -48,7 +48,8 @@ class BAData(Structure):  # thx_ba_data
 
 class TilePattern(Structure):  # thx_tile_pattern: tile-level symbolic factorisation (device int32 tables + one host table)
     _fields_ = [("ntiles", c_int32)] + [(k, c_void_p) for k in ("col_ptr", "col_row", "tile_kptr", "tile_k", "diag_kptr", "diag_k",
-                                                               "col_count_host", "row_ptr", "row_tile")]
+                                                               "col_count_host", "row_ptr", "row_tile",
+                                                               "tile_sa", "tile_sb", "diag_s", "row_slot")] + [("nslots", c_int32)]
 
 
 class HBlockLayout(Structure):  # thx_hblock_layout: block-compact Hessian (device int32 tables)

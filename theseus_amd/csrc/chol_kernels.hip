@@ -621,11 +621,15 @@ struct NoHook {
 // TILE-wide column blocks ktiles[0 .. K / TILE) -- the block columns in which BOTH operand row panels are structurally
 // non-zero.  The list is wave uniform (scalar loads); skipping a block of exact zeros leaves every accumulator bit unchanged.
 // SPLIT16 (fp64 SYRK): the chunk's columns [16 h, 16 h + 16) are staged as sub-chunk h at sA + h * 128 * LDT, row stride LDT.
+// ``ksa`` / ``ksb`` (tile-packed factor): per K-list element the SLOT of the A / B operand tile; Arows / Brows then point at the
+// problem's packed buffer, ``ld`` is TILE and ``packed_elems`` the buffer's extent (rows of a tile beyond the matrix are zero in
+// the buffer itself, never written).
 template <typename T, bool SAME, bool GEMV, int LDT, bool SPLIT16 = false, typename Compute, typename Hook = NoHook>
 __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA, const T* __restrict__ Brows,
                                         int validB, int64_t ld, int K, T* sA, T* sB, int tid, const T* gemv_y,
                                         T* gemv_part, Compute&& compute, Hook&& after_issue = NoHook{},
-                                        const int32_t* __restrict__ ktiles = nullptr) {
+                                        const int32_t* __restrict__ ktiles = nullptr, const int32_t* __restrict__ ksa = nullptr,
+                                        const int32_t* __restrict__ ksb = nullptr, int64_t packed_elems = 0) {
   using C = CT<T>;
   using V = typename C::V;
   constexpr int TPR = C::KB / C::VEC;   // threads per staged row (16 bytes each)
@@ -639,10 +643,11 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   // workgroups per CU = 256 VGPRs, spilled them, and every reload put an s_waitcnt vmcnt(0) into the prefetch), and rows
   // outside the matrix are zeroed by the hardware bounds check (extent = valid rows) instead of v_cndmask / exec branches.
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(Arows), 0, (int)((int64_t)validA * ld * (int64_t)sizeof(T)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(SAME ? Arows : Brows), 0, (int)((int64_t)(SAME ? validA : validB) * ld * (int64_t)sizeof(T)), 0x00020000);
+  const bool packed = ksa != nullptr;
+  const int extA = packed ? (int)(packed_elems * (int64_t)sizeof(T)) : (int)((int64_t)validA * ld * (int64_t)sizeof(T));
+  const int extB = packed ? extA : (int)((int64_t)(SAME ? validA : validB) * ld * (int64_t)sizeof(T));
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Arows), 0, extA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(SAME ? Arows : Brows), 0, extB, 0x00020000);
   unsigned voff[NP];
 #pragma unroll
   for (int u = 0; u < NP; ++u) voff[u] = (unsigned)(((lrow + RPP * u) * (int)ld + lc * C::VEC) * (int)sizeof(T));
@@ -651,14 +656,14 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   // fp32 one, one chunk ahead does not cover the load latency (factor -2.9 %).
   constexpr int AHEAD = C::KB * (int)sizeof(T) <= 128 ? 2 : 1;
   uint4 ra[AHEAD][NP], rb[AHEAD][NP];
-  auto gload = [&](uint4 (&xa)[NP], uint4 (&xb)[NP], int k0) __attribute__((always_inline)) {
-    const int so = k0 * (int)sizeof(T);
+  // (so.x / so.y: scalar byte offsets of the chunk inside the A / B operand buffers; the same unless the factor is tile-packed)
+  auto gload = [&](uint4 (&xa)[NP], uint4 (&xb)[NP], int2 so) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
-      const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], so, 0);
+      const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], so.x, 0);
       xa[u] = make_uint4(va.x, va.y, va.z, va.w);
       if (!SAME) {
-        const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff[u], so, 0);
+        const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff[u], so.y, 0);
         xb[u] = make_uint4(vb.x, vb.y, vb.z, vb.w);
       }
     }
@@ -671,16 +676,28 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   // could not prove the offset wave uniform.)
   typedef const int32_t __attribute__((address_space(4))) * klist_t;
   const klist_t kl = (klist_t)(uintptr_t)ktiles;
+  const klist_t ka = (klist_t)(uintptr_t)ksa, kb = (klist_t)(uintptr_t)ksb;
   auto kof = [&](int kc) __attribute__((always_inline)) -> int {
     const int k0 = kl ? kl[kc / CPT] * TILE + (kc % CPT) * C::KB : kc * C::KB;
     return __builtin_amdgcn_readfirstlane(k0);
+  };
+  // byte offsets of chunk kc in the two operand buffers
+  auto sof = [&](int kc) __attribute__((always_inline)) -> int2 {
+    if (!packed) {
+      const int so = kof(kc) * (int)sizeof(T);
+      return make_int2(so, so);
+    }
+    const int within = (kc % CPT) * C::KB;
+    const int a = (ka[kc / CPT] * TILE * TILE + within) * (int)sizeof(T);
+    const int bq = SAME ? a : (kb[kc / CPT] * TILE * TILE + within) * (int)sizeof(T);
+    return make_int2(__builtin_amdgcn_readfirstlane(a), __builtin_amdgcn_readfirstlane(bq));
   };
   T gsum = T(0);
   // one k-chunk: registers -> LDS, refill the registers with the chunk AHEAD steps on, MFMAs on the staged chunk
   // (a static s_setprio per hardware wave slot, to push the two co-resident workgroups out of lockstep, measured no gain)
   auto step = [&](uint4 (&xa)[NP], uint4 (&xb)[NP], int kc) __attribute__((always_inline)) {
     // column of the chunk to prefetch: the K-list entry is fetched here so that its (scalar) load completes under the staging
-    const int knext = kc + AHEAD < nk ? kof(kc + AHEAD) : 0;
+    const int2 knext = kc + AHEAD < nk ? sof(kc + AHEAD) : make_int2(0, 0);
 #ifdef THX_EXP_NOSTAGE  // timing experiment: no register -> LDS staging and only one barrier per chunk (garbage results)
     if (kc == 0) {
 #pragma unroll
@@ -737,7 +754,7 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   };
 #pragma unroll
   for (int a = 0; a < AHEAD; ++a)
-    if (a < nk) gload(ra[a], rb[a], kof(a));
+    if (a < nk) gload(ra[a], rb[a], sof(a));
   after_issue();
   for (int kc = 0; kc < nk; kc += AHEAD) {
     step(ra[0], rb[0], kc);
@@ -755,11 +772,12 @@ __device__ __forceinline__ void kloop(const T* __restrict__ Arows, int validA, c
                                       int validB, int64_t ld, int K, T* sA, T* sB,
                                       typename Engine<T>::Acc& acc, int tid, const T* gemv_y = nullptr,
                                       T* gemv_part = nullptr, Hook&& after_issue = NoHook{},
-                                      const int32_t* __restrict__ ktiles = nullptr) {
+                                      const int32_t* __restrict__ ktiles = nullptr, const int32_t* __restrict__ ksa = nullptr,
+                                      const int32_t* __restrict__ ksb = nullptr, int64_t packed_elems = 0) {
   const int wave = tid >> 6, lane = tid & 63;
   kloop_f<T, SAME, GEMV, CT<T>::LDT>(Arows, validA, Brows, validB, ld, K, sA, sB, tid, gemv_y, gemv_part, [&]() __attribute__((always_inline)) {
     Engine<T>::chunk(sA, (SAME ? sA : sB) + 32 * wave * CT<T>::LDT, acc, lane);
-  }, after_issue, ktiles);
+  }, after_issue, ktiles, ksa, ksb, packed_elems);
 }
 
 
@@ -1112,7 +1130,27 @@ struct TilePat {
   const int32_t* tile_k;     // ... block columns k < j in which L_ik and L_jk are both non-zero
   const int32_t* diag_kptr;  // (ntiles + 1) K-list of diagonal tile j ...
   const int32_t* diag_k;     // ... block columns k < j with L_jk non-zero
+  // TILE-PACKED factor (nslots > 0): L is (B, nslots, TILE, TILE) -- only the tiles of the pattern exist: slot j = diagonal tile
+  // j, slot ntiles + e = off-diagonal entry e -- and every K-list element carries the slots of its two operand tiles
+  const int32_t* tile_sa;    // (per tile_k element) slot of L_jk
+  const int32_t* tile_sb;    //                      slot of L_ik
+  const int32_t* diag_s;     // (per diag_k element) slot of L_jk
+  int32_t nslots;            // 0: L is the dense (B, ld, ld) frame
 };
+
+// where a kernel finds / puts the tiles of L: the dense frame (row stride ld) or the tile-packed buffer (row stride TILE)
+struct LFrame {
+  int64_t pstride;   // elements per problem
+  int64_t ld;        // row stride of a tile
+  bool packed;
+  __device__ __forceinline__ int64_t tile(int ti, int tj, int slot) const {   // element offset of tile (ti, tj) inside a problem
+    return packed ? (int64_t)slot * TILE * TILE : (int64_t)ti * TILE * ld + (int64_t)tj * TILE;
+  }
+};
+__device__ __forceinline__ LFrame lframe(const TilePat& pat, int64_t ld) {
+  const bool packed = pat.nslots > 0;
+  return LFrame{packed ? (int64_t)pat.nslots * TILE * TILE : ld * ld, packed ? (int64_t)TILE : ld, packed};
+}
 
 // Fused forward substitution through a finished panel column (sub-block column sb of the diagonal tile), on blocks in the
 // register layout of Engine::Blk:  y_s = W_ss u_s ;  u_u += (-L_us) y_s  for the sub-blocks below.  ONE implementation for both
@@ -1228,7 +1266,11 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   T* ybuf = ubuf + 32;
   const int b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t mat = (int64_t)b * ld * ld;
+  const LFrame lf = lframe(pat, ld);
+  const int64_t mat = (int64_t)b * ld * ld;            // H: always the dense frame (or the block list)
+  const int64_t lmat = (int64_t)b * lf.pstride;        // L: dense frame or tile-packed
+  const int64_t ldt = lf.ld;
+  T* const Ljj = L + lmat + lf.tile(j, j, j);          // the diagonal tile of L
   const int row0 = j * TILE;
   const int valid = min(TILE, n - row0);
 
@@ -1276,17 +1318,18 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   // tile-sparse: only the block columns k < j in which row panel j is non-zero
   const int32_t* klist = pat.diag_k ? pat.diag_k + pat.diag_kptr[j] : nullptr;
   const int Kspan = pat.diag_k ? (pat.diag_kptr[j + 1] - pat.diag_kptr[j]) * TILE : row0;
-  kloop_f<T, true, true, E::SYRK_LDT, (sizeof(T) == 8 && CT<T>::KB == 32)>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, Kspan, tile, nullptr, tid,
-                         fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
+  kloop_f<T, true, true, E::SYRK_LDT, (sizeof(T) == 8 && CT<T>::KB == 32)>(
+      L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld), valid, nullptr, 0, ldt, Kspan, tile, nullptr, tid,
+      fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
     if (wave == 0) E::template syrk36<0>(tile, acc, lane);
     else if (wave == 1) E::template syrk36<1>(tile, acc, lane);
     else if (wave == 2) E::template syrk36<2>(tile, acc, lane);
     else E::template syrk36<3>(tile, acc, lane);
   },
 #ifdef THX_OFF_PROLOGUE_FIRST
-  NoHook{}, klist);
+  NoHook{}, klist, lf.packed ? pat.diag_s + pat.diag_kptr[j] : nullptr, nullptr, lf.pstride);
 #else
-  prologue, klist);
+  prologue, klist, lf.packed ? pat.diag_s + pat.diag_kptr[j] : nullptr, nullptr, lf.pstride);
 #endif
 
   // ---- S = H_jj (+ damping on the diagonal) - acc -> LDS tile; identity padding outside the matrix ----
@@ -1329,8 +1372,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 #ifndef THX_POTRF_FLAT
     if (wave == sw) {
       THX_STAMP();
-      const int bad = potrf_inv32_blocked<T>(Dss, L + mat + (int64_t)(row0 + 32 * sb) * ld + row0 + 32 * sb, ld,
-                                             valid - 32 * sb, lane);
+      const int bad = potrf_inv32_blocked<T>(Dss, Ljj + (int64_t)(32 * sb) * ldt + 32 * sb, ldt, valid - 32 * sb, lane);
       if (bad != 0 && lane == 0 && info[b] == 0) info[b] = row0 + 32 * sb + bad;
       THX_STAMP();
     }
@@ -1356,7 +1398,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
       // L_ss straight to global memory: one 32-element row per lane, zeros above the diagonal
       const int lr = lane & 31, grow = 32 * sb + lr;
       if (lane < 32 && grow < valid) {
-        V* gp = reinterpret_cast<V*>(L + mat + (int64_t)(row0 + grow) * ld + row0 + 32 * sb);
+        V* gp = reinterpret_cast<V*>(Ljj + (int64_t)grow * ldt + 32 * sb);
 #pragma unroll
         for (int q = 0; q < 32 / C::VEC; ++q) {
           if constexpr (sizeof(T) == 4) {
@@ -1432,7 +1474,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   {  // (the panel's sub-blocks above the diagonal are never read -- chol_offdiag and the solves use the lower ten -- and
      //  are not written)
     constexpr int VPR = 32 / C::VEC;  // vectors per sub-block row
-    T* Lt = L + mat + (int64_t)row0 * ld + row0;
+    T* Lt = Ljj;
     T* P = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
     for (int u = 0; u < 4; ++u)
       for (int v = 0; v <= u; ++v) {
@@ -1443,7 +1485,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
           const V val = *reinterpret_cast<const V*>(blk + rr * C::LDB + c);
           *reinterpret_cast<V*>(P + (32 * u + rr) * TILE + 32 * v + c) = val;
           if (u > v && 32 * u + rr < valid) {
-            V* dst = reinterpret_cast<V*>(Lt + (int64_t)(32 * u + rr) * ld + 32 * v + c);
+            V* dst = reinterpret_cast<V*>(Lt + (int64_t)(32 * u + rr) * ldt + 32 * v + c);
             if constexpr (sizeof(T) == 4) *dst = make_float4(-val.x, -val.y, -val.z, -val.w);
             else *dst = make_double2(-val.x, -val.y);
           }
@@ -1506,7 +1548,10 @@ chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict
   T* ybuf = stage + E::SYRK_STAGE;                           // y_0:j of the earlier columns
   const int b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t mat = (int64_t)b * ld * ld;
+  const LFrame lf = lframe(pat, ld);
+  const int64_t mat = (int64_t)b * ld * ld;            // H (dense frame)
+  const int64_t lmat = (int64_t)b * lf.pstride;        // L (dense frame or tile-packed)
+  const int64_t ldt = lf.ld;
   const int row0 = j * TILE;
   const int valid = min(TILE, n - row0);
   const bool fwd = rhs != nullptr;
@@ -1538,23 +1583,24 @@ chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict
   };
   const int32_t* klist = pat.diag_k ? pat.diag_k + pat.diag_kptr[j] : nullptr;
   const int Kspan = pat.diag_k ? (pat.diag_kptr[j + 1] - pat.diag_kptr[j]) * TILE : row0;
-  kloop_f<T, true, true, E::SYRK_LDT, (sizeof(T) == 8 && CT<T>::KB == 32)>(L + mat + (int64_t)row0 * ld, valid, nullptr, 0, ld, Kspan, stage, nullptr, tid,
-                                      fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
+  kloop_f<T, true, true, E::SYRK_LDT, (sizeof(T) == 8 && CT<T>::KB == 32)>(
+      L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld), valid, nullptr, 0, ldt, Kspan, stage, nullptr, tid,
+      fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
     if (wave == 0) E::template syrk36<0>(stage, acc, lane);
     else if (wave == 1) E::template syrk36<1>(stage, acc, lane);
     else if (wave == 2) E::template syrk36<2>(stage, acc, lane);
     else E::template syrk36<3>(stage, acc, lane);
-  }, prologue, klist);
+  }, prologue, klist, lf.packed ? pat.diag_s + pat.diag_kptr[j] : nullptr, nullptr, lf.pstride);
 
   {
     const bool damp = damping != nullptr;
     const T lam = damp ? damping[b] : T(0);
-    T* Lt = L + mat + (int64_t)row0 * ld + row0;
+    T* Lt = L + lmat + lf.tile(j, j, j);
     const bool sd = damp && !HB;
-    if (wave == 0) E::template syrk36_store_global<0>(Lt, ld, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
-    else if (wave == 1) E::template syrk36_store_global<1>(Lt, ld, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
-    else if (wave == 2) E::template syrk36_store_global<2>(Lt, ld, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
-    else E::template syrk36_store_global<3>(Lt, ld, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
+    if (wave == 0) E::template syrk36_store_global<0>(Lt, ldt, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
+    else if (wave == 1) E::template syrk36_store_global<1>(Lt, ldt, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
+    else if (wave == 2) E::template syrk36_store_global<2>(Lt, ldt, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
+    else E::template syrk36_store_global<3>(Lt, ldt, hpre, acc, lane, valid, sd, lam, ellipsoidal, damping_eps);
     if constexpr (HB) {
       // block-compact H: the tile now holds -L_j L_j^T; its pieces of H (+ damping on the diagonal) are added in place.  The
       // stores above are this workgroup's own: visible to all its threads after the fence + barrier.
@@ -1563,7 +1609,7 @@ chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict
       hbp.foreach(hb, b, tid, [&](int r, int c, T v) __attribute__((always_inline)) {
         if (c > r || r >= valid) return;
         if (r == c && damp) v = ellipsoidal ? v + (lam * v + damping_eps) : v + lam;
-        Lt[(int64_t)r * ld + c] += v;
+        Lt[(int64_t)r * ldt + c] += v;
       });
     }
   }
@@ -1578,8 +1624,9 @@ __device__ __forceinline__ constexpr int bidx(int u, int v) { return u * (u + 1)
 
 template <typename T>
 __global__ void __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1)
-chol_potrf_kernel(T* __restrict__ L, T* __restrict__ panel, int32_t* __restrict__ info, int n, int64_t ld, int j, int ntiles,
-                  T* __restrict__ yout, int64_t ldv) {
+chol_potrf_kernel(T* __restrict__ L, T* __restrict__ panel, int32_t* __restrict__ info, int n, int64_t pstride, int64_t tile_off,
+                  int64_t ld, int j, int ntiles, T* __restrict__ yout, int64_t ldv) {
+  // (the diagonal tile of problem b starts at L + b * pstride + tile_off, row stride ld: dense frame or tile-packed factor)
   using C = CT<T>;
   using E = Engine<T>;
   using Blk = typename E::Blk;
@@ -1590,9 +1637,8 @@ chol_potrf_kernel(T* __restrict__ L, T* __restrict__ panel, int32_t* __restrict_
   constexpr int PARK = sizeof(T) == 4 ? 3 : 0;
   __shared__ __attribute__((aligned(16))) T park[PARK > 0 ? PARK * 32 * C::LDB : 4];
   const int b = blockIdx.x, lane = threadIdx.x;
-  const int64_t mat = (int64_t)b * ld * ld;
   const int row0 = j * TILE, valid = min(TILE, n - row0);
-  T* Lt = L + mat + (int64_t)row0 * ld + row0;
+  T* Lt = L + (int64_t)b * pstride + tile_off;
   const bool fwd = yout != nullptr;
 
   // the tile: S (written by chol_syrk_kernel) -> registers; identity outside the matrix
@@ -1714,7 +1760,13 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   const int Kspan = pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE;
   if (b >= B) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t mat = (int64_t)b * ld * ld;
+  const LFrame lf = lframe(pat, ld);
+  const int64_t mat = (int64_t)b * ld * ld;            // H (dense frame)
+  const int64_t lmat = (int64_t)b * lf.pstride;        // L (dense frame or tile-packed)
+  const int64_t ldt = lf.ld;
+  float* const Lij = L + lmat + lf.tile(i, j, ntiles + ent);   // the tile this workgroup produces
+  const int32_t* ksa = lf.packed ? pat.tile_sa + pat.tile_kptr[ent] : nullptr;
+  const int32_t* ksb = lf.packed ? pat.tile_sb + pat.tile_kptr[ent] : nullptr;
   const int col0 = j * TILE, row0 = i * TILE;
   const int validB = min(TILE, n - row0);  // j is never the last tile: all 128 columns are inside the matrix
   float* sA = smem;
@@ -1770,12 +1822,12 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
 #endif
   // (two LDS staging buffers with ONE barrier per k-chunk instead of one buffer with two -- panel copy moved behind the
   //  loop to keep 2 workgroups/CU -- measured the same 9.3-9.4 k cycles per chunk: the barriers are not the K-loop's limit)
+  const float* Ap = L + lmat + (lf.packed ? 0 : (int64_t)col0 * ld);   // rows of block row j (operand A) / i (operand B)
+  const float* Bp = L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld);
 #ifdef THX_OFF_PROLOGUE_FIRST
-  kloop<float, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, Kspan, sA, sB, P, tid,
-                      nullptr, nullptr, NoHook{}, klist);
+  kloop<float, false>(Ap, TILE, Bp, validB, ldt, Kspan, sA, sB, P, tid, nullptr, nullptr, NoHook{}, klist, ksa, ksb, lf.pstride);
 #else
-  kloop<float, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, Kspan, sA, sB, P, tid,
-                      nullptr, nullptr, prologue, klist);
+  kloop<float, false>(Ap, TILE, Bp, validB, ldt, Kspan, sA, sB, P, tid, nullptr, nullptr, prologue, klist, ksa, ksb, lf.pstride);
 #endif
 #ifdef THX_OFF_PROF
   __builtin_amdgcn_sched_barrier(0);
@@ -1852,7 +1904,7 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   __builtin_amdgcn_sched_barrier(0);
 #endif
   if (rvalid) {
-    float* Lrow = L + mat + (int64_t)(row0 + r) * ld + col0 + 4 * g;
+    float* Lrow = Lij + (int64_t)r * ldt + 4 * g;
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
@@ -1865,7 +1917,7 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   st[4] = (long long)__builtin_readcyclecounter();
   __syncthreads();
   if (tid == 0) {
-    float* o = L + mat + (int64_t)row0 * ld + col0;
+    float* o = Lij;
     for (int k = 1; k < 5; ++k) o[k] = (float)(st[k] - st[0]);
     o[5] = (float)((long long)wall_clock64() - wc0);  // 100 MHz ticks
   }
@@ -1926,7 +1978,13 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   if (b >= B) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int rl = lane & 15, kq = lane >> 4;
-  const int64_t mat = (int64_t)b * ld * ld;
+  const LFrame lf = lframe(pat, ld);
+  const int64_t mat = (int64_t)b * ld * ld;            // H (dense frame)
+  const int64_t lmat = (int64_t)b * lf.pstride;        // L (dense frame or tile-packed)
+  const int64_t ldt = lf.ld;
+  double* const Lij = L + lmat + lf.tile(i, j, ntiles + ent);
+  const int32_t* ksa = lf.packed ? pat.tile_sa + pat.tile_kptr[ent] : nullptr;
+  const int32_t* ksb = lf.packed ? pat.tile_sb + pat.tile_kptr[ent] : nullptr;
   const int col0 = j * TILE, row0 = i * TILE;
   const int validB = min(TILE, n - row0);
   double* sA = smem;
@@ -1936,8 +1994,8 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   E::zero(P);
   HBPre<double, HB ? HB_NPRE_OFF : 1> hbp;
   if constexpr (HB) hbp.load(hb, b, i, j, tid);
-  kloop<double, false>(L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, Kspan, sA, sB, P, tid,
-                       nullptr, nullptr, NoHook{}, klist);
+  kloop<double, false>(L + lmat + (lf.packed ? 0 : (int64_t)col0 * ld), TILE, L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld), validB,
+                       ldt, Kspan, sA, sB, P, tid, nullptr, nullptr, NoHook{}, klist, ksa, ksb, lf.pstride);
   if constexpr (HB) {
     // block-compact H: the tile's pieces through the (free) staging buffers, 32 rows -- one wave's -- at a time
     constexpr int LDH = 130;
@@ -2063,7 +2121,7 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   for (int h = 0; h < 2; ++h) {
     const int r = 32 * wave + 16 * h + rl;
     if (r < validB) {
-      double* Lrow = L + mat + (int64_t)(row0 + r) * ld + col0 + kq;
+      double* Lrow = Lij + (int64_t)r * ldt + kq;
 #pragma unroll
       for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
@@ -2102,6 +2160,8 @@ static size_t solve_smem(int npad) {
 struct RowPat {
   const int32_t* __restrict__ row_ptr;   // [ntiles + 1]
   const int32_t* __restrict__ row_tile;  // [row_ptr[ntiles]]
+  const int32_t* __restrict__ row_slot;  // tile-packed factor: the slot of every listed tile (else nullptr)
+  int32_t nslots;                        // tile-packed factor: slots per problem (else 0)
 };
 
 // L y = rhs (stand-alone; the LM iteration gets y from the factorisation).
@@ -2120,7 +2180,8 @@ chol_fwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* _
   T* tv = yv + npad;            // [128]
   T* ubuf = tv + 128;           // [32]
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const T* Lb = L + (int64_t)b * ld * ld;
+  const bool packed = LIST && rp.nslots > 0;
+  const T* Lb = L + (int64_t)b * (packed ? (int64_t)rp.nslots * TILE * TILE : ld * ld);
   const T* rb = rhs + (int64_t)b * ldv;
   T* yb = y + (int64_t)b * ldv;
   if constexpr (!LIST) {
@@ -2138,6 +2199,9 @@ chol_fwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* _
       T s[4] = {T(0), T(0), T(0), T(0)};
       for (int it = lane; it < items; it += 64) {
         const int k = LIST ? rp.row_tile[l0 + it / QPT] * TILE + (it % QPT) * C::VEC : it * C::VEC;
+        // the listed tile's rows: dense frame (row0 + r) * ld + k, or the packed tile's own 128 x 128 block
+        const T* Lt_ = packed ? Lb + (int64_t)rp.row_slot[l0 + it / QPT] * TILE * TILE + (it % QPT) * C::VEC : Lb + (int64_t)row0 * ld + k;
+        const int64_t lds_ = packed ? TILE : ld;
         V yk;
         if constexpr (LIST) {   // (scalar loads: a row of the vector need not be 16-byte aligned)
           if constexpr (sizeof(T) == 4) yk = V{yb[k], yb[k + 1], yb[k + 2], yb[k + 3]};
@@ -2149,7 +2213,7 @@ chol_fwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* _
         for (int u = 0; u < 4; ++u) {
           const int r = rr + 4 * u;
           if (r < valid) {
-            const V lv = *reinterpret_cast<const V*>(Lb + (int64_t)(row0 + r) * ld + k);
+            const V lv = *reinterpret_cast<const V*>(Lt_ + (int64_t)r * lds_);
             if constexpr (sizeof(T) == 4) s[u] += lv.x * yk.x + lv.y * yk.y + lv.z * yk.z + lv.w * yk.w;
             else s[u] += lv.x * yk.x + lv.y * yk.y;
           }
@@ -2196,7 +2260,8 @@ chol_bwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* _
   T* xb = z + npad;            // [128] current block
   T* ubuf = xb + 128;          // [32]
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const T* Lb = L + (int64_t)b * ld * ld;
+  const bool packed = LIST && rp.nslots > 0;
+  const T* Lb = L + (int64_t)b * (packed ? (int64_t)rp.nslots * TILE * TILE : ld * ld);
   T* zg = x + (int64_t)b * ldv;   // LIST: the working vector IS the output (global, L2 resident)
   if constexpr (LIST) {
     if (yin != x)
@@ -2227,12 +2292,13 @@ chol_bwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* _
     for (int it = tid; it < items; it += 256) {
       const int k = LIST ? rp.row_tile[l0 + it / QPT] * TILE + (it % QPT) * C::VEC : it * C::VEC;
       T s[4] = {T(0), T(0), T(0), T(0)};
-      const T* Lk = Lb + (int64_t)row0 * ld + k;
+      const T* Lk = packed ? Lb + (int64_t)rp.row_slot[l0 + it / QPT] * TILE * TILE + (it % QPT) * C::VEC : Lb + (int64_t)row0 * ld + k;
+      const int64_t lds_ = packed ? (int64_t)TILE : ld;   // (row stride of the listed tile)
       int rr = 0;
       for (; rr + 8 <= valid; rr += 8) {
         V lv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) lv[u] = *reinterpret_cast<const V*>(Lk + (int64_t)(rr + u) * ld);
+        for (int u = 0; u < 8; ++u) lv[u] = *reinterpret_cast<const V*>(Lk + (int64_t)(rr + u) * lds_);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const T xv = xb[rr + u];
@@ -2244,7 +2310,7 @@ chol_bwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* _
         }
       }
       for (; rr < valid; ++rr) {
-        const V lv = *reinterpret_cast<const V*>(Lk + (int64_t)rr * ld);
+        const V lv = *reinterpret_cast<const V*>(Lk + (int64_t)rr * lds_);
         const T xv = xb[rr];
         if constexpr (sizeof(T) == 4) {
           s[0] += lv.x * xv; s[1] += lv.y * xv; s[2] += lv.z * xv; s[3] += lv.w * xv;
@@ -2333,11 +2399,21 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   const bool use_hb = hbp != nullptr;
   const HBlk hb = use_hb ? *hbp : HBlk{nullptr, 0, 0, nullptr, nullptr, nullptr};
   const int ntiles = (n + TILE - 1) / TILE;
-  TilePat pat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  TilePat pat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  // ld == 0: L is the TILE-PACKED factor (B, nslots, TILE, TILE) of the pattern
+  const bool packed = ld == 0;
+  if (packed && (!tp || tp->nslots <= 0 || !tp->tile_sa || !tp->tile_sb || !tp->diag_s))
+    return fail("thx_chol_factor: a tile-packed factor (ld = 0) needs a tile pattern with slot tables");
   if (tp) {
     if (tp->ntiles != ntiles) return fail("thx_chol_factor_sparse: the tile pattern was built for another matrix order");
-    pat = TilePat{tp->col_ptr, tp->col_row, tp->tile_kptr, tp->tile_k, tp->diag_kptr, tp->diag_k};
+    pat = TilePat{tp->col_ptr, tp->col_row, tp->tile_kptr, tp->tile_k, tp->diag_kptr, tp->diag_k,
+                  packed ? tp->tile_sa : nullptr, packed ? tp->tile_sb : nullptr, packed ? tp->diag_s : nullptr,
+                  packed ? tp->nslots : 0};
   }
+  const int64_t hstride = (int64_t)ld * ld;                                            // H frame (dense H only; never packed)
+  const int64_t lstride = packed ? (int64_t)tp->nslots * TILE * TILE : (int64_t)ld * ld;   // elements of L per problem
+  if (packed && lstride * (int64_t)sizeof(T) > 0x7fffffffLL)
+    return fail("thx_chol_factor: tile-packed factor larger than 2 GB per problem");
   // diagonal phase: chol_syrk_kernel + chol_potrf_kernel from g_split_diag_min problems per call on (measured, n = 1536: fp32
   // 45.1 vs 46.0 ms at batch 4096, fp64 101.6 vs 105.2 ms; equal at batch 1024; 3.74 vs 3.51 ms at batch 256 -- the second
   // launch per column costs more than the chain there), else the fused chol_diag_kernel
@@ -2419,8 +2495,8 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   };
   auto launch_off = [&](const Half& h, int j, int i_first, int nrt) {
     const int Bpad = (h.nb + 7) / 8 * 8;
-    const int64_t mo = (int64_t)h.b0 * ld * ld, po = (int64_t)h.b0 * ntiles * TILE * TILE;
-    const T* Hh = use_hb ? nullptr : (const T*)H + mo;
+    const int64_t mo = (int64_t)h.b0 * lstride, po = (int64_t)h.b0 * ntiles * TILE * TILE;
+    const T* Hh = use_hb ? nullptr : (const T*)H + (int64_t)h.b0 * hstride;
     if constexpr (sizeof(T) == 4) {
       if (use_hb)
         hipLaunchKernelGGL(chol_offdiag_f32_kernel<true>, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, h.s, Hh, (float*)L + mo,
@@ -2438,11 +2514,11 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     }
   };
   auto launch_diag = [&](const Half& h, int j) {
-    const int64_t mo = (int64_t)h.b0 * ld * ld, po = (int64_t)h.b0 * ntiles * TILE * TILE;
+    const int64_t mo = (int64_t)h.b0 * lstride, po = (int64_t)h.b0 * ntiles * TILE * TILE;
     const T* rh = rhs ? (const T*)rhs + (int64_t)h.b0 * ldv : nullptr;
     T* yh = y ? (T*)y + (int64_t)h.b0 * ldv : nullptr;
     const T* dh = damping ? (const T*)damping + h.b0 : nullptr;
-    const T* Hh = use_hb ? nullptr : (const T*)H + mo;
+    const T* Hh = use_hb ? nullptr : (const T*)H + (int64_t)h.b0 * hstride;
     if (fused_diag) {
       if (use_hb)
         hipLaunchKernelGGL((chol_diag_kernel<T, true>), dim3(h.nb), dim3(256), dsm, h.s, Hh, (T*)L + mo, (T*)panel + po,
@@ -2457,8 +2533,9 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       else
         hipLaunchKernelGGL((chol_syrk_kernel<T, false>), dim3(h.nb), dim3(256), dsm, h.s, Hh, (T*)L + mo, dh, ellipsoidal,
                            (T)eps, n, ld, j, rh, yh, ldv, pat, hb_of(h));
-      hipLaunchKernelGGL(chol_potrf_kernel<T>, dim3(h.nb), dim3(64), 0, h.s, (T*)L + mo, (T*)panel + po, info + h.b0, n, ld, j,
-                         ntiles, rh ? yh : nullptr, ldv);
+      const int64_t tile_off = packed ? (int64_t)j * TILE * TILE : (int64_t)j * TILE * ld + (int64_t)j * TILE;
+      hipLaunchKernelGGL(chol_potrf_kernel<T>, dim3(h.nb), dim3(64), 0, h.s, (T*)L + mo, (T*)panel + po, info + h.b0, n, lstride,
+                         tile_off, packed ? (int64_t)TILE : ld, j, ntiles, rh ? yh : nullptr, ldv);
     }
   };
   for (int j = 0; j < ntiles; ++j) {
@@ -2503,7 +2580,10 @@ static int solve_impl(const void* L, int64_t ld, int n, int B, const void* panel
       attr = sm;
     }
   }
-  const RowPat rp{list ? tp->row_ptr : nullptr, list ? tp->row_tile : nullptr};
+  const bool packed = ld == 0;
+  if (packed && (!list || !tp->row_slot || tp->nslots <= 0))
+    return fail("thx_chol_solve: a tile-packed factor (ld = 0) needs thx_chol_solve_sparse and a pattern with slot tables");
+  const RowPat rp{list ? tp->row_ptr : nullptr, list ? tp->row_tile : nullptr, packed ? tp->row_slot : nullptr, packed ? tp->nslots : 0};
   const T* src = (const T*)rhs;
   if (forward) {
     if (list)
@@ -2534,7 +2614,8 @@ extern "C" {
 static int check_factor_args(const void* H, const void* L, const void* panel, const void* info, int n, int B,
                              int64_t ld) {
   if (!H || !L || !panel || !info) return fail("thx_chol_factor: null pointer");
-  if (n <= 0 || B <= 0 || ld < n || (ld % 32) != 0) return fail("thx_chol_factor: need n>0, B>0, ld>=n, ld%32==0");
+  if (n <= 0 || B <= 0 || (ld != 0 && (ld < n || (ld % 32) != 0)))
+    return fail("thx_chol_factor: need n>0, B>0, ld>=n, ld%32==0 (ld = 0: tile-packed factor)");
   return 0;
 }
 
@@ -2567,6 +2648,7 @@ int thx_chol_factor_sparse(const void* H, int64_t ld, int32_t n, int32_t B, cons
                            double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y, int64_t ldv,
                            const thx_tile_pattern* pattern, int dtype, void* stream) {
   if (int r = check_factor_args(H, L, Winv, info, n, B, ld)) return r;
+  if (ld == 0) return fail("thx_chol_factor_sparse: H is a dense frame here (ld >= n); the tile-packed factor goes with thx_chol_factor_hblocks");
   if (!pattern || !pattern->col_ptr || !pattern->col_row || !pattern->tile_kptr || !pattern->tile_k || !pattern->diag_kptr ||
       !pattern->diag_k || !pattern->col_count_host)
     return fail("thx_chol_factor_sparse: incomplete tile pattern");
@@ -2583,7 +2665,7 @@ int thx_chol_factor_sparse(const void* H, int64_t ld, int32_t n, int32_t B, cons
 static int solve_dispatch(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs, void* x,
                           int64_t ldv, bool fwd, bool bwd, int dtype, void* stream, const thx_tile_pattern* tp = nullptr) {
   if (!L || !Winv || !rhs || !x) return fail("thx_chol_solve: null pointer");
-  if (n <= 0 || B <= 0 || ld < n || ldv < n) return fail("thx_chol_solve: bad sizes");
+  if (n <= 0 || B <= 0 || (ld != 0 && ld < n) || ldv < n) return fail("thx_chol_solve: bad sizes");
   THX_DISPATCH(dtype, return solve_impl<float>(L, ld, n, B, Winv, rhs, x, ldv, fwd, bwd, as_stream(stream), tp),
                return solve_impl<double>(L, ld, n, B, Winv, rhs, x, ldv, fwd, bwd, as_stream(stream), tp));
   return 0;

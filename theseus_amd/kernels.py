@@ -374,8 +374,9 @@ class HipKernels:
                                              _lib.dtype_code(Hc.dtype), _lib.stream_ptr(Hc.device)), "thx_hblocks_diag")
 
     def chol_factor_hblocks(self, hb, Hc, n, damping, ellipsoidal, damping_eps, L, panels, info, pattern=None, rhs=None, y=None):
-        """thx_chol_factor_forward / thx_chol_factor_sparse (``pattern``) with H read from the block list."""
-        B, ld = L.shape[0], L.shape[-1]
+        """thx_chol_factor_forward / thx_chol_factor_sparse (``pattern``) with H read from the block list.  ``L`` (B, ld, ld): the
+        dense frame; (B, nslots, 128, 128): the TILE-PACKED factor of ``pattern`` (ld = 0 in the C ABI)."""
+        B, ld = L.shape[0], (0 if L.dim() == 4 else L.shape[-1])
         _lib.check(self.lib.thx_chol_factor_hblocks(
             hb.c, _lib.ptr(Hc), Hc.stride(0), n, B, _lib.ptr(damping), int(bool(ellipsoidal)), float(damping_eps), _lib.ptr(L), ld,
             _lib.ptr(panels), _lib.ptr(info), _lib.ptr(rhs), _lib.ptr(y), rhs.stride(0) if rhs is not None else n,
@@ -617,8 +618,8 @@ class HipKernels:
 
     def chol_solve_sparse(self, L, n, panels, rhs, x, pattern, backward_only=False):
         """thx_chol_solve_sparse: the triangular solves over the structurally non-zero tiles of L only (``pattern``: a
-        theseus_amd.sparse.TilePattern); ``backward_only``: x = L^-T rhs."""
-        B, ld = L.shape[0], L.shape[-1]
+        theseus_amd.sparse.TilePattern); ``backward_only``: x = L^-T rhs.  ``L`` may be the tile-packed factor (4-D)."""
+        B, ld = L.shape[0], (0 if L.dim() == 4 else L.shape[-1])
         _lib.check(self.lib.thx_chol_solve_sparse(_lib.ptr(L), ld, n, B, _lib.ptr(panels), _lib.ptr(rhs), _lib.ptr(x),
                                                   rhs.stride(0), int(bool(backward_only)), pattern.c_struct(L.device),
                                                   _lib.dtype_code(L.dtype), _lib.stream_ptr(L.device)), "thx_chol_solve_sparse")

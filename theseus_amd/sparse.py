@@ -74,6 +74,7 @@ class TilePattern:
                 lp[np.ix_(rows, rows)] |= np.tril(np.ones((rows.size, rows.size), dtype=bool))
         self.n, self.ntiles, self.lower = n, nt, lp
         col_ptr, col_row, tile_kptr, tile_k, diag_kptr, diag_k = [0], [], [0], [], [0], []
+        tile_ij = []     # (i, j) of every element of tile_k, for the slot tables of the tile-packed factor
         for j in range(nt):
             dk = np.nonzero(lp[j, :j])[0]
             diag_k += dk.tolist()
@@ -85,6 +86,7 @@ class TilePattern:
             for i in sorted(rows, key=lambda r: (-len(klists[r]), r)):
                 col_row.append(i)
                 tile_k += klists[i]
+                tile_ij += [(i, j)] * len(klists[i])
                 tile_kptr.append(len(tile_k))
             col_ptr.append(len(col_row))
         row_ptr, row_tile = [0], []     # the same pattern by rows (list-driven triangular solves)
@@ -92,8 +94,20 @@ class TilePattern:
             row_tile += np.nonzero(lp[i, :i])[0].tolist()
             row_ptr.append(len(row_tile))
         i32 = lambda a: np.asarray(a if len(a) else [0], dtype=np.int32)  # noqa: E731
+        # tile-packed factor: slot j = diagonal tile j, slot nt + e = off-diagonal entry e = tile (col_row[e], column of e)
+        slot = {(j, j): j for j in range(nt)}
+        for j in range(nt):
+            for e in range(col_ptr[j], col_ptr[j + 1]):
+                slot[(col_row[e], j)] = nt + e
+        self.nslots = nt + len(col_row)
+        self.slot = slot
+        tile_sa = [slot[(j, k)] for (i, j), k in zip(tile_ij, tile_k)]
+        tile_sb = [slot[(i, k)] for (i, j), k in zip(tile_ij, tile_k)]
+        diag_s = [slot[(j, k)] for j in range(nt) for k in diag_k[diag_kptr[j]:diag_kptr[j + 1]]]
+        row_slot = [slot[(i, k)] for i in range(nt) for k in row_tile[row_ptr[i]:row_ptr[i + 1]]]
         self.tables = dict(col_ptr=i32(col_ptr), col_row=i32(col_row), tile_kptr=i32(tile_kptr), tile_k=i32(tile_k),
-                           diag_kptr=i32(diag_kptr), diag_k=i32(diag_k), row_ptr=i32(row_ptr), row_tile=i32(row_tile))
+                           diag_kptr=i32(diag_kptr), diag_k=i32(diag_k), row_ptr=i32(row_ptr), row_tile=i32(row_tile),
+                           tile_sa=i32(tile_sa), tile_sb=i32(tile_sb), diag_s=i32(diag_s), row_slot=i32(row_slot))
         self.col_count = np.ascontiguousarray(np.diff(np.asarray(col_ptr, dtype=np.int64)).astype(np.int32))
         self.l_tiles = int(lp.sum())
         # tile products the numeric factorisation executes (K-loop tiles + one TRSM / POTRF per tile) vs the dense count
@@ -113,6 +127,7 @@ class TilePattern:
             t = {k: torch.from_numpy(v).to(device) for k, v in self.tables.items()}
             c = _lib.TilePattern()
             c.ntiles = self.ntiles
+            c.nslots = self.nslots
             for k, v in t.items():
                 setattr(c, k, v.data_ptr())
             c.col_count_host = self.col_count.ctypes.data
@@ -128,10 +143,43 @@ def tile_pattern(structure, dof: int) -> TilePattern:
 class HipSparseCholeskyCore(HipCholeskyCore):
     """HipCholeskyCore whose factorisation follows the tile pattern of its linearization."""
 
-    def _sparse_init(self):
+    def _sparse_init(self, packed_factor: Optional[bool] = None):
         self._core_init()
         lin = self.linearization
         self.pattern = tile_pattern(lin.packed.structure, lin.packed.dof)
+        # TILE-PACKED factor: L holds only the tiles of the pattern, (B, nslots, 128, 128), instead of a dense (B, ld, ld) frame
+        # (n = 12288, chain graph: 12 MB instead of 604 MB per problem in fp32 -- the batch sizes of the reference's sweep fit).
+        # Goes with the block-compact Hessian (thx_chol_factor_hblocks: neither H nor L is a dense frame then).
+        compact = bool(getattr(lin, "_compact", False))
+        if packed_factor and not compact:
+            raise RuntimeError("packed_factor=True needs the block-compact Hessian (SE3 pose graphs on the HIP kernels)")
+        self.packed_factor = compact if packed_factor is None else bool(packed_factor)
+
+    def _ensure_buffers(self):
+        if not self.packed_factor:
+            return HipCholeskyCore._ensure_buffers(self)
+        lin = self.linearization
+        g = lin.g
+        shape = (g.shape[0], self.pattern.nslots, TILE, TILE)
+        if self.L is None or tuple(self.L.shape) != shape or self.L.device != g.device or self.L.dtype != g.dtype:
+            B = g.shape[0]
+            self.L = torch.zeros(shape, dtype=g.dtype, device=g.device)   # (rows of a tile beyond the matrix stay zero: never written)
+            self.panels = torch.empty(B, self.pattern.ntiles, TILE, TILE, dtype=g.dtype, device=g.device)
+            self._y = torch.empty(B, lin.n, dtype=g.dtype, device=g.device)
+            self.info = torch.zeros(B, dtype=torch.int32, device=g.device)
+            self._lam = torch.empty(B, dtype=g.dtype, device=g.device)
+
+    def dense_factor(self) -> torch.Tensor:
+        """The factor as a dense (B, ld, ld) lower-triangular frame (tests / inspection; the solver never builds it)."""
+        if not self.packed_factor:
+            return self.L
+        lin = self.linearization
+        ld = lin.ld
+        out = torch.zeros(self.L.shape[0], ld, ld, dtype=self.L.dtype, device=self.L.device)
+        for (i, j), slot in self.pattern.slot.items():
+            r1, c1 = min(TILE * (i + 1), ld), min(TILE * (j + 1), ld)
+            out[:, TILE * i:r1, TILE * j:c1] = self.L[:, slot, :r1 - TILE * i, :c1 - TILE * j]
+        return out
 
     def factorize(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
                   damping_eps: float = 1e-8, rhs: Optional[torch.Tensor] = None):
@@ -160,7 +208,8 @@ class HipSparseCholeskySolver(HipSparseCholeskyCore, LinearSolver):
     variable ordering (pass ``linearization_kwargs=dict(ordering=...)`` to impose another one)."""
 
     def __init__(self, objective: Objective, linearization_cls: Optional[Type[Linearization]] = None,
-                 linearization_kwargs: Optional[Dict[str, Any]] = None, check_singular: bool = False, **kwargs):
+                 linearization_kwargs: Optional[Dict[str, Any]] = None, check_singular: bool = False,
+                 packed_factor: Optional[bool] = None, **kwargs):
         linearization_cls = linearization_cls or HipLinearization
         if not (isinstance(linearization_cls, type) and issubclass(linearization_cls, HipLinearization)):
             raise RuntimeError(f"HipSparseCholeskySolver only works with theseus_amd.HipLinearization, but {linearization_cls} "
@@ -170,7 +219,7 @@ class HipSparseCholeskySolver(HipSparseCholeskyCore, LinearSolver):
             linearization_kwargs["ordering"] = fill_reducing_ordering(objective)
         LinearSolver.__init__(self, objective, linearization_cls, linearization_kwargs)
         self._check_singular = check_singular
-        self._sparse_init()
+        self._sparse_init(packed_factor)
 
     def solve(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
               damping_eps: float = 1e-8, check_info: bool = True, **kwargs) -> torch.Tensor:
