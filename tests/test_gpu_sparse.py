@@ -218,3 +218,24 @@ def test_tile_packed_factor_runs_a_4096_pose_graph_at_the_reference_sweeps_batch
     assert int(solver.info.abs().sum()) == 0
     assert info.err_history[:, -1].mean() < 0.05 * info.err_history[:, 0].mean()
     assert peak < 60.0
+
+
+def test_fp64_beyond_the_fused_forward_substitution_limit():
+    """1700 SE3 poses in fp64: n = 10200 -- more than the fused forward substitution can keep in LDS next to the diagonal tile
+    (~9 k in fp64).  The solver then factorises without it and runs both list-driven triangular solves: the run converges and
+    the last linear system is solved to rounding."""
+    import theseus_amd as th
+    P, B, dtype = 1700, 3, torch.float64
+    opt = _chain_problem(th, P, B, dtype)()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # (a refused factorisation would surface as the loop's RuntimeWarning)
+        sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(damping=1e-2, track_err_history=True))
+    solver, lin = opt.linear_solver, opt.linear_solver.linearization
+    assert solver._unfused_forward and torch.isfinite(info.err_history).all()
+    assert info.err_history[:, -1].mean() < 0.05 * info.err_history[:, 0].mean()
+    lin.linearize()
+    delta = solver.solve(damping=1e-2, ellipsoidal_damping=False)
+    Hf = lin.AtA + 1e-2 * torch.eye(lin.n, dtype=dtype, device="cuda")
+    r = (Hf @ delta.unsqueeze(2)).squeeze(2) - lin.Atb.squeeze(2)
+    assert (r.abs().max() / lin.Atb.abs().max()).item() < 1e-10

@@ -124,9 +124,25 @@ class HipCholeskyCore:
     def _solve(self, damping, ellipsoidal_damping, damping_eps, check_info) -> torch.Tensor:
         if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
             raise ValueError("Damping must be a float or a 1-D tensor.")
-        y = self.factorize(damping, ellipsoidal_damping, damping_eps, rhs=self.linearization.g)
-        delta = torch.empty_like(y)
-        self._substitute(y, delta, backward_only=True)
+        g = self.linearization.g
+        y = None
+        if not getattr(self, "_unfused_forward", False):
+            try:
+                y = self.factorize(damping, ellipsoidal_damping, damping_eps, rhs=g)
+            except RuntimeError as e:
+                # the fused forward substitution keeps y_0:j in LDS next to the diagonal tile: n <= ~28 k in fp32, ~9 k in fp64
+                # (fused diagonal kernel; ~18 k with the split one).  Beyond that: factorise without it and run both triangular
+                # solves afterwards (the list-driven solves of the tile-sparse solver have no size limit).  The C side refuses
+                # before launching anything, so nothing has to be undone.
+                if "fused forward substitution" not in str(e):
+                    raise
+                self._unfused_forward = True
+        delta = torch.empty_like(g)
+        if y is not None:
+            self._substitute(y, delta, backward_only=True)
+        else:
+            self.factorize(damping, ellipsoidal_damping, damping_eps, rhs=None)
+            self._substitute(g, delta, backward_only=False)
         if getattr(self, "_check_singular", False):
             # dense_solver.py:91-103: items whose UNDAMPED AtA hits a zero LU pivot are dropped (zero step, no failure).  Here:
             # a zero on diag(AtA) (an all-zero column of A), and -- for an undamped solve -- any item whose Cholesky
