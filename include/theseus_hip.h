@@ -75,20 +75,27 @@ typedef struct {
   int64_t prior_target_bstride;
   const void* w_prior;       /* (K, Bw, 6)                                              */
   int64_t w_prior_bstride;
-  /* RobustCostFunction wrappers (theseus/core/robust_cost_function.py:52-135, flatten_dims = False): one loss kind per
-   * cost role (THX_LOSS_*), log_loss_radius per cost.  kind THX_LOSS_NONE: the pointer is not read. */
+  /* RobustCostFunction wrappers (theseus/core/robust_cost_function.py:52-135): a LOSS CODE = THX_LOSS_{NONE,WELSCH,HUBER},
+   * | THX_LOSS_FLATTEN for flatten_dims = True (every residual row its own robust term, :89-96,118-133), and
+   * log_loss_radius per cost.  robust_<role> is the code of every cost of the role; when the costs of a role differ
+   * (some plain, some Welsch, some Huber, some flattened) robust_<role> is any non-zero code and loss_<role> holds one code
+   * per cost.  Code THX_LOSS_NONE: the cost's log_radius entry is not read (role code NONE and no table: the pointer is
+   * not read). */
   int32_t robust_between;
   const void* log_radius_between;    /* (E, Br, 1), Br in {1, B} */
   int64_t log_radius_between_bstride; /* 1 or 0 */
   int32_t robust_prior;
   const void* log_radius_prior;      /* (K, Br, 1) */
   int64_t log_radius_prior_bstride;
+  const int32_t* loss_between;       /* (E) loss code per Between cost, or NULL: robust_between for all */
+  const int32_t* loss_prior;         /* (K) */
 } thx_pg_data;
 
-/* theseus/core/robust_loss.py:33-52 */
+/* theseus/core/robust_loss.py:33-52; THX_LOSS_FLATTEN: RobustCostFunction(flatten_dims=True) */
 #define THX_LOSS_NONE 0
 #define THX_LOSS_WELSCH 1
 #define THX_LOSS_HUBER 2
+#define THX_LOSS_FLATTEN 4
 
 const char* thx_last_error(void);
 int thx_abi_version(void);
@@ -407,7 +414,7 @@ typedef struct {
   const void* k1;
   const void* k2;
   int64_t calib_bstride;  /* 1 or 0 (shared by the three) */
-  int32_t robust_obs;  /* THX_LOSS_* on the Reprojection costs */
+  int32_t robust_obs;  /* loss code (THX_LOSS_* [| THX_LOSS_FLATTEN]) of the Reprojection costs */
   const void* log_radius_obs;  /* (O, Br, 1) */
   int64_t log_radius_obs_bstride;
   const void* cam_prior_target;  /* (Kc, Bt, 3, 4) */

@@ -227,7 +227,7 @@ def gen_pg_full(th, lieF, only=None):
         d = full_size_data(lieF, B, seed, dtype)
         edges = d["edges"]
         obj, poses = build_reference_objective(th, d, dtype)
-        opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, abs_err_tolerance=0.0,
+        opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=not flatten, abs_err_tolerance=0.0,
                                     rel_err_tolerance=0.0, max_iterations=ITERS, step_size=1.0)
         taps = dict(Atb=[], delta=[], err=[])
 
@@ -507,6 +507,92 @@ def gen_pg_full_implicit(th, lieF):
     print("pg_full_f64_implicit loss", loss.item(), "gauge-free loss", loss_rel.item(), "|grad_rel_meas|", meas.grad.abs().max().item(),
           "|grad_rel_wb|", wb.grad.abs().max().item(), "|grad_rel_tgt|", tgt.grad.abs().max().item(),
           "|grad_rel_wp|", wp.grad.abs().max().item())
+
+
+MIXED_LOSSES = (None, "welsch", "huber", "welsch+flatten", "huber+flatten")
+
+
+def gen_pg_mixed_robust(th, lieF):
+    """Plain, Welsch, Huber and flatten_dims=True costs MIXED inside one objective (theseus/core/robust_cost_function.py:52-135):
+    Between cost k wears MIXED_LOSSES[k % 5], the first prior is a flattened Welsch cost, the second is plain; one
+    log_loss_radius Variable per robust cost (some batched -- the reference's flatten_dims path itself only broadcasts a
+    batch-1 radius, and only un-vectorized: its vectorizer stacks the radii to (N B, 1) against (N B dim, 1) squared errors),
+    radii spread around the initial squared errors so that inliers, the knee and outliers all occur.  Recorded: the first linearization, the error metric, a damped LM run, and the gradients of
+    TheseusLayer(backward_mode="implicit") w.r.t. measurements, weights, prior targets and every log_loss_radius."""
+    dtype = torch.float64
+    for name, G, iters in (("pg_f64_mixed_robust", "SE3", 6), ("pg2_f64_mixed_robust", "SE2", 6)):
+        if G == "SE3":
+            d = make_problem(dtype=dtype, th=th, lieF=lieF, P=8, E=15, B=3, seed=41, batched_weights=True, pose_noise=(0.3, 0.25))
+            grp = th.SE3
+        else:   # the SE2 graph of pg2_f64_lm_adaptive (gen_se2 must have run)
+            g = np.load(os.path.join(OUT, "pg2_f64_lm_adaptive.npz"))
+            d = dict(P=int(g["P"]), edges=torch.from_numpy(g["edges"]), meas=torch.from_numpy(g["meas"]),
+                     w_between=torch.from_numpy(g["w_between"]), prior_idx=torch.from_numpy(g["prior_idx"]),
+                     prior_target=torch.from_numpy(g["prior_target"]), w_prior=torch.from_numpy(g["w_prior"]),
+                     poses=torch.from_numpy(g["poses0"]))
+            grp = th.SE2
+        B, P, E, Kp = d["poses"].shape[0], d["P"], d["edges"].shape[0], d["prior_idx"].shape[0]
+        dof = 6 if G == "SE3" else 3
+        gen = torch.Generator().manual_seed(7)
+        meas = d["meas"].clone().requires_grad_(True)
+        wb = d["w_between"].clone().requires_grad_(True)
+        tgt = d["prior_target"].clone().requires_grad_(True)
+        wp = d["w_prior"][:, :, :1].clone().requires_grad_(True)
+        loss_b = [MIXED_LOSSES[k % 5] for k in range(E)]
+        loss_p = ["welsch+flatten"] + [None] * (Kp - 1)
+        # radii: log of (typical squared weighted error) * lognormal spread; batched for odd k
+        lr_b = (torch.full((B, E, 1), 4.0, dtype=dtype) + 2.0 * torch.randn(B, E, 1, dtype=dtype, generator=gen))
+        shared_b = [k % 2 == 0 or (loss_b[k] or "").endswith("+flatten") for k in range(E)]   # radius stored (1, 1)
+        lr_b[:, shared_b] = lr_b[:1, shared_b]
+        lr_p = (torch.full((1, Kp, 1), -6.0, dtype=dtype) + torch.randn(1, Kp, 1, dtype=dtype, generator=gen)).repeat(B, 1, 1)
+        lr_b, lr_p = lr_b.requires_grad_(True), lr_p.requires_grad_(True)
+        LOSS = {"welsch": th.WelschLoss, "huber": th.HuberLoss}
+
+        def wrap(cf, spec, radius, nm):
+            if spec is None:
+                return cf
+            return th.RobustCostFunction(cf, LOSS[spec.split("+")[0]], th.Variable(radius, name="log_radius_" + nm),
+                                         flatten_dims=spec.endswith("+flatten"), name="robust_" + nm)
+
+        obj = th.Objective(dtype=dtype)
+        poses = [grp(tensor=d["poses"][:, k].clone(), name=f"pose_{k}") for k in range(P)]
+        for k in range(E):
+            i, j = d["edges"][k].tolist()
+            cw = th.DiagonalCostWeight(th.Variable(wb[:, k], name=f"w_{k}"))
+            cf = th.Between(poses[i], poses[j], grp(tensor=meas[:, k], name=f"meas_{k}"), cw, name=f"between_{k}")
+            obj.add(wrap(cf, loss_b[k], lr_b[:1, k] if shared_b[k] else lr_b[:, k], f"between_{k}"))
+        for k in range(Kp):
+            sw = th.ScaleCostWeight(th.Variable(wp[:, k], name=f"pw_{k}"))
+            cf = th.Difference(poses[int(d["prior_idx"][k])], grp(tensor=tgt[:, k], name=f"prior_target_{k}"), sw, name=f"prior_{k}")
+            obj.add(wrap(cf, loss_p[k], lr_p[:1, k], f"prior_{k}"))
+        opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=False, max_iterations=iters,
+                                    step_size=1.0, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+        with torch.no_grad():
+            obj.update()
+            lin = opt.linear_solver.linearization
+            lin.linearize()
+            A0, b0 = lin.A.clone().numpy(), lin.b.clone().numpy()
+            err0 = obj.error_metric().clone().numpy()
+            errvec0 = obj.error().clone().numpy()
+        layer = th.TheseusLayer(opt, vectorize=False)
+        sol, info = layer.forward(optimizer_kwargs=dict(backward_mode="implicit", damping=1e-2, track_err_history=True))
+        coef = torch.randn(B, P, *d["poses"].shape[2:], dtype=dtype, generator=torch.Generator().manual_seed(5))
+        final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
+        loss = (coef * final).sum()
+        loss.backward()
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"),
+            group=np.array(G), P=P, edges=d["edges"].numpy(), meas=d["meas"].numpy(), w_between=d["w_between"].numpy(),
+            prior_idx=d["prior_idx"].numpy(), prior_target=d["prior_target"].numpy(), w_prior=d["w_prior"].numpy(),
+            poses0=d["poses"].numpy(), loss_between=np.array([x or "" for x in loss_b]), loss_prior=np.array([x or "" for x in loss_p]),
+            log_radius_between=lr_b.detach().numpy(), log_radius_prior=lr_p.detach().numpy(),
+            A0=A0, b0=b0, err0=err0, errvec0=errvec0, err_history=info.err_history.numpy(),
+            final=final.detach().numpy(), coef=coef.numpy(), loss=loss.item(),
+            grad_meas=meas.grad.numpy(), grad_w_between=wb.grad.numpy(), grad_prior_target=tgt.grad.numpy(),
+            grad_w_prior=wp.grad.numpy(), grad_log_radius_between=lr_b.grad.numpy(), grad_log_radius_prior=lr_p.grad.numpy(),
+            opt_kwargs=np.array(repr(dict(max_iterations=iters, step_size=1.0, damping=1e-2, gauss_newton=False))))
+        print(name, "err", err0.mean(), "->", info.err_history[:, -1].mean().item(), "loss", loss.item(),
+              "|grad_lr|", lr_b.grad.abs().max().item(), lr_p.grad.abs().max().item())
 
 
 def gen_implicit(th, lieF):
@@ -837,7 +923,7 @@ def gen_ba(th, only=None):
               Np - len(pt_prior_idx))
 
 
-def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5):
+def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten=False):
     """Implicit backward through a bundle-adjustment objective (examples/bundle_adjustment.py:184-215 learns log_loss_radius this
     way): LM under no_grad, one undamped GN step with the Hessian detached and grad enabled; loss = <coef, final cameras> +
     <coef, final points>; gradients w.r.t. log_loss_radius, the image features, the calibration (focal, k1, k2), the
@@ -880,7 +966,9 @@ def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5):
                                 calib_k1=k1v[obs_cam[o]], calib_k2=k2v[obs_cam[o]],
                                 image_feature_point=th.Point2(tensor=leaves["feat"][:, o], name=f"Feat{o}"), weight=w,
                                 name=f"reproj_{o}")
-        obj.add(th.RobustCostFunction(cf, th.HuberLoss, log_radius, name=f"robust_{o}"))
+        # flatten=True: every image coordinate its own Huber term (robust_cost_function.py:89-96,118-133; the reference's
+        # flatten_dims path needs the un-vectorized objective and a batch-1 radius)
+        obj.add(th.RobustCostFunction(cf, th.HuberLoss, log_radius, name=f"robust_{o}", flatten_dims=flatten))
     dw = th.ScaleCostWeight(th.Variable(leaves["w_reg"].view(1, 1), name="w_reg"))
     zero_pt, ident = th.Point3(dtype=dtype, name="zero_point"), th.SE3(dtype=dtype, name="zero_se3")
     var_order, cost_order = [], [("obs", o) for o in range(O)]
@@ -902,9 +990,9 @@ def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5):
         obj.add(th.Difference(cam_v[i], th.SE3(tensor=leaves["gt_cams"][:, k], name=f"gt_cam{i}"), cw, name=f"camera_diff_{i}"))
         cost_order.append(("cam_prior", len(cam_prior_idx)))
         cam_prior_idx.append(i)
-    opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, abs_err_tolerance=0.0,
+    opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=not flatten, abs_err_tolerance=0.0,
                                 rel_err_tolerance=0.0, max_iterations=iters, step_size=1.0)
-    sol, info = th.TheseusLayer(opt).forward(optimizer_kwargs=dict(backward_mode="implicit", damping=1e-2))
+    sol, info = th.TheseusLayer(opt, vectorize=not flatten).forward(optimizer_kwargs=dict(backward_mode="implicit", damping=1e-2))
     used = sorted(set(obs_pt.tolist()))
     final_c = torch.stack([sol[f"Cam{i}"] for i in range(C)], 1)
     final_p = torch.stack([sol[f"Pt{i}"] for i in used], 1)
@@ -923,7 +1011,7 @@ def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5):
         pt_prior_idx=np.array(pt_prior_idx, dtype=np.int64), w_pt_prior=np.full((1, len(pt_prior_idx), 3), float(leaves["w_reg"])),
         var_kind=np.array([0 if k == "cam" else 1 for k, _ in var_order]), var_idx=np.array([i for _, i in var_order]),
         cost_kind=np.array([{"obs": 0, "cam_prior": 1, "pt_prior": 2}[k] for k, _ in cost_order]), cost_idx=np.array([i for _, i in cost_order]),
-        robust=np.array(robust), log_radius=np.float64(1.5), final_cams=d(final_c), final_pts=d(final_p), coef_c=coef_c.numpy(),
+        robust=np.array(robust + ("+flatten" if flatten else "")), log_radius=np.float64(1.5), final_cams=d(final_c), final_pts=d(final_p), coef_c=coef_c.numpy(),
         coef_p=coef_p.numpy(), loss=loss.item(), n_reg_cam=n_reg_cam,
         grad_log_radius=d(leaves["log_radius"].grad), grad_feat=d(leaves["feat"].grad), grad_focal=d(leaves["focal"].grad),
         grad_k1=d(leaves["k1"].grad), grad_k2=d(leaves["k2"].grad), grad_w_obs=d(leaves["w_obs"].grad),
@@ -981,6 +1069,8 @@ def main():
         gen_implicit(th, lieF)
     if not only or "se2" in only:
         gen_se2(th)
+    if not only or "mixed_robust" in only:
+        gen_pg_mixed_robust(th, lieF)
     if not only or "so3" in only:
         gen_so3(th, lieF)
     if not only or "se2_implicit" in only:
@@ -997,6 +1087,8 @@ def main():
         gen_pg_full(th, lieF, only & {"pg_full_f64_lm", "pg_full_f32_lm"})
     if not only or "ba_implicit" in only:
         gen_ba_implicit(th)
+    if not only or "ba_flatten_implicit" in only:
+        gen_ba_implicit(th, name="ba_f64_flatten_implicit", flatten=True)
     if "pg_full_f64_implicit" in only:     # (full size: asked for by name, ~1 min)
         gen_pg_full_implicit(th, lieF)
     if "ba_mid_f64_implicit" in only:      # 32 cameras: the reduced camera system takes two Cholesky tiles

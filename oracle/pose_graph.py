@@ -7,7 +7,7 @@ Follows, on packed tensors instead of per-variable Python objects:
   DenseLinearization                theseus/optimizer/dense_linearization.py:29-62
   DenseSolver._apply_damping        theseus/optimizer/linear/dense_solver.py:38-64
   CholeskyDenseSolver._solve_sytem  theseus/optimizer/linear/dense_solver.py:159-161
-  RobustCostFunction / Welsch,Huber theseus/core/robust_cost_function.py:87-135, theseus/core/robust_loss.py:13-52
+  RobustCostFunction (incl. flatten_dims) / Welsch,Huber theseus/core/robust_cost_function.py:87-135, theseus/core/robust_loss.py:13-52
   retract / error_metric            theseus/core/objective.py:37-38,562-641,873-914, theseus/core/variable.py:65-69
   LM loop                           theseus/optimizer/nonlinear/nonlinear_least_squares.py:100-215,338-365
                                     theseus/optimizer/nonlinear/levenberg_marquardt.py:114-201
@@ -61,11 +61,12 @@ class PGProblem:
     w_prior: torch.Tensor        # (1|B, K, 6)
     cost_order: Optional[List[Tuple[str, int]]] = None  # [('between',k)|('prior',k)] add order
     group: str = "SE3"           # "SE3": tensors (...,3,4), dof 6; "SE2": tensors (...,4) = [x,y,cos,sin], dof 3
-    # RobustCostFunction wrappers (robust_cost_function.py): loss kind ("welsch" | "huber" | None) per cost role and
-    # log_loss_radius broadcastable to (B, E|K, 1)
-    robust_between: Optional[str] = None
+    # RobustCostFunction wrappers (robust_cost_function.py): loss spec per cost role -- "welsch" | "huber" | None, with
+    # "+flatten" appended for flatten_dims=True, or a LIST of such specs, one per cost of the role -- and log_loss_radius
+    # broadcastable to (B, E|K, 1) (the entries of plain costs are not read)
+    robust_between: Optional[object] = None
     log_radius_between: Optional[torch.Tensor] = None
-    robust_prior: Optional[str] = None
+    robust_prior: Optional[object] = None
     log_radius_prior: Optional[torch.Tensor] = None
 
     def __post_init__(self):
@@ -138,21 +139,53 @@ def loss_linearize(kind, x, log_radius):
     raise ValueError(kind)
 
 
+def _per_cost(kind, count):
+    """A loss spec -- None | "welsch" | "huber" [+ "+flatten" for flatten_dims=True], or one such entry per cost of the role
+    (plain, Welsch, Huber and flattened costs mixed) -- as (count, 1) tensors: kind index 0/1/2, flatten flag."""
+    specs = [kind] * count if kind is None or isinstance(kind, str) else list(kind)
+    if len(specs) != count:
+        raise ValueError("one loss spec per cost")
+    k = torch.tensor([0 if s is None else {"welsch": 1, "huber": 2}[s.split("+")[0]] for s in specs]).view(count, 1)
+    f = torch.tensor([s is not None and s.endswith("+flatten") for s in specs]).view(count, 1)
+    return k, f
+
+
+def _simple(kind):
+    return kind is None or (isinstance(kind, str) and "+" not in kind)
+
+
+def _both(fn, k, x, log_radius):
+    return torch.where(k == 1, fn("welsch", x, log_radius), fn("huber", x, log_radius))
+
+
 def robust_rescale(jacs, e, kind, log_radius):
-    """robust_cost_function.py:115-135 (flatten_dims=False): J, e <- sqrt(rho'(|e|^2) + eps) * (J, e)."""
+    """robust_cost_function.py:115-135: J, e <- sqrt(rho'(|e|^2) + eps) * (J, e); with flatten_dims (:118-133) every row r is
+    its own term: row r of (J, e) scaled by sqrt(rho'(e_r^2) + eps)."""
     if kind is None:
         return jacs, e
-    sqn = (e**2).sum(-1, keepdim=True)
-    rs = (loss_linearize(kind, sqn, log_radius) + _ROBUST_EPS).sqrt()
+    if _simple(kind):
+        sqn = (e**2).sum(-1, keepdim=True)
+        rs = (loss_linearize(kind, sqn, log_radius) + _ROBUST_EPS).sqrt()
+        return [rs.unsqueeze(-1) * J for J in jacs], rs * e
+    k, f = _per_cost(kind, e.shape[1])
+    x = torch.where(f, e**2, (e**2).sum(-1, keepdim=True).expand_as(e))
+    rs = torch.where(k == 0, torch.ones_like(x), (_both(loss_linearize, k, x, log_radius) + _ROBUST_EPS).sqrt())
     return [rs.unsqueeze(-1) * J for J in jacs], rs * e
 
 
 def robust_weighted_error(e, kind, log_radius):
-    """robust_cost_function.py:87-106: ones * sqrt(rho(|e|^2) / dim + eps), so that |h|^2 = rho (+ dim eps)."""
+    """robust_cost_function.py:87-106: ones * sqrt(rho(|e|^2) / dim + eps), so that |h|^2 = rho (+ dim eps); with flatten_dims
+    (:89-96) sqrt(rho(e_r^2) + eps) per row."""
     if kind is None:
         return e
-    sqn = (e**2).sum(-1, keepdim=True)
-    return torch.ones_like(e) * (loss_evaluate(kind, sqn, log_radius) / e.shape[-1] + _ROBUST_EPS).sqrt()
+    if _simple(kind):
+        sqn = (e**2).sum(-1, keepdim=True)
+        return torch.ones_like(e) * (loss_evaluate(kind, sqn, log_radius) / e.shape[-1] + _ROBUST_EPS).sqrt()
+    k, f = _per_cost(kind, e.shape[1])
+    x = torch.where(f, e**2, (e**2).sum(-1, keepdim=True).expand_as(e))
+    rho = _both(loss_evaluate, k, x, log_radius)
+    h = torch.where(f, (rho + _ROBUST_EPS).sqrt(), (rho / e.shape[-1] + _ROBUST_EPS).sqrt())
+    return torch.where(k == 0, e, h)
 
 
 def cost_terms(p: PGProblem, poses):

@@ -112,7 +112,7 @@ def run_ba_implicit(th, g, kernels=None, device="cpu", opt_kwargs=None):
         c, p = int(g["obs_cam"][o]), int(g["obs_pt"][o])
         cf = th.Reprojection(camera_pose=cam_v[c], world_point=pt_v[p], focal_length=fl[c], calib_k1=k1[c], calib_k2=k2[c],
                              image_feature_point=th.Point2(tensor=leaves["feat"][:, o], name=f"Feat{o}"), weight=w, name=f"reproj_{o}")
-        obj.add(th.RobustCostFunction(cf, th.HuberLoss, radius, name=f"robust_{o}"))
+        obj.add(th.RobustCostFunction(cf, th.HuberLoss, radius, name=f"robust_{o}", flatten_dims=str(g["robust"]).endswith("+flatten")))
     dw = th.ScaleCostWeight(th.Variable(leaves["w_reg"].view(1, 1), name="w_reg"))
     ident = th.SE3(tensor=torch.eye(3, 4, dtype=dtype, device=device).unsqueeze(0), name="zero_se3")
     zero_pt = th.Point3(tensor=torch.zeros(1, 3, dtype=dtype, device=device), name="zero_point")

@@ -5,17 +5,26 @@ from theseus_amd.compiler import PoseGraphStructure
 from theseus_amd.kernels import PGTensors, round_up
 
 
+def loss_codes(spec, device="cuda"):
+    """the oracle's loss spec (oracle/pose_graph.py: PGProblem.robust_*) -> (role code, per-cost int32 table | None)."""
+    one = lambda s: 0 if s is None else {"welsch": 1, "huber": 2}[s.split("+")[0]] | (4 if s.endswith("+flatten") else 0)  # noqa: E731
+    if spec is None or isinstance(spec, str):
+        return one(spec), None
+    codes = [one(s) for s in spec]
+    return next(c for c in codes if c), torch.tensor(codes, dtype=torch.int32, device=device)
+
+
 def to_device_problem(p, poses0, device="cuda"):
     """oracle PGProblem (batch-major) -> (PoseGraphStructure, PGTensors) in entity-major device layout."""
     s = PoseGraphStructure.build(p.num_poses, p.edges.tolist(), p.prior_idx.tolist(), dof=p.dof)
     em = lambda t: t.transpose(0, 1).contiguous().to(device)  # noqa: E731  (B,X,...) -> (X,B,...)
-    kind = {None: 0, "welsch": 1, "huber": 2}
     E, Kp = p.edges.shape[0], p.prior_idx.shape[0]
     lr = lambda x, n: None if x is None else em(x.expand(-1, n, 1).to(poses0.dtype))  # noqa: E731
+    (rb, tb), (rp, tp) = loss_codes(p.robust_between, device), loss_codes(p.robust_prior, device)
     t = PGTensors(poses=em(poses0), meas=em(p.meas), w_between=em(p.w_between),
                   prior_target=em(p.prior_target), w_prior=em(p.w_prior),
-                  robust_between=kind[p.robust_between], log_radius_between=lr(p.log_radius_between, E),
-                  robust_prior=kind[p.robust_prior], log_radius_prior=lr(p.log_radius_prior, Kp))
+                  robust_between=rb, log_radius_between=lr(p.log_radius_between, E), loss_between=tb,
+                  robust_prior=rp, log_radius_prior=lr(p.log_radius_prior, Kp), loss_prior=tp)
     return s, t
 
 

@@ -10,7 +10,10 @@ from oracle import lie
 from oracle import pose_graph as opg
 
 
-LOSS = {0: None, 1: "welsch", 2: "huber"}  # theseus_amd._lib.LOSS_*
+def loss_spec(code, table=None):
+    """theseus_amd loss code(s) (_lib.LOSS_* | _lib.LOSS_FLATTEN; per-cost table) -> the oracle's loss spec."""
+    one = lambda c: None if c == 0 else {1: "welsch", 2: "huber"}[c & 3] + ("+flatten" if c & 4 else "")  # noqa: E731
+    return one(int(code)) if table is None else [one(int(c)) for c in table.tolist()]
 
 
 class OracleKernels:
@@ -27,9 +30,9 @@ class OracleKernels:
                           prior_idx=torch.from_numpy(h.prior_pose).long(),
                           prior_target=bm(t.prior_target), w_prior=bm(t.w_prior),
                           group="SE2" if t.poses.dim() == 3 else ("SO3" if t.poses.shape[-1] == 3 else "SE3"),
-                          robust_between=LOSS[t.robust_between],
+                          robust_between=loss_spec(t.robust_between, t.loss_between),
                           log_radius_between=bm(t.log_radius_between) if t.robust_between else None,
-                          robust_prior=LOSS[t.robust_prior],
+                          robust_prior=loss_spec(t.robust_prior, t.loss_prior),
                           log_radius_prior=bm(t.log_radius_prior) if t.robust_prior else None)
         return p, bm(t.poses if poses is None else poses)
 
@@ -143,7 +146,7 @@ class OracleKernels:
             cam_prior_idx=lg("cam_prior_cam")[:h.num_cam_priors], cam_prior_target=bm(t.cam_prior_target),
             w_cam_prior=bm(t.w_cam_prior), pt_prior_idx=lg("pt_prior_pt")[:h.num_pt_priors],
             pt_prior_target=bm(t.pt_prior_target), w_pt_prior=bm(t.w_pt_prior), var_order=[], cost_order=[],
-            robust_obs=LOSS[t.robust_obs], log_radius_obs=bm(t.log_radius_obs) if t.robust_obs else None)
+            robust_obs=loss_spec(t.robust_obs), log_radius_obs=bm(t.log_radius_obs) if t.robust_obs else None)
         return p, (bm(t.cams if cams is None else cams), bm(t.points if points is None else points))
 
     def ba_assemble(self, s, t, Hcc, Hpp, W, gd, g, diag):

@@ -54,8 +54,11 @@ def test_schur_block_tables_partition_the_pair_list():
     assert s.num_pairs == want
 
 
-def test_ba_implicit_backward_matches_reference_gradients():
-    """backward_mode="implicit" on a bundle-adjustment objective through theseus_amd's host path (BAImplicitStep: retract VJP ->
+@pytest.mark.parametrize("name", ["ba_f64_implicit", "ba_f64_flatten_implicit"])
+def test_ba_implicit_backward_matches_reference_gradients(name):
+    """(``ba_f64_flatten_implicit``: the Reprojection costs wrapped with flatten_dims=True -- every image coordinate its own
+    Huber term, robust_cost_function.py:89-96,118-133.)
+    backward_mode="implicit" on a bundle-adjustment objective through theseus_amd's host path (BAImplicitStep: retract VJP ->
     solve with the cached Schur factor -> thx_ba_vjp; TEST stand-in kernels here, HIP kernels in tests/test_gpu_ba.py): the
     gradients the REAL reference produced (oracle/gen_golden.py:gen_ba_implicit) w.r.t. log_loss_radius, the image features,
     the calibration, the observation weight, the strong camera priors' targets / weight and the regularisers' weight."""
@@ -66,7 +69,7 @@ def test_ba_implicit_backward_matches_reference_gradients():
     from tests.ba_common import run_ba_implicit
     from tests.helpers import load_golden
     from tests.oracle_kernels import OracleKernels
-    g = load_golden("ba_f64_implicit")
+    g = load_golden(name)
     got = run_ba_implicit(th, g, OracleKernels(), "cpu")
     np.testing.assert_allclose(got["final_cams"], g["final_cams"], rtol=0, atol=1e-7)
     np.testing.assert_allclose(got["final_pts"], g["final_pts"], rtol=0, atol=1e-6)

@@ -195,14 +195,17 @@ def test_ba_full_size_matches_the_reference_run():
     np.testing.assert_allclose(info.err_history[:, :k].numpy(), g["err_history"][:, :k], rtol=1e-6)
 
 
-def test_ba_implicit_backward_matches_reference_gradients():
-    """backward_mode="implicit" on a bundle-adjustment objective through the HIP kernels (thx_se3_retract_vjp -> solve with the
+@pytest.mark.parametrize("name", ["ba_f64_implicit", "ba_f64_flatten_implicit"])
+def test_ba_implicit_backward_matches_reference_gradients(name):
+    """(``ba_f64_flatten_implicit``: the Reprojection costs wrapped with flatten_dims=True -- every image coordinate its own
+    Huber term, robust_cost_function.py:89-96,118-133.)
+    backward_mode="implicit" on a bundle-adjustment objective through the HIP kernels (thx_se3_retract_vjp -> solve with the
     cached Schur factor -> thx_ba_vjp): the gradients the REAL reference produced (oracle/gen_golden.py:gen_ba_implicit) w.r.t.
     log_loss_radius, the image features, the calibration (dual numbers), the observation weight, the strong camera priors'
     targets / weight and the regularisers' weight."""
     import theseus_amd as th
     from tests.ba_common import run_ba_implicit
-    g = load_golden("ba_f64_implicit")
+    g = load_golden(name)
     got = run_ba_implicit(th, g, None, "cuda")
     np.testing.assert_allclose(got["final_cams"], g["final_cams"], rtol=0, atol=1e-7)
     np.testing.assert_allclose(got["final_pts"], g["final_pts"], rtol=0, atol=1e-6)

@@ -28,8 +28,8 @@ def robust_problem(name, kind, dtype, both_roles):
     lrp = (xp.median() * torch.exp(2.0 * torch.randn(1, Kp, 1, dtype=torch.float64, generator=gen))).log()
     r = lambda x: x.to(dtype).double()  # noqa: E731
     p = dataclasses.replace(p, meas=r(p.meas), w_between=r(p.w_between), prior_target=r(p.prior_target), w_prior=r(p.w_prior),
-                            robust_between=kind, log_radius_between=r(lrb),
-                            robust_prior=kind if both_roles else None, log_radius_prior=r(lrp) if both_roles else None)
+                            robust_between=spec(E, 0), log_radius_between=r(lrb),
+                            robust_prior=spec(Kp, 3) if both_roles else None, log_radius_prior=r(lrp) if both_roles else None)
     return p, r(poses0)
 
 
@@ -43,7 +43,11 @@ def to_dtype(p, dtype):
 @pytest.mark.parametrize("name,kind,dtype,both", [
     ("pg_f64_lm_adaptive_ellips", "welsch", torch.float64, True), ("pg_f64_lm_adaptive_ellips", "huber", torch.float64, True),
     ("pg_f64_lm", "welsch", torch.float32, False), ("pg_f64_lm", "huber", torch.float32, True),
-    ("pg2_f64_lm_adaptive", "welsch", torch.float64, True), ("pg2_f64_lm_adaptive", "huber", torch.float32, False)])
+    ("pg2_f64_lm_adaptive", "welsch", torch.float64, True), ("pg2_f64_lm_adaptive", "huber", torch.float32, False),
+    ("pg_f64_lm_adaptive_ellips", "mixed", torch.float64, True), ("pg_f64_lm", "mixed", torch.float32, True),
+    ("pg_f64_lm", "huber+flatten", torch.float64, False), ("pg2_f64_lm_adaptive", "mixed", torch.float64, True),
+    ("pg2_f64_lm_adaptive", "welsch+flatten", torch.float32, True), ("pg3_f64_lm_adaptive", "mixed", torch.float64, True),
+    ("pg3_f64_lm", "mixed", torch.float32, True)])
 def test_robust_assemble_error_jacobians_vs_oracle(name, kind, dtype, both):
     from tests.gpu_helpers import alloc_dense, sym_from_lower, to_device_problem
     from theseus_amd.kernels import default_kernels
@@ -60,7 +64,7 @@ def test_robust_assemble_error_jacobians_vs_oracle(name, kind, dtype, both):
     B, n, d = poses0.shape[0], s.num_cols, p.dof
     H, gv, _ = alloc_dense(B, n, dtype)
     K.pg_assemble(ds, t, H, gv)
-    rel = 5e-7 if f32 else (1e-9 if p.group == "SE2" else 5e-12)
+    rel = 5e-7 if f32 else (5e-12 if p.group == "SE3" else 1e-9)
     assert (sym_from_lower(H, n).cpu().double() - H64).abs().max() <= rel * H64.abs().max()
     assert (gv.cpu().double() - g64[..., 0]).abs().max() <= rel * g64.abs().max()
     part = torch.empty(16, B, dtype=dtype, device="cuda")
@@ -76,17 +80,23 @@ def test_robust_assemble_error_jacobians_vs_oracle(name, kind, dtype, both):
         assert (got.cpu().double() - want).abs().max() <= (3e-7 if f32 else max(rel, 1e-11)) * want.abs().max()
 
 
-@pytest.mark.parametrize("kind,dtype,both", [("welsch", torch.float64, True), ("huber", torch.float64, True),
-                                             ("welsch", torch.float32, False)])
-def test_robust_vjp_vs_oracle_autograd(kind, dtype, both):
-    """thx_pg_vjp with robust costs: gradients w.r.t. measurements, weights, targets AND log_loss_radius against torch
-    autograd through the oracle (rho' is not detached, robust_cost_function.py:115-135)."""
+@pytest.mark.parametrize("name,kind,dtype,both", [
+    ("pg_f64_implicit_b", "welsch", torch.float64, True), ("pg_f64_implicit_b", "huber", torch.float64, True),
+    ("pg_f64_implicit_b", "welsch", torch.float32, False), ("pg_f64_implicit_b", "mixed", torch.float64, True),
+    ("pg_f64_implicit_b", "huber+flatten", torch.float32, True), ("pg2_f64_implicit", "mixed", torch.float64, True),
+    ("pg2_f64_implicit", "welsch+flatten", torch.float64, False), ("pg3_f64_implicit", "mixed", torch.float64, True),
+    ("pg3_f64_implicit", "huber+flatten", torch.float32, True)])
+def test_robust_vjp_vs_oracle_autograd(name, kind, dtype, both):
+    """thx_pg_vjp / thx_pg2_vjp / thx_pgso3_vjp with robust costs: gradients w.r.t. measurements, weights, targets AND
+    log_loss_radius against torch autograd through the oracle (rho' is not detached, robust_cost_function.py:115-135); "mixed":
+    per-cost loss table, the radius gradient of a plain cost inside a robust role is 0."""
     from tests.gpu_helpers import to_device_problem
     from theseus_amd.kernels import default_kernels
     K = default_kernels()
-    p, poses0 = robust_problem("pg_f64_implicit_b", kind, dtype, both)
+    p, poses0 = robust_problem(name, kind, dtype, both)
     f32 = dtype == torch.float32
-    B, n = poses0.shape[0], 6 * p.num_poses
+    B, d = poses0.shape[0], p.dof
+    n, gs = d * p.num_poses, tuple(poses0.shape[2:])
     E, Kp = p.edges.shape[0], p.prior_idx.shape[0]
     w = torch.randn(B, n, dtype=torch.float64, generator=torch.Generator().manual_seed(3)).to(dtype).double()
     full = lambda a: a.expand(B, *a.shape[1:]).clone().requires_grad_(True)  # noqa: E731
@@ -101,12 +111,42 @@ def test_robust_vjp_vs_oracle_autograd(kind, dtype, both):
         ref = torch.autograd.grad((w * Atb.squeeze(2)).sum(), leaves)
     s, t = to_device_problem(to_dtype(p, dtype), poses0.to(dtype))
     new = lambda *sh: torch.empty(*sh, dtype=dtype, device="cuda")  # noqa: E731
-    outs = [new(E, B, 3, 4), new(E, B, 6), new(Kp, B, 3, 4), new(Kp, B, 6), new(E, B, 1)] + ([new(Kp, B, 1)] if both else [])
+    outs = [new(E, B, *gs), new(E, B, d), new(Kp, B, *gs), new(Kp, B, d), new(E, B, 1)] + ([new(Kp, B, 1)] if both else [])
     K.pg_vjp(s.on("cuda"), t, w.to(dtype).cuda(), *outs[:4], g_lrb=outs[4], g_lrp=outs[5] if both else None)
     tol = 5e-7 if f32 else 1e-9
     for k, (got, want) in enumerate(zip(outs, ref)):
         want = want.transpose(0, 1)
         assert (got.cpu().double() - want).abs().max() <= tol * want.abs().max(), k
+    if kind == "mixed":   # the plain costs of a mixed role: exact zeros in the radius gradient
+        plain = [k for k, sp in enumerate(p.robust_between) if sp is None]
+        assert plain and bool((outs[4][plain] == 0).all())
+
+
+@pytest.mark.parametrize("name,dtype", [("pg_f64_mixed_robust", torch.float64), ("pg2_f64_mixed_robust", torch.float64),
+                                        ("pg_f64_mixed_robust", torch.float32)])
+def test_mixed_and_flattened_robust_costs_match_the_reference(name, dtype):
+    """Plain, Welsch, Huber and flatten_dims=True costs mixed inside one objective, END TO END through the HIP path (packer's
+    per-cost loss table -> thx_pg_assemble_blocks / thx_pg_error / thx_pg_vjp): error vector / metric, the damped LM run and the
+    implicit-backward gradients incl. every log_loss_radius against the REAL reference's run (tests/golden/*_mixed_robust.npz,
+    oracle/gen_golden.py:gen_pg_mixed_robust).  fp32: inside the band the fp32 rounding of the inputs allows."""
+    import theseus_amd as th
+    from tests.mixed_robust_common import check_grads, run_mixed_implicit
+    g = load_golden(name)
+    f32 = dtype == torch.float32
+    r = run_mixed_implicit(th, g, "cuda", dtype=dtype)
+    packed = r["opt"].linear_solver.linearization.packed
+    assert packed.tensors.loss_between is not None and packed.tensors.loss_between.dtype == torch.int32
+    np.testing.assert_allclose(r["err0"].double().numpy(), g["err0"], rtol=2e-5 if f32 else 1e-12)
+    np.testing.assert_allclose(r["errvec0"].double().numpy(), g["errvec0"], rtol=0,
+                               atol=(2e-5 if f32 else 1e-12) * np.abs(g["errvec0"]).max())
+    np.testing.assert_allclose(r["info"].err_history.double().numpy(), g["err_history"], rtol=2e-3 if f32 else 1e-6)
+    np.testing.assert_allclose(r["final"].double().numpy(), g["final"], rtol=0, atol=2e-3 if f32 else 5e-8)
+    if not f32:
+        assert abs(r["loss"] - float(g["loss"])) < 1e-6
+        check_grads(g, r["grads"], 2e-6)
+    else:
+        assert abs(r["loss"] - float(g["loss"])) < 2e-3 * max(1.0, abs(float(g["loss"])))
+        check_grads(g, r["grads"], 5e-2)
 
 
 def test_reference_pgo_known_answer_through_the_hip_path():

@@ -294,3 +294,46 @@ def test_so3_pose_graph_matches_reference(name, tol):
         for it in range(len(info.deltas)):
             np.testing.assert_allclose(info.deltas[it].numpy(), g["delta"][it], rtol=0,
                                        atol=tol * max(1.0, np.abs(g["delta"][it]).max()))
+
+
+@pytest.mark.parametrize("name", ["pg_f64_mixed_robust", "pg2_f64_mixed_robust"])
+def test_mixed_robust_objective_matches_reference(name):
+    """Plain, Welsch, Huber and flatten_dims=True costs mixed inside one role (theseus/core/robust_cost_function.py:52-135):
+    the oracle's per-cost loss specs against the REAL reference -- first linearization, error vector / metric, the damped LM
+    run, and the implicit-backward gradients w.r.t. measurements, weights, targets and every log_loss_radius."""
+    import dataclasses
+    from tests.mixed_robust_common import GRAD_KEYS, mixed_problem
+    g = load_golden(name)
+    p, poses0, kw = mixed_problem(g)
+    A, b = opg.dense_linearize(p, poses0)
+    np.testing.assert_allclose(A.numpy(), g["A0"], rtol=0, atol=1e-11 * np.abs(g["A0"]).max())
+    np.testing.assert_allclose(b.numpy(), g["b0"], rtol=0, atol=1e-11 * np.abs(g["b0"]).max())
+    np.testing.assert_allclose(opg.error_metric(p, poses0).numpy(), g["err0"], rtol=1e-12)
+    np.testing.assert_allclose(opg.error_vector(p, poses0).numpy(), g["errvec0"], rtol=0, atol=1e-12 * np.abs(g["errvec0"]).max())
+    kw.pop("gauss_newton")
+    iters = kw.pop("max_iterations")
+    with torch.no_grad():
+        x, info = opg.lm_optimize(p, poses0, max_iterations=iters - 1, abs_err_tolerance=0.0, rel_err_tolerance=0.0, **kw)
+    np.testing.assert_allclose(torch.stack(info.err_history, 1).numpy(), g["err_history"][:, :iters], rtol=1e-6)   # (stored fp32)
+    leaves = dict(meas=p.meas.clone().requires_grad_(True), w_between=p.w_between.clone().requires_grad_(True),
+                  prior_target=p.prior_target.clone().requires_grad_(True), w_prior=p.w_prior[:, :, :1].clone().requires_grad_(True),
+                  log_radius_between=p.log_radius_between.clone().requires_grad_(True),
+                  log_radius_prior=p.log_radius_prior.clone().requires_grad_(True))
+    # a radius the batch shares is ONE reference Variable (leaf[:1, k]): its gradient is the sum over the batch, in row 0
+    from tests.mixed_robust_common import shared_radius
+
+    def radius(leaf, shared):
+        cols = [leaf[:1, k].expand(leaf.shape[0], -1) if s else leaf[:, k] for k, s in enumerate(shared)]
+        return torch.stack(cols, 1)
+    pg = dataclasses.replace(p, meas=leaves["meas"], w_between=leaves["w_between"], prior_target=leaves["prior_target"],
+                             w_prior=leaves["w_prior"].expand(-1, -1, p.dof),
+                             log_radius_between=radius(leaves["log_radius_between"], shared_radius(g, "between")),
+                             log_radius_prior=radius(leaves["log_radius_prior"], shared_radius(g, "prior")))
+    final, _ = opg.implicit_final_step(pg, x)
+    np.testing.assert_allclose(final.detach().numpy(), g["final"], rtol=0, atol=5e-8)
+    loss = (torch.from_numpy(g["coef"]) * final).sum()
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    for key, ref in GRAD_KEYS:
+        got, want = leaves[key].grad.numpy(), g[ref]
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)

@@ -49,3 +49,26 @@ def test_reference_pgo_known_answer_through_host_path():
     losses, want = run_kat(th, OracleKernels())
     for a, b in zip(losses, want):
         assert a == pytest.approx(b, rel=1e-10, abs=1e-10), (losses, want)
+
+
+@pytest.mark.parametrize("name", ["pg_f64_mixed_robust", "pg2_f64_mixed_robust"])
+def test_mixed_and_flattened_robust_costs_through_host_path(name):
+    """Plain, Welsch, Huber and flatten_dims=True costs mixed inside one role (robust_cost_function.py:52-135): the packer's
+    per-cost loss table (theseus_amd/packed.py), Objective.error(), the LM loop and the implicit backward incl. the gradient of
+    every log_loss_radius, against the REAL reference's fixture.  GPU twin: tests/test_gpu_robust.py."""
+    import numpy as np
+    import theseus_amd as th
+    from tests.helpers import load_golden
+    from tests.mixed_robust_common import check_grads, run_mixed_implicit
+    from tests.oracle_kernels import OracleKernels
+    g = load_golden(name)
+    r = run_mixed_implicit(th, g, "cpu", OracleKernels())
+    packed = r["opt"].linear_solver.linearization.packed
+    assert packed.loss_between is not None and packed.loss_prior is not None      # both roles are mixed
+    assert sorted(set(packed.loss_between.tolist())) == [0, 1, 2, 5, 6] and packed.loss_prior.tolist()[0] == 5
+    np.testing.assert_allclose(r["err0"].numpy(), g["err0"], rtol=1e-12)
+    np.testing.assert_allclose(r["errvec0"].numpy(), g["errvec0"], rtol=0, atol=1e-12 * np.abs(g["errvec0"]).max())
+    np.testing.assert_allclose(r["info"].err_history.numpy(), g["err_history"], rtol=1e-6)
+    np.testing.assert_allclose(r["final"].numpy(), g["final"], rtol=0, atol=5e-8)
+    assert abs(r["loss"] - float(g["loss"])) < 1e-6
+    check_grads(g, r["grads"], 2e-6)

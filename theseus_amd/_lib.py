@@ -19,7 +19,8 @@ THX_TILE = 128
 THX_ERR_CHUNKS = 16
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
-ABI_VERSION = 17
+LOSS_FLATTEN = 4  # THX_LOSS_FLATTEN: RobustCostFunction(flatten_dims=True), or-ed into a loss code
+ABI_VERSION = 18
 
 
 class LieEps(Structure):
@@ -78,9 +79,11 @@ class PGData(Structure):
         ("w_between", c_void_p), ("w_between_bstride", c_int64),
         ("prior_target", c_void_p), ("prior_target_bstride", c_int64),
         ("w_prior", c_void_p), ("w_prior_bstride", c_int64),
-        # RobustCostFunction wrappers: loss kind (LOSS_*) per cost role + log_loss_radius (E|K, Br, 1)
+        # RobustCostFunction wrappers: loss code (LOSS_* [| LOSS_FLATTEN]) per cost role + log_loss_radius (E|K, Br, 1);
+        # loss_<role>: int32 code per cost when the costs of a role differ
         ("robust_between", c_int32), ("log_radius_between", c_void_p), ("log_radius_between_bstride", c_int64),
         ("robust_prior", c_int32), ("log_radius_prior", c_void_p), ("log_radius_prior_bstride", c_int64),
+        ("loss_between", c_void_p), ("loss_prior", c_void_p),
     ]
 
 

@@ -90,15 +90,16 @@ __device__ __forceinline__ void load_obs(const thx_ba_data& d, int o, int c, int
   a.k2 = (double)static_cast<const T*>(d.k2)[ci];
   a.lr = d.robust_obs ? load_log_radius<T>(d.log_radius_obs, o, b, B, d.log_radius_obs_bstride) : 0.0;
 }
-__device__ __forceinline__ void robustify_obs(int kind, double lr, Reproj& r, bool jac) {
-  if (kind == THX_LOSS_NONE) return;
-  const double s = robust_rescale<2>(kind, r.e, lr);
-  r.e[0] *= s; r.e[1] *= s;
+__device__ __forceinline__ void robustify_obs(int code, double lr, Reproj& r, bool jac) {
+  if (code == THX_LOSS_NONE) return;
+  double f[2];
+  robust_row_scale<2>(code, r.e, lr, f);   // robust.cuh: one factor, or one per row with THX_LOSS_FLATTEN
+  r.e[0] *= f[0]; r.e[1] *= f[1];
   if (jac) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) r.Jc[i] *= s;
+    for (int i = 0; i < 6; ++i) { r.Jc[i] *= f[0]; r.Jc[6 + i] *= f[1]; }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) r.Jp[i] *= s;
+    for (int i = 0; i < 3; ++i) { r.Jp[i] *= f[0]; r.Jp[3 + i] *= f[1]; }
   }
 }
 
@@ -593,7 +594,7 @@ static int check_ba(const thx_ba_structure* s, const thx_ba_data* d) {
   if (s->num_cams <= 0 || s->num_points <= 0 || d->batch <= 0) return fail("thx_ba: empty problem");
   if (!d->cams || !d->points) return fail("thx_ba: null variables");
   if (s->num_obs > 0 && (!d->feat || !d->w_obs || !d->focal || !d->k1 || !d->k2)) return fail("thx_ba: null observation data");
-  if (d->robust_obs < 0 || d->robust_obs > 2 || (d->robust_obs && !d->log_radius_obs)) return fail("thx_ba: bad robust loss");
+  if (!loss_code_valid(d->robust_obs) || (d->robust_obs && !d->log_radius_obs)) return fail("thx_ba: bad robust loss");
   if ((d->feat_bstride != 0 && d->feat_bstride != 2) || (d->w_obs_bstride != 0 && d->w_obs_bstride != 2) ||
       (d->calib_bstride != 0 && d->calib_bstride != 1) || (d->cam_prior_target_bstride != 0 && d->cam_prior_target_bstride != 12) ||
       (d->w_cam_prior_bstride != 0 && d->w_cam_prior_bstride != 6) || (d->pt_prior_target_bstride != 0 && d->pt_prior_target_bstride != 3) ||

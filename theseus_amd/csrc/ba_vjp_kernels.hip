@@ -75,21 +75,21 @@ ba_vjp_kernel(thx_ba_structure s, thx_ba_data d, const T* __restrict__ wvec, int
     for (int k = 0; k < 3; ++k) qp[k] = (double)wv[nc + 3 * pt_i + k];
     double al[2], ep[2];
     reproj_alpha_eps<double>(cam, X, feat, f, k1, k2, qc, qp, al, ep);
-    double phi = 0.0, x = 0.0;
+    double phi_r[2], x_r[2], Phi[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      phi -= sw[r] * sw[r] * al[r] * ep[r];
-      x += sw[r] * sw[r] * ep[r] * ep[r];
+      phi_r[r] = -sw[r] * sw[r] * al[r] * ep[r];
+      x_r[r] = sw[r] * sw[r] * ep[r] * ep[r];
     }
-    double m = 1.0, m_x = 0.0, m_l = 0.0;
-    if (d.robust_obs != THX_LOSS_NONE)
-      rescale2_partials(d.robust_obs, x, load_log_radius<T>(d.log_radius_obs, o, b, B, d.log_radius_obs_bstride), m, m_x, m_l);
+    RobustTerms<2> rt;   // robust.cuh
+    rt.eval(d.robust_obs, x_r, d.robust_obs ? load_log_radius<T>(d.log_radius_obs, o, b, B, d.log_radius_obs_bstride) : 0.0);
+    rt.group(phi_r, Phi);
     const int64_t ob = (int64_t)o * B + b;
-    if (g_lr) g_lr[ob] = (T)(phi * m_l);
+    if (g_lr) g_lr[ob] = (T)(phi_r[0] * rt.m_l[0] + phi_r[1] * rt.m_l[1]);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      if (g_feat) g_feat[ob * 2 + r] = (T)(m * sw[r] * sw[r] * al[r] - phi * m_x * 2.0 * sw[r] * sw[r] * ep[r]);
-      if (g_wobs) g_wobs[ob * 2 + r] = (T)(-m * 2.0 * sw[r] * al[r] * ep[r] + phi * m_x * 2.0 * sw[r] * ep[r] * ep[r]);
+      if (g_feat) g_feat[ob * 2 + r] = (T)(rt.m[r] * sw[r] * sw[r] * al[r] - Phi[r] * rt.m_x[r] * 2.0 * sw[r] * sw[r] * ep[r]);
+      if (g_wobs) g_wobs[ob * 2 + r] = (T)(-rt.m[r] * 2.0 * sw[r] * al[r] * ep[r] + Phi[r] * rt.m_x[r] * 2.0 * sw[r] * ep[r] * ep[r]);
     }
     if (g_focal) {  // one dual evaluation per calibration parameter
       T* outs[3] = {g_focal, g_k1, g_k2};
@@ -97,13 +97,11 @@ ba_vjp_kernel(thx_ba_structure s, thx_ba_data d, const T* __restrict__ wvec, int
         D2 ald[2], epd[2];
         reproj_alpha_eps<D2>(cam, X, feat, D2(f, k == 0 ? 1.0 : 0.0), D2(k1, k == 1 ? 1.0 : 0.0), D2(k2, k == 2 ? 1.0 : 0.0), qc, qp,
                              ald, epd);
-        double dphi = 0.0, dx = 0.0;
+        double g = 0.0;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          dphi -= sw[r] * sw[r] * (ald[r].d * ep[r] + al[r] * epd[r].d);
-          dx += 2.0 * sw[r] * sw[r] * ep[r] * epd[r].d;
-        }
-        outs[k][ob] = (T)(m * dphi + phi * m_x * dx);
+        for (int r = 0; r < 2; ++r)
+          g += rt.m[r] * (-sw[r] * sw[r] * (ald[r].d * ep[r] + al[r] * epd[r].d)) + Phi[r] * rt.m_x[r] * (2.0 * sw[r] * sw[r] * ep[r] * epd[r].d);
+        outs[k][ob] = (T)g;
       }
     }
   } else if (c < s.num_obs + s.num_cam_priors) {

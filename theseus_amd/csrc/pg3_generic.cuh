@@ -70,16 +70,20 @@ __device__ __forceinline__ void m3_tvec_sub(const double* P, const double* e, do
   for (int i = 0; i < 3; ++i) g[i] -= P[i] * e[0] + P[3 + i] * e[1] + P[6 + i] * e[2];
 }
 template <typename T>
-__device__ __forceinline__ void robustify2(int kind, const void* lr, int64_t lr_bs, int64_t entity, int b, int B,
+__device__ __forceinline__ void robustify2(int code, const void* lr, int64_t lr_bs, int64_t entity, int b, int B,
                                            double* ev, double* J0, double* J1) {
-  if (kind == THX_LOSS_NONE) return;
-  const double f = robust_rescale<3>(kind, ev, load_log_radius<T>(lr, entity, b, B, lr_bs));
+  if (code == THX_LOSS_NONE) return;
+  double f[3];
+  robust_row_scale<3>(code, ev, load_log_radius<T>(lr, entity, b, B, lr_bs), f);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    if (J0) J0[i] *= f;
-    if (J1) J1[i] *= f;
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (J0) J0[3 * r + c] *= f[r];
+      if (J1) J1[3 * r + c] *= f[r];
+    }
+    ev[r] *= f[r];
   }
-  ev[0] *= f; ev[1] *= f; ev[2] *= f;
 }
 template <typename T>
 __device__ __forceinline__ void load3(const T* __restrict__ p, double* w) {
@@ -125,13 +129,13 @@ pg3_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_
     }
     if (side == 0) {
       between_eval3<G>(Xp, Xq, M, w, eps, ev, J0, J1, true);
-      robustify2<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, J0, J1);
+      robustify2<T>(loss_code(d.robust_between, d.loss_between, e), d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, J0, J1);
       m3_tmul_acc(J0, J0, Dg);
       m3_tvec_sub(J0, ev, gv);
       if (lower) m3_tmul_acc(J0, J1, Off);
     } else {
       between_eval3<G>(Xq, Xp, M, w, eps, ev, J0, J1, true);
-      robustify2<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, J0, J1);
+      robustify2<T>(loss_code(d.robust_between, d.loss_between, e), d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, J0, J1);
       m3_tmul_acc(J1, J1, Dg);
       m3_tvec_sub(J1, ev, gv);
       if (lower) m3_tmul_acc(J1, J0, Off);
@@ -147,7 +151,7 @@ pg3_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_
     double w[3], ev[3], J[9];
     load3(wp + ((int64_t)id * wpB) * 3 + (int64_t)b * d.w_prior_bstride, w);
     local_eval3<G>(Tg, Xp, w, eps, ev, J, true);
-    robustify2<T>(d.robust_prior, d.log_radius_prior, d.log_radius_prior_bstride, id, b, B, ev, J, nullptr);
+    robustify2<T>(loss_code(d.robust_prior, d.loss_prior, id), d.log_radius_prior, d.log_radius_prior_bstride, id, b, B, ev, J, nullptr);
     m3_tmul_acc(J, J, Dg);
     m3_tvec_sub(J, ev, gv);
   }
@@ -178,8 +182,8 @@ pg3_error_partial_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ part
     double w[3], ev[3];
     load3(static_cast<const T*>(d.w_between) + ((int64_t)e * wB) * 3 + (int64_t)b * d.w_between_bstride, w);
     between_eval3<G>(Xi, Xj, M, w, eps, ev, nullptr, nullptr, false);
-    acc += robust_sq_error<3>(d.robust_between, ev,
-                              d.robust_between ? load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride) : 0.0);
+    const int code = loss_code(d.robust_between, d.loss_between, e);
+    acc += robust_sq_error<3>(code, ev, code ? load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride) : 0.0);
   }
   const int kc = (K + THX_ERR_CHUNKS - 1) / THX_ERR_CHUNKS, k1 = min(K, (ch + 1) * kc);
   const int64_t tB = d.prior_target_bstride ? B : 1, wpB = d.w_prior_bstride ? B : 1;
@@ -189,8 +193,8 @@ pg3_error_partial_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ part
     double w[3], ev[3];
     load3(static_cast<const T*>(d.w_prior) + ((int64_t)k * wpB) * 3 + (int64_t)b * d.w_prior_bstride, w);
     local_eval3<G>(Tg, X, w, eps, ev, nullptr, false);
-    acc += robust_sq_error<3>(d.robust_prior, ev,
-                              d.robust_prior ? load_log_radius<T>(d.log_radius_prior, k, b, B, d.log_radius_prior_bstride) : 0.0);
+    const int code = loss_code(d.robust_prior, d.loss_prior, k);
+    acc += robust_sq_error<3>(code, ev, code ? load_log_radius<T>(d.log_radius_prior, k, b, B, d.log_radius_prior_bstride) : 0.0);
   }
   partials[(int64_t)ch * B + b] = (T)acc;
 }
@@ -223,7 +227,7 @@ pg3_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* 
     const typename G::X M = G::load(static_cast<const T*>(d.meas) + ((int64_t)e * mB) * G::REC + (int64_t)b * d.meas_bstride);
     load3(static_cast<const T*>(d.w_between) + ((int64_t)e * wB) * 3 + (int64_t)b * d.w_between_bstride, w);
     between_eval3<G>(Xi, Xj, M, w, eps, ev, J0, J1, true);
-    robustify2<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, J0, J1);
+    robustify2<T>(loss_code(d.robust_between, d.loss_between, e), d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, J0, J1);
     const int64_t o = (int64_t)e * B + b;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -238,7 +242,7 @@ pg3_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* 
     const typename G::X Tg = G::load(static_cast<const T*>(d.prior_target) + ((int64_t)k * tB) * G::REC + (int64_t)b * d.prior_target_bstride);
     load3(static_cast<const T*>(d.w_prior) + ((int64_t)k * wB) * 3 + (int64_t)b * d.w_prior_bstride, w);
     local_eval3<G>(Tg, X, w, eps, ev, J0, true);
-    robustify2<T>(d.robust_prior, d.log_radius_prior, d.log_radius_prior_bstride, k, b, B, ev, J0, nullptr);
+    robustify2<T>(loss_code(d.robust_prior, d.loss_prior, k), d.log_radius_prior, d.log_radius_prior_bstride, k, b, B, ev, J0, nullptr);
     const int64_t o = (int64_t)k * B + b;
 #pragma unroll
     for (int q = 0; q < 9; ++q)
@@ -315,9 +319,7 @@ static int check_pg3(const thx_pg_structure* s, const thx_pg_data* d, const char
     return fail("meas / prior_target batch stride must be 0 or the record size of the group");
   if ((d->w_between_bstride != 0 && d->w_between_bstride != 3) || (d->w_prior_bstride != 0 && d->w_prior_bstride != 3))
     return fail("weight batch stride must be 0 or 3");
-  if ((d->robust_between && !d->log_radius_between) || (d->robust_prior && !d->log_radius_prior))
-    return fail("robust cost without log_loss_radius");
-  if (d->robust_between < 0 || d->robust_between > 2 || d->robust_prior < 0 || d->robust_prior > 2) return fail("bad loss kind");
+  if (const char* why = check_robust(d)) return fail(why);
   (void)group;
   return 0;
 }

@@ -14,31 +14,35 @@
 #include "robust.cuh"
 
 namespace thx {
-__device__ __forceinline__ void sjac_scale(SJac<double>& J, double f) {
+__device__ __forceinline__ void sjac_scale_rows(SJac<double>& J, const double* f) {
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { J.a[i] *= f; J.c[i] *= f; J.d[i] *= f; }
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { J.a[3 * r + c] *= f[r]; J.c[3 * r + c] *= f[r]; J.d[3 * r + c] *= f[3 + r]; }
 }
-// robust rescale of a Between / Local evaluation (robust_cost_function.py:115-135)
+// robust rescale of a Between / Local evaluation (robust_cost_function.py:115-135); ``code``: robust.cuh
 template <typename T>
-__device__ __forceinline__ void robustify(int kind, const void* lr, int64_t lr_bs, int64_t entity, int b, int B,
+__device__ __forceinline__ void robustify(int code, const void* lr, int64_t lr_bs, int64_t entity, int b, int B,
                                           double* ev, SJac<double>* J0, SJac<double>* J1) {
-  if (kind == THX_LOSS_NONE) return;
-  const double f = robust_rescale<6>(kind, ev, load_log_radius<T>(lr, entity, b, B, lr_bs));
-  if (J0) sjac_scale(*J0, f);
-  if (J1) sjac_scale(*J1, f);
+  if (code == THX_LOSS_NONE) return;
+  double f[6];
+  robust_row_scale<6>(code, ev, load_log_radius<T>(lr, entity, b, B, lr_bs), f);
+  if (J0) sjac_scale_rows(*J0, f);
+  if (J1) sjac_scale_rows(*J1, f);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) ev[i] *= f;
+  for (int i = 0; i < 6; ++i) ev[i] *= f[i];
 }
-// Robust costs in the assembly kernel: the rescale factor f = sqrt(rho'(|w e|^2) + eps) only needs the residual, so it is
-// computed from a residual-only evaluation FIRST and folded into the weights (J' = f J, e' = f e  <=>  w' = f w) -- the
-// Jacobian pass then runs exactly as for plain costs and nothing but six weights is live across the exp() of the loss
+// Robust costs in the assembly kernel: the rescale factors f_r = sqrt(rho'(x_r) + eps) only need the residual, so they are
+// computed from a residual-only evaluation FIRST and folded into the weights (J' = diag(f) J, e' = diag(f) e  <=>  w' = f w)
+// -- the Jacobian pass then runs exactly as for plain costs and nothing but six weights is live across the exp() of the loss
 // (rescaling the finished fp64 Jacobians spilled 440 bytes per lane).
 template <typename T>
-__device__ __forceinline__ void robust_weights(int kind, const void* lr, int64_t lr_bs, int64_t entity, int b, int B,
+__device__ __forceinline__ void robust_weights(int code, const void* lr, int64_t lr_bs, int64_t entity, int b, int B,
                                                const double* ev, T* w) {
-  const double f = robust_rescale<6>(kind, ev, load_log_radius<T>(lr, entity, b, B, lr_bs));
+  double f[6];
+  robust_row_scale<6>(code, ev, load_log_radius<T>(lr, entity, b, B, lr_bs), f);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) w[i] = (T)((double)w[i] * f);
+  for (int i = 0; i < 6; ++i) w[i] = (T)((double)w[i] * f[i]);
 }
 }  // namespace thx
 
@@ -156,9 +160,9 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
     }
     if (side == 0) {  // p is v0: own Jacobian J0, other J1
       if constexpr (ROBUST) {
-        if (d.robust_between) {
+        if (const int code = loss_code(d.robust_between, d.loss_between, e)) {
           between_eval_hp<T>(Xp, Xq, M, w, eps, ev, nullptr, nullptr, false);
-          robust_weights<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, w);
+          robust_weights<T>(code, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, w);
         }
       }
       between_eval_hp(Xp, Xq, M, w, eps, ev, &J0d, &J1d, true);
@@ -168,9 +172,9 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
       if (lower) sjac_tmul_acc(J0, narrow<T>(J1d), Off);
     } else {  // p is v1
       if constexpr (ROBUST) {
-        if (d.robust_between) {
+        if (const int code = loss_code(d.robust_between, d.loss_between, e)) {
           between_eval_hp<T>(Xq, Xp, M, w, eps, ev, nullptr, nullptr, false);
-          robust_weights<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, w);
+          robust_weights<T>(code, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, w);
         }
       }
       between_eval_hp(Xq, Xp, M, w, eps, ev, &J0d, &J1d, true);
@@ -203,9 +207,9 @@ pg_assemble_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ H, int64_t
     load6(wp + ((int64_t)id * wB) * 6 + (int64_t)b * d.w_prior_bstride, w);
     SJac<double> Jd;
     if constexpr (ROBUST) {
-      if (d.robust_prior) {
+      if (const int code = loss_code(d.robust_prior, d.loss_prior, id)) {
         local_eval_hp<T>(Tg, Xp, w, eps, ev, nullptr, false);
-        robust_weights<T>(d.robust_prior, d.log_radius_prior, d.log_radius_prior_bstride, id, b, B, ev, w);
+        robust_weights<T>(code, d.log_radius_prior, d.log_radius_prior_bstride, id, b, B, ev, w);
       }
     }
     local_eval_hp(Tg, Xp, w, eps, ev, &Jd, true);
@@ -254,8 +258,8 @@ pg_error_partial_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ parti
     double ev[6];
     load6(wb + ((int64_t)e * wB) * 6 + (int64_t)b * d.w_between_bstride, w);
     between_eval_hp<T>(Xi, Xj, M, w, eps, ev, nullptr, nullptr, false);
-    acc += robust_sq_error<6>(d.robust_between, ev,
-                              d.robust_between ? load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride) : 0.0);
+    const int code = loss_code(d.robust_between, d.loss_between, e);
+    acc += robust_sq_error<6>(code, ev, code ? load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride) : 0.0);
   }
   const T* tgt = static_cast<const T*>(d.prior_target);
   const T* wp = static_cast<const T*>(d.w_prior);
@@ -271,8 +275,8 @@ pg_error_partial_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ parti
     double ev[6];
     load6(wp + ((int64_t)k * wpB) * 6 + (int64_t)b * d.w_prior_bstride, w);
     local_eval_hp<T>(Tg, X, w, eps, ev, nullptr, false);
-    acc += robust_sq_error<6>(d.robust_prior, ev,
-                              d.robust_prior ? load_log_radius<T>(d.log_radius_prior, k, b, B, d.log_radius_prior_bstride) : 0.0);
+    const int code = loss_code(d.robust_prior, d.loss_prior, k);
+    acc += robust_sq_error<6>(code, ev, code ? load_log_radius<T>(d.log_radius_prior, k, b, B, d.log_radius_prior_bstride) : 0.0);
   }
   partials[(int64_t)ch * B + b] = (T)acc;
 }
@@ -312,7 +316,7 @@ pg_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* _
     load6(static_cast<const T*>(d.w_between) + ((int64_t)e * wB) * 6 + (int64_t)b * d.w_between_bstride, w);
     SJac<double> J0d, J1d;
     between_eval_hp(Xi, Xj, M, w, eps, ev, &J0d, &J1d, true);
-    robustify<T>(d.robust_between, d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, &J0d, &J1d);
+    robustify<T>(loss_code(d.robust_between, d.loss_between, e), d.log_radius_between, d.log_radius_between_bstride, e, b, B, ev, &J0d, &J1d);
     const SJac<T> J0 = narrow<T>(J0d), J1 = narrow<T>(J1d);
     const int64_t o = (int64_t)e * B + b;
     if (J0o) {
@@ -339,7 +343,7 @@ pg_jacobians_kernel(thx_pg_structure s, thx_pg_data d, T* __restrict__ J0o, T* _
     load6(static_cast<const T*>(d.w_prior) + ((int64_t)k * wB) * 6 + (int64_t)b * d.w_prior_bstride, w);
     SJac<double> Jd;
     local_eval_hp(Tg, X, w, eps, ev, &Jd, true);
-    robustify<T>(d.robust_prior, d.log_radius_prior, d.log_radius_prior_bstride, k, b, B, ev, &Jd, nullptr);
+    robustify<T>(loss_code(d.robust_prior, d.loss_prior, k), d.log_radius_prior, d.log_radius_prior_bstride, k, b, B, ev, &Jd, nullptr);
     const SJac<T> J = narrow<T>(Jd);
     const int64_t o = (int64_t)k * B + b;
     if (Jpo) {
@@ -481,9 +485,7 @@ static int check_pg(const thx_pg_structure* s, const thx_pg_data* d) {
   if (d->prior_target_bstride != 0 && d->prior_target_bstride != 12) return fail("prior_target_bstride must be 0 or 12");
   if (d->w_between_bstride != 0 && d->w_between_bstride != 6) return fail("w_between_bstride must be 0 or 6");
   if (d->w_prior_bstride != 0 && d->w_prior_bstride != 6) return fail("w_prior_bstride must be 0 or 6");
-  if ((d->robust_between && !d->log_radius_between) || (d->robust_prior && !d->log_radius_prior))
-    return fail("robust cost without log_loss_radius");
-  if (d->robust_between < 0 || d->robust_between > 2 || d->robust_prior < 0 || d->robust_prior > 2) return fail("bad loss kind");
+  if (const char* why = check_robust(d)) return fail(why);
   return 0;
 }
 
@@ -540,7 +542,7 @@ using namespace thx;
 extern "C" {
 
 const char* thx_last_error(void) { return last_error().c_str(); }
-int thx_abi_version(void) { return 17; }
+int thx_abi_version(void) { return 18; }
 
 int thx_copy_where(const uint8_t* mask, const void* src, void* dst, int64_t N, int32_t B, int32_t record_bytes, void* stream) {
   if (!mask || !src || !dst || N < 0 || B <= 0 || record_bytes <= 0 || (record_bytes & 3))

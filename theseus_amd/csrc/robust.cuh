@@ -1,7 +1,10 @@
-// RobustCostFunction on device (theseus/core/robust_cost_function.py:87-135, flatten_dims = False) with the losses of
+// RobustCostFunction on device (theseus/core/robust_cost_function.py:87-135) with the losses of
 // theseus/core/robust_loss.py:33-52.  x = squared norm of the WEIGHTED error, log_radius as stored by the reference.
 //   linearisation pass:  (J, e) <- sqrt(rho'(x) + 1e-20) (J, e)
 //   error metric:        |h|^2 = dim * (rho(x) / dim + 1e-20)
+// flatten_dims = True (robust_cost_function.py:89-96,118-133): every residual row is its own term -- x_r = e_r^2, row r of
+// (J, e) scaled by sqrt(rho'(x_r) + 1e-20), |h|^2 = sum_r (rho(x_r) + 1e-20).
+// A LOSS CODE = THX_LOSS_* | THX_LOSS_FLATTEN; one per cost role, or one per cost (thx_pg_data.loss_between / loss_prior).
 // Evaluated in fp64 registers like the rest of the per-cost chain.
 #pragma once
 #include "../../include/theseus_hip.h"
@@ -58,17 +61,92 @@ __device__ __forceinline__ double sqnorm(const double* e) {
   for (int i = 0; i < DIM; ++i) x += e[i] * e[i];
   return x;
 }
+// the loss code of one cost: the per-cost table when the role has one, else the role's code
+__device__ __forceinline__ int loss_code(int role_code, const int32_t* __restrict__ per_cost, int64_t entity) {
+  return per_cost ? per_cost[entity] : role_code;
+}
+__host__ __device__ __forceinline__ bool loss_code_valid(int code) {
+  return code >= 0 && (code & ~THX_LOSS_FLATTEN) <= THX_LOSS_HUBER && code != THX_LOSS_FLATTEN;
+}
 // what the cost contributes to 2 * error_metric
 template <int DIM>
-__device__ __forceinline__ double robust_sq_error(int kind, const double* e, double log_radius) {
-  const double x = sqnorm<DIM>(e);
-  if (kind == THX_LOSS_NONE) return x;
-  const double h = sqrt(loss_evaluate(kind, x, log_radius) / DIM + kRobustEps);
+__device__ __forceinline__ double robust_sq_error(int code, const double* e, double log_radius) {
+  if (code == THX_LOSS_NONE) return sqnorm<DIM>(e);
+  const int kind = code & ~THX_LOSS_FLATTEN;
+  if (code & THX_LOSS_FLATTEN) {
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+      const double h = sqrt(loss_evaluate(kind, e[i] * e[i], log_radius) + kRobustEps);
+      acc += h * h;
+    }
+    return acc;
+  }
+  const double h = sqrt(loss_evaluate(kind, sqnorm<DIM>(e), log_radius) / DIM + kRobustEps);
   return DIM * (h * h);
 }
+// per-row rescale factors f_r = sqrt(rho'(x_r) + eps) (all equal without flatten_dims; 1 for a plain cost)
 template <int DIM>
-__device__ __forceinline__ double robust_rescale(int kind, const double* e, double log_radius) {
-  return sqrt(loss_linearize(kind, sqnorm<DIM>(e), log_radius) + kRobustEps);
+__device__ __forceinline__ void robust_row_scale(int code, const double* e, double log_radius, double* f) {
+  if (code == THX_LOSS_NONE) {
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) f[i] = 1.0;
+    return;
+  }
+  const int kind = code & ~THX_LOSS_FLATTEN;
+  if (code & THX_LOSS_FLATTEN) {
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) f[i] = sqrt(loss_linearize(kind, e[i] * e[i], log_radius) + kRobustEps);
+  } else {
+    const double s = sqrt(loss_linearize(kind, sqnorm<DIM>(e), log_radius) + kRobustEps);
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) f[i] = s;
+  }
 }
+// host-side validation of the robust fields of a thx_pg_data (NULL: fine)
+inline const char* check_robust(const thx_pg_data* d) {
+  if ((d->robust_between && !d->log_radius_between) || (d->robust_prior && !d->log_radius_prior))
+    return "robust cost without log_loss_radius";
+  if (!loss_code_valid(d->robust_between) || !loss_code_valid(d->robust_prior)) return "bad loss kind";
+  if ((d->loss_between && !d->robust_between) || (d->loss_prior && !d->robust_prior))
+    return "a per-cost loss table needs a non-zero role code (and log_loss_radius)";
+  return nullptr;
+}
+
+// Backward terms of a robust cost whose per-row squared weighted errors are x_r: m_r = rho'(X_r) + eps with its partials at
+// X_r = x_r (flatten_dims) or X_r = sum x (one term).  With phi = sum_r phi_r the plain cost's scalar, the robust one is
+// sum_r m_r phi_r and  d/dtheta = sum_r [ m_r dphi_r + Phi_r m_x,r dx_r ],  d/dlog_radius = sum_r phi_r m_l,r,
+// Phi_r = phi_r (flatten_dims) | phi (one term): ``group`` maps the per-row phi_r to Phi_r in place.
+template <int DIM>
+struct RobustTerms {
+  double m[DIM], m_x[DIM], m_l[DIM];
+  bool flat;
+  __device__ __forceinline__ void eval(int code, const double* x, double log_radius) {
+    flat = (code & THX_LOSS_FLATTEN) != 0;
+    const int kind = code & ~THX_LOSS_FLATTEN;
+    if (code == THX_LOSS_NONE) {
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) { m[r] = 1.0; m_x[r] = 0.0; m_l[r] = 0.0; }
+    } else if (flat) {
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) rescale2_partials(kind, x[r], log_radius, m[r], m_x[r], m_l[r]);
+    } else {
+      double xs = 0.0;
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) xs += x[r];
+      rescale2_partials(kind, xs, log_radius, m[0], m_x[0], m_l[0]);
+#pragma unroll
+      for (int r = 1; r < DIM; ++r) { m[r] = m[0]; m_x[r] = m_x[0]; m_l[r] = m_l[0]; }
+    }
+  }
+  // phi_r -> Phi_r
+  __device__ __forceinline__ void group(const double* phi_r, double* Phi) const {
+    double tot = 0.0;
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) tot += phi_r[r];
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) Phi[r] = flat ? phi_r[r] : tot;
+  }
+};
 
 }  // namespace thx

@@ -18,22 +18,20 @@ __device__ __forceinline__ SE2<double> se2_load_d(const T* __restrict__ p) {
   return SE2<double>{(double)p[0], (double)p[1], (double)p[2], (double)p[3]};
 }
 
-// phi_plain = - sum_r s_r^2 (Jlog q)_r xi_r and x = sum_r (s_r xi_r)^2 for E = Z^-1 C, on any scalar type
+// per row r: phi_r = - s_r^2 (Jlog q)_r xi_r (phi_plain = sum_r phi_r) and x_r = (s_r xi_r)^2 for E = Z^-1 C, on any scalar type
 template <typename S>
 __device__ __forceinline__ void cost_phi2(const SE2<S>& Z, const SE2<S>& C, const double* q, const double* s, const Eps2<S>& eps,
-                                          S& phi, S& x, S* a_out, S* xi_out) {
+                                          S* phi_r, S* x_r, S* a_out, S* xi_out) {
   SE2<S> Zi, E;
   se2_inv(Z, Zi);
   se2_mul(Zi, C, E);
   S xi[3], J[9];
   se2_log_jlog(E, eps, xi, J, true);
-  phi = S(0.0);
-  x = S(0.0);
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const S a = J[3 * r] * S(q[0]) + J[3 * r + 1] * S(q[1]) + J[3 * r + 2] * S(q[2]);
-    phi = phi - S(s[r] * s[r]) * a * xi[r];
-    x = x + S(s[r] * s[r]) * xi[r] * xi[r];
+    phi_r[r] = S(0.0) - S(s[r] * s[r]) * a * xi[r];
+    x_r[r] = S(s[r] * s[r]) * xi[r] * xi[r];
     if (a_out) { a_out[r] = a; xi_out[r] = xi[r]; }
   }
 }
@@ -41,21 +39,29 @@ __device__ __forceinline__ void cost_phi2(const SE2<S>& Z, const SE2<S>& C, cons
 __device__ __forceinline__ void cost_vjp2(const SE2<double>& Z, const SE2<double>& C, const double* q, const double* s,
                                           const Eps2<double>& eps, int loss, double log_radius, double* gZ, double* gs,
                                           double* glr) {
-  double phi, x, a[3], xi[3];
-  cost_phi2<double>(Z, C, q, s, eps, phi, x, a, xi);
-  double m = 1.0, m_x = 0.0, m_l = 0.0;
-  if (loss != THX_LOSS_NONE) rescale2_partials(loss, x, log_radius, m, m_x, m_l);
-  *glr = phi * m_l;
+  double phi_r[3], x_r[3], Phi[3], a[3], xi[3];
+  cost_phi2<double>(Z, C, q, s, eps, phi_r, x_r, a, xi);
+  RobustTerms<3> rt;   // robust.cuh
+  rt.eval(loss, x_r, log_radius);
+  rt.group(phi_r, Phi);
+  double gl = 0.0;
 #pragma unroll
-  for (int r = 0; r < 3; ++r) gs[r] = m * (-2.0 * s[r] * a[r] * xi[r]) + phi * m_x * (2.0 * s[r] * xi[r] * xi[r]);
+  for (int r = 0; r < 3; ++r) {
+    gl += phi_r[r] * rt.m_l[r];
+    gs[r] = rt.m[r] * (-2.0 * s[r] * a[r] * xi[r]) + Phi[r] * rt.m_x[r] * (2.0 * s[r] * xi[r] * xi[r]);
+  }
+  *glr = gl;
   const Eps2<D2> epsd{D2(eps.nz), D2(eps.dnz)};
   const SE2<D2> Cd{D2(C.x), D2(C.y), D2(C.c), D2(C.s)};
   for (int k = 0; k < 4; ++k) {  // one dual evaluation per raw entry [x, y, cos, sin] of Z
     const SE2<D2> Zd{D2(Z.x, k == 0 ? 1.0 : 0.0), D2(Z.y, k == 1 ? 1.0 : 0.0), D2(Z.c, k == 2 ? 1.0 : 0.0),
                      D2(Z.s, k == 3 ? 1.0 : 0.0)};
-    D2 phid, xd;
+    D2 phid[3], xd[3];
     cost_phi2<D2>(Zd, Cd, q, s, epsd, phid, xd, nullptr, nullptr);
-    gZ[k] = m * phid.d + phi * m_x * xd.d;
+    double g = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) g += rt.m[r] * phid[r].d + Phi[r] * rt.m_x[r] * xd[r].d;
+    gZ[k] = g;
   }
 }
 
@@ -94,11 +100,9 @@ pg2_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wvec, in
     }
     outZ = g_meas + ((int64_t)e * B + b) * 4;
     outS = g_wb + ((int64_t)e * B + b) * 3;
-    loss = d.robust_between;
-    if (loss) {
-      lr = load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride);
-      outL = g_lrb ? g_lrb + (int64_t)e * B + b : nullptr;
-    }
+    loss = loss_code(d.robust_between, d.loss_between, e);
+    if (loss) lr = load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride);
+    if (d.robust_between) outL = g_lrb ? g_lrb + (int64_t)e * B + b : nullptr;   // (a plain cost of a mixed role: 0)
   } else {
     const int k = c - s.num_edges, p = s.prior_pose[k];
     const int64_t tB = d.prior_target_bstride ? B : 1, wB = d.w_prior_bstride ? B : 1;
@@ -112,11 +116,9 @@ pg2_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wvec, in
     }
     outZ = g_tgt + ((int64_t)k * B + b) * 4;
     outS = g_wp + ((int64_t)k * B + b) * 3;
-    loss = d.robust_prior;
-    if (loss) {
-      lr = load_log_radius<T>(d.log_radius_prior, k, b, B, d.log_radius_prior_bstride);
-      outL = g_lrp ? g_lrp + (int64_t)k * B + b : nullptr;
-    }
+    loss = loss_code(d.robust_prior, d.loss_prior, k);
+    if (loss) lr = load_log_radius<T>(d.log_radius_prior, k, b, B, d.log_radius_prior_bstride);
+    if (d.robust_prior) outL = g_lrp ? g_lrp + (int64_t)k * B + b : nullptr;
   }
   cost_vjp2(Z, C, q, sw, eps, loss, lr, gZ, gs, &glr);
   if (outL) *outL = (T)glr;
@@ -168,8 +170,7 @@ int thx_pg2_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, 
   if (s->num_edges > 0 && (!grad_meas || !grad_w_between)) return fail("thx_pg2_vjp: null edge gradient buffer");
   if (s->num_priors > 0 && (!grad_prior_target || !grad_w_prior)) return fail("thx_pg2_vjp: null prior gradient buffer");
   if (ldw < 3 * (int64_t)s->num_poses) return fail("thx_pg2_vjp: ldw < n");
-  if ((d->robust_between && !d->log_radius_between) || (d->robust_prior && !d->log_radius_prior))
-    return fail("thx_pg2_vjp: robust cost without log_loss_radius");
+  if (const char* why = check_robust(d)) return fail(why);
   dim3 grid((d->batch + 63) / 64, s->num_edges + s->num_priors), block(64);
   if (grid.y == 0) return 0;
   THX_DISPATCH(dtype,

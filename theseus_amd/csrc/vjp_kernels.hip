@@ -63,11 +63,9 @@ pg_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wvec, int
     }
     outZ = g_meas + ((int64_t)e * B + b) * 12;
     outS = g_wb + ((int64_t)e * B + b) * 6;
-    loss = d.robust_between;
-    if (loss) {
-      lr = load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride);
-      outL = g_lrb ? g_lrb + (int64_t)e * B + b : nullptr;
-    }
+    loss = loss_code(d.robust_between, d.loss_between, e);
+    if (loss) lr = load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride);
+    if (d.robust_between) outL = g_lrb ? g_lrb + (int64_t)e * B + b : nullptr;   // (a plain cost of a mixed role: 0)
   } else {
     const int k = c - s.num_edges, p = s.prior_pose[k];
     const int64_t tB = d.prior_target_bstride ? B : 1, wB = d.w_prior_bstride ? B : 1;
@@ -81,11 +79,9 @@ pg_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wvec, int
     }
     outZ = g_tgt + ((int64_t)k * B + b) * 12;
     outS = g_wp + ((int64_t)k * B + b) * 6;
-    loss = d.robust_prior;
-    if (loss) {
-      lr = load_log_radius<T>(d.log_radius_prior, k, b, B, d.log_radius_prior_bstride);
-      outL = g_lrp ? g_lrp + (int64_t)k * B + b : nullptr;
-    }
+    loss = loss_code(d.robust_prior, d.loss_prior, k);
+    if (loss) lr = load_log_radius<T>(d.log_radius_prior, k, b, B, d.log_radius_prior_bstride);
+    if (d.robust_prior) outL = g_lrp ? g_lrp + (int64_t)k * B + b : nullptr;
   }
   cost_vjp(Z, C, q, sw, eps, loss, lr, gZ, gs, &glr);
   if (outL) *outL = (T)glr;
@@ -142,8 +138,7 @@ int thx_pg_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, i
   if (s->num_edges > 0 && (!grad_meas || !grad_w_between)) return fail("thx_pg_vjp: null edge gradient buffer");
   if (s->num_priors > 0 && (!grad_prior_target || !grad_w_prior)) return fail("thx_pg_vjp: null prior gradient buffer");
   if (ldw < 6 * (int64_t)s->num_poses) return fail("thx_pg_vjp: ldw < n");
-  if ((d->robust_between && !d->log_radius_between) || (d->robust_prior && !d->log_radius_prior))
-    return fail("thx_pg_vjp: robust cost without log_loss_radius");
+  if (const char* why = check_robust(d)) return fail(why);
   dim3 grid((d->batch + 63) / 64, s->num_edges + s->num_priors), block(64);
   if (grid.y == 0) return 0;
   THX_DISPATCH(dtype,

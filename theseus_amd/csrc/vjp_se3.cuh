@@ -1,6 +1,6 @@
 // SE3 cost-term VJP shared by the pose-graph (vjp_kernels.hip) and the bundle-adjustment (ba_vjp_kernels.hip) backward
-// kernels: gradient of  phi = - m(x, log_radius) sum_r s_r^2 (Jlog(E) q)_r log(E)_r ,  E = Z^-1 C, w.r.t. the 12 raw entries of
-// Z, the 6 weights s and log_radius -- see vjp_kernels.hip for the derivation and the torchlie backward semantics it follows.
+// kernels: gradient of  phi = - sum_r m_r(x, log_radius) s_r^2 (Jlog(E) q)_r log(E)_r ,  E = Z^-1 C, w.r.t. the 12 raw entries of
+// Z, the 6 weights s and log_radius (m_r: one factor for the cost, or one per row with flatten_dims) -- see vjp_kernels.hip for the derivation and the torchlie backward semantics it follows.
 #pragma once
 #include "common.cuh"
 #include "dual.cuh"
@@ -43,19 +43,23 @@ __device__ __forceinline__ void cost_vjp(const SE3<double>& Z, const SE3<double>
       a[3 + i] = t2[i];
     }
   }
-  // robust factor m(x, log_radius) and the plain phi
-  double m = 1.0, m_x = 0.0, m_l = 0.0, phi = 0.0;
+  // robust factors m_r(x, log_radius) and the plain per-row phi_r (robust.cuh: RobustTerms)
+  double phi_r[6], x_r[6], Phi[6];
 #pragma unroll
-  for (int r = 0; r < 6; ++r) phi -= s[r] * s[r] * a[r] * xi[r];
-  if (loss != THX_LOSS_NONE) {
-    double x = 0.0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) x += (s[r] * xi[r]) * (s[r] * xi[r]);
-    rescale2_partials(loss, x, log_radius, m, m_x, m_l);
+  for (int r = 0; r < 6; ++r) {
+    phi_r[r] = -s[r] * s[r] * a[r] * xi[r];
+    x_r[r] = (s[r] * xi[r]) * (s[r] * xi[r]);
   }
-  *glr = phi * m_l;
+  RobustTerms<6> rt;
+  rt.eval(loss, x_r, log_radius);
+  rt.group(phi_r, Phi);
+  double gl = 0.0;
 #pragma unroll
-  for (int r = 0; r < 6; ++r) gs[r] = m * (-2.0 * s[r] * a[r] * xi[r]) + phi * m_x * (2.0 * s[r] * xi[r] * xi[r]);
+  for (int r = 0; r < 6; ++r) {
+    gl += phi_r[r] * rt.m_l[r];
+    gs[r] = rt.m[r] * (-2.0 * s[r] * a[r] * xi[r]) + Phi[r] * rt.m_x[r] * (2.0 * s[r] * xi[r] * xi[r]);
+  }
+  *glr = gl;
   const Eps<D2> epsd{D2(eps.nz), D2(eps.dnz), D2(eps.npi)};
   SE3<D2> Cd;
 #pragma unroll
@@ -110,13 +114,11 @@ __device__ __forceinline__ void cost_vjp(const SE3<double>& Z, const SE3<double>
       da[i] = top;
       da[3 + i] = bot;
     }
-    double g = 0.0, dx = 0.0;
+    double g = 0.0;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      g -= s[r] * s[r] * (da[r] * xi[r] + a[r] * dxi[r]);
-      dx += 2.0 * s[r] * s[r] * xi[r] * dxi[r];
-    }
-    gZ[k] = m * g + phi * m_x * dx;
+    for (int r = 0; r < 6; ++r)
+      g += rt.m[r] * (-s[r] * s[r] * (da[r] * xi[r] + a[r] * dxi[r])) + Phi[r] * rt.m_x[r] * (2.0 * s[r] * s[r] * xi[r] * dxi[r]);
+    gZ[k] = g;
   }
 }
 

@@ -29,18 +29,22 @@ __device__ __forceinline__ void cost_vjp_so3(const double* Z, const double* C, c
   mat3_tmul(Z, C, E);
   so3_log_jlog<double>(E, eps, xi, J, true);
   mat3_vec(J, q, a);
-  double m = 1.0, m_x = 0.0, m_l = 0.0, phi = 0.0;
+  double phi_r[3], x_r[3], Phi[3];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) phi -= s[r] * s[r] * a[r] * xi[r];
-  if (loss != THX_LOSS_NONE) {
-    double x = 0.0;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) x += (s[r] * xi[r]) * (s[r] * xi[r]);
-    rescale2_partials(loss, x, log_radius, m, m_x, m_l);
+  for (int r = 0; r < 3; ++r) {
+    phi_r[r] = -s[r] * s[r] * a[r] * xi[r];
+    x_r[r] = (s[r] * xi[r]) * (s[r] * xi[r]);
   }
-  *glr = phi * m_l;
+  RobustTerms<3> rt;   // robust.cuh
+  rt.eval(loss, x_r, log_radius);
+  rt.group(phi_r, Phi);
+  double gl = 0.0;
 #pragma unroll
-  for (int r = 0; r < 3; ++r) gs[r] = m * (-2.0 * s[r] * a[r] * xi[r]) + phi * m_x * (2.0 * s[r] * xi[r] * xi[r]);
+  for (int r = 0; r < 3; ++r) {
+    gl += phi_r[r] * rt.m_l[r];
+    gs[r] = rt.m[r] * (-2.0 * s[r] * a[r] * xi[r]) + Phi[r] * rt.m_x[r] * (2.0 * s[r] * xi[r] * xi[r]);
+  }
+  *glr = gl;
   const Eps<D2> epsd{D2(eps.nz), D2(eps.dnz), D2(eps.npi)};
   D2 Cd[9];
 #pragma unroll
@@ -62,13 +66,11 @@ __device__ __forceinline__ void cost_vjp_so3(const double* Z, const double* C, c
     mat3_vec(J, u, dxi);
 #pragma unroll
     for (int i = 0; i < 3; ++i) da[i] = Jd[3 * i].d * q[0] + Jd[3 * i + 1].d * q[1] + Jd[3 * i + 2].d * q[2];
-    double g = 0.0, dx = 0.0;
+    double g = 0.0;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      g -= s[r] * s[r] * (da[r] * xi[r] + a[r] * dxi[r]);
-      dx += 2.0 * s[r] * s[r] * xi[r] * dxi[r];
-    }
-    gZ[k] = m * g + phi * m_x * dx;
+    for (int r = 0; r < 3; ++r)
+      g += rt.m[r] * (-s[r] * s[r] * (da[r] * xi[r] + a[r] * dxi[r])) + Phi[r] * rt.m_x[r] * (2.0 * s[r] * s[r] * xi[r] * dxi[r]);
+    gZ[k] = g;
   }
 }
 
@@ -107,11 +109,9 @@ pgso3_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wvec, 
     }
     outZ = g_meas + ((int64_t)e * B + b) * 9;
     outS = g_wb + ((int64_t)e * B + b) * 3;
-    loss = d.robust_between;
-    if (loss) {
-      lr = load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride);
-      outL = g_lrb ? g_lrb + (int64_t)e * B + b : nullptr;
-    }
+    loss = loss_code(d.robust_between, d.loss_between, e);
+    if (loss) lr = load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride);
+    if (d.robust_between) outL = g_lrb ? g_lrb + (int64_t)e * B + b : nullptr;   // (a plain cost of a mixed role: 0)
   } else {
     const int k = c - s.num_edges, p = s.prior_pose[k];
     const int64_t tB = d.prior_target_bstride ? B : 1, wB = d.w_prior_bstride ? B : 1;
@@ -125,11 +125,9 @@ pgso3_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wvec, 
     }
     outZ = g_tgt + ((int64_t)k * B + b) * 9;
     outS = g_wp + ((int64_t)k * B + b) * 3;
-    loss = d.robust_prior;
-    if (loss) {
-      lr = load_log_radius<T>(d.log_radius_prior, k, b, B, d.log_radius_prior_bstride);
-      outL = g_lrp ? g_lrp + (int64_t)k * B + b : nullptr;
-    }
+    loss = loss_code(d.robust_prior, d.loss_prior, k);
+    if (loss) lr = load_log_radius<T>(d.log_radius_prior, k, b, B, d.log_radius_prior_bstride);
+    if (d.robust_prior) outL = g_lrp ? g_lrp + (int64_t)k * B + b : nullptr;
   }
   cost_vjp_so3(Z, C, q, sw, eps, loss, lr, gZ, gs, &glr);
   if (outL) *outL = (T)glr;
@@ -177,8 +175,7 @@ int thx_pgso3_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w
   if (s->num_edges > 0 && (!grad_meas || !grad_w_between)) return fail("thx_pgso3_vjp: null edge gradient buffer");
   if (s->num_priors > 0 && (!grad_prior_target || !grad_w_prior)) return fail("thx_pgso3_vjp: null prior gradient buffer");
   if (ldw < 3 * (int64_t)s->num_poses) return fail("thx_pgso3_vjp: ldw < n");
-  if ((d->robust_between && !d->log_radius_between) || (d->robust_prior && !d->log_radius_prior))
-    return fail("thx_pgso3_vjp: robust cost without log_loss_radius");
+  if (const char* why = check_robust(d)) return fail(why);
   dim3 grid((d->batch + 63) / 64, s->num_edges + s->num_priors), block(64);
   if (grid.y == 0) return 0;
   THX_DISPATCH(dtype,

@@ -4,6 +4,7 @@
 that does not depend on a GPU (batch sharding, LM control flow) can be unit-tested on CPU with a
 stand-in injected by tests/; nothing in this package provides such a stand-in.
 """
+import dataclasses
 from dataclasses import dataclass
 from typing import Optional
 
@@ -163,11 +164,18 @@ class PGTensors:
     w_between: torch.Tensor      # (E, Bw, 6)       SE2: (E, Bw, 3)
     prior_target: torch.Tensor   # (K, Bt, 3, 4)
     w_prior: torch.Tensor        # (K, Bw, 6)
-    # RobustCostFunction wrappers: loss kind (_lib.LOSS_*) per role and log_loss_radius (E|K, Br, 1)
+    # RobustCostFunction wrappers: loss code (_lib.LOSS_* [| _lib.LOSS_FLATTEN]) per role and log_loss_radius (E|K, Br, 1);
+    # loss_<role>: (E|K,) int32 code per cost when the costs of one role differ (robust_<role> is then any non-zero code)
     robust_between: int = 0
     log_radius_between: Optional[torch.Tensor] = None
     robust_prior: int = 0
     log_radius_prior: Optional[torch.Tensor] = None
+    loss_between: Optional[torch.Tensor] = None
+    loss_prior: Optional[torch.Tensor] = None
+
+    def without_robust(self) -> "PGTensors":
+        """The same costs with their RobustCostFunction wrappers taken off."""
+        return dataclasses.replace(self, robust_between=0, robust_prior=0, loss_between=None, loss_prior=None)
 
     @property
     def batch(self):
@@ -204,8 +212,15 @@ class PGTensors:
         for role in ("between", "prior"):
             kind = getattr(self, "robust_" + role)
             setattr(d, "robust_" + role, int(kind))
+            table = getattr(self, "loss_" + role)
             if kind:
                 put("log_radius_" + role, getattr(self, "log_radius_" + role), 1)
+                if table is not None:
+                    if table.dtype != torch.int32 or table.shape != (getattr(self, "log_radius_" + role).shape[0],):
+                        raise ValueError(f"loss_{role}: one int32 loss code per cost")
+                    setattr(d, "loss_" + role, _lib.ptr(table, "loss_" + role).value)
+            elif table is not None:
+                raise ValueError(f"loss_{role}: a per-cost loss table needs a non-zero robust_{role}")
         return d
 
 

@@ -11,6 +11,7 @@ import dataclasses
 import weakref
 from typing import Optional
 
+import numpy as np
 import torch
 
 from .compiler import PoseGraphStructure
@@ -60,16 +61,23 @@ _LOSS_KIND = {"WelschLoss": _lib.LOSS_WELSCH, "HuberLoss": _lib.LOSS_HUBER}
 
 
 def _unwrap_robust(c):
-    """cost -> (base cost, loss kind, log_loss_radius variable | None)  (theseus/core/robust_cost_function.py:52-85)."""
+    """cost -> (base cost, loss code, log_loss_radius variable | None); code = _lib.LOSS_* | _lib.LOSS_FLATTEN for
+    ``flatten_dims=True``  (theseus/core/robust_cost_function.py:52-85)."""
     if "RobustCostFunction" not in {k.__name__ for k in type(c).__mro__}:
         return c, _lib.LOSS_NONE, None
     kind = _LOSS_KIND.get(type(c.loss).__name__)
     if kind is None:
         raise UnsupportedObjective(f"HIP backend fuses WelschLoss / HuberLoss; got {type(c.loss).__name__} ({c.name}). "
                                    "There is no CPU/eager fallback.")
-    if c.flatten_dims:
-        raise UnsupportedObjective(f"HIP backend: RobustCostFunction(flatten_dims=True) is not fused ({c.name}).")
-    return c.cost_function, kind, c.log_loss_radius
+    return c.cost_function, kind | (_lib.LOSS_FLATTEN if c.flatten_dims else 0), c.log_loss_radius
+
+
+def _role_codes(codes):
+    """loss codes of one cost role -> (role code, per-cost table | None): one code when all costs agree, else the first non-zero
+    code + the (count,) int32 table (include/theseus_hip.h: thx_pg_data.loss_between / loss_prior)."""
+    if len(set(codes)) <= 1:
+        return (codes[0] if codes else _lib.LOSS_NONE), None
+    return next(c for c in codes if c), np.asarray(codes, dtype=np.int32)
 
 
 def _aux_vars(x):
@@ -104,7 +112,7 @@ class PackedPoseGraph:
         self.prior_costs = []
         row = 0
         self.edge_radius, self.prior_radius = [], []   # log_loss_radius Variable per robust cost
-        kinds = {"Between": set(), "Difference": set()}
+        codes = {"Between": [], "Difference": []}
         for wrapped in objective.cost_functions.values():
             c, loss, radius = _unwrap_robust(wrapped)
             if _kind(c) == "Between":
@@ -112,24 +120,22 @@ class PackedPoseGraph:
                 e_rows.append(row)
                 self.edge_costs.append(c)
                 self.edge_radius.append(radius)
-                kinds["Between"].add(loss)
+                codes["Between"].append(loss)
             elif _kind(c) == "Difference":
                 priors.append(index[c.var.name])
                 p_rows.append(row)
                 self.prior_costs.append(c)
                 self.prior_radius.append(radius)
-                kinds["Difference"].add(loss)
+                codes["Difference"].append(loss)
             else:
                 raise UnsupportedObjective(
                     f"HIP backend has no fused kernel for cost function {type(c).__name__} ({c.name}); "
                     "supported: Between, Difference/Local on SE3 / SE2 / SO3.  There is no CPU/eager fallback.")
             row += c.dim()
-        for role, ks in kinds.items():
-            if len(ks) > 1:
-                raise UnsupportedObjective(f"HIP backend: all {role} costs must share one robust loss kind (or none).")
         self._refuse_fast_approx(UnsupportedObjective)
-        self.robust_between = kinds["Between"].pop() if kinds["Between"] else _lib.LOSS_NONE
-        self.robust_prior = kinds["Difference"].pop() if kinds["Difference"] else _lib.LOSS_NONE
+        # plain, Welsch, Huber and flatten_dims costs may be mixed inside one role: per-cost loss table
+        self.robust_between, self.loss_between = _role_codes(codes["Between"])
+        self.robust_prior, self.loss_prior = _role_codes(codes["Difference"])
         self.structure = PoseGraphStructure.build(len(self.pose_vars), edges, priors, e_rows, p_rows, dof=self.dof)
         self.n = self.structure.num_cols
         self.m = self.structure.num_rows
@@ -238,11 +244,15 @@ class PackedPoseGraph:
             wb = self._stack([_weight_diag(c.weight, dof) for c in self.edge_costs], B) if E else empty(0, 1, dof)
             tgt = self._stack([c.target.tensor for c in self.prior_costs], B) if Kp else empty(0, 1, *gs)
             wp = self._stack([_weight_diag(c.weight, dof) for c in self.prior_costs], B) if Kp else empty(0, 1, dof)
-            lrb = self._stack([r.tensor.view(-1, 1) for r in self.edge_radius], B) if self.robust_between else None
-            lrp = self._stack([r.tensor.view(-1, 1) for r in self.prior_radius], B) if self.robust_prior else None
+            unused = empty(1, 1)   # the log_radius slot of a plain cost inside a mixed role (never read)
+            radii = lambda rs: self._stack([unused if r is None else r.tensor.view(-1, 1) for r in rs], B)  # noqa: E731
+            table = lambda a: None if a is None else torch.from_numpy(a).to(dev)  # noqa: E731
             self.tensors = PGTensors(poses=poses, meas=meas, w_between=wb, prior_target=tgt, w_prior=wp,
-                                     robust_between=self.robust_between, log_radius_between=lrb,
-                                     robust_prior=self.robust_prior, log_radius_prior=lrp)
+                                     robust_between=self.robust_between,
+                                     log_radius_between=radii(self.edge_radius) if self.robust_between else None,
+                                     robust_prior=self.robust_prior,
+                                     log_radius_prior=radii(self.prior_radius) if self.robust_prior else None,
+                                     loss_between=table(self.loss_between), loss_prior=table(self.loss_prior))
         else:
             self.tensors.poses = poses
         # (the auxiliary entries of the deep stamp: what this call saw -- _repoint_variables patches the poses' entries)
@@ -423,7 +433,7 @@ class PackedPoseGraph:
             Jp = torch.empty(max(Kp, 1), B, d, d, dtype=dt, device=dev)
         eb = torch.empty(max(E, 1), B, d, dtype=dt, device=dev)
         ep = torch.empty(max(Kp, 1), B, d, dtype=dt, device=dev)
-        t = self.tensors if robust else dataclasses.replace(self.tensors, robust_between=0, robust_prior=0)
+        t = self.tensors if robust else self.tensors.without_robust()
         self.K.pg_jacobians(self.dstruct, t, J0, J1, eb, Jp, ep)
         if not jacobians:
             return None, None, eb[:E], None, ep[:Kp]
@@ -434,19 +444,24 @@ class PackedPoseGraph:
         _, _, eb, _, ep = self.jacobian_blocks(robust=False, jacobians=False)
         t = self.tensors
 
-        def robust_error(e, kind, lr):
-            # robust_cost_function.py:87-106: ones * sqrt(rho(|e|^2) / dim + eps) -- elementwise torch on the device
-            # the errors live on (Objective.error() is not on the optimiser's path)
-            if not kind:
+        def robust_error(e, role_code, lr, table):
+            # robust_cost_function.py:87-106: ones * sqrt(rho(|e|^2) / dim + eps), or sqrt(rho(e_r^2) + eps) per row with
+            # flatten_dims -- elementwise torch on the device the errors live on (Objective.error() is not on the
+            # optimiser's path)
+            if not role_code:
                 return e
-            x, r = (e ** 2).sum(-1, keepdim=True), lr.exp()
-            if kind == _lib.LOSS_WELSCH:
-                rho = r - r * torch.exp(-x / (r + 1e-20))
-            else:
-                rho = torch.where(x > r, 2 * torch.sqrt(r * torch.maximum(x, r) + 1e-20) - r, x)
-            return torch.ones_like(e) * (rho / e.shape[-1] + 1e-20).sqrt()
-        eb = robust_error(eb, t.robust_between, t.log_radius_between)
-        ep = robust_error(ep, t.robust_prior, t.log_radius_prior)
+            codes = table if table is not None else torch.full((e.shape[0],), role_code, dtype=torch.int32, device=e.device)
+            codes = codes.view(-1, 1, 1)
+            flat, kind = (codes & _lib.LOSS_FLATTEN) != 0, codes & ~_lib.LOSS_FLATTEN
+            x = torch.where(flat, e ** 2, (e ** 2).sum(-1, keepdim=True).expand_as(e))
+            r = lr.exp()
+            welsch = r - r * torch.exp(-x / (r + 1e-20))
+            huber = torch.where(x > r, 2 * torch.sqrt(r * torch.maximum(x, r) + 1e-20) - r, x)
+            rho = torch.where(kind == _lib.LOSS_WELSCH, welsch, huber)
+            h = torch.where(flat, (rho + 1e-20).sqrt(), (rho / e.shape[-1] + 1e-20).sqrt())
+            return torch.where(kind == _lib.LOSS_NONE, e, h)
+        eb = robust_error(eb, t.robust_between, t.log_radius_between, t.loss_between)
+        ep = robust_error(ep, t.robust_prior, t.log_radius_prior, t.loss_prior)
         B = self.batch
         out = torch.empty(B, self.m, dtype=eb.dtype, device=eb.device)
         s = self.structure
