@@ -93,10 +93,12 @@ def run_mixed_implicit(th, g, device, kernels=None, dtype=torch.float64, backwar
     return out
 
 
-def check_grads(g, grads, rel):
+def check_grads(g, grads, rel, keys=None):
     """gradients against the reference's; the radius of a shared-radius cost receives the SUM over the batch in row 0 of the
     fixture's (B, count, 1) leaf (the reference's Variable held ``leaf[:1, k]``) -- same layout on both sides."""
     for key, ref in GRAD_KEYS:
+        if keys is not None and key not in keys:
+            continue
         want = g[ref]
         got = grads[key].double().numpy()
         scale = np.abs(want).max()

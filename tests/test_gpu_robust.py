@@ -14,12 +14,18 @@ from tests.helpers import f32_thresholds, golden_problem, load_golden
 pytestmark = pytest.mark.gpu
 
 
+MIXED = (None, "welsch", "huber", "welsch+flatten", "huber+flatten")
+
+
 def robust_problem(name, kind, dtype, both_roles):
     """A golden pose graph with its costs wrapped in a robust loss; radii chosen so that inliers (x << r), the knee
-    (x ~ r) and outliers (x >> r) all occur at the initial iterate.  Values are rounded to ``dtype`` first."""
+    (x ~ r) and outliers (x >> r) all occur at the initial iterate.  Values are rounded to ``dtype`` first.
+    ``kind`` "mixed": cost k of a role wears MIXED[k % 5] -- plain, Welsch, Huber and flatten_dims=True costs inside one role
+    (the per-cost loss table of thx_pg_data); "welsch+flatten" / "huber+flatten": flatten_dims=True on every cost."""
     g = load_golden(name)
     p, poses0, _ = golden_problem(g)
     B, E, Kp = poses0.shape[0], p.edges.shape[0], p.prior_idx.shape[0]
+    spec = lambda n, off: [MIXED[(k + off) % 5] for k in range(n)] if kind == "mixed" else kind  # noqa: E731
     gen = torch.Generator().manual_seed(5)
     with torch.no_grad():
         eb, ep = opg.weighted_errors(p, poses0)
@@ -145,8 +151,12 @@ def test_mixed_and_flattened_robust_costs_match_the_reference(name, dtype):
         assert abs(r["loss"] - float(g["loss"])) < 1e-6
         check_grads(g, r["grads"], 2e-6)
     else:
+        # fp32: the gradients w.r.t. weights and radii; those w.r.t. the RAW 3x4 entries of measurements / targets (torchlie's
+        # backward convention) move by O(1) of their scale when the iterate moves by the 2e-5 that separates an fp32 run from
+        # an fp64 run on the same fp32 inputs (measured: profiles/r3/s_mixed_robust_f32_gradients.txt) -- they are pinned in
+        # fp64 above and, kernel against oracle on identical inputs, in test_robust_vjp_vs_oracle_autograd
         assert abs(r["loss"] - float(g["loss"])) < 2e-3 * max(1.0, abs(float(g["loss"])))
-        check_grads(g, r["grads"], 5e-2)
+        check_grads(g, r["grads"], 2e-2, keys=("w_between", "w_prior", "log_radius_between", "log_radius_prior"))
 
 
 def test_reference_pgo_known_answer_through_the_hip_path():
