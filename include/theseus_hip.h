@@ -373,8 +373,12 @@ int thx_pg_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, i
  *        S = Hcc' - Hcp Hpp'^-1 Hpc,  rhs = gc - Hcp Hpp'^-1 gp,  S delta_c = rhs  (thx_chol_factor_forward, no damping),
  *        delta_p = Hpp'^-1 (gp - Hpc delta_c);   ' = damping applied (dense_solver.py:38-64).
  *      Internal column order: cameras (6 each) then points (3 each); g / delta / diag are (B, n), n = 6C + 3Np.
- *      Layouts (entity major, batch fastest): cams (C,B,3,4), points (Np,B,3), Hcc (C,B,6,6), Hpp (Np,B,6) =
- *      [xx,xy,xz,yy,yz,zz], W (O,B,6,3) = Jc^T Jp per observation, Hinv (Np,B,6), tvec (B,3Np), gd (B,n).
+ *      Layouts: variables and auxiliary data entity major, batch next: cams (C,B,3,4), points (Np,B,3); gd (B,n).  The fp64
+ *      block workspaces are PLANAR -- (entity, component, B), the batch index INNERMOST: Hcc (C,36,B) row-major 6x6 blocks,
+ *      Hpp / Hinv (Np,6,B) = [xx,xy,xz,yy,yz,zz], W (O,18,B) = Jc^T Jp (6x3 row major) per observation, tvec (Np,3,B).  A
+ *      lane of these kernels is one (entity, problem) and a wave is 64 consecutive problems of one entity: component i of the
+ *      wave is 512 contiguous bytes, every load / store instruction moves full lines (with a record per lane -- (entity, B,
+ *      component) -- a 16-byte load of the 144-byte W records touched 72 lines, each of them nine times).
  *      PRECISION: the block quantities Hcc, Hpp, W, gd, Hinv, tvec are ALWAYS fp64 buffers, whatever `dtype` is: the
  *      Schur complement subtracts quantities of the size of Hcc from Hcc, so fp32 blocks would put fp32 rounding of
  *      |Hcc| -- not of |S| -- into S.  S, rhs, g, diag, delta are `dtype` (S feeds the fp32 / fp64 MFMA Cholesky). */

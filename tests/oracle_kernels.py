@@ -161,11 +161,12 @@ class OracleKernels:
         gc.index_add_(1, p.cam_prior_idx, -(Jcp.transpose(2, 3) @ ecp.unsqueeze(3)).squeeze(3).expand(B, -1, 6))
         gp = torch.zeros(B, Np, 3, dtype=g.dtype).index_add_(1, p.obs_pt, -(Jp.transpose(2, 3) @ e.unsqueeze(3)).squeeze(3))
         gp.index_add_(1, p.pt_prior_idx, -(p.w_pt_prior * ept).expand(B, -1, 3))
-        Hcc.copy_(hcc.transpose(0, 1))
+        planar = lambda x: x.reshape(x.shape[0], x.shape[1], -1).permute(1, 2, 0)  # noqa: E731  (B, N, ...) -> (N, comps, B)
+        Hcc.copy_(planar(hcc))
         iu = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
-        Hpp.copy_(torch.stack([hpp[:, :, i, j] for i, j in iu], -1).transpose(0, 1))
+        Hpp.copy_(planar(torch.stack([hpp[:, :, i, j] for i, j in iu], -1)))
         if p.obs_cam.numel():
-            W[:p.obs_cam.numel()].copy_((Jc.transpose(2, 3) @ Jp).transpose(0, 1))
+            W[:p.obs_cam.numel()].copy_(planar(Jc.transpose(2, 3) @ Jp))
         g[:, :6 * C] = gc.reshape(B, -1)
         g[:, 6 * C:] = gp.reshape(B, -1)
         gd.copy_(g)
@@ -240,7 +241,8 @@ class OracleKernels:
         C, Np, O = h.num_cams, h.num_points, h.num_obs
         B = g.shape[0]
         oc, op = (torch.from_numpy(h.t[k].astype("int64"))[:O] for k in ("obs_cam", "obs_pt"))
-        hcc, hpp = Hcc.transpose(0, 1).clone(), self._sym3(Hpp.transpose(0, 1))
+        batch_major = lambda x, *sh: x.permute(2, 0, 1).reshape(x.shape[2], x.shape[0], *sh)  # noqa: E731  planar -> (B, N, ...)
+        hcc, hpp = batch_major(Hcc, 6, 6).clone(), self._sym3(batch_major(Hpp, 6))
         if damping is not None:
             lam = damping.view(B, 1, 1)
             dc, dp = hcc.diagonal(dim1=2, dim2=3), hpp.diagonal(dim1=2, dim2=3)
@@ -249,11 +251,11 @@ class OracleKernels:
         _, inf = torch.linalg.cholesky_ex(hpp)
         info.copy_((inf != 0).any(1).to(info.dtype))
         hi = torch.linalg.inv(hpp)
-        Hinv.copy_(torch.stack([hi[..., 0, 0], hi[..., 0, 1], hi[..., 0, 2], hi[..., 1, 1], hi[..., 1, 2], hi[..., 2, 2]], -1).transpose(0, 1))
+        Hinv.copy_(torch.stack([hi[..., 0, 0], hi[..., 0, 1], hi[..., 0, 2], hi[..., 1, 1], hi[..., 1, 2], hi[..., 2, 2]], -1).permute(1, 2, 0))
         gp = g[:, 6 * C:].reshape(B, Np, 3)
         tv = (hi @ gp.unsqueeze(3)).squeeze(3)
-        tvec.copy_(tv.reshape(B, -1))
-        Wb = W[:O].transpose(0, 1)                                        # (B,O,6,3)
+        tvec.copy_(tv.permute(1, 2, 0))
+        Wb = batch_major(W[:O], 6, 3)                                     # (B,O,6,3)
         Hcp = torch.zeros(B, 6 * C, 3 * Np, dtype=g.dtype)
         for o in range(O):
             c, p_ = int(oc[o]), int(op[o])
@@ -274,10 +276,11 @@ class OracleKernels:
         B = delta.shape[0]
         oc, op = (torch.from_numpy(h.t[k].astype("int64"))[:O] for k in ("obs_cam", "obs_pt"))
         dc = delta[:, :6 * C].reshape(B, C, 6)
+        batch_major = lambda x, *sh: x.permute(2, 0, 1).reshape(x.shape[2], x.shape[0], *sh)  # noqa: E731  planar -> (B, N, ...)
         acc = torch.zeros(B, Np, 3, dtype=delta.dtype).index_add_(
-            1, op, (W[:O].transpose(0, 1).transpose(2, 3) @ dc[:, oc].unsqueeze(3)).squeeze(3))
-        hi = self._sym3(Hinv.transpose(0, 1))
-        delta[:, 6 * C:] = (tvec.reshape(B, Np, 3) - (hi @ acc.unsqueeze(3)).squeeze(3)).reshape(B, -1)
+            1, op, (batch_major(W[:O], 6, 3).transpose(2, 3) @ dc[:, oc].unsqueeze(3)).squeeze(3))
+        hi = self._sym3(batch_major(Hinv, 6))
+        delta[:, 6 * C:] = (batch_major(tvec, 3) - (hi @ acc.unsqueeze(3)).squeeze(3)).reshape(B, -1)
 
     def ba_error(self, s, t, partials, err, cams=None, points=None):
         p, state = self._ba_problem(s, t, cams, points)

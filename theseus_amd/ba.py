@@ -483,8 +483,9 @@ class HipSchurLinearizationCore:
             new = lambda *sh: torch.empty(*sh, dtype=dt, device=dev)  # noqa: E731
             f64 = lambda *sh: torch.empty(*sh, dtype=torch.float64, device=dev)  # noqa: E731
             # block quantities in fp64 for every dtype: the Schur complement cancels at the scale of Hcc
-            self.Hcc, self.Hpp = f64(s.num_cams, B, 6, 6), f64(s.num_points, B, 6)
-            self.W, self.gd = f64(max(s.num_obs, 1), B, 6, 3), f64(B, p.n)
+            # (planar workspaces: (entity, component, B), the batch innermost -- include/theseus_hip.h, "Layouts")
+            self.Hcc, self.Hpp = f64(s.num_cams, 36, B), f64(s.num_points, 6, B)
+            self.W, self.gd = f64(max(s.num_obs, 1), 18, B), f64(B, p.n)
             self.g, self.diag = new(B, p.n), new(B, p.n)
 
     def _assemble(self):
@@ -564,8 +565,8 @@ class HipSchurSolverCore:
             self.L = torch.zeros_like(self.S)
             self.panels = torch.empty(B, nt, _lib.THX_TILE, _lib.THX_TILE, dtype=dt, device=dev)
             self.rhs, self._y, self._dc = (torch.empty(B, nc, dtype=dt, device=dev) for _ in range(3))
-            self.Hinv = torch.empty(s.num_points, B, 6, dtype=torch.float64, device=dev)
-            self.tvec = torch.empty(B, 3 * s.num_points, dtype=torch.float64, device=dev)
+            self.Hinv = torch.empty(s.num_points, 6, B, dtype=torch.float64, device=dev)
+            self.tvec = torch.empty(s.num_points, 3, B, dtype=torch.float64, device=dev)
             self.delta = torch.empty(B, lin.n, dtype=dt, device=dev)
             self.info_chol = torch.zeros(B, dtype=torch.int32, device=dev)
             self.info_pts = torch.zeros(B, dtype=torch.int32, device=dev)

@@ -2,6 +2,7 @@
 // Jacobian evaluation, block assembly, Schur complement on the camera block, back substitution, error metric.
 // Same mapping as the pose-graph kernels: one lane per (entity, problem), batch index fastest across the wave, entity
 // tables wave-uniform, owner-computes (no atomics, bit-reproducible); per-cost arithmetic in fp64 registers.
+#include <type_traits>
 #include "common.cuh"
 #include "robust.cuh"
 
@@ -72,6 +73,19 @@ __device__ __forceinline__ SE3<double> load_cam(const T* __restrict__ p) {
   return X;
 }
 
+// The fp64 block workspaces of this path -- W (O, 18), Hcc (C, 36), Hpp / Hinv (Np, 6), tvec (Np, 3) -- are PLANAR: (entity,
+// component, B) with the batch index innermost.  A lane is one (entity, problem); the 64 lanes of a wave are 64 consecutive
+// problems of ONE entity, so component i of all lanes is 512 contiguous bytes: every load / store instruction moves four full
+// 128-B lines.  With the record-per-lane layout (entity, B, component) a wave's 16-byte load of an 144-byte W record touched 72
+// lines and every line was touched by nine different instructions (ba_schur_block: 2.4-2.7 ms for 1.3 GB of W).
+#ifndef THX_BA_PLANAR
+#define THX_BA_PLANAR 1
+#endif
+template <int NC>
+__device__ __forceinline__ int64_t ws_at(int64_t entity, int i, int b, int B) {
+  return THX_BA_PLANAR ? (entity * NC + i) * (int64_t)B + b : (entity * (int64_t)B + b) * NC + i;
+}
+
 // everything one observation needs besides its two variables
 template <typename T>
 struct ObsAux {
@@ -129,11 +143,10 @@ ba_point_kernel(thx_ba_structure s, thx_ba_data d, double* __restrict__ Hpp, dou
     h[5] += r.Jp[2] * r.Jp[2] + r.Jp[5] * r.Jp[5];
 #pragma unroll
     for (int i = 0; i < 3; ++i) gp[i] -= r.Jp[i] * r.e[0] + r.Jp[3 + i] * r.e[1];
-    double* Wo = W + ((int64_t)o * B + b) * 18;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) Wo[3 * i + j] = r.Jc[i] * r.Jp[j] + r.Jc[6 + i] * r.Jp[3 + j];
+      for (int j = 0; j < 3; ++j) W[ws_at<18>(o, 3 * i + j, b, B)] = r.Jc[i] * r.Jp[j] + r.Jc[6 + i] * r.Jp[3 + j];
   }
   for (int k = s.pt_prior_ptr[p]; k < s.pt_prior_ptr[p + 1]; ++k) {
     const int id = s.pt_prior_id[k];
@@ -149,9 +162,8 @@ ba_point_kernel(thx_ba_structure s, thx_ba_data d, double* __restrict__ Hpp, dou
       gp[i] -= w * e;
     }
   }
-  double* Hp = Hpp + ((int64_t)p * B + b) * 6;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) Hp[i] = h[i];
+  for (int i = 0; i < 6; ++i) Hpp[ws_at<6>(p, i, b, B)] = h[i];
   const int64_t col = 6 * (int64_t)s.num_cams + 3 * p;
   T* gb = g + (int64_t)b * ldv + col;
   T* db = diag + (int64_t)b * ldv + col;
@@ -205,9 +217,8 @@ ba_camera_kernel(thx_ba_structure s, thx_ba_data d, double* __restrict__ Hcc, do
     sjac_tmul_acc(Jd, Jd, Hc);
     sjac_tvec_sub(Jd, ev, gc);
   }
-  double* Ho = Hcc + ((int64_t)c * B + b) * 36;
 #pragma unroll
-  for (int i = 0; i < 36; ++i) Ho[i] = Hc[i];
+  for (int i = 0; i < 36; ++i) Hcc[ws_at<36>(c, i, b, B)] = Hc[i];
   T* gb = g + (int64_t)b * ldv + 6 * c;
   T* db = diag + (int64_t)b * ldv + 6 * c;
   double* gdb = gd + (int64_t)b * ldv + 6 * c;
@@ -227,7 +238,9 @@ ba_point_invert_kernel(thx_ba_structure s, int B, const double* __restrict__ Hpp
                        double* __restrict__ tvec, int32_t* __restrict__ info) {
   const int b = blockIdx.x * 64 + threadIdx.x, p = blockIdx.y;
   if (b >= B) return;
-  const double* Hp = Hpp + ((int64_t)p * B + b) * 6;
+  double Hp[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Hp[i] = Hpp[ws_at<6>(p, i, b, B)];
   double hd[3] = {Hp[0], Hp[3], Hp[5]};
   if (damping) {  // DenseSolver._apply_damping (dense_solver.py:38-64)
     const double lam = (double)damping[b];
@@ -242,15 +255,33 @@ ba_point_invert_kernel(thx_ba_structure s, int B, const double* __restrict__ Hpp
   if (!(a > 0.0) || !(m2 > 0.0) || !(det > 0.0)) info[b] = 6 * s.num_cams + 3 * p + 1;  // any writer: value only flags failure
   const double id = 1.0 / det;
   const double inv[6] = {A * id, Bc * id, C * id, (a * f - c * c) * id, (bb * c - a * e) * id, m2 * id};
-  double* Ho = Hinv + ((int64_t)p * B + b) * 6;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) Ho[i] = inv[i];
+  for (int i = 0; i < 6; ++i) Hinv[ws_at<6>(p, i, b, B)] = inv[i];
   const double* gp = g + (int64_t)b * ldv + 6 * (int64_t)s.num_cams + 3 * p;
   const double g0 = gp[0], g1 = gp[1], g2 = gp[2];
-  double* tp = tvec + (int64_t)b * (3 * (int64_t)s.num_points) + 3 * p;
-  tp[0] = inv[0] * g0 + inv[1] * g1 + inv[2] * g2;
-  tp[1] = inv[1] * g0 + inv[3] * g1 + inv[4] * g2;
-  tp[2] = inv[2] * g0 + inv[4] * g1 + inv[5] * g2;
+  tvec[ws_at<3>(p, 0, b, B)] = inv[0] * g0 + inv[1] * g1 + inv[2] * g2;
+  tvec[ws_at<3>(p, 1, b, B)] = inv[1] * g0 + inv[3] * g1 + inv[4] * g2;
+  tvec[ws_at<3>(p, 2, b, B)] = inv[2] * g0 + inv[4] * g1 + inv[5] * g2;
+}
+
+// one 6-element row of an S block: three 2-element stores when the frame allows (ld even: every row of a 6 x 6 block then
+// starts on a 2-element boundary) -- a lane's row is 24 (fp32) / 48 (fp64) contiguous bytes of ITS problem's frame, nothing
+// coalesces across lanes, so the number of store instructions (each 64 partial-line writes) is what counts
+template <typename T>
+__device__ __forceinline__ void store_row6(T* __restrict__ p, const double* v, bool pairs) {
+  using T2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+  if (pairs) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      T2 w;
+      w.x = (T)v[2 * c];
+      w.y = (T)v[2 * c + 1];
+      *reinterpret_cast<T2*>(p + 2 * c) = w;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) p[c] = (T)v[c];
+  }
 }
 
 // M (6x3) = W (6x3) * Hinv (sym 3x3)
@@ -281,13 +312,10 @@ ba_schur_block_kernel(thx_ba_structure s, int B, const double* __restrict__ W, c
     const int o1 = s.pair_o1[q], o2 = s.pair_o2[q];
     const int p = s.obs_pt[o1];
     double W1[18], W2[18], h[6], M[18];
-    const double* W1p = W + ((int64_t)o1 * B + b) * 18;
-    const double* W2p = W + ((int64_t)o2 * B + b) * 18;
-    const double* hp = Hinv + ((int64_t)p * B + b) * 6;
 #pragma unroll
-    for (int i = 0; i < 18; ++i) { W1[i] = W1p[i]; W2[i] = W2p[i]; }
+    for (int i = 0; i < 18; ++i) { W1[i] = W[ws_at<18>(o1, i, b, B)]; W2[i] = W[ws_at<18>(o2, i, b, B)]; }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) h[i] = hp[i];
+    for (int i = 0; i < 6; ++i) h[i] = Hinv[ws_at<6>(p, i, b, B)];
     w_times_sym(W1, h, M);
 #pragma unroll
     for (int r = 0; r < 6; ++r)
@@ -296,10 +324,9 @@ ba_schur_block_kernel(thx_ba_structure s, int B, const double* __restrict__ W, c
         Off[6 * r + c] -= M[3 * r] * W2[3 * c] + M[3 * r + 1] * W2[3 * c + 1] + M[3 * r + 2] * W2[3 * c + 2];
   }
   T* Sb = S + (int64_t)b * ld * ld;
+  const bool pairs = (ld & 1) == 0;
 #pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = 0; c < 6; ++c) Sb[(int64_t)(6 * c1 + r) * ld + 6 * c2 + c] = (T)Off[6 * r + c];
+  for (int r = 0; r < 6; ++r) store_row6(Sb + (int64_t)(6 * c1 + r) * ld + 6 * c2, Off + 6 * r, pairs);
 }
 
 // ---- Schur 2b: one lane per (camera c1, problem): the diagonal block S_c1c1 (Hcc' - its pairs) and rhs_c1 ----
@@ -312,14 +339,13 @@ ba_schur_kernel(thx_ba_structure s, int B, const double* __restrict__ Hcc, const
   const int b = blockIdx.x * 64 + threadIdx.x, c1 = blockIdx.y;
   if (b >= B) return;
   double Dg[36], rv[6];
-  const double* Hc = Hcc + ((int64_t)c1 * B + b) * 36;
 #pragma unroll
-  for (int i = 0; i < 36; ++i) Dg[i] = Hc[i];
+  for (int i = 0; i < 36; ++i) Dg[i] = Hcc[ws_at<36>(c1, i, b, B)];
   if (damping) {
     const double lam = (double)damping[b];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const double h = Hc[7 * i];
+      const double h = Dg[7 * i];
       Dg[7 * i] = ellipsoidal ? h + (lam * h + (double)eps) : h + lam;
     }
   }
@@ -332,24 +358,20 @@ ba_schur_kernel(thx_ba_structure s, int B, const double* __restrict__ Hcc, const
     const int o1 = s.pair_o1[k], o2 = s.pair_o2[k];
     const int p = s.obs_pt[o1];
     double W1[18], W2[18], h[6], M[18];
-    const double* W1p = W + ((int64_t)o1 * B + b) * 18;
-    const double* W2p = W + ((int64_t)o2 * B + b) * 18;
-    const double* hp = Hinv + ((int64_t)p * B + b) * 6;
 #pragma unroll
-    for (int i = 0; i < 18; ++i) W1[i] = W1p[i];
+    for (int i = 0; i < 18; ++i) W1[i] = W[ws_at<18>(o1, i, b, B)];
     if (o1 == o2) {   // (block uniform: the structure is shared by the batch) a camera sees a point once -- the usual case
 #pragma unroll
       for (int i = 0; i < 18; ++i) W2[i] = W1[i];
-      const double* tp = tvec + (int64_t)b * (3 * (int64_t)s.num_points) + 3 * p;
-      const double t0 = tp[0], t1 = tp[1], t2 = tp[2];
+      const double t0 = tvec[ws_at<3>(p, 0, b, B)], t1 = tvec[ws_at<3>(p, 1, b, B)], t2 = tvec[ws_at<3>(p, 2, b, B)];
 #pragma unroll
       for (int i = 0; i < 6; ++i) rv[i] -= W1[3 * i] * t0 + W1[3 * i + 1] * t1 + W1[3 * i + 2] * t2;
     } else {
 #pragma unroll
-      for (int i = 0; i < 18; ++i) W2[i] = W2p[i];
+      for (int i = 0; i < 18; ++i) W2[i] = W[ws_at<18>(o2, i, b, B)];
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) h[i] = hp[i];
+    for (int i = 0; i < 6; ++i) h[i] = Hinv[ws_at<6>(p, i, b, B)];
     w_times_sym(W1, h, M);
 #pragma unroll
     for (int r = 0; r < 6; ++r)
@@ -357,10 +379,9 @@ ba_schur_kernel(thx_ba_structure s, int B, const double* __restrict__ Hcc, const
       for (int c = 0; c < 6; ++c)
         Dg[6 * r + c] -= M[3 * r] * W2[3 * c] + M[3 * r + 1] * W2[3 * c + 1] + M[3 * r + 2] * W2[3 * c + 2];
   }
+  const bool pairs = (ld & 1) == 0;
 #pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = 0; c < 6; ++c) Sb[(int64_t)(6 * c1 + r) * ld + 6 * c1 + c] = (T)Dg[6 * r + c];
+  for (int r = 0; r < 6; ++r) store_row6(Sb + (int64_t)(6 * c1 + r) * ld + 6 * c1, Dg + 6 * r, pairs);
 #pragma unroll
   for (int i = 0; i < 6; ++i) rhs[(int64_t)b * ldr + 6 * c1 + i] = (T)rv[i];
 }
@@ -375,18 +396,20 @@ ba_backsub_kernel(thx_ba_structure s, int B, const double* __restrict__ W, const
   double acc[3] = {0, 0, 0};
   for (int k = s.pt_ptr[p]; k < s.pt_ptr[p + 1]; ++k) {
     const int o = s.pt_obs[k], c = s.obs_cam[o];
-    const double* Wo = W + ((int64_t)o * B + b) * 18;
     const T* dc = delta + (int64_t)b * ldv + 6 * c;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const double di = (double)dc[i];
-      acc[0] += Wo[3 * i] * di;
-      acc[1] += Wo[3 * i + 1] * di;
-      acc[2] += Wo[3 * i + 2] * di;
+      acc[0] += W[ws_at<18>(o, 3 * i, b, B)] * di;
+      acc[1] += W[ws_at<18>(o, 3 * i + 1, b, B)] * di;
+      acc[2] += W[ws_at<18>(o, 3 * i + 2, b, B)] * di;
     }
   }
-  const double* h = Hinv + ((int64_t)p * B + b) * 6;
-  const double* tp = tvec + (int64_t)b * (3 * (int64_t)s.num_points) + 3 * p;
+  double h[6], tp[3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) h[i] = Hinv[ws_at<6>(p, i, b, B)];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tp[i] = tvec[ws_at<3>(p, i, b, B)];
   T* dp = delta + (int64_t)b * ldv + 6 * (int64_t)s.num_cams + 3 * p;
   dp[0] = (T)(tp[0] - (h[0] * acc[0] + h[1] * acc[1] + h[2] * acc[2]));
   dp[1] = (T)(tp[1] - (h[1] * acc[0] + h[3] * acc[1] + h[4] * acc[2]));
