@@ -2,7 +2,6 @@
 // Jacobian evaluation, block assembly, Schur complement on the camera block, back substitution, error metric.
 // Same mapping as the pose-graph kernels: one lane per (entity, problem), batch index fastest across the wave, entity
 // tables wave-uniform, owner-computes (no atomics, bit-reproducible); per-cost arithmetic in fp64 registers.
-#include <type_traits>
 #include "common.cuh"
 #include "robust.cuh"
 
@@ -266,16 +265,16 @@ ba_point_invert_kernel(thx_ba_structure s, int B, const double* __restrict__ Hpp
 
 // one 6-element row of an S block: three 2-element stores when the frame allows (ld even: every row of a 6 x 6 block then
 // starts on a 2-element boundary) -- a lane's row is 24 (fp32) / 48 (fp64) contiguous bytes of ITS problem's frame, nothing
-// coalesces across lanes, so the number of store instructions (each 64 partial-line writes) is what counts
+// coalesces across lanes, so the number of store instructions (each 64 partial-line writes) is what counts.  Measured on one box
+// (profiles/r3/y_ab_ba_schur_store_modes.txt): nontemporal stores 2.3x SLOWER (the write-back L2 merges the segments of a line),
+// one 4- + one 2-element store per row slower too (3.6 vs 3.15 ms: the alignment branch)
 template <typename T>
 __device__ __forceinline__ void store_row6(T* __restrict__ p, const double* v, bool pairs) {
-  using T2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+  typedef T T2 __attribute__((ext_vector_type(2)));
   if (pairs) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      T2 w;
-      w.x = (T)v[2 * c];
-      w.y = (T)v[2 * c + 1];
+      const T2 w = {(T)v[2 * c], (T)v[2 * c + 1]};
       *reinterpret_cast<T2*>(p + 2 * c) = w;
     }
   } else {
