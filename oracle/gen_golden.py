@@ -509,6 +509,58 @@ def gen_pg_full_implicit(th, lieF):
           "|grad_rel_wp|", wp.grad.abs().max().item())
 
 
+def gen_simple_example(th):
+    """BASELINE.json configs[0]: examples/simple_example.py -- fit y = v exp(x), an AutoDiffCostFunction on a Vector, batch 16,
+    GaussNewton + CholeskyDenseSolver, implicit backward w.r.t. the auxiliary variable x through TheseusLayer -- and a two-
+    variable LM variant (y = a exp(b x) is nonlinear in (a, b): damping, several iterations, two blocks per cost)."""
+    dtype = torch.float64
+    B, N = 16, 20
+    gen = torch.Generator().manual_seed(0)
+    x_true = torch.linspace(-1, 1, N, dtype=dtype).view(1, -1).repeat(B, 1)
+    c_true = 0.5 + 0.2 * torch.rand(B, 1, dtype=dtype, generator=gen)
+    y = c_true * torch.exp(x_true)
+    x0 = x_true + 0.05 * torch.randn(B, N, dtype=dtype, generator=gen)
+    out = dict(x0=x0.numpy(), y=y.numpy())
+    # (1) the example
+    x, yv, v = th.Variable(x0.clone(), name="x"), th.Variable(y, name="y"), th.Vector(1, name="v", dtype=dtype)
+
+    def error_fn(optim_vars, aux_vars):
+        xx, yy = aux_vars
+        return yy.tensor - optim_vars[0].tensor * torch.exp(xx.tensor)
+    obj = th.Objective(dtype=dtype)
+    obj.add(th.AutoDiffCostFunction([v], error_fn, N, aux_vars=[x, yv], cost_weight=th.ScaleCostWeight(torch.tensor(1.0, dtype=dtype))))
+    layer = th.TheseusLayer(th.GaussNewton(obj, max_iterations=10))
+    phi = x0.clone().requires_grad_(True)
+    sol, info = layer.forward(input_tensors={"x": phi, "v": torch.ones(B, 1, dtype=dtype)},
+                              optimizer_kwargs={"backward_mode": "implicit", "track_err_history": True})
+    loss = ((sol["v"] - 0.5) ** 2).mean()
+    loss.backward()
+    out.update(v=sol["v"].detach().numpy(), loss=loss.item(), grad_x=phi.grad.numpy(), err_history=info.err_history.numpy(),
+               converged_iter=info.converged_iter.numpy(), status=np.array([int(s.value) for s in info.status]))
+    # (2) two variables, LM
+    a, b = th.Vector(1, name="a", dtype=dtype), th.Vector(1, name="b", dtype=dtype)
+    x2, y2 = th.Variable(x0.clone(), name="x"), th.Variable(y, name="y")
+    w = th.DiagonalCostWeight(th.Variable(torch.linspace(0.5, 1.5, N, dtype=dtype).view(1, -1), name="w"))
+
+    def error_fn2(optim_vars, aux_vars):
+        xx, yy = aux_vars
+        return yy.tensor - optim_vars[0].tensor * torch.exp(optim_vars[1].tensor * xx.tensor)
+    obj2 = th.Objective(dtype=dtype)
+    obj2.add(th.AutoDiffCostFunction([a, b], error_fn2, N, aux_vars=[x2, y2], cost_weight=w))
+    opt2 = th.LevenbergMarquardt(obj2, max_iterations=8, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    phi2 = x0.clone().requires_grad_(True)
+    sol2, info2 = th.TheseusLayer(opt2).forward(
+        input_tensors={"x": phi2, "a": torch.ones(B, 1, dtype=dtype), "b": 0.3 * torch.ones(B, 1, dtype=dtype)},
+        optimizer_kwargs={"backward_mode": "implicit", "track_err_history": True, "damping": 0.1, "adaptive_damping": True})
+    loss2 = ((sol2["a"] - 0.5) ** 2).mean() + ((sol2["b"] - 1.0) ** 2).mean()
+    loss2.backward()
+    out.update(a2=sol2["a"].detach().numpy(), b2=sol2["b"].detach().numpy(), loss2=loss2.item(), grad_x2=phi2.grad.numpy(),
+               err_history2=info2.err_history.numpy())
+    np.savez_compressed(os.path.join(OUT, "simple_example.npz"), **out)
+    print("simple_example loss", loss.item(), "|grad|", phi.grad.abs().max().item(), "lm loss", loss2.item(),
+          "err", info2.err_history[0].tolist())
+
+
 MIXED_LOSSES = (None, "welsch", "huber", "welsch+flatten", "huber+flatten")
 
 
@@ -1067,6 +1119,8 @@ def main():
     gen_lm(th, lieF, only)
     if not only or "implicit" in only:
         gen_implicit(th, lieF)
+    if not only or "simple_example" in only:
+        gen_simple_example(th)
     if not only or "se2" in only:
         gen_se2(th)
     if not only or "mixed_robust" in only:

@@ -78,7 +78,8 @@ class Variable:
 
 
 class Vector(Variable):
-    """Euclidean variable (theseus/geometry/vector.py); only used as an auxiliary variable here."""
+    """Euclidean variable (theseus/geometry/vector.py): auxiliary data of the fused objectives, optimisation variable of the
+    generic path (theseus_amd/euclidean.py)."""
 
     def __init__(self, dof: Optional[int] = None, tensor: Optional[torch.Tensor] = None,
                  name: Optional[str] = None, dtype: Optional[torch.dtype] = None):
@@ -90,6 +91,16 @@ class Vector(Variable):
 
     def dof(self) -> int:
         return self.tensor.shape[1]
+
+    # theseus/geometry/vector.py:150-178: local(a, b) = b - a, retraction = addition
+    def local(self, other: "Vector") -> torch.Tensor:
+        return other.tensor - self.tensor
+
+    def retract(self, delta: torch.Tensor) -> "Vector":
+        return Vector(tensor=self.tensor + delta)
+
+    def copy(self, new_name: Optional[str] = None) -> "Vector":
+        return Vector(tensor=self.tensor.clone(), name=new_name or f"{self.name}_copy")
 
 
 class Point3(Vector):
@@ -456,6 +467,69 @@ class CostFunction(abc.ABC):
 
     def weighted_error(self) -> torch.Tensor:
         return self.error() * self.weight.sqrt_diag(self.dim())
+
+    def weighted_jacobians_error(self):
+        """(theseus/core/cost_function.py:107-122) for cost functions that implement ``jacobians()`` -- the fused ones never
+        evaluate their Jacobians in torch."""
+        jacobians, err = self.jacobians()
+        w = self.weight.sqrt_diag(self.dim())
+        return [j * w.unsqueeze(2) for j in jacobians], err * w
+
+
+class AutoDiffCostFunction(CostFunction):
+    """User error function, Jacobians by automatic differentiation (theseus/core/cost_function.py:203-393, the default
+    ``AutogradMode.VMAP``: ``vmap(jacrev(err_fn))`` over the batch, :298-341).  ``err_fn(optim_vars, aux_vars)`` -> (B, dim)
+    receives tuples of variables and reads their ``.tensor``.  Optimisation variables must be Euclidean here (the Jacobian
+    w.r.t. the tensor IS the Jacobian w.r.t. the tangent: vector.py ``project`` is the identity)."""
+
+    def __init__(self, optim_vars: Sequence[Variable], err_fn, dim: int, cost_weight: Optional[CostWeight] = None,
+                 aux_vars: Optional[Sequence[Variable]] = None, name: Optional[str] = None, **autograd_kwargs):
+        super().__init__(cost_weight if cost_weight is not None else ScaleCostWeight(1.0), name)
+        if len(optim_vars) < 1:
+            raise ValueError("AutodiffCostFunction must receive at least one optimization variable.")
+        self._optim_vars, self._aux_vars = list(optim_vars), list(aux_vars or [])
+        self._err_fn, self._dim = err_fn, int(dim)
+
+    def optim_vars(self):
+        return list(self._optim_vars)
+
+    def aux_vars(self):
+        return list(self._aux_vars)
+
+    def dim(self) -> int:
+        return self._dim
+
+    def error(self) -> torch.Tensor:
+        err = self._err_fn(optim_vars=tuple(self._optim_vars), aux_vars=tuple(self._aux_vars))
+        if err.shape[1] != self._dim:
+            raise ValueError("Output dimension of given error function doesn't match self.dim().")
+        return err
+
+    def jacobians(self):
+        import copy
+        from torch.func import jacrev, vmap
+        err = self.error()
+        for v in self._optim_vars:
+            if "Vector" not in {c.__name__ for c in type(v).__mro__}:
+                raise NotImplementedError("AutoDiffCostFunction: optimisation variables must be Euclidean (Vector / Point2 / "
+                                          f"Point3) on this back end; got {type(v).__name__} ({v.name}).")
+        B = max(t.shape[0] for t in (v.tensor for v in self._optim_vars + self._aux_vars))
+        full = lambda t: t if t.shape[0] == B else t.expand(B, *t.shape[1:])  # noqa: E731
+        opt_t = tuple(full(v.tensor) for v in self._optim_vars)
+        aux_t = tuple(full(v.tensor) for v in self._aux_vars)
+        # shallow copies hold the per-sample tensors inside the transform (the reference's _tmp_optim_vars / _tmp_aux_vars)
+        tmp_opt = tuple(copy.copy(v) for v in self._optim_vars)
+        tmp_aux = tuple(copy.copy(v) for v in self._aux_vars)
+
+        def one(opt_tensors, aux_tensors):
+            for h, t in zip(tmp_opt, opt_tensors):
+                h.tensor = t.unsqueeze(0)
+            for h, t in zip(tmp_aux, aux_tensors):
+                h.tensor = t.unsqueeze(0)
+            return self._err_fn(optim_vars=tmp_opt, aux_vars=tmp_aux)[0]
+
+        jac = vmap(jacrev(one, argnums=0))(opt_t, aux_t)
+        return [j.reshape(B, self._dim, -1) for j in jac], err
 
 
 class Between(CostFunction):

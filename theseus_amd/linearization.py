@@ -164,7 +164,7 @@ class HipLinearizationCore:
     def _ensure_buffers(self):
         self.packed.sync()
         B = self.packed.batch
-        dev, dt = self.packed.tensors.poses.device, self.objective.dtype
+        dev, dt = self.packed.device, self.objective.dtype
         if self._compact:
             if self.Hc is None or self.Hc.shape[0] != B or self.Hc.device != dev or self.Hc.dtype != dt:
                 hb = self.packed.structure.hessian_blocks()
@@ -180,6 +180,9 @@ class HipLinearizationCore:
         """Dense A (B,m,n) and b (B,m) -- for tests / foreign consumers only
         (dense_linearization.py:29-56); the optimiser never calls this."""
         p = self.packed
+        if hasattr(p, "dense_A_b"):     # generic path (theseus_amd/euclidean.py)
+            self._A, self._b = p.dense_A_b()
+            return
         J0, J1, eb, Jp, ep = p.jacobian_blocks()
         B, s, d = p.batch, p.structure, p.dof
         A = torch.zeros(B, p.m, p.n, dtype=J0.dtype, device=J0.device)
@@ -202,6 +205,9 @@ class HipLinearizationCore:
             self._H = None      # (a dense expansion of the previous linearization is stale)
         else:
             self.packed.assemble(self._H, self.g)
+        self._after_assemble()
+
+    def _after_assemble(self):
         self._AtA_cache = None
         self._A = self._b = None
         self._Jblocks = None

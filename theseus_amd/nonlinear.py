@@ -149,7 +149,7 @@ class NonlinearLeastSquares(abc.ABC):
             # bundle-adjustment objectives (SE3 cameras + Point3 points) default to the Schur-complement solver
             from .ba import HipSchurSolver
             kinds = {type(v).__name__ for v in objective.optim_vars.values()}
-            linear_solver_cls = HipSchurSolver if "Point3" in kinds else HipCholeskySolver
+            linear_solver_cls = HipSchurSolver if {"Point3", "SE3"} <= kinds else HipCholeskySolver
         self.linear_solver = linear_solver_cls(objective, linearization_cls=linearization_cls,
                                                linearization_kwargs=linearization_kwargs,
                                                **(linear_solver_kwargs or {}))
@@ -556,6 +556,9 @@ class NonlinearLeastSquares(abc.ABC):
             from .ba import ba_implicit_step
             with torch.set_grad_enabled(outer_grad):
                 return ba_implicit_step(self, packed, float(step), kwargs)
+        if packed.group == "Euclidean":   # generic objectives: theseus_amd/euclidean.py (torch forms g, cached-factor solve)
+            with torch.set_grad_enabled(outer_grad):
+                return packed.implicit_step(self, float(step), kwargs)
         if packed.group not in ("SE3", "SE2", "SO3"):
             raise NotImplementedError("HIP back end: backward_mode='implicit' is fused for SE3 / SE2 / SO3 pose graphs and "
                                       f"bundle adjustment (got {packed.group}); there is no autograd/CPU fallback.")

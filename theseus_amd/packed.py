@@ -501,12 +501,23 @@ class PackedPoseGraph:
         return out
 
 
-def packed_for(objective: Objective, kernels=None, order=None) -> PackedPoseGraph:
-    """Get (or build) the packed representation attached to an objective (``order``: variable names in column order)."""
+def packed_for(objective: Objective, kernels=None, order=None):
+    """Get (or build) the packed representation attached to an objective (``order``: variable names in column order): the fused
+    pose-graph one, or -- Euclidean variables with cost functions that hand over their Jacobian blocks -- the generic one of
+    theseus_amd/euclidean.py."""
+    from .euclidean import PackedEuclidean
     p = getattr(objective, "_packed", None)
     order = tuple(order) if order is not None else tuple(objective.optim_vars.keys())
-    if (p is None or not isinstance(p, PackedPoseGraph) or p.version != objective.current_version
+    if (p is None or not isinstance(p, (PackedPoseGraph, PackedEuclidean)) or p.version != objective.current_version
             or (kernels is not None and p.K is not kernels) or p.order != order):
-        p = PackedPoseGraph(objective, kernels, order)
+        try:
+            p = PackedPoseGraph(objective, kernels, order)
+        except UnsupportedObjective as fused_error:
+            if not isinstance(objective, Objective):   # the reference's own Objective: theseus_amd/plugin.py has its generic path
+                raise
+            try:
+                p = PackedEuclidean(objective, kernels, order)
+            except UnsupportedObjective:
+                raise fused_error from None
         objective._packed = p
     return p
