@@ -556,6 +556,31 @@ def gen_simple_example(th):
     loss2.backward()
     out.update(a2=sol2["a"].detach().numpy(), b2=sol2["b"].detach().numpy(), loss2=loss2.item(), grad_x2=phi2.grad.numpy(),
                err_history2=info2.err_history.numpy())
+    # (3) optimizer variants on the two-variable fit (far start: b = 2.5): track_best_solution / track_state_history,
+    #     adaptive LM with a tiny and an ellipsoidal damping, Dogleg
+    ys = 0.7 * torch.exp(1.3 * x_true[:6, :12]) + 0.01 * torch.randn(6, 12, dtype=dtype, generator=gen)
+    out.update(v_x=x_true[:6, :12].numpy(), v_y=ys.numpy())
+    variants = (("gn", th.GaussNewton, dict(track_best_solution=True, track_state_history=True)),
+                ("lm_tiny", th.LevenbergMarquardt, dict(damping=1e-6, adaptive_damping=True, track_best_solution=True)),
+                ("dogleg", th.Dogleg, dict(track_state_history=True)),
+                ("lm_ellips", th.LevenbergMarquardt, dict(damping=0.1, ellipsoidal_damping=True, adaptive_damping=True)))
+    for tag, cls, okw in variants:
+        a3, b3 = th.Vector(1, name="a", dtype=dtype), th.Vector(1, name="b", dtype=dtype)
+        x3, y3 = th.Variable(x_true[:6, :12].clone(), name="x"), th.Variable(ys.clone(), name="y")
+        obj3 = th.Objective(dtype=dtype)
+        obj3.add(th.AutoDiffCostFunction([a3, b3], error_fn2, 12, aux_vars=[x3, y3], cost_weight=th.ScaleCostWeight(torch.tensor(1.0, dtype=dtype))))
+        opt3 = cls(obj3, max_iterations=8, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+        with torch.no_grad():
+            sol3, info3 = th.TheseusLayer(opt3).forward(
+                input_tensors={"a": torch.ones(6, 1, dtype=dtype), "b": 2.5 * torch.ones(6, 1, dtype=dtype)},
+                optimizer_kwargs=dict(track_err_history=True, **okw))
+        out.update({f"v_{tag}_a": sol3["a"].numpy(), f"v_{tag}_b": sol3["b"].numpy(), f"v_{tag}_err": info3.err_history.numpy()})
+        if info3.best_solution is not None:
+            out.update({f"v_{tag}_best_a": info3.best_solution["a"].numpy(), f"v_{tag}_best_b": info3.best_solution["b"].numpy(),
+                        f"v_{tag}_best_err": info3.best_err.numpy(), f"v_{tag}_best_iter": info3.best_iter.numpy()})
+        if info3.state_history is not None:
+            out.update({f"v_{tag}_hist_b": info3.state_history["b"].numpy()})
+        print("variant", tag, info3.err_history[0].tolist())
     np.savez_compressed(os.path.join(OUT, "simple_example.npz"), **out)
     print("simple_example loss", loss.item(), "|grad|", phi.grad.abs().max().item(), "lm loss", loss2.item(),
           "err", info2.err_history[0].tolist())

@@ -67,3 +67,41 @@ def test_generic_linearization_matches_torch_on_a_two_cost_objective():
     bad.add(th.AutoDiffCostFunction([pose], lambda optim_vars, aux_vars: optim_vars[0].tensor.reshape(-1, 12), 12))
     with pytest.raises(th.UnsupportedObjective):
         th.HipLinearization(bad, kernels=OracleKernels())
+
+
+@pytest.mark.parametrize("tag,cls,okw", [
+    ("gn", "GaussNewton", dict(track_best_solution=True, track_state_history=True)),
+    ("lm_tiny", "LevenbergMarquardt", dict(damping=1e-6, adaptive_damping=True, track_best_solution=True)),
+    ("dogleg", "Dogleg", dict(track_state_history=True)),
+    ("lm_ellips", "LevenbergMarquardt", dict(damping=0.1, ellipsoidal_damping=True, adaptive_damping=True))])
+def test_generic_path_optimizer_variants_match_the_reference(tag, cls, okw):
+    """The two-variable fit y = a exp(b x) through Gauss-Newton / adaptive LM (plain and ellipsoidal damping) / Dogleg on the
+    generic path, with track_best_solution and track_state_history, against the REAL reference's runs
+    (tests/golden/simple_example.npz: v_* entries)."""
+    import theseus_amd as th
+    from tests.oracle_kernels import OracleKernels
+    g = load_golden("simple_example")
+    dt = torch.float64
+    xs, ys = torch.from_numpy(g["v_x"]), torch.from_numpy(g["v_y"])
+    B, N = xs.shape
+    a, b = th.Vector(1, name="a", dtype=dt), th.Vector(1, name="b", dtype=dt)
+    x, y = th.Variable(xs.clone(), name="x"), th.Variable(ys.clone(), name="y")
+
+    def f(optim_vars, aux_vars):
+        return aux_vars[1].tensor - optim_vars[0].tensor * torch.exp(optim_vars[1].tensor * aux_vars[0].tensor)
+    obj = th.Objective(dtype=dt)
+    obj.add(th.AutoDiffCostFunction([a, b], f, N, aux_vars=[x, y], cost_weight=th.ScaleCostWeight(torch.tensor(1.0, dtype=dt))))
+    opt = getattr(th, cls)(obj, max_iterations=8, abs_err_tolerance=0.0, rel_err_tolerance=0.0,
+                           linearization_kwargs=dict(kernels=OracleKernels()))
+    with torch.no_grad():
+        sol, info = th.TheseusLayer(opt).forward({"a": torch.ones(B, 1, dtype=dt), "b": 2.5 * torch.ones(B, 1, dtype=dt)},
+                                                 optimizer_kwargs=dict(track_err_history=True, **okw))
+    np.testing.assert_allclose(info.err_history.numpy(), g[f"v_{tag}_err"], rtol=1e-6)
+    np.testing.assert_allclose(sol["a"].numpy(), g[f"v_{tag}_a"], rtol=1e-9)
+    np.testing.assert_allclose(sol["b"].numpy(), g[f"v_{tag}_b"], rtol=1e-9)
+    if okw.get("track_best_solution"):
+        np.testing.assert_allclose(info.best_solution["a"].numpy(), g[f"v_{tag}_best_a"], rtol=1e-9)
+        np.testing.assert_allclose(info.best_solution["b"].numpy(), g[f"v_{tag}_best_b"], rtol=1e-9)
+        np.testing.assert_allclose(info.best_err.numpy(), g[f"v_{tag}_best_err"], rtol=1e-9)
+    if okw.get("track_state_history"):
+        np.testing.assert_allclose(info.state_history["b"].numpy(), g[f"v_{tag}_hist_b"], rtol=1e-9)
