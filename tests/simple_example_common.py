@@ -63,3 +63,46 @@ def check_simple_example(g, r, rel=1e-9):
     assert abs(r["loss2"] - float(g["loss2"])) < 1e-9
     np.testing.assert_allclose(r["grad_x2"], g["grad_x2"], rtol=0, atol=1e-6 * np.abs(g["grad_x2"]).max())
     np.testing.assert_allclose(r["err_history2"], g["err_history2"], rtol=1e-6)
+
+
+UNROLLED = (("gn_unroll", "GaussNewton", "unroll", {}, 0.0),
+            ("gn_trunc", "GaussNewton", "truncated", dict(backward_num_iterations=3), 0.0),
+            ("lm_unroll", "LevenbergMarquardt", "unroll", dict(damping=0.5, ellipsoidal_damping=True, adaptive_damping=True), 0.0),
+            ("lm_trunc", "LevenbergMarquardt", "truncated", dict(damping=0.5, adaptive_damping=True, backward_num_iterations=2), 0.0),
+            ("gn_trunc_conv", "GaussNewton", "truncated", dict(backward_num_iterations=2), 1e-6))
+
+
+def run_unrolled(th, g, tag, device, kernels=None):
+    """backward_mode "unroll" / "truncated" on the two-variable fit (tests/golden/simple_example.npz: u_* entries, the REAL
+    reference differentiating through its iterations): solution, loss and the gradients w.r.t. x, y and the cost weight."""
+    _, cls, mode, okw, tol = next(u for u in UNROLLED if u[0] == tag)
+    dt = torch.float64
+    xl = torch.from_numpy(g["v_x"]).to(device).clone().requires_grad_(True)
+    yl = torch.from_numpy(g["v_y"]).to(device).clone().requires_grad_(True)
+    wl = torch.linspace(0.5, 1.5, xl.shape[1], dtype=dt, device=device).view(1, -1).clone().requires_grad_(True)
+    a, b = th.Vector(1, name="a", dtype=dt), th.Vector(1, name="b", dtype=dt)
+    a.to(device)
+    b.to(device)
+
+    def f(optim_vars, aux_vars):
+        return aux_vars[1].tensor - optim_vars[0].tensor * torch.exp(optim_vars[1].tensor * aux_vars[0].tensor)
+    obj = th.Objective(dtype=dt)
+    obj.add(th.AutoDiffCostFunction([a, b], f, xl.shape[1], aux_vars=[th.Variable(xl, name="x"), th.Variable(yl, name="y")],
+                                    cost_weight=th.DiagonalCostWeight(th.Variable(wl, name="w"))))
+    lkw = dict(linearization_kwargs=dict(kernels=kernels)) if kernels is not None else {}
+    opt = getattr(th, cls)(obj, max_iterations=6, abs_err_tolerance=tol, rel_err_tolerance=tol, **lkw)
+    B = xl.shape[0]
+    sol, info = th.TheseusLayer(opt).forward({"a": torch.ones(B, 1, dtype=dt, device=device), "b": 2.5 * torch.ones(B, 1, dtype=dt, device=device)},
+                                             optimizer_kwargs=dict(track_err_history=True, backward_mode=mode, **okw))
+    loss = ((sol["a"] - 0.5) ** 2).mean() + ((sol["b"] - 1.0) ** 2).mean()
+    loss.backward()
+    r = lambda k: g[f"u_{tag}_{k}"]  # noqa: E731
+    np.testing.assert_allclose(sol["a"].detach().cpu().numpy(), r("a"), rtol=1e-10)
+    np.testing.assert_allclose(sol["b"].detach().cpu().numpy(), r("b"), rtol=1e-10)
+    assert abs(float(loss.detach()) - float(r("loss"))) < 1e-12
+    for leaf, key in ((xl, "gx"), (yl, "gy"), (wl, "gw")):
+        want = r(key)
+        np.testing.assert_allclose(leaf.grad.cpu().numpy(), want, rtol=0, atol=1e-9 * np.abs(want).max(), err_msg=key)
+    np.testing.assert_allclose(info.err_history.numpy(), r("err"), rtol=1e-6)    # (inf where the reference has inf)
+    assert info.converged_iter.tolist() == r("conv").tolist()
+    assert [int(s.value) for s in info.status] == r("status").tolist()

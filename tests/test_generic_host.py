@@ -105,3 +105,36 @@ def test_generic_path_optimizer_variants_match_the_reference(tag, cls, okw):
         np.testing.assert_allclose(info.best_err.numpy(), g[f"v_{tag}_best_err"], rtol=1e-9)
     if okw.get("track_state_history"):
         np.testing.assert_allclose(info.state_history["b"].numpy(), g[f"v_{tag}_hist_b"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["gn_unroll", "gn_trunc", "lm_unroll", "lm_trunc", "gn_trunc_conv"])
+def test_differentiating_through_the_iterations_matches_the_reference(tag):
+    """BackwardMode.UNROLL / TRUNCATED on the generic path (nonlinear_least_squares.py:222-282: the Hessian is part of the graph):
+    Gauss-Newton and adaptive (ellipsoidal) LM, with and without the convergence tests, against the REAL reference's gradients.
+    The fused pose-graph path refuses these modes when there is something to differentiate."""
+    import theseus_amd as th
+    from tests.oracle_kernels import OracleKernels
+    from tests.simple_example_common import run_unrolled
+    run_unrolled(th, load_golden("simple_example"), tag, "cpu", OracleKernels())
+
+
+def test_fused_path_refuses_unrolled_differentiation():
+    import theseus_amd as th
+    from tests.helpers import load_golden as lg
+    from tests.implicit_common import run_implicit  # noqa: F401  (same fixture family)
+    from tests.oracle_kernels import OracleKernels
+    g = lg("pg_f64_implicit")
+    t = torch.from_numpy
+    meas = t(g["meas"]).clone().requires_grad_(True)
+    obj = th.Objective(dtype=torch.float64)
+    poses = [th.SE3(tensor=t(g["poses0"])[:, k].clone(), name=f"pose_{k}") for k in range(int(g["P"]))]
+    for k in range(g["edges"].shape[0]):
+        i, j = g["edges"][k].tolist()
+        obj.add(th.Between(poses[i], poses[j], th.SE3(tensor=meas[:, k], name=f"meas_{k}"),
+                           th.DiagonalCostWeight(th.Variable(t(g["w_between"])[:, k].clone(), name=f"w_{k}")), name=f"between_{k}"))
+    opt = th.LevenbergMarquardt(obj, max_iterations=3, linearization_kwargs=dict(kernels=OracleKernels()))
+    for mode, extra in (("unroll", {}), ("truncated", dict(backward_num_iterations=1))):
+        with pytest.raises(NotImplementedError, match="fused HIP path"):
+            th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode=mode, **extra))
+    with torch.no_grad():   # nothing to differentiate: both modes are the plain loop
+        th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode="truncated", backward_num_iterations=1))

@@ -11,6 +11,9 @@ moves around is ONE (B, n) tensor; the variables' tensors are column views of it
 
 Implicit backward (nonlinear_least_squares.py:121-135,265-292): the grad-enabled last Gauss-Newton step keeps H outside
 autograd; ``g`` is formed by torch from the differentiable blocks, the solve's backward is one solve with the cached factor.
+``backward_mode="unroll"`` / ``"truncated"`` (:222-282): the differentiated iterations keep H IN the graph -- torch forms the
+(small) normal equations from the blocks, the damped solve runs on the kernels as in every other iteration and is one autograd
+node whose backward is a solve with a copy of that iteration's factor (``_UnrolledSolve``).
 """
 import warnings
 from typing import List, Optional
@@ -46,9 +49,9 @@ class PackedEuclidean:
                     f"{type(v).__name__} ({v.name}).  There is no CPU/eager fallback.")
         self.costs = list(objective.cost_functions.values())
         for c in self.costs:
-            if not hasattr(c, "weighted_jacobians_error"):
-                raise UnsupportedObjective(f"HIP backend, generic path: {type(c).__name__} ({c.name}) has no "
-                                           "weighted_jacobians_error().")
+            if not hasattr(c, "jacobians"):
+                raise UnsupportedObjective(f"HIP backend, generic path: {type(c).__name__} ({c.name}) does not implement "
+                                           "jacobians().")
         self.cols, col = [], 0
         for v in self.vars:
             self.cols.append((col, v.dof()))
@@ -270,6 +273,46 @@ class PackedEuclidean:
         self.K.vec_retract(self._rec(self._state), delta, 0, step, m, self._rec(out))
         return out
 
+    # ---- BackwardMode.UNROLL / TRUNCATED: one iteration as a differentiable function of the state and of whatever the cost
+    #      functions depend on (nonlinear_least_squares.py:100-215 with the Hessian IN the graph) -------------------------------
+    def normal_equations(self, Js, es):
+        """(H (B, n, n) symmetric, g (B, n)) from the weighted blocks, by torch: the differentiable twin of ``assemble``."""
+        B = self.batch
+        ref = es[0]
+        H = torch.zeros(B, self.n, self.n, dtype=ref.dtype, device=ref.device)
+        g = torch.zeros(B, self.n, dtype=ref.dtype, device=ref.device)
+        for c, (J, e) in enumerate(zip(Js, es)):
+            for sa, ka in enumerate(self.cost_vars[c]):
+                ca, da = self.cols[ka]
+                g[:, ca:ca + da] = g[:, ca:ca + da] - (J[sa].transpose(1, 2) @ e.unsqueeze(2)).squeeze(2)
+                for sb, kb in enumerate(self.cost_vars[c]):
+                    cb, db = self.cols[kb]
+                    H[:, ca:ca + da, cb:cb + db] = H[:, ca:ca + da, cb:cb + db] + J[sa].transpose(1, 2) @ J[sb]
+        return H, g
+
+    def unrolled_step(self, opt, X: torch.Tensor, frozen: Optional[torch.Tensor], kwargs):
+        """X -> (X + step * delta where not ``frozen``, delta): the blocks are evaluated at X with the graph, the kernels get
+        their detached values (what ``compute_delta`` factorises and LM's accept test reads), the solve is the autograd node."""
+        solver = opt.linear_solver
+        lin = solver.linearization
+        lin._ensure_buffers()
+        Js, es = [], []
+        with self._at(self, X):
+            for c in self.costs:
+                jac, err = c.weighted_jacobians_error()
+                Js.append([j.contiguous() for j in jac])
+                es.append(err.contiguous())
+        Jd, ed = [[j.detach() for j in J] for J in Js], [e.detach() for e in es]
+        self.asm.assemble(self.K, Jd, ed, lin._H, lin.g)
+        self._blocks = (Jd, ed)
+        lin._after_assemble()
+        H, g = self.normal_equations(Js, es)
+        delta = _UnrolledSolve.apply(opt, kwargs, H, g)
+        X_new = X + float(opt.params.step_size) * delta
+        if frozen is not None:
+            X_new = torch.where(frozen.view(-1, 1), X, X_new)
+        return X_new, delta
+
     # ---- BackwardMode.IMPLICIT ----------------------------------------------------------------------------------------------
     def implicit_step(self, opt, step: float, kwargs):
         solver = opt.linear_solver
@@ -314,3 +357,38 @@ class _CachedFactorSolve(torch.autograd.Function):
             raise RuntimeError("implicit backward: the cached Cholesky factor of this forward pass was overwritten by "
                                "a later factorisation on the same optimizer; call backward() before the next forward().")
         return None, None, solver.solve_with_factor(grad_delta.contiguous())
+
+
+class _UnrolledSolve(torch.autograd.Function):
+    """delta = (H + D)^-1 g as a differentiable function of H and g (D: the optimizer's damping of this iteration, a function of
+    diag(H) when ellipsoidal -- dense_solver.py:38-64).  Forward: the optimizer's own ``compute_delta`` on the kernels (the
+    buffers hold the detached H, g).  Backward, with w = (H + D)^-1 grad_delta from a COPY of this iteration's factor (later
+    iterations overwrite the solver's):  grad_g = w,  grad_H = -w delta^T - diag(lambda w * delta) [ellipsoidal]."""
+
+    @staticmethod
+    def forward(ctx, opt, kwargs, H, g):
+        solver = opt.linear_solver
+        delta = opt.compute_delta(**kwargs)
+        if bool(solver.info.ne(0).any()):
+            try:
+                solver.check_info()
+            except RuntimeError as run_err:
+                raise RuntimeError(f"There was an error while running the linear optimizer. Original error message: {run_err}. "
+                                   "Backward pass will not work. To obtain the best solution seen before the error, run with "
+                                   "torch.no_grad()") from None
+        damped, ellipsoidal, _ = solver._factored_with
+        ctx.solver, ctx.n = solver, solver.linearization.n
+        ctx.L, ctx.panels = solver.L.clone(), solver.panels.clone()
+        ctx.lam = solver._lam.clone() if (damped and ellipsoidal) else None
+        ctx.save_for_backward(delta)
+        return delta
+
+    @staticmethod
+    def backward(ctx, grad_delta):
+        (delta,) = ctx.saved_tensors
+        w = torch.empty_like(delta)
+        ctx.solver.K.chol_solve(ctx.L, ctx.n, ctx.panels, grad_delta.contiguous(), w)
+        grad_H = -(w.unsqueeze(2) * delta.unsqueeze(1))
+        if ctx.lam is not None:
+            grad_H = grad_H - torch.diag_embed(ctx.lam.view(-1, 1) * w * delta)
+        return None, None, grad_H, w

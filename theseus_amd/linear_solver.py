@@ -87,6 +87,7 @@ class HipCholeskyCore:
                 lam.fill_(float(damping))
         y = self._y if rhs is not None else None
         self.factor_version += 1
+        self._factored_with = (lam is not None, bool(ellipsoidal_damping), float(damping_eps))   # (what L L^T is the factor of)
         self._factor_call(lam, ellipsoidal_damping, damping_eps, rhs, y)
         return y
 

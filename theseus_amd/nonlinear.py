@@ -218,9 +218,8 @@ class NonlinearLeastSquares(abc.ABC):
             return self._optimize_loop(**kwargs)
         except BaseException:
             packed = self.linear_solver.linearization.packed
-            if getattr(packed, "tensors", None) is not None:
-                with torch.no_grad():
-                    packed.flush_variables()
+            with torch.no_grad():
+                packed.flush_variables()   # (a no-op unless the loop left the variables pointing at a stale buffer)
             raise
 
     def _optimize_loop(self, track_best_solution: bool = False, track_err_history: bool = False,
@@ -229,21 +228,38 @@ class NonlinearLeastSquares(abc.ABC):
                        end_iter_callback: Optional[Callable] = None, **kwargs) -> NonlinearOptimizerInfo:
         backward_mode = BackwardMode.resolve(backward_mode)
         outer_grad = torch.is_grad_enabled()
-        if backward_mode in (BackwardMode.TRUNCATED, BackwardMode.DLM):
-            raise NotImplementedError(f"backward_mode={backward_mode.name} is not supported by the HIP back end "
-                                      "(supported: 'implicit'; 'unroll' without gradients).")
-        if backward_mode == BackwardMode.UNROLL and outer_grad and self._needs_grad():
-            raise NotImplementedError(
-                "Differentiating through the unrolled iterations (backward_mode='unroll') is not supported by the "
-                "HIP back end: the kernels are outside autograd.  Use backward_mode='implicit' (one backward linear "
-                "solve with the cached factor), or call under torch.no_grad().")
+        if backward_mode == BackwardMode.DLM:
+            raise NotImplementedError("backward_mode=DLM is not supported by the HIP back end "
+                                      "(supported: 'implicit'; 'unroll' / 'truncated' see below).")
         implicit = backward_mode == BackwardMode.IMPLICIT
         lin: HipLinearization = self.linear_solver.linearization
         packed = lin.packed
+        # Differentiating THROUGH iterations (UNROLL: all of them, TRUNCATED: the last ``backward_num_iterations``;
+        # nonlinear_least_squares.py:222-282): the Hessian is part of the graph there, i.e. the derivatives of every cost's
+        # Jacobian are needed.  The generic path has them (its blocks come from torch: theseus_amd/euclidean.py); the fused
+        # pose-graph / bundle-adjustment kernels do not.
+        unrolled = backward_mode in (BackwardMode.UNROLL, BackwardMode.TRUNCATED) and outer_grad and self._needs_grad()
+        if unrolled and getattr(packed, "group", None) != "Euclidean":
+            raise NotImplementedError(
+                f"Differentiating through the iterations (backward_mode='{backward_mode.name.lower()}') is not supported by the "
+                "fused HIP path: the kernels are outside autograd.  Use backward_mode='implicit' (one backward linear "
+                "solve with the cached factor), or call under torch.no_grad().")
+        if unrolled and (track_best_solution or track_state_history or isinstance(self, TrustRegion)):
+            raise NotImplementedError("differentiable iterations on the generic path: Gauss-Newton / Levenberg-Marquardt, without "
+                                      "track_best_solution / track_state_history.")
         with torch.no_grad():
             packed.sync(deep=True)   # once per optimize(): also catches in-place edits of the variables' tensors
         self.reset(**kwargs, backward_mode=backward_mode)
-        _, loop_iters = self._split_backward_iters(backward_mode=backward_mode, **kwargs) if implicit else (0, self.params.max_iterations)
+        tail_iters = 0
+        if implicit:
+            _, loop_iters = self._split_backward_iters(backward_mode=backward_mode, **kwargs)
+        elif backward_mode == BackwardMode.TRUNCATED:
+            # (without anything to differentiate the two loops of the reference are one loop with a fresh convergence mask in
+            #  between; run as the differentiable tail only when there is a graph to build)
+            tail, head = self._split_backward_iters(backward_mode=backward_mode, **kwargs)
+            loop_iters, tail_iters = (head, tail) if unrolled else (self.params.max_iterations, 0)
+        else:
+            loop_iters, tail_iters = (0, self.params.max_iterations) if unrolled else (self.params.max_iterations, 0)
         with torch.no_grad():
             packed.sync()
             packed.privatize_state()   # never recycle the buffer the previous optimize() handed to the user
@@ -495,6 +511,65 @@ class NonlinearLeastSquares(abc.ABC):
                         end_iter_callback(self, info, delta, it)
                     it += 1
                     info.iters_done = it
+
+            # ---- BackwardMode.UNROLL / TRUNCATED with a graph: the reference's SECOND loop (nonlinear_least_squares.py:264-282)
+            #      -- same iteration, caller's grad mode, a fresh convergence mask -- then _merge_infos
+            #      (nonlinear_optimizer.py:220-266).  Host-synchronous: these are a handful of small iterations. ----
+            if tail_iters > 0 and not (info.status == NonlinearOptimizerStatus.FAIL).any():
+                packed.flush_variables()
+                X = packed.state.detach()
+                g_conv = torch.zeros(B, dtype=torch.bool, device=dev)
+                g_conv_iter = torch.zeros(B, dtype=torch.long, device=dev)   # the reference's counter: += 1 while not converged
+                g_status_conv = torch.zeros(B, dtype=torch.bool, device=dev)
+                g_last, g_it, attempts, g_errs = last_err, 0, 0, []
+                while g_it < tail_iters:
+                    with torch.set_grad_enabled(outer_grad):
+                        X_cand, delta = packed.unrolled_step(self, X, g_conv, kwargs)
+                    err_new = packed.error_metric(state=X_cand.detach())
+                    reject = self._complete_step(delta.detach(), err_new, g_last, step_size=p.step_size, **kwargs)
+                    if reject is not None:
+                        rb = reject.bool()
+                        if bool(rb.all()):
+                            attempts += 1
+                            if attempts < self._MAX_ALL_REJECT_ATTEMPTS:
+                                continue
+                        with torch.set_grad_enabled(outer_grad):
+                            X_cand = torch.where(rb.view(-1, 1), X, X_cand)
+                        err = torch.where(rb, g_last, err_new)
+                    else:
+                        err = err_new
+                    attempts = 0
+                    X = X_cand
+                    # _update_info + _check_convergence of this iteration
+                    g_conv_iter = g_conv_iter + (~g_conv).long()
+                    if verbose:
+                        print(f"Nonlinear optimizer. Iteration: {it + g_it + 1}. Error: {err.mean().item()}")
+                    if need_conv:
+                        g_conv = (torch.ones_like(g_conv) if self.reducer.mean_abs(err) < p.abs_err_tolerance
+                                  else self._check_convergence(err, g_last))
+                        g_status_conv = g_status_conv | g_conv
+                        if bool(g_conv.all()):
+                            break    # (as in the first loop: the converging iteration is not counted, its error not merged)
+                    g_errs.append(err)
+                    g_last = err
+                    if end_iter_callback is not None:
+                        packed.swap_state(X, repoint=True)
+                        end_iter_callback(self, info, delta.detach(), it + g_it)
+                    g_it += 1
+                packed.swap_state(X, repoint=True)      # the variables view the (graph-carrying) result
+                # _merge_infos
+                if err_hist is not None and g_errs:
+                    err_hist[:, it + 1:it + 1 + g_it] = torch.stack(g_errs, 1)
+                undecided = ~(converged if converged is not None else torch.zeros(B, dtype=torch.bool, device=dev))
+                if need_conv:
+                    # problems the first loop left at MAX_ITERATIONS take the second loop's verdict; their counters add up
+                    first_count = torch.full_like(conv_iter, it)
+                    newly = undecided & g_status_conv
+                    conv_iter = torch.where(newly, first_count + g_conv_iter, conv_iter)
+                    converged = newly if converged is None else (converged | newly)
+                info.last_err = last_err
+                it += g_it
+                info.iters_done = it
 
             # ---- BackwardMode.IMPLICIT: the last step is an undamped Gauss-Newton step with the Hessian detached,
             #      executed under the caller's grad mode (nonlinear_least_squares.py:121-135,265-292) ----
