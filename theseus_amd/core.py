@@ -705,6 +705,7 @@ class Objective:
         self._packed = None
         self._num_updates_variables: Dict[str, int] = {}
         self.current_version = 0
+        self._update_stamp = None   # (Variable._global_updates, current_version) of the last full update()
 
     # theseus/core/objective.py:148-300 (add / registration, name clash checks)
     def add(self, cost_function: CostFunction):
@@ -766,6 +767,9 @@ class Objective:
     def update(self, input_tensors: Optional[Dict[str, torch.Tensor]] = None,
                batch_ignore_mask: Optional[torch.Tensor] = None):
         input_tensors = input_tensors or {}
+        if not input_tensors and self.batch_size is not None and self._update_stamp == (Variable._global_updates, self.current_version):
+            return   # nothing was updated anywhere since the last resolve: skip the pass over every variable (42 k of them in
+                     # a bundle-adjustment objective: ~30 ms of host time per TheseusLayer.forward)
         for name, t in input_tensors.items():
             if name in self.optim_vars:
                 self.optim_vars[name].update(t, batch_ignore_mask=batch_ignore_mask)
@@ -779,6 +783,7 @@ class Objective:
         devs = {v.device for v in self._all_variables()}
         if len(devs) == 1:
             self.device = devs.pop()
+        self._update_stamp = (Variable._global_updates, self.current_version)
 
     def to(self, *args, **kwargs):
         for v in self._all_variables():
