@@ -615,6 +615,49 @@ def gen_simple_example(th):
           "err", info2.err_history[0].tolist())
 
 
+def gen_pg_unrolled(th, lieF):
+    """Differentiating THROUGH the iterations of an SE3 pose graph (BackwardMode.UNROLL / TRUNCATED,
+    nonlinear_least_squares.py:222-282: the Hessian is part of the graph): the gradients of <coef, final poses> w.r.t. the
+    measurements, the weights, the prior targets and the prior scales.  The fused HIP path does not support these modes yet --
+    the fixture pins the ORACLE (tests/test_oracle_golden.py), which is what the kernels will be tested against."""
+    dtype = torch.float64
+    cases = (("gn_unroll", th.GaussNewton, "unroll", 3, {}),
+             ("lm_unroll", th.LevenbergMarquardt, "unroll", 4, dict(damping=0.05, adaptive_damping=True)),
+             ("lm_trunc", th.LevenbergMarquardt, "truncated", 5, dict(damping=0.02, backward_num_iterations=2)))
+    out = {}
+    d = make_problem(dtype=dtype, th=th, lieF=lieF, P=6, E=10, B=3, seed=51, batched_weights=True, pose_noise=(0.2, 0.15))
+    B, P = d["poses"].shape[:2]
+    coef = torch.randn(B, P, 3, 4, dtype=dtype, generator=torch.Generator().manual_seed(9))
+    out.update(P=P, edges=d["edges"].numpy(), meas=d["meas"].numpy(), w_between=d["w_between"].numpy(), prior_idx=d["prior_idx"].numpy(),
+               prior_target=d["prior_target"].numpy(), w_prior=d["w_prior"].numpy(), poses0=d["poses"].numpy(), coef=coef.numpy())
+    for tag, cls, mode, iters, okw in cases:
+        meas = d["meas"].clone().requires_grad_(True)
+        wb = d["w_between"].clone().requires_grad_(True)
+        tgt = d["prior_target"].clone().requires_grad_(True)
+        wp = d["w_prior"][:, :, :1].clone().requires_grad_(True)
+        obj = th.Objective(dtype=dtype)
+        poses = [th.SE3(tensor=d["poses"][:, k].clone(), name=f"pose_{k}") for k in range(P)]
+        for k in range(d["edges"].shape[0]):
+            i, j = d["edges"][k].tolist()
+            obj.add(th.Between(poses[i], poses[j], th.SE3(tensor=meas[:, k], name=f"meas_{k}"),
+                               th.DiagonalCostWeight(th.Variable(wb[:, k], name=f"w_{k}")), name=f"between_{k}"))
+        for k in range(d["prior_idx"].shape[0]):
+            obj.add(th.Difference(poses[int(d["prior_idx"][k])], th.SE3(tensor=tgt[:, k], name=f"prior_target_{k}"),
+                                  th.ScaleCostWeight(th.Variable(wp[:, k], name=f"pw_{k}")), name=f"prior_{k}"))
+        opt = cls(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, max_iterations=iters, step_size=1.0,
+                  abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+        sol, info = th.TheseusLayer(opt).forward(optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **okw))
+        final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
+        loss = (coef * final).sum()
+        loss.backward()
+        out.update({f"{tag}_final": final.detach().numpy(), f"{tag}_loss": loss.item(), f"{tag}_grad_meas": meas.grad.numpy(),
+                    f"{tag}_grad_w_between": wb.grad.numpy(), f"{tag}_grad_prior_target": tgt.grad.numpy(),
+                    f"{tag}_grad_w_prior": wp.grad.numpy(), f"{tag}_err_history": info.err_history.numpy(),
+                    f"{tag}_kwargs": np.array(repr(dict(okw, max_iterations=iters, mode=mode, gauss_newton=cls is th.GaussNewton)))})
+        print("pg_unrolled", tag, "loss", loss.item(), "|grad_meas|", meas.grad.abs().max().item(), info.err_history[0].tolist())
+    np.savez_compressed(os.path.join(OUT, "pg_f64_unrolled.npz"), **out)
+
+
 MIXED_LOSSES = (None, "welsch", "huber", "welsch+flatten", "huber+flatten")
 
 
@@ -1175,6 +1218,8 @@ def main():
         gen_implicit(th, lieF)
     if not only or "simple_example" in only:
         gen_simple_example(th)
+    if not only or "pg_unrolled" in only:
+        gen_pg_unrolled(th, lieF)
     if not only or "se2" in only:
         gen_se2(th)
     if not only or "mixed_robust" in only:

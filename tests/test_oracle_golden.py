@@ -337,3 +337,40 @@ def test_mixed_robust_objective_matches_reference(name):
     for key, ref in GRAD_KEYS:
         got, want = leaves[key].grad.numpy(), g[ref]
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
+
+
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc"])
+def test_unrolled_gradients_of_a_pose_graph_match_reference(tag):
+    """BackwardMode.UNROLL / TRUNCATED on an SE3 pose graph (the Hessian is part of the graph,
+    nonlinear_least_squares.py:222-282): torch autograd THROUGH the oracle's loop reproduces the REAL reference's gradients
+    (tests/golden/pg_f64_unrolled.npz).  The fused HIP path refuses these modes today -- this pins the oracle the
+    kernels will be tested against."""
+    import ast
+    import dataclasses
+    g = load_golden("pg_f64_unrolled")
+    p, poses0, _ = golden_problem({**g, "opt_kwargs": "{}"})
+    kw = ast.literal_eval(str(g[f"{tag}_kwargs"]))
+    mode, iters, gn = kw.pop("mode"), kw.pop("max_iterations"), kw.pop("gauss_newton")
+    k_grad = kw.pop("backward_num_iterations", iters) if mode == "truncated" else iters
+    leaves = dict(meas=p.meas.clone().requires_grad_(True), w_between=p.w_between.clone().requires_grad_(True),
+                  prior_target=p.prior_target.clone().requires_grad_(True),
+                  w_prior=p.w_prior[:, :, :1].clone().requires_grad_(True))
+    pg = dataclasses.replace(p, meas=leaves["meas"], w_between=leaves["w_between"], prior_target=leaves["prior_target"],
+                             w_prior=leaves["w_prior"].expand(-1, -1, p.dof))
+    common = dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0, gauss_newton=gn, **kw)
+    x = poses0
+    errs = []
+    if iters - k_grad > 0:          # the no-grad head of TRUNCATED (fixed damping in the fixture: no state to carry over)
+        with torch.no_grad():
+            x, info = opg.lm_optimize(p, x, max_iterations=iters - k_grad, **common)
+        errs += info.err_history
+    x, info = opg.lm_optimize(pg, x, max_iterations=k_grad, **common)
+    errs += info.err_history[1:] if errs else info.err_history
+    np.testing.assert_allclose(x.detach().numpy(), g[f"{tag}_final"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(torch.stack([e.detach() for e in errs], 1).numpy(), g[f"{tag}_err_history"], rtol=1e-6)
+    loss = (torch.from_numpy(g["coef"]) * x).sum()
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{tag}_loss"])) < 1e-9
+    for key in ("meas", "w_between", "prior_target", "w_prior"):
+        got, want = leaves[key].grad.numpy(), g[f"{tag}_grad_{key}"]
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
