@@ -59,6 +59,10 @@ class BAProblem:
     cost_order: List[Tuple[str, int]]   # row order: ("obs", o) | ("cam_prior", k) | ("pt_prior", k)
     robust_obs: Optional[str] = None
     log_radius_obs: Optional[torch.Tensor] = None   # broadcastable to (B, O, 1)
+    # camera-camera Between costs (odometry; theseus/embodied/measurements/between.py:38-45): cost_order kind "cam_between"
+    cc_edges: Optional[torch.Tensor] = None         # (Ecc, 2) long: Between(v0 = camera i, v1 = camera j)
+    cc_meas: Optional[torch.Tensor] = None          # (1|B, Ecc, 3, 4)
+    w_cc: Optional[torch.Tensor] = None             # (1|B, Ecc, 6)
 
     @property
     def n(self):
@@ -66,7 +70,7 @@ class BAProblem:
 
     @property
     def m(self):
-        return sum({"obs": 2, "cam_prior": 6, "pt_prior": 3}[k] for k, _ in self.cost_order)
+        return sum({"obs": 2, "cam_prior": 6, "pt_prior": 3, "cam_between": 6}[k] for k, _ in self.cost_order)
 
     def col_starts(self):
         cs, c = {}, 0
@@ -88,10 +92,19 @@ class BAProblem:
         ept = (pts[:, self.pt_prior_idx] - self.pt_prior_target) * self.w_pt_prior     # vector.py:150-178, J = I
         return Jc, Jp, e, e_raw, Jcp, ecp, ept
 
+    def cc_terms(self, state):
+        """weighted Jacobians / error of the camera-camera Between costs: J0, J1 (B, Ecc, 6, 6), e (B, Ecc, 6), or None."""
+        if self.cc_edges is None or self.cc_edges.shape[0] == 0:
+            return None
+        cams = state[0]
+        return opg.between_jac_err(cams[:, self.cc_edges[:, 0]], cams[:, self.cc_edges[:, 1]], self.cc_meas, self.w_cc, opg.GROUPS["SE3"])
+
     def error_metric(self, state):
         _, _, _, e_raw, _, ecp, ept = self.terms(state)
         h = opg.robust_weighted_error(e_raw, self.robust_obs, self.log_radius_obs)
-        return 0.5 * ((h**2).sum((1, 2)) + (ecp**2).sum((1, 2)) + (ept**2).sum((1, 2)))
+        err = 0.5 * ((h**2).sum((1, 2)) + (ecp**2).sum((1, 2)) + (ept**2).sum((1, 2)))
+        cc = self.cc_terms(state)
+        return err if cc is None else err + 0.5 * (cc[2]**2).sum((1, 2))
 
     def dense_linearize(self, state):
         cams, pts = state
@@ -100,9 +113,16 @@ class BAProblem:
         A = torch.zeros(B, self.m, self.n, dtype=cams.dtype)
         b = torch.zeros(B, self.m, dtype=cams.dtype)
         cs = self.col_starts()
+        odo = self.cc_terms(state)
         r = 0
         for kind, k in self.cost_order:
-            if kind == "obs":
+            if kind == "cam_between":
+                ci, cj = cs[("cam", int(self.cc_edges[k, 0]))], cs[("cam", int(self.cc_edges[k, 1]))]
+                A[:, r:r + 6, ci:ci + 6] = odo[0][:, k]
+                A[:, r:r + 6, cj:cj + 6] = odo[1][:, k]
+                b[:, r:r + 6] = -odo[2][:, k]
+                r += 6
+            elif kind == "obs":
                 cc, cp = cs[("cam", int(self.obs_cam[k]))], cs[("pt", int(self.obs_pt[k]))]
                 A[:, r:r + 2, cc:cc + 6] = Jc[:, k]
                 A[:, r:r + 2, cp:cp + 3] = Jp[:, k]

@@ -960,6 +960,11 @@ def gen_ba(th, only=None):
     cases = [("ba_f64_lm", torch.float64, 4, dict(max_iterations=8, step_size=1.0), dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True), "huber", small),
              ("ba_f64_gn", torch.float64, 3, dict(max_iterations=6, step_size=0.5), None, None, small),
              ("ba_f32_lm", torch.float32, 4, dict(max_iterations=6, step_size=1.0), dict(damping=1e-2), "welsch", small),
+             # beyond the example's shape: odometry -- Between costs on consecutive CAMERAS next to the reprojections (the reduced
+             # camera system gets off-diagonal blocks that no shared point produces).  Pins the ORACLE; the HIP path does not
+             # fuse camera-camera costs yet
+             ("ba_f64_camcam_lm", torch.float64, 3, dict(max_iterations=6, step_size=1.0),
+              dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True), "huber", small),
              # reduced camera system 192 x 192 (two 128-tiles of the Cholesky, multi-row Schur tables), 512 points
              ("ba_mid_f64_lm", torch.float64, 2, dict(max_iterations=4, step_size=1.0),
               dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True), "huber",
@@ -1030,6 +1035,18 @@ def gen_ba(th, only=None):
             obj.add(th.Difference(cam_v[i], th.SE3(tensor=gt_c[:, i].clone(), name=f"gt_cam{i}"), cw, name=f"camera_diff_{i}"))
             cost_order.append(("cam_prior", len(cam_prior_idx)))
             cam_prior_idx.append(i)
+        extra = {}
+        if "camcam" in name:
+            cc_edges = np.array([(i, i + 1) for i in range(C - 1)] + [(C - 1, 0)], dtype=np.int64)   # the last one points backwards
+            rel = lieF.SE3.compose(lieF.SE3.inv(gt_c[0, cc_edges[:, 0]].double()), gt_c[0, cc_edges[:, 1]].double())
+            noise = lieF.SE3.exp(torch.cat([0.05 * rnd(B * len(cc_edges), 3), 0.01 * rnd(B * len(cc_edges), 3)], 1))
+            cc_meas = lieF.SE3.compose(rel.repeat(B, 1, 1), noise).view(B, len(cc_edges), 3, 4).to(dtype)
+            w_cc = (0.5 + torch.rand(1, len(cc_edges), 6, dtype=torch.float64, generator=gen)).to(dtype) * 3.0
+            for k, (i, j) in enumerate(cc_edges.tolist()):
+                obj.add(th.Between(cam_v[i], cam_v[j], th.SE3(tensor=cc_meas[:, k].clone(), name=f"odo_{k}"),
+                                   th.DiagonalCostWeight(th.Variable(w_cc[:, k].clone(), name=f"w_odo_{k}")), name=f"odometry_{k}"))
+                cost_order.append(("cam_between", k))
+            extra = dict(cc_edges=cc_edges, cc_meas=cc_meas.numpy(), w_cc=w_cc.numpy())
         obj.update()
         cls = th.LevenbergMarquardt if lmk is not None else th.GaussNewton
         opt = cls(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, abs_err_tolerance=0.0, rel_err_tolerance=0.0, **ok)
@@ -1062,12 +1079,12 @@ def gen_ba(th, only=None):
             cam_prior_idx=np.array(cam_prior_idx, dtype=np.int64), cam_prior_target=cam_prior_target.numpy(), w_cam_prior=w_cam_prior.numpy(),
             pt_prior_idx=np.array(pt_prior_idx, dtype=np.int64), w_pt_prior=np.full((1, len(pt_prior_idx), 3), reg_w, dtype=feat.numpy().dtype),
             var_kind=np.array([0 if k == "cam" else 1 for k, _ in var_order]), var_idx=np.array([i for _, i in var_order]),
-            cost_kind=np.array([{"obs": 0, "cam_prior": 1, "pt_prior": 2}[k] for k, _ in cost_order]), cost_idx=np.array([i for _, i in cost_order]),
+            cost_kind=np.array([{"obs": 0, "cam_prior": 1, "pt_prior": 2, "cam_between": 3}[k] for k, _ in cost_order]), cost_idx=np.array([i for _, i in cost_order]),
             robust=np.array(robust or ""), log_radius=np.float64(1.5), A0=A0, b0=b0, err0=err0, AtA=np.stack(taps["AtA"]),
             Atb=np.stack(taps["Atb"]), delta=np.stack(taps["delta"]), err_history=info.err_history.numpy(),
             final_cams=torch.stack([v.tensor for v in cam_v], 1).numpy(), final_pts=torch.stack([v.tensor for v in pt_v], 1).numpy(),
             var_start_cols=np.array(lin.var_start_cols), num_rows=lin.num_rows, num_cols=lin.num_cols,
-            opt_kwargs=np.array(repr(dict(ok, **(lmk or {}), gauss_newton=lmk is None))))
+            opt_kwargs=np.array(repr(dict(ok, **(lmk or {}), gauss_newton=lmk is None))), **extra)
         print(name, "err", info.err_history[:, 0].numpy(), "->", info.err_history[:, -1].numpy(), "unobserved points:",
               Np - len(pt_prior_idx))
 
@@ -1159,7 +1176,7 @@ def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten
         cam_prior_idx=np.array(cam_prior_idx, dtype=np.int64), cam_prior_target=cam_prior_target.numpy(), w_cam_prior=w_cam_prior.numpy(),
         pt_prior_idx=np.array(pt_prior_idx, dtype=np.int64), w_pt_prior=np.full((1, len(pt_prior_idx), 3), float(leaves["w_reg"])),
         var_kind=np.array([0 if k == "cam" else 1 for k, _ in var_order]), var_idx=np.array([i for _, i in var_order]),
-        cost_kind=np.array([{"obs": 0, "cam_prior": 1, "pt_prior": 2}[k] for k, _ in cost_order]), cost_idx=np.array([i for _, i in cost_order]),
+        cost_kind=np.array([{"obs": 0, "cam_prior": 1, "pt_prior": 2, "cam_between": 3}[k] for k, _ in cost_order]), cost_idx=np.array([i for _, i in cost_order]),
         robust=np.array(robust + ("+flatten" if flatten else "")), log_radius=np.float64(1.5), final_cams=d(final_c), final_pts=d(final_p), coef_c=coef_c.numpy(),
         coef_p=coef_p.numpy(), loss=loss.item(), n_reg_cam=n_reg_cam,
         grad_log_radius=d(leaves["log_radius"].grad), grad_feat=d(leaves["feat"].grad), grad_focal=d(leaves["focal"].grad),
@@ -1233,8 +1250,8 @@ def main():
     if not only or "pgo_kat" in only:
         gen_pgo_kat(th)
     if not only or "ba" in only:   # (the small cases; the multi-tile and full-size ones are asked for by name)
-        gen_ba(th, {"ba_f64_lm", "ba_f64_gn", "ba_f32_lm"})
-    if only & {"ba_mid_f64_lm", "ba_mid_f32_lm", "ba_full_f64_lm"}:
+        gen_ba(th, {"ba_f64_lm", "ba_f64_gn", "ba_f32_lm", "ba_f64_camcam_lm"})
+    if only & {"ba_mid_f64_lm", "ba_mid_f32_lm", "ba_full_f64_lm", "ba_f64_camcam_lm"}:
         gen_ba(th, only)
     if not only or only & {"pg_full_f64_lm", "pg_full_f32_lm"}:
         gen_pg_full(th, lieF, only & {"pg_full_f64_lm", "pg_full_f32_lm"})

@@ -60,7 +60,7 @@ def ba_problem(g):
     used = sorted(i for k, i in zip(kinds, idxs) if k == 1)
     remap = {old: new for new, old in enumerate(used)}
     var_order = [("cam", i) if k == 0 else ("pt", remap[i]) for k, i in zip(kinds, idxs)]
-    cost_order = [(("obs", "cam_prior", "pt_prior")[k], int(i)) for k, i in zip(g["cost_kind"].tolist(), g["cost_idx"].tolist())]
+    cost_order = [(("obs", "cam_prior", "pt_prior", "cam_between")[k], int(i)) for k, i in zip(g["cost_kind"].tolist(), g["cost_idx"].tolist())]
     dtype = t(g["cams0"]).dtype
     robust = str(g["robust"]) or None
     p = oba.BAProblem(
@@ -70,6 +70,8 @@ def ba_problem(g):
         pt_prior_idx=torch.tensor([remap[i] for i in g["pt_prior_idx"].tolist()]),
         pt_prior_target=torch.zeros(1, g["pt_prior_idx"].shape[0], 3, dtype=dtype), w_pt_prior=t(g["w_pt_prior"]),
         var_order=var_order, cost_order=cost_order, robust_obs=robust,
-        log_radius_obs=torch.full((1, 1, 1), float(g["log_radius"]), dtype=dtype) if robust else None)
+        log_radius_obs=torch.full((1, 1, 1), float(g["log_radius"]), dtype=dtype) if robust else None,
+        cc_edges=t(g["cc_edges"]) if "cc_edges" in g else None, cc_meas=t(g["cc_meas"]) if "cc_edges" in g else None,
+        w_cc=t(g["w_cc"]) if "cc_edges" in g else None)
     kw = ast.literal_eval(str(g["opt_kwargs"]))
     return p, (t(g["cams0"]), t(g["pts0"])[:, used]), kw, used

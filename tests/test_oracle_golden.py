@@ -188,10 +188,11 @@ def test_reference_pgo_known_answer_test():
         assert got == pytest.approx(want, rel=1e-10, abs=1e-10), (losses, g["losses_published"])
 
 
-@pytest.mark.parametrize("name,tol", [("ba_f64_lm", 1e-7), ("ba_f64_gn", 1e-7), ("ba_f32_lm", 5e-3)])
+@pytest.mark.parametrize("name,tol", [("ba_f64_lm", 1e-7), ("ba_f64_gn", 1e-7), ("ba_f32_lm", 5e-3), ("ba_f64_camcam_lm", 1e-7)])
 def test_bundle_adjustment_matches_reference(name, tol):
     """oracle/ba.py (Reprojection + robust loss + SE3 / Point3 Difference priors, mixed variable ordering) against the
-    reference's DenseLinearization + CholeskyDenseSolver run (oracle/gen_golden.py:gen_ba)."""
+    reference's DenseLinearization + CholeskyDenseSolver run (oracle/gen_golden.py:gen_ba).  ``ba_f64_camcam_lm`` adds
+    camera-camera Between (odometry) costs -- beyond the example's shape; oracle only so far."""
     from tests.helpers import ba_problem
     g = load_golden(name)
     p, state0, kw, used = ba_problem(g)
