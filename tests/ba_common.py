@@ -41,6 +41,10 @@ def build_ba_objective(th, g, device="cpu"):
         elif kind == 2:
             i = int(g["pt_prior_idx"][k])
             obj.add(th.Difference(pt_v[i], zero_pt, th.ScaleCostWeight(w_p[:, k, :1].clone()), name=f"pt_prior_{k}"))
+        elif kind == 3:   # camera-camera Between (odometry): tests/golden/ba_f64_camcam_lm.npz
+            i, j = g["cc_edges"][k].tolist()
+            obj.add(th.Between(cam_v[i], cam_v[j], th.SE3(tensor=t(g["cc_meas"])[:, k].clone(), name=f"odo_{k}"),
+                               th.DiagonalCostWeight(th.Variable(t(g["w_cc"])[:, k].clone(), name=f"w_odo_{k}")), name=f"odometry_{k}"))
     return obj, cam_v, pt_v
 
 

@@ -9,8 +9,10 @@ from tests.ba_common import reference_columns, run_ba
 from tests.helpers import load_golden
 
 
-@pytest.mark.parametrize("name", ["ba_f64_lm", "ba_f64_gn"])
+@pytest.mark.parametrize("name", ["ba_f64_lm", "ba_f64_gn", "ba_f64_camcam_lm"])
 def test_ba_host_path_matches_reference(name):
+    """(``ba_f64_camcam_lm``: Between costs on consecutive cameras next to the reprojections -- beyond the example's shape; their
+    blocks come from the pose-graph kernels over the camera buffer and join the Schur complement, theseus_amd/ba.py.)"""
     import theseus_amd as th
     from tests.oracle_kernels import OracleKernels
     g = load_golden(name)
@@ -106,3 +108,37 @@ def test_banded_reduced_system_is_factorised_along_its_tile_pattern():
     np.testing.assert_allclose(out[True][0].numpy(), out[False][0].numpy(), rtol=0, atol=1e-12)
     np.testing.assert_allclose(out[True][1].numpy(), out[False][1].numpy(), rtol=1e-12)
     assert (out[True][1][:, -1] < out[True][1][:, 0]).all()
+
+
+def test_camera_camera_costs_av_rows_and_dogleg():
+    """``Av`` of a bundle-adjustment linearization with camera-camera Between costs: the odometry rows (thx_pg_jacobians over the
+    camera buffer) next to the thx_ba_av rows, against the oracle's dense A in the reference's row / column layout; Dogleg (which
+    reads Av) runs on the objective; the implicit backward refuses gradients w.r.t. the odometry measurements (not wired yet)."""
+    import theseus_amd as th
+    from tests.ba_common import build_ba_objective, reference_columns
+    from tests.helpers import ba_problem
+    from tests.oracle_kernels import OracleKernels
+    g = load_golden("ba_f64_camcam_lm")
+    obj, cam_v, pt_v = build_ba_objective(th, g, "cpu")
+    opt = th.Dogleg(obj, max_iterations=3, abs_err_tolerance=0.0, rel_err_tolerance=0.0, linearization_kwargs=dict(kernels=OracleKernels()))
+    lin = opt.linear_solver.linearization
+    assert len(lin.packed.cc_costs) == g["cc_edges"].shape[0]
+    lin.linearize()
+    p, state0, _, used = ba_problem(g)
+    A, b = p.dense_linearize(state0)                       # reference layout: rows in cost add order, columns in insertion order
+    cols, _ = reference_columns(g)
+    v = torch.randn(A.shape[0], lin.n, dtype=torch.float64, generator=torch.Generator().manual_seed(4))
+    want = (A @ v[:, cols].unsqueeze(2)).squeeze(2)        # v is in the linearization's order (cameras, then points)
+    np.testing.assert_allclose(lin.Av(v).numpy(), want.numpy(), rtol=0, atol=1e-9 * float(want.abs().max()))
+    np.testing.assert_allclose(lin.g.numpy()[:, cols], (A.transpose(1, 2) @ b.unsqueeze(2)).squeeze(2).numpy(), rtol=0,
+                               atol=1e-9 * float(lin.g.abs().max()))
+    with torch.no_grad():
+        _, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(track_err_history=True, trust_region_init=2.0))
+    assert (info.err_history[:, -1] < info.err_history[:, 0]).all()
+    # implicit mode: the odometry measurements are not differentiable yet
+    obj2, _, _ = build_ba_objective(th, g, "cpu")
+    meas = next(c for c in obj2.cost_functions.values() if c.name == "odometry_0").measurement
+    meas.tensor = meas.tensor.clone().requires_grad_(True)
+    opt2 = th.LevenbergMarquardt(obj2, max_iterations=2, linearization_kwargs=dict(kernels=OracleKernels()))
+    with pytest.raises(NotImplementedError, match="camera-camera"):
+        th.TheseusLayer(opt2).forward(None, optimizer_kwargs=dict(backward_mode="implicit", damping=1e-2))

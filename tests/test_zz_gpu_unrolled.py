@@ -1,4 +1,4 @@
-"""-m gpu, collected LAST: BackwardMode.UNROLL / TRUNCATED on the generic path through the HIP kernels (thx_block_assemble, the
+"""-m gpu, collected LAST (features added after the round's last GPU run): BackwardMode.UNROLL / TRUNCATED on the generic path through the HIP kernels (thx_block_assemble, the
 tiled Cholesky's damped factorisation, thx_chol_solve with a copy of each iteration's factor in the backward) against the REAL
 reference's gradients (tests/golden/simple_example.npz).  CPU twin with the stand-in kernels: tests/test_generic_host.py."""
 import pytest
@@ -13,3 +13,21 @@ pytestmark = pytest.mark.gpu
 def test_differentiating_through_the_iterations_on_the_gpu(tag):
     import theseus_amd as th
     run_unrolled(th, load_golden("simple_example"), tag, "cuda")
+
+
+def test_ba_with_camera_camera_costs_on_the_gpu():
+    """Bundle adjustment with Between (odometry) costs on consecutive cameras through the HIP kernels -- thx_pg_assemble /
+    thx_pg_error over the camera buffer joined with the Schur complement (theseus_amd/ba.py) -- against the REAL reference's run
+    (tests/golden/ba_f64_camcam_lm.npz).  CPU twin with the stand-in kernels: tests/test_ba_host.py."""
+    import numpy as np
+    import theseus_amd as th
+    from tests.ba_common import reference_columns, run_ba
+    g = load_golden("ba_f64_camcam_lm")
+    cams, pts, used, deltas, info, opt = run_ba(th, g, None, "cuda")
+    assert len(opt.linear_solver.linearization.packed.cc_costs) == g["cc_edges"].shape[0]
+    np.testing.assert_allclose(cams.cpu().numpy(), g["final_cams"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(pts.cpu().numpy(), g["final_pts"][:, used], rtol=0, atol=1e-5)
+    k = min(info.err_history.shape[1], g["err_history"].shape[1])
+    np.testing.assert_allclose(info.err_history[:, :k].numpy(), g["err_history"][:, :k], rtol=1e-6)
+    cols, _ = reference_columns(g)
+    np.testing.assert_allclose(deltas[0].cpu().numpy()[:, cols], g["delta"][0], rtol=0, atol=1e-7 * max(1.0, np.abs(g["delta"][0]).max()))

@@ -16,7 +16,8 @@ import torch
 
 from . import _lib
 from .core import Objective, Variable
-from .kernels import default_kernels, fast_approx_local_jacobians, round_up
+from .compiler import PoseGraphStructure
+from .kernels import PGTensors, default_kernels, fast_approx_local_jacobians, round_up
 from .linear_solver import LinearSolver
 from .linearization import Linearization, VariableOrdering
 from .packed import UnsupportedObjective, _aux_vars, _kind, _unwrap_robust, _weight_diag
@@ -184,8 +185,9 @@ class PackedBA:
         ci = {v.name: k for k, v in enumerate(self.cam_vars)}
         pi = {v.name: k for k, v in enumerate(self.pt_vars)}
         self.obs_costs, self.obs_radius, self.cam_prior_costs, self.pt_prior_costs = [], [], [], []
+        self.cc_costs, cc_edges = [], []   # camera-camera Between costs (odometry): a pose graph over the cameras
         obs_cam, obs_pt, cpc, ppp, kinds = [], [], [], [], set()
-        row, rows = 0, ([], [], [])   # first row of every cost in the reference's (B, m) layouts: cost ADD order
+        row, rows = 0, ([], [], [], [])   # first row of every cost in the reference's (B, m) layouts: cost ADD order
         for wrapped in objective.cost_functions.values():
             c, loss, radius = _unwrap_robust(wrapped)
             names = {k.__name__ for k in type(c).__mro__}
@@ -208,14 +210,25 @@ class PackedBA:
                     self.pt_prior_costs.append(c)
                     rows[2].append(row)
                     row += 3
+            elif _kind(c) == "Between" and not loss and c.v0.name in ci and c.v1.name in ci:
+                cc_edges.append((ci[c.v0.name], ci[c.v1.name]))
+                self.cc_costs.append(c)
+                rows[3].append(row)
+                row += 6
             else:
                 raise UnsupportedObjective(f"HIP bundle adjustment has no fused kernel for {type(wrapped).__name__} "
-                                           f"({wrapped.name}); supported: Reprojection (optionally robust), Difference.")
+                                           f"({wrapped.name}); supported: Reprojection (optionally robust), Difference, "
+                                           "Between on two cameras.")
         if len(kinds) > 1:
             raise UnsupportedObjective("HIP bundle adjustment: all Reprojection costs must share one robust loss kind.")
         self.robust_obs = kinds.pop() if kinds else _lib.LOSS_NONE
         self._refuse_fast_approx(UnsupportedObjective)
         self.structure = BAStructure(len(self.cam_vars), len(self.pt_vars), obs_cam, obs_pt, cpc, ppp)
+        # Camera-camera costs ride on the pose-graph kernels (thx_pg_assemble / thx_pg_error / thx_pg_jacobians / thx_pg_vjp over
+        # the CAMERA buffer): their 6 x 6 blocks are added to the camera part of the system before / after the point elimination
+        # (HipSchurLinearizationCore._assemble, HipSchurSolverCore._solve).
+        self.cc_structure = PoseGraphStructure.build(len(self.cam_vars), cc_edges, [], edge_row_start=rows[3]) if cc_edges else None
+        self.cc_tensors: Optional[PGTensors] = None
         self.n = self.structure.n
         self.nc = 6 * len(self.cam_vars)
         self.m = objective.dim()
@@ -259,6 +272,9 @@ class PackedBA:
                 yield r
         for c in self.cam_prior_costs + self.pt_prior_costs:
             yield c.target
+            yield from _aux_vars(c.weight)
+        for c in self.cc_costs:
+            yield c.measurement
             yield from _aux_vars(c.weight)
 
     def _counters_unchanged(self) -> bool:
@@ -331,6 +347,10 @@ class PackedBA:
         self.tensors = BATensors(cams=cams, points=pts, feat=feat, w_obs=w_obs, focal=focal, k1=k1, k2=k2,
                                  cam_prior_target=cpt, w_cam_prior=wcp, pt_prior_target=ppt, w_pt_prior=wpp,
                                  robust_obs=self.robust_obs, log_radius_obs=lr)
+        if self.cc_costs:
+            self.cc_tensors = PGTensors(poses=cams, meas=self._stack([c.measurement.tensor for c in self.cc_costs], B),
+                                        w_between=self._stack([_weight_diag(c.weight, 6) for c in self.cc_costs], B),
+                                        prior_target=empty(0, 1, 3, 4), w_prior=empty(0, 1, 6))
         self._repoint_variables()
 
     def _repoint_variables(self):
@@ -437,7 +457,16 @@ class PackedBA:
         err = out if out is not None else torch.empty(B, dtype=self.objective.dtype, device=part.device)
         cams, pts = state if state is not None else (None, None)
         self.K.ba_error(self.dstruct, self.tensors, part, err, cams=cams, points=pts)
+        if self.cc_costs:   # + the camera-camera costs' share of the metric (thx_pg_error over the camera buffer)
+            err_cc = self._buf("err_cc", (B,))
+            self.K.pg_error(self.cc_dstruct, self.cc_tensors, self._buf("err_part_cc", (_lib.THX_ERR_CHUNKS, B)), err_cc,
+                            poses=cams if cams is not None else self.tensors.cams)
+            err.add_(err_cc)
         return err
+
+    @property
+    def cc_dstruct(self):
+        return self.cc_structure.on(self.device)
 
     def retract(self, delta: torch.Tensor, step: float, ignore_mask: Optional[torch.Tensor], out):
         self.sync()
@@ -493,12 +522,32 @@ class HipSchurLinearizationCore:
             self.Hcc, self.Hpp = f64(s.num_cams, 36, B), f64(s.num_points, 6, B)
             self.W, self.gd = f64(max(s.num_obs, 1), 18, B), f64(B, p.n)
             self.g, self.diag = new(B, p.n), new(B, p.n)
+            if p.cc_costs:   # the camera-camera costs' blocks: a dense (6C)^2 frame like the reduced system's (zero-filled once)
+                ldc = round_up(p.nc, 32)
+                self.H_odo, self.g_odo = torch.zeros(B, ldc, ldc, dtype=dt, device=dev), new(B, p.nc)
+                C = s.num_cams
+                k = torch.arange(6, device=dev)
+                base = 6 * torch.arange(C, device=dev).view(C, 1, 1)
+                self._odo_rows, self._odo_cols = (base + k.view(1, 6, 1)).expand(C, 6, 6), (base + k.view(1, 1, 6)).expand(C, 6, 6)
 
     def _assemble(self):
         self._ensure_buffers()
         p = self.packed
         p._refuse_fast_approx()
         self.K.ba_assemble(p.dstruct, p.tensors, self.Hcc, self.Hpp, self.W, self.gd, self.g, self.diag)
+        if p.cc_costs:
+            # camera-camera Between costs: thx_pg_assemble over the camera buffer.  Their DIAGONAL blocks and gradient join the
+            # camera blocks before the point elimination (damping sees them); the off-diagonal blocks are added to the reduced
+            # system after it (HipSchurSolverCore._solve):  S = (Hcc + Hodo)' - Hcp Hpp'^-1 Hpc.
+            self.K.pg_assemble(p.cc_dstruct, p.cc_tensors, self.H_odo, self.g_odo, poses=p.tensors.cams)
+            nc = p.nc
+            D = torch.tril(self.H_odo[:, self._odo_rows, self._odo_cols])           # (B, C, 6, 6): lower part is what is defined
+            D = (D + torch.tril(D, -1).transpose(2, 3)).double()
+            self.Hcc.add_(D.reshape(D.shape[0], D.shape[1], 36).permute(1, 2, 0))
+            self.H_odo[:, self._odo_rows, self._odo_cols] = 0                       # what is left: the off-diagonal blocks
+            self.gd[:, :nc].add_(self.g_odo.double())
+            self.g[:, :nc].add_(self.g_odo)
+            self.diag[:, :nc].add_(D.diagonal(dim1=2, dim2=3).reshape(D.shape[0], nc).to(self.diag.dtype))
 
     def _linearize_jacobian_impl(self):
         raise NotImplementedError("the dense Jacobian of a bundle-adjustment objective is not materialised")
@@ -524,8 +573,21 @@ class HipSchurLinearizationCore:
             p._cost_rows_dev[key] = tuple(torch.from_numpy(r).to(v.device) for r in p.cost_rows)
         v = v.to(self.objective.dtype).contiguous()
         out_t = torch.empty(p.m, v.shape[0], dtype=v.dtype, device=v.device)
-        self.K.ba_av(p.dstruct, p.tensors, v, p._cost_rows_dev[key], out_t)
-        return out_t.t().contiguous()
+        self.K.ba_av(p.dstruct, p.tensors, v, p._cost_rows_dev[key][:3], out_t)
+        out = out_t.t().contiguous()
+        if p.cc_costs:   # rows of the camera-camera costs: J0 v_i + J1 v_j from thx_pg_jacobians over the camera buffer
+            E, B = len(p.cc_costs), v.shape[0]
+            J0, J1 = (torch.empty(E, B, 6, 6, dtype=v.dtype, device=v.device) for _ in range(2))
+            eb = torch.empty(E, B, 6, dtype=v.dtype, device=v.device)
+            Jp, ep = torch.empty(1, B, 6, 6, dtype=v.dtype, device=v.device), torch.empty(1, B, 6, dtype=v.dtype, device=v.device)
+            self.K.pg_jacobians(p.cc_dstruct, p.cc_tensors, J0, J1, eb, Jp, ep, poses=p.tensors.cams)
+            st = p.cc_structure
+            vc = v[:, :p.nc].reshape(B, -1, 6)
+            vi = vc[:, torch.from_numpy(st.edge_i).long().to(v.device)].transpose(0, 1).unsqueeze(3)   # (E, B, 6, 1)
+            vj = vc[:, torch.from_numpy(st.edge_j).long().to(v.device)].transpose(0, 1).unsqueeze(3)
+            rows = (p._cost_rows_dev[key][3].long().view(-1, 1) + torch.arange(6, device=v.device)).view(-1)
+            out[:, rows] = (J0 @ vi + J1 @ vj).squeeze(3).transpose(0, 1).reshape(B, -1)
+        return out
 
     def diagonal_scaling(self, v: torch.Tensor) -> torch.Tensor:
         return self.diag * v
@@ -558,6 +620,22 @@ class HipSchurSolverCore:
         self.S = self.L = self.panels = self.info_chol = self.info_pts = None
         self.pattern, self.sparse, self._want_sparse = None, False, bool(sparse_reduced_system)
         self.factor_version = 0
+        self._odo_only = None
+
+    @staticmethod
+    def _blocks_only_odometry(p):
+        """(rows, cols) index tensors of the 6 x 6 blocks of S that ONLY camera-camera costs fill (no shared point), or None."""
+        t, st = p.structure.t, p.cc_structure
+        shared = set(zip(t["blk_c1"].tolist(), t["blk_c2"].tolist()))
+        only = sorted({(max(i, j), min(i, j)) for i, j in zip(st.edge_i.tolist(), st.edge_j.tolist())} - shared)
+        if not only:
+            return None
+        dev = p.device
+        k = torch.arange(6, device=dev)
+        c1 = 6 * torch.tensor([a for a, _ in only], device=dev).view(-1, 1, 1)
+        c2 = 6 * torch.tensor([b for _, b in only], device=dev).view(-1, 1, 1)
+        n = len(only)
+        return (c1 + k.view(1, 6, 1)).expand(n, 6, 6), (c2 + k.view(1, 1, 6)).expand(n, 6, 6)
 
     def _ensure_buffers(self):
         lin = self.linearization
@@ -587,6 +665,10 @@ class HipSchurSolverCore:
             cams = np.arange(lin.packed.structure.num_cams, dtype=np.int64)
             blocks = np.concatenate([np.stack([cams, cams], 1),
                                      np.stack([t["blk_c1"].astype(np.int64), t["blk_c2"].astype(np.int64)], 1)], 0)
+            if lin.packed.cc_costs:   # + the blocks the camera-camera costs put into the reduced system
+                st = lin.packed.cc_structure
+                ei, ej = st.edge_i.astype(np.int64), st.edge_j.astype(np.int64)
+                blocks = np.concatenate([blocks, np.stack([np.maximum(ei, ej), np.minimum(ei, ej)], 1)], 0)
             self.pattern = TilePattern(nc, blocks, 6)
             self.sparse = self._want_sparse and self.pattern.l_tiles < self.pattern.ntiles * (self.pattern.ntiles + 1) // 2
 
@@ -621,6 +703,15 @@ class HipSchurSolverCore:
         self._factor_args = (lam.clone() if lam is not None else None, ellipsoidal_damping, damping_eps)
         self.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, lin.gd, lam, ellipsoidal_damping, damping_eps, self.S, self.rhs,
                         self.Hinv, self.tvec, self.info_pts)
+        if p.cc_costs:
+            # thx_ba_schur writes (does not accumulate) the blocks two cameras share through a point; the off-diagonal blocks of
+            # the camera-camera costs are added on top.  Blocks only they touch keep the previous call's sum otherwise: zero them
+            # first.  (A full-frame pass: the price of composing existing kernels -- DESIGN.md 4.3.)
+            if self._odo_only is None:
+                self._odo_only = self._blocks_only_odometry(p)
+            if self._odo_only is not None:
+                self.S[:, self._odo_only[0], self._odo_only[1]] = 0
+            self.S.add_(lin.H_odo)
         if self.sparse:
             self.K.chol_factor_sparse(self.S, p.nc, None, False, damping_eps, self.L, self.panels, self.info_chol, self.pattern,
                                       rhs=self.rhs, y=self._y)
@@ -758,6 +849,9 @@ def ba_implicit_step(opt, packed, step: float, kwargs):
     packed.flush_variables()
     packed.sync(force=True)   # re-pack the auxiliary tensors WITH their autograd history
     t = packed.tensors
+    if packed.cc_costs and (packed.cc_tensors.meas.requires_grad or packed.cc_tensors.w_between.requires_grad):
+        raise NotImplementedError("HIP bundle adjustment: the implicit backward does not reach the measurements / weights of "
+                                  "camera-camera Between costs yet (gradients w.r.t. everything else are available).")
     cams, pts, delta = BAImplicitStep.apply(opt, packed, step, kwargs, t.feat, t.w_obs, t.focal, t.k1, t.k2, t.log_radius_obs,
                                             t.cam_prior_target, t.w_cam_prior, t.pt_prior_target, t.w_pt_prior)
     return (cams, pts), delta
