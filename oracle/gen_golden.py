@@ -1089,7 +1089,7 @@ def gen_ba(th, only=None):
               Np - len(pt_prior_idx))
 
 
-def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten=False):
+def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten=False, camcam=False):
     """Implicit backward through a bundle-adjustment objective (examples/bundle_adjustment.py:184-215 learns log_loss_radius this
     way): LM under no_grad, one undamped GN step with the Hessian detached and grad enabled; loss = <coef, final cameras> +
     <coef, final points>; gradients w.r.t. log_loss_radius, the image features, the calibration (focal, k1, k2), the
@@ -1156,6 +1156,19 @@ def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten
         obj.add(th.Difference(cam_v[i], th.SE3(tensor=leaves["gt_cams"][:, k], name=f"gt_cam{i}"), cw, name=f"camera_diff_{i}"))
         cost_order.append(("cam_prior", len(cam_prior_idx)))
         cam_prior_idx.append(i)
+    extra = {}
+    if camcam:   # odometry: Between costs on consecutive cameras (+ one pointing backwards), measurements / weights differentiable
+        cc_edges = np.array([(i, i + 1) for i in range(C - 1)] + [(C - 1, 0)], dtype=np.int64)
+        gt_all = torch.stack([c.pose.tensor[0] for c in ba.gt_cameras]).double()
+        rel = lieF.SE3.compose(lieF.SE3.inv(gt_all[cc_edges[:, 0]]), gt_all[cc_edges[:, 1]])
+        noise = lieF.SE3.exp(torch.cat([0.05 * rnd(B * len(cc_edges), 3), 0.01 * rnd(B * len(cc_edges), 3)], 1))
+        leaves["cc_meas"] = lieF.SE3.compose(rel.repeat(B, 1, 1), noise).view(B, len(cc_edges), 3, 4).to(dtype).requires_grad_(True)
+        leaves["w_cc"] = ((0.5 + torch.rand(1, len(cc_edges), 6, dtype=torch.float64, generator=gen)) * 3.0).to(dtype).requires_grad_(True)
+        for k, (i, j) in enumerate(cc_edges.tolist()):
+            obj.add(th.Between(cam_v[i], cam_v[j], th.SE3(tensor=leaves["cc_meas"][:, k], name=f"odo_{k}"),
+                               th.DiagonalCostWeight(th.Variable(leaves["w_cc"][:, k], name=f"w_odo_{k}")), name=f"odometry_{k}"))
+            cost_order.append(("cam_between", k))
+        extra = dict(cc_edges=cc_edges)
     opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=not flatten, abs_err_tolerance=0.0,
                                 rel_err_tolerance=0.0, max_iterations=iters, step_size=1.0)
     sol, info = th.TheseusLayer(opt, vectorize=not flatten).forward(optimizer_kwargs=dict(backward_mode="implicit", damping=1e-2))
@@ -1182,7 +1195,9 @@ def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten
         grad_log_radius=d(leaves["log_radius"].grad), grad_feat=d(leaves["feat"].grad), grad_focal=d(leaves["focal"].grad),
         grad_k1=d(leaves["k1"].grad), grad_k2=d(leaves["k2"].grad), grad_w_obs=d(leaves["w_obs"].grad),
         grad_gt_cams=d(leaves["gt_cams"].grad), grad_w_strong=d(leaves["w_strong"].grad), grad_w_reg=d(leaves["w_reg"].grad),
-        opt_kwargs=np.array(repr(dict(max_iterations=iters, step_size=1.0, damping=1e-2, gauss_newton=False))))
+        opt_kwargs=np.array(repr(dict(max_iterations=iters, step_size=1.0, damping=1e-2, gauss_newton=False))),
+        **extra, **({"cc_meas": d(leaves["cc_meas"]), "w_cc": d(leaves["w_cc"]), "grad_cc_meas": d(leaves["cc_meas"].grad),
+                     "grad_w_cc": d(leaves["w_cc"].grad)} if camcam else {}))
     print(name, "loss", loss.item(), {k: float(v.grad.abs().max()) for k, v in leaves.items()})
 
 
@@ -1259,6 +1274,8 @@ def main():
         gen_ba_implicit(th)
     if not only or "ba_flatten_implicit" in only:
         gen_ba_implicit(th, name="ba_f64_flatten_implicit", flatten=True)
+    if not only or "ba_camcam_implicit" in only:
+        gen_ba_implicit(th, name="ba_f64_camcam_implicit", camcam=True)
     if "pg_full_f64_implicit" in only:     # (full size: asked for by name, ~1 min)
         gen_pg_full_implicit(th, lieF)
     if "ba_mid_f64_implicit" in only:      # 32 cameras: the reduced camera system takes two Cholesky tiles

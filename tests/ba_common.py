@@ -128,6 +128,12 @@ def run_ba_implicit(th, g, kernels=None, device="cpu", opt_kwargs=None):
     cw = th.ScaleCostWeight(th.Variable(leaves["w_strong"].view(1, 1), name="w_strong"))
     for k, i in enumerate((0, C - 1)):
         obj.add(th.Difference(cam_v[i], th.SE3(tensor=leaves["gt_cams"][:, k], name=f"gt_cam{i}"), cw, name=f"camera_diff_{i}"))
+    if "cc_edges" in g:   # camera-camera Between (odometry) costs with differentiable measurements / weights
+        leaves["cc_meas"] = t(g["cc_meas"]).clone().requires_grad_(True)
+        leaves["w_cc"] = t(g["w_cc"]).clone().requires_grad_(True)
+        for k, (i, j) in enumerate(g["cc_edges"].tolist()):
+            obj.add(th.Between(cam_v[i], cam_v[j], th.SE3(tensor=leaves["cc_meas"][:, k], name=f"odo_{k}"),
+                               th.DiagonalCostWeight(th.Variable(leaves["w_cc"][:, k], name=f"w_odo_{k}")), name=f"odometry_{k}"))
     kw = ast.literal_eval(str(g["opt_kwargs"]))
     kw.pop("gauss_newton")
     okw = dict(max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0)

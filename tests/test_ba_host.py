@@ -56,7 +56,7 @@ def test_schur_block_tables_partition_the_pair_list():
     assert s.num_pairs == want
 
 
-@pytest.mark.parametrize("name", ["ba_f64_implicit", "ba_f64_flatten_implicit"])
+@pytest.mark.parametrize("name", ["ba_f64_implicit", "ba_f64_flatten_implicit", "ba_f64_camcam_implicit"])
 def test_ba_implicit_backward_matches_reference_gradients(name):
     """(``ba_f64_flatten_implicit``: the Reprojection costs wrapped with flatten_dims=True -- every image coordinate its own
     Huber term, robust_cost_function.py:89-96,118-133.)
@@ -76,7 +76,10 @@ def test_ba_implicit_backward_matches_reference_gradients(name):
     np.testing.assert_allclose(got["final_cams"], g["final_cams"], rtol=0, atol=1e-7)
     np.testing.assert_allclose(got["final_pts"], g["final_pts"], rtol=0, atol=1e-6)
     assert abs(got["loss"] - float(g["loss"])) < 1e-5
-    for k in ("log_radius", "feat", "focal", "k1", "k2", "w_obs", "gt_cams", "w_strong", "w_reg"):
+    keys = ("log_radius", "feat", "focal", "k1", "k2", "w_obs", "gt_cams", "w_strong", "w_reg")
+    if "cc_edges" in g:   # ba_f64_camcam_implicit: + the odometry measurements / weights (thx_pg_vjp over the camera columns)
+        keys += ("cc_meas", "w_cc")
+    for k in keys:
         want = g["grad_" + k]
         np.testing.assert_allclose(got["grad_" + k], want, rtol=0, atol=5e-6 * max(np.abs(want).max(), 1e-12), err_msg=k)
 
@@ -113,7 +116,7 @@ def test_banded_reduced_system_is_factorised_along_its_tile_pattern():
 def test_camera_camera_costs_av_rows_and_dogleg():
     """``Av`` of a bundle-adjustment linearization with camera-camera Between costs: the odometry rows (thx_pg_jacobians over the
     camera buffer) next to the thx_ba_av rows, against the oracle's dense A in the reference's row / column layout; Dogleg (which
-    reads Av) runs on the objective; the implicit backward refuses gradients w.r.t. the odometry measurements (not wired yet)."""
+    reads Av) runs on the objective."""
     import theseus_amd as th
     from tests.ba_common import build_ba_objective, reference_columns
     from tests.helpers import ba_problem
@@ -135,10 +138,3 @@ def test_camera_camera_costs_av_rows_and_dogleg():
     with torch.no_grad():
         _, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(track_err_history=True, trust_region_init=2.0))
     assert (info.err_history[:, -1] < info.err_history[:, 0]).all()
-    # implicit mode: the odometry measurements are not differentiable yet
-    obj2, _, _ = build_ba_objective(th, g, "cpu")
-    meas = next(c for c in obj2.cost_functions.values() if c.name == "odometry_0").measurement
-    meas.tensor = meas.tensor.clone().requires_grad_(True)
-    opt2 = th.LevenbergMarquardt(obj2, max_iterations=2, linearization_kwargs=dict(kernels=OracleKernels()))
-    with pytest.raises(NotImplementedError, match="camera-camera"):
-        th.TheseusLayer(opt2).forward(None, optimizer_kwargs=dict(backward_mode="implicit", damping=1e-2))

@@ -31,3 +31,19 @@ def test_ba_with_camera_camera_costs_on_the_gpu():
     np.testing.assert_allclose(info.err_history[:, :k].numpy(), g["err_history"][:, :k], rtol=1e-6)
     cols, _ = reference_columns(g)
     np.testing.assert_allclose(deltas[0].cpu().numpy()[:, cols], g["delta"][0], rtol=0, atol=1e-7 * max(1.0, np.abs(g["delta"][0]).max()))
+
+
+def test_ba_with_camera_camera_costs_implicit_backward_on_the_gpu():
+    """... and its implicit backward: all gradient groups of tests/golden/ba_f64_camcam_implicit.npz incl. the odometry measurements
+    and weights (thx_pg_vjp over the camera columns of the backward solve)."""
+    import numpy as np
+    import theseus_amd as th
+    from tests.ba_common import run_ba_implicit
+    g = load_golden("ba_f64_camcam_implicit")
+    got = run_ba_implicit(th, g, None, "cuda")
+    np.testing.assert_allclose(got["final_cams"], g["final_cams"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(got["final_pts"], g["final_pts"], rtol=0, atol=1e-6)
+    assert abs(got["loss"] - float(g["loss"])) < 1e-5
+    for k in ("log_radius", "feat", "focal", "k1", "k2", "w_obs", "gt_cams", "w_strong", "w_reg", "cc_meas", "w_cc"):
+        want = g["grad_" + k]
+        np.testing.assert_allclose(got["grad_" + k], want, rtol=0, atol=5e-6 * max(np.abs(want).max(), 1e-12), err_msg=k)

@@ -764,6 +764,7 @@ class BAImplicitStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, opt, packed, step, kwargs, *aux):
         import warnings
+        aux, cc_aux = aux[:len(BAImplicitStep.NAMES)], aux[len(BAImplicitStep.NAMES):]   # (+ cc_meas, w_cc with odometry costs)
         solver = opt.linear_solver
         lin = solver.linearization
         lin._assemble()
@@ -781,6 +782,9 @@ class BAImplicitStep(torch.autograd.Function):
         packed.retract(delta, step, None, new)
         ctx.opt, ctx.packed, ctx.step, ctx.factor_version = opt, packed, step, solver.factor_version
         ctx.tensors = detached_ba_tensors(packed.tensors, cams, pts, aux)
+        ctx.cc_tensors = None
+        if cc_aux:
+            ctx.cc_tensors = dataclasses.replace(packed.cc_tensors, poses=cams, meas=cc_aux[0].detach(), w_between=cc_aux[1].detach())
         ctx.delta = delta
         ctx.mark_non_differentiable(delta)
         return new[0], new[1], delta
@@ -800,7 +804,15 @@ class BAImplicitStep(torch.autograd.Function):
         if g_pts is not None:
             gd[:, nc:] = g_pts.permute(1, 0, 2).reshape(B, -1) * ctx.step                   # X + step * delta
         w = solver.solve_with_factor(gd)   # the backward linear solve
-        return (None, None, None, None) + ba_vjp_grads(K, packed, t, w)
+        grads = ba_vjp_grads(K, packed, t, w)
+        if ctx.cc_tensors is not None:   # camera-camera Between costs: thx_pg_vjp over the camera columns of w
+            ct, E = ctx.cc_tensors, len(packed.cc_costs)
+            new = lambda *sh: torch.empty(*sh, dtype=dt, device=dev)  # noqa: E731
+            g_meas, g_wb = new(E, B, 3, 4), new(E, B, 6)
+            K.pg_vjp(packed.cc_dstruct, ct, w[:, :nc].contiguous(), g_meas, g_wb, new(1, B, 3, 4), new(1, B, 6))
+            fit = lambda g_, like: g_.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else g_  # noqa: E731
+            grads = grads + (fit(g_meas, ct.meas), fit(g_wb, ct.w_between))
+        return (None, None, None, None) + grads
 
 
 def ba_vjp_grads(K, packed, t, w):
@@ -849,11 +861,9 @@ def ba_implicit_step(opt, packed, step: float, kwargs):
     packed.flush_variables()
     packed.sync(force=True)   # re-pack the auxiliary tensors WITH their autograd history
     t = packed.tensors
-    if packed.cc_costs and (packed.cc_tensors.meas.requires_grad or packed.cc_tensors.w_between.requires_grad):
-        raise NotImplementedError("HIP bundle adjustment: the implicit backward does not reach the measurements / weights of "
-                                  "camera-camera Between costs yet (gradients w.r.t. everything else are available).")
+    cc = (packed.cc_tensors.meas, packed.cc_tensors.w_between) if packed.cc_costs else ()
     cams, pts, delta = BAImplicitStep.apply(opt, packed, step, kwargs, t.feat, t.w_obs, t.focal, t.k1, t.k2, t.log_radius_obs,
-                                            t.cam_prior_target, t.w_cam_prior, t.pt_prior_target, t.w_pt_prior)
+                                            t.cam_prior_target, t.w_cam_prior, t.pt_prior_target, t.w_pt_prior, *cc)
     return (cams, pts), delta
 
 

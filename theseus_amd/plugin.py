@@ -516,6 +516,9 @@ class HipSchurLinearization(HipSchurLinearizationCore, _RefLinearization):
         if graph:
             packed.sync(force=True)   # re-pack WITH the autograd history of the auxiliary variables
             t = packed.tensors
+            if packed.cc_costs and (packed.cc_tensors.meas.requires_grad or packed.cc_tensors.w_between.requires_grad):
+                raise NotImplementedError("theseus_amd plugin: gradients w.r.t. the measurements / weights of camera-camera "
+                                          "Between costs of a bundle-adjustment objective are wired for theseus_amd's own loop only.")
             self._g_graph = _FusedAtbBA.apply(self, t.feat, t.w_obs, t.focal, t.k1, t.k2, t.log_radius_obs,
                                               t.cam_prior_target, t.w_cam_prior, t.pt_prior_target, t.w_pt_prior)
         else:
