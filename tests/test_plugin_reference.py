@@ -324,7 +324,7 @@ def test_unmodified_reference_bundle_adjustment_example_runs_on_the_plugin(ref, 
     np.testing.assert_allclose(radius, ref_radius, rtol=1e-9)
 
 
-@pytest.mark.parametrize("name", ["ba_f64_lm", "ba_f64_gn"])
+@pytest.mark.parametrize("name", ["ba_f64_lm", "ba_f64_gn", "ba_f64_camcam_lm"])
 def test_reference_loop_drives_the_bundle_adjustment_plugin(ref, name):
     """The REAL th.LevenbergMarquardt / th.GaussNewton loop with theseus_amd.plugin.HipSchurSolver on a bundle-adjustment
     objective built from the reference's own classes (th.eb.Reprojection, th.RobustCostFunction, th.Difference on SE3 and
@@ -337,7 +337,7 @@ def test_reference_loop_drives_the_bundle_adjustment_plugin(ref, name):
     class RefNames:  # build_ba_objective speaks theseus_amd's names: map them onto the reference's
         Objective, SE3, Point3, Point2, Vector, Difference = th.Objective, th.SE3, th.Point3, th.Point2, th.Vector, th.Difference
         ScaleCostWeight, RobustCostFunction, HuberLoss, WelschLoss = th.ScaleCostWeight, th.RobustCostFunction, th.HuberLoss, th.WelschLoss
-        Reprojection = th.eb.Reprojection
+        Reprojection, Between, DiagonalCostWeight, Variable = th.eb.Reprojection, th.Between, th.DiagonalCostWeight, th.Variable
     g = load_golden(name)
     obj, cam_v, pt_v = build_ba_objective(RefNames, g, DEVICE)
     if DEVICE != "cpu":
