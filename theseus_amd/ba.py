@@ -522,13 +522,15 @@ class HipSchurLinearizationCore:
             self.Hcc, self.Hpp = f64(s.num_cams, 36, B), f64(s.num_points, 6, B)
             self.W, self.gd = f64(max(s.num_obs, 1), 18, B), f64(B, p.n)
             self.g, self.diag = new(B, p.n), new(B, p.n)
-            if p.cc_costs:   # the camera-camera costs' blocks: a dense (6C)^2 frame like the reduced system's (zero-filled once)
-                ldc = round_up(p.nc, 32)
-                self.H_odo, self.g_odo = torch.zeros(B, ldc, ldc, dtype=dt, device=dev), new(B, p.nc)
-                C = s.num_cams
+            if p.cc_costs:   # index tables of the camera-camera costs' blocks (their Jacobians: thx_pg_jacobians, per linearize)
+                st = p.cc_structure
+                self._cc_i = torch.from_numpy(st.edge_i.astype(np.int64)).to(dev)
+                self._cc_j = torch.from_numpy(st.edge_j.astype(np.int64)).to(dev)
+                hi, lo = torch.maximum(self._cc_i, self._cc_j), torch.minimum(self._cc_i, self._cc_j)
                 k = torch.arange(6, device=dev)
-                base = 6 * torch.arange(C, device=dev).view(C, 1, 1)
-                self._odo_rows, self._odo_cols = (base + k.view(1, 6, 1)).expand(C, 6, 6), (base + k.view(1, 1, 6)).expand(C, 6, 6)
+                self._cc_rows = (6 * hi.view(-1, 1, 1) + k.view(1, 6, 1)).expand(-1, 6, 6)     # (E, 6, 6) rows / columns of the
+                self._cc_cols = (6 * lo.view(-1, 1, 1) + k.view(1, 1, 6)).expand(-1, 6, 6)     # off-diagonal block of edge e in S
+                self._cc_v0_is_row = (self._cc_i > self._cc_j).view(-1, 1, 1, 1)
 
     def _assemble(self):
         self._ensure_buffers()
@@ -536,18 +538,33 @@ class HipSchurLinearizationCore:
         p._refuse_fast_approx()
         self.K.ba_assemble(p.dstruct, p.tensors, self.Hcc, self.Hpp, self.W, self.gd, self.g, self.diag)
         if p.cc_costs:
-            # camera-camera Between costs: thx_pg_assemble over the camera buffer.  Their DIAGONAL blocks and gradient join the
-            # camera blocks before the point elimination (damping sees them); the off-diagonal blocks are added to the reduced
-            # system after it (HipSchurSolverCore._solve):  S = (Hcc + Hodo)' - Hcp Hpp'^-1 Hpc.
-            self.K.pg_assemble(p.cc_dstruct, p.cc_tensors, self.H_odo, self.g_odo, poses=p.tensors.cams)
+            # camera-camera Between costs: their weighted Jacobian blocks from thx_pg_jacobians over the camera buffer; the 6 x 6
+            # products are a handful of small batched GEMMs.  Diagonal blocks and gradient join the camera blocks BEFORE the point
+            # elimination (damping sees them); the off-diagonal blocks are added to the reduced system AFTER it
+            # (HipSchurSolverCore._solve):  S = (Hcc + Hodo)' - Hcp Hpp'^-1 Hpc.
+            E, B, dt, dev = len(p.cc_costs), self.g.shape[0], self.g.dtype, self.g.device
+            J0, J1 = (torch.empty(E, B, 6, 6, dtype=dt, device=dev) for _ in range(2))
+            eb = torch.empty(E, B, 6, dtype=dt, device=dev)
+            self.K.pg_jacobians(p.cc_dstruct, p.cc_tensors, J0, J1, eb, torch.empty(1, B, 6, 6, dtype=dt, device=dev),
+                                torch.empty(1, B, 6, dtype=dt, device=dev), poses=p.tensors.cams)
+            self._cc_J = (J0, J1)                                                  # (Av reads them)
+            J0d, J1d, ed = J0.double(), J1.double(), eb.double().unsqueeze(3)
+            D0, D1 = J0d.transpose(2, 3) @ J0d, J1d.transpose(2, 3) @ J1d            # (E, B, 6, 6) diagonal-block contributions
+            g0, g1 = -(J0d.transpose(2, 3) @ ed).squeeze(3), -(J1d.transpose(2, 3) @ ed).squeeze(3)
+            planar = lambda x: x.reshape(E, B, -1).transpose(1, 2)                 # noqa: E731  (E, B, ...) -> (E, comps, B)
+            self.Hcc.index_add_(0, self._cc_i, planar(D0)).index_add_(0, self._cc_j, planar(D1))
             nc = p.nc
-            D = torch.tril(self.H_odo[:, self._odo_rows, self._odo_cols])           # (B, C, 6, 6): lower part is what is defined
-            D = (D + torch.tril(D, -1).transpose(2, 3)).double()
-            self.Hcc.add_(D.reshape(D.shape[0], D.shape[1], 36).permute(1, 2, 0))
-            self.H_odo[:, self._odo_rows, self._odo_cols] = 0                       # what is left: the off-diagonal blocks
-            self.gd[:, :nc].add_(self.g_odo.double())
-            self.g[:, :nc].add_(self.g_odo)
-            self.diag[:, :nc].add_(D.diagonal(dim1=2, dim2=3).reshape(D.shape[0], nc).to(self.diag.dtype))
+            gsum = torch.zeros(B, p.structure.num_cams, 6, dtype=torch.float64, device=dev)
+            gsum.index_add_(1, self._cc_i, g0.transpose(0, 1)).index_add_(1, self._cc_j, g1.transpose(0, 1))
+            dsum = torch.zeros_like(gsum)
+            dsum.index_add_(1, self._cc_i, D0.diagonal(dim1=2, dim2=3).transpose(0, 1))
+            dsum.index_add_(1, self._cc_j, D1.diagonal(dim1=2, dim2=3).transpose(0, 1))
+            self.gd[:, :nc].add_(gsum.reshape(B, nc))
+            self.g[:, :nc].add_(gsum.reshape(B, nc).to(dt))
+            self.diag[:, :nc].add_(dsum.reshape(B, nc).to(dt))
+            # block (max(i, j), min(i, j)) of S: J_row^T J_col
+            off = torch.where(self._cc_v0_is_row, J0d.transpose(2, 3) @ J1d, J1d.transpose(2, 3) @ J0d)
+            self._cc_off = off.transpose(0, 1).to(dt).contiguous()                 # (B, E, 6, 6)
 
     def _linearize_jacobian_impl(self):
         raise NotImplementedError("the dense Jacobian of a bundle-adjustment objective is not materialised")
@@ -575,16 +592,12 @@ class HipSchurLinearizationCore:
         out_t = torch.empty(p.m, v.shape[0], dtype=v.dtype, device=v.device)
         self.K.ba_av(p.dstruct, p.tensors, v, p._cost_rows_dev[key][:3], out_t)
         out = out_t.t().contiguous()
-        if p.cc_costs:   # rows of the camera-camera costs: J0 v_i + J1 v_j from thx_pg_jacobians over the camera buffer
-            E, B = len(p.cc_costs), v.shape[0]
-            J0, J1 = (torch.empty(E, B, 6, 6, dtype=v.dtype, device=v.device) for _ in range(2))
-            eb = torch.empty(E, B, 6, dtype=v.dtype, device=v.device)
-            Jp, ep = torch.empty(1, B, 6, 6, dtype=v.dtype, device=v.device), torch.empty(1, B, 6, dtype=v.dtype, device=v.device)
-            self.K.pg_jacobians(p.cc_dstruct, p.cc_tensors, J0, J1, eb, Jp, ep, poses=p.tensors.cams)
-            st = p.cc_structure
+        if p.cc_costs:   # rows of the camera-camera costs: J0 v_i + J1 v_j (the blocks of this linearization)
+            B = v.shape[0]
+            J0, J1 = self._cc_J
             vc = v[:, :p.nc].reshape(B, -1, 6)
-            vi = vc[:, torch.from_numpy(st.edge_i).long().to(v.device)].transpose(0, 1).unsqueeze(3)   # (E, B, 6, 1)
-            vj = vc[:, torch.from_numpy(st.edge_j).long().to(v.device)].transpose(0, 1).unsqueeze(3)
+            vi = vc[:, self._cc_i].transpose(0, 1).unsqueeze(3)   # (E, B, 6, 1)
+            vj = vc[:, self._cc_j].transpose(0, 1).unsqueeze(3)
             rows = (p._cost_rows_dev[key][3].long().view(-1, 1) + torch.arange(6, device=v.device)).view(-1)
             out[:, rows] = (J0 @ vi + J1 @ vj).squeeze(3).transpose(0, 1).reshape(B, -1)
         return out
@@ -705,13 +718,14 @@ class HipSchurSolverCore:
                         self.Hinv, self.tvec, self.info_pts)
         if p.cc_costs:
             # thx_ba_schur writes (does not accumulate) the blocks two cameras share through a point; the off-diagonal blocks of
-            # the camera-camera costs are added on top.  Blocks only they touch keep the previous call's sum otherwise: zero them
-            # first.  (A full-frame pass: the price of composing existing kernels -- DESIGN.md 4.3.)
+            # the camera-camera costs are scatter-added on top.  Blocks only they touch would keep the previous call's sum: zeroed
+            # first.
             if self._odo_only is None:
-                self._odo_only = self._blocks_only_odometry(p)
-            if self._odo_only is not None:
+                self._odo_only = self._blocks_only_odometry(p) or ()
+            if self._odo_only:
                 self.S[:, self._odo_only[0], self._odo_only[1]] = 0
-            self.S.add_(lin.H_odo)
+            bidx = torch.arange(self.S.shape[0], device=self.S.device).view(-1, 1, 1, 1)
+            self.S.index_put_((bidx, lin._cc_rows.unsqueeze(0), lin._cc_cols.unsqueeze(0)), lin._cc_off, accumulate=True)
         if self.sparse:
             self.K.chol_factor_sparse(self.S, p.nc, None, False, damping_eps, self.L, self.panels, self.info_chol, self.pattern,
                                       rhs=self.rhs, y=self._y)
