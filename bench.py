@@ -14,6 +14,8 @@ The headline (`metric` / `value` / `roofline` / `cpu_baseline` / `parity` at the
   N = 1 : "fp64_b4096"       configs[2]'s dtype and per-GPU share (32768 / 8 problems) on one GPU,
           "ba_512_8192_32768_b256"   configs[3] (bundle adjustment, Schur complement + tile-sparse Cholesky),
           "implicit_b1024"   configs[4] (forward LM + implicit backward through TheseusLayer),
+          "simple_example_b16"   configs[0] (the plumbing case: AutoDiffCostFunction on a Vector, Gauss-Newton + implicit
+                             backward on the generic path; reports correctness against the closed form, ~1 s),
   N > 1 : "strong_f64_32768" configs[2] itself: 32768 fp64 problems sharded over the N GPUs (strong scaling), each rank's
           share solved in sub-batches of 4096, one all_gather of the solved poses,
 each with its own value / ms_per_step / roofline / parity / cpu_baseline (`--legs none` skips them).
@@ -593,6 +595,57 @@ def pg_run(cfg, ctx):
     return result
 
 
+def simple_run(cfg, ctx):
+    """BASELINE.json configs[0] -- examples/simple_example.py: fit y = v exp(x), ONE AutoDiffCostFunction on a 1-d Vector, batch 16,
+    Gauss-Newton + dense Cholesky, implicit backward w.r.t. the abscissae -- on theseus_amd's own API (theseus_amd/euclidean.py:
+    thx_block_assemble + the tiled Cholesky).  The plumbing case: what it reports is correctness.  The problem is linear in v, so
+    the exact solution is v* = sum(y e^x) / sum(e^2x) and the gradient of a loss of v* follows by plain autograd of that
+    closed form -- the parity check needs no oracle."""
+    import theseus_amd as th
+    dev, dt = ctx.device, torch.float64
+    B, N = cfg.batch, cfg.points
+    gen = torch.Generator().manual_seed(0)
+    xs = torch.linspace(-1, 1, N, dtype=dt).view(1, -1).repeat(B, 1)
+    amp = 0.5 + 0.2 * torch.rand(B, 1, dtype=dt, generator=gen)
+    ys = (amp * xs.exp()).to(dev)
+    x0 = (xs + 0.05 * torch.randn(B, N, dtype=dt, generator=gen)).to(dev)
+    x, y, v = th.Variable(x0.clone(), name="x"), th.Variable(ys, name="y"), th.Vector(tensor=torch.ones(B, 1, dtype=dt, device=dev), name="v")
+
+    def residual(optim_vars, aux_vars):
+        return aux_vars[1].tensor - optim_vars[0].tensor * aux_vars[0].tensor.exp()
+    obj = th.Objective(dtype=dt)
+    obj.add(th.AutoDiffCostFunction([v], residual, N, aux_vars=[x, y], cost_weight=th.ScaleCostWeight(torch.ones(1, 1, dtype=dt, device=dev))))
+    opt = th.GaussNewton(obj, max_iterations=10, linearization_kwargs=dict(kernels=ctx.kernels) if ctx.kernels is not None else None)
+    layer = th.TheseusLayer(opt)
+
+    def once():
+        phi = x0.clone().requires_grad_(True)
+        sol, info = layer.forward({"x": phi, "v": torch.ones(B, 1, dtype=dt, device=dev)}, optimizer_kwargs={"backward_mode": "implicit"})
+        loss = ((sol["v"] - 0.5) ** 2).mean()
+        loss.backward()
+        return sol["v"].detach(), phi.grad, info
+    once()                                                   # warm-up (kernel modules, buffers)
+    if ctx.on_gpu:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(cfg.steps):
+        vsol, grad, info = once()
+    if ctx.on_gpu:
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / cfg.steps
+    ph = x0.clone().requires_grad_(True)
+    vstar = (ys * ph.exp()).sum(1, keepdim=True) / (2 * ph).exp().sum(1, keepdim=True)
+    ((vstar - 0.5) ** 2).mean().backward()
+    iters = int(info.iters_done)
+    return {"metric": "forward (Gauss-Newton) + implicit backward calls/s", "value": 1e3 / ms, "unit": "calls/s", "ms_per_step": ms,
+            "dtype": "f64", "data": "synthetic" if ctx.on_gpu else "TEST-STANDIN", "iters_done": iters,
+            "config": {"workload": f"examples/simple_example.py shape: {N}-point fit of y = v exp(x), AutoDiffCostFunction on Vector(1), "
+                                   f"batch {B}, GaussNewton(max_iterations=10) + implicit backward"},
+            "parity": {"against": "closed form v* = sum(y e^x) / sum(e^2x) and its autograd gradient (fp64)",
+                       "max_abs_v_err": float((vsol - vstar.detach()).abs().max()),
+                       "grad_x_rel_err": float((grad - ph.grad).abs().max() / ph.grad.abs().max())}}
+
+
 def ba_run(cfg, ctx):
     """BASELINE.json configs[3]: bundle adjustment, 512 SE3 cameras / 8192 Point3 / 32768 robust Reprojection costs, batch 256,
     adaptive ellipsoidal LM; the reduced camera system (Schur complement, 3072 x 3072) goes through the tile-sparse MFMA
@@ -791,7 +844,7 @@ def main():
     unmodified = (args.dtype == "f32" and args.solver == "dense" and not args.implicit and args.total_batch == 0
                   and not args.adaptive and args.poses == 256 and args.edges == 1024 and args.batch == 4096)
     if args.legs == "auto":
-        legs = (["fp64", "ba", "implicit"] if world == 1 else ["strong"]) if (unmodified and on_gpu) else []
+        legs = (["fp64", "ba", "implicit", "simple"] if world == 1 else ["strong"]) if (unmodified and on_gpu) else []
     elif args.legs == "none":
         legs = []
     else:
@@ -828,6 +881,8 @@ def main():
         leg("implicit_b1024", lambda: pg_run(variant(implicit=True, batch=min(1024, args.batch), sparse_leg=False,
                                                      cpu_sample=min(args.cpu_sample, 2), parity_sample=min(args.parity_sample, 1)),
                                              ctx))
+    if "simple" in legs and world == 1:
+        leg("simple_example_b16", lambda: simple_run(SimpleNamespace(batch=16, points=20, steps=5), ctx))
     if "strong" in legs:
         # BASELINE.json configs[2]: 32768 fp64 problems over the N GPUs of the node, each rank's share in sub-batches of 4096
         leg("strong_f64_32768" if args.strong_total == 32768 else f"strong_{args.dtype if standin else 'f64'}_{args.strong_total}",

@@ -74,3 +74,11 @@ def test_single_rank_legs_ride_in_the_same_line():
     r = _bench("--batch", "2", "--legs", "fp64")
     assert r["n_gpus"] == 1 and r["configs"]["fp64_b4096"]["dtype"] == "f64" and r["configs"]["fp64_b4096"]["iters_done"] == 2
     assert "configs" not in _bench("--batch", "2")          # a modified headline run carries no legs by default
+
+
+def test_config0_leg_rides_in_the_line():
+    """BASELINE.json configs[0] (examples/simple_example.py shape) as a leg: generic path, implicit backward, parity against the closed
+    form of the linear least-squares problem -- no oracle involved."""
+    r = _bench("--batch", "2", "--legs", "simple")
+    leg = r["configs"]["simple_example_b16"]
+    assert leg["parity"]["max_abs_v_err"] < 1e-12 and leg["parity"]["grad_x_rel_err"] < 1e-9 and leg["iters_done"] >= 1
