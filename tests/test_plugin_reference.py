@@ -585,3 +585,41 @@ def test_check_singular_matches_the_reference(ref):
     good = [0, 2]
     np.testing.assert_allclose(out["ours"][good].detach().cpu().numpy(), out["ref"][good].detach().cpu().numpy(), rtol=0,
                                atol=2e-3 * np.abs(out["ref"][good].detach().cpu().numpy()).max())
+
+
+@cpu_only
+@pytest.mark.parametrize("tag", ["gn_unroll", "gn_trunc", "lm_unroll", "lm_trunc", "gn_trunc_conv"])
+def test_reference_loop_differentiates_through_the_plugin_on_generic_objectives(ref, tag):
+    """backward_mode "unroll" (TheseusLayer's default) / "truncated" with the REAL loop and the plugin's Linearization /
+    LinearSolver on a generic objective: the Hessian is part of the graph (its dense form by torch from the reference's
+    differentiable blocks), the damped solve runs on the kernels as one autograd node.  Gradients equal the ones the reference
+    produced with its own dense path (tests/golden/simple_example.npz: u_* entries)."""
+    th, thp = ref
+    from tests.simple_example_common import UNROLLED
+    g = load_golden("simple_example")
+    _, cls, mode, okw, tol = next(u for u in UNROLLED if u[0] == tag)
+    dt = torch.float64
+    xl = torch.from_numpy(g["v_x"]).clone().requires_grad_(True)
+    yl = torch.from_numpy(g["v_y"]).clone().requires_grad_(True)
+    wl = torch.linspace(0.5, 1.5, 12, dtype=dt).view(1, -1).clone().requires_grad_(True)
+    a, b = th.Vector(1, name="a", dtype=dt), th.Vector(1, name="b", dtype=dt)
+
+    def f(optim_vars, aux_vars):
+        return aux_vars[1].tensor - optim_vars[0].tensor * torch.exp(optim_vars[1].tensor * aux_vars[0].tensor)
+    obj = th.Objective(dtype=dt)
+    obj.add(th.AutoDiffCostFunction([a, b], f, 12, aux_vars=[th.Variable(xl, name="x"), th.Variable(yl, name="y")],
+                                    cost_weight=th.DiagonalCostWeight(th.Variable(wl, name="w"))))
+    opt = getattr(th, cls)(obj, max_iterations=6, abs_err_tolerance=tol, rel_err_tolerance=tol,
+                           linear_solver_cls=thp.HipCholeskySolver, linearization_kwargs=_kernels())
+    sol, info = th.TheseusLayer(opt).forward(input_tensors={"a": torch.ones(6, 1, dtype=dt), "b": 2.5 * torch.ones(6, 1, dtype=dt)},
+                                             optimizer_kwargs=dict(track_err_history=True, backward_mode=mode, **okw))
+    assert not opt.linear_solver.linearization.fused
+    loss = ((sol["a"] - 0.5) ** 2).mean() + ((sol["b"] - 1.0) ** 2).mean()
+    loss.backward()
+    r = lambda k: g[f"u_{tag}_{k}"]  # noqa: E731
+    np.testing.assert_allclose(sol["a"].detach().numpy(), r("a"), rtol=1e-10)
+    assert abs(loss.item() - float(r("loss"))) < 1e-12
+    for leaf, key in ((xl, "gx"), (yl, "gy"), (wl, "gw")):
+        want = r(key)
+        np.testing.assert_allclose(leaf.grad.numpy(), want, rtol=0, atol=1e-9 * np.abs(want).max(), err_msg=key)
+    np.testing.assert_allclose(info.err_history.numpy(), r("err"), rtol=1e-6)

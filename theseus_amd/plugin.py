@@ -89,6 +89,35 @@ class _CachedFactorSolve(torch.autograd.Function):
         return None, None, None, None, s.solve_with_factor(grad_delta.contiguous())
 
 
+class _UnrolledFactorSolve(torch.autograd.Function):
+    """delta = (H + D)^-1 g as a differentiable function of H AND g (backward_mode "unroll" / "truncated" on the generic path:
+    the reference keeps the Hessian in the graph there, nonlinear_least_squares.py:100-135).  Forward: the kernels on the detached
+    values.  Backward, with w = (H + D)^-1 grad_delta from a COPY of this call's factor (the loop factorises again before the
+    backward runs):  grad_g = w,  grad_H = -w delta^T - diag(lambda w * delta) [ellipsoidal: D = lambda diag(H) + eps]."""
+
+    @staticmethod
+    def forward(ctx, solver, damping, ellipsoidal, eps, H, g):
+        y = solver.factorize(damping, ellipsoidal, eps, rhs=g.detach().contiguous())
+        delta = torch.empty_like(y)
+        solver._substitute(y, delta, backward_only=True)
+        solver.check_info()
+        ctx.solver, ctx.n = solver, solver.linearization.n
+        ctx.L, ctx.panels = solver.L.clone(), solver.panels.clone()
+        ctx.lam = solver._lam.clone() if (damping is not None and ellipsoidal) else None
+        ctx.save_for_backward(delta)
+        return delta
+
+    @staticmethod
+    def backward(ctx, grad_delta):
+        (delta,) = ctx.saved_tensors
+        w = torch.empty_like(delta)
+        ctx.solver.K.chol_solve(ctx.L, ctx.n, ctx.panels, grad_delta.contiguous(), w)
+        grad_H = -(w.unsqueeze(2) * delta.unsqueeze(1))
+        if ctx.lam is not None:
+            grad_H = grad_H - torch.diag_embed(ctx.lam.view(-1, 1) * w * delta)
+        return None, None, None, None, grad_H, w
+
+
 class _HipRetract(torch.autograd.Function):
     """X_new = X exp(delta) on the packed pose buffer (thx_se3_retract / thx_se2_retract), differentiable w.r.t. delta:
     the backward is thx_se3_retract_vjp / thx_se2_retract_vjp.  (X itself is the detached iterate of the no-grad loop.)"""
@@ -263,6 +292,7 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
         cost_vars = [[self.ordering.index_of(cf.optim_var_at(i).name) for i in range(cf.num_optim_vars())] for cf in costs]
         self.asm = BlockAssembler(list(zip(self.var_start_cols, self.var_dims)), cost_vars, [cf.dim() for cf in costs])
         self._n, self._ld = self.num_cols, round_up(self.num_cols, 32)
+        self._H_graph, self._detach_hessian_now = None, True
         self.H = self.g = None
         self._AtA_cache = self._A = self._b = None
 
@@ -294,7 +324,18 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
         ed = [e.detach() for e in es]
         self.asm.assemble(self.K, Jd, ed, self.H, self.g, gradient=not need_graph)
         self._blocks = (Jd, ed)  # the launch reads these tensors: keep them alive
-        self._g_graph = None
+        self._g_graph = self._H_graph = None
+        if need_graph and not self._detach_hessian_now:
+            # backward_mode "unroll" / "truncated": the Hessian is part of the graph -- its (small) dense form by torch from the
+            # same differentiable blocks; the solve's backward returns grad_H (_UnrolledFactorSolve)
+            Hg = torch.zeros(B, self.n, self.n, dtype=dt, device=dev)
+            for c, J in enumerate(Js):
+                for sa, va in enumerate(self.asm.cost_vars[c]):
+                    ca, da = self.asm.var_cols[va]
+                    for sb, vb in enumerate(self.asm.cost_vars[c]):
+                        cb, db = self.asm.var_cols[vb]
+                        Hg[:, ca:ca + da, cb:cb + db] = Hg[:, ca:ca + da, cb:cb + db] + J[sa].transpose(1, 2) @ J[sb]
+            self._H_graph = Hg
         if need_graph:  # Atb = A^T b from the reference's differentiable Jacobians, block by block (no dense A)
             parts: List[Optional[torch.Tensor]] = [None] * len(self.var_dims)
             for c, (J, e) in enumerate(zip(Js, es)):
@@ -336,8 +377,9 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
 
     def _linearize_hessian_impl(self, _detach_hessian: bool = False):
         if not self.fused:
+            self._detach_hessian_now = bool(_detach_hessian)
             self._assemble_generic()
-            graph = self._g_graph is not None
+            return   # (generic path: with the Hessian in the graph when the reference asks for it)
         else:
             packed = self.packed
             graph = torch.is_grad_enabled() and any(v.tensor.requires_grad for v in packed._tracked())
@@ -405,6 +447,9 @@ class HipCholeskySolver(HipCholeskyCore, _RefCholeskyDenseSolver):
         if g is not None and torch.is_grad_enabled():
             if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
                 raise ValueError("Damping must be a float or a 1-D tensor.")
+            Hg = getattr(self.linearization, "_H_graph", None)
+            if Hg is not None:
+                return _UnrolledFactorSolve.apply(self, damping, ellipsoidal_damping, damping_eps, Hg, g)
             return _CachedFactorSolve.apply(self, damping, ellipsoidal_damping, damping_eps, g)
         return self._solve(damping, ellipsoidal_damping, damping_eps, check_info=True)
 
