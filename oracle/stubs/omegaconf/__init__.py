@@ -1,5 +1,18 @@
 # Test-infrastructure stub (NOT product code): attribute-dict stand-in for omegaconf.
+import re
+
 import yaml
+
+
+class _Loader(yaml.SafeLoader):
+    """YAML 1.2 floats: OmegaConf reads ``1e-3`` as a float, PyYAML's YAML 1.1 resolver as a string."""
+
+
+_Loader.add_implicit_resolver(
+    "tag:yaml.org,2002:float",
+    re.compile(r"^[-+]?(?:[0-9][0-9_]*\.[0-9_]*(?:[eE][-+]?[0-9]+)?|\.[0-9_]+(?:[eE][-+]?[0-9]+)?|[0-9][0-9_]*[eE][-+]?[0-9]+"
+               r"|\.(?:inf|Inf|INF)|\.(?:nan|NaN|NAN))$"),
+    list("-+0123456789."))
 
 
 class DictConfig(dict):
@@ -34,7 +47,7 @@ class OmegaConf:
     @staticmethod
     def load(path):
         with open(path) as f:
-            return _wrap(yaml.safe_load(f))
+            return _wrap(yaml.load(f, Loader=_Loader))
 
     @staticmethod
     def create(d):

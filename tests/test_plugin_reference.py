@@ -292,6 +292,9 @@ def test_unmodified_reference_bundle_adjustment_example_runs_on_the_plugin(ref, 
     cfg.outer_optim.num_epochs = 2
     cfg.inner_optim.verbose = False
     cfg.inner_optim.max_iters = 3
+    # 60 of the config's 200 points: the REFERENCE's dense run keeps one copy of A per slice-assignment alive for its backward
+    # (dense_linearization.py:44-55 under autograd) -- 58 GB of host memory at the config's ~1600 observations, 3 GB at ~480
+    cfg.num_points = 60
     cfg.inner_optim.reg_w = float(cfg.inner_optim.reg_w)
     standin = OracleKernels()
     calls = {"ba_assemble": 0, "ba_vjp": 0}

@@ -272,9 +272,12 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
 
     def __init__(self, objective: th.Objective, ordering=None, kernels=None, objective_hooks: bool = True,
                  block_hessian: Optional[bool] = None, **kwargs):
+        self._ext_AtA = self._ext_Atb = None
         _RefLinearization.__init__(self, objective, ordering)
         self._g_graph: Optional[torch.Tensor] = None
         try:
+            if not objective.cost_functions:
+                raise UnsupportedObjective("an objective without cost functions")
             self._core_init(objective, kernels, block_hessian)
             self.fused = True
         except UnsupportedObjective:
@@ -284,17 +287,48 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
 
     # ---- generic path ------------------------------------------------------------------------------------
     def _generic_init(self, objective, kernels):
-        if [v.name for v in self.ordering] != list(objective.optim_vars.keys()):
-            raise NotImplementedError("HipLinearization uses the default (insertion) variable ordering.")
         self.K = kernels or default_kernels()
         self.packed = None
-        costs = list(objective.cost_functions.values())
-        cost_vars = [[self.ordering.index_of(cf.optim_var_at(i).name) for i in range(cf.num_optim_vars())] for cf in costs]
-        self.asm = BlockAssembler(list(zip(self.var_start_cols, self.var_dims)), cost_vars, [cf.dim() for cf in costs])
+        self.asm, self._asm_sig = None, None   # compiled at the first linearize(): the column spans come from the Jacobians
         self._n, self._ld = self.num_cols, round_up(self.num_cols, 32)
         self._H_graph, self._detach_hessian_now = None, True
         self.H = self.g = None
         self._AtA_cache = self._A = self._b = None
+        # column -> (position in self.ordering, offset inside that variable): any caller-supplied ordering (linearization.py:18-41)
+        self._col_var = [(k, j) for k, d in enumerate(self.var_dims) for j in range(d)]
+
+    def _column_blocks(self, cf, jacobians):
+        """The reference writes Jacobian i of a cost function into the columns that START at the cost's i-th optimisation variable
+        and span ``J.shape[2]`` of them (dense_linearization.py:44-52) -- a Jacobian may be wider than its variable (one (B, d, m)
+        block for m one-dimensional variables that are adjacent in the ordering: tests/theseus_tests/optimizer/nonlinear/
+        common.py:76-79), the list may be shorter than the variable list, and a later block overwrites an earlier one.  Returns
+        [(variable position in the ordering, [(jacobian index, first column of it) | None per column of the variable])] for the
+        variables the cost touches, ascending."""
+        owner = {}
+        for i, J in enumerate(jacobians):
+            c0 = self.var_start_cols[self.ordering.index_of(cf.optim_var_at(i).name)]
+            if J.ndim != 3 or c0 + J.shape[2] > self.num_cols:
+                raise ValueError(f"cost function {cf.name}: Jacobian {i} of shape {tuple(J.shape)} does not fit into the columns "
+                                 f"[{c0}, {self.num_cols}) it starts at")
+            for j in range(J.shape[2]):
+                owner[c0 + j] = (i, j)
+        touched = {}
+        for col, src in owner.items():
+            k, off = self._col_var[col]
+            touched.setdefault(k, [None] * self.var_dims[k])[off] = src
+        return sorted(touched.items())
+
+    @staticmethod
+    def _gather_block(jacobians, cols):
+        """One (B, dim, dof) block of a variable from its column sources (a plain view in the ordinary one-Jacobian-per-variable case)."""
+        i0, j0 = cols[0] if cols[0] is not None else (None, None)
+        if i0 is not None and all(c == (i0, j0 + t) for t, c in enumerate(cols)):
+            J = jacobians[i0]
+            return J if (j0 == 0 and J.shape[2] == len(cols)) else J[:, :, j0:j0 + len(cols)]
+        ref = jacobians[next(c[0] for c in cols if c is not None)]
+        B = max(J.shape[0] for J in jacobians)
+        zero = ref.new_zeros(B, ref.shape[1], 1)
+        return torch.cat([zero if c is None else jacobians[c[0]][:, :, c[1]:c[1] + 1].expand(B, -1, -1) for c in cols], dim=2)
 
     @property
     def n(self):
@@ -305,11 +339,21 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
         return self.packed.ld if self.fused else self._ld
 
     def _weighted_blocks(self):
-        Js, es = [], []
+        """Per cost function: the weighted Jacobian block of every variable it touches + the weighted error; (re)compiles the block
+        structure when the Jacobians' column spans are seen for the first time (or change)."""
+        raw, sig = [], []
         for cf in self.objective._get_jacobians_iter():  # vectorised when the objective is (objective.py:836-843)
             jac, err = cf.weighted_jacobians_error()
-            Js.append([j.contiguous() for j in jac])
-            es.append(err.contiguous())
+            blocks = self._column_blocks(cf, jac)
+            raw.append((jac, err, blocks, cf.dim()))
+            sig.append(tuple((k, tuple(cols)) for k, cols in blocks))
+        sig = tuple(sig)
+        if sig != self._asm_sig:
+            self.asm = BlockAssembler(list(zip(self.var_start_cols, self.var_dims)), [[k for k, _ in b] for _, _, b, _ in raw],
+                                      [d for _, _, _, d in raw])
+            self._asm_sig = sig
+        Js = [[self._gather_block(jac, cols).contiguous() for _, cols in blocks] for jac, _, blocks, _ in raw]
+        es = [err.contiguous() for _, err, _, _ in raw]
         return Js, es
 
     def _assemble_generic(self):
@@ -362,6 +406,30 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
             r += d
         self._A, self._b = A, b
 
+    # ``_AtA`` / ``_Atb`` are plain attributes of the reference's DenseLinearization (dense_linearization.py:24-27,60-62) that its
+    # tests assign to and then modify IN PLACE through the ``AtA`` property (test_dense_solver.py:24-104): an assigned tensor is
+    # kept as it is and served by ``AtA`` / ``Atb`` / ``solve()`` until the next ``linearize()``.
+    @property
+    def _AtA(self):
+        if self._ext_AtA is not None:
+            return self._ext_AtA
+        return self._full_AtA() if (self.fused and self.linearized or not self.fused and self.H is not None) else None
+
+    @_AtA.setter
+    def _AtA(self, value):
+        self._ext_AtA = value
+
+    @property
+    def _Atb(self):
+        if self._ext_Atb is not None:
+            return self._ext_Atb
+        g = self._g_graph if self._g_graph is not None else self.g
+        return None if g is None else g.unsqueeze(2)
+
+    @_Atb.setter
+    def _Atb(self, value):
+        self._ext_Atb = value
+
     # ---- the ABC ---------------------------------------------------------------------------------------------
     def _linearize_jacobian_impl(self):
         if self.fused:
@@ -376,6 +444,7 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
             self._materialize_generic_A_b()
 
     def _linearize_hessian_impl(self, _detach_hessian: bool = False):
+        self._ext_AtA = self._ext_Atb = None
         if not self.fused:
             self._detach_hessian_now = bool(_detach_hessian)
             self._assemble_generic()
@@ -414,11 +483,48 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
         return self._full_AtA()
 
     def _ata_impl(self) -> torch.Tensor:
-        return self._full_AtA()
+        return self._ext_AtA if self._ext_AtA is not None else self._full_AtA()
 
     def _atb_impl(self) -> torch.Tensor:
+        if self._ext_Atb is not None:
+            return self._ext_Atb
         g = self._g_graph if self._g_graph is not None else self.g
         return g.unsqueeze(2)
+
+
+class _TensorSystem:
+    """``AtA`` / ``Atb`` handed over as plain tensors instead of the packed Hessian of a HipLinearization: a foreign
+    ``Linearization`` put on the solver after construction (tests/theseus_tests/optimizer/nonlinear/common.py:213-269), or
+    ``linearization._AtA`` / ``._Atb`` assigned directly (tests/theseus_tests/optimizer/linear/test_dense_solver.py:24-104).
+    The tensors are copied into the (B, ld, ld) frame the Cholesky kernels read; the originals are never written."""
+    _compact = False
+    linearized = True
+
+    def __init__(self, K):
+        self.K, self.H, self.g, self.n, self.ld = K, None, None, 0, 0
+
+    def load(self, AtA: torch.Tensor, Atb: torch.Tensor):
+        if AtA.ndim != 3 or AtA.shape[1] != AtA.shape[2]:
+            raise ValueError("Matrix must have a 3 dimensions, the first one being a batch dimension, and be square.")
+        B, n = AtA.shape[0], AtA.shape[1]
+        ld = round_up(max(n, 1), 32)
+        if self.H is None or tuple(self.H.shape) != (B, ld, ld) or self.H.dtype != AtA.dtype or self.H.device != AtA.device:
+            self.H = torch.zeros(B, ld, ld, dtype=AtA.dtype, device=AtA.device)
+        self.H[:, :n, :n].copy_(AtA.detach())
+        self.g = Atb.detach().reshape(B, n).contiguous()
+        self.n, self.ld = n, ld
+
+    def diagonal(self) -> torch.Tensor:
+        d = torch.empty(self.g.shape[0], self.n, dtype=self.g.dtype, device=self.g.device)
+        self.K.diag(self.H, self.n, d)
+        return d
+
+
+class _TensorSystemSolver(HipCholeskyCore):
+    def __init__(self, K, check_singular: bool):
+        self.linearization = _TensorSystem(K)
+        self._check_singular = check_singular
+        self._core_init()
 
 
 class HipCholeskySolver(HipCholeskyCore, _RefCholeskyDenseSolver):
@@ -443,15 +549,30 @@ class HipCholeskySolver(HipCholeskyCore, _RefCholeskyDenseSolver):
               damping_eps: float = 1e-8, **kwargs) -> torch.Tensor:
         # failure = RuntimeError, which the reference loop turns into FAIL status under no_grad
         # (nonlinear_least_squares.py:138-152)
-        g = self.linearization._g_graph
+        lin = self.linearization
+        if not isinstance(lin, HipLinearization) or lin._ext_AtA is not None or lin._ext_Atb is not None:
+            return self._solve_tensor_system(lin.AtA, lin.Atb, damping, ellipsoidal_damping, damping_eps)
+        g = lin._g_graph
         if g is not None and torch.is_grad_enabled():
             if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
                 raise ValueError("Damping must be a float or a 1-D tensor.")
-            Hg = getattr(self.linearization, "_H_graph", None)
+            Hg = getattr(lin, "_H_graph", None)
             if Hg is not None:
                 return _UnrolledFactorSolve.apply(self, damping, ellipsoidal_damping, damping_eps, Hg, g)
             return _CachedFactorSolve.apply(self, damping, ellipsoidal_damping, damping_eps, g)
         return self._solve(damping, ellipsoidal_damping, damping_eps, check_info=True)
+
+    def _solve_tensor_system(self, AtA, Atb, damping, ellipsoidal_damping, damping_eps) -> torch.Tensor:
+        """``solve()`` on whatever ``linearization.AtA`` / ``.Atb`` return (dense_solver.py:84-123 reads nothing else): same
+        kernels, the system copied into their frame first (``_TensorSystem``)."""
+        sub = getattr(self, "_tensor_solver", None)
+        if sub is None:
+            sub = self._tensor_solver = _TensorSystemSolver(self.K, self._check_singular)
+        sub.linearization.load(AtA, Atb)
+        if torch.is_grad_enabled() and (AtA.requires_grad or Atb.requires_grad):
+            return _UnrolledFactorSolve.apply(sub, damping, ellipsoidal_damping, damping_eps, AtA,
+                                              Atb.reshape(AtA.shape[0], AtA.shape[1]))
+        return sub._solve(damping, ellipsoidal_damping, damping_eps, check_info=True)
 
     def _solve_sytem(self, Atb: torch.Tensor, AtA: torch.Tensor) -> torch.Tensor:  # abstract in DenseSolver
         raise NotImplementedError("HipCholeskySolver.solve() factorises its linearization's packed Hessian")

@@ -1,0 +1,85 @@
+"""Why does tests/test_gpu_unrolled.py[lm_trunc] differ from the reference fixture by 2.4e-9 on one problem (GPUTEST_r03)?
+Runs the two-variable adaptive-LM fit of tests/simple_example_common.py with the TEST stand-in kernels on the CPU and with the HIP
+kernels on cuda:0, iterate by iterate (track_state_history), and prints per problem and iteration: a, b on both, their difference,
+the error history on both.  An accept / reject flip shows as an iterate that stays on one side and moves on the other."""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import theseus_amd as th  # noqa: E402
+from tests.helpers import load_golden  # noqa: E402
+from tests.oracle_kernels import OracleKernels  # noqa: E402
+from tests.simple_example_common import UNROLLED  # noqa: E402
+
+
+def run(tag, device, kernels):
+    g = load_golden("simple_example")
+    _, cls, mode, okw, tol = next(u for u in UNROLLED if u[0] == tag)
+    dt = torch.float64
+    xl = torch.from_numpy(g["v_x"]).to(device)
+    yl = torch.from_numpy(g["v_y"]).to(device)
+    wl = torch.linspace(0.5, 1.5, xl.shape[1], dtype=dt, device=device).view(1, -1)
+    a, b = th.Vector(1, name="a", dtype=dt), th.Vector(1, name="b", dtype=dt)
+    a.to(device)
+    b.to(device)
+
+    def f(optim_vars, aux_vars):
+        return aux_vars[1].tensor - optim_vars[0].tensor * torch.exp(optim_vars[1].tensor * aux_vars[0].tensor)
+    obj = th.Objective(dtype=dt)
+    obj.add(th.AutoDiffCostFunction([a, b], f, xl.shape[1], aux_vars=[th.Variable(xl, name="x"), th.Variable(yl, name="y")],
+                                    cost_weight=th.DiagonalCostWeight(th.Variable(wl, name="w"))))
+    lkw = dict(linearization_kwargs=dict(kernels=kernels)) if kernels is not None else {}
+    opt = getattr(th, cls)(obj, max_iterations=6, abs_err_tolerance=tol, rel_err_tolerance=tol, **lkw)
+    B = xl.shape[0]
+    okw = dict(okw)
+    okw.pop("backward_num_iterations", None)
+    with torch.no_grad():
+        sol, info = th.TheseusLayer(opt).forward({"a": torch.ones(B, 1, dtype=dt, device=device), "b": 2.5 * torch.ones(B, 1, dtype=dt, device=device)},
+                                                 optimizer_kwargs=dict(track_err_history=True, track_state_history=True, backward_mode="unroll", **okw))
+    return g, info
+
+
+def final(tag, device, kernels):
+    """The test's own path (truncated, with gradients): final a, b at full precision."""
+    from tests.simple_example_common import run_unrolled
+    import tests.simple_example_common as sec
+    got = {}
+    orig = np.testing.assert_allclose
+
+    def spy(actual, desired, *a, **k):
+        got.setdefault("vals", []).append((np.asarray(actual).copy(), np.asarray(desired).copy()))
+    np.testing.assert_allclose = spy
+    try:
+        sec.run_unrolled(th, load_golden("simple_example"), tag, device, kernels)
+    except AssertionError:
+        pass
+    finally:
+        np.testing.assert_allclose = orig
+    return got["vals"][:2]
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "lm_trunc"
+    torch.set_default_dtype(torch.float64)   # (info.state_history is allocated in the default dtype, like the reference's)
+    for dev, k in (("cpu", OracleKernels()), ("cuda", None)):
+        (a, ra), (b, rb) = final(tag, dev, k)
+        print(f"{dev}: truncated-with-grad final, rel diff to the reference fixture: a {np.abs(a - ra).ravel() / np.abs(ra).ravel()} b {np.abs(b - rb).ravel() / np.abs(rb).ravel()}")
+    g, cpu = run(tag, "cpu", OracleKernels())
+    _, gpu = run(tag, "cuda", None)
+    np.set_printoptions(precision=17, linewidth=200)
+    B = cpu.err_history.shape[0]
+    for p in range(B):
+        print(f"problem {p}: reference final a {g[f'u_{tag}_a'][p, 0]!r} b {g[f'u_{tag}_b'][p, 0]!r}")
+        for k in range(cpu.err_history.shape[1]):
+            ca, cb = float(cpu.state_history["a"][p, 0, k]), float(cpu.state_history["b"][p, 0, k])
+            ga, gb = float(gpu.state_history["a"][p, 0, k]), float(gpu.state_history["b"][p, 0, k])
+            print(f"  it {k}: cpu a {ca!r} b {cb!r} err {float(cpu.err_history[p, k])!r} | gpu a {ga!r} b {gb!r} err {float(gpu.err_history[p, k])!r} "
+                  f"| rel da {abs(ca - ga) / max(abs(ca), 1e-300):.2e} db {abs(cb - gb) / max(abs(cb), 1e-300):.2e}"
+                  f"{'  <- stayed (cpu)' if k and ca == float(cpu.state_history['a'][p, 0, k - 1]) else ''}"
+                  f"{'  <- stayed (gpu)' if k and ga == float(gpu.state_history['a'][p, 0, k - 1]) else ''}")
+
+
+if __name__ == "__main__":
+    main()
