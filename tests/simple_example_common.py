@@ -97,12 +97,30 @@ def run_unrolled(th, g, tag, device, kernels=None):
     loss = ((sol["a"] - 0.5) ** 2).mean() + ((sol["b"] - 1.0) ** 2).mean()
     loss.backward()
     r = lambda k: g[f"u_{tag}_{k}"]  # noqa: E731
-    np.testing.assert_allclose(sol["a"].detach().cpu().numpy(), r("a"), rtol=1e-10)
-    np.testing.assert_allclose(sol["b"].detach().cpu().numpy(), r("b"), rtol=1e-10)
-    assert abs(float(loss.detach()) - float(r("loss"))) < 1e-12
+    # A problem sitting at its minimum has an accept / reject decision -- rho = (e_prev - e_new) / predicted,
+    # levenberg_marquardt.py:173-201 -- whose numerator is rounding noise: a coin flip between "stay" and "take one more step of size
+    # <= sqrt(2 * noise / lambda_min(H)) ~ 3e-9".  GPUTEST_r03's lm_trunc failure was exactly this (profiles/r4/a_diag_lm_trunc.txt:
+    # problem 2 takes its 6th step on the GPU, b moves by 2.97e-9, the error by 1 ulp; the reference stays; the stand-in kernels on
+    # ANOTHER host CPU flip problem 3 instead).  Criterion, in fp64 (the fixture's error history is fp32): the objective at OUR final
+    # iterate equals the objective at the REFERENCE's to 64 ulp -- both are the converged minimum -- then the iterates are compared
+    # at 1e-8; everything else at 1e-10.
+    def objective_at(av, bv):
+        with torch.no_grad():
+            res = (yl - av * torch.exp(bv * xl)) * wl
+            return 0.5 * (res ** 2).sum(dim=1)
+    e_ours = objective_at(sol["a"].detach(), sol["b"].detach())
+    e_ref = objective_at(torch.from_numpy(r("a")).to(device), torch.from_numpy(r("b")).to(device))
+    noise = ((e_ours - e_ref).abs() <= 64 * np.finfo(np.float64).eps * e_ref).cpu().numpy()
+    rtol = np.where(noise, 1e-8, 1e-10).reshape(-1, 1)
+    for key in ("a", "b"):
+        got, want = sol[key].detach().cpu().numpy(), r(key)
+        assert (np.abs(got - want) <= rtol * np.abs(want)).all(), (key, np.abs(got - want) / np.abs(want), rtol.ravel())
+    assert abs(float(loss.detach()) - float(r("loss"))) < (1e-12 if not noise.any() else 1e-9)
     for leaf, key in ((xl, "gx"), (yl, "gy"), (wl, "gw")):
         want = r(key)
         np.testing.assert_allclose(leaf.grad.cpu().numpy(), want, rtol=0, atol=1e-9 * np.abs(want).max(), err_msg=key)
     np.testing.assert_allclose(info.err_history.numpy(), r("err"), rtol=1e-6)    # (inf where the reference has inf)
+    if mode == "unroll":   # one loop in the reference: info.last_err is the error after the last iteration
+        np.testing.assert_allclose(info.last_err.detach().cpu().numpy(), r("err")[:, -1], rtol=1e-6)
     assert info.converged_iter.tolist() == r("conv").tolist()
     assert [int(s.value) for s in info.status] == r("status").tolist()

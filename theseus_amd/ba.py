@@ -357,9 +357,9 @@ class PackedBA:
         # (after the implicit last step the state carries an autograd graph: the per-variable views stay attached to it)
         with torch.set_grad_enabled(self.tensors.cams.requires_grad or self.tensors.points.requires_grad):
             for v, t in zip(self.cam_vars, self.tensors.cams.unbind(0)):  # one call builds all the views
-                v.tensor = t
+                v._tensor = t
             for v, t in zip(self.pt_vars, self.tensors.points.unbind(0)):
-                v.tensor = t
+                v._tensor = t
         if not self._counters_unchanged():
             self._stamp = self._current_stamp()
         # deep stamp: only the optimisation variables were re-pointed here -- the auxiliary variables' entries (the bulk: 1 k

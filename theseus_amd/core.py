@@ -28,8 +28,20 @@ class Variable:
     def __init__(self, tensor: torch.Tensor, name: Optional[str] = None):
         self._id = next(Variable._ids)
         self.name = name if name else f"{self.__class__.__name__}__{self._id}"
-        self.tensor = tensor
+        self._tensor = tensor
         self._num_updates = 0
+
+    @property
+    def tensor(self) -> torch.Tensor:
+        return self._tensor
+
+    @tensor.setter
+    def tensor(self, value: torch.Tensor):
+        # a plain attribute in the reference (core/variable.py:21): assigning it is allowed, and may change the batch size or the
+        # device -- counted like update(), so Objective.update()'s "nothing changed" fast path re-resolves them.  The package's own
+        # re-pointing of variables at views of its packed buffers (same shape, same device) writes ``_tensor`` directly.
+        self._tensor = value
+        Variable._global_updates += 1
 
     def update(self, data: Union[torch.Tensor, "Variable"], batch_ignore_mask: Optional[torch.Tensor] = None):
         if isinstance(data, Variable):
@@ -43,9 +55,9 @@ class Variable:
                              f"{self.name} has dtype {self.dtype}.")
         if batch_ignore_mask is not None and batch_ignore_mask.any():
             mask = batch_ignore_mask.view([-1] + [1] * (data.ndim - 1))
-            self.tensor = torch.where(mask, self.tensor, data)  # core/variable.py:65-69
+            self._tensor = torch.where(mask, self._tensor, data)  # core/variable.py:65-69
         else:
-            self.tensor = data
+            self._tensor = data
         self._num_updates += 1
         Variable._global_updates += 1
 
@@ -66,7 +78,7 @@ class Variable:
         return self.tensor.ndim
 
     def to(self, *args, **kwargs):
-        self.tensor = self.tensor.to(*args, **kwargs)
+        self._tensor = self._tensor.to(*args, **kwargs)
         self._num_updates += 1
         Variable._global_updates += 1
 
@@ -523,9 +535,9 @@ class AutoDiffCostFunction(CostFunction):
 
         def one(opt_tensors, aux_tensors):
             for h, t in zip(tmp_opt, opt_tensors):
-                h.tensor = t.unsqueeze(0)
+                h._tensor = t.unsqueeze(0)
             for h, t in zip(tmp_aux, aux_tensors):
-                h.tensor = t.unsqueeze(0)
+                h._tensor = t.unsqueeze(0)
             return self._err_fn(optim_vars=tmp_opt, aux_vars=tmp_aux)[0]
 
         jac = vmap(jacrev(one, argnums=0))(opt_t, aux_t)

@@ -92,7 +92,7 @@ class PackedEuclidean:
         with torch.set_grad_enabled(self._state.requires_grad):
             self._views = [self._state[:, c0:c0 + d] for c0, d in self.cols]
         for v, t in zip(self.vars, self._views):
-            v.tensor = t
+            v._tensor = t
         self._vars_stale = False
         self._state_exposed = True
 
@@ -181,11 +181,11 @@ class PackedEuclidean:
         def __enter__(self):
             self.saved = [v.tensor for v in self.p.vars]
             for v, (c0, d) in zip(self.p.vars, self.p.cols):
-                v.tensor = self.state[:, c0:c0 + d]
+                v._tensor = self.state[:, c0:c0 + d]
 
         def __exit__(self, *a):
             for v, t in zip(self.p.vars, self.saved):
-                v.tensor = t
+                v._tensor = t
 
     def error_vector(self, state=None):
         self.sync()

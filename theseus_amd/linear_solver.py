@@ -53,6 +53,7 @@ class HipCholeskyCore:
             self._y = torch.empty(B, lin.n, dtype=g.dtype, device=g.device)
             self.info = torch.zeros(B, dtype=torch.int32, device=g.device)
             self._lam = torch.empty(B, dtype=g.dtype, device=g.device)
+            self._unfused_forward = False   # (decided per system size: see _solve)
 
     def _linearized(self) -> bool:
         lin = self.linearization
@@ -122,6 +123,14 @@ class HipCholeskyCore:
         too, and is solved here as it is there."""
         return (self.linearization.diagonal() == 0).any(dim=1)
 
+    def post_singular_warning(self):
+        """The reference's warning for ``check_singular=True`` (dense_solver.py:97-102) -- one host look at a device flag: called
+        where the host synchronises anyway."""
+        seen = getattr(self, "_singular_seen", None)
+        self._singular_seen = None
+        if seen is not None and bool(seen):
+            warnings.warn("Singular matrix found in batch, solution will be set to all 0 for all singular matrices.", RuntimeWarning)
+
     def _solve(self, damping, ellipsoidal_damping, damping_eps, check_info) -> torch.Tensor:
         if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
             raise ValueError("Damping must be a float or a 1-D tensor.")
@@ -145,21 +154,21 @@ class HipCholeskyCore:
             self.factorize(damping, ellipsoidal_damping, damping_eps, rhs=None)
             self._substitute(g, delta, backward_only=False)
         if getattr(self, "_check_singular", False):
-            # dense_solver.py:91-103: items whose UNDAMPED AtA hits a zero LU pivot are dropped (zero step, no failure).  Here:
-            # a zero on diag(AtA) (an all-zero column of A), and -- for an undamped solve -- any item whose Cholesky
-            # factorisation broke down (exactly dependent columns: the reference's LU meets the same zero pivot).  With
-            # damping the reference still tests the undamped matrix; a rank-deficient item with a non-zero diagonal is then
-            # STEPPED here (its damped system is positive definite) where the reference zeroes it -- documented divergence.
-            # Device-side select, no host sync (the loop's sync-free path stays sync-free); the reference's warning is
-            # raised where the host looks at the solve anyway (check_info=True).
+            # dense_solver.py:91-103: items whose UNDAMPED AtA hits an exactly zero LU pivot are dropped (zero step, no failure, a
+            # RuntimeWarning).  Here: a zero on diag(AtA) -- an all-zero column of A, the case A^T A produces (singular_mask).  Any
+            # OTHER breakdown of the factorisation keeps its info code: the item is a FAILED solve (RuntimeError / FAIL status), as
+            # it is in the reference, whose LU passes a rank-deficient matrix with a rounding residue on to torch.linalg.cholesky.
+            # (Corner left different: exactly dependent columns with an exactly zero LU pivot but a non-zero diagonal -- the
+            # reference zeroes the step, this solver reports the failed factorisation.)
+            # Device-side select, no host sync; the warning is raised where the host looks at the solve anyway (check_info=True)
+            # or, for the sync-free loop, by post_singular_warning() after the loop's own synchronisation.
             singular = self.singular_mask()
-            if damping is None:
-                singular = singular | self.info.ne(0)
             delta.masked_fill_(singular.unsqueeze(1), 0.0)
             self.info.masked_fill_(singular, 0)   # a dropped item is not a failed solve
-            if check_info and bool(singular.any()):
-                warnings.warn("Singular matrix found in batch, solution will be set to all 0 for all singular matrices.",
-                              RuntimeWarning)
+            seen = singular.any()
+            self._singular_seen = seen if getattr(self, "_singular_seen", None) is None else (self._singular_seen | seen)
+            if check_info:
+                self.post_singular_warning()
         if check_info:
             self.check_info()
         return delta

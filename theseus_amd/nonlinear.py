@@ -567,7 +567,9 @@ class NonlinearLeastSquares(abc.ABC):
                     newly = undecided & g_status_conv
                     conv_iter = torch.where(newly, first_count + g_conv_iter, conv_iter)
                     converged = newly if converged is None else (converged | newly)
-                info.last_err = last_err
+                # TRUNCATED: _merge_infos leaves the FIRST loop's last_err in the merged info (nonlinear_optimizer.py:220-266);
+                # UNROLL is ONE loop in the reference (nonlinear_least_squares.py:252-268), whose _update_info sets it every iteration
+                info.last_err = g_last.detach() if backward_mode == BackwardMode.UNROLL else last_err
                 it += g_it
                 info.iters_done = it
 
@@ -602,6 +604,8 @@ class NonlinearLeastSquares(abc.ABC):
                 info.iters_done = it
             packed.flush_variables()
             # ---- bookkeeping, one device->host copy ----
+            if getattr(self.linear_solver, "_check_singular", False) and hasattr(self.linear_solver, "post_singular_warning"):
+                self.linear_solver.post_singular_warning()    # (check_singular=True: the reference warns from inside solve())
             if converged is not None and not (info.status == NonlinearOptimizerStatus.FAIL).any():
                 cm = converged.cpu().numpy()
                 info.status[cm] = NonlinearOptimizerStatus.CONVERGED
@@ -753,24 +757,6 @@ class TrustRegion(NonlinearLeastSquares, abc.ABC):
 class Dogleg(TrustRegion):
     """theseus/optimizer/nonlinear/dogleg.py:18-116 (Nocedal & Wright, pp. 73-77)."""
     EPS = 1e-7
-
-    def _step_state(self):
-        """Per-problem tensors that ``_complete_step`` carries from one iteration to the next (LM: the damping vector;
-        trust-region methods: the radii).  The sync-free loop snapshots them on the device so that an all-rejected iteration
-        can be replayed from its own start."""
-        return []
-
-    def _set_step_state(self, tensors) -> None:
-        pass
-
-    def _has_step_state_hooks(self) -> bool:
-        """True when this class's ``_complete_step`` is covered by ``_step_state`` / ``_set_step_state`` -- i.e. for the
-        optimizers of this package; a user subclass that overrides ``_complete_step`` must override the hooks too (or this)."""
-        cls = type(self)
-        for base in cls.__mro__:
-            if "_complete_step" in base.__dict__:
-                return "_step_state" in base.__dict__ or base is NonlinearLeastSquares
-        return True
 
     def _join_compute_delta(self):
         one = torch.ones((), dtype=torch.bool, device=self._trust_region.device)

@@ -291,7 +291,7 @@ class PackedPoseGraph:
         with torch.set_grad_enabled(poses.requires_grad):
             views = poses.unbind(0)  # one call builds all the views
             for v, t in zip(self.pose_vars, views):
-                v.tensor = t
+                v._tensor = t
         self.remember_views(poses, views)
         if not self._counters_unchanged():
             self._stamp = self._current_stamp()
