@@ -117,6 +117,34 @@ def test_plugin_through_theseus_layer_and_failure_path(ref):
     assert all(s == th.NonlinearOptimizerStatus.FAIL for s in info.status)
 
 
+def test_lagged_failure_check_reports_fail_one_solve_late_and_changes_nothing_otherwise(ref):
+    """``linear_solver_kwargs=dict(lagged_failure_check=True)``: no host look at the factorisation's info inside solve().  Same
+    trajectory on a healthy problem; a failed factorisation drops its step on the device and is raised by the NEXT solve() --
+    the reference loop still ends in FAIL (nonlinear_least_squares.py:138-152) with the variables where they were."""
+    th, thp = ref
+    g = load_golden("pg_f64_lm")
+    obj, poses = _objective(th, g)
+    opt = th.LevenbergMarquardt(obj, linear_solver_cls=thp.HipCholeskySolver, linearization_kwargs=_kernels(),
+                                linear_solver_kwargs=dict(lagged_failure_check=True), max_iterations=6,
+                                abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    assert opt.linear_solver._lagged
+    with torch.no_grad():
+        sol, info = th.TheseusLayer(opt).forward(optimizer_kwargs=dict(damping=1e-3))
+    final = torch.stack([sol[f"pose_{k}"] for k in range(int(g["P"]))], 1).detach().cpu().numpy()
+    np.testing.assert_allclose(final, g["final"], rtol=0, atol=5e-8)
+    for cf in obj.cost_functions.values():
+        for v in cf.weight.aux_vars:
+            v.update(torch.zeros_like(v.tensor))
+    before = [p.tensor.clone() for p in poses]
+    with torch.no_grad(), pytest.warns(RuntimeWarning):
+        info = th.GaussNewton(obj, linear_solver_cls=thp.HipCholeskySolver, linearization_kwargs=_kernels(),
+                              linear_solver_kwargs=dict(lagged_failure_check=True), max_iterations=3,
+                              abs_err_tolerance=0.0, rel_err_tolerance=0.0).optimize()
+    assert all(s == th.NonlinearOptimizerStatus.FAIL for s in info.status)
+    for p, b in zip(poses, before):
+        assert torch.equal(p.tensor, b)            # the failed steps were dropped, not applied
+
+
 @cpu_only
 @pytest.mark.parametrize("optimizer", ["LevenbergMarquardt", "Dogleg"])
 def test_non_pose_graph_objective_takes_the_generic_path(ref, optimizer):

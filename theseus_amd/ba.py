@@ -259,6 +259,9 @@ class PackedBA:
     def _tracked(self):
         return self._tracked_list
 
+    def tracked_list(self):
+        return self._tracked_list
+
     def _walk_tracked(self):
         yield from self.cam_vars
         yield from self.pt_vars
@@ -305,7 +308,8 @@ class PackedBA:
             return
         # (nobody called Variable.update() / to() since the last look: the update counters -- the shallow stamp -- are what they
         #  were; a pass over 42 k variables of a bundle-adjustment objective is ~10 ms of host time per optimize())
-        stamp = self._stamp if self._counters_unchanged() else self._current_stamp()
+        shallow = self._own_variables or self._stamp is None    # (reference Variables: the deep stamp alone, see PackedPoseGraph.sync)
+        stamp = self._stamp if (self._counters_unchanged() or not shallow) else self._current_stamp()
         dstamp = self._current_stamp(deep=True) if deep else None
         if (not force and self.tensors is not None and stamp == self._stamp and (not deep or dstamp == self._deep_stamp)):
             self._global_stamp = Variable._global_updates
@@ -356,10 +360,11 @@ class PackedBA:
     def _repoint_variables(self):
         # (after the implicit last step the state carries an autograd graph: the per-variable views stay attached to it)
         with torch.set_grad_enabled(self.tensors.cams.requires_grad or self.tensors.points.requires_grad):
+            attr = "_tensor" if self._own_variables else "tensor"   # (own Variable: no update count for a re-pointing, core.py)
             for v, t in zip(self.cam_vars, self.tensors.cams.unbind(0)):  # one call builds all the views
-                v._tensor = t
+                setattr(v, attr, t)
             for v, t in zip(self.pt_vars, self.tensors.points.unbind(0)):
-                v._tensor = t
+                setattr(v, attr, t)
         if not self._counters_unchanged():
             self._stamp = self._current_stamp()
         # deep stamp: only the optimisation variables were re-pointed here -- the auxiliary variables' entries (the bulk: 1 k

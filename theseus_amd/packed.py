@@ -143,7 +143,7 @@ class PackedPoseGraph:
         self.version = objective.current_version
         self.tensors: Optional[PGTensors] = None
         # the O(1) "nothing changed" test relies on theseus_amd.core.Variable's global update counter
-        self._own_variables = all(isinstance(v, Variable) for v in self._tracked())
+        self._own_variables = all(isinstance(v, Variable) for v in self.tracked_list())
         self._stamp = None
         self._deep_stamp = None
         self._global_stamp = -1
@@ -177,15 +177,27 @@ class PackedPoseGraph:
             if r is not None:
                 yield r
 
+    def tracked_list(self):
+        """Every variable the packed buffers are built from, each ONCE (a cost weight shared by 1024 edges is one entry), the
+        optimisation variables (poses) first.  The objective is frozen once an optimizer holds it (Optimizer.optimize checks its
+        version): the walk over the cost functions is done once."""
+        tracked = self.__dict__.get("_tracked_list")
+        if tracked is None:
+            seen, tracked = set(), []
+            for v in self._tracked():
+                if id(v) not in seen:
+                    seen.add(id(v))
+                    tracked.append(v)
+            self._tracked_list = tracked
+        return tracked
+
     def _counters_unchanged(self) -> bool:
         return self._own_variables and self._stamp is not None and Variable._global_updates == self._global_stamp
 
     def _current_stamp(self, deep: bool = False, count: Optional[int] = None):
         # the objective is frozen once an optimizer holds it (Optimizer.optimize checks its version): the walk over the cost
         # functions is done once, later stamps are one pass over the cached list (7 k variables at the headline size)
-        tracked = self.__dict__.get("_tracked_list")
-        if tracked is None:
-            tracked = self._tracked_list = list(self._tracked())   # the optimisation variables (poses) come first
+        tracked = self.tracked_list()
         if count is not None:
             tracked = tracked[:count]
         if deep:
@@ -216,14 +228,17 @@ class PackedPoseGraph:
             return  # nobody called Variable.update()/to() since the last look: O(1) fast path
         # (nobody called Variable.update() / to() since the last look: the update counters -- the shallow stamp -- are what they
         #  were; a pass over 42 k variables of a bundle-adjustment objective is ~10 ms of host time per optimize())
-        stamp = self._stamp if self._counters_unchanged() else self._current_stamp()
+        # (the reference's Variable: the deep stamp -- storage + version of every tensor -- is the only one looked at: a
+        #  Variable.update() that changes neither is not a change.  One pass per call instead of two.)
+        shallow = self._own_variables or self._stamp is None
+        stamp = self._stamp if (self._counters_unchanged() or not shallow) else self._current_stamp()
         dstamp = self._current_stamp(deep=True) if deep else None
         nP = len(self.pose_vars)
         if force or self.tensors is None:
             poses_changed = aux_changed = True
         else:
-            poses_changed = stamp[:nP] != self._stamp[:nP] or (deep and dstamp[:nP] != self._deep_stamp[:nP])
-            aux_changed = stamp[nP:] != self._stamp[nP:] or (deep and dstamp[nP:] != self._deep_stamp[nP:])
+            poses_changed = (shallow and stamp[:nP] != self._stamp[:nP]) or (deep and dstamp[:nP] != self._deep_stamp[:nP])
+            aux_changed = (shallow and stamp[nP:] != self._stamp[nP:]) or (deep and dstamp[nP:] != self._deep_stamp[nP:])
         if not (poses_changed or aux_changed):
             self._global_stamp = Variable._global_updates
             return
@@ -290,8 +305,9 @@ class PackedPoseGraph:
         # and the per-variable views must stay attached to it
         with torch.set_grad_enabled(poses.requires_grad):
             views = poses.unbind(0)  # one call builds all the views
+            attr = "_tensor" if self._own_variables else "tensor"   # (own Variable: no update count for a re-pointing, core.py)
             for v, t in zip(self.pose_vars, views):
-                v._tensor = t
+                setattr(v, attr, t)
         self.remember_views(poses, views)
         if not self._counters_unchanged():
             self._stamp = self._current_stamp()

@@ -220,7 +220,7 @@ class HipObjectiveHooks:
         return HipObjectiveHooks(objective, packed)
 
     def needs_graph(self) -> bool:
-        return torch.is_grad_enabled() and any(v.tensor.requires_grad for v in self.packed._tracked())
+        return torch.is_grad_enabled() and any(v.tensor.requires_grad for v in self.packed.tracked_list())
 
     # ---- _vectorization_run: nothing to precompute (the reference's version is a full torch Jacobian pass per update) ----
     def run(self, *args, **kwargs):
@@ -451,7 +451,7 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
             return   # (generic path: with the Hessian in the graph when the reference asks for it)
         else:
             packed = self.packed
-            graph = torch.is_grad_enabled() and any(v.tensor.requires_grad for v in packed._tracked())
+            graph = torch.is_grad_enabled() and any(v.tensor.requires_grad for v in packed.tracked_list())
             if graph:
                 packed.sync(force=True)  # re-pack WITH the autograd history of the auxiliary variables
                 t = packed.tensors
@@ -536,7 +536,8 @@ class HipCholeskySolver(HipCholeskyCore, _RefCholeskyDenseSolver):
     (dense_solver.py:28-32)."""
 
     def __init__(self, objective: th.Objective, linearization_cls: Optional[Type[_RefLinearization]] = None,
-                 linearization_kwargs: Optional[Dict[str, Any]] = None, check_singular: bool = False, **kwargs):
+                 linearization_kwargs: Optional[Dict[str, Any]] = None, check_singular: bool = False,
+                 lagged_failure_check: bool = False, **kwargs):
         linearization_cls = linearization_cls or HipLinearization
         if not (isinstance(linearization_cls, type) and issubclass(linearization_cls, HipLinearization)):
             raise RuntimeError("HipCholeskySolver only works with theseus_amd.plugin.HipLinearization, "
@@ -544,6 +545,42 @@ class HipCholeskySolver(HipCholeskyCore, _RefCholeskyDenseSolver):
         _RefLinearSolver.__init__(self, objective, linearization_cls, linearization_kwargs)
         self._check_singular = check_singular
         self._core_init()
+        self._lagged = bool(lagged_failure_check)
+        self._lag = None
+
+    # ``lagged_failure_check=True`` (off by default; ``linear_solver_kwargs=dict(lagged_failure_check=True)``): ``solve()`` does not
+    # wait for the factorisation to learn whether it failed.  The default look at ``info`` is the ONE host synchronisation the
+    # plugin adds to an iteration of the reference's loop, and it sits right behind the 43 ms factorisation: everything the loop
+    # does on the host afterwards (_step: ~1500 Variable.update calls, retraction, error, ~4.5 ms at 256 poses) runs with the GPU
+    # idle.  Lagged: a failed item's step is zeroed ON THE DEVICE (its variables stay where they were), the flag travels to pinned
+    # host memory behind the solve, and the RuntimeError is raised by the NEXT solve() -- inside the loop's try block, after the
+    # loop's own end-of-iteration synchronisation, so it is never late by more than one iteration: status FAIL as in the
+    # reference (nonlinear_least_squares.py:138-152), with one more (unchanged-state) column in the error history.  What the flag
+    # gives up: a failure in the LAST iteration of an optimize() -- including the case where the dropped step makes the loop's
+    # relative-error test fire (an unchanged error reads as "converged") -- is only a RuntimeWarning at the next reset() / solve(),
+    # and the status says CONVERGED / MAX_ITERATIONS.  Hence opt-in.
+    def reset(self, **kwargs):
+        if self._lagged and self._lag is not None and self._lag.seen():
+            self._lag = None
+            import warnings
+            warnings.warn("HipCholeskySolver(lagged_failure_check=True): the last linear solve of the previous optimize() failed "
+                          "(not positive definite); its step was dropped.", RuntimeWarning)
+        self._lag = None
+
+    def _lagged_solve(self, damping, ellipsoidal_damping, damping_eps) -> torch.Tensor:
+        from .nonlinear import _LaggedFlag
+        if self._lag is not None and self._lag.seen():
+            self._lag = None
+            raise RuntimeError("linalg.cholesky: the factorisation of the previous linear solve could not be completed because the "
+                               "input is not positive-definite (HipCholeskySolver(lagged_failure_check=True): reported one "
+                               "solve late; that step was dropped).")
+        delta = self._solve(damping, ellipsoidal_damping, damping_eps, check_info=False)
+        failed = self.info.ne(0)
+        delta.masked_fill_(failed.unsqueeze(1), 0.0)
+        if self._lag is None:
+            self._lag = _LaggedFlag(delta.device)
+        self._lag.post(failed.any())
+        return delta
 
     def solve(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
               damping_eps: float = 1e-8, **kwargs) -> torch.Tensor:
@@ -560,6 +597,8 @@ class HipCholeskySolver(HipCholeskyCore, _RefCholeskyDenseSolver):
             if Hg is not None:
                 return _UnrolledFactorSolve.apply(self, damping, ellipsoidal_damping, damping_eps, Hg, g)
             return _CachedFactorSolve.apply(self, damping, ellipsoidal_damping, damping_eps, g)
+        if self._lagged:
+            return self._lagged_solve(damping, ellipsoidal_damping, damping_eps)
         return self._solve(damping, ellipsoidal_damping, damping_eps, check_info=True)
 
     def _solve_tensor_system(self, AtA, Atb, damping, ellipsoidal_damping, damping_eps) -> torch.Tensor:
@@ -674,7 +713,7 @@ class HipSchurLinearization(HipSchurLinearizationCore, _RefLinearization):
 
     def _linearize_hessian_impl(self, _detach_hessian: bool = False):
         packed = self.packed
-        graph = torch.is_grad_enabled() and any(v.tensor.requires_grad for v in packed._tracked())
+        graph = torch.is_grad_enabled() and any(v.tensor.requires_grad for v in packed.tracked_list())
         if graph and not _detach_hessian:
             raise NotImplementedError(
                 "theseus_amd builds the Hessian outside autograd: differentiating through it (backward_mode='unroll' "

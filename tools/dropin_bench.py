@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--adaptive", action="store_true")
+    ap.add_argument("--lagged", action="store_true", help="linear_solver_kwargs=dict(lagged_failure_check=True): no host sync in solve()")
     ap.add_argument("--no-hooks", action="store_true", help="only Linearization + LinearSolver replaced (round-1 boundary)")
     ap.add_argument("--reference-gpu-batch", type=int, default=0,
                     help="also run the UNMODIFIED reference (DenseLinearization + CholeskyDenseSolver through PyTorch-ROCm) on the "
@@ -70,6 +71,7 @@ def main():
                           name="pose_prior"))
     opt = th.LevenbergMarquardt(obj, linear_solver_cls=thp.HipCholeskySolver, linearization_cls=thp.HipLinearization,
                                 linearization_kwargs=dict(objective_hooks=not args.no_hooks, **lkw), max_iterations=K,
+                                linear_solver_kwargs=dict(lagged_failure_check=args.lagged),
                                 abs_err_tolerance=0.0, rel_err_tolerance=0.0, step_size=1.0)
     layer = th.TheseusLayer(opt)
     layer.to(dev)
@@ -156,7 +158,7 @@ def main():
     b = torch.stack([msol[f"VERTEX_SE3__{k}"] for k in range(P)], 1)
     print(json.dumps({
         "what": "real theseus loop + theseus_amd.plugin vs theseus_amd's own loop, same inputs, same kernels",
-        "hooks": not args.no_hooks, "dtype": args.dtype, "batch": B, "poses": P, "edges": E, "lm_iterations": iters,
+        "hooks": not args.no_hooks, "lagged_failure_check": args.lagged, "dtype": args.dtype, "batch": B, "poses": P, "edges": E, "lm_iterations": iters,
         "dropin_problem_iterations_per_s": B * iters / dt, "dropin_ms_per_iteration": dt / iters * 1e3,
         "mirror_problem_iterations_per_s": B * minfo.iters_done / mdt, "mirror_ms_per_iteration": mdt / minfo.iters_done * 1e3,
         "max_abs_pose_difference": float((a - b).abs().max()),
