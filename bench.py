@@ -879,7 +879,7 @@ def main():
                                                                      cpu_baseline=args.cpu_sample > 0), ctx))
     if "implicit" in legs and world == 1:
         leg("implicit_b1024", lambda: pg_run(variant(implicit=True, batch=min(1024, args.batch), sparse_leg=False,
-                                                     cpu_sample=min(args.cpu_sample, 2), parity_sample=min(args.parity_sample, 1)),
+                                                     cpu_sample=min(args.cpu_sample, 2), parity_sample=min(args.parity_sample, 8)),
                                              ctx))
     if "simple" in legs and world == 1:
         leg("simple_example_b16", lambda: simple_run(SimpleNamespace(batch=16, points=20, steps=5), ctx))

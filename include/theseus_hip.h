@@ -293,6 +293,10 @@ typedef struct {
   const int32_t* diag_s;          /* (per diag_k element) slot of L_jk */
   const int32_t* row_slot;        /* (per row_tile element) slot of that tile */
   int32_t nslots;                 /* ntiles + entries */
+  /* LOOK-AHEAD (batches below the two-stream threshold): (ntiles) HOST flags, 1 = the FIRST entry of block column j is tile
+   * (j + 1, j).  The factorisation then launches that tile on its own and starts the diagonal phase of column j + 1 under the rest
+   * of column j (left-looking: diag(j + 1) needs only row j + 1 of the earlier columns).  NULL: no look-ahead. */
+  const int32_t* col_head_host;
 } thx_tile_pattern;
 int thx_chol_factor_sparse(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
                            double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y, int64_t ldv,

@@ -14,7 +14,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("THX_GOLDEN_OUT", os.path.join(os.path.dirname(HERE), "tests", "golden"))   # (a scratch directory for timing re-runs)
 
 
 def import_reference():
@@ -1068,8 +1068,14 @@ def gen_ba(th, only=None):
             lin.linearize()
             A0, b0 = lin.A.clone().numpy(), lin.b.clone().numpy()
         err0 = obj.error_metric().clone().numpy()
+        import time
+        t_opt = time.perf_counter()
         with torch.no_grad():
             info = opt.optimize(track_err_history=True, end_iter_callback=cb, **(lmk or {}))
+        t_opt = time.perf_counter() - t_opt
+        # (quoted by bench.py's bundle-adjustment leg as the reference's own wall time at BASELINE configs[3]'s size)
+        print(f"TIMING {name}: the reference's optimize() = {t_opt:.1f} s for {B} problem(s) x {len(taps['delta'])} LM iterations, "
+              f"{torch.get_num_threads()} torch threads, dtype {dtype}", flush=True)
         Kc = len(cam_prior_idx)
         cam_prior_target = torch.cat([torch.eye(3, 4, dtype=dtype).view(1, 1, 3, 4).repeat(1, n_reg_cam, 1, 1), gt_c[:, [0, C - 1]]], 1)
         w_cam_prior = torch.cat([torch.full((1, n_reg_cam, 6), reg_w, dtype=dtype), torch.full((1, 2, 6), 100.0, dtype=dtype)], 1)

@@ -13,7 +13,7 @@ def relative_poses(X):
     return torch.cat([Rt @ R1, Rt @ (t1 - t0)], -1)
 
 
-def run_implicit(th, g, device, kernels=None, gauge_free=False):
+def run_implicit(th, g, device, kernels=None, gauge_free=False, **extra_optimizer_kwargs):
     t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
     _, _, kw = golden_problem(g)
     kw.pop("gauss_newton")
@@ -38,7 +38,8 @@ def run_implicit(th, g, device, kernels=None, gauge_free=False):
     opt = th.LevenbergMarquardt(obj, linearization_kwargs=lkw, max_iterations=kw.pop("max_iterations"),
                                 step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0)
     layer = th.TheseusLayer(opt)
-    sol, info = layer.forward(None, optimizer_kwargs=dict(backward_mode="implicit", track_err_history=True, **kw))
+    sol, info = layer.forward(None, optimizer_kwargs=dict(backward_mode="implicit", track_err_history=True, **kw,
+                                                             **extra_optimizer_kwargs))
     final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
     loss = (t(g["coef"]) * final).sum()
     loss.backward(retain_graph=gauge_free)

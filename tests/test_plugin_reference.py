@@ -415,6 +415,32 @@ def test_bundle_adjustment_implicit_backward_through_the_reference_loop(ref):
         np.testing.assert_allclose(out["grad_" + k].reshape(ref_g.shape), ref_g, rtol=5e-6, atol=5e-6 * np.abs(ref_g).max(), err_msg=k)
 
 
+def test_camera_camera_between_gradients_through_the_reference_loop(ref):
+    """Bundle adjustment with odometry (Between costs on consecutive cameras), backward_mode="implicit" through the REAL loop:
+    the gradients w.r.t. the odometry measurements and weights too (thx_pg_vjp over the camera columns of the backward solve,
+    ``_FusedAtbBA``) -- all eleven groups of tests/golden/ba_f64_camcam_implicit.npz (between.py:34-45 is plain autograd in the
+    reference)."""
+    th, thp = ref
+    from tests.ba_common import run_ba_implicit
+
+    class RefNames:
+        Objective, SE3, Point3, Point2, Vector, Variable, Difference, Between = (th.Objective, th.SE3, th.Point3, th.Point2, th.Vector,
+                                                                                th.Variable, th.Difference, th.Between)
+        ScaleCostWeight, DiagonalCostWeight = th.ScaleCostWeight, th.DiagonalCostWeight
+        RobustCostFunction, HuberLoss, WelschLoss = th.RobustCostFunction, th.HuberLoss, th.WelschLoss
+        Reprojection = th.eb.Reprojection
+        LevenbergMarquardt, TheseusLayer = th.LevenbergMarquardt, th.TheseusLayer
+    g = load_golden("ba_f64_camcam_implicit")
+    out = run_ba_implicit(RefNames, g, device=DEVICE,
+                          opt_kwargs=dict(linear_solver_cls=thp.HipSchurSolver, linearization_kwargs=_kernels(), vectorize=True))
+    np.testing.assert_allclose(out["final_cams"], g["final_cams"], rtol=0, atol=1e-7)
+    assert abs(out["loss"] - float(g["loss"])) <= 1e-7 * abs(float(g["loss"]))
+    for k in ("feat", "focal", "k1", "k2", "log_radius", "w_obs", "gt_cams", "w_strong", "w_reg", "cc_meas", "w_cc"):
+        ref_g = g["grad_" + k]
+        np.testing.assert_allclose(out["grad_" + k].reshape(ref_g.shape), ref_g, rtol=0, atol=5e-6 * max(np.abs(ref_g).max(), 1e-12),
+                                   err_msg=k)
+
+
 def test_dogleg_on_bundle_adjustment_through_the_plugin(ref):
     """th.Dogleg needs ``linearization.Av``: for bundle adjustment the plugin answers from thx_ba_av (per-cost Jacobian blocks,
     no dense Jacobian).  Av against the reference's DenseLinearization under the same variable ordering, then the REAL

@@ -50,7 +50,7 @@ class BAData(Structure):  # thx_ba_data
 class TilePattern(Structure):  # thx_tile_pattern: tile-level symbolic factorisation (device int32 tables + one host table)
     _fields_ = [("ntiles", c_int32)] + [(k, c_void_p) for k in ("col_ptr", "col_row", "tile_kptr", "tile_k", "diag_kptr", "diag_k",
                                                                "col_count_host", "row_ptr", "row_tile",
-                                                               "tile_sa", "tile_sb", "diag_s", "row_slot")] + [("nslots", c_int32)]
+                                                               "tile_sa", "tile_sb", "diag_s", "row_slot")] + [("nslots", c_int32), ("col_head_host", c_void_p)]
 
 
 class HBlockLayout(Structure):  # thx_hblock_layout: block-compact Hessian (device int32 tables)

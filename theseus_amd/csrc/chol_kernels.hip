@@ -1753,8 +1753,9 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
   const int b = (slot / nrow_tiles) * 8 + xcd;
-  // row tiles [i_first, i_first + nrow_tiles) of block column j -- or, tile-sparse, the column's non-zero row tiles
-  const int ent = pat.col_row ? pat.col_ptr[j] + (slot % nrow_tiles) : 0;
+  // row tiles [i_first, i_first + nrow_tiles) of block column j -- or, tile-sparse, entries [i_first, i_first + nrow_tiles) of the
+  // column's list of non-zero row tiles
+  const int ent = pat.col_row ? pat.col_ptr[j] + i_first + (slot % nrow_tiles) : 0;   // (tile-sparse: i_first = first ENTRY of the launch)
   const int i = pat.col_row ? pat.col_row[ent] : i_first + (slot % nrow_tiles);
   const int32_t* klist = pat.col_row ? pat.tile_k + pat.tile_kptr[ent] : nullptr;
   const int Kspan = pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE;
@@ -1971,7 +1972,7 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
   const int b = (slot / nrow_tiles) * 8 + xcd;
-  const int ent = pat.col_row ? pat.col_ptr[j] + (slot % nrow_tiles) : 0;
+  const int ent = pat.col_row ? pat.col_ptr[j] + i_first + (slot % nrow_tiles) : 0;   // (tile-sparse: i_first = first ENTRY of the launch)
   const int i = pat.col_row ? pat.col_row[ent] : i_first + (slot % nrow_tiles);
   const int32_t* klist = pat.col_row ? pat.tile_k + pat.tile_kptr[ent] : nullptr;
   const int Kspan = pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE;
@@ -2383,6 +2384,7 @@ struct DeviceLaunchState {
   bool attr_off = false;
   hipStream_t aux[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_lag[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
+  hipEvent_t ev_diag = nullptr, ev_rest = nullptr;   // look-ahead schedule (one part): diag(j) done / rest of column j done
 };
 static std::mutex g_launch_mutex;
 static DeviceLaunchState& launch_state() {
@@ -2538,6 +2540,65 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
                          tile_off, packed ? (int64_t)TILE : ld, j, ntiles, rh ? yh : nullptr, ldv);
     }
   };
+  // LOOK-AHEAD for batches that do not fill the chip (one part, i.e. B < THX_CHOL_SPLIT_MIN; THX_CHOL_LOOKAHEAD=0 turns it off).
+  // Left-looking: tile (i, j) needs rows i and j of the columns before j.  So the diagonal phase of column j + 1 needs, of column
+  // j, only tile (j + 1, j) -- and at batch 256 that phase is B workgroups with one busy wave each (80 us on a 3072-column banded
+  // system, 24 times).  Column j's off-diagonal launch is therefore split: HEAD = tile (j + 1, j) on the caller's stream, followed
+  // at once by diag(j + 1); REST = the other row tiles on the auxiliary stream, concurrent with both.  Dependencies:
+  //   REST(j)  after diag(j)                     (event ev_diag; the earlier HEADs precede diag(j) on the caller's stream)
+  //   HEAD(j)  after diag(j) and REST(j - 1)     (row j + 1 of column j - 1 is a REST tile: event ev_rest)
+  //   diag(j+1) after HEAD(j) [stream order] -- its other inputs, rows j + 1 of columns < j, were waited for by HEAD(j).
+  // Tile-sparse: only if the host put tile (j + 1, j) FIRST in column j's entry list (col_head_host); otherwise the column runs
+  // as before (diag(j + 1) waits for all of column j).  Same kernels, same arithmetic: bit-identical results.
+  static const bool lookahead_cfg = [] {
+    const char* e = getenv("THX_CHOL_LOOKAHEAD");
+    return e ? atoi(e) != 0 : true;
+  }();
+  const bool lookahead = lookahead_cfg && !split && ntiles > 2 && (!tp || tp->col_head_host != nullptr);
+  if (lookahead) {
+    if (!ds.ev_fork) hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming);
+    if (!ds.ev_diag) {
+      hipEventCreateWithFlags(&ds.ev_diag, hipEventDisableTiming);
+      hipEventCreateWithFlags(&ds.ev_rest, hipEventDisableTiming);
+    }
+    if (!ds.aux[0]) {
+      hipStreamCreateWithFlags(&ds.aux[0], hipStreamNonBlocking);
+      hipEventCreateWithFlags(&ds.ev_lag[0], hipEventDisableTiming);
+      hipEventCreateWithFlags(&ds.ev_join[0], hipEventDisableTiming);
+    }
+    const Half h0 = halves[0];
+    const Half h1 = {ds.aux[0], 0, B};
+    hipEventRecord(ds.ev_fork, st);
+    hipStreamWaitEvent(h1.s, ds.ev_fork, 0);
+    bool rest_pending = false;   // a REST launch whose completion the caller's stream has not waited for yet
+    for (int j = 0; j < ntiles; ++j) {
+      launch_diag(h0, j);
+      const int nrt = tp ? tp->col_count_host[j] : ntiles - 1 - j;
+      if (nrt <= 0) continue;
+      const bool head = tp ? tp->col_head_host[j] != 0 : true;   // the launch's first tile is (j + 1, j)
+      const int n_head = head ? 1 : 0, n_rest = nrt - n_head;
+      if (n_rest > 0) {
+        hipEventRecord(ds.ev_diag, h0.s);
+        hipStreamWaitEvent(h1.s, ds.ev_diag, 0);
+      }
+      if (rest_pending) {   // HEAD(j) / the next diagonal phase read REST(j - 1)'s tiles
+        hipStreamWaitEvent(h0.s, ds.ev_rest, 0);
+        rest_pending = false;
+      }
+      if (n_head) launch_off(h0, j, tp ? 0 : j + 1, 1);
+      if (n_rest > 0) {
+        launch_off(h1, j, tp ? n_head : j + 1 + n_head, n_rest);
+        hipEventRecord(ds.ev_rest, h1.s);
+        rest_pending = true;
+        if (!head) {   // no look-ahead for this column: diag(j + 1) needs a tile of this launch
+          hipStreamWaitEvent(h0.s, ds.ev_rest, 0);
+          rest_pending = false;
+        }
+      }
+    }
+    if (rest_pending) hipStreamWaitEvent(st, ds.ev_rest, 0);
+    return check_launch("thx_chol_factor");
+  }
   for (int j = 0; j < ntiles; ++j) {
     for (int k = 0; k < nparts; ++k) {
       const Half& h = halves[k];
@@ -2546,7 +2607,7 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       launch_diag(h, j);
       if (split && k + 1 < nparts && j == 0) hipEventRecord(ds.ev_lag[k], h.s);
       const int nrt = tp ? tp->col_count_host[j] : ntiles - 1 - j;   // (tile-sparse: the column's non-zero row tiles)
-      if (nrt > 0) launch_off(h, j, j + 1, nrt);
+      if (nrt > 0) launch_off(h, j, tp ? 0 : j + 1, nrt);
     }
   }
   if (split) {

@@ -655,7 +655,7 @@ class HipSparseCholeskySolver(HipSparseCholeskyCore, _RefCholeskyDenseSolver):
 
 
 # ---- bundle adjustment (theseus_amd/ba.py): Schur-complement linearization / solver for the REAL theseus loop ----------
-from .ba import HipSchurLinearizationCore, HipSchurSolverCore, ba_vjp_grads, detached_ba_tensors  # noqa: E402
+from .ba import BAImplicitStep, HipSchurLinearizationCore, HipSchurSolverCore, ba_vjp_grads, detached_ba_tensors  # noqa: E402
 
 
 class _FusedAtbBA(torch.autograd.Function):
@@ -666,15 +666,33 @@ class _FusedAtbBA(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lin, *aux):
         HipSchurLinearizationCore._assemble(lin)
-        t = lin.packed.tensors
+        packed = lin.packed
+        t = packed.tensors
+        n_aux = len(BAImplicitStep.NAMES)
+        aux, cc_aux = aux[:n_aux], aux[n_aux:]     # (+ the camera-camera Between costs' measurements and weights)
         ctx.lin = lin
         ctx.tensors = detached_ba_tensors(t, t.cams.detach(), t.points.detach(), aux)
+        ctx.cc_tensors = None
+        if cc_aux:
+            import dataclasses
+            ctx.cc_tensors = dataclasses.replace(packed.cc_tensors, poses=t.cams.detach(), meas=cc_aux[0].detach(),
+                                                 w_between=cc_aux[1].detach())
         return lin.g.clone()
 
     @staticmethod
     def backward(ctx, grad_g):
         lin = ctx.lin
-        return (None,) + ba_vjp_grads(lin.K, lin.packed, ctx.tensors, grad_g.contiguous())
+        packed, K = lin.packed, lin.K
+        w = grad_g.contiguous()
+        grads = ba_vjp_grads(K, packed, ctx.tensors, w)
+        if ctx.cc_tensors is not None:   # thx_pg_vjp over the camera columns of w (as BAImplicitStep.backward, theseus_amd/ba.py)
+            ct, E, B = ctx.cc_tensors, len(packed.cc_costs), w.shape[0]
+            new = lambda *sh: torch.empty(*sh, dtype=w.dtype, device=w.device)  # noqa: E731
+            g_meas, g_wb = new(E, B, 3, 4), new(E, B, 6)
+            K.pg_vjp(packed.cc_dstruct, ct, w[:, :packed.nc].contiguous(), g_meas, g_wb, new(1, B, 3, 4), new(1, B, 6))
+            fit = lambda g_, like: g_.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else g_  # noqa: E731
+            grads = grads + (fit(g_meas, ct.meas), fit(g_wb, ct.w_between))
+        return (None,) + grads
 
 
 class _CachedSchurSolve(torch.autograd.Function):
@@ -721,11 +739,9 @@ class HipSchurLinearization(HipSchurLinearizationCore, _RefLinearization):
         if graph:
             packed.sync(force=True)   # re-pack WITH the autograd history of the auxiliary variables
             t = packed.tensors
-            if packed.cc_costs and (packed.cc_tensors.meas.requires_grad or packed.cc_tensors.w_between.requires_grad):
-                raise NotImplementedError("theseus_amd plugin: gradients w.r.t. the measurements / weights of camera-camera "
-                                          "Between costs of a bundle-adjustment objective are wired for theseus_amd's own loop only.")
+            cc = (packed.cc_tensors.meas, packed.cc_tensors.w_between) if packed.cc_costs else ()
             self._g_graph = _FusedAtbBA.apply(self, t.feat, t.w_obs, t.focal, t.k1, t.k2, t.log_radius_obs,
-                                              t.cam_prior_target, t.w_cam_prior, t.pt_prior_target, t.w_pt_prior)
+                                              t.cam_prior_target, t.w_cam_prior, t.pt_prior_target, t.w_pt_prior, *cc)
         else:
             self._g_graph = None
             self._assemble()

@@ -83,7 +83,9 @@ class TilePattern:
             klists = {i: np.nonzero(lp[i, :j] & lp[j, :j])[0].tolist() for i in rows}
             # longest K-loop first: the workgroups of a launch are dispatched in entry order, so the long ones start early and
             # the short ones fill the tail (LPT scheduling)
-            for i in sorted(rows, key=lambda r: (-len(klists[r]), r)):
+            # -- after tile (j + 1, j), which goes FIRST when it exists: the factorisation's look-ahead schedule launches it on
+            # its own so that the diagonal phase of column j + 1 can start under the rest of column j (col_head_host)
+            for i in sorted(rows, key=lambda r: (r != j + 1, -len(klists[r]), r)):
                 col_row.append(i)
                 tile_k += klists[i]
                 tile_ij += [(i, j)] * len(klists[i])
@@ -109,6 +111,8 @@ class TilePattern:
                            diag_kptr=i32(diag_kptr), diag_k=i32(diag_k), row_ptr=i32(row_ptr), row_tile=i32(row_tile),
                            tile_sa=i32(tile_sa), tile_sb=i32(tile_sb), diag_s=i32(diag_s), row_slot=i32(row_slot))
         self.col_count = np.ascontiguousarray(np.diff(np.asarray(col_ptr, dtype=np.int64)).astype(np.int32))
+        self.col_head = np.ascontiguousarray(np.array([1 if (col_ptr[j + 1] > col_ptr[j] and col_row[col_ptr[j]] == j + 1) else 0
+                                                       for j in range(nt)], dtype=np.int32))
         self.l_tiles = int(lp.sum())
         # tile products the numeric factorisation executes (K-loop tiles + one TRSM / POTRF per tile) vs the dense count
         self.tile_products = len(tile_k) + len(diag_k) + self.l_tiles
@@ -131,6 +135,7 @@ class TilePattern:
             for k, v in t.items():
                 setattr(c, k, v.data_ptr())
             c.col_count_host = self.col_count.ctypes.data
+            c.col_head_host = self.col_head.ctypes.data
             self._dev[key] = (c, t)
         return self._dev[key][0]
 
