@@ -691,6 +691,12 @@ def ba_run(cfg, ctx):
     dense_flops = B * nc ** 3 / 3.0
     executed = B * pat.flops if pat is not None else dense_flops
     kernel_ms = sum(v["total_ms"] for v in phases.values()) / max(solves, 1)
+    ba_traffic = {}
+    try:  # HBM bytes of the factorisation / of one whole linear solve, measured offline with rocprofv3 --pmc (profiles/traffic.json)
+        ba_traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(
+            f"ba_{cfg.dtype}_c{meta['num_cams']}_o{meta['num_obs']}_b{B}", {})
+    except (OSError, ValueError):
+        pass
     result = {
         "metric": "LM iterations/sec (batch x vars) on bundle adjustment", "value": B * iters / dt,
         "unit": "problem-iterations/s", "ms_per_step": dt / iters * 1e3, "dtype": cfg.dtype, "steps": K_iters, "warmup": W,
@@ -707,7 +713,9 @@ def ba_run(cfg, ctx):
                                        f"column, non-zero tiles only)",
             # EXECUTED flops (the band of the reduced system: structurally zero tiles are skipped) / HIP-event time
             "achieved": executed / (fac["avg_ms"] * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-            "frac": executed / (fac["avg_ms"] * 1e-3) / 1e12 / peak, "traffic": None,
+            "frac": executed / (fac["avg_ms"] * 1e-3) / 1e12 / peak, "traffic": ba_traffic.get("bytes_per_factor_call"),
+            "traffic_unit": "bytes per factor call (PMC, rocprofv3)", "traffic_source": ba_traffic.get("source"),
+            "traffic_per_solve": ba_traffic.get("bytes_per_solve"),
             "flops_per_launch": executed, "avg_launch_ms": fac["avg_ms"],
             "executed": None if pat is None else {
                 "of_dense": pat.flops / pat.dense_flops, "tiles_of_L": [pat.l_tiles, pat.ntiles * (pat.ntiles + 1) // 2],
@@ -761,7 +769,15 @@ def ba_run(cfg, ctx):
                 "kind": "port",
                 "sample": f"REDUCED SIZE: {int(g['C'])} cameras / {int(g['Np'])} points / {g['obs_cam'].shape[0]} observations, "
                           f"{Bm} problems x {oinfo.iters_done} LM iterations ({cpu_s:.1f} s), dense oracle (n = "
-                          f"{6 * int(g['C'])} + 3 x points); the 512-camera dense formulation is 20.6 GB of A per problem"}
+                          f"{6 * int(g['C'])} + 3 x points); the 512-camera dense formulation is 20.6 GB of A per problem",
+                # NOT measured in this run (it takes 9 minutes and 30 GB): the UNMODIFIED reference at THIS leg's size, recorded
+                # when tests/golden/ba_full_f64_lm.npz was (re)generated -- profiles/r4/d_reference_ba_full_size_cpu_timing.txt
+                "reference_full_size": {
+                    "value": 2 / 532.0, "unit": "problem-iterations/s", "cores": 8, "kind": "reference", "dtype": "f64",
+                    "where": "build container (not this box), oracle/gen_golden.py ba_full_f64_lm",
+                    "sample": "512 cameras / 8192 points / 32768 observations, ONE problem x 2 adaptive LM iterations = 532.0 s "
+                              "(theseus LevenbergMarquardt + DenseLinearization + CholeskyDenseSolver, dense A 20.6 GB)",
+                    "speedup_of_this_leg": result["value"] / (2 / 532.0)}}
         except FileNotFoundError as e:
             result["cpu_baseline"] = {"error": f"fixture missing: {e}"}
     return result

@@ -90,7 +90,7 @@ def run_unrolled(th, g, tag, device, kernels=None):
     obj.add(th.AutoDiffCostFunction([a, b], f, xl.shape[1], aux_vars=[th.Variable(xl, name="x"), th.Variable(yl, name="y")],
                                     cost_weight=th.DiagonalCostWeight(th.Variable(wl, name="w"))))
     lkw = dict(linearization_kwargs=dict(kernels=kernels)) if kernels is not None else {}
-    opt = getattr(th, cls)(obj, max_iterations=6, abs_err_tolerance=tol, rel_err_tolerance=tol, **lkw)
+    opt = getattr(th, cls)(obj, max_iterations=int(g[f"u_{tag}_iters"]), abs_err_tolerance=tol, rel_err_tolerance=tol, **lkw)
     B = xl.shape[0]
     sol, info = th.TheseusLayer(opt).forward({"a": torch.ones(B, 1, dtype=dt, device=device), "b": 2.5 * torch.ones(B, 1, dtype=dt, device=device)},
                                              optimizer_kwargs=dict(track_err_history=True, backward_mode=mode, **okw))

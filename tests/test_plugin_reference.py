@@ -666,7 +666,7 @@ def test_reference_loop_differentiates_through_the_plugin_on_generic_objectives(
     obj = th.Objective(dtype=dt)
     obj.add(th.AutoDiffCostFunction([a, b], f, 12, aux_vars=[th.Variable(xl, name="x"), th.Variable(yl, name="y")],
                                     cost_weight=th.DiagonalCostWeight(th.Variable(wl, name="w"))))
-    opt = getattr(th, cls)(obj, max_iterations=6, abs_err_tolerance=tol, rel_err_tolerance=tol,
+    opt = getattr(th, cls)(obj, max_iterations=int(g[f"u_{tag}_iters"]), abs_err_tolerance=tol, rel_err_tolerance=tol,
                            linear_solver_cls=thp.HipCholeskySolver, linearization_kwargs=_kernels())
     sol, info = th.TheseusLayer(opt).forward(input_tensors={"a": torch.ones(6, 1, dtype=dt), "b": 2.5 * torch.ones(6, 1, dtype=dt)},
                                              optimizer_kwargs=dict(track_err_history=True, backward_mode=mode, **okw))

@@ -1939,8 +1939,15 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
 //   * the substitution runs IN PLACE: X_s = W_ss P_s goes through a 32-VGPR temporary back into P_s's registers, which
 //     then serve as the B operand of the updates P_u += (-L_us) X_s.  128 + 32 accumulator VGPRs instead of 256.
 // ------------------------------------------------------------------------------------------------
-// 48 KB: panel phase A (six 8 KB sub-blocks), staged over the K-loop buffers (2 x 128 x LDT doubles = 36.9 KB with 16-column chunks)
-constexpr int OFF64_SMEM = (2 * 128 * CT<double>::LDT * 8 > 6 * 1024 * 8) ? 2 * 128 * CT<double>::LDT * 8 : 6 * 1024 * 8;
+// LDS of the fp64 off-diagonal kernel (round 4): the K-loop's staging buffers (2 x 128 x LDT doubles = 36.9 KB with 16-column
+// chunks; after the K-loop: four 8 KB panel sub-blocks) + a 40 KB region E for panel sub-blocks 0..4, which land there straight
+// from global memory (global_load_lds, no registers) while the FIRST k-chunk is in flight -- 76.9 KB, two workgroups per CU.
+// The substitution starts on E the moment the K-loop ends; sub-blocks 5..9 are requested then and arrive under its first five
+// block products.  (Round 3: all ten sub-blocks were fetched after the K-loop, in two phases, each an exposed round trip.)
+constexpr int OFF64_STAGE = (2 * 128 * CT<double>::LDT * 8 > 4 * 1024 * 8) ? 2 * 128 * CT<double>::LDT * 8 : 4 * 1024 * 8;
+constexpr int OFF64_EBLK = 5;
+constexpr int OFF64_SMEM = OFF64_STAGE + OFF64_EBLK * 1024 * 8;
+static_assert(2 * OFF64_SMEM <= 160 * 1024, "two fp64 off-diagonal workgroups per CU");
 
 // D.block(S) += Pc[block idx] * Bs.block(Tt)^T, Pc block: 32 x 32 doubles, element (r, c) at r * 32 + (c ^ 2 (r & 15))
 template <int S, int Tt, typename DT>
@@ -1995,12 +2002,66 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   E::zero(P);
   HBPre<double, HB ? HB_NPRE_OFF : 1> hbp;
   if constexpr (HB) hbp.load(hb, b, i, j, tid);
+  // panel sub-block q (row-major list of the lower triangle): block row SB[q], block column TB[q]
+  const double* Pn = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
+  double* const smemE = smem + OFF64_STAGE / 8;
+  // sub-blocks 0..4 -> E by LDS-direct loads: lane l of wave w, pass u writes the 16-byte unit U = 256 u + 64 w + l of the block
+  // (row r = U / 16, unit u' = U % 16) and fetches the unit u' ^ (r & 15) of that row -- the XOR swizzle sub_mma64 reads with
+  auto prefetch_panel = [&]() __attribute__((always_inline)) {
+    constexpr int SB[5] = {0, 1, 1, 2, 2}, TB[5] = {0, 0, 1, 0, 1};
+#pragma unroll
+    for (int q = 0; q < OFF64_EBLK; ++q)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int U = 256 * u + 64 * wave + lane, r = U >> 4, up = U & 15;
+        const double* src = Pn + (32 * SB[q] + r) * TILE + 32 * TB[q] + 2 * (up ^ (r & 15));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smemE + q * 1024 + (256 * u + 64 * wave) * 2),
+                                         16, 0, 0);
+      }
+  };
   kloop<double, false>(L + lmat + (lf.packed ? 0 : (int64_t)col0 * ld), TILE, L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld), validB,
-                       ldt, Kspan, sA, sB, P, tid, nullptr, nullptr, NoHook{}, klist, ksa, ksb, lf.pstride);
+                       ldt, Kspan, sA, sB, P, tid, nullptr, nullptr, prefetch_panel, klist, ksa, ksb, lf.pstride);
+  // sub-blocks 5..9: requested now (the K-loop's prefetch registers are free) next to H; 5..8 go into the staging buffers as soon
+  // as those are free, W_33 (sub-block 9) waits in 8 VGPRs for sub-block 0's place in E
+  double2 late[5][2];
+  if constexpr (!HB) {
+    // dense H: 5..8 straight into the staging buffers (LDS-direct, no registers: the 128 VGPRs of the H tile are about to be in
+    // flight) -- after a barrier: the K-loop ends on a chunk's MFMAs, a slower wave may still be reading its fragments
+    __syncthreads();
+    constexpr int SB[4] = {2, 3, 3, 3}, TB[4] = {2, 0, 1, 2};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int U = 256 * u + 64 * wave + lane, r = U >> 4, up = U & 15;
+        const double* src = Pn + (32 * SB[q] + r) * TILE + 32 * TB[q] + 2 * (up ^ (r & 15));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + q * 1024 + (256 * u + 64 * wave) * 2),
+                                         16, 0, 0);
+      }
+  }
+  {
+    constexpr int SB[5] = {2, 3, 3, 3, 3}, TB[5] = {2, 0, 1, 2, 3};
+    const int pi = tid >> 3, pc = tid & 7;  // row of the sub-block, 32-byte piece (4 doubles) of the row
+#pragma unroll
+    for (int q = HB ? 0 : 4; q < 5; ++q) {
+      const double2* src = reinterpret_cast<const double2*>(Pn + (32 * SB[q] + pi) * TILE + 32 * TB[q] + 4 * pc);
+      late[q][0] = src[0];
+      late[q][1] = src[1];
+    }
+  }
+  auto put_late = [&](int q, double* dst_blk) __attribute__((always_inline)) {
+    const int pi = tid >> 3, pc = tid & 7;
+    double* dst = dst_blk + pi * 32;
+    // columns 4pc, 4pc+1 | 4pc+2, 4pc+3 -> swizzled pairs (2-double pieces stay contiguous: the swizzle is even)
+    *reinterpret_cast<double2*>(dst + ((4 * pc) ^ (2 * (pi & 15)))) = late[q][0];
+    *reinterpret_cast<double2*>(dst + ((4 * pc + 2) ^ (2 * (pi & 15)))) = late[q][1];
+  };
   if constexpr (HB) {
     // block-compact H: the tile's pieces through the (free) staging buffers, 32 rows -- one wave's -- at a time
     constexpr int LDH = 130;
-    static_assert(32 * LDH * 8 <= OFF64_SMEM, "a quarter of an H tile must fit in the staging buffers");
+    static_assert(32 * LDH * 8 <= OFF64_STAGE, "a quarter of an H tile must fit in the staging buffers");
     __syncthreads();
 #pragma unroll
     for (int rd = 0; rd < 4; ++rd) {
@@ -2038,44 +2099,18 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
       }
   }
   }
-  // ---- panel sub-blocks -> LDS (swizzled), phase A: block rows 0..2 (six blocks) ----
-  const double* Pn = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
-  auto stage = [&](int first, int count) __attribute__((always_inline)) {
-    constexpr int SB[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3}, TB[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
-    const int pi = tid >> 3, pc = tid & 7;  // row of the sub-block, 32-byte piece (4 doubles) of the row
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k < count) {
-        const int blk = first + k;
-        int sbk = 0, tbk = 0;
-#pragma unroll
-        for (int q = 0; q < 10; ++q)
-          if (q == blk) { sbk = SB[q]; tbk = TB[q]; }
-        const double2* src = reinterpret_cast<const double2*>(Pn + (32 * sbk + pi) * TILE + 32 * tbk + 4 * pc);
-        const double2 v0 = src[0], v1 = src[1];
-        double* dst = smem + (size_t)k * 1024 + pi * 32;
-        // columns 4pc, 4pc+1 | 4pc+2, 4pc+3 -> swizzled pairs (2-double pieces stay contiguous: the swizzle is even)
-        *reinterpret_cast<double2*>(dst + ((4 * pc) ^ (2 * (pi & 15)))) = v0;
-        *reinterpret_cast<double2*>(dst + ((4 * pc + 2) ^ (2 * (pi & 15)))) = v1;
-      }
-    }
-  };
-  // (the K-loop ends on a barrier: the staging buffers are free)
-  stage(0, 4);
-  {  // blocks 4, 5 of phase A
-    constexpr int SB2[2] = {2, 2}, TB2[2] = {1, 2};
-    const int pi = tid >> 3, pc = tid & 7;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const double2* src = reinterpret_cast<const double2*>(Pn + (32 * SB2[k] + pi) * TILE + 32 * TB2[k] + 4 * pc);
-      const double2 v0 = src[0], v1 = src[1];
-      double* dst = smem + (size_t)(4 + k) * 1024 + pi * 32;
-      *reinterpret_cast<double2*>(dst + ((4 * pc) ^ (2 * (pi & 15)))) = v0;
-      *reinterpret_cast<double2*>(dst + ((4 * pc + 2) ^ (2 * (pi & 15)))) = v1;
-    }
+  // sub-blocks 5..8 -> the staging buffers (free: the K-loop / the H rounds ended on a barrier; column 0 has neither, and nobody
+  // has touched them)
+  if constexpr (HB) {
+    put_late(0, smem + 0 * 1024);
+    put_late(1, smem + 1 * 1024);
+    put_late(2, smem + 2 * 1024);
+    put_late(3, smem + 3 * 1024);
   }
+  // E (LDS-direct loads of the prologue) and the staging buffers complete and visible to every wave
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // ---- in-place substitution, sub-block columns 0..2 ----
+  // ---- in-place substitution ----
   auto solve_diag = [&](auto is, const double* Wss) __attribute__((always_inline)) {
     constexpr int sb = decltype(is)::value;
     f64x4 T0[2], T1[2];
@@ -2104,19 +2139,20 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
-  solve_diag(I0{}, smem + 0 * 1024);
-  update(I1{}, I0{}, smem + 1 * 1024);
-  solve_diag(I1{}, smem + 2 * 1024);
-  update(I2{}, I0{}, smem + 3 * 1024);
-  update(I2{}, I1{}, smem + 4 * 1024);
-  solve_diag(I2{}, smem + 5 * 1024);
-  __syncthreads();  // phase A blocks consumed
-  stage(6, 4);      // phase B: block row 3
-  __syncthreads();
-  update(I3{}, I0{}, smem + 0 * 1024);
-  update(I3{}, I1{}, smem + 1 * 1024);
-  update(I3{}, I2{}, smem + 2 * 1024);
-  solve_diag(I3{}, smem + 3 * 1024);
+  // sub-blocks 0..4 from E (there since the first k-chunk)
+  solve_diag(I0{}, smemE + 0 * 1024);
+  update(I1{}, I0{}, smemE + 1 * 1024);
+  solve_diag(I1{}, smemE + 2 * 1024);
+  update(I2{}, I0{}, smemE + 3 * 1024);
+  update(I2{}, I1{}, smemE + 4 * 1024);
+  __syncthreads();                  // every wave is done with E
+  put_late(4, smemE + 0 * 1024);    // sub-block 9 = W_33 takes sub-block 0's place
+  solve_diag(I2{}, smem + 0 * 1024);
+  update(I3{}, I0{}, smem + 1 * 1024);
+  update(I3{}, I1{}, smem + 2 * 1024);
+  update(I3{}, I2{}, smem + 3 * 1024);
+  __syncthreads();                  // W_33 in place
+  solve_diag(I3{}, smemE + 0 * 1024);
   // ---- store X (in P's registers) ----
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -2554,7 +2590,11 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     const char* e = getenv("THX_CHOL_LOOKAHEAD");
     return e ? atoi(e) != 0 : true;
   }();
-  const bool lookahead = lookahead_cfg && !split && ntiles > 2 && (!tp || tp->col_head_host != nullptr);
+  // Measured (profiles/r4/c_ab_lookahead_small_batch_factor.txt, same box, two rounds): the banded reduced camera system of the
+  // bundle-adjustment config (3072 columns, batch 256, 158 of 300 tiles) 6.82 -> 6.60 ms; DENSE frames do not gain (n = 1536:
+  // batch 256 3.5 ms either way, batch 512 6.2 -> 6.4 ms; n = 3072 batch 256 21.6 -> 21.8 ms: REST(j) of a dense column is most
+  // of the launch, the dispatcher does not run the two queues side by side) -- so: tile-sparse only.
+  const bool lookahead = lookahead_cfg && !split && ntiles > 2 && tp && tp->col_head_host != nullptr;
   if (lookahead) {
     if (!ds.ev_fork) hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming);
     if (!ds.ev_diag) {

@@ -31,7 +31,7 @@ def run(tag, device, kernels):
     obj.add(th.AutoDiffCostFunction([a, b], f, xl.shape[1], aux_vars=[th.Variable(xl, name="x"), th.Variable(yl, name="y")],
                                     cost_weight=th.DiagonalCostWeight(th.Variable(wl, name="w"))))
     lkw = dict(linearization_kwargs=dict(kernels=kernels)) if kernels is not None else {}
-    opt = getattr(th, cls)(obj, max_iterations=6, abs_err_tolerance=tol, rel_err_tolerance=tol, **lkw)
+    opt = getattr(th, cls)(obj, max_iterations=int(sys.argv[2]) if len(sys.argv) > 2 else 6, abs_err_tolerance=tol, rel_err_tolerance=tol, **lkw)
     B = xl.shape[0]
     okw = dict(okw)
     okw.pop("backward_num_iterations", None)
