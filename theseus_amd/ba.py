@@ -25,6 +25,11 @@ from .packed import UnsupportedObjective, _aux_vars, _kind, _unwrap_robust, _wei
 ERR_CHUNKS = _lib.THX_BA_ERR_CHUNKS
 
 
+import operator
+
+_GET_TENSOR = {True: operator.attrgetter("_tensor"), False: operator.attrgetter("tensor")}   # own Variable: skip the property
+_DATA_PTR, _VERSION, _NUM_UPDATES = operator.methodcaller("data_ptr"), operator.attrgetter("_version"), operator.attrgetter("_num_updates")
+
 def _csr(owner: np.ndarray, n: int, secondary: Optional[np.ndarray] = None):
     """ids grouped by owner (stable / sorted by ``secondary``) -> (ptr (n+1), ids)."""
     ids = np.arange(owner.shape[0])
@@ -291,9 +296,20 @@ class PackedBA:
             tracked = self._tracked_list = list(self._tracked())
         if count is not None:
             tracked = tracked[:count]
-        if deep:  # in-place edits of a variable's tensor (see PackedPoseGraph._current_stamp)
-            return tuple([(t.data_ptr(), t._version) for t in (v.tensor for v in tracked)])
-        return tuple([v._num_updates for v in tracked])
+        if deep:
+            # tensor identity + autograd version counter: catches IN-PLACE edits of a variable's tensor that never go
+            # through Variable.update() (an nn.Parameter stepped by a torch optimizer, ``var.tensor.mul_()``) and plain
+            # ``var.tensor = other`` -- the reference re-reads ``var.tensor`` at every evaluation (core/objective.py:813-830)
+            # and sees those.  One C-level pass per column (42 k variables of a bundle-adjustment objective: 7 ms instead of
+            # 16).  Identity = the storage pointer for the optimisation variables (their tensors are views of the packed state:
+            # holding them would pin a state buffer), the tensor OBJECT for the auxiliary ones -- kept referenced until the next
+            # stamp, so an id cannot be recycled in between.
+            ts = list(map(_GET_TENSOR[self._own_variables], tracked))
+            n_opt = min(len(self.cam_vars) + len(self.pt_vars), len(ts))
+            self._deep_refs = ts[n_opt:] if count is None else getattr(self, "_deep_refs", None)
+            keys = tuple(map(_DATA_PTR, ts[:n_opt])) + tuple(map(id, ts[n_opt:]))
+            return tuple(zip(keys, map(_VERSION, ts)))
+        return tuple(map(_NUM_UPDATES, tracked))
 
     @staticmethod
     def _stack(ts, B):
