@@ -361,6 +361,34 @@ class OracleKernels:
             if leaf.shape[1] > 0:
                 out[:leaf.shape[1]].copy_((g if g is not None else torch.zeros_like(leaf)).transpose(0, 1))
 
+    def pg_unroll_vjp(self, s, t, w, delta, g_pose_i, g_pose_j, g_meas, g_wb, g_pose_p, g_tgt, g_wp, poses=None):
+        """thx_pg_unroll_vjp: per cost, the gradient of phi = -(J w) . (r + J delta) by torch autograd through the oracle's
+        Between / Local formulas (which carry the reference's autograd conventions)."""
+        p, x = self._problem(s, t, poses)
+        if p.group != "SE3" or p.robust_between or p.robust_prior:
+            raise NotImplementedError("stand-in pg_unroll_vjp: plain SE3 pose graphs")
+        B = x.shape[0]
+        E, Kp = p.edges.shape[0], p.prior_idx.shape[0]
+        i, j = p.edges[:, 0], p.edges[:, 1]
+        blk = lambda v, idx: v.view(B, -1, 6)[:, idx]   # noqa: E731   (B, n) -> (B, len(idx), 6)
+        with torch.enable_grad():
+            full = lambda a: a.detach().expand(B, *a.shape[1:]).clone().requires_grad_(True)  # noqa: E731
+            v0, v1, vp = full(x[:, i]), full(x[:, j]), full(x[:, p.prior_idx])
+            meas, wb, tgt, wp = full(p.meas), full(p.w_between), full(p.prior_target), full(p.w_prior)
+            mv = lambda J, v: (J @ v.unsqueeze(-1)).squeeze(-1)   # noqa: E731
+            phi = x.new_zeros(())
+            if E:
+                J0, J1, eb = opg.between_jac_err(v0, v1, meas, wb, p.G)
+                phi = phi - ((mv(J0, blk(w, i)) + mv(J1, blk(w, j))) * (eb + mv(J0, blk(delta, i)) + mv(J1, blk(delta, j)))).sum()
+            if Kp:
+                Jp, ep = opg.local_jac_err(tgt, vp, wp, p.G)
+                phi = phi - (mv(Jp, blk(w, p.prior_idx)) * (ep + mv(Jp, blk(delta, p.prior_idx)))).sum()
+            leaves = [v0, v1, meas, wb, vp, tgt, wp]
+            grads = torch.autograd.grad(phi, leaves, allow_unused=True)
+        for out, g, leaf in zip((g_pose_i, g_pose_j, g_meas, g_wb, g_pose_p, g_tgt, g_wp), grads, leaves):
+            if leaf.shape[1] > 0:
+                out[:leaf.shape[1]].copy_((g if g is not None else torch.zeros_like(leaf)).transpose(0, 1))
+
     # ---- dense solver ------------------------------------------------------------------------------
     def chol_factor(self, H, n, damping, ellipsoidal, damping_eps, L, panels, info, rhs=None, y=None):
         Hl = torch.tril(H[:, :n, :n])

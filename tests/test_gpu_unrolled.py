@@ -15,6 +15,54 @@ def test_differentiating_through_the_iterations_on_the_gpu(tag):
     run_unrolled(th, load_golden("simple_example"), tag, "cuda")
 
 
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc"])
+def test_differentiating_through_the_iterations_of_a_pose_graph_on_the_gpu(tag):
+    """BackwardMode.UNROLL / TRUNCATED on an SE3 pose graph through the HIP kernels (thx_pg_unroll_vjp, thx_se3_retract_vjp,
+    thx_chol_solve with a copy of each iteration's factor) against the REAL reference's gradients
+    (tests/golden/pg_f64_unrolled.npz).  CPU twin: tests/test_unrolled_host.py; the kernel's maths on the host:
+    tests/test_unroll_math_host.py."""
+    import theseus_amd as th
+    from tests.unrolled_common import run_pg_unrolled
+    run_pg_unrolled(th, load_golden("pg_f64_unrolled"), tag, "cuda")
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_unroll_vjp_kernel_against_autograd_through_the_oracle(dtype):
+    """thx_pg_unroll_vjp on its own: per-cost gradients of phi = -(J w).(r + J delta) for random w, delta against torch autograd
+    through the oracle's Between / Local formulas (tests/oracle_kernels.py:pg_unroll_vjp): fp64 to rounding; fp32 storage
+    (double arithmetic inside, the same fp32-rounded inputs on both sides, fp32 Taylor thresholds) to the output's rounding."""
+    import contextlib
+    import dataclasses
+    import torch
+    from tests.gpu_helpers import to_device_problem
+    from tests.helpers import f32_thresholds, golden_problem
+    from tests.oracle_kernels import OracleKernels
+    from theseus_amd.kernels import default_kernels
+    g = load_golden("pg_f64_unrolled")
+    p, poses0, _ = golden_problem({**g, "opt_kwargs": "{}"})
+    dt = torch.float64 if dtype == "f64" else torch.float32
+    r = (lambda x: x) if dtype == "f64" else (lambda x: x.float().double())
+    p = dataclasses.replace(p, meas=r(p.meas), w_between=r(p.w_between), prior_target=r(p.prior_target), w_prior=r(p.w_prior))
+    poses0 = r(poses0)
+    B, n = poses0.shape[0], 6 * p.num_poses
+    gen = torch.Generator().manual_seed(3)
+    w, d = (r(torch.randn(B, n, dtype=torch.float64, generator=gen)) for _ in range(2))
+    cast = lambda x: x.to(dt)  # noqa: E731
+    p_d = dataclasses.replace(p, meas=cast(p.meas), w_between=cast(p.w_between), prior_target=cast(p.prior_target), w_prior=cast(p.w_prior))
+    s, t = to_device_problem(p_d, cast(poses0))
+    s64, t64 = to_device_problem(p, poses0, device="cpu")
+    E, Kp = s.num_edges, s.num_priors
+    shapes = [(E, B, 3, 4), (E, B, 3, 4), (E, B, 3, 4), (E, B, 6), (Kp, B, 3, 4), (Kp, B, 3, 4), (Kp, B, 6)]
+    got = [torch.zeros(*sh, dtype=dt, device="cuda") for sh in shapes]
+    default_kernels().pg_unroll_vjp(s.on("cuda"), t, cast(w).cuda(), cast(d).cuda(), *got)
+    want = [torch.zeros(*sh, dtype=torch.float64) for sh in shapes]
+    with (f32_thresholds() if dtype == "f32" else contextlib.nullcontext()):
+        OracleKernels().pg_unroll_vjp(s64.on("cpu"), t64, w, d, *want)
+    tol = 1e-10 if dtype == "f64" else 5e-7
+    for a, b_, name in zip(got, want, ("pose_i", "pose_j", "meas", "w_between", "pose_prior", "prior_target", "w_prior")):
+        assert (a.cpu().double() - b_).abs().max() <= tol * max(1.0, float(b_.abs().max())), name
+
+
 def test_ba_with_camera_camera_costs_on_the_gpu():
     """Bundle adjustment with Between (odometry) costs on consecutive cameras through the HIP kernels -- thx_pg_assemble /
     thx_pg_error over the camera buffer joined with the Schur complement (theseus_amd/ba.py) -- against the REAL reference's run

@@ -1,0 +1,76 @@
+"""The device maths of BackwardMode.UNROLL / TRUNCATED for SE3 pose graphs (theseus_amd/csrc/unroll_se3.cuh) WITHOUT a GPU: the
+header is plain C++ over lie.cuh / dual.cuh, compiled here for the host (tests/hostmath: a 6-line shim for <hip/hip_runtime.h>)
+and compared with torch autograd through the oracle's formulas -- which carry the reference's autograd conventions (log's
+passthrough backward, plain graphs for inverse / compose / adjoint / Jlog) and are pinned to the reference's own unrolled
+gradients by tests/test_oracle_golden.py::test_unrolled_gradients_of_a_pose_graph_match_reference."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lie
+from oracle import pose_graph as opg
+from tests.conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def hostmath(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("hostmath") / "libhostmath.so")
+    src = os.path.join(ROOT, "tests", "hostmath")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", f"-I{src}", f"-I{ROOT}/theseus_amd/csrc", "-Wno-unknown-pragmas",
+                    os.path.join(src, "hostmath.cpp"), "-o", out], check=True)
+    return ctypes.CDLL(out)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _rand_pose(gen, scale_t, scale_r):
+    xi = torch.cat([scale_t * (2 * torch.rand(1, 3, dtype=torch.float64, generator=gen) - 1),
+                    scale_r * (2 * torch.rand(1, 3, dtype=torch.float64, generator=gen) - 1)], 1)
+    return lie.se3_exp(xi)[0]
+
+
+EPS64 = np.array([lie.EPS[torch.float64][k] for k in ("near_zero", "d_near_zero", "near_pi")])
+
+
+@pytest.mark.parametrize("seed,scale_r", [(0, 1.0), (1, 2.5), (2, 0.3), (3, 1e-3)])   # (1e-3: the near-zero Taylor branches)
+def test_between_cost_unrolled_vjp_matches_autograd_through_the_oracle(hostmath, seed, scale_r):
+    gen = torch.Generator().manual_seed(seed)
+    Xi, Xj = _rand_pose(gen, 2.0, 1.5), _rand_pose(gen, 2.0, 1.5)
+    D = lie.se3_compose(lie.se3_inverse(Xi), Xj)
+    Z = lie.se3_compose(D, _rand_pose(gen, 0.2 * scale_r, scale_r))   # E = Z^-1 D has a rotation of ~scale_r
+    s = 0.5 + torch.rand(6, dtype=torch.float64, generator=gen)
+    wi, wj, di, dj = (torch.randn(6, dtype=torch.float64, generator=gen) for _ in range(4))
+    leaves = [t.clone().requires_grad_(True) for t in (Xi, Xj, Z, s)]
+    J0, J1, e = opg.between_jac_err(leaves[0], leaves[1], leaves[2], leaves[3])
+    phi = -((J0 @ wi + J1 @ wj) * (e + J0 @ di + J1 @ dj)).sum()
+    phi.backward()
+    out = np.zeros(42)
+    hostmath.hm_edge_vjp(*(_ptr(np.ascontiguousarray(t.detach().numpy().reshape(-1))) for t in (Xi, Xj, Z, s, wi, wj, di, dj)),
+                         _ptr(EPS64), _ptr(out))
+    for k, (name, sl) in enumerate((("Xi", slice(0, 12)), ("Xj", slice(12, 24)), ("Z", slice(24, 36)), ("s", slice(36, 42)))):
+        want = leaves[k].grad.numpy().reshape(-1)
+        np.testing.assert_allclose(out[sl], want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()), err_msg=name)
+
+
+@pytest.mark.parametrize("seed,scale_r", [(0, 1.0), (1, 1e-3)])
+def test_prior_cost_unrolled_vjp_matches_autograd_through_the_oracle(hostmath, seed, scale_r):
+    gen = torch.Generator().manual_seed(10 + seed)
+    X = _rand_pose(gen, 2.0, 1.5)
+    T = lie.se3_compose(X, _rand_pose(gen, 0.2 * scale_r, scale_r))
+    s = 0.5 + torch.rand(6, dtype=torch.float64, generator=gen)
+    w, d = (torch.randn(6, dtype=torch.float64, generator=gen) for _ in range(2))
+    leaves = [t.clone().requires_grad_(True) for t in (X, T, s)]
+    J, e = opg.local_jac_err(leaves[1], leaves[0], leaves[2])
+    phi = -((J @ w) * (e + J @ d)).sum()
+    phi.backward()
+    out = np.zeros(30)
+    hostmath.hm_prior_vjp(*(_ptr(np.ascontiguousarray(t.detach().numpy().reshape(-1))) for t in (X, T, s, w, d)), _ptr(EPS64), _ptr(out))
+    for k, (name, sl) in enumerate((("X", slice(0, 12)), ("T", slice(12, 24)), ("s", slice(24, 30)))):
+        want = leaves[k].grad.numpy().reshape(-1)
+        np.testing.assert_allclose(out[sl], want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()), err_msg=name)

@@ -1,0 +1,42 @@
+"""BackwardMode.UNROLL / TRUNCATED on an SE3 pose graph through theseus_amd's own loop (PGUnrolledIteration: thx_pg_unroll_vjp +
+a copy of every differentiated iteration's factor), against the gradients the REAL reference recorded by differentiating through
+its iterations (tests/golden/pg_f64_unrolled.npz, oracle/gen_golden.py:gen_pg_unrolled).  Shared by the CPU twin (stand-in
+kernels) and the GPU test."""
+import ast
+
+import numpy as np
+import torch
+
+
+def run_pg_unrolled(th, g, tag, device, kernels=None):
+    t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
+    kw = ast.literal_eval(str(g[f"{tag}_kwargs"]))
+    mode, iters, gn = kw.pop("mode"), kw.pop("max_iterations"), kw.pop("gauss_newton")
+    P = int(g["P"])
+    leaves = dict(meas=t(g["meas"]).requires_grad_(True), w_between=t(g["w_between"]).requires_grad_(True),
+                  prior_target=t(g["prior_target"]).requires_grad_(True),
+                  w_prior=t(g["w_prior"])[:, :, :1].clone().requires_grad_(True))
+    obj = th.Objective(dtype=leaves["meas"].dtype)
+    poses0 = t(g["poses0"])
+    poses = [th.SE3(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    for k in range(g["edges"].shape[0]):
+        i, j = g["edges"][k].tolist()
+        obj.add(th.Between(poses[i], poses[j], th.SE3(tensor=leaves["meas"][:, k], name=f"meas_{k}"),
+                           th.DiagonalCostWeight(th.Variable(leaves["w_between"][:, k], name=f"w_{k}")), name=f"between_{k}"))
+    for k in range(g["prior_idx"].shape[0]):
+        obj.add(th.Difference(poses[int(g["prior_idx"][k])], th.SE3(tensor=leaves["prior_target"][:, k], name=f"prior_target_{k}"),
+                              th.ScaleCostWeight(th.Variable(leaves["w_prior"][:, k], name=f"pw_{k}")), name=f"prior_{k}"))
+    lkw = dict(linearization_kwargs=dict(kernels=kernels)) if kernels is not None else {}
+    cls = th.GaussNewton if gn else th.LevenbergMarquardt
+    opt = cls(obj, max_iterations=iters, step_size=1.0, abs_err_tolerance=0.0, rel_err_tolerance=0.0, **lkw)
+    sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **kw))
+    final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
+    loss = (t(g["coef"]) * final).sum()
+    loss.backward()
+    np.testing.assert_allclose(final.detach().cpu().numpy(), g[f"{tag}_final"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(info.err_history.numpy(), g[f"{tag}_err_history"], rtol=1e-6)
+    assert abs(float(loss.detach()) - float(g[f"{tag}_loss"])) < 1e-9
+    for key in ("meas", "w_between", "prior_target", "w_prior"):
+        got, want = leaves[key].grad.cpu().numpy(), g[f"{tag}_grad_{key}"]
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
+    return info

@@ -85,3 +85,83 @@ class ImplicitStep(torch.autograd.Function):
         K.retract_vjp(t.poses, ctx.delta, ctx.step, grad_x.contiguous(), gd)
         w = solver.solve_with_factor(gd)  # the backward linear solve
         return (None, None, None) + pg_vjp_grads(K, packed, t, w)
+
+
+class PGUnrolledIteration(torch.autograd.Function):
+    """One DIFFERENTIATED iteration of an SE3 pose graph (BackwardMode.UNROLL / TRUNCATED,
+    theseus/optimizer/nonlinear/nonlinear_least_squares.py:223-292: the Hessian is part of the graph):
+    ``X_new = X exp(step * delta)``, ``delta = (H(X, theta) + lambda I)^-1 g(X, theta)``.  Forward: the optimizer's own kernels
+    at the detached iterate (assemble, damped factorisation, solves, retraction).  Backward, given grad_X_new (raw 3 x 4 entries):
+    thx_se3_retract_vjp -> grad_delta; Compose.backward's plain matrix rule -> the direct path to grad_X; one thx_chol_solve with a
+    COPY of this iteration's factor -> w; thx_pg_unroll_vjp(w, delta) -> the per-cost gradients of phi = -(J w).(r + J delta)
+    w.r.t. both poses, the measurement / target and the weights (include/theseus_hip.h).  The poses' gradients are summed over
+    each pose's incident costs in a fixed order (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, opt, packed, frozen, kwargs, X, meas, w_between, prior_target, w_prior):
+        solver = opt.linear_solver
+        lin, K = solver.linearization, packed.K
+        Xd = X.detach().contiguous()
+        t = packed.tensors
+        t.poses = Xd                       # the kernels linearise at the tail loop's iterate
+        lin._assemble()
+        delta = opt.compute_delta(**kwargs)
+        if bool(solver.info.ne(0).any()):
+            try:
+                solver.check_info()
+            except RuntimeError as run_err:
+                raise RuntimeError(f"There was an error while running the linear optimizer. Original error message: {run_err}. "
+                                   "Backward pass will not work. To obtain the best solution seen before the error, run with "
+                                   "torch.no_grad()") from None
+        damped, ellipsoidal, _ = solver._factored_with
+        if damped and ellipsoidal:
+            raise NotImplementedError("differentiating through the iterations of a pose graph: ellipsoidal damping puts "
+                                      "lambda diag(H) into the graph, which thx_pg_unroll_vjp does not cover; use "
+                                      "ellipsoidal_damping=False (the reference's default) or backward_mode='implicit'.")
+        step = float(opt.params.step_size)
+        mask = frozen.to(torch.uint8).contiguous() if frozen is not None else None
+        X_new = torch.empty_like(Xd)
+        K.retract(Xd, delta, step, mask, X_new)
+        ctx.packed, ctx.step, ctx.frozen, ctx.n = packed, step, frozen, lin.n
+        ctx.tensors = detached_tensors(t, Xd, meas, w_between, prior_target, w_prior, None, None)
+        ctx.L, ctx.panels = solver.L.clone(), solver.panels.clone()   # (later iterations overwrite the solver's factor)
+        ctx.delta = delta.detach().clone()
+        ctx.mark_non_differentiable(delta)
+        return X_new, delta
+
+    @staticmethod
+    def backward(ctx, G, _grad_delta):
+        packed, t, K, n, step = ctx.packed, ctx.tensors, ctx.packed.K, ctx.n, ctx.step
+        X, delta = t.poses, ctx.delta
+        P, B = X.shape[:2]
+        dt, dev = X.dtype, X.device
+        G = G.contiguous()
+        gd = torch.empty(B, n, dtype=dt, device=dev)
+        K.retract_vjp(X, delta, step, G, gd)
+        # Compose.backward w.r.t. the left factor (se3_impl.py:739-747): [G_R E_R^T + G_t E_t^T | G_t], E = exp(step * delta)
+        E = K.se3_exp((step * delta).view(B, P, 6).transpose(0, 1).reshape(P * B, 6).contiguous()).view(P, B, 3, 4)
+        GX = torch.cat([G[..., :3] @ E[..., :3].transpose(-1, -2) + G[..., 3:] @ E[..., 3:].transpose(-1, -2), G[..., 3:]], -1)
+        if ctx.frozen is not None:           # frozen problems: X_new = X
+            fz = ctx.frozen.bool()
+            gd = gd * (~fz).to(dt).view(-1, 1)
+            GX = torch.where(fz.view(1, B, 1, 1), G, GX)
+        w = torch.empty_like(gd)
+        K.chol_solve(ctx.L, n, ctx.panels, gd.contiguous(), w)
+        s = packed.structure
+        E_, Kp = s.num_edges, s.num_priors
+        new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
+        gpi, gpj, gm, gwb = new(max(E_, 1), B, 3, 4), new(max(E_, 1), B, 3, 4), new(max(E_, 1), B, 3, 4), new(max(E_, 1), B, 6)
+        gpp, gt, gwp = new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 6)
+        K.pg_unroll_vjp(packed.dstruct, t, w, delta, gpi, gpj, gm, gwb, gpp, gt, gwp)
+        # every pose's incident costs, in a fixed order: rows of [gpi ; gpj ; gpp ; 0]
+        inc = packed.unroll_incidence(dev)
+        src = torch.cat([gpi[:E_], gpj[:E_], gpp[:Kp], new(1, B, 3, 4)], 0)
+        GX = GX + src[inc].sum(1)
+
+        def fit(g, count, like):   # (count, B, ...) -> the packed input's shape (count, 1|B, ...)
+            if like is None:
+                return None
+            g = g[:count]
+            return g.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else g
+        return (None, None, None, None, GX, fit(gm, E_, t.meas), fit(gwb, E_, t.w_between), fit(gt, Kp, t.prior_target),
+                fit(gwp, Kp, t.w_prior))

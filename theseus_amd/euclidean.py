@@ -290,6 +290,12 @@ class PackedEuclidean:
                     H[:, ca:ca + da, cb:cb + db] = H[:, ca:ca + da, cb:cb + db] + J[sa].transpose(1, 2) @ J[sb]
         return H, g
 
+    def prepare_unroll(self):
+        pass   # (the blocks are evaluated by torch at every differentiated iteration: nothing to re-pack)
+
+    def where_state(self, mask: torch.Tensor, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        return torch.where(mask.view(-1, 1), a, b)
+
     def unrolled_step(self, opt, X: torch.Tensor, frozen: Optional[torch.Tensor], kwargs):
         """X -> (X + step * delta where not ``frozen``, delta): the blocks are evaluated at X with the graph, the kernels get
         their detached values (what ``compute_delta`` factorises and LM's accept test reads), the solve is the autograd node."""

@@ -239,11 +239,12 @@ class NonlinearLeastSquares(abc.ABC):
         # Jacobian are needed.  The generic path has them (its blocks come from torch: theseus_amd/euclidean.py); the fused
         # pose-graph / bundle-adjustment kernels do not.
         unrolled = backward_mode in (BackwardMode.UNROLL, BackwardMode.TRUNCATED) and outer_grad and self._needs_grad()
-        if unrolled and getattr(packed, "group", None) != "Euclidean":
+        if unrolled and not hasattr(packed, "unrolled_step"):
             raise NotImplementedError(
-                f"Differentiating through the iterations (backward_mode='{backward_mode.name.lower()}') is not supported by the "
-                "fused HIP path: the kernels are outside autograd.  Use backward_mode='implicit' (one backward linear "
-                "solve with the cached factor), or call under torch.no_grad().")
+                f"Differentiating through the iterations (backward_mode='{backward_mode.name.lower()}') is fused for generic "
+                f"(Euclidean) objectives and SE3 pose graphs, not for {getattr(packed, 'group', type(packed).__name__)} objectives: "
+                "the kernels are outside autograd.  Use backward_mode='implicit' (one backward linear solve with the cached "
+                "factor), or call under torch.no_grad().")
         if unrolled and (track_best_solution or track_state_history or isinstance(self, TrustRegion)):
             raise NotImplementedError("differentiable iterations on the generic path: Gauss-Newton / Levenberg-Marquardt, without "
                                       "track_best_solution / track_state_history.")
@@ -517,6 +518,8 @@ class NonlinearLeastSquares(abc.ABC):
             #      (nonlinear_optimizer.py:220-266).  Host-synchronous: these are a handful of small iterations. ----
             if tail_iters > 0 and not (info.status == NonlinearOptimizerStatus.FAIL).any():
                 packed.flush_variables()
+                with torch.set_grad_enabled(outer_grad):
+                    packed.prepare_unroll()
                 X = packed.state.detach()
                 g_conv = torch.zeros(B, dtype=torch.bool, device=dev)
                 g_conv_iter = torch.zeros(B, dtype=torch.long, device=dev)   # the reference's counter: += 1 while not converged
@@ -534,7 +537,7 @@ class NonlinearLeastSquares(abc.ABC):
                             if attempts < self._MAX_ALL_REJECT_ATTEMPTS:
                                 continue
                         with torch.set_grad_enabled(outer_grad):
-                            X_cand = torch.where(rb.view(-1, 1), X, X_cand)
+                            X_cand = packed.where_state(rb, X, X_cand)
                         err = torch.where(rb, g_last, err_new)
                     else:
                         err = err_new

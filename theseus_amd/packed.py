@@ -361,6 +361,45 @@ class PackedPoseGraph:
         if self._vars_stale and self.tensors is not None:
             self._repoint_variables()
 
+    # ---- BackwardMode.UNROLL / TRUNCATED (theseus_amd/autograd.py:PGUnrolledIteration) ---------------------------------------
+    def prepare_unroll(self):
+        """Before the differentiable tail loop: re-pack the auxiliary tensors WITH their autograd history (once)."""
+        if self.group != "SE3" or self.robust_between or self.robust_prior:
+            raise NotImplementedError(
+                "Differentiating through the iterations (backward_mode='unroll' / 'truncated') is fused for SE3 pose graphs "
+                f"without robust cost functions (got {self.group}" + (", robust costs" if self.robust_between or self.robust_prior else "")
+                + ").  Use backward_mode='implicit' (one backward linear solve with the cached factor), or call under "
+                "torch.no_grad().")
+        self.flush_variables()
+        self.sync(force=True)
+
+    def unrolled_step(self, opt, X: torch.Tensor, frozen: Optional[torch.Tensor], kwargs):
+        """X -> (X exp(step * delta) where not ``frozen``, delta) as ONE autograd node over the kernels."""
+        from .autograd import PGUnrolledIteration
+        t = self.tensors
+        return PGUnrolledIteration.apply(opt, self, frozen, kwargs, X, t.meas, t.w_between, t.prior_target, t.w_prior)
+
+    def where_state(self, mask: torch.Tensor, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        """Per problem: ``a`` where ``mask`` else ``b`` (differentiable torch select on (P, B, ...) states)."""
+        return torch.where(mask.view(1, -1, *([1] * (a.dim() - 2))), a, b)
+
+    def unroll_incidence(self, device) -> torch.Tensor:
+        """(P, Dmax) rows of [grad_pose_i (E) ; grad_pose_j (E) ; grad_pose_prior (K) ; zero row] that belong to each pose."""
+        key = ("unroll_inc", str(device))
+        if key not in self._scratch:
+            s = self.structure
+            E, Kp = s.num_edges, s.num_priors
+            rows = [[] for _ in range(s.num_poses)]
+            for e in range(E):
+                rows[int(s.edge_i[e])].append(e)
+                rows[int(s.edge_j[e])].append(E + e)
+            for k in range(Kp):
+                rows[int(s.prior_pose[k])].append(2 * E + k)
+            dmax = max(1, max(len(r) for r in rows))
+            pad = 2 * E + Kp
+            self._scratch[key] = torch.tensor([r + [pad] * (dmax - len(r)) for r in rows], dtype=torch.long, device=device)
+        return self._scratch[key]
+
     # ---- optimisation state: what the LM loop moves around (here: the packed pose buffer) --------------
     @property
     def state(self):
