@@ -680,3 +680,47 @@ def test_reference_loop_differentiates_through_the_plugin_on_generic_objectives(
         want = r(key)
         np.testing.assert_allclose(leaf.grad.numpy(), want, rtol=0, atol=1e-9 * np.abs(want).max(), err_msg=key)
     np.testing.assert_allclose(info.err_history.numpy(), r("err"), rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc"])
+def test_reference_loop_differentiates_through_the_plugin_on_se3_pose_graphs(ref, tag):
+    """backward_mode "unroll" / "truncated" on an SE3 pose graph through the REAL loop with the FUSED path behind it: the
+    reference linearizes with the Hessian in the graph (nonlinear_least_squares.py:100-135); the plugin assembles H, g with the
+    kernels and makes solve() one autograd node over the packed poses and the auxiliary tensors (_FusedUnrolledSolve:
+    thx_pg_unroll_vjp + a copy of each iteration's factor); retraction and error evaluation in between are the reference's own
+    differentiable ops.  Gradients against the reference's own dense run (tests/golden/pg_f64_unrolled.npz)."""
+    import ast
+    th, thp = ref
+    g = load_golden("pg_f64_unrolled")
+    dtype = torch.float64
+    t = lambda a: torch.from_numpy(a).to(DEVICE)  # noqa: E731
+    kw = ast.literal_eval(str(g[f"{tag}_kwargs"]))
+    mode, iters, gn = kw.pop("mode"), kw.pop("max_iterations"), kw.pop("gauss_newton")
+    P = int(g["P"])
+    meas, wb = t(g["meas"]).requires_grad_(True), t(g["w_between"]).requires_grad_(True)
+    tgt, wp = t(g["prior_target"]).requires_grad_(True), t(g["w_prior"])[:, :, :1].clone().requires_grad_(True)
+    obj = th.Objective(dtype=dtype)
+    poses = [th.SE3(tensor=t(g["poses0"])[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    for k in range(g["edges"].shape[0]):
+        i, j = g["edges"][k].tolist()
+        obj.add(th.Between(poses[i], poses[j], th.SE3(tensor=meas[:, k], name=f"meas_{k}"),
+                           th.DiagonalCostWeight(th.Variable(wb[:, k], name=f"w_{k}")), name=f"between_{k}"))
+    for k in range(g["prior_idx"].shape[0]):
+        obj.add(th.Difference(poses[int(g["prior_idx"][k])], th.SE3(tensor=tgt[:, k], name=f"prior_target_{k}"),
+                              th.ScaleCostWeight(th.Variable(wp[:, k], name=f"pw_{k}")), name=f"prior_{k}"))
+    cls = th.GaussNewton if gn else th.LevenbergMarquardt
+    opt = cls(obj, linear_solver_cls=thp.HipCholeskySolver, linearization_cls=thp.HipLinearization, linearization_kwargs=_kernels(),
+              vectorize=True, max_iterations=iters, step_size=1.0, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    assert opt.linear_solver.linearization.fused
+    layer = th.TheseusLayer(opt)
+    if DEVICE != "cpu":
+        layer.to(DEVICE)
+    sol, info = layer.forward(optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **kw))
+    final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
+    loss = (t(g["coef"]) * final).sum()
+    loss.backward()
+    np.testing.assert_allclose(final.detach().cpu().numpy(), g[f"{tag}_final"], rtol=0, atol=1e-9)
+    assert abs(float(loss.detach()) - float(g[f"{tag}_loss"])) < 1e-9
+    for leaf, key in ((meas, "meas"), (wb, "w_between"), (tgt, "prior_target"), (wp, "w_prior")):
+        want = g[f"{tag}_grad_{key}"]
+        np.testing.assert_allclose(leaf.grad.cpu().numpy(), want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)

@@ -118,6 +118,55 @@ class _UnrolledFactorSolve(torch.autograd.Function):
         return None, None, None, None, grad_H, w
 
 
+class _FusedUnrolledSolve(torch.autograd.Function):
+    """delta = (H(X, theta) + lambda I)^-1 g(X, theta) of an SE3 pose graph as a differentiable function of the packed poses AND the
+    auxiliary tensors -- ``backward_mode="unroll"`` / ``"truncated"`` through the REAL loop, which linearizes with
+    ``_detach_hessian=False`` (nonlinear_least_squares.py:100-135).  Forward: the damped factorisation and the solves on the kernels
+    (H, g were assembled by ``linearize()`` at the detached values).  Backward: w = one solve with a COPY of this call's factor,
+    then ``thx_pg_unroll_vjp`` (include/theseus_hip.h; theseus_amd/autograd.py:PGUnrolledIteration is the same node plus the
+    retraction, for theseus_amd's own loop).  The retraction and the error evaluation in between are the reference's own
+    differentiable ops."""
+
+    @staticmethod
+    def forward(ctx, solver, damping, ellipsoidal, eps, poses, meas, w_between, prior_target, w_prior):
+        lin = solver.linearization
+        packed = lin.packed
+        y = solver.factorize(damping, ellipsoidal, eps, rhs=lin.g)
+        delta = torch.empty_like(y)
+        solver._substitute(y, delta, backward_only=True)
+        solver.check_info()
+        if damping is not None and ellipsoidal:
+            raise NotImplementedError("theseus_amd plugin: differentiating through the iterations of a pose graph with ellipsoidal "
+                                      "damping (lambda diag(H) in the graph) is not fused; use ellipsoidal_damping=False or "
+                                      "backward_mode='implicit'.")
+        ctx.packed, ctx.n = packed, lin.n
+        ctx.tensors = detached_tensors(packed.tensors, poses, meas, w_between, prior_target, w_prior, None, None)
+        ctx.L, ctx.panels = solver.L.clone(), solver.panels.clone()
+        ctx.delta = delta.clone()
+        return delta
+
+    @staticmethod
+    def backward(ctx, grad_delta):
+        packed, t, K = ctx.packed, ctx.tensors, ctx.packed.K
+        P, B = t.poses.shape[:2]
+        dt, dev = t.poses.dtype, t.poses.device
+        w = torch.empty_like(ctx.delta)
+        K.chol_solve(ctx.L, ctx.n, ctx.panels, grad_delta.contiguous(), w)
+        st = packed.structure
+        E, Kp = st.num_edges, st.num_priors
+        new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
+        gpi, gpj, gm, gwb = new(max(E, 1), B, 3, 4), new(max(E, 1), B, 3, 4), new(max(E, 1), B, 3, 4), new(max(E, 1), B, 6)
+        gpp, gt, gwp = new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 6)
+        K.pg_unroll_vjp(packed.dstruct, t, w, ctx.delta, gpi, gpj, gm, gwb, gpp, gt, gwp)
+        GX = torch.cat([gpi[:E], gpj[:E], gpp[:Kp], new(1, B, 3, 4)], 0)[packed.unroll_incidence(dev)].sum(1)
+
+        def fit(g, count, like):
+            g = g[:count]
+            return g.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else g
+        return (None, None, None, None, GX, fit(gm, E, t.meas), fit(gwb, E, t.w_between), fit(gt, Kp, t.prior_target),
+                fit(gwp, Kp, t.w_prior))
+
+
 class _HipRetract(torch.autograd.Function):
     """X_new = X exp(delta) on the packed pose buffer (thx_se3_retract / thx_se2_retract), differentiable w.r.t. delta:
     the backward is thx_se3_retract_vjp / thx_se2_retract_vjp.  (X itself is the detached iterate of the no-grad loop.)"""
@@ -452,6 +501,16 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
         else:
             packed = self.packed
             graph = torch.is_grad_enabled() and any(v.tensor.requires_grad for v in packed.tracked_list())
+            self._unroll = None
+            if graph and not _detach_hessian:
+                # backward_mode "unroll" / "truncated": the Hessian is part of the graph.  SE3 pose graphs: H and g are assembled
+                # at the detached values, solve() becomes ONE autograd node over (poses, auxiliary tensors) -- _FusedUnrolledSolve
+                packed.prepare_unroll()      # (refuses SE2 / SO3 / robust costs; re-packs poses and auxiliary tensors WITH history)
+                t = packed.tensors
+                self._g_graph = None
+                self._assemble()
+                self._unroll = (t.poses, t.meas, t.w_between, t.prior_target, t.w_prior)
+                return
             if graph:
                 packed.sync(force=True)  # re-pack WITH the autograd history of the auxiliary variables
                 t = packed.tensors
@@ -589,6 +648,10 @@ class HipCholeskySolver(HipCholeskyCore, _RefCholeskyDenseSolver):
         lin = self.linearization
         if not isinstance(lin, HipLinearization) or lin._ext_AtA is not None or lin._ext_Atb is not None:
             return self._solve_tensor_system(lin.AtA, lin.Atb, damping, ellipsoidal_damping, damping_eps)
+        if getattr(lin, "_unroll", None) is not None and torch.is_grad_enabled():
+            if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
+                raise ValueError("Damping must be a float or a 1-D tensor.")
+            return _FusedUnrolledSolve.apply(self, damping, ellipsoidal_damping, damping_eps, *lin._unroll)
         g = lin._g_graph
         if g is not None and torch.is_grad_enabled():
             if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
