@@ -897,6 +897,24 @@ def main():
         leg("implicit_b1024", lambda: pg_run(variant(implicit=True, batch=min(1024, args.batch), sparse_leg=False,
                                                      cpu_sample=min(args.cpu_sample, 2), parity_sample=min(args.parity_sample, 8)),
                                              ctx))
+    if os.environ.get("THX_REFERENCE_ROOT") and world == 1 and not standin and ("dropin" in legs or args.legs == "auto"):
+        # the DROP-IN on hardware: the REAL theseus loop (its Objective / LevenbergMarquardt / TheseusLayer) with theseus_amd.plugin
+        # behind it on the headline workload, next to theseus_amd's own loop on the same inputs (tools/dropin_bench.py; only where
+        # a copy of the reference is importable: tools/dropin_gpu.sh stages one for a single gpurun call)
+        def dropin():
+            import subprocess
+            out = {}
+            for tag, extra in (("checked", []), ("lagged_failure_check", ["--lagged"])):
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dropin_bench.py"), "--steps", "10", *extra],
+                                   capture_output=True, text=True, timeout=600)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                out[tag] = json.loads(line[-1]) if line else {"error": r.stderr[-400:]}
+            best = out["checked"]
+            return {"metric": "LM iterations/sec through the REAL theseus loop + theseus_amd.plugin", "unit": "problem-iterations/s",
+                    "value": best.get("dropin_problem_iterations_per_s"), "mirror_loop": best.get("mirror_problem_iterations_per_s"),
+                    "fraction_of_mirror_loop": (best["dropin_problem_iterations_per_s"] / best["mirror_problem_iterations_per_s"]
+                                                if "dropin_problem_iterations_per_s" in best else None), "runs": out}
+        leg("dropin_real_theseus_loop", dropin)
     if "simple" in legs and world == 1:
         leg("simple_example_b16", lambda: simple_run(SimpleNamespace(batch=16, points=20, steps=5), ctx))
     if "strong" in legs:

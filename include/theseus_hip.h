@@ -370,17 +370,19 @@ int thx_pg_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, i
 
 /* ---- Differentiating THROUGH the iterations (BackwardMode.UNROLL / TRUNCATED, nonlinear_least_squares.py:223-292; the Hessian is
  *      part of the graph: dense_linearization.py:58-62 without the detach) on SE3 pose graphs.  One differentiated iteration is
- *      delta = (H + lambda I)^-1 g,  X_new = X exp(step * delta).  Its backward, given grad_X_new (raw 3x4 entries):
+ *      delta = (H + D)^-1 g,  X_new = X exp(step * delta).  Its backward, given grad_X_new (raw 3x4 entries):
  *        grad_delta = thx_se3_retract_vjp(grad_X_new);  grad_X += Compose.backward (plain: [G_R E_R^T + G_t E_t^T | G_t])
- *        w          = (H + lambda I)^-1 grad_delta          (thx_chol_solve with a COPY of that iteration's factor)
+ *        w          = (H + D)^-1 grad_delta                 (thx_chol_solve with a COPY of that iteration's factor)
  *        thx_pg_unroll_vjp(w, delta): per cost, the gradient of  phi = -(J w) . (r + J delta)  -- i.e. of w^T g - w^T H delta with
  *        w, delta constant -- w.r.t. the raw entries of BOTH poses (grad_pose_i / grad_pose_j (E,B,3,4): the host adds them to
  *        the poses' gradients in a fixed order), of the measurement (E,B,3,4) and the weights (E,B,6); priors: grad_pose_prior /
  *        grad_prior_target (K,B,3,4), grad_w_prior (K,B,6).  Same autograd conventions as thx_pg_vjp (log: passthrough backward;
- *        inverse / compose / adjoint / Jlog: plain).  Robust costs and ellipsoidal damping are refused (lambda diag(H) would add
- *        a third term).  w, delta: (B, n), row strides ldw / ldd. */
+ *        inverse / compose / adjoint / Jlog: plain).  ``ellipsoidal_damping``: NULL for D = lambda I (constant), or the (B) vector
+ *        lambda of D = lambda diag(H) + eps (dense_solver.py:38-64) -- phi then has the third term -lambda sum_i w_i delta_i
+ *        H_ii, H_ii = the cost's sum of squared (weighted) Jacobian entries of column i.  Robust costs are refused.
+ *        w, delta: (B, n), row strides ldw / ldd. */
 int thx_pg_unroll_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, int64_t ldw, const void* delta, int64_t ldd,
-                      void* grad_pose_i, void* grad_pose_j, void* grad_meas, void* grad_w_between, void* grad_pose_prior,
+                      const void* ellipsoidal_damping, void* grad_pose_i, void* grad_pose_j, void* grad_meas, void* grad_w_between, void* grad_pose_prior,
                       void* grad_prior_target, void* grad_w_prior, int dtype, const thx_lie_eps* eps, void* stream);
 
 /* ---- Bundle adjustment (BASELINE.json configs[3]; examples/bundle_adjustment.py:103-160): camera poses SE3 + Point3

@@ -626,7 +626,9 @@ def gen_pg_unrolled(th, lieF):
     dtype = torch.float64
     cases = (("gn_unroll", th.GaussNewton, "unroll", 3, {}),
              ("lm_unroll", th.LevenbergMarquardt, "unroll", 4, dict(damping=0.05, adaptive_damping=True)),
-             ("lm_trunc", th.LevenbergMarquardt, "truncated", 5, dict(damping=0.02, backward_num_iterations=2)))
+             ("lm_trunc", th.LevenbergMarquardt, "truncated", 5, dict(damping=0.02, backward_num_iterations=2)),
+             # ellipsoidal damping: lambda diag(H) + eps is part of the graph (dense_solver.py:38-64)
+             ("lm_ellips_unroll", th.LevenbergMarquardt, "unroll", 4, dict(damping=0.05, adaptive_damping=True, ellipsoidal_damping=True)))
     out = {}
     d = make_problem(dtype=dtype, th=th, lieF=lieF, P=6, E=10, B=3, seed=51, batched_weights=True, pose_noise=(0.2, 0.15))
     B, P = d["poses"].shape[:2]

@@ -361,7 +361,7 @@ class OracleKernels:
             if leaf.shape[1] > 0:
                 out[:leaf.shape[1]].copy_((g if g is not None else torch.zeros_like(leaf)).transpose(0, 1))
 
-    def pg_unroll_vjp(self, s, t, w, delta, g_pose_i, g_pose_j, g_meas, g_wb, g_pose_p, g_tgt, g_wp, poses=None):
+    def pg_unroll_vjp(self, s, t, w, delta, g_pose_i, g_pose_j, g_meas, g_wb, g_pose_p, g_tgt, g_wp, poses=None, ell_damping=None):
         """thx_pg_unroll_vjp: per cost, the gradient of phi = -(J w) . (r + J delta) by torch autograd through the oracle's
         Between / Local formulas (which carry the reference's autograd conventions)."""
         p, x = self._problem(s, t, poses)
@@ -380,9 +380,14 @@ class OracleKernels:
             if E:
                 J0, J1, eb = opg.between_jac_err(v0, v1, meas, wb, p.G)
                 phi = phi - ((mv(J0, blk(w, i)) + mv(J1, blk(w, j))) * (eb + mv(J0, blk(delta, i)) + mv(J1, blk(delta, j)))).sum()
+                if ell_damping is not None:   # ellipsoidal damping: -lambda sum_i w_i delta_i H_ii
+                    lam = ell_damping.view(B, 1, 1)
+                    phi = phi - (lam * ((J0 ** 2).sum(-2) * blk(w, i) * blk(delta, i) + (J1 ** 2).sum(-2) * blk(w, j) * blk(delta, j))).sum()
             if Kp:
                 Jp, ep = opg.local_jac_err(tgt, vp, wp, p.G)
                 phi = phi - (mv(Jp, blk(w, p.prior_idx)) * (ep + mv(Jp, blk(delta, p.prior_idx)))).sum()
+                if ell_damping is not None:
+                    phi = phi - (ell_damping.view(B, 1, 1) * (Jp ** 2).sum(-2) * blk(w, p.prior_idx) * blk(delta, p.prior_idx)).sum()
             leaves = [v0, v1, meas, wb, vp, tgt, wp]
             grads = torch.autograd.grad(phi, leaves, allow_unused=True)
         for out, g, leaf in zip((g_pose_i, g_pose_j, g_meas, g_wb, g_pose_p, g_tgt, g_wp), grads, leaves):

@@ -340,7 +340,7 @@ def test_mixed_robust_objective_matches_reference(name):
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
 
 
-@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc"])
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll"])
 def test_unrolled_gradients_of_a_pose_graph_match_reference(tag):
     """BackwardMode.UNROLL / TRUNCATED on an SE3 pose graph (the Hessian is part of the graph,
     nonlinear_least_squares.py:222-282): torch autograd THROUGH the oracle's loop reproduces the REAL reference's gradients

@@ -682,7 +682,7 @@ def test_reference_loop_differentiates_through_the_plugin_on_generic_objectives(
     np.testing.assert_allclose(info.err_history.numpy(), r("err"), rtol=1e-6)
 
 
-@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc"])
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll"])
 def test_reference_loop_differentiates_through_the_plugin_on_se3_pose_graphs(ref, tag):
     """backward_mode "unroll" / "truncated" on an SE3 pose graph through the REAL loop with the FUSED path behind it: the
     reference linearizes with the Hessian in the graph (nonlinear_least_squares.py:100-135); the plugin assembles H, g with the

@@ -38,8 +38,9 @@ def _rand_pose(gen, scale_t, scale_r):
 EPS64 = np.array([lie.EPS[torch.float64][k] for k in ("near_zero", "d_near_zero", "near_pi")])
 
 
+@pytest.mark.parametrize("lam", [0.0, 0.37])     # (> 0: ellipsoidal damping's term -lambda sum_i w_i delta_i H_ii)
 @pytest.mark.parametrize("seed,scale_r", [(0, 1.0), (1, 2.5), (2, 0.3), (3, 1e-3)])   # (1e-3: the near-zero Taylor branches)
-def test_between_cost_unrolled_vjp_matches_autograd_through_the_oracle(hostmath, seed, scale_r):
+def test_between_cost_unrolled_vjp_matches_autograd_through_the_oracle(hostmath, seed, scale_r, lam):
     gen = torch.Generator().manual_seed(seed)
     Xi, Xj = _rand_pose(gen, 2.0, 1.5), _rand_pose(gen, 2.0, 1.5)
     D = lie.se3_compose(lie.se3_inverse(Xi), Xj)
@@ -49,17 +50,20 @@ def test_between_cost_unrolled_vjp_matches_autograd_through_the_oracle(hostmath,
     leaves = [t.clone().requires_grad_(True) for t in (Xi, Xj, Z, s)]
     J0, J1, e = opg.between_jac_err(leaves[0], leaves[1], leaves[2], leaves[3])
     phi = -((J0 @ wi + J1 @ wj) * (e + J0 @ di + J1 @ dj)).sum()
+    phi = phi - lam * (((J0 ** 2).sum(0) * wi * di).sum() + ((J1 ** 2).sum(0) * wj * dj).sum())   # -lambda sum_i w_i delta_i (J^T J)_ii
     phi.backward()
     out = np.zeros(42)
+    hostmath.hm_edge_vjp.argtypes = [ctypes.POINTER(ctypes.c_double)] * 9 + [ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
     hostmath.hm_edge_vjp(*(_ptr(np.ascontiguousarray(t.detach().numpy().reshape(-1))) for t in (Xi, Xj, Z, s, wi, wj, di, dj)),
-                         _ptr(EPS64), _ptr(out))
+                         _ptr(EPS64), lam, _ptr(out))
     for k, (name, sl) in enumerate((("Xi", slice(0, 12)), ("Xj", slice(12, 24)), ("Z", slice(24, 36)), ("s", slice(36, 42)))):
         want = leaves[k].grad.numpy().reshape(-1)
         np.testing.assert_allclose(out[sl], want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()), err_msg=name)
 
 
+@pytest.mark.parametrize("lam", [0.0, 0.37])
 @pytest.mark.parametrize("seed,scale_r", [(0, 1.0), (1, 1e-3)])
-def test_prior_cost_unrolled_vjp_matches_autograd_through_the_oracle(hostmath, seed, scale_r):
+def test_prior_cost_unrolled_vjp_matches_autograd_through_the_oracle(hostmath, seed, scale_r, lam):
     gen = torch.Generator().manual_seed(10 + seed)
     X = _rand_pose(gen, 2.0, 1.5)
     T = lie.se3_compose(X, _rand_pose(gen, 0.2 * scale_r, scale_r))
@@ -67,10 +71,12 @@ def test_prior_cost_unrolled_vjp_matches_autograd_through_the_oracle(hostmath, s
     w, d = (torch.randn(6, dtype=torch.float64, generator=gen) for _ in range(2))
     leaves = [t.clone().requires_grad_(True) for t in (X, T, s)]
     J, e = opg.local_jac_err(leaves[1], leaves[0], leaves[2])
-    phi = -((J @ w) * (e + J @ d)).sum()
+    phi = -((J @ w) * (e + J @ d)).sum() - lam * ((J ** 2).sum(0) * w * d).sum()
     phi.backward()
     out = np.zeros(30)
-    hostmath.hm_prior_vjp(*(_ptr(np.ascontiguousarray(t.detach().numpy().reshape(-1))) for t in (X, T, s, w, d)), _ptr(EPS64), _ptr(out))
+    hostmath.hm_prior_vjp.argtypes = [ctypes.POINTER(ctypes.c_double)] * 6 + [ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    hostmath.hm_prior_vjp(*(_ptr(np.ascontiguousarray(t.detach().numpy().reshape(-1))) for t in (X, T, s, w, d)), _ptr(EPS64), lam,
+                          _ptr(out))
     for k, (name, sl) in enumerate((("X", slice(0, 12)), ("T", slice(12, 24)), ("s", slice(24, 30)))):
         want = leaves[k].grad.numpy().reshape(-1)
         np.testing.assert_allclose(out[sl], want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()), err_msg=name)

@@ -94,6 +94,7 @@ class PGUnrolledIteration(torch.autograd.Function):
     at the detached iterate (assemble, damped factorisation, solves, retraction).  Backward, given grad_X_new (raw 3 x 4 entries):
     thx_se3_retract_vjp -> grad_delta; Compose.backward's plain matrix rule -> the direct path to grad_X; one thx_chol_solve with a
     COPY of this iteration's factor -> w; thx_pg_unroll_vjp(w, delta) -> the per-cost gradients of phi = -(J w).(r + J delta)
+    [- lambda sum_i w_i delta_i H_ii with ellipsoidal damping]
     w.r.t. both poses, the measurement / target and the weights (include/theseus_hip.h).  The poses' gradients are summed over
     each pose's incident costs in a fixed order (no atomics)."""
 
@@ -114,10 +115,7 @@ class PGUnrolledIteration(torch.autograd.Function):
                                    "Backward pass will not work. To obtain the best solution seen before the error, run with "
                                    "torch.no_grad()") from None
         damped, ellipsoidal, _ = solver._factored_with
-        if damped and ellipsoidal:
-            raise NotImplementedError("differentiating through the iterations of a pose graph: ellipsoidal damping puts "
-                                      "lambda diag(H) into the graph, which thx_pg_unroll_vjp does not cover; use "
-                                      "ellipsoidal_damping=False (the reference's default) or backward_mode='implicit'.")
+        ctx.ell = solver._lam.clone() if (damped and ellipsoidal) else None   # D = lambda diag(H) + eps: lambda diag(H) is in the graph
         step = float(opt.params.step_size)
         mask = frozen.to(torch.uint8).contiguous() if frozen is not None else None
         X_new = torch.empty_like(Xd)
@@ -152,7 +150,7 @@ class PGUnrolledIteration(torch.autograd.Function):
         new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
         gpi, gpj, gm, gwb = new(max(E_, 1), B, 3, 4), new(max(E_, 1), B, 3, 4), new(max(E_, 1), B, 3, 4), new(max(E_, 1), B, 6)
         gpp, gt, gwp = new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 6)
-        K.pg_unroll_vjp(packed.dstruct, t, w, delta, gpi, gpj, gm, gwb, gpp, gt, gwp)
+        K.pg_unroll_vjp(packed.dstruct, t, w, delta, gpi, gpj, gm, gwb, gpp, gt, gwp, ell_damping=ctx.ell)
         # every pose's incident costs, in a fixed order: rows of [gpi ; gpj ; gpp ; 0]
         inc = packed.unroll_incidence(dev)
         src = torch.cat([gpi[:E_], gpj[:E_], gpp[:Kp], new(1, B, 3, 4)], 0)

@@ -2,10 +2,12 @@
 // reference differentiates THROUGH every iteration delta = (H + D)^-1 g, H = A^T A and g = A^T b both in the graph.  With
 // w = (H + D)^-1 dL/d delta (one solve with that iteration's factor) the iteration's contribution to every gradient is the
 // gradient of the SCALAR
-//     psi = w^T g - w^T H delta = - sum_costs (J w)_c . (r_c + (J delta)_c)          (w, delta held constant; D = lambda I)
+//     psi = w^T g - w^T (H + D) delta,   D = lambda I (spherical: constant) or lambda diag(H) + eps (ellipsoidal, dense_solver.py:38-64)
+//         = - sum_costs (J w)_c . (r_c + (J delta)_c)  -  [ellipsoidal]  lambda sum_i w_i delta_i H_ii        (w, delta held constant)
 // and, cost by cost (Between: E = Z^-1 Xi^-1 Xj, r = s * log E, J_j = s * Jlog(E), J_i = -s * Jlog(E) Ad((Xi^-1 Xj)^-1)),
 //     phi = - sum_r s_r^2 (Jlog q_w)_r (log(E)_r + (Jlog q_delta)_r),   q_v = v_j - Ad(D^-1) v_i,   D = Xi^-1 Xj
-// (Difference / Local priors: E = T^-1 X, q_v = v).  This header evaluates phi and its derivative along ONE direction of the
+//           - [ellipsoidal] lambda sum_r s_r^2 sum_k ((J_j)_rk^2 w_jk delta_jk + (J_i)_rk^2 w_ik delta_ik)       (H_ii = sum of squares of column i)
+// (Difference / Local priors: E = T^-1 X, q_v = v, one Jacobian).  This header evaluates phi and its derivative along ONE direction of the
 // raw 3 x 4 entries of Xi, Xj, Z in forward mode (Dual<double> through the closed forms of lie.cuh): inverse / compose / adjoint /
 // the Jlog closed forms have plain autograd graphs in the reference, log(E)'s own derivative is torchlie's passthrough backward
 // (se3_impl.py:487-493): d log = Jlog [E_R^T dE_t ; vee(E_R^T dE_R) / 2] -- the convention thx_pg_vjp (vjp_se3.cuh) already
@@ -78,10 +80,29 @@ __device__ __forceinline__ void unroll_log_jlog(const SE3<UD>& E, const Eps<UD>&
   }
 }
 
-// phi of a Between cost (value and directional derivative); a_out / b_out (may be null): (Jlog q_w)_r and log(E)_r + (Jlog q_delta)_r
+// sum_r s_r^2 sum_k M_rk^2 c_k  for the 6 x 6 block M = [[A, B], [0, C]] (rows r, columns k), c = w * delta of one variable
+template <typename S>
+__device__ __forceinline__ S unroll_colsq(const S* A, const S* Bm, const S* C, const double* s, const double* wv, const double* dv) {
+  S acc(0.0);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    S top(0.0), bot(0.0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      top = top + A[3 * r + k] * A[3 * r + k] * S(wv[k] * dv[k]) + Bm[3 * r + k] * Bm[3 * r + k] * S(wv[3 + k] * dv[3 + k]);
+      bot = bot + C[3 * r + k] * C[3 * r + k] * S(wv[3 + k] * dv[3 + k]);
+    }
+    acc = acc + S(s[r] * s[r]) * top + S(s[3 + r] * s[3 + r]) * bot;
+  }
+  return acc;
+}
+
+// phi of a Between cost (value and directional derivative); a_out / b_out (may be null): (Jlog q_w)_r and log(E)_r + (Jlog q_delta)_r;
+// lam != 0: ellipsoidal damping's term; the weight gradient of that term goes to ell_gs (may be null): d/ds_r = 2 s_r (...)_r
 __device__ __forceinline__ UD unroll_edge_phi(const SE3<UD>& Xi, const SE3<UD>& Xj, const SE3<UD>& Z, const double* s,
                                               const double* wi, const double* wj, const double* di, const double* dj,
-                                              const Eps<UD>& eps, double* a_out, double* b_out) {
+                                              const Eps<UD>& eps, double* a_out, double* b_out, double lam = 0.0,
+                                              double* ell_rows = nullptr) {
   SE3<UD> Xii, D, Zi, E, Dinv;
   se3_inv(Xi, Xii);
   se3_mul(Xii, Xj, D);
@@ -102,12 +123,46 @@ __device__ __forceinline__ UD unroll_edge_phi(const SE3<UD>& Xi, const SE3<UD>& 
     if (a_out) a_out[r] = a[r].v;
     if (b_out) b_out[r] = bsum.v;
   }
+  if (lam != 0.0) {
+    // J_j = [[Jr, Jt], [0, Jr]];  J_i = -J_j Ad(Dinv) = -[[Jr R, Jr hat(t) R + Jt R], [0, Jr R]]  (signs drop out of the squares)
+    UD JrR[9], hR[9], JrhR[9], JtR[9], TR[9];
+    mat3_mul(Jr, Dinv.R, JrR);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {   // column k of hat(t) R = t x R[:, k]
+      UD col[3] = {Dinv.R[k], Dinv.R[3 + k], Dinv.R[6 + k]}, cr[3];
+      cross3(Dinv.t, col, cr);
+      hR[k] = cr[0];
+      hR[3 + k] = cr[1];
+      hR[6 + k] = cr[2];
+    }
+    mat3_mul(Jr, hR, JrhR);
+    mat3_mul(Jt, Dinv.R, JtR);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) TR[k] = JrhR[k] + JtR[k];
+    const UD ell = unroll_colsq(Jr, Jt, Jr, s, wj, dj) + unroll_colsq(JrR, TR, JrR, s, wi, di);
+    phi = phi - UD(lam) * ell;
+    if (ell_rows) {   // per-row sums (without s_r^2) for the weight gradient
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        double top = 0.0, bot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          top += Jr[3 * r + k].v * Jr[3 * r + k].v * wj[k] * dj[k] + Jt[3 * r + k].v * Jt[3 * r + k].v * wj[3 + k] * dj[3 + k] +
+                 JrR[3 * r + k].v * JrR[3 * r + k].v * wi[k] * di[k] + TR[3 * r + k].v * TR[3 * r + k].v * wi[3 + k] * di[3 + k];
+          bot += Jr[3 * r + k].v * Jr[3 * r + k].v * wj[3 + k] * dj[3 + k] + JrR[3 * r + k].v * JrR[3 * r + k].v * wi[3 + k] * di[3 + k];
+        }
+        ell_rows[r] = top;
+        ell_rows[3 + r] = bot;
+      }
+    }
+  }
   return phi;
 }
 
 // phi of a Difference / Local prior: E = T^-1 X, J = Jlog(E)
 __device__ __forceinline__ UD unroll_prior_phi(const SE3<UD>& X, const SE3<UD>& T, const double* s, const double* w,
-                                               const double* d, const Eps<UD>& eps, double* a_out, double* b_out) {
+                                               const double* d, const Eps<UD>& eps, double* a_out, double* b_out, double lam = 0.0,
+                                               double* ell_rows = nullptr) {
   SE3<UD> Ti, E;
   se3_inv(T, Ti);
   se3_mul(Ti, X, E);
@@ -128,6 +183,22 @@ __device__ __forceinline__ UD unroll_prior_phi(const SE3<UD>& X, const SE3<UD>& 
     if (a_out) a_out[r] = a[r].v;
     if (b_out) b_out[r] = bsum.v;
   }
+  if (lam != 0.0) {
+    phi = phi - UD(lam) * unroll_colsq(Jr, Jt, Jr, s, w, d);
+    if (ell_rows) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        double top = 0.0, bot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          top += Jr[3 * r + k].v * Jr[3 * r + k].v * w[k] * d[k] + Jt[3 * r + k].v * Jt[3 * r + k].v * w[3 + k] * d[3 + k];
+          bot += Jr[3 * r + k].v * Jr[3 * r + k].v * w[3 + k] * d[3 + k];
+        }
+        ell_rows[r] = top;
+        ell_rows[3 + r] = bot;
+      }
+    }
+  }
   return phi;
 }
 
@@ -145,22 +216,23 @@ __device__ __forceinline__ void unroll_seed(const SE3<double>& X, int k, SE3<UD>
 // Gradients of a Between cost's phi: gXi, gXj, gZ (12 raw entries each), gs (6 weights)
 __device__ __forceinline__ void unroll_edge_vjp(const SE3<double>& Xi, const SE3<double>& Xj, const SE3<double>& Z, const double* s,
                                                 const double* wi, const double* wj, const double* di, const double* dj,
-                                                const Eps<double>& eps, double* gXi, double* gXj, double* gZ, double* gs) {
+                                                const Eps<double>& eps, double* gXi, double* gXj, double* gZ, double* gs,
+                                                double lam = 0.0) {
   const Eps<UD> epsd{UD(eps.nz), UD(eps.dnz), UD(eps.npi)};
   SE3<UD> A, Bv, C;
-  double a[6], b[6];
+  double a[6], b[6], ell[6] = {0, 0, 0, 0, 0, 0};
   unroll_seed(Xi, -1, A);
   unroll_seed(Xj, -1, Bv);
   unroll_seed(Z, -1, C);
-  (void)unroll_edge_phi(A, Bv, C, s, wi, wj, di, dj, epsd, a, b);
+  (void)unroll_edge_phi(A, Bv, C, s, wi, wj, di, dj, epsd, a, b, lam, ell);
 #pragma unroll
-  for (int r = 0; r < 6; ++r) gs[r] = -2.0 * s[r] * a[r] * b[r];
+  for (int r = 0; r < 6; ++r) gs[r] = -2.0 * s[r] * (a[r] * b[r] + lam * ell[r]);
   for (int k = 0; k < 36; ++k) {   // run-time loop: one dual evaluation per raw entry of Xi, Xj, Z
     const int which = k / 12, e = k % 12;
     unroll_seed(Xi, which == 0 ? e : -1, A);
     unroll_seed(Xj, which == 1 ? e : -1, Bv);
     unroll_seed(Z, which == 2 ? e : -1, C);
-    const double g = unroll_edge_phi(A, Bv, C, s, wi, wj, di, dj, epsd, nullptr, nullptr).d;
+    const double g = unroll_edge_phi(A, Bv, C, s, wi, wj, di, dj, epsd, nullptr, nullptr, lam, nullptr).d;
     if (which == 0) gXi[e] = g;
     else if (which == 1) gXj[e] = g;
     else gZ[e] = g;
@@ -168,20 +240,21 @@ __device__ __forceinline__ void unroll_edge_vjp(const SE3<double>& Xi, const SE3
 }
 
 __device__ __forceinline__ void unroll_prior_vjp(const SE3<double>& X, const SE3<double>& T, const double* s, const double* w,
-                                                 const double* d, const Eps<double>& eps, double* gX, double* gT, double* gs) {
+                                                 const double* d, const Eps<double>& eps, double* gX, double* gT, double* gs,
+                                                 double lam = 0.0) {
   const Eps<UD> epsd{UD(eps.nz), UD(eps.dnz), UD(eps.npi)};
   SE3<UD> A, Bv;
-  double a[6], b[6];
+  double a[6], b[6], ell[6] = {0, 0, 0, 0, 0, 0};
   unroll_seed(X, -1, A);
   unroll_seed(T, -1, Bv);
-  (void)unroll_prior_phi(A, Bv, s, w, d, epsd, a, b);
+  (void)unroll_prior_phi(A, Bv, s, w, d, epsd, a, b, lam, ell);
 #pragma unroll
-  for (int r = 0; r < 6; ++r) gs[r] = -2.0 * s[r] * a[r] * b[r];
+  for (int r = 0; r < 6; ++r) gs[r] = -2.0 * s[r] * (a[r] * b[r] + lam * ell[r]);
   for (int k = 0; k < 24; ++k) {
     const int which = k / 12, e = k % 12;
     unroll_seed(X, which == 0 ? e : -1, A);
     unroll_seed(T, which == 1 ? e : -1, Bv);
-    const double g = unroll_prior_phi(A, Bv, s, w, d, epsd, nullptr, nullptr).d;
+    const double g = unroll_prior_phi(A, Bv, s, w, d, epsd, nullptr, nullptr, lam, nullptr).d;
     if (which == 0) gX[e] = g;
     else gT[e] = g;
   }

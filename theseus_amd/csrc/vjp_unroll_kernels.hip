@@ -10,7 +10,7 @@ namespace thx {
 template <typename T>
 __global__ void __launch_bounds__(64)
 pg_unroll_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wvec, int64_t ldw, const T* __restrict__ dvec,
-                     int64_t ldd, T* __restrict__ g_pose_i, T* __restrict__ g_pose_j, T* __restrict__ g_meas,
+                     int64_t ldd, const T* __restrict__ ell_damping, T* __restrict__ g_pose_i, T* __restrict__ g_pose_j, T* __restrict__ g_meas,
                      T* __restrict__ g_wb, T* __restrict__ g_pose_p, T* __restrict__ g_tgt, T* __restrict__ g_wp, Eps<T> eps_t) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   const int c = blockIdx.y;
@@ -21,6 +21,7 @@ pg_unroll_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wv
   const T* wv = wvec + (int64_t)b * ldw;
   const T* dv = dvec + (int64_t)b * ldd;
   double sw[6], gs[6];
+  const double lam = ell_damping ? (double)ell_damping[b] : 0.0;   // ellipsoidal damping: lambda_b (null: spherical / none)
   if (c < s.num_edges) {
     const int e = c, i = s.edge_i[e], j = s.edge_j[e];
     const int64_t mB = d.meas_bstride ? B : 1, wB = d.w_between_bstride ? B : 1;
@@ -38,7 +39,7 @@ pg_unroll_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wv
       dj[k] = (double)dv[6 * j + k];
       sw[k] = (double)wp[k];
     }
-    unroll_edge_vjp(Xi, Xj, Z, sw, wi, wj, di, dj, eps, gXi, gXj, gZ, gs);
+    unroll_edge_vjp(Xi, Xj, Z, sw, wi, wj, di, dj, eps, gXi, gXj, gZ, gs, lam);
     T* oi = g_pose_i + ((int64_t)e * B + b) * 12;
     T* oj = g_pose_j + ((int64_t)e * B + b) * 12;
     T* oz = g_meas + ((int64_t)e * B + b) * 12;
@@ -65,7 +66,7 @@ pg_unroll_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wv
       d6[r] = (double)dv[6 * p + r];
       sw[r] = (double)wp[r];
     }
-    unroll_prior_vjp(X, Tg, sw, w6, d6, eps, gX, gT, gs);
+    unroll_prior_vjp(X, Tg, sw, w6, d6, eps, gX, gT, gs, lam);
     T* ox = g_pose_p + ((int64_t)k0 * B + b) * 12;
     T* ot = g_tgt + ((int64_t)k0 * B + b) * 12;
     T* os = g_wp + ((int64_t)k0 * B + b) * 6;
@@ -86,7 +87,7 @@ using namespace thx;
 extern "C" {
 
 int thx_pg_unroll_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, int64_t ldw, const void* delta, int64_t ldd,
-                      void* grad_pose_i, void* grad_pose_j, void* grad_meas, void* grad_w_between, void* grad_pose_prior,
+                      const void* ellipsoidal_damping, void* grad_pose_i, void* grad_pose_j, void* grad_meas, void* grad_w_between, void* grad_pose_prior,
                       void* grad_prior_target, void* grad_w_prior, int dtype, const thx_lie_eps* eps, void* stream) {
   if (!s || !d || !w || !delta || !eps) return fail("thx_pg_unroll_vjp: null argument");
   if (s->num_edges > 0 && (!grad_pose_i || !grad_pose_j || !grad_meas || !grad_w_between))
@@ -100,11 +101,11 @@ int thx_pg_unroll_vjp(const thx_pg_structure* s, const thx_pg_data* d, const voi
   if (grid.y == 0) return 0;
   THX_DISPATCH(dtype,
                hipLaunchKernelGGL(pg_unroll_vjp_kernel<float>, grid, block, 0, as_stream(stream), *s, *d, (const float*)w, ldw,
-                                  (const float*)delta, ldd, (float*)grad_pose_i, (float*)grad_pose_j, (float*)grad_meas,
+                                  (const float*)delta, ldd, (const float*)ellipsoidal_damping, (float*)grad_pose_i, (float*)grad_pose_j, (float*)grad_meas,
                                   (float*)grad_w_between, (float*)grad_pose_prior, (float*)grad_prior_target, (float*)grad_w_prior,
                                   make_eps<float>(eps)),
                hipLaunchKernelGGL(pg_unroll_vjp_kernel<double>, grid, block, 0, as_stream(stream), *s, *d, (const double*)w, ldw,
-                                  (const double*)delta, ldd, (double*)grad_pose_i, (double*)grad_pose_j, (double*)grad_meas,
+                                  (const double*)delta, ldd, (const double*)ellipsoidal_damping, (double*)grad_pose_i, (double*)grad_pose_j, (double*)grad_meas,
                                   (double*)grad_w_between, (double*)grad_pose_prior, (double*)grad_prior_target,
                                   (double*)grad_w_prior, make_eps<double>(eps)));
   return check_launch("thx_pg_unroll_vjp");

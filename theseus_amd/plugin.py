@@ -135,10 +135,7 @@ class _FusedUnrolledSolve(torch.autograd.Function):
         delta = torch.empty_like(y)
         solver._substitute(y, delta, backward_only=True)
         solver.check_info()
-        if damping is not None and ellipsoidal:
-            raise NotImplementedError("theseus_amd plugin: differentiating through the iterations of a pose graph with ellipsoidal "
-                                      "damping (lambda diag(H) in the graph) is not fused; use ellipsoidal_damping=False or "
-                                      "backward_mode='implicit'.")
+        ctx.ell = solver._lam.clone() if (damping is not None and ellipsoidal) else None   # (lambda diag(H) is in the graph)
         ctx.packed, ctx.n = packed, lin.n
         ctx.tensors = detached_tensors(packed.tensors, poses, meas, w_between, prior_target, w_prior, None, None)
         ctx.L, ctx.panels = solver.L.clone(), solver.panels.clone()
@@ -157,7 +154,7 @@ class _FusedUnrolledSolve(torch.autograd.Function):
         new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
         gpi, gpj, gm, gwb = new(max(E, 1), B, 3, 4), new(max(E, 1), B, 3, 4), new(max(E, 1), B, 3, 4), new(max(E, 1), B, 6)
         gpp, gt, gwp = new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 6)
-        K.pg_unroll_vjp(packed.dstruct, t, w, ctx.delta, gpi, gpj, gm, gwb, gpp, gt, gwp)
+        K.pg_unroll_vjp(packed.dstruct, t, w, ctx.delta, gpi, gpj, gm, gwb, gpp, gt, gwp, ell_damping=ctx.ell)
         GX = torch.cat([gpi[:E], gpj[:E], gpp[:Kp], new(1, B, 3, 4)], 0)[packed.unroll_incidence(dev)].sum(1)
 
         def fit(g, count, like):
