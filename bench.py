@@ -895,7 +895,7 @@ def main():
                                                                      cpu_baseline=args.cpu_sample > 0), ctx))
     if "implicit" in legs and world == 1:
         leg("implicit_b1024", lambda: pg_run(variant(implicit=True, batch=min(1024, args.batch), sparse_leg=False,
-                                                     cpu_sample=min(args.cpu_sample, 2), parity_sample=min(args.parity_sample, 8)),
+                                                     cpu_sample=min(args.cpu_sample, 2), parity_sample=min(args.parity_sample, 4)),
                                              ctx))
     if os.environ.get("THX_REFERENCE_ROOT") and world == 1 and not standin and ("dropin" in legs or args.legs == "auto"):
         # the DROP-IN on hardware: the REAL theseus loop (its Objective / LevenbergMarquardt / TheseusLayer) with theseus_amd.plugin
