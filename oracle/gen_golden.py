@@ -628,7 +628,9 @@ def gen_pg_unrolled(th, lieF):
              ("lm_unroll", th.LevenbergMarquardt, "unroll", 4, dict(damping=0.05, adaptive_damping=True)),
              ("lm_trunc", th.LevenbergMarquardt, "truncated", 5, dict(damping=0.02, backward_num_iterations=2)),
              # ellipsoidal damping: lambda diag(H) + eps is part of the graph (dense_solver.py:38-64)
-             ("lm_ellips_unroll", th.LevenbergMarquardt, "unroll", 4, dict(damping=0.05, adaptive_damping=True, ellipsoidal_damping=True)))
+             ("lm_ellips_unroll", th.LevenbergMarquardt, "unroll", 4, dict(damping=0.05, adaptive_damping=True, ellipsoidal_damping=True)),
+             # convergence tests ON: problems converge (and are frozen) inside the differentiated iterations, the loop stops early
+             ("gn_trunc_conv", th.GaussNewton, "truncated", 6, dict(backward_num_iterations=4, __tol__=5e-6)))
     out = {}
     d = make_problem(dtype=dtype, th=th, lieF=lieF, P=6, E=10, B=3, seed=51, batched_weights=True, pose_noise=(0.2, 0.15))
     B, P = d["poses"].shape[:2]
@@ -649,8 +651,10 @@ def gen_pg_unrolled(th, lieF):
         for k in range(d["prior_idx"].shape[0]):
             obj.add(th.Difference(poses[int(d["prior_idx"][k])], th.SE3(tensor=tgt[:, k], name=f"prior_target_{k}"),
                                   th.ScaleCostWeight(th.Variable(wp[:, k], name=f"pw_{k}")), name=f"prior_{k}"))
+        okw = dict(okw)
+        tol = okw.pop("__tol__", 0.0)
         opt = cls(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, max_iterations=iters, step_size=1.0,
-                  abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+                  abs_err_tolerance=0.0, rel_err_tolerance=tol)
         sol, info = th.TheseusLayer(opt).forward(optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **okw))
         final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
         loss = (coef * final).sum()
@@ -659,6 +663,10 @@ def gen_pg_unrolled(th, lieF):
                     f"{tag}_grad_w_between": wb.grad.numpy(), f"{tag}_grad_prior_target": tgt.grad.numpy(),
                     f"{tag}_grad_w_prior": wp.grad.numpy(), f"{tag}_err_history": info.err_history.numpy(),
                     f"{tag}_kwargs": np.array(repr(dict(okw, max_iterations=iters, mode=mode, gauss_newton=cls is th.GaussNewton)))})
+        if tol:
+            out.update({f"{tag}_rel_tol": tol, f"{tag}_conv": info.converged_iter.numpy(),
+                        f"{tag}_status": np.array([int(s_.value) for s_ in info.status])})
+            print("   converged_iter", info.converged_iter.tolist(), "status", [s_.name for s_ in info.status])
         print("pg_unrolled", tag, "loss", loss.item(), "|grad_meas|", meas.grad.abs().max().item(), info.err_history[0].tolist())
     np.savez_compressed(os.path.join(OUT, "pg_f64_unrolled.npz"), **out)
 

@@ -682,7 +682,7 @@ def test_reference_loop_differentiates_through_the_plugin_on_generic_objectives(
     np.testing.assert_allclose(info.err_history.numpy(), r("err"), rtol=1e-6)
 
 
-@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll"])
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll", "gn_trunc_conv"])
 def test_reference_loop_differentiates_through_the_plugin_on_se3_pose_graphs(ref, tag):
     """backward_mode "unroll" / "truncated" on an SE3 pose graph through the REAL loop with the FUSED path behind it: the
     reference linearizes with the Hessian in the graph (nonlinear_least_squares.py:100-135); the plugin assembles H, g with the
@@ -710,7 +710,8 @@ def test_reference_loop_differentiates_through_the_plugin_on_se3_pose_graphs(ref
                               th.ScaleCostWeight(th.Variable(wp[:, k], name=f"pw_{k}")), name=f"prior_{k}"))
     cls = th.GaussNewton if gn else th.LevenbergMarquardt
     opt = cls(obj, linear_solver_cls=thp.HipCholeskySolver, linearization_cls=thp.HipLinearization, linearization_kwargs=_kernels(),
-              vectorize=True, max_iterations=iters, step_size=1.0, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+              vectorize=True, max_iterations=iters, step_size=1.0, abs_err_tolerance=0.0,
+              rel_err_tolerance=float(g[f"{tag}_rel_tol"]) if f"{tag}_rel_tol" in g else 0.0)
     assert opt.linear_solver.linearization.fused
     layer = th.TheseusLayer(opt)
     if DEVICE != "cpu":
@@ -724,3 +725,5 @@ def test_reference_loop_differentiates_through_the_plugin_on_se3_pose_graphs(ref
     for leaf, key in ((meas, "meas"), (wb, "w_between"), (tgt, "prior_target"), (wp, "w_prior")):
         want = g[f"{tag}_grad_{key}"]
         np.testing.assert_allclose(leaf.grad.cpu().numpy(), want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
+    if f"{tag}_conv" in g:
+        assert info.converged_iter.tolist() == g[f"{tag}_conv"].tolist()

@@ -8,7 +8,7 @@ from tests.helpers import load_golden
 from tests.unrolled_common import run_pg_unrolled
 
 
-@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll"])
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll", "gn_trunc_conv"])
 def test_differentiating_through_the_iterations_of_a_pose_graph(tag):
     import theseus_amd as th
     from tests.oracle_kernels import OracleKernels

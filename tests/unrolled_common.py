@@ -28,7 +28,8 @@ def run_pg_unrolled(th, g, tag, device, kernels=None):
                               th.ScaleCostWeight(th.Variable(leaves["w_prior"][:, k], name=f"pw_{k}")), name=f"prior_{k}"))
     lkw = dict(linearization_kwargs=dict(kernels=kernels)) if kernels is not None else {}
     cls = th.GaussNewton if gn else th.LevenbergMarquardt
-    opt = cls(obj, max_iterations=iters, step_size=1.0, abs_err_tolerance=0.0, rel_err_tolerance=0.0, **lkw)
+    tol = float(g[f"{tag}_rel_tol"]) if f"{tag}_rel_tol" in g else 0.0
+    opt = cls(obj, max_iterations=iters, step_size=1.0, abs_err_tolerance=0.0, rel_err_tolerance=tol, **lkw)
     sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **kw))
     final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
     loss = (t(g["coef"]) * final).sum()
@@ -39,4 +40,7 @@ def run_pg_unrolled(th, g, tag, device, kernels=None):
     for key in ("meas", "w_between", "prior_target", "w_prior"):
         got, want = leaves[key].grad.cpu().numpy(), g[f"{tag}_grad_{key}"]
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
+    if tol:   # problems converge -- and are frozen -- at different differentiated iterations; the loop stops early
+        assert info.converged_iter.tolist() == g[f"{tag}_conv"].tolist()
+        assert [int(s_.value) for s_ in info.status] == g[f"{tag}_status"].tolist()
     return info
