@@ -379,11 +379,14 @@ int thx_pg_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, i
  *        grad_prior_target (K,B,3,4), grad_w_prior (K,B,6).  Same autograd conventions as thx_pg_vjp (log: passthrough backward;
  *        inverse / compose / adjoint / Jlog: plain).  ``ellipsoidal_damping``: NULL for D = lambda I (constant), or the (B) vector
  *        lambda of D = lambda diag(H) + eps (dense_solver.py:38-64) -- phi then has the third term -lambda sum_i w_i delta_i
- *        H_ii, H_ii = the cost's sum of squared (weighted) Jacobian entries of column i.  Robust costs are refused.
+ *        H_ii, H_ii = the cost's sum of squared (weighted) Jacobian entries of column i.  RobustCostFunction (not detached,
+ *        robust_cost_function.py:115-135): Phi = sum_r m_r phi_r with m_r = rho'(x_r) + eps, every loss code of thx_pg_data;
+ *        grad_log_radius_between (E,B) / grad_log_radius_prior (K,B) as in thx_pg_vjp (may be NULL).
  *        w, delta: (B, n), row strides ldw / ldd. */
 int thx_pg_unroll_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, int64_t ldw, const void* delta, int64_t ldd,
                       const void* ellipsoidal_damping, void* grad_pose_i, void* grad_pose_j, void* grad_meas, void* grad_w_between, void* grad_pose_prior,
-                      void* grad_prior_target, void* grad_w_prior, int dtype, const thx_lie_eps* eps, void* stream);
+                      void* grad_prior_target, void* grad_w_prior, void* grad_log_radius_between, void* grad_log_radius_prior, int dtype,
+                      const thx_lie_eps* eps, void* stream);
 
 /* ---- Bundle adjustment (BASELINE.json configs[3]; examples/bundle_adjustment.py:103-160): camera poses SE3 + Point3
  *      world points, costs = Reprojection (theseus/embodied/measurements/reprojection.py:54-94, dim 2; SE3.transform_from

@@ -630,7 +630,11 @@ def gen_pg_unrolled(th, lieF):
              # ellipsoidal damping: lambda diag(H) + eps is part of the graph (dense_solver.py:38-64)
              ("lm_ellips_unroll", th.LevenbergMarquardt, "unroll", 4, dict(damping=0.05, adaptive_damping=True, ellipsoidal_damping=True)),
              # convergence tests ON: problems converge (and are frozen) inside the differentiated iterations, the loop stops early
-             ("gn_trunc_conv", th.GaussNewton, "truncated", 6, dict(backward_num_iterations=4, __tol__=5e-6)))
+             ("gn_trunc_conv", th.GaussNewton, "truncated", 6, dict(backward_num_iterations=4, __tol__=5e-6)),
+             # RobustCostFunction in the unrolled graph (robust_cost_function.py:115-135: the rescale is NOT detached): Welsch on every
+             # Between cost with ONE learnable log_loss_radius; Huber with flatten_dims=True on the Between costs AND the prior
+             ("lm_welsch_unroll", th.LevenbergMarquardt, "unroll", 4, dict(damping=0.05, __robust__=("welsch", False, False))),
+             ("gn_huberflat_trunc", th.GaussNewton, "truncated", 5, dict(backward_num_iterations=3, __robust__=("huber", True, True))))
     out = {}
     d = make_problem(dtype=dtype, th=th, lieF=lieF, P=6, E=10, B=3, seed=51, batched_weights=True, pose_noise=(0.2, 0.15))
     B, P = d["poses"].shape[:2]
@@ -642,20 +646,28 @@ def gen_pg_unrolled(th, lieF):
         wb = d["w_between"].clone().requires_grad_(True)
         tgt = d["prior_target"].clone().requires_grad_(True)
         wp = d["w_prior"][:, :, :1].clone().requires_grad_(True)
+        okw = dict(okw)
+        tol = okw.pop("__tol__", 0.0)
+        robust = okw.pop("__robust__", None)    # (loss kind, flatten_dims, also on the priors)
+        lr = torch.tensor([[0.0 if robust and robust[0] == "welsch" else -5.0]], dtype=dtype, requires_grad=True)   # log_loss_radius
+        radius = th.Vector(tensor=lr, name="log_loss_radius")
+        wrap = lambda cf, nm: cf if not robust else th.RobustCostFunction(  # noqa: E731
+            cf, th.WelschLoss if robust[0] == "welsch" else th.HuberLoss, radius, name=nm, flatten_dims=robust[1])
         obj = th.Objective(dtype=dtype)
         poses = [th.SE3(tensor=d["poses"][:, k].clone(), name=f"pose_{k}") for k in range(P)]
         for k in range(d["edges"].shape[0]):
             i, j = d["edges"][k].tolist()
-            obj.add(th.Between(poses[i], poses[j], th.SE3(tensor=meas[:, k], name=f"meas_{k}"),
-                               th.DiagonalCostWeight(th.Variable(wb[:, k], name=f"w_{k}")), name=f"between_{k}"))
+            obj.add(wrap(th.Between(poses[i], poses[j], th.SE3(tensor=meas[:, k], name=f"meas_{k}"),
+                                    th.DiagonalCostWeight(th.Variable(wb[:, k], name=f"w_{k}")), name=f"between_{k}"), f"robust_between_{k}"))
         for k in range(d["prior_idx"].shape[0]):
-            obj.add(th.Difference(poses[int(d["prior_idx"][k])], th.SE3(tensor=tgt[:, k], name=f"prior_target_{k}"),
-                                  th.ScaleCostWeight(th.Variable(wp[:, k], name=f"pw_{k}")), name=f"prior_{k}"))
-        okw = dict(okw)
-        tol = okw.pop("__tol__", 0.0)
-        opt = cls(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, max_iterations=iters, step_size=1.0,
+            cf = th.Difference(poses[int(d["prior_idx"][k])], th.SE3(tensor=tgt[:, k], name=f"prior_target_{k}"),
+                               th.ScaleCostWeight(th.Variable(wp[:, k], name=f"pw_{k}")), name=f"prior_{k}")
+            obj.add(wrap(cf, f"robust_prior_{k}") if robust and robust[2] else cf)
+        # (flatten_dims: the reference's vectorizer stacks the radii to (N B, 1) against (N B dim, 1) squared errors -- un-vectorized)
+        vec = not (robust and robust[1])
+        opt = cls(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=vec, max_iterations=iters, step_size=1.0,
                   abs_err_tolerance=0.0, rel_err_tolerance=tol)
-        sol, info = th.TheseusLayer(opt).forward(optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **okw))
+        sol, info = th.TheseusLayer(opt, vectorize=vec).forward(optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **okw))
         final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
         loss = (coef * final).sum()
         loss.backward()
@@ -663,6 +675,10 @@ def gen_pg_unrolled(th, lieF):
                     f"{tag}_grad_w_between": wb.grad.numpy(), f"{tag}_grad_prior_target": tgt.grad.numpy(),
                     f"{tag}_grad_w_prior": wp.grad.numpy(), f"{tag}_err_history": info.err_history.numpy(),
                     f"{tag}_kwargs": np.array(repr(dict(okw, max_iterations=iters, mode=mode, gauss_newton=cls is th.GaussNewton)))})
+        if robust:
+            out.update({f"{tag}_robust": np.array(robust[0] + ("+flatten" if robust[1] else "")), f"{tag}_robust_prior": bool(robust[2]),
+                        f"{tag}_log_radius": lr.detach().numpy(), f"{tag}_grad_log_radius": lr.grad.numpy()})
+            print("   grad log_radius", lr.grad.item())
         if tol:
             out.update({f"{tag}_rel_tol": tol, f"{tag}_conv": info.converged_iter.numpy(),
                         f"{tag}_status": np.array([int(s_.value) for s_ in info.status])})

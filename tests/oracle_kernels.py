@@ -361,12 +361,14 @@ class OracleKernels:
             if leaf.shape[1] > 0:
                 out[:leaf.shape[1]].copy_((g if g is not None else torch.zeros_like(leaf)).transpose(0, 1))
 
-    def pg_unroll_vjp(self, s, t, w, delta, g_pose_i, g_pose_j, g_meas, g_wb, g_pose_p, g_tgt, g_wp, poses=None, ell_damping=None):
-        """thx_pg_unroll_vjp: per cost, the gradient of phi = -(J w) . (r + J delta) by torch autograd through the oracle's
-        Between / Local formulas (which carry the reference's autograd conventions)."""
+    def pg_unroll_vjp(self, s, t, w, delta, g_pose_i, g_pose_j, g_meas, g_wb, g_pose_p, g_tgt, g_wp, poses=None, ell_damping=None,
+                      g_lrb=None, g_lrp=None):
+        """thx_pg_unroll_vjp: per cost, the gradient of Phi = -(J w) . (r + J delta) [- lambda sum_i w_i delta_i H_ii] (J, r with the
+        cost weight and the robust rescale) by torch autograd through the oracle's Between / Local formulas (which carry the
+        reference's autograd conventions)."""
         p, x = self._problem(s, t, poses)
-        if p.group != "SE3" or p.robust_between or p.robust_prior:
-            raise NotImplementedError("stand-in pg_unroll_vjp: plain SE3 pose graphs")
+        if p.group != "SE3":
+            raise NotImplementedError("stand-in pg_unroll_vjp: SE3 pose graphs")
         B = x.shape[0]
         E, Kp = p.edges.shape[0], p.prior_idx.shape[0]
         i, j = p.edges[:, 0], p.edges[:, 1]
@@ -375,23 +377,28 @@ class OracleKernels:
             full = lambda a: a.detach().expand(B, *a.shape[1:]).clone().requires_grad_(True)  # noqa: E731
             v0, v1, vp = full(x[:, i]), full(x[:, j]), full(x[:, p.prior_idx])
             meas, wb, tgt, wp = full(p.meas), full(p.w_between), full(p.prior_target), full(p.w_prior)
+            lrb = full(p.log_radius_between.expand(-1, E, 1)) if p.robust_between else None
+            lrp = full(p.log_radius_prior.expand(-1, Kp, 1)) if p.robust_prior else None
             mv = lambda J, v: (J @ v.unsqueeze(-1)).squeeze(-1)   # noqa: E731
+            lam = None if ell_damping is None else ell_damping.view(B, 1, 1)
             phi = x.new_zeros(())
             if E:
                 J0, J1, eb = opg.between_jac_err(v0, v1, meas, wb, p.G)
+                (J0, J1), eb = opg.robust_rescale([J0, J1], eb, p.robust_between, lrb)
                 phi = phi - ((mv(J0, blk(w, i)) + mv(J1, blk(w, j))) * (eb + mv(J0, blk(delta, i)) + mv(J1, blk(delta, j)))).sum()
-                if ell_damping is not None:   # ellipsoidal damping: -lambda sum_i w_i delta_i H_ii
-                    lam = ell_damping.view(B, 1, 1)
+                if lam is not None:   # ellipsoidal damping: -lambda sum_i w_i delta_i H_ii
                     phi = phi - (lam * ((J0 ** 2).sum(-2) * blk(w, i) * blk(delta, i) + (J1 ** 2).sum(-2) * blk(w, j) * blk(delta, j))).sum()
             if Kp:
                 Jp, ep = opg.local_jac_err(tgt, vp, wp, p.G)
+                (Jp,), ep = opg.robust_rescale([Jp], ep, p.robust_prior, lrp)
                 phi = phi - (mv(Jp, blk(w, p.prior_idx)) * (ep + mv(Jp, blk(delta, p.prior_idx)))).sum()
-                if ell_damping is not None:
-                    phi = phi - (ell_damping.view(B, 1, 1) * (Jp ** 2).sum(-2) * blk(w, p.prior_idx) * blk(delta, p.prior_idx)).sum()
-            leaves = [v0, v1, meas, wb, vp, tgt, wp]
+                if lam is not None:
+                    phi = phi - (lam * (Jp ** 2).sum(-2) * blk(w, p.prior_idx) * blk(delta, p.prior_idx)).sum()
+            leaves = [v0, v1, meas, wb, vp, tgt, wp] + [l for l in (lrb, lrp) if l is not None]
             grads = torch.autograd.grad(phi, leaves, allow_unused=True)
-        for out, g, leaf in zip((g_pose_i, g_pose_j, g_meas, g_wb, g_pose_p, g_tgt, g_wp), grads, leaves):
-            if leaf.shape[1] > 0:
+        outs = [g_pose_i, g_pose_j, g_meas, g_wb, g_pose_p, g_tgt, g_wp] + [o for o, l in ((g_lrb, lrb), (g_lrp, lrp)) if l is not None]
+        for out, g, leaf in zip(outs, grads, leaves):
+            if out is not None and leaf.shape[1] > 0:
                 out[:leaf.shape[1]].copy_((g if g is not None else torch.zeros_like(leaf)).transpose(0, 1))
 
     # ---- dense solver ------------------------------------------------------------------------------

@@ -15,7 +15,8 @@ def test_differentiating_through_the_iterations_on_the_gpu(tag):
     run_unrolled(th, load_golden("simple_example"), tag, "cuda")
 
 
-@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll", "gn_trunc_conv"])
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll", "gn_trunc_conv", "lm_welsch_unroll",
+                                 "gn_huberflat_trunc"])
 def test_differentiating_through_the_iterations_of_a_pose_graph_on_the_gpu(tag):
     """BackwardMode.UNROLL / TRUNCATED on an SE3 pose graph through the HIP kernels (thx_pg_unroll_vjp, thx_se3_retract_vjp,
     thx_chol_solve with a copy of each iteration's factor) against the REAL reference's gradients

@@ -38,45 +38,76 @@ def _rand_pose(gen, scale_t, scale_r):
 EPS64 = np.array([lie.EPS[torch.float64][k] for k in ("near_zero", "d_near_zero", "near_pi")])
 
 
+LOSSES = [(0, None), (1, "welsch"), (2, "huber"), (5, "welsch+flatten"), (6, "huber+flatten")]   # (THX_LOSS_* code, oracle spec)
+
+
+def _robust(Js, e, spec, log_radius):
+    """RobustCostFunction's rescale of one cost (robust_cost_function.py:115-135) through the oracle: (6, n) blocks, (6,) error."""
+    if spec is None:
+        return Js, e
+    Jr, er = opg.robust_rescale([J.view(1, 1, *J.shape) for J in Js], e.view(1, 1, 6), spec if "+" not in spec else [spec], log_radius)
+    return [J.view(6, -1) for J in Jr], er.view(6)
+
+
+@pytest.mark.parametrize("code,spec", LOSSES)
 @pytest.mark.parametrize("lam", [0.0, 0.37])     # (> 0: ellipsoidal damping's term -lambda sum_i w_i delta_i H_ii)
 @pytest.mark.parametrize("seed,scale_r", [(0, 1.0), (1, 2.5), (2, 0.3), (3, 1e-3)])   # (1e-3: the near-zero Taylor branches)
-def test_between_cost_unrolled_vjp_matches_autograd_through_the_oracle(hostmath, seed, scale_r, lam):
+def test_between_cost_unrolled_vjp_matches_autograd_through_the_oracle(hostmath, seed, scale_r, lam, code, spec):
     gen = torch.Generator().manual_seed(seed)
     Xi, Xj = _rand_pose(gen, 2.0, 1.5), _rand_pose(gen, 2.0, 1.5)
     D = lie.se3_compose(lie.se3_inverse(Xi), Xj)
     Z = lie.se3_compose(D, _rand_pose(gen, 0.2 * scale_r, scale_r))   # E = Z^-1 D has a rotation of ~scale_r
     s = 0.5 + torch.rand(6, dtype=torch.float64, generator=gen)
     wi, wj, di, dj = (torch.randn(6, dtype=torch.float64, generator=gen) for _ in range(4))
-    leaves = [t.clone().requires_grad_(True) for t in (Xi, Xj, Z, s)]
+    # (log_loss_radius near the squared error, so that Huber's knee and Welsch's decay are both exercised)
+    with torch.no_grad():
+        x0 = float((opg.between_jac_err(Xi, Xj, Z, s)[2] ** 2).sum())
+    lr = torch.tensor([[np.log(max(x0, 1e-12)) - 0.3 + 0.2 * seed]], dtype=torch.float64)
+    leaves = [t.clone().requires_grad_(True) for t in (Xi, Xj, Z, s, lr)]
     J0, J1, e = opg.between_jac_err(leaves[0], leaves[1], leaves[2], leaves[3])
+    (J0, J1), e = _robust([J0, J1], e, spec, leaves[4])
     phi = -((J0 @ wi + J1 @ wj) * (e + J0 @ di + J1 @ dj)).sum()
     phi = phi - lam * (((J0 ** 2).sum(0) * wi * di).sum() + ((J1 ** 2).sum(0) * wj * dj).sum())   # -lambda sum_i w_i delta_i (J^T J)_ii
     phi.backward()
-    out = np.zeros(42)
-    hostmath.hm_edge_vjp.argtypes = [ctypes.POINTER(ctypes.c_double)] * 9 + [ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    out = np.zeros(43)
+    hostmath.hm_edge_vjp.argtypes = [ctypes.POINTER(ctypes.c_double)] * 9 + [ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                                                              ctypes.POINTER(ctypes.c_double)]
     hostmath.hm_edge_vjp(*(_ptr(np.ascontiguousarray(t.detach().numpy().reshape(-1))) for t in (Xi, Xj, Z, s, wi, wj, di, dj)),
-                         _ptr(EPS64), lam, _ptr(out))
-    for k, (name, sl) in enumerate((("Xi", slice(0, 12)), ("Xj", slice(12, 24)), ("Z", slice(24, 36)), ("s", slice(36, 42)))):
+                         _ptr(EPS64), lam, code, float(lr), _ptr(out))
+    for k, (name, sl) in enumerate((("Xi", slice(0, 12)), ("Xj", slice(12, 24)), ("Z", slice(24, 36)), ("s", slice(36, 42)),
+                                    ("log_radius", slice(42, 43)))):
+        if leaves[k].grad is None:      # (a plain cost does not depend on log_loss_radius)
+            assert name == "log_radius" and out[42] == 0.0
+            continue
         want = leaves[k].grad.numpy().reshape(-1)
         np.testing.assert_allclose(out[sl], want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()), err_msg=name)
 
 
+@pytest.mark.parametrize("code,spec", LOSSES)
 @pytest.mark.parametrize("lam", [0.0, 0.37])
 @pytest.mark.parametrize("seed,scale_r", [(0, 1.0), (1, 1e-3)])
-def test_prior_cost_unrolled_vjp_matches_autograd_through_the_oracle(hostmath, seed, scale_r, lam):
+def test_prior_cost_unrolled_vjp_matches_autograd_through_the_oracle(hostmath, seed, scale_r, lam, code, spec):
     gen = torch.Generator().manual_seed(10 + seed)
     X = _rand_pose(gen, 2.0, 1.5)
     T = lie.se3_compose(X, _rand_pose(gen, 0.2 * scale_r, scale_r))
     s = 0.5 + torch.rand(6, dtype=torch.float64, generator=gen)
     w, d = (torch.randn(6, dtype=torch.float64, generator=gen) for _ in range(2))
-    leaves = [t.clone().requires_grad_(True) for t in (X, T, s)]
+    with torch.no_grad():
+        x0 = float((opg.local_jac_err(T, X, s)[1] ** 2).sum())
+    lr = torch.tensor([[np.log(max(x0, 1e-12)) - 0.2]], dtype=torch.float64)
+    leaves = [t.clone().requires_grad_(True) for t in (X, T, s, lr)]
     J, e = opg.local_jac_err(leaves[1], leaves[0], leaves[2])
+    (J,), e = _robust([J], e, spec, leaves[3])
     phi = -((J @ w) * (e + J @ d)).sum() - lam * ((J ** 2).sum(0) * w * d).sum()
     phi.backward()
-    out = np.zeros(30)
-    hostmath.hm_prior_vjp.argtypes = [ctypes.POINTER(ctypes.c_double)] * 6 + [ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    out = np.zeros(31)
+    hostmath.hm_prior_vjp.argtypes = [ctypes.POINTER(ctypes.c_double)] * 6 + [ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                                                               ctypes.POINTER(ctypes.c_double)]
     hostmath.hm_prior_vjp(*(_ptr(np.ascontiguousarray(t.detach().numpy().reshape(-1))) for t in (X, T, s, w, d)), _ptr(EPS64), lam,
-                          _ptr(out))
-    for k, (name, sl) in enumerate((("X", slice(0, 12)), ("T", slice(12, 24)), ("s", slice(24, 30)))):
+                          code, float(lr), _ptr(out))
+    for k, (name, sl) in enumerate((("X", slice(0, 12)), ("T", slice(12, 24)), ("s", slice(24, 30)), ("log_radius", slice(30, 31)))):
+        if leaves[k].grad is None:
+            assert name == "log_radius" and out[30] == 0.0
+            continue
         want = leaves[k].grad.numpy().reshape(-1)
         np.testing.assert_allclose(out[sl], want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()), err_msg=name)

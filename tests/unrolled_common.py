@@ -19,13 +19,23 @@ def run_pg_unrolled(th, g, tag, device, kernels=None):
     obj = th.Objective(dtype=leaves["meas"].dtype)
     poses0 = t(g["poses0"])
     poses = [th.SE3(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    # RobustCostFunction wrappers (fixtures lm_welsch_unroll / gn_huberflat_trunc): one learnable log_loss_radius
+    robust = str(g[f"{tag}_robust"]) if f"{tag}_robust" in g else None
+    wrap = lambda cf, nm: cf  # noqa: E731
+    if robust:
+        leaves["log_radius"] = t(g[f"{tag}_log_radius"]).clone().requires_grad_(True)
+        radius = th.Vector(tensor=leaves["log_radius"], name="log_loss_radius")
+        loss_cls = th.WelschLoss if robust.startswith("welsch") else th.HuberLoss
+        wrap = lambda cf, nm: th.RobustCostFunction(cf, loss_cls, radius, name=nm, flatten_dims=robust.endswith("+flatten"))  # noqa: E731
     for k in range(g["edges"].shape[0]):
         i, j = g["edges"][k].tolist()
-        obj.add(th.Between(poses[i], poses[j], th.SE3(tensor=leaves["meas"][:, k], name=f"meas_{k}"),
-                           th.DiagonalCostWeight(th.Variable(leaves["w_between"][:, k], name=f"w_{k}")), name=f"between_{k}"))
+        obj.add(wrap(th.Between(poses[i], poses[j], th.SE3(tensor=leaves["meas"][:, k], name=f"meas_{k}"),
+                                th.DiagonalCostWeight(th.Variable(leaves["w_between"][:, k], name=f"w_{k}")), name=f"between_{k}"),
+                     f"robust_between_{k}"))
     for k in range(g["prior_idx"].shape[0]):
-        obj.add(th.Difference(poses[int(g["prior_idx"][k])], th.SE3(tensor=leaves["prior_target"][:, k], name=f"prior_target_{k}"),
-                              th.ScaleCostWeight(th.Variable(leaves["w_prior"][:, k], name=f"pw_{k}")), name=f"prior_{k}"))
+        cf = th.Difference(poses[int(g["prior_idx"][k])], th.SE3(tensor=leaves["prior_target"][:, k], name=f"prior_target_{k}"),
+                           th.ScaleCostWeight(th.Variable(leaves["w_prior"][:, k], name=f"pw_{k}")), name=f"prior_{k}")
+        obj.add(wrap(cf, f"robust_prior_{k}") if robust and bool(g[f"{tag}_robust_prior"]) else cf)
     lkw = dict(linearization_kwargs=dict(kernels=kernels)) if kernels is not None else {}
     cls = th.GaussNewton if gn else th.LevenbergMarquardt
     tol = float(g[f"{tag}_rel_tol"]) if f"{tag}_rel_tol" in g else 0.0
@@ -34,10 +44,13 @@ def run_pg_unrolled(th, g, tag, device, kernels=None):
     final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
     loss = (t(g["coef"]) * final).sum()
     loss.backward()
-    np.testing.assert_allclose(final.detach().cpu().numpy(), g[f"{tag}_final"], rtol=0, atol=1e-9)
+    # (the Welsch case is still descending after its 4 iterations -- error 5.2 -> 0.9 -- and its down-weighted system is less
+    #  well conditioned: the tiled Cholesky and LAPACK's differ by 2e-9 on the final poses there, 1e-10 elsewhere)
+    tol_x = 2e-8 if robust else 1e-9
+    np.testing.assert_allclose(final.detach().cpu().numpy(), g[f"{tag}_final"], rtol=0, atol=tol_x)
     np.testing.assert_allclose(info.err_history.numpy(), g[f"{tag}_err_history"], rtol=1e-6)
-    assert abs(float(loss.detach()) - float(g[f"{tag}_loss"])) < 1e-9
-    for key in ("meas", "w_between", "prior_target", "w_prior"):
+    assert abs(float(loss.detach()) - float(g[f"{tag}_loss"])) < 10 * tol_x
+    for key in ("meas", "w_between", "prior_target", "w_prior") + (("log_radius",) if robust else ()):
         got, want = leaves[key].grad.cpu().numpy(), g[f"{tag}_grad_{key}"]
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
     if tol:   # problems converge -- and are frozen -- at different differentiated iterations; the loop stops early

@@ -99,7 +99,7 @@ class PGUnrolledIteration(torch.autograd.Function):
     each pose's incident costs in a fixed order (no atomics)."""
 
     @staticmethod
-    def forward(ctx, opt, packed, frozen, kwargs, X, meas, w_between, prior_target, w_prior):
+    def forward(ctx, opt, packed, frozen, kwargs, X, meas, w_between, prior_target, w_prior, lr_between, lr_prior):
         solver = opt.linear_solver
         lin, K = solver.linearization, packed.K
         Xd = X.detach().contiguous()
@@ -121,7 +121,7 @@ class PGUnrolledIteration(torch.autograd.Function):
         X_new = torch.empty_like(Xd)
         K.retract(Xd, delta, step, mask, X_new)
         ctx.packed, ctx.step, ctx.frozen, ctx.n = packed, step, frozen, lin.n
-        ctx.tensors = detached_tensors(t, Xd, meas, w_between, prior_target, w_prior, None, None)
+        ctx.tensors = detached_tensors(t, Xd, meas, w_between, prior_target, w_prior, lr_between, lr_prior)
         ctx.L, ctx.panels = solver.L.clone(), solver.panels.clone()   # (later iterations overwrite the solver's factor)
         ctx.delta = delta.detach().clone()
         ctx.mark_non_differentiable(delta)
@@ -150,16 +150,18 @@ class PGUnrolledIteration(torch.autograd.Function):
         new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
         gpi, gpj, gm, gwb = new(max(E_, 1), B, 3, 4), new(max(E_, 1), B, 3, 4), new(max(E_, 1), B, 3, 4), new(max(E_, 1), B, 6)
         gpp, gt, gwp = new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 6)
-        K.pg_unroll_vjp(packed.dstruct, t, w, delta, gpi, gpj, gm, gwb, gpp, gt, gwp, ell_damping=ctx.ell)
+        glb = new(max(E_, 1), B, 1) if t.robust_between else None
+        glp = new(max(Kp, 1), B, 1) if t.robust_prior else None
+        K.pg_unroll_vjp(packed.dstruct, t, w, delta, gpi, gpj, gm, gwb, gpp, gt, gwp, ell_damping=ctx.ell, g_lrb=glb, g_lrp=glp)
         # every pose's incident costs, in a fixed order: rows of [gpi ; gpj ; gpp ; 0]
         inc = packed.unroll_incidence(dev)
         src = torch.cat([gpi[:E_], gpj[:E_], gpp[:Kp], new(1, B, 3, 4)], 0)
         GX = GX + src[inc].sum(1)
 
         def fit(g, count, like):   # (count, B, ...) -> the packed input's shape (count, 1|B, ...)
-            if like is None:
+            if like is None or g is None:
                 return None
             g = g[:count]
             return g.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else g
         return (None, None, None, None, GX, fit(gm, E_, t.meas), fit(gwb, E_, t.w_between), fit(gt, Kp, t.prior_target),
-                fit(gwp, Kp, t.w_prior))
+                fit(gwp, Kp, t.w_prior), fit(glb, E_, t.log_radius_between), fit(glp, Kp, t.log_radius_prior))

@@ -17,6 +17,7 @@
 #pragma once
 #include "dual.cuh"
 #include "lie.cuh"
+#include "robust.cuh"
 
 namespace thx {
 
@@ -80,29 +81,14 @@ __device__ __forceinline__ void unroll_log_jlog(const SE3<UD>& E, const Eps<UD>&
   }
 }
 
-// sum_r s_r^2 sum_k M_rk^2 c_k  for the 6 x 6 block M = [[A, B], [0, C]] (rows r, columns k), c = w * delta of one variable
-template <typename S>
-__device__ __forceinline__ S unroll_colsq(const S* A, const S* Bm, const S* C, const double* s, const double* wv, const double* dv) {
-  S acc(0.0);
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    S top(0.0), bot(0.0);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      top = top + A[3 * r + k] * A[3 * r + k] * S(wv[k] * dv[k]) + Bm[3 * r + k] * Bm[3 * r + k] * S(wv[3 + k] * dv[3 + k]);
-      bot = bot + C[3 * r + k] * C[3 * r + k] * S(wv[3 + k] * dv[3 + k]);
-    }
-    acc = acc + S(s[r] * s[r]) * top + S(s[3 + r] * s[3 + r]) * bot;
-  }
-  return acc;
-}
-
 // phi of a Between cost (value and directional derivative); a_out / b_out (may be null): (Jlog q_w)_r and log(E)_r + (Jlog q_delta)_r;
 // lam != 0: ellipsoidal damping's term; the weight gradient of that term goes to ell_gs (may be null): d/ds_r = 2 s_r (...)_r
-__device__ __forceinline__ UD unroll_edge_phi(const SE3<UD>& Xi, const SE3<UD>& Xj, const SE3<UD>& Z, const double* s,
-                                              const double* wi, const double* wj, const double* di, const double* dj,
-                                              const Eps<UD>& eps, double* a_out, double* b_out, double lam = 0.0,
-                                              double* ell_rows = nullptr) {
+// phi_r[6] / x_r[6]: the rows of phi (phi = sum_r phi_r: what a plain cost contributes) and the squared weighted errors
+// x_r = (s_r log(E)_r)^2 a robust loss looks at -- value and directional derivative.
+__device__ __forceinline__ void unroll_edge_phi(const SE3<UD>& Xi, const SE3<UD>& Xj, const SE3<UD>& Z, const double* s,
+                                                const double* wi, const double* wj, const double* di, const double* dj,
+                                                const Eps<UD>& eps, double lam, UD* phi_r, UD* x_r, double* a_out, double* b_out,
+                                                double* ell_rows, double* xi_out) {
   SE3<UD> Xii, D, Zi, E, Dinv;
   se3_inv(Xi, Xii);
   se3_mul(Xii, Xj, D);
@@ -115,13 +101,14 @@ __device__ __forceinline__ UD unroll_edge_phi(const SE3<UD>& Xi, const SE3<UD>& 
   unroll_q(Dinv, di, dj, qd);
   unroll_jlog_apply(Jr, Jt, qw, a);
   unroll_jlog_apply(Jr, Jt, qd, c);
-  UD phi(0.0);
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
     const UD bsum = xi[r] + c[r];
-    phi = phi - UD(s[r] * s[r]) * (a[r] * bsum);
+    phi_r[r] = UD(0.0) - UD(s[r] * s[r]) * (a[r] * bsum);
+    x_r[r] = UD(s[r] * s[r]) * (xi[r] * xi[r]);
     if (a_out) a_out[r] = a[r].v;
     if (b_out) b_out[r] = bsum.v;
+    if (xi_out) xi_out[r] = xi[r].v;
   }
   if (lam != 0.0) {
     // J_j = [[Jr, Jt], [0, Jr]];  J_i = -J_j Ad(Dinv) = -[[Jr R, Jr hat(t) R + Jt R], [0, Jr R]]  (signs drop out of the squares)
@@ -139,30 +126,30 @@ __device__ __forceinline__ UD unroll_edge_phi(const SE3<UD>& Xi, const SE3<UD>& 
     mat3_mul(Jt, Dinv.R, JtR);
 #pragma unroll
     for (int k = 0; k < 9; ++k) TR[k] = JrhR[k] + JtR[k];
-    const UD ell = unroll_colsq(Jr, Jt, Jr, s, wj, dj) + unroll_colsq(JrR, TR, JrR, s, wi, di);
-    phi = phi - UD(lam) * ell;
-    if (ell_rows) {   // per-row sums (without s_r^2) for the weight gradient
+    // row r of the ellipsoidal term (without s_r^2): sum_k (J_j)_rk^2 w_jk delta_jk + (J_i)_rk^2 w_ik delta_ik
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        double top = 0.0, bot = 0.0;
+    for (int r = 0; r < 3; ++r) {
+      UD top(0.0), bot(0.0);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          top += Jr[3 * r + k].v * Jr[3 * r + k].v * wj[k] * dj[k] + Jt[3 * r + k].v * Jt[3 * r + k].v * wj[3 + k] * dj[3 + k] +
-                 JrR[3 * r + k].v * JrR[3 * r + k].v * wi[k] * di[k] + TR[3 * r + k].v * TR[3 * r + k].v * wi[3 + k] * di[3 + k];
-          bot += Jr[3 * r + k].v * Jr[3 * r + k].v * wj[3 + k] * dj[3 + k] + JrR[3 * r + k].v * JrR[3 * r + k].v * wi[3 + k] * di[3 + k];
-        }
-        ell_rows[r] = top;
-        ell_rows[3 + r] = bot;
+      for (int k = 0; k < 3; ++k) {
+        top = top + Jr[3 * r + k] * Jr[3 * r + k] * UD(wj[k] * dj[k]) + Jt[3 * r + k] * Jt[3 * r + k] * UD(wj[3 + k] * dj[3 + k]) +
+              JrR[3 * r + k] * JrR[3 * r + k] * UD(wi[k] * di[k]) + TR[3 * r + k] * TR[3 * r + k] * UD(wi[3 + k] * di[3 + k]);
+        bot = bot + Jr[3 * r + k] * Jr[3 * r + k] * UD(wj[3 + k] * dj[3 + k]) + JrR[3 * r + k] * JrR[3 * r + k] * UD(wi[3 + k] * di[3 + k]);
+      }
+      phi_r[r] = phi_r[r] - UD(lam * s[r] * s[r]) * top;
+      phi_r[3 + r] = phi_r[3 + r] - UD(lam * s[3 + r] * s[3 + r]) * bot;
+      if (ell_rows) {
+        ell_rows[r] = top.v;
+        ell_rows[3 + r] = bot.v;
       }
     }
   }
-  return phi;
 }
 
 // phi of a Difference / Local prior: E = T^-1 X, J = Jlog(E)
-__device__ __forceinline__ UD unroll_prior_phi(const SE3<UD>& X, const SE3<UD>& T, const double* s, const double* w,
-                                               const double* d, const Eps<UD>& eps, double* a_out, double* b_out, double lam = 0.0,
-                                               double* ell_rows = nullptr) {
+__device__ __forceinline__ void unroll_prior_phi(const SE3<UD>& X, const SE3<UD>& T, const double* s, const double* w,
+                                                 const double* d, const Eps<UD>& eps, double lam, UD* phi_r, UD* x_r, double* a_out,
+                                                 double* b_out, double* ell_rows, double* xi_out) {
   SE3<UD> Ti, E;
   se3_inv(T, Ti);
   se3_mul(Ti, X, E);
@@ -175,31 +162,32 @@ __device__ __forceinline__ UD unroll_prior_phi(const SE3<UD>& X, const SE3<UD>& 
   }
   unroll_jlog_apply(Jr, Jt, qw, a);
   unroll_jlog_apply(Jr, Jt, qd, c);
-  UD phi(0.0);
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
     const UD bsum = xi[r] + c[r];
-    phi = phi - UD(s[r] * s[r]) * (a[r] * bsum);
+    phi_r[r] = UD(0.0) - UD(s[r] * s[r]) * (a[r] * bsum);
+    x_r[r] = UD(s[r] * s[r]) * (xi[r] * xi[r]);
     if (a_out) a_out[r] = a[r].v;
     if (b_out) b_out[r] = bsum.v;
+    if (xi_out) xi_out[r] = xi[r].v;
   }
   if (lam != 0.0) {
-    phi = phi - UD(lam) * unroll_colsq(Jr, Jt, Jr, s, w, d);
-    if (ell_rows) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        double top = 0.0, bot = 0.0;
+    for (int r = 0; r < 3; ++r) {
+      UD top(0.0), bot(0.0);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          top += Jr[3 * r + k].v * Jr[3 * r + k].v * w[k] * d[k] + Jt[3 * r + k].v * Jt[3 * r + k].v * w[3 + k] * d[3 + k];
-          bot += Jr[3 * r + k].v * Jr[3 * r + k].v * w[3 + k] * d[3 + k];
-        }
-        ell_rows[r] = top;
-        ell_rows[3 + r] = bot;
+      for (int k = 0; k < 3; ++k) {
+        top = top + Jr[3 * r + k] * Jr[3 * r + k] * UD(w[k] * d[k]) + Jt[3 * r + k] * Jt[3 * r + k] * UD(w[3 + k] * d[3 + k]);
+        bot = bot + Jr[3 * r + k] * Jr[3 * r + k] * UD(w[3 + k] * d[3 + k]);
+      }
+      phi_r[r] = phi_r[r] - UD(lam * s[r] * s[r]) * top;
+      phi_r[3 + r] = phi_r[3 + r] - UD(lam * s[3 + r] * s[3 + r]) * bot;
+      if (ell_rows) {
+        ell_rows[r] = top.v;
+        ell_rows[3 + r] = bot.v;
       }
     }
   }
-  return phi;
 }
 
 // SE3<UD> from values with the raw entry k (0..11, row major 3 x 4) seeded (k < 0: no seed)
@@ -213,26 +201,65 @@ __device__ __forceinline__ void unroll_seed(const SE3<double>& X, int k, SE3<UD>
   }
 }
 
-// Gradients of a Between cost's phi: gXi, gXj, gZ (12 raw entries each), gs (6 weights)
+// Robust combination (robust_cost_function.py:115-135: (J, e) <- sqrt(rho'(x) + eps) (J, e), NOT detached): with m_r = rho'(X_r) + eps
+// the cost contributes Phi = sum_r m_r phi_r;  dPhi = sum_r [ m_r dphi_r + P_r m_x,r dx_r ],  P_r = phi_r (flatten_dims) | sum phi.
+struct UnrollRobust {
+  RobustTerms<6> rt;
+  double P[6];
+  __device__ __forceinline__ void setup(int loss, double log_radius, const UD* phi_r, const UD* x_r) {
+    double xv[6], pv[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      xv[r] = x_r[r].v;
+      pv[r] = phi_r[r].v;
+    }
+    rt.eval(loss, xv, log_radius);
+    rt.group(pv, P);
+  }
+  __device__ __forceinline__ double dot(const UD* phi_r, const UD* x_r) const {
+    double g = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) g += rt.m[r] * phi_r[r].d + P[r] * rt.m_x[r] * x_r[r].d;
+    return g;
+  }
+  // weight gradients: phi_r = -s_r^2 (a_r b_r + lambda ell_r) and x_r = s_r^2 xi_r^2
+  __device__ __forceinline__ void weights(const double* s, const UD* phi_r, const double* a, const double* b, const double* ell,
+                                          double lam, const double* xi, double* gs, double* glr) const {
+    double gl = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      gs[r] = rt.m[r] * (-2.0 * s[r] * (a[r] * b[r] + lam * ell[r])) + P[r] * rt.m_x[r] * (2.0 * s[r] * xi[r] * xi[r]);
+      gl += phi_r[r].v * rt.m_l[r];
+    }
+    *glr = gl;
+  }
+};
+
+// Gradients of a Between cost's Phi: gXi, gXj, gZ (12 raw entries each), gs (6 weights), glr (log_loss_radius; 0 for a plain cost)
 __device__ __forceinline__ void unroll_edge_vjp(const SE3<double>& Xi, const SE3<double>& Xj, const SE3<double>& Z, const double* s,
                                                 const double* wi, const double* wj, const double* di, const double* dj,
                                                 const Eps<double>& eps, double* gXi, double* gXj, double* gZ, double* gs,
-                                                double lam = 0.0) {
+                                                double lam = 0.0, int loss = THX_LOSS_NONE, double log_radius = 0.0,
+                                                double* glr = nullptr) {
   const Eps<UD> epsd{UD(eps.nz), UD(eps.dnz), UD(eps.npi)};
   SE3<UD> A, Bv, C;
-  double a[6], b[6], ell[6] = {0, 0, 0, 0, 0, 0};
+  UD phi_r[6], x_r[6];
+  double xi[6], a[6], b[6], ell[6] = {0, 0, 0, 0, 0, 0}, gl = 0.0;
   unroll_seed(Xi, -1, A);
   unroll_seed(Xj, -1, Bv);
   unroll_seed(Z, -1, C);
-  (void)unroll_edge_phi(A, Bv, C, s, wi, wj, di, dj, epsd, a, b, lam, ell);
-#pragma unroll
-  for (int r = 0; r < 6; ++r) gs[r] = -2.0 * s[r] * (a[r] * b[r] + lam * ell[r]);
+  unroll_edge_phi(A, Bv, C, s, wi, wj, di, dj, epsd, lam, phi_r, x_r, a, b, ell, xi);
+  UnrollRobust rb;
+  rb.setup(loss, log_radius, phi_r, x_r);
+  rb.weights(s, phi_r, a, b, ell, lam, xi, gs, &gl);
+  if (glr) *glr = gl;
   for (int k = 0; k < 36; ++k) {   // run-time loop: one dual evaluation per raw entry of Xi, Xj, Z
     const int which = k / 12, e = k % 12;
     unroll_seed(Xi, which == 0 ? e : -1, A);
     unroll_seed(Xj, which == 1 ? e : -1, Bv);
     unroll_seed(Z, which == 2 ? e : -1, C);
-    const double g = unroll_edge_phi(A, Bv, C, s, wi, wj, di, dj, epsd, nullptr, nullptr, lam, nullptr).d;
+    unroll_edge_phi(A, Bv, C, s, wi, wj, di, dj, epsd, lam, phi_r, x_r, nullptr, nullptr, nullptr, nullptr);
+    const double g = rb.dot(phi_r, x_r);
     if (which == 0) gXi[e] = g;
     else if (which == 1) gXj[e] = g;
     else gZ[e] = g;
@@ -241,20 +268,25 @@ __device__ __forceinline__ void unroll_edge_vjp(const SE3<double>& Xi, const SE3
 
 __device__ __forceinline__ void unroll_prior_vjp(const SE3<double>& X, const SE3<double>& T, const double* s, const double* w,
                                                  const double* d, const Eps<double>& eps, double* gX, double* gT, double* gs,
-                                                 double lam = 0.0) {
+                                                 double lam = 0.0, int loss = THX_LOSS_NONE, double log_radius = 0.0,
+                                                 double* glr = nullptr) {
   const Eps<UD> epsd{UD(eps.nz), UD(eps.dnz), UD(eps.npi)};
   SE3<UD> A, Bv;
-  double a[6], b[6], ell[6] = {0, 0, 0, 0, 0, 0};
+  UD phi_r[6], x_r[6];
+  double xi[6], a[6], b[6], ell[6] = {0, 0, 0, 0, 0, 0}, gl = 0.0;
   unroll_seed(X, -1, A);
   unroll_seed(T, -1, Bv);
-  (void)unroll_prior_phi(A, Bv, s, w, d, epsd, a, b, lam, ell);
-#pragma unroll
-  for (int r = 0; r < 6; ++r) gs[r] = -2.0 * s[r] * (a[r] * b[r] + lam * ell[r]);
+  unroll_prior_phi(A, Bv, s, w, d, epsd, lam, phi_r, x_r, a, b, ell, xi);
+  UnrollRobust rb;
+  rb.setup(loss, log_radius, phi_r, x_r);
+  rb.weights(s, phi_r, a, b, ell, lam, xi, gs, &gl);
+  if (glr) *glr = gl;
   for (int k = 0; k < 24; ++k) {
     const int which = k / 12, e = k % 12;
     unroll_seed(X, which == 0 ? e : -1, A);
     unroll_seed(T, which == 1 ? e : -1, Bv);
-    const double g = unroll_prior_phi(A, Bv, s, w, d, epsd, nullptr, nullptr, lam, nullptr).d;
+    unroll_prior_phi(A, Bv, s, w, d, epsd, lam, phi_r, x_r, nullptr, nullptr, nullptr, nullptr);
+    const double g = rb.dot(phi_r, x_r);
     if (which == 0) gX[e] = g;
     else gT[e] = g;
   }

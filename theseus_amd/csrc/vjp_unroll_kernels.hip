@@ -11,7 +11,8 @@ template <typename T>
 __global__ void __launch_bounds__(64)
 pg_unroll_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wvec, int64_t ldw, const T* __restrict__ dvec,
                      int64_t ldd, const T* __restrict__ ell_damping, T* __restrict__ g_pose_i, T* __restrict__ g_pose_j, T* __restrict__ g_meas,
-                     T* __restrict__ g_wb, T* __restrict__ g_pose_p, T* __restrict__ g_tgt, T* __restrict__ g_wp, Eps<T> eps_t) {
+                     T* __restrict__ g_wb, T* __restrict__ g_pose_p, T* __restrict__ g_tgt, T* __restrict__ g_wp,
+                     T* __restrict__ g_lrb, T* __restrict__ g_lrp, Eps<T> eps_t) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   const int c = blockIdx.y;
   const int B = d.batch;
@@ -39,7 +40,11 @@ pg_unroll_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wv
       dj[k] = (double)dv[6 * j + k];
       sw[k] = (double)wp[k];
     }
-    unroll_edge_vjp(Xi, Xj, Z, sw, wi, wj, di, dj, eps, gXi, gXj, gZ, gs, lam);
+    const int loss = loss_code(d.robust_between, d.loss_between, e);
+    const double lr = loss ? load_log_radius<T>(d.log_radius_between, e, b, B, d.log_radius_between_bstride) : 0.0;
+    double glr = 0.0;
+    unroll_edge_vjp(Xi, Xj, Z, sw, wi, wj, di, dj, eps, gXi, gXj, gZ, gs, lam, loss, lr, &glr);
+    if (d.robust_between && g_lrb) g_lrb[(int64_t)e * B + b] = (T)glr;   // (a plain cost of a mixed role: 0)
     T* oi = g_pose_i + ((int64_t)e * B + b) * 12;
     T* oj = g_pose_j + ((int64_t)e * B + b) * 12;
     T* oz = g_meas + ((int64_t)e * B + b) * 12;
@@ -66,7 +71,11 @@ pg_unroll_vjp_kernel(thx_pg_structure s, thx_pg_data d, const T* __restrict__ wv
       d6[r] = (double)dv[6 * p + r];
       sw[r] = (double)wp[r];
     }
-    unroll_prior_vjp(X, Tg, sw, w6, d6, eps, gX, gT, gs, lam);
+    const int loss = loss_code(d.robust_prior, d.loss_prior, k0);
+    const double lr = loss ? load_log_radius<T>(d.log_radius_prior, k0, b, B, d.log_radius_prior_bstride) : 0.0;
+    double glr = 0.0;
+    unroll_prior_vjp(X, Tg, sw, w6, d6, eps, gX, gT, gs, lam, loss, lr, &glr);
+    if (d.robust_prior && g_lrp) g_lrp[(int64_t)k0 * B + b] = (T)glr;
     T* ox = g_pose_p + ((int64_t)k0 * B + b) * 12;
     T* ot = g_tgt + ((int64_t)k0 * B + b) * 12;
     T* os = g_wp + ((int64_t)k0 * B + b) * 6;
@@ -88,26 +97,27 @@ extern "C" {
 
 int thx_pg_unroll_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, int64_t ldw, const void* delta, int64_t ldd,
                       const void* ellipsoidal_damping, void* grad_pose_i, void* grad_pose_j, void* grad_meas, void* grad_w_between, void* grad_pose_prior,
-                      void* grad_prior_target, void* grad_w_prior, int dtype, const thx_lie_eps* eps, void* stream) {
+                      void* grad_prior_target, void* grad_w_prior, void* grad_log_radius_between, void* grad_log_radius_prior, int dtype,
+                      const thx_lie_eps* eps, void* stream) {
   if (!s || !d || !w || !delta || !eps) return fail("thx_pg_unroll_vjp: null argument");
   if (s->num_edges > 0 && (!grad_pose_i || !grad_pose_j || !grad_meas || !grad_w_between))
     return fail("thx_pg_unroll_vjp: null edge gradient buffer");
   if (s->num_priors > 0 && (!grad_pose_prior || !grad_prior_target || !grad_w_prior))
     return fail("thx_pg_unroll_vjp: null prior gradient buffer");
   if (ldw < 6 * (int64_t)s->num_poses || ldd < 6 * (int64_t)s->num_poses) return fail("thx_pg_unroll_vjp: ldw / ldd < n");
-  if (d->robust_between || d->robust_prior)
-    return fail("thx_pg_unroll_vjp: robust cost functions are not supported when differentiating through the iterations");
+  if (const char* why = check_robust(d)) return fail(why);
   dim3 grid((d->batch + 63) / 64, s->num_edges + s->num_priors), block(64);
   if (grid.y == 0) return 0;
   THX_DISPATCH(dtype,
                hipLaunchKernelGGL(pg_unroll_vjp_kernel<float>, grid, block, 0, as_stream(stream), *s, *d, (const float*)w, ldw,
                                   (const float*)delta, ldd, (const float*)ellipsoidal_damping, (float*)grad_pose_i, (float*)grad_pose_j, (float*)grad_meas,
                                   (float*)grad_w_between, (float*)grad_pose_prior, (float*)grad_prior_target, (float*)grad_w_prior,
-                                  make_eps<float>(eps)),
+                                  (float*)grad_log_radius_between, (float*)grad_log_radius_prior, make_eps<float>(eps)),
                hipLaunchKernelGGL(pg_unroll_vjp_kernel<double>, grid, block, 0, as_stream(stream), *s, *d, (const double*)w, ldw,
                                   (const double*)delta, ldd, (const double*)ellipsoidal_damping, (double*)grad_pose_i, (double*)grad_pose_j, (double*)grad_meas,
                                   (double*)grad_w_between, (double*)grad_pose_prior, (double*)grad_prior_target,
-                                  (double*)grad_w_prior, make_eps<double>(eps)));
+                                  (double*)grad_w_prior, (double*)grad_log_radius_between, (double*)grad_log_radius_prior,
+                                  make_eps<double>(eps)));
   return check_launch("thx_pg_unroll_vjp");
 }
 

@@ -128,7 +128,7 @@ class _FusedUnrolledSolve(torch.autograd.Function):
     differentiable ops."""
 
     @staticmethod
-    def forward(ctx, solver, damping, ellipsoidal, eps, poses, meas, w_between, prior_target, w_prior):
+    def forward(ctx, solver, damping, ellipsoidal, eps, poses, meas, w_between, prior_target, w_prior, lr_between, lr_prior):
         lin = solver.linearization
         packed = lin.packed
         y = solver.factorize(damping, ellipsoidal, eps, rhs=lin.g)
@@ -137,7 +137,7 @@ class _FusedUnrolledSolve(torch.autograd.Function):
         solver.check_info()
         ctx.ell = solver._lam.clone() if (damping is not None and ellipsoidal) else None   # (lambda diag(H) is in the graph)
         ctx.packed, ctx.n = packed, lin.n
-        ctx.tensors = detached_tensors(packed.tensors, poses, meas, w_between, prior_target, w_prior, None, None)
+        ctx.tensors = detached_tensors(packed.tensors, poses, meas, w_between, prior_target, w_prior, lr_between, lr_prior)
         ctx.L, ctx.panels = solver.L.clone(), solver.panels.clone()
         ctx.delta = delta.clone()
         return delta
@@ -154,14 +154,18 @@ class _FusedUnrolledSolve(torch.autograd.Function):
         new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
         gpi, gpj, gm, gwb = new(max(E, 1), B, 3, 4), new(max(E, 1), B, 3, 4), new(max(E, 1), B, 3, 4), new(max(E, 1), B, 6)
         gpp, gt, gwp = new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 6)
-        K.pg_unroll_vjp(packed.dstruct, t, w, ctx.delta, gpi, gpj, gm, gwb, gpp, gt, gwp, ell_damping=ctx.ell)
+        glb = new(max(E, 1), B, 1) if t.robust_between else None
+        glp = new(max(Kp, 1), B, 1) if t.robust_prior else None
+        K.pg_unroll_vjp(packed.dstruct, t, w, ctx.delta, gpi, gpj, gm, gwb, gpp, gt, gwp, ell_damping=ctx.ell, g_lrb=glb, g_lrp=glp)
         GX = torch.cat([gpi[:E], gpj[:E], gpp[:Kp], new(1, B, 3, 4)], 0)[packed.unroll_incidence(dev)].sum(1)
 
         def fit(g, count, like):
+            if g is None or like is None:
+                return None
             g = g[:count]
             return g.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else g
         return (None, None, None, None, GX, fit(gm, E, t.meas), fit(gwb, E, t.w_between), fit(gt, Kp, t.prior_target),
-                fit(gwp, Kp, t.w_prior))
+                fit(gwp, Kp, t.w_prior), fit(glb, E, t.log_radius_between), fit(glp, Kp, t.log_radius_prior))
 
 
 class _HipRetract(torch.autograd.Function):
@@ -502,11 +506,11 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
             if graph and not _detach_hessian:
                 # backward_mode "unroll" / "truncated": the Hessian is part of the graph.  SE3 pose graphs: H and g are assembled
                 # at the detached values, solve() becomes ONE autograd node over (poses, auxiliary tensors) -- _FusedUnrolledSolve
-                packed.prepare_unroll()      # (refuses SE2 / SO3 / robust costs; re-packs poses and auxiliary tensors WITH history)
+                packed.prepare_unroll()      # (refuses SE2 / SO3; re-packs poses and auxiliary tensors WITH history)
                 t = packed.tensors
                 self._g_graph = None
                 self._assemble()
-                self._unroll = (t.poses, t.meas, t.w_between, t.prior_target, t.w_prior)
+                self._unroll = (t.poses, t.meas, t.w_between, t.prior_target, t.w_prior, t.log_radius_between, t.log_radius_prior)
                 return
             if graph:
                 packed.sync(force=True)  # re-pack WITH the autograd history of the auxiliary variables
