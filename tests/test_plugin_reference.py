@@ -732,3 +732,61 @@ def test_reference_loop_differentiates_through_the_plugin_on_se3_pose_graphs(ref
         np.testing.assert_allclose(leaf.grad.cpu().numpy(), want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
     if f"{tag}_conv" in g:
         assert info.converged_iter.tolist() == g[f"{tag}_conv"].tolist()
+
+
+@cpu_only
+def test_generic_path_places_jacobian_blocks_like_dense_linearization(ref):
+    """dense_linearization.py:44-52 writes Jacobian i of a cost into the columns that START at the cost's i-th variable and span
+    ``J.shape[2]`` of them -- a list shorter than the variable list, a block wider than its variable, a later block OVERWRITING part
+    of an earlier one, under a caller-supplied ordering: ``HipLinearization``'s A, b, AtA, Atb equal the reference's own
+    DenseLinearization on the same objective (the reference's optimizer tests rely on the first two cases,
+    tests/theseus_tests/optimizer/nonlinear/common.py:76-79)."""
+    th, thp = ref
+    from tests.oracle_kernels import OracleKernels
+    B = 4
+    gen = torch.Generator().manual_seed(5)
+
+    class Odd(th.CostFunction):
+        def __init__(self, vs, blocks, dim, name):
+            super().__init__(th.ScaleCostWeight(torch.tensor(1.5)), name=name)
+            for k, v in enumerate(vs):
+                setattr(self, f"v{k}", v)
+                self.register_optim_var(f"v{k}")
+            self._blocks, self._dim = blocks, dim
+            self._J = [torch.randn(B, dim, w, generator=gen) for w in blocks]
+            self._e = torch.randn(B, dim, generator=gen)
+
+        def error(self):
+            return self._e
+
+        def jacobians(self):
+            return self._J, self._e
+
+        def dim(self):
+            return self._dim
+
+        def _copy_impl(self, new_name=None):
+            raise NotImplementedError
+
+    a, b_, c, d = (th.Vector(n, name=nm) for n, nm in ((2, "a"), (1, "b"), (3, "c"), (2, "d")))
+    for v in (a, b_, c, d):
+        v.update(torch.zeros(B, v.dof()))
+    obj = th.Objective()
+    obj.add(Odd([a, b_, c], [6], 3, "wide"))            # one block over a, b and c (they are adjacent in the ordering below)
+    obj.add(Odd([b_, c, d], [1, 3], 2, "short"))        # two blocks for three variables
+    obj.add(Odd([a, b_], [3, 1], 4, "overlap"))         # the second block overwrites the last column of the first
+    ordering = th.VariableOrdering(obj, default_order=False)
+    for v in (d, a, b_, c):
+        ordering.append(v)
+    obj.update()
+    ref_lin = th.DenseLinearization(obj, ordering=ordering)
+    ref_lin.linearize()
+    lin = thp.HipLinearization(obj, ordering=ordering, kernels=OracleKernels())
+    assert not lin.fused
+    lin.linearize()
+    np.testing.assert_allclose(lin.A.numpy(), ref_lin.A.numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(lin.b.numpy(), ref_lin.b.numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(lin.AtA.numpy(), ref_lin.AtA.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lin.Atb.numpy(), ref_lin.Atb.numpy(), rtol=1e-5, atol=1e-5)
+    v = torch.randn(B, lin.num_cols, generator=gen)
+    np.testing.assert_allclose(lin.Av(v).numpy(), ref_lin.Av(v).numpy(), rtol=1e-5, atol=1e-5)
