@@ -388,6 +388,17 @@ int thx_pg_unroll_vjp(const thx_pg_structure* s, const thx_pg_data* d, const voi
                       void* grad_prior_target, void* grad_w_prior, void* grad_log_radius_between, void* grad_log_radius_prior, int dtype,
                       const thx_lie_eps* eps, void* stream);
 
+/* The 3-dof twins (SE2: 4-element records [x, y, cos, sin], plain autograd everywhere, theseus/geometry/se2.py; SO3: 9-element
+ * records, torchlie's passthrough backward for log, so3_impl.py:489-496): same arguments, 3-vectors for the weights. */
+int thx_pg2_unroll_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, int64_t ldw, const void* delta, int64_t ldd,
+                       const void* ellipsoidal_damping, void* grad_pose_i, void* grad_pose_j, void* grad_meas, void* grad_w_between,
+                       void* grad_pose_prior, void* grad_prior_target, void* grad_w_prior, void* grad_log_radius_between,
+                       void* grad_log_radius_prior, int dtype, const thx_se2_eps* eps, void* stream);
+int thx_pgso3_unroll_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, int64_t ldw, const void* delta, int64_t ldd,
+                         const void* ellipsoidal_damping, void* grad_pose_i, void* grad_pose_j, void* grad_meas,
+                         void* grad_w_between, void* grad_pose_prior, void* grad_prior_target, void* grad_w_prior,
+                         void* grad_log_radius_between, void* grad_log_radius_prior, int dtype, const thx_lie_eps* eps, void* stream);
+
 /* ---- Bundle adjustment (BASELINE.json configs[3]; examples/bundle_adjustment.py:103-160): camera poses SE3 + Point3
  *      world points, costs = Reprojection (theseus/embodied/measurements/reprojection.py:54-94, dim 2; SE3.transform_from
  *      + Jacobians: torchlie/functional/se3_impl.py:757-777) optionally wrapped in RobustCostFunction, Difference priors on

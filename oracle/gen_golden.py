@@ -921,6 +921,48 @@ def gen_so3_implicit(th):
     print("pg3_f64_implicit loss", loss.item(), "|grad_meas|", meas.grad.abs().max().item())
 
 
+def gen_pg23_unrolled(th):
+    """BackwardMode.UNROLL / TRUNCATED on SE2 and SO3 pose graphs: the problems of pg2_f64_implicit / pg3_f64_implicit (read back
+    from OUT), differentiated THROUGH the reference's iterations -- Gauss-Newton unrolled, LM truncated, adaptive ellipsoidal LM
+    unrolled.  Written to pg2_f64_unrolled.npz / pg3_f64_unrolled.npz."""
+    dtype = torch.float64
+    cases = (("gn_unroll", th.GaussNewton, "unroll", 3, {}),
+             ("lm_trunc", th.LevenbergMarquardt, "truncated", 5, dict(damping=0.02, backward_num_iterations=2)),
+             ("lm_ellips_unroll", th.LevenbergMarquardt, "unroll", 4, dict(damping=0.05, adaptive_damping=True, ellipsoidal_damping=True)))
+    for src, G, dst in (("pg2_f64_implicit", th.SE2, "pg2_f64_unrolled"), ("pg3_f64_implicit", th.SO3, "pg3_f64_unrolled")):
+        f = np.load(os.path.join(OUT, src + ".npz"))
+        t = torch.from_numpy
+        P, edges, prior_idx = int(f["P"]), f["edges"], f["prior_idx"]
+        coef = t(f["coef"])
+        out = {k: f[k] for k in ("group", "P", "edges", "meas", "w_between", "prior_idx", "prior_target", "w_prior", "poses0", "coef")}
+        for tag, cls, mode, iters, okw in cases:
+            meas = t(f["meas"]).clone().requires_grad_(True)
+            wb = t(f["w_between"]).clone().requires_grad_(True)
+            tgt = t(f["prior_target"]).clone().requires_grad_(True)
+            wp = t(f["w_prior"])[:, :, :1].clone().requires_grad_(True)
+            obj = th.Objective(dtype=dtype)
+            pv = [G(tensor=t(f["poses0"])[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+            for k in range(edges.shape[0]):
+                i, j = edges[k].tolist()
+                obj.add(th.Between(pv[i], pv[j], G(tensor=meas[:, k], name=f"meas_{k}"),
+                                   th.DiagonalCostWeight(th.Variable(wb[:, k], name=f"w_{k}")), name=f"between_{k}"))
+            for k in range(prior_idx.shape[0]):
+                obj.add(th.Difference(pv[int(prior_idx[k])], G(tensor=tgt[:, k], name=f"tgt_{k}"),
+                                      th.ScaleCostWeight(th.Variable(wp[:, k], name=f"pw_{k}")), name=f"prior_{k}"))
+            opt = cls(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True, max_iterations=iters, step_size=1.0,
+                      abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+            sol, info = th.TheseusLayer(opt).forward(optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **okw))
+            final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
+            loss = (coef * final).sum()
+            loss.backward()
+            out.update({f"{tag}_final": final.detach().numpy(), f"{tag}_loss": loss.item(), f"{tag}_grad_meas": meas.grad.numpy(),
+                        f"{tag}_grad_w_between": wb.grad.numpy(), f"{tag}_grad_prior_target": tgt.grad.numpy(),
+                        f"{tag}_grad_w_prior": wp.grad.numpy(), f"{tag}_err_history": info.err_history.numpy(),
+                        f"{tag}_kwargs": np.array(repr(dict(okw, max_iterations=iters, mode=mode, gauss_newton=cls is th.GaussNewton)))})
+            print(dst, tag, "loss", loss.item(), "|grad_meas|", meas.grad.abs().max().item(), info.err_history[0].tolist())
+        np.savez_compressed(os.path.join(OUT, dst + ".npz"), **out)
+
+
 # the reference's own known-answer test for this path: tests/theseus_tests/test_pgo_benchmark.py:34-39
 PGO_KAT_LOSSES = [-0.29886279606812166, -0.3054215856589109, -0.27485602196709225, -0.3005231105990632]
 
@@ -1297,6 +1339,8 @@ def main():
         gen_se2_implicit(th)
     if not only or "so3_implicit" in only:
         gen_so3_implicit(th)
+    if not only or "pg23_unrolled" in only:
+        gen_pg23_unrolled(th)
     if not only or "pgo_kat" in only:
         gen_pgo_kat(th)
     if not only or "ba" in only:   # (the small cases; the multi-tile and full-size ones are asked for by name)

@@ -33,3 +33,24 @@ void hm_prior_vjp(const double* X, const double* T, const double* s, const doubl
   unroll_prior_vjp(A, B, s, w, d, e, out, out + 12, out + 24, lam, loss, log_radius, out + 30);
 }
 }
+
+// ---- 3-dof groups (theseus_amd/csrc/unroll_g3.cuh): group 2 = SE2 (raw 4), 3 = SO3 (raw 9) ----
+#include "unroll_g3.cuh"
+
+extern "C" {
+
+// out: g[3 * NR] (Xi, Xj, Z) gs[3] glr[1]; prior (edge = 0): the Xi third stays 0, Xj = the variable, Z = the target
+void hm_g3_vjp(int group, int edge, const double* Xi, const double* Xj, const double* Z, const double* s, const double* wi,
+               const double* wj, const double* di, const double* dj, const double* eps, double lam, int loss, double log_radius,
+               double* out) {
+  if (group == 2) {
+    const Eps2<double> e{eps[0], eps[1]};
+    if (edge) unroll3_vjp<UG_SE2, true>(Xi, Xj, Z, s, wi, wj, di, dj, e, lam, loss, log_radius, out, out + 12, out + 15);
+    else unroll3_vjp<UG_SE2, false>(Xi, Xj, Z, s, wi, wj, di, dj, e, lam, loss, log_radius, out, out + 12, out + 15);
+  } else {
+    const Eps<double> e{eps[0], eps[1], eps[2]};
+    if (edge) unroll3_vjp<UG_SO3, true>(Xi, Xj, Z, s, wi, wj, di, dj, e, lam, loss, log_radius, out, out + 27, out + 30);
+    else unroll3_vjp<UG_SO3, false>(Xi, Xj, Z, s, wi, wj, di, dj, e, lam, loss, log_radius, out, out + 27, out + 30);
+  }
+}
+}

@@ -367,12 +367,10 @@ class OracleKernels:
         cost weight and the robust rescale) by torch autograd through the oracle's Between / Local formulas (which carry the
         reference's autograd conventions)."""
         p, x = self._problem(s, t, poses)
-        if p.group != "SE3":
-            raise NotImplementedError("stand-in pg_unroll_vjp: SE3 pose graphs")
         B = x.shape[0]
         E, Kp = p.edges.shape[0], p.prior_idx.shape[0]
         i, j = p.edges[:, 0], p.edges[:, 1]
-        blk = lambda v, idx: v.view(B, -1, 6)[:, idx]   # noqa: E731   (B, n) -> (B, len(idx), 6)
+        blk = lambda v, idx: v.view(B, -1, p.dof)[:, idx]   # noqa: E731   (B, n) -> (B, len(idx), dof)
         with torch.enable_grad():
             full = lambda a: a.detach().expand(B, *a.shape[1:]).clone().requires_grad_(True)  # noqa: E731
             v0, v1, vp = full(x[:, i]), full(x[:, j]), full(x[:, p.prior_idx])

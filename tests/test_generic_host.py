@@ -116,26 +116,3 @@ def test_differentiating_through_the_iterations_matches_the_reference(tag):
     from tests.oracle_kernels import OracleKernels
     from tests.simple_example_common import run_unrolled
     run_unrolled(th, load_golden("simple_example"), tag, "cpu", OracleKernels())
-
-
-def test_fused_path_refuses_unrolled_differentiation():
-    """SE3 pose graphs differentiate through their iterations since round 4 (tests/test_unrolled_host.py); SE2 / SO3 pose graphs
-    and bundle adjustment still refuse loudly (no autograd / CPU fallback)."""
-    import theseus_amd as th
-    from tests.helpers import load_golden as lg
-    from tests.oracle_kernels import OracleKernels
-    g = lg("pg2_f64_implicit")
-    t = torch.from_numpy
-    meas = t(g["meas"]).clone().requires_grad_(True)
-    obj = th.Objective(dtype=torch.float64)
-    poses = [th.SE2(tensor=t(g["poses0"])[:, k].clone(), name=f"pose_{k}") for k in range(int(g["P"]))]
-    for k in range(g["edges"].shape[0]):
-        i, j = g["edges"][k].tolist()
-        obj.add(th.Between(poses[i], poses[j], th.SE2(tensor=meas[:, k], name=f"meas_{k}"),
-                           th.DiagonalCostWeight(th.Variable(t(g["w_between"])[:, k].clone(), name=f"w_{k}")), name=f"between_{k}"))
-    opt = th.LevenbergMarquardt(obj, max_iterations=3, linearization_kwargs=dict(kernels=OracleKernels()))
-    for mode, extra in (("unroll", {}), ("truncated", dict(backward_num_iterations=1))):
-        with pytest.raises(NotImplementedError, match="fused for SE3 pose graphs"):
-            th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode=mode, **extra))
-    with torch.no_grad():   # nothing to differentiate: both modes are the plain loop
-        th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode="truncated", backward_num_iterations=1))

@@ -27,6 +27,15 @@ def test_differentiating_through_the_iterations_of_a_pose_graph_on_the_gpu(tag):
     run_pg_unrolled(th, load_golden("pg_f64_unrolled"), tag, "cuda")
 
 
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_trunc", "lm_ellips_unroll"])
+@pytest.mark.parametrize("fixture", ["pg2_f64_unrolled", "pg3_f64_unrolled"])
+def test_differentiating_through_the_iterations_of_se2_and_so3_pose_graphs_on_the_gpu(fixture, tag):
+    """thx_pg2_unroll_vjp / thx_pgso3_unroll_vjp against the REAL reference's gradients (CPU twin: tests/test_unrolled_host.py)."""
+    import theseus_amd as th
+    from tests.unrolled_common import run_pg_unrolled
+    run_pg_unrolled(th, load_golden(fixture), tag, "cuda")
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_unroll_vjp_kernel_against_autograd_through_the_oracle(dtype):
     """thx_pg_unroll_vjp on its own: per-cost gradients of phi = -(J w).(r + J delta) for random w, delta against torch autograd

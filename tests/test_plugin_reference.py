@@ -790,3 +790,43 @@ def test_generic_path_places_jacobian_blocks_like_dense_linearization(ref):
     np.testing.assert_allclose(lin.Atb.numpy(), ref_lin.Atb.numpy(), rtol=1e-5, atol=1e-5)
     v = torch.randn(B, lin.num_cols, generator=gen)
     np.testing.assert_allclose(lin.Av(v).numpy(), ref_lin.Av(v).numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_trunc", "lm_ellips_unroll"])
+@pytest.mark.parametrize("fixture", ["pg2_f64_unrolled", "pg3_f64_unrolled"])
+def test_reference_loop_differentiates_through_the_plugin_on_se2_and_so3_pose_graphs(ref, fixture, tag):
+    """... and on the 3-dof groups (thx_pg2_unroll_vjp / thx_pgso3_unroll_vjp behind ``_FusedUnrolledSolve``)."""
+    import ast
+    th, thp = ref
+    g = load_golden(fixture)
+    G = th.SE2 if str(g["group"]) == "SE2" else th.SO3
+    t = lambda a: torch.from_numpy(a).to(DEVICE)  # noqa: E731
+    kw = ast.literal_eval(str(g[f"{tag}_kwargs"]))
+    mode, iters, gn = kw.pop("mode"), kw.pop("max_iterations"), kw.pop("gauss_newton")
+    P = int(g["P"])
+    meas, wb = t(g["meas"]).requires_grad_(True), t(g["w_between"]).requires_grad_(True)
+    tgt, wp = t(g["prior_target"]).requires_grad_(True), t(g["w_prior"])[:, :, :1].clone().requires_grad_(True)
+    obj = th.Objective(dtype=torch.float64)
+    poses = [G(tensor=t(g["poses0"])[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    for k in range(g["edges"].shape[0]):
+        i, j = g["edges"][k].tolist()
+        obj.add(th.Between(poses[i], poses[j], G(tensor=meas[:, k], name=f"meas_{k}"),
+                           th.DiagonalCostWeight(th.Variable(wb[:, k], name=f"w_{k}")), name=f"between_{k}"))
+    for k in range(g["prior_idx"].shape[0]):
+        obj.add(th.Difference(poses[int(g["prior_idx"][k])], G(tensor=tgt[:, k], name=f"tgt_{k}"),
+                              th.ScaleCostWeight(th.Variable(wp[:, k], name=f"pw_{k}")), name=f"prior_{k}"))
+    cls = th.GaussNewton if gn else th.LevenbergMarquardt
+    opt = cls(obj, linear_solver_cls=thp.HipCholeskySolver, linearization_cls=thp.HipLinearization, linearization_kwargs=_kernels(),
+              vectorize=True, max_iterations=iters, step_size=1.0, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    assert opt.linear_solver.linearization.fused
+    layer = th.TheseusLayer(opt)
+    if DEVICE != "cpu":
+        layer.to(DEVICE)
+    sol, info = layer.forward(optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **kw))
+    final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
+    loss = (t(g["coef"]) * final).sum()
+    loss.backward()
+    np.testing.assert_allclose(final.detach().cpu().numpy(), g[f"{tag}_final"], rtol=0, atol=1e-9)
+    for leaf, key in ((meas, "meas"), (wb, "w_between"), (tgt, "prior_target"), (wp, "w_prior")):
+        want = g[f"{tag}_grad_{key}"]
+        np.testing.assert_allclose(leaf.grad.cpu().numpy(), want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)

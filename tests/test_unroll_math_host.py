@@ -111,3 +111,79 @@ def test_prior_cost_unrolled_vjp_matches_autograd_through_the_oracle(hostmath, s
             continue
         want = leaves[k].grad.numpy().reshape(-1)
         np.testing.assert_allclose(out[sl], want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()), err_msg=name)
+
+
+# ---- SE2 / SO3 (theseus_amd/csrc/unroll_g3.cuh) ----------------------------------------------------------------------------------
+def _g3_setup(group, gen, scale_r):
+    from oracle import lie_se2, lie_so3
+    f64 = torch.float64
+    rnd3 = lambda a, b_: torch.cat([a * (2 * torch.rand(1, 2, dtype=f64, generator=gen) - 1),      # noqa: E731
+                                    b_ * (2 * torch.rand(1, 1, dtype=f64, generator=gen) - 1)], 1)
+    if group == "SE2":
+        pose = lambda a, b_: lie_se2.se2_exp(rnd3(a, b_))[0]      # noqa: E731
+        eps = np.array([lie_se2.EPS[f64]["near_zero"], lie_se2.EPS[f64]["d_near_zero"], 0.0])
+        return pose, opg.GROUPS["SE2"], eps, 4, 2
+    pose = lambda a, b_: lie_so3.so3_exp(b_ * (2 * torch.rand(1, 3, dtype=f64, generator=gen) - 1))[0]   # noqa: E731
+    return pose, opg.GROUPS["SO3"], EPS64, 9, 3
+
+
+@pytest.mark.parametrize("code,spec", LOSSES)
+@pytest.mark.parametrize("lam", [0.0, 0.37])
+@pytest.mark.parametrize("seed,scale_r", [(0, 1.0), (1, 2.0), (2, 1e-4)])   # (1e-4: the near-zero Taylor branches of both groups)
+@pytest.mark.parametrize("group", ["SE2", "SO3"])
+def test_three_dof_groups_unrolled_vjp_matches_autograd_through_the_oracle(hostmath, group, seed, scale_r, lam, code, spec):
+    gen = torch.Generator().manual_seed(100 + seed)
+    pose, G, eps, NR, gid = _g3_setup(group, gen, scale_r)
+    Xi, Xj = pose(2.0, 1.5), pose(2.0, 1.5)
+    D = G.compose(G.inverse(Xi), Xj)
+    Z = G.compose(D, pose(0.2 * scale_r, scale_r))
+    s = 0.5 + torch.rand(3, dtype=torch.float64, generator=gen)
+    wi, wj, di, dj = (torch.randn(3, dtype=torch.float64, generator=gen) for _ in range(4))
+
+    def robust(Js, e, lr):
+        if spec is None:
+            return Js, e
+        Jr, er = opg.robust_rescale([J.view(1, 1, *J.shape) for J in Js], e.view(1, 1, 3), spec if "+" not in spec else [spec], lr)
+        return [J.view(3, -1) for J in Jr], er.view(3)
+    hostmath.hm_g3_vjp.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_double)] * 9 + [
+        ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    flat = lambda t: _ptr(np.ascontiguousarray(t.detach().numpy().reshape(-1)))   # noqa: E731
+    # ---- Between ----
+    with torch.no_grad():
+        x0 = float((opg.between_jac_err(Xi, Xj, Z, s, G)[2] ** 2).sum())
+    lr = torch.tensor([[np.log(max(x0, 1e-12)) - 0.3 + 0.2 * seed]], dtype=torch.float64)
+    leaves = [t.clone().requires_grad_(True) for t in (Xi, Xj, Z, s, lr)]
+    J0, J1, e = opg.between_jac_err(leaves[0], leaves[1], leaves[2], leaves[3], G)
+    (J0, J1), e = robust([J0, J1], e, leaves[4])
+    phi = -((J0 @ wi + J1 @ wj) * (e + J0 @ di + J1 @ dj)).sum()
+    phi = phi - lam * (((J0 ** 2).sum(0) * wi * di).sum() + ((J1 ** 2).sum(0) * wj * dj).sum())
+    phi.backward()
+    out = np.zeros(3 * NR + 4)
+    hostmath.hm_g3_vjp(gid, 1, flat(Xi), flat(Xj), flat(Z), flat(s), flat(wi), flat(wj), flat(di), flat(dj), _ptr(eps), lam, code,
+                       float(lr), _ptr(out))
+    for k, (name, sl) in enumerate((("Xi", slice(0, NR)), ("Xj", slice(NR, 2 * NR)), ("Z", slice(2 * NR, 3 * NR)),
+                                    ("s", slice(3 * NR, 3 * NR + 3)), ("log_radius", slice(3 * NR + 3, 3 * NR + 4)))):
+        if leaves[k].grad is None:
+            assert name == "log_radius" and out[3 * NR + 3] == 0.0
+            continue
+        want = leaves[k].grad.numpy().reshape(-1)
+        np.testing.assert_allclose(out[sl], want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()), err_msg=f"between {name}")
+    # ---- Difference / Local prior ----
+    X, T = Xj, G.compose(Xj, pose(0.2 * scale_r, scale_r))
+    with torch.no_grad():
+        x0 = float((opg.local_jac_err(T, X, s, G)[1] ** 2).sum())
+    lr = torch.tensor([[np.log(max(x0, 1e-12)) - 0.2]], dtype=torch.float64)
+    leaves = [t.clone().requires_grad_(True) for t in (X, T, s, lr)]
+    J, e = opg.local_jac_err(leaves[1], leaves[0], leaves[2], G)
+    (J,), e = robust([J], e, leaves[3])
+    phi = -((J @ wj) * (e + J @ dj)).sum() - lam * ((J ** 2).sum(0) * wj * dj).sum()
+    phi.backward()
+    out = np.zeros(3 * NR + 4)
+    hostmath.hm_g3_vjp(gid, 0, flat(X), flat(X), flat(T), flat(s), flat(wi), flat(wj), flat(di), flat(dj), _ptr(eps), lam, code,
+                       float(lr), _ptr(out))
+    for k, (name, sl) in enumerate((("X", slice(NR, 2 * NR)), ("T", slice(2 * NR, 3 * NR)), ("s", slice(3 * NR, 3 * NR + 3)),
+                                    ("log_radius", slice(3 * NR + 3, 3 * NR + 4)))):
+        if leaves[k].grad is None:
+            continue
+        want = leaves[k].grad.numpy().reshape(-1)
+        np.testing.assert_allclose(out[sl], want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()), err_msg=f"prior {name}")

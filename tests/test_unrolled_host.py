@@ -16,21 +16,33 @@ def test_differentiating_through_the_iterations_of_a_pose_graph(tag):
     run_pg_unrolled(th, load_golden("pg_f64_unrolled"), tag, "cpu", OracleKernels())
 
 
-def test_other_groups_are_refused_loudly():
-    """SE2 / SO3 pose graphs (and bundle adjustment) do not differentiate through their iterations on the fused path: a loud
-    NotImplementedError, no autograd / CPU fallback (tests/test_generic_host.py::test_fused_path_refuses_unrolled_differentiation)."""
-    import torch
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_trunc", "lm_ellips_unroll"])
+@pytest.mark.parametrize("fixture", ["pg2_f64_unrolled", "pg3_f64_unrolled"])
+def test_differentiating_through_the_iterations_of_se2_and_so3_pose_graphs(fixture, tag):
+    """The 3-dof groups (thx_pg2_unroll_vjp / thx_pgso3_unroll_vjp; SE2: plain autograd everywhere, SO3: torchlie's conventions) on
+    the problems of the implicit fixtures, differentiated through the reference's iterations (oracle/gen_golden.py:
+    gen_pg23_unrolled)."""
     import theseus_amd as th
     from tests.oracle_kernels import OracleKernels
-    g = load_golden("pg3_f64_implicit")
-    t = torch.from_numpy
-    meas = t(g["meas"]).clone().requires_grad_(True)
-    obj = th.Objective(dtype=torch.float64)
-    poses = [th.SO3(tensor=t(g["poses0"])[:, k].clone(), name=f"pose_{k}") for k in range(int(g["P"]))]
-    for k in range(g["edges"].shape[0]):
-        i, j = g["edges"][k].tolist()
-        obj.add(th.Between(poses[i], poses[j], th.SO3(tensor=meas[:, k], name=f"meas_{k}"),
-                           th.DiagonalCostWeight(th.Variable(t(g["w_between"])[:, k].clone(), name=f"w_{k}")), name=f"between_{k}"))
-    opt = th.GaussNewton(obj, max_iterations=2, linearization_kwargs=dict(kernels=OracleKernels()))
-    with pytest.raises(NotImplementedError, match="fused for SE3 pose graphs"):
-        th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode="unroll"))
+    run_pg_unrolled(th, load_golden(fixture), tag, "cpu", OracleKernels())
+
+
+def test_bundle_adjustment_refuses_unrolled_differentiation():
+    """Bundle adjustment does not differentiate through its iterations on the fused path: a loud NotImplementedError, no autograd /
+    CPU fallback."""
+    import torch
+    import theseus_amd as th
+    from tests.ba_common import run_ba_implicit
+    from tests.oracle_kernels import OracleKernels
+    g = load_golden("ba_f64_implicit")
+
+    class Unroll:
+        """theseus_amd with TheseusLayer.forward forced to backward_mode='unroll'."""
+        def __getattr__(self, k):
+            return getattr(th, k)
+
+        class TheseusLayer(th.TheseusLayer):
+            def forward(self, inputs=None, optimizer_kwargs=None):
+                return super().forward(inputs, optimizer_kwargs=dict(optimizer_kwargs or {}, backward_mode="unroll"))
+    with pytest.raises(NotImplementedError, match="implicit"):
+        run_ba_implicit(Unroll(), g, OracleKernels(), "cpu")

@@ -18,7 +18,8 @@ def run_pg_unrolled(th, g, tag, device, kernels=None):
                   w_prior=t(g["w_prior"])[:, :, :1].clone().requires_grad_(True))
     obj = th.Objective(dtype=leaves["meas"].dtype)
     poses0 = t(g["poses0"])
-    poses = [th.SE3(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    G = {"SE2": th.SE2, "SO3": th.SO3}.get(str(g["group"]) if "group" in g else "SE3", th.SE3)
+    poses = [G(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
     # RobustCostFunction wrappers (fixtures lm_welsch_unroll / gn_huberflat_trunc): one learnable log_loss_radius
     robust = str(g[f"{tag}_robust"]) if f"{tag}_robust" in g else None
     wrap = lambda cf, nm: cf  # noqa: E731
@@ -29,11 +30,11 @@ def run_pg_unrolled(th, g, tag, device, kernels=None):
         wrap = lambda cf, nm: th.RobustCostFunction(cf, loss_cls, radius, name=nm, flatten_dims=robust.endswith("+flatten"))  # noqa: E731
     for k in range(g["edges"].shape[0]):
         i, j = g["edges"][k].tolist()
-        obj.add(wrap(th.Between(poses[i], poses[j], th.SE3(tensor=leaves["meas"][:, k], name=f"meas_{k}"),
+        obj.add(wrap(th.Between(poses[i], poses[j], G(tensor=leaves["meas"][:, k], name=f"meas_{k}"),
                                 th.DiagonalCostWeight(th.Variable(leaves["w_between"][:, k], name=f"w_{k}")), name=f"between_{k}"),
                      f"robust_between_{k}"))
     for k in range(g["prior_idx"].shape[0]):
-        cf = th.Difference(poses[int(g["prior_idx"][k])], th.SE3(tensor=leaves["prior_target"][:, k], name=f"prior_target_{k}"),
+        cf = th.Difference(poses[int(g["prior_idx"][k])], G(tensor=leaves["prior_target"][:, k], name=f"prior_target_{k}"),
                            th.ScaleCostWeight(th.Variable(leaves["w_prior"][:, k], name=f"pw_{k}")), name=f"prior_{k}")
         obj.add(wrap(cf, f"robust_prior_{k}") if robust and bool(g[f"{tag}_robust_prior"]) else cf)
     lkw = dict(linearization_kwargs=dict(kernels=kernels)) if kernels is not None else {}

@@ -165,6 +165,10 @@ _SIGNATURES = {
                    c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
     "thx_pg_unroll_vjp": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
+    "thx_pg2_unroll_vjp": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, POINTER(SE2Eps), c_void_p],
+    "thx_pgso3_unroll_vjp": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
     "thx_block_assemble": [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int64,
                            c_void_p, c_int64, c_int32, c_int, c_void_p],
     "thx_diag": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_int, c_void_p],

@@ -87,8 +87,28 @@ class ImplicitStep(torch.autograd.Function):
         return (None, None, None) + pg_vjp_grads(K, packed, t, w)
 
 
+def compose_left_backward(K, group: str, X, delta, step: float, G):
+    """grad w.r.t. X of X_new = X exp(step * delta) given G = grad_X_new (raw entries), as the reference's autograd produces it:
+    SE3 / SO3 -- torchlie's Compose.backward (se3_impl.py:739-747, so3_impl.py:702-707): the plain matrix rule
+    [G_R E_R^T + G_t E_t^T | G_t] / G E^T; SE2 -- plain autograd through theseus/geometry/se2.py's compose on [x, y, cos, sin]."""
+    P, B = X.shape[:2]
+    dof = delta.shape[1] // P
+    xi = (step * delta).view(B, P, dof).transpose(0, 1).reshape(P * B, dof).contiguous()
+    if group == "SE3":
+        E = K.se3_exp(xi).view(P, B, 3, 4)
+        return torch.cat([G[..., :3] @ E[..., :3].transpose(-1, -2) + G[..., 3:] @ E[..., 3:].transpose(-1, -2), G[..., 3:]], -1)
+    if group == "SO3":
+        E = K.so3_exp(xi).view(P, B, 3, 3)
+        return G @ E.transpose(-1, -2)
+    E = K.se2_exp(xi).view(P, B, 4)
+    ex, ey, ec, es = E.unbind(-1)
+    gx, gy, gc, gs = G.unbind(-1)
+    # x' = x + c ex - s ey,  y' = y + s ex + c ey,  c' = c ec - s es,  s' = s ec + c es
+    return torch.stack([gx, gy, gx * ex + gy * ey + gc * ec + gs * es, -gx * ey + gy * ex - gc * es + gs * ec], -1)
+
+
 class PGUnrolledIteration(torch.autograd.Function):
-    """One DIFFERENTIATED iteration of an SE3 pose graph (BackwardMode.UNROLL / TRUNCATED,
+    """One DIFFERENTIATED iteration of an SE3 / SE2 / SO3 pose graph (BackwardMode.UNROLL / TRUNCATED,
     theseus/optimizer/nonlinear/nonlinear_least_squares.py:223-292: the Hessian is part of the graph):
     ``X_new = X exp(step * delta)``, ``delta = (H(X, theta) + lambda I)^-1 g(X, theta)``.  Forward: the optimizer's own kernels
     at the detached iterate (assemble, damped factorisation, solves, retraction).  Backward, given grad_X_new (raw 3 x 4 entries):
@@ -136,26 +156,25 @@ class PGUnrolledIteration(torch.autograd.Function):
         G = G.contiguous()
         gd = torch.empty(B, n, dtype=dt, device=dev)
         K.retract_vjp(X, delta, step, G, gd)
-        # Compose.backward w.r.t. the left factor (se3_impl.py:739-747): [G_R E_R^T + G_t E_t^T | G_t], E = exp(step * delta)
-        E = K.se3_exp((step * delta).view(B, P, 6).transpose(0, 1).reshape(P * B, 6).contiguous()).view(P, B, 3, 4)
-        GX = torch.cat([G[..., :3] @ E[..., :3].transpose(-1, -2) + G[..., 3:] @ E[..., 3:].transpose(-1, -2), G[..., 3:]], -1)
+        GX = compose_left_backward(K, t.group, X, delta, step, G)
         if ctx.frozen is not None:           # frozen problems: X_new = X
             fz = ctx.frozen.bool()
             gd = gd * (~fz).to(dt).view(-1, 1)
-            GX = torch.where(fz.view(1, B, 1, 1), G, GX)
+            GX = torch.where(fz.view(1, B, *([1] * (X.dim() - 2))), G, GX)
         w = torch.empty_like(gd)
         K.chol_solve(ctx.L, n, ctx.panels, gd.contiguous(), w)
         s = packed.structure
         E_, Kp = s.num_edges, s.num_priors
         new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
-        gpi, gpj, gm, gwb = new(max(E_, 1), B, 3, 4), new(max(E_, 1), B, 3, 4), new(max(E_, 1), B, 3, 4), new(max(E_, 1), B, 6)
-        gpp, gt, gwp = new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 6)
+        rec, dof = tuple(X.shape[2:]), packed.dof       # group record (3,4) | (4,) | (3,3), tangent size 6 | 3 | 3
+        gpi, gpj, gm, gwb = new(max(E_, 1), B, *rec), new(max(E_, 1), B, *rec), new(max(E_, 1), B, *rec), new(max(E_, 1), B, dof)
+        gpp, gt, gwp = new(max(Kp, 1), B, *rec), new(max(Kp, 1), B, *rec), new(max(Kp, 1), B, dof)
         glb = new(max(E_, 1), B, 1) if t.robust_between else None
         glp = new(max(Kp, 1), B, 1) if t.robust_prior else None
         K.pg_unroll_vjp(packed.dstruct, t, w, delta, gpi, gpj, gm, gwb, gpp, gt, gwp, ell_damping=ctx.ell, g_lrb=glb, g_lrp=glp)
         # every pose's incident costs, in a fixed order: rows of [gpi ; gpj ; gpp ; 0]
         inc = packed.unroll_incidence(dev)
-        src = torch.cat([gpi[:E_], gpj[:E_], gpp[:Kp], new(1, B, 3, 4)], 0)
+        src = torch.cat([gpi[:E_], gpj[:E_], gpp[:Kp], new(1, B, *rec)], 0)
         GX = GX + src[inc].sum(1)
 
         def fit(g, count, like):   # (count, B, ...) -> the packed input's shape (count, 1|B, ...)

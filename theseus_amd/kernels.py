@@ -596,14 +596,15 @@ class HipKernels:
 
     def pg_unroll_vjp(self, s: DeviceStructure, t: PGTensors, w, delta, g_pose_i, g_pose_j, g_meas, g_wb, g_pose_p, g_tgt, g_wp,
                       poses=None, ell_damping=None, g_lrb=None, g_lrp=None):
-        """thx_pg_unroll_vjp (include/theseus_hip.h): the per-cost backward of one differentiated iteration of an SE3 pose graph."""
-        if t.group != "SE3":
-            raise NotImplementedError("differentiating through the iterations is fused for SE3 pose graphs")
+        """thx_pg_unroll_vjp / thx_pg2_unroll_vjp / thx_pgso3_unroll_vjp (include/theseus_hip.h): the per-cost backward of one
+        differentiated iteration of an SE3 / SE2 / SO3 pose graph."""
         dt = w.dtype
-        _lib.check(self.lib.thx_pg_unroll_vjp(s.c, t.c_struct(poses), _lib.ptr(w), w.stride(0), _lib.ptr(delta), delta.stride(0),
-                                              _lib.ptr(ell_damping), _lib.ptr(g_pose_i), _lib.ptr(g_pose_j), _lib.ptr(g_meas), _lib.ptr(g_wb),
-                                              _lib.ptr(g_pose_p), _lib.ptr(g_tgt), _lib.ptr(g_wp), _lib.ptr(g_lrb), _lib.ptr(g_lrp),
-                                              _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(w.device)), "thx_pg_unroll_vjp")
+        fn, eps = {"SE3": ("thx_pg_unroll_vjp", lie_eps), "SE2": ("thx_pg2_unroll_vjp", se2_eps),
+                   "SO3": ("thx_pgso3_unroll_vjp", lie_eps)}[t.group]
+        _lib.check(getattr(self.lib, fn)(s.c, t.c_struct(poses), _lib.ptr(w), w.stride(0), _lib.ptr(delta), delta.stride(0),
+                                         _lib.ptr(ell_damping), _lib.ptr(g_pose_i), _lib.ptr(g_pose_j), _lib.ptr(g_meas), _lib.ptr(g_wb),
+                                         _lib.ptr(g_pose_p), _lib.ptr(g_tgt), _lib.ptr(g_wp), _lib.ptr(g_lrb), _lib.ptr(g_lrp),
+                                         _lib.dtype_code(dt), eps(dt), _lib.stream_ptr(w.device)), fn)
 
     # ---- dense solver ---------------------------------------------------------------------------
     def chol_factor(self, H, n, damping, ellipsoidal, damping_eps, L, panels, info, rhs=None, y=None):

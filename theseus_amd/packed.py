@@ -364,11 +364,10 @@ class PackedPoseGraph:
     # ---- BackwardMode.UNROLL / TRUNCATED (theseus_amd/autograd.py:PGUnrolledIteration) ---------------------------------------
     def prepare_unroll(self):
         """Before the differentiable tail loop: re-pack the auxiliary tensors WITH their autograd history (once)."""
-        if self.group != "SE3":
+        if self.group not in ("SE3", "SE2", "SO3"):
             raise NotImplementedError(
-                "Differentiating through the iterations (backward_mode='unroll' / 'truncated') is fused for SE3 pose graphs "
-                f"(got {self.group}).  Use backward_mode='implicit' (one backward linear solve with the cached factor), or call "
-                "under torch.no_grad().")
+                "Differentiating through the iterations (backward_mode='unroll' / 'truncated') is fused for SE3 / SE2 / SO3 pose "
+                f"graphs (got {self.group}).  Use backward_mode='implicit', or call under torch.no_grad().")
         self.flush_variables()
         self.sync(force=True)
 

@@ -152,12 +152,13 @@ class _FusedUnrolledSolve(torch.autograd.Function):
         st = packed.structure
         E, Kp = st.num_edges, st.num_priors
         new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
-        gpi, gpj, gm, gwb = new(max(E, 1), B, 3, 4), new(max(E, 1), B, 3, 4), new(max(E, 1), B, 3, 4), new(max(E, 1), B, 6)
-        gpp, gt, gwp = new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 3, 4), new(max(Kp, 1), B, 6)
+        rec, dof = tuple(t.poses.shape[2:]), packed.dof
+        gpi, gpj, gm, gwb = new(max(E, 1), B, *rec), new(max(E, 1), B, *rec), new(max(E, 1), B, *rec), new(max(E, 1), B, dof)
+        gpp, gt, gwp = new(max(Kp, 1), B, *rec), new(max(Kp, 1), B, *rec), new(max(Kp, 1), B, dof)
         glb = new(max(E, 1), B, 1) if t.robust_between else None
         glp = new(max(Kp, 1), B, 1) if t.robust_prior else None
         K.pg_unroll_vjp(packed.dstruct, t, w, ctx.delta, gpi, gpj, gm, gwb, gpp, gt, gwp, ell_damping=ctx.ell, g_lrb=glb, g_lrp=glp)
-        GX = torch.cat([gpi[:E], gpj[:E], gpp[:Kp], new(1, B, 3, 4)], 0)[packed.unroll_incidence(dev)].sum(1)
+        GX = torch.cat([gpi[:E], gpj[:E], gpp[:Kp], new(1, B, *rec)], 0)[packed.unroll_incidence(dev)].sum(1)
 
         def fit(g, count, like):
             if g is None or like is None:
@@ -506,7 +507,7 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
             if graph and not _detach_hessian:
                 # backward_mode "unroll" / "truncated": the Hessian is part of the graph.  SE3 pose graphs: H and g are assembled
                 # at the detached values, solve() becomes ONE autograd node over (poses, auxiliary tensors) -- _FusedUnrolledSolve
-                packed.prepare_unroll()      # (refuses SE2 / SO3; re-packs poses and auxiliary tensors WITH history)
+                packed.prepare_unroll()      # (re-packs poses and auxiliary tensors WITH history)
                 t = packed.tensors
                 self._g_graph = None
                 self._assemble()
