@@ -124,6 +124,36 @@ struct Engine<float> {
 #pragma unroll
       for (int j = 0; j < 16; ++j) a.v[i][j] = 0.f;
   }
+#ifdef THX_KLOOP_PIPE
+  // EXPERIMENT (round 4): the fragment reads software-pipelined by hand -- hipcc emits "ds_read_b128; s_waitcnt lgkmcnt(0); 4 MFMAs"
+  // per A fragment; here the read of fragment n + 1 is issued before the MFMAs of fragment n (a two-deep register ring, the four
+  // B fragments of the chunk loaded up front) and the order is pinned with sched_group_barrier (0x100 = DS read, 0x008 = MFMA).
+  static __device__ __forceinline__ void chunk(const float* sA, const float* sBw, Acc& acc, int lane) {
+    const int rl = lane & 31, g = lane >> 5;
+    float4 fb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb[ks] = *reinterpret_cast<const float4*>(sBw + rl * 36 + 8 * ks + 4 * g);
+    auto ld = [&](int n) __attribute__((always_inline)) {   // fragment n = (ks, cb) = (n / 4, n % 4)
+      return *reinterpret_cast<const float4*>(sA + (32 * (n & 3) + rl) * 36 + 8 * (n >> 2) + 4 * g);
+    };
+    float4 ring[2];
+    ring[0] = ld(0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      if (n + 1 < 16) ring[(n + 1) & 1] = ld(n + 1);
+      const float4 fa = ring[n & 1];
+      const float4 b = fb[n >> 2];
+      const int cb = n & 3;
+      acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, b.x, acc.v[cb], 0, 0, 0);
+      acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, b.y, acc.v[cb], 0, 0, 0);
+      acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, b.z, acc.v[cb], 0, 0, 0);
+      acc.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, b.w, acc.v[cb], 0, 0, 0);
+      if (n + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+  }
+#else
   static __device__ __forceinline__ void chunk(const float* sA, const float* sBw, Acc& acc, int lane) {
     const int rl = lane & 31, g = lane >> 5;
 #pragma unroll
@@ -139,6 +169,7 @@ struct Engine<float> {
       }
     }
   }
+#endif
 
   // SYRK of the diagonal tile on the 36 lower 16x16 blocks of its 8x8 block grid, nine per wave: wave g owns block
   // rows 4+g (5+g blocks) and 3-g (4-g blocks) -- equal MFMA counts on all four SIMDs, 56 % of the full tile.
