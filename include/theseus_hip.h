@@ -477,6 +477,26 @@ int thx_ba_vjp(const thx_ba_structure* s, const thx_ba_data* d, const void* w, i
                void* grad_w_cam_prior, void* grad_pt_prior_target, void* grad_w_pt_prior, int dtype, const thx_lie_eps* eps,
                void* stream);
 
+/* BackwardMode.UNROLL / TRUNCATED on a bundle-adjustment objective (nonlinear_least_squares.py:223-292: the Hessian is part of
+ * the graph; thx_pg_unroll_vjp above has the derivation).  Per iteration, with w = (H + D)^-1 grad_delta (one Schur solve with that
+ * iteration's factor) and delta that iteration's step, both (B, n) in the internal column order [cameras | points]: per cost, the
+ * gradient of  phi = -(J w) . (r + J delta)  [- lambda sum_k w_k delta_k H_kk with ``ellipsoidal_damping`` = the (B) vector lambda
+ * of D = lambda diag(H) + eps; NULL for D = lambda I / none]  w.r.t. the raw entries of the camera (O,B,3,4) and the point (O,B,3) of
+ * every Reprojection cost, its feature (O,B,2), weights (O,B,2), calibration (PER OBSERVATION (O,B) each) and log_loss_radius (O,B;
+ * may be NULL); the camera (Kc,B,3,4), target (Kc,B,3,4) and weights (Kc,B,6) of every SE3 Difference prior; the point, target
+ * and weights (Kp,B,3 each) of every Point3 Difference prior.  The host sums cam_obs / cam_prior_cam over the costs of a camera
+ * and pt_obs / pt_prior_pt over the costs of a point.  RobustCostFunction is part of the graph (not detached,
+ * robust_cost_function.py:115-135).  Reference graph: reprojection.py:54-94 with SE3.transform_from's plain backward
+ * (torchlie/functional/se3_impl.py:757-800). */
+typedef struct {
+  void *cam_obs, *pt_obs, *feat, *w_obs, *focal, *k1, *k2, *log_radius_obs;
+  void *cam_prior_cam, *cam_prior_target, *w_cam_prior;
+  void *pt_prior_pt, *pt_prior_target, *w_pt_prior;
+} thx_ba_unroll_grads;
+int thx_ba_unroll_vjp(const thx_ba_structure* s, const thx_ba_data* d, const void* w, int64_t ldw, const void* delta, int64_t ldd,
+                      const void* ellipsoidal_damping, const thx_ba_unroll_grads* out, int dtype, const thx_lie_eps* eps,
+                      void* stream);
+
 /* linearize: Hcc, Hpp, W, gd (fp64) and g = [gc | gp], diag = diag(H) (dtype); row stride ldv for gd, g, diag */
 int thx_ba_assemble(const thx_ba_structure* s, const thx_ba_data* d, void* Hcc, void* Hpp, void* W, void* gd, void* g,
                     void* diag, int64_t ldv, int dtype, const thx_lie_eps* eps, void* stream);

@@ -1166,11 +1166,13 @@ def gen_ba(th, only=None):
               Np - len(pt_prior_idx))
 
 
-def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten=False, camcam=False):
+def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten=False, camcam=False, mode="implicit", okw=None):
     """Implicit backward through a bundle-adjustment objective (examples/bundle_adjustment.py:184-215 learns log_loss_radius this
     way): LM under no_grad, one undamped GN step with the Hessian detached and grad enabled; loss = <coef, final cameras> +
     <coef, final points>; gradients w.r.t. log_loss_radius, the image features, the calibration (focal, k1, k2), the
-    observation weight, the strong camera priors' targets and weight, the regularisers' weight."""
+    observation weight, the strong camera priors' targets and weight, the regularisers' weight.
+    ``mode`` = "unroll" / "truncated" (+ ``okw``: the optimizer kwargs): the same objective differentiated THROUGH its iterations
+    (nonlinear_least_squares.py:223-292) -- the ba_f64_*unroll* / *trunc* fixtures."""
     import theseus.utils.examples as theg
     dtype, robust = torch.float64, "huber"
     dims = dims or dict(num_cameras=6, num_points=40, average_track_length=4, track_locality=0.3)
@@ -1248,7 +1250,8 @@ def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten
         extra = dict(cc_edges=cc_edges)
     opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=not flatten, abs_err_tolerance=0.0,
                                 rel_err_tolerance=0.0, max_iterations=iters, step_size=1.0)
-    sol, info = th.TheseusLayer(opt, vectorize=not flatten).forward(optimizer_kwargs=dict(backward_mode="implicit", damping=1e-2))
+    okw = dict(damping=1e-2) if okw is None else dict(okw)
+    sol, info = th.TheseusLayer(opt, vectorize=not flatten).forward(optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **okw))
     used = sorted(set(obs_pt.tolist()))
     final_c = torch.stack([sol[f"Cam{i}"] for i in range(C)], 1)
     final_p = torch.stack([sol[f"Pt{i}"] for i in used], 1)
@@ -1272,7 +1275,8 @@ def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten
         grad_log_radius=d(leaves["log_radius"].grad), grad_feat=d(leaves["feat"].grad), grad_focal=d(leaves["focal"].grad),
         grad_k1=d(leaves["k1"].grad), grad_k2=d(leaves["k2"].grad), grad_w_obs=d(leaves["w_obs"].grad),
         grad_gt_cams=d(leaves["gt_cams"].grad), grad_w_strong=d(leaves["w_strong"].grad), grad_w_reg=d(leaves["w_reg"].grad),
-        opt_kwargs=np.array(repr(dict(max_iterations=iters, step_size=1.0, damping=1e-2, gauss_newton=False))),
+        opt_kwargs=np.array(repr(dict(okw, max_iterations=iters, step_size=1.0, gauss_newton=False, **({} if mode == "implicit" else {"backward_mode": mode})))),
+        err_history=info.err_history.numpy(),
         **extra, **({"cc_meas": d(leaves["cc_meas"]), "w_cc": d(leaves["w_cc"]), "grad_cc_meas": d(leaves["cc_meas"].grad),
                      "grad_w_cc": d(leaves["w_cc"].grad)} if camcam else {}))
     print(name, "loss", loss.item(), {k: float(v.grad.abs().max()) for k, v in leaves.items()})
@@ -1355,6 +1359,15 @@ def main():
         gen_ba_implicit(th, name="ba_f64_flatten_implicit", flatten=True)
     if not only or "ba_camcam_implicit" in only:
         gen_ba_implicit(th, name="ba_f64_camcam_implicit", camcam=True)
+    if not only or "ba_unrolled" in only:
+        # differentiating through the iterations of a bundle-adjustment objective: adaptive LM with ellipsoidal damping, all iterations;
+        # flatten_dims + spherical damping, the last two of four; camera-camera Between costs next to the reprojections
+        gen_ba_implicit(th, name="ba_f64_unroll_lm", iters=3, mode="unroll",
+                        okw=dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True))
+        gen_ba_implicit(th, name="ba_f64_flatten_trunc_lm", iters=4, flatten=True, mode="truncated",
+                        okw=dict(damping=1e-2, backward_num_iterations=2))
+        gen_ba_implicit(th, name="ba_f64_camcam_unroll_lm", iters=3, camcam=True, mode="unroll",
+                        okw=dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True))
     if "pg_full_f64_implicit" in only:     # (full size: asked for by name, ~1 min)
         gen_pg_full_implicit(th, lieF)
     if "ba_mid_f64_implicit" in only:      # 32 cameras: the reduced camera system takes two Cholesky tiles

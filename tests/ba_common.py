@@ -136,6 +136,7 @@ def run_ba_implicit(th, g, kernels=None, device="cpu", opt_kwargs=None):
                                th.DiagonalCostWeight(th.Variable(leaves["w_cc"][:, k], name=f"w_odo_{k}")), name=f"odometry_{k}"))
     kw = ast.literal_eval(str(g["opt_kwargs"]))
     kw.pop("gauss_newton")
+    mode = kw.pop("backward_mode", "implicit")     # ("unroll" / "truncated": the ba_f64_*unroll* / *trunc* fixtures)
     okw = dict(max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0)
     if kernels is not None:
         okw["linearization_kwargs"] = dict(kernels=kernels)
@@ -144,13 +145,14 @@ def run_ba_implicit(th, g, kernels=None, device="cpu", opt_kwargs=None):
     layer = th.TheseusLayer(opt)
     if device != "cpu" and opt_kwargs is not None:   # (the REAL theseus keeps Objective.device separately from its tensors')
         layer.to(device)
-    sol, info = layer.forward(None, optimizer_kwargs=dict(backward_mode="implicit", **kw))
+    sol, info = layer.forward(None, optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **kw))
     used = sorted(set(g["obs_pt"].tolist()))
     final_c = torch.stack([sol[f"Cam{i}"] for i in range(C)], 1)
     final_p = torch.stack([sol[f"Pt{i}"] for i in used], 1)
     loss = (t(g["coef_c"]) * final_c).sum() + (t(g["coef_p"]) * final_p).sum()
     loss.backward()
-    out = dict(final_cams=final_c.detach().cpu().numpy(), final_pts=final_p.detach().cpu().numpy(), loss=float(loss))
+    out = dict(final_cams=final_c.detach().cpu().numpy(), final_pts=final_p.detach().cpu().numpy(), loss=float(loss),
+               err_history=info.err_history.cpu().numpy())
     for k, v in leaves.items():
         out["grad_" + k] = v.grad.detach().cpu().numpy()
     return out

@@ -54,3 +54,23 @@ void hm_g3_vjp(int group, int edge, const double* Xi, const double* Xj, const do
   }
 }
 }
+
+// ---- bundle adjustment (theseus_amd/csrc/unroll_ba.cuh) ----
+#include "unroll_ba.cuh"
+
+extern "C" {
+
+// calib = [focal, k1, k2]; out: gcam[12] gX[3] gfeat[2] gs[2] gcal[3] glr[1]
+void hm_reproj_vjp(const double* cam, const double* X, const double* feat, const double* calib, const double* s, const double* wc,
+                   const double* wp, const double* dc, const double* dp, double lam, int loss, double log_radius, double* out) {
+  SE3<double> C;
+  load(cam, C);
+  unroll_reproj_vjp(C, X, feat, calib[0], calib[1], calib[2], s, wc, wp, dc, dp, lam, loss, log_radius, out, out + 12, out + 15,
+                    out + 17, out + 19, out + 22);
+}
+
+// out: gX[3] gT[3] gs[3]
+void hm_pt_prior_vjp(const double* X, const double* t, const double* s, const double* w, const double* d, double lam, double* out) {
+  unroll_pt_prior_vjp(X, t, s, w, d, lam, out, out + 3, out + 6);
+}
+}

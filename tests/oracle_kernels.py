@@ -231,6 +231,61 @@ class OracleKernels:
             elif g.shape[1] > 0:
                 out[:g.shape[1]].copy_(g.transpose(0, 1))
 
+    def ba_unroll_vjp(self, s, t, w, delta, grads, ell_damping=None):
+        """thx_ba_unroll_vjp: per cost, the gradient of Phi = -(J w) . (r + J delta) [- lambda sum_k w_k delta_k H_kk] (J, r with the
+        cost weight and the robust rescale) by torch autograd through the oracle's Reprojection / Difference formulas; every cost
+        owns a copy of its camera / point, so the gradients come out per cost as the kernel reports them."""
+        import dataclasses
+        from oracle import ba as oba
+        p, (cams, pts) = self._ba_problem(s, t)
+        B, C, Np, O = cams.shape[0], p.num_cams, p.num_points, p.obs_cam.numel()
+        Kc, Kp = p.cam_prior_idx.numel(), p.pt_prior_idx.numel()
+        wc, wp = w[:, :6 * C].reshape(B, C, 6), w[:, 6 * C:].reshape(B, Np, 3)
+        dc, dp = delta[:, :6 * C].reshape(B, C, 6), delta[:, 6 * C:].reshape(B, Np, 3)
+        lam = None if ell_damping is None else ell_damping.view(B, 1, 1)
+        mv = lambda J, v: (J @ v.unsqueeze(-1)).squeeze(-1)   # noqa: E731
+        with torch.enable_grad():
+            full = lambda a: a.detach().expand(B, *a.shape[1:]).clone().requires_grad_(True)  # noqa: E731
+            lv = dict(cam_obs=full(cams[:, p.obs_cam]), pt_obs=full(pts[:, p.obs_pt]), feat=full(p.feat), w_obs=full(p.w_obs),
+                      focal=full(p.focal[:, p.obs_cam]), k1=full(p.k1[:, p.obs_cam]), k2=full(p.k2[:, p.obs_cam]),
+                      cam_prior_cam=full(cams[:, p.cam_prior_idx]), cam_prior_target=full(p.cam_prior_target),
+                      w_cam_prior=full(p.w_cam_prior), pt_prior_pt=full(pts[:, p.pt_prior_idx]),
+                      pt_prior_target=full(p.pt_prior_target), w_pt_prior=full(p.w_pt_prior))
+            if p.robust_obs:
+                lv["log_radius_obs"] = full(p.log_radius_obs.expand(-1, O, 1))
+            phi = cams.new_zeros(())
+            if O:
+                Jc, Jp, e = oba.reprojection_jac_err(lv["cam_obs"], lv["pt_obs"], lv["feat"], lv["focal"], lv["k1"], lv["k2"])
+                ws = lv["w_obs"]
+                Jc, Jp, e = Jc * ws.unsqueeze(-1), Jp * ws.unsqueeze(-1), e * ws
+                (Jc, Jp), e = opg.robust_rescale([Jc, Jp], e, p.robust_obs, lv.get("log_radius_obs"))
+                wco, wpo, dco, dpo = wc[:, p.obs_cam], wp[:, p.obs_pt], dc[:, p.obs_cam], dp[:, p.obs_pt]
+                phi = phi - ((mv(Jc, wco) + mv(Jp, wpo)) * (e + mv(Jc, dco) + mv(Jp, dpo))).sum()
+                if lam is not None:
+                    phi = phi - (lam * ((Jc ** 2).sum(-2) * wco * dco)).sum() - (lam * ((Jp ** 2).sum(-2) * wpo * dpo)).sum()
+            if Kc:
+                Jq, eq = opg.local_jac_err(lv["cam_prior_target"], lv["cam_prior_cam"], lv["w_cam_prior"])
+                wq, dq = wc[:, p.cam_prior_idx], dc[:, p.cam_prior_idx]
+                phi = phi - (mv(Jq, wq) * (eq + mv(Jq, dq))).sum()
+                if lam is not None:
+                    phi = phi - (lam * (Jq ** 2).sum(-2) * wq * dq).sum()
+            if Kp:
+                sw = lv["w_pt_prior"]
+                et = (lv["pt_prior_pt"] - lv["pt_prior_target"]) * sw
+                wq, dq = wp[:, p.pt_prior_idx], dp[:, p.pt_prior_idx]
+                phi = phi - (sw * wq * (et + sw * dq)).sum()
+                if lam is not None:
+                    phi = phi - (lam * sw ** 2 * wq * dq).sum()
+            names = list(lv)
+            gr = dict(zip(names, torch.autograd.grad(phi, [lv[k] for k in names], allow_unused=True)))
+        for k, out in grads.items():
+            if out is None or k not in gr or lv[k].shape[1] == 0:
+                continue
+            g = gr[k] if gr[k] is not None else torch.zeros_like(lv[k])
+            if k in ("focal", "k1", "k2"):
+                g = g.squeeze(-1)
+            out[:g.shape[1]].copy_(g.transpose(0, 1))
+
     @staticmethod
     def _sym3(h):  # (..., 6) -> (..., 3, 3)
         return torch.stack([torch.stack([h[..., 0], h[..., 1], h[..., 2]], -1), torch.stack([h[..., 1], h[..., 3], h[..., 4]], -1),

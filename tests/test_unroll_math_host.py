@@ -187,3 +187,72 @@ def test_three_dof_groups_unrolled_vjp_matches_autograd_through_the_oracle(hostm
             continue
         want = leaves[k].grad.numpy().reshape(-1)
         np.testing.assert_allclose(out[sl], want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()), err_msg=f"prior {name}")
+
+
+# ---- bundle adjustment (theseus_amd/csrc/unroll_ba.cuh) -----------------------------------------------------------------------
+def _robust2(Js, e, spec, log_radius):
+    if spec is None:
+        return Js, e
+    Jr, er = opg.robust_rescale([J.view(1, 1, *J.shape) for J in Js], e.view(1, 1, 2), spec if "+" not in spec else [spec], log_radius)
+    return [J.view(2, -1) for J in Jr], er.view(2)
+
+
+@pytest.mark.parametrize("code,spec", LOSSES)
+@pytest.mark.parametrize("lam", [0.0, 0.37])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_reprojection_cost_unrolled_vjp_matches_autograd_through_the_oracle(hostmath, seed, lam, code, spec):
+    """Reprojection (reprojection.py:54-94) in thx_ba_unroll_vjp: camera, point, feature, weights, calibration, log_loss_radius."""
+    from oracle import ba as oba
+    f64 = torch.float64
+    gen = torch.Generator().manual_seed(200 + seed)
+    cam = _rand_pose(gen, 0.5, 0.4)
+    X = torch.randn(3, dtype=f64, generator=gen) * 0.5
+    X = lie.se3_inverse(cam)[:, :3] @ (torch.tensor([0.3, -0.2, -4.0], dtype=f64) + X * 0.3 - cam[:, 3])   # in front of the camera
+    calib = torch.tensor([500.0 + 30 * seed, -0.05 + 0.02 * seed, 0.01 * seed], dtype=f64)
+    s = 0.5 + torch.rand(2, dtype=f64, generator=gen)
+    wc, dc = (torch.randn(6, dtype=f64, generator=gen) * 0.05 for _ in range(2))
+    wp, dp = (torch.randn(3, dtype=f64, generator=gen) * 0.05 for _ in range(2))
+    with torch.no_grad():
+        e0 = oba.reprojection_jac_err(cam, X, torch.zeros(2, dtype=f64), calib[0:1], calib[1:2], calib[2:3])[2]
+    feat = e0 + torch.randn(2, dtype=f64, generator=gen) * 3.0          # a residual of a few pixels
+    x0 = float(((e0 - feat) * s).pow(2).sum())
+    lr = torch.tensor([[np.log(max(x0, 1e-12)) - 0.3 + 0.2 * seed]], dtype=f64)
+    leaves = [t.clone().requires_grad_(True) for t in (cam, X, feat, s, calib, lr)]
+    c_ = leaves[4]
+    Jc, Jp, e = oba.reprojection_jac_err(leaves[0], leaves[1], leaves[2], c_[0:1], c_[1:2], c_[2:3])
+    Jc, Jp, e = Jc * leaves[3].unsqueeze(-1), Jp * leaves[3].unsqueeze(-1), e * leaves[3]
+    (Jc, Jp), e = _robust2([Jc, Jp], e, spec, leaves[5])
+    phi = -((Jc @ wc + Jp @ wp) * (e + Jc @ dc + Jp @ dp)).sum()
+    phi = phi - lam * (((Jc ** 2).sum(0) * wc * dc).sum() + ((Jp ** 2).sum(0) * wp * dp).sum())
+    phi.backward()
+    out = np.zeros(23)
+    hostmath.hm_reproj_vjp.argtypes = [ctypes.POINTER(ctypes.c_double)] * 9 + [ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                                                                ctypes.POINTER(ctypes.c_double)]
+    hostmath.hm_reproj_vjp(*(_ptr(np.ascontiguousarray(t.detach().numpy().reshape(-1))) for t in (cam, X, feat, calib, s, wc, wp, dc, dp)),
+                           lam, code, float(lr), _ptr(out))
+    slices = (("cam", 0, slice(0, 12)), ("X", 1, slice(12, 15)), ("feat", 2, slice(15, 17)), ("s", 3, slice(17, 19)),
+              ("calib", 4, slice(19, 22)), ("log_radius", 5, slice(22, 23)))
+    for name, k, sl in slices:
+        if leaves[k].grad is None:
+            assert name == "log_radius" and out[22] == 0.0
+            continue
+        want = leaves[k].grad.numpy().reshape(-1)
+        np.testing.assert_allclose(out[sl], want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()), err_msg=name)
+
+
+@pytest.mark.parametrize("lam", [0.0, 0.37])
+def test_point_prior_unrolled_vjp_matches_autograd(hostmath, lam):
+    """Point3 Difference (vector.py:150-178: e = x - target, J = I) in thx_ba_unroll_vjp."""
+    f64 = torch.float64
+    gen = torch.Generator().manual_seed(5)
+    X, T, s, w, d = (torch.randn(3, dtype=f64, generator=gen) for _ in range(5))
+    leaves = [t.clone().requires_grad_(True) for t in (X, T, s)]
+    J = torch.diag_embed(leaves[2])
+    e = (leaves[0] - leaves[1]) * leaves[2]
+    phi = -((J @ w) * (e + J @ d)).sum() - lam * ((J ** 2).sum(0) * w * d).sum()
+    phi.backward()
+    out = np.zeros(9)
+    hostmath.hm_pt_prior_vjp.argtypes = [ctypes.POINTER(ctypes.c_double)] * 5 + [ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    hostmath.hm_pt_prior_vjp(*(_ptr(np.ascontiguousarray(t.detach().numpy())) for t in (X, T, s, w, d)), lam, _ptr(out))
+    for k, sl in enumerate((slice(0, 3), slice(3, 6), slice(6, 9))):
+        np.testing.assert_allclose(out[sl], leaves[k].grad.numpy(), rtol=0, atol=1e-12)

@@ -2,6 +2,7 @@
 theseus_amd/autograd.py:PGUnrolledIteration -- the chain over iterations, the retraction's two paths, the factor copies, the fixed
 order sum of the poses' gradients, accept / reject selects -- against the REAL reference's gradients.  The kernel's maths itself is
 checked without a GPU by tests/test_unroll_math_host.py, the kernel on the GPU by tests/test_gpu_unrolled.py."""
+import numpy as np
 import pytest
 
 from tests.helpers import load_golden
@@ -27,22 +28,32 @@ def test_differentiating_through_the_iterations_of_se2_and_so3_pose_graphs(fixtu
     run_pg_unrolled(th, load_golden(fixture), tag, "cpu", OracleKernels())
 
 
-def test_bundle_adjustment_refuses_unrolled_differentiation():
-    """Bundle adjustment does not differentiate through its iterations on the fused path: a loud NotImplementedError, no autograd /
-    CPU fallback."""
-    import torch
+BA_UNROLLED = ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm"]
+
+
+def check_ba_unrolled(g, got, grad_tol=5e-6):
+    np.testing.assert_allclose(got["final_cams"], g["final_cams"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(got["final_pts"], g["final_pts"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got["err_history"], g["err_history"], rtol=1e-6)
+    assert abs(got["loss"] - float(g["loss"])) < 1e-5
+    keys = ("log_radius", "feat", "focal", "k1", "k2", "w_obs", "gt_cams", "w_strong", "w_reg")
+    if "cc_edges" in g:
+        keys += ("cc_meas", "w_cc")
+    for k in keys:
+        want = g["grad_" + k]
+        np.testing.assert_allclose(got["grad_" + k], want, rtol=0, atol=grad_tol * max(np.abs(want).max(), 1e-12), err_msg=k)
+
+
+@pytest.mark.parametrize("name", BA_UNROLLED)
+def test_bundle_adjustment_unrolled_gradients_match_the_reference(name):
+    """BackwardMode.UNROLL / TRUNCATED on a bundle-adjustment objective (theseus_amd/ba.py:BAUnrolledIteration; TEST stand-in
+    kernels here, the HIP kernels in tests/test_gpu_unrolled.py) against the gradients the REAL reference produced
+    (oracle/gen_golden.py:gen_ba_implicit with mode="unroll" / "truncated"): adaptive LM with ellipsoidal damping through all
+    iterations; flatten_dims Huber + spherical damping through the last two of four; camera-camera Between costs next to the
+    reprojections.  Gradients w.r.t. log_loss_radius, the image features, the calibration, the observation weight, the strong
+    camera priors' targets / weight, the regularisers' weight (+ the odometry measurements / weights)."""
     import theseus_amd as th
     from tests.ba_common import run_ba_implicit
     from tests.oracle_kernels import OracleKernels
-    g = load_golden("ba_f64_implicit")
-
-    class Unroll:
-        """theseus_amd with TheseusLayer.forward forced to backward_mode='unroll'."""
-        def __getattr__(self, k):
-            return getattr(th, k)
-
-        class TheseusLayer(th.TheseusLayer):
-            def forward(self, inputs=None, optimizer_kwargs=None):
-                return super().forward(inputs, optimizer_kwargs=dict(optimizer_kwargs or {}, backward_mode="unroll"))
-    with pytest.raises(NotImplementedError, match="implicit"):
-        run_ba_implicit(Unroll(), g, OracleKernels(), "cpu")
+    g = load_golden(name)
+    check_ba_unrolled(g, run_ba_implicit(th, g, OracleKernels(), "cpu"))

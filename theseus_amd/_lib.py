@@ -47,6 +47,14 @@ class BAData(Structure):  # thx_ba_data
     ]
 
 
+BA_UNROLL_GRADS = ("cam_obs", "pt_obs", "feat", "w_obs", "focal", "k1", "k2", "log_radius_obs", "cam_prior_cam", "cam_prior_target",
+                   "w_cam_prior", "pt_prior_pt", "pt_prior_target", "w_pt_prior")
+
+
+class BAUnrollGrads(Structure):  # thx_ba_unroll_grads: per-cost outputs of thx_ba_unroll_vjp
+    _fields_ = [(k, c_void_p) for k in BA_UNROLL_GRADS]
+
+
 class TilePattern(Structure):  # thx_tile_pattern: tile-level symbolic factorisation (device int32 tables + one host table)
     _fields_ = [("ntiles", c_int32)] + [(k, c_void_p) for k in ("col_ptr", "col_row", "tile_kptr", "tile_k", "diag_kptr", "diag_k",
                                                                "col_count_host", "row_ptr", "row_tile",
@@ -127,6 +135,8 @@ _SIGNATURES = {
                   POINTER(LieEps), c_void_p],
     "thx_ba_vjp": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
+    "thx_ba_unroll_vjp": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_int64, c_void_p, c_int64, c_void_p, POINTER(BAUnrollGrads),
+                          c_int, POINTER(LieEps), c_void_p],
     "thx_copy_where": [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p],
     "thx_vec_retract": [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int,
                         c_void_p],

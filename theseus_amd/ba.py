@@ -8,6 +8,7 @@ EXACTLY by eliminating the points: fused block assembly (thx_ba_assemble), Schur
 back substitution (thx_ba_backsub).  Column order of this linearization: cameras, then points, each in objective order --
 a ``VariableOrdering`` like any user-supplied one (theseus/optimizer/linearization.py:18-41).
 """
+import contextlib
 import dataclasses
 from typing import Any, Dict, Optional, Type, Union
 
@@ -317,7 +318,20 @@ class PackedBA:
             return torch.stack(ts, dim=0).contiguous()
         return torch.stack([t.expand(B, *t.shape[1:]) for t in ts], dim=0).contiguous()
 
+    @contextlib.contextmanager
+    def pinned(self, tensors, cc_tensors=None):
+        """Run the kernels on ANOTHER snapshot of the problem (a saved iterate, in a backward pass): ``tensors`` / ``cc_tensors`` stand
+        in for the live ones and sync() leaves them alone."""
+        live, live_cc, was = self.tensors, self.cc_tensors, self.__dict__.get("_pinned", False)
+        self.tensors, self.cc_tensors, self._pinned = tensors, (cc_tensors if cc_tensors is not None else live_cc), True
+        try:
+            yield
+        finally:
+            self.tensors, self.cc_tensors, self._pinned = live, live_cc, was
+
     def sync(self, force: bool = False, deep: bool = False):
+        if self.__dict__.get("_pinned", False):
+            return
         deep = deep or not self._own_variables   # see PackedPoseGraph.sync
         if (not force and not deep and self.tensors is not None
                 and Variable._global_updates == self._global_stamp):
@@ -443,6 +457,25 @@ class PackedBA:
         else:
             self._vars_stale = True
         return old
+
+    # ---- BackwardMode.UNROLL / TRUNCATED (theseus_amd/nonlinear.py: the differentiable tail loop) ------------------------------
+    def prepare_unroll(self):
+        """Before the differentiable tail loop: re-pack the auxiliary tensors WITH their autograd history (once)."""
+        self.flush_variables()
+        self.sync(force=True)
+
+    def unrolled_step(self, opt, X, frozen: Optional[torch.Tensor], kwargs):
+        """(cams, points) -> ((cams exp(step * delta_c), points + step * delta_p) where not ``frozen``, delta) as ONE autograd node."""
+        t = self.tensors
+        cc = (self.cc_tensors.meas, self.cc_tensors.w_between) if self.cc_costs else ()
+        cams, pts, delta = BAUnrolledIteration.apply(opt, self, frozen, kwargs, X[0], X[1], t.feat, t.w_obs, t.focal, t.k1, t.k2,
+                                                     t.log_radius_obs, t.cam_prior_target, t.w_cam_prior, t.pt_prior_target,
+                                                     t.w_pt_prior, *cc)
+        return (cams, pts), delta
+
+    def where_state(self, mask: torch.Tensor, a, b):
+        """Per problem: ``a`` where ``mask`` else ``b`` (differentiable torch select on both halves of the state)."""
+        return (torch.where(mask.view(1, -1, 1, 1), a[0], b[0]), torch.where(mask.view(1, -1, 1), a[1], b[1]))
 
     def keep_where(self, mask, out):
         self.copy_where(mask, self.state, out)
@@ -848,6 +881,110 @@ class BAImplicitStep(torch.autograd.Function):
             fit = lambda g_, like: g_.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else g_  # noqa: E731
             grads = grads + (fit(g_meas, ct.meas), fit(g_wb, ct.w_between))
         return (None, None, None, None) + grads
+
+
+class BAUnrolledIteration(torch.autograd.Function):
+    """One DIFFERENTIATED iteration of a bundle-adjustment objective (BackwardMode.UNROLL / TRUNCATED,
+    theseus/optimizer/nonlinear/nonlinear_least_squares.py:223-292: the Hessian is part of the graph):
+    ``cams_new = cams exp(step * delta_c)``, ``points_new = points + step * delta_p``, ``delta = (H + D)^-1 g`` by point elimination.
+    Forward: the optimizer's own kernels at the detached iterate.  Backward, given the gradients of the new state: thx_se3_retract_vjp /
+    identity -> grad_delta; Compose.backward's matrix rule / identity -> the direct path; the iteration's Schur system is REBUILT at
+    the saved iterate with the saved damping (same kernels, same bits: the factor of a (B, 6C, 6C) reduced system per iteration is
+    not kept) and solved for w = (H + D)^-1 grad_delta; thx_ba_unroll_vjp(w, delta) [+ thx_pg_unroll_vjp over the camera columns for
+    camera-camera Between costs] -> per-cost gradients, summed per camera / point."""
+
+    @staticmethod
+    def forward(ctx, opt, packed, frozen, kwargs, cams, pts, *aux):
+        aux, cc_aux = aux[:len(BAImplicitStep.NAMES)], aux[len(BAImplicitStep.NAMES):]
+        solver = opt.linear_solver
+        lin, K = solver.linearization, packed.K
+        cd, pd = cams.detach().contiguous(), pts.detach().contiguous()
+        t = packed.tensors
+        t.cams, t.points = cd, pd                       # the kernels linearise at the tail loop's iterate
+        lin._assemble()
+        delta = opt.compute_delta(**kwargs)
+        if bool(solver.info.ne(0).any()):
+            try:
+                solver.check_info()
+            except RuntimeError as run_err:
+                raise RuntimeError(f"There was an error while running the linear optimizer. Original error message: {run_err}. "
+                                   "Backward pass will not work. To obtain the best solution seen before the error, run with "
+                                   "torch.no_grad()") from None
+        step = float(opt.params.step_size)
+        mask = frozen.to(torch.uint8).contiguous() if frozen is not None else None
+        new = (torch.empty_like(cd), torch.empty_like(pd))
+        packed.retract(delta, step, mask, new)
+        ctx.opt, ctx.packed, ctx.step, ctx.frozen = opt, packed, step, frozen
+        ctx.factor_args = solver._factor_args            # (lambda clone | None, ellipsoidal, eps) of THIS iteration
+        ctx.tensors = detached_ba_tensors(t, cd, pd, aux)
+        ctx.cc_tensors = None
+        if cc_aux:
+            ctx.cc_tensors = dataclasses.replace(packed.cc_tensors, poses=cd, meas=cc_aux[0].detach(), w_between=cc_aux[1].detach())
+        ctx.delta = delta.detach().clone()
+        ctx.mark_non_differentiable(delta)
+        return new[0], new[1], delta
+
+    @staticmethod
+    def backward(ctx, g_cams, g_pts, _g_delta):
+        packed, solver = ctx.packed, ctx.opt.linear_solver
+        lin, K, t, step, delta = solver.linearization, packed.K, ctx.tensors, ctx.step, ctx.delta
+        s = packed.structure
+        C, Np, B, n, nc = s.num_cams, s.num_points, t.cams.shape[1], lin.n, packed.nc
+        dt, dev = t.cams.dtype, t.cams.device
+        g_cams = torch.zeros_like(t.cams) if g_cams is None else g_cams.contiguous()
+        g_pts = torch.zeros_like(t.points) if g_pts is None else g_pts.contiguous()
+        gd = torch.zeros(B, n, dtype=dt, device=dev)
+        K.se3_retract_vjp(t.cams, delta, step, g_cams, gd)                                # camera columns [0, 6C)
+        gd[:, nc:] = g_pts.permute(1, 0, 2).reshape(B, -1) * step                         # X + step * delta
+        from .autograd import compose_left_backward
+        GC = compose_left_backward(K, "SE3", t.cams, delta[:, :nc].contiguous(), step, g_cams)
+        GP = g_pts
+        if ctx.frozen is not None:           # frozen problems: state_new = state
+            fz = ctx.frozen.bool()
+            gd = gd * (~fz).to(dt).view(-1, 1)
+            GC = torch.where(fz.view(1, B, 1, 1), g_cams, GC)
+        # this iteration's damped Schur system again (the buffers were overwritten by the later iterations)
+        lam, ell, eps = ctx.factor_args
+        with packed.pinned(t, ctx.cc_tensors):
+            lin._assemble()
+            solver._solve(lam, ell, eps, check_info=False)
+            w = solver.solve_with_factor(gd)
+        O, Kc, Kp = s.num_obs, s.num_cam_priors, s.num_pt_priors
+        new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
+        g = dict(cam_obs=new(max(O, 1), B, 3, 4), pt_obs=new(max(O, 1), B, 3), feat=new(max(O, 1), B, 2), w_obs=new(max(O, 1), B, 2),
+                 focal=new(max(O, 1), B), k1=new(max(O, 1), B), k2=new(max(O, 1), B),
+                 log_radius_obs=new(max(O, 1), B, 1) if t.robust_obs else None,
+                 cam_prior_cam=new(max(Kc, 1), B, 3, 4), cam_prior_target=new(max(Kc, 1), B, 3, 4), w_cam_prior=new(max(Kc, 1), B, 6),
+                 pt_prior_pt=new(max(Kp, 1), B, 3), pt_prior_target=new(max(Kp, 1), B, 3), w_pt_prior=new(max(Kp, 1), B, 3))
+        ell_lam = lam if (lam is not None and ell) else None
+        K.ba_unroll_vjp(packed.dstruct, t, w.contiguous(), delta, g, ell_damping=ell_lam)
+        idx = lambda key, cnt: torch.from_numpy(np.asarray(s.t[key][:cnt], dtype=np.int64)).to(dev)  # noqa: E731
+        oc, op = idx("obs_cam", O), idx("obs_pt", O)
+        GC = GC + torch.zeros_like(GC).index_add_(0, oc, g["cam_obs"][:O]).index_add_(0, idx("cam_prior_cam", Kc), g["cam_prior_cam"][:Kc])
+        GP = GP + torch.zeros_like(GP).index_add_(0, op, g["pt_obs"][:O]).index_add_(0, idx("pt_prior_pt", Kp), g["pt_prior_pt"][:Kp])
+        for k in ("focal", "k1", "k2"):      # calibration: per observation -> per camera
+            g[k] = torch.zeros(C, B, dtype=dt, device=dev).index_add_(0, oc, g[k][:O]).unsqueeze(2)
+
+        def fit(grad, count, like):   # (count, B, ...) -> the packed input's shape (count, 1|B, ...)
+            if grad is None or like is None:
+                return None
+            grad = grad[:count]
+            return grad.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else grad
+        grads = (fit(g["feat"], O, t.feat), fit(g["w_obs"], O, t.w_obs), fit(g["focal"], C, t.focal), fit(g["k1"], C, t.k1),
+                 fit(g["k2"], C, t.k2), fit(g["log_radius_obs"], O, t.log_radius_obs), fit(g["cam_prior_target"], Kc, t.cam_prior_target),
+                 fit(g["w_cam_prior"], Kc, t.w_cam_prior), fit(g["pt_prior_target"], Kp, t.pt_prior_target),
+                 fit(g["w_pt_prior"], Kp, t.w_pt_prior))
+        if ctx.cc_tensors is not None:   # camera-camera Between costs: thx_pg_unroll_vjp over the camera columns of w, delta
+            ct, st = ctx.cc_tensors, packed.cc_structure
+            E = st.num_edges
+            gpi, gpj, gm, gwb = new(E, B, 3, 4), new(E, B, 3, 4), new(E, B, 3, 4), new(E, B, 6)
+            K.pg_unroll_vjp(packed.cc_dstruct, ct, w[:, :nc].contiguous(), delta[:, :nc].contiguous(), gpi, gpj, gm, gwb,
+                            new(1, B, 3, 4), new(1, B, 3, 4), new(1, B, 6), ell_damping=ell_lam)
+            ei = torch.from_numpy(st.edge_i.astype(np.int64)).to(dev)
+            ej = torch.from_numpy(st.edge_j.astype(np.int64)).to(dev)
+            GC = GC + torch.zeros_like(GC).index_add_(0, ei, gpi).index_add_(0, ej, gpj)
+            grads = grads + (fit(gm, E, ct.meas), fit(gwb, E, ct.w_between))
+        return (None, None, None, None, GC, GP) + grads
 
 
 def ba_vjp_grads(K, packed, t, w):

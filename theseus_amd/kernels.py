@@ -500,6 +500,19 @@ class HipKernels:
         _lib.check(self.lib.thx_ba_vjp(s.c, d, _lib.ptr(w), w.stride(0), *[_lib.ptr(grads.get(k)) for k in order],
                                        _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(w.device)), "thx_ba_vjp")
 
+    def ba_unroll_vjp(self, s, t, w, delta, grads, ell_damping=None):
+        """thx_ba_unroll_vjp: ``grads`` = dict name -> preallocated tensor over _lib.BA_UNROLL_GRADS (log_radius_obs may be
+        missing); ``ell_damping`` (B,) lambda with ellipsoidal damping, else None."""
+        d = t.c_struct()
+        dt = w.dtype
+        out = _lib.BAUnrollGrads()
+        for k in _lib.BA_UNROLL_GRADS:
+            g = grads.get(k)
+            setattr(out, k, _lib.ptr(g).value if g is not None and g.numel() else None)
+        _lib.check(self.lib.thx_ba_unroll_vjp(s.c, d, _lib.ptr(w), w.stride(0), _lib.ptr(delta), delta.stride(0),
+                                              _lib.ptr(ell_damping), out, _lib.dtype_code(dt), lie_eps(dt),
+                                              _lib.stream_ptr(w.device)), "thx_ba_unroll_vjp")
+
     def copy_where(self, mask, src, dst):
         """dst[k, b] <- src[k, b] where mask[b]; src / dst (N, B, ...) contiguous, mask (B,) bool or uint8."""
         if src.shape != dst.shape or src.dtype != dst.dtype or not (src.is_contiguous() and dst.is_contiguous()):

@@ -520,7 +520,8 @@ class NonlinearLeastSquares(abc.ABC):
                 packed.flush_variables()
                 with torch.set_grad_enabled(outer_grad):
                     packed.prepare_unroll()
-                X = packed.state.detach()
+                det = lambda x: tuple(y.detach() for y in x) if isinstance(x, tuple) else x.detach()  # noqa: E731  (BA: (cams, points))
+                X = det(packed.state)
                 g_conv = torch.zeros(B, dtype=torch.bool, device=dev)
                 g_conv_iter = torch.zeros(B, dtype=torch.long, device=dev)   # the reference's counter: += 1 while not converged
                 g_status_conv = torch.zeros(B, dtype=torch.bool, device=dev)
@@ -528,7 +529,7 @@ class NonlinearLeastSquares(abc.ABC):
                 while g_it < tail_iters:
                     with torch.set_grad_enabled(outer_grad):
                         X_cand, delta = packed.unrolled_step(self, X, g_conv, kwargs)
-                    err_new = packed.error_metric(state=X_cand.detach())
+                    err_new = packed.error_metric(state=det(X_cand))
                     reject = self._complete_step(delta.detach(), err_new, g_last, step_size=p.step_size, **kwargs)
                     if reject is not None:
                         rb = reject.bool()
