@@ -111,7 +111,7 @@ def test_generic_path_optimizer_variants_match_the_reference(tag, cls, okw):
 def test_differentiating_through_the_iterations_matches_the_reference(tag):
     """BackwardMode.UNROLL / TRUNCATED on the generic path (nonlinear_least_squares.py:222-282: the Hessian is part of the graph):
     Gauss-Newton and adaptive (ellipsoidal) LM, with and without the convergence tests, against the REAL reference's gradients.
-    The fused pose-graph path refuses these modes when there is something to differentiate."""
+    (The fused pose-graph / bundle-adjustment paths: tests/test_unrolled_host.py.)"""
     import theseus_amd as th
     from tests.oracle_kernels import OracleKernels
     from tests.simple_example_common import run_unrolled

@@ -105,3 +105,63 @@ def test_ba_with_camera_camera_costs_implicit_backward_on_the_gpu():
     for k in ("log_radius", "feat", "focal", "k1", "k2", "w_obs", "gt_cams", "w_strong", "w_reg", "cc_meas", "w_cc"):
         want = g["grad_" + k]
         np.testing.assert_allclose(got["grad_" + k], want, rtol=0, atol=5e-6 * max(np.abs(want).max(), 1e-12), err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm"])
+def test_bundle_adjustment_unrolled_gradients_on_the_gpu(name):
+    """BackwardMode.UNROLL / TRUNCATED on a bundle-adjustment objective through the HIP kernels (thx_ba_unroll_vjp, the Schur system
+    of every differentiated iteration rebuilt and solved in the backward, thx_pg_unroll_vjp for the camera-camera costs) against the
+    REAL reference's gradients.  CPU twin: tests/test_unrolled_host.py; the kernel's maths on the host:
+    tests/test_unroll_math_host.py."""
+    import theseus_amd as th
+    from tests.ba_common import run_ba_implicit
+    from tests.test_unrolled_host import check_ba_unrolled
+    g = load_golden(name)
+    check_ba_unrolled(g, run_ba_implicit(th, g, None, "cuda"))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("ellipsoidal", [False, True])
+def test_ba_unroll_vjp_kernel_against_autograd_through_the_oracle(dtype, ellipsoidal):
+    """thx_ba_unroll_vjp on its own: the per-cost gradients for random w, delta (and lambda) against torch autograd through the
+    oracle's Reprojection / Difference formulas (tests/oracle_kernels.py:ba_unroll_vjp) on the same (fp32-rounded) inputs."""
+    import contextlib
+    import numpy as np
+    import torch
+    import theseus_amd as th
+    from tests.ba_common import build_ba_objective
+    from tests.helpers import f32_thresholds
+    from tests.oracle_kernels import OracleKernels
+    from theseus_amd import _lib
+    g = dict(load_golden("ba_f64_unroll_lm"))
+    if dtype == "f32":
+        g = {k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 and v.ndim > 0 else v) for k, v in g.items()}
+    g64 = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in g.items()}
+    packs = []
+    for gg, dev, K in ((g, "cuda", None), (g64, "cpu", OracleKernels())):
+        obj, _, _ = build_ba_objective(th, gg, dev)
+        lin = th.HipSchurLinearization(obj, **({} if K is None else dict(kernels=K)))
+        lin.packed.sync(force=True)
+        packs.append(lin.packed)
+    pd, pc = packs
+    B, n = pd.batch, pd.n
+    dt = torch.float64 if dtype == "f64" else torch.float32
+    gen = torch.Generator().manual_seed(11)
+    w, d = (torch.randn(B, n, dtype=torch.float64, generator=gen).to(dt) * 0.05 for _ in range(2))
+    lam = (0.01 + torch.rand(B, dtype=torch.float64, generator=gen)).to(dt) if ellipsoidal else None
+    s = pd.structure
+    O, Kc, Kp = s.num_obs, s.num_cam_priors, s.num_pt_priors
+    shapes = dict(cam_obs=(O, B, 3, 4), pt_obs=(O, B, 3), feat=(O, B, 2), w_obs=(O, B, 2), focal=(O, B), k1=(O, B), k2=(O, B),
+                  log_radius_obs=(O, B, 1), cam_prior_cam=(Kc, B, 3, 4), cam_prior_target=(Kc, B, 3, 4), w_cam_prior=(Kc, B, 6),
+                  pt_prior_pt=(Kp, B, 3), pt_prior_target=(Kp, B, 3), w_pt_prior=(Kp, B, 3))
+    assert set(shapes) == set(_lib.BA_UNROLL_GRADS)
+    got = {k: torch.zeros(*sh, dtype=dt, device="cuda") for k, sh in shapes.items()}
+    want = {k: torch.zeros(*sh, dtype=torch.float64) for k, sh in shapes.items()}
+    pd.K.ba_unroll_vjp(pd.dstruct, pd.tensors, w.cuda(), d.cuda(), got, ell_damping=None if lam is None else lam.cuda())
+    with (f32_thresholds() if dtype == "f32" else contextlib.nullcontext()):
+        pc.K.ba_unroll_vjp(pc.dstruct, pc.tensors, w.double(), d.double(), want, ell_damping=None if lam is None else lam.double())
+    tol = 1e-10 if dtype == "f64" else 5e-7
+    for k in shapes:
+        a, b_ = got[k].cpu().double(), want[k]
+        assert float(b_.abs().max()) > 0, k
+        assert (a - b_).abs().max() <= tol * max(1.0, float(b_.abs().max())), (k, float((a - b_).abs().max()), float(b_.abs().max()))

@@ -344,8 +344,8 @@ def test_mixed_robust_objective_matches_reference(name):
 def test_unrolled_gradients_of_a_pose_graph_match_reference(tag):
     """BackwardMode.UNROLL / TRUNCATED on an SE3 pose graph (the Hessian is part of the graph,
     nonlinear_least_squares.py:222-282): torch autograd THROUGH the oracle's loop reproduces the REAL reference's gradients
-    (tests/golden/pg_f64_unrolled.npz).  The fused HIP path refuses these modes today -- this pins the oracle the
-    kernels will be tested against."""
+    (tests/golden/pg_f64_unrolled.npz).  This pins the oracle the kernels are tested against
+    (tests/test_unroll_math_host.py, tests/test_gpu_unrolled.py)."""
     import ast
     import dataclasses
     g = load_golden("pg_f64_unrolled")
@@ -375,3 +375,44 @@ def test_unrolled_gradients_of_a_pose_graph_match_reference(tag):
     for key in ("meas", "w_between", "prior_target", "w_prior"):
         got, want = leaves[key].grad.numpy(), g[f"{tag}_grad_{key}"]
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
+
+
+@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm"])
+def test_unrolled_gradients_of_bundle_adjustment_match_reference(name):
+    """BackwardMode.UNROLL / TRUNCATED on a bundle-adjustment objective: torch autograd THROUGH the oracle's loop (oracle/ba.py's
+    Reprojection / Difference / Between restatements, the dense damped solve) reproduces the REAL reference's gradients
+    (oracle/gen_golden.py:gen_ba_implicit with mode="unroll" / "truncated").  This pins the oracle that thx_ba_unroll_vjp is tested
+    against (tests/oracle_kernels.py:ba_unroll_vjp, tests/test_unroll_math_host.py, tests/test_gpu_unrolled.py)."""
+    import dataclasses
+    from tests.helpers import ba_problem
+    g = load_golden(name)
+    p, state0, kw, used = ba_problem(g)
+    mode, iters, gn = kw.pop("backward_mode"), kw.pop("max_iterations"), kw.pop("gauss_newton")
+    k_grad = kw.pop("backward_num_iterations", iters) if mode == "truncated" else iters
+    n_reg = int(g["n_reg_cam"])
+    leaf = lambda x: x.clone().requires_grad_(True)  # noqa: E731
+    leaves = dict(feat=leaf(p.feat), focal=leaf(p.focal), k1=leaf(p.k1), k2=leaf(p.k2), log_radius=leaf(p.log_radius_obs),
+                  gt_cams=leaf(p.cam_prior_target[:, n_reg:]))
+    repl = dict(feat=leaves["feat"], focal=leaves["focal"], k1=leaves["k1"], k2=leaves["k2"], log_radius_obs=leaves["log_radius"],
+                cam_prior_target=torch.cat([p.cam_prior_target[:, :n_reg], leaves["gt_cams"]], 1))
+    if "cc_edges" in g:
+        leaves.update(cc_meas=leaf(p.cc_meas), w_cc=leaf(p.w_cc))
+        repl.update(cc_meas=leaves["cc_meas"], w_cc=leaves["w_cc"])
+    pg = dataclasses.replace(p, **repl)
+    common = dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0, gauss_newton=gn, **kw)
+    x, errs = state0, []
+    if iters - k_grad > 0:          # the no-grad head of TRUNCATED (fixed damping in the fixture: no state to carry over)
+        with torch.no_grad():
+            x, info = opg.lm_optimize(p, x, max_iterations=iters - k_grad, **common)
+        errs += info.err_history
+    x, info = opg.lm_optimize(pg, x, max_iterations=k_grad, **common)
+    errs += info.err_history[1:] if errs else info.err_history
+    np.testing.assert_allclose(x[0].detach().numpy(), g["final_cams"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(x[1].detach().numpy(), g["final_pts"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(torch.stack([e.detach() for e in errs], 1).numpy(), g["err_history"], rtol=1e-6)
+    loss = (torch.from_numpy(g["coef_c"]) * x[0]).sum() + (torch.from_numpy(g["coef_p"]) * x[1]).sum()
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-7
+    for key, v in leaves.items():
+        want = g["grad_" + key]
+        np.testing.assert_allclose(v.grad.numpy().reshape(want.shape), want, rtol=0, atol=2e-6 * max(np.abs(want).max(), 1e-12), err_msg=key)

@@ -441,6 +441,32 @@ def test_camera_camera_between_gradients_through_the_reference_loop(ref):
                                    err_msg=k)
 
 
+@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_camcam_unroll_lm"])
+def test_bundle_adjustment_unrolled_gradients_through_the_reference_loop(ref, name):
+    """backward_mode "unroll" on a bundle-adjustment objective through the REAL loop with the Schur path behind it: every
+    ``solve()`` is one autograd node over (cameras, points, auxiliary tensors) -- ``_FusedUnrolledSchurSolve`` (the call's Schur
+    system rebuilt in the backward, thx_ba_unroll_vjp [+ thx_pg_unroll_vjp for the odometry]); retraction and error evaluation in
+    between are the reference's own differentiable ops.  Gradients against the reference's own dense run."""
+    th, thp = ref
+    from tests.ba_common import run_ba_implicit
+    from tests.test_unrolled_host import check_ba_unrolled
+
+    class RefNames:
+        Objective, SE3, Point3, Point2, Vector, Variable, Difference, Between = (th.Objective, th.SE3, th.Point3, th.Point2, th.Vector,
+                                                                                th.Variable, th.Difference, th.Between)
+        ScaleCostWeight, DiagonalCostWeight = th.ScaleCostWeight, th.DiagonalCostWeight
+        RobustCostFunction, HuberLoss, WelschLoss = th.RobustCostFunction, th.HuberLoss, th.WelschLoss
+        Reprojection = th.eb.Reprojection
+        LevenbergMarquardt, TheseusLayer = th.LevenbergMarquardt, th.TheseusLayer
+    g = load_golden(name)
+    out = run_ba_implicit(RefNames, g, device=DEVICE,
+                          opt_kwargs=dict(linear_solver_cls=thp.HipSchurSolver, linearization_kwargs=_kernels(), vectorize=True))
+    for k in list(out):
+        if k.startswith("grad_"):
+            out[k] = out[k].reshape(g[k].shape)
+    check_ba_unrolled(g, out)
+
+
 def test_dogleg_on_bundle_adjustment_through_the_plugin(ref):
     """th.Dogleg needs ``linearization.Av``: for bundle adjustment the plugin answers from thx_ba_av (per-cost Jacobian blocks,
     no dense Jacobian).  Av against the reference's DenseLinearization under the same variable ordering, then the REAL

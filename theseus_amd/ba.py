@@ -883,6 +883,59 @@ class BAImplicitStep(torch.autograd.Function):
         return (None, None, None, None) + grads
 
 
+def ba_unroll_backward(packed, solver, t, cc_t, factor_args, delta, grad_delta):
+    """The part of an unrolled iteration's backward that both loops share (BAUnrolledIteration below, theseus_amd/plugin.py for
+    the reference's loop): given grad_delta (B, n), rebuild this iteration's damped Schur system at the saved tensors ``t`` (the
+    buffers were overwritten by the later iterations; same kernels, same bits), w = (H + D)^-1 grad_delta, thx_ba_unroll_vjp
+    [+ thx_pg_unroll_vjp over the camera columns for camera-camera Between costs].  Returns (grad_cams (C,B,3,4), grad_points
+    (Np,B,3), gradients of the auxiliary tensors in BAImplicitStep.NAMES order [+ cc_meas, w_cc])."""
+    lin, K = solver.linearization, packed.K
+    s = packed.structure
+    C, B, nc = s.num_cams, t.cams.shape[1], packed.nc
+    dt, dev = t.cams.dtype, t.cams.device
+    lam, ell, eps = factor_args
+    with packed.pinned(t, cc_t):
+        HipSchurLinearizationCore._assemble(lin)
+        solver._solve(lam, ell, eps, check_info=False)
+        w = solver.solve_with_factor(grad_delta.contiguous())
+    O, Kc, Kp = s.num_obs, s.num_cam_priors, s.num_pt_priors
+    new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
+    g = dict(cam_obs=new(max(O, 1), B, 3, 4), pt_obs=new(max(O, 1), B, 3), feat=new(max(O, 1), B, 2), w_obs=new(max(O, 1), B, 2),
+             focal=new(max(O, 1), B), k1=new(max(O, 1), B), k2=new(max(O, 1), B),
+             log_radius_obs=new(max(O, 1), B, 1) if t.robust_obs else None,
+             cam_prior_cam=new(max(Kc, 1), B, 3, 4), cam_prior_target=new(max(Kc, 1), B, 3, 4), w_cam_prior=new(max(Kc, 1), B, 6),
+             pt_prior_pt=new(max(Kp, 1), B, 3), pt_prior_target=new(max(Kp, 1), B, 3), w_pt_prior=new(max(Kp, 1), B, 3))
+    ell_lam = lam if (lam is not None and ell) else None
+    K.ba_unroll_vjp(packed.dstruct, t, w.contiguous(), delta, g, ell_damping=ell_lam)
+    idx = lambda key, cnt: torch.from_numpy(np.asarray(s.t[key][:cnt], dtype=np.int64)).to(dev)  # noqa: E731
+    oc, op = idx("obs_cam", O), idx("obs_pt", O)
+    GC = torch.zeros_like(t.cams).index_add_(0, oc, g["cam_obs"][:O]).index_add_(0, idx("cam_prior_cam", Kc), g["cam_prior_cam"][:Kc])
+    GP = torch.zeros_like(t.points).index_add_(0, op, g["pt_obs"][:O]).index_add_(0, idx("pt_prior_pt", Kp), g["pt_prior_pt"][:Kp])
+    for k in ("focal", "k1", "k2"):      # calibration: per observation -> per camera
+        g[k] = torch.zeros(C, B, dtype=dt, device=dev).index_add_(0, oc, g[k][:O]).unsqueeze(2)
+
+    def fit(grad, count, like):   # (count, B, ...) -> the packed input's shape (count, 1|B, ...)
+        if grad is None or like is None:
+            return None
+        grad = grad[:count]
+        return grad.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else grad
+    grads = (fit(g["feat"], O, t.feat), fit(g["w_obs"], O, t.w_obs), fit(g["focal"], C, t.focal), fit(g["k1"], C, t.k1),
+             fit(g["k2"], C, t.k2), fit(g["log_radius_obs"], O, t.log_radius_obs), fit(g["cam_prior_target"], Kc, t.cam_prior_target),
+             fit(g["w_cam_prior"], Kc, t.w_cam_prior), fit(g["pt_prior_target"], Kp, t.pt_prior_target),
+             fit(g["w_pt_prior"], Kp, t.w_pt_prior))
+    if cc_t is not None:   # camera-camera Between costs: thx_pg_unroll_vjp over the camera columns of w, delta
+        st = packed.cc_structure
+        E = st.num_edges
+        gpi, gpj, gm, gwb = new(E, B, 3, 4), new(E, B, 3, 4), new(E, B, 3, 4), new(E, B, 6)
+        K.pg_unroll_vjp(packed.cc_dstruct, cc_t, w[:, :nc].contiguous(), delta[:, :nc].contiguous(), gpi, gpj, gm, gwb,
+                        new(1, B, 3, 4), new(1, B, 3, 4), new(1, B, 6), ell_damping=ell_lam)
+        ei = torch.from_numpy(st.edge_i.astype(np.int64)).to(dev)
+        ej = torch.from_numpy(st.edge_j.astype(np.int64)).to(dev)
+        GC = GC.index_add_(0, ei, gpi).index_add_(0, ej, gpj)
+        grads = grads + (fit(gm, E, cc_t.meas), fit(gwb, E, cc_t.w_between))
+    return GC, GP, grads
+
+
 class BAUnrolledIteration(torch.autograd.Function):
     """One DIFFERENTIATED iteration of a bundle-adjustment objective (BackwardMode.UNROLL / TRUNCATED,
     theseus/optimizer/nonlinear/nonlinear_least_squares.py:223-292: the Hessian is part of the graph):
@@ -943,47 +996,8 @@ class BAUnrolledIteration(torch.autograd.Function):
             fz = ctx.frozen.bool()
             gd = gd * (~fz).to(dt).view(-1, 1)
             GC = torch.where(fz.view(1, B, 1, 1), g_cams, GC)
-        # this iteration's damped Schur system again (the buffers were overwritten by the later iterations)
-        lam, ell, eps = ctx.factor_args
-        with packed.pinned(t, ctx.cc_tensors):
-            lin._assemble()
-            solver._solve(lam, ell, eps, check_info=False)
-            w = solver.solve_with_factor(gd)
-        O, Kc, Kp = s.num_obs, s.num_cam_priors, s.num_pt_priors
-        new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
-        g = dict(cam_obs=new(max(O, 1), B, 3, 4), pt_obs=new(max(O, 1), B, 3), feat=new(max(O, 1), B, 2), w_obs=new(max(O, 1), B, 2),
-                 focal=new(max(O, 1), B), k1=new(max(O, 1), B), k2=new(max(O, 1), B),
-                 log_radius_obs=new(max(O, 1), B, 1) if t.robust_obs else None,
-                 cam_prior_cam=new(max(Kc, 1), B, 3, 4), cam_prior_target=new(max(Kc, 1), B, 3, 4), w_cam_prior=new(max(Kc, 1), B, 6),
-                 pt_prior_pt=new(max(Kp, 1), B, 3), pt_prior_target=new(max(Kp, 1), B, 3), w_pt_prior=new(max(Kp, 1), B, 3))
-        ell_lam = lam if (lam is not None and ell) else None
-        K.ba_unroll_vjp(packed.dstruct, t, w.contiguous(), delta, g, ell_damping=ell_lam)
-        idx = lambda key, cnt: torch.from_numpy(np.asarray(s.t[key][:cnt], dtype=np.int64)).to(dev)  # noqa: E731
-        oc, op = idx("obs_cam", O), idx("obs_pt", O)
-        GC = GC + torch.zeros_like(GC).index_add_(0, oc, g["cam_obs"][:O]).index_add_(0, idx("cam_prior_cam", Kc), g["cam_prior_cam"][:Kc])
-        GP = GP + torch.zeros_like(GP).index_add_(0, op, g["pt_obs"][:O]).index_add_(0, idx("pt_prior_pt", Kp), g["pt_prior_pt"][:Kp])
-        for k in ("focal", "k1", "k2"):      # calibration: per observation -> per camera
-            g[k] = torch.zeros(C, B, dtype=dt, device=dev).index_add_(0, oc, g[k][:O]).unsqueeze(2)
-
-        def fit(grad, count, like):   # (count, B, ...) -> the packed input's shape (count, 1|B, ...)
-            if grad is None or like is None:
-                return None
-            grad = grad[:count]
-            return grad.sum(1, keepdim=True) if like.shape[1] == 1 and B != 1 else grad
-        grads = (fit(g["feat"], O, t.feat), fit(g["w_obs"], O, t.w_obs), fit(g["focal"], C, t.focal), fit(g["k1"], C, t.k1),
-                 fit(g["k2"], C, t.k2), fit(g["log_radius_obs"], O, t.log_radius_obs), fit(g["cam_prior_target"], Kc, t.cam_prior_target),
-                 fit(g["w_cam_prior"], Kc, t.w_cam_prior), fit(g["pt_prior_target"], Kp, t.pt_prior_target),
-                 fit(g["w_pt_prior"], Kp, t.w_pt_prior))
-        if ctx.cc_tensors is not None:   # camera-camera Between costs: thx_pg_unroll_vjp over the camera columns of w, delta
-            ct, st = ctx.cc_tensors, packed.cc_structure
-            E = st.num_edges
-            gpi, gpj, gm, gwb = new(E, B, 3, 4), new(E, B, 3, 4), new(E, B, 3, 4), new(E, B, 6)
-            K.pg_unroll_vjp(packed.cc_dstruct, ct, w[:, :nc].contiguous(), delta[:, :nc].contiguous(), gpi, gpj, gm, gwb,
-                            new(1, B, 3, 4), new(1, B, 3, 4), new(1, B, 6), ell_damping=ell_lam)
-            ei = torch.from_numpy(st.edge_i.astype(np.int64)).to(dev)
-            ej = torch.from_numpy(st.edge_j.astype(np.int64)).to(dev)
-            GC = GC + torch.zeros_like(GC).index_add_(0, ei, gpi).index_add_(0, ej, gpj)
-            grads = grads + (fit(gm, E, ct.meas), fit(gwb, E, ct.w_between))
+        gC, gP, grads = ba_unroll_backward(packed, solver, t, ctx.cc_tensors, ctx.factor_args, delta, gd)
+        GC, GP = GC + gC, GP + gP
         return (None, None, None, None, GC, GP) + grads
 
 

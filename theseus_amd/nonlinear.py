@@ -237,7 +237,7 @@ class NonlinearLeastSquares(abc.ABC):
         # Differentiating THROUGH iterations (UNROLL: all of them, TRUNCATED: the last ``backward_num_iterations``;
         # nonlinear_least_squares.py:222-282): the Hessian is part of the graph there, i.e. the derivatives of every cost's
         # Jacobian are needed.  The generic path has them (its blocks come from torch: theseus_amd/euclidean.py); the fused
-        # pose-graph / bundle-adjustment kernels do not.
+        # pose-graph / bundle-adjustment paths have one autograd node per iteration (thx_pg*_unroll_vjp / thx_ba_unroll_vjp).
         unrolled = backward_mode in (BackwardMode.UNROLL, BackwardMode.TRUNCATED) and outer_grad and self._needs_grad()
         if unrolled and not hasattr(packed, "unrolled_step"):
             raise NotImplementedError(

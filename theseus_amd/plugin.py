@@ -20,7 +20,9 @@ Both feed ``thx_chol_factor_forward`` / ``thx_chol_solve_backward``.  Autograd: 
 (= ``_detach_hessian=True``, what ``backward_mode="implicit"`` asks for); ``Atb`` and ``solve()`` are
 differentiable -- the solve's backward is one ``thx_chol_solve`` with the cached factor, the fused ``Atb``'s backward
 is ``thx_pg_vjp``, the generic ``Atb`` is formed by torch from the reference's own differentiable Jacobians.
-Unrolled differentiation THROUGH the Hessian is refused.
+``backward_mode="unroll"`` / ``"truncated"`` (the Hessian in the graph): the generic path keeps H in torch's graph, the fused
+pose-graph / bundle-adjustment paths make ``solve()`` one autograd node over the packed state and auxiliary tensors
+(``_FusedUnrolledSolve`` / ``_FusedUnrolledSchurSolve``).
 
 ``theseus`` is imported at module import: this file is only usable where the reference is installed (it is not on
 the GPU box of this build; tests/test_plugin_reference.py exercises it in the container that has /root/reference).
@@ -720,7 +722,8 @@ class HipSparseCholeskySolver(HipSparseCholeskyCore, _RefCholeskyDenseSolver):
 
 
 # ---- bundle adjustment (theseus_amd/ba.py): Schur-complement linearization / solver for the REAL theseus loop ----------
-from .ba import BAImplicitStep, HipSchurLinearizationCore, HipSchurSolverCore, ba_vjp_grads, detached_ba_tensors  # noqa: E402
+from .ba import (BAImplicitStep, HipSchurLinearizationCore, HipSchurSolverCore, ba_unroll_backward, ba_vjp_grads,  # noqa: E402
+                 detached_ba_tensors)
 
 
 class _FusedAtbBA(torch.autograd.Function):
@@ -779,6 +782,37 @@ class _CachedSchurSolve(torch.autograd.Function):
         return None, None, None, None, solver.solve_with_factor(grad_delta.contiguous())
 
 
+class _FusedUnrolledSchurSolve(torch.autograd.Function):
+    """delta = (H(X, theta) + D)^-1 g(X, theta) of a bundle-adjustment objective as a differentiable function of the packed cameras,
+    points AND auxiliary tensors -- ``backward_mode="unroll"`` / ``"truncated"`` through the REAL loop (which linearizes with
+    ``_detach_hessian=False``, nonlinear_least_squares.py:100-135).  Forward: point elimination + the reduced system's factorisation
+    on the kernels.  Backward: ``ba_unroll_backward`` (theseus_amd/ba.py: the call's Schur system rebuilt at the saved tensors, one
+    solve, ``thx_ba_unroll_vjp``).  The retraction and the error evaluation in between are the reference's own differentiable ops."""
+
+    @staticmethod
+    def forward(ctx, solver, damping, ellipsoidal, eps, cams, pts, *aux):
+        import dataclasses
+        packed = solver.linearization.packed
+        n_aux = len(BAImplicitStep.NAMES)
+        aux, cc_aux = aux[:n_aux], aux[n_aux:]
+        delta = solver._solve(damping, ellipsoidal, eps, check_info=True).clone()
+        ctx.solver, ctx.factor_args = solver, solver._factor_args
+        ctx.tensors = detached_ba_tensors(packed.tensors, cams.detach(), pts.detach(), aux)
+        ctx.cc_tensors = None
+        if cc_aux:
+            ctx.cc_tensors = dataclasses.replace(packed.cc_tensors, poses=cams.detach(), meas=cc_aux[0].detach(),
+                                                 w_between=cc_aux[1].detach())
+        ctx.delta = delta.clone()
+        return delta
+
+    @staticmethod
+    def backward(ctx, grad_delta):
+        solver = ctx.solver
+        GC, GP, grads = ba_unroll_backward(solver.linearization.packed, solver, ctx.tensors, ctx.cc_tensors, ctx.factor_args,
+                                           ctx.delta, grad_delta)
+        return (None, None, None, None, GC, GP) + grads
+
+
 class HipSchurLinearization(HipSchurLinearizationCore, _RefLinearization):
     """``linearization_cls`` for bundle-adjustment objectives (SE3 cameras + Point3 points, th.eb.Reprojection optionally
     robust, th.Difference priors).  Sets ``ordering`` = cameras, then points -- the reference retracts and reads ``delta``
@@ -797,10 +831,18 @@ class HipSchurLinearization(HipSchurLinearizationCore, _RefLinearization):
     def _linearize_hessian_impl(self, _detach_hessian: bool = False):
         packed = self.packed
         graph = torch.is_grad_enabled() and any(v.tensor.requires_grad for v in packed.tracked_list())
+        self._unroll = None
         if graph and not _detach_hessian:
-            raise NotImplementedError(
-                "theseus_amd builds the Hessian outside autograd: differentiating through it (backward_mode='unroll' "
-                "with gradients) is not supported.  Use backward_mode='implicit', or run under torch.no_grad().")
+            # backward_mode "unroll" / "truncated": the Hessian is part of the graph -- blocks assembled at the detached values,
+            # solve() becomes ONE autograd node over (cameras, points, auxiliary tensors): _FusedUnrolledSchurSolve
+            packed.prepare_unroll()      # (re-packs the state and the auxiliary tensors WITH history)
+            t = packed.tensors
+            self._g_graph = None
+            self._assemble()
+            cc = (packed.cc_tensors.meas, packed.cc_tensors.w_between) if packed.cc_costs else ()
+            self._unroll = (t.cams, t.points, t.feat, t.w_obs, t.focal, t.k1, t.k2, t.log_radius_obs, t.cam_prior_target,
+                            t.w_cam_prior, t.pt_prior_target, t.w_pt_prior) + cc
+            return
         if graph:
             packed.sync(force=True)   # re-pack WITH the autograd history of the auxiliary variables
             t = packed.tensors
@@ -833,6 +875,11 @@ class HipSchurSolver(HipSchurSolverCore, _RefCholeskyDenseSolver):
 
     def solve(self, damping=None, ellipsoidal_damping: bool = True, damping_eps: float = 1e-8, **kwargs) -> torch.Tensor:
         g = self.linearization._g_graph
+        unroll = getattr(self.linearization, "_unroll", None)
+        if unroll is not None and torch.is_grad_enabled():
+            if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
+                raise ValueError("Damping must be a float or a 1-D tensor.")
+            return _FusedUnrolledSchurSolve.apply(self, damping, ellipsoidal_damping, damping_eps, *unroll)
         if g is not None and torch.is_grad_enabled():
             if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
                 raise ValueError("Damping must be a float or a 1-D tensor.")
