@@ -151,7 +151,7 @@ def run_ba_implicit(th, g, kernels=None, device="cpu", opt_kwargs=None):
     final_p = torch.stack([sol[f"Pt{i}"] for i in used], 1)
     loss = (t(g["coef_c"]) * final_c).sum() + (t(g["coef_p"]) * final_p).sum()
     loss.backward()
-    out = dict(final_cams=final_c.detach().cpu().numpy(), final_pts=final_p.detach().cpu().numpy(), loss=float(loss),
+    out = dict(final_cams=final_c.detach().cpu().numpy(), final_pts=final_p.detach().cpu().numpy(), loss=float(loss.detach()),
                err_history=info.err_history.cpu().numpy())
     for k, v in leaves.items():
         out["grad_" + k] = v.grad.detach().cpu().numpy()
