@@ -241,13 +241,12 @@ class NonlinearLeastSquares(abc.ABC):
         unrolled = backward_mode in (BackwardMode.UNROLL, BackwardMode.TRUNCATED) and outer_grad and self._needs_grad()
         if unrolled and not hasattr(packed, "unrolled_step"):
             raise NotImplementedError(
-                f"Differentiating through the iterations (backward_mode='{backward_mode.name.lower()}') is fused for generic "
-                f"(Euclidean) objectives and SE3 pose graphs, not for {getattr(packed, 'group', type(packed).__name__)} objectives: "
-                "the kernels are outside autograd.  Use backward_mode='implicit' (one backward linear solve with the cached "
-                "factor), or call under torch.no_grad().")
+                f"Differentiating through the iterations (backward_mode='{backward_mode.name.lower()}') needs a packer with "
+                f"unrolled_step() (generic, pose-graph and bundle-adjustment objectives have one; got {type(packed).__name__}).  "
+                "Use backward_mode='implicit', or call under torch.no_grad().")
         if unrolled and (track_best_solution or track_state_history or isinstance(self, TrustRegion)):
-            raise NotImplementedError("differentiable iterations on the generic path: Gauss-Newton / Levenberg-Marquardt, without "
-                                      "track_best_solution / track_state_history.")
+            raise NotImplementedError("differentiable iterations (backward_mode='unroll' / 'truncated' with gradients): Gauss-Newton / "
+                                      "Levenberg-Marquardt, without track_best_solution / track_state_history.")
         with torch.no_grad():
             packed.sync(deep=True)   # once per optimize(): also catches in-place edits of the variables' tensors
         self.reset(**kwargs, backward_mode=backward_mode)

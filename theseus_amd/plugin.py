@@ -523,10 +523,6 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
             else:
                 self._g_graph = None
                 self._assemble()
-        if graph and not _detach_hessian:
-            raise NotImplementedError(
-                "theseus_amd builds the Hessian outside autograd: differentiating through it (backward_mode='unroll' "
-                "with gradients) is not supported.  Use backward_mode='implicit', or run under torch.no_grad().")
 
     def Av(self, v: torch.Tensor) -> torch.Tensor:
         if self.fused:
