@@ -1653,8 +1653,11 @@ chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict
 
 __device__ __forceinline__ constexpr int bidx(int u, int v) { return u * (u + 1) / 2 + v; }
 
+#ifndef THX_POTRF_F64_WAVES_PER_SIMD
+#define THX_POTRF_F64_WAVES_PER_SIMD 1   // (experiment knob: 2 = at most 256 registers, the compiler spills the rest to scratch)
+#endif
 template <typename T>
-__global__ void __launch_bounds__(64, sizeof(T) == 4 ? 2 : 1)
+__global__ void __launch_bounds__(64, sizeof(T) == 4 ? 2 : THX_POTRF_F64_WAVES_PER_SIMD)
 chol_potrf_kernel(T* __restrict__ L, T* __restrict__ panel, int32_t* __restrict__ info, int n, int64_t pstride, int64_t tile_off,
                   int64_t ld, int j, int ntiles, T* __restrict__ yout, int64_t ldv) {
   // (the diagonal tile of problem b starts at L + b * pstride + tile_off, row stride ld: dense frame or tile-packed factor)
