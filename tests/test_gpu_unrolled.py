@@ -1,6 +1,8 @@
-"""-m gpu, collected LAST (features added after the round's last GPU run): BackwardMode.UNROLL / TRUNCATED on the generic path through the HIP kernels (thx_block_assemble, the
-tiled Cholesky's damped factorisation, thx_chol_solve with a copy of each iteration's factor in the backward) against the REAL
-reference's gradients (tests/golden/simple_example.npz).  CPU twin with the stand-in kernels: tests/test_generic_host.py."""
+"""-m gpu: BackwardMode.UNROLL / TRUNCATED through the HIP kernels -- the generic path (thx_block_assemble, the tiled Cholesky's
+damped factorisation, thx_chol_solve with a copy of each iteration's factor in the backward), SE3 / SE2 / SO3 pose graphs
+(thx_pg*_unroll_vjp) and bundle adjustment (thx_ba_unroll_vjp) -- against the REAL reference's gradients (tests/golden/), plus the
+bundle-adjustment objective with camera-camera costs.  CPU twins with the stand-in kernels: tests/test_generic_host.py,
+tests/test_unrolled_host.py; last run on the GPU: profiles/r4/j_pytest_gpu_unrolled_ba.txt."""
 import pytest
 
 from tests.helpers import load_golden
