@@ -1248,9 +1248,10 @@ def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten
                                th.DiagonalCostWeight(th.Variable(leaves["w_cc"][:, k], name=f"w_odo_{k}")), name=f"odometry_{k}"))
             cost_order.append(("cam_between", k))
         extra = dict(cc_edges=cc_edges)
-    opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=not flatten, abs_err_tolerance=0.0,
-                                rel_err_tolerance=0.0, max_iterations=iters, step_size=1.0)
     okw = dict(damping=1e-2) if okw is None else dict(okw)
+    rel_tol = okw.pop("__tol__", 0.0)      # (> 0: the convergence tests are on, problems are frozen inside the differentiated iterations)
+    opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=not flatten, abs_err_tolerance=0.0,
+                                rel_err_tolerance=rel_tol, max_iterations=iters, step_size=1.0)
     sol, info = th.TheseusLayer(opt, vectorize=not flatten).forward(optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **okw))
     used = sorted(set(obs_pt.tolist()))
     final_c = torch.stack([sol[f"Cam{i}"] for i in range(C)], 1)
@@ -1276,10 +1277,13 @@ def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten
         grad_k1=d(leaves["k1"].grad), grad_k2=d(leaves["k2"].grad), grad_w_obs=d(leaves["w_obs"].grad),
         grad_gt_cams=d(leaves["gt_cams"].grad), grad_w_strong=d(leaves["w_strong"].grad), grad_w_reg=d(leaves["w_reg"].grad),
         opt_kwargs=np.array(repr(dict(okw, max_iterations=iters, step_size=1.0, gauss_newton=False, **({} if mode == "implicit" else {"backward_mode": mode})))),
-        err_history=info.err_history.numpy(),
+        err_history=info.err_history.numpy(), rel_tol=rel_tol, converged_iter=info.converged_iter.numpy(),
+        status=np.array([int(s_.value) for s_ in info.status]),
         **extra, **({"cc_meas": d(leaves["cc_meas"]), "w_cc": d(leaves["w_cc"]), "grad_cc_meas": d(leaves["cc_meas"].grad),
                      "grad_w_cc": d(leaves["w_cc"].grad)} if camcam else {}))
     print(name, "loss", loss.item(), {k: float(v.grad.abs().max()) for k, v in leaves.items()})
+    if rel_tol:
+        print("   converged_iter", info.converged_iter.tolist(), "status", [s_.name for s_ in info.status], info.err_history.tolist())
 
 
 def gen_g2o(th):
@@ -1368,6 +1372,9 @@ def main():
                         okw=dict(damping=1e-2, backward_num_iterations=2))
         gen_ba_implicit(th, name="ba_f64_camcam_unroll_lm", iters=3, camcam=True, mode="unroll",
                         okw=dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True))
+        # convergence tests ON: the problems converge (and are frozen) at different differentiated iterations
+        gen_ba_implicit(th, name="ba_f64_trunc_conv_lm", iters=7, mode="truncated",
+                        okw=dict(damping=1e-2, backward_num_iterations=5, __tol__=1.2e-4))
     if "pg_full_f64_implicit" in only:     # (full size: asked for by name, ~1 min)
         gen_pg_full_implicit(th, lieF)
     if "ba_mid_f64_implicit" in only:      # 32 cameras: the reduced camera system takes two Cholesky tiles

@@ -137,7 +137,8 @@ def run_ba_implicit(th, g, kernels=None, device="cpu", opt_kwargs=None):
     kw = ast.literal_eval(str(g["opt_kwargs"]))
     kw.pop("gauss_newton")
     mode = kw.pop("backward_mode", "implicit")     # ("unroll" / "truncated": the ba_f64_*unroll* / *trunc* fixtures)
-    okw = dict(max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+    okw = dict(max_iterations=kw.pop("max_iterations"), step_size=kw.pop("step_size"), abs_err_tolerance=0.0,
+               rel_err_tolerance=float(g["rel_tol"]) if "rel_tol" in g else 0.0)   # (ba_f64_trunc_conv_lm: convergence tests on)
     if kernels is not None:
         okw["linearization_kwargs"] = dict(kernels=kernels)
     okw.update(opt_kwargs or {})
@@ -152,7 +153,8 @@ def run_ba_implicit(th, g, kernels=None, device="cpu", opt_kwargs=None):
     loss = (t(g["coef_c"]) * final_c).sum() + (t(g["coef_p"]) * final_p).sum()
     loss.backward()
     out = dict(final_cams=final_c.detach().cpu().numpy(), final_pts=final_p.detach().cpu().numpy(), loss=float(loss.detach()),
-               err_history=info.err_history.cpu().numpy())
+               err_history=info.err_history.cpu().numpy(), converged_iter=info.converged_iter.cpu().numpy(),
+               status=np.array([int(s_.value) for s_ in info.status]))
     for k, v in leaves.items():
         out["grad_" + k] = v.grad.detach().cpu().numpy()
     return out

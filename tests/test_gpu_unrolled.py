@@ -109,7 +109,7 @@ def test_ba_with_camera_camera_costs_implicit_backward_on_the_gpu():
         np.testing.assert_allclose(got["grad_" + k], want, rtol=0, atol=5e-6 * max(np.abs(want).max(), 1e-12), err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm"])
+@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm", "ba_f64_trunc_conv_lm"])
 def test_bundle_adjustment_unrolled_gradients_on_the_gpu(name):
     """BackwardMode.UNROLL / TRUNCATED on a bundle-adjustment objective through the HIP kernels (thx_ba_unroll_vjp, the Schur system
     of every differentiated iteration rebuilt and solved in the backward, thx_pg_unroll_vjp for the camera-camera costs) against the

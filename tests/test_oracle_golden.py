@@ -377,7 +377,7 @@ def test_unrolled_gradients_of_a_pose_graph_match_reference(tag):
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
 
 
-@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm"])
+@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm", "ba_f64_trunc_conv_lm"])
 def test_unrolled_gradients_of_bundle_adjustment_match_reference(name):
     """BackwardMode.UNROLL / TRUNCATED on a bundle-adjustment objective: torch autograd THROUGH the oracle's loop (oracle/ba.py's
     Reprojection / Difference / Between restatements, the dense damped solve) reproduces the REAL reference's gradients
@@ -399,7 +399,8 @@ def test_unrolled_gradients_of_bundle_adjustment_match_reference(name):
         leaves.update(cc_meas=leaf(p.cc_meas), w_cc=leaf(p.w_cc))
         repl.update(cc_meas=leaves["cc_meas"], w_cc=leaves["w_cc"])
     pg = dataclasses.replace(p, **repl)
-    common = dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0, gauss_newton=gn, **kw)
+    tol = float(g["rel_tol"]) if "rel_tol" in g else 0.0    # (ba_f64_trunc_conv_lm: the problems are frozen as they converge)
+    common = dict(abs_err_tolerance=0.0, rel_err_tolerance=tol, gauss_newton=gn, **kw)
     x, errs = state0, []
     if iters - k_grad > 0:          # the no-grad head of TRUNCATED (fixed damping in the fixture: no state to carry over)
         with torch.no_grad():
@@ -409,7 +410,8 @@ def test_unrolled_gradients_of_bundle_adjustment_match_reference(name):
     errs += info.err_history[1:] if errs else info.err_history
     np.testing.assert_allclose(x[0].detach().numpy(), g["final_cams"], rtol=0, atol=1e-8)
     np.testing.assert_allclose(x[1].detach().numpy(), g["final_pts"], rtol=0, atol=1e-7)
-    np.testing.assert_allclose(torch.stack([e.detach() for e in errs], 1).numpy(), g["err_history"], rtol=1e-6)
+    if tol == 0.0:
+        np.testing.assert_allclose(torch.stack([e.detach() for e in errs], 1).numpy(), g["err_history"], rtol=1e-6)
     loss = (torch.from_numpy(g["coef_c"]) * x[0]).sum() + (torch.from_numpy(g["coef_p"]) * x[1]).sum()
     loss.backward()
     assert abs(loss.item() - float(g["loss"])) < 1e-7

@@ -441,7 +441,7 @@ def test_camera_camera_between_gradients_through_the_reference_loop(ref):
                                    err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_camcam_unroll_lm"])
+@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_camcam_unroll_lm", "ba_f64_trunc_conv_lm"])
 def test_bundle_adjustment_unrolled_gradients_through_the_reference_loop(ref, name):
     """backward_mode "unroll" on a bundle-adjustment objective through the REAL loop with the Schur path behind it: every
     ``solve()`` is one autograd node over (cameras, points, auxiliary tensors) -- ``_FusedUnrolledSchurSolve`` (the call's Schur

@@ -28,7 +28,7 @@ def test_differentiating_through_the_iterations_of_se2_and_so3_pose_graphs(fixtu
     run_pg_unrolled(th, load_golden(fixture), tag, "cpu", OracleKernels())
 
 
-BA_UNROLLED = ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm"]
+BA_UNROLLED = ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm", "ba_f64_trunc_conv_lm"]
 
 
 def check_ba_unrolled(g, got, grad_tol=5e-6):
@@ -36,6 +36,9 @@ def check_ba_unrolled(g, got, grad_tol=5e-6):
     np.testing.assert_allclose(got["final_pts"], g["final_pts"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(got["err_history"], g["err_history"], rtol=1e-6)
     assert abs(got["loss"] - float(g["loss"])) < 1e-5
+    if "rel_tol" in g and float(g["rel_tol"]) > 0:   # convergence tests on: who converged, and when
+        np.testing.assert_array_equal(got["converged_iter"], g["converged_iter"])
+        np.testing.assert_array_equal(got["status"], g["status"])
     keys = ("log_radius", "feat", "focal", "k1", "k2", "w_obs", "gt_cams", "w_strong", "w_reg")
     if "cc_edges" in g:
         keys += ("cc_meas", "w_cc")
@@ -50,7 +53,8 @@ def test_bundle_adjustment_unrolled_gradients_match_the_reference(name):
     kernels here, the HIP kernels in tests/test_gpu_unrolled.py) against the gradients the REAL reference produced
     (oracle/gen_golden.py:gen_ba_implicit with mode="unroll" / "truncated"): adaptive LM with ellipsoidal damping through all
     iterations; flatten_dims Huber + spherical damping through the last two of four; camera-camera Between costs next to the
-    reprojections.  Gradients w.r.t. log_loss_radius, the image features, the calibration, the observation weight, the strong
+    reprojections; the convergence tests on (ba_f64_trunc_conv_lm: the three problems converge, and are frozen, at iterations 3, 4, 5
+    of which the last five are differentiated).  Gradients w.r.t. log_loss_radius, the image features, the calibration, the observation weight, the strong
     camera priors' targets / weight, the regularisers' weight (+ the odometry measurements / weights)."""
     import theseus_amd as th
     from tests.ba_common import run_ba_implicit
