@@ -634,7 +634,9 @@ def gen_pg_unrolled(th, lieF):
              # RobustCostFunction in the unrolled graph (robust_cost_function.py:115-135: the rescale is NOT detached): Welsch on every
              # Between cost with ONE learnable log_loss_radius; Huber with flatten_dims=True on the Between costs AND the prior
              ("lm_welsch_unroll", th.LevenbergMarquardt, "unroll", 4, dict(damping=0.05, __robust__=("welsch", False, False))),
-             ("gn_huberflat_trunc", th.GaussNewton, "truncated", 5, dict(backward_num_iterations=3, __robust__=("huber", True, True))))
+             ("gn_huberflat_trunc", th.GaussNewton, "truncated", 5, dict(backward_num_iterations=3, __robust__=("huber", True, True))),
+             # step_size 0.5: the retraction's step factor on both paths of the backward
+             ("lm_step_unroll", th.LevenbergMarquardt, "unroll", 3, dict(damping=0.05, __step__=0.5)))
     out = {}
     d = make_problem(dtype=dtype, th=th, lieF=lieF, P=6, E=10, B=3, seed=51, batched_weights=True, pose_noise=(0.2, 0.15))
     B, P = d["poses"].shape[:2]
@@ -648,6 +650,7 @@ def gen_pg_unrolled(th, lieF):
         wp = d["w_prior"][:, :, :1].clone().requires_grad_(True)
         okw = dict(okw)
         tol = okw.pop("__tol__", 0.0)
+        step = okw.pop("__step__", 1.0)
         robust = okw.pop("__robust__", None)    # (loss kind, flatten_dims, also on the priors)
         lr = torch.tensor([[0.0 if robust and robust[0] == "welsch" else -5.0]], dtype=dtype, requires_grad=True)   # log_loss_radius
         radius = th.Vector(tensor=lr, name="log_loss_radius")
@@ -665,7 +668,7 @@ def gen_pg_unrolled(th, lieF):
             obj.add(wrap(cf, f"robust_prior_{k}") if robust and robust[2] else cf)
         # (flatten_dims: the reference's vectorizer stacks the radii to (N B, 1) against (N B dim, 1) squared errors -- un-vectorized)
         vec = not (robust and robust[1])
-        opt = cls(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=vec, max_iterations=iters, step_size=1.0,
+        opt = cls(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=vec, max_iterations=iters, step_size=step,
                   abs_err_tolerance=0.0, rel_err_tolerance=tol)
         sol, info = th.TheseusLayer(opt, vectorize=vec).forward(optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **okw))
         final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
@@ -679,6 +682,8 @@ def gen_pg_unrolled(th, lieF):
             out.update({f"{tag}_robust": np.array(robust[0] + ("+flatten" if robust[1] else "")), f"{tag}_robust_prior": bool(robust[2]),
                         f"{tag}_log_radius": lr.detach().numpy(), f"{tag}_grad_log_radius": lr.grad.numpy()})
             print("   grad log_radius", lr.grad.item())
+        if step != 1.0:
+            out[f"{tag}_step"] = step
         if tol:
             out.update({f"{tag}_rel_tol": tol, f"{tag}_conv": info.converged_iter.numpy(),
                         f"{tag}_status": np.array([int(s_.value) for s_ in info.status])})
@@ -1250,8 +1255,9 @@ def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten
         extra = dict(cc_edges=cc_edges)
     okw = dict(damping=1e-2) if okw is None else dict(okw)
     rel_tol = okw.pop("__tol__", 0.0)      # (> 0: the convergence tests are on, problems are frozen inside the differentiated iterations)
+    step = okw.pop("__step__", 1.0)        # optimizer step_size
     opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=not flatten, abs_err_tolerance=0.0,
-                                rel_err_tolerance=rel_tol, max_iterations=iters, step_size=1.0)
+                                rel_err_tolerance=rel_tol, max_iterations=iters, step_size=step)
     sol, info = th.TheseusLayer(opt, vectorize=not flatten).forward(optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **okw))
     used = sorted(set(obs_pt.tolist()))
     final_c = torch.stack([sol[f"Cam{i}"] for i in range(C)], 1)
@@ -1276,7 +1282,7 @@ def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten
         grad_log_radius=d(leaves["log_radius"].grad), grad_feat=d(leaves["feat"].grad), grad_focal=d(leaves["focal"].grad),
         grad_k1=d(leaves["k1"].grad), grad_k2=d(leaves["k2"].grad), grad_w_obs=d(leaves["w_obs"].grad),
         grad_gt_cams=d(leaves["gt_cams"].grad), grad_w_strong=d(leaves["w_strong"].grad), grad_w_reg=d(leaves["w_reg"].grad),
-        opt_kwargs=np.array(repr(dict(okw, max_iterations=iters, step_size=1.0, gauss_newton=False, **({} if mode == "implicit" else {"backward_mode": mode})))),
+        opt_kwargs=np.array(repr(dict(okw, max_iterations=iters, step_size=step, gauss_newton=False, **({} if mode == "implicit" else {"backward_mode": mode})))),
         err_history=info.err_history.numpy(), rel_tol=rel_tol, converged_iter=info.converged_iter.numpy(),
         status=np.array([int(s_.value) for s_ in info.status]),
         **extra, **({"cc_meas": d(leaves["cc_meas"]), "w_cc": d(leaves["w_cc"]), "grad_cc_meas": d(leaves["cc_meas"].grad),
@@ -1372,6 +1378,10 @@ def main():
                         okw=dict(damping=1e-2, backward_num_iterations=2))
         gen_ba_implicit(th, name="ba_f64_camcam_unroll_lm", iters=3, camcam=True, mode="unroll",
                         okw=dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True))
+        # step_size 0.6 (the retraction's step factor on both paths of the backward), a smaller problem
+        gen_ba_implicit(th, name="ba_f64_step_unroll_lm", iters=3, mode="unroll", B=2,
+                        dims=dict(num_cameras=4, num_points=16, average_track_length=3, track_locality=0.5),
+                        okw=dict(damping=1e-2, ellipsoidal_damping=True, __step__=0.6))
         # convergence tests ON: the problems converge (and are frozen) at different differentiated iterations
         gen_ba_implicit(th, name="ba_f64_trunc_conv_lm", iters=7, mode="truncated",
                         okw=dict(damping=1e-2, backward_num_iterations=5, __tol__=1.2e-4))

@@ -18,7 +18,7 @@ def test_differentiating_through_the_iterations_on_the_gpu(tag):
 
 
 @pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll", "gn_trunc_conv", "lm_welsch_unroll",
-                                 "gn_huberflat_trunc"])
+                                 "gn_huberflat_trunc", "lm_step_unroll"])
 def test_differentiating_through_the_iterations_of_a_pose_graph_on_the_gpu(tag):
     """BackwardMode.UNROLL / TRUNCATED on an SE3 pose graph through the HIP kernels (thx_pg_unroll_vjp, thx_se3_retract_vjp,
     thx_chol_solve with a copy of each iteration's factor) against the REAL reference's gradients
@@ -109,7 +109,8 @@ def test_ba_with_camera_camera_costs_implicit_backward_on_the_gpu():
         np.testing.assert_allclose(got["grad_" + k], want, rtol=0, atol=5e-6 * max(np.abs(want).max(), 1e-12), err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm", "ba_f64_trunc_conv_lm"])
+@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm", "ba_f64_trunc_conv_lm",
+                                  "ba_f64_step_unroll_lm"])
 def test_bundle_adjustment_unrolled_gradients_on_the_gpu(name):
     """BackwardMode.UNROLL / TRUNCATED on a bundle-adjustment objective through the HIP kernels (thx_ba_unroll_vjp, the Schur system
     of every differentiated iteration rebuilt and solved in the backward, thx_pg_unroll_vjp for the camera-camera costs) against the

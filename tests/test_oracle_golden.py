@@ -340,7 +340,7 @@ def test_mixed_robust_objective_matches_reference(name):
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
 
 
-@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll"])
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll", "lm_step_unroll"])
 def test_unrolled_gradients_of_a_pose_graph_match_reference(tag):
     """BackwardMode.UNROLL / TRUNCATED on an SE3 pose graph (the Hessian is part of the graph,
     nonlinear_least_squares.py:222-282): torch autograd THROUGH the oracle's loop reproduces the REAL reference's gradients
@@ -358,7 +358,8 @@ def test_unrolled_gradients_of_a_pose_graph_match_reference(tag):
                   w_prior=p.w_prior[:, :, :1].clone().requires_grad_(True))
     pg = dataclasses.replace(p, meas=leaves["meas"], w_between=leaves["w_between"], prior_target=leaves["prior_target"],
                              w_prior=leaves["w_prior"].expand(-1, -1, p.dof))
-    common = dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0, gauss_newton=gn, **kw)
+    step = float(g[f"{tag}_step"]) if f"{tag}_step" in g else 1.0
+    common = dict(abs_err_tolerance=0.0, rel_err_tolerance=0.0, gauss_newton=gn, step_size=step, **kw)
     x = poses0
     errs = []
     if iters - k_grad > 0:          # the no-grad head of TRUNCATED (fixed damping in the fixture: no state to carry over)
@@ -377,7 +378,8 @@ def test_unrolled_gradients_of_a_pose_graph_match_reference(tag):
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
 
 
-@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm", "ba_f64_trunc_conv_lm"])
+@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm", "ba_f64_trunc_conv_lm",
+                                  "ba_f64_step_unroll_lm"])
 def test_unrolled_gradients_of_bundle_adjustment_match_reference(name):
     """BackwardMode.UNROLL / TRUNCATED on a bundle-adjustment objective: torch autograd THROUGH the oracle's loop (oracle/ba.py's
     Reprojection / Difference / Between restatements, the dense damped solve) reproduces the REAL reference's gradients

@@ -441,7 +441,7 @@ def test_camera_camera_between_gradients_through_the_reference_loop(ref):
                                    err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_camcam_unroll_lm", "ba_f64_trunc_conv_lm"])
+@pytest.mark.parametrize("name", ["ba_f64_unroll_lm", "ba_f64_camcam_unroll_lm", "ba_f64_trunc_conv_lm", "ba_f64_step_unroll_lm"])
 def test_bundle_adjustment_unrolled_gradients_through_the_reference_loop(ref, name):
     """backward_mode "unroll" on a bundle-adjustment objective through the REAL loop with the Schur path behind it: every
     ``solve()`` is one autograd node over (cameras, points, auxiliary tensors) -- ``_FusedUnrolledSchurSolve`` (the call's Schur
@@ -708,7 +708,8 @@ def test_reference_loop_differentiates_through_the_plugin_on_generic_objectives(
     np.testing.assert_allclose(info.err_history.numpy(), r("err"), rtol=1e-6)
 
 
-@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll", "gn_trunc_conv", "lm_welsch_unroll"])
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll", "gn_trunc_conv", "lm_welsch_unroll",
+                                 "lm_step_unroll"])
 def test_reference_loop_differentiates_through_the_plugin_on_se3_pose_graphs(ref, tag):
     """backward_mode "unroll" / "truncated" on an SE3 pose graph through the REAL loop with the FUSED path behind it: the
     reference linearizes with the Hessian in the graph (nonlinear_least_squares.py:100-135); the plugin assembles H, g with the
@@ -740,8 +741,8 @@ def test_reference_loop_differentiates_through_the_plugin_on_se3_pose_graphs(ref
                               th.ScaleCostWeight(th.Variable(wp[:, k], name=f"pw_{k}")), name=f"prior_{k}"))
     cls = th.GaussNewton if gn else th.LevenbergMarquardt
     opt = cls(obj, linear_solver_cls=thp.HipCholeskySolver, linearization_cls=thp.HipLinearization, linearization_kwargs=_kernels(),
-              vectorize=True, max_iterations=iters, step_size=1.0, abs_err_tolerance=0.0,
-              rel_err_tolerance=float(g[f"{tag}_rel_tol"]) if f"{tag}_rel_tol" in g else 0.0)
+              vectorize=True, max_iterations=iters, step_size=float(g[f"{tag}_step"]) if f"{tag}_step" in g else 1.0,
+              abs_err_tolerance=0.0, rel_err_tolerance=float(g[f"{tag}_rel_tol"]) if f"{tag}_rel_tol" in g else 0.0)
     assert opt.linear_solver.linearization.fused
     layer = th.TheseusLayer(opt)
     if DEVICE != "cpu":

@@ -10,7 +10,7 @@ from tests.unrolled_common import run_pg_unrolled
 
 
 @pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll", "gn_trunc_conv", "lm_welsch_unroll",
-                                 "gn_huberflat_trunc"])
+                                 "gn_huberflat_trunc", "lm_step_unroll"])
 def test_differentiating_through_the_iterations_of_a_pose_graph(tag):
     import theseus_amd as th
     from tests.oracle_kernels import OracleKernels
@@ -28,7 +28,7 @@ def test_differentiating_through_the_iterations_of_se2_and_so3_pose_graphs(fixtu
     run_pg_unrolled(th, load_golden(fixture), tag, "cpu", OracleKernels())
 
 
-BA_UNROLLED = ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm", "ba_f64_trunc_conv_lm"]
+BA_UNROLLED = ["ba_f64_unroll_lm", "ba_f64_flatten_trunc_lm", "ba_f64_camcam_unroll_lm", "ba_f64_trunc_conv_lm", "ba_f64_step_unroll_lm"]
 
 
 def check_ba_unrolled(g, got, grad_tol=5e-6):

@@ -40,7 +40,8 @@ def run_pg_unrolled(th, g, tag, device, kernels=None):
     lkw = dict(linearization_kwargs=dict(kernels=kernels)) if kernels is not None else {}
     cls = th.GaussNewton if gn else th.LevenbergMarquardt
     tol = float(g[f"{tag}_rel_tol"]) if f"{tag}_rel_tol" in g else 0.0
-    opt = cls(obj, max_iterations=iters, step_size=1.0, abs_err_tolerance=0.0, rel_err_tolerance=tol, **lkw)
+    step = float(g[f"{tag}_step"]) if f"{tag}_step" in g else 1.0
+    opt = cls(obj, max_iterations=iters, step_size=step, abs_err_tolerance=0.0, rel_err_tolerance=tol, **lkw)
     sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **kw))
     final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
     loss = (t(g["coef"]) * final).sum()
