@@ -602,11 +602,14 @@ def gen_simple_example(th):
         obj4.add(th.AutoDiffCostFunction([a4, b4], error_fn2, 12, aux_vars=[x4, y4],
                                          cost_weight=th.DiagonalCostWeight(th.Variable(wl, name="w"))))
         opt4 = cls(obj4, max_iterations=iters, abs_err_tolerance=tol, rel_err_tolerance=tol)
+        a0 = torch.ones(6, 1, dtype=dtype, requires_grad=True)            # the INITIAL values are leaves too (UNROLL reaches them)
+        b0 = (2.5 * torch.ones(6, 1, dtype=dtype)).requires_grad_(True)
         sol4, info4 = th.TheseusLayer(opt4).forward(
-            input_tensors={"a": torch.ones(6, 1, dtype=dtype), "b": 2.5 * torch.ones(6, 1, dtype=dtype)},
-            optimizer_kwargs=dict(track_err_history=True, backward_mode=mode, **okw))
+            input_tensors={"a": a0, "b": b0}, optimizer_kwargs=dict(track_err_history=True, backward_mode=mode, **okw))
         loss4 = ((sol4["a"] - 0.5) ** 2).mean() + ((sol4["b"] - 1.0) ** 2).mean()
         loss4.backward()
+        if a0.grad is not None:
+            out.update({f"u_{tag}_ga0": a0.grad.numpy(), f"u_{tag}_gb0": b0.grad.numpy()})
         out.update({f"u_{tag}_a": sol4["a"].detach().numpy(), f"u_{tag}_b": sol4["b"].detach().numpy(), f"u_{tag}_loss": loss4.item(),
                     f"u_{tag}_gx": xl.grad.numpy(), f"u_{tag}_gy": yl.grad.numpy(), f"u_{tag}_gw": wl.grad.numpy(),
                     f"u_{tag}_err": info4.err_history.numpy(), f"u_{tag}_conv": info4.converged_iter.numpy(),
@@ -657,7 +660,8 @@ def gen_pg_unrolled(th, lieF):
         wrap = lambda cf, nm: cf if not robust else th.RobustCostFunction(  # noqa: E731
             cf, th.WelschLoss if robust[0] == "welsch" else th.HuberLoss, radius, name=nm, flatten_dims=robust[1])
         obj = th.Objective(dtype=dtype)
-        poses = [th.SE3(tensor=d["poses"][:, k].clone(), name=f"pose_{k}") for k in range(P)]
+        p0 = d["poses"].clone().requires_grad_(True)     # the INITIAL values are leaves too (UNROLL reaches them, TRUNCATED's head is no_grad)
+        poses = [th.SE3(tensor=p0[:, k], name=f"pose_{k}") for k in range(P)]
         for k in range(d["edges"].shape[0]):
             i, j = d["edges"][k].tolist()
             obj.add(wrap(th.Between(poses[i], poses[j], th.SE3(tensor=meas[:, k], name=f"meas_{k}"),
@@ -682,6 +686,8 @@ def gen_pg_unrolled(th, lieF):
             out.update({f"{tag}_robust": np.array(robust[0] + ("+flatten" if robust[1] else "")), f"{tag}_robust_prior": bool(robust[2]),
                         f"{tag}_log_radius": lr.detach().numpy(), f"{tag}_grad_log_radius": lr.grad.numpy()})
             print("   grad log_radius", lr.grad.item())
+        if p0.grad is not None:
+            out[f"{tag}_grad_poses0"] = p0.grad.numpy()
         if step != 1.0:
             out[f"{tag}_step"] = step
         if tol:
@@ -1204,8 +1210,14 @@ def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten
     obs_cam = np.array([o.camera_index for o in ba.observations], dtype=np.int64)
     obs_pt = np.array([int(o.point_index) for o in ba.observations], dtype=np.int64)
     obj = th.Objective(dtype=dtype)
-    cam_v = [th.SE3(tensor=cams0[:, i].clone(), name=f"Cam{i}") for i in range(C)]
-    pt_v = [th.Point3(tensor=pts0[:, i].clone(), name=f"Pt{i}") for i in range(Np)]
+    if mode == "unroll":    # the INITIAL values are leaves too: UNROLL differentiates from the first iteration
+        leaves["cams0"] = cams0.clone().requires_grad_(True)
+        leaves["pts0"] = pts0.clone().requires_grad_(True)
+        cam_v = [th.SE3(tensor=leaves["cams0"][:, i], name=f"Cam{i}") for i in range(C)]
+        pt_v = [th.Point3(tensor=leaves["pts0"][:, i], name=f"Pt{i}") for i in range(Np)]
+    else:
+        cam_v = [th.SE3(tensor=cams0[:, i].clone(), name=f"Cam{i}") for i in range(C)]
+        pt_v = [th.Point3(tensor=pts0[:, i].clone(), name=f"Pt{i}") for i in range(Np)]
     fl = [th.Vector(tensor=leaves["focal"][:, i], name=f"fl{i}") for i in range(C)]
     k1v = [th.Vector(tensor=leaves["k1"][:, i], name=f"k1_{i}") for i in range(C)]
     k2v = [th.Vector(tensor=leaves["k2"][:, i], name=f"k2_{i}") for i in range(C)]
@@ -1283,6 +1295,7 @@ def gen_ba_implicit(th, name="ba_f64_implicit", dims=None, B=3, iters=5, flatten
         grad_k1=d(leaves["k1"].grad), grad_k2=d(leaves["k2"].grad), grad_w_obs=d(leaves["w_obs"].grad),
         grad_gt_cams=d(leaves["gt_cams"].grad), grad_w_strong=d(leaves["w_strong"].grad), grad_w_reg=d(leaves["w_reg"].grad),
         opt_kwargs=np.array(repr(dict(okw, max_iterations=iters, step_size=step, gauss_newton=False, **({} if mode == "implicit" else {"backward_mode": mode})))),
+        **({"grad_cams0": d(leaves["cams0"].grad), "grad_pts0": d(leaves["pts0"].grad)} if mode == "unroll" else {}),
         err_history=info.err_history.numpy(), rel_tol=rel_tol, converged_iter=info.converged_iter.numpy(),
         status=np.array([int(s_.value) for s_ in info.status]),
         **extra, **({"cc_meas": d(leaves["cc_meas"]), "w_cc": d(leaves["w_cc"]), "grad_cc_meas": d(leaves["cc_meas"].grad),

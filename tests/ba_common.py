@@ -105,8 +105,13 @@ def run_ba_implicit(th, g, kernels=None, device="cpu", opt_kwargs=None):
     leaves = {k: v.clone().requires_grad_(True) for k, v in leaves.items()}
     cams0, pts0 = t(g["cams0"]), t(g["pts0"])
     obj = th.Objective(dtype=dtype)
-    cam_v = [th.SE3(tensor=cams0[:, i].clone(), name=f"Cam{i}") for i in range(C)]
-    pt_v = [th.Point3(tensor=pts0[:, i].clone(), name=f"Pt{i}") for i in range(Np)]
+    if "grad_cams0" in g:   # UNROLL fixtures: the gradient reaches the INITIAL cameras / points too
+        leaves["cams0"], leaves["pts0"] = cams0.clone().requires_grad_(True), pts0.clone().requires_grad_(True)
+        cam_v = [th.SE3(tensor=leaves["cams0"][:, i], name=f"Cam{i}") for i in range(C)]
+        pt_v = [th.Point3(tensor=leaves["pts0"][:, i], name=f"Pt{i}") for i in range(Np)]
+    else:
+        cam_v = [th.SE3(tensor=cams0[:, i].clone(), name=f"Cam{i}") for i in range(C)]
+        pt_v = [th.Point3(tensor=pts0[:, i].clone(), name=f"Pt{i}") for i in range(Np)]
     fl = [th.Vector(tensor=leaves["focal"][:, i], name=f"fl{i}") for i in range(C)]
     k1 = [th.Vector(tensor=leaves["k1"][:, i], name=f"k1_{i}") for i in range(C)]
     k2 = [th.Vector(tensor=leaves["k2"][:, i], name=f"k2_{i}") for i in range(C)]

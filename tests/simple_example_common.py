@@ -92,8 +92,9 @@ def run_unrolled(th, g, tag, device, kernels=None):
     lkw = dict(linearization_kwargs=dict(kernels=kernels)) if kernels is not None else {}
     opt = getattr(th, cls)(obj, max_iterations=int(g[f"u_{tag}_iters"]), abs_err_tolerance=tol, rel_err_tolerance=tol, **lkw)
     B = xl.shape[0]
-    sol, info = th.TheseusLayer(opt).forward({"a": torch.ones(B, 1, dtype=dt, device=device), "b": 2.5 * torch.ones(B, 1, dtype=dt, device=device)},
-                                             optimizer_kwargs=dict(track_err_history=True, backward_mode=mode, **okw))
+    a0 = torch.ones(B, 1, dtype=dt, device=device, requires_grad=True)      # (UNROLL: the gradient reaches the initial values too)
+    b0 = (2.5 * torch.ones(B, 1, dtype=dt, device=device)).requires_grad_(True)
+    sol, info = th.TheseusLayer(opt).forward({"a": a0, "b": b0}, optimizer_kwargs=dict(track_err_history=True, backward_mode=mode, **okw))
     loss = ((sol["a"] - 0.5) ** 2).mean() + ((sol["b"] - 1.0) ** 2).mean()
     loss.backward()
     r = lambda k: g[f"u_{tag}_{k}"]  # noqa: E731
@@ -119,6 +120,10 @@ def run_unrolled(th, g, tag, device, kernels=None):
     for leaf, key in ((xl, "gx"), (yl, "gy"), (wl, "gw")):
         want = r(key)
         np.testing.assert_allclose(leaf.grad.cpu().numpy(), want, rtol=0, atol=1e-9 * np.abs(want).max(), err_msg=key)
+    if f"u_{tag}_ga0" in g:
+        for leaf, key in ((a0, "ga0"), (b0, "gb0")):
+            want = r(key)
+            np.testing.assert_allclose(leaf.grad.cpu().numpy(), want, rtol=0, atol=1e-8 * np.abs(want).max(), err_msg=key)
     np.testing.assert_allclose(info.err_history.numpy(), r("err"), rtol=1e-6)    # (inf where the reference has inf)
     if mode == "unroll":   # one loop in the reference: info.last_err is the error after the last iteration
         np.testing.assert_allclose(info.last_err.detach().cpu().numpy(), r("err")[:, -1], rtol=1e-6)

@@ -727,7 +727,8 @@ def test_reference_loop_differentiates_through_the_plugin_on_se3_pose_graphs(ref
     meas, wb = t(g["meas"]).requires_grad_(True), t(g["w_between"]).requires_grad_(True)
     tgt, wp = t(g["prior_target"]).requires_grad_(True), t(g["w_prior"])[:, :, :1].clone().requires_grad_(True)
     obj = th.Objective(dtype=dtype)
-    poses = [th.SE3(tensor=t(g["poses0"])[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    p0 = t(g["poses0"]).clone().requires_grad_(f"{tag}_grad_poses0" in g)   # (UNROLL: the gradient reaches the initial values too)
+    poses = [th.SE3(tensor=p0[:, k] if p0.requires_grad else p0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
     robust = f"{tag}_robust" in g      # (Welsch RobustCostFunction on every Between cost, one learnable log_loss_radius)
     lr = t(g[f"{tag}_log_radius"]).clone().requires_grad_(True) if robust else None
     radius = th.Vector(tensor=lr, name="log_loss_radius") if robust else None
@@ -757,6 +758,9 @@ def test_reference_loop_differentiates_through_the_plugin_on_se3_pose_graphs(ref
     for leaf, key in ((meas, "meas"), (wb, "w_between"), (tgt, "prior_target"), (wp, "w_prior")) + (((lr, "log_radius"),) if robust else ()):
         want = g[f"{tag}_grad_{key}"]
         np.testing.assert_allclose(leaf.grad.cpu().numpy(), want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
+    if p0.requires_grad:
+        want = g[f"{tag}_grad_poses0"]
+        np.testing.assert_allclose(p0.grad.cpu().numpy(), want, rtol=0, atol=1e-5 * np.abs(want).max(), err_msg="poses0")
     if f"{tag}_conv" in g:
         assert info.converged_iter.tolist() == g[f"{tag}_conv"].tolist()
 

@@ -45,6 +45,10 @@ def check_ba_unrolled(g, got, grad_tol=5e-6):
     for k in keys:
         want = g["grad_" + k]
         np.testing.assert_allclose(got["grad_" + k], want, rtol=0, atol=grad_tol * max(np.abs(want).max(), 1e-12), err_msg=k)
+    for k in ("cams0", "pts0"):    # UNROLL: the INITIAL values of the optimisation variables (raw entries; tests/unrolled_common.py)
+        if "grad_" + k in g:
+            want = g["grad_" + k]
+            np.testing.assert_allclose(got["grad_" + k], want, rtol=0, atol=1e-5 * np.abs(want).max(), err_msg=k)
 
 
 @pytest.mark.parametrize("name", BA_UNROLLED)

@@ -18,8 +18,10 @@ def run_pg_unrolled(th, g, tag, device, kernels=None):
                   w_prior=t(g["w_prior"])[:, :, :1].clone().requires_grad_(True))
     obj = th.Objective(dtype=leaves["meas"].dtype)
     poses0 = t(g["poses0"])
+    if f"{tag}_grad_poses0" in g:    # UNROLL: the gradient reaches the INITIAL values of the optimisation variables too
+        poses0 = leaves["poses0"] = poses0.clone().requires_grad_(True)
     G = {"SE2": th.SE2, "SO3": th.SO3}.get(str(g["group"]) if "group" in g else "SE3", th.SE3)
-    poses = [G(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+    poses = [G(tensor=poses0[:, k] if poses0.requires_grad else poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
     # RobustCostFunction wrappers (fixtures lm_welsch_unroll / gn_huberflat_trunc): one learnable log_loss_radius
     robust = str(g[f"{tag}_robust"]) if f"{tag}_robust" in g else None
     wrap = lambda cf, nm: cf  # noqa: E731
@@ -55,6 +57,11 @@ def run_pg_unrolled(th, g, tag, device, kernels=None):
     for key in ("meas", "w_between", "prior_target", "w_prior") + (("log_radius",) if robust else ()):
         got, want = leaves[key].grad.cpu().numpy(), g[f"{tag}_grad_{key}"]
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
+    if "poses0" in leaves:
+        # (raw-entry gradients of the start: dominated by the directions OFF the manifold, amplified by the weak gauge prior --
+        #  the oracle's own autograd differs from the reference's by 1e-6 of the largest entry on the worst problem, 1e-13 on the best)
+        got, want = leaves["poses0"].grad.cpu().numpy(), g[f"{tag}_grad_poses0"]
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-5 * np.abs(want).max(), err_msg="poses0")
     if tol:   # problems converge -- and are frozen -- at different differentiated iterations; the loop stops early
         assert info.converged_iter.tolist() == g[f"{tag}_conv"].tolist()
         assert [int(s_.value) for s_ in info.status] == g[f"{tag}_status"].tolist()

@@ -385,7 +385,14 @@ class PackedBA:
             self.cc_tensors = PGTensors(poses=cams, meas=self._stack([c.measurement.tensor for c in self.cc_costs], B),
                                         w_between=self._stack([_weight_diag(c.weight, 6) for c in self.cc_costs], B),
                                         prior_target=empty(0, 1, 3, 4), w_prior=empty(0, 1, 6))
-        self._repoint_variables()
+        if not (cams.requires_grad or pts.requires_grad) and any(v.tensor.requires_grad for v in self.cam_vars + self.pt_vars):
+            # (packed under no_grad from tensors that carry autograd history: see PackedPoseGraph.sync -- the variables keep them)
+            self._stamp = self._current_stamp() if not self._counters_unchanged() else self._stamp
+            self._global_stamp = Variable._global_updates
+            self._vars_stale = False
+            self._state_exposed = False
+        else:
+            self._repoint_variables()
 
     def _repoint_variables(self):
         # (after the implicit last step the state carries an autograd graph: the per-variable views stay attached to it)
@@ -472,6 +479,13 @@ class PackedBA:
                                                      t.log_radius_obs, t.cam_prior_target, t.w_cam_prior, t.pt_prior_target,
                                                      t.w_pt_prior, *cc)
         return (cams, pts), delta
+
+    def state_with_graph(self, tensors):
+        """(cams, points) assembled from the variables' OWN tensors (``optim_variables`` order: cameras, then points), autograd
+        history kept: where BackwardMode.UNROLL starts, so that gradients reach the values the caller passed in."""
+        B, C = self.batch, len(self.cam_vars)
+        full = [t if t.shape[0] == B else t.expand(B, *t.shape[1:]) for t in tensors]
+        return (torch.stack(full[:C], dim=0), torch.stack(full[C:], dim=0))
 
     def where_state(self, mask: torch.Tensor, a, b):
         """Per problem: ``a`` where ``mask`` else ``b`` (differentiable torch select on both halves of the state)."""

@@ -296,6 +296,12 @@ class PackedEuclidean:
     def where_state(self, mask: torch.Tensor, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         return torch.where(mask.view(-1, 1), a, b)
 
+    def state_with_graph(self, tensors):
+        """The state assembled from the optimisation variables' OWN tensors (in ``optim_variables`` order), autograd history kept:
+        where BackwardMode.UNROLL starts, so that gradients reach the values the caller passed in."""
+        B = self._state.shape[0]
+        return torch.cat([t if t.shape[0] == B else t.expand(B, -1) for t in tensors], dim=1)
+
     def unrolled_step(self, opt, X: torch.Tensor, frozen: Optional[torch.Tensor], kwargs):
         """X -> (X + step * delta where not ``frozen``, delta): the blocks are evaluated at X with the graph, the kernels get
         their detached values (what ``compute_delta`` factorises and LM's accept test reads), the solve is the autograd node."""

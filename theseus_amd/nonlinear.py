@@ -238,7 +238,15 @@ class NonlinearLeastSquares(abc.ABC):
         # nonlinear_least_squares.py:222-282): the Hessian is part of the graph there, i.e. the derivatives of every cost's
         # Jacobian are needed.  The generic path has them (its blocks come from torch: theseus_amd/euclidean.py); the fused
         # pose-graph / bundle-adjustment paths have one autograd node per iteration (thx_pg*_unroll_vjp / thx_ba_unroll_vjp).
-        unrolled = backward_mode in (BackwardMode.UNROLL, BackwardMode.TRUNCATED) and outer_grad and self._needs_grad()
+        # (UNROLL differentiates from the FIRST iteration: the caller's own tensors of the optimisation variables -- a learned
+        #  initialisation passed through TheseusLayer.forward -- are part of the graph; kept before the first sync re-points the variables)
+        init_tensors = None
+        if backward_mode == BackwardMode.UNROLL and outer_grad:
+            ts = [v.tensor for v in packed.optim_variables]
+            if any(t.requires_grad for t in ts):
+                init_tensors = ts
+        unrolled = (backward_mode in (BackwardMode.UNROLL, BackwardMode.TRUNCATED) and outer_grad
+                    and (self._needs_grad() or init_tensors is not None))
         if unrolled and not hasattr(packed, "unrolled_step"):
             raise NotImplementedError(
                 f"Differentiating through the iterations (backward_mode='{backward_mode.name.lower()}') needs a packer with "
@@ -521,6 +529,9 @@ class NonlinearLeastSquares(abc.ABC):
                     packed.prepare_unroll()
                 det = lambda x: tuple(y.detach() for y in x) if isinstance(x, tuple) else x.detach()  # noqa: E731  (BA: (cams, points))
                 X = det(packed.state)
+                if init_tensors is not None and it == 0 and hasattr(packed, "state_with_graph"):
+                    with torch.set_grad_enabled(outer_grad):
+                        X = packed.state_with_graph(init_tensors)     # same values, the caller's autograd history
                 g_conv = torch.zeros(B, dtype=torch.bool, device=dev)
                 g_conv_iter = torch.zeros(B, dtype=torch.long, device=dev)   # the reference's counter: += 1 while not converged
                 g_status_conv = torch.zeros(B, dtype=torch.bool, device=dev)

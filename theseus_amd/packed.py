@@ -295,6 +295,14 @@ class PackedPoseGraph:
             self._global_stamp = Variable._global_updates
             self._vars_stale = False
             self._state_exposed = True
+        elif not poses.requires_grad and any(v.tensor.requires_grad for v in self.pose_vars):
+            # packed under no_grad from tensors that carry autograd history (the values the caller passed in, about to be
+            # differentiated through: backward_mode="unroll"): re-pointing the variables to views of this graph-less copy would cut
+            # them off -- they keep their tensors (same values), the copy is private
+            self._stamp = stamp
+            self._global_stamp = Variable._global_updates
+            self._vars_stale = False
+            self._state_exposed = False
         else:
             self._repoint_variables()
 
@@ -381,6 +389,12 @@ class PackedPoseGraph:
     def where_state(self, mask: torch.Tensor, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         """Per problem: ``a`` where ``mask`` else ``b`` (differentiable torch select on (P, B, ...) states)."""
         return torch.where(mask.view(1, -1, *([1] * (a.dim() - 2))), a, b)
+
+    def state_with_graph(self, tensors):
+        """The packed state assembled from the pose variables' OWN tensors (``optim_variables`` order), autograd history kept: where
+        BackwardMode.UNROLL starts, so that gradients reach the values the caller passed in."""
+        B = self.batch
+        return torch.stack([t if t.shape[0] == B else t.expand(B, *t.shape[1:]) for t in tensors], dim=0)
 
     def unroll_incidence(self, device) -> torch.Tensor:
         """(P, Dmax) rows of [grad_pose_i (E) ; grad_pose_j (E) ; grad_pose_prior (K) ; zero row] that belong to each pose."""
