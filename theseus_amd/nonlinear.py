@@ -241,7 +241,7 @@ class NonlinearLeastSquares(abc.ABC):
         # (UNROLL differentiates from the FIRST iteration: the caller's own tensors of the optimisation variables -- a learned
         #  initialisation passed through TheseusLayer.forward -- are part of the graph; kept before the first sync re-points the variables)
         init_tensors = None
-        if backward_mode == BackwardMode.UNROLL and outer_grad:
+        if backward_mode in (BackwardMode.UNROLL, BackwardMode.TRUNCATED) and outer_grad:   # (TRUNCATED: only if its no_grad head is empty)
             ts = [v.tensor for v in packed.optim_variables]
             if any(t.requires_grad for t in ts):
                 init_tensors = ts
