@@ -823,6 +823,34 @@ def test_generic_path_places_jacobian_blocks_like_dense_linearization(ref):
     np.testing.assert_allclose(lin.Av(v).numpy(), ref_lin.Av(v).numpy(), rtol=1e-5, atol=1e-5)
 
 
+def test_dogleg_with_unrolled_gradients_is_refused_on_the_fused_path(ref):
+    """th.Dogleg reads ``linearization.Av`` (dogleg.py:66), which the fused path answers from kernels outside autograd: with
+    backward_mode="unroll" and something to differentiate the gradient would be silently incomplete -- refused loudly (the
+    reference's loop re-raises as RuntimeError, nonlinear_least_squares.py:138-152); under no_grad the same call runs."""
+    th, thp = ref
+    g = load_golden("pg_f64_unrolled")
+    t = lambda a: torch.from_numpy(a).to(DEVICE)  # noqa: E731
+    meas = t(g["meas"]).clone().requires_grad_(True)
+    obj = th.Objective(dtype=torch.float64)
+    poses = [th.SE3(tensor=t(g["poses0"])[:, k].clone(), name=f"pose_{k}") for k in range(int(g["P"]))]
+    for k in range(g["edges"].shape[0]):
+        i, j = g["edges"][k].tolist()
+        obj.add(th.Between(poses[i], poses[j], th.SE3(tensor=meas[:, k], name=f"meas_{k}"),
+                           th.DiagonalCostWeight(th.Variable(t(g["w_between"])[:, k].clone(), name=f"w_{k}")), name=f"between_{k}"))
+    obj.add(th.Difference(poses[int(g["prior_idx"][0])], th.SE3(tensor=t(g["prior_target"])[:, 0].clone(), name="target"),
+                          th.ScaleCostWeight(th.Variable(t(g["w_prior"])[:, 0, :1].clone(), name="pw")), name="prior"))
+    opt = th.Dogleg(obj, max_iterations=2, step_size=1.0, linear_solver_cls=thp.HipCholeskySolver,
+                    linearization_cls=thp.HipLinearization, linearization_kwargs=_kernels(), vectorize=True)
+    layer = th.TheseusLayer(opt)
+    if DEVICE != "cpu":
+        layer.to(DEVICE)
+    with pytest.raises(RuntimeError, match="outside autograd"):
+        layer.forward(optimizer_kwargs=dict(backward_mode="unroll"))
+    with torch.no_grad():
+        _, info = layer.forward(optimizer_kwargs=dict(backward_mode="unroll"))
+    assert info.status is not None
+
+
 @pytest.mark.parametrize("tag", ["gn_unroll", "lm_trunc", "lm_ellips_unroll"])
 @pytest.mark.parametrize("fixture", ["pg2_f64_unrolled", "pg3_f64_unrolled"])
 def test_reference_loop_differentiates_through_the_plugin_on_se2_and_so3_pose_graphs(ref, fixture, tag):

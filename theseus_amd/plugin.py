@@ -52,6 +52,17 @@ from . import kernels as _kernels
 _kernels.use_reference_global_params(_REF_GLOBAL_PARAMS)
 
 
+def _refuse_unrolled_av(lin):
+    """Differentiating THROUGH the iterations on a fused path: ``solve()`` is the autograd node (Gauss-Newton / Levenberg-Marquardt
+    need nothing else); ``Av`` -- read by Dogleg / TrustRegion steps (dogleg.py:66, trust_region.py:97) -- comes from kernels outside
+    autograd, so a gradient through it would be silently incomplete."""
+    if getattr(lin, "_unroll", None) is not None and torch.is_grad_enabled():
+        raise NotImplementedError(
+            "backward_mode='unroll' / 'truncated' with gradients on a fused pose-graph / bundle-adjustment path differentiates "
+            "solve() only (GaussNewton, LevenbergMarquardt); Av() of this linearization is outside autograd (Dogleg / TrustRegion "
+            "steps).  Use backward_mode='implicit', or the generic path.")
+
+
 class _FusedAtb(torch.autograd.Function):
     """g = A^T b of a pose graph as a differentiable function of the packed auxiliary tensors: forward is
     ``thx_pg_assemble`` (which also refreshes H), backward is ``thx_pg_vjp``."""
@@ -526,6 +537,7 @@ class HipLinearization(HipLinearizationCore, _RefLinearization):
 
     def Av(self, v: torch.Tensor) -> torch.Tensor:
         if self.fused:
+            _refuse_unrolled_av(self)
             return HipLinearizationCore.Av(self, v)
         Jd, _ = self._blocks   # generic path: the reference's weighted Jacobian blocks of this linearization
         out = torch.zeros(v.shape[0], self.num_rows, dtype=v.dtype, device=v.device)
@@ -852,6 +864,10 @@ class HipSchurLinearization(HipSchurLinearizationCore, _RefLinearization):
     def _atb_impl(self) -> torch.Tensor:
         g = self._g_graph if self._g_graph is not None else self.g
         return g.unsqueeze(2)
+
+    def Av(self, v: torch.Tensor) -> torch.Tensor:
+        _refuse_unrolled_av(self)
+        return HipSchurLinearizationCore.Av(self, v)
 
 
 class HipSchurSolver(HipSchurSolverCore, _RefCholeskyDenseSolver):
