@@ -35,12 +35,13 @@ def test_stale_factor_is_detected_and_unroll_with_grad_refused():
                           th.ScaleCostWeight(torch.tensor(1.0, dtype=torch.float64)), name="prior"))
     opt = th.LevenbergMarquardt(obj, linearization_kwargs=dict(kernels=OracleKernels()), max_iterations=3)
     layer = th.TheseusLayer(opt)
-    # (unrolled differentiation of an SE3 pose graph is fused since round 4: tests/test_unrolled_host.py; track_best_solution is
-    #  not available in that mode)
-    with pytest.raises(NotImplementedError, match="track_best_solution"):
-        layer.forward(None, optimizer_kwargs=dict(backward_mode="unroll", track_best_solution=True))
+    # (unrolled differentiation of an SE3 pose graph is fused since round 4: tests/test_unrolled_host.py; a trust-region optimizer
+    #  with unrolled gradients is what is still refused)
+    dog = th.Dogleg(obj, linearization_kwargs=dict(kernels=OracleKernels()), max_iterations=3)
+    with pytest.raises(NotImplementedError, match="trust-region"):
+        th.TheseusLayer(dog).forward(None, optimizer_kwargs=dict(backward_mode="unroll"))
     with torch.no_grad():  # without gradients the default mode is the plain loop
-        layer.forward(None, optimizer_kwargs=dict(backward_mode="unroll", track_best_solution=True))
+        th.TheseusLayer(dog).forward(None, optimizer_kwargs=dict(backward_mode="unroll"))
     sol, _ = layer.forward(None, optimizer_kwargs=dict(backward_mode="implicit"))
     loss = sum(v.sum() for v in sol.values())
     with torch.no_grad():

@@ -252,9 +252,9 @@ class NonlinearLeastSquares(abc.ABC):
                 f"Differentiating through the iterations (backward_mode='{backward_mode.name.lower()}') needs a packer with "
                 f"unrolled_step() (generic, pose-graph and bundle-adjustment objectives have one; got {type(packed).__name__}).  "
                 "Use backward_mode='implicit', or call under torch.no_grad().")
-        if unrolled and (track_best_solution or track_state_history or isinstance(self, TrustRegion)):
+        if unrolled and isinstance(self, TrustRegion):
             raise NotImplementedError("differentiable iterations (backward_mode='unroll' / 'truncated' with gradients): Gauss-Newton / "
-                                      "Levenberg-Marquardt, without track_best_solution / track_state_history.")
+                                      "Levenberg-Marquardt (a trust-region step reads Av / the Cauchy point outside autograd).")
         with torch.no_grad():
             packed.sync(deep=True)   # once per optimize(): also catches in-place edits of the variables' tensors
         self.reset(**kwargs, backward_mode=backward_mode)
@@ -565,6 +565,13 @@ class NonlinearLeastSquares(abc.ABC):
                         if bool(g_conv.all()):
                             break    # (as in the first loop: the converging iteration is not counted, its error not merged)
                     g_errs.append(err)
+                    if state_hist is not None:         # (_update_info: detached copies, nonlinear_optimizer.py:150-207)
+                        state_hist.record(it + g_it + 1, det(X))
+                    if track_best_solution:
+                        better = err < best_err
+                        packed.copy_where(better, det(X), best_state)
+                        best_err = torch.where(better, err, best_err)
+                        best_iter = torch.where(better, torch.full_like(best_iter, it + g_it), best_iter)
                     g_last = err
                     if end_iter_callback is not None:
                         packed.swap_state(X, repoint=True)
