@@ -1167,6 +1167,7 @@ struct TilePat {
   const int32_t* tile_sb;    //                      slot of L_ik
   const int32_t* diag_s;     // (per diag_k element) slot of L_jk
   int32_t nslots;            // 0: L is the dense (B, ld, ld) frame
+  int32_t lpt;               // chol_offdiag's block -> (problem, entry) map: 1 = the ENTRY is the slow index (longest K-lists first)
 };
 
 // where a kernel finds / puts the tiles of L: the dense frame (row stride ld) or the tile-packed buffer (row stride TILE)
@@ -1786,11 +1787,18 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
-  const int b = (slot / nrow_tiles) * 8 + xcd;
+  // Default map: the problem is the slow index -- all row tiles of a problem run at the same time on ONE XCD and share the column
+  // panel in its L2.  pat.lpt (small-batch tile-sparse launches, the look-ahead schedule): the ENTRY is the slow index, i.e. the
+  // column's entries are dispatched longest K-list first (a band's entries are sorted that way: the nearer the diagonal, the
+  // longer) -- with two to three rounds of workgroups per launch the tail of a LONG tile started last costs more than the panel
+  // re-reads (same-box A/B profiles/r4/s_: banded BA system 6.62 -> 6.34 / 6.46 ms, bit-identical factor).
+  const int b8 = gridDim.x / (8 * nrow_tiles);
+  const int b = pat.lpt ? (slot % b8) * 8 + xcd : (slot / nrow_tiles) * 8 + xcd;
+  const int rslot = pat.lpt ? slot / b8 : slot % nrow_tiles;
   // row tiles [i_first, i_first + nrow_tiles) of block column j -- or, tile-sparse, entries [i_first, i_first + nrow_tiles) of the
   // column's list of non-zero row tiles
-  const int ent = pat.col_row ? pat.col_ptr[j] + i_first + (slot % nrow_tiles) : 0;   // (tile-sparse: i_first = first ENTRY of the launch)
-  const int i = pat.col_row ? pat.col_row[ent] : i_first + (slot % nrow_tiles);
+  const int ent = pat.col_row ? pat.col_ptr[j] + i_first + rslot : 0;   // (tile-sparse: i_first = first ENTRY of the launch)
+  const int i = pat.col_row ? pat.col_row[ent] : i_first + rslot;
   const int32_t* klist = pat.col_row ? pat.tile_k + pat.tile_kptr[ent] : nullptr;
   const int Kspan = pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE;
   if (b >= B) return;
@@ -2012,9 +2020,11 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   double* smem = reinterpret_cast<double*>(smem_raw);
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
-  const int b = (slot / nrow_tiles) * 8 + xcd;
-  const int ent = pat.col_row ? pat.col_ptr[j] + i_first + (slot % nrow_tiles) : 0;   // (tile-sparse: i_first = first ENTRY of the launch)
-  const int i = pat.col_row ? pat.col_row[ent] : i_first + (slot % nrow_tiles);
+  const int b8 = gridDim.x / (8 * nrow_tiles);       // (the two block maps: chol_offdiag_f32_kernel)
+  const int b = pat.lpt ? (slot % b8) * 8 + xcd : (slot / nrow_tiles) * 8 + xcd;
+  const int rslot = pat.lpt ? slot / b8 : slot % nrow_tiles;
+  const int ent = pat.col_row ? pat.col_ptr[j] + i_first + rslot : 0;   // (tile-sparse: i_first = first ENTRY of the launch)
+  const int i = pat.col_row ? pat.col_row[ent] : i_first + rslot;
   const int32_t* klist = pat.col_row ? pat.tile_k + pat.tile_kptr[ent] : nullptr;
   const int Kspan = pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE;
   if (b >= B) return;
@@ -2471,7 +2481,7 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   const bool use_hb = hbp != nullptr;
   const HBlk hb = use_hb ? *hbp : HBlk{nullptr, 0, 0, nullptr, nullptr, nullptr};
   const int ntiles = (n + TILE - 1) / TILE;
-  TilePat pat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  TilePat pat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
   // ld == 0: L is the TILE-PACKED factor (B, nslots, TILE, TILE) of the pattern
   const bool packed = ld == 0;
   if (packed && (!tp || tp->nslots <= 0 || !tp->tile_sa || !tp->tile_sb || !tp->diag_s))
@@ -2480,7 +2490,7 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     if (tp->ntiles != ntiles) return fail("thx_chol_factor_sparse: the tile pattern was built for another matrix order");
     pat = TilePat{tp->col_ptr, tp->col_row, tp->tile_kptr, tp->tile_k, tp->diag_kptr, tp->diag_k,
                   packed ? tp->tile_sa : nullptr, packed ? tp->tile_sb : nullptr, packed ? tp->diag_s : nullptr,
-                  packed ? tp->nslots : 0};
+                  packed ? tp->nslots : 0, 0};
   }
   const int64_t hstride = (int64_t)ld * ld;                                            // H frame (dense H only; never packed)
   const int64_t lstride = packed ? (int64_t)tp->nslots * TILE * TILE : (int64_t)ld * ld;   // elements of L per problem
@@ -2629,6 +2639,11 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   // batch 256 3.5 ms either way, batch 512 6.2 -> 6.4 ms; n = 3072 batch 256 21.6 -> 21.8 ms: REST(j) of a dense column is most
   // of the launch, the dispatcher does not run the two queues side by side) -- so: tile-sparse only.
   const bool lookahead = lookahead_cfg && !split && ntiles > 2 && tp && tp->col_head_host != nullptr;
+  static const bool lpt_cfg = [] {
+    const char* e = getenv("THX_CHOL_LPT");
+    return e ? atoi(e) != 0 : true;
+  }();
+  pat.lpt = (lookahead && lpt_cfg) ? 1 : 0;
   if (lookahead) {
     if (!ds.ev_fork) hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming);
     if (!ds.ev_diag) {
