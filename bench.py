@@ -753,7 +753,6 @@ def ba_run(cfg, ctx):
     #      problem (one reference iteration there: ~5 min on 6 cores), not a bounded sample ----
     if cfg.cpu_baseline:
         try:
-            import ast
             from oracle import pose_graph as opg
             from tests.helpers import ba_problem, load_golden
             g = load_golden("ba_mid_f64_lm")

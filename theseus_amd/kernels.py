@@ -5,7 +5,6 @@ that does not depend on a GPU (batch sharding, LM control flow) can be unit-test
 stand-in injected by tests/; nothing in this package provides such a stand-in.
 """
 import dataclasses
-import os
 from dataclasses import dataclass
 from typing import Optional
 

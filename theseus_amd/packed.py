@@ -7,7 +7,6 @@ stacking tensors for batched ATen calls it keeps ONE entity-major buffer per rol
 the fused HIP kernels index directly.  Variables are tracked by ``_num_updates`` so that the
 buffers are re-packed only when somebody changed a variable behind our back.
 """
-import dataclasses
 import weakref
 from typing import Optional
 
