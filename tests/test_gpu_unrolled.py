@@ -29,6 +29,14 @@ def test_differentiating_through_the_iterations_of_a_pose_graph_on_the_gpu(tag):
     run_pg_unrolled(th, load_golden("pg_f64_unrolled"), tag, "cuda")
 
 
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_ellips_unroll", "gn_trunc_conv", "lm_welsch_unroll"])
+def test_differentiating_through_the_iterations_with_the_tile_sparse_solver_on_the_gpu(tag):
+    """... over ``HipSparseCholeskySolver``: thx_chol_solve_sparse on a copy of the iteration's tile-packed factor in the backward."""
+    import theseus_amd as th
+    from tests.unrolled_common import run_pg_unrolled
+    run_pg_unrolled(th, load_golden("pg_f64_unrolled"), tag, "cuda", solver_cls=th.HipSparseCholeskySolver)
+
+
 @pytest.mark.parametrize("tag", ["gn_unroll", "lm_trunc", "lm_ellips_unroll"])
 @pytest.mark.parametrize("fixture", ["pg2_f64_unrolled", "pg3_f64_unrolled"])
 def test_differentiating_through_the_iterations_of_se2_and_so3_pose_graphs_on_the_gpu(fixture, tag):

@@ -711,6 +711,19 @@ def test_reference_loop_differentiates_through_the_plugin_on_generic_objectives(
 @pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll", "gn_trunc_conv", "lm_welsch_unroll",
                                  "lm_step_unroll"])
 def test_reference_loop_differentiates_through_the_plugin_on_se3_pose_graphs(ref, tag):
+    _unrolled_se3_through_the_reference_loop(ref, tag, "HipCholeskySolver")
+
+
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_ellips_unroll", "gn_trunc_conv", "lm_welsch_unroll"])
+def test_reference_loop_differentiates_through_the_tile_sparse_solver(ref, tag):
+    """... and with ``HipSparseCholeskySolver`` behind the loop (its solve() used to fall through to the plain solve
+    under backward_mode "unroll" -- a delta without a grad_fn on the GPU, i.e. silently incomplete gradients): the same node, the
+    backward's solve runs along the tile pattern on a copy of the iteration's tile-packed factor, the columns follow the solver's
+    reverse Cuthill-McKee ordering."""
+    _unrolled_se3_through_the_reference_loop(ref, tag, "HipSparseCholeskySolver")
+
+
+def _unrolled_se3_through_the_reference_loop(ref, tag, solver_name, mode_override=None, extra_okw=None):
     """backward_mode "unroll" / "truncated" on an SE3 pose graph through the REAL loop with the FUSED path behind it: the
     reference linearizes with the Hessian in the graph (nonlinear_least_squares.py:100-135); the plugin assembles H, g with the
     kernels and makes solve() one autograd node over the packed poses and the auxiliary tensors (_FusedUnrolledSolve:
@@ -723,6 +736,9 @@ def test_reference_loop_differentiates_through_the_plugin_on_se3_pose_graphs(ref
     t = lambda a: torch.from_numpy(a).to(DEVICE)  # noqa: E731
     kw = ast.literal_eval(str(g[f"{tag}_kwargs"]))
     mode, iters, gn = kw.pop("mode"), kw.pop("max_iterations"), kw.pop("gauss_newton")
+    if mode_override is not None:
+        mode = mode_override
+        kw.pop("backward_num_iterations", None) if mode == "unroll" else None
     P = int(g["P"])
     meas, wb = t(g["meas"]).requires_grad_(True), t(g["w_between"]).requires_grad_(True)
     tgt, wp = t(g["prior_target"]).requires_grad_(True), t(g["w_prior"])[:, :, :1].clone().requires_grad_(True)
@@ -741,17 +757,21 @@ def test_reference_loop_differentiates_through_the_plugin_on_se3_pose_graphs(ref
         obj.add(th.Difference(poses[int(g["prior_idx"][k])], th.SE3(tensor=tgt[:, k], name=f"prior_target_{k}"),
                               th.ScaleCostWeight(th.Variable(wp[:, k], name=f"pw_{k}")), name=f"prior_{k}"))
     cls = th.GaussNewton if gn else th.LevenbergMarquardt
-    opt = cls(obj, linear_solver_cls=thp.HipCholeskySolver, linearization_cls=thp.HipLinearization, linearization_kwargs=_kernels(),
+    plug = (dict(linear_solver_cls=getattr(thp, solver_name), linearization_cls=thp.HipLinearization, linearization_kwargs=_kernels())
+            if solver_name is not None else dict(linear_solver_cls=th.CholeskyDenseSolver))   # (None: the reference on its own)
+    opt = cls(obj, **plug,
               vectorize=True, max_iterations=iters, step_size=float(g[f"{tag}_step"]) if f"{tag}_step" in g else 1.0,
               abs_err_tolerance=0.0, rel_err_tolerance=float(g[f"{tag}_rel_tol"]) if f"{tag}_rel_tol" in g else 0.0)
-    assert opt.linear_solver.linearization.fused
+    assert solver_name is None or opt.linear_solver.linearization.fused
     layer = th.TheseusLayer(opt)
     if DEVICE != "cpu":
         layer.to(DEVICE)
-    sol, info = layer.forward(optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **kw))
+    sol, info = layer.forward(optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **kw, **(extra_okw or {})))
     final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
     loss = (t(g["coef"]) * final).sum()
     loss.backward()
+    if mode_override is not None or extra_okw:
+        return info, final.detach(), meas.grad     # (a variant of the fixture's run: the caller compares)
     tol_x = 2e-8 if robust else 1e-9      # (tests/unrolled_common.py says why)
     np.testing.assert_allclose(final.detach().cpu().numpy(), g[f"{tag}_final"], rtol=0, atol=tol_x)
     assert abs(float(loss.detach()) - float(g[f"{tag}_loss"])) < 10 * tol_x
@@ -763,6 +783,40 @@ def test_reference_loop_differentiates_through_the_plugin_on_se3_pose_graphs(ref
         np.testing.assert_allclose(p0.grad.cpu().numpy(), want, rtol=0, atol=1e-5 * np.abs(want).max(), err_msg="poses0")
     if f"{tag}_conv" in g:
         assert info.converged_iter.tolist() == g[f"{tag}_conv"].tolist()
+
+
+@cpu_only
+@pytest.mark.parametrize("mode", ["unroll", "truncated"])
+def test_bookkeeping_of_the_differentiated_iterations_matches_the_reference(ref, mode):
+    """The iteration on which EVERY problem converges inside the differentiated iterations: the reference's
+    _update_info runs before its convergence test (nonlinear_least_squares.py:192-203), so that iteration still competes for
+    best_solution / best_err, and in UNROLL's single loop it is in err_history / state_history at [it + 1] with best_iter = it;
+    TRUNCATED's _merge_infos (nonlinear_optimizer.py:220-266) copies only the counted columns and keeps the first loop's best_iter.
+    theseus_amd's own loop (stand-in kernels) against the reference ON ITS OWN, same problem, tracking on."""
+    th, _ = ref
+    import theseus_amd as tha
+    from tests.oracle_kernels import OracleKernels
+    from tests.unrolled_common import run_pg_unrolled
+    track = dict(track_best_solution=True, track_state_history=True)
+    want, want_final, want_grad = _unrolled_se3_through_the_reference_loop(ref, "gn_trunc_conv", None, mode_override=mode,
+                                                                           extra_okw=track)
+    got, got_final, got_grad = run_pg_unrolled(tha, load_golden("pg_f64_unrolled"), "gn_trunc_conv", "cpu", OracleKernels(),
+                                               mode_override=mode, extra_okw=track)
+    np.testing.assert_allclose(got_final.numpy(), want_final.numpy(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(got_grad.numpy(), want_grad.numpy(), rtol=0, atol=2e-6 * float(want_grad.abs().max()))
+    eh_w, eh_g = want.err_history.numpy(), got.err_history.numpy()
+    assert np.array_equal(np.isinf(eh_w), np.isinf(eh_g)), (eh_w, eh_g)          # the same columns were written
+    np.testing.assert_allclose(eh_g[~np.isinf(eh_g)], eh_w[~np.isinf(eh_w)], rtol=1e-6)
+    assert got.best_iter.tolist() == want.best_iter.tolist()
+    np.testing.assert_allclose(got.best_err.detach().numpy(), want.best_err.detach().numpy(), rtol=1e-6)
+    assert got.converged_iter.tolist() == want.converged_iter.tolist()
+    assert [int(x.value) for x in got.status] == [int(x.value) for x in want.status]
+    for name, hw in want.state_history.items():
+        hg = got.state_history[name].numpy()
+        assert np.array_equal(np.isinf(hw.numpy()), np.isinf(hg)), name
+        fin = ~np.isinf(hg)
+        np.testing.assert_allclose(hg[fin], hw.numpy()[fin], rtol=0, atol=1e-6, err_msg=name)
+        np.testing.assert_allclose(got.best_solution[name].numpy(), want.best_solution[name].numpy(), rtol=0, atol=1e-6)
 
 
 @cpu_only

@@ -17,6 +17,15 @@ def test_differentiating_through_the_iterations_of_a_pose_graph(tag):
     run_pg_unrolled(th, load_golden("pg_f64_unrolled"), tag, "cpu", OracleKernels())
 
 
+@pytest.mark.parametrize("tag", ["gn_unroll", "lm_ellips_unroll", "gn_trunc_conv", "lm_welsch_unroll"])
+def test_differentiating_through_the_iterations_with_the_tile_sparse_solver(tag):
+    """The same node over ``HipSparseCholeskySolver`` (reverse Cuthill-McKee column order, the backward's solve along the tile
+    pattern on a copy of the iteration's factor: ``solve_with_snapshot``)."""
+    import theseus_amd as th
+    from tests.oracle_kernels import OracleKernels
+    run_pg_unrolled(th, load_golden("pg_f64_unrolled"), tag, "cpu", OracleKernels(), solver_cls=th.HipSparseCholeskySolver)
+
+
 @pytest.mark.parametrize("tag", ["gn_unroll", "lm_trunc", "lm_ellips_unroll"])
 @pytest.mark.parametrize("fixture", ["pg2_f64_unrolled", "pg3_f64_unrolled"])
 def test_differentiating_through_the_iterations_of_se2_and_so3_pose_graphs(fixture, tag):

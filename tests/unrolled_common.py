@@ -8,10 +8,14 @@ import numpy as np
 import torch
 
 
-def run_pg_unrolled(th, g, tag, device, kernels=None):
+def run_pg_unrolled(th, g, tag, device, kernels=None, solver_cls=None, mode_override=None, extra_okw=None):
     t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
     kw = ast.literal_eval(str(g[f"{tag}_kwargs"]))
     mode, iters, gn = kw.pop("mode"), kw.pop("max_iterations"), kw.pop("gauss_newton")
+    if mode_override is not None:   # (a variant of the fixture's run: the caller compares)
+        mode = mode_override
+        if mode == "unroll":
+            kw.pop("backward_num_iterations", None)
     P = int(g["P"])
     leaves = dict(meas=t(g["meas"]).requires_grad_(True), w_between=t(g["w_between"]).requires_grad_(True),
                   prior_target=t(g["prior_target"]).requires_grad_(True),
@@ -43,11 +47,16 @@ def run_pg_unrolled(th, g, tag, device, kernels=None):
     cls = th.GaussNewton if gn else th.LevenbergMarquardt
     tol = float(g[f"{tag}_rel_tol"]) if f"{tag}_rel_tol" in g else 0.0
     step = float(g[f"{tag}_step"]) if f"{tag}_step" in g else 1.0
+    if solver_cls is not None:
+        lkw["linear_solver_cls"] = solver_cls
     opt = cls(obj, max_iterations=iters, step_size=step, abs_err_tolerance=0.0, rel_err_tolerance=tol, **lkw)
-    sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **kw))
+    sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode=mode, track_err_history=True, **kw,
+                                                                         **(extra_okw or {})))
     final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
     loss = (t(g["coef"]) * final).sum()
     loss.backward()
+    if mode_override is not None or extra_okw:
+        return info, final.detach(), leaves["meas"].grad
     # (the Welsch case is still descending after its 4 iterations -- error 5.2 -> 0.9 -- and its down-weighted system is less
     #  well conditioned: the tiled Cholesky and LAPACK's differ by 2e-9 on the final poses there, 1e-10 elsewhere)
     tol_x = 2e-8 if robust else 1e-9

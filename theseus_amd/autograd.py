@@ -142,7 +142,7 @@ class PGUnrolledIteration(torch.autograd.Function):
         K.retract(Xd, delta, step, mask, X_new)
         ctx.packed, ctx.step, ctx.frozen, ctx.n = packed, step, frozen, lin.n
         ctx.tensors = detached_tensors(t, Xd, meas, w_between, prior_target, w_prior, lr_between, lr_prior)
-        ctx.L, ctx.panels = solver.L.clone(), solver.panels.clone()   # (later iterations overwrite the solver's factor)
+        ctx.solver, ctx.factor = solver, solver.factor_snapshot()   # (later iterations overwrite the solver's factor)
         ctx.delta = delta.detach().clone()
         ctx.mark_non_differentiable(delta)
         return X_new, delta
@@ -161,8 +161,7 @@ class PGUnrolledIteration(torch.autograd.Function):
             fz = ctx.frozen.bool()
             gd = gd * (~fz).to(dt).view(-1, 1)
             GX = torch.where(fz.view(1, B, *([1] * (X.dim() - 2))), G, GX)
-        w = torch.empty_like(gd)
-        K.chol_solve(ctx.L, n, ctx.panels, gd.contiguous(), w)
+        w = ctx.solver.solve_with_snapshot(ctx.factor, gd)
         s = packed.structure
         E_, Kp = s.num_edges, s.num_priors
         new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731

@@ -390,7 +390,7 @@ class _UnrolledSolve(torch.autograd.Function):
                                    "torch.no_grad()") from None
         damped, ellipsoidal, _ = solver._factored_with
         ctx.solver, ctx.n = solver, solver.linearization.n
-        ctx.L, ctx.panels = solver.L.clone(), solver.panels.clone()
+        ctx.factor = solver.factor_snapshot()
         ctx.lam = solver._lam.clone() if (damped and ellipsoidal) else None
         ctx.save_for_backward(delta)
         return delta
@@ -398,8 +398,7 @@ class _UnrolledSolve(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_delta):
         (delta,) = ctx.saved_tensors
-        w = torch.empty_like(delta)
-        ctx.solver.K.chol_solve(ctx.L, ctx.n, ctx.panels, grad_delta.contiguous(), w)
+        w = ctx.solver.solve_with_snapshot(ctx.factor, grad_delta)
         grad_H = -(w.unsqueeze(2) * delta.unsqueeze(1))
         if ctx.lam is not None:
             grad_H = grad_H - torch.diag_embed(ctx.lam.view(-1, 1) * w * delta)

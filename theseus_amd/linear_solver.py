@@ -99,6 +99,19 @@ class HipCholeskyCore:
         self._substitute(rhs, x, backward_only=False)
         return x
 
+    def factor_snapshot(self):
+        """A private copy of the CURRENT factor, for a solve after the solver has factorised again (the differentiated iterations
+        of BackwardMode.UNROLL / TRUNCATED: every iteration's backward solves with that iteration's factor)."""
+        return self.L.clone(), self.panels.clone()
+
+    def solve_with_snapshot(self, snapshot, rhs: torch.Tensor) -> torch.Tensor:
+        """(L L^T)^-1 rhs with a factor kept by ``factor_snapshot`` (dense frame: thx_chol_solve)."""
+        L, panels = snapshot
+        rhs = rhs.contiguous()
+        x = torch.empty_like(rhs)
+        self.K.chol_solve(L, self.linearization.n, panels, rhs, x)
+        return x
+
     def _substitute(self, rhs, x, backward_only: bool):
         """x = L^-T rhs (``backward_only``) or (L L^T)^-1 rhs with the current factor (dense frame: every tile of L)."""
         if backward_only:

@@ -554,24 +554,35 @@ class NonlinearLeastSquares(abc.ABC):
                         err = err_new
                     attempts = 0
                     X = X_cand
-                    # _update_info + _check_convergence of this iteration
+                    # _update_info, THEN _check_convergence (nonlinear_least_squares.py:192-203): the iteration on which everybody
+                    # converges is not counted, but it has been through _update_info -- it competes for best_solution, and in UNROLL's
+                    # single loop its error / state are in the histories at [it + 1].  TRUNCATED's second loop has its own info, of
+                    # which _merge_infos (nonlinear_optimizer.py:220-266) copies ``grad_iters_done`` history columns (not the
+                    # converging iteration's), merges best_solution / best_err, and leaves best_iter the first loop's.
+                    single_loop = backward_mode == BackwardMode.UNROLL
                     g_conv_iter = g_conv_iter + (~g_conv).long()
                     if verbose:
                         print(f"Nonlinear optimizer. Iteration: {it + g_it + 1}. Error: {err.mean().item()}")
+                    conv_new, everybody = g_conv, False
                     if need_conv:
-                        g_conv = (torch.ones_like(g_conv) if self.reducer.mean_abs(err) < p.abs_err_tolerance
-                                  else self._check_convergence(err, g_last))
-                        g_status_conv = g_status_conv | g_conv
-                        if bool(g_conv.all()):
-                            break    # (as in the first loop: the converging iteration is not counted, its error not merged)
-                    g_errs.append(err)
-                    if state_hist is not None:         # (_update_info: detached copies, nonlinear_optimizer.py:150-207)
-                        state_hist.record(it + g_it + 1, det(X))
+                        conv_new = (torch.ones_like(g_conv) if self.reducer.mean_abs(err) < p.abs_err_tolerance
+                                    else self._check_convergence(err, g_last))
+                        everybody = bool(conv_new.all())
+                    if single_loop or not everybody:
+                        g_errs.append(err)
+                        if state_hist is not None:         # (detached copies, nonlinear_optimizer.py:150-207)
+                            state_hist.record(it + g_it + 1, det(X))
                     if track_best_solution:
                         better = err < best_err
                         packed.copy_where(better, det(X), best_state)
                         best_err = torch.where(better, err, best_err)
-                        best_iter = torch.where(better, torch.full_like(best_iter, it + g_it), best_iter)
+                        if single_loop:
+                            best_iter = torch.where(better, torch.full_like(best_iter, it + g_it), best_iter)
+                    if need_conv:
+                        g_conv = conv_new
+                        g_status_conv = g_status_conv | g_conv
+                        if everybody:
+                            break
                     g_last = err
                     if end_iter_callback is not None:
                         packed.swap_state(X, repoint=True)
@@ -580,7 +591,7 @@ class NonlinearLeastSquares(abc.ABC):
                 packed.swap_state(X, repoint=True)      # the variables view the (graph-carrying) result
                 # _merge_infos
                 if err_hist is not None and g_errs:
-                    err_hist[:, it + 1:it + 1 + g_it] = torch.stack(g_errs, 1)
+                    err_hist[:, it + 1:it + 1 + len(g_errs)] = torch.stack(g_errs, 1)   # (UNROLL: the converging iteration's too)
                 undecided = ~(converged if converged is not None else torch.zeros(B, dtype=torch.bool, device=dev))
                 if need_conv:
                     # problems the first loop left at MAX_ITERATIONS take the second loop's verdict; their counters add up

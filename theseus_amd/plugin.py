@@ -115,7 +115,7 @@ class _UnrolledFactorSolve(torch.autograd.Function):
         solver._substitute(y, delta, backward_only=True)
         solver.check_info()
         ctx.solver, ctx.n = solver, solver.linearization.n
-        ctx.L, ctx.panels = solver.L.clone(), solver.panels.clone()
+        ctx.factor = solver.factor_snapshot()
         ctx.lam = solver._lam.clone() if (damping is not None and ellipsoidal) else None
         ctx.save_for_backward(delta)
         return delta
@@ -123,8 +123,7 @@ class _UnrolledFactorSolve(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_delta):
         (delta,) = ctx.saved_tensors
-        w = torch.empty_like(delta)
-        ctx.solver.K.chol_solve(ctx.L, ctx.n, ctx.panels, grad_delta.contiguous(), w)
+        w = ctx.solver.solve_with_snapshot(ctx.factor, grad_delta)
         grad_H = -(w.unsqueeze(2) * delta.unsqueeze(1))
         if ctx.lam is not None:
             grad_H = grad_H - torch.diag_embed(ctx.lam.view(-1, 1) * w * delta)
@@ -144,14 +143,15 @@ class _FusedUnrolledSolve(torch.autograd.Function):
     def forward(ctx, solver, damping, ellipsoidal, eps, poses, meas, w_between, prior_target, w_prior, lr_between, lr_prior):
         lin = solver.linearization
         packed = lin.packed
-        y = solver.factorize(damping, ellipsoidal, eps, rhs=lin.g)
-        delta = torch.empty_like(y)
-        solver._substitute(y, delta, backward_only=True)
-        solver.check_info()
+        # the no-grad path's own solve: the unfused-forward fallback for systems beyond the fused substitution's LDS plan and the
+        # check_singular masking included, so that a problem behaves the same with and without gradients
+        delta = solver._solve(damping, ellipsoidal, eps, check_info=True)
         ctx.ell = solver._lam.clone() if (damping is not None and ellipsoidal) else None   # (lambda diag(H) is in the graph)
         ctx.packed, ctx.n = packed, lin.n
         ctx.tensors = detached_tensors(packed.tensors, poses, meas, w_between, prior_target, w_prior, lr_between, lr_prior)
-        ctx.L, ctx.panels = solver.L.clone(), solver.panels.clone()
+        # one copy of the factor per differentiated iteration (dense frame: B x ld x ld elements; the tile-sparse solver's packed
+        # factor: its non-zero tiles) -- later iterations overwrite the solver's own
+        ctx.solver, ctx.factor = solver, solver.factor_snapshot()
         ctx.delta = delta.clone()
         return delta
 
@@ -160,8 +160,7 @@ class _FusedUnrolledSolve(torch.autograd.Function):
         packed, t, K = ctx.packed, ctx.tensors, ctx.packed.K
         P, B = t.poses.shape[:2]
         dt, dev = t.poses.dtype, t.poses.device
-        w = torch.empty_like(ctx.delta)
-        K.chol_solve(ctx.L, ctx.n, ctx.panels, grad_delta.contiguous(), w)
+        w = ctx.solver.solve_with_snapshot(ctx.factor, grad_delta)
         st = packed.structure
         E, Kp = st.num_edges, st.num_priors
         new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731
@@ -718,7 +717,14 @@ class HipSparseCholeskySolver(HipSparseCholeskyCore, _RefCholeskyDenseSolver):
 
     def solve(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
               damping_eps: float = 1e-8, **kwargs) -> torch.Tensor:
-        g = self.linearization._g_graph
+        lin = self.linearization
+        if getattr(lin, "_unroll", None) is not None and torch.is_grad_enabled():
+            # backward_mode "unroll" / "truncated": the same node as the dense solver's; its backward solves along the tile pattern
+            # with a copy of this call's (tile-packed) factor
+            if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
+                raise ValueError("Damping must be a float or a 1-D tensor.")
+            return _FusedUnrolledSolve.apply(self, damping, ellipsoidal_damping, damping_eps, *lin._unroll)
+        g = lin._g_graph
         if g is not None and torch.is_grad_enabled():
             if damping is not None and isinstance(damping, torch.Tensor) and damping.ndim > 1:
                 raise ValueError("Damping must be a float or a 1-D tensor.")

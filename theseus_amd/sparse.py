@@ -200,8 +200,18 @@ class HipSparseCholeskyCore(HipCholeskyCore):
                 lam.fill_(float(damping))
         y = self._y if rhs is not None else None
         self.factor_version += 1
+        self._factored_with = (lam is not None, bool(ellipsoidal_damping), float(damping_eps))   # (what L L^T is the factor of)
         self._factor_call(lam, ellipsoidal_damping, damping_eps, rhs, y, pattern=self.pattern)
         return y
+
+    def solve_with_snapshot(self, snapshot, rhs: torch.Tensor) -> torch.Tensor:
+        """(L L^T)^-1 rhs with a kept copy of a factor: the list-driven solves along the pattern (the copy has the solver's own
+        layout -- tile-packed or dense frame -- which thx_chol_solve would misread)."""
+        L, panels = snapshot
+        rhs = rhs.contiguous()
+        x = torch.empty_like(rhs)
+        self.K.chol_solve_sparse(L, self.linearization.n, panels, rhs, x, self.pattern, backward_only=False)
+        return x
 
     def _substitute(self, rhs, x, backward_only: bool):
         """The triangular solves over the non-zero tiles of L only (thx_chol_solve_sparse; no limit on n)."""
