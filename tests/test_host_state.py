@@ -33,6 +33,42 @@ def test_in_place_edit_of_an_auxiliary_tensor_is_seen():
     assert (e2 > 5.0 * e1).all(), (e1, e2)   # Between errors carry w^2 = 9x; the priors keep theirs
 
 
+def test_swapping_the_storage_under_an_auxiliary_tensor_is_seen():
+    """``var.tensor.data = other`` / ``tensor.set_()`` keep the tensor OBJECT and its version counter and move only the storage
+    (the auxiliary stamp keyed on the object alone missed it; key = object + storage + version)."""
+    th, g, obj, opt, layer = _layer(iters=1)
+    w_vars = [c.weight.diagonal for c in obj.cost_functions.values() if hasattr(c.weight, "diagonal")]
+    start = {k: v.tensor.clone() for k, v in obj.optim_vars.items()}
+    _, info1 = layer.forward(None, optimizer_kwargs=dict(track_err_history=True, damping=1e-3))
+    for w in w_vars:
+        t = w.tensor
+        ver = t._version
+        t.data = t.detach() * 3.0
+        assert t._version == ver and w.tensor is t
+    _, info2 = layer.forward(start, optimizer_kwargs=dict(track_err_history=True, damping=1e-3))
+    e1, e2 = info1.err_history[:, 0], info2.err_history[:, 0]
+    assert (e2 > 5.0 * e1).all(), (e1, e2)
+
+
+def test_variables_view_the_packed_state_outside_unrolled_differentiation():
+    """Pose tensors that require grad + a plain (no_grad / implicit) optimize(): the variables are re-pointed at the packed state
+    as everywhere else -- only an optimize() that differentiates from the initial tensors (UNROLL / TRUNCATED) leaves them on the
+    caller's graph-carrying tensors."""
+    th, g, obj, opt, layer = _layer(iters=2)
+    for v in obj.optim_vars.values():
+        v.update(v.tensor.clone().requires_grad_(True))
+    seen = []
+
+    def cb(optimizer, info, delta, it):
+        packed = optimizer.linear_solver.linearization.packed
+        v = next(iter(obj.optim_vars.values()))
+        seen.append(v.tensor.data_ptr() == packed.state[0].data_ptr() or not v.tensor.requires_grad)
+    with torch.no_grad():
+        opt.optimize(damping=1e-3, end_iter_callback=cb)
+    assert seen and all(seen)
+    assert not opt.linear_solver.linearization.packed._keep_graph_tensors
+
+
 def test_in_place_edit_without_any_update_is_seen():
     th, g, obj, opt, layer = _layer(iters=1)
     layer.forward(None, optimizer_kwargs=dict(damping=1e-3))

@@ -250,6 +250,7 @@ class PackedBA:
         self._own_variables = all(isinstance(v, Variable) for v in self._tracked_list)
         self._stamp = None
         self._deep_stamp = None
+        self._keep_graph_tensors = False   # (see PackedPoseGraph)
         self._global_stamp = -1
         self._vars_stale = False
         self._state_exposed = False
@@ -308,7 +309,9 @@ class PackedBA:
             ts = list(map(_GET_TENSOR[self._own_variables], tracked))
             n_opt = min(len(self.cam_vars) + len(self.pt_vars), len(ts))
             self._deep_refs = ts[n_opt:] if count is None else getattr(self, "_deep_refs", None)
-            keys = tuple(map(_DATA_PTR, ts[:n_opt])) + tuple(map(id, ts[n_opt:]))
+            # (auxiliary: object AND storage -- ``var.tensor.data = other`` / ``tensor.set_()`` keep the object and its version)
+            aux = ts[n_opt:]
+            keys = tuple(map(_DATA_PTR, ts[:n_opt])) + tuple(zip(map(id, aux), map(_DATA_PTR, aux)))
             return tuple(zip(keys, map(_VERSION, ts)))
         return tuple(map(_NUM_UPDATES, tracked))
 
@@ -385,7 +388,8 @@ class PackedBA:
             self.cc_tensors = PGTensors(poses=cams, meas=self._stack([c.measurement.tensor for c in self.cc_costs], B),
                                         w_between=self._stack([_weight_diag(c.weight, 6) for c in self.cc_costs], B),
                                         prior_target=empty(0, 1, 3, 4), w_prior=empty(0, 1, 6))
-        if not (cams.requires_grad or pts.requires_grad) and any(v.tensor.requires_grad for v in self.cam_vars + self.pt_vars):
+        if (not (cams.requires_grad or pts.requires_grad) and (self._keep_graph_tensors or not self._own_variables)
+                and any(v.tensor.requires_grad for v in self.cam_vars + self.pt_vars)):
             # (packed under no_grad from tensors that carry autograd history: see PackedPoseGraph.sync -- the variables keep them)
             self._stamp = self._current_stamp() if not self._counters_unchanged() else self._stamp
             self._global_stamp = Variable._global_updates

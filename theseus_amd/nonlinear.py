@@ -214,13 +214,15 @@ class NonlinearLeastSquares(abc.ABC):
         variables are re-pointed at the state reached so far BEFORE the exception leaves: otherwise the next
         ``forward(new_inputs)`` would see the stale flag, flush the old private buffer over the user's new tensors and
         silently optimise the previous problem."""
+        packed = self.linear_solver.linearization.packed
         try:
             return self._optimize_loop(**kwargs)
         except BaseException:
-            packed = self.linear_solver.linearization.packed
             with torch.no_grad():
                 packed.flush_variables()   # (a no-op unless the loop left the variables pointing at a stale buffer)
             raise
+        finally:
+            packed._keep_graph_tensors = False
 
     def _optimize_loop(self, track_best_solution: bool = False, track_err_history: bool = False,
                        track_state_history: bool = False, verbose: bool = False,
@@ -255,6 +257,8 @@ class NonlinearLeastSquares(abc.ABC):
         if unrolled and isinstance(self, TrustRegion):
             raise NotImplementedError("differentiable iterations (backward_mode='unroll' / 'truncated' with gradients): Gauss-Newton / "
                                       "Levenberg-Marquardt (a trust-region step reads Av / the Cauchy point outside autograd).")
+        # (only THEN may a no_grad re-pack leave the variables on their own graph-carrying tensors instead of views of the packed state)
+        packed._keep_graph_tensors = init_tensors is not None
         with torch.no_grad():
             packed.sync(deep=True)   # once per optimize(): also catches in-place edits of the variables' tensors
         self.reset(**kwargs, backward_mode=backward_mode)

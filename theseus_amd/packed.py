@@ -150,6 +150,7 @@ class PackedPoseGraph:
         self._own_variables = all(isinstance(v, Variable) for v in self.tracked_list())
         self._stamp = None
         self._deep_stamp = None
+        self._keep_graph_tensors = False   # set by the optimizer around an optimize() that differentiates from the initial tensors
         self._global_stamp = -1
         self._vars_stale = False
         self._state_exposed = False
@@ -215,7 +216,9 @@ class PackedPoseGraph:
             ts = list(map(_GET_TENSOR[self._own_variables], tracked))
             n_opt = min(len(self.pose_vars), len(ts))
             self._deep_refs = ts[n_opt:] if count is None else getattr(self, "_deep_refs", None)
-            keys = tuple(map(_DATA_PTR, ts[:n_opt])) + tuple(map(id, ts[n_opt:]))
+            # (auxiliary: object AND storage -- ``var.tensor.data = other`` / ``tensor.set_()`` keep the object and its version)
+            aux = ts[n_opt:]
+            keys = tuple(map(_DATA_PTR, ts[:n_opt])) + tuple(zip(map(id, aux), map(_DATA_PTR, aux)))
             return tuple(zip(keys, map(_VERSION, ts)))
         return tuple(map(_NUM_UPDATES, tracked))
 
@@ -294,10 +297,14 @@ class PackedPoseGraph:
             self._global_stamp = Variable._global_updates
             self._vars_stale = False
             self._state_exposed = True
-        elif not poses.requires_grad and any(v.tensor.requires_grad for v in self.pose_vars):
+        elif (not poses.requires_grad and (self._keep_graph_tensors or not self._own_variables)
+              and any(v.tensor.requires_grad for v in self.pose_vars)):
             # packed under no_grad from tensors that carry autograd history (the values the caller passed in, about to be
             # differentiated through: backward_mode="unroll"): re-pointing the variables to views of this graph-less copy would cut
-            # them off -- they keep their tensors (same values), the copy is private
+            # them off -- they keep their tensors (same values), the copy is private.  Only where that is needed: theseus_amd's
+            # own loop says so for the optimize() calls that captured the initial tensors (``_keep_graph_tensors``: everywhere
+            # else the variables view the packed state, also inside callbacks and after an exception); under the reference's
+            # loop (its Variable class), which re-assigns every variable every iteration anyway.
             self._stamp = stamp
             self._global_stamp = Variable._global_updates
             self._vars_stale = False
