@@ -21,7 +21,8 @@ from .compiler import PoseGraphStructure
 from .kernels import PGTensors, default_kernels, fast_approx_local_jacobians, round_up
 from .linear_solver import LinearSolver
 from .linearization import Linearization, VariableOrdering
-from .packed import UnsupportedObjective, _aux_vars, _kind, _unwrap_robust, _weight_diag
+from .packed import (UnsupportedObjective, _AuxDeepStamp, _aux_vars, _kind, _opt_deep_stamp, _unwrap_robust, _views_deep_stamp,
+                     _weight_diag)
 
 ERR_CHUNKS = _lib.THX_BA_ERR_CHUNKS
 
@@ -250,6 +251,7 @@ class PackedBA:
         self._own_variables = all(isinstance(v, Variable) for v in self._tracked_list)
         self._stamp = None
         self._deep_stamp = None
+        self._aux_stamp = _AuxDeepStamp()
         self._keep_graph_tensors = False   # (see PackedPoseGraph)
         self._global_stamp = -1
         self._vars_stale = False
@@ -299,20 +301,11 @@ class PackedBA:
         if count is not None:
             tracked = tracked[:count]
         if deep:
-            # tensor identity + autograd version counter: catches IN-PLACE edits of a variable's tensor that never go
-            # through Variable.update() (an nn.Parameter stepped by a torch optimizer, ``var.tensor.mul_()``) and plain
-            # ``var.tensor = other`` -- the reference re-reads ``var.tensor`` at every evaluation (core/objective.py:813-830)
-            # and sees those.  One C-level pass per column (42 k variables of a bundle-adjustment objective: 7 ms instead of
-            # 16).  Identity = the storage pointer for the optimisation variables (their tensors are views of the packed state:
-            # holding them would pin a state buffer), the tensor OBJECT for the auxiliary ones -- kept referenced until the next
-            # stamp, so an id cannot be recycled in between.
+            # (optimisation part, auxiliary part): see PackedPoseGraph._current_stamp / packed._AuxDeepStamp
             ts = list(map(_GET_TENSOR[self._own_variables], tracked))
             n_opt = min(len(self.cam_vars) + len(self.pt_vars), len(ts))
-            self._deep_refs = ts[n_opt:] if count is None else getattr(self, "_deep_refs", None)
-            # (auxiliary: object AND storage -- ``var.tensor.data = other`` / ``tensor.set_()`` keep the object and its version)
-            aux = ts[n_opt:]
-            keys = tuple(map(_DATA_PTR, ts[:n_opt])) + tuple(zip(map(id, aux), map(_DATA_PTR, aux)))
-            return tuple(zip(keys, map(_VERSION, ts)))
+            opt = _opt_deep_stamp(ts[:n_opt])
+            return opt if count is not None else (opt, self._aux_stamp.stamp(ts[n_opt:]))
         return tuple(map(_NUM_UPDATES, tracked))
 
     @staticmethod
@@ -412,8 +405,8 @@ class PackedBA:
         # measurements of a pose graph, 33 k features of a bundle-adjustment problem) are still the ones sync() looked at
         n_opt = len(self.cam_vars) + len(self.pt_vars)
         old = self._deep_stamp
-        if old is not None and len(old) == len(self._stamp):
-            self._deep_stamp = self._current_stamp(deep=True, count=n_opt) + old[n_opt:]
+        if old is not None:
+            self._deep_stamp = (_views_deep_stamp((self.tensors.cams, self.tensors.points)), old[1])
         else:
             self._deep_stamp = self._current_stamp(deep=True)
         self._global_stamp = Variable._global_updates

@@ -25,6 +25,64 @@ import operator
 _GET_TENSOR = {True: operator.attrgetter("_tensor"), False: operator.attrgetter("tensor")}   # own Variable: skip the property
 _DATA_PTR, _VERSION, _NUM_UPDATES = operator.methodcaller("data_ptr"), operator.attrgetter("_version"), operator.attrgetter("_num_updates")
 
+# one C++ loop over a list of tensors instead of 33 k method calls (torch's cudagraph trees check their static inputs with it)
+_PTRS_EQUAL = getattr(torch._C, "_tensors_data_ptrs_at_indices_equal", None)
+
+
+class _AuxDeepStamp:
+    """Deep stamp of the AUXILIARY variables' tensors (measurements, weights, ... -- 33 k of them in a bundle-adjustment objective):
+    has anybody replaced a tensor object, swapped the storage under one (``var.tensor.data = other`` / ``set_()``: object and
+    version counter stay), or edited one in place (``var.tensor.mul_()``: only the autograd version counter moves)?  The reference
+    re-reads ``var.tensor`` at every evaluation (core/objective.py:813-830) and sees all three.
+
+    Three flat comparisons instead of a 3-tuple per tensor (12 ms at 33 k tensors):
+      * the tuple of object ids (0.9 ms; the tensors are kept referenced here, so an id cannot be recycled);
+      * the storage pointers, in one C++ call against the cached list (2 ms; a Python pass of ``data_ptr()`` calls: 4.3 ms);
+      * the version counters of one REPRESENTATIVE per group of tensors that share one: views share their base's counter
+        (``feat[:, k]`` for 32768 observations is one counter), so an in-place edit through ANY of them moves the representative's.
+        A tensor's ``_base`` is fixed at creation: the grouping holds for as long as the ids do."""
+
+    def __init__(self):
+        self.refs = self.ids = self.ptrs = self.ptrs_t = self.reps = self.idx = None
+
+    def stamp(self, ts):
+        ids = tuple(map(id, ts))
+        if ids != self.ids:
+            self.refs, self.ids = ts, ids
+            self.ptrs = list(map(_DATA_PTR, ts))
+            self.ptrs_t = tuple(self.ptrs)
+            self.idx = list(range(len(ts)))
+            groups = {}
+            for t in ts:
+                base = t._base
+                groups.setdefault(id(base) if base is not None else id(t), t)
+            self.reps = list(groups.values())
+        else:
+            same = _PTRS_EQUAL(ts, self.ptrs, self.idx) if (_PTRS_EQUAL is not None and ts) else list(map(_DATA_PTR, ts)) == self.ptrs
+            if not same:
+                self.ptrs = list(map(_DATA_PTR, ts))
+                self.ptrs_t = tuple(self.ptrs)
+        return ids, self.ptrs_t, tuple(map(_VERSION, self.reps))
+
+
+def _opt_deep_stamp(ts):
+    """Deep stamp of the optimisation variables' tensors: storage pointer + version counter (they are views of the packed state:
+    holding the objects would pin a state buffer), as two flat tuples."""
+    return tuple(map(_DATA_PTR, ts)), tuple(map(_VERSION, ts))
+
+
+def _views_deep_stamp(buffers):
+    """``_opt_deep_stamp`` of variables that were JUST re-pointed at ``buf.unbind(0)`` of these buffers, without touching the 8.7 k
+    view objects: view k starts ``k * stride(0)`` elements into its buffer and shares the buffer's version counter."""
+    ptrs, vers = (), ()
+    for buf in buffers:
+        n, step = buf.shape[0], buf.stride(0) * buf.element_size()
+        base = buf.data_ptr()
+        ptrs += tuple(range(base, base + n * step, step)) if step else (base,) * n
+        vers += (buf._version,) * n
+    return ptrs, vers
+
+
 class UnsupportedObjective(NotImplementedError):
     pass
 
@@ -150,6 +208,7 @@ class PackedPoseGraph:
         self._own_variables = all(isinstance(v, Variable) for v in self.tracked_list())
         self._stamp = None
         self._deep_stamp = None
+        self._aux_stamp = _AuxDeepStamp()
         self._keep_graph_tensors = False   # set by the optimizer around an optimize() that differentiates from the initial tensors
         self._global_stamp = -1
         self._vars_stale = False
@@ -206,20 +265,13 @@ class PackedPoseGraph:
         if count is not None:
             tracked = tracked[:count]
         if deep:
-            # tensor identity + autograd version counter: catches IN-PLACE edits of a variable's tensor that never go
-            # through Variable.update() (an nn.Parameter stepped by a torch optimizer, ``var.tensor.mul_()``) and plain
-            # ``var.tensor = other`` -- the reference re-reads ``var.tensor`` at every evaluation (core/objective.py:813-830)
-            # and sees those.  One C-level pass per column (42 k variables of a bundle-adjustment objective: 7 ms instead of
-            # 16).  Identity = the storage pointer for the optimisation variables (their tensors are views of the packed state:
-            # holding them would pin a state buffer), the tensor OBJECT for the auxiliary ones -- kept referenced until the next
-            # stamp, so an id cannot be recycled in between.
+            # (optimisation part, auxiliary part): catches IN-PLACE edits of a variable's tensor that never go through
+            # Variable.update() (an nn.Parameter stepped by a torch optimizer, ``var.tensor.mul_()``), ``var.tensor = other`` and
+            # ``var.tensor.data = other`` -- see _AuxDeepStamp.  ``count``: the optimisation part alone.
             ts = list(map(_GET_TENSOR[self._own_variables], tracked))
             n_opt = min(len(self.pose_vars), len(ts))
-            self._deep_refs = ts[n_opt:] if count is None else getattr(self, "_deep_refs", None)
-            # (auxiliary: object AND storage -- ``var.tensor.data = other`` / ``tensor.set_()`` keep the object and its version)
-            aux = ts[n_opt:]
-            keys = tuple(map(_DATA_PTR, ts[:n_opt])) + tuple(zip(map(id, aux), map(_DATA_PTR, aux)))
-            return tuple(zip(keys, map(_VERSION, ts)))
+            opt = _opt_deep_stamp(ts[:n_opt])
+            return opt if count is not None else (opt, self._aux_stamp.stamp(ts[n_opt:]))
         return tuple(map(_NUM_UPDATES, tracked))
 
     @staticmethod
@@ -252,8 +304,8 @@ class PackedPoseGraph:
         if force or self.tensors is None:
             poses_changed = aux_changed = True
         else:
-            poses_changed = (shallow and stamp[:nP] != self._stamp[:nP]) or (deep and dstamp[:nP] != self._deep_stamp[:nP])
-            aux_changed = (shallow and stamp[nP:] != self._stamp[nP:]) or (deep and dstamp[nP:] != self._deep_stamp[nP:])
+            poses_changed = (shallow and stamp[:nP] != self._stamp[:nP]) or (deep and dstamp[0] != self._deep_stamp[0])
+            aux_changed = (shallow and stamp[nP:] != self._stamp[nP:]) or (deep and dstamp[1] != self._deep_stamp[1])
         if not (poses_changed or aux_changed):
             self._global_stamp = Variable._global_updates
             return
@@ -342,8 +394,8 @@ class PackedPoseGraph:
         # measurements of a pose graph, 33 k features of a bundle-adjustment problem) are still the ones sync() looked at
         n_opt = len(self.pose_vars)
         old = self._deep_stamp
-        if old is not None and len(old) == len(self._stamp):
-            self._deep_stamp = self._current_stamp(deep=True, count=n_opt) + old[n_opt:]
+        if old is not None:
+            self._deep_stamp = (_views_deep_stamp((poses,)), old[1])
         else:
             self._deep_stamp = self._current_stamp(deep=True)
         self._global_stamp = Variable._global_updates
