@@ -1817,8 +1817,9 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   float* Pc = smem + OFF32_STAGE_FLOATS;
 
 #ifdef THX_OFF_PROF  // timing build (tools/prof/off_prof.py): cycle stamps overwrite the head of the output tile
-  long long st[6];
+  long long st[7];
   st[0] = (long long)__builtin_readcyclecounter();
+  st[5] = 0;
   const long long wc0 = (long long)wall_clock64();
 #endif
   // ---- prefetch: panel sub-blocks (s,t), t <= s, then the H tile.  Issued from inside the K-loop's prologue, AFTER the
@@ -1920,6 +1921,11 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
       }
     __syncthreads();  // panel copy visible (also when the K-loop had no iterations)
   }
+#ifdef THX_OFF_PROF
+  __builtin_amdgcn_sched_barrier(0);
+  st[5] = (long long)__builtin_readcyclecounter();   // P = H - sum done (block-compact H: the gather rounds)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   Engine<float>::Acc X;
   Engine<float>::zero(X);
 #ifdef THX_EXP_FULLINV   // timing experiment: the dataflow of a FULL 128 x 128 inverse in the panel, X_s = sum_{t <= s} W_st P_t --
@@ -1963,6 +1969,7 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
     float* o = Lij;
     for (int k = 1; k < 5; ++k) o[k] = (float)(st[k] - st[0]);
     o[5] = (float)((long long)wall_clock64() - wc0);  // 100 MHz ticks
+    o[6] = (float)(st[5] - st[0]);
   }
 #endif
 }
@@ -2042,6 +2049,15 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   double* sA = smem;
   double* sB = smem + 128 * CT<double>::LDT;
 
+#ifdef THX_OFF_PROF64   // timing build (tools/prof/off_prof64.py): cycle stamps overwrite the head of the output tile
+  long long st64[16];
+  for (int k = 0; k < 16; ++k) st64[k] = 0;
+  st64[0] = (long long)__builtin_readcyclecounter();
+  const long long wc64 = (long long)wall_clock64();
+#define THX_ST64(k) do { __builtin_amdgcn_sched_barrier(0); st64[k] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define THX_ST64(k)
+#endif
   E::Acc P;
   E::zero(P);
   HBPre<double, HB ? HB_NPRE_OFF : 1> hbp;
@@ -2068,6 +2084,7 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
                        ldt, Kspan, sA, sB, P, tid, nullptr, nullptr, prefetch_panel, klist, ksa, ksb, lf.pstride);
   // sub-blocks 5..9: requested now (the K-loop's prefetch registers are free) next to H; 5..8 go into the staging buffers as soon
   // as those are free, W_33 (sub-block 9) waits in 8 VGPRs for sub-block 0's place in E
+  THX_ST64(1);   // K-loop done
   double2 late[5][2];
   if constexpr (!HB) {
     // dense H: 5..8 straight into the staging buffers (LDS-direct, no registers: the 128 VGPRs of the H tile are about to be in
@@ -2107,8 +2124,12 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
     constexpr int LDH = 130;
     static_assert(32 * LDH * 8 <= OFF64_STAGE, "a quarter of an H tile must fit in the staging buffers");
     __syncthreads();
+    THX_ST64(8);    // (sub-stamps 8..11: the first barrier -- the K-loop's last MFMAs drained --, then the gather rounds 1..3 begin)
 #pragma unroll
     for (int rd = 0; rd < 4; ++rd) {
+      if (rd == 1) THX_ST64(9);
+      if (rd == 2) THX_ST64(10);
+      if (rd == 3) THX_ST64(11);
       for (int k = tid; k < 32 * LDH / 2; k += 256) reinterpret_cast<double2*>(smem)[k] = make_double2(0.0, 0.0);
       __syncthreads();
       hbp.foreach(hb, b, tid, [&](int rr, int cc, double v) __attribute__((always_inline)) {
@@ -2143,6 +2164,7 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
       }
   }
   }
+  THX_ST64(2);   // P = H - sum
   // sub-blocks 5..8 -> the staging buffers (free: the K-loop / the H rounds ended on a barrier; column 0 has neither, and nobody
   // has touched them)
   if constexpr (HB) {
@@ -2154,6 +2176,7 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   // E (LDS-direct loads of the prologue) and the staging buffers complete and visible to every wave
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  THX_ST64(3);   // panel staged and visible
   // ---- in-place substitution ----
   auto solve_diag = [&](auto is, const double* Wss) __attribute__((always_inline)) {
     constexpr int sb = decltype(is)::value;
@@ -2197,6 +2220,7 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   update(I3{}, I2{}, smem + 3 * 1024);
   __syncthreads();                  // W_33 in place
   solve_diag(I3{}, smemE + 0 * 1024);
+  THX_ST64(4);   // substitution done
   // ---- store X (in P's registers) ----
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -2209,6 +2233,18 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
         for (int rho = 0; rho < 4; ++rho) Lrow[16 * cb + 4 * rho] = P.v[h][cb][rho];
     }
   }
+#ifdef THX_OFF_PROF64
+  __builtin_amdgcn_s_waitcnt(0);
+  st64[5] = (long long)__builtin_readcyclecounter();
+  __syncthreads();
+  if (tid == 0) {
+    double* o = Lij;
+    for (int k = 1; k < 6; ++k) o[k] = (double)(st64[k] - st64[0]);
+    o[6] = (double)((long long)wall_clock64() - wc64);  // 100 MHz ticks
+    for (int k = 8; k < 12; ++k) o[k] = (double)(st64[k] - st64[0]);
+  }
+#endif
+#undef THX_ST64
 }
 
 // ------------------------------------------------------------------------------------------------
