@@ -1970,6 +1970,11 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
     for (int k = 1; k < 5; ++k) o[k] = (float)(st[k] - st[0]);
     o[5] = (float)((long long)wall_clock64() - wc0);  // 100 MHz ticks
     o[6] = (float)(st[5] - st[0]);
+    // where and when this workgroup ran (tools/prof/off_occupancy.py): raw 32-bit words
+    o[7] = __int_as_float((int)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4));    // HW_REG_HW_ID
+    o[8] = __int_as_float((int)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20));   // HW_REG_XCC_ID
+    o[9] = __int_as_float((int)(unsigned)wc0);
+    o[10] = __int_as_float((int)(unsigned)wall_clock64());
   }
 #endif
 }
