@@ -343,6 +343,12 @@ int thx_chol_solve(const void* L, int64_t ld, int32_t n, int32_t B, const void* 
  *      their pivot chains instead of three).  The split pays from `min_batch` problems per call on (default 2048; 0 = always
  *      split, INT32_MAX = never); `previous` (may be NULL) receives the old value. */
 int thx_chol_set_split_diag_min_batch(int32_t min_batch, int32_t* previous);
+/*      Schedule knob of the fp32 thx_chol_factor* on dense factor frames (process-wide; bit-identical factor either way).  on != 0
+ *      (default; environment THX_CHOL_COLPAIR=0 starts with it off): two block columns at a time -- diag(j), tile (j+1, j),
+ *      diag(j+1), then ONE workgroup per row tile i >= j+2 produces L_ij and L_i,j+1, streaming row panel L_i,0:j from HBM once
+ *      for both (the factorisation runs at the socket's power cap; its HBM traffic is a quarter of that power).  `previous`
+ *      (may be NULL) receives the old value. */
+int thx_chol_set_column_pairs(int32_t on, int32_t* previous);
 /*      (block-compact Hessian, see thx_hblock_layout) */
 int thx_chol_factor_hblocks(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t n, int32_t B,
                             const void* damping, int ellipsoidal, double damping_eps, void* L, int64_t ld, void* Winv,

@@ -88,6 +88,38 @@ def test_factor_from_blocks_is_bit_identical(K, name, ellipsoidal, split):
             assert torch.equal(Pa[:, :, 32 * u:32 * u + 32, 32 * v:32 * v + 32], Pb[:, :, 32 * u:32 * u + 32, 32 * v:32 * v + 32])
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_factor_from_blocks_in_column_pairs_is_bit_identical(K, split):
+    """thx_chol_factor_hblocks, fp32, 12 tile columns: the column-pair schedule (both H tiles of a workgroup gathered from the
+    block list) against the column-by-column one -- L, panels, y bit for bit."""
+    s, hb, dhb, H, gv, Hc, g2, n, ld = _assembled(K, "pg_full_f32_lm")
+    B = H.shape[0]
+    nt = (n + 127) // 128
+    lam = torch.full((B,), 1e-3, dtype=H.dtype, device="cuda")
+    prev_split = K.chol_split_diag_min_batch(0 if split else 2 ** 31 - 1)
+    out = []
+    try:
+        for pairs in (True, False):
+            prev = K.chol_column_pairs(pairs)
+            try:
+                L = torch.zeros_like(H)
+                panels = torch.zeros(B, nt, 128, 128, dtype=H.dtype, device="cuda")
+                info = torch.empty(B, dtype=torch.int32, device="cuda")
+                y = torch.empty_like(gv)
+                K.chol_factor_hblocks(dhb, Hc, n, lam, False, 1e-8, L, panels, info, rhs=gv, y=y)
+                out.append((torch.tril(L[:, :n, :n]), panels, y, info))
+            finally:
+                K.chol_column_pairs(prev)
+    finally:
+        K.chol_split_diag_min_batch(prev_split)
+    (La, Pa, ya, ia), (Lb, Pb, yb, ib) = out
+    assert int(ia.abs().sum()) == 0 and int(ib.abs().sum()) == 0
+    assert torch.equal(La, Lb) and torch.equal(ya, yb)
+    for u in range(4):
+        for v in range(u + 1):
+            assert torch.equal(Pa[:, :, 32 * u:32 * u + 32, 32 * v:32 * v + 32], Pb[:, :, 32 * u:32 * u + 32, 32 * v:32 * v + 32])
+
+
 @pytest.mark.parametrize("solver", ["dense", "sparse"])
 @pytest.mark.parametrize("name", ["pg_full_f32_lm", "pg_full_f64_lm"])
 def test_lm_with_block_hessian_equals_dense_frame(name, solver):

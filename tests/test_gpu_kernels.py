@@ -263,6 +263,40 @@ def test_chol_split_and_fused_diagonal_phase_agree(K, dtype):
     assert (xa - xb).abs().max() <= (2e-5 if dtype == torch.float32 else 1e-13) * xb.abs().max()
 
 
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("n,B", [(258, 5), (390, 12), (700, 9), (1100, 16), (1536, 8)])
+def test_chol_column_pairs_are_bit_identical(K, n, B, split):
+    """fp32, dense frame: two block columns per off-diagonal launch (chol_offdiag2_f32_kernel: row panel L_i streamed once for
+    tiles (i, j) and (i, j + 1), column j's share of the second tile from the first tile's registers) run the same MFMAs in the
+    same order as the column-by-column schedule: L, the panels, the fused forward substitution and the solution agree bit for
+    bit -- 3 ... 12 tile columns, last tile partial (258, 390, 700, 1100) or full, batch not a multiple of 8."""
+    from tests.gpu_helpers import factor_and_solve
+    from theseus_amd.kernels import round_up
+    dtype = torch.float32
+    M = _random_spd(B, n, dtype, seed=n + B)
+    rhs = torch.randn(B, n, dtype=torch.float64, generator=torch.Generator().manual_seed(2)).to(dtype).cuda()
+    ld = round_up(n, 32)
+    H = torch.zeros(B, ld, ld, dtype=dtype)
+    H[:, :n, :n] = torch.tril(M)
+    H = H.cuda()
+    lam = torch.full((B,), 0.05, dtype=dtype, device="cuda")
+    out = {}
+    prev_split = K.chol_split_diag_min_batch(0 if split else 2 ** 31 - 1)
+    try:
+        for pairs in (True, False):
+            prev = K.chol_column_pairs(pairs)
+            try:
+                out[pairs] = factor_and_solve(K, H, n, rhs, damping=lam, ellipsoidal=True, eps=1e-8, fused=True)
+            finally:
+                K.chol_column_pairs(prev)
+    finally:
+        K.chol_split_diag_min_batch(prev_split)
+    (La, xa, ia), (Lb, xb, ib) = out[True], out[False]
+    assert int(ia.abs().sum()) == 0 and int(ib.abs().sum()) == 0
+    assert torch.equal(torch.tril(La[:, :n, :n]), torch.tril(Lb[:, :n, :n]))
+    assert torch.equal(xa, xb)
+
+
 def test_chol_split_diagonal_phase_reports_non_positive_definite(K, split_diag):
     from tests.gpu_helpers import factor_and_solve
     n, B = 260, 4

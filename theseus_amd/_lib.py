@@ -159,6 +159,7 @@ _SIGNATURES = {
     "thx_chol_solve_sparse": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                               POINTER(TilePattern), c_int, c_void_p],
     "thx_chol_set_split_diag_min_batch": [c_int32, POINTER(c_int32)],
+    "thx_chol_set_column_pairs": [c_int32, POINTER(c_int32)],
     "thx_pg_assemble_blocks": [POINTER(PGStructure), POINTER(PGData), POINTER(HBlockLayout), c_void_p, c_int64, c_void_p, c_int,
                                POINTER(LieEps), c_void_p],
     "thx_hblocks_expand": [POINTER(HBlockLayout), c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int, c_void_p],

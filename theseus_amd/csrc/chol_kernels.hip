@@ -1979,6 +1979,251 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// chol_offdiag2, fp32, dense L frame: tiles (i, j) AND (i, j + 1) of row tile i >= j + 2 in one workgroup (round 5).
+// Under thx_chol_factor the socket sits at its 1400 W cap (rocm-smi: 1356 W, 2.2 GHz; an HBM copy alone costs ~140 W per
+// TB/s, profiles/r5/q_, r_): the factorisation's 2.7 TB/s are a quarter of its power.  Left-looking, tile (i, j) streams row
+// panel L_i,0:j once per COLUMN j; here it is streamed once per column PAIR -- the K-loop over block columns 0 .. j - 1 stages
+// three operand chunks (rows j, rows j + 1, rows i) for two tile products (4 for 2 before: -25 % operand loads, staging stores
+// and barriers per MFMA, half the row-panel bytes from HBM), then
+//   X0 = (H_ij - P0) L_jj^-T                      (the substitution of chol_offdiag, stored as L_ij)
+//   P1 += X0 L_{j+1,j}^T                           (block column j's share of tile (i, j + 1): X0 stays in the accumulator
+//                                                   registers and is the MFMAs' B operand itself -- an MFMA's k index is only a
+//                                                   pairing of columns, and the accumulator layout pairs its columns the way the
+//                                                   staged fragments do; the four chunks of L_{j+1,j} are staged as in the K-loop)
+//   X1 = (H_i,j+1 - P1) L_{j+1,j+1}^-T
+// Every accumulator receives the SAME MFMAs in the SAME order as in chol_offdiag_f32_kernel: the factor is bit-identical.
+// Needs diag(j), tile (j + 1, j) and diag(j + 1) before it: the host launches column j's head tile alone (factor_impl).
+// LDS 76 KB (two workgroups per CU): [0, 54 KB) three staging buffers | [36 KB, 76 KB) the panel copy of the substitution in
+// progress (lands there straight from global memory after the K-loop; overlaps the third staging buffer only).
+// ------------------------------------------------------------------------------------------------
+constexpr int OFF2_PANEL_OFF = 2 * 128 * 36;              // floats: right behind staging buffers 0 and 1
+constexpr int OFF2_SMEM = (OFF2_PANEL_OFF + 10 * 1024) * 4;   // 76 KB
+static_assert(64 * 132 <= OFF2_PANEL_OFF, "the H gather (half a tile) must not touch the panel copy");
+static_assert(2 * 128 * 36 <= OFF2_PANEL_OFF, "staging buffers 0 and 1 must not touch the panel copy");
+static_assert(OFF2_SMEM >= 3 * 128 * 36 * 4 && 2 * OFF2_SMEM <= 160 * 1024, "three staging buffers; two workgroups per CU");
+
+template <bool HB>
+__global__ void __launch_bounds__(256, 2)
+chol_offdiag2_f32_kernel(const float* __restrict__ H, float* __restrict__ L, const float* __restrict__ panel, int n,
+                         int64_t ld, int j, int ntiles, int i_first, int nrow_tiles, int B, HBlk hb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int b = (slot / nrow_tiles) * 8 + xcd;   // problem-major: all row tiles of a problem on ONE XCD (panel rows j, j + 1 in its L2)
+  const int i = i_first + slot % nrow_tiles;
+  if (b >= B) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t mat = (int64_t)b * ld * ld;
+  const int col0 = j * TILE, row0 = i * TILE;
+  const int validB = min(TILE, n - row0);
+  float* sA0 = smem;
+  float* sA1 = smem + 128 * 36;
+  float* sB = smem + 2 * 128 * 36;
+  float* Pc = smem + OFF2_PANEL_OFF;
+  const int r = 32 * wave + (lane & 31), g = lane >> 5, rl = lane & 31;
+  const bool rvalid = r < validB;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+  HBPre<float, HB ? HB_NPRE_OFF : 1> hb0, hb1;
+  // ---- K-loop over block columns 0 .. j - 1: P0 += L_i L_j^T, P1 += L_i L_{j+1}^T ----
+  const int lrow = tid >> 3, lc = tid & 7;
+  unsigned voff[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) voff[u] = (unsigned)(((lrow + 32 * u) * (int)ld + lc * 4) * 4);
+  const float* Lb = L + mat;
+  const __amdgpu_buffer_rsrc_t rsA0 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lb + (int64_t)col0 * ld), 0, (int)(TILE * ld * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA1 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lb + (int64_t)(col0 + TILE) * ld), 0, (int)(TILE * ld * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lb + (int64_t)row0 * ld), 0, (int)(validB * ld * 4), 0x00020000);
+  uint4 q0[4], q1[4], qb[4];
+  auto gload3 = [&](int kc) __attribute__((always_inline)) {
+    const int so = kc * 32 * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsA0, voff[u], so, 0);
+      const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rsA1, voff[u], so, 0);
+      const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff[u], so, 0);
+      q0[u] = make_uint4(a.x, a.y, a.z, a.w);
+      q1[u] = make_uint4(c.x, c.y, c.z, c.w);
+      qb[u] = make_uint4(d.x, d.y, d.z, d.w);
+    }
+  };
+  auto gload1 = [&](int kc) __attribute__((always_inline)) {   // rows j + 1 only (block column j's share)
+    const int so = kc * 32 * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rsA1, voff[u], so, 0);
+      q1[u] = make_uint4(c.x, c.y, c.z, c.w);
+    }
+  };
+  Engine<float>::Acc P0, P1;
+  Engine<float>::zero(P0);
+  Engine<float>::zero(P1);
+  const int nk = 4 * j;
+  if (nk > 0) gload3(0);
+  if constexpr (HB) {
+    hb0.load(hb, b, i, j, tid);
+    hb1.load(hb, b, i, j + 1, tid);
+  }
+  const float* sBw = sB + 32 * wave * 36;
+  for (int kc = 0; kc < nk; ++kc) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = lrow + 32 * u;
+      *reinterpret_cast<uint4*>(sA0 + row * 36 + 4 * lc) = q0[u];
+      *reinterpret_cast<uint4*>(sA1 + row * 36 + 4 * lc) = q1[u];
+      *reinterpret_cast<uint4*>(sB + row * 36 + 4 * lc) = qb[u];
+    }
+    __syncthreads();
+    if (kc + 1 < nk) gload3(kc + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float4 fb = *reinterpret_cast<const float4*>(sBw + rl * 36 + 8 * ks + 4 * g);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const float4 fa = *reinterpret_cast<const float4*>(sA0 + (32 * cb + rl) * 36 + 8 * ks + 4 * g);
+        P0.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, P0.v[cb], 0, 0, 0);
+        P0.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, P0.v[cb], 0, 0, 0);
+        P0.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, P0.v[cb], 0, 0, 0);
+        P0.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, P0.v[cb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const float4 fa = *reinterpret_cast<const float4*>(sA1 + (32 * cb + rl) * 36 + 8 * ks + 4 * g);
+        P1.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, P1.v[cb], 0, 0, 0);
+        P1.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, P1.v[cb], 0, 0, 0);
+        P1.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, P1.v[cb], 0, 0, 0);
+        P1.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, P1.v[cb], 0, 0, 0);
+      }
+    }
+  }
+
+  // panel of diagonal tile jj: global -> LDS directly (global_load_lds: no registers -- ten pieces per thread held across the H
+  // gather were spilled), in the substitution's swizzled layout: LDS slot (row pi, 16-byte slot ps) of a sub-block receives the
+  // row's piece ps ^ ((pi >> 1) & 7); a wave fills 1 KB of consecutive slots per instruction
+  auto panel_dma = [&](int jj) __attribute__((always_inline)) {
+    const float* Pn = panel + ((int64_t)b * ntiles + jj) * TILE * TILE;
+    const int pi = 8 * wave + (lane >> 3), pc = (lane & 7) ^ ((pi >> 1) & 7);
+    const float* src = Pn + pi * TILE + 4 * pc;
+    static_for<4>([&](auto is) __attribute__((always_inline)) {
+      constexpr int sb = decltype(is)::value;
+      static_for<sb + 1>([&](auto it) __attribute__((always_inline)) {
+        constexpr int tb = decltype(it)::value;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 32 * sb * TILE + 32 * tb),
+                                         (__attribute__((address_space(3))) void*)(Pc + (sb * (sb + 1) / 2 + tb) * 1024 + wave * 256),
+                                         16, 0, 0);
+      });
+    });
+  };
+  // P <- H_(i, jj) - P  (block-compact H: the tile's pieces through the free staging buffers, 64 rows at a time; dense: loads)
+  auto h_minus = [&](Engine<float>::Acc& P, const HBPre<float, HB ? HB_NPRE_OFF : 1>& hbp, int jj) __attribute__((always_inline)) {
+    if constexpr (HB) {
+      constexpr int LDH = 132;
+      __syncthreads();   // whatever read the staging buffers last is done
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        for (int k = tid; k < 64 * LDH / 4; k += 256) reinterpret_cast<float4*>(smem)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        hbp.foreach(hb, b, tid, [&](int rr, int cc, float v) __attribute__((always_inline)) {
+          if ((rr >> 6) == half) smem[(rr & 63) * LDH + cc] = v;
+        });
+        __syncthreads();
+        if ((wave >> 1) == half) {
+          const float* hrow = smem + (r & 63) * LDH + 4 * g;
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4 h = *reinterpret_cast<const float4*>(hrow + 32 * cb + 8 * q);
+              P.v[cb][4 * q + 0] = h.x - P.v[cb][4 * q + 0];
+              P.v[cb][4 * q + 1] = h.y - P.v[cb][4 * q + 1];
+              P.v[cb][4 * q + 2] = h.z - P.v[cb][4 * q + 2];
+              P.v[cb][4 * q + 3] = h.w - P.v[cb][4 * q + 3];
+            }
+        }
+        __syncthreads();
+      }
+    } else {
+      const float* Hrow = H + mat + (int64_t)(row0 + (rvalid ? r : 0)) * ld + jj * TILE + 4 * g;
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        float4 h[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = *reinterpret_cast<const float4*>(Hrow + 32 * cb + 8 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          P.v[cb][4 * q + 0] = (rvalid ? h[q].x : 0.f) - P.v[cb][4 * q + 0];
+          P.v[cb][4 * q + 1] = (rvalid ? h[q].y : 0.f) - P.v[cb][4 * q + 1];
+          P.v[cb][4 * q + 2] = (rvalid ? h[q].z : 0.f) - P.v[cb][4 * q + 2];
+          P.v[cb][4 * q + 3] = (rvalid ? h[q].w : 0.f) - P.v[cb][4 * q + 3];
+        }
+      }
+    }
+  };
+  // X = P L_jj^-T with the panel copy in LDS (chol_offdiag's substitution), X -> tile (i, jj) of L
+  auto substitute_store = [&](Engine<float>::Acc& P, Engine<float>::Acc& X, int jj) __attribute__((always_inline)) {
+    Engine<float>::zero(X);
+    static_for<4>([&](auto is) __attribute__((always_inline)) {
+      constexpr int sb = decltype(is)::value;
+      static_for<sb>([&](auto it) __attribute__((always_inline)) {
+        constexpr int tb = decltype(it)::value;
+        sub_mma_sw<sb, tb>(Pc, X, P, lane);  // P_s += (-L_st) X_t
+      });
+      sub_mma_sw<sb, sb>(Pc, P, X, lane);    // X_s  = W_ss P_s
+    });
+    if (rvalid) {
+      float* Lrow = L + mat + (int64_t)(row0 + r) * ld + jj * TILE + 4 * g;
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(Lrow + 32 * cb + 8 * q) =
+              make_float4(X.v[cb][4 * q], X.v[cb][4 * q + 1], X.v[cb][4 * q + 2], X.v[cb][4 * q + 3]);
+    }
+  };
+
+  // ---- tile (i, j) ----
+  __syncthreads();      // the K-loop's last chunk has been consumed: the panel copy overlaps staging buffer 2
+  panel_dma(j);
+  h_minus(P0, hb0, j);
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of the panel have landed
+  __syncthreads();
+  gload1(nk);           // first chunk of L_{j+1,j}: in flight under the substitution
+  Engine<float>::Acc X0;
+  substitute_store(P0, X0, j);
+  // ---- block column j's share of tile (i, j + 1): P1 += X0 L_{j+1,j}^T, X0 from registers ----
+  static_for<4>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int c = decltype(ic)::value;
+    __syncthreads();    // (c = 0: the substitution's reads of the panel copy are done as well)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4*>(sA1 + (lrow + 32 * u) * 36 + 4 * lc) = q1[u];
+    __syncthreads();
+    if (c == 0) panel_dma(j + 1);   // lands under the four chunks' MFMAs
+    if (c < 3) gload1(nk + c + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const float4 fa = *reinterpret_cast<const float4*>(sA1 + (32 * cb + rl) * 36 + 8 * ks + 4 * g);
+        P1.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, X0.v[c][4 * ks + 0], P1.v[cb], 0, 0, 0);
+        P1.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, X0.v[c][4 * ks + 1], P1.v[cb], 0, 0, 0);
+        P1.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, X0.v[c][4 * ks + 2], P1.v[cb], 0, 0, 0);
+        P1.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, X0.v[c][4 * ks + 3], P1.v[cb], 0, 0, 0);
+      }
+    }
+  });
+  // ---- tile (i, j + 1) ----
+  h_minus(P1, hb1, j + 1);
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+  __syncthreads();
+  substitute_store(P1, X0, j + 1);
+}
+
 // (A variant computing TWO row tiles per workgroup -- the column panel streamed once for both products, 3 staged operand
 //  tiles per 2 tile products, half the workgroups, H / panel loaded after the K-loop, 240 VGPRs, 54 KB LDS -- measured
 //  48.5 ms against 48.3 ms for this kernel on the same box at n = 1536, batch 4096, and the same at n = 3072 / batch 256 and
@@ -2496,6 +2741,11 @@ static std::atomic<int> g_split_diag_min{[] {
   return e ? atoi(e) : 2048;
 }()};
 
+static std::atomic<int> g_column_pairs{[] {
+  const char* e = getenv("THX_CHOL_COLPAIR");   // (initial value of thx_chol_set_column_pairs's knob)
+  return e ? atoi(e) : 1;
+}()};
+
 // Launch-side state is kept PER DEVICE (a process may drive several GPUs, from several threads): the dynamic-LDS limits
 // raised with hipFuncSetAttribute, and the auxiliary stream + events of the two-stream schedule, which belong to the device
 // they were created on.
@@ -2563,6 +2813,10 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF32_SMEM);
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f32_kernel<true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF32_SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag2_f32_kernel<false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, OFF2_SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag2_f32_kernel<true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, OFF2_SMEM);
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<true>),
@@ -2634,6 +2888,20 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       else
         hipLaunchKernelGGL(chol_offdiag_f64_kernel<false>, dim3(Bpad * nrt), dim3(256), OFF64_SMEM, h.s, Hh, (double*)L + mo,
                            (const double*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));
+    }
+  };
+  // tiles (i, j) and (i, j + 1) of row tiles [i_first, i_first + nrt) in one workgroup each (chol_offdiag2_f32_kernel)
+  auto launch_pair = [&](const Half& h, int j, int i_first, int nrt) {
+    if constexpr (sizeof(T) == 4) {
+      const int Bpad = (h.nb + 7) / 8 * 8;
+      const int64_t mo = (int64_t)h.b0 * lstride, po = (int64_t)h.b0 * ntiles * TILE * TILE;
+      const float* Hh = use_hb ? nullptr : (const float*)H + (int64_t)h.b0 * hstride;
+      if (use_hb)
+        hipLaunchKernelGGL(chol_offdiag2_f32_kernel<true>, dim3(Bpad * nrt), dim3(256), OFF2_SMEM, h.s, Hh, (float*)L + mo,
+                           (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, hb_of(h));
+      else
+        hipLaunchKernelGGL(chol_offdiag2_f32_kernel<false>, dim3(Bpad * nrt), dim3(256), OFF2_SMEM, h.s, Hh, (float*)L + mo,
+                           (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, hb_of(h));
     }
   };
   auto launch_diag = [&](const Half& h, int j) {
@@ -2729,16 +2997,29 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     if (rest_pending) hipStreamWaitEvent(st, ds.ev_rest, 0);
     return check_launch("thx_chol_factor");
   }
-  for (int j = 0; j < ntiles; ++j) {
+  // COLUMN PAIRS (fp32, dense L frame without a tile pattern; THX_CHOL_COLPAIR=0 / thx_chol_set_column_pairs(0) turn them off): block columns j, j + 1 with row
+  // tiles below j + 1 run as  diag(j) -> tile (j + 1, j) alone -> diag(j + 1) -> one chol_offdiag2 workgroup per row tile i >= j + 2
+  // producing (i, j) and (i, j + 1) -- the same arithmetic in the same order, so the factor is bit-identical to the
+  // column-by-column schedule; the row panels are streamed from HBM once per pair.
+  const bool colpair = g_column_pairs.load() != 0 && sizeof(T) == 4 && !tp && !packed;
+  for (int j = 0; j < ntiles;) {
+    const bool pair = colpair && j + 2 < ntiles;
     for (int k = 0; k < nparts; ++k) {
       const Half& h = halves[k];
       if (h.nb <= 0) continue;
       if (split && k > 0 && j == 0) hipStreamWaitEvent(h.s, ds.ev_lag[k - 1], 0);  // part k: one diagonal phase behind part k-1
       launch_diag(h, j);
       if (split && k + 1 < nparts && j == 0) hipEventRecord(ds.ev_lag[k], h.s);
+      if (pair) {
+        launch_off(h, j, j + 1, 1);
+        launch_diag(h, j + 1);
+        launch_pair(h, j, j + 2, ntiles - 2 - j);
+        continue;
+      }
       const int nrt = tp ? tp->col_count_host[j] : ntiles - 1 - j;   // (tile-sparse: the column's non-zero row tiles)
       if (nrt > 0) launch_off(h, j, tp ? 0 : j + 1, nrt);
     }
+    j += pair ? 2 : 1;
   }
   if (split) {
     for (int k = 0; k + 1 < nparts; ++k) {
@@ -2895,6 +3176,12 @@ int thx_chol_factor_hblocks(const thx_hblock_layout* layout, const void* Hc, int
 int thx_chol_set_split_diag_min_batch(int32_t min_batch, int32_t* previous) {
   if (min_batch < 0) return fail("thx_chol_set_split_diag_min_batch: min_batch < 0");
   const int old = g_split_diag_min.exchange(min_batch);
+  if (previous) *previous = old;
+  return 0;
+}
+
+int thx_chol_set_column_pairs(int32_t on, int32_t* previous) {
+  const int old = g_column_pairs.exchange(on ? 1 : 0);
   if (previous) *previous = old;
   return 0;
 }

@@ -650,6 +650,14 @@ class HipKernels:
         _lib.check(self.lib.thx_chol_set_split_diag_min_batch(int(min_batch), ctypes.byref(prev)), "thx_chol_set_split_diag_min_batch")
         return int(prev.value)
 
+    def chol_column_pairs(self, on: bool) -> bool:
+        """Schedule knob of the fp32 dense-frame factorisation (include/theseus_hip.h: thx_chol_set_column_pairs): two block
+        columns per off-diagonal launch, bit-identical factor.  Returns the previous setting."""
+        import ctypes
+        prev = ctypes.c_int32(0)
+        _lib.check(self.lib.thx_chol_set_column_pairs(1 if on else 0, ctypes.byref(prev)), "thx_chol_set_column_pairs")
+        return bool(prev.value)
+
     def chol_solve(self, L, n, panels, rhs, x):
         B, ld = L.shape[0], L.shape[-1]
         _lib.check(self.lib.thx_chol_solve(_lib.ptr(L), ld, n, B, _lib.ptr(panels), _lib.ptr(rhs), _lib.ptr(x),
