@@ -428,7 +428,7 @@ def pg_run(cfg, ctx):
                 "bound": "mfma",
                 "kernel": ("thx_chol_factor_hblocks" + (" along the tile pattern" if sparse else "") if "chol_factor_hblocks" in phases
                            else ("thx_chol_factor_sparse" if sparse else "thx_chol_factor_forward")) +
-                          " (chol_syrk + chol_potrf [or chol_diag] + chol_offdiag launches per block column)",
+                          " (chol_syrk + chol_potrf [or chol_diag] + chol_offdiag launches per block column; fp32 dense frames: chol_offdiag2 per column pair)",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": traffic, "traffic_unit": "bytes per factor call (PMC, rocprofv3)",
                 "traffic_source": traffic_src, "flops_per_launch": flops_per_launch, "avg_launch_ms": fac["avg_ms"],
