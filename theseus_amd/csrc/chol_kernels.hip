@@ -1233,6 +1233,11 @@ struct HBPre {
   T v[NPRE];
   int rc[NPRE];   // (r << 8) | c inside the tile, -1: nothing
   int p0, cnt;
+  // BRANCH-FREE (round 5): the loads of all NPRE elements are independent of each other -- with an ``if (idx < cnt)`` around each
+  // element hipcc emitted  table load, s_waitcnt vmcnt(0), table load, s_waitcnt vmcnt(0), value load  once per element, i.e.
+  // 2 NPRE exposed round trips at the head of every workgroup (6 per off-diagonal tile, 14 per SYRK workgroup).  Now: both tables
+  // of all elements in one batch, one wait, all values in one batch whose wait is the first use (after the K-loop).  A lane
+  // without an element reads element 0 of the tile's first piece and discards it.
   __device__ __forceinline__ void load(const HBlk& hb, int b, int ti, int tj, int tid) {
     const T* base = static_cast<const T*>(hb.blocks) + (int64_t)b * hb.bstride;
     const int bd = hb.bd, bb = bd * bd, t = ti * (ti + 1) / 2 + tj;
@@ -1240,17 +1245,29 @@ struct HBPre {
     cnt = (hb.tile_ptr[t + 1] - p0) * bb;
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int idx = tid + 256 * k;
       rc[k] = -1;
       v[k] = T(0);
-      if (idx < cnt) {
-        const int pc = p0 + idx / bb, e = idx % bb;
-        const int w = hb.piece_rc[pc];
-        const int r = (int)(short)(w >> 16) + e / bd, c = (int)(short)(w & 0xffff) + e % bd;
-        if (r >= 0 && r < TILE && c >= 0 && c < TILE) {
-          rc[k] = (r << 8) | c;
-          v[k] = base[(int64_t)hb.piece_blk[pc] * bb + e];
-        }
+    }
+    if (cnt <= 0) return;   // (workgroup uniform; p0 may be the END of the piece list)
+    int w[NPRE], blk[NPRE], e[NPRE];
+    bool ok[NPRE];
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int idx = tid + 256 * k;
+      ok[k] = idx < cnt;
+      const int idc = ok[k] ? idx : 0;
+      const int pc = p0 + idc / bb;
+      e[k] = idc % bb;
+      w[k] = hb.piece_rc[pc];
+      blk[k] = hb.piece_blk[pc];
+    }
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int r = (int)(short)(w[k] >> 16) + e[k] / bd, c = (int)(short)(w[k] & 0xffff) + e[k] % bd;
+      const T val = base[(int64_t)blk[k] * bb + e[k]];
+      if (ok[k] && r >= 0 && r < TILE && c >= 0 && c < TILE) {
+        rc[k] = (r << 8) | c;
+        v[k] = val;
       }
     }
   }
@@ -1272,6 +1289,68 @@ struct HBPre {
   }
 };
 constexpr int HB_NPRE_OFF = 3;    // off-diagonal tiles of a pose graph: <= ~20 pieces (720 elements)
+
+// The pieces of the ADJACENT lower tiles (ti, tj) and (ti, tj + 1) (chol_offdiag2: one workgroup produces both): their runs of
+// the piece list are consecutive (tile index ti (ti + 1) / 2 + tj), so they are fetched as ONE run -- both tables of all
+// elements in one batch, one exposed round trip, the values in flight until the first gather.  rc: (tile << 16) | (r << 8) | c.
+template <typename T, int NPRE>
+struct HBPre2 {
+  T v[NPRE];
+  int rc[NPRE];
+  int p0, p1, cnt;   // first piece of tile 0 / of tile 1, elements of both
+  __device__ __forceinline__ void load(const HBlk& hb, int b, int ti, int tj, int tid) {
+    const T* base = static_cast<const T*>(hb.blocks) + (int64_t)b * hb.bstride;
+    const int bd = hb.bd, bb = bd * bd, t = ti * (ti + 1) / 2 + tj;
+    p0 = hb.tile_ptr[t];
+    p1 = hb.tile_ptr[t + 1];
+    cnt = (hb.tile_ptr[t + 2] - p0) * bb;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      rc[k] = -1;
+      v[k] = T(0);
+    }
+    if (cnt <= 0) return;   // (workgroup uniform)
+    int w[NPRE], blk[NPRE], e[NPRE], pcs[NPRE];
+    bool ok[NPRE];
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int idx = tid + 256 * k;
+      ok[k] = idx < cnt;
+      const int idc = ok[k] ? idx : 0;
+      pcs[k] = p0 + idc / bb;
+      e[k] = idc % bb;
+      w[k] = hb.piece_rc[pcs[k]];
+      blk[k] = hb.piece_blk[pcs[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int r = (int)(short)(w[k] >> 16) + e[k] / bd, c = (int)(short)(w[k] & 0xffff) + e[k] % bd;
+      const T val = base[(int64_t)blk[k] * bb + e[k]];
+      if (ok[k] && r >= 0 && r < TILE && c >= 0 && c < TILE) {
+        rc[k] = ((pcs[k] >= p1 ? 1 : 0) << 16) | (r << 8) | c;
+        v[k] = val;
+      }
+    }
+  }
+  // f(r, c, value) for the pieces of tile ``sel`` (0 / 1)
+  template <typename F>
+  __device__ __forceinline__ void foreach(const HBlk& hb, int b, int tid, int sel, F&& f) const {
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k)
+      if (rc[k] >= 0 && (rc[k] >> 16) == sel) f((rc[k] >> 8) & 255, rc[k] & 255, v[k]);
+    if (cnt > 256 * NPRE) {   // (rare: more pieces than the registers hold)
+      const T* base = static_cast<const T*>(hb.blocks) + (int64_t)b * hb.bstride;
+      const int bd = hb.bd, bb = bd * bd;
+      for (int idx = tid + 256 * NPRE; idx < cnt; idx += 256) {
+        const int pc = p0 + idx / bb, e = idx % bb;
+        if ((pc >= p1 ? 1 : 0) != sel) continue;
+        const int w = hb.piece_rc[pc];
+        const int r = (int)(short)(w >> 16) + e / bd, c = (int)(short)(w & 0xffff) + e % bd;
+        if (r >= 0 && r < TILE && c >= 0 && c < TILE) f(r, c, base[(int64_t)hb.piece_blk[pc] * bb + e]);
+      }
+    }
+  }
+};
 constexpr int HB_NPRE_DIAG = 7;   // diagonal tiles: ~21 diagonal blocks + their chain / loop-closure neighbours (~49 pieces)
 
 template <typename T>
@@ -2026,7 +2105,7 @@ chol_offdiag2_f32_kernel(const float* __restrict__ H, float* __restrict__ L, con
   const bool rvalid = r < validB;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-  HBPre<float, HB ? HB_NPRE_OFF : 1> hb0, hb1;
+  HBPre2<float, HB ? 2 * HB_NPRE_OFF : 1> hb2;
   // ---- K-loop over block columns 0 .. j - 1: P0 += L_i L_j^T, P1 += L_i L_{j+1}^T ----
   const int lrow = tid >> 3, lc = tid & 7;
   unsigned voff[4];
@@ -2065,10 +2144,7 @@ chol_offdiag2_f32_kernel(const float* __restrict__ H, float* __restrict__ L, con
   Engine<float>::zero(P1);
   const int nk = 4 * j;
   if (nk > 0) gload3(0);
-  if constexpr (HB) {
-    hb0.load(hb, b, i, j, tid);
-    hb1.load(hb, b, i, j + 1, tid);
-  }
+  if constexpr (HB) hb2.load(hb, b, i, j, tid);
   const float* sBw = sB + 32 * wave * 36;
   for (int kc = 0; kc < nk; ++kc) {
     __syncthreads();
@@ -2121,7 +2197,7 @@ chol_offdiag2_f32_kernel(const float* __restrict__ H, float* __restrict__ L, con
     });
   };
   // P <- H_(i, jj) - P  (block-compact H: the tile's pieces through the free staging buffers, 64 rows at a time; dense: loads)
-  auto h_minus = [&](Engine<float>::Acc& P, const HBPre<float, HB ? HB_NPRE_OFF : 1>& hbp, int jj) __attribute__((always_inline)) {
+  auto h_minus = [&](Engine<float>::Acc& P, int sel, int jj) __attribute__((always_inline)) {
     if constexpr (HB) {
       constexpr int LDH = 132;
       __syncthreads();   // whatever read the staging buffers last is done
@@ -2129,7 +2205,7 @@ chol_offdiag2_f32_kernel(const float* __restrict__ H, float* __restrict__ L, con
       for (int half = 0; half < 2; ++half) {
         for (int k = tid; k < 64 * LDH / 4; k += 256) reinterpret_cast<float4*>(smem)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
-        hbp.foreach(hb, b, tid, [&](int rr, int cc, float v) __attribute__((always_inline)) {
+        hb2.foreach(hb, b, tid, sel, [&](int rr, int cc, float v) __attribute__((always_inline)) {
           if ((rr >> 6) == half) smem[(rr & 63) * LDH + cc] = v;
         });
         __syncthreads();
@@ -2190,7 +2266,7 @@ chol_offdiag2_f32_kernel(const float* __restrict__ H, float* __restrict__ L, con
   // ---- tile (i, j) ----
   __syncthreads();      // the K-loop's last chunk has been consumed: the panel copy overlaps staging buffer 2
   panel_dma(j);
-  h_minus(P0, hb0, j);
+  h_minus(P0, 0, j);
   __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's pieces of the panel have landed
   __syncthreads();
   gload1(nk);           // first chunk of L_{j+1,j}: in flight under the substitution
@@ -2218,7 +2294,7 @@ chol_offdiag2_f32_kernel(const float* __restrict__ H, float* __restrict__ L, con
     }
   });
   // ---- tile (i, j + 1) ----
-  h_minus(P1, hb1, j + 1);
+  h_minus(P1, 1, j + 1);
   __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
   __syncthreads();
   substitute_store(P1, X0, j + 1);
