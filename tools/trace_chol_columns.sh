@@ -48,8 +48,11 @@ for r in rows[start:end]:
     if "syrk" in short or "chol_diag_kernel" in short:
         j += 1
     fl = None
-    if "offdiag" in short:
-        fl = B * (nt - 1 - j) * (2 * j * t3 + 1.25 * t3)
+    rt = wgs // ((B + 7) // 8 * 8)     # row tiles of an off-diagonal launch
+    if "offdiag2" in short:            # column pair (j - 1, j): two K-loops over j - 1 tiles, X0 L^T, two substitutions per workgroup
+        fl = B * rt * (4 * (j - 1) + 2 + 2.5) * t3
+    elif "offdiag" in short:           # one tile per workgroup (column by column; with pairs: the head tile / the last column)
+        fl = B * rt * (2 * j * t3 + 1.25 * t3)
     elif "syrk" in short or "chol_diag_kernel" in short:
         fl = B * j * t3 * 36 / 64 * 2 / 2 * 2    # 36 of 64 16x16 blocks of a t x t x (j t) product
     tf = fl / d / 1e6 if fl else float("nan")
