@@ -1,6 +1,6 @@
 """Socket power / shader clock of the factorisation next to its pieces (librocm_smi64 sampler + energy counter, tools/smi.py):
 idle, an HBM copy, thx_chol_factor fp32 (two streams / one) and fp64, and the modes of tools/microbench/power_pieces
-(theseus_amd/lib/variants/power_pieces, built by tools/gpu_round5_r.sh).  usage: python tools/power_model.py [seconds]"""
+(theseus_amd/lib/variants/power_pieces, built by tools/gpu_round5_t.sh).  usage: python tools/power_model.py [seconds]"""
 import os, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,6 @@
 """Socket power, energy counter and shader clock of GPU 0 through librocm_smi64 (ctypes; the amdgpu hwmon files of this
 image return a stale 290 W / 2398 MHz while rocm-smi itself reports 1356 W / 2207 MHz under the factorisation -- measured in
-profiles/r5/q_).  Sampler: a thread polling power + sclk every `period` seconds; the energy accumulator gives the exact mean."""
+profiles/r5/q_rocm_smi_during_factor.txt).  Sampler: a thread polling power + sclk every `period` seconds; the energy accumulator gives the exact mean."""
 import ctypes, threading, time
 
 
