@@ -2317,8 +2317,9 @@ chol_offdiag2_f32_kernel(const float* __restrict__ H, float* __restrict__ L, con
 // LDS of the fp64 off-diagonal kernel (round 4): the K-loop's staging buffers (2 x 128 x LDT doubles = 36.9 KB with 16-column
 // chunks; after the K-loop: four 8 KB panel sub-blocks) + a 40 KB region E for panel sub-blocks 0..4, which land there straight
 // from global memory (global_load_lds, no registers) while the FIRST k-chunk is in flight -- 76.9 KB, two workgroups per CU.
-// The substitution starts on E the moment the K-loop ends; sub-blocks 5..9 are requested then and arrive under its first five
-// block products.  (Round 3: all ten sub-blocks were fetched after the K-loop, in two phases, each an exposed round trip.)
+// The substitution starts on E the moment the K-loop ends; sub-blocks 5..8 are requested then (LDS-direct into the staging buffers)
+// and arrive under its first five block products, W_33 takes sub-block 0's place in E under the next four.  (Round 3: all ten
+// sub-blocks were fetched after the K-loop, in two phases, each an exposed round trip.)
 constexpr int OFF64_STAGE = (2 * 128 * CT<double>::LDT * 8 > 4 * 1024 * 8) ? 2 * 128 * CT<double>::LDT * 8 : 4 * 1024 * 8;
 constexpr int OFF64_EBLK = 5;
 constexpr int OFF64_SMEM = OFF64_STAGE + OFF64_EBLK * 1024 * 8;
@@ -2408,10 +2409,11 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   };
   kloop<double, false>(L + lmat + (lf.packed ? 0 : (int64_t)col0 * ld), TILE, L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld), validB,
                        ldt, Kspan, sA, sB, P, tid, nullptr, nullptr, prefetch_panel, klist, ksa, ksb, lf.pstride);
-  // sub-blocks 5..9: requested now (the K-loop's prefetch registers are free) next to H; 5..8 go into the staging buffers as soon
-  // as those are free, W_33 (sub-block 9) waits in 8 VGPRs for sub-block 0's place in E
+  // sub-blocks 5..8 go LDS-direct into the staging buffers as soon as those are free (dense H: now, next to the H loads;
+  // block-compact H: after the gather rounds), W_33 (sub-block 9) LDS-direct into sub-block 0's place in E once E has been read.
+  // No panel data in registers: round 4 parked sub-blocks 5..9 (block-compact H) / W_33 (dense H) in VGPRs from here on and
+  // hipcc spilled them -- 160 B per thread through scratch, 1 GB of extra HBM traffic per launch (profiles/r5/ab_, ac_).
   THX_ST64(1);   // K-loop done
-  double2 late[5][2];
   if constexpr (!HB) {
     // dense H: 5..8 straight into the staging buffers (LDS-direct, no registers: the 128 VGPRs of the H tile are about to be in
     // flight) -- after a barrier: the K-loop ends on a chunk's MFMAs, a slower wave may still be reading its fragments
@@ -2428,22 +2430,15 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
                                          16, 0, 0);
       }
   }
-  {
-    constexpr int SB[5] = {2, 3, 3, 3, 3}, TB[5] = {2, 0, 1, 2, 3};
-    const int pi = tid >> 3, pc = tid & 7;  // row of the sub-block, 32-byte piece (4 doubles) of the row
+  // one panel sub-block (block row sbr, block column sbc) -> LDS at dst, LDS-direct, in sub_mma64's swizzled layout
+  auto panel_dma = [&](int sbr, int sbc, double* dst) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = HB ? 0 : 4; q < 5; ++q) {
-      const double2* src = reinterpret_cast<const double2*>(Pn + (32 * SB[q] + pi) * TILE + 32 * TB[q] + 4 * pc);
-      late[q][0] = src[0];
-      late[q][1] = src[1];
+    for (int u = 0; u < 2; ++u) {
+      const int U = 256 * u + 64 * wave + lane, r = U >> 4, up = U & 15;
+      const double* src = Pn + (32 * sbr + r) * TILE + 32 * sbc + 2 * (up ^ (r & 15));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + (256 * u + 64 * wave) * 2), 16, 0, 0);
     }
-  }
-  auto put_late = [&](int q, double* dst_blk) __attribute__((always_inline)) {
-    const int pi = tid >> 3, pc = tid & 7;
-    double* dst = dst_blk + pi * 32;
-    // columns 4pc, 4pc+1 | 4pc+2, 4pc+3 -> swizzled pairs (2-double pieces stay contiguous: the swizzle is even)
-    *reinterpret_cast<double2*>(dst + ((4 * pc) ^ (2 * (pi & 15)))) = late[q][0];
-    *reinterpret_cast<double2*>(dst + ((4 * pc + 2) ^ (2 * (pi & 15)))) = late[q][1];
   };
   if constexpr (HB) {
     // block-compact H: the tile's pieces through the (free) staging buffers, 32 rows -- one wave's -- at a time
@@ -2491,17 +2486,22 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   }
   }
   THX_ST64(2);   // P = H - sum
-  // sub-blocks 5..8 -> the staging buffers (free: the K-loop / the H rounds ended on a barrier; column 0 has neither, and nobody
-  // has touched them)
   if constexpr (HB) {
-    put_late(0, smem + 0 * 1024);
-    put_late(1, smem + 1 * 1024);
-    put_late(2, smem + 2 * 1024);
-    put_late(3, smem + 3 * 1024);
+    // sub-blocks 5..8 -> the staging buffers, LDS-direct, now that the gather rounds are done with them (their last barrier has
+    // passed); they land under the first five block products, which read E.  E itself was requested in the prologue: every wave
+    // has waited for its own pieces inside the K-loop (older loads) -- or right here when the K-loop was empty -- and the gather's
+    // barriers published them.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (Kspan == 0) __syncthreads();
+    panel_dma(2, 2, smem + 0 * 1024);
+    panel_dma(3, 0, smem + 1 * 1024);
+    panel_dma(3, 1, smem + 2 * 1024);
+    panel_dma(3, 2, smem + 3 * 1024);
+  } else {
+    // E (LDS-direct loads of the prologue) and the staging buffers complete and visible to every wave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
-  // E (LDS-direct loads of the prologue) and the staging buffers complete and visible to every wave
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
   THX_ST64(3);   // panel staged and visible
   // ---- in-place substitution ----
   auto solve_diag = [&](auto is, const double* Wss) __attribute__((always_inline)) {
@@ -2538,12 +2538,15 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   solve_diag(I1{}, smemE + 2 * 1024);
   update(I2{}, I0{}, smemE + 3 * 1024);
   update(I2{}, I1{}, smemE + 4 * 1024);
-  __syncthreads();                  // every wave is done with E
-  put_late(4, smemE + 0 * 1024);    // sub-block 9 = W_33 takes sub-block 0's place
+  if constexpr (HB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // sub-blocks 5..8 (LDS-direct) and W_33 have landed
+  __syncthreads();                  // every wave is done with E (block-compact H: and sees sub-blocks 5..8)
+  panel_dma(3, 3, smemE + 0 * 1024);   // sub-block 9 = W_33 takes sub-block 0's place: LDS-direct, lands under the next four block
+                                       // products (round 4 parked it in 8 VGPRs from the K-loop's end on: spilled to scratch)
   solve_diag(I2{}, smem + 0 * 1024);
   update(I3{}, I0{}, smem + 1 * 1024);
   update(I3{}, I1{}, smem + 2 * 1024);
   update(I3{}, I2{}, smem + 3 * 1024);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                  // W_33 in place
   solve_diag(I3{}, smemE + 0 * 1024);
   THX_ST64(4);   // substitution done
