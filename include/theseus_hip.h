@@ -309,6 +309,39 @@ int thx_chol_factor_sparse(const void* H, int64_t ld, int32_t n, int32_t B, cons
 int thx_chol_solve_sparse(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs, void* x,
                           int64_t ldv, int backward_only, const thx_tile_pattern* pattern, int dtype, void* stream);
 
+/* ---- LEVEL-SCHEDULED tile-sparse Cholesky: elimination-tree parallelism INSIDE a problem -- what a fill-reducing permutation
+ *      gives the reference's BaSpaCho path (theseus/extlib/baspacho_solver.cpp:284-291 createSolver with a permutation, :332;
+ *      theseus/optimizer/linear/baspacho_sparse_solver.py:58-148), in the regime it is used in (evaluations/
+ *      pose_graph_synthetic.sh:5-12: batch 8-256, up to 4096 poses), where a banded ordering leaves a chain of ntiles dependent
+ *      launch pairs with only the batch as parallelism.
+ *      The host (theseus_amd/sparse.py:LevelPattern) orders the variables by NESTED DISSECTION at tile granularity, pads every tile
+ *      to whole variables (tile j holds tile_valid[j] <= THX_TILE rows / columns of the matrix, the rest is identity padding: no
+ *      variable straddles a tile boundary, so tiles in different subtrees are independent), numbers the block columns level by
+ *      level of the tile elimination tree and sorts each level's off-diagonal entries longest K-list first.  Then
+ *        thx_chol_factor_levels: per level ONE diagonal launch over (problems x block columns of the level) and ONE off-diagonal
+ *          launch over (problems x entries of the level) -- same kernels as thx_chol_factor_hblocks.  H is the block list read
+ *          through `layout`, whose tile_ptr / piece_* tables are built for the PADDED tiles; L is the tile-packed factor
+ *          (B, nslots, THX_TILE, THX_TILE) of `pattern` (zero-initialised once), Winv (B, ntiles, THX_TILE, THX_TILE).
+ *        thx_chol_solve_levels: which = 0: x = (L L^T)^-1 rhs, 1: x = L^-T rhs, 2: x = L^-1 rhs; one launch per level and direction, one
+ *          workgroup per (problem, block row); rhs / x are vectors of the PADDED order (B, >= ntiles * THX_TILE), row stride ldv;
+ *          x may alias rhs.
+ *        thx_vec_gather: dst[b][k] = idx[k] >= 0 ? src[b][idx[k]] : 0 for k < n -- between the linearization's vectors (g, delta)
+ *          and the padded ones (idx: device int32). */
+typedef struct {
+  int32_t nlevels;
+  const int32_t* level_col_host;  /* (nlevels + 1) HOST: level l = block columns [level_col_host[l], level_col_host[l + 1]) */
+  const int32_t* level_ent_host;  /* (nlevels + 1) HOST: ... and off-diagonal entries [level_ent_host[l], level_ent_host[l + 1]) */
+  const int32_t* ent_col;         /* DEVICE (entries): block column of entry e (col_ptr is not used by the level kernels) */
+  const int32_t* tile_valid;      /* DEVICE (ntiles): rows / columns of tile j that are matrix (a multiple of the block size) */
+} thx_level_schedule;
+int thx_chol_factor_levels(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t B, const void* damping,
+                           int ellipsoidal, double damping_eps, void* L, void* Winv, int32_t* info,
+                           const thx_tile_pattern* pattern, const thx_level_schedule* schedule, int dtype, void* stream);
+int thx_chol_solve_levels(const void* L, int32_t B, const void* Winv, const void* rhs, void* x, int64_t ldv, int which,
+                          const thx_tile_pattern* pattern, const thx_level_schedule* schedule, int dtype, void* stream);
+int thx_vec_gather(const void* src, int64_t lds, void* dst, int64_t ldd, const int32_t* idx, int32_t n, int32_t B, int dtype,
+                   void* stream);
+
 /* ---- LinearSolver.solve(): replaces DenseSolver._apply_damping + CholeskyDenseSolver._solve_sytem
  *      (linear/dense_solver.py:38-64,159-161).
  *      thx_chol_factor: L L^T = H + damping (out of place: H stays undamped, as the reference

@@ -13,7 +13,8 @@ def relative_poses(X):
     return torch.cat([Rt @ R1, Rt @ (t1 - t0)], -1)
 
 
-def run_implicit(th, g, device, kernels=None, gauge_free=False, **extra_optimizer_kwargs):
+def run_implicit(th, g, device, kernels=None, gauge_free=False, solver=None, **extra_optimizer_kwargs):
+    # (``solver``: dict(linear_solver_cls=..., linear_solver_kwargs=...) -- default: the optimizer's own, the dense solver)
     t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
     _, _, kw = golden_problem(g)
     kw.pop("gauss_newton")
@@ -35,7 +36,7 @@ def run_implicit(th, g, device, kernels=None, gauge_free=False, **extra_optimize
         obj.add(th.Difference(poses[int(g["prior_idx"][k])],
                               G(tensor=leaves["prior_target"][:, k], name=f"prior_target_{k}"), sw, name=f"prior_{k}"))
     lkw = dict(kernels=kernels) if kernels is not None else None
-    opt = th.LevenbergMarquardt(obj, linearization_kwargs=lkw, max_iterations=kw.pop("max_iterations"),
+    opt = th.LevenbergMarquardt(obj, linearization_kwargs=lkw, **(solver or {}), max_iterations=kw.pop("max_iterations"),
                                 step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0)
     layer = th.TheseusLayer(opt)
     sol, info = layer.forward(None, optimizer_kwargs=dict(backward_mode="implicit", track_err_history=True, **kw,

@@ -79,7 +79,8 @@ def _sparse_vs_dense(dtype, n, B):
     assert ((Lc @ Lc.transpose(1, 2) - Hd).abs().max() / Hd.abs().max()).item() < (5e-6 if dtype == torch.float32 else 1e-13)
 
 
-def test_lm_on_a_large_chain_graph_sparse_equals_dense():
+@pytest.mark.parametrize("ordering", ["rcm", "nd"])
+def test_lm_on_a_large_chain_graph_sparse_equals_dense(ordering):
     """560 SE3 poses (n = 3360, 27 tiles; fp64 -- the DENSE solver's triangular-solve kernels keep the right-hand side in LDS,
     which bounds fp64 at n <= 3680, fp32 at n <= ~23000), shuffled labels: the sparse solver (RCM ordering + tile pattern)
     reproduces the dense solver's LM run; the pattern prunes most of the tile products."""
@@ -101,12 +102,16 @@ def test_lm_on_a_large_chain_graph_sparse_equals_dense():
         for k, (i, j) in enumerate(edges):
             obj.add(th.Between(pv[i], pv[j], th.SE3(tensor=meas[k].clone(), name=f"m_{k}"), w, name=f"b_{k}"))
         obj.add(th.Difference(pv[edges[0][0]], th.SE3(tensor=gt[:, edges[0][0]].clone(), name="anchor"), w, name="prior"))
-        opt = th.LevenbergMarquardt(obj, linear_solver_cls=solver_cls, max_iterations=5, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+        opt = th.LevenbergMarquardt(obj, linear_solver_cls=solver_cls, max_iterations=5, abs_err_tolerance=0.0, rel_err_tolerance=0.0,
+                                    linear_solver_kwargs=dict(ordering=ordering) if solver_cls is th.HipSparseCholeskySolver else None)
         sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(damping=1e-2, track_err_history=True))
         return torch.stack([sol[f"pose_{k}"] for k in range(P)], 1), info, opt
     dense, dinfo, _ = run(th.HipCholeskySolver)
     sparse, sinfo, opt = run(th.HipSparseCholeskySolver)
     pat = opt.linear_solver.pattern
+    assert opt.linear_solver.levels == (ordering == "nd")
+    if ordering == "nd":   # elimination-tree parallelism: a handful of dependent launch levels instead of one per block column
+        assert pat.nlevels <= 6 < pat.ntiles
     print(f"[sparse LM] tiles of L: {pat.l_tiles} of {pat.ntiles * (pat.ntiles + 1) // 2}; tile products {pat.tile_products} vs dense {pat.dense_tile_products}")
     assert pat.tile_products * 5 < pat.dense_tile_products
     np.testing.assert_allclose(sparse.cpu().numpy(), dense.cpu().numpy(), rtol=0, atol=1e-9)
@@ -179,7 +184,7 @@ def test_tile_packed_factor_is_bit_identical_to_the_dense_frame(dtype, P):
     build = _chain_problem(th, P, B, dtype)
     out = {}
     for packed in (True, False):
-        opt = build(packed_factor=packed)
+        opt = build(packed_factor=packed, ordering="rcm")     # (the column-by-column schedule: same arithmetic in both layouts)
         solver = opt.linear_solver
         assert solver.packed_factor == packed
         sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(damping=1e-2, adaptive_damping=True, track_err_history=True))
@@ -226,7 +231,7 @@ def test_fp64_beyond_the_fused_forward_substitution_limit():
     the last linear system is solved to rounding."""
     import theseus_amd as th
     P, B, dtype = 1700, 3, torch.float64
-    opt = _chain_problem(th, P, B, dtype)()
+    opt = _chain_problem(th, P, B, dtype)(ordering="rcm")   # (the fused forward substitution belongs to the column-by-column schedule)
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("error")          # (a refused factorisation would surface as the loop's RuntimeWarning)
@@ -239,3 +244,73 @@ def test_fp64_beyond_the_fused_forward_substitution_limit():
     Hf = lin.AtA + 1e-2 * torch.eye(lin.n, dtype=dtype, device="cuda")
     r = (Hf @ delta.unsqueeze(2)).squeeze(2) - lin.Atb.squeeze(2)
     assert (r.abs().max() / lin.Atb.abs().max()).item() < 1e-10
+
+
+# ---- the level-scheduled solver (tile-level nested dissection, thx_chol_factor_levels / thx_chol_solve_levels) -----------------
+@pytest.mark.parametrize("dtype,P,B", [(torch.float32, 700, 6), (torch.float64, 300, 3), (torch.float32, 1500, 40)])
+def test_level_schedule_factor_and_solves(dtype, P, B):
+    """The factor the level schedule leaves in the tile-packed buffer IS the Cholesky factor of the damped Hessian in the padded
+    order (identity on the padding), the solves invert it, a snapshot of it solves the same, and the split / fused diagonal
+    schedules (picked per level by its workgroup count) give the same bits."""
+    import theseus_amd as th
+    opt = _chain_problem(th, P, B, dtype)(ordering="nd")
+    solver, lin = opt.linear_solver, opt.linear_solver.linearization
+    pat = solver.pattern
+    assert solver.levels and solver.packed_factor and lin._compact and pat.nlevels < pat.ntiles
+    opt.objective.update()
+    lin.linearize()
+    out = {}
+    for split_min in (1, 1 << 30):          # every level through chol_syrk + chol_potrf / through the fused chol_diag
+        prev = th.default_kernels().chol_split_diag_min_batch(split_min)
+        try:
+            delta = solver.solve(damping=0.05, ellipsoidal_damping=True, damping_eps=1e-8)
+        finally:
+            th.default_kernels().chol_split_diag_min_batch(prev)
+        out[split_min] = (delta.clone(), solver.L.clone())
+    assert torch.equal(out[1][0], out[1 << 30][0]) and torch.equal(out[1][1], out[1 << 30][1])
+    assert int(solver.info.abs().sum()) == 0
+    n, npad = lin.n, pat.npad
+    H = lin.AtA.double()
+    Hd = H + torch.diag_embed(0.05 * H.diagonal(dim1=1, dim2=2) + 1e-8)
+    idx = torch.from_numpy(pat.pad_of_col).long().cuda()
+    Lp = solver.dense_factor()[:2].double()
+    assert Lp.shape[-1] == npad
+    LLt = Lp @ Lp.transpose(1, 2)
+    tol = 5e-6 if dtype == torch.float32 else 1e-13
+    assert ((LLt[:, idx[:, None], idx[None, :]] - Hd[:2]).abs().max() / Hd.abs().max()).item() < tol
+    pad = torch.ones(npad, dtype=torch.bool, device="cuda")
+    pad[idx] = False
+    assert float(Lp[:, pad, :].abs().max()) == 0.0 and float(Lp[:, :, pad].abs().max()) == 0.0   # padding: never written
+    g = lin.Atb.squeeze(2)
+    r = (Hd @ delta.double().unsqueeze(2)).squeeze(2) - g.double()
+    assert (r.abs().max() / g.abs().max()).item() < (2e-2 if dtype == torch.float32 else 1e-10)
+    x = solver.solve_with_factor(g.contiguous())
+    assert torch.equal(x, delta)                                    # fused-forward handle and the two-gather path: same kernels
+    snap = solver.factor_snapshot()
+    solver.solve(damping=7.0, ellipsoidal_damping=False)            # the solver factorises something else ...
+    assert torch.equal(solver.solve_with_snapshot(snap, g.contiguous()), delta)   # ... the snapshot still solves the first system
+
+
+def test_level_schedule_not_positive_definite_is_reported():
+    import theseus_amd as th
+    opt = _chain_problem(th, 400, 3, torch.float32)(ordering="nd")
+    solver, lin = opt.linear_solver, opt.linear_solver.linearization
+    opt.objective.update()
+    lin.linearize()
+    with pytest.raises(RuntimeError, match="not positive-definite"):
+        solver.solve(damping=-1e6, ellipsoidal_damping=False)
+
+
+def test_full_size_implicit_gradients_through_the_level_schedule():
+    """configs[4]'s shape (256 poses / 1024 edges with RANDOM loop closures: separators are wide, the elimination tree is shallow
+    but not a chain) through HipSparseCholeskySolver(ordering="nd"): forward LM, the undamped last step, the backward solve with
+    the cached level-scheduled factor -- against the gradients the REAL reference produced (tests/golden/pg_full_f64_implicit)."""
+    import theseus_amd as th
+    from tests.helpers import load_golden
+    from tests.implicit_common import check_full_size_implicit, run_implicit
+    g = load_golden("pg_full_f64_implicit")
+    final, loss, grads, info, opt, _ = run_implicit(th, g, "cuda", gauge_free=True,
+                                                    solver=dict(linear_solver_cls=th.HipSparseCholeskySolver,
+                                                                linear_solver_kwargs=dict(ordering="nd")))
+    assert opt.linear_solver.levels and opt.linear_solver.pattern.nlevels < opt.linear_solver.pattern.ntiles
+    check_full_size_implicit(g, final, loss, grads, "full size implicit fp64, level schedule")

@@ -124,3 +124,144 @@ def test_slot_tables_of_the_tile_packed_factor():
     for i in range(nt):
         for q in range(t["row_ptr"][i], t["row_ptr"][i + 1]):
             assert tiles[int(t["row_slot"][q])] == (i, int(t["row_tile"][q]))
+
+
+# ---- elimination-tree parallelism: tile-level nested dissection + the level schedule (thx_chol_factor_levels) ----------------
+def _level_setup(P=1200, seed=2, method="nd", batch_hint=64):
+    from theseus_amd.compiler import PoseGraphStructure
+    from theseus_amd.sparse import LevelPattern, tile_nested_dissection
+    edges = chain_graph(P, stride=7, span=5, seed=seed)
+    order, counts, info = tile_nested_dissection(P, edges, 128 // 6, batch_hint=batch_hint, method=method)
+    pos = np.empty(P, dtype=np.int64)
+    pos[np.asarray(order)] = np.arange(P)
+    s = PoseGraphStructure.build(P, [(int(pos[a]), int(pos[b])) for a, b in edges], [0])
+    return s, LevelPattern(s.lower_block_pattern(), 6, counts), info, order
+
+
+def test_nested_dissection_of_a_chain_has_log_depth():
+    from theseus_amd.sparse import nested_dissection, _symbolic_tiles
+    nt = 200
+    adj = np.zeros((nt, nt), dtype=bool)
+    idx = np.arange(nt - 1)
+    adj[idx, idx + 1] = adj[idx + 1, idx] = True
+    order = np.asarray(nested_dissection(adj, leaf=1))
+    assert sorted(order.tolist()) == list(range(nt))
+    lp, level = _symbolic_tiles(np.tril(adj[np.ix_(order, order)]))
+    assert level.max() + 1 <= 9                                  # ~log2(200) dependent levels instead of 200
+    assert lp.sum() <= 3 * nt                                    # a node keeps at most its two separator neighbours: <= 3 tiles per column
+    band, blevel = _symbolic_tiles(np.tril(adj))
+    assert blevel.max() + 1 == nt and band.sum() == 2 * nt - 1   # the band order: no fill, a chain of nt dependent columns
+
+
+def test_level_pattern_tables():
+    s, pat, info, order = _level_setup()
+    t, nt = pat.tables, pat.ntiles
+    assert sorted(order) == list(range(1200)) and info["method"].startswith("nd")
+    assert pat.nlevels <= 8 and pat.nlevels == info["levels"] and nt == (1200 + 20) // 21
+    assert np.all(np.diff(pat.level) >= 0)                                         # block columns numbered level by level
+    assert pat.level_col[0] == 0 and pat.level_col[-1] == nt and pat.level_ent[-1] == len(t["col_row"]) == pat.nslots - nt
+    assert t["tile_valid"].tolist() == (6 * pat.tile_count).tolist() and t["tile_valid"].max() <= 128
+    tiles = {v: k for k, v in pat.slot.items()}
+    assert len(tiles) == pat.nslots == pat.l_tiles
+    for lv in range(pat.nlevels):
+        cols = range(pat.level_col[lv], pat.level_col[lv + 1])
+        for j in cols:                                                              # a column depends on lower levels only
+            dk = t["diag_k"][t["diag_kptr"][j]:t["diag_kptr"][j + 1]]
+            assert dk.tolist() == np.nonzero(pat.lower[j, :j])[0].tolist() and all(pat.level[k] < lv for k in dk)
+            assert [tiles[int(q)] for q in t["diag_s"][t["diag_kptr"][j]:t["diag_kptr"][j + 1]]] == [(j, int(k)) for k in dk]
+        ents = range(pat.level_ent[lv], pat.level_ent[lv + 1])
+        assert sorted((int(t["col_row"][e]), int(t["ent_col"][e])) for e in ents) == \
+            sorted((int(i), j) for j in cols for i in np.nonzero(pat.lower[j + 1:, j])[0] + j + 1)
+        klens = [int(t["tile_kptr"][e + 1] - t["tile_kptr"][e]) for e in ents]
+        assert klens == sorted(klens, reverse=True)                                 # longest K-list first inside a level
+        for e in ents:
+            i, j = int(t["col_row"][e]), int(t["ent_col"][e])
+            q0, q1 = t["tile_kptr"][e], t["tile_kptr"][e + 1]
+            assert t["tile_k"][q0:q1].tolist() == np.nonzero(pat.lower[i, :j] & pat.lower[j, :j])[0].tolist()
+            assert pat.slot[(i, j)] == nt + e
+            for q in range(q0, q1):
+                k = int(t["tile_k"][q])
+                assert tiles[int(t["tile_sa"][q])] == (j, k) and tiles[int(t["tile_sb"][q])] == (i, k)
+    # rows of one level touch disjoint column blocks (the backward solve pushes without atomics)
+    for lv in range(pat.nlevels):
+        seen = set()
+        for i in range(pat.level_col[lv], pat.level_col[lv + 1]):
+            ks = set(t["row_tile"][t["row_ptr"][i]:t["row_ptr"][i + 1]].tolist())
+            assert not (ks & seen)
+            seen |= ks
+    # padded order <-> column order
+    assert pat.npad == 128 * nt and pat.n == 7200
+    assert np.array_equal(pat.col_of_pad[pat.pad_of_col], np.arange(pat.n)) and (pat.col_of_pad < 0).sum() == pat.npad - pat.n
+
+
+def test_the_time_model_keeps_the_band_order_for_huge_batches():
+    """At thousands of problems per call the batch alone fills the chip: the order with the least arithmetic (the band) wins;
+    at the reference's sweep sizes (evaluations/pose_graph_synthetic.sh: batch 8 - 256) the log-depth order does."""
+    from theseus_amd.sparse import tile_nested_dissection
+    edges = chain_graph(2048, stride=7, span=5, seed=2)
+    assert tile_nested_dissection(2048, edges, 21, batch_hint=8192)[2]["method"] == "band"
+    assert tile_nested_dissection(2048, edges, 21, batch_hint=64)[2]["method"].startswith("nd")
+
+
+def test_level_schedule_emulated_on_the_host_solves_the_system():
+    """The level schedule executed literally -- tile by tile from the device tables, every level's columns / entries / rows in
+    ARBITRARY order (they must not depend on each other), H gathered through the padded piece tables, vectors through the
+    gather maps -- gives the solution of the unpadded system."""
+    s, pat, _, _ = _level_setup(P=500, seed=5)
+    hb = s.hessian_blocks()
+    rng = np.random.default_rng(0)
+    n, d, T, nt = pat.n, 6, 128, pat.ntiles
+    A = np.zeros((n, n))
+    for r, c in s.lower_block_pattern():
+        A[d * r:d * r + d, d * c:d * c + d] = rng.standard_normal((d, d))
+    A = np.tril(A) + np.tril(A, -1).T + 30 * np.eye(n)
+    Hc = hb.pack_dense(A[None])[0]
+    tile_ptr, piece_blk, piece_rc = pat.piece_tables(hb)
+
+    def h_tile(i, j):
+        out = np.zeros((T, T))
+        tt = i * (i + 1) // 2 + j
+        for pc in range(tile_ptr[tt], tile_ptr[tt + 1]):
+            rc = int(piece_rc[pc]) & 0xFFFFFFFF
+            r0, c0 = rc >> 16, rc & 0xFFFF
+            out[r0:r0 + d, c0:c0 + d] = Hc[piece_blk[pc] * d * d:(piece_blk[pc] + 1) * d * d].reshape(d, d)
+        return out
+    t = pat.tables
+    L = np.zeros((pat.nslots, T, T))
+    for lv in range(pat.nlevels):
+        for j in rng.permutation(np.arange(pat.level_col[lv], pat.level_col[lv + 1])):
+            S = np.tril(h_tile(j, j))
+            S = S + np.tril(S, -1).T
+            v = int(t["tile_valid"][j])
+            S[v:, :] = 0
+            S[:, v:] = 0
+            S[np.arange(v, T), np.arange(v, T)] = 1.0                               # identity padding
+            for q in range(t["diag_kptr"][j], t["diag_kptr"][j + 1]):
+                S -= L[t["diag_s"][q]] @ L[t["diag_s"][q]].T
+            L[j] = np.linalg.cholesky(S)
+        for e in rng.permutation(np.arange(pat.level_ent[lv], pat.level_ent[lv + 1])):
+            i, j = int(t["col_row"][e]), int(t["ent_col"][e])
+            Pm = h_tile(i, j)
+            for q in range(t["tile_kptr"][e], t["tile_kptr"][e + 1]):
+                Pm -= L[t["tile_sb"][q]] @ L[t["tile_sa"][q]].T
+            L[nt + e] = np.linalg.solve(L[j], Pm.T).T
+    g = rng.standard_normal(n)
+    y = np.zeros(pat.npad)
+    y[pat.pad_of_col] = g
+    for lv in range(pat.nlevels):                                                   # forward, bottom up: rows pull
+        for i in rng.permutation(np.arange(pat.level_col[lv], pat.level_col[lv + 1])):
+            acc = y[T * i:T * i + T].copy()
+            for q in range(t["row_ptr"][i], t["row_ptr"][i + 1]):
+                k = int(t["row_tile"][q])
+                acc -= L[t["row_slot"][q]] @ y[T * k:T * k + T]
+            y[T * i:T * i + T] = np.linalg.solve(L[i], acc)
+    for lv in reversed(range(pat.nlevels)):                                         # backward, top down: rows push
+        for i in rng.permutation(np.arange(pat.level_col[lv], pat.level_col[lv + 1])):
+            xi = np.linalg.solve(L[i].T, y[T * i:T * i + T])
+            y[T * i:T * i + T] = xi
+            for q in range(t["row_ptr"][i], t["row_ptr"][i + 1]):
+                k = int(t["row_tile"][q])
+                y[T * k:T * k + T] -= L[t["row_slot"][q]].T @ xi
+    x = y[pat.pad_of_col]
+    np.testing.assert_allclose(x, np.linalg.solve(A, g), rtol=0, atol=1e-11)
+    assert np.abs(y[pat.col_of_pad < 0]).max() == 0.0                               # padding stays exactly zero

@@ -20,7 +20,7 @@ THX_ERR_CHUNKS = 16
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
 LOSS_FLATTEN = 4  # THX_LOSS_FLATTEN: RobustCostFunction(flatten_dims=True), or-ed into a loss code
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class LieEps(Structure):
@@ -59,6 +59,10 @@ class TilePattern(Structure):  # thx_tile_pattern: tile-level symbolic factorisa
     _fields_ = [("ntiles", c_int32)] + [(k, c_void_p) for k in ("col_ptr", "col_row", "tile_kptr", "tile_k", "diag_kptr", "diag_k",
                                                                "col_count_host", "row_ptr", "row_tile",
                                                                "tile_sa", "tile_sb", "diag_s", "row_slot")] + [("nslots", c_int32), ("col_head_host", c_void_p)]
+
+
+class LevelSchedule(Structure):  # thx_level_schedule: elimination-tree levels of a tile pattern (2 host + 2 device int32 tables)
+    _fields_ = [("nlevels", c_int32)] + [(k, c_void_p) for k in ("level_col_host", "level_ent_host", "ent_col", "tile_valid")]
 
 
 class HBlockLayout(Structure):  # thx_hblock_layout: block-compact Hessian (device int32 tables)
@@ -166,6 +170,11 @@ _SIGNATURES = {
     "thx_hblocks_diag": [POINTER(HBlockLayout), c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int, c_void_p],
     "thx_chol_factor_hblocks": [POINTER(HBlockLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p,
                                 c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(TilePattern), c_int, c_void_p],
+    "thx_chol_factor_levels": [POINTER(HBlockLayout), c_void_p, c_int64, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,
+                               c_void_p, POINTER(TilePattern), POINTER(LevelSchedule), c_int, c_void_p],
+    "thx_chol_solve_levels": [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(TilePattern),
+                              POINTER(LevelSchedule), c_int, c_void_p],
+    "thx_vec_gather": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int, c_void_p],
     "thx_chol_solve": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                        c_void_p],
     "thx_chol_solve_backward": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,

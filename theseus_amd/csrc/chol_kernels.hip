@@ -1168,7 +1168,16 @@ struct TilePat {
   const int32_t* diag_s;     // (per diag_k element) slot of L_jk
   int32_t nslots;            // 0: L is the dense (B, ld, ld) frame
   int32_t lpt;               // chol_offdiag's block -> (problem, entry) map: 1 = the ENTRY is the slow index (longest K-lists first)
+  // LEVEL schedule (thx_chol_factor_levels): one launch covers every block column of an elimination-tree level
+  const int32_t* ent_col;    // (entries) block column of entry e -- the launch's entries then are [i_first, i_first + nrow_tiles)
+  const int32_t* tile_valid; // (ntiles) rows / columns of tile j inside the matrix, the rest is identity padding (per-tile padding:
+                             // no variable straddles a tile boundary); nullptr: min(TILE, n - j * TILE)
 };
+
+// rows (= columns) of diagonal tile j that belong to the matrix
+__device__ __forceinline__ int tile_rows(const TilePat& pat, int n, int j) {
+  return pat.tile_valid ? pat.tile_valid[j] : min(TILE, n - j * TILE);
+}
 
 // where a kernel finds / puts the tiles of L: the dense frame (row stride ld) or the tile-packed buffer (row stride TILE)
 struct LFrame {
@@ -1365,11 +1374,12 @@ struct DiagSmem {
 template <typename T, bool HB>
 __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 3 : 1)
 chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ panel, const T* __restrict__ damping,
-                 int ellipsoidal, T damping_eps, int32_t* __restrict__ info, int n, int64_t ld, int j, int ntiles,
+                 int ellipsoidal, T damping_eps, int32_t* __restrict__ info, int n, int64_t ld, int j0, int ntiles,
                  const T* __restrict__ rhs, T* __restrict__ yout, int64_t ldv, TilePat pat, HBlk hb) {
   using C = CT<T>;
   using V = typename C::V;
   using E = Engine<T>;
+  const int j = j0 + blockIdx.y;   // (level schedule: blockIdx.y runs over the level's block columns)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tile = reinterpret_cast<T*>(smem_raw);  // lower sub-blocks (tblk); its head doubles as the K-loop staging buffer
   T* vvec = reinterpret_cast<T*>(smem_raw + DiagSmem<T>::tile);
@@ -1383,7 +1393,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   const int64_t ldt = lf.ld;
   T* const Ljj = L + lmat + lf.tile(j, j, j);          // the diagonal tile of L
   const int row0 = j * TILE;
-  const int valid = min(TILE, n - row0);
+  const int valid = tile_rows(pat, n, j);
 
   const bool fwd = rhs != nullptr;
 #ifdef THX_DIAG_PROF
@@ -1652,8 +1662,9 @@ struct SyrkSmem {
 template <typename T, bool HB>
 __global__ void __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2)
 chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict__ damping, int ellipsoidal, T damping_eps,
-                 int n, int64_t ld, int j, const T* __restrict__ rhs, T* __restrict__ yout, int64_t ldv, TilePat pat, HBlk hb) {
+                 int n, int64_t ld, int j0, const T* __restrict__ rhs, T* __restrict__ yout, int64_t ldv, TilePat pat, HBlk hb) {
   using E = Engine<T>;
+  const int j = j0 + blockIdx.y;   // (level schedule: blockIdx.y runs over the level's block columns)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* stage = reinterpret_cast<T*>(smem_raw);                 // K-loop staging buffer, 128 x SYRK_LDT
   T* ybuf = stage + E::SYRK_STAGE;                           // y_0:j of the earlier columns
@@ -1664,7 +1675,7 @@ chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict
   const int64_t lmat = (int64_t)b * lf.pstride;        // L (dense frame or tile-packed)
   const int64_t ldt = lf.ld;
   const int row0 = j * TILE;
-  const int valid = min(TILE, n - row0);
+  const int valid = tile_rows(pat, n, j);
   const bool fwd = rhs != nullptr;
 
   typename E::Sy acc[9];
@@ -1738,9 +1749,12 @@ __device__ __forceinline__ constexpr int bidx(int u, int v) { return u * (u + 1)
 #endif
 template <typename T>
 __global__ void __launch_bounds__(64, sizeof(T) == 4 ? 2 : THX_POTRF_F64_WAVES_PER_SIMD)
-chol_potrf_kernel(T* __restrict__ L, T* __restrict__ panel, int32_t* __restrict__ info, int n, int64_t pstride, int64_t tile_off,
-                  int64_t ld, int j, int ntiles, T* __restrict__ yout, int64_t ldv) {
-  // (the diagonal tile of problem b starts at L + b * pstride + tile_off, row stride ld: dense frame or tile-packed factor)
+chol_potrf_kernel(T* __restrict__ L, T* __restrict__ panel, int32_t* __restrict__ info, int n, int64_t pstride, int64_t tile_off0,
+                  int64_t ld, int j0, int ntiles, T* __restrict__ yout, int64_t ldv, const int32_t* __restrict__ tile_valid) {
+  // (the diagonal tile of problem b starts at L + b * pstride + tile_off, row stride ld: dense frame or tile-packed factor;
+  //  level schedule -- tile-packed factor only -- blockIdx.y runs over the level's block columns: slot j0 + blockIdx.y)
+  const int j = j0 + blockIdx.y;
+  const int64_t tile_off = tile_off0 + (int64_t)blockIdx.y * TILE * TILE;
   using C = CT<T>;
   using E = Engine<T>;
   using Blk = typename E::Blk;
@@ -1751,7 +1765,7 @@ chol_potrf_kernel(T* __restrict__ L, T* __restrict__ panel, int32_t* __restrict_
   constexpr int PARK = sizeof(T) == 4 ? 3 : 0;
   __shared__ __attribute__((aligned(16))) T park[PARK > 0 ? PARK * 32 * C::LDB : 4];
   const int b = blockIdx.x, lane = threadIdx.x;
-  const int row0 = j * TILE, valid = min(TILE, n - row0);
+  const int row0 = j * TILE, valid = tile_valid ? tile_valid[j] : min(TILE, n - row0);
   T* Lt = L + (int64_t)b * pstride + tile_off;
   const bool fwd = yout != nullptr;
 
@@ -1861,7 +1875,7 @@ __device__ __forceinline__ void sub_mma_sw(const float* Pc, const Engine<float>:
 template <bool HB>
 __global__ void __launch_bounds__(256, 2)
 chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, const float* __restrict__ panel, int n,
-                        int64_t ld, int j, int ntiles, int i_first, int nrow_tiles, int B, TilePat pat, HBlk hb) {
+                        int64_t ld, int jarg, int ntiles, int i_first, int nrow_tiles, int B, TilePat pat, HBlk hb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int bid = blockIdx.x;
@@ -1876,7 +1890,10 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   const int rslot = pat.lpt ? slot / b8 : slot % nrow_tiles;
   // row tiles [i_first, i_first + nrow_tiles) of block column j -- or, tile-sparse, entries [i_first, i_first + nrow_tiles) of the
   // column's list of non-zero row tiles
-  const int ent = pat.col_row ? pat.col_ptr[j] + i_first + rslot : 0;   // (tile-sparse: i_first = first ENTRY of the launch)
+  // (tile-sparse: i_first = first ENTRY of the launch, relative to the column's list -- level schedule: absolute, and the entry
+  //  names its block column)
+  const int ent = pat.col_row ? (pat.ent_col ? 0 : pat.col_ptr[jarg]) + i_first + rslot : 0;
+  const int j = pat.ent_col ? pat.ent_col[ent] : jarg;
   const int i = pat.col_row ? pat.col_row[ent] : i_first + rslot;
   const int32_t* klist = pat.col_row ? pat.tile_k + pat.tile_kptr[ent] : nullptr;
   const int Kspan = pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE;
@@ -1890,7 +1907,7 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   const int32_t* ksa = lf.packed ? pat.tile_sa + pat.tile_kptr[ent] : nullptr;
   const int32_t* ksb = lf.packed ? pat.tile_sb + pat.tile_kptr[ent] : nullptr;
   const int col0 = j * TILE, row0 = i * TILE;
-  const int validB = min(TILE, n - row0);  // j is never the last tile: all 128 columns are inside the matrix
+  const int validB = tile_rows(pat, n, i);  // (columns of tile j beyond the matrix -- last tile / per-tile padding -- come out as exact zeros)
   float* sA = smem;
   float* sB = smem + 128 * 36;
   float* Pc = smem + OFF32_STAGE_FLOATS;
@@ -2348,7 +2365,7 @@ __device__ __forceinline__ void sub_mma64(const double* blk, const Engine<double
 template <bool HB>
 __global__ void __launch_bounds__(256, 2)
 chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, const double* __restrict__ panel, int n,
-                        int64_t ld, int j, int ntiles, int i_first, int nrow_tiles, int B, TilePat pat, HBlk hb) {
+                        int64_t ld, int jarg, int ntiles, int i_first, int nrow_tiles, int B, TilePat pat, HBlk hb) {
   using E = Engine<double>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* smem = reinterpret_cast<double*>(smem_raw);
@@ -2357,7 +2374,10 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   const int b8 = gridDim.x / (8 * nrow_tiles);       // (the two block maps: chol_offdiag_f32_kernel)
   const int b = pat.lpt ? (slot % b8) * 8 + xcd : (slot / nrow_tiles) * 8 + xcd;
   const int rslot = pat.lpt ? slot / b8 : slot % nrow_tiles;
-  const int ent = pat.col_row ? pat.col_ptr[j] + i_first + rslot : 0;   // (tile-sparse: i_first = first ENTRY of the launch)
+  // (tile-sparse: i_first = first ENTRY of the launch, relative to the column's list -- level schedule: absolute, and the entry
+  //  names its block column)
+  const int ent = pat.col_row ? (pat.ent_col ? 0 : pat.col_ptr[jarg]) + i_first + rslot : 0;
+  const int j = pat.ent_col ? pat.ent_col[ent] : jarg;
   const int i = pat.col_row ? pat.col_row[ent] : i_first + rslot;
   const int32_t* klist = pat.col_row ? pat.tile_k + pat.tile_kptr[ent] : nullptr;
   const int Kspan = pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE;
@@ -2372,7 +2392,7 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   const int32_t* ksa = lf.packed ? pat.tile_sa + pat.tile_kptr[ent] : nullptr;
   const int32_t* ksb = lf.packed ? pat.tile_sb + pat.tile_kptr[ent] : nullptr;
   const int col0 = j * TILE, row0 = i * TILE;
-  const int validB = min(TILE, n - row0);
+  const int validB = tile_rows(pat, n, i);
   double* sA = smem;
   double* sB = smem + 128 * CT<double>::LDT;
 
@@ -2608,6 +2628,10 @@ struct RowPat {
   const int32_t* __restrict__ row_tile;  // [row_ptr[ntiles]]
   const int32_t* __restrict__ row_slot;  // tile-packed factor: the slot of every listed tile (else nullptr)
   int32_t nslots;                        // tile-packed factor: slots per problem (else 0)
+  // LEVEL schedule (thx_chol_solve_levels): one launch = the block rows [j0, j0 + gridDim.y) of one elimination-tree level (they do
+  // not depend on each other), one workgroup per (problem, block row); j0 < 0: one workgroup walks all block rows of its problem
+  int32_t j0;
+  const int32_t* __restrict__ tile_valid;   // per-tile padding (see TilePat)
 };
 
 // L y = rhs (stand-alone; the LM iteration gets y from the factorisation).
@@ -2635,8 +2659,9 @@ chol_fwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* _
     __syncthreads();
   }
   constexpr int QPT = TILE / C::VEC;   // VEC-wide column groups per tile
-  for (int jb = 0; jb < ntiles; ++jb) {
-    const int row0 = jb * TILE, valid = min(TILE, n - row0);
+  const int jlo = (LIST && rp.j0 >= 0) ? rp.j0 + (int)blockIdx.y : 0, jhi = (LIST && rp.j0 >= 0) ? jlo + 1 : ntiles;
+  for (int jb = jlo; jb < jhi; ++jb) {
+    const int row0 = jb * TILE, valid = (LIST && rp.tile_valid) ? rp.tile_valid[jb] : min(TILE, n - row0);
     panel_g2l<T>(panel + ((int64_t)b * ntiles + jb) * TILE * TILE, tile, tid);
     // t[r] = sum_{k < row0} L[row0 + r][k] y[k]: wave w takes rows r = w (mod 4), four rows in flight
     const int l0 = LIST ? rp.row_ptr[jb] : 0;
@@ -2710,15 +2735,18 @@ chol_bwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* _
   const T* Lb = L + (int64_t)b * (packed ? (int64_t)rp.nslots * TILE * TILE : ld * ld);
   T* zg = x + (int64_t)b * ldv;   // LIST: the working vector IS the output (global, L2 resident)
   if constexpr (LIST) {
-    if (yin != x)
+    if (yin != x && rp.j0 < 0)   // (level schedule: the host copies y into x before the first level's launch)
       for (int k = tid; k < n; k += 256) zg[k] = yin[(int64_t)b * ldv + k];
   } else {
     for (int k = tid; k < npad; k += 256) z[k] = k < n ? yin[(int64_t)b * ldv + k] : T(0);
   }
   __syncthreads();
   constexpr int QPT = TILE / C::VEC;
-  for (int jb = ntiles - 1; jb >= 0; --jb) {
-    const int row0 = jb * TILE, valid = min(TILE, n - row0);
+  // (level schedule: the rows of a level scatter into DISJOINT column blocks of z -- the non-zero rows of a block column are a
+  //  chain of the elimination tree, no two of them on one level -- so the push needs no atomics)
+  const int jhi = (LIST && rp.j0 >= 0) ? rp.j0 + (int)blockIdx.y : ntiles - 1, jlo = (LIST && rp.j0 >= 0) ? jhi : 0;
+  for (int jb = jhi; jb >= jlo; --jb) {
+    const int row0 = jb * TILE, valid = (LIST && rp.tile_valid) ? rp.tile_valid[jb] : min(TILE, n - row0);
     panel_g2l<T>(panel + ((int64_t)b * ntiles + jb) * TILE * TILE, tile, tid);
     if (tid < TILE) xb[tid] = LIST ? (tid < valid ? zg[row0 + tid] : T(0)) : z[row0 + tid];
     __syncthreads();
@@ -2813,6 +2841,16 @@ lm_accept_kernel(const T* __restrict__ delta, const T* __restrict__ g, int64_t l
   }
 }
 
+// dst[b][k] = idx[k] >= 0 ? src[b][idx[k]] : 0  -- the solver's permuted / padded vectors <-> the linearization's (thx_vec_gather)
+template <typename T>
+__global__ void vec_gather_kernel(const T* __restrict__ src, int64_t lds, T* __restrict__ dst, int64_t ldd,
+                                  const int32_t* __restrict__ idx, int n) {
+  const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int i = idx[k];
+  dst[(int64_t)b * ldd + k] = i >= 0 ? src[(int64_t)b * lds + i] : T(0);
+}
+
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 static std::atomic<int> g_split_diag_min{[] {
@@ -2847,11 +2885,11 @@ static DeviceLaunchState& launch_state() {
 template <typename T>
 static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damping, int ellipsoidal, double eps,
                        void* L, void* panel, int32_t* info, const void* rhs, void* y, int64_t ldv, hipStream_t st,
-                       const thx_tile_pattern* tp = nullptr, const HBlk* hbp = nullptr) {
+                       const thx_tile_pattern* tp = nullptr, const HBlk* hbp = nullptr, const thx_level_schedule* ls = nullptr) {
   const bool use_hb = hbp != nullptr;
   const HBlk hb = use_hb ? *hbp : HBlk{nullptr, 0, 0, nullptr, nullptr, nullptr};
   const int ntiles = (n + TILE - 1) / TILE;
-  TilePat pat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+  TilePat pat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
   // ld == 0: L is the TILE-PACKED factor (B, nslots, TILE, TILE) of the pattern
   const bool packed = ld == 0;
   if (packed && (!tp || tp->nslots <= 0 || !tp->tile_sa || !tp->tile_sb || !tp->diag_s))
@@ -2860,7 +2898,7 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     if (tp->ntiles != ntiles) return fail("thx_chol_factor_sparse: the tile pattern was built for another matrix order");
     pat = TilePat{tp->col_ptr, tp->col_row, tp->tile_kptr, tp->tile_k, tp->diag_kptr, tp->diag_k,
                   packed ? tp->tile_sa : nullptr, packed ? tp->tile_sb : nullptr, packed ? tp->diag_s : nullptr,
-                  packed ? tp->nslots : 0, 0};
+                  packed ? tp->nslots : 0, 0, ls ? ls->ent_col : nullptr, ls ? ls->tile_valid : nullptr};
   }
   const int64_t hstride = (int64_t)ld * ld;                                            // H frame (dense H only; never packed)
   const int64_t lstride = packed ? (int64_t)tp->nslots * TILE * TILE : (int64_t)ld * ld;   // elements of L per problem
@@ -2869,12 +2907,25 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   // diagonal phase: chol_syrk_kernel + chol_potrf_kernel from g_split_diag_min problems per call on (measured, n = 1536: fp32
   // 45.1 vs 46.0 ms at batch 4096, fp64 101.6 vs 105.2 ms; equal at batch 1024; 3.74 vs 3.51 ms at batch 256 -- the second
   // launch per column costs more than the chain there), else the fused chol_diag_kernel
-  const bool fused_diag = B < g_split_diag_min.load();
+  const int split_diag_min = g_split_diag_min.load();
+  const bool fused_diag = B < split_diag_min;
   const size_t dsm = fused_diag ? DiagSmem<T>::bytes(rhs ? ntiles * TILE : 0) : SyrkSmem<T>::bytes(rhs ? ntiles * TILE : 0);
   if (dsm > LDS_LIMIT) return fail("thx_chol_factor: n too large for the fused forward substitution (LDS)");
+  if (ls && (rhs || !packed || !use_hb)) return fail("thx_chol_factor_levels: tile-packed factor, block-compact H, no fused forward substitution");
   std::lock_guard<std::mutex> guard(g_launch_mutex);   // (the whole enqueue: the auxiliary stream / events are shared)
   DeviceLaunchState& ds = launch_state();
   constexpr int ti = sizeof(T) == 8;
+  if (ls) {   // (both diagonal schedules may be taken, level by level; no y buffer: well below the default limit, raised anyway)
+    const size_t d0 = DiagSmem<T>::bytes(0), s0 = SyrkSmem<T>::bytes(0);
+    if (d0 > ds.attr_diag[ti][1]) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d0);
+      ds.attr_diag[ti][1] = d0;
+    }
+    if (s0 > ds.attr_syrk[ti][1]) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(chol_syrk_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s0);
+      ds.attr_syrk[ti][1] = s0;
+    }
+  }
   if (fused_diag && dsm > ds.attr_diag[ti][use_hb]) {
     hipFuncSetAttribute(use_hb ? reinterpret_cast<const void*>(chol_diag_kernel<T, true>)
                                : reinterpret_cast<const void*>(chol_diag_kernel<T, false>),
@@ -2983,31 +3034,52 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
                            (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, hb_of(h));
     }
   };
-  auto launch_diag = [&](const Half& h, int j) {
+  // (nc > 1: the level schedule -- block columns [j, j + nc) in one launch, blockIdx.y the column; `fused` / `smem`: which of the
+  //  two diagonal schedules this launch takes, see fused_diag)
+  auto launch_diag_n = [&](const Half& h, int j, int nc, bool fused, size_t smem) {
     const int64_t mo = (int64_t)h.b0 * lstride, po = (int64_t)h.b0 * ntiles * TILE * TILE;
     const T* rh = rhs ? (const T*)rhs + (int64_t)h.b0 * ldv : nullptr;
     T* yh = y ? (T*)y + (int64_t)h.b0 * ldv : nullptr;
     const T* dh = damping ? (const T*)damping + h.b0 : nullptr;
     const T* Hh = use_hb ? nullptr : (const T*)H + (int64_t)h.b0 * hstride;
-    if (fused_diag) {
+    if (fused) {
       if (use_hb)
-        hipLaunchKernelGGL((chol_diag_kernel<T, true>), dim3(h.nb), dim3(256), dsm, h.s, Hh, (T*)L + mo, (T*)panel + po,
+        hipLaunchKernelGGL((chol_diag_kernel<T, true>), dim3(h.nb, nc), dim3(256), smem, h.s, Hh, (T*)L + mo, (T*)panel + po,
                            dh, ellipsoidal, (T)eps, info + h.b0, n, ld, j, ntiles, rh, yh, ldv, pat, hb_of(h));
       else
-        hipLaunchKernelGGL((chol_diag_kernel<T, false>), dim3(h.nb), dim3(256), dsm, h.s, Hh, (T*)L + mo, (T*)panel + po,
+        hipLaunchKernelGGL((chol_diag_kernel<T, false>), dim3(h.nb, nc), dim3(256), smem, h.s, Hh, (T*)L + mo, (T*)panel + po,
                            dh, ellipsoidal, (T)eps, info + h.b0, n, ld, j, ntiles, rh, yh, ldv, pat, hb_of(h));
     } else {
       if (use_hb)
-        hipLaunchKernelGGL((chol_syrk_kernel<T, true>), dim3(h.nb), dim3(256), dsm, h.s, Hh, (T*)L + mo, dh, ellipsoidal,
+        hipLaunchKernelGGL((chol_syrk_kernel<T, true>), dim3(h.nb, nc), dim3(256), smem, h.s, Hh, (T*)L + mo, dh, ellipsoidal,
                            (T)eps, n, ld, j, rh, yh, ldv, pat, hb_of(h));
       else
-        hipLaunchKernelGGL((chol_syrk_kernel<T, false>), dim3(h.nb), dim3(256), dsm, h.s, Hh, (T*)L + mo, dh, ellipsoidal,
+        hipLaunchKernelGGL((chol_syrk_kernel<T, false>), dim3(h.nb, nc), dim3(256), smem, h.s, Hh, (T*)L + mo, dh, ellipsoidal,
                            (T)eps, n, ld, j, rh, yh, ldv, pat, hb_of(h));
       const int64_t tile_off = packed ? (int64_t)j * TILE * TILE : (int64_t)j * TILE * ld + (int64_t)j * TILE;
-      hipLaunchKernelGGL(chol_potrf_kernel<T>, dim3(h.nb), dim3(64), 0, h.s, (T*)L + mo, (T*)panel + po, info + h.b0, n, lstride,
-                         tile_off, packed ? (int64_t)TILE : ld, j, ntiles, rh ? yh : nullptr, ldv);
+      hipLaunchKernelGGL(chol_potrf_kernel<T>, dim3(h.nb, nc), dim3(64), 0, h.s, (T*)L + mo, (T*)panel + po, info + h.b0, n, lstride,
+                         tile_off, packed ? (int64_t)TILE : ld, j, ntiles, rh ? yh : nullptr, ldv, pat.tile_valid);
     }
   };
+  auto launch_diag = [&](const Half& h, int j) { launch_diag_n(h, j, 1, fused_diag, dsm); };
+  // LEVEL SCHEDULE (thx_chol_factor_levels): the block columns of one elimination-tree level do not depend on each other (a column
+  // needs, of the earlier columns, only those in which its own row panel is non-zero: its descendants in the tree) and the host
+  // numbered the columns level by level -- so: ONE diagonal launch and ONE off-diagonal launch per level, B x (columns of the
+  // level) and B x (entries of the level) workgroups.  A banded ordering's chain of ntiles dependent launch pairs becomes
+  // ~log2(ntiles) of them under a nested-dissection ordering (theseus_amd/sparse.py:LevelPattern).
+  if (ls) {
+    pat.lpt = 1;   // (the level's entries are sorted longest K-list first; consecutive workgroups = the problems of one entry)
+    const Half h{st, 0, B};
+    for (int l = 0; l < ls->nlevels; ++l) {
+      const int j0 = ls->level_col_host[l], nc = ls->level_col_host[l + 1] - j0;
+      const int e0 = ls->level_ent_host[l], ne = ls->level_ent_host[l + 1] - e0;
+      if (nc <= 0) continue;
+      const bool fused = (int64_t)B * nc < split_diag_min;
+      launch_diag_n(h, j0, nc, fused, fused ? DiagSmem<T>::bytes(0) : SyrkSmem<T>::bytes(0));
+      if (ne > 0) launch_off(h, j0, e0, ne);
+    }
+    return check_launch("thx_chol_factor_levels");
+  }
   // LOOK-AHEAD for batches that do not fill the chip (one part, i.e. B < THX_CHOL_SPLIT_MIN; THX_CHOL_LOOKAHEAD=0 turns it off).
   // Left-looking: tile (i, j) needs rows i and j of the columns before j.  So the diagonal phase of column j + 1 needs, of column
   // j, only tile (j + 1, j) -- and at batch 256 that phase is B workgroups with one busy wave each (80 us on a 3072-column banded
@@ -3111,7 +3183,8 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
 
 template <typename T>
 static int solve_impl(const void* L, int64_t ld, int n, int B, const void* panel, const void* rhs, void* x,
-                      int64_t ldv, bool forward, bool backward, hipStream_t st, const thx_tile_pattern* tp = nullptr) {
+                      int64_t ldv, bool forward, bool backward, hipStream_t st, const thx_tile_pattern* tp = nullptr,
+                      const thx_level_schedule* ls = nullptr) {
   const int ntiles = (n + TILE - 1) / TILE;
   const bool list = tp != nullptr;
   const size_t sm = solve_smem<T>(list ? 0 : ntiles * TILE);
@@ -3134,8 +3207,37 @@ static int solve_impl(const void* L, int64_t ld, int n, int B, const void* panel
   const bool packed = ld == 0;
   if (packed && (!list || !tp->row_slot || tp->nslots <= 0))
     return fail("thx_chol_solve: a tile-packed factor (ld = 0) needs thx_chol_solve_sparse and a pattern with slot tables");
-  const RowPat rp{list ? tp->row_ptr : nullptr, list ? tp->row_tile : nullptr, packed ? tp->row_slot : nullptr, packed ? tp->nslots : 0};
+  RowPat rp{list ? tp->row_ptr : nullptr, list ? tp->row_tile : nullptr, packed ? tp->row_slot : nullptr, packed ? tp->nslots : 0,
+            -1, ls ? ls->tile_valid : nullptr};
   const T* src = (const T*)rhs;
+  if (ls) {
+    // LEVEL SCHEDULE: one launch per elimination-tree level, one workgroup per (problem, block row of the level) -- forward bottom
+    // up (a row pulls from its descendants' blocks of y), backward top down (a row pushes into its descendants' blocks of x)
+    if (!list) return fail("thx_chol_solve_levels: needs the tile pattern");
+    if (forward) {
+      for (int l = 0; l < ls->nlevels; ++l) {
+        rp.j0 = ls->level_col_host[l];
+        const int nc = ls->level_col_host[l + 1] - rp.j0;
+        if (nc > 0)
+          hipLaunchKernelGGL((chol_fwd_kernel<T, true>), dim3(B, nc), dim3(256), sm, st, (const T*)L, (const T*)panel, src, (T*)x, n,
+                             ld, ldv, ntiles, rp);
+      }
+      src = (const T*)x;
+    }
+    if (backward) {
+      if (src != (const T*)x)
+        hipMemcpy2DAsync(x, (size_t)ldv * sizeof(T), src, (size_t)ldv * sizeof(T), (size_t)n * sizeof(T), (size_t)B,
+                         hipMemcpyDeviceToDevice, st);
+      for (int l = ls->nlevels - 1; l >= 0; --l) {
+        rp.j0 = ls->level_col_host[l];
+        const int nc = ls->level_col_host[l + 1] - rp.j0;
+        if (nc > 0)
+          hipLaunchKernelGGL((chol_bwd_kernel<T, true>), dim3(B, nc), dim3(256), sm, st, (const T*)L, (const T*)panel, (const T*)x,
+                             (T*)x, n, ld, ldv, ntiles, rp);
+      }
+    }
+    return check_launch("thx_chol_solve_levels");
+  }
   if (forward) {
     if (list)
       hipLaunchKernelGGL((chol_fwd_kernel<T, true>), dim3(B), dim3(256), sm, st, (const T*)L, (const T*)panel, src, (T*)x, n,
@@ -3250,6 +3352,66 @@ int thx_chol_factor_hblocks(const thx_hblock_layout* layout, const void* Hc, int
                return factor_impl<double>(nullptr, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
                                           as_stream(stream), pattern, &hb));
   return 0;
+}
+
+static int check_levels(const thx_tile_pattern* pattern, const thx_level_schedule* ls, const char* who) {
+  if (!pattern || !pattern->col_ptr || !pattern->col_row || !pattern->tile_kptr || !pattern->tile_k || !pattern->diag_kptr ||
+      !pattern->diag_k || !pattern->row_ptr || !pattern->row_tile || !pattern->tile_sa || !pattern->tile_sb || !pattern->diag_s ||
+      !pattern->row_slot || pattern->nslots <= 0 || pattern->ntiles <= 0)
+    return fail(who, ": incomplete tile pattern (the level schedule works on the tile-packed factor)");
+  if (!ls || ls->nlevels <= 0 || !ls->level_col_host || !ls->level_ent_host || !ls->ent_col || !ls->tile_valid)
+    return fail(who, ": incomplete level schedule");
+  if (ls->level_col_host[0] != 0 || ls->level_col_host[ls->nlevels] != pattern->ntiles || ls->level_ent_host[0] != 0 ||
+      ls->level_ent_host[ls->nlevels] != pattern->nslots - pattern->ntiles)
+    return fail(who, ": the level schedule does not cover the pattern's block columns / entries");
+  for (int l = 0; l < ls->nlevels; ++l)
+    if (ls->level_col_host[l + 1] < ls->level_col_host[l] || ls->level_ent_host[l + 1] < ls->level_ent_host[l] ||
+        ls->level_col_host[l + 1] - ls->level_col_host[l] > 65535)
+      return fail(who, ": level tables must be non-decreasing, at most 65535 block columns per level");
+  return 0;
+}
+
+int thx_chol_factor_levels(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t B, const void* damping,
+                           int ellipsoidal, double damping_eps, void* L, void* Winv, int32_t* info,
+                           const thx_tile_pattern* pattern, const thx_level_schedule* schedule, int dtype, void* stream) {
+  if (!layout || !layout->tile_ptr || !layout->piece_blk || !layout->piece_rc || !Hc || !L || !Winv || !info || B <= 0)
+    return fail("thx_chol_factor_levels: null pointer / incomplete block layout / B <= 0");
+  if (int r = check_levels(pattern, schedule, "thx_chol_factor_levels")) return r;
+  if (layout->ntiles != pattern->ntiles || bstride < (int64_t)layout->nblocks * layout->bd * layout->bd)
+    return fail("thx_chol_factor_levels: the block layout is not this pattern's");
+  const int n = pattern->ntiles * TILE;   // (the padded order: every tile is whole, tile_valid says how much of it is matrix)
+  const HBlk hb{Hc, bstride, layout->bd, layout->tile_ptr, layout->piece_blk, layout->piece_rc};
+  THX_DISPATCH(dtype,
+               return factor_impl<float>(nullptr, 0, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, nullptr, nullptr, 0,
+                                         as_stream(stream), pattern, &hb, schedule),
+               return factor_impl<double>(nullptr, 0, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, nullptr, nullptr, 0,
+                                          as_stream(stream), pattern, &hb, schedule));
+  return 0;
+}
+
+int thx_chol_solve_levels(const void* L, int32_t B, const void* Winv, const void* rhs, void* x, int64_t ldv, int which,
+                          const thx_tile_pattern* pattern, const thx_level_schedule* schedule, int dtype, void* stream) {
+  if (!L || !Winv || !rhs || !x || B <= 0 || B > 65535) return fail("thx_chol_solve_levels: null pointer / B out of range");
+  if (which < 0 || which > 2) return fail("thx_chol_solve_levels: which = 0 (both), 1 (backward only), 2 (forward only)");
+  if (int r = check_levels(pattern, schedule, "thx_chol_solve_levels")) return r;
+  const int n = pattern->ntiles * TILE;
+  if (ldv < n) return fail("thx_chol_solve_levels: rhs / x are vectors of the PADDED order, ldv >= ntiles * THX_TILE");
+  THX_DISPATCH(dtype,
+               return solve_impl<float>(L, 0, n, B, Winv, rhs, x, ldv, which != 1, which != 2, as_stream(stream), pattern, schedule),
+               return solve_impl<double>(L, 0, n, B, Winv, rhs, x, ldv, which != 1, which != 2, as_stream(stream), pattern, schedule));
+  return 0;
+}
+
+int thx_vec_gather(const void* src, int64_t lds, void* dst, int64_t ldd, const int32_t* idx, int32_t n, int32_t B, int dtype,
+                   void* stream) {
+  if (!src || !dst || !idx || n <= 0 || B <= 0 || B > 65535 || src == dst) return fail("thx_vec_gather: bad args");
+  dim3 grid((n + 255) / 256, B), block(256);
+  THX_DISPATCH(dtype,
+               hipLaunchKernelGGL(vec_gather_kernel<float>, grid, block, 0, as_stream(stream), (const float*)src, lds, (float*)dst,
+                                  ldd, idx, n),
+               hipLaunchKernelGGL(vec_gather_kernel<double>, grid, block, 0, as_stream(stream), (const double*)src, lds,
+                                  (double*)dst, ldd, idx, n));
+  return check_launch("thx_vec_gather");
 }
 
 int thx_chol_set_split_diag_min_batch(int32_t min_batch, int32_t* previous) {

@@ -17,6 +17,11 @@ inline int fail(const char* what) {
   return -1;
 }
 
+inline int fail(const char* who, const char* what) {
+  last_error() = std::string(who) + what;
+  return -1;
+}
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

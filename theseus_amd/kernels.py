@@ -398,6 +398,27 @@ class HipKernels:
             pattern.c_struct(L.device) if pattern is not None else None, _lib.dtype_code(L.dtype), _lib.stream_ptr(L.device)),
             "thx_chol_factor_hblocks")
 
+    # ---- level-scheduled tile-sparse Cholesky (include/theseus_hip.h: thx_level_schedule; theseus_amd/sparse.py:LevelPattern) ----
+    def chol_factor_levels(self, layout, Hc, damping, ellipsoidal, damping_eps, L, panels, info, pattern):
+        """thx_chol_factor_levels: ``layout`` = the block list's piece tables for the pattern's PADDED tiles; L tile-packed."""
+        dev = L.device
+        _lib.check(self.lib.thx_chol_factor_levels(
+            layout.c, _lib.ptr(Hc), Hc.stride(0), L.shape[0], _lib.ptr(damping), int(bool(ellipsoidal)), float(damping_eps),
+            _lib.ptr(L), _lib.ptr(panels), _lib.ptr(info), pattern.c_struct(dev), pattern.c_levels(dev), _lib.dtype_code(L.dtype),
+            _lib.stream_ptr(dev)), "thx_chol_factor_levels")
+
+    def chol_solve_levels(self, L, panels, rhs, x, pattern, which=0):
+        """thx_chol_solve_levels on vectors of the padded order (which: 0 both, 1 backward only, 2 forward only)."""
+        dev = L.device
+        _lib.check(self.lib.thx_chol_solve_levels(
+            _lib.ptr(L), L.shape[0], _lib.ptr(panels), _lib.ptr(rhs), _lib.ptr(x), x.stride(0), int(which), pattern.c_struct(dev),
+            pattern.c_levels(dev), _lib.dtype_code(L.dtype), _lib.stream_ptr(dev)), "thx_chol_solve_levels")
+
+    def vec_gather(self, src, dst, idx):
+        """dst[b, k] = src[b, idx[k]] (0 where idx[k] < 0)."""
+        _lib.check(self.lib.thx_vec_gather(_lib.ptr(src), src.stride(0), _lib.ptr(dst), dst.stride(0), _lib.ptr(idx), dst.shape[1],
+                                           dst.shape[0], _lib.dtype_code(src.dtype), _lib.stream_ptr(src.device)), "thx_vec_gather")
+
     def pg_error(self, s: DeviceStructure, t: PGTensors, partials, err, poses=None):
         d = t.c_struct(poses)
         dt = err.dtype

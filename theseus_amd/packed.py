@@ -366,14 +366,22 @@ class PackedPoseGraph:
 
     # ---- buffers whose per-pose views are known (so that a list of variable tensors can be recognised as one buffer) ----
     def remember_views(self, buf: torch.Tensor, views):
-        # WEAK references: remembering a buffer must not keep it (50 MB at the headline size) alive -- the caching allocator
-        # would have to hipMalloc fresh state buffers in every optimize() (measured: +20 ms per optimize)
-        self._known = [(weakref.ref(buf), tuple(weakref.ref(v) for v in views))] + self._known[:1]
+        # A WEAK reference to the buffer: remembering it must not keep it (50 MB at the headline size) alive -- the caching
+        # allocator would have to hipMalloc fresh state buffers in every optimize() (measured: +20 ms per optimize).  The views
+        # are remembered by object id + storage pointer, not by weak references: a weakref to a tensor costs ~4 us to create,
+        # 35 ms per TheseusLayer.forward at 4096 poses (profiles/r6/).  A recycled id alone cannot pass for a view: the same
+        # object would also have to start at the same address inside the (still alive) buffer.
+        self._known = [(weakref.ref(buf), tuple(map(id, views)), list(map(_DATA_PTR, views)))] + self._known[:1]
 
     def buffer_of(self, tensors):
-        for wbuf, views in self._known:
+        ids = None
+        for wbuf, vids, ptrs in self._known:
             buf = wbuf()
-            if buf is not None and len(views) == len(tensors) and all(a is r() for a, r in zip(tensors, views)):
+            if buf is None or len(vids) != len(tensors):
+                continue
+            if ids is None:
+                ids = tuple(map(id, tensors))
+            if ids == vids and list(map(_DATA_PTR, tensors)) == ptrs and tensors[0].shape == buf.shape[1:]:
                 return buf
         return None
 

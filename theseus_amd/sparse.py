@@ -14,6 +14,7 @@ Dense ``n^3/3`` stops scaling beyond ~2-4 k poses (evaluations/pose_graph_synthe
   non-zero tiles only, each K-loop walking its list -- the work follows the fill instead of ``n^3/3``.  Storage stays the
   dense row-major frame (288 GB of HBM hold batch 64 of n = 12288 in fp32); tiles outside the pattern are never touched.
 """
+import os
 from typing import Any, Dict, List, Optional, Sequence, Tuple, Type, Union
 
 import numpy as np
@@ -38,9 +39,7 @@ def rcm_order(num_nodes: int, edges: Sequence[Tuple[int, int]]) -> List[int]:
     return reverse_cuthill_mckee((a + a.T).tocsr(), symmetric_mode=True).tolist()
 
 
-def fill_reducing_ordering(objective, ordering_cls=VariableOrdering):
-    """VariableOrdering of a pose-graph objective by reverse Cuthill-McKee on (pose, pose) adjacency of its costs
-    (``ordering_cls``: theseus_amd's mirror class, or the reference's th.optimizer.VariableOrdering for the plugin)."""
+def _objective_graph(objective):
     names = list(objective.optim_vars.keys())
     index = {n: k for k, n in enumerate(names)}
     edges = []
@@ -48,10 +47,40 @@ def fill_reducing_ordering(objective, ordering_cls=VariableOrdering):
         ov = c.optim_vars
         vs = [index[v.name] for v in (ov() if callable(ov) else ov)]
         edges += [(a, b) for i, a in enumerate(vs) for b in vs[i + 1:]]
+    return names, edges
+
+
+def fill_reducing_ordering(objective, ordering_cls=VariableOrdering):
+    """VariableOrdering of a pose-graph objective by reverse Cuthill-McKee on (pose, pose) adjacency of its costs
+    (``ordering_cls``: theseus_amd's mirror class, or the reference's th.optimizer.VariableOrdering for the plugin)."""
+    names, edges = _objective_graph(objective)
     ordering = ordering_cls(objective, default_order=False)
     for k in rcm_order(len(names), edges):
         ordering.append(objective.optim_vars[names[k]])
     return ordering
+
+
+def level_ordering(objective, ordering_cls=VariableOrdering, method: str = "auto", batch_hint: Optional[int] = None):
+    """(VariableOrdering, variables per tile, info) for the LEVEL-SCHEDULED solver: tile-level nested dissection of the
+    objective's variable graph (tile_nested_dissection) -- or (RCM ordering, None, info) when the level schedule does not apply:
+    variables that are not all SE3 (the block-compact Hessian it reads is implemented for SE3 pose graphs), or ``method="rcm"``,
+    or the time model ranks the plain band order first (then the column-by-column schedule with its look-ahead is the better
+    one).  ``batch_hint``: the batch size the model ranks the candidate orders at (default: the objective's, else 64)."""
+    names, edges = _objective_graph(objective)
+    vs = [objective.optim_vars[n] for n in names]
+    dofs = {int(v.dof()) for v in vs}
+    se3 = bool(vs) and all(type(v).__name__ == "SE3" for v in vs) and dofs == {6}
+    if method == "rcm" or not se3 or TILE // 6 >= len(vs):
+        return fill_reducing_ordering(objective, ordering_cls), None, dict(method="rcm")
+    if batch_hint is None:
+        batch_hint = getattr(objective, "batch_size", None) or 64
+    order, counts, info = tile_nested_dissection(len(names), edges, TILE // 6, batch_hint=int(batch_hint), method=method)
+    if info["method"] == "band" and method == "auto":
+        return fill_reducing_ordering(objective, ordering_cls), None, dict(method="rcm", model=info)
+    ordering = ordering_cls(objective, default_order=False)
+    for k in order:
+        ordering.append(objective.optim_vars[names[k]])
+    return ordering, counts, info
 
 
 class TilePattern:
@@ -140,25 +169,378 @@ class TilePattern:
         return self._dev[key][0]
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+# Elimination-tree parallelism: nested dissection at TILE granularity + level-scheduled launches (thx_chol_factor_levels)
+# ------------------------------------------------------------------------------------------------------------------------------
+def _components(adj: np.ndarray, nodes: np.ndarray) -> List[np.ndarray]:
+    """Connected components of the subgraph induced by ``nodes`` (adj: dense bool matrix)."""
+    left = set(int(v) for v in nodes)
+    inside = np.zeros(adj.shape[0], dtype=bool)
+    inside[nodes] = True
+    out = []
+    while left:
+        seed = min(left)
+        comp, frontier = [seed], [seed]
+        left.discard(seed)
+        seen = np.zeros(adj.shape[0], dtype=bool)
+        seen[seed] = True
+        while frontier:
+            nb = np.nonzero(adj[frontier].any(axis=0) & inside & ~seen)[0]
+            seen[nb] = True
+            frontier = nb.tolist()
+            comp += frontier
+            left.difference_update(frontier)
+        out.append(np.array(sorted(comp), dtype=np.int64))
+    return out
+
+
+def _bfs_levels(adj: np.ndarray, nodes: np.ndarray, root: int) -> List[np.ndarray]:
+    inside = np.zeros(adj.shape[0], dtype=bool)
+    inside[nodes] = True
+    seen = np.zeros(adj.shape[0], dtype=bool)
+    seen[root] = True
+    levels, frontier = [np.array([root], dtype=np.int64)], [root]
+    while True:
+        nb = np.nonzero(adj[frontier].any(axis=0) & inside & ~seen)[0]
+        if not nb.size:
+            return levels
+        seen[nb] = True
+        levels.append(nb)
+        frontier = nb.tolist()
+
+
+def _pseudo_peripheral(adj: np.ndarray, nodes: np.ndarray) -> int:
+    """A node of (nearly) maximal eccentricity in the connected subgraph ``nodes`` (George-Liu: repeat BFS from the lowest-degree
+    node of the last level while the level structure gets deeper)."""
+    inside = np.zeros(adj.shape[0], dtype=bool)
+    inside[nodes] = True
+    deg = lambda v: int((adj[v] & inside).sum())  # noqa: E731
+    root = int(min(nodes.tolist(), key=deg))
+    depth = -1
+    for _ in range(8):
+        lv = _bfs_levels(adj, nodes, root)
+        if len(lv) <= depth:
+            break
+        depth = len(lv)
+        root = int(min(lv[-1].tolist(), key=deg))
+    return root
+
+
+def nested_dissection(adj: np.ndarray, leaf: int = 1) -> List[int]:
+    """Nested-dissection elimination order of a graph (dense symmetric bool adjacency, no self loops): recursive bisection by the
+    middle level of a BFS level structure rooted at a pseudo-peripheral node (George's automatic nested dissection), the
+    separator thinned to the nodes that really touch the far side.  Subgraphs of <= ``leaf`` nodes are numbered in index order
+    (the caller's band order).  Children before separators: the order's elimination tree has depth ~log2 on chain-/mesh-like
+    graphs -- that depth is the number of dependent launch pairs of thx_chol_factor_levels."""
+    order: List[int] = []
+
+    def rec(nodes: np.ndarray):
+        if nodes.size <= max(leaf, 1):
+            order.extend(sorted(nodes.tolist()))
+            return
+        comps = _components(adj, nodes)
+        if len(comps) > 1:
+            for c in comps:
+                rec(c)
+            return
+        lv = _bfs_levels(adj, nodes, _pseudo_peripheral(adj, nodes))
+        if len(lv) < 3:       # (a clique-like subgraph: no separator worth having)
+            order.extend(sorted(nodes.tolist()))
+            return
+        sizes = np.array([x.size for x in lv])
+        cum = np.cumsum(sizes)
+        total = int(cum[-1])
+        # separator = level m (1 <= m <= len - 2): balance the two sides, prefer thin levels
+        cost = [max(cum[m - 1], total - cum[m]) + 2 * sizes[m] for m in range(1, len(lv) - 1)]
+        m = 1 + int(np.argmin(cost))
+        far = np.concatenate(lv[m + 1:])
+        far_mask = np.zeros(adj.shape[0], dtype=bool)
+        far_mask[far] = True
+        touches = (adj[lv[m]] & far_mask).any(axis=1)
+        sep = lv[m][touches]
+        near = np.concatenate(lv[:m] + [lv[m][~touches]])
+        rec(np.sort(near))
+        rec(np.sort(far))
+        order.extend(sorted(sep.tolist()))
+
+    rec(np.arange(adj.shape[0], dtype=np.int64))
+    return order
+
+
+def _symbolic_tiles(lp: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Symbolic Cholesky of a lower bool tile pattern (in place fill) -> (filled pattern, level of every column in the elimination
+    tree: 0 for a column that depends on no other, else 1 + the deepest column its row panel touches)."""
+    nt = lp.shape[0]
+    lp = np.tril(lp | np.eye(nt, dtype=bool))
+    for j in range(nt):
+        rows = np.nonzero(lp[j + 1:, j])[0] + j + 1
+        if rows.size:
+            lp[np.ix_(rows, rows)] |= np.tril(np.ones((rows.size, rows.size), dtype=bool))
+    level = np.zeros(nt, dtype=np.int64)
+    for j in range(nt):
+        k = np.nonzero(lp[j, :j])[0]
+        if k.size:
+            level[j] = level[k].max() + 1
+    return lp, level
+
+
+def _schedule_cost_us(lp: np.ndarray, level: np.ndarray, batch: int) -> float:
+    """Rough time model of one level-scheduled factorisation (microseconds; only used to rank candidate orderings): per level one
+    diagonal launch (~3 workgroups per CU, a workgroup = SYRK over its K-list + the ~90 us pivot chain of the 128 x 128 tile) and
+    one off-diagonal launch (2 workgroups per CU, ~18 us per K-list tile + ~14 us of substitution)."""
+    nt = lp.shape[0]
+    rowcount = np.array([int(lp[j, :j].sum()) for j in range(nt)])
+    total = 0.0
+    for lv in range(int(level.max()) + 1):
+        cols = np.nonzero(level == lv)[0]
+        t_d = 90.0 + 9.0 * rowcount[cols]
+        total += 8.0 + max(float(t_d.max()), float(t_d.sum()) * batch / 768.0)
+        t_o = []
+        for j in cols:
+            for i in np.nonzero(lp[j + 1:, j])[0] + j + 1:
+                t_o.append(14.0 + 18.0 * int((lp[i, :j] & lp[j, :j]).sum()))
+        if t_o:
+            total += 8.0 + max(max(t_o), sum(t_o) * batch / 512.0)
+    return total
+
+
+def tile_nested_dissection(num_vars: int, edges: Sequence[Tuple[int, int]], vars_per_tile: int, batch_hint: int = 64,
+                           method: str = "auto") -> Tuple[List[int], List[int], Dict[str, Any]]:
+    """Variable order + tile partition for the level-scheduled solver.
+
+    1. reverse Cuthill-McKee on the variable graph, cut into CLUSTERS of ``vars_per_tile`` consecutive variables (= one 128-wide
+       Cholesky tile each, padded: no variable straddles a tile) -- clusters of a banded order are compact;
+    2. candidate cluster orders on the QUOTIENT graph: the band order itself (a chain of dependent columns, least fill) and nested
+       dissections with leaf chains of 1, 2, 4 clusters (log-depth elimination trees, more fill), ranked by a time model of the
+       level schedule at ``batch_hint`` problems (``method``: "auto" | "band" | "nd");
+    3. the chosen order's columns are renumbered LEVEL BY LEVEL of its elimination tree (a topological order of the same tree:
+       same fill), which is what thx_chol_factor_levels launches.
+    Returns (variable order, variables per tile, info)."""
+    perm = rcm_order(num_vars, edges)
+    vpt = int(vars_per_tile)
+    nc = (num_vars + vpt - 1) // vpt
+    cluster_of = np.empty(num_vars, dtype=np.int64)
+    cluster_of[np.asarray(perm, dtype=np.int64)] = np.arange(num_vars) // vpt
+    adj = np.zeros((nc, nc), dtype=bool)
+    if len(edges):
+        e = np.asarray(edges, dtype=np.int64)
+        a, b = cluster_of[e[:, 0]], cluster_of[e[:, 1]]
+        adj[a, b] = True
+        adj[b, a] = True
+    np.fill_diagonal(adj, False)
+    cands: Dict[str, List[int]] = {}
+    if method in ("auto", "band"):
+        cands["band"] = list(range(nc))
+    if method in ("auto", "nd"):
+        for leaf in (1, 2, 4):
+            cands[f"nd{leaf}"] = nested_dissection(adj, leaf=leaf)
+    if not cands:
+        raise ValueError(f"unknown ordering method {method!r}")
+    best = None
+    for name, order in cands.items():
+        o = np.asarray(order, dtype=np.int64)
+        lp, level = _symbolic_tiles(np.tril(adj[np.ix_(o, o)]))
+        cost = _schedule_cost_us(lp, level, batch_hint)
+        if best is None or cost < best[0]:
+            best = (cost, name, o, level, int(lp.sum()))
+    cost, name, o, level, l_tiles = best
+    o = o[np.argsort(level, kind="stable")]          # level by level (stable: a level keeps the candidate's internal order)
+    members = [[] for _ in range(nc)]
+    for k, v in enumerate(perm):
+        members[k // vpt].append(int(v))
+    order = [v for c in o.tolist() for v in members[c]]
+    counts = [len(members[c]) for c in o.tolist()]
+    info = dict(method=name, levels=int(level.max()) + 1, tiles=nc, l_tiles=l_tiles, model_us=cost,
+                candidates={k: None for k in cands})
+    return order, counts, info
+
+
+class LevelPattern:
+    """Tile-level symbolic Cholesky for thx_chol_factor_levels / thx_chol_solve_levels (include/theseus_hip.h:
+    thx_tile_pattern + thx_level_schedule): PADDED tiles (tile j holds ``tile_count[j]`` whole variables, the rest of its 128
+    rows / columns is identity padding), block columns numbered level by level of the tile elimination tree, every level's
+    off-diagonal entries sorted longest K-list first; the factor is tile-packed (slot j = diagonal tile j, slot ntiles + e =
+    entry e)."""
+
+    def __init__(self, blocks: np.ndarray, dof: int, tile_count: Sequence[int]):
+        """``blocks``: (nb, 2) (row, col) VARIABLE positions (row >= col) of the non-zero blocks of tril(H) in the linearization's
+        column order; ``tile_count``: consecutive variables per tile."""
+        counts = np.asarray(tile_count, dtype=np.int64)
+        if counts.min() < 1 or (counts * dof).max() > TILE:
+            raise ValueError("every tile holds between 1 and TILE // dof variables")
+        nt, P = counts.size, int(counts.sum())
+        start = np.concatenate([[0], np.cumsum(counts)])
+        tile_of = np.repeat(np.arange(nt), counts)
+        slot_of = np.arange(P) - start[tile_of]
+        self.dof, self.ntiles, self.nvars = dof, nt, P
+        self.n, self.npad = dof * P, TILE * nt
+        self.tile_count, self.tile_of, self.slot_of = counts, tile_of, slot_of
+        lp0 = np.zeros((nt, nt), dtype=bool)
+        lp0[tile_of[blocks[:, 0]], tile_of[blocks[:, 1]]] = True
+        self.h_tiles = int(np.tril(lp0 | np.eye(nt, dtype=bool)).sum())
+        lp, level = _symbolic_tiles(lp0)
+        if np.any(np.diff(level) < 0):
+            raise ValueError("block columns must be numbered level by level of the tile elimination tree "
+                             "(theseus_amd.sparse.tile_nested_dissection produces such an order)")
+        self.lower, self.level = lp, level
+        nlev = int(level.max()) + 1
+        self.nlevels = nlev
+        level_col = np.searchsorted(level, np.arange(nlev + 1)).astype(np.int32)
+        diag_kptr, diag_k = [0], []
+        for j in range(nt):
+            diag_k += np.nonzero(lp[j, :j])[0].tolist()
+            diag_kptr.append(len(diag_k))
+        col_row, ent_col, tile_kptr, tile_k, tile_ij, level_ent = [], [], [0], [], [], [0]
+        for lv in range(nlev):
+            ents = []
+            for j in range(level_col[lv], level_col[lv + 1]):
+                for i in (np.nonzero(lp[j + 1:, j])[0] + j + 1).tolist():
+                    ents.append((i, j, np.nonzero(lp[i, :j] & lp[j, :j])[0].tolist()))
+            ents.sort(key=lambda t: (-len(t[2]), t[1], t[0]))      # longest K-loop first (LPT), then by column
+            for i, j, kl in ents:
+                col_row.append(i)
+                ent_col.append(j)
+                tile_k += kl
+                tile_ij += [(i, j)] * len(kl)
+                tile_kptr.append(len(tile_k))
+            level_ent.append(len(col_row))
+        slot = {(j, j): j for j in range(nt)}
+        for e, (i, j) in enumerate(zip(col_row, ent_col)):
+            slot[(i, j)] = nt + e
+        self.slot, self.nslots = slot, nt + len(col_row)
+        row_ptr, row_tile = [0], []
+        for i in range(nt):
+            row_tile += np.nonzero(lp[i, :i])[0].tolist()
+            row_ptr.append(len(row_tile))
+        i32 = lambda a: np.ascontiguousarray(np.asarray(a if len(a) else [0], dtype=np.int32))  # noqa: E731
+        self.tables = dict(
+            col_ptr=i32(np.zeros(nt + 1)),   # (not used by the level kernels: entries are addressed absolutely, ent_col names the column)
+            col_row=i32(col_row), tile_kptr=i32(tile_kptr), tile_k=i32(tile_k), diag_kptr=i32(diag_kptr), diag_k=i32(diag_k),
+            row_ptr=i32(row_ptr), row_tile=i32(row_tile),
+            tile_sa=i32([slot[(j, k)] for (i, j), k in zip(tile_ij, tile_k)]),
+            tile_sb=i32([slot[(i, k)] for (i, j), k in zip(tile_ij, tile_k)]),
+            diag_s=i32([slot[(j, k)] for j in range(nt) for k in diag_k[diag_kptr[j]:diag_kptr[j + 1]]]),
+            row_slot=i32([slot[(i, k)] for i in range(nt) for k in row_tile[row_ptr[i]:row_ptr[i + 1]]]),
+            ent_col=i32(ent_col), tile_valid=i32(counts * dof))
+        self.level_col = np.ascontiguousarray(level_col, dtype=np.int32)
+        self.level_ent = np.ascontiguousarray(np.asarray(level_ent, dtype=np.int32))
+        self.col_count = np.zeros(nt, dtype=np.int32)     # (host tables of the column-by-column schedule: not used)
+        self.l_tiles = int(lp.sum())
+        self.tile_products = len(tile_k) + len(diag_k) + self.l_tiles
+        t3 = float(TILE) ** 3
+        self.flops = 2 * t3 * len(tile_k) + t3 * len(diag_k) + t3 * len(col_row) + t3 / 3 * nt
+        self.dense_tile_products = sum(j * (nt - j) + (nt - j) for j in range(nt))
+        self.dense_flops = sum((nt - 1 - j) * (2 * t3 * j + t3) + t3 * j + t3 / 3 for j in range(nt))
+        # vectors: padded position of every column of the linearization, and back (-1: padding)
+        col = (TILE * tile_of + dof * slot_of)[:, None] + np.arange(dof)[None, :]
+        self.pad_of_col = np.ascontiguousarray(col.reshape(-1).astype(np.int32))
+        src = np.full(self.npad, -1, dtype=np.int32)
+        src[self.pad_of_col] = np.arange(self.n, dtype=np.int32)
+        self.col_of_pad = src
+        self._dev: Dict[str, Any] = {}
+
+    def piece_tables(self, hblocks) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """tile_ptr / piece_blk / piece_rc of thx_hblock_layout for the PADDED tiles: every block lies in exactly one tile
+        (``hblocks``: compiler.HessianBlocks of the linearization -- the block ids are its)."""
+        d, nt = self.dof, self.ntiles
+        b = np.asarray(hblocks.blocks, dtype=np.int64)
+        ti, tj = self.tile_of[b[:, 0]], self.tile_of[b[:, 1]]
+        t = ti * (ti + 1) // 2 + tj
+        order = np.argsort(t, kind="stable")
+        tile_ptr = np.zeros(nt * (nt + 1) // 2 + 1, dtype=np.int64)
+        np.add.at(tile_ptr, t + 1, 1)
+        tile_ptr = np.cumsum(tile_ptr).astype(np.int32)
+        r0, c0 = d * self.slot_of[b[:, 0]], d * self.slot_of[b[:, 1]]
+        rc = ((r0 & 0xFFFF) << 16) | (c0 & 0xFFFF)
+        return tile_ptr, np.ascontiguousarray(order.astype(np.int32)), np.ascontiguousarray(rc[order].astype(np.uint32).view(np.int32))
+
+    def _device(self, device):
+        key = str(device)
+        if key not in self._dev:
+            t = {k: torch.from_numpy(v).to(device) for k, v in self.tables.items()}
+            c = _lib.TilePattern()
+            c.ntiles, c.nslots = self.ntiles, self.nslots
+            for k, v in t.items():
+                if k not in ("ent_col", "tile_valid"):
+                    setattr(c, k, v.data_ptr())
+            c.col_count_host = self.col_count.ctypes.data
+            c.col_head_host = None
+            ls = _lib.LevelSchedule()
+            ls.nlevels = self.nlevels
+            ls.level_col_host, ls.level_ent_host = self.level_col.ctypes.data, self.level_ent.ctypes.data
+            ls.ent_col, ls.tile_valid = t["ent_col"].data_ptr(), t["tile_valid"].data_ptr()
+            vec = dict(pad_of_col=torch.from_numpy(self.pad_of_col).to(device), col_of_pad=torch.from_numpy(self.col_of_pad).to(device))
+            self._dev[key] = (c, ls, t, vec)
+        return self._dev[key]
+
+    def c_struct(self, device) -> _lib.TilePattern:
+        return self._device(device)[0]
+
+    def c_levels(self, device) -> _lib.LevelSchedule:
+        return self._device(device)[1]
+
+    def vec_maps(self, device):
+        return self._device(device)[3]
+
+
 def tile_pattern(structure, dof: int) -> TilePattern:
     """Symbolic tile factorisation of a pose-graph structure (theseus_amd.compiler.PoseGraphStructure)."""
     return TilePattern(structure.num_cols, structure.lower_block_pattern(), dof)
 
 
+class _LevelLayout:
+    """thx_hblock_layout for thx_chol_factor_levels: the block list of the linearization (compiler.HessianBlocks: ids, block size)
+    with tile_ptr / piece_* built for the padded tiles of a LevelPattern."""
+
+    def __init__(self, pattern: LevelPattern, hblocks, device):
+        tile_ptr, piece_blk, piece_rc = pattern.piece_tables(hblocks)
+        self.t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(device)
+                  for k, v in dict(tile_ptr=tile_ptr, piece_blk=piece_blk, piece_rc=piece_rc).items()}
+        base = hblocks.on(device)
+        c = _lib.HBlockLayout()
+        c.nblocks, c.bd, c.nvars, c.ntiles = hblocks.nblocks, hblocks.bd, hblocks.nvars, pattern.ntiles
+        c.diag_blk, c.inc_blk = base.t["diag_blk"].data_ptr(), base.t["inc_blk"].data_ptr()
+        for k, v in self.t.items():
+            setattr(c, k, v.data_ptr())
+        self.c, self._base = c, base
+
+
 class HipSparseCholeskyCore(HipCholeskyCore):
     """HipCholeskyCore whose factorisation follows the tile pattern of its linearization."""
 
-    def _sparse_init(self, packed_factor: Optional[bool] = None):
+    levels = False   # True: LevelPattern + thx_chol_factor_levels / thx_chol_solve_levels (elimination-tree parallelism)
+
+    def _sparse_init(self, packed_factor: Optional[bool] = None, tile_count: Optional[Sequence[int]] = None):
         self._core_init()
         lin = self.linearization
+        compact = bool(getattr(lin, "_compact", False))
+        self.levels = tile_count is not None
+        if self.levels:
+            # LEVEL SCHEDULE: the linearization's column order is a tile-level nested dissection (tile_nested_dissection), tile j
+            # holds tile_count[j] whole variables.  The solver works in the PADDED order (ntiles * 128): g is gathered into it,
+            # delta gathered back (thx_vec_gather); H is read from the block list through piece tables built for the padded tiles.
+            if not compact:
+                raise RuntimeError("the level-scheduled solver needs the block-compact Hessian (SE3 pose graphs on the HIP kernels)")
+            self.pattern = LevelPattern(lin.packed.structure.lower_block_pattern(), lin.packed.dof, tile_count)
+            if self.pattern.nvars != lin.packed.structure.num_poses:
+                raise ValueError("tile_count does not cover the linearization's variables")
+            self.packed_factor = True
+            self._level_layouts: Dict[str, Any] = {}
+            return
         self.pattern = tile_pattern(lin.packed.structure, lin.packed.dof)
         # TILE-PACKED factor: L holds only the tiles of the pattern, (B, nslots, 128, 128), instead of a dense (B, ld, ld) frame
         # (n = 12288, chain graph: 12 MB instead of 604 MB per problem in fp32 -- the batch sizes of the reference's sweep fit).
         # Goes with the block-compact Hessian (thx_chol_factor_hblocks: neither H nor L is a dense frame then).
-        compact = bool(getattr(lin, "_compact", False))
         if packed_factor and not compact:
             raise RuntimeError("packed_factor=True needs the block-compact Hessian (SE3 pose graphs on the HIP kernels)")
         self.packed_factor = compact if packed_factor is None else bool(packed_factor)
+
+    def _level_layout(self, device):
+        """thx_hblock_layout of the linearization's block list with the piece tables of the PADDED tiles (one per device)."""
+        key = str(device)
+        if key not in self._level_layouts:
+            self._level_layouts[key] = _LevelLayout(self.pattern, self.linearization.packed.structure.hessian_blocks(), device)
+        return self._level_layouts[key]
 
     def _ensure_buffers(self):
         if not self.packed_factor:
@@ -173,13 +555,16 @@ class HipSparseCholeskyCore(HipCholeskyCore):
             self._y = torch.empty(B, lin.n, dtype=g.dtype, device=g.device)
             self.info = torch.zeros(B, dtype=torch.int32, device=g.device)
             self._lam = torch.empty(B, dtype=g.dtype, device=g.device)
+            if self.levels:   # vectors of the padded order: y (forward-substituted right-hand side) and the working vector
+                self._yp = torch.empty(B, self.pattern.npad, dtype=g.dtype, device=g.device)
+                self._xp = torch.empty(B, self.pattern.npad, dtype=g.dtype, device=g.device)
 
     def dense_factor(self) -> torch.Tensor:
         """The factor as a dense (B, ld, ld) lower-triangular frame (tests / inspection; the solver never builds it)."""
         if not self.packed_factor:
             return self.L
         lin = self.linearization
-        ld = lin.ld
+        ld = self.pattern.npad if self.levels else lin.ld      # (level schedule: the frame of the PADDED order)
         out = torch.zeros(self.L.shape[0], ld, ld, dtype=self.L.dtype, device=self.L.device)
         for (i, j), slot in self.pattern.slot.items():
             r1, c1 = min(TILE * (i + 1), ld), min(TILE * (j + 1), ld)
@@ -201,8 +586,29 @@ class HipSparseCholeskyCore(HipCholeskyCore):
         y = self._y if rhs is not None else None
         self.factor_version += 1
         self._factored_with = (lam is not None, bool(ellipsoidal_damping), float(damping_eps))   # (what L L^T is the factor of)
+        if self.levels:
+            lin = self.linearization
+            dev = self.L.device
+            self.K.chol_factor_levels(self._level_layout(dev), lin.Hc, lam, ellipsoidal_damping, damping_eps, self.L, self.panels,
+                                      self.info, self.pattern)
+            if rhs is None:
+                return None
+            # y = L^-1 rhs in the padded order (a handle _substitute recognises: the backward half needs no second gather)
+            self.K.vec_gather(rhs.contiguous(), self._yp, self.pattern.vec_maps(dev)["col_of_pad"])
+            self.K.chol_solve_levels(self.L, self.panels, self._yp, self._yp, self.pattern, which=2)
+            return self._yp
         self._factor_call(lam, ellipsoidal_damping, damping_eps, rhs, y, pattern=self.pattern)
         return y
+
+    def _solve_levels(self, L, panels, rhs, x, backward_only: bool):
+        maps = self.pattern.vec_maps(L.device)
+        if rhs is self._yp:
+            src = self._yp
+        else:
+            self.K.vec_gather(rhs.contiguous(), self._xp, maps["col_of_pad"])
+            src = self._xp
+        self.K.chol_solve_levels(L, panels, src, self._xp, self.pattern, which=1 if backward_only else 0)
+        self.K.vec_gather(self._xp, x, maps["pad_of_col"])
 
     def solve_with_snapshot(self, snapshot, rhs: torch.Tensor) -> torch.Tensor:
         """(L L^T)^-1 rhs with a kept copy of a factor: the list-driven solves along the pattern (the copy has the solver's own
@@ -210,31 +616,52 @@ class HipSparseCholeskyCore(HipCholeskyCore):
         L, panels = snapshot
         rhs = rhs.contiguous()
         x = torch.empty_like(rhs)
+        if self.levels:
+            self._solve_levels(L, panels, rhs, x, backward_only=False)
+            return x
         self.K.chol_solve_sparse(L, self.linearization.n, panels, rhs, x, self.pattern, backward_only=False)
         return x
 
     def _substitute(self, rhs, x, backward_only: bool):
         """The triangular solves over the non-zero tiles of L only (thx_chol_solve_sparse; no limit on n)."""
+        if self.levels:
+            return self._solve_levels(self.L, self.panels, rhs, x, backward_only)
         self.K.chol_solve_sparse(self.L, self.linearization.n, self.panels, rhs, x, self.pattern, backward_only=backward_only)
 
 
 class HipSparseCholeskySolver(HipSparseCholeskyCore, LinearSolver):
     """``linear_solver_cls`` for large pose graphs (SE3 / SE2 / SO3): tile-sparse factorisation under a fill-reducing
-    variable ordering (pass ``linearization_kwargs=dict(ordering=...)`` to impose another one)."""
+    variable ordering (pass ``linearization_kwargs=dict(ordering=...)`` to impose another one).
+
+    ``ordering``: "auto" (default) | "nd" | "rcm".  SE3 pose graphs get a tile-level NESTED DISSECTION and the level-scheduled
+    factorisation / solves (elimination-tree parallelism inside a problem: thx_chol_factor_levels) unless the time model prefers
+    the band; "rcm" = reverse Cuthill-McKee + the column-by-column schedule (rounds 3-5)."""
 
     def __init__(self, objective: Objective, linearization_cls: Optional[Type[Linearization]] = None,
                  linearization_kwargs: Optional[Dict[str, Any]] = None, check_singular: bool = False,
-                 packed_factor: Optional[bool] = None, **kwargs):
+                 packed_factor: Optional[bool] = None, ordering: str = "auto", batch_hint: Optional[int] = None, **kwargs):
         linearization_cls = linearization_cls or HipLinearization
         if not (isinstance(linearization_cls, type) and issubclass(linearization_cls, HipLinearization)):
             raise RuntimeError(f"HipSparseCholeskySolver only works with theseus_amd.HipLinearization, but {linearization_cls} "
                                "was provided.")
         linearization_kwargs = dict(linearization_kwargs or {})
+        tile_count = None
+        self.ordering_info: Dict[str, Any] = dict(method="given")
         if linearization_kwargs.get("ordering") is None:
-            linearization_kwargs["ordering"] = fill_reducing_ordering(objective)
+            kern = linearization_kwargs.get("kernels")
+            levels_possible = (kern is None or hasattr(kern, "pg_assemble_blocks")) and linearization_kwargs.get("block_hessian") is not False \
+                and os.environ.get("THX_DENSE_HESSIAN", "0") != "1" and packed_factor is not False
+            method = os.environ.get("THX_SPARSE_ORDERING", ordering)
+            linearization_kwargs["ordering"], tile_count, self.ordering_info = level_ordering(
+                objective, method=method if levels_possible else "rcm", batch_hint=batch_hint)
         LinearSolver.__init__(self, objective, linearization_cls, linearization_kwargs)
+        if tile_count is not None and not getattr(self.linearization, "_compact", False):
+            # (the linearization did not take the block-compact path after all: the column-by-column schedule on an RCM order)
+            linearization_kwargs["ordering"] = fill_reducing_ordering(objective)
+            tile_count, self.ordering_info = None, dict(method="rcm")
+            LinearSolver.__init__(self, objective, linearization_cls, linearization_kwargs)
         self._check_singular = check_singular
-        self._sparse_init(packed_factor)
+        self._sparse_init(packed_factor, tile_count)
 
     def solve(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
               damping_eps: float = 1e-8, check_info: bool = True, **kwargs) -> torch.Tensor:

@@ -44,8 +44,21 @@ def run(solver_cls):
 
 ds, si, so, xs = run(th.HipSparseCholeskySolver)
 pat = so.linear_solver.pattern
+if os.environ.get("BENCH_SPARSE_PHASES", "0") == "1":   # per-phase device time of one linear solve (events around the calls)
+    sv, lin = so.linear_solver, so.linear_solver.linearization
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    with torch.no_grad():
+        for _ in range(2):
+            ev[0].record(); lin.linearize(); ev[1].record(); sv.factorize(1e-2, False, 1e-8, rhs=None); ev[2].record()
+            x = sv.solve_with_factor(lin.g); ev[3].record()
+        torch.cuda.synchronize()
+    print(f"phases: linearize {ev[0].elapsed_time(ev[1]):.3f} ms, factor {ev[1].elapsed_time(ev[2]):.3f} ms "
+          f"({pat.flops * B / ev[1].elapsed_time(ev[2]) / 1e9:.1f} TFLOP/s executed), both solves {ev[2].elapsed_time(ev[3]):.3f} ms")
+pat = so.linear_solver.pattern
 print(f"{P} poses / {len(edges)} edges, n = {6 * P} ({pat.ntiles} tiles), batch {B}, {dtype}: L tiles {pat.l_tiles} of "
-      f"{pat.ntiles * (pat.ntiles + 1) // 2}, tile products {pat.tile_products} vs dense {pat.dense_tile_products}")
+      f"{pat.ntiles * (pat.ntiles + 1) // 2}, tile products {pat.tile_products} vs dense {pat.dense_tile_products}; ordering "
+      f"{so.linear_solver.ordering_info.get('method')}, {getattr(pat, 'nlevels', pat.ntiles)} dependent launch levels, "
+      f"{pat.flops / 1e9:.2f} GFLOP per factorisation")
 print(f"sparse: {ds / iters * 1e3:.2f} ms / LM iteration = {B * iters / ds:.0f} problem-iterations/s; error {si.err_history[:, 0].mean():.1f} -> {si.err_history[:, -1].mean():.4f}")
 if os.environ.get("BENCH_SPARSE_DENSE", "1") == "1":
     dd, di, _, xd = run(th.HipCholeskySolver)
