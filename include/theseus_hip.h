@@ -138,6 +138,22 @@ int thx_pg2_vjp(const thx_pg_structure* s, const thx_pg_data* d, const void* w, 
                 void* grad_w_between, void* grad_prior_target, void* grad_w_prior, void* grad_log_radius_between,
                 void* grad_log_radius_prior, int dtype, const thx_se2_eps* eps, void* stream);
 
+/* ---- SO2 variables (planar rotation-only graphs): theseus/geometry/so2.py -- exp_map :167-186 (update_from_angle :96-100),
+ *      _log_map_impl :206-223, _adjoint_impl :116-117, _compose_impl :225-231, _inverse_impl :233-235 -- under Between / Local
+ *      (embodied/measurements/between.py:38-45, embodied/misc/local_cost_fn.py:42-61) and the retraction
+ *      (geometry/lie_group.py:197-198).  Group records of 2 ([cos, sin]), tangents / weights of 1, 1x1 blocks, column layout
+ *      pose * 1; thx_pg_structure / thx_pg_data are shared (batch strides 2 / 1 / 0).  The group has no Taylor switches: no eps
+ *      argument.  Records are never re-normalised (the reference's constructors pass tensors through unchanged).
+ *      thx_so2_op: 0 exp (a = theta (N,1) -> out (N,2), jac (N,1,1) = 1 or NULL), 1 log (a = X -> out (N,1), jac), 2 compose
+ *      (a, b -> out), 3 inverse, 4 adjoint (out (N,1,1) = 1). */
+int thx_pgso2_assemble(const thx_pg_structure* s, const thx_pg_data* d, void* H, int64_t ld, void* g, int dtype, void* stream);
+int thx_pgso2_error(const thx_pg_structure* s, const thx_pg_data* d, void* partials, void* err, int dtype, void* stream);
+int thx_pgso2_jacobians(const thx_pg_structure* s, const thx_pg_data* d, void* J0, void* J1, void* eb, void* Jp, void* ep,
+                        int dtype, void* stream);
+int thx_so2_retract(const void* poses, const void* delta, int64_t ldd, double step, const uint8_t* ignore_mask, void* out,
+                    int32_t P, int32_t B, int dtype, void* stream);
+int thx_so2_op(int op, const void* a, const void* b, void* out, void* jac, int64_t N, int dtype, void* stream);
+
 /* ---- SO3 variables (rotation-only graphs): theseus/geometry/so3.py over torchlie's SO3 closed forms
  *      (torchlie/torchlie/functional/so3_impl.py:220-261 exp, :270-320 Jexp, :390-433 log, :442-479 Jlog; adjoint = R,
  *      inverse = R^T, compose = R0 R1), group records of 9 (3x3 row major), tangents / weights of 3, 3x3 blocks, column
@@ -321,7 +337,9 @@ int thx_chol_solve_sparse(const void* L, int64_t ld, int32_t n, int32_t B, const
  *        thx_chol_factor_levels: per level ONE diagonal launch over (problems x block columns of the level) and ONE off-diagonal
  *          launch over (problems x entries of the level) -- same kernels as thx_chol_factor_hblocks.  H is the block list read
  *          through `layout`, whose tile_ptr / piece_* tables are built for the PADDED tiles; L is the tile-packed factor
- *          (B, nslots, THX_TILE, THX_TILE) of `pattern` (zero-initialised once), Winv (B, ntiles, THX_TILE, THX_TILE).
+ *          (B, nslots, THX_TILE, THX_TILE) of `pattern` (zero-initialised once), Winv (B, ntiles, THX_TILE, THX_TILE).  rhs / y
+ *          (both NULL or both given, vectors of the PADDED order, y must not alias rhs): the forward substitution y = L^-1 rhs
+ *          fused into the diagonal launches as in thx_chol_factor_forward -- a column keeps its K-list's blocks of y in LDS.
  *        thx_chol_solve_levels: which = 0: x = (L L^T)^-1 rhs, 1: x = L^-T rhs, 2: x = L^-1 rhs; one launch per level and direction, one
  *          workgroup per (problem, block row); rhs / x are vectors of the PADDED order (B, >= ntiles * THX_TILE), row stride ldv;
  *          x may alias rhs.
@@ -331,12 +349,14 @@ typedef struct {
   int32_t nlevels;
   const int32_t* level_col_host;  /* (nlevels + 1) HOST: level l = block columns [level_col_host[l], level_col_host[l + 1]) */
   const int32_t* level_ent_host;  /* (nlevels + 1) HOST: ... and off-diagonal entries [level_ent_host[l], level_ent_host[l + 1]) */
+  const int32_t* level_maxk_host; /* (nlevels) HOST: longest diagonal K-list (diag_kptr) among the level's block columns */
   const int32_t* ent_col;         /* DEVICE (entries): block column of entry e (col_ptr is not used by the level kernels) */
   const int32_t* tile_valid;      /* DEVICE (ntiles): rows / columns of tile j that are matrix (a multiple of the block size) */
 } thx_level_schedule;
 int thx_chol_factor_levels(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t B, const void* damping,
-                           int ellipsoidal, double damping_eps, void* L, void* Winv, int32_t* info,
-                           const thx_tile_pattern* pattern, const thx_level_schedule* schedule, int dtype, void* stream);
+                           int ellipsoidal, double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y,
+                           int64_t ldv, const thx_tile_pattern* pattern, const thx_level_schedule* schedule, int dtype,
+                           void* stream);
 int thx_chol_solve_levels(const void* L, int32_t B, const void* Winv, const void* rhs, void* x, int64_t ldv, int which,
                           const thx_tile_pattern* pattern, const thx_level_schedule* schedule, int dtype, void* stream);
 int thx_vec_gather(const void* src, int64_t lds, void* dst, int64_t ldd, const int32_t* idx, int32_t n, int32_t B, int dtype,

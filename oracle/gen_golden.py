@@ -103,7 +103,7 @@ def build_reference_objective(th, d, dtype):
     examples/pose_graph/pose_graph_synthetic.py:130-152."""
     B = d["poses"].shape[0]
     obj = th.Objective(dtype=dtype)
-    G = {"SE2": th.SE2, "SO3": th.SO3}.get(d.get("group", "SE3"), th.SE3)
+    G = {"SE2": th.SE2, "SO3": th.SO3, "SO2": th.SO2}.get(d.get("group", "SE3"), th.SE3)
     poses = [G(tensor=d["poses"][:, k].clone(), name=f"pose_{k}") for k in range(d["P"])]
     for k in range(d["edges"].shape[0]):
         i, j = d["edges"][k].tolist()
@@ -410,6 +410,88 @@ def gen_so3(th, lieF):
         final = torch.stack([p_.tensor for p_ in pv], 1).numpy()
         np.savez_compressed(
             os.path.join(OUT, name + ".npz"), group=np.array("SO3"), P=P, edges=edges.numpy(), meas=meas.numpy(),
+            w_between=w_between.numpy(), prior_idx=prior_idx.numpy(), prior_target=prior_target.numpy(),
+            w_prior=w_prior.numpy(), poses0=poses.numpy(), final=final, err0=err0, err_history=info.err_history.numpy(),
+            AtA=np.stack(taps["AtA"][:1]), Atb=np.stack(taps["Atb"]), A0=taps["A"][0], b0=taps["b"][0],
+            delta=np.stack(taps["delta"]), last_err=np.stack(taps["err"]),
+            var_start_cols=np.array(lin.var_start_cols), var_dims=np.array(lin.var_dims), num_rows=lin.num_rows,
+            num_cols=lin.num_cols, opt_kwargs=np.array(repr(dict(ok, **lmk, gauss_newton=False))))
+        print(name, "err", err0.mean(), "->", info.err_history[:, -1].mean().item())
+
+
+def gen_so2(th):
+    """SO2 as a variable type of its own (theseus/geometry/so2.py): Lie-op fixtures (exp / log with their unit Jacobians, adjoint,
+    inverse, compose; angles through zero, +-pi and the atan2 branch cut) and LM trajectories of planar rotation-only graphs
+    (Between + Difference on th.SO2) with DenseLinearization + CholeskyDenseSolver."""
+    gen = torch.Generator().manual_seed(31)
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        special = torch.tensor([0.0, 1e-9, -1e-7, 1e-3, -0.5, 1.0, 2.0, 3.0, -3.0, np.pi - 1e-6, -np.pi + 1e-6, np.pi / 2, -np.pi / 2,
+                                3.5, -4.0, 7.0], dtype=torch.float64)
+        theta = torch.cat([special, 3.0 * torch.randn(48, dtype=torch.float64, generator=gen)]).to(dtype).unsqueeze(1)
+        jl = []
+        X = th.SO2.exp_map(theta, jacobians=jl)
+        jexp = jl[0]
+        Y = th.SO2.exp_map((2.0 * torch.randn(theta.shape[0], 1, dtype=torch.float64, generator=gen)).to(dtype))
+        jl = []
+        log = X.log_map(jacobians=jl)
+        np.savez_compressed(os.path.join(OUT, f"lie_so2_{tag}.npz"), xi=theta.numpy(), exp=X.tensor.numpy(), jexp=jexp.numpy(),
+                            log=log.numpy(), jlog=jl[0].numpy(), adj=X.adjoint().numpy(), inv=X.inverse().tensor.numpy(),
+                            Y=Y.tensor.numpy(), compose=X.compose(Y).tensor.numpy())
+    cases = [
+        ("pgso2_f64_lm", dict(P=12, E=22, B=4, dtype=torch.float64, seed=61), dict(max_iterations=6, step_size=1.0), dict(damping=1e-3)),
+        ("pgso2_f32_lm", dict(P=12, E=22, B=8, dtype=torch.float32, seed=61), dict(max_iterations=6, step_size=1.0), dict(damping=1e-3)),
+        ("pgso2_f64_lm_adaptive", dict(P=9, E=15, B=5, dtype=torch.float64, seed=63, batched_weights=True),
+         dict(max_iterations=8, step_size=0.8), dict(damping=1.0, adaptive_damping=True, ellipsoidal_damping=True)),
+    ]
+    ex = lambda t: th.SO2.exp_map(t).tensor  # noqa: E731
+    comp = lambda a, b: th.SO2(tensor=a).compose(th.SO2(tensor=b)).tensor  # noqa: E731
+    inv = lambda a: th.SO2(tensor=a).inverse().tensor  # noqa: E731
+    for name, pk, ok, lmk in cases:
+        dtype, seed, P, E, B = pk["dtype"], pk["seed"], pk["P"], pk["E"], pk["B"]
+        gen = torch.Generator().manual_seed(seed)
+        rng = np.random.default_rng(seed)
+        edges = [(i, i + 1) for i in range(P - 1)]
+        while len(edges) < E:
+            i, j = sorted(rng.choice(P, 2, replace=False).tolist())
+            edges.append((j, i) if rng.random() < 0.3 else (i, j))
+        edges = torch.tensor(edges, dtype=torch.long)
+        rnd = lambda n, rs: ex(rs * (2 * torch.rand(n, 1, dtype=torch.float64, generator=gen) - 1))  # noqa: E731
+        gt = rnd(B * P, 3.0).view(B, P, 2)
+        gi, gj = gt[:, edges[:, 0]].reshape(-1, 2), gt[:, edges[:, 1]].reshape(-1, 2)
+        meas = comp(comp(inv(gi), gj), rnd(B * E, 0.03)).view(B, E, 2).to(dtype)
+        poses = comp(gt.reshape(-1, 2), rnd(B * P, 0.3)).view(B, P, 2).to(dtype)
+        if pk.get("batched_weights"):
+            w_between = ((0.5 + torch.rand(B, E, 1, dtype=torch.float64, generator=gen)) * 10).to(dtype)
+        else:
+            w_between = torch.tensor([[[1 / 0.03]]], dtype=torch.float64).repeat(1, E, 1).to(dtype)
+        prior_idx = torch.tensor([0, P // 2], dtype=torch.long)
+        prior_target = comp(gt[:, prior_idx].reshape(-1, 2), rnd(B * 2, 0.01)).view(B, 2, 2).to(dtype)
+        w_prior = torch.tensor([[[1e-1], [2.0]]], dtype=dtype)
+        obj = th.Objective(dtype=dtype)
+        pv = [th.SO2(tensor=poses[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+        for k in range(E):
+            i, j = edges[k].tolist()
+            cw = th.DiagonalCostWeight(th.Variable(w_between[:, k].clone(), name=f"w_{k}"))
+            obj.add(th.Between(pv[i], pv[j], th.SO2(tensor=meas[:, k].clone(), name=f"meas_{k}"), cw, name=f"between_{k}"))
+        for k in range(2):
+            sw = th.ScaleCostWeight(th.Variable(w_prior[:, k, :1].clone(), name=f"pw_{k}"))
+            obj.add(th.Difference(pv[int(prior_idx[k])], th.SO2(tensor=prior_target[:, k].clone(), name=f"tgt_{k}"), sw, name=f"prior_{k}"))
+        obj.update()
+        opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=True,
+                                    abs_err_tolerance=0.0, rel_err_tolerance=0.0, **ok)
+        taps = dict(AtA=[], Atb=[], delta=[], A=[], b=[], err=[])
+
+        def cb(optimizer, info, delta, it):
+            lin = optimizer.linear_solver.linearization
+            for k_, v_ in (("AtA", lin.AtA), ("Atb", lin.Atb), ("A", lin.A), ("b", lin.b), ("delta", delta), ("err", info.last_err)):
+                taps[k_].append(v_.clone().numpy())
+        lin = opt.linear_solver.linearization
+        with torch.no_grad():
+            err0 = obj.error_metric().clone().numpy()
+            info = opt.optimize(track_err_history=True, end_iter_callback=cb, **lmk)
+        final = torch.stack([p_.tensor for p_ in pv], 1).numpy()
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"), group=np.array("SO2"), P=P, edges=edges.numpy(), meas=meas.numpy(),
             w_between=w_between.numpy(), prior_idx=prior_idx.numpy(), prior_target=prior_target.numpy(),
             w_prior=w_prior.numpy(), poses0=poses.numpy(), final=final, err0=err0, err_history=info.err_history.numpy(),
             AtA=np.stack(taps["AtA"][:1]), Atb=np.stack(taps["Atb"]), A0=taps["A"][0], b0=taps["b"][0],
@@ -1362,6 +1444,8 @@ def main():
         gen_pg_mixed_robust(th, lieF)
     if not only or "so3" in only:
         gen_so3(th, lieF)
+    if not only or "so2" in only:
+        gen_so2(th)
     if not only or "se2_implicit" in only:
         gen_se2_implicit(th)
     if not only or "so3_implicit" in only:

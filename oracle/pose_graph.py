@@ -18,7 +18,7 @@ from typing import List, Optional, Tuple
 
 import torch
 
-from . import lie, lie_se2, lie_so3
+from . import lie, lie_se2, lie_so2, lie_so3
 
 MIN_DAMPING, MAX_DAMPING = 1.0e-7, 1.0e7  # levenberg_marquardt.py:52-53
 
@@ -44,7 +44,14 @@ class _SO3:
     log_jlog = staticmethod(lie_so3.so3_log_jlog_autograd)
 
 
-GROUPS = {"SE3": _SE3, "SE2": _SE2, "SO3": _SO3}
+class _SO2:
+    name, dof = "SO2", 1
+    compose, inverse, adjoint, retract = (staticmethod(lie_so2.so2_compose), staticmethod(lie_so2.so2_inverse),
+                                          staticmethod(lie_so2.so2_adjoint), staticmethod(lie_so2.so2_retract))
+    log_jlog = staticmethod(lie_so2.so2_log_jlog)
+
+
+GROUPS = {"SE3": _SE3, "SE2": _SE2, "SO3": _SO3, "SO2": _SO2}
 
 
 @dataclass
@@ -279,7 +286,7 @@ def retract(poses, delta, ignore_mask=None, G=None):
     """objective.py:873-914 / vectorizer.py:410-469 / variable.py:65-69: X.exp(delta), masked rows keep X."""
     B, P = poses.shape[:2]
     if G is None:
-        G = _SE2 if poses.ndim == 3 else (_SO3 if poses.shape[-1] == 3 else _SE3)
+        G = (_SO2 if poses.shape[-1] == 2 else _SE2) if poses.ndim == 3 else (_SO3 if poses.shape[-1] == 3 else _SE3)
     new = G.retract(poses, delta.view(B, P, G.dof))
     if ignore_mask is not None:
         new = torch.where(ignore_mask.view([B] + [1] * (poses.ndim - 1)), poses, new)

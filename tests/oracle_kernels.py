@@ -29,7 +29,7 @@ class OracleKernels:
                           meas=bm(t.meas), w_between=bm(t.w_between),
                           prior_idx=torch.from_numpy(h.prior_pose).long(),
                           prior_target=bm(t.prior_target), w_prior=bm(t.w_prior),
-                          group="SE2" if t.poses.dim() == 3 else ("SO3" if t.poses.shape[-1] == 3 else "SE3"),
+                          group=("SO2" if t.poses.shape[-1] == 2 else "SE2") if t.poses.dim() == 3 else ("SO3" if t.poses.shape[-1] == 3 else "SE3"),
                           robust_between=loss_spec(t.robust_between, t.loss_between),
                           log_radius_between=bm(t.log_radius_between) if t.robust_between else None,
                           robust_prior=loss_spec(t.robust_prior, t.loss_prior),
@@ -109,6 +109,29 @@ class OracleKernels:
 
     def so3_adjoint(self, X):
         return X.clone()
+
+    # ---- SO2 elementwise -------------------------------------------------------------------------
+    def so2_exp(self, theta, jac=False):
+        from oracle import lie_so2
+        X, J = lie_so2.so2_exp_jexp(theta)
+        return (X, J) if jac else X
+
+    def so2_log(self, X, jac=False):
+        from oracle import lie_so2
+        th_, J = lie_so2.so2_log_jlog(X)
+        return (th_, J) if jac else th_
+
+    def so2_compose(self, X, Y):
+        from oracle import lie_so2
+        return lie_so2.so2_compose(X, Y)
+
+    def so2_inverse(self, X):
+        from oracle import lie_so2
+        return lie_so2.so2_inverse(X)
+
+    def so2_adjoint(self, X):
+        from oracle import lie_so2
+        return lie_so2.so2_adjoint(X)
 
     # ---- SE2 elementwise -------------------------------------------------------------------------
     def se2_exp(self, xi, jac=False):

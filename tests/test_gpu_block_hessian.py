@@ -133,7 +133,8 @@ def test_lm_with_block_hessian_equals_dense_frame(name, solver):
         obj, _ = build_objective(th, g)
         cls = th.HipCholeskySolver if solver == "dense" else th.HipSparseCholeskySolver
         opt = th.LevenbergMarquardt(obj, linear_solver_cls=cls, max_iterations=4, abs_err_tolerance=0.0, rel_err_tolerance=0.0,
-                                    linearization_kwargs=dict(block_hessian=compact))
+                                    linearization_kwargs=dict(block_hessian=compact),
+                                    linear_solver_kwargs=dict(ordering="rcm") if solver == "sparse" else None)
         lin = opt.linear_solver.linearization
         assert lin._compact == compact
         sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(

@@ -124,7 +124,7 @@ def test_sample_agrees_with_exact_evaluation_of_the_same_inputs(full_run):
 
 
 # ---- the same size against the REAL reference (tests/golden/pg_full_*.npz, oracle/gen_golden.py:gen_pg_full) ----------------
-def _run_fixture(name, solver="dense"):
+def _run_fixture(name, solver="dense", ordering=None):
     import theseus_amd as th
     from tests.helpers import golden_problem, load_golden
     from tests.test_gpu_lm import build_objective
@@ -134,8 +134,11 @@ def _run_fixture(name, solver="dense"):
     kw.pop("gauss_newton")
     cls = th.HipCholeskySolver if solver == "dense" else th.HipSparseCholeskySolver
     opt = th.LevenbergMarquardt(obj, linear_solver_cls=cls, max_iterations=kw.pop("max_iterations"),
-                                step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+                                step_size=kw.pop("step_size"), abs_err_tolerance=0.0, rel_err_tolerance=0.0,
+                                linear_solver_kwargs=dict(ordering=ordering) if ordering else None)
     lin = opt.linear_solver.linearization
+    if ordering:
+        assert opt.linear_solver.levels == (ordering == "nd")
     if solver == "dense":
         assert lin.var_start_cols == list(g["var_start_cols"]) and lin.var_dims == list(g["var_dims"])   # structure: bit exact
     assert lin.num_rows == int(g["num_rows"]) and lin.num_cols == int(g["num_cols"]) == 6 * P
@@ -174,17 +177,18 @@ def test_fp64_matches_the_reference_run_at_full_size():
     np.testing.assert_allclose(info.err_history.numpy()[:, 0], g["err0"], rtol=1e-12)
 
 
-def test_tile_sparse_solver_under_its_rcm_ordering_matches_the_reference_run():
+@pytest.mark.parametrize("ordering", ["rcm", "nd"])
+def test_tile_sparse_solver_under_its_own_ordering_matches_the_reference_run(ordering):
     """The reference-derived fixture through HipSparseCholeskySolver: the pose columns are PERMUTED (reverse Cuthill-McKee
-    `VariableOrdering`), the Hessian is the block list built from the permuted structure, the factorisation follows the tile
-    pattern -- and the solution must be the reference's (which used the natural order and a dense LAPACK factorisation):
-    final poses, and every step mapped back to the reference's column order."""
+    `VariableOrdering` / a tile-level nested dissection with the level-scheduled factorisation), the Hessian is the block list built
+    from the permuted structure, the factorisation follows the tile pattern -- and the solution must be the reference's (which used
+    the natural order and a dense LAPACK factorisation): final poses, and the cost of every iteration."""
     import numpy as np
     import theseus_amd as th
-    g, final, deltas, atbs, info = _run_fixture("pg_full_f64_lm", solver="sparse")
+    g, final, deltas, atbs, info = _run_fixture("pg_full_f64_lm", solver="sparse", ordering=ordering)
     err = (final - torch.from_numpy(g["final"])).abs().max().item()
     rel = (_relative_poses(final) - _relative_poses(torch.from_numpy(g["final"]))).abs().max().item()
-    print(f"[full size fp64, tile-sparse / RCM] max |pose - reference| = {err:.3e}, gauge-free = {rel:.3e}")
+    print(f"[full size fp64, tile-sparse / {ordering}] max |pose - reference| = {err:.3e}, gauge-free = {rel:.3e}")
     assert err <= 2e-7 and rel <= 2e-8, (err, rel)
     np.testing.assert_allclose(info.err_history.numpy()[:, 1:].T, g["last_err"], rtol=1e-9)
 

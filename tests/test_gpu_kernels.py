@@ -119,9 +119,40 @@ def test_so3_ops_vs_reference_golden(K, tag, dtype):
         assert (rows(got[k] - g[k]) <= ref_dev + 4e-7 * scale).all(), k
 
 
+@pytest.mark.parametrize("tag,dtype", [("f32", torch.float32), ("f64", torch.float64)])
+def test_so2_ops_vs_reference_golden(K, tag, dtype):
+    """thx_so2_op against the reference's SO2 outputs (theseus/geometry/so2.py:116-117,167-235): the angle <-> [cos, sin] maps,
+    the angle-addition compose, the inverse and the unit Jacobians / adjoint; angles through 0, +-pi and beyond.  fp32: within
+    fp32 rounding of the exact value, hence inside the reference's own fp32 band (the kernels evaluate in fp64 registers)."""
+    from oracle import lie_so2
+    g = load_golden(f"lie_so2_{tag}")
+    th_ = torch.from_numpy(g["xi"]).cuda()
+    X, J = K.so2_exp(th_, jac=True)
+    Xg, Yg = torch.from_numpy(g["exp"]).cuda(), torch.from_numpy(g["Y"]).cuda()
+    lg, Jl = K.so2_log(Xg, jac=True)
+    got = dict(exp=X, jexp=J, log=lg, jlog=Jl, adj=K.so2_adjoint(Xg), inv=K.so2_inverse(Xg), compose=K.so2_compose(Xg, Yg))
+    got = {k: v.cpu().numpy() for k, v in got.items()}
+    for k in ("jexp", "jlog", "adj", "inv"):
+        np.testing.assert_array_equal(got[k], g[k], err_msg=k)          # exact: ones, and a sign flip
+    if dtype == torch.float64:
+        for k in ("exp", "log", "compose"):
+            np.testing.assert_allclose(got[k], g[k], rtol=1e-14, atol=1e-14, err_msg=k)
+        return
+    th64, X64, Y64 = (torch.from_numpy(g[k]).double() for k in ("xi", "exp", "Y"))
+    exact = dict(exp=lie_so2.so2_exp(th64), log=lie_so2.so2_log(X64), compose=lie_so2.so2_compose(X64, Y64))
+    for k, ex in exact.items():
+        ex = ex.numpy()
+        rows = lambda a: np.abs(a).reshape(ex.shape[0], -1).max(1)  # noqa: E731
+        scale = np.maximum(1.0, rows(ex))
+        dev, ref_dev = rows(got[k] - ex), rows(g[k] - ex)
+        assert (dev <= 2e-7 * scale).all(), (k, (dev / scale).max())
+        assert (rows(got[k] - g[k]) <= ref_dev + 2e-7 * scale).all(), k
+
+
 CASES = ["pg_f64_lm", "pg_f32_lm", "pg_f32_lm_b16", "pg_f64_lm_adaptive_ellips", "pg_f64_gn",
          "pg2_f64_lm", "pg2_f32_lm", "pg2_f64_lm_adaptive",   # pg2_*: SE2 (thx_pg2_*)
-         "pg3_f64_lm", "pg3_f32_lm", "pg3_f64_lm_adaptive"]   # pg3_*: SO3 (thx_pgso3_*)
+         "pg3_f64_lm", "pg3_f32_lm", "pg3_f64_lm_adaptive",   # pg3_*: SO3 (thx_pgso3_*)
+         "pgso2_f64_lm", "pgso2_f32_lm", "pgso2_f64_lm_adaptive"]   # pgso2_*: SO2 (thx_pgso2_*)
 
 
 @pytest.mark.parametrize("name", CASES)

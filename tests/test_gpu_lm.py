@@ -16,7 +16,7 @@ def build_objective(th, g, device="cuda"):
     obj = th.Objective(dtype=dtype)
     P = int(g["P"])
     poses0 = t(g["poses0"])
-    G = {"SE2": th.SE2, "SO3": th.SO3}.get(str(g["group"]) if "group" in g else "SE3", th.SE3)
+    G = {"SE2": th.SE2, "SO3": th.SO3, "SO2": th.SO2}.get(str(g["group"]) if "group" in g else "SE3", th.SE3)
     poses = [G(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
     for k in range(g["edges"].shape[0]):
         i, j = g["edges"][k].tolist()
@@ -36,7 +36,8 @@ def build_objective(th, g, device="cuda"):
 CASES = [("pg_f64_lm", 1e-7), ("pg_f64_gn", 1e-7), ("pg_f64_lm_adaptive", 1e-7),
          ("pg_f64_lm_adaptive_ellips", 1e-7), ("pg_f64_lm_adaptive_rejects", 1e-7),
          ("pg2_f64_lm", 1e-7), ("pg2_f64_lm_adaptive", 1e-7),   # pg2_*: SE2 pose graphs (theseus/geometry/se2.py)
-         ("pg3_f64_lm", 1e-7), ("pg3_f64_lm_adaptive", 1e-7)]   # pg3_*: SO3 rotation graphs (theseus/geometry/so3.py)
+         ("pg3_f64_lm", 1e-7), ("pg3_f64_lm_adaptive", 1e-7),   # pg3_*: SO3 rotation graphs (theseus/geometry/so3.py)
+         ("pgso2_f64_lm", 1e-7), ("pgso2_f64_lm_adaptive", 1e-7)]   # pgso2_*: SO2 planar rotation graphs (theseus/geometry/so2.py)
 
 
 def well_conditioned_steps(g, n_iters):

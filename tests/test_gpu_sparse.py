@@ -284,11 +284,14 @@ def test_level_schedule_factor_and_solves(dtype, P, B):
     g = lin.Atb.squeeze(2)
     r = (Hd @ delta.double().unsqueeze(2)).squeeze(2) - g.double()
     assert (r.abs().max() / g.abs().max()).item() < (2e-2 if dtype == torch.float32 else 1e-10)
+    # the cached-factor solve (both halves through thx_chol_solve_levels) against the step whose forward half was fused into the
+    # factorisation: same factor, another summation order in the forward substitution
     x = solver.solve_with_factor(g.contiguous())
-    assert torch.equal(x, delta)                                    # fused-forward handle and the two-gather path: same kernels
+    stol = (2e-4 if dtype == torch.float32 else 1e-11) * float(delta.abs().max())
+    assert float((x - delta).abs().max()) <= stol and torch.isfinite(delta).all()
     snap = solver.factor_snapshot()
     solver.solve(damping=7.0, ellipsoidal_damping=False)            # the solver factorises something else ...
-    assert torch.equal(solver.solve_with_snapshot(snap, g.contiguous()), delta)   # ... the snapshot still solves the first system
+    assert torch.equal(solver.solve_with_snapshot(snap, g.contiguous()), x)   # ... the snapshot still solves the first system
 
 
 def test_level_schedule_not_positive_definite_is_reported():

@@ -297,6 +297,44 @@ def test_so3_pose_graph_matches_reference(name, tol):
                                        atol=tol * max(1.0, np.abs(g["delta"][it]).max()))
 
 
+@pytest.mark.parametrize("tag,dtype,tol", [("f32", torch.float32, 2e-6), ("f64", torch.float64, 1e-14)])
+def test_so2_ops_match_reference(tag, dtype, tol):
+    """theseus/geometry/so2.py:116-117,167-235 restated (oracle/lie_so2.py) against the reference's own outputs."""
+    from oracle import lie_so2
+    g = load_golden(f"lie_so2_{tag}")
+    th_, X, Y = (torch.from_numpy(g[k]) for k in ("xi", "exp", "Y"))
+    assert th_.dtype == dtype and X.shape[1] == 2
+    R, J = lie_so2.so2_exp_jexp(th_)
+    np.testing.assert_allclose(R.numpy(), g["exp"], rtol=tol, atol=tol)
+    np.testing.assert_array_equal(J.numpy(), g["jexp"])
+    log, jlog = lie_so2.so2_log_jlog(X)
+    np.testing.assert_allclose(log.numpy(), g["log"], rtol=tol, atol=tol)
+    np.testing.assert_array_equal(jlog.numpy(), g["jlog"])
+    np.testing.assert_array_equal(lie_so2.so2_adjoint(X).numpy(), g["adj"])
+    np.testing.assert_array_equal(lie_so2.so2_inverse(X).numpy(), g["inv"])
+    np.testing.assert_allclose(lie_so2.so2_compose(X, Y).numpy(), g["compose"], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("name,tol", [("pgso2_f64_lm", 5e-9), ("pgso2_f64_lm_adaptive", 5e-9), ("pgso2_f32_lm", 1e-3)])
+def test_so2_pose_graph_matches_reference(name, tol):
+    g = load_golden(name)
+    p, poses0, kw = golden_problem(g)
+    assert p.group == "SO2" and p.n == int(g["num_cols"]) == p.num_poses and p.m == int(g["num_rows"])
+    A, b = opg.dense_linearize(p, poses0)
+    f32 = tol > 1e-6
+    np.testing.assert_allclose(A.numpy(), g["A0"], atol=np.abs(g["A0"]).max() * (1e-5 if f32 else 1e-12))
+    np.testing.assert_allclose(b.numpy(), g["b0"], atol=np.abs(g["b0"]).max() * (1e-5 if f32 else 1e-12))
+    AtA, Atb = opg.hessian(A, b)
+    np.testing.assert_allclose(AtA.numpy(), g["AtA"][0], rtol=0, atol=np.abs(g["AtA"][0]).max() * (1e-5 if f32 else 1e-12))
+    np.testing.assert_allclose(opg.error_metric(p, poses0).numpy(), g["err0"], rtol=1e-5 if f32 else 1e-12)
+    final, info = opg.lm_optimize(p, poses0, abs_err_tolerance=0.0, rel_err_tolerance=0.0, keep_taps=True, **kw)
+    np.testing.assert_allclose(final.numpy(), g["final"], rtol=0, atol=tol)
+    if len(info.deltas) == g["delta"].shape[0]:
+        for it in range(len(info.deltas)):
+            np.testing.assert_allclose(info.deltas[it].numpy(), g["delta"][it], rtol=0,
+                                       atol=tol * max(1.0, np.abs(g["delta"][it]).max()))
+
+
 @pytest.mark.parametrize("name", ["pg_f64_mixed_robust", "pg2_f64_mixed_robust"])
 def test_mixed_robust_objective_matches_reference(name):
     """Plain, Welsch, Huber and flatten_dims=True costs mixed inside one role (theseus/core/robust_cost_function.py:52-135):

@@ -56,6 +56,7 @@ def _objective(th, g):
 
 @pytest.mark.parametrize("name", ["pg_f64_lm", "pg_f64_lm_adaptive_ellips", "pg_f64_lm_adaptive_rejects", "pg_f64_gn",
                                   "pg2_f64_lm", "pg2_f64_lm_adaptive", "pg3_f64_lm", "pg3_f64_lm_adaptive",
+                                  "pgso2_f64_lm", "pgso2_f64_lm_adaptive",                              # th.SO2 variables: fused too
                                   "pg_f64_dogleg", "pg_f64_dogleg_rejects"])   # th.Dogleg: Av() from the Jacobian blocks
 def test_reference_loop_drives_the_plugin(ref, name):
     th, thp = ref

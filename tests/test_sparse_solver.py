@@ -7,10 +7,8 @@ import torch
 
 def chain_graph(P, stride=7, span=5, seed=0, shuffle=True):
     """odometry chain + local loop closures; pose NAMES are shuffled so that insertion order is far from banded."""
-    rng = np.random.default_rng(seed)
-    edges = [(i, i + 1) for i in range(P - 1)] + [(i, i + span) for i in range(0, P - span, stride)]
-    label = rng.permutation(P) if shuffle else np.arange(P)
-    return [(int(label[a]), int(label[b])) for a, b in edges]
+    from theseus_amd.utils.synthetic import chain_graph_topology
+    return chain_graph_topology(P, stride=stride, span=span, seed=seed, shuffle=shuffle)
 
 
 def test_tile_pattern_covers_the_numeric_fill():

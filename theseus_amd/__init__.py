@@ -4,13 +4,13 @@ Host-side mirror of the reference's modelling + optimizer API for the SE3 / SE2 
 hand-written HIP kernels behind a C ABI (include/theseus_hip.h, theseus_amd/csrc).  No CPU fallback.
 """
 from .core import (AutoDiffCostFunction, Between, CostFunction, CostWeight, DiagonalCostWeight, Difference, HuberLoss, Local,  # noqa: F401
-                   Objective, Point2, Point3, Reprojection, RobustCostFunction, RobustLoss, ScaleCostWeight, SE2, SE3, SO3,
+                   Objective, Point2, Point3, Reprojection, RobustCostFunction, RobustLoss, ScaleCostWeight, SE2, SE3, SO2, SO3,
                    Variable, Vector, WelschLoss)
 from .kernels import (HipKernels, default_kernels, reset_global_params, set_global_params, set_lie_eps,  # noqa: F401
                       set_se2_eps)
 from .layer import TheseusLayer  # noqa: F401
 from .linear_solver import HipCholeskySolver, LinearSolver  # noqa: F401
-from .sparse import HipSparseCholeskySolver, fill_reducing_ordering  # noqa: F401
+from .sparse import HipSparseCholeskySolver, fill_reducing_ordering, level_ordering  # noqa: F401
 from .linearization import HipLinearization, Linearization, VariableOrdering  # noqa: F401
 from .nonlinear import (BackwardMode, Dogleg, GaussNewton, LevenbergMarquardt, NonlinearLeastSquares,  # noqa: F401
                         NonlinearOptimizerInfo, NonlinearOptimizerStatus, TrustRegion)

@@ -62,7 +62,7 @@ class TilePattern(Structure):  # thx_tile_pattern: tile-level symbolic factorisa
 
 
 class LevelSchedule(Structure):  # thx_level_schedule: elimination-tree levels of a tile pattern (2 host + 2 device int32 tables)
-    _fields_ = [("nlevels", c_int32)] + [(k, c_void_p) for k in ("level_col_host", "level_ent_host", "ent_col", "tile_valid")]
+    _fields_ = [("nlevels", c_int32)] + [(k, c_void_p) for k in ("level_col_host", "level_ent_host", "level_maxk_host", "ent_col", "tile_valid")]
 
 
 class HBlockLayout(Structure):  # thx_hblock_layout: block-compact Hessian (device int32 tables)
@@ -129,6 +129,11 @@ _SIGNATURES = {
     "thx_so3_retract": [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p, c_int32, c_int32, c_int,
                         POINTER(LieEps), c_void_p],
     "thx_so3_op": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(LieEps), c_void_p],
+    "thx_pgso2_assemble": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_int64, c_void_p, c_int, c_void_p],
+    "thx_pgso2_error": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_void_p, c_int, c_void_p],
+    "thx_pgso2_jacobians": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "thx_so2_retract": [c_void_p, c_void_p, c_int64, c_double, c_void_p, c_void_p, c_int32, c_int32, c_int, c_void_p],
+    "thx_so2_op": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     "thx_ba_assemble": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                         c_int, POINTER(LieEps), c_void_p],
     "thx_ba_schur": [POINTER(BAStructure), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_double,
@@ -171,7 +176,7 @@ _SIGNATURES = {
     "thx_chol_factor_hblocks": [POINTER(HBlockLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p,
                                 c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(TilePattern), c_int, c_void_p],
     "thx_chol_factor_levels": [POINTER(HBlockLayout), c_void_p, c_int64, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,
-                               c_void_p, POINTER(TilePattern), POINTER(LevelSchedule), c_int, c_void_p],
+                               c_void_p, c_void_p, c_void_p, c_int64, POINTER(TilePattern), POINTER(LevelSchedule), c_int, c_void_p],
     "thx_chol_solve_levels": [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(TilePattern),
                               POINTER(LevelSchedule), c_int, c_void_p],
     "thx_vec_gather": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int, c_void_p],

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtheseus_hip.so")
-SOURCES = ["pg_kernels.hip", "chol_kernels.hip", "vjp_kernels.hip", "block_kernels.hip", "pg2_kernels.hip", "ba_kernels.hip", "vjp2_kernels.hip", "pgso3_kernels.hip", "ba_vjp_kernels.hip", "vjpso3_kernels.hip", "vjp_unroll_kernels.hip", "vjp_unroll3_kernels.hip", "vjp_unroll_ba_kernels.hip"]
+SOURCES = ["pg_kernels.hip", "chol_kernels.hip", "vjp_kernels.hip", "block_kernels.hip", "pg2_kernels.hip", "ba_kernels.hip", "vjp2_kernels.hip", "pgso3_kernels.hip", "pgso2_kernels.hip", "ba_vjp_kernels.hip", "vjpso3_kernels.hip", "vjp_unroll_kernels.hip", "vjp_unroll3_kernels.hip", "vjp_unroll_ba_kernels.hip"]
 HEADERS = ["lie.cuh", "lie_se2.cuh", "lie_so3.cuh", "pg3_generic.cuh", "vjp_se3.cuh", "unroll_se3.cuh", "unroll_g3.cuh", "unroll_ba.cuh", "dual.cuh", "robust.cuh", "common.cuh", os.path.join("..", "..", "include", "theseus_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"]
 

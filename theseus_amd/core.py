@@ -379,6 +379,80 @@ class SO3(Variable):
         return SO3(tensor=self.tensor.clone(), name=new_name or f"{self.name}_copy")
 
 
+class SO2(Variable):
+    """SO2 group element batch, tensor (B,2) = [cos, sin]; tangent theta (1); right perturbations
+    (theseus/geometry/so2.py:20-120; every Jacobian of the group is the scalar 1: :116-117,167-223)."""
+
+    def __init__(self, theta: Optional[torch.Tensor] = None, tensor: Optional[torch.Tensor] = None,
+                 name: Optional[str] = None, dtype: Optional[torch.dtype] = None):
+        if theta is not None and tensor is not None:
+            raise ValueError("Please provide only one of theta or tensor.")
+        if theta is not None:
+            if theta.ndim == 1:
+                theta = theta.unsqueeze(1)
+            if theta.ndim != 2 or theta.shape[1] != 1:
+                raise ValueError("Argument theta must be have ndim = 1, or ndim=2 and shape[1] = 1.")
+            tensor = torch.cat([theta.cos(), theta.sin()], dim=1)   # so2.py:96-100
+        if tensor is None:
+            tensor = torch.tensor([[1.0, 0.0]], dtype=dtype or torch.get_default_dtype())
+        if tensor.ndim == 1:
+            tensor = tensor.unsqueeze(0)
+        if tensor.ndim != 2 or tensor.shape[1] != 2:
+            raise ValueError("SO2 data tensors can only be 2D vectors.")
+        if dtype is not None and tensor.dtype != dtype:
+            tensor = tensor.to(dtype)
+        super().__init__(tensor, name)
+
+    @staticmethod
+    def dof() -> int:
+        return 1
+
+    @staticmethod
+    def exp_map(tangent_vector: torch.Tensor, jacobians: Optional[List[torch.Tensor]] = None) -> "SO2":
+        if tangent_vector.ndim != 2 or tangent_vector.shape[1] != 1:
+            raise ValueError("Tangent vectors of SO2 should be 1-D vectors.")
+        K = default_kernels()
+        if jacobians is not None:
+            X, J = K.so2_exp(tangent_vector, jac=True)
+            jacobians.append(J)
+        else:
+            X = K.so2_exp(tangent_vector)
+        return SO2(tensor=X)
+
+    def log_map(self, jacobians: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+        K = default_kernels()
+        if jacobians is not None:
+            th, J = K.so2_log(self.tensor, jac=True)
+            jacobians.append(J)
+            return th
+        return K.so2_log(self.tensor)
+
+    def adjoint(self) -> torch.Tensor:
+        return default_kernels().so2_adjoint(self.tensor)
+
+    def inverse(self) -> "SO2":
+        return SO2(tensor=default_kernels().so2_inverse(self.tensor))
+
+    def compose(self, other: "SO2") -> "SO2":
+        a, b = _broadcast_pair(self.tensor, other.tensor)
+        return SO2(tensor=default_kernels().so2_compose(a, b))
+
+    def between(self, other: "SO2") -> "SO2":
+        return self.inverse().compose(other)
+
+    def local(self, other: "SO2") -> torch.Tensor:
+        return self.between(other).log_map()
+
+    def retract(self, delta: torch.Tensor) -> "SO2":
+        return self.compose(SO2.exp_map(delta))
+
+    def theta(self) -> torch.Tensor:
+        return self.log_map()   # so2.py:113-114
+
+    def copy(self, new_name: Optional[str] = None) -> "SO2":
+        return SO2(tensor=self.tensor.clone(), name=new_name or f"{self.name}_copy")
+
+
 def _broadcast_pair(a, b):
     if a.shape[0] != b.shape[0]:
         if a.shape[0] == 1:

@@ -33,6 +33,7 @@
 // backward pass).
 #include "common.cuh"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
@@ -660,7 +661,10 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
                                         int validB, int64_t ld, int K, T* sA, T* sB, int tid, const T* gemv_y,
                                         T* gemv_part, Compute&& compute, Hook&& after_issue = NoHook{},
                                         const int32_t* __restrict__ ktiles = nullptr, const int32_t* __restrict__ ksa = nullptr,
-                                        const int32_t* __restrict__ ksb = nullptr, int64_t packed_elems = 0) {
+                                        const int32_t* __restrict__ ksb = nullptr, int64_t packed_elems = 0,
+                                        bool gemv_compact = false) {
+  // (gemv_compact: gemv_y holds the K-LIST's blocks of y back to back -- element kc * KB belongs to chunk kc -- instead of the
+  //  whole vector: the level schedule's diagonal kernels, whose K-lists are short and scattered over all of y)
   using C = CT<T>;
   using V = typename C::V;
   constexpr int TPR = C::KB / C::VEC;   // threads per staged row (16 bytes each)
@@ -765,7 +769,7 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
         constexpr int HALF = C::KB / 2;
         // (thread pair (2r, 2r+1): the two 16-column halves of row r -- with SPLIT16 the two sub-chunks)
         const V* rp = reinterpret_cast<const V*>(sA + (tid >> 1) * LDT + (SPLIT16 ? (tid & 1) * 128 * LDT : (tid & 1) * HALF));
-        const V* yp = reinterpret_cast<const V*>(gemv_y + kof(kc) + (tid & 1) * HALF);
+        const V* yp = reinterpret_cast<const V*>(gemv_y + (gemv_compact ? kc * C::KB : kof(kc)) + (tid & 1) * HALF);
 #pragma unroll
         for (int i = 0; i < HALF / C::VEC; ++i) {
           const V a = rp[i], yv = yp[i];
@@ -1406,6 +1410,10 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   THX_STAMP();
 
   // SYRK on the 36 lower 16x16 blocks of the tile, nine per wave (Engine<T>::syrk36)
+  // tile-sparse: only the block columns k < j in which row panel j is non-zero
+  const int32_t* klist = pat.diag_k ? pat.diag_k + pat.diag_kptr[j] : nullptr;
+  const int Kspan = pat.diag_k ? (pat.diag_kptr[j + 1] - pat.diag_kptr[j]) * TILE : row0;
+  const bool ycompact = pat.ent_col != nullptr;   // (level schedule: ybuf holds the K-list's blocks of y only)
   typename E::Sy acc[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i)
@@ -1417,8 +1425,13 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   // H_jj blocks, in flight during the whole K-loop
   HBPre<T, HB ? HB_NPRE_DIAG : 1> hbp;
   auto prologue = [&]() __attribute__((always_inline)) {
-    if (fwd)
-      for (int k = tid; k < row0; k += 256) ybuf[k] = yout[(int64_t)b * ldv + k];
+    if (fwd) {
+      if (ycompact) {   // level schedule: the blocks of y this column's K-list names, back to back
+        for (int k = tid; k < Kspan; k += 256) ybuf[k] = yout[(int64_t)b * ldv + klist[k >> 7] * TILE + (k & (TILE - 1))];
+      } else {
+        for (int k = tid; k < row0; k += 256) ybuf[k] = yout[(int64_t)b * ldv + k];
+      }
+    }
     if constexpr (!HB) {
       const T* Hjj = H + mat + (int64_t)row0 * ld + row0;
       if (wave == 0) E::template syrk36_prefetch<0>(Hjj, ld, valid, hpre, lane);
@@ -1436,9 +1449,6 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 #ifdef THX_OFF_PROLOGUE_FIRST   // the round-1 order (A/B timing)
   prologue();
 #endif
-  // tile-sparse: only the block columns k < j in which row panel j is non-zero
-  const int32_t* klist = pat.diag_k ? pat.diag_k + pat.diag_kptr[j] : nullptr;
-  const int Kspan = pat.diag_k ? (pat.diag_kptr[j + 1] - pat.diag_kptr[j]) * TILE : row0;
   kloop_f<T, true, true, E::SYRK_LDT, (sizeof(T) == 8 && CT<T>::KB == 32)>(
       L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld), valid, nullptr, 0, ldt, Kspan, tile, nullptr, tid,
       fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
@@ -1448,9 +1458,9 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
     else E::template syrk36<3>(tile, acc, lane);
   },
 #ifdef THX_OFF_PROLOGUE_FIRST
-  NoHook{}, klist, lf.packed ? pat.diag_s + pat.diag_kptr[j] : nullptr, nullptr, lf.pstride);
+  NoHook{}, klist, lf.packed ? pat.diag_s + pat.diag_kptr[j] : nullptr, nullptr, lf.pstride, ycompact);
 #else
-  prologue, klist, lf.packed ? pat.diag_s + pat.diag_kptr[j] : nullptr, nullptr, lf.pstride);
+  prologue, klist, lf.packed ? pat.diag_s + pat.diag_kptr[j] : nullptr, nullptr, lf.pstride, ycompact);
 #endif
 
   // ---- S = H_jj (+ damping on the diagonal) - acc -> LDS tile; identity padding outside the matrix ----
@@ -1678,6 +1688,10 @@ chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict
   const int valid = tile_rows(pat, n, j);
   const bool fwd = rhs != nullptr;
 
+  // tile-sparse: only the block columns k < j in which row panel j is non-zero
+  const int32_t* klist = pat.diag_k ? pat.diag_k + pat.diag_kptr[j] : nullptr;
+  const int Kspan = pat.diag_k ? (pat.diag_kptr[j + 1] - pat.diag_kptr[j]) * TILE : row0;
+  const bool ycompact = pat.ent_col != nullptr;   // (level schedule: ybuf holds the K-list's blocks of y only)
   typename E::Sy acc[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i)
@@ -1687,8 +1701,13 @@ chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict
   std::conditional_t<sizeof(T) == 4, float4, f64x4> hpre[9];
   HBPre<T, HB ? HB_NPRE_DIAG : 1> hbp;
   auto prologue = [&]() __attribute__((always_inline)) {
-    if (fwd)
-      for (int k = tid; k < row0; k += 256) ybuf[k] = yout[(int64_t)b * ldv + k];
+    if (fwd) {
+      if (ycompact) {   // level schedule: the blocks of y this column's K-list names, back to back
+        for (int k = tid; k < Kspan; k += 256) ybuf[k] = yout[(int64_t)b * ldv + klist[k >> 7] * TILE + (k & (TILE - 1))];
+      } else {
+        for (int k = tid; k < row0; k += 256) ybuf[k] = yout[(int64_t)b * ldv + k];
+      }
+    }
     if constexpr (!HB) {
       const T* Hjj = H + mat + (int64_t)row0 * ld + row0;
       if (wave == 0) E::template syrk36_prefetch<0>(Hjj, ld, valid, hpre, lane);
@@ -1703,8 +1722,6 @@ chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict
       hbp.load(hb, b, j, j, tid);
     }
   };
-  const int32_t* klist = pat.diag_k ? pat.diag_k + pat.diag_kptr[j] : nullptr;
-  const int Kspan = pat.diag_k ? (pat.diag_kptr[j + 1] - pat.diag_kptr[j]) * TILE : row0;
   kloop_f<T, true, true, E::SYRK_LDT, (sizeof(T) == 8 && CT<T>::KB == 32)>(
       L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld), valid, nullptr, 0, ldt, Kspan, stage, nullptr, tid,
       fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
@@ -1712,7 +1729,7 @@ chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict
     else if (wave == 1) E::template syrk36<1>(stage, acc, lane);
     else if (wave == 2) E::template syrk36<2>(stage, acc, lane);
     else E::template syrk36<3>(stage, acc, lane);
-  }, prologue, klist, lf.packed ? pat.diag_s + pat.diag_kptr[j] : nullptr, nullptr, lf.pstride);
+  }, prologue, klist, lf.packed ? pat.diag_s + pat.diag_kptr[j] : nullptr, nullptr, lf.pstride, ycompact);
 
   {
     const bool damp = damping != nullptr;
@@ -2911,12 +2928,22 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   const bool fused_diag = B < split_diag_min;
   const size_t dsm = fused_diag ? DiagSmem<T>::bytes(rhs ? ntiles * TILE : 0) : SyrkSmem<T>::bytes(rhs ? ntiles * TILE : 0);
   if (dsm > LDS_LIMIT) return fail("thx_chol_factor: n too large for the fused forward substitution (LDS)");
-  if (ls && (rhs || !packed || !use_hb)) return fail("thx_chol_factor_levels: tile-packed factor, block-compact H, no fused forward substitution");
+  if (ls && (!packed || !use_hb)) return fail("thx_chol_factor_levels: tile-packed factor + block-compact H");
+  // level schedule + fused forward substitution: a column keeps only its K-list's blocks of y in LDS -- the launch of level l is
+  // sized for the longest K-list of that level (level_maxk_host)
+  size_t ls_smem_max = 0;
+  if (ls) {
+    for (int l = 0; l < ls->nlevels; ++l) {
+      const int yp = rhs ? ls->level_maxk_host[l] * TILE : 0;
+      ls_smem_max = std::max(ls_smem_max, std::max(DiagSmem<T>::bytes(yp), SyrkSmem<T>::bytes(yp)));
+    }
+    if (ls_smem_max > LDS_LIMIT) return fail("thx_chol_factor_levels: K-list too long for the fused forward substitution (LDS)");
+  }
   std::lock_guard<std::mutex> guard(g_launch_mutex);   // (the whole enqueue: the auxiliary stream / events are shared)
   DeviceLaunchState& ds = launch_state();
   constexpr int ti = sizeof(T) == 8;
   if (ls) {   // (both diagonal schedules may be taken, level by level; no y buffer: well below the default limit, raised anyway)
-    const size_t d0 = DiagSmem<T>::bytes(0), s0 = SyrkSmem<T>::bytes(0);
+    const size_t d0 = ls_smem_max, s0 = ls_smem_max;
     if (d0 > ds.attr_diag[ti][1]) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)d0);
       ds.attr_diag[ti][1] = d0;
@@ -3075,7 +3102,8 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       const int e0 = ls->level_ent_host[l], ne = ls->level_ent_host[l + 1] - e0;
       if (nc <= 0) continue;
       const bool fused = (int64_t)B * nc < split_diag_min;
-      launch_diag_n(h, j0, nc, fused, fused ? DiagSmem<T>::bytes(0) : SyrkSmem<T>::bytes(0));
+      const int yp = rhs ? ls->level_maxk_host[l] * TILE : 0;
+      launch_diag_n(h, j0, nc, fused, fused ? DiagSmem<T>::bytes(yp) : SyrkSmem<T>::bytes(yp));
       if (ne > 0) launch_off(h, j0, e0, ne);
     }
     return check_launch("thx_chol_factor_levels");
@@ -3359,7 +3387,7 @@ static int check_levels(const thx_tile_pattern* pattern, const thx_level_schedul
       !pattern->diag_k || !pattern->row_ptr || !pattern->row_tile || !pattern->tile_sa || !pattern->tile_sb || !pattern->diag_s ||
       !pattern->row_slot || pattern->nslots <= 0 || pattern->ntiles <= 0)
     return fail(who, ": incomplete tile pattern (the level schedule works on the tile-packed factor)");
-  if (!ls || ls->nlevels <= 0 || !ls->level_col_host || !ls->level_ent_host || !ls->ent_col || !ls->tile_valid)
+  if (!ls || ls->nlevels <= 0 || !ls->level_col_host || !ls->level_ent_host || !ls->level_maxk_host || !ls->ent_col || !ls->tile_valid)
     return fail(who, ": incomplete level schedule");
   if (ls->level_col_host[0] != 0 || ls->level_col_host[ls->nlevels] != pattern->ntiles || ls->level_ent_host[0] != 0 ||
       ls->level_ent_host[ls->nlevels] != pattern->nslots - pattern->ntiles)
@@ -3372,19 +3400,22 @@ static int check_levels(const thx_tile_pattern* pattern, const thx_level_schedul
 }
 
 int thx_chol_factor_levels(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t B, const void* damping,
-                           int ellipsoidal, double damping_eps, void* L, void* Winv, int32_t* info,
-                           const thx_tile_pattern* pattern, const thx_level_schedule* schedule, int dtype, void* stream) {
+                           int ellipsoidal, double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y,
+                           int64_t ldv, const thx_tile_pattern* pattern, const thx_level_schedule* schedule, int dtype,
+                           void* stream) {
   if (!layout || !layout->tile_ptr || !layout->piece_blk || !layout->piece_rc || !Hc || !L || !Winv || !info || B <= 0)
     return fail("thx_chol_factor_levels: null pointer / incomplete block layout / B <= 0");
   if (int r = check_levels(pattern, schedule, "thx_chol_factor_levels")) return r;
   if (layout->ntiles != pattern->ntiles || bstride < (int64_t)layout->nblocks * layout->bd * layout->bd)
     return fail("thx_chol_factor_levels: the block layout is not this pattern's");
   const int n = pattern->ntiles * TILE;   // (the padded order: every tile is whole, tile_valid says how much of it is matrix)
+  if ((rhs == nullptr) != (y == nullptr) || (rhs && ldv < n)) return fail("thx_chol_factor_levels: rhs / y are vectors of the PADDED order (ldv >= ntiles * THX_TILE)");
+  if (rhs && rhs == y) return fail("thx_chol_factor_levels: y must not alias rhs");
   const HBlk hb{Hc, bstride, layout->bd, layout->tile_ptr, layout->piece_blk, layout->piece_rc};
   THX_DISPATCH(dtype,
-               return factor_impl<float>(nullptr, 0, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, nullptr, nullptr, 0,
+               return factor_impl<float>(nullptr, 0, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
                                          as_stream(stream), pattern, &hb, schedule),
-               return factor_impl<double>(nullptr, 0, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, nullptr, nullptr, 0,
+               return factor_impl<double>(nullptr, 0, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
                                           as_stream(stream), pattern, &hb, schedule));
   return 0;
 }

@@ -37,7 +37,7 @@ __device__ __forceinline__ void so3_log_jlog(const S* R, const thx::Eps<S>& eps,
 }
 
 struct GroupSO3 {
-  static constexpr int REC = 9;
+  static constexpr int REC = 9, DOF = 3;
   using X = SO3m<double>;
   using Eps = thx::Eps<double>;
 

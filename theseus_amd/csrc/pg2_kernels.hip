@@ -7,7 +7,7 @@
 namespace thx {
 
 struct GroupSE2 {
-  static constexpr int REC = 4;
+  static constexpr int REC = 4, DOF = 3;
   using X = SE2<double>;
   using Eps = Eps2<double>;
   template <typename T>

@@ -146,12 +146,12 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
-GROUP_RECORD = {"SE3": (12, 6), "SO3": (9, 3), "SE2": (4, 3)}   # (scalars per record, dof)
+GROUP_RECORD = {"SE3": (12, 6), "SO3": (9, 3), "SE2": (4, 3), "SO2": (2, 1)}   # (scalars per record, dof)
 
 
 def group_of(poses: torch.Tensor) -> str:
     if poses.dim() == 3:
-        return "SE2"
+        return "SO2" if poses.shape[-1] == 2 else "SE2"
     return "SO3" if poses.shape[-1] == 3 else "SE3"
 
 
@@ -183,11 +183,11 @@ class PGTensors:
 
     @property
     def se2(self) -> bool:
-        return self.poses.dim() == 3
+        return self.poses.dim() == 3 and self.poses.shape[-1] == 4
 
     @property
     def group(self) -> str:
-        """Read off the record shape: SE3 (3,4), SO3 (3,3), SE2 (4,)."""
+        """Read off the record shape: SE3 (3,4), SO3 (3,3), SE2 (4,), SO2 (2,)."""
         return group_of(self.poses)
 
     def c_struct(self, poses: Optional[torch.Tensor] = None) -> _lib.PGData:
@@ -351,10 +351,52 @@ class HipKernels:
         self._so3_op(4, X, None, A, None)
         return A
 
-    # ---- pose graph (SE3 records (3,4) -> thx_pg_*, SE2 records (4,) -> thx_pg2_*, SO3 records (3,3) -> thx_pgso3_*) ----
+    # ---- SO2 elementwise (theseus/geometry/so2.py:167-235: records [cos, sin], tangent theta, every Jacobian 1) ----
+    def _so2_op(self, op, a, b, out, jac):
+        _lib.check(self.lib.thx_so2_op(op, _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), _lib.ptr(jac), a.shape[0],
+                                       _lib.dtype_code(a.dtype), _lib.stream_ptr(a.device)), "thx_so2_op")
+
+    def so2_exp(self, theta, jac=False):
+        theta = theta.contiguous()
+        X = theta.new_empty(theta.shape[0], 2)
+        J = theta.new_empty(theta.shape[0], 1, 1) if jac else None
+        self._so2_op(0, theta, None, X, J)
+        return (X, J) if jac else X
+
+    def so2_log(self, X, jac=False):
+        X = X.contiguous()
+        th = X.new_empty(X.shape[0], 1)
+        J = X.new_empty(X.shape[0], 1, 1) if jac else None
+        self._so2_op(1, X, None, th, J)
+        return (th, J) if jac else th
+
+    def so2_compose(self, X, Y):
+        X, Y = X.contiguous(), Y.contiguous()
+        Z = torch.empty_like(X)
+        self._so2_op(2, X, Y, Z, None)
+        return Z
+
+    def so2_inverse(self, X):
+        X = X.contiguous()
+        Y = torch.empty_like(X)
+        self._so2_op(3, X, None, Y, None)
+        return Y
+
+    def so2_adjoint(self, X):
+        X = X.contiguous()
+        A = X.new_empty(X.shape[0], 1, 1)
+        self._so2_op(4, X, None, A, None)
+        return A
+
+    # ---- pose graph (SE3 records (3,4) -> thx_pg_*, SE2 records (4,) -> thx_pg2_*, SO3 records (3,3) -> thx_pgso3_*, SO2 records
+    #      (2,) -> thx_pgso2_*) ----
     def pg_assemble(self, s: DeviceStructure, t: PGTensors, H, g, poses=None):
         d = t.c_struct(poses)
         dt = H.dtype
+        if t.group == "SO2":
+            _lib.check(self.lib.thx_pgso2_assemble(s.c, d, _lib.ptr(H, "H"), H.shape[-1], _lib.ptr(g, "g"),
+                                                   _lib.dtype_code(dt), _lib.stream_ptr(H.device)), "thx_pgso2_assemble")
+            return
         if t.group == "SO3":
             _lib.check(self.lib.thx_pgso3_assemble(s.c, d, _lib.ptr(H, "H"), H.shape[-1], _lib.ptr(g, "g"),
                                                    _lib.dtype_code(dt), lie_eps(dt), _lib.stream_ptr(H.device)),
@@ -399,13 +441,14 @@ class HipKernels:
             "thx_chol_factor_hblocks")
 
     # ---- level-scheduled tile-sparse Cholesky (include/theseus_hip.h: thx_level_schedule; theseus_amd/sparse.py:LevelPattern) ----
-    def chol_factor_levels(self, layout, Hc, damping, ellipsoidal, damping_eps, L, panels, info, pattern):
-        """thx_chol_factor_levels: ``layout`` = the block list's piece tables for the pattern's PADDED tiles; L tile-packed."""
+    def chol_factor_levels(self, layout, Hc, damping, ellipsoidal, damping_eps, L, panels, info, pattern, rhs=None, y=None):
+        """thx_chol_factor_levels: ``layout`` = the block list's piece tables for the pattern's PADDED tiles; L tile-packed;
+        rhs / y: padded vectors of the fused forward substitution."""
         dev = L.device
         _lib.check(self.lib.thx_chol_factor_levels(
             layout.c, _lib.ptr(Hc), Hc.stride(0), L.shape[0], _lib.ptr(damping), int(bool(ellipsoidal)), float(damping_eps),
-            _lib.ptr(L), _lib.ptr(panels), _lib.ptr(info), pattern.c_struct(dev), pattern.c_levels(dev), _lib.dtype_code(L.dtype),
-            _lib.stream_ptr(dev)), "thx_chol_factor_levels")
+            _lib.ptr(L), _lib.ptr(panels), _lib.ptr(info), _lib.ptr(rhs), _lib.ptr(y), y.stride(0) if y is not None else 0,
+            pattern.c_struct(dev), pattern.c_levels(dev), _lib.dtype_code(L.dtype), _lib.stream_ptr(dev)), "thx_chol_factor_levels")
 
     def chol_solve_levels(self, L, panels, rhs, x, pattern, which=0):
         """thx_chol_solve_levels on vectors of the padded order (which: 0 both, 1 backward only, 2 forward only)."""
@@ -422,6 +465,10 @@ class HipKernels:
     def pg_error(self, s: DeviceStructure, t: PGTensors, partials, err, poses=None):
         d = t.c_struct(poses)
         dt = err.dtype
+        if t.group == "SO2":
+            _lib.check(self.lib.thx_pgso2_error(s.c, d, _lib.ptr(partials), _lib.ptr(err), _lib.dtype_code(dt),
+                                                _lib.stream_ptr(err.device)), "thx_pgso2_error")
+            return
         if t.group == "SO3":
             _lib.check(self.lib.thx_pgso3_error(s.c, d, _lib.ptr(partials), _lib.ptr(err), _lib.dtype_code(dt),
                                                 lie_eps(dt), _lib.stream_ptr(err.device)), "thx_pgso3_error")
@@ -436,6 +483,10 @@ class HipKernels:
     def pg_jacobians(self, s: DeviceStructure, t: PGTensors, J0, J1, eb, Jp, ep, poses=None):
         d = t.c_struct(poses)
         dt = t.poses.dtype
+        if t.group == "SO2":
+            _lib.check(self.lib.thx_pgso2_jacobians(s.c, d, _lib.ptr(J0), _lib.ptr(J1), _lib.ptr(eb), _lib.ptr(Jp), _lib.ptr(ep),
+                                                    _lib.dtype_code(dt), _lib.stream_ptr(t.poses.device)), "thx_pgso2_jacobians")
+            return
         if t.group == "SO3":
             _lib.check(self.lib.thx_pgso3_jacobians(s.c, d, _lib.ptr(J0), _lib.ptr(J1), _lib.ptr(eb), _lib.ptr(Jp),
                                                     _lib.ptr(ep), _lib.dtype_code(dt), lie_eps(dt),
@@ -457,6 +508,11 @@ class HipKernels:
             return self.se3_retract(poses, delta, step, ignore_mask, out)
         P, B = poses.shape[:2]
         dt = poses.dtype
+        if grp == "SO2":
+            _lib.check(self.lib.thx_so2_retract(_lib.ptr(poses), _lib.ptr(delta), delta.stride(0), float(step),
+                                                _lib.ptr(ignore_mask), _lib.ptr(out), P, B, _lib.dtype_code(dt),
+                                                _lib.stream_ptr(poses.device)), "thx_so2_retract")
+            return
         if grp == "SO3":
             _lib.check(self.lib.thx_so3_retract(_lib.ptr(poses), _lib.ptr(delta), delta.stride(0), float(step),
                                                 _lib.ptr(ignore_mask), _lib.ptr(out), P, B, _lib.dtype_code(dt),

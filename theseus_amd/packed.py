@@ -91,7 +91,7 @@ class UnsupportedObjective(NotImplementedError):
 # and the real ``theseus`` ones alike (theseus_amd/plugin.py plugs this back end into the reference's own loop).
 def _kind(obj) -> str:
     names = {c.__name__ for c in type(obj).__mro__}
-    for k in ("SE3", "SE2", "SO3", "Between"):
+    for k in ("SE3", "SE2", "SO3", "SO2", "Between"):
         if k in names:
             return k
     if "Local" in names or "Difference" in names:
@@ -99,8 +99,8 @@ def _kind(obj) -> str:
     return type(obj).__name__
 
 
-GROUP_SHAPE = {"SE3": (3, 4), "SE2": (4,), "SO3": (3, 3)}
-GROUP_DOF = {"SE3": 6, "SE2": 3, "SO3": 3}
+GROUP_SHAPE = {"SE3": (3, 4), "SE2": (4,), "SO3": (3, 3), "SO2": (2,)}
+GROUP_DOF = {"SE3": 6, "SE2": 3, "SO3": 3, "SO2": 1}
 
 
 def _weight_diag(w, dof: int) -> torch.Tensor:
@@ -162,7 +162,7 @@ class PackedPoseGraph:
             kind = _kind(v)
             if kind not in GROUP_SHAPE or (self.group is not None and kind != self.group):
                 raise UnsupportedObjective(
-                    f"HIP backend fuses objectives whose optimisation variables are all SE3, all SE2 or all SO3; got "
+                    f"HIP backend fuses objectives whose optimisation variables are all SE3, all SE2, all SO3 or all SO2; got "
                     f"{type(v).__name__} ({v.name}). There is no CPU/eager fallback.")
             self.group = kind
             self.pose_vars.append(v)

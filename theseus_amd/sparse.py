@@ -424,6 +424,8 @@ class LevelPattern:
             ent_col=i32(ent_col), tile_valid=i32(counts * dof))
         self.level_col = np.ascontiguousarray(level_col, dtype=np.int32)
         self.level_ent = np.ascontiguousarray(np.asarray(level_ent, dtype=np.int32))
+        dk = np.diff(np.asarray(diag_kptr))
+        self.level_maxk = np.ascontiguousarray(np.array([dk[level_col[lv]:level_col[lv + 1]].max() for lv in range(nlev)], dtype=np.int32))
         self.col_count = np.zeros(nt, dtype=np.int32)     # (host tables of the column-by-column schedule: not used)
         self.l_tiles = int(lp.sum())
         self.tile_products = len(tile_k) + len(diag_k) + self.l_tiles
@@ -468,6 +470,7 @@ class LevelPattern:
             ls = _lib.LevelSchedule()
             ls.nlevels = self.nlevels
             ls.level_col_host, ls.level_ent_host = self.level_col.ctypes.data, self.level_ent.ctypes.data
+            ls.level_maxk_host = self.level_maxk.ctypes.data
             ls.ent_col, ls.tile_valid = t["ent_col"].data_ptr(), t["tile_valid"].data_ptr()
             vec = dict(pad_of_col=torch.from_numpy(self.pad_of_col).to(device), col_of_pad=torch.from_numpy(self.col_of_pad).to(device))
             self._dev[key] = (c, ls, t, vec)
@@ -556,8 +559,10 @@ class HipSparseCholeskyCore(HipCholeskyCore):
             self.info = torch.zeros(B, dtype=torch.int32, device=g.device)
             self._lam = torch.empty(B, dtype=g.dtype, device=g.device)
             if self.levels:   # vectors of the padded order: y (forward-substituted right-hand side) and the working vector
-                self._yp = torch.empty(B, self.pattern.npad, dtype=g.dtype, device=g.device)
-                self._xp = torch.empty(B, self.pattern.npad, dtype=g.dtype, device=g.device)
+                # (zero once: the kernels write the matrix rows only -- the padding entries must stay exact zeros, they meet the
+                #  zero columns of L in the fused forward substitution's products)
+                self._yp = torch.zeros(B, self.pattern.npad, dtype=g.dtype, device=g.device)
+                self._xp = torch.zeros(B, self.pattern.npad, dtype=g.dtype, device=g.device)
 
     def dense_factor(self) -> torch.Tensor:
         """The factor as a dense (B, ld, ld) lower-triangular frame (tests / inspection; the solver never builds it)."""
@@ -589,13 +594,15 @@ class HipSparseCholeskyCore(HipCholeskyCore):
         if self.levels:
             lin = self.linearization
             dev = self.L.device
-            self.K.chol_factor_levels(self._level_layout(dev), lin.Hc, lam, ellipsoidal_damping, damping_eps, self.L, self.panels,
-                                      self.info, self.pattern)
             if rhs is None:
+                self.K.chol_factor_levels(self._level_layout(dev), lin.Hc, lam, ellipsoidal_damping, damping_eps, self.L, self.panels,
+                                          self.info, self.pattern)
                 return None
-            # y = L^-1 rhs in the padded order (a handle _substitute recognises: the backward half needs no second gather)
-            self.K.vec_gather(rhs.contiguous(), self._yp, self.pattern.vec_maps(dev)["col_of_pad"])
-            self.K.chol_solve_levels(self.L, self.panels, self._yp, self._yp, self.pattern, which=2)
+            # y = L^-1 rhs in the padded order, fused into the diagonal launches (a handle _substitute recognises: the backward
+            # half needs no second gather)
+            self.K.vec_gather(rhs.contiguous(), self._xp, self.pattern.vec_maps(dev)["col_of_pad"])
+            self.K.chol_factor_levels(self._level_layout(dev), lin.Hc, lam, ellipsoidal_damping, damping_eps, self.L, self.panels,
+                                      self.info, self.pattern, rhs=self._xp, y=self._yp)
             return self._yp
         self._factor_call(lam, ellipsoidal_damping, damping_eps, rhs, y, pattern=self.pattern)
         return y

@@ -37,6 +37,18 @@ def pose_graph_topology(num_poses: int, num_edges: int, topology_seed: int = 0) 
     return edges
 
 
+def chain_graph_topology(num_poses: int, stride: int = 7, span: int = 5, seed: int = 0, shuffle: bool = True) -> List[Tuple[int, int]]:
+    """A SLAM-like LARGE graph for the tile-sparse solver: the odometry chain (k, k + 1) plus a local loop closure (k, k + span)
+    every ``stride`` poses -- the regime of the reference's sparse sweep (evaluations/pose_graph_synthetic.sh:5-12: up to 4096
+    poses) with closures that stay local, as a trajectory's do.  ``shuffle``: pose LABELS are permuted, so the insertion order is
+    far from banded and the solver's own ordering has to find the structure."""
+    P = num_poses
+    rng = np.random.default_rng(seed)
+    edges = [(i, i + 1) for i in range(P - 1)] + [(i, i + span) for i in range(0, P - span, stride)]
+    label = rng.permutation(P) if shuffle else np.arange(P)
+    return [(int(label[a]), int(label[b])) for a, b in edges]
+
+
 def _noise(K, B, ts, rs, dtype, device, gen):
     u = 2.0 * torch.rand(B, 6, dtype=dtype, device=device, generator=gen) - 1.0
     u[:, :3] *= ts
