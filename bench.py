@@ -426,7 +426,10 @@ def pg_run(cfg, ctx):
             gathered = gather_solution(opt.linear_solver.linearization.packed.tensors.poses)
             sync()
             gather_ms = (time.perf_counter() - tg0) * 1e3
-            assert gathered.shape[1] == world * B
+            # (weak scaling: world x B problems; strong scaling: the last sub-batch of every rank's share -- shares of a job that
+            #  does not divide by the rank count differ by one, shard_bounds)
+            assert gathered.shape[1] == (world * B if not strong else sum(
+                plan_sub_batches(cfg.total_batch, r_, world, cfg.batch)[0] for r_ in range(world))), gathered.shape
             del gathered
         local_dt = time.perf_counter() - t0   # this rank's own work, before it waits for the others
         barrier()
@@ -450,7 +453,7 @@ def pg_run(cfg, ctx):
         err_hist = info.err_history
         result = {
             "metric": "LM iterations/sec (batch x vars) on SE3 pose-graph",
-            "value": world * n_sub * B * iters_done / dt,
+            "value": (cfg.total_batch if strong else world * n_sub * B) * iters_done / dt,
             "unit": "problem-iterations/s",
             "n_gpus": world, "steps": K_iters, "warmup": W, "ms_per_step": dt / max(iters_done, 1) * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
@@ -458,13 +461,14 @@ def pg_run(cfg, ctx):
             "config": {"workload": f"SE3 pose-graph {P} poses / {E} Between edges + 1 prior, batch {n_sub * B} per GPU, "
                                    f"LM damping {cfg.damping}{' adaptive' if cfg.adaptive else ''} + "
                                    f"{'tile-sparse Cholesky (RCM ordering)' if cfg.solver == 'sparse' else 'dense Cholesky'}",
-                       "poses": P, "edges": E, "batch_per_gpu": n_sub * B, "global_batch": world * n_sub * B, "n": n,
+                       "poses": P, "edges": E, "batch_per_gpu": n_sub * B, "global_batch": cfg.total_batch if strong else world * n_sub * B,
+                       "n": n,
                        "parallelism": f"batch-shard x{world}" + (f", {n_sub} sub-batches of {B} per GPU" if strong else "")},
             "ranks": world if world == 1 else dist.get_world_size(),
             "collective_backend": None if world == 1 else dist.get_backend(),
             "rank_ms_per_step": {"min": min(rank_ms) / max(iters_done, 1), "max": max(rank_ms) / max(iters_done, 1)},
             "all_gather_ms": gather_ms,
-            "pose_updates_per_s": world * n_sub * B * iters_done * P / dt,
+            "pose_updates_per_s": (cfg.total_batch if strong else world * n_sub * B) * iters_done * P / dt,
             "iters_done": iters_done,
             "mean_error": [float(err_hist[:, 0].mean()), float(err_hist[:, iters_done].mean())],
         }
@@ -687,7 +691,8 @@ def pg_run(cfg, ctx):
         #      dense headline (value / roofline above are the dense solver's).
         obj2 = syn.build_pose_graph_objective(edges, P, dtype=dtype, device=device)
         opt2 = th.LevenbergMarquardt(obj2, linear_solver_cls=th.HipSparseCholeskySolver, max_iterations=K_iters,
-                                     abs_err_tolerance=0.0, rel_err_tolerance=0.0, step_size=1.0)
+                                     abs_err_tolerance=0.0, rel_err_tolerance=0.0, step_size=1.0,
+                                     linear_solver_kwargs=dict(ordering="auto", batch_hint=B))   # (the time model ranks the orders at THIS batch)
         layer2 = th.TheseusLayer(opt2)
         timer2 = KernelTimer(opt2.linear_solver.K)
         with torch.no_grad():
@@ -704,9 +709,10 @@ def pg_run(cfg, ctx):
             timer2.enabled = False
         pat = opt2.linear_solver.pattern
         sm2 = timer2.summary()
-        fms = (sm2.get("chol_factor_hblocks") or sm2["chol_factor_sparse"])["avg_ms"]
+        fms = (sm2.get("chol_factor_levels") or sm2.get("chol_factor_hblocks") or sm2["chol_factor_sparse"])["avg_ms"]
         result["tile_sparse"] = {
-            "solver": "HipSparseCholeskySolver (reverse Cuthill-McKee ordering, tile pattern of L)",
+            "solver": "HipSparseCholeskySolver (ordering 'auto' at this batch size: " + str(opt2.linear_solver.ordering_info.get("method")) +
+                      ("; level-scheduled" if opt2.linear_solver.levels else "; reverse Cuthill-McKee, column-by-column schedule") + ", tile pattern of L)",
             "value": B * info2.iters_done / dt2, "unit": "problem-iterations/s", "ms_per_step": dt2 / info2.iters_done * 1e3,
             "factor_ms": fms, "tiles_of_L": [pat.l_tiles, pat.ntiles * (pat.ntiles + 1) // 2],
             "executed_flops_of_dense": pat.flops / pat.dense_flops,

@@ -263,7 +263,7 @@ int thx_block_assemble(const thx_block_target* h_targets, const thx_block_term* 
 /* ---- Objective.error_metric(): 0.5 * ||weighted error||^2 per problem (core/objective.py:37-38,
  *      562-641).  `partials` is a (B, THX_ERR_CHUNKS) scratch; the reduction order is fixed
  *      (deterministic).  err is (B). */
-#define THX_ERR_CHUNKS 16
+#define THX_ERR_CHUNKS 128
 int thx_pg_error(const thx_pg_structure* s, const thx_pg_data* d, void* partials, void* err, int dtype,
                  const thx_lie_eps* eps, void* stream);
 
@@ -279,6 +279,22 @@ int thx_pg_jacobians(const thx_pg_structure* s, const thx_pg_data* d, void* J0, 
 int thx_se3_retract(const void* poses, const void* delta, int64_t ldd, double step,
                     const uint8_t* ignore_mask, void* out, int32_t P, int32_t B, int dtype,
                     const thx_lie_eps* eps, void* stream);
+
+/* ---- PER-CALL schedule of the factorisations (every thx_chol_factor* takes one as its last argument; NULL = the defaults).  The
+ *      library keeps no mutable schedule state: two callers with different schedules in one process do not see each other.  The
+ *      factor is the same either way (bit-identical: tests/test_gpu_kernels.py, tests/test_gpu_sparse.py).
+ *        split_diag_min_batch: the diagonal phase of a block column runs either as ONE kernel (SYRK + the serial tile
+ *          factorisation in the same workgroup) or SPLIT into an MFMA-only SYRK kernel and a one-wave-per-tile kernel that keeps
+ *          the tile in registers (eight tiles per CU in their pivot chains instead of three).  The split pays from this many
+ *          problems per launch on (the level schedule: problems x block columns of the level); 0 = always split, INT32_MAX =
+ *          never; < 0: the default (2048, or the environment's THX_CHOL_SPLIT_DIAG_MIN read once at load time).
+ *        column_pairs: fp32 factorisations on dense factor frames, two block columns at a time -- diag(j), tile (j+1, j),
+ *          diag(j+1), then ONE workgroup per row tile i >= j+2 produces L_ij and L_i,j+1, streaming row panel L_i,0:j from HBM
+ *          once for both; 1 on, 0 off, < 0: the default (on, or THX_CHOL_COLPAIR). */
+typedef struct {
+  int32_t split_diag_min_batch;
+  int32_t column_pairs;
+} thx_chol_schedule;
 
 /* ---- tile-sparse Cholesky for LARGE pose graphs -- the functional analogue of BaspachoSparseSolver
  *      (theseus/optimizer/linear/baspacho_sparse_solver.py:23-148; symbolic analysis once, numeric factorisation per iteration).
@@ -316,7 +332,7 @@ typedef struct {
 } thx_tile_pattern;
 int thx_chol_factor_sparse(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
                            double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y, int64_t ldv,
-                           const thx_tile_pattern* pattern, int dtype, void* stream);
+                           const thx_tile_pattern* pattern, int dtype, void* stream, const thx_chol_schedule* schedule);
 /*      thx_chol_solve_sparse: x = (L L^T)^-1 rhs (backward_only != 0: x = L^-T rhs, the second half after the fused forward
  *      substitution of thx_chol_factor_sparse) streaming only the structurally non-zero tiles of L (row lists of the pattern)
  *      -- where the dense-frame solves read ntiles^2 / 2 tiles per problem, the dominant cost of a large sparse graph's
@@ -356,7 +372,7 @@ typedef struct {
 int thx_chol_factor_levels(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t B, const void* damping,
                            int ellipsoidal, double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y,
                            int64_t ldv, const thx_tile_pattern* pattern, const thx_level_schedule* schedule, int dtype,
-                           void* stream);
+                           void* stream, const thx_chol_schedule* chol_schedule);
 int thx_chol_solve_levels(const void* L, int32_t B, const void* Winv, const void* rhs, void* x, int64_t ldv, int which,
                           const thx_tile_pattern* pattern, const thx_level_schedule* schedule, int dtype, void* stream);
 int thx_vec_gather(const void* src, int64_t lds, void* dst, int64_t ldd, const int32_t* idx, int32_t n, int32_t B, int dtype,
@@ -382,31 +398,20 @@ int thx_vec_gather(const void* src, int64_t lds, void* dst, int64_t ldd, const i
  *      thx_chol_solve: x = (L L^T)^-1 rhs with a cached factor, any rhs -- the backward pass solves
  *        with it (cf. optimizer/autograd/baspacho_sparse_autograd.py:117-168); x may alias rhs. */
 int thx_chol_factor(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
-                    double damping_eps, void* L, void* Winv, int32_t* info, int dtype, void* stream);
+                    double damping_eps, void* L, void* Winv, int32_t* info, int dtype, void* stream,
+                    const thx_chol_schedule* schedule);
 int thx_chol_factor_forward(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
                             double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y,
-                            int64_t ldv, int dtype, void* stream);
+                            int64_t ldv, int dtype, void* stream, const thx_chol_schedule* schedule);
 int thx_chol_solve_backward(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* y,
                             void* x, int64_t ldv, int dtype, void* stream);
 int thx_chol_solve(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs,
                    void* x, int64_t ldv, int dtype, void* stream);
-/*      Schedule knob of thx_chol_factor* (process-wide; results are the same factorisation either way).  The diagonal
- *      phase of a block column runs either as ONE kernel (SYRK + the serial tile factorisation in the same workgroup) or SPLIT
- *      into an MFMA-only SYRK kernel and a one-wave-per-tile kernel that keeps the tile in registers (eight tiles per CU in
- *      their pivot chains instead of three).  The split pays from `min_batch` problems per call on (default 2048; 0 = always
- *      split, INT32_MAX = never); `previous` (may be NULL) receives the old value. */
-int thx_chol_set_split_diag_min_batch(int32_t min_batch, int32_t* previous);
-/*      Schedule knob of the fp32 thx_chol_factor* on dense factor frames (process-wide; bit-identical factor either way).  on != 0
- *      (default; environment THX_CHOL_COLPAIR=0 starts with it off): two block columns at a time -- diag(j), tile (j+1, j),
- *      diag(j+1), then ONE workgroup per row tile i >= j+2 produces L_ij and L_i,j+1, streaming row panel L_i,0:j from HBM once
- *      for both (the factorisation runs at the socket's power cap; its HBM traffic is a quarter of that power).  `previous`
- *      (may be NULL) receives the old value. */
-int thx_chol_set_column_pairs(int32_t on, int32_t* previous);
 /*      (block-compact Hessian, see thx_hblock_layout) */
 int thx_chol_factor_hblocks(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t n, int32_t B,
                             const void* damping, int ellipsoidal, double damping_eps, void* L, int64_t ld, void* Winv,
                             int32_t* info, const void* rhs, void* y, int64_t ldv, const thx_tile_pattern* pattern, int dtype,
-                            void* stream);
+                            void* stream, const thx_chol_schedule* schedule);
 
 /* ---- Implicit backward (BackwardMode.IMPLICIT, nonlinear/nonlinear_least_squares.py:121-135,265-292): the
  *      grad-enabled last step is X_new = X exp(step * delta), delta = H^-1 g(theta) with H detached

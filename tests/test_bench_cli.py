@@ -82,3 +82,28 @@ def test_config0_leg_rides_in_the_line():
     r = _bench("--batch", "2", "--legs", "simple")
     leg = r["configs"]["simple_example_b16"]
     assert leg["parity"]["max_abs_v_err"] < 1e-12 and leg["parity"]["grad_x_rel_err"] < 1e-9 and leg["iters_done"] >= 1
+
+
+def test_gpus_8_is_the_drivers_command_shape():
+    """The driver's 8-GPU line is `bench.py --gpus 8 --steps K --warmup W` and nothing else: eight ranks, the weak-scaling headline
+    (every rank its own batch, one all_gather of eight shards) AND the strong-scaling leg in the same line, in the shape of
+    configs[2] -- 32768 / 8 = 4096 per rank in sub-batches -- scaled down: 32 problems, 4 per rank, 2 sub-batches of 2, every rank
+    in every collective.  Stand-in kernels over gloo: what is checked is that the path is correct by construction -- it cannot
+    hang, it shards what it says, its all_gather returns world x batch problems."""
+    r = _bench("--gpus", "8", "--batch", "2", "--legs", "strong", "--strong-total", "32")
+    assert r["n_gpus"] == 8 and r["ranks"] == 8 and r["collective_backend"] == "gloo" and r["scaling"] == "weak"
+    assert r["config"]["global_batch"] == 16 and r["config"]["batch_per_gpu"] == 2 and r["all_gather_ms"] is not None
+    assert r["iters_done"] == 2 and r["value"] == pytest.approx(16 * 2 / (r["ms_per_step"] * 2 * 1e-3), rel=1e-6)
+    leg = r["configs"]["strong_f64_32"]
+    assert leg["scaling"] == "strong" and leg["n_gpus"] == 8 and leg["config"]["global_batch"] == 32
+    assert leg["config"]["batch_per_gpu"] == 4 and "2 sub-batches of 2" in leg["config"]["parallelism"]
+    assert leg["all_gather_ms"] is not None and leg["iters_done"] == 2
+
+
+def test_gpus_8_uneven_shards():
+    """A job that does not divide by the rank count: 37 problems over 8 ranks = shares of 5, 5, 5, 5, 5, 4, 4, 4 (shard_bounds),
+    each within one sub-batch -- the all_gather carries unequal shards, the batch-global predicates reduce over all 37."""
+    r = _bench("--gpus", "8", "--total-batch", "37", "--batch", "8")
+    assert r["n_gpus"] == 8 and r["scaling"] == "strong" and r["config"]["global_batch"] == 37
+    assert r["value"] == pytest.approx(37 * 2 / (r["ms_per_step"] * 2 * 1e-3), rel=1e-6)
+    assert r["iters_done"] == 2 and r["all_gather_ms"] is not None

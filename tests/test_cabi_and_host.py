@@ -41,12 +41,12 @@ def test_bad_arguments_are_rejected_without_a_gpu(lib_path):
     """Argument validation happens on the host side of the C ABI, before any launch."""
     from theseus_amd import _lib
     lib = _lib.load()
-    rc = lib.thx_chol_factor(None, 32, 6, 1, None, 0, 1e-8, None, None, None, 0, None)
+    rc = lib.thx_chol_factor(None, 32, 6, 1, None, 0, 1e-8, None, None, None, 0, None, None)
     assert rc != 0 and b"null pointer" in lib.thx_last_error()
     one = ctypes.c_void_p(16)
-    rc = lib.thx_chol_factor(one, 33, 6, 1, None, 0, 1e-8, one, one, one, 0, None)  # ld % 32 != 0
+    rc = lib.thx_chol_factor(one, 33, 6, 1, None, 0, 1e-8, one, one, one, 0, None, None)  # ld % 32 != 0
     assert rc != 0 and b"ld" in lib.thx_last_error()
-    rc = lib.thx_chol_factor(one, 32, 6, 1, None, 0, 1e-8, one, one, one, 7, None)  # bad dtype
+    rc = lib.thx_chol_factor(one, 32, 6, 1, None, 0, 1e-8, one, one, one, 7, None, None)  # bad dtype
     assert rc != 0 and b"dtype" in lib.thx_last_error()
 
 

@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from theseus_amd._lib import THX_ERR_CHUNKS
+
 from oracle import pose_graph as opg
 from tests.helpers import golden_problem, load_golden
 
@@ -25,7 +27,7 @@ def _check_pg(p, poses0, rel=5e-12):
     AtA, Atb = opg.hessian(A, b)
     assert (sym_from_lower(H, n).cpu() - AtA).abs().max() <= rel * AtA.abs().max()
     assert (gv.cpu() - Atb[..., 0]).abs().max() <= rel * max(Atb.abs().max().item(), 1e-300)
-    part = torch.empty(16, B, dtype=poses0.dtype, device="cuda")
+    part = torch.empty(THX_ERR_CHUNKS, B, dtype=poses0.dtype, device="cuda")
     err = torch.empty(B, dtype=poses0.dtype, device="cuda")
     K.pg_error(ds, t, part, err)
     np.testing.assert_allclose(err.cpu().numpy(), opg.error_metric(p, poses0).numpy(), rtol=1e-12)

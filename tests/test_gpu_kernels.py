@@ -3,6 +3,8 @@ import numpy as np
 import pytest
 import torch
 
+from theseus_amd._lib import THX_ERR_CHUNKS
+
 from oracle import lie as olie
 from oracle import pose_graph as opg
 from tests.helpers import golden_problem, load_golden
@@ -203,7 +205,7 @@ def test_assemble_error_jacobians_vs_reference_golden(K, name):
         pat[d * r:d * r + d, d * c:d * c + d] = True
     assert not (H[:, :n, :n].cpu().numpy()[:, ~pat] != 0).any()
     # error metric
-    part = torch.empty(16, B, dtype=dtype, device="cuda")
+    part = torch.empty(THX_ERR_CHUNKS, B, dtype=dtype, device="cuda")
     err = torch.empty(B, dtype=dtype, device="cuda")
     K.pg_error(ds, t, part, err)
     if f32:

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+from theseus_amd._lib import THX_ERR_CHUNKS
+
 from oracle import pose_graph as opg
 from tests.helpers import f32_thresholds, golden_problem, load_golden
 
@@ -73,7 +75,7 @@ def test_robust_assemble_error_jacobians_vs_oracle(name, kind, dtype, both):
     rel = 5e-7 if f32 else (5e-12 if p.group == "SE3" else 1e-9)
     assert (sym_from_lower(H, n).cpu().double() - H64).abs().max() <= rel * H64.abs().max()
     assert (gv.cpu().double() - g64[..., 0]).abs().max() <= rel * g64.abs().max()
-    part = torch.empty(16, B, dtype=dtype, device="cuda")
+    part = torch.empty(THX_ERR_CHUNKS, B, dtype=dtype, device="cuda")
     err = torch.empty(B, dtype=dtype, device="cuda")
     K.pg_error(ds, t, part, err)
     np.testing.assert_allclose(err.cpu().double().numpy(), err64.numpy(), rtol=3e-7 if f32 else 1e-12)

@@ -4,6 +4,7 @@ order sum of the poses' gradients, accept / reject selects -- against the REAL r
 checked without a GPU by tests/test_unroll_math_host.py, the kernel on the GPU by tests/test_gpu_unrolled.py."""
 import numpy as np
 import pytest
+import torch
 
 from tests.helpers import load_golden
 from tests.unrolled_common import run_pg_unrolled
@@ -115,3 +116,48 @@ def test_best_solution_and_state_history_are_tracked_through_differentiated_iter
     np.testing.assert_allclose(info.best_err.numpy(), errs.min(dim=1).values.numpy(), rtol=1e-6)
     for b in range(errs.shape[0]):
         np.testing.assert_allclose(info.best_solution["pose_3"][b].numpy(), hist[b, ..., int(k_best[b])].numpy(), rtol=0, atol=1e-6)
+
+
+def test_unrolled_gradients_of_a_dropped_singular_item_are_zero():
+    """check_singular=True (dense_solver.py:91-103) under backward_mode="unroll": a batch item whose system is singular gets a zero
+    step in every iteration -- its final poses are its initial ones, so NOTHING it depends on may receive a gradient through it
+    (the reference's masked assignment), and the broken factor of that item must not leak NaNs into the others' gradients."""
+    import warnings
+    import theseus_amd as th
+    from tests.oracle_kernels import OracleKernels
+    g = dict(load_golden("pg_f64_lm_adaptive_ellips"))     # batched DiagonalCostWeights
+    B, P = g["poses0"].shape[0], int(g["P"])
+    wb, wp = g["w_between"].copy(), np.repeat(g["w_prior"], B, axis=0).copy()
+    wb[2] = 0.0
+    wp[2] = 0.0
+
+    def run(items):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a[items]))  # noqa: E731
+        leaves = dict(meas=t(g["meas"]).requires_grad_(True), w_between=t(wb).requires_grad_(True),
+                      prior_target=t(g["prior_target"]).requires_grad_(True), w_prior=t(wp)[:, :, :1].clone().requires_grad_(True))
+        poses0 = t(g["poses0"])
+        obj = th.Objective(dtype=torch.float64)
+        poses = [th.SE3(tensor=poses0[:, k].clone(), name=f"pose_{k}") for k in range(P)]
+        for k in range(g["edges"].shape[0]):
+            i, j = g["edges"][k].tolist()
+            obj.add(th.Between(poses[i], poses[j], th.SE3(tensor=leaves["meas"][:, k], name=f"meas_{k}"),
+                               th.DiagonalCostWeight(th.Variable(leaves["w_between"][:, k], name=f"w_{k}")), name=f"between_{k}"))
+        for k in range(g["prior_idx"].shape[0]):
+            obj.add(th.Difference(poses[int(g["prior_idx"][k])], th.SE3(tensor=leaves["prior_target"][:, k], name=f"tgt_{k}"),
+                                  th.ScaleCostWeight(th.Variable(leaves["w_prior"][:, k], name=f"pw_{k}")), name=f"prior_{k}"))
+        opt = th.LevenbergMarquardt(obj, max_iterations=3, abs_err_tolerance=0.0, rel_err_tolerance=0.0,
+                                    linearization_kwargs=dict(kernels=OracleKernels()), linear_solver_kwargs=dict(check_singular=True))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)      # "Singular matrix found in batch"
+            sol, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(backward_mode="unroll", damping=0.1))
+        final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
+        (final * torch.linspace(0.5, 1.5, final[0].numel(), dtype=torch.float64).view(1, *final.shape[1:])).sum().backward()
+        return final.detach(), poses0, {k: v.grad for k, v in leaves.items()}
+    final, poses0, grads = run([0, 1, 2, 3])
+    assert torch.equal(final[2], poses0[2])                                  # the dropped item never moved
+    for k, gr in grads.items():
+        assert torch.isfinite(gr).all(), k
+        assert float(gr[2].abs().max()) == 0.0, k                            # ... and nothing reaches its inputs
+    _, _, ref = run([0, 1, 3])                                               # the others: as if the dropped item were not there
+    for k in grads:
+        np.testing.assert_allclose(grads[k][[0, 1, 3]].numpy(), ref[k].numpy(), rtol=1e-9, atol=1e-12, err_msg=k)

@@ -16,11 +16,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("THESEUS_HIP_LIB") or os.path.join(_HERE, "lib", "libtheseus_hip.so")
 
 THX_TILE = 128
-THX_ERR_CHUNKS = 16
+THX_ERR_CHUNKS = 128
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
 LOSS_FLATTEN = 4  # THX_LOSS_FLATTEN: RobustCostFunction(flatten_dims=True), or-ed into a loss code
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class LieEps(Structure):
@@ -59,6 +59,10 @@ class TilePattern(Structure):  # thx_tile_pattern: tile-level symbolic factorisa
     _fields_ = [("ntiles", c_int32)] + [(k, c_void_p) for k in ("col_ptr", "col_row", "tile_kptr", "tile_k", "diag_kptr", "diag_k",
                                                                "col_count_host", "row_ptr", "row_tile",
                                                                "tile_sa", "tile_sb", "diag_s", "row_slot")] + [("nslots", c_int32), ("col_head_host", c_void_p)]
+
+
+class CholSchedule(Structure):  # thx_chol_schedule: per-call schedule of the factorisations (negative = the library default)
+    _fields_ = [("split_diag_min_batch", c_int32), ("column_pairs", c_int32)]
 
 
 class LevelSchedule(Structure):  # thx_level_schedule: elimination-tree levels of a tile pattern (2 host + 2 device int32 tables)
@@ -160,23 +164,23 @@ _SIGNATURES = {
     "thx_pgso3_vjp": [POINTER(PGStructure), POINTER(PGData), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                       c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
     "thx_chol_factor": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,
-                        c_void_p, c_int, c_void_p],
+                        c_void_p, c_int, c_void_p, POINTER(CholSchedule)],
     "thx_chol_factor_forward": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,
-                                c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
+                                c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, POINTER(CholSchedule)],
     "thx_chol_factor_sparse": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_int64, POINTER(TilePattern), c_int, c_void_p],
+                               c_void_p, c_void_p, c_int64, POINTER(TilePattern), c_int, c_void_p, POINTER(CholSchedule)],
     "thx_chol_solve_sparse": [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                               POINTER(TilePattern), c_int, c_void_p],
-    "thx_chol_set_split_diag_min_batch": [c_int32, POINTER(c_int32)],
-    "thx_chol_set_column_pairs": [c_int32, POINTER(c_int32)],
     "thx_pg_assemble_blocks": [POINTER(PGStructure), POINTER(PGData), POINTER(HBlockLayout), c_void_p, c_int64, c_void_p, c_int,
                                POINTER(LieEps), c_void_p],
     "thx_hblocks_expand": [POINTER(HBlockLayout), c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int, c_void_p],
     "thx_hblocks_diag": [POINTER(HBlockLayout), c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int, c_void_p],
     "thx_chol_factor_hblocks": [POINTER(HBlockLayout), c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int, c_double, c_void_p,
-                                c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(TilePattern), c_int, c_void_p],
+                                c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(TilePattern), c_int, c_void_p,
+                                POINTER(CholSchedule)],
     "thx_chol_factor_levels": [POINTER(HBlockLayout), c_void_p, c_int64, c_int32, c_void_p, c_int, c_double, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_void_p, c_int64, POINTER(TilePattern), POINTER(LevelSchedule), c_int, c_void_p],
+                               c_void_p, c_void_p, c_void_p, c_int64, POINTER(TilePattern), POINTER(LevelSchedule), c_int, c_void_p,
+                               POINTER(CholSchedule)],
     "thx_chol_solve_levels": [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int, POINTER(TilePattern),
                               POINTER(LevelSchedule), c_int, c_void_p],
     "thx_vec_gather": [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int, c_void_p],
@@ -230,9 +234,17 @@ def load():
     return lib
 
 
+_TRACE_CALLS = bool(int(os.environ.get("THX_TRACE_CALLS", "0")))   # debugging aid: synchronise + name every library call
+
+
 def check(rc, what):
     if rc != 0:
         raise RuntimeError(f"{what} failed ({rc}): {load().thx_last_error().decode()}")
+    if _TRACE_CALLS:
+        import sys
+        print(f"[thx] {what} queued", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        print(f"[thx] {what} done", file=sys.stderr, flush=True)
 
 
 def dtype_code(dtype):

@@ -59,7 +59,7 @@ class ImplicitStep(torch.autograd.Function):
             delta = opt.compute_delta(**kwargs)
             solver.check_info()
         else:
-            delta = torch.empty_like(y)
+            delta = torch.empty_like(lin.g)   # (NOT like y: the level schedule's y is its padded vector)
             solver._substitute(y, delta, backward_only=True)
         X = packed.tensors.poses.detach()
         X_new = torch.empty_like(X)
@@ -135,6 +135,7 @@ class PGUnrolledIteration(torch.autograd.Function):
                                    "Backward pass will not work. To obtain the best solution seen before the error, run with "
                                    "torch.no_grad()") from None
         damped, ellipsoidal, _ = solver._factored_with
+        ctx.dropped = solver.dropped_mask() if hasattr(solver, "dropped_mask") else None   # check_singular: zero step, zero gradient
         ctx.ell = solver._lam.clone() if (damped and ellipsoidal) else None   # D = lambda diag(H) + eps: lambda diag(H) is in the graph
         step = float(opt.params.step_size)
         mask = frozen.to(torch.uint8).contiguous() if frozen is not None else None
@@ -161,7 +162,11 @@ class PGUnrolledIteration(torch.autograd.Function):
             fz = ctx.frozen.bool()
             gd = gd * (~fz).to(dt).view(-1, 1)
             GX = torch.where(fz.view(1, B, *([1] * (X.dim() - 2))), G, GX)
+        if ctx.dropped is not None:   # (a dropped item's step is the constant zero; its factor may be broken)
+            gd = gd.masked_fill(ctx.dropped.unsqueeze(1), 0.0)
         w = ctx.solver.solve_with_snapshot(ctx.factor, gd)
+        if ctx.dropped is not None:
+            w = w.masked_fill(ctx.dropped.unsqueeze(1), 0.0)
         s = packed.structure
         E_, Kp = s.num_edges, s.num_priors
         new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731

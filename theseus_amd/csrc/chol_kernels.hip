@@ -2870,15 +2870,17 @@ __global__ void vec_gather_kernel(const T* __restrict__ src, int64_t lds, T* __r
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-static std::atomic<int> g_split_diag_min{[] {
-  const char* e = getenv("THX_CHOL_SPLIT_DIAG_MIN");   // (initial value of thx_chol_set_split_diag_min_batch's knob)
+// Defaults of the per-call schedule (thx_chol_schedule; a negative field / a NULL pointer selects them): read once from the
+// environment, never written afterwards -- the library keeps no mutable schedule state, two callers with different schedules in
+// one process do not see each other.
+static const int g_split_diag_min_default = [] {
+  const char* e = getenv("THX_CHOL_SPLIT_DIAG_MIN");
   return e ? atoi(e) : 2048;
-}()};
-
-static std::atomic<int> g_column_pairs{[] {
-  const char* e = getenv("THX_CHOL_COLPAIR");   // (initial value of thx_chol_set_column_pairs's knob)
+}();
+static const int g_column_pairs_default = [] {
+  const char* e = getenv("THX_CHOL_COLPAIR");
   return e ? atoi(e) : 1;
-}()};
+}();
 
 // Launch-side state is kept PER DEVICE (a process may drive several GPUs, from several threads): the dynamic-LDS limits
 // raised with hipFuncSetAttribute, and the auxiliary stream + events of the two-stream schedule, which belong to the device
@@ -2902,7 +2904,8 @@ static DeviceLaunchState& launch_state() {
 template <typename T>
 static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damping, int ellipsoidal, double eps,
                        void* L, void* panel, int32_t* info, const void* rhs, void* y, int64_t ldv, hipStream_t st,
-                       const thx_tile_pattern* tp = nullptr, const HBlk* hbp = nullptr, const thx_level_schedule* ls = nullptr) {
+                       const thx_tile_pattern* tp = nullptr, const HBlk* hbp = nullptr, const thx_level_schedule* ls = nullptr,
+                       const thx_chol_schedule* sched = nullptr) {
   const bool use_hb = hbp != nullptr;
   const HBlk hb = use_hb ? *hbp : HBlk{nullptr, 0, 0, nullptr, nullptr, nullptr};
   const int ntiles = (n + TILE - 1) / TILE;
@@ -2921,10 +2924,11 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   const int64_t lstride = packed ? (int64_t)tp->nslots * TILE * TILE : (int64_t)ld * ld;   // elements of L per problem
   if (packed && lstride * (int64_t)sizeof(T) > 0x7fffffffLL)
     return fail("thx_chol_factor: tile-packed factor larger than 2 GB per problem");
-  // diagonal phase: chol_syrk_kernel + chol_potrf_kernel from g_split_diag_min problems per call on (measured, n = 1536: fp32
+  // diagonal phase: chol_syrk_kernel + chol_potrf_kernel from split_diag_min problems per call on (measured, n = 1536: fp32
   // 45.1 vs 46.0 ms at batch 4096, fp64 101.6 vs 105.2 ms; equal at batch 1024; 3.74 vs 3.51 ms at batch 256 -- the second
   // launch per column costs more than the chain there), else the fused chol_diag_kernel
-  const int split_diag_min = g_split_diag_min.load();
+  const int split_diag_min = (sched && sched->split_diag_min_batch >= 0) ? sched->split_diag_min_batch : g_split_diag_min_default;
+  const int column_pairs = (sched && sched->column_pairs >= 0) ? sched->column_pairs : g_column_pairs_default;
   const bool fused_diag = B < split_diag_min;
   const size_t dsm = fused_diag ? DiagSmem<T>::bytes(rhs ? ntiles * TILE : 0) : SyrkSmem<T>::bytes(rhs ? ntiles * TILE : 0);
   if (dsm > LDS_LIMIT) return fail("thx_chol_factor: n too large for the fused forward substitution (LDS)");
@@ -3096,15 +3100,52 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   // ~log2(ntiles) of them under a nested-dissection ordering (theseus_amd/sparse.py:LevelPattern).
   if (ls) {
     pat.lpt = 1;   // (the level's entries are sorted longest K-list first; consecutive workgroups = the problems of one entry)
-    const Half h{st, 0, B};
+    // TWO HALF BATCHES ON TWO STREAMS (THX_LEVEL_SPLIT_MIN=<problems> turns it on; default OFF): a level is SYRK (memory) -> potrf
+    // (one wave per tile in its pivot chain: latency) -> off-diagonal tiles (matrix cores); one half's potrf could run underneath the
+    // other half's off-diagonal launch (kernel trace at 4096 poses / batch 256: potrf 1.9 ms + SYRK 2.1 ms of a 9.3 ms
+    // factorisation with the matrix cores idle).  MEASURED, NOT A WIN (profiles/r6/c_bench_sparse_two_streams.txt: factor 9.00 vs
+    // 9.16 ms at batch 256, 2.81 vs 2.76 ms at batch 64; the LM iteration 14.3 vs 13.9 / 5.66 vs 5.61 ms): a level's launches are
+    // one to two rounds of workgroups, halving them halves the occupancy of each.  The halves are disjoint problems: no dependence
+    // between the streams, same arithmetic.
+    static const int level_split_min = [] {
+      const char* e = getenv("THX_LEVEL_SPLIT_MIN");
+      return e ? atoi(e) : 0;
+    }();
+    const bool two = level_split_min > 0 && B >= level_split_min && B >= 16;
+    Half hv[2] = {{st, 0, B}, {st, 0, 0}};
+    if (two) {
+      if (!ds.ev_fork) hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming);
+      if (!ds.aux[0]) {
+        hipStreamCreateWithFlags(&ds.aux[0], hipStreamNonBlocking);
+        hipEventCreateWithFlags(&ds.ev_lag[0], hipEventDisableTiming);
+        hipEventCreateWithFlags(&ds.ev_join[0], hipEventDisableTiming);
+      }
+      const int per = min((B / 2 + 7) / 8 * 8, B);
+      hv[0] = {st, 0, per};
+      hv[1] = {ds.aux[0], per, B - per};
+      hipEventRecord(ds.ev_fork, st);
+      hipStreamWaitEvent(ds.aux[0], ds.ev_fork, 0);
+    }
     for (int l = 0; l < ls->nlevels; ++l) {
       const int j0 = ls->level_col_host[l], nc = ls->level_col_host[l + 1] - j0;
       const int e0 = ls->level_ent_host[l], ne = ls->level_ent_host[l + 1] - e0;
       if (nc <= 0) continue;
-      const bool fused = (int64_t)B * nc < split_diag_min;
       const int yp = rhs ? ls->level_maxk_host[l] * TILE : 0;
-      launch_diag_n(h, j0, nc, fused, fused ? DiagSmem<T>::bytes(yp) : SyrkSmem<T>::bytes(yp));
-      if (ne > 0) launch_off(h, j0, e0, ne);
+      for (int k = 0; k < (two ? 2 : 1); ++k) {
+        const Half& h = hv[k];
+        if (h.nb <= 0) continue;
+        // (the schedule of the diagonal phase follows the LAUNCH's workgroup count -- whole batch, so that a problem's arithmetic
+        //  does not depend on which half it is in)
+        const bool fused = (int64_t)B * nc < split_diag_min;
+        if (two && k == 1 && l == 0) hipStreamWaitEvent(h.s, ds.ev_lag[0], 0);   // half 1: one diagonal phase behind half 0
+        launch_diag_n(h, j0, nc, fused, fused ? DiagSmem<T>::bytes(yp) : SyrkSmem<T>::bytes(yp));
+        if (two && k == 0 && l == 0) hipEventRecord(ds.ev_lag[0], h.s);
+        if (ne > 0) launch_off(h, j0, e0, ne);
+      }
+    }
+    if (two) {
+      hipEventRecord(ds.ev_join[0], ds.aux[0]);
+      hipStreamWaitEvent(st, ds.ev_join[0], 0);
     }
     return check_launch("thx_chol_factor_levels");
   }
@@ -3176,11 +3217,11 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     if (rest_pending) hipStreamWaitEvent(st, ds.ev_rest, 0);
     return check_launch("thx_chol_factor");
   }
-  // COLUMN PAIRS (fp32, dense L frame without a tile pattern; THX_CHOL_COLPAIR=0 / thx_chol_set_column_pairs(0) turn them off): block columns j, j + 1 with row
+  // COLUMN PAIRS (fp32, dense L frame without a tile pattern; THX_CHOL_COLPAIR=0 / thx_chol_schedule.column_pairs = 0 turn them off): block columns j, j + 1 with row
   // tiles below j + 1 run as  diag(j) -> tile (j + 1, j) alone -> diag(j + 1) -> one chol_offdiag2 workgroup per row tile i >= j + 2
   // producing (i, j) and (i, j + 1) -- the same arithmetic in the same order, so the factor is bit-identical to the
   // column-by-column schedule; the row panels are streamed from HBM once per pair.
-  const bool colpair = g_column_pairs.load() != 0 && sizeof(T) == 4 && !tp && !packed;
+  const bool colpair = column_pairs != 0 && sizeof(T) == 4 && !tp && !packed;
   for (int j = 0; j < ntiles;) {
     const bool pair = colpair && j + 2 < ntiles;
     for (int k = 0; k < nparts; ++k) {
@@ -3301,33 +3342,33 @@ static int check_factor_args(const void* H, const void* L, const void* panel, co
 }
 
 int thx_chol_factor(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
-                    double damping_eps, void* L, void* Winv, int32_t* info, int dtype, void* stream) {
+                    double damping_eps, void* L, void* Winv, int32_t* info, int dtype, void* stream, const thx_chol_schedule* schedule) {
   if (int r = check_factor_args(H, L, Winv, info, n, B, ld)) return r;
   THX_DISPATCH(dtype,
                return factor_impl<float>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, nullptr,
-                                         nullptr, 0, as_stream(stream)),
+                                         nullptr, 0, as_stream(stream), nullptr, nullptr, nullptr, schedule),
                return factor_impl<double>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, nullptr,
-                                          nullptr, 0, as_stream(stream)));
+                                          nullptr, 0, as_stream(stream), nullptr, nullptr, nullptr, schedule));
   return 0;
 }
 
 int thx_chol_factor_forward(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
                             double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y,
-                            int64_t ldv, int dtype, void* stream) {
+                            int64_t ldv, int dtype, void* stream, const thx_chol_schedule* schedule) {
   if (int r = check_factor_args(H, L, Winv, info, n, B, ld)) return r;
   if (!rhs || !y || ldv < n) return fail("thx_chol_factor_forward: rhs / y / ldv");
   if (rhs == y) return fail("thx_chol_factor_forward: y must not alias rhs");
   THX_DISPATCH(dtype,
                return factor_impl<float>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
-                                         as_stream(stream)),
+                                         as_stream(stream), nullptr, nullptr, nullptr, schedule),
                return factor_impl<double>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
-                                          as_stream(stream)));
+                                          as_stream(stream), nullptr, nullptr, nullptr, schedule));
   return 0;
 }
 
 int thx_chol_factor_sparse(const void* H, int64_t ld, int32_t n, int32_t B, const void* damping, int ellipsoidal,
                            double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y, int64_t ldv,
-                           const thx_tile_pattern* pattern, int dtype, void* stream) {
+                           const thx_tile_pattern* pattern, int dtype, void* stream, const thx_chol_schedule* schedule) {
   if (int r = check_factor_args(H, L, Winv, info, n, B, ld)) return r;
   if (ld == 0) return fail("thx_chol_factor_sparse: H is a dense frame here (ld >= n); the tile-packed factor goes with thx_chol_factor_hblocks");
   if (!pattern || !pattern->col_ptr || !pattern->col_row || !pattern->tile_kptr || !pattern->tile_k || !pattern->diag_kptr ||
@@ -3337,9 +3378,9 @@ int thx_chol_factor_sparse(const void* H, int64_t ld, int32_t n, int32_t B, cons
   if (rhs && rhs == y) return fail("thx_chol_factor_sparse: y must not alias rhs");
   THX_DISPATCH(dtype,
                return factor_impl<float>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
-                                         as_stream(stream), pattern),
+                                         as_stream(stream), pattern, nullptr, nullptr, schedule),
                return factor_impl<double>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
-                                          as_stream(stream), pattern));
+                                          as_stream(stream), pattern, nullptr, nullptr, schedule));
   return 0;
 }
 
@@ -3362,7 +3403,7 @@ int thx_chol_solve_sparse(const void* L, int64_t ld, int32_t n, int32_t B, const
 int thx_chol_factor_hblocks(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t n, int32_t B,
                             const void* damping, int ellipsoidal, double damping_eps, void* L, int64_t ld, void* Winv,
                             int32_t* info, const void* rhs, void* y, int64_t ldv, const thx_tile_pattern* pattern, int dtype,
-                            void* stream) {
+                            void* stream, const thx_chol_schedule* schedule) {
   if (!layout || !layout->tile_ptr || !layout->piece_blk || !layout->piece_rc || !Hc)
     return fail("thx_chol_factor_hblocks: incomplete block layout");
   if (int r = check_factor_args(Hc, L, Winv, info, n, B, ld)) return r;
@@ -3376,9 +3417,9 @@ int thx_chol_factor_hblocks(const thx_hblock_layout* layout, const void* Hc, int
   const HBlk hb{Hc, bstride, layout->bd, layout->tile_ptr, layout->piece_blk, layout->piece_rc};
   THX_DISPATCH(dtype,
                return factor_impl<float>(nullptr, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
-                                         as_stream(stream), pattern, &hb),
+                                         as_stream(stream), pattern, &hb, nullptr, schedule),
                return factor_impl<double>(nullptr, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
-                                          as_stream(stream), pattern, &hb));
+                                          as_stream(stream), pattern, &hb, nullptr, schedule));
   return 0;
 }
 
@@ -3402,7 +3443,7 @@ static int check_levels(const thx_tile_pattern* pattern, const thx_level_schedul
 int thx_chol_factor_levels(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t B, const void* damping,
                            int ellipsoidal, double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y,
                            int64_t ldv, const thx_tile_pattern* pattern, const thx_level_schedule* schedule, int dtype,
-                           void* stream) {
+                           void* stream, const thx_chol_schedule* chol_schedule) {
   if (!layout || !layout->tile_ptr || !layout->piece_blk || !layout->piece_rc || !Hc || !L || !Winv || !info || B <= 0)
     return fail("thx_chol_factor_levels: null pointer / incomplete block layout / B <= 0");
   if (int r = check_levels(pattern, schedule, "thx_chol_factor_levels")) return r;
@@ -3414,9 +3455,9 @@ int thx_chol_factor_levels(const thx_hblock_layout* layout, const void* Hc, int6
   const HBlk hb{Hc, bstride, layout->bd, layout->tile_ptr, layout->piece_blk, layout->piece_rc};
   THX_DISPATCH(dtype,
                return factor_impl<float>(nullptr, 0, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
-                                         as_stream(stream), pattern, &hb, schedule),
+                                         as_stream(stream), pattern, &hb, schedule, chol_schedule),
                return factor_impl<double>(nullptr, 0, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
-                                          as_stream(stream), pattern, &hb, schedule));
+                                          as_stream(stream), pattern, &hb, schedule, chol_schedule));
   return 0;
 }
 
@@ -3443,19 +3484,6 @@ int thx_vec_gather(const void* src, int64_t lds, void* dst, int64_t ldd, const i
                hipLaunchKernelGGL(vec_gather_kernel<double>, grid, block, 0, as_stream(stream), (const double*)src, lds,
                                   (double*)dst, ldd, idx, n));
   return check_launch("thx_vec_gather");
-}
-
-int thx_chol_set_split_diag_min_batch(int32_t min_batch, int32_t* previous) {
-  if (min_batch < 0) return fail("thx_chol_set_split_diag_min_batch: min_batch < 0");
-  const int old = g_split_diag_min.exchange(min_batch);
-  if (previous) *previous = old;
-  return 0;
-}
-
-int thx_chol_set_column_pairs(int32_t on, int32_t* previous) {
-  const int old = g_column_pairs.exchange(on ? 1 : 0);
-  if (previous) *previous = old;
-  return 0;
 }
 
 int thx_chol_solve(const void* L, int64_t ld, int32_t n, int32_t B, const void* Winv, const void* rhs, void* x,

@@ -237,7 +237,7 @@ __global__ void pg3_error_reduce_kernel(const T* __restrict__ partials, T* __res
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   T acc = T(0);
-#pragma unroll
+#pragma unroll 8
   for (int c = 0; c < THX_ERR_CHUNKS; ++c) acc += partials[(int64_t)c * B + b];
   err[b] = T(0.5) * acc;
 }

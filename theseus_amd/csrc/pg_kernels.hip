@@ -286,7 +286,7 @@ __global__ void pg_error_reduce_kernel(const T* __restrict__ partials, T* __rest
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   T acc = T(0);
-#pragma unroll
+#pragma unroll 8
   for (int c = 0; c < THX_ERR_CHUNKS; ++c) acc += partials[(int64_t)c * B + b];
   err[b] = T(0.5) * acc;
 }
@@ -542,7 +542,7 @@ using namespace thx;
 extern "C" {
 
 const char* thx_last_error(void) { return last_error().c_str(); }
-int thx_abi_version(void) { return 19; }
+int thx_abi_version(void) { return 20; }
 
 int thx_copy_where(const uint8_t* mask, const void* src, void* dst, int64_t N, int32_t B, int32_t record_bytes, void* stream) {
   if (!mask || !src || !dst || N < 0 || B <= 0 || record_bytes <= 0 || (record_bytes & 3))

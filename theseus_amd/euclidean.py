@@ -357,7 +357,7 @@ class _CachedFactorSolve(torch.autograd.Function):
             delta = opt.compute_delta(**kwargs)
             solver.check_info()
         else:
-            delta = torch.empty_like(y)
+            delta = torch.empty_like(lin.g)   # (NOT like y: the level schedule's y is its padded vector)
             solver._substitute(y, delta, backward_only=True)
         ctx.solver, ctx.factor_version = solver, solver.factor_version
         return delta
@@ -391,6 +391,7 @@ class _UnrolledSolve(torch.autograd.Function):
         damped, ellipsoidal, _ = solver._factored_with
         ctx.solver, ctx.n = solver, solver.linearization.n
         ctx.factor = solver.factor_snapshot()
+        ctx.dropped = solver.dropped_mask() if hasattr(solver, "dropped_mask") else None   # check_singular: zero step, zero gradient
         ctx.lam = solver._lam.clone() if (damped and ellipsoidal) else None
         ctx.save_for_backward(delta)
         return delta
@@ -398,7 +399,11 @@ class _UnrolledSolve(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_delta):
         (delta,) = ctx.saved_tensors
+        if ctx.dropped is not None:
+            grad_delta = grad_delta.masked_fill(ctx.dropped.unsqueeze(1), 0.0)
         w = ctx.solver.solve_with_snapshot(ctx.factor, grad_delta)
+        if ctx.dropped is not None:
+            w = w.masked_fill(ctx.dropped.unsqueeze(1), 0.0)
         grad_H = -(w.unsqueeze(2) * delta.unsqueeze(1))
         if ctx.lam is not None:
             grad_H = grad_H - torch.diag_embed(ctx.lam.view(-1, 1) * w * delta)

@@ -231,6 +231,13 @@ class HipKernels:
 
     def __init__(self):
         self.lib = _lib.load()
+        # per-call schedule of the factorisations (include/theseus_hip.h: thx_chol_schedule), handed to every thx_chol_factor* call
+        # of THIS kernels object: -1 = the library default.  The library itself keeps no schedule state.
+        self.chol_schedule = _lib.CholSchedule(-1, -1)
+
+    def _sched(self):
+        import ctypes
+        return ctypes.byref(self.chol_schedule)
 
     # ---- SE3 elementwise ----------------------------------------------------------------------
     def se3_exp(self, xi, jac=False):
@@ -437,8 +444,8 @@ class HipKernels:
         _lib.check(self.lib.thx_chol_factor_hblocks(
             hb.c, _lib.ptr(Hc), Hc.stride(0), n, B, _lib.ptr(damping), int(bool(ellipsoidal)), float(damping_eps), _lib.ptr(L), ld,
             _lib.ptr(panels), _lib.ptr(info), _lib.ptr(rhs), _lib.ptr(y), rhs.stride(0) if rhs is not None else n,
-            pattern.c_struct(L.device) if pattern is not None else None, _lib.dtype_code(L.dtype), _lib.stream_ptr(L.device)),
-            "thx_chol_factor_hblocks")
+            pattern.c_struct(L.device) if pattern is not None else None, _lib.dtype_code(L.dtype), _lib.stream_ptr(L.device),
+            self._sched()), "thx_chol_factor_hblocks")
 
     # ---- level-scheduled tile-sparse Cholesky (include/theseus_hip.h: thx_level_schedule; theseus_amd/sparse.py:LevelPattern) ----
     def chol_factor_levels(self, layout, Hc, damping, ellipsoidal, damping_eps, L, panels, info, pattern, rhs=None, y=None):
@@ -448,7 +455,8 @@ class HipKernels:
         _lib.check(self.lib.thx_chol_factor_levels(
             layout.c, _lib.ptr(Hc), Hc.stride(0), L.shape[0], _lib.ptr(damping), int(bool(ellipsoidal)), float(damping_eps),
             _lib.ptr(L), _lib.ptr(panels), _lib.ptr(info), _lib.ptr(rhs), _lib.ptr(y), y.stride(0) if y is not None else 0,
-            pattern.c_struct(dev), pattern.c_levels(dev), _lib.dtype_code(L.dtype), _lib.stream_ptr(dev)), "thx_chol_factor_levels")
+            pattern.c_struct(dev), pattern.c_levels(dev), _lib.dtype_code(L.dtype), _lib.stream_ptr(dev), self._sched()),
+            "thx_chol_factor_levels")
 
     def chol_solve_levels(self, L, panels, rhs, x, pattern, which=0):
         """thx_chol_solve_levels on vectors of the padded order (which: 0 both, 1 backward only, 2 forward only)."""
@@ -459,6 +467,8 @@ class HipKernels:
 
     def vec_gather(self, src, dst, idx):
         """dst[b, k] = src[b, idx[k]] (0 where idx[k] < 0)."""
+        if dst.dim() != 2 or src.dim() != 2 or dst.shape[1] != idx.numel() or dst.shape[0] != src.shape[0] or idx.dtype != torch.int32:
+            raise ValueError(f"vec_gather: dst {tuple(dst.shape)} / src {tuple(src.shape)} / idx {tuple(idx.shape)} {idx.dtype} do not fit")
         _lib.check(self.lib.thx_vec_gather(_lib.ptr(src), src.stride(0), _lib.ptr(dst), dst.stride(0), _lib.ptr(idx), dst.shape[1],
                                            dst.shape[0], _lib.dtype_code(src.dtype), _lib.stream_ptr(src.device)), "thx_vec_gather")
 
@@ -702,11 +712,11 @@ class HipKernels:
         common = (_lib.ptr(H), ld, n, B, _lib.ptr(damping), int(bool(ellipsoidal)), float(damping_eps), _lib.ptr(L),
                   _lib.ptr(panels), _lib.ptr(info))
         if rhs is None:
-            _lib.check(self.lib.thx_chol_factor(*common, _lib.dtype_code(H.dtype), _lib.stream_ptr(H.device)),
+            _lib.check(self.lib.thx_chol_factor(*common, _lib.dtype_code(H.dtype), _lib.stream_ptr(H.device), self._sched()),
                        "thx_chol_factor")
         else:
             _lib.check(self.lib.thx_chol_factor_forward(*common, _lib.ptr(rhs), _lib.ptr(y), rhs.stride(0),
-                                                        _lib.dtype_code(H.dtype), _lib.stream_ptr(H.device)),
+                                                        _lib.dtype_code(H.dtype), _lib.stream_ptr(H.device), self._sched()),
                        "thx_chol_factor_forward")
 
     def chol_factor_sparse(self, H, n, damping, ellipsoidal, damping_eps, L, panels, info, pattern, rhs=None, y=None):
@@ -717,23 +727,22 @@ class HipKernels:
                                                    float(damping_eps), _lib.ptr(L), _lib.ptr(panels), _lib.ptr(info),
                                                    _lib.ptr(rhs), _lib.ptr(y), rhs.stride(0) if rhs is not None else 0,
                                                    pattern.c_struct(H.device), _lib.dtype_code(H.dtype),
-                                                   _lib.stream_ptr(H.device)), "thx_chol_factor_sparse")
+                                                   _lib.stream_ptr(H.device), self._sched()), "thx_chol_factor_sparse")
 
     def chol_split_diag_min_batch(self, min_batch: int) -> int:
-        """Schedule knob of the factorisation (include/theseus_hip.h: thx_chol_set_split_diag_min_batch): batches of at least
-        ``min_batch`` problems run the diagonal phase as SYRK kernel + one-wave-per-tile kernel.  Returns the previous value."""
-        import ctypes
-        prev = ctypes.c_int32(0)
-        _lib.check(self.lib.thx_chol_set_split_diag_min_batch(int(min_batch), ctypes.byref(prev)), "thx_chol_set_split_diag_min_batch")
-        return int(prev.value)
+        """Schedule of THIS kernels object's factorisations (include/theseus_hip.h: thx_chol_schedule.split_diag_min_batch): from
+        ``min_batch`` problems per launch on, the diagonal phase runs as SYRK kernel + one-wave-per-tile kernel (-1: the library
+        default).  Returns the previous value.  Per call in the C ABI: the library keeps no schedule state."""
+        prev = int(self.chol_schedule.split_diag_min_batch)
+        self.chol_schedule.split_diag_min_batch = min(int(min_batch), 2 ** 31 - 1)
+        return prev
 
-    def chol_column_pairs(self, on: bool) -> bool:
-        """Schedule knob of the fp32 dense-frame factorisation (include/theseus_hip.h: thx_chol_set_column_pairs): two block
-        columns per off-diagonal launch, bit-identical factor.  Returns the previous setting."""
-        import ctypes
-        prev = ctypes.c_int32(0)
-        _lib.check(self.lib.thx_chol_set_column_pairs(1 if on else 0, ctypes.byref(prev)), "thx_chol_set_column_pairs")
-        return bool(prev.value)
+    def chol_column_pairs(self, on) -> int:
+        """Schedule of THIS kernels object's fp32 dense-frame factorisations (thx_chol_schedule.column_pairs): two block columns
+        per off-diagonal launch, bit-identical factor (1 on, 0 off, -1 the library default).  Returns the previous setting."""
+        prev = int(self.chol_schedule.column_pairs)
+        self.chol_schedule.column_pairs = int(on)
+        return prev
 
     def chol_solve(self, L, n, panels, rhs, x):
         B, ld = L.shape[0], L.shape[-1]

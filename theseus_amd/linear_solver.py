@@ -136,6 +136,12 @@ class HipCholeskyCore:
         too, and is solved here as it is there."""
         return (self.linearization.diagonal() == 0).any(dim=1)
 
+    def dropped_mask(self) -> Optional[torch.Tensor]:
+        """(B,) bool of the batch items the LAST ``_solve`` dropped under ``check_singular=True`` (zero step, dense_solver.py:91-103),
+        else None.  The differentiated nodes keep it: a dropped item's step does not depend on anything, its gradients are zero
+        (the reference's masked assignment), and its -- possibly broken -- factor must not reach the backward."""
+        return getattr(self, "_last_singular", None) if getattr(self, "_check_singular", False) else None
+
     def post_singular_warning(self):
         """The reference's warning for ``check_singular=True`` (dense_solver.py:97-102) -- one host look at a device flag: called
         where the host synchronises anyway."""
@@ -176,6 +182,7 @@ class HipCholeskyCore:
             # Device-side select, no host sync; the warning is raised where the host looks at the solve anyway (check_info=True)
             # or, for the sync-free loop, by post_singular_warning() after the loop's own synchronisation.
             singular = self.singular_mask()
+            self._last_singular = singular
             delta.masked_fill_(singular.unsqueeze(1), 0.0)
             self.info.masked_fill_(singular, 0)   # a dropped item is not a failed solve
             seen = singular.any()

@@ -58,7 +58,14 @@ class _AuxDeepStamp:
                 groups.setdefault(id(base) if base is not None else id(t), t)
             self.reps = list(groups.values())
         else:
-            same = _PTRS_EQUAL(ts, self.ptrs, self.idx) if (_PTRS_EQUAL is not None and ts) else list(map(_DATA_PTR, ts)) == self.ptrs
+            same = None
+            if _PTRS_EQUAL is not None and ts:
+                try:
+                    same = _PTRS_EQUAL(ts, self.ptrs, self.idx)
+                except TypeError:      # (a private torch symbol: another signature in another release -> the Python pass)
+                    same = None
+            if same is None:
+                same = list(map(_DATA_PTR, ts)) == self.ptrs
             if not same:
                 self.ptrs = list(map(_DATA_PTR, ts))
                 self.ptrs_t = tuple(self.ptrs)
@@ -311,7 +318,8 @@ class PackedPoseGraph:
             return
         self.flush_variables()
         obj = self.objective
-        obj._resolve_batch_size()
+        if not (self._own_variables and obj._batch_size_is_current()):   # (Objective.update just walked the variables)
+            obj._resolve_batch_size()
         B = obj.batch_size
         dev, dt = self.pose_vars[0].device, obj.dtype
         gs, dof = self.gshape, self.dof

@@ -87,7 +87,7 @@ class _CachedFactorSolve(torch.autograd.Function):
     @staticmethod
     def forward(ctx, solver, damping, ellipsoidal, eps, g):
         y = solver.factorize(damping, ellipsoidal, eps, rhs=g.detach().contiguous())
-        delta = torch.empty_like(y)
+        delta = y.new_empty(y.shape[0], solver.linearization.n)   # (NOT like y: the level schedule's y is its padded vector)
         solver._substitute(y, delta, backward_only=True)   # (tile-sparse solver: the list-driven solve)
         solver.check_info()
         ctx.solver, ctx.version = solver, solver.factor_version
@@ -111,7 +111,7 @@ class _UnrolledFactorSolve(torch.autograd.Function):
     @staticmethod
     def forward(ctx, solver, damping, ellipsoidal, eps, H, g):
         y = solver.factorize(damping, ellipsoidal, eps, rhs=g.detach().contiguous())
-        delta = torch.empty_like(y)
+        delta = y.new_empty(y.shape[0], solver.linearization.n)   # (NOT like y: the level schedule's y is its padded vector)
         solver._substitute(y, delta, backward_only=True)
         solver.check_info()
         ctx.solver, ctx.n = solver, solver.linearization.n
@@ -146,6 +146,7 @@ class _FusedUnrolledSolve(torch.autograd.Function):
         # the no-grad path's own solve: the unfused-forward fallback for systems beyond the fused substitution's LDS plan and the
         # check_singular masking included, so that a problem behaves the same with and without gradients
         delta = solver._solve(damping, ellipsoidal, eps, check_info=True)
+        ctx.dropped = solver.dropped_mask()   # check_singular: items whose step was set to zero -- zero gradient, like the reference
         ctx.ell = solver._lam.clone() if (damping is not None and ellipsoidal) else None   # (lambda diag(H) is in the graph)
         ctx.packed, ctx.n = packed, lin.n
         ctx.tensors = detached_tensors(packed.tensors, poses, meas, w_between, prior_target, w_prior, lr_between, lr_prior)
@@ -160,7 +161,11 @@ class _FusedUnrolledSolve(torch.autograd.Function):
         packed, t, K = ctx.packed, ctx.tensors, ctx.packed.K
         P, B = t.poses.shape[:2]
         dt, dev = t.poses.dtype, t.poses.device
+        if ctx.dropped is not None:   # (the dropped items' factor may be broken: neither their grad_delta nor their w goes on)
+            grad_delta = grad_delta.masked_fill(ctx.dropped.unsqueeze(1), 0.0)
         w = ctx.solver.solve_with_snapshot(ctx.factor, grad_delta)
+        if ctx.dropped is not None:
+            w = w.masked_fill(ctx.dropped.unsqueeze(1), 0.0)
         st = packed.structure
         E, Kp = st.num_edges, st.num_priors
         new = lambda *sh: torch.zeros(*sh, dtype=dt, device=dev)  # noqa: E731

@@ -15,6 +15,7 @@ Dense ``n^3/3`` stops scaling beyond ~2-4 k poses (evaluations/pose_graph_synthe
   dense row-major frame (288 GB of HBM hold batch 64 of n = 12288 in fp32); tiles outside the pattern are never touched.
 """
 import os
+import re
 from typing import Any, Dict, List, Optional, Sequence, Tuple, Type, Union
 
 import numpy as np
@@ -70,7 +71,7 @@ def level_ordering(objective, ordering_cls=VariableOrdering, method: str = "auto
     vs = [objective.optim_vars[n] for n in names]
     dofs = {int(v.dof()) for v in vs}
     se3 = bool(vs) and all(type(v).__name__ == "SE3" for v in vs) and dofs == {6}
-    if method == "rcm" or not se3 or TILE // 6 >= len(vs):
+    if method == "rcm" or not se3 or TILE // 6 >= len(vs):   # (one tile: nothing to dissect)
         return fill_reducing_ordering(objective, ordering_cls), None, dict(method="rcm")
     if batch_hint is None:
         batch_hint = getattr(objective, "batch_size", None) or 64
@@ -226,17 +227,44 @@ def _pseudo_peripheral(adj: np.ndarray, nodes: np.ndarray) -> int:
     return root
 
 
+def minimum_degree(adj: np.ndarray, nodes: Optional[Sequence[int]] = None) -> List[int]:
+    """Greedy minimum-degree elimination order of ``nodes`` (default: all) in the graph ``adj`` (dense symmetric bool): the node
+    with the fewest neighbours goes next (ties: lowest index), its neighbours become a clique.  Nodes outside ``nodes`` stay in
+    the graph as neighbours that are never eliminated -- the separators a leaf of the nested dissection hangs on: a chain with
+    one such anchor is numbered from its far end towards it (no fill)."""
+    n = adj.shape[0]
+    nb = [set(np.nonzero(adj[v])[0].tolist()) for v in range(n)]
+    todo = set(range(n) if nodes is None else (int(v) for v in nodes))
+    order: List[int] = []
+    while todo:
+        v = min(todo, key=lambda u: (len(nb[u]), u))
+        todo.discard(v)
+        order.append(v)
+        ring = nb[v]
+        for a in ring:
+            nb[a].discard(v)
+            nb[a] |= ring - {a}
+        nb[v] = set()
+    return order
+
+
 def nested_dissection(adj: np.ndarray, leaf: int = 1) -> List[int]:
     """Nested-dissection elimination order of a graph (dense symmetric bool adjacency, no self loops): recursive bisection by the
     middle level of a BFS level structure rooted at a pseudo-peripheral node (George's automatic nested dissection), the
     separator thinned to the nodes that really touch the far side.  Subgraphs of <= ``leaf`` nodes are numbered in index order
     (the caller's band order).  Children before separators: the order's elimination tree has depth ~log2 on chain-/mesh-like
-    graphs -- that depth is the number of dependent launch pairs of thx_chol_factor_levels."""
+    graphs -- that depth is the number of dependent launch pairs of thx_chol_factor_levels.  Leaves of several nodes are numbered
+    by minimum degree with the separators above them kept in the graph (a leaf chain runs TOWARDS its separator)."""
     order: List[int] = []
+    pending: List[np.ndarray] = []      # leaves, numbered once the whole separator structure is known
 
     def rec(nodes: np.ndarray):
         if nodes.size <= max(leaf, 1):
-            order.extend(sorted(nodes.tolist()))
+            if nodes.size > 1:
+                pending.append(nodes)
+                order.extend([-1 - len(pending)] * nodes.size)    # placeholder, filled in below
+            else:
+                order.extend(sorted(nodes.tolist()))
             return
         comps = _components(adj, nodes)
         if len(comps) > 1:
@@ -264,6 +292,27 @@ def nested_dissection(adj: np.ndarray, leaf: int = 1) -> List[int]:
         order.extend(sorted(sep.tolist()))
 
     rec(np.arange(adj.shape[0], dtype=np.int64))
+    if pending:
+        out: List[int] = []
+        k = 0
+        while k < len(order):
+            if order[k] >= 0:
+                out.append(order[k])
+                k += 1
+                continue
+            leaf_nodes = pending[-2 - order[k]]
+            # the leaf's own nodes by minimum degree inside (leaf + everything numbered AFTER it: its separators)
+            later = set(v for v in order[k + leaf_nodes.size:] if v >= 0)
+            for q in range(k + leaf_nodes.size, len(order)):
+                if order[q] < 0:
+                    later |= set(pending[-2 - order[q]].tolist())
+            keep = np.zeros(adj.shape[0], dtype=bool)
+            keep[list(later)] = True
+            keep[leaf_nodes] = True
+            sub = adj & keep[:, None] & keep[None, :]
+            out.extend(minimum_degree(sub, leaf_nodes.tolist()))
+            k += leaf_nodes.size
+        order = out
     return order
 
 
@@ -285,22 +334,30 @@ def _symbolic_tiles(lp: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
 
 
 def _schedule_cost_us(lp: np.ndarray, level: np.ndarray, batch: int) -> float:
-    """Rough time model of one level-scheduled factorisation (microseconds; only used to rank candidate orderings): per level one
-    diagonal launch (~3 workgroups per CU, a workgroup = SYRK over its K-list + the ~90 us pivot chain of the 128 x 128 tile) and
-    one off-diagonal launch (2 workgroups per CU, ~18 us per K-list tile + ~14 us of substitution)."""
+    """Time model of one level-scheduled linear solve (factorisation with the fused forward substitution + the backward solve), in
+    microseconds -- only used to RANK candidate orderings.  Per level three launches, each the larger of a latency term (the
+    launch is a few workgroups: one workgroup's own duration) and a throughput term (workgroups x cost per workgroup with the
+    chip full).  Constants from kernel traces of tools/bench_sparse.py at 4096 poses (profiles/r6/: batch 8 -- a fused diagonal
+    workgroup alone 36 us + 5.5 us per K-list tile, an off-diagonal one 15 us + 7 us per tile, a backward-solve row 19 us;
+    batch 256 -- 0.0575 us per diagonal tile through SYRK + potrf, 0.033 us per off-diagonal workgroup + 0.022 us per K-list
+    tile, 0.012 us per 64 KB tile the backward solve streams); checked against the measured factorisations of six orderings at
+    batch 8 / 64 / 256 (profiles/r6/d_orderings.txt: the ranking agrees, the times within ~15 %)."""
     nt = lp.shape[0]
-    rowcount = np.array([int(lp[j, :j].sum()) for j in range(nt)])
+    rowcount = lp.sum(axis=1) - 1                     # off-diagonal tiles of block row j = K-list length of diagonal tile j
     total = 0.0
     for lv in range(int(level.max()) + 1):
         cols = np.nonzero(level == lv)[0]
-        t_d = 90.0 + 9.0 * rowcount[cols]
-        total += 8.0 + max(float(t_d.max()), float(t_d.sum()) * batch / 768.0)
-        t_o = []
+        kd = rowcount[cols]
+        total += 3.0 + max(36.0 + 5.5 * float(kd.max()), batch * float((0.0575 + 0.01 * kd).sum()))
+        ko = []
         for j in cols:
-            for i in np.nonzero(lp[j + 1:, j])[0] + j + 1:
-                t_o.append(14.0 + 18.0 * int((lp[i, :j] & lp[j, :j]).sum()))
-        if t_o:
-            total += 8.0 + max(max(t_o), sum(t_o) * batch / 512.0)
+            rows = np.nonzero(lp[j + 1:, j])[0] + j + 1
+            if rows.size:
+                ko.append((lp[rows, :j] & lp[j, :j]).sum(axis=1))
+        if ko:
+            ko = np.concatenate(ko)
+            total += 3.0 + max(15.0 + 7.0 * float(ko.max()), batch * float((0.033 + 0.022 * ko).sum()))
+        total += 3.0 + max(19.0, batch * 0.012 * float(cols.size + kd.sum()))      # backward solve: panels + the rows' tiles
     return total
 
 
@@ -331,16 +388,24 @@ def tile_nested_dissection(num_vars: int, edges: Sequence[Tuple[int, int]], vars
     cands: Dict[str, List[int]] = {}
     if method in ("auto", "band"):
         cands["band"] = list(range(nc))
-    if method in ("auto", "nd"):
-        for leaf in (1, 2, 4):
+    # leaves of 1 cluster: the deepest dissection (log-depth tree, every interior cluster pays the fill of a parallel chain
+    # elimination: ~2.6 x the band's arithmetic on a chain-like graph); leaves of nc / 2, nc / 4, nc / 8 clusters: two, four, eight
+    # long chains running towards a few separators -- two ("twisted factorisation") cost no fill at all, at half the band's depth
+    leaves = sorted({1, 4} | {max(1, -(-nc // d)) for d in (2, 4, 8, 16)})
+    m = re.fullmatch(r"nd(\d+)", method)
+    for leaf in ([int(m.group(1))] if m else leaves):
+        if m or method in ("auto", "nd"):
             cands[f"nd{leaf}"] = nested_dissection(adj, leaf=leaf)
+    if method in ("auto", "md"):
+        cands["md"] = minimum_degree(adj)
     if not cands:
         raise ValueError(f"unknown ordering method {method!r}")
-    best = None
+    best, model = None, {}
     for name, order in cands.items():
         o = np.asarray(order, dtype=np.int64)
         lp, level = _symbolic_tiles(np.tril(adj[np.ix_(o, o)]))
         cost = _schedule_cost_us(lp, level, batch_hint)
+        model[name] = dict(model_us=round(cost, 1), levels=int(level.max()) + 1, l_tiles=int(lp.sum()))
         if best is None or cost < best[0]:
             best = (cost, name, o, level, int(lp.sum()))
     cost, name, o, level, l_tiles = best
@@ -350,8 +415,7 @@ def tile_nested_dissection(num_vars: int, edges: Sequence[Tuple[int, int]], vars
         members[k // vpt].append(int(v))
     order = [v for c in o.tolist() for v in members[c]]
     counts = [len(members[c]) for c in o.tolist()]
-    info = dict(method=name, levels=int(level.max()) + 1, tiles=nc, l_tiles=l_tiles, model_us=cost,
-                candidates={k: None for k in cands})
+    info = dict(method=name, levels=int(level.max()) + 1, tiles=nc, l_tiles=l_tiles, model_us=cost, candidates=model)
     return order, counts, info
 
 

@@ -35,10 +35,14 @@ def run(solver_cls):
     with torch.no_grad():
         layer.forward(start, optimizer_kwargs=dict(damping=1e-2, track_err_history=True))   # (same kwargs as the timed call)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        sol, info = layer.forward(start, optimizer_kwargs=dict(damping=1e-2, track_err_history=True))
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        dts = []
+        for _ in range(3):      # (the best of three timed calls: a fresh box's first calls carry one-time costs)
+            t0 = time.perf_counter()
+            sol, info = layer.forward(start, optimizer_kwargs=dict(damping=1e-2, track_err_history=True))
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
+        dt = min(dts)
+        print("timed calls (ms):", [round(1e3 * x, 1) for x in dts])
     return dt, info, opt, torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
 
 
