@@ -50,7 +50,8 @@ class KernelTimer:
 
     NAMES = ["pg_assemble", "pg_assemble_blocks", "chol_factor", "chol_factor_sparse", "chol_factor_hblocks", "chol_factor_levels",
              "chol_solve_backward", "chol_solve", "chol_solve_sparse", "chol_solve_levels",
-             "se3_retract", "pg_error", "lm_accept", "ba_assemble", "ba_schur", "ba_backsub", "ba_error", "ba_retract"]
+             "se3_retract", "pg_error", "lm_accept", "ba_assemble", "ba_schur", "ba_schur_blocks", "ba_backsub", "ba_error", "ba_retract",
+             "vec_gather"]
 
     def __init__(self, K):
         self.K, self.events, self.enabled = K, {}, False
@@ -947,8 +948,11 @@ def ba_run(cfg, ctx):
     phases = timer.summary()
     pat = getattr(solver, "pattern", None) if getattr(solver, "sparse", False) else None
     nc = 6 * meta["num_cams"]
-    fname = "chol_factor_sparse" if pat is not None else "chol_factor"
+    levels = bool(getattr(solver, "levels", False))
+    fname = "chol_factor_levels" if levels else ("chol_factor_sparse" if pat is not None else "chol_factor")
     fac = phases.get(fname, {"avg_ms": float("nan")})
+    ordering_info = dict(getattr(solver, "ordering_info", {}) or {})
+    ordering_info.pop("candidates", None)
     peak = PEAK[cfg.dtype]
     dense_flops = B * nc ** 3 / 3.0
     executed = B * pat.flops if pat is not None else dense_flops
@@ -971,8 +975,10 @@ def ba_run(cfg, ctx):
                    "n": meta["n"], "n_reduced": nc},
         "mean_error": [float(info.err_history[:, 0].mean()), float(info.err_history[:, info.iters_done].mean())],
         "roofline": {
-            "bound": "mfma", "kernel": f"thx_{fname} on the reduced camera system (chol_diag + chol_offdiag launches per block "
-                                       f"column, non-zero tiles only)",
+            "bound": "mfma", "kernel": f"thx_{fname} on the reduced camera system (chol_diag + chol_offdiag launches per "
+                                       + ("elimination-tree level of the cameras' tile-level nested dissection, S read from the "
+                                          "block list thx_ba_schur_blocks wrote" if levels else "block column") +
+                                       ", non-zero tiles only)",
             # EXECUTED flops (the band of the reduced system: structurally zero tiles are skipped) / HIP-event time
             "achieved": executed / (fac["avg_ms"] * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
             "frac": executed / (fac["avg_ms"] * 1e-3) / 1e12 / peak, "traffic": ba_traffic.get("bytes_per_factor_call"),
@@ -988,6 +994,9 @@ def ba_run(cfg, ctx):
                           "device_gap_frac": round(1.0 - kernel_ms / (dt / max(solves, 1) * 1e3), 4),
                           "frac": executed / (peak * 1e12) * 1e3 / (dt / max(solves, 1) * 1e3)}},
         "phases_ms_per_call": {k: round(v["avg_ms"], 4) for k, v in phases.items()},
+        "reduced_system": {"level_scheduled": levels, "ordering": ordering_info,
+                           "levels": int(pat.nlevels) if levels else None, "tiles": int(pat.ntiles) if pat is not None else None,
+                           "S": "block list (36 contiguous values per camera-pair block)" if levels else "dense frame"},
     }
     del sol, info, layer, opt, obj, timer, solver, packed
     free_device_memory()

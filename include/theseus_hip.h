@@ -570,6 +570,19 @@ int thx_ba_assemble(const thx_ba_structure* s, const thx_ba_data* d, void* Hcc, 
 int thx_ba_schur(const thx_ba_structure* s, int32_t B, const void* Hcc, const void* Hpp, const void* W, const void* gd,
                  int64_t ldv, const void* damping, int ellipsoidal, double damping_eps, void* S, int64_t ld, void* rhs,
                  int64_t ldr, void* Hinv, void* tvec, int32_t* info, int dtype, void* stream);
+/* thx_ba_schur with S written as a BLOCK LIST -- the values of a thx_hblock_layout with bd = 6, (B, bstride), 36 contiguous
+ * elements per block and problem (bstride a multiple of 4, >= 36 (C + num_blocks)) -- instead of a dense frame: what
+ * thx_chol_factor_levels reads, so that the reduced camera system is factorised along ITS elimination tree (the analogue of
+ * BaSpaCho's fill-reducing permutation of the camera block, theseus/extlib/baspacho_solver.cpp:284-291,332; the reference's
+ * Schur complement: theseus/optimizer/linear/baspacho_sparse_solver.py:58-148 eliminates the points the same way).  Block
+ * diag_blk[c] receives S_cc (damped), block (blk_dst[k] & 0x3fffffff) the block of the structure's k-th camera pair
+ * (blk_c1[k], blk_c2[k]) -- TRANSPOSED where bit 30 of blk_dst[k] is set: the list holds tril(S) in the SOLVER's camera order,
+ * which may put c2 behind c1.  A lane writes its block as 144 (fp32) / 288 (fp64) contiguous bytes; rhs, Hinv, tvec, info as
+ * thx_ba_schur (rhs in the structure's camera order: the solver gathers it into its padded order with thx_vec_gather). */
+int thx_ba_schur_blocks(const thx_ba_structure* s, int32_t B, const void* Hcc, const void* Hpp, const void* W, const void* gd,
+                        int64_t ldv, const void* damping, int ellipsoidal, double damping_eps, void* Sc, int64_t bstride,
+                        const int32_t* diag_blk, const int32_t* blk_dst, void* rhs, int64_t ldr, void* Hinv, void* tvec,
+                        int32_t* info, int dtype, void* stream);
 /* delta_p = tvec - Hinv Hpc delta_c, written to delta[:, 6C:] (delta_c = delta[:, :6C] is read) */
 int thx_ba_backsub(const thx_ba_structure* s, int32_t B, const void* W, const void* Hinv, const void* tvec, void* delta,
                    int64_t ldv, int dtype, void* stream);

@@ -113,10 +113,10 @@ def test_ba_non_positive_definite_sets_fail_status():
 
 
 # ---- multi-tile / full-size fixtures (oracle/gen_golden.py: ba_mid_*, ba_full_f64_lm) --------------------------------------
-def _ba_first_system(th, g, f32=False):
+def _ba_first_system(th, g, f32=False, solver_kwargs=None):
     import ast
     obj, _, _ = build_ba_objective(th, g, "cuda")
-    opt = th.LevenbergMarquardt(obj, max_iterations=1)
+    opt = th.LevenbergMarquardt(obj, max_iterations=1, linear_solver_kwargs=solver_kwargs)
     solver, lin = opt.linear_solver, opt.linear_solver.linearization
     obj.update()
     lin.linearize()
@@ -138,7 +138,7 @@ def test_ba_multi_tile_matches_reference():
     import theseus_amd as th
     g = load_golden("ba_mid_f64_lm")
     err, solver = _ba_first_system(th, g)
-    assert solver.S.shape[-1] >= 192 and err <= 1e-8, err
+    assert solver.linearization.packed.nc == 192 and err <= 1e-8, err
     cams, pts, used, deltas, info, _ = run_ba(th, g, None, "cuda")
     dc = np.abs(cams.cpu().numpy() - g["final_cams"]).max()
     dp = np.abs(pts.cpu().numpy() - g["final_pts"][:, used]).max()
@@ -184,7 +184,7 @@ def test_ba_full_size_matches_the_reference_run():
     g = load_golden("ba_full_f64_lm")
     assert int(g["C"]) == 512 and g["obs_cam"].shape[0] == 32768
     err, solver = _ba_first_system(th, g)
-    assert solver.S.shape[-1] == 3072 and err <= 1e-7, err
+    assert solver.linearization.packed.nc == 3072 and solver.levels and solver.pattern.nlevels < solver.pattern.ntiles and err <= 1e-7, err
     cams, pts, used, deltas, info, _ = run_ba(th, g, None, "cuda")
     dc = np.abs(cams.cpu().numpy() - g["final_cams"]).max()
     dp = np.abs(pts.cpu().numpy() - g["final_pts"][:, used]).max()
@@ -287,3 +287,78 @@ def test_ba_av_and_dogleg_on_the_gpu(name):
     if f64:
         np.testing.assert_array_equal(a[3].numpy(), b[3].numpy())
     assert (a[2][:, -1] < a[2][:, 0]).all()
+
+
+# ---- round 6: the reduced camera system as a block list, factorised along its elimination tree ------------------------------
+@pytest.mark.parametrize("name", ["ba_mid_f64_lm", "ba_mid_f32_lm"])
+def test_schur_block_list_equals_the_dense_frame(name):
+    """thx_ba_schur_blocks writes the SAME numbers as thx_ba_schur (same kernels, same arithmetic, another store): block c =
+    S_cc, block C + k = the k-th camera pair's block -- transposed where the solver's order puts c2 behind c1 -- and the same
+    rhs / Hinv / tvec; through the C ABI."""
+    import theseus_amd as th
+    g = load_golden(name)
+    got = {}
+    for ordering in ("natural", "nd"):
+        obj, _, _ = build_ba_objective(th, g, "cuda")
+        opt = th.LevenbergMarquardt(obj, max_iterations=1, linear_solver_kwargs=dict(ordering=ordering))
+        solver, lin = opt.linear_solver, opt.linear_solver.linearization
+        obj.update()
+        lin.linearize()
+        lam = torch.full((lin.g.shape[0],), 0.02, dtype=lin.g.dtype, device="cuda")
+        delta = solver.solve(damping=lam, ellipsoidal_damping=True, damping_eps=1e-8).clone()
+        got[ordering] = (solver, delta)
+    dense, lev = got["natural"][0], got["nd"][0]
+    assert not dense.levels and lev.levels and lev.Sc is not None and dense.S is not None and lev.S is None
+    s = lev.linearization.packed.structure
+    C, K = s.num_cams, s.num_blocks
+    Sc = lev.Sc[:, :36 * (C + K)].view(-1, C + K, 6, 6)
+    S = dense.S
+    dst = lev._level_t["blk_dst"].cpu().numpy()
+    c1, c2 = s.t["blk_c1"][:K].astype(np.int64), s.t["blk_c2"][:K].astype(np.int64)
+    for c in range(C):
+        assert torch.equal(Sc[:, c], S[:, 6 * c:6 * c + 6, 6 * c:6 * c + 6])
+    flipped = 0
+    for k in range(K):
+        blk = S[:, 6 * c1[k]:6 * c1[k] + 6, 6 * c2[k]:6 * c2[k] + 6]
+        tr = bool((dst[k] >> 30) & 1)
+        flipped += tr
+        assert (dst[k] & 0x3fffffff) == C + k
+        assert torch.equal(Sc[:, C + k], blk.transpose(1, 2) if tr else blk)
+    assert flipped > 0                                                   # (the dissection really reorders cameras)
+    assert torch.equal(lev.rhs, dense.rhs) and torch.equal(lev.Hinv, dense.Hinv) and torch.equal(lev.tvec, dense.tvec)
+    # the two factorisations (other order, other summation order) solve the same system
+    d0, d1 = got["natural"][1], got["nd"][1]
+    tol = 1e-9 if lev.Sc.dtype == torch.float64 else 2e-3
+    assert ((d0 - d1).abs().max() / d0.abs().max()).item() < tol
+    # the cached factor solves another right-hand side the same in both modes (the implicit backward's solve)
+    r = torch.randn(lin.g.shape[0], lin.n, dtype=lin.g.dtype, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    w0, w1 = dense.solve_with_factor(r), lev.solve_with_factor(r)
+    assert ((w0 - w1).abs().max() / w0.abs().max()).item() < tol
+
+
+@pytest.mark.parametrize("ordering", ["natural", "nd", "md"])
+def test_ba_full_size_first_solve_under_every_camera_order(ordering):
+    """The reference's first linear solve at 512 / 8192 / 32768 (tests/golden/ba_full_f64_lm) under the cameras' own order
+    (dense frame, column by column), a tile-level nested dissection and minimum degree (block list, level schedule)."""
+    import theseus_amd as th
+    g = load_golden("ba_full_f64_lm")
+    err, solver = _ba_first_system(th, g, solver_kwargs=dict(ordering=ordering))
+    assert solver.levels == (ordering != "natural") and err <= 1e-7, err
+    if solver.levels:
+        assert solver.pattern.ntiles == 25 and int(solver.info.abs().sum()) == 0
+
+
+def test_ba_level_mode_not_positive_definite_is_reported():
+    import warnings
+    import theseus_amd as th
+    g = dict(load_golden("ba_mid_f64_lm"))
+    g["w_cam_prior"] = g["w_cam_prior"] * 0.0
+    g["w_pt_prior"] = g["w_pt_prior"] * 0.0
+    g["feat"] = g["feat"] * 0.0   # the gauge freedom makes the undamped system singular
+    obj, _, _ = build_ba_objective(th, g, "cuda")
+    opt = th.GaussNewton(obj, max_iterations=2, linear_solver_kwargs=dict(ordering="nd"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        info = opt.optimize()
+    assert opt.linear_solver.levels
+    assert all(s in (th.NonlinearOptimizerStatus.FAIL, th.NonlinearOptimizerStatus.MAX_ITERATIONS) for s in info.status)

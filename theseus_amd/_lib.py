@@ -20,7 +20,7 @@ THX_ERR_CHUNKS = 128
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
 LOSS_FLATTEN = 4  # THX_LOSS_FLATTEN: RobustCostFunction(flatten_dims=True), or-ed into a loss code
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 class LieEps(Structure):
@@ -142,6 +142,8 @@ _SIGNATURES = {
                         c_int, POINTER(LieEps), c_void_p],
     "thx_ba_schur": [POINTER(BAStructure), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_double,
                      c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "thx_ba_schur_blocks": [POINTER(BAStructure), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_double,
+                            c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "thx_ba_backsub": [POINTER(BAStructure), c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     "thx_ba_error": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_void_p, c_int, POINTER(LieEps), c_void_p],
     "thx_ba_av": [POINTER(BAStructure), POINTER(BAData), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -689,16 +689,41 @@ class HipSchurLinearization(HipSchurLinearizationCore, Linearization):
         return self._atb_impl()
 
 
+class _SchurBlockList:
+    """The reduced camera system as a block list (include/theseus_hip.h: thx_hblock_layout values, bd = 6): what
+    theseus_amd.sparse._LevelLayout needs of a compiler.HessianBlocks -- ``blocks`` (row, col) in the solver's camera order."""
+
+    def __init__(self, blocks: np.ndarray, num_cams: int):
+        self.blocks = np.ascontiguousarray(blocks, dtype=np.int64)
+        self.nblocks, self.bd, self.nvars = int(blocks.shape[0]), 6, int(num_cams)
+        self.elems = self.nblocks * 36
+        self.bstride = (self.elems + 3) // 4 * 4
+        self._dev: Dict[str, Any] = {}
+
+    def on(self, device):
+        key = str(device)
+        if key not in self._dev:
+            z = torch.zeros(1, dtype=torch.int32, device=device)   # (diag_blk / inc_blk: read by the pose-graph assembly only)
+            self._dev[key] = type("DeviceBlockList", (), dict(t=dict(diag_blk=z, inc_blk=z)))()
+        return self._dev[key]
+
+
 class HipSchurSolverCore:
     """(H + damping) delta = g of a bundle-adjustment linearization by block elimination of the points + the tiled dense
     Cholesky on the reduced camera system.  Same ``solve`` contract and failure behaviour as ``HipCholeskySolver``."""
 
-    def _schur_solver_init(self, sparse_reduced_system: bool = True):
+    def _schur_solver_init(self, sparse_reduced_system: bool = True, ordering: str = "auto"):
         self.K = self.linearization.K
         self.S = self.L = self.panels = self.info_chol = self.info_pts = None
         self.pattern, self.sparse, self._want_sparse = None, False, bool(sparse_reduced_system)
         self.factor_version = 0
         self._odo_only = None
+        # LEVEL MODE (round 6): S as a block list (thx_ba_schur_blocks) in a tile-level nested-dissection order of the cameras,
+        # factorised along its elimination tree (thx_chol_factor_levels).  ordering: "auto" (the time model of
+        # theseus_amd.sparse ranks the candidate orders at this batch size; the band order keeps the column-by-column schedule
+        # on the dense frame) | "nd" / "nd<leaf>" / "md" (level mode with that order) | "natural" (rounds 3-5: dense frame).
+        self.levels, self._ordering, self.ordering_info = False, str(ordering), dict(method="natural")
+        self.Sc = self._level = None
 
     @staticmethod
     def _blocks_only_odometry(p):
@@ -715,10 +740,69 @@ class HipSchurSolverCore:
         n = len(only)
         return (c1 + k.view(1, 6, 1)).expand(n, 6, 6), (c2 + k.view(1, 1, 6)).expand(n, 6, 6)
 
+    def _level_setup(self, B: int) -> bool:
+        """Decide the mode once (first solve): True = level mode, with the pattern / block tables built."""
+        p = self.linearization.packed
+        self._level = False
+        if self._ordering == "natural" or not self._want_sparse or p.cc_costs or not hasattr(self.K, "ba_schur_blocks"):
+            return False   # (camera-camera costs scatter-add into the dense frame: that path stays as it was)
+        from .sparse import TILE, LevelPattern, tile_nested_dissection
+        s = p.structure
+        C, t = s.num_cams, s.t
+        if C <= TILE // 6:
+            return False   # (one tile: nothing to dissect)
+        c1, c2 = t["blk_c1"].astype(np.int64)[:s.num_blocks], t["blk_c2"].astype(np.int64)[:s.num_blocks]
+        order, counts, info = tile_nested_dissection(C, list(zip(c1.tolist(), c2.tolist())), TILE // 6, batch_hint=int(B),
+                                                     method=self._ordering)
+        self.ordering_info = info
+        if info["method"] == "band" and self._ordering == "auto":
+            return False   # (no order beats the cameras' own at this batch size: the column-by-column schedule with its look-ahead)
+        order = np.asarray(order, dtype=np.int64)
+        pos = np.empty(C, dtype=np.int64)
+        pos[order] = np.arange(C)
+        # the block list in the SOLVER's order: block c = S_cc at (pos c, pos c); block C + k = the k-th camera pair, transposed
+        # where the order puts c2 behind c1
+        p1, p2 = pos[c1], pos[c2]
+        blocks = np.concatenate([np.stack([pos, pos], 1), np.stack([np.maximum(p1, p2), np.minimum(p1, p2)], 1)], 0)
+        self._blocklist = _SchurBlockList(blocks, C)
+        self.pattern = LevelPattern(blocks, 6, counts)
+        dst = (C + np.arange(c1.size, dtype=np.int64)) | ((p1 < p2).astype(np.int64) << 30)
+        # vectors: the structure's camera columns <-> the padded order (LevelPattern's maps are in the solver's order)
+        col = (6 * pos[:, None] + np.arange(6)[None, :]).reshape(-1)                      # solver column of structure column
+        pad_of_col = self.pattern.pad_of_col[col]
+        col_of_pad = np.full(self.pattern.npad, -1, dtype=np.int32)
+        col_of_pad[pad_of_col] = np.arange(6 * C, dtype=np.int32)
+        dev = self.linearization.g.device
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)  # noqa: E731
+        self._level_t = dict(diag_blk=i32(np.arange(C)), blk_dst=i32(dst if dst.size else [0]), pad_of_col=i32(pad_of_col),
+                             col_of_pad=i32(col_of_pad))
+        from .sparse import _LevelLayout
+        self._level_layout = _LevelLayout(self.pattern, self._blocklist, dev)
+        self._level = True
+        return True
+
     def _ensure_buffers(self):
         lin = self.linearization
         B, nc = lin.g.shape[0], lin.packed.nc
         dev, dt = lin.g.device, lin.g.dtype
+        if self._level is None:
+            self.levels = self._level_setup(B)
+        if self.levels:
+            if self.Sc is None or self.Sc.shape[0] != B or self.Sc.device != dev or self.Sc.dtype != dt:
+                s, pat, T = lin.packed.structure, self.pattern, _lib.THX_TILE
+                self.Sc = torch.zeros(B, self._blocklist.bstride, dtype=dt, device=dev)
+                self.L = torch.zeros(B, pat.nslots, T, T, dtype=dt, device=dev)       # tile-packed factor
+                self.panels = torch.empty(B, pat.ntiles, T, T, dtype=dt, device=dev)
+                self.rhs, self._dc = (torch.empty(B, nc, dtype=dt, device=dev) for _ in range(2))
+                self._xp, self._yp = (torch.zeros(B, pat.npad, dtype=dt, device=dev) for _ in range(2))   # (padding stays zero)
+                self.Hinv = torch.empty(s.num_points, 6, B, dtype=torch.float64, device=dev)
+                self.tvec = torch.empty(s.num_points, 3, B, dtype=torch.float64, device=dev)
+                self.delta = torch.empty(B, lin.n, dtype=dt, device=dev)
+                self.info_chol = torch.zeros(B, dtype=torch.int32, device=dev)
+                self.info_pts = torch.zeros(B, dtype=torch.int32, device=dev)
+                self._lam = torch.empty(B, dtype=dt, device=dev)
+                self.sparse = True
+            return
         if self.S is None or self.S.shape[0] != B or self.S.device != dev or self.S.dtype != dt:
             ld = round_up(nc, 32)
             nt = (nc + _lib.THX_TILE - 1) // _lib.THX_TILE
@@ -779,6 +863,20 @@ class HipSchurSolverCore:
         p = lin.packed
         self.factor_version += 1
         self._factor_args = (lam.clone() if lam is not None else None, ellipsoidal_damping, damping_eps)
+        if self.levels:
+            K, t = self.K, self._level_t
+            K.ba_schur_blocks(p.dstruct, lin.Hcc, lin.Hpp, lin.W, lin.gd, lam, ellipsoidal_damping, damping_eps, self.Sc,
+                              t["diag_blk"], t["blk_dst"], self.rhs, self.Hinv, self.tvec, self.info_pts)
+            K.vec_gather(self.rhs, self._xp, t["col_of_pad"])
+            K.chol_factor_levels(self._level_layout, self.Sc, None, False, damping_eps, self.L, self.panels, self.info_chol,
+                                 self.pattern, rhs=self._xp, y=self._yp)
+            K.chol_solve_levels(self.L, self.panels, self._yp, self._xp, self.pattern, which=1)
+            K.vec_gather(self._xp, self._dc, t["pad_of_col"])
+            self.delta[:, :p.nc].copy_(self._dc)
+            K.ba_backsub(p.dstruct, lin.W, self.Hinv, self.tvec, self.delta)
+            if check_info:
+                self.check_info()
+            return self.delta
         self.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, lin.gd, lam, ellipsoidal_damping, damping_eps, self.S, self.rhs,
                         self.Hinv, self.tvec, self.info_pts)
         if p.cc_costs:
@@ -820,6 +918,18 @@ class HipSchurSolverCore:
         rc = torch.empty_like(self.rhs)
         tv = torch.empty_like(self.tvec)
         scratch_info = torch.zeros_like(self.info_pts)
+        if self.levels:
+            K, t = self.K, self._level_t
+            K.ba_schur_blocks(p.dstruct, lin.Hcc, lin.Hpp, lin.W, gd, lam, ell, eps, self.Sc, t["diag_blk"], t["blk_dst"], rc,
+                              self.Hinv, tv, scratch_info)
+            K.vec_gather(rc, self._xp, t["col_of_pad"])
+            K.chol_solve_levels(self.L, self.panels, self._xp, self._xp, self.pattern, which=0)
+            dc = torch.empty_like(rc)
+            K.vec_gather(self._xp, dc, t["pad_of_col"])
+            out = torch.empty(rhs.shape[0], lin.n, dtype=self.Sc.dtype, device=rhs.device)
+            out[:, :p.nc].copy_(dc)
+            K.ba_backsub(p.dstruct, lin.W, self.Hinv, tv, out)
+            return out
         self.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, gd, lam, ell, eps, self.S, rc, self.Hinv, tv, scratch_info)
         dc = torch.empty_like(rc)
         if self.sparse:
@@ -1066,14 +1176,16 @@ def ba_implicit_step(opt, packed, step: float, kwargs):
 
 class HipSchurSolver(HipSchurSolverCore, LinearSolver):
     def __init__(self, objective: Objective, linearization_cls: Optional[Type[Linearization]] = None,
-                 linearization_kwargs: Optional[Dict[str, Any]] = None, sparse_reduced_system: bool = True, **kwargs):
+                 linearization_kwargs: Optional[Dict[str, Any]] = None, sparse_reduced_system: bool = True,
+                 ordering: str = "auto", **kwargs):
         """``sparse_reduced_system=False``: factorise the reduced camera system as a dense matrix even where its tile pattern
-        has holes (for comparisons; the result is the same bit for bit)."""
+        has holes (for comparisons; the result is the same bit for bit).  ``ordering``: "auto" | "nd" | "md" | "natural" -- the
+        camera order of the reduced system's factorisation (HipSchurSolverCore._schur_solver_init)."""
         linearization_cls = linearization_cls or HipSchurLinearization
         if not (isinstance(linearization_cls, type) and issubclass(linearization_cls, HipSchurLinearization)):
             raise RuntimeError(f"HipSchurSolver only works with HipSchurLinearization, but {linearization_cls} was provided.")
         LinearSolver.__init__(self, objective, linearization_cls, linearization_kwargs)
-        self._schur_solver_init(sparse_reduced_system)
+        self._schur_solver_init(sparse_reduced_system, ordering)
 
     def solve(self, damping: Optional[Union[float, torch.Tensor]] = None, ellipsoidal_damping: bool = True,
               damping_eps: float = 1e-8, check_info: bool = True, **kwargs) -> torch.Tensor:

@@ -283,6 +283,41 @@ __device__ __forceinline__ void store_row6(T* __restrict__ p, const double* v, b
   }
 }
 
+// a 6 x 6 block as 36 contiguous values of a block list (thx_ba_schur_blocks): 144 (fp32) / 288 (fp64) contiguous bytes per lane in
+// 16-byte stores -- every store instruction writes whole 16-byte segments, against six 24-byte row segments in a dense frame (which
+// the memory system saw as 2.85 GB of writes for 1.4 GB of blocks).  ``transposed``: the list holds the block of the pair the other
+// way round (the solver's elimination order).
+template <typename T>
+__device__ __forceinline__ void store_block36(T* __restrict__ p, const double* v, bool transposed) {
+  constexpr int VEC = 16 / sizeof(T);
+  typedef T TV __attribute__((ext_vector_type(VEC)));
+  TV* dst = reinterpret_cast<TV*>(p);
+  if (transposed) {
+#pragma unroll
+    for (int k = 0; k < 36 / VEC; ++k) {
+      TV w;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) w[e] = (T)v[6 * ((VEC * k + e) % 6) + (VEC * k + e) / 6];
+      dst[k] = w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 36 / VEC; ++k) {
+      TV w;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) w[e] = (T)v[VEC * k + e];
+      dst[k] = w;
+    }
+  }
+}
+
+// where thx_ba_schur_blocks puts the blocks of S (blk_dst == nullptr: the dense frame of thx_ba_schur)
+struct SchurBlockDst {
+  const int32_t* diag_blk;   // (C): block id of S_cc
+  const int32_t* blk_dst;    // (num_blocks): block id of the k-th camera pair | bit 30: stored transposed
+  int64_t bstride;           // elements per problem
+};
+
 // M (6x3) = W (6x3) * Hinv (sym 3x3)
 __device__ __forceinline__ void w_times_sym(const double* W, const double* h, double* M) {
 #pragma unroll
@@ -300,7 +335,7 @@ __device__ __forceinline__ void w_times_sym(const double* W, const double* h, do
 template <typename T>
 __global__ void __launch_bounds__(64)
 ba_schur_block_kernel(thx_ba_structure s, int B, const double* __restrict__ W, const double* __restrict__ Hinv,
-                      T* __restrict__ S, int64_t ld) {
+                      T* __restrict__ S, int64_t ld, SchurBlockDst bl) {
   const int b = blockIdx.y * 64 + threadIdx.x, k = blockIdx.x;  // blocks along x: their number can exceed 65535
   if (b >= B) return;
   const int c1 = s.blk_c1[k], c2 = s.blk_c2[k];
@@ -322,6 +357,11 @@ ba_schur_block_kernel(thx_ba_structure s, int B, const double* __restrict__ W, c
       for (int c = 0; c < 6; ++c)
         Off[6 * r + c] -= M[3 * r] * W2[3 * c] + M[3 * r + 1] * W2[3 * c + 1] + M[3 * r + 2] * W2[3 * c + 2];
   }
+  if (bl.blk_dst) {   // (block uniform)
+    const int d = bl.blk_dst[k];
+    store_block36(S + (int64_t)b * bl.bstride + (int64_t)(d & 0x3fffffff) * 36, Off, ((d >> 30) & 1) != 0);
+    return;
+  }
   T* Sb = S + (int64_t)b * ld * ld;
   const bool pairs = (ld & 1) == 0;
 #pragma unroll
@@ -334,7 +374,7 @@ __global__ void __launch_bounds__(64)
 ba_schur_kernel(thx_ba_structure s, int B, const double* __restrict__ Hcc, const double* __restrict__ W,
                 const double* __restrict__ g, int64_t ldv, const T* __restrict__ damping, int ellipsoidal, T eps,
                 const double* __restrict__ Hinv, const double* __restrict__ tvec, T* __restrict__ S, int64_t ld,
-                T* __restrict__ rhs, int64_t ldr) {
+                T* __restrict__ rhs, int64_t ldr, SchurBlockDst bl) {
   const int b = blockIdx.x * 64 + threadIdx.x, c1 = blockIdx.y;
   if (b >= B) return;
   double Dg[36], rv[6];
@@ -378,9 +418,13 @@ ba_schur_kernel(thx_ba_structure s, int B, const double* __restrict__ Hcc, const
       for (int c = 0; c < 6; ++c)
         Dg[6 * r + c] -= M[3 * r] * W2[3 * c] + M[3 * r + 1] * W2[3 * c + 1] + M[3 * r + 2] * W2[3 * c + 2];
   }
-  const bool pairs = (ld & 1) == 0;
+  if (bl.blk_dst) {
+    store_block36(S + (int64_t)b * bl.bstride + (int64_t)bl.diag_blk[c1] * 36, Dg, false);
+  } else {
+    const bool pairs = (ld & 1) == 0;
 #pragma unroll
-  for (int r = 0; r < 6; ++r) store_row6(Sb + (int64_t)(6 * c1 + r) * ld + 6 * c1, Dg + 6 * r, pairs);
+    for (int r = 0; r < 6; ++r) store_row6(Sb + (int64_t)(6 * c1 + r) * ld + 6 * c1, Dg + 6 * r, pairs);
+  }
 #pragma unroll
   for (int i = 0; i < 6; ++i) rhs[(int64_t)b * ldr + 6 * c1 + i] = (T)rv[i];
 }
@@ -657,11 +701,10 @@ int thx_ba_assemble(const thx_ba_structure* s, const thx_ba_data* d, void* Hcc, 
   return check_launch("thx_ba_assemble");
 }
 
-int thx_ba_schur(const thx_ba_structure* s, int32_t B, const void* Hcc, const void* Hpp, const void* W, const void* gd,
-                 int64_t ldv, const void* damping, int ellipsoidal, double damping_eps, void* S, int64_t ld, void* rhs,
-                 int64_t ldr, void* Hinv, void* tvec, int32_t* info, int dtype, void* stream) {
-  if (!s || !Hcc || !Hpp || !gd || !S || !rhs || !Hinv || !tvec || !info || B <= 0) return fail("thx_ba_schur: null argument");
-  if (ld < 6 * (int64_t)s->num_cams || ldr < 6 * (int64_t)s->num_cams) return fail("thx_ba_schur: ld < 6 C");
+static int ba_schur_impl(const thx_ba_structure* s, int32_t B, const void* Hcc, const void* Hpp, const void* W, const void* gd,
+                         int64_t ldv, const void* damping, int ellipsoidal, double damping_eps, void* S, int64_t ld, void* rhs,
+                         int64_t ldr, void* Hinv, void* tvec, int32_t* info, int dtype, void* stream, SchurBlockDst bl,
+                         const char* what) {
   const dim3 block(64), gp((B + 63) / 64, s->num_points), gc((B + 63) / 64, s->num_cams);
   hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)B, as_stream(stream));
   THX_DISPATCH(dtype,
@@ -671,10 +714,10 @@ int thx_ba_schur(const thx_ba_structure* s, int32_t B, const void* Hcc, const vo
                                     (double*)Hinv, (double*)tvec, info);
                  if (s->num_blocks > 0)
                    hipLaunchKernelGGL(ba_schur_block_kernel<float>, dim3(s->num_blocks, (B + 63) / 64), block, 0,
-                                      as_stream(stream), *s, B, (const double*)W, (const double*)Hinv, (float*)S, ld);
+                                      as_stream(stream), *s, B, (const double*)W, (const double*)Hinv, (float*)S, ld, bl);
                  hipLaunchKernelGGL(ba_schur_kernel<float>, gc, block, 0, as_stream(stream), *s, B, (const double*)Hcc,
                                     (const double*)W, (const double*)gd, ldv, (const float*)damping, ellipsoidal,
-                                    (float)damping_eps, (const double*)Hinv, (const double*)tvec, (float*)S, ld, (float*)rhs, ldr);
+                                    (float)damping_eps, (const double*)Hinv, (const double*)tvec, (float*)S, ld, (float*)rhs, ldr, bl);
                },
                {
                  hipLaunchKernelGGL(ba_point_invert_kernel<double>, gp, block, 0, as_stream(stream), *s, B,
@@ -682,12 +725,35 @@ int thx_ba_schur(const thx_ba_structure* s, int32_t B, const void* Hcc, const vo
                                     damping_eps, (double*)Hinv, (double*)tvec, info);
                  if (s->num_blocks > 0)
                    hipLaunchKernelGGL(ba_schur_block_kernel<double>, dim3(s->num_blocks, (B + 63) / 64), block, 0,
-                                      as_stream(stream), *s, B, (const double*)W, (const double*)Hinv, (double*)S, ld);
+                                      as_stream(stream), *s, B, (const double*)W, (const double*)Hinv, (double*)S, ld, bl);
                  hipLaunchKernelGGL(ba_schur_kernel<double>, gc, block, 0, as_stream(stream), *s, B, (const double*)Hcc,
                                     (const double*)W, (const double*)gd, ldv, (const double*)damping, ellipsoidal, damping_eps,
-                                    (const double*)Hinv, (const double*)tvec, (double*)S, ld, (double*)rhs, ldr);
+                                    (const double*)Hinv, (const double*)tvec, (double*)S, ld, (double*)rhs, ldr, bl);
                });
-  return check_launch("thx_ba_schur");
+  return check_launch(what);
+}
+
+int thx_ba_schur(const thx_ba_structure* s, int32_t B, const void* Hcc, const void* Hpp, const void* W, const void* gd,
+                 int64_t ldv, const void* damping, int ellipsoidal, double damping_eps, void* S, int64_t ld, void* rhs,
+                 int64_t ldr, void* Hinv, void* tvec, int32_t* info, int dtype, void* stream) {
+  if (!s || !Hcc || !Hpp || !gd || !S || !rhs || !Hinv || !tvec || !info || B <= 0) return fail("thx_ba_schur: null argument");
+  if (ld < 6 * (int64_t)s->num_cams || ldr < 6 * (int64_t)s->num_cams) return fail("thx_ba_schur: ld < 6 C");
+  return ba_schur_impl(s, B, Hcc, Hpp, W, gd, ldv, damping, ellipsoidal, damping_eps, S, ld, rhs, ldr, Hinv, tvec, info, dtype,
+                       stream, SchurBlockDst{nullptr, nullptr, 0}, "thx_ba_schur");
+}
+
+int thx_ba_schur_blocks(const thx_ba_structure* s, int32_t B, const void* Hcc, const void* Hpp, const void* W, const void* gd,
+                        int64_t ldv, const void* damping, int ellipsoidal, double damping_eps, void* Sc, int64_t bstride,
+                        const int32_t* diag_blk, const int32_t* blk_dst, void* rhs, int64_t ldr, void* Hinv, void* tvec,
+                        int32_t* info, int dtype, void* stream) {
+  if (!s || !Hcc || !Hpp || !gd || !Sc || !rhs || !Hinv || !tvec || !info || !diag_blk || B <= 0)
+    return fail("thx_ba_schur_blocks: null argument");
+  if (s->num_blocks > 0 && !blk_dst) return fail("thx_ba_schur_blocks: blk_dst missing");
+  if (bstride < 36 * ((int64_t)s->num_cams + s->num_blocks) || (bstride & 3) != 0 || ldr < 6 * (int64_t)s->num_cams)
+    return fail("thx_ba_schur_blocks: bstride (36 elements per block, a multiple of 4) / ldr < 6 C");
+  static const int32_t none = 0;   // (kernels test blk_dst for the mode: a structure without camera pairs still writes the diagonal blocks)
+  return ba_schur_impl(s, B, Hcc, Hpp, W, gd, ldv, damping, ellipsoidal, damping_eps, Sc, 0, rhs, ldr, Hinv, tvec, info, dtype,
+                       stream, SchurBlockDst{diag_blk, blk_dst ? blk_dst : &none, bstride}, "thx_ba_schur_blocks");
 }
 
 int thx_ba_backsub(const thx_ba_structure* s, int32_t B, const void* W, const void* Hinv, const void* tvec, void* delta,

@@ -1289,14 +1289,42 @@ struct HBPre {
 #pragma unroll
     for (int k = 0; k < NPRE; ++k)
       if (rc[k] >= 0) f(rc[k] >> 8, rc[k] & 255, v[k]);
-    if (cnt > 256 * NPRE) {   // (rare: a tile with more pieces than the registers hold)
+    if (cnt > 256 * NPRE) {   // a tile with more pieces than the registers hold
       const T* base = static_cast<const T*>(hb.blocks) + (int64_t)b * hb.bstride;
       const int bd = hb.bd, bb = bd * bd;
-      for (int idx = tid + 256 * NPRE; idx < cnt; idx += 256) {
-        const int pc = p0 + idx / bb, e = idx % bb;
-        const int w = hb.piece_rc[pc];
-        const int r = (int)(short)(w >> 16) + e / bd, c = (int)(short)(w & 0xffff) + e % bd;
-        if (r >= 0 && r < TILE && c >= 0 && c < TILE) f(r, c, base[(int64_t)hb.piece_blk[pc] * bb + e]);
+      if (bd == 6) {
+        // ONE PIECE PER THREAD (6 x 6 blocks: the reduced camera system of a bundle adjustment fills a tile with up to 21 x 21
+        // of them -- 15876 elements; element by element that was 62 rounds of  table, table, value  per thread): a block is 36
+        // contiguous values, read as three batches of twelve (16-byte vectors), its table entries once.  The piece that holds
+        // element 256 NPRE of the tile's run is split with the register part above.
+        constexpr int VEC = 16 / sizeof(T), NV = 12 / VEC;
+        typedef T TV __attribute__((ext_vector_type(VEC)));
+        const int pb = (256 * NPRE) / 36, eb = (256 * NPRE) % 36, np = cnt / 36;
+        for (int q = pb + tid; q < np; q += 256) {
+          const int w = hb.piece_rc[p0 + q];
+          const int r0 = (int)(short)(w >> 16), c0 = (int)(short)(w & 0xffff);
+          const TV* src = reinterpret_cast<const TV*>(base + (int64_t)hb.piece_blk[p0 + q] * 36);
+          const int e0 = q == pb ? eb : 0;
+#pragma unroll
+          for (int part = 0; part < 3; ++part) {
+            TV val[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) val[k] = src[NV * part + k];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+              const int e = 12 * part + k;           // (compile-time: e / 6, e % 6 are constants)
+              const int r = r0 + e / 6, c = c0 + e % 6;
+              if (e >= e0 && r >= 0 && r < TILE && c >= 0 && c < TILE) f(r, c, val[k / VEC][k % VEC]);
+            }
+          }
+        }
+      } else {
+        for (int idx = tid + 256 * NPRE; idx < cnt; idx += 256) {
+          const int pc = p0 + idx / bb, e = idx % bb;
+          const int w = hb.piece_rc[pc];
+          const int r = (int)(short)(w >> 16) + e / bd, c = (int)(short)(w & 0xffff) + e % bd;
+          if (r >= 0 && r < TILE && c >= 0 && c < TILE) f(r, c, base[(int64_t)hb.piece_blk[pc] * bb + e]);
+        }
       }
     }
   }

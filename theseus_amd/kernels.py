@@ -557,6 +557,16 @@ class HipKernels:
                                          S.shape[-1], _lib.ptr(rhs), rhs.stride(0), _lib.ptr(Hinv), _lib.ptr(tvec),
                                          _lib.ptr(info), _lib.dtype_code(S.dtype), _lib.stream_ptr(S.device)), "thx_ba_schur")
 
+    def ba_schur_blocks(self, s, Hcc, Hpp, W, gd, damping, ellipsoidal, damping_eps, Sc, diag_blk, blk_dst, rhs, Hinv, tvec, info):
+        """thx_ba_schur_blocks: S as a block list ``Sc`` (B, bstride), 36 contiguous values per 6 x 6 block (diag_blk / blk_dst:
+        device int32 block ids, bit 30 of blk_dst = stored transposed)."""
+        B = gd.shape[0]
+        _lib.check(self.lib.thx_ba_schur_blocks(s.c, B, _lib.ptr(Hcc), _lib.ptr(Hpp), _lib.ptr(W), _lib.ptr(gd), gd.stride(0),
+                                                _lib.ptr(damping), int(bool(ellipsoidal)), float(damping_eps), _lib.ptr(Sc),
+                                                Sc.stride(0), _lib.ptr(diag_blk), _lib.ptr(blk_dst), _lib.ptr(rhs), rhs.stride(0),
+                                                _lib.ptr(Hinv), _lib.ptr(tvec), _lib.ptr(info), _lib.dtype_code(Sc.dtype),
+                                                _lib.stream_ptr(Sc.device)), "thx_ba_schur_blocks")
+
     def ba_backsub(self, s, W, Hinv, tvec, delta):
         B = delta.shape[0]
         _lib.check(self.lib.thx_ba_backsub(s.c, B, _lib.ptr(W), _lib.ptr(Hinv), _lib.ptr(tvec), _lib.ptr(delta),

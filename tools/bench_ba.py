@@ -16,7 +16,9 @@ iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
 t0 = time.time()
 obj, meta = make_ba_objective(C, Np, B, dtype=dt)
 print(f"objective built in {time.time() - t0:.1f} s: {meta['num_cams']} cams, {meta['num_points']} points, {meta['num_obs']} obs, n = {meta['n']}")
-opt = th.LevenbergMarquardt(obj, max_iterations=iters, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
+ordering = os.environ.get("BENCH_BA_ORDERING", "auto")   # camera order of the reduced system (HipSchurSolver(ordering=...))
+opt = th.LevenbergMarquardt(obj, max_iterations=iters, abs_err_tolerance=0.0, rel_err_tolerance=0.0,
+                            linear_solver_kwargs=dict(ordering=ordering))
 layer = th.TheseusLayer(opt)
 kw = dict(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True, track_err_history=True)
 t0 = time.time()
@@ -42,18 +44,30 @@ def timed(name, fn, reps=3):
 
 p = lin.packed
 timed("ba_assemble", lambda: lin._assemble())
-timed("ba_schur", lambda: solver.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, lin.gd, lam, True, 1e-8, solver.S, solver.rhs, solver.Hinv, solver.tvec, solver.info_pts))
-timed("chol_factor(S) dense", lambda: solver.K.chol_factor(solver.S, p.nc, None, False, 1e-8, solver.L, solver.panels, solver.info_chol, rhs=solver.rhs, y=solver._y))
-dense_ms = phases.pop("chol_factor(S) dense")   # for comparison only: the solver factorises along the tile pattern of S
-if solver.sparse:
-    timed("chol_factor(S)", lambda: solver.K.chol_factor_sparse(solver.S, p.nc, None, False, 1e-8, solver.L, solver.panels, solver.info_chol, solver.pattern, rhs=solver.rhs, y=solver._y))
+if solver.levels:
+    t = solver._level_t
+    K = solver.K
+    timed("ba_schur_blocks", lambda: K.ba_schur_blocks(p.dstruct, lin.Hcc, lin.Hpp, lin.W, lin.gd, lam, True, 1e-8, solver.Sc, t["diag_blk"], t["blk_dst"], solver.rhs, solver.Hinv, solver.tvec, solver.info_pts))
+    timed("vec_gather", lambda: K.vec_gather(solver.rhs, solver._xp, t["col_of_pad"]))
+    timed("chol_factor(S)", lambda: K.chol_factor_levels(solver._level_layout, solver.Sc, None, False, 1e-8, solver.L, solver.panels, solver.info_chol, solver.pattern, rhs=solver._xp, y=solver._yp))
+    timed("chol_backward", lambda: K.chol_solve_levels(solver.L, solver.panels, solver._yp, solver._xp, solver.pattern, which=1))
+    timed("ba_backsub", lambda: K.ba_backsub(p.dstruct, lin.W, solver.Hinv, solver.tvec, solver.delta))
+    dense_ms = float("nan")
+    print(f"level mode: ordering {solver.ordering_info.get('method')}, {solver.pattern.nlevels} levels over {solver.pattern.ntiles} tiles, "
+          f"L tiles {solver.pattern.l_tiles}; candidates {solver.ordering_info.get('candidates')}")
 else:
-    phases["chol_factor(S)"] = dense_ms
-if solver.sparse:
-    timed("chol_backward", lambda: solver.K.chol_solve_sparse(solver.L, p.nc, solver.panels, solver._y, solver._dc, solver.pattern, backward_only=True))
-else:
-    timed("chol_backward", lambda: solver.K.chol_solve_backward(solver.L, p.nc, solver.panels, solver._y, solver._dc))
-timed("ba_backsub", lambda: solver.K.ba_backsub(p.dstruct, lin.W, solver.Hinv, solver.tvec, solver.delta))
+  timed("ba_schur", lambda: solver.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, lin.gd, lam, True, 1e-8, solver.S, solver.rhs, solver.Hinv, solver.tvec, solver.info_pts))
+  timed("chol_factor(S) dense", lambda: solver.K.chol_factor(solver.S, p.nc, None, False, 1e-8, solver.L, solver.panels, solver.info_chol, rhs=solver.rhs, y=solver._y))
+  dense_ms = phases.pop("chol_factor(S) dense")   # for comparison only: the solver factorises along the tile pattern of S
+  if solver.sparse:
+      timed("chol_factor(S)", lambda: solver.K.chol_factor_sparse(solver.S, p.nc, None, False, 1e-8, solver.L, solver.panels, solver.info_chol, solver.pattern, rhs=solver.rhs, y=solver._y))
+  else:
+      phases["chol_factor(S)"] = dense_ms
+  if solver.sparse:
+      timed("chol_backward", lambda: solver.K.chol_solve_sparse(solver.L, p.nc, solver.panels, solver._y, solver._dc, solver.pattern, backward_only=True))
+  else:
+      timed("chol_backward", lambda: solver.K.chol_solve_backward(solver.L, p.nc, solver.panels, solver._y, solver._dc))
+  timed("ba_backsub", lambda: solver.K.ba_backsub(p.dstruct, lin.W, solver.Hinv, solver.tvec, solver.delta))
 timed("ba_error", lambda: p.error_metric())
 spare = p.alloc_state()
 timed("retract", lambda: p.retract(solver.delta, 1.0, None, spare))
