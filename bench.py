@@ -847,9 +847,28 @@ def small_batch_run(cfg, ctx):
             setattr(opt.linear_solver.K, n_, getattr(type(opt.linear_solver.K), n_).__get__(opt.linear_solver.K))
         fac = ph.get("chol_factor_hblocks") or ph.get("chol_factor") or {"avg_ms": float("nan")}
         tf = B * n ** 3 / 3.0 / (fac["avg_ms"] * 1e-3) / 1e12
+        rl_max = int(opt.linear_solver.K.chol_schedule.right_looking_max_batch)
+        rl_max = 32 if rl_max < 0 else rl_max      # (include/theseus_hip.h: thx_chol_schedule.right_looking_max_batch, default 32)
         points[f"b{B}"] = {"value": B * info.iters_done / dt, "ms_per_step": dt / info.iters_done * 1e3, "factor_ms": fac["avg_ms"],
                            "factor_TFLOPs": tf, "factor_frac_of_peak": tf / PEAK["f32"],
+                           "schedule": "right-looking (one workgroup per tile product)" if B <= rl_max else "left-looking",
                            "mean_error": [float(info.err_history[:, 0].mean()), float(info.err_history[:, info.iters_done].mean())]}
+        if B <= rl_max:   # the same inputs through the left-looking schedule (what rounds 1-5 ran at every batch size)
+            prev = opt.linear_solver.K.chol_right_looking_max_batch(0)
+            try:
+                with torch.no_grad():
+                    layer.forward(inputs, optimizer_kwargs=okw)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    _, info2 = layer.forward(inputs, optimizer_kwargs=okw)
+                    torch.cuda.synchronize()
+                    dt2 = time.perf_counter() - t0
+            finally:
+                opt.linear_solver.K.chol_right_looking_max_batch(prev)
+            points[f"b{B}"]["left_looking"] = {"ms_per_step": dt2 / info2.iters_done * 1e3, "value": B * info2.iters_done / dt2,
+                                               "final_mean_error": float(info2.err_history[:, info2.iters_done].mean())}
+            points[f"b{B}"]["speedup_vs_left_looking"] = dt2 / info2.iters_done / (dt / info.iters_done)
+            del info2
         del sol, info, inputs, layer, opt, obj
         free_device_memory()
     return {"metric": "LM iterations/sec (batch x vars) on SE3 pose-graph", "unit": "problem-iterations/s", "dtype": "f32", "steps": K_iters,

@@ -290,10 +290,17 @@ int thx_se3_retract(const void* poses, const void* delta, int64_t ldd, double st
  *          never; < 0: the default (2048, or the environment's THX_CHOL_SPLIT_DIAG_MIN read once at load time).
  *        column_pairs: fp32 factorisations on dense factor frames, two block columns at a time -- diag(j), tile (j+1, j),
  *          diag(j+1), then ONE workgroup per row tile i >= j+2 produces L_ij and L_i,j+1, streaming row panel L_i,0:j from HBM
- *          once for both; 1 on, 0 off, < 0: the default (on, or THX_CHOL_COLPAIR). */
+ *          once for both; 1 on, 0 off, < 0: the default (on, or THX_CHOL_COLPAIR).
+ *        right_looking_max_batch: fp32 factorisations on dense factor frames (no tile pattern, ld >= ntiles * THX_TILE) of at most
+ *          this many problems take the RIGHT-LOOKING schedule -- per block column the tile factorisation, the substitutions and
+ *          one workgroup per tile of the trailing matrix, each a single 128^3 product -- instead of the left-looking one whose
+ *          serial K-loops leave the chip empty at 8 ... 64 problems (the reference's published batch range,
+ *          evaluations/pose_graph_synthetic.sh:7).  Another summation order: the factor agrees with the left-looking one to
+ *          rounding, not bit for bit.  0 = never; < 0: the default (32, or THX_CHOL_RL_MAX_BATCH). */
 typedef struct {
   int32_t split_diag_min_batch;
   int32_t column_pairs;
+  int32_t right_looking_max_batch;
 } thx_chol_schedule;
 
 /* ---- tile-sparse Cholesky for LARGE pose graphs -- the functional analogue of BaspachoSparseSolver

@@ -296,6 +296,63 @@ def test_chol_split_and_fused_diagonal_phase_agree(K, dtype):
     assert (xa - xb).abs().max() <= (2e-5 if dtype == torch.float32 else 1e-13) * xb.abs().max()
 
 
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("ellipsoidal", [False, True])
+@pytest.mark.parametrize("n,B", [(384, 3), (640, 8), (1536, 8), (1536, 29), (1024, 32)])
+def test_chol_right_looking_schedule_of_small_batches(K, n, B, ellipsoidal, fused):
+    """fp32, dense frames, <= 32 problems, whole tiles (thx_chol_schedule.right_looking_max_batch): per block column the tile
+    factorisation, the substitutions and one workgroup per tile of the trailing matrix.  Against LAPACK in fp64 (L L^T = H + D, the
+    solution) at the tolerances of the left-looking tests, and against the left-looking schedule on the same inputs: another
+    summation order, the same factor to rounding; the strict upper triangle of L stays zero."""
+    from tests.gpu_helpers import factor_and_solve
+    dtype = torch.float32
+    M = _random_spd(B, n, dtype, seed=3 * n + B)
+    rhs = torch.randn(B, n, dtype=torch.float64, generator=torch.Generator().manual_seed(5)).to(dtype).cuda()
+    H = torch.tril(M).cuda().contiguous()           # (ld = n: a multiple of 128)
+    lam = torch.linspace(0.02, 0.3, B).to(dtype).cuda()
+    out = {}
+    for rl in (True, False):
+        prev = K.chol_right_looking_max_batch(64 if rl else 0)
+        try:
+            out[rl] = factor_and_solve(K, H, n, rhs, damping=lam, ellipsoidal=ellipsoidal, eps=1e-6, fused=fused)
+        finally:
+            K.chol_right_looking_max_batch(prev)
+    (Lr, xr, ir), (Ll, xl, il) = out[True], out[False]
+    assert int(ir.abs().sum()) == 0 and int(il.abs().sum()) == 0
+    assert not torch.equal(Lr, Ll)                                        # (it IS another schedule)
+    assert float(torch.triu(Lr, 1).abs().max()) == 0.0
+    Md = M.double().cuda()
+    dg = torch.diagonal(Md, dim1=1, dim2=2)
+    D = lam.double().view(-1, 1) * dg + 1e-6 if ellipsoidal else lam.double().view(-1, 1).expand(B, n)
+    Hd = Md + torch.diag_embed(D)
+    Lref = torch.linalg.cholesky(Hd)
+    scale = Lref.abs().max()
+    assert float((Lr.double() - Lref).abs().max() / scale) < 2e-5
+    assert float((Lr - Ll).abs().max() / scale) < 2e-5
+    xref = torch.cholesky_solve(rhs.double().cpu().unsqueeze(2), Lref.cpu()).squeeze(2).cuda()   # (LAPACK on the host)
+    assert float((xr.double() - xref).abs().max() / xref.abs().max()) < 2e-3
+    assert float((xr - xl).abs().max() / xref.abs().max()) < 2e-3
+    # residual of the fp32 solution in the damped system: at the level of the left-looking schedule's
+    res = lambda x: float(((Hd @ x.double().unsqueeze(2)).squeeze(2) - rhs.double()).abs().max() / rhs.abs().max())  # noqa: E731
+    assert res(xr) < 2.0 * res(xl) + 1e-6
+
+
+def test_chol_right_looking_reports_non_positive_definite(K):
+    from tests.gpu_helpers import factor_and_solve
+    n, B = 640, 6
+    M = _random_spd(B, n, torch.float32, seed=9)
+    M[2, 300, 300] = -5.0            # breaks positive definiteness in block column 2 of problem 2
+    H = torch.tril(M).cuda().contiguous()
+    rhs = torch.ones(B, n, dtype=torch.float32, device="cuda")
+    prev = K.chol_right_looking_max_batch(64)
+    try:
+        _, _, info = factor_and_solve(K, H, n, rhs)
+    finally:
+        K.chol_right_looking_max_batch(prev)
+    info = info.cpu()
+    assert int(info[2]) != 0 and int(info.ne(0).sum()) == 1
+
+
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("n,B", [(258, 5), (390, 12), (700, 9), (1100, 16), (1536, 8)])
 def test_chol_column_pairs_are_bit_identical(K, n, B, split):

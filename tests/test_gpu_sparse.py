@@ -31,10 +31,12 @@ def _banded_spd(B, n, bw_tiles, dtype, seed):
 def test_sparse_factorisation_is_bit_identical_to_dense(dtype, n, B, split_diag):
     from theseus_amd.kernels import default_kernels
     prev = default_kernels().chol_split_diag_min_batch(0 if split_diag else 2 ** 31 - 1)
+    prev_rl = default_kernels().chol_right_looking_max_batch(0)   # (the dense side left-looking too, whatever its batch size)
     try:
         _sparse_vs_dense(dtype, n, B)
     finally:
         default_kernels().chol_split_diag_min_batch(prev)
+        default_kernels().chol_right_looking_max_batch(prev_rl)
 
 
 def _sparse_vs_dense(dtype, n, B):

@@ -1176,6 +1176,15 @@ struct TilePat {
   const int32_t* ent_col;    // (entries) block column of entry e -- the launch's entries then are [i_first, i_first + nrow_tiles)
   const int32_t* tile_valid; // (ntiles) rows / columns of tile j inside the matrix, the rest is identity padding (per-tile padding:
                              // no variable straddles a tile boundary); nullptr: min(TILE, n - j * TILE)
+  // RIGHT-LOOKING schedule of small dense batches (factor_impl: "rl"): 0 = the left-looking kernels as they are; 1 = no K-loop
+  // (the tile read from the H argument already carries every earlier column's update: chol_diag = the tile factorisation alone,
+  // chol_offdiag = the substitution alone); 2 + jc = chol_offdiag as the TRAILING UPDATE of block column jc: workgroup slot t ->
+  // tile (i, k), jc < k <= i, receives  A_ik - L_i,jc L_k,jc^T  (no substitution), written to the L frame
+  int32_t rl;
+  // right-looking schedule with a right-hand side: the vector being forward-substituted, (B, rl_ldv) -- g on entry; chol_diag
+  // turns block j into y_j in place, every substitution tile (i, j) then takes  L_ij y_j  off block i (chol_offdiag, rl == 1)
+  void* rl_y;
+  int64_t rl_ldv;
 };
 
 // rows (= columns) of diagonal tile j that belong to the matrix
@@ -1234,6 +1243,7 @@ struct HBlk {
   const int32_t* tile_ptr;
   const int32_t* piece_blk;
   const int32_t* piece_rc;
+  const int32_t* diag_blk;   // (nvars) block id of variable v's diagonal block (the right-looking schedule's damping pass; may be null)
 };
 
 // The pieces of lower tile (ti, tj) of problem b -- f(r, c, value), (r, c) relative to the tile origin and inside the tile; the
@@ -1440,7 +1450,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   // SYRK on the 36 lower 16x16 blocks of the tile, nine per wave (Engine<T>::syrk36)
   // tile-sparse: only the block columns k < j in which row panel j is non-zero
   const int32_t* klist = pat.diag_k ? pat.diag_k + pat.diag_kptr[j] : nullptr;
-  const int Kspan = pat.diag_k ? (pat.diag_kptr[j + 1] - pat.diag_kptr[j]) * TILE : row0;
+  const int Kspan = pat.rl ? 0 : (pat.diag_k ? (pat.diag_kptr[j + 1] - pat.diag_kptr[j]) * TILE : row0);
   const bool ycompact = pat.ent_col != nullptr;   // (level schedule: ybuf holds the K-list's blocks of y only)
   typename E::Sy acc[9];
 #pragma unroll
@@ -1938,10 +1948,22 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   // (tile-sparse: i_first = first ENTRY of the launch, relative to the column's list -- level schedule: absolute, and the entry
   //  names its block column)
   const int ent = pat.col_row ? (pat.ent_col ? 0 : pat.col_ptr[jarg]) + i_first + rslot : 0;
-  const int j = pat.ent_col ? pat.ent_col[ent] : jarg;
-  const int i = pat.col_row ? pat.col_row[ent] : i_first + rslot;
+  // right-looking trailing update of block column jc (pat.rl = 2 + jc; dense frames): slot t -> tile (i, k), jc < k <= i,
+  // rows of the lower triangle numbered row by row; "j" is the tile's own block column k, the K-loop is the one tile jc
+  const bool upd = pat.rl >= 2;
+  const int jc = pat.rl - 2;
+  int ui = 0, uk = 0;
+  if (upd) {
+    ui = (int)((__builtin_sqrtf(8.f * (float)rslot + 1.f) - 1.f) * 0.5f);
+    while ((ui + 1) * (ui + 2) / 2 <= rslot) ++ui;
+    while (ui * (ui + 1) / 2 > rslot) --ui;
+    uk = rslot - ui * (ui + 1) / 2;
+  }
+  const int j = upd ? jc + 1 + uk : (pat.ent_col ? pat.ent_col[ent] : jarg);
+  const int i = upd ? jc + 1 + ui : (pat.col_row ? pat.col_row[ent] : i_first + rslot);
   const int32_t* klist = pat.col_row ? pat.tile_k + pat.tile_kptr[ent] : nullptr;
-  const int Kspan = pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE;
+  const int Kspan = pat.rl ? (upd ? TILE : 0) : (pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE);
+  const int kcol0 = upd ? jc * TILE : 0;               // first column of the K-loop inside the row panels
   if (b >= B) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const LFrame lf = lframe(pat, ld);
@@ -1981,7 +2003,7 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
 #pragma unroll
         for (int q = 0; q < 4; ++q) hr[cb][q] = *reinterpret_cast<const float4*>(Hrow + 32 * cb + 8 * q);
     }
-    {  // panel: global -> LDS (swizzled), one 16-byte piece of each of the ten sub-blocks per thread
+    if (!upd) {  // panel: global -> LDS (swizzled), one 16-byte piece of each of the ten sub-blocks per thread
       const float* Pn = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
       const int pi = tid >> 3, pc = tid & 7;
       float* dst = Pc + pi * 32 + ((pc ^ ((pi >> 1) & 7)) << 2);
@@ -2007,12 +2029,13 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
 #endif
   // (two LDS staging buffers with ONE barrier per k-chunk instead of one buffer with two -- panel copy moved behind the
   //  loop to keep 2 workgroups/CU -- measured the same 9.3-9.4 k cycles per chunk: the barriers are not the K-loop's limit)
-  const float* Ap = L + lmat + (lf.packed ? 0 : (int64_t)col0 * ld);   // rows of block row j (operand A) / i (operand B)
-  const float* Bp = L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld);
+  const float* Ap = L + lmat + (lf.packed ? 0 : (int64_t)col0 * ld) + kcol0;   // rows of block row j (operand A) / i (operand B)
+  const float* Bp = L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld) + kcol0;
+  const int validA = upd ? tile_rows(pat, n, j) : TILE;   // (update: tile column k may be the LAST block row)
 #ifdef THX_OFF_PROLOGUE_FIRST
-  kloop<float, false>(Ap, TILE, Bp, validB, ldt, Kspan, sA, sB, P, tid, nullptr, nullptr, NoHook{}, klist, ksa, ksb, lf.pstride);
+  kloop<float, false>(Ap, validA, Bp, validB, ldt, Kspan, sA, sB, P, tid, nullptr, nullptr, NoHook{}, klist, ksa, ksb, lf.pstride);
 #else
-  kloop<float, false>(Ap, TILE, Bp, validB, ldt, Kspan, sA, sB, P, tid, nullptr, nullptr, prologue, klist, ksa, ksb, lf.pstride);
+  kloop<float, false>(Ap, validA, Bp, validB, ldt, Kspan, sA, sB, P, tid, nullptr, nullptr, prologue, klist, ksa, ksb, lf.pstride);
 #endif
 #ifdef THX_OFF_PROF
   __builtin_amdgcn_sched_barrier(0);
@@ -2067,6 +2090,23 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   st[5] = (long long)__builtin_readcyclecounter();   // P = H - sum done (block-compact H: the gather rounds)
   __builtin_amdgcn_sched_barrier(0);
 #endif
+  if (upd) {   // trailing update: the tile goes back as it is (a diagonal tile: its lower triangle, zeros above)
+    if (rvalid) {
+      float* Lrow = Lij + (int64_t)r * ldt + 4 * g;
+      const int rt = 32 * wave + (lane & 31);   // row inside the tile
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = 32 * cb + 8 * q + 4 * g;
+          const bool dg = i == j;
+          *reinterpret_cast<float4*>(Lrow + 32 * cb + 8 * q) =
+              make_float4(dg && c + 0 > rt ? 0.f : P.v[cb][4 * q], dg && c + 1 > rt ? 0.f : P.v[cb][4 * q + 1],
+                          dg && c + 2 > rt ? 0.f : P.v[cb][4 * q + 2], dg && c + 3 > rt ? 0.f : P.v[cb][4 * q + 3]);
+        }
+    }
+    return;
+  }
   Engine<float>::Acc X;
   Engine<float>::zero(X);
 #ifdef THX_EXP_FULLINV   // timing experiment: the dataflow of a FULL 128 x 128 inverse in the panel, X_s = sum_{t <= s} W_st P_t --
@@ -2101,6 +2141,20 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<float4*>(Lrow + 32 * cb + 8 * q) =
             make_float4(X.v[cb][4 * q], X.v[cb][4 * q + 1], X.v[cb][4 * q + 2], X.v[cb][4 * q + 3]);
+  }
+  if (pat.rl_y) {   // right-looking forward substitution: block i of the vector loses L_ij y_j (a row's 128 columns sit in two lanes)
+    float* yb = static_cast<float*>(pat.rl_y) + (int64_t)b * pat.rl_ldv;
+    const float* yj = yb + col0 + 4 * g;
+    float dot = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 yv = *reinterpret_cast<const float4*>(yj + 32 * cb + 8 * q);
+        dot += X.v[cb][4 * q] * yv.x + X.v[cb][4 * q + 1] * yv.y + X.v[cb][4 * q + 2] * yv.z + X.v[cb][4 * q + 3] * yv.w;
+      }
+    dot += __shfl_xor(dot, 32);
+    if (g == 0 && rvalid) yb[row0 + r] -= dot;
   }
 #ifdef THX_OFF_PROF
   __builtin_amdgcn_s_waitcnt(0);
@@ -2886,6 +2940,29 @@ lm_accept_kernel(const T* __restrict__ delta, const T* __restrict__ g, int64_t l
   }
 }
 
+// right-looking schedule: the damping of the diagonal elements d >= d0 of the working matrix in the L frame,
+// A_dd += ellipsoidal ? lambda H_dd + eps : lambda, with H_dd the ORIGINAL diagonal (dense H frame or block list) -- block column 0
+// gets its damping from chol_diag as always; the other diagonal tiles have just been written by the first trailing update
+template <typename T>
+__global__ void rl_damp_kernel(T* __restrict__ L, int64_t ld, const T* __restrict__ H, int64_t ldh, HBlk hb,
+                               const T* __restrict__ damping, int ellipsoidal, T eps, int d0, int n) {
+  const int b = blockIdx.y, d = d0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  const T lam = damping[b];
+  T add = lam;
+  if (ellipsoidal) {
+    T h;
+    if (hb.blocks) {
+      const int v = d / hb.bd, e = d % hb.bd;
+      h = static_cast<const T*>(hb.blocks)[(int64_t)b * hb.bstride + (int64_t)hb.diag_blk[v] * hb.bd * hb.bd + e * hb.bd + e];
+    } else {
+      h = H[(int64_t)b * ldh * ldh + (int64_t)d * ldh + d];
+    }
+    add = lam * h + eps;
+  }
+  L[(int64_t)b * ld * ld + (int64_t)d * ld + d] += add;
+}
+
 // dst[b][k] = idx[k] >= 0 ? src[b][idx[k]] : 0  -- the solver's permuted / padded vectors <-> the linearization's (thx_vec_gather)
 template <typename T>
 __global__ void vec_gather_kernel(const T* __restrict__ src, int64_t lds, T* __restrict__ dst, int64_t ldd,
@@ -2908,6 +2985,10 @@ static const int g_split_diag_min_default = [] {
 static const int g_column_pairs_default = [] {
   const char* e = getenv("THX_CHOL_COLPAIR");
   return e ? atoi(e) : 1;
+}();
+static const int g_right_looking_max_default = [] {
+  const char* e = getenv("THX_CHOL_RL_MAX_BATCH");
+  return e ? atoi(e) : 32;
 }();
 
 // Launch-side state is kept PER DEVICE (a process may drive several GPUs, from several threads): the dynamic-LDS limits
@@ -2957,6 +3038,7 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   // launch per column costs more than the chain there), else the fused chol_diag_kernel
   const int split_diag_min = (sched && sched->split_diag_min_batch >= 0) ? sched->split_diag_min_batch : g_split_diag_min_default;
   const int column_pairs = (sched && sched->column_pairs >= 0) ? sched->column_pairs : g_column_pairs_default;
+  const int rl_max_batch = (sched && sched->right_looking_max_batch >= 0) ? sched->right_looking_max_batch : g_right_looking_max_default;
   const bool fused_diag = B < split_diag_min;
   const size_t dsm = fused_diag ? DiagSmem<T>::bytes(rhs ? ntiles * TILE : 0) : SyrkSmem<T>::bytes(rhs ? ntiles * TILE : 0);
   if (dsm > LDS_LIMIT) return fail("thx_chol_factor: n too large for the fused forward substitution (LDS)");
@@ -3245,11 +3327,91 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     if (rest_pending) hipStreamWaitEvent(st, ds.ev_rest, 0);
     return check_launch("thx_chol_factor");
   }
+  // RIGHT-LOOKING SCHEDULE for SMALL dense batches (fp32, dense L frame without a tile pattern, whole tiles inside the frame, up to
+  // thx_chol_schedule.right_looking_max_batch problems).  Left-looking, block column j is two dependent launches whose workgroups
+  // walk K-loops of j tiles -- the diagonal one with ONE workgroup per problem: at 8 ... 64 problems the chip is 3 ... 25 % occupied
+  // and a factorisation is the sum of those serial K-loops (n = 1536, batch 8: 1.62 ms, 0.04 of the MFMA peak).  Here every tile
+  // product is its own workgroup: per block column  chol_diag (the tile factorisation alone) -> chol_offdiag as the substitution
+  // alone, B (ntiles - 1 - j) tiles -> chol_offdiag as the trailing update, B m (m + 1) / 2 tiles each receiving ONE product; the
+  // working matrix lives in the L frame (first touched by column 0's update, which reads H), the damping of the later diagonal
+  // tiles is added once after that update.  Same tile kernels, another summation order: the factor differs from the left-looking
+  // one in the last bits (tests: against LAPACK and against the left-looking solution).  The forward substitution runs as its
+  // own kernel afterwards.
+  if constexpr (sizeof(T) == 4) {
+    if (!tp && !packed && !split && fused_diag && ntiles >= 3 && B <= rl_max_batch && ld >= (int64_t)ntiles * TILE &&
+        (!use_hb || !damping || hb.diag_blk)) {
+      if (dsm > ds.attr_diag[ti][0]) {   // (the later columns run the dense-frame instance on the L frame whatever H is)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dsm);
+        ds.attr_diag[ti][0] = dsm;
+      }
+      const Half h{st, 0, B};
+      const int Bpad = (B + 7) / 8 * 8;
+      // forward substitution riding on the schedule (vectors with 16-byte rows; else its own kernel afterwards, code 1000): y starts
+      // as a copy of g; chol_diag(j) turns block j into y_j in place, the substitution tiles of column j update the blocks below
+      const bool fwd_fused = rhs && (ldv % 4) == 0 && (reinterpret_cast<uintptr_t>(y) % 16) == 0;
+      if (fwd_fused) {
+        hipMemcpy2DAsync(y, (size_t)ldv * sizeof(T), rhs, (size_t)ldv * sizeof(T), (size_t)n * sizeof(T), (size_t)B, hipMemcpyDeviceToDevice, st);
+        rhs = y;
+      }
+      TilePat p0 = pat, p1 = pat;
+      p1.rl = 1;
+      if (fwd_fused) {
+        p0.rl_y = p1.rl_y = y;
+        p0.rl_ldv = p1.rl_ldv = ldv;
+      }
+      const float* yc = fwd_fused ? (const float*)y : nullptr;
+      const HBlk nohb{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr};
+      const float* Lc = (const float*)L;
+      const size_t dsm0 = DiagSmem<T>::bytes(0);
+      auto upd = [&](int jc, bool first) {
+        const int m = ntiles - 1 - jc;
+        TilePat pu = pat;
+        pu.rl = 2 + jc;
+        if (first && use_hb)
+          hipLaunchKernelGGL(chol_offdiag_f32_kernel<true>, dim3(Bpad * (m * (m + 1) / 2)), dim3(256), OFF32_SMEM, st, (const float*)nullptr,
+                             (float*)L, (const float*)panel, n, ld, jc, ntiles, 0, m * (m + 1) / 2, B, pu, hb);
+        else
+          hipLaunchKernelGGL(chol_offdiag_f32_kernel<false>, dim3(Bpad * (m * (m + 1) / 2)), dim3(256), OFF32_SMEM, st,
+                             first ? (const float*)H : Lc, (float*)L, (const float*)panel, n, ld, jc, ntiles, 0, m * (m + 1) / 2, B, pu, nohb);
+      };
+      // block column 0: the kernels as they are (no earlier columns), reading H
+      launch_diag_n(h, 0, 1, true, dsm);   // (with a right-hand side: y_0 = W_00 g_0 -- kept when the forward substitution is fused)
+      if (use_hb)
+        hipLaunchKernelGGL(chol_offdiag_f32_kernel<true>, dim3(Bpad * (ntiles - 1)), dim3(256), OFF32_SMEM, st, (const float*)nullptr,
+                           (float*)L, (const float*)panel, n, ld, 0, ntiles, 1, ntiles - 1, B, p0, hb);
+      else
+        hipLaunchKernelGGL(chol_offdiag_f32_kernel<false>, dim3(Bpad * (ntiles - 1)), dim3(256), OFF32_SMEM, st, (const float*)H,
+                           (float*)L, (const float*)panel, n, ld, 0, ntiles, 1, ntiles - 1, B, p0, nohb);
+      upd(0, true);
+      if (damping)
+        hipLaunchKernelGGL(rl_damp_kernel<float>, dim3((n - TILE + 255) / 256, B), dim3(256), 0, st, (float*)L, ld, (const float*)H, ld, hb,
+                           (const float*)damping, ellipsoidal, (float)eps, TILE, n);
+      for (int j = 1; j < ntiles; ++j) {
+        hipLaunchKernelGGL((chol_diag_kernel<float, false>), dim3(B, 1), dim3(256), fwd_fused ? dsm : dsm0, st, Lc, (float*)L,
+                           (float*)panel, (const float*)nullptr, 0, 0.f, info, n, ld, j, ntiles, yc, (float*)(fwd_fused ? y : nullptr), ldv,
+                           p1, nohb);
+        if (j + 1 == ntiles) break;
+        hipLaunchKernelGGL(chol_offdiag_f32_kernel<false>, dim3(Bpad * (ntiles - 1 - j)), dim3(256), OFF32_SMEM, st, Lc, (float*)L,
+                           (const float*)panel, n, ld, j, ntiles, j + 1, ntiles - 1 - j, B, p1, nohb);
+        upd(j, false);
+      }
+      if (int r = check_launch("thx_chol_factor (right-looking)")) return r;
+      return (rhs && !fwd_fused) ? 1000 : 0;   // (1000: the caller runs the forward substitution as its own kernel)
+    }
+  }
   // COLUMN PAIRS (fp32, dense L frame without a tile pattern; THX_CHOL_COLPAIR=0 / thx_chol_schedule.column_pairs = 0 turn them off): block columns j, j + 1 with row
   // tiles below j + 1 run as  diag(j) -> tile (j + 1, j) alone -> diag(j + 1) -> one chol_offdiag2 workgroup per row tile i >= j + 2
   // producing (i, j) and (i, j + 1) -- the same arithmetic in the same order, so the factor is bit-identical to the
   // column-by-column schedule; the row panels are streamed from HBM once per pair.
-  const bool colpair = column_pairs != 0 && sizeof(T) == 4 && !tp && !packed;
+  // (pairs from 128 problems per call on: the pair schedule's chain per two columns is diag, head tile, diag, pair tiles -- one
+  //  more dependent launch than two plain columns -- and below ~128 problems the launches are too small to pay for it: n = 1536,
+  //  batch 8 / 16 / 32 / 64: 1.62 / 1.64 / 1.67 / 1.85 ms with pairs, 1.42 / 1.44 / 1.50 / 1.73 ms without; 128: 2.25 / 2.23; 256:
+  //  3.25 / 3.30 -- profiles/r6/j_ab_small_batch.txt.  Bit-identical either way.)
+  static const int pair_min_batch = [] {
+    const char* e = getenv("THX_CHOL_COLPAIR_MIN_BATCH");
+    return e ? atoi(e) : 128;
+  }();
+  const bool colpair = column_pairs != 0 && sizeof(T) == 4 && !tp && !packed && B >= pair_min_batch;
   for (int j = 0; j < ntiles;) {
     const bool pair = colpair && j + 2 < ntiles;
     for (int k = 0; k < nparts; ++k) {
@@ -3355,6 +3517,16 @@ static int solve_impl(const void* L, int64_t ld, int n, int B, const void* panel
   return check_launch("thx_chol_solve");
 }
 
+// factor_impl + (right-looking schedule: return code 1000) the forward substitution as its own kernel -- outside factor_impl's
+// launch lock, which solve_impl takes itself
+template <typename T, typename... A>
+static int factor_then_forward(const void* H, int64_t ld, int n, int B, const void* damping, int ellipsoidal, double eps, void* L,
+                               void* panel, int32_t* info, const void* rhs, void* y, int64_t ldv, hipStream_t st, A... more) {
+  const int r = factor_impl<T>(H, ld, n, B, damping, ellipsoidal, eps, L, panel, info, rhs, y, ldv, st, more...);
+  if (r != 1000) return r;
+  return solve_impl<T>(L, ld, n, B, panel, rhs, y, ldv, true, false, st);
+}
+
 }  // namespace thx
 
 using namespace thx;
@@ -3373,9 +3545,9 @@ int thx_chol_factor(const void* H, int64_t ld, int32_t n, int32_t B, const void*
                     double damping_eps, void* L, void* Winv, int32_t* info, int dtype, void* stream, const thx_chol_schedule* schedule) {
   if (int r = check_factor_args(H, L, Winv, info, n, B, ld)) return r;
   THX_DISPATCH(dtype,
-               return factor_impl<float>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, nullptr,
+               return factor_then_forward<float>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, nullptr,
                                          nullptr, 0, as_stream(stream), nullptr, nullptr, nullptr, schedule),
-               return factor_impl<double>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, nullptr,
+               return factor_then_forward<double>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, nullptr,
                                           nullptr, 0, as_stream(stream), nullptr, nullptr, nullptr, schedule));
   return 0;
 }
@@ -3387,9 +3559,9 @@ int thx_chol_factor_forward(const void* H, int64_t ld, int32_t n, int32_t B, con
   if (!rhs || !y || ldv < n) return fail("thx_chol_factor_forward: rhs / y / ldv");
   if (rhs == y) return fail("thx_chol_factor_forward: y must not alias rhs");
   THX_DISPATCH(dtype,
-               return factor_impl<float>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
+               return factor_then_forward<float>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
                                          as_stream(stream), nullptr, nullptr, nullptr, schedule),
-               return factor_impl<double>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
+               return factor_then_forward<double>(H, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
                                           as_stream(stream), nullptr, nullptr, nullptr, schedule));
   return 0;
 }
@@ -3442,11 +3614,11 @@ int thx_chol_factor_hblocks(const thx_hblock_layout* layout, const void* Hc, int
     return fail("thx_chol_factor_hblocks: incomplete tile pattern");
   if ((rhs == nullptr) != (y == nullptr) || (rhs && ldv < n)) return fail("thx_chol_factor_hblocks: rhs / y / ldv");
   if (rhs && rhs == y) return fail("thx_chol_factor_hblocks: y must not alias rhs");
-  const HBlk hb{Hc, bstride, layout->bd, layout->tile_ptr, layout->piece_blk, layout->piece_rc};
+  const HBlk hb{Hc, bstride, layout->bd, layout->tile_ptr, layout->piece_blk, layout->piece_rc, layout->diag_blk};
   THX_DISPATCH(dtype,
-               return factor_impl<float>(nullptr, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
+               return factor_then_forward<float>(nullptr, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
                                          as_stream(stream), pattern, &hb, nullptr, schedule),
-               return factor_impl<double>(nullptr, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
+               return factor_then_forward<double>(nullptr, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
                                           as_stream(stream), pattern, &hb, nullptr, schedule));
   return 0;
 }

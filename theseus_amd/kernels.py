@@ -233,7 +233,7 @@ class HipKernels:
         self.lib = _lib.load()
         # per-call schedule of the factorisations (include/theseus_hip.h: thx_chol_schedule), handed to every thx_chol_factor* call
         # of THIS kernels object: -1 = the library default.  The library itself keeps no schedule state.
-        self.chol_schedule = _lib.CholSchedule(-1, -1)
+        self.chol_schedule = _lib.CholSchedule(-1, -1, -1)
 
     def _sched(self):
         import ctypes
@@ -752,6 +752,14 @@ class HipKernels:
         per off-diagonal launch, bit-identical factor (1 on, 0 off, -1 the library default).  Returns the previous setting."""
         prev = int(self.chol_schedule.column_pairs)
         self.chol_schedule.column_pairs = int(on)
+        return prev
+
+    def chol_right_looking_max_batch(self, max_batch: int) -> int:
+        """Schedule of THIS kernels object's fp32 dense-frame factorisations (thx_chol_schedule.right_looking_max_batch): batches of
+        at most ``max_batch`` problems take the right-looking schedule (0 never, -1 the library default).  Returns the previous
+        setting."""
+        prev = int(self.chol_schedule.right_looking_max_batch)
+        self.chol_schedule.right_looking_max_batch = int(max_batch)
         return prev
 
     def chol_solve(self, L, n, panels, rhs, x):

@@ -133,7 +133,7 @@ class PoseGraphDataset:
             sizes.extend(p.shape[0] for p in gt_poses)
         sizes.extend(e.relative_pose.shape[0] for e in edges)
         if len(set(sizes)) != 1:
-            raise ValueError("Provided data has muliple batches.")
+            raise ValueError(f"poses, ground-truth poses and edge measurements must share one dataset size, got {sorted(set(sizes))}")
         self.poses = poses
         self.edges = edges
         self.gt_poses = gt_poses
