@@ -2875,10 +2875,12 @@ chol_bwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* _
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const T xv = xb[rr + u];
+          // (explicit fused multiply-adds: -ffp-contract leaves the choice to the vectoriser, which mixes packed multiplies +
+          //  adds into the chain -- the block-row kernel below must reproduce this sum bit for bit)
           if constexpr (sizeof(T) == 4) {
-            s[0] += lv[u].x * xv; s[1] += lv[u].y * xv; s[2] += lv[u].z * xv; s[3] += lv[u].w * xv;
+            s[0] = fma_t(lv[u].x, xv, s[0]); s[1] = fma_t(lv[u].y, xv, s[1]); s[2] = fma_t(lv[u].z, xv, s[2]); s[3] = fma_t(lv[u].w, xv, s[3]);
           } else {
-            s[0] += lv[u].x * xv; s[1] += lv[u].y * xv;
+            s[0] = fma_t(lv[u].x, xv, s[0]); s[1] = fma_t(lv[u].y, xv, s[1]);
           }
         }
       }
@@ -2886,9 +2888,9 @@ chol_bwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* _
         const V lv = *reinterpret_cast<const V*>(Lk + (int64_t)rr * lds_);
         const T xv = xb[rr];
         if constexpr (sizeof(T) == 4) {
-          s[0] += lv.x * xv; s[1] += lv.y * xv; s[2] += lv.z * xv; s[3] += lv.w * xv;
+          s[0] = fma_t(lv.x, xv, s[0]); s[1] = fma_t(lv.y, xv, s[1]); s[2] = fma_t(lv.z, xv, s[2]); s[3] = fma_t(lv.w, xv, s[3]);
         } else {
-          s[0] += lv.x * xv; s[1] += lv.y * xv;
+          s[0] = fma_t(lv.x, xv, s[0]); s[1] = fma_t(lv.y, xv, s[1]);
         }
       }
       if constexpr (LIST) {   // (scalar accesses: a row of the vector need not be 16-byte aligned, ldv = n = 6 P)
@@ -2903,6 +2905,60 @@ chol_bwd_kernel(const T* __restrict__ L, const T* __restrict__ panel, const T* _
   }
   if constexpr (!LIST)
     for (int k = tid; k < n; k += 256) x[(int64_t)b * ldv + k] = z[k];
+}
+
+// L^T x = y for SMALL batches on dense frames, one launch per block row instead of one workgroup per problem (round 6):
+// chol_bwd_kernel streams a problem's whole lower triangle through ONE workgroup.  Here block row jb is its own launch, x is the
+// working vector (z) in place:
+//   workgroup (k, b), k < jb:  z_k -= L_jb,k^T x_jb   (x_jb is final: the previous launch finished it) -- and the workgroup of
+//   k = jb - 1 then holds the finished z_jb-1 (rows above jb pushed into it in earlier launches: stream order) and turns it into
+//   x_jb-1 = L_jj^-T z_jb-1 through the panel, in place: the only writer of that block in this launch.
+// The first launch (jb = ntiles) only finishes the last block.  Per column the same sums in the same order as chol_bwd_kernel
+// (rows ascending, fused multiply-adds; the same panel substitution): the solution is bit-identical.
+template <typename T>
+__global__ void __launch_bounds__(256)
+chol_bwd_rows_kernel(const T* __restrict__ L, const T* __restrict__ panel, T* __restrict__ x, int n, int64_t ld, int64_t ldv,
+                     int ntiles, int jb) {
+  using C = CT<T>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);
+  T* xb = tile + 128 * C::LDM;   // [128]
+  T* ubuf = xb + 128;            // [32]
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  T* xg = x + (int64_t)b * ldv;
+  if (jb < ntiles) {   // push of block row jb into column block k
+    const int row0 = jb * TILE, valid = min(TILE, n - row0);
+    if (tid < TILE) xb[tid] = tid < valid ? xg[row0 + tid] : T(0);
+    __syncthreads();
+    if (tid < TILE) {
+      const T* Lk = L + (int64_t)b * ld * ld + (int64_t)row0 * ld + k * TILE + tid;
+      T s = T(0);
+      int rr = 0;
+      for (; rr + 16 <= valid; rr += 16) {
+        T lv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) lv[u] = Lk[(int64_t)(rr + u) * ld];
+        // (explicit fused multiply-adds: left to -ffp-contract the vectoriser emits packed multiplies + separate adds for half of
+        //  the chain -- other roundings than chol_bwd_kernel's v_fmac chain)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s = fma_t(lv[u], xb[rr + u], s);
+      }
+      for (; rr < valid; ++rr) s = fma_t(Lk[(int64_t)rr * ld], xb[rr], s);
+      xg[k * TILE + tid] -= s;
+    }
+    if (k != jb - 1) return;   // (workgroup uniform)
+    __syncthreads();           // block jb - 1 of x is finished and visible to this workgroup (its own writes)
+  } else if (k != 0) {
+    return;
+  }
+  // finish block jf = jb - 1: x_jf = L_jf,jf^-T z_jf through the panel
+  const int jf = jb - 1, row0 = jf * TILE, valid = min(TILE, n - row0);
+  panel_g2l<T>(panel + ((int64_t)b * ntiles + jf) * TILE * TILE, tile, tid);
+  if (tid < TILE) xb[tid] = tid < valid ? xg[row0 + tid] : T(0);
+  __syncthreads();
+  if (wave == 0) panel_backward<T>(tile, xb, ubuf, lane);
+  __syncthreads();
+  if (tid < valid) xg[row0 + tid] = xb[tid];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2996,7 +3052,7 @@ static const int g_right_looking_max_default = [] {
 // they were created on.
 constexpr int MAX_DEVICES = 64;
 struct DeviceLaunchState {
-  size_t attr_diag[2][2] = {{0, 0}, {0, 0}}, attr_syrk[2][2] = {{0, 0}, {0, 0}}, attr_solve[2] = {0, 0};   // [0] float, [1] double (x HB)
+  size_t attr_diag[2][2] = {{0, 0}, {0, 0}}, attr_syrk[2][2] = {{0, 0}, {0, 0}}, attr_solve[2] = {0, 0}, attr_bwd_rows[2] = {0, 0};   // [0] float, [1] double (x HB)
   bool attr_off = false;
   hipStream_t aux[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_lag[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
@@ -3505,6 +3561,33 @@ static int solve_impl(const void* L, int64_t ld, int n, int B, const void* panel
       hipLaunchKernelGGL((chol_fwd_kernel<T, false>), dim3(B), dim3(256), sm, st, (const T*)L, (const T*)panel, src, (T*)x, n,
                          ld, ldv, ntiles, rp);
     src = (const T*)x;  // the backward pass then runs in place
+  }
+  // small batches, dense frame: one launch per block row (chol_bwd_rows_kernel; bit-identical to chol_bwd_kernel) -- up to
+  // THX_CHOL_BWD_ROWS_MAX_BATCH problems per call (default 32).  A SMALL gain: chol_bwd_kernel's push already runs 256 threads
+  // x 8 loads deep (n = 1536, batch 8: 115 us; block rows: 101 us, twelve launches of 5.5 ... 9 us; no difference from 64
+  // problems on, profiles/r6/o_ab_bwd_rows.txt) -- it is chol_fwd_kernel's row dots that take 0.46 ms at any batch size, and
+  // the right-looking schedule fuses the forward substitution instead.
+  static const int bwd_rows_max = [] {
+    const char* e = getenv("THX_CHOL_BWD_ROWS_MAX_BATCH");
+    return e ? atoi(e) : 32;
+  }();
+  if (backward && !list && ntiles >= 3 && B <= bwd_rows_max && B <= 65535) {
+    if (src != (const T*)x)
+      hipMemcpy2DAsync(x, (size_t)ldv * sizeof(T), src, (size_t)ldv * sizeof(T), (size_t)n * sizeof(T), (size_t)B,
+                       hipMemcpyDeviceToDevice, st);
+    const size_t smr = solve_smem<T>(0);
+    {
+      std::lock_guard<std::mutex> guard(g_launch_mutex);
+      size_t& attr = launch_state().attr_bwd_rows[sizeof(T) == 8];
+      if (smr > attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(chol_bwd_rows_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smr);
+        attr = smr;
+      }
+    }
+    for (int jb = ntiles; jb >= 1; --jb)
+      hipLaunchKernelGGL((chol_bwd_rows_kernel<T>), dim3(jb < ntiles ? jb : 1, B), dim3(256), smr, st, (const T*)L, (const T*)panel,
+                         (T*)x, n, ld, ldv, ntiles, jb);
+    return check_launch("thx_chol_solve (block rows)");
   }
   if (backward) {
     if (list)

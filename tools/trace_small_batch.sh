@@ -14,14 +14,19 @@ rows = sorted(csv.DictReader(open(fs[0])), key=lambda r: int(r["Start_Timestamp"
 def short(n):
     m = re.search(r"(chol_\w+_kernel)<([^>]*)>", n)
     return f"{m.group(1)}<{m.group(2)}>" if m else n.split("(")[0].replace("void thx::", "")[:44]
-# the LAST factorisation of the run (= the right-looking variant's): from the last hipMemset-like fill before the last chol_fwd
-last = max(i for i, r in enumerate(rows) if "chol_fwd" in r["Kernel_Name"] or "chol_diag" in r["Kernel_Name"])
-a = last
-while a > 0 and not ("chol_diag" in rows[a]["Kernel_Name"] and "chol" not in rows[a - 1]["Kernel_Name"] and "rl_damp" not in rows[a - 1]["Kernel_Name"]):
+# the LAST complete LM iteration of the run: from the assemble kernel before the last backward-solve launch to the retraction
+# after it
+lb = max(i for i, r in enumerate(rows) if "chol_bwd" in r["Kernel_Name"])
+a = lb
+while a > 0 and "assemble" not in rows[a]["Kernel_Name"]:
     a -= 1
+last = lb
 t0 = int(rows[a]["Start_Timestamp"])
 print(f"{'kernel':46s} {'start_us':>9s} {'dur_us':>8s} {'end_us':>9s} {'wgs':>7s}")
-for r in rows[a:last + 1]:
+end = last
+while end + 1 < len(rows) and "retract" not in rows[end]["Kernel_Name"]:
+    end += 1
+for r in rows[a:end + 1]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     wgs = int(r.get("Grid_Size", 0)) // max(int(r.get("Workgroup_Size", 1)), 1)
     print(f"{short(r['Kernel_Name']):46s} {(s - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} {(e - t0) / 1e3:9.1f} {wgs:7d}")
