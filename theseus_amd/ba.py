@@ -746,7 +746,9 @@ class HipSchurSolverCore:
         self._level = False
         if self._ordering == "natural" or not self._want_sparse or p.cc_costs or not hasattr(self.K, "ba_schur_blocks"):
             return False   # (camera-camera costs scatter-add into the dense frame: that path stays as it was)
-        from .sparse import TILE, LevelPattern, tile_nested_dissection
+        from .sparse import LEVEL_SCHEDULE_MAX_BATCH, TILE, LevelPattern, tile_nested_dissection
+        if self._ordering == "auto" and B >= LEVEL_SCHEDULE_MAX_BATCH:
+            return False   # (the batch fills the chip several times over: the column schedule's half-batch streams, sparse.level_ordering)
         s = p.structure
         C, t = s.num_cams, s.t
         if C <= TILE // 6:

@@ -51,6 +51,9 @@ def _objective_graph(objective):
     return names, edges
 
 
+LEVEL_SCHEDULE_MAX_BATCH = 1024   # ordering="auto": from this batch size on the column-by-column schedule under RCM (see level_ordering)
+
+
 def fill_reducing_ordering(objective, ordering_cls=VariableOrdering):
     """VariableOrdering of a pose-graph objective by reverse Cuthill-McKee on (pose, pose) adjacency of its costs
     (``ordering_cls``: theseus_amd's mirror class, or the reference's th.optimizer.VariableOrdering for the plugin)."""
@@ -75,6 +78,12 @@ def level_ordering(objective, ordering_cls=VariableOrdering, method: str = "auto
         return fill_reducing_ordering(objective, ordering_cls), None, dict(method="rcm")
     if batch_hint is None:
         batch_hint = getattr(objective, "batch_size", None) or 64
+    if method == "auto" and int(batch_hint) >= LEVEL_SCHEDULE_MAX_BATCH:
+        # the batch alone fills the chip several times over: the column-by-column schedule with its two half-batch streams (one
+        # half's diagonal phases under the other half's off-diagonal launches) and unpadded tiles is the faster one -- headline
+        # topology at batch 4096: 100.5 k problem-iterations/s against 94.5 k through the level schedule (13 padded tiles instead
+        # of 12, one stream; profiles/r6/q_ab_tile_sparse_ordering_batch_4096.txt).  The time model does not see those streams.
+        return fill_reducing_ordering(objective, ordering_cls), None, dict(method="rcm", reason=f"batch >= {LEVEL_SCHEDULE_MAX_BATCH}")
     order, counts, info = tile_nested_dissection(len(names), edges, TILE // 6, batch_hint=int(batch_hint), method=method)
     if info["method"] == "band" and method == "auto":
         return fill_reducing_ordering(objective, ordering_cls), None, dict(method="rcm", model=info)
