@@ -787,7 +787,8 @@ def sparse_run(cfg, ctx):
                                f"prior, batch {B}, LM damping {cfg.damping} + HipSparseCholeskySolver(ordering={cfg.ordering!r})",
                    "poses": P, "edges": len(edges), "batch": B, "n": 6 * P,
                    "regime": "evaluations/pose_graph_synthetic.sh:5-12 (the reference's sparse-solver sweep: batch 8-256, to 4096 poses)"},
-        "ordering": dict(solver.ordering_info, candidates=None), "levels": getattr(pat, "nlevels", pat.ntiles), "tiles": pat.ntiles,
+        "ordering": dict(solver.ordering_info, candidates=None), "levels": getattr(pat, "tree_levels", getattr(pat, "nlevels", pat.ntiles)), "launch_levels": getattr(pat, "nlevels", pat.ntiles),
+        "subtree_streams": bool(getattr(pat, "two_streams", False)), "tiles": pat.ntiles,
         "tiles_of_L": pat.l_tiles, "level_scheduled": bool(solver.levels),
         "factor_ms": fac["avg_ms"], "solves_ms_per_iteration": sol_ms, "executed_GFLOP_per_factorisation": pat.flops / 1e9,
         "executed_TFLOPs": tf, "executed_frac_of_peak": tf / PEAK["f32"],
@@ -1014,7 +1015,8 @@ def ba_run(cfg, ctx):
                           "frac": executed / (peak * 1e12) * 1e3 / (dt / max(solves, 1) * 1e3)}},
         "phases_ms_per_call": {k: round(v["avg_ms"], 4) for k, v in phases.items()},
         "reduced_system": {"level_scheduled": levels, "ordering": ordering_info,
-                           "levels": int(pat.nlevels) if levels else None, "tiles": int(pat.ntiles) if pat is not None else None,
+                           "levels": int(pat.tree_levels) if levels else None, "launch_levels": int(pat.nlevels) if levels else None,
+                           "subtree_streams": bool(getattr(pat, "two_streams", False)), "tiles": int(pat.ntiles) if pat is not None else None,
                            "S": "block list (36 contiguous values per camera-pair block)" if levels else "dense frame"},
     }
     del sol, info, layer, opt, obj, timer, solver, packed

@@ -375,6 +375,12 @@ typedef struct {
   const int32_t* level_maxk_host; /* (nlevels) HOST: longest diagonal K-list (diag_kptr) among the level's block columns */
   const int32_t* ent_col;         /* DEVICE (entries): block column of entry e (col_ptr is not used by the level kernels) */
   const int32_t* tile_valid;      /* DEVICE (ntiles): rows / columns of tile j that are matrix (a multiple of the block size) */
+  const int32_t* level_stream_host; /* (nlevels) HOST or NULL: launch stream of level l -- 0 the caller's, 1 the library's second
+                                     * stream; + 4: both streams join in front of this level (the trunk of the elimination tree).
+                                     * A "level" then is one SUBTREE's share of a tree level: subtrees of the tile elimination tree
+                                     * do not see each other, so the two streams need no ordering against each other and one
+                                     * chain's diagonal phases (one busy wave per workgroup) run beside the other's off-diagonal
+                                     * tiles.  NULL: every level on the caller's stream.  Read by thx_chol_factor_levels only. */
 } thx_level_schedule;
 int thx_chol_factor_levels(const thx_hblock_layout* layout, const void* Hc, int64_t bstride, int32_t B, const void* damping,
                            int ellipsoidal, double damping_eps, void* L, void* Winv, int32_t* info, const void* rhs, void* y,

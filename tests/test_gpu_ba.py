@@ -184,7 +184,7 @@ def test_ba_full_size_matches_the_reference_run():
     g = load_golden("ba_full_f64_lm")
     assert int(g["C"]) == 512 and g["obs_cam"].shape[0] == 32768
     err, solver = _ba_first_system(th, g)
-    assert solver.linearization.packed.nc == 3072 and solver.levels and solver.pattern.nlevels < solver.pattern.ntiles and err <= 1e-7, err
+    assert solver.linearization.packed.nc == 3072 and solver.levels and solver.pattern.tree_levels < solver.pattern.ntiles and err <= 1e-7, err
     cams, pts, used, deltas, info, _ = run_ba(th, g, None, "cuda")
     dc = np.abs(cams.cpu().numpy() - g["final_cams"]).max()
     dp = np.abs(pts.cpu().numpy() - g["final_pts"][:, used]).max()

@@ -113,7 +113,7 @@ def test_lm_on_a_large_chain_graph_sparse_equals_dense(ordering):
     pat = opt.linear_solver.pattern
     assert opt.linear_solver.levels == (ordering == "nd")
     if ordering == "nd":   # elimination-tree parallelism: a handful of dependent launch levels instead of one per block column
-        assert pat.nlevels <= 6 < pat.ntiles
+        assert pat.tree_levels <= 6 < pat.ntiles
     print(f"[sparse LM] tiles of L: {pat.l_tiles} of {pat.ntiles * (pat.ntiles + 1) // 2}; tile products {pat.tile_products} vs dense {pat.dense_tile_products}")
     assert pat.tile_products * 5 < pat.dense_tile_products
     np.testing.assert_allclose(sparse.cpu().numpy(), dense.cpu().numpy(), rtol=0, atol=1e-9)
@@ -258,7 +258,7 @@ def test_level_schedule_factor_and_solves(dtype, P, B):
     opt = _chain_problem(th, P, B, dtype)(ordering="nd")
     solver, lin = opt.linear_solver, opt.linear_solver.linearization
     pat = solver.pattern
-    assert solver.levels and solver.packed_factor and lin._compact and pat.nlevels < pat.ntiles
+    assert solver.levels and solver.packed_factor and lin._compact and pat.tree_levels < pat.ntiles
     opt.objective.update()
     lin.linearize()
     out = {}
@@ -317,5 +317,5 @@ def test_full_size_implicit_gradients_through_the_level_schedule():
     final, loss, grads, info, opt, _ = run_implicit(th, g, "cuda", gauge_free=True,
                                                     solver=dict(linear_solver_cls=th.HipSparseCholeskySolver,
                                                                 linear_solver_kwargs=dict(ordering="nd")))
-    assert opt.linear_solver.levels and opt.linear_solver.pattern.nlevels < opt.linear_solver.pattern.ntiles
+    assert opt.linear_solver.levels and opt.linear_solver.pattern.tree_levels < opt.linear_solver.pattern.ntiles
     check_full_size_implicit(g, final, loss, grads, "full size implicit fp64, level schedule")

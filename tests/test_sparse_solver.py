@@ -155,7 +155,7 @@ def test_level_pattern_tables():
     s, pat, info, order = _level_setup()
     t, nt = pat.tables, pat.ntiles
     assert sorted(order) == list(range(1200)) and info["method"].startswith("nd")
-    assert pat.nlevels <= 8 and pat.nlevels == info["levels"] and nt == (1200 + 20) // 21
+    assert pat.tree_levels <= 8 and pat.tree_levels == info["levels"] and pat.nlevels <= 2 * pat.tree_levels and nt == (1200 + 20) // 21
     assert np.all(np.diff(pat.level) >= 0)                                         # block columns numbered level by level
     assert pat.level_col[0] == 0 and pat.level_col[-1] == nt and pat.level_ent[-1] == len(t["col_row"]) == pat.nslots - nt
     assert t["tile_valid"].tolist() == (6 * pat.tile_count).tolist() and t["tile_valid"].max() <= 128

@@ -66,7 +66,8 @@ class CholSchedule(Structure):  # thx_chol_schedule: per-call schedule of the fa
 
 
 class LevelSchedule(Structure):  # thx_level_schedule: elimination-tree levels of a tile pattern (2 host + 2 device int32 tables)
-    _fields_ = [("nlevels", c_int32)] + [(k, c_void_p) for k in ("level_col_host", "level_ent_host", "level_maxk_host", "ent_col", "tile_valid")]
+    _fields_ = [("nlevels", c_int32)] + [(k, c_void_p) for k in ("level_col_host", "level_ent_host", "level_maxk_host", "ent_col", "tile_valid",
+                                                                 "level_stream_host")]
 
 
 class HBlockLayout(Structure):  # thx_hblock_layout: block-compact Hessian (device int32 tables)

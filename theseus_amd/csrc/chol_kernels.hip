@@ -3292,11 +3292,53 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       hipEventRecord(ds.ev_fork, st);
       hipStreamWaitEvent(ds.aux[0], ds.ev_fork, 0);
     }
+    // SUBTREE STREAMS (level_stream_host; not together with the half-batch split): levels of group 1 on the second stream, one
+    // diagonal phase behind group 0, joined in front of the first trunk level
+    const int32_t* lstr = two ? nullptr : ls->level_stream_host;
+    static const bool chains_on = [] {
+      const char* e = getenv("THX_LEVEL_CHAINS");
+      return e ? atoi(e) != 0 : true;
+    }();
+    if (!chains_on) lstr = nullptr;
+    bool forked = false, lag_recorded = false, lag_waited = false;
+    if (lstr) {
+      if (!ds.ev_fork) hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming);
+      if (!ds.aux[0]) {
+        hipStreamCreateWithFlags(&ds.aux[0], hipStreamNonBlocking);
+        hipEventCreateWithFlags(&ds.ev_lag[0], hipEventDisableTiming);
+        hipEventCreateWithFlags(&ds.ev_join[0], hipEventDisableTiming);
+      }
+      hipEventRecord(ds.ev_fork, st);
+      hipStreamWaitEvent(ds.aux[0], ds.ev_fork, 0);
+      forked = true;
+    }
     for (int l = 0; l < ls->nlevels; ++l) {
       const int j0 = ls->level_col_host[l], nc = ls->level_col_host[l + 1] - j0;
       const int e0 = ls->level_ent_host[l], ne = ls->level_ent_host[l + 1] - e0;
       if (nc <= 0) continue;
       const int yp = rhs ? ls->level_maxk_host[l] * TILE : 0;
+      if (lstr) {
+        const int code = lstr[l];
+        if (forked && (code & 4)) {   // the trunk: everything below it has to be there
+          hipEventRecord(ds.ev_join[0], ds.aux[0]);
+          hipStreamWaitEvent(st, ds.ev_join[0], 0);
+          forked = false;
+        }
+        const bool second = forked && (code & 3) == 1;
+        const Half h{second ? ds.aux[0] : st, 0, B};
+        const bool fused = (int64_t)B * nc < split_diag_min;
+        if (second && !lag_waited && lag_recorded) {   // group 1 starts one diagonal phase behind group 0
+          hipStreamWaitEvent(h.s, ds.ev_lag[0], 0);
+          lag_waited = true;
+        }
+        launch_diag_n(h, j0, nc, fused, fused ? DiagSmem<T>::bytes(yp) : SyrkSmem<T>::bytes(yp));
+        if (!second && forked && !lag_recorded) {
+          hipEventRecord(ds.ev_lag[0], st);
+          lag_recorded = true;
+        }
+        if (ne > 0) launch_off(h, j0, e0, ne);
+        continue;
+      }
       for (int k = 0; k < (two ? 2 : 1); ++k) {
         const Half& h = hv[k];
         if (h.nb <= 0) continue;
@@ -3309,7 +3351,7 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
         if (ne > 0) launch_off(h, j0, e0, ne);
       }
     }
-    if (two) {
+    if (two || forked) {
       hipEventRecord(ds.ev_join[0], ds.aux[0]);
       hipStreamWaitEvent(st, ds.ev_join[0], 0);
     }

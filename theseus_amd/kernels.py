@@ -463,7 +463,7 @@ class HipKernels:
         dev = L.device
         _lib.check(self.lib.thx_chol_solve_levels(
             _lib.ptr(L), L.shape[0], _lib.ptr(panels), _lib.ptr(rhs), _lib.ptr(x), x.stride(0), int(which), pattern.c_struct(dev),
-            pattern.c_levels(dev), _lib.dtype_code(L.dtype), _lib.stream_ptr(dev)), "thx_chol_solve_levels")
+            pattern.c_solve_levels(dev), _lib.dtype_code(L.dtype), _lib.stream_ptr(dev)), "thx_chol_solve_levels")
 
     def vec_gather(self, src, dst, idx):
         """dst[b, k] = src[b, idx[k]] (0 where idx[k] < 0)."""

@@ -342,6 +342,49 @@ def _symbolic_tiles(lp: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     return lp, level
 
 
+def _subtree_groups(lp: np.ndarray) -> np.ndarray:
+    """Stream group of every block column for the level schedule's two chain streams: walk the tile elimination tree (parent of
+    column j = its first non-zero row tile below the diagonal) down from the root(s) while a node has one child -- that path is
+    the TRUNK (group -1: launched after both streams have joined); at the first node with several children their subtrees are
+    dealt to groups 0 / 1, largest first onto the lighter group.  Subtrees do not see each other (a column's K-lists name its
+    descendants only), so the two groups' launches need no ordering against each other.  A tree that never branches (a band): all
+    columns in group 0, no trunk."""
+    nt = lp.shape[0]
+    parent = np.full(nt, -1, dtype=np.int64)
+    for j in range(nt):
+        rows = np.nonzero(lp[j + 1:, j])[0]
+        if rows.size:
+            parent[j] = j + 1 + rows[0]
+    children: List[List[int]] = [[] for _ in range(nt)]
+    roots = []
+    for j in range(nt):
+        (children[parent[j]] if parent[j] >= 0 else roots).append(j)
+    size = np.ones(nt, dtype=np.int64)
+    for j in range(nt):                      # (children have smaller indices than their parent)
+        if parent[j] >= 0:
+            size[parent[j]] += size[j]
+    group = np.zeros(nt, dtype=np.int64)
+    heads, trunk = roots, []
+    while len(heads) == 1:
+        trunk.append(heads[0])
+        heads = children[heads[0]]
+    if not heads:                            # a chain: nothing to split
+        return group
+    group[trunk] = -1
+    load = [0, 0]
+    for h in sorted(heads, key=lambda v: -int(size[v])):
+        g = 0 if load[0] <= load[1] else 1
+        load[g] += int(size[h])
+        stack = [h]
+        while stack:
+            v = stack.pop()
+            group[v] = g
+            stack.extend(children[v])
+    if min(load) == 0:                       # everything landed on one stream
+        group[group >= 0] = 0
+    return group
+
+
 def _schedule_cost_us(lp: np.ndarray, level: np.ndarray, batch: int) -> float:
     """Time model of one level-scheduled linear solve (factorisation with the fused forward substitution + the backward solve), in
     microseconds -- only used to RANK candidate orderings.  Per level three launches, each the larger of a latency term (the
@@ -419,6 +462,10 @@ def tile_nested_dissection(num_vars: int, edges: Sequence[Tuple[int, int]], vars
             best = (cost, name, o, level, int(lp.sum()))
     cost, name, o, level, l_tiles = best
     o = o[np.argsort(level, kind="stable")]          # level by level (stable: a level keeps the candidate's internal order)
+    # ... and inside a level by stream group (LevelPattern splits every level into one launch pair per group)
+    lp_l, level_l = _symbolic_tiles(np.tril(adj[np.ix_(o, o)]))
+    grp = _subtree_groups(lp_l)
+    o = o[np.lexsort((np.arange(nc), grp, level_l))]
     members = [[] for _ in range(nc)]
     for k, v in enumerate(perm):
         members[k // vpt].append(int(v))
@@ -455,10 +502,41 @@ class LevelPattern:
         if np.any(np.diff(level) < 0):
             raise ValueError("block columns must be numbered level by level of the tile elimination tree "
                              "(theseus_amd.sparse.tile_nested_dissection produces such an order)")
-        self.lower, self.level = lp, level
+        self.lower, self.tree_level = lp, level
+        self.tree_levels = int(level.max()) + 1
+        self.tree_level_col = np.ascontiguousarray(np.searchsorted(level, np.arange(self.tree_levels + 1)).astype(np.int32))
+        # LAUNCH levels: a tree level is split by stream group when its columns are sorted by group (tile_nested_dissection does
+        # that) -- group 0 on the caller's stream, group 1 on the library's second stream, the trunk (-1) on the caller's stream
+        # after the join; the groups' subtrees do not see each other, so a level's two launch pairs are independent and the two
+        # streams drift apart: one chain's diagonal phase (one busy wave per workgroup) runs beside the other's off-diagonal tiles
+        group = _subtree_groups(lp)
+        key = level * 3 + (group + 1)
+        # ... only for CHAIN-like subtrees (at most two columns of a group on a tree level: the two-chain orders of a band, e.g. the
+        # reduced camera system of bundle adjustment): a bushy level cut in two is two half-size launches, which costs more than
+        # the overlap returns (4096 poses under nd1 at batch 8: factor 0.84 -> 0.98 ms with the split, 1.39 without the streams).
+        # Same-box A/B against ONE launch pair per tree level (profiles/r6/u_ab_subtree_streams.txt, three interleaved rounds):
+        # bundle adjustment under nd13: factor 6.66 - 6.73 vs 6.85 - 6.90 ms, but 11.08 - 11.42 vs 11.19 - 11.25 ms per linear solve
+        # inside the LM loop; 4096 poses under two chains (nd98) at batch 256: factor 7.91 vs 7.43 ms.  The trunk of the tree (the
+        # separator: seven serial block columns of the camera system) has nothing to overlap with.  Kept behind the switch.
+        widest = max((int(((level == lv) & (group == g)).sum()) for lv in range(int(level.max()) + 1) for g in (0, 1)), default=0)
+        if (np.any(np.diff(key) < 0) or widest > 2 or not (group == 1).any()     # (else: levels only, everything on one stream)
+                or os.environ.get("THX_LEVEL_SUBTREES", "0") != "1"):   # MEASURED, NOT A WIN: off unless THX_LEVEL_SUBTREES=1
+            group = np.zeros(nt, dtype=np.int64)
+            key = level * 3 + 1
+        _, plevel = np.unique(key, return_inverse=True)
+        self.group = group
+        level = plevel.astype(np.int64)
+        self.level = level
         nlev = int(level.max()) + 1
         self.nlevels = nlev
         level_col = np.searchsorted(level, np.arange(nlev + 1)).astype(np.int32)
+        # stream of every launch level: 0 | 1, +4 on the first trunk level (both streams join in front of it)
+        lstream = np.array([max(int(group[level_col[lv]]), 0) for lv in range(nlev)], dtype=np.int32)
+        trunk_lv = [lv for lv in range(nlev) if group[level_col[lv]] < 0]
+        if trunk_lv and (lstream == 1).any():
+            lstream[trunk_lv[0]] |= 4
+        self.level_stream = np.ascontiguousarray(lstream)
+        self.two_streams = bool((lstream & 3 == 1).any())
         diag_kptr, diag_k = [0], []
         for j in range(nt):
             diag_k += np.nonzero(lp[j, :j])[0].tolist()
@@ -499,6 +577,13 @@ class LevelPattern:
         self.level_ent = np.ascontiguousarray(np.asarray(level_ent, dtype=np.int32))
         dk = np.diff(np.asarray(diag_kptr))
         self.level_maxk = np.ascontiguousarray(np.array([dk[level_col[lv]:level_col[lv + 1]].max() for lv in range(nlev)], dtype=np.int32))
+        # the same tables per TREE level (the solves' schedule: a tree level = one or two consecutive launch levels)
+        first = np.searchsorted(level, self.tree_level_col[:-1])          # first launch level of every tree level
+        bounds = np.concatenate([level[self.tree_level_col[:-1]], [nlev]]).astype(np.int64)
+        self.tree_level_ent = np.ascontiguousarray(self.level_ent[bounds].astype(np.int32))
+        self.tree_level_maxk = np.ascontiguousarray(np.array([self.level_maxk[bounds[t]:bounds[t + 1]].max() for t in range(self.tree_levels)],
+                                                             dtype=np.int32))
+        del first
         self.col_count = np.zeros(nt, dtype=np.int32)     # (host tables of the column-by-column schedule: not used)
         self.l_tiles = int(lp.sum())
         self.tile_products = len(tile_k) + len(diag_k) + self.l_tiles
@@ -544,9 +629,18 @@ class LevelPattern:
             ls.nlevels = self.nlevels
             ls.level_col_host, ls.level_ent_host = self.level_col.ctypes.data, self.level_ent.ctypes.data
             ls.level_maxk_host = self.level_maxk.ctypes.data
+            ls.level_stream_host = self.level_stream.ctypes.data if self.two_streams else None
             ls.ent_col, ls.tile_valid = t["ent_col"].data_ptr(), t["tile_valid"].data_ptr()
+            # the triangular solves walk TREE levels (a tree level's columns are contiguous: the stream groups only order them
+            # inside it) -- one launch per tree level and direction, on the caller's stream
+            lt = _lib.LevelSchedule()
+            lt.nlevels = self.tree_levels
+            lt.level_col_host = self.tree_level_col.ctypes.data
+            lt.level_ent_host, lt.level_maxk_host = self.tree_level_ent.ctypes.data, self.tree_level_maxk.ctypes.data
+            lt.level_stream_host = None
+            lt.ent_col, lt.tile_valid = t["ent_col"].data_ptr(), t["tile_valid"].data_ptr()
             vec = dict(pad_of_col=torch.from_numpy(self.pad_of_col).to(device), col_of_pad=torch.from_numpy(self.col_of_pad).to(device))
-            self._dev[key] = (c, ls, t, vec)
+            self._dev[key] = (c, ls, t, vec, lt)
         return self._dev[key]
 
     def c_struct(self, device) -> _lib.TilePattern:
@@ -554,6 +648,9 @@ class LevelPattern:
 
     def c_levels(self, device) -> _lib.LevelSchedule:
         return self._device(device)[1]
+
+    def c_solve_levels(self, device) -> _lib.LevelSchedule:
+        return self._device(device)[4]
 
     def vec_maps(self, device):
         return self._device(device)[3]

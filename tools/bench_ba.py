@@ -53,7 +53,7 @@ if solver.levels:
     timed("chol_backward", lambda: K.chol_solve_levels(solver.L, solver.panels, solver._yp, solver._xp, solver.pattern, which=1))
     timed("ba_backsub", lambda: K.ba_backsub(p.dstruct, lin.W, solver.Hinv, solver.tvec, solver.delta))
     dense_ms = float("nan")
-    print(f"level mode: ordering {solver.ordering_info.get('method')}, {solver.pattern.nlevels} levels over {solver.pattern.ntiles} tiles, "
+    print(f"level mode: ordering {solver.ordering_info.get('method')}, {solver.pattern.tree_levels} tree levels ({solver.pattern.nlevels} launch levels, two streams: {solver.pattern.two_streams}) over {solver.pattern.ntiles} tiles, "
           f"L tiles {solver.pattern.l_tiles}; candidates {solver.ordering_info.get('candidates')}")
 else:
   timed("ba_schur", lambda: solver.K.ba_schur(p.dstruct, lin.Hcc, lin.Hpp, lin.W, lin.gd, lam, True, 1e-8, solver.S, solver.rhs, solver.Hinv, solver.tvec, solver.info_pts))

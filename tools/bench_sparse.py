@@ -61,7 +61,7 @@ if os.environ.get("BENCH_SPARSE_PHASES", "0") == "1":   # per-phase device time 
 pat = so.linear_solver.pattern
 print(f"{P} poses / {len(edges)} edges, n = {6 * P} ({pat.ntiles} tiles), batch {B}, {dtype}: L tiles {pat.l_tiles} of "
       f"{pat.ntiles * (pat.ntiles + 1) // 2}, tile products {pat.tile_products} vs dense {pat.dense_tile_products}; ordering "
-      f"{so.linear_solver.ordering_info.get('method')}, {getattr(pat, 'nlevels', pat.ntiles)} dependent launch levels, "
+      f"{so.linear_solver.ordering_info.get('method')}, {getattr(pat, 'tree_levels', getattr(pat, 'nlevels', pat.ntiles))} dependent levels (subtree streams: {getattr(pat, 'two_streams', False)}), "
       f"{pat.flops / 1e9:.2f} GFLOP per factorisation")
 print(f"sparse: {ds / iters * 1e3:.2f} ms / LM iteration = {B * iters / ds:.0f} problem-iterations/s; error {si.err_history[:, 0].mean():.1f} -> {si.err_history[:, -1].mean():.4f}")
 if os.environ.get("BENCH_SPARSE_DENSE", "1") == "1":
