@@ -291,7 +291,7 @@ int thx_se3_retract(const void* poses, const void* delta, int64_t ldd, double st
  *        column_pairs: fp32 factorisations on dense factor frames, two block columns at a time -- diag(j), tile (j+1, j),
  *          diag(j+1), then ONE workgroup per row tile i >= j+2 produces L_ij and L_i,j+1, streaming row panel L_i,0:j from HBM
  *          once for both; 1 on, 0 off, < 0: the default (on, or THX_CHOL_COLPAIR).
- *        right_looking_max_batch: fp32 factorisations on dense factor frames (no tile pattern, ld >= ntiles * THX_TILE) of at most
+ *        right_looking_max_batch: factorisations (fp32 and fp64) on dense factor frames (no tile pattern, ld >= ntiles * THX_TILE) of at most
  *          this many problems take the RIGHT-LOOKING schedule -- per block column the tile factorisation, the substitutions and
  *          one workgroup per tile of the trailing matrix, each a single 128^3 product -- instead of the left-looking one whose
  *          serial K-loops leave the chip empty at 8 ... 64 problems (the reference's published batch range,

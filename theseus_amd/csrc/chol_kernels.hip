@@ -2461,7 +2461,8 @@ __device__ __forceinline__ void sub_mma64(const double* blk, const Engine<double
   }
 }
 
-template <bool HB>
+template <bool HB, bool RL = false>   // (RL: the right-looking schedule's modes, TilePat.rl / rl_y -- an instance of its own: in the
+                                      //  left-looking instance the extra live values spilled 268 - 700 B per lane through scratch)
 __global__ void __launch_bounds__(256, 2)
 chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, const double* __restrict__ panel, int n,
                         int64_t ld, int jarg, int ntiles, int i_first, int nrow_tiles, int B, TilePat pat, HBlk hb) {
@@ -2476,10 +2477,21 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   // (tile-sparse: i_first = first ENTRY of the launch, relative to the column's list -- level schedule: absolute, and the entry
   //  names its block column)
   const int ent = pat.col_row ? (pat.ent_col ? 0 : pat.col_ptr[jarg]) + i_first + rslot : 0;
-  const int j = pat.ent_col ? pat.ent_col[ent] : jarg;
-  const int i = pat.col_row ? pat.col_row[ent] : i_first + rslot;
+  // (right-looking schedule, TilePat.rl: see chol_offdiag_f32_kernel)
+  const bool upd = RL && pat.rl >= 2;
+  const int jc = pat.rl - 2;
+  int ui = 0, uk = 0;
+  if (RL && upd) {
+    ui = (int)((__builtin_sqrtf(8.f * (float)rslot + 1.f) - 1.f) * 0.5f);
+    while ((ui + 1) * (ui + 2) / 2 <= rslot) ++ui;
+    while (ui * (ui + 1) / 2 > rslot) --ui;
+    uk = rslot - ui * (ui + 1) / 2;
+  }
+  const int j = upd ? jc + 1 + uk : (pat.ent_col ? pat.ent_col[ent] : jarg);
+  const int i = upd ? jc + 1 + ui : (pat.col_row ? pat.col_row[ent] : i_first + rslot);
   const int32_t* klist = pat.col_row ? pat.tile_k + pat.tile_kptr[ent] : nullptr;
-  const int Kspan = pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE;
+  const int Kspan = (RL && pat.rl) ? (upd ? TILE : 0) : (pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE);
+  const int kcol0 = upd ? jc * TILE : 0;
   if (b >= B) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int rl = lane & 15, kq = lane >> 4;
@@ -2514,6 +2526,7 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   // sub-blocks 0..4 -> E by LDS-direct loads: lane l of wave w, pass u writes the 16-byte unit U = 256 u + 64 w + l of the block
   // (row r = U / 16, unit u' = U % 16) and fetches the unit u' ^ (r & 15) of that row -- the XOR swizzle sub_mma64 reads with
   auto prefetch_panel = [&]() __attribute__((always_inline)) {
+    if (upd) return;   // (trailing update: no substitution, no panel)
     constexpr int SB[5] = {0, 1, 1, 2, 2}, TB[5] = {0, 0, 1, 0, 1};
 #pragma unroll
     for (int q = 0; q < OFF64_EBLK; ++q)
@@ -2526,14 +2539,15 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
                                          16, 0, 0);
       }
   };
-  kloop<double, false>(L + lmat + (lf.packed ? 0 : (int64_t)col0 * ld), TILE, L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld), validB,
+  kloop<double, false>(L + lmat + (lf.packed ? 0 : (int64_t)col0 * ld) + kcol0, upd ? tile_rows(pat, n, j) : TILE,
+                       L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld) + kcol0, validB,
                        ldt, Kspan, sA, sB, P, tid, nullptr, nullptr, prefetch_panel, klist, ksa, ksb, lf.pstride);
   // sub-blocks 5..8 go LDS-direct into the staging buffers as soon as those are free (dense H: now, next to the H loads;
   // block-compact H: after the gather rounds), W_33 (sub-block 9) LDS-direct into sub-block 0's place in E once E has been read.
   // No panel data in registers: round 4 parked sub-blocks 5..9 (block-compact H) / W_33 (dense H) in VGPRs from here on and
   // hipcc spilled them -- 160 B per thread through scratch, 1 GB of extra HBM traffic per launch (profiles/r5/ab_, ac_).
   THX_ST64(1);   // K-loop done
-  if constexpr (!HB) {
+  if (!HB && !upd) {
     // dense H: 5..8 straight into the staging buffers (LDS-direct, no registers: the 128 VGPRs of the H tile are about to be in
     // flight) -- after a barrier: the K-loop ends on a chunk's MFMAs, a slower wave may still be reading its fragments
     __syncthreads();
@@ -2605,6 +2619,23 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   }
   }
   THX_ST64(2);   // P = H - sum
+  if (RL && upd) {   // trailing update: the tile goes back as it is (a diagonal tile: its lower triangle, zeros above)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = 32 * wave + 16 * h + rl;
+      if (r < validB) {
+        double* Lrow = Lij + (int64_t)r * ldt + kq;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+          for (int rho = 0; rho < 4; ++rho) {
+            const int c = 16 * cb + 4 * rho + kq;
+            Lrow[16 * cb + 4 * rho] = (i == j && c > r) ? 0.0 : P.v[h][cb][rho];
+          }
+      }
+    }
+    return;
+  }
   if constexpr (HB) {
     // sub-blocks 5..8 -> the staging buffers, LDS-direct, now that the gather rounds are done with them (their last barrier has
     // passed); they land under the first five block products, which read E.  E itself was requested in the prologue: every wave
@@ -2679,6 +2710,22 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
       for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
         for (int rho = 0; rho < 4; ++rho) Lrow[16 * cb + 4 * rho] = P.v[h][cb][rho];
+    }
+  }
+  if (RL && pat.rl_y) {   // right-looking forward substitution: block i of the vector loses L_ij y_j (a row's 128 columns sit in four lanes)
+    double* yb = static_cast<double*>(pat.rl_y) + (int64_t)b * pat.rl_ldv;
+    const double* yj = yb + col0 + kq;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double dot = 0.0;
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) dot += P.v[h][cb][rho] * yj[16 * cb + 4 * rho];
+      dot += __shfl_xor(dot, 16);
+      dot += __shfl_xor(dot, 32);
+      const int r = 32 * wave + 16 * h + rl;
+      if (kq == 0 && r < validB) yb[row0 + r] -= dot;
     }
   }
 #ifdef THX_OFF_PROF64
@@ -3148,6 +3195,10 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<false, true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<true, true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
     ds.attr_off = true;
   }
   hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)B, st);
@@ -3425,7 +3476,7 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     if (rest_pending) hipStreamWaitEvent(st, ds.ev_rest, 0);
     return check_launch("thx_chol_factor");
   }
-  // RIGHT-LOOKING SCHEDULE for SMALL dense batches (fp32, dense L frame without a tile pattern, whole tiles inside the frame, up to
+  // RIGHT-LOOKING SCHEDULE for SMALL dense batches (dense L frame without a tile pattern, whole tiles inside the frame, up to
   // thx_chol_schedule.right_looking_max_batch problems).  Left-looking, block column j is two dependent launches whose workgroups
   // walk K-loops of j tiles -- the diagonal one with ONE workgroup per problem: at 8 ... 64 problems the chip is 3 ... 25 % occupied
   // and a factorisation is the sum of those serial K-loops (n = 1536, batch 8: 1.62 ms, 0.04 of the MFMA peak).  Here every tile
@@ -3435,7 +3486,7 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   // tiles is added once after that update.  Same tile kernels, another summation order: the factor differs from the left-looking
   // one in the last bits (tests: against LAPACK and against the left-looking solution).  The forward substitution runs as its
   // own kernel afterwards.
-  if constexpr (sizeof(T) == 4) {
+  {
     if (!tp && !packed && !split && fused_diag && ntiles >= 3 && B <= rl_max_batch && ld >= (int64_t)ntiles * TILE &&
         (!use_hb || !damping || hb.diag_blk)) {
       if (dsm > ds.attr_diag[ti][0]) {   // (the later columns run the dense-frame instance on the L frame whatever H is)
@@ -3457,50 +3508,54 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
         p0.rl_y = p1.rl_y = y;
         p0.rl_ldv = p1.rl_ldv = ldv;
       }
-      const float* yc = fwd_fused ? (const float*)y : nullptr;
       const HBlk nohb{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr};
-      const float* Lc = (const float*)L;
+      const T* Lc = (const T*)L;
+      const T* yc = fwd_fused ? (const T*)y : nullptr;
       const size_t dsm0 = DiagSmem<T>::bytes(0);
+      // one chol_offdiag launch: nrt workgroup slots per problem (row tiles / update tiles), H from the block list, the dense H
+      // frame or the L frame
+      auto off = [&](bool hbsrc, const T* Hsrc, int jarg, int i_first, int nrt, const TilePat& pp) {
+        if constexpr (sizeof(T) == 4) {
+          if (hbsrc)
+            hipLaunchKernelGGL(chol_offdiag_f32_kernel<true>, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, st, (const float*)nullptr, (float*)L,
+                               (const float*)panel, n, ld, jarg, ntiles, i_first, nrt, B, pp, hb);
+          else
+            hipLaunchKernelGGL(chol_offdiag_f32_kernel<false>, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, st, (const float*)Hsrc, (float*)L,
+                               (const float*)panel, n, ld, jarg, ntiles, i_first, nrt, B, pp, nohb);
+        } else {
+          if (hbsrc)
+            hipLaunchKernelGGL((chol_offdiag_f64_kernel<true, true>), dim3(Bpad * nrt), dim3(256), OFF64_SMEM, st, (const double*)nullptr, (double*)L,
+                               (const double*)panel, n, ld, jarg, ntiles, i_first, nrt, B, pp, hb);
+          else
+            hipLaunchKernelGGL((chol_offdiag_f64_kernel<false, true>), dim3(Bpad * nrt), dim3(256), OFF64_SMEM, st, (const double*)Hsrc, (double*)L,
+                               (const double*)panel, n, ld, jarg, ntiles, i_first, nrt, B, pp, nohb);
+        }
+      };
       auto upd = [&](int jc, bool first) {
         const int m = ntiles - 1 - jc;
         TilePat pu = pat;
         pu.rl = 2 + jc;
-        if (first && use_hb)
-          hipLaunchKernelGGL(chol_offdiag_f32_kernel<true>, dim3(Bpad * (m * (m + 1) / 2)), dim3(256), OFF32_SMEM, st, (const float*)nullptr,
-                             (float*)L, (const float*)panel, n, ld, jc, ntiles, 0, m * (m + 1) / 2, B, pu, hb);
-        else
-          hipLaunchKernelGGL(chol_offdiag_f32_kernel<false>, dim3(Bpad * (m * (m + 1) / 2)), dim3(256), OFF32_SMEM, st,
-                             first ? (const float*)H : Lc, (float*)L, (const float*)panel, n, ld, jc, ntiles, 0, m * (m + 1) / 2, B, pu, nohb);
+        off(first && use_hb, first ? (const T*)H : Lc, jc, 0, m * (m + 1) / 2, pu);
       };
       // block column 0: the kernels as they are (no earlier columns), reading H
       launch_diag_n(h, 0, 1, true, dsm);   // (with a right-hand side: y_0 = W_00 g_0 -- kept when the forward substitution is fused)
-      if (use_hb)
-        hipLaunchKernelGGL(chol_offdiag_f32_kernel<true>, dim3(Bpad * (ntiles - 1)), dim3(256), OFF32_SMEM, st, (const float*)nullptr,
-                           (float*)L, (const float*)panel, n, ld, 0, ntiles, 1, ntiles - 1, B, p0, hb);
-      else
-        hipLaunchKernelGGL(chol_offdiag_f32_kernel<false>, dim3(Bpad * (ntiles - 1)), dim3(256), OFF32_SMEM, st, (const float*)H,
-                           (float*)L, (const float*)panel, n, ld, 0, ntiles, 1, ntiles - 1, B, p0, nohb);
+      off(use_hb, (const T*)H, 0, 1, ntiles - 1, p0);
       upd(0, true);
       if (damping)
-        hipLaunchKernelGGL(rl_damp_kernel<float>, dim3((n - TILE + 255) / 256, B), dim3(256), 0, st, (float*)L, ld, (const float*)H, ld, hb,
-                           (const float*)damping, ellipsoidal, (float)eps, TILE, n);
+        hipLaunchKernelGGL(rl_damp_kernel<T>, dim3((n - TILE + 255) / 256, B), dim3(256), 0, st, (T*)L, ld, (const T*)H, ld, hb,
+                           (const T*)damping, ellipsoidal, (T)eps, TILE, n);
       for (int j = 1; j < ntiles; ++j) {
-        hipLaunchKernelGGL((chol_diag_kernel<float, false>), dim3(B, 1), dim3(256), fwd_fused ? dsm : dsm0, st, Lc, (float*)L,
-                           (float*)panel, (const float*)nullptr, 0, 0.f, info, n, ld, j, ntiles, yc, (float*)(fwd_fused ? y : nullptr), ldv,
+        hipLaunchKernelGGL((chol_diag_kernel<T, false>), dim3(B, 1), dim3(256), fwd_fused ? dsm : dsm0, st, Lc, (T*)L,
+                           (T*)panel, (const T*)nullptr, 0, T(0), info, n, ld, j, ntiles, yc, (T*)(fwd_fused ? y : nullptr), ldv,
                            p1, nohb);
         if (j + 1 == ntiles) break;
-        hipLaunchKernelGGL(chol_offdiag_f32_kernel<false>, dim3(Bpad * (ntiles - 1 - j)), dim3(256), OFF32_SMEM, st, Lc, (float*)L,
-                           (const float*)panel, n, ld, j, ntiles, j + 1, ntiles - 1 - j, B, p1, nohb);
+        off(false, Lc, j, j + 1, ntiles - 1 - j, p1);
         upd(j, false);
       }
       if (int r = check_launch("thx_chol_factor (right-looking)")) return r;
       return (rhs && !fwd_fused) ? 1000 : 0;   // (1000: the caller runs the forward substitution as its own kernel)
     }
   }
-  // COLUMN PAIRS (fp32, dense L frame without a tile pattern; THX_CHOL_COLPAIR=0 / thx_chol_schedule.column_pairs = 0 turn them off): block columns j, j + 1 with row
-  // tiles below j + 1 run as  diag(j) -> tile (j + 1, j) alone -> diag(j + 1) -> one chol_offdiag2 workgroup per row tile i >= j + 2
-  // producing (i, j) and (i, j + 1) -- the same arithmetic in the same order, so the factor is bit-identical to the
-  // column-by-column schedule; the row panels are streamed from HBM once per pair.
   // (pairs from 128 problems per call on: the pair schedule's chain per two columns is diag, head tile, diag, pair tiles -- one
   //  more dependent launch than two plain columns -- and below ~128 problems the launches are too small to pay for it: n = 1536,
   //  batch 8 / 16 / 32 / 64: 1.62 / 1.64 / 1.67 / 1.85 ms with pairs, 1.42 / 1.44 / 1.50 / 1.73 ms without; 128: 2.25 / 2.23; 256:

@@ -1,6 +1,6 @@
 """Dense Cholesky at the reference's batch sizes (256 poses / 1024 edges, batch 8 ... 256): the left-looking schedule against the
 right-looking one (thx_chol_schedule.right_looking_max_batch) and column pairs on / off, same process, same inputs.
-usage: python tools/ab_small_batch.py [batches, default 8,16,32,64,128,256]"""
+usage: python tools/ab_small_batch.py [batches, default 8,16,32,64,128,256] [f32|f64]"""
 import os
 import sys
 import time
@@ -10,7 +10,9 @@ import torch
 import theseus_amd as th
 from theseus_amd.utils import synthetic as syn
 
-P, E, iters, dtype, dev = 256, 1024, 10, torch.float32, "cuda"
+P, E, iters, dev = 256, 1024, 10, "cuda"
+dtype = {"f32": torch.float32, "f64": torch.float64}[sys.argv[2] if len(sys.argv) > 2 else "f32"]
+PEAK = 157.3 if dtype == torch.float32 else 78.6
 n = 6 * P
 batches = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "8,16,32,64,128,256").split(",")]
 edges = syn.pose_graph_topology(P, E, topology_seed=0)
@@ -52,6 +54,6 @@ for B in batches:
             K.chol_column_pairs(prev[1])
         tf = B * n ** 3 / 3.0 / (fac * 1e-3) / 1e12
         print(f"batch {B:4d} {name:24s}: {best:7.3f} ms / LM iteration, factor + forward {fac:7.3f} ms = {tf:6.1f} TFLOP/s "
-              f"({tf / 157.3:.3f} of peak); error {float(info.err_history[:, 0].mean()):.1f} -> "
+              f"({tf / PEAK:.3f} of peak); error {float(info.err_history[:, 0].mean()):.1f} -> "
               f"{float(info.err_history[:, info.iters_done].mean()):.4f}", flush=True)
         del sol, info, layer, opt, obj
