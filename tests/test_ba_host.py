@@ -138,3 +138,99 @@ def test_camera_camera_costs_av_rows_and_dogleg():
     with torch.no_grad():
         _, info = th.TheseusLayer(opt).forward(None, optimizer_kwargs=dict(track_err_history=True, trust_region_init=2.0))
     assert (info.err_history[:, -1] < info.err_history[:, 0]).all()
+
+
+# ---- round 6: the reduced camera system as a block list in a dissection order of the cameras (level mode) -- the HOST side ----
+class _LevelStandIns:
+    """CPU stand-ins of the four kernels the level mode of HipSchurSolver adds (mixed into OracleKernels): thx_ba_schur_blocks as
+    the dense-frame stand-in + a scatter by the solver's block tables (incl. the transposed blocks), thx_chol_factor_levels /
+    thx_chol_solve_levels as a dense Cholesky of the matrix the PADDED piece tables describe (identity on the padding), and
+    thx_vec_gather.  What they check is every table the host builds: block ids, transposition flags, piece tables, vector maps."""
+
+    def ba_schur_blocks(self, s, Hcc, Hpp, W, g, damping, ellipsoidal, damping_eps, Sc, diag_blk, blk_dst, rhs, Hinv, tvec, info):
+        h = s.host
+        C, K = h.num_cams, h.num_blocks
+        S = torch.zeros(g.shape[0], 6 * C, 6 * C, dtype=Sc.dtype)
+        self.ba_schur(s, Hcc, Hpp, W, g, damping, ellipsoidal, damping_eps, S, rhs, Hinv, tvec, info)
+        Sc.zero_()
+        blocks = Sc[:, :36 * (C + K)].view(-1, C + K, 6, 6)
+        for c in range(C):
+            blocks[:, int(diag_blk[c])] = S[:, 6 * c:6 * c + 6, 6 * c:6 * c + 6]
+        c1, c2 = h.t["blk_c1"][:K].astype("int64"), h.t["blk_c2"][:K].astype("int64")
+        for k in range(K):
+            d = int(blk_dst[k])
+            blk = S[:, 6 * c1[k]:6 * c1[k] + 6, 6 * c2[k]:6 * c2[k] + 6]
+            blocks[:, d & 0x3fffffff] = blk.transpose(1, 2) if (d >> 30) & 1 else blk
+
+    def _padded_dense(self, layout, Hc, pattern):
+        T, nt = 128, pattern.ntiles
+        tile_ptr, piece_blk, piece_rc = (layout.t[k].numpy() for k in ("tile_ptr", "piece_blk", "piece_rc"))
+        A = torch.zeros(Hc.shape[0], nt * T, nt * T, dtype=Hc.dtype)
+        for ti in range(nt):
+            for tj in range(ti + 1):
+                t = ti * (ti + 1) // 2 + tj
+                for pc in range(tile_ptr[t], tile_ptr[t + 1]):
+                    rc = int(piece_rc[pc]) & 0xFFFFFFFF
+                    r, c = rc >> 16, rc & 0xFFFF
+                    blk = Hc[:, 36 * int(piece_blk[pc]):36 * int(piece_blk[pc]) + 36].view(-1, 6, 6)
+                    A[:, T * ti + r:T * ti + r + 6, T * tj + c:T * tj + c + 6] = blk
+        A = torch.tril(A) + torch.tril(A, -1).transpose(1, 2)
+        pad = torch.from_numpy(pattern.col_of_pad < 0)
+        A[:, pad, pad] = 1.0
+        return A
+
+    def chol_factor_levels(self, layout, Hc, damping, ellipsoidal, damping_eps, L, panels, info, pattern, rhs=None, y=None):
+        assert damping is None
+        Ld, inf = torch.linalg.cholesky_ex(self._padded_dense(layout, Hc, pattern))
+        info.copy_(inf.to(info.dtype))
+        self._Ld = Ld
+        if rhs is not None:
+            y.copy_(torch.linalg.solve_triangular(Ld, rhs.unsqueeze(2), upper=False).squeeze(2))
+
+    def chol_solve_levels(self, L, panels, rhs, x, pattern, which=0):
+        v = rhs.unsqueeze(2)
+        if which in (0, 2):
+            v = torch.linalg.solve_triangular(self._Ld, v, upper=False)
+        if which in (0, 1):
+            v = torch.linalg.solve_triangular(self._Ld.transpose(1, 2), v, upper=True)
+        x.copy_(v.squeeze(2))
+
+    def vec_gather(self, src, dst, idx):
+        i = idx.long()
+        dst.copy_(torch.where(i >= 0, src[:, i.clamp(min=0)], torch.zeros((), dtype=src.dtype)))
+
+
+def test_level_mode_tables_give_the_dense_frames_solution():
+    """96 cameras on a line (5 padded tiles, a real dissection: cameras change places, some camera pairs are stored transposed):
+    HipSchurSolver(ordering="nd") through the stand-ins above takes the same LM steps as the natural order on the dense frame --
+    and its cached-factor solve (the implicit backward's) the same as well."""
+    import theseus_amd as th
+    from tests.oracle_kernels import OracleKernels
+    from theseus_amd.utils.synthetic_ba import make_ba_objective
+
+    class K2(_LevelStandIns, OracleKernels):
+        pass
+    out = {}
+    for ordering in ("natural", "nd"):
+        K = K2()
+        obj, meta = make_ba_objective(96, 768, 2, track_length=4, dtype=torch.float64, device="cpu", seed=1, kernels=K)
+        opt = th.LevenbergMarquardt(obj, max_iterations=2, abs_err_tolerance=0.0, rel_err_tolerance=0.0,
+                                    linearization_kwargs=dict(kernels=K), linear_solver_kwargs=dict(ordering=ordering))
+        solver = opt.linear_solver
+        with torch.no_grad():
+            info = opt.optimize(damping=1e-2, adaptive_damping=True, ellipsoidal_damping=True, track_err_history=True)
+            r = torch.randn(2, solver.linearization.n, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+            w = solver.solve_with_factor(r)
+        assert solver.levels == (ordering == "nd")
+        if solver.levels:
+            t = solver._level_t
+            dst = t["blk_dst"].numpy()
+            assert ((dst >> 30) & 1).any() and not ((dst >> 30) & 1).all()          # some pairs transposed, not all
+            pat = solver.pattern
+            assert pat.ntiles == 5 and pat.tree_levels < pat.ntiles
+            poc, cop = t["pad_of_col"].numpy(), t["col_of_pad"].numpy()
+            assert np.array_equal(cop[poc], np.arange(6 * 96)) and (cop < 0).sum() == pat.npad - 6 * 96
+        out[ordering] = (solver.delta.clone(), info.err_history.clone(), w)
+    np.testing.assert_allclose(out["nd"][0].numpy(), out["natural"][0].numpy(), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(out["nd"][1].numpy(), out["natural"][1].numpy(), rtol=1e-11)
+    np.testing.assert_allclose(out["nd"][2].numpy(), out["natural"][2].numpy(), rtol=0, atol=1e-9 * float(out["natural"][2].abs().max()))

@@ -266,3 +266,21 @@ def test_level_schedule_emulated_on_the_host_solves_the_system():
     x = y[pat.pad_of_col]
     np.testing.assert_allclose(x, np.linalg.solve(A, g), rtol=0, atol=1e-11)
     assert np.abs(y[pat.col_of_pad < 0]).max() == 0.0                               # padding stays exactly zero
+
+
+def test_subtree_groups_of_the_tile_elimination_tree():
+    """Stream groups for thx_level_schedule.level_stream_host: a band is one chain (no split); two chains towards a separator are
+    groups 0 / 1 with the separator's chain as the trunk (-1); a subtree never shares a K-list with the other group."""
+    from theseus_amd.sparse import _subtree_groups, _symbolic_tiles
+    nt = 9
+    band = np.eye(nt, dtype=bool) | np.eye(nt, k=-1, dtype=bool)
+    assert _subtree_groups(_symbolic_tiles(band)[0]).tolist() == [0] * nt
+    # columns 0-2 and 3-5: two chains; 6-8: the separator chain both end in
+    lp0 = np.eye(nt, dtype=bool)
+    for a, b in ((1, 0), (2, 1), (4, 3), (5, 4), (6, 2), (6, 5), (7, 6), (8, 7)):
+        lp0[a, b] = True
+    lp, level = _symbolic_tiles(lp0)
+    g = _subtree_groups(lp)
+    assert g[6:].tolist() == [-1, -1, -1] and sorted({tuple(g[:3].tolist()), tuple(g[3:6].tolist())}) == [(0, 0, 0), (1, 1, 1)]
+    for j in range(6):                                   # a column's K-list (its row of L) stays inside its own group
+        assert all(g[k] == g[j] for k in np.nonzero(lp[j, :j])[0])
