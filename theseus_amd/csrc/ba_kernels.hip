@@ -311,9 +311,9 @@ __device__ __forceinline__ void store_block36(T* __restrict__ p, const double* v
   }
 }
 
-// where thx_ba_schur_blocks puts the blocks of S (blk_dst == nullptr: the dense frame of thx_ba_schur)
+// where thx_ba_schur_blocks puts the blocks of S (diag_blk == nullptr: the dense frame of thx_ba_schur)
 struct SchurBlockDst {
-  const int32_t* diag_blk;   // (C): block id of S_cc
+  const int32_t* diag_blk;   // (C): block id of S_cc; nullptr: the dense frame of thx_ba_schur
   const int32_t* blk_dst;    // (num_blocks): block id of the k-th camera pair | bit 30: stored transposed
   int64_t bstride;           // elements per problem
 };
@@ -357,7 +357,7 @@ ba_schur_block_kernel(thx_ba_structure s, int B, const double* __restrict__ W, c
       for (int c = 0; c < 6; ++c)
         Off[6 * r + c] -= M[3 * r] * W2[3 * c] + M[3 * r + 1] * W2[3 * c + 1] + M[3 * r + 2] * W2[3 * c + 2];
   }
-  if (bl.blk_dst) {   // (block uniform)
+  if (bl.diag_blk) {   // (block list; block uniform)
     const int d = bl.blk_dst[k];
     store_block36(S + (int64_t)b * bl.bstride + (int64_t)(d & 0x3fffffff) * 36, Off, ((d >> 30) & 1) != 0);
     return;
@@ -418,7 +418,7 @@ ba_schur_kernel(thx_ba_structure s, int B, const double* __restrict__ Hcc, const
       for (int c = 0; c < 6; ++c)
         Dg[6 * r + c] -= M[3 * r] * W2[3 * c] + M[3 * r + 1] * W2[3 * c + 1] + M[3 * r + 2] * W2[3 * c + 2];
   }
-  if (bl.blk_dst) {
+  if (bl.diag_blk) {
     store_block36(S + (int64_t)b * bl.bstride + (int64_t)bl.diag_blk[c1] * 36, Dg, false);
   } else {
     const bool pairs = (ld & 1) == 0;
@@ -751,9 +751,8 @@ int thx_ba_schur_blocks(const thx_ba_structure* s, int32_t B, const void* Hcc, c
   if (s->num_blocks > 0 && !blk_dst) return fail("thx_ba_schur_blocks: blk_dst missing");
   if (bstride < 36 * ((int64_t)s->num_cams + s->num_blocks) || (bstride & 3) != 0 || ldr < 6 * (int64_t)s->num_cams)
     return fail("thx_ba_schur_blocks: bstride (36 elements per block, a multiple of 4) / ldr < 6 C");
-  static const int32_t none = 0;   // (kernels test blk_dst for the mode: a structure without camera pairs still writes the diagonal blocks)
   return ba_schur_impl(s, B, Hcc, Hpp, W, gd, ldv, damping, ellipsoidal, damping_eps, Sc, 0, rhs, ldr, Hinv, tvec, info, dtype,
-                       stream, SchurBlockDst{diag_blk, blk_dst ? blk_dst : &none, bstride}, "thx_ba_schur_blocks");
+                       stream, SchurBlockDst{diag_blk, blk_dst, bstride}, "thx_ba_schur_blocks");
 }
 
 int thx_ba_backsub(const thx_ba_structure* s, int32_t B, const void* W, const void* Hinv, const void* tvec, void* delta,

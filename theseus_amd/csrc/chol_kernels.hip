@@ -3077,6 +3077,7 @@ __global__ void vec_gather_kernel(const T* __restrict__ src, int64_t lds, T* __r
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
+constexpr int FACTOR_NEEDS_FORWARD = 1000;   // factor_impl -> factor_then_forward: factor done, y = L^-1 rhs still to be computed
 
 // Defaults of the per-call schedule (thx_chol_schedule; a negative field / a NULL pointer selects them): read once from the
 // environment, never written afterwards -- the library keeps no mutable schedule state, two callers with different schedules in
@@ -3495,7 +3496,7 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       }
       const Half h{st, 0, B};
       const int Bpad = (B + 7) / 8 * 8;
-      // forward substitution riding on the schedule (vectors with 16-byte rows; else its own kernel afterwards, code 1000): y starts
+      // forward substitution riding on the schedule (vectors with 16-byte rows; else its own kernel afterwards, FACTOR_NEEDS_FORWARD): y starts
       // as a copy of g; chol_diag(j) turns block j into y_j in place, the substitution tiles of column j update the blocks below
       const bool fwd_fused = rhs && (ldv % 4) == 0 && (reinterpret_cast<uintptr_t>(y) % 16) == 0;
       if (fwd_fused) {
@@ -3553,7 +3554,7 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
         upd(j, false);
       }
       if (int r = check_launch("thx_chol_factor (right-looking)")) return r;
-      return (rhs && !fwd_fused) ? 1000 : 0;   // (1000: the caller runs the forward substitution as its own kernel)
+      return (rhs && !fwd_fused) ? FACTOR_NEEDS_FORWARD : 0;   // (the caller runs the forward substitution as its own kernel)
     }
   }
   // (pairs from 128 problems per call on: the pair schedule's chain per two columns is diag, head tile, diag, pair tiles -- one
@@ -3697,13 +3698,13 @@ static int solve_impl(const void* L, int64_t ld, int n, int B, const void* panel
   return check_launch("thx_chol_solve");
 }
 
-// factor_impl + (right-looking schedule: return code 1000) the forward substitution as its own kernel -- outside factor_impl's
+// factor_impl + (right-looking schedule: return code FACTOR_NEEDS_FORWARD) the forward substitution as its own kernel -- outside factor_impl's
 // launch lock, which solve_impl takes itself
 template <typename T, typename... A>
 static int factor_then_forward(const void* H, int64_t ld, int n, int B, const void* damping, int ellipsoidal, double eps, void* L,
                                void* panel, int32_t* info, const void* rhs, void* y, int64_t ldv, hipStream_t st, A... more) {
   const int r = factor_impl<T>(H, ld, n, B, damping, ellipsoidal, eps, L, panel, info, rhs, y, ldv, st, more...);
-  if (r != 1000) return r;
+  if (r != FACTOR_NEEDS_FORWARD) return r;
   return solve_impl<T>(L, ld, n, B, panel, rhs, y, ldv, true, false, st);
 }
 
