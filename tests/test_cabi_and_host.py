@@ -48,6 +48,24 @@ def test_bad_arguments_are_rejected_without_a_gpu(lib_path):
     assert rc != 0 and b"ld" in lib.thx_last_error()
     rc = lib.thx_chol_factor(one, 32, 6, 1, None, 0, 1e-8, one, one, one, 7, None, None)  # bad dtype
     assert rc != 0 and b"dtype" in lib.thx_last_error()
+    # round 6 entry points: thx_ba_schur_blocks (block list too short / no block tables), thx_vec_gather (aliasing), the level pair
+    s = _lib.BAStructure()
+    s.num_cams, s.num_points, s.num_blocks = 4, 8, 3
+    args = lambda sc, bstride, diag, dst: (ctypes.byref(s), 2, one, one, one, one, 48, None, 0, 1e-8, sc, bstride, diag, dst, one, 24,  # noqa: E731
+                                           one, one, one, 0, None)
+    rc = lib.thx_ba_schur_blocks(*args(one, 36 * 7, None, one))
+    assert rc != 0 and b"null argument" in lib.thx_last_error()
+    rc = lib.thx_ba_schur_blocks(*args(one, 36 * 7, one, None))
+    assert rc != 0 and b"blk_dst" in lib.thx_last_error()
+    rc = lib.thx_ba_schur_blocks(*args(one, 36 * 6, one, one))        # 4 diagonal + 3 pair blocks need 36 * 7 elements
+    assert rc != 0 and b"bstride" in lib.thx_last_error()
+    rc = lib.thx_vec_gather(one, 8, one, 8, one, 8, 2, 0, None)          # src == dst
+    assert rc != 0 and b"bad args" in lib.thx_last_error()
+    rc = lib.thx_chol_factor_levels(None, one, 36, 2, None, 0, 1e-8, one, one, one, None, None, 0, None, None, 0, None, None)
+    assert rc != 0 and b"block layout" in lib.thx_last_error()
+    sched = _lib.CholSchedule(-1, -1, -1)                                # (a schedule does not rescue bad arguments)
+    rc = lib.thx_chol_factor(one, 33, 6, 1, None, 0, 1e-8, one, one, one, 0, None, ctypes.byref(sched))
+    assert rc != 0 and b"ld" in lib.thx_last_error()
 
 
 def test_product_has_no_cpu_fallback():
