@@ -781,6 +781,7 @@ def gen_pg_unrolled(th, lieF):
 
 
 MIXED_LOSSES = (None, "welsch", "huber", "welsch+flatten", "huber+flatten")
+MIXED_LOSSES_HINGE = ("hinge", None, "hinge+flatten", "huber", "hinge")    # (round 6: HingeLoss, robust_loss.py:55-62)
 
 
 def gen_pg_mixed_robust(th, lieF):
@@ -791,7 +792,8 @@ def gen_pg_mixed_robust(th, lieF):
     radii spread around the initial squared errors so that inliers, the knee and outliers all occur.  Recorded: the first linearization, the error metric, a damped LM run, and the gradients of
     TheseusLayer(backward_mode="implicit") w.r.t. measurements, weights, prior targets and every log_loss_radius."""
     dtype = torch.float64
-    for name, G, iters in (("pg_f64_mixed_robust", "SE3", 6), ("pg2_f64_mixed_robust", "SE2", 6)):
+    for name, G, iters in (("pg_f64_mixed_robust", "SE3", 6), ("pg2_f64_mixed_robust", "SE2", 6), ("pg_f64_mixed_hinge", "SE3", 6)):
+        mixed = MIXED_LOSSES_HINGE if name.endswith("hinge") else MIXED_LOSSES
         if G == "SE3":
             d = make_problem(dtype=dtype, th=th, lieF=lieF, P=8, E=15, B=3, seed=41, batched_weights=True, pose_noise=(0.3, 0.25))
             grp = th.SE3
@@ -809,15 +811,15 @@ def gen_pg_mixed_robust(th, lieF):
         wb = d["w_between"].clone().requires_grad_(True)
         tgt = d["prior_target"].clone().requires_grad_(True)
         wp = d["w_prior"][:, :, :1].clone().requires_grad_(True)
-        loss_b = [MIXED_LOSSES[k % 5] for k in range(E)]
-        loss_p = ["welsch+flatten"] + [None] * (Kp - 1)
+        loss_b = [mixed[k % 5] for k in range(E)]
+        loss_p = (["hinge+flatten"] if name.endswith("hinge") else ["welsch+flatten"]) + [None] * (Kp - 1)
         # radii: log of (typical squared weighted error) * lognormal spread; batched for odd k
         lr_b = (torch.full((B, E, 1), 4.0, dtype=dtype) + 2.0 * torch.randn(B, E, 1, dtype=dtype, generator=gen))
         shared_b = [k % 2 == 0 or (loss_b[k] or "").endswith("+flatten") for k in range(E)]   # radius stored (1, 1)
         lr_b[:, shared_b] = lr_b[:1, shared_b]
         lr_p = (torch.full((1, Kp, 1), -6.0, dtype=dtype) + torch.randn(1, Kp, 1, dtype=dtype, generator=gen)).repeat(B, 1, 1)
         lr_b, lr_p = lr_b.requires_grad_(True), lr_p.requires_grad_(True)
-        LOSS = {"welsch": th.WelschLoss, "huber": th.HuberLoss}
+        LOSS = {"welsch": th.WelschLoss, "huber": th.HuberLoss, "hinge": th.HingeLoss}
 
         def wrap(cf, spec, radius, nm):
             if spec is None:
@@ -851,6 +853,8 @@ def gen_pg_mixed_robust(th, lieF):
         final = torch.stack([sol[f"pose_{k}"] for k in range(P)], 1)
         loss = (coef * final).sum()
         loss.backward()
+        # (a HingeLoss radius only selects the branch of a torch.where: no autograd path -- .grad stays None: recorded as zeros)
+        gz = lambda t: t.grad if t.grad is not None else torch.zeros_like(t)  # noqa: E731
         np.savez_compressed(
             os.path.join(OUT, name + ".npz"),
             group=np.array(G), P=P, edges=d["edges"].numpy(), meas=d["meas"].numpy(), w_between=d["w_between"].numpy(),
@@ -860,10 +864,10 @@ def gen_pg_mixed_robust(th, lieF):
             A0=A0, b0=b0, err0=err0, errvec0=errvec0, err_history=info.err_history.numpy(),
             final=final.detach().numpy(), coef=coef.numpy(), loss=loss.item(),
             grad_meas=meas.grad.numpy(), grad_w_between=wb.grad.numpy(), grad_prior_target=tgt.grad.numpy(),
-            grad_w_prior=wp.grad.numpy(), grad_log_radius_between=lr_b.grad.numpy(), grad_log_radius_prior=lr_p.grad.numpy(),
+            grad_w_prior=wp.grad.numpy(), grad_log_radius_between=gz(lr_b).numpy(), grad_log_radius_prior=gz(lr_p).numpy(),
             opt_kwargs=np.array(repr(dict(max_iterations=iters, step_size=1.0, damping=1e-2, gauss_newton=False))))
         print(name, "err", err0.mean(), "->", info.err_history[:, -1].mean().item(), "loss", loss.item(),
-              "|grad_lr|", lr_b.grad.abs().max().item(), lr_p.grad.abs().max().item())
+              "|grad_lr|", gz(lr_b).abs().max().item(), gz(lr_p).abs().max().item())
 
 
 def gen_implicit(th, lieF):

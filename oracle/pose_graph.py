@@ -133,6 +133,8 @@ def loss_evaluate(kind, x, log_radius):
         return r - r * torch.exp(-x / (r + _LOSS_EPS))
     if kind == "huber":
         return torch.where(x > r, 2 * torch.sqrt(r * torch.maximum(x, r) + _LOSS_EPS) - r, x)
+    if kind == "hinge":          # robust_loss.py:56-58
+        return torch.where(x > r, torch.sqrt(x) - torch.sqrt(r), torch.full_like(x, _LOSS_EPS))
     raise ValueError(kind)
 
 
@@ -143,16 +145,18 @@ def loss_linearize(kind, x, log_radius):
         return torch.exp(-x / (r + _LOSS_EPS))
     if kind == "huber":
         return torch.sqrt(r / torch.maximum(x, r) + _LOSS_EPS)
+    if kind == "hinge":          # robust_loss.py:60-62
+        return torch.where(x > r, 1.0 / (2 * torch.sqrt(x) + _LOSS_EPS), torch.zeros_like(x))
     raise ValueError(kind)
 
 
 def _per_cost(kind, count):
-    """A loss spec -- None | "welsch" | "huber" [+ "+flatten" for flatten_dims=True], or one such entry per cost of the role
-    (plain, Welsch, Huber and flattened costs mixed) -- as (count, 1) tensors: kind index 0/1/2, flatten flag."""
+    """A loss spec -- None | "welsch" | "huber" | "hinge" [+ "+flatten" for flatten_dims=True], or one such entry per cost of the role
+    (plain, Welsch, Huber and flattened costs mixed) -- as (count, 1) tensors: kind index 0/1/2/3, flatten flag."""
     specs = [kind] * count if kind is None or isinstance(kind, str) else list(kind)
     if len(specs) != count:
         raise ValueError("one loss spec per cost")
-    k = torch.tensor([0 if s is None else {"welsch": 1, "huber": 2}[s.split("+")[0]] for s in specs]).view(count, 1)
+    k = torch.tensor([0 if s is None else {"welsch": 1, "huber": 2, "hinge": 3}[s.split("+")[0]] for s in specs]).view(count, 1)
     f = torch.tensor([s is not None and s.endswith("+flatten") for s in specs]).view(count, 1)
     return k, f
 
@@ -162,7 +166,7 @@ def _simple(kind):
 
 
 def _both(fn, k, x, log_radius):
-    return torch.where(k == 1, fn("welsch", x, log_radius), fn("huber", x, log_radius))
+    return torch.where(k == 1, fn("welsch", x, log_radius), torch.where(k == 3, fn("hinge", x, log_radius), fn("huber", x, log_radius)))
 
 
 def robust_rescale(jacs, e, kind, log_radius):

@@ -43,7 +43,7 @@ def run_mixed_implicit(th, g, device, kernels=None, dtype=torch.float64, backwar
                   log_radius_between=t(g["log_radius_between"]).requires_grad_(backward),
                   log_radius_prior=t(g["log_radius_prior"]).requires_grad_(backward))
     G = {"SE2": th.SE2, "SO3": th.SO3}.get(str(g["group"]), th.SE3)
-    LOSS = {"welsch": th.WelschLoss, "huber": th.HuberLoss}
+    LOSS = {"welsch": th.WelschLoss, "huber": th.HuberLoss, "hinge": th.HingeLoss}
 
     def wrap(cf, spec, radius, shared, nm):
         if spec is None:
@@ -101,5 +101,6 @@ def check_grads(g, grads, rel, keys=None):
             continue
         want = g[ref]
         got = grads[key].double().numpy()
-        scale = np.abs(want).max()
+        # (a HingeLoss radius has no gradient: the reference records autograd noise of ~1e-23 there -- an absolute floor)
+        scale = max(np.abs(want).max(), 1e-12)
         assert np.abs(got - want).max() <= rel * scale, (key, np.abs(got - want).max() / scale)

@@ -335,7 +335,7 @@ def test_so2_pose_graph_matches_reference(name, tol):
                                        atol=tol * max(1.0, np.abs(g["delta"][it]).max()))
 
 
-@pytest.mark.parametrize("name", ["pg_f64_mixed_robust", "pg2_f64_mixed_robust"])
+@pytest.mark.parametrize("name", ["pg_f64_mixed_robust", "pg2_f64_mixed_robust", "pg_f64_mixed_hinge"])
 def test_mixed_robust_objective_matches_reference(name):
     """Plain, Welsch, Huber and flatten_dims=True costs mixed inside one role (theseus/core/robust_cost_function.py:52-135):
     the oracle's per-cost loss specs against the REAL reference -- first linearization, error vector / metric, the damped LM
@@ -375,7 +375,8 @@ def test_mixed_robust_objective_matches_reference(name):
     assert abs(loss.item() - float(g["loss"])) < 1e-6
     for key, ref in GRAD_KEYS:
         got, want = leaves[key].grad.numpy(), g[ref]
-        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max(), err_msg=key)
+        # (a HingeLoss radius has no gradient: the reference records autograd noise of ~1e-23 there -- an absolute floor)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * max(np.abs(want).max(), 1e-12), err_msg=key)
 
 
 @pytest.mark.parametrize("tag", ["gn_unroll", "lm_unroll", "lm_trunc", "lm_ellips_unroll", "lm_step_unroll"])

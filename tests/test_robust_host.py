@@ -51,7 +51,7 @@ def test_reference_pgo_known_answer_through_host_path():
         assert a == pytest.approx(b, rel=1e-10, abs=1e-10), (losses, want)
 
 
-@pytest.mark.parametrize("name", ["pg_f64_mixed_robust", "pg2_f64_mixed_robust"])
+@pytest.mark.parametrize("name", ["pg_f64_mixed_robust", "pg2_f64_mixed_robust", "pg_f64_mixed_hinge"])
 def test_mixed_and_flattened_robust_costs_through_host_path(name):
     """Plain, Welsch, Huber and flatten_dims=True costs mixed inside one role (robust_cost_function.py:52-135): the packer's
     per-cost loss table (theseus_amd/packed.py), Objective.error(), the LM loop and the implicit backward incl. the gradient of
@@ -65,7 +65,10 @@ def test_mixed_and_flattened_robust_costs_through_host_path(name):
     r = run_mixed_implicit(th, g, "cpu", OracleKernels())
     packed = r["opt"].linear_solver.linearization.packed
     assert packed.loss_between is not None and packed.loss_prior is not None      # both roles are mixed
-    assert sorted(set(packed.loss_between.tolist())) == [0, 1, 2, 5, 6] and packed.loss_prior.tolist()[0] == 5
+    if name.endswith("hinge"):     # plain, Huber, Hinge and flattened Hinge; the first prior a flattened Hinge cost
+        assert sorted(set(packed.loss_between.tolist())) == [0, 2, 3, 7] and packed.loss_prior.tolist()[0] == 7
+    else:
+        assert sorted(set(packed.loss_between.tolist())) == [0, 1, 2, 5, 6] and packed.loss_prior.tolist()[0] == 5
     np.testing.assert_allclose(r["err0"].numpy(), g["err0"], rtol=1e-12)
     np.testing.assert_allclose(r["errvec0"].numpy(), g["errvec0"], rtol=0, atol=1e-12 * np.abs(g["errvec0"]).max())
     np.testing.assert_allclose(r["info"].err_history.numpy(), g["err_history"], rtol=1e-6)

@@ -18,9 +18,9 @@ LIB_PATH = os.environ.get("THESEUS_HIP_LIB") or os.path.join(_HERE, "lib", "libt
 THX_TILE = 128
 THX_ERR_CHUNKS = 128
 THX_BA_ERR_CHUNKS = 256
-LOSS_NONE, LOSS_WELSCH, LOSS_HUBER = 0, 1, 2  # THX_LOSS_* (theseus/core/robust_loss.py:33-52)
+LOSS_NONE, LOSS_WELSCH, LOSS_HUBER, LOSS_HINGE = 0, 1, 2, 3  # THX_LOSS_* (theseus/core/robust_loss.py:33-62)
 LOSS_FLATTEN = 4  # THX_LOSS_FLATTEN: RobustCostFunction(flatten_dims=True), or-ed into a loss code
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 class LieEps(Structure):

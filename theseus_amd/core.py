@@ -734,6 +734,18 @@ class HuberLoss(RobustLoss):
         return torch.sqrt(radius / torch.max(x, radius) + RobustLoss._LOSS_EPS)
 
 
+class HingeLoss(RobustLoss):
+    """robust_loss.py:55-62: no cost inside the radius, sqrt(x) - sqrt(radius) beyond it."""
+
+    @staticmethod
+    def _evaluate_impl(x, radius):
+        return torch.where(x > radius, torch.sqrt(x) - torch.sqrt(radius), RobustLoss._LOSS_EPS)
+
+    @staticmethod
+    def _linearize_impl(x, radius):
+        return torch.where(x > radius, 1.0 / (2 * torch.sqrt(x) + RobustLoss._LOSS_EPS), 0.0)
+
+
 class RobustCostFunction(CostFunction):
     """Wraps a cost function: its weighted error / Jacobians are rescaled by sqrt(rho'(|w e|^2) + eps) in the
     linearization and its contribution to the objective is rho(|w e|^2) (robust_cost_function.py:52-135)."""

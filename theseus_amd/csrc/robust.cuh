@@ -1,5 +1,5 @@
 // RobustCostFunction on device (theseus/core/robust_cost_function.py:87-135) with the losses of
-// theseus/core/robust_loss.py:33-52.  x = squared norm of the WEIGHTED error, log_radius as stored by the reference.
+// theseus/core/robust_loss.py:33-62 (Welsch, Huber, Hinge).  x = squared norm of the WEIGHTED error, log_radius as stored by the reference.
 //   linearisation pass:  (J, e) <- sqrt(rho'(x) + 1e-20) (J, e)
 //   error metric:        |h|^2 = dim * (rho(x) / dim + 1e-20)
 // flatten_dims = True (robust_cost_function.py:89-96,118-133): every residual row is its own term -- x_r = e_r^2, row r of
@@ -18,12 +18,14 @@ constexpr double kRobustEps = 1e-20;  // robust_cost_function.py:52
 __device__ __forceinline__ double loss_linearize(int kind, double x, double log_radius) {
   const double r = exp(log_radius);
   if (kind == THX_LOSS_WELSCH) return exp(-x / (r + kLossEps));
+  if (kind == THX_LOSS_HINGE) return x > r ? 1.0 / (2.0 * sqrt(x) + kLossEps) : 0.0;   // robust_loss.py:60-62
   return sqrt(r / fmax(x, r) + kLossEps);  // Huber
 }
 // rho(x)
 __device__ __forceinline__ double loss_evaluate(int kind, double x, double log_radius) {
   const double r = exp(log_radius);
   if (kind == THX_LOSS_WELSCH) return r - r * exp(-x / (r + kLossEps));
+  if (kind == THX_LOSS_HINGE) return x > r ? sqrt(x) - sqrt(r) : kLossEps;   // robust_loss.py:56-58
   return x > r ? 2.0 * sqrt(r * fmax(x, r) + kLossEps) - r : x;  // Huber
 }
 // m = rho'(x) + 1e-20 (the square of the rescale factor) with its partial derivatives w.r.t. x and log_radius
@@ -35,6 +37,18 @@ __device__ __forceinline__ void rescale2_partials(int kind, double x, double log
     m = v + kRobustEps;
     dm_dx = -v / rr;
     dm_dl = v * x / (rr * rr) * r;
+  } else if (kind == THX_LOSS_HINGE) {
+    // rho' = 1 / (2 sqrt(x) + eps) beyond the radius, 0 inside: the radius enters through the branch only (no gradient, as in
+    // the reference's torch.where)
+    if (x > r) {
+      const double sx = sqrt(x), den = 2.0 * sx + kLossEps;
+      m = 1.0 / den + kRobustEps;
+      dm_dx = -1.0 / (den * den * sx);
+    } else {
+      m = kRobustEps;
+      dm_dx = 0.0;
+    }
+    dm_dl = 0.0;
   } else {
     const double mx = fmax(x, r), v = sqrt(r / mx + kLossEps);
     m = v + kRobustEps;
@@ -66,7 +80,7 @@ __device__ __forceinline__ int loss_code(int role_code, const int32_t* __restric
   return per_cost ? per_cost[entity] : role_code;
 }
 __host__ __device__ __forceinline__ bool loss_code_valid(int code) {
-  return code >= 0 && (code & ~THX_LOSS_FLATTEN) <= THX_LOSS_HUBER && code != THX_LOSS_FLATTEN;
+  return code >= 0 && (code & ~THX_LOSS_FLATTEN) <= THX_LOSS_HINGE && code != THX_LOSS_FLATTEN;
 }
 // what the cost contributes to 2 * error_metric
 template <int DIM>

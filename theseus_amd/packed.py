@@ -126,7 +126,7 @@ def _weight_diag(w, dof: int) -> torch.Tensor:
                                "There is no CPU/eager fallback.")
 
 
-_LOSS_KIND = {"WelschLoss": _lib.LOSS_WELSCH, "HuberLoss": _lib.LOSS_HUBER}
+_LOSS_KIND = {"WelschLoss": _lib.LOSS_WELSCH, "HuberLoss": _lib.LOSS_HUBER, "HingeLoss": _lib.LOSS_HINGE}
 
 
 def _unwrap_robust(c):
@@ -136,7 +136,7 @@ def _unwrap_robust(c):
         return c, _lib.LOSS_NONE, None
     kind = _LOSS_KIND.get(type(c.loss).__name__)
     if kind is None:
-        raise UnsupportedObjective(f"HIP backend fuses WelschLoss / HuberLoss; got {type(c.loss).__name__} ({c.name}). "
+        raise UnsupportedObjective(f"HIP backend fuses WelschLoss / HuberLoss / HingeLoss; got {type(c.loss).__name__} ({c.name}). "
                                    "There is no CPU/eager fallback.")
     return c.cost_function, kind | (_lib.LOSS_FLATTEN if c.flatten_dims else 0), c.log_loss_radius
 
@@ -618,7 +618,8 @@ class PackedPoseGraph:
             r = lr.exp()
             welsch = r - r * torch.exp(-x / (r + 1e-20))
             huber = torch.where(x > r, 2 * torch.sqrt(r * torch.maximum(x, r) + 1e-20) - r, x)
-            rho = torch.where(kind == _lib.LOSS_WELSCH, welsch, huber)
+            hinge = torch.where(x > r, x.sqrt() - r.sqrt(), torch.full_like(x, 1e-20))
+            rho = torch.where(kind == _lib.LOSS_WELSCH, welsch, torch.where(kind == _lib.LOSS_HINGE, hinge, huber))
             h = torch.where(flat, (rho + 1e-20).sqrt(), (rho / e.shape[-1] + 1e-20).sqrt())
             return torch.where(kind == _lib.LOSS_NONE, e, h)
         eb = robust_error(eb, t.robust_between, t.log_radius_between, t.loss_between)
