@@ -299,7 +299,7 @@ def test_chol_split_and_fused_diagonal_phase_agree(K, dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("ellipsoidal", [False, True])
-@pytest.mark.parametrize("n,B", [(384, 3), (640, 8), (1536, 8), (1536, 29), (1024, 32)])
+@pytest.mark.parametrize("n,B", [(384, 3), (640, 8), (1536, 8), (1536, 29), (1024, 32), (600, 5), (1290, 4)])
 def test_chol_right_looking_schedule_of_small_batches(K, n, B, ellipsoidal, fused, dtype):
     """fp32, dense frames, <= 32 problems, whole tiles (thx_chol_schedule.right_looking_max_batch): per block column the tile
     factorisation, the substitutions and one workgroup per tile of the trailing matrix.  Against LAPACK in fp64 (L L^T = H + D, the
@@ -309,7 +309,10 @@ def test_chol_right_looking_schedule_of_small_batches(K, n, B, ellipsoidal, fuse
     f32 = dtype == torch.float32
     M = _random_spd(B, n, dtype, seed=3 * n + B)
     rhs = torch.randn(B, n, dtype=torch.float64, generator=torch.Generator().manual_seed(5)).to(dtype).cuda()
-    H = torch.tril(M).cuda().contiguous()           # (ld = n: a multiple of 128)
+    ld = (n + 127) // 128 * 128                      # whole tiles inside the frame (n = 600 / 1290: the last tile is partial)
+    H = torch.zeros(B, ld, ld, dtype=dtype)
+    H[:, :n, :n] = torch.tril(M)
+    H = H.cuda()
     lam = torch.linspace(0.02, 0.3, B).to(dtype).cuda()
     out = {}
     for rl in (True, False):
@@ -322,6 +325,7 @@ def test_chol_right_looking_schedule_of_small_batches(K, n, B, ellipsoidal, fuse
     assert int(ir.abs().sum()) == 0 and int(il.abs().sum()) == 0
     assert not torch.equal(Lr, Ll)                                        # (it IS another schedule)
     assert float(torch.triu(Lr, 1).abs().max()) == 0.0
+    Lr, Ll = Lr[:, :n, :n], Ll[:, :n, :n]
     Md = M.double().cuda()
     dg = torch.diagonal(Md, dim1=1, dim2=2)
     D = lam.double().view(-1, 1) * dg + 1e-6 if ellipsoidal else lam.double().view(-1, 1).expand(B, n)
