@@ -145,7 +145,13 @@ ba_point_kernel(thx_ba_structure s, thx_ba_data d, double* __restrict__ Hpp, dou
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) W[ws_at<18>(o, 3 * i + j, b, B)] = r.Jc[i] * r.Jp[j] + r.Jc[6 + i] * r.Jp[3 + j];
+      for (int j = 0; j < 3; ++j) {
+        double wv = r.Jc[i] * r.Jp[j] + r.Jc[6 + i] * r.Jp[3 + j];
+#ifdef THX_EXP_W32   // numerics experiment: what an fp32 W workspace would do to fp32 problems (rounded on store, layout unchanged)
+        if (sizeof(T) == 4) wv = (double)(float)wv;
+#endif
+        W[ws_at<18>(o, 3 * i + j, b, B)] = wv;
+      }
   }
   for (int k = s.pt_prior_ptr[p]; k < s.pt_prior_ptr[p + 1]; ++k) {
     const int id = s.pt_prior_id[k];
