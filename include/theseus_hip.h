@@ -75,7 +75,7 @@ typedef struct {
   int64_t prior_target_bstride;
   const void* w_prior;       /* (K, Bw, 6)                                              */
   int64_t w_prior_bstride;
-  /* RobustCostFunction wrappers (theseus/core/robust_cost_function.py:52-135): a LOSS CODE = THX_LOSS_{NONE,WELSCH,HUBER,HINGE},
+  /* RobustCostFunction wrappers (theseus/core/robust_cost_function.py:52-135): a LOSS CODE = THX_LOSS_{NONE,WELSCH,HUBER,HINGE,GEMAN_MCCLURE},
    * | THX_LOSS_FLATTEN for flatten_dims = True (every residual row its own robust term, :89-96,118-133), and
    * log_loss_radius per cost.  robust_<role> is the code of every cost of the role; when the costs of a role differ
    * (some plain, some Welsch, some Huber, some flattened) robust_<role> is any non-zero code and loss_<role> holds one code
@@ -91,12 +91,14 @@ typedef struct {
   const int32_t* loss_prior;         /* (K) */
 } thx_pg_data;
 
-/* theseus/core/robust_loss.py:33-62; THX_LOSS_FLATTEN: RobustCostFunction(flatten_dims=True) */
+/* theseus/core/robust_loss.py:33-113; THX_LOSS_FLATTEN: RobustCostFunction(flatten_dims=True) */
 #define THX_LOSS_NONE 0
 #define THX_LOSS_WELSCH 1
 #define THX_LOSS_HUBER 2
 #define THX_LOSS_HINGE 3   /* robust_loss.py:55-62: rho = sqrt(x) - sqrt(r) beyond the radius, rho' = 0 inside it */
 #define THX_LOSS_FLATTEN 4
+#define THX_LOSS_GEMAN_MCCLURE 8   /* robust_loss.py:92-113 (GNCRobustCostFunction, robust_cost_function.py:173-222): the cost's
+                                    * log_radius entry is log(mu * radius) -- the host adds log(gnc_control_val) */
 
 const char* thx_last_error(void);
 int thx_abi_version(void);

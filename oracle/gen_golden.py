@@ -782,6 +782,7 @@ def gen_pg_unrolled(th, lieF):
 
 MIXED_LOSSES = (None, "welsch", "huber", "welsch+flatten", "huber+flatten")
 MIXED_LOSSES_HINGE = ("hinge", None, "hinge+flatten", "huber", "hinge")    # (round 6: HingeLoss, robust_loss.py:55-62)
+MIXED_LOSSES_GNC = ("gm", None, "huber", "gm+flatten", "gm")               # (GNCRobustCostFunction + GemanMcClureLoss, :64-113)
 
 
 def gen_pg_mixed_robust(th, lieF):
@@ -792,8 +793,9 @@ def gen_pg_mixed_robust(th, lieF):
     radii spread around the initial squared errors so that inliers, the knee and outliers all occur.  Recorded: the first linearization, the error metric, a damped LM run, and the gradients of
     TheseusLayer(backward_mode="implicit") w.r.t. measurements, weights, prior targets and every log_loss_radius."""
     dtype = torch.float64
-    for name, G, iters in (("pg_f64_mixed_robust", "SE3", 6), ("pg2_f64_mixed_robust", "SE2", 6), ("pg_f64_mixed_hinge", "SE3", 6)):
-        mixed = MIXED_LOSSES_HINGE if name.endswith("hinge") else MIXED_LOSSES
+    for name, G, iters in (("pg_f64_mixed_robust", "SE3", 6), ("pg2_f64_mixed_robust", "SE2", 6), ("pg_f64_mixed_hinge", "SE3", 6),
+                           ("pg_f64_mixed_gnc", "SE3", 6)):
+        mixed = MIXED_LOSSES_HINGE if name.endswith("hinge") else (MIXED_LOSSES_GNC if name.endswith("gnc") else MIXED_LOSSES)
         if G == "SE3":
             d = make_problem(dtype=dtype, th=th, lieF=lieF, P=8, E=15, B=3, seed=41, batched_weights=True, pose_noise=(0.3, 0.25))
             grp = th.SE3
@@ -812,18 +814,25 @@ def gen_pg_mixed_robust(th, lieF):
         tgt = d["prior_target"].clone().requires_grad_(True)
         wp = d["w_prior"][:, :, :1].clone().requires_grad_(True)
         loss_b = [mixed[k % 5] for k in range(E)]
-        loss_p = (["hinge+flatten"] if name.endswith("hinge") else ["welsch+flatten"]) + [None] * (Kp - 1)
+        loss_p = (["hinge+flatten"] if name.endswith("hinge") else ["gm"] if name.endswith("gnc") else ["welsch+flatten"]) + [None] * (Kp - 1)
         # radii: log of (typical squared weighted error) * lognormal spread; batched for odd k
         lr_b = (torch.full((B, E, 1), 4.0, dtype=dtype) + 2.0 * torch.randn(B, E, 1, dtype=dtype, generator=gen))
         shared_b = [k % 2 == 0 or (loss_b[k] or "").endswith("+flatten") for k in range(E)]   # radius stored (1, 1)
         lr_b[:, shared_b] = lr_b[:1, shared_b]
         lr_p = (torch.full((1, Kp, 1), -6.0, dtype=dtype) + torch.randn(1, Kp, 1, dtype=dtype, generator=gen)).repeat(B, 1, 1)
         lr_b, lr_p = lr_b.requires_grad_(True), lr_p.requires_grad_(True)
+        # GNC control values (one per cost, shared by the batch; only read by the "gm" costs): mu in [1, 4]
+        mu_b = (1.0 + 3.0 * torch.rand(1, E, 1, dtype=dtype, generator=gen)).requires_grad_(True)
+        mu_p = (1.0 + 3.0 * torch.rand(1, Kp, 1, dtype=dtype, generator=gen)).requires_grad_(True)
         LOSS = {"welsch": th.WelschLoss, "huber": th.HuberLoss, "hinge": th.HingeLoss}
 
-        def wrap(cf, spec, radius, nm):
+        def wrap(cf, spec, radius, nm, mu=None):
             if spec is None:
                 return cf
+            if spec.split("+")[0] == "gm":
+                return th.GNCRobustCostFunction(cf, th.GemanMcClureLoss, th.Variable(radius, name="log_radius_" + nm),
+                                                th.Variable(mu, name="gnc_" + nm), flatten_dims=spec.endswith("+flatten"),
+                                                name="robust_" + nm)
             return th.RobustCostFunction(cf, LOSS[spec.split("+")[0]], th.Variable(radius, name="log_radius_" + nm),
                                          flatten_dims=spec.endswith("+flatten"), name="robust_" + nm)
 
@@ -833,11 +842,11 @@ def gen_pg_mixed_robust(th, lieF):
             i, j = d["edges"][k].tolist()
             cw = th.DiagonalCostWeight(th.Variable(wb[:, k], name=f"w_{k}"))
             cf = th.Between(poses[i], poses[j], grp(tensor=meas[:, k], name=f"meas_{k}"), cw, name=f"between_{k}")
-            obj.add(wrap(cf, loss_b[k], lr_b[:1, k] if shared_b[k] else lr_b[:, k], f"between_{k}"))
+            obj.add(wrap(cf, loss_b[k], lr_b[:1, k] if shared_b[k] else lr_b[:, k], f"between_{k}", mu_b[:, k]))
         for k in range(Kp):
             sw = th.ScaleCostWeight(th.Variable(wp[:, k], name=f"pw_{k}"))
             cf = th.Difference(poses[int(d["prior_idx"][k])], grp(tensor=tgt[:, k], name=f"prior_target_{k}"), sw, name=f"prior_{k}")
-            obj.add(wrap(cf, loss_p[k], lr_p[:1, k], f"prior_{k}"))
+            obj.add(wrap(cf, loss_p[k], lr_p[:1, k], f"prior_{k}", mu_p[:, k]))
         opt = th.LevenbergMarquardt(obj, linear_solver_cls=th.CholeskyDenseSolver, vectorize=False, max_iterations=iters,
                                     step_size=1.0, abs_err_tolerance=0.0, rel_err_tolerance=0.0)
         with torch.no_grad():
@@ -865,6 +874,8 @@ def gen_pg_mixed_robust(th, lieF):
             final=final.detach().numpy(), coef=coef.numpy(), loss=loss.item(),
             grad_meas=meas.grad.numpy(), grad_w_between=wb.grad.numpy(), grad_prior_target=tgt.grad.numpy(),
             grad_w_prior=wp.grad.numpy(), grad_log_radius_between=gz(lr_b).numpy(), grad_log_radius_prior=gz(lr_p).numpy(),
+            **(dict(gnc_between=mu_b.detach().numpy(), gnc_prior=mu_p.detach().numpy(), grad_gnc_between=gz(mu_b).numpy(),
+                    grad_gnc_prior=gz(mu_p).numpy()) if name.endswith("gnc") else {}),
             opt_kwargs=np.array(repr(dict(max_iterations=iters, step_size=1.0, damping=1e-2, gauss_newton=False))))
         print(name, "err", err0.mean(), "->", info.err_history[:, -1].mean().item(), "loss", loss.item(),
               "|grad_lr|", gz(lr_b).abs().max().item(), gz(lr_p).abs().max().item())

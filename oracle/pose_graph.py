@@ -135,6 +135,8 @@ def loss_evaluate(kind, x, log_radius):
         return torch.where(x > r, 2 * torch.sqrt(r * torch.maximum(x, r) + _LOSS_EPS) - r, x)
     if kind == "hinge":          # robust_loss.py:56-58
         return torch.where(x > r, torch.sqrt(x) - torch.sqrt(r), torch.full_like(x, _LOSS_EPS))
+    if kind == "gm":             # robust_loss.py:96-107, Geman-McClure; r = mu * radius (log_radius carries log(mu * radius))
+        return r * x / (r + x + _LOSS_EPS)
     raise ValueError(kind)
 
 
@@ -147,16 +149,18 @@ def loss_linearize(kind, x, log_radius):
         return torch.sqrt(r / torch.maximum(x, r) + _LOSS_EPS)
     if kind == "hinge":          # robust_loss.py:60-62
         return torch.where(x > r, 1.0 / (2 * torch.sqrt(x) + _LOSS_EPS), torch.zeros_like(x))
+    if kind == "gm":             # robust_loss.py:109-113
+        return r ** 2 / ((r + x) ** 2 + _LOSS_EPS)
     raise ValueError(kind)
 
 
 def _per_cost(kind, count):
-    """A loss spec -- None | "welsch" | "huber" | "hinge" [+ "+flatten" for flatten_dims=True], or one such entry per cost of the role
-    (plain, Welsch, Huber and flattened costs mixed) -- as (count, 1) tensors: kind index 0/1/2/3, flatten flag."""
+    """A loss spec -- None | "welsch" | "huber" | "hinge" | "gm" (Geman-McClure: the radius entry is log(mu * radius)) [+ "+flatten" for flatten_dims=True], or one such entry per cost of the role
+    (plain, Welsch, Huber and flattened costs mixed) -- as (count, 1) tensors: kind index 0/1/2/3/8, flatten flag."""
     specs = [kind] * count if kind is None or isinstance(kind, str) else list(kind)
     if len(specs) != count:
         raise ValueError("one loss spec per cost")
-    k = torch.tensor([0 if s is None else {"welsch": 1, "huber": 2, "hinge": 3}[s.split("+")[0]] for s in specs]).view(count, 1)
+    k = torch.tensor([0 if s is None else {"welsch": 1, "huber": 2, "hinge": 3, "gm": 8}[s.split("+")[0]] for s in specs]).view(count, 1)
     f = torch.tensor([s is not None and s.endswith("+flatten") for s in specs]).view(count, 1)
     return k, f
 
@@ -166,7 +170,9 @@ def _simple(kind):
 
 
 def _both(fn, k, x, log_radius):
-    return torch.where(k == 1, fn("welsch", x, log_radius), torch.where(k == 3, fn("hinge", x, log_radius), fn("huber", x, log_radius)))
+    return torch.where(k == 1, fn("welsch", x, log_radius),
+                       torch.where(k == 3, fn("hinge", x, log_radius),
+                                   torch.where(k == 8, fn("gm", x, log_radius), fn("huber", x, log_radius))))
 
 
 def robust_rescale(jacs, e, kind, log_radius):

@@ -7,7 +7,7 @@ from theseus_amd.kernels import PGTensors, round_up
 
 def loss_codes(spec, device="cuda"):
     """the oracle's loss spec (oracle/pose_graph.py: PGProblem.robust_*) -> (role code, per-cost int32 table | None)."""
-    one = lambda s: 0 if s is None else {"welsch": 1, "huber": 2, "hinge": 3}[s.split("+")[0]] | (4 if s.endswith("+flatten") else 0)  # noqa: E731
+    one = lambda s: 0 if s is None else {"welsch": 1, "huber": 2, "hinge": 3, "gm": 8}[s.split("+")[0]] | (4 if s.endswith("+flatten") else 0)  # noqa: E731
     if spec is None or isinstance(spec, str):
         return one(spec), None
     codes = [one(s) for s in spec]

@@ -12,7 +12,7 @@ from oracle import pose_graph as opg
 
 def loss_spec(code, table=None):
     """theseus_amd loss code(s) (_lib.LOSS_* | _lib.LOSS_FLATTEN; per-cost table) -> the oracle's loss spec."""
-    one = lambda c: None if c == 0 else {1: "welsch", 2: "huber", 3: "hinge"}[c & 3] + ("+flatten" if c & 4 else "")  # noqa: E731
+    one = lambda c: None if c == 0 else {1: "welsch", 2: "huber", 3: "hinge", 8: "gm"}[c & ~4] + ("+flatten" if c & 4 else "")  # noqa: E731
     return one(int(code)) if table is None else [one(int(c)) for c in table.tolist()]
 
 

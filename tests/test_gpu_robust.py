@@ -131,7 +131,8 @@ def test_robust_vjp_vs_oracle_autograd(name, kind, dtype, both):
 
 
 @pytest.mark.parametrize("name,dtype", [("pg_f64_mixed_robust", torch.float64), ("pg2_f64_mixed_robust", torch.float64),
-                                        ("pg_f64_mixed_robust", torch.float32), ("pg_f64_mixed_hinge", torch.float64)])
+                                        ("pg_f64_mixed_robust", torch.float32), ("pg_f64_mixed_hinge", torch.float64),
+                                        ("pg_f64_mixed_gnc", torch.float64)])
 def test_mixed_and_flattened_robust_costs_match_the_reference(name, dtype):
     """Plain, Welsch, Huber and flatten_dims=True costs mixed inside one objective, END TO END through the HIP path (packer's
     per-cost loss table -> thx_pg_assemble_blocks / thx_pg_error / thx_pg_vjp): error vector / metric, the damped LM run and the

@@ -335,7 +335,7 @@ def test_so2_pose_graph_matches_reference(name, tol):
                                        atol=tol * max(1.0, np.abs(g["delta"][it]).max()))
 
 
-@pytest.mark.parametrize("name", ["pg_f64_mixed_robust", "pg2_f64_mixed_robust", "pg_f64_mixed_hinge"])
+@pytest.mark.parametrize("name", ["pg_f64_mixed_robust", "pg2_f64_mixed_robust", "pg_f64_mixed_hinge", "pg_f64_mixed_gnc"])
 def test_mixed_robust_objective_matches_reference(name):
     """Plain, Welsch, Huber and flatten_dims=True costs mixed inside one role (theseus/core/robust_cost_function.py:52-135):
     the oracle's per-cost loss specs against the REAL reference -- first linearization, error vector / metric, the damped LM
@@ -364,17 +364,27 @@ def test_mixed_robust_objective_matches_reference(name):
     def radius(leaf, shared):
         cols = [leaf[:1, k].expand(leaf.shape[0], -1) if s else leaf[:, k] for k, s in enumerate(shared)]
         return torch.stack(cols, 1)
+    # (these leaves start from the FIXTURE's log_loss_radius, not from p's entries, which already carry log(mu) for "gm" costs)
+    from tests.mixed_robust_common import effective_radius, specs
+    leaves["log_radius_between"] = torch.from_numpy(g["log_radius_between"]).clone().requires_grad_(True)
+    leaves["log_radius_prior"] = torch.from_numpy(g["log_radius_prior"]).clone().requires_grad_(True)
+    gnc = "gnc_between" in g
+    if gnc:
+        leaves["gnc_between"] = torch.from_numpy(g["gnc_between"]).clone().requires_grad_(True)
+        leaves["gnc_prior"] = torch.from_numpy(g["gnc_prior"]).clone().requires_grad_(True)
     pg = dataclasses.replace(p, meas=leaves["meas"], w_between=leaves["w_between"], prior_target=leaves["prior_target"],
                              w_prior=leaves["w_prior"].expand(-1, -1, p.dof),
-                             log_radius_between=radius(leaves["log_radius_between"], shared_radius(g, "between")),
-                             log_radius_prior=radius(leaves["log_radius_prior"], shared_radius(g, "prior")))
+                             log_radius_between=effective_radius(radius(leaves["log_radius_between"], shared_radius(g, "between")),
+                                                                 leaves["gnc_between"] if gnc else None, specs(g, "between")),
+                             log_radius_prior=effective_radius(radius(leaves["log_radius_prior"], shared_radius(g, "prior")),
+                                                               leaves["gnc_prior"] if gnc else None, specs(g, "prior")))
     final, _ = opg.implicit_final_step(pg, x)
     np.testing.assert_allclose(final.detach().numpy(), g["final"], rtol=0, atol=5e-8)
     loss = (torch.from_numpy(g["coef"]) * final).sum()
     loss.backward()
     assert abs(loss.item() - float(g["loss"])) < 1e-6
-    for key, ref in GRAD_KEYS:
-        got, want = leaves[key].grad.numpy(), g[ref]
+    for key, ref in GRAD_KEYS + ((("gnc_between", "grad_gnc_between"), ("gnc_prior", "grad_gnc_prior")) if gnc else ()):
+        got, want = (leaves[key].grad if leaves[key].grad is not None else torch.zeros_like(leaves[key])).numpy(), g[ref]
         # (a HingeLoss radius has no gradient: the reference records autograd noise of ~1e-23 there -- an absolute floor)
         np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * max(np.abs(want).max(), 1e-12), err_msg=key)
 

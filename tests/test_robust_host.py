@@ -51,7 +51,7 @@ def test_reference_pgo_known_answer_through_host_path():
         assert a == pytest.approx(b, rel=1e-10, abs=1e-10), (losses, want)
 
 
-@pytest.mark.parametrize("name", ["pg_f64_mixed_robust", "pg2_f64_mixed_robust", "pg_f64_mixed_hinge"])
+@pytest.mark.parametrize("name", ["pg_f64_mixed_robust", "pg2_f64_mixed_robust", "pg_f64_mixed_hinge", "pg_f64_mixed_gnc"])
 def test_mixed_and_flattened_robust_costs_through_host_path(name):
     """Plain, Welsch, Huber and flatten_dims=True costs mixed inside one role (robust_cost_function.py:52-135): the packer's
     per-cost loss table (theseus_amd/packed.py), Objective.error(), the LM loop and the implicit backward incl. the gradient of
@@ -67,6 +67,8 @@ def test_mixed_and_flattened_robust_costs_through_host_path(name):
     assert packed.loss_between is not None and packed.loss_prior is not None      # both roles are mixed
     if name.endswith("hinge"):     # plain, Huber, Hinge and flattened Hinge; the first prior a flattened Hinge cost
         assert sorted(set(packed.loss_between.tolist())) == [0, 2, 3, 7] and packed.loss_prior.tolist()[0] == 7
+    elif name.endswith("gnc"):     # plain, Huber, Geman-McClure (GNCRobustCostFunction) plain and flattened; the first prior Geman-McClure
+        assert sorted(set(packed.loss_between.tolist())) == [0, 2, 8, 12] and packed.loss_prior.tolist()[0] == 8
     else:
         assert sorted(set(packed.loss_between.tolist())) == [0, 1, 2, 5, 6] and packed.loss_prior.tolist()[0] == 5
     np.testing.assert_allclose(r["err0"].numpy(), g["err0"], rtol=1e-12)

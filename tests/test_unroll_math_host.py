@@ -38,7 +38,7 @@ def _rand_pose(gen, scale_t, scale_r):
 EPS64 = np.array([lie.EPS[torch.float64][k] for k in ("near_zero", "d_near_zero", "near_pi")])
 
 
-LOSSES = [(0, None), (1, "welsch"), (2, "huber"), (5, "welsch+flatten"), (6, "huber+flatten"), (3, "hinge"), (7, "hinge+flatten")]   # (THX_LOSS_* code, oracle spec)
+LOSSES = [(0, None), (1, "welsch"), (2, "huber"), (5, "welsch+flatten"), (6, "huber+flatten"), (3, "hinge"), (7, "hinge+flatten"), (8, "gm"), (12, "gm+flatten")]   # (THX_LOSS_* code, oracle spec)
 
 
 def _robust(Js, e, spec, log_radius):

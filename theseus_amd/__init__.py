@@ -3,7 +3,8 @@
 Host-side mirror of the reference's modelling + optimizer API for the SE3 / SE2 pose-graph hot path, over
 hand-written HIP kernels behind a C ABI (include/theseus_hip.h, theseus_amd/csrc).  No CPU fallback.
 """
-from .core import (AutoDiffCostFunction, Between, CostFunction, CostWeight, DiagonalCostWeight, Difference, HingeLoss, HuberLoss, Local,  # noqa: F401
+from .core import (AutoDiffCostFunction, Between, CostFunction, CostWeight, DiagonalCostWeight, Difference, GemanMcClureLoss,  # noqa: F401
+                   GNCRobustCostFunction, GNCRobustLoss, HingeLoss, HuberLoss, Local,
                    Objective, Point2, Point3, Reprojection, RobustCostFunction, RobustLoss, ScaleCostWeight, SE2, SE3, SO2, SO3,
                    Variable, Vector, WelschLoss)
 from .kernels import (HipKernels, default_kernels, reset_global_params, set_global_params, set_lie_eps,  # noqa: F401

@@ -20,7 +20,8 @@ THX_ERR_CHUNKS = 128
 THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER, LOSS_HINGE = 0, 1, 2, 3  # THX_LOSS_* (theseus/core/robust_loss.py:33-62)
 LOSS_FLATTEN = 4  # THX_LOSS_FLATTEN: RobustCostFunction(flatten_dims=True), or-ed into a loss code
-ABI_VERSION = 22
+LOSS_GEMAN_MCCLURE = 8  # THX_LOSS_GEMAN_MCCLURE (robust_loss.py:92-113; the radius entry carries log(mu * radius))
+ABI_VERSION = 23
 
 
 class LieEps(Structure):

@@ -21,8 +21,8 @@ from .compiler import PoseGraphStructure
 from .kernels import PGTensors, default_kernels, fast_approx_local_jacobians, round_up
 from .linear_solver import LinearSolver
 from .linearization import Linearization, VariableOrdering
-from .packed import (UnsupportedObjective, _AuxDeepStamp, _aux_vars, _kind, _opt_deep_stamp, _unwrap_robust, _views_deep_stamp,
-                     _weight_diag)
+from .packed import (UnsupportedObjective, _AuxDeepStamp, _aux_vars, _kind, _opt_deep_stamp, _radius_vars, _unwrap_robust,
+                     _views_deep_stamp, _weight_diag)
 
 ERR_CHUNKS = _lib.THX_BA_ERR_CHUNKS
 
@@ -280,8 +280,7 @@ class PackedBA:
             yield c.calib_k1
             yield c.calib_k2
             yield from _aux_vars(c.weight)
-            if r is not None:
-                yield r
+            yield from _radius_vars(r)
         for c in self.cam_prior_costs + self.pt_prior_costs:
             yield c.target
             yield from _aux_vars(c.weight)

@@ -746,6 +746,30 @@ class HingeLoss(RobustLoss):
         return torch.where(x > radius, 1.0 / (2 * torch.sqrt(x) + RobustLoss._LOSS_EPS), 0.0)
 
 
+class GNCRobustLoss(RobustLoss, abc.ABC):
+    """robust_loss.py:64-89: a loss with a graduated-non-convexity control value ``mu`` next to the radius."""
+
+    @classmethod
+    def evaluate(cls, x: torch.Tensor, log_radius: torch.Tensor, mu: torch.Tensor) -> torch.Tensor:   # type: ignore[override]
+        return cls._evaluate_impl(x, log_radius.exp(), mu)
+
+    @classmethod
+    def linearize(cls, x: torch.Tensor, log_radius: torch.Tensor, mu: torch.Tensor) -> torch.Tensor:   # type: ignore[override]
+        return cls._linearize_impl(x, log_radius.exp(), mu)
+
+
+class GemanMcClureLoss(GNCRobustLoss):
+    """robust_loss.py:92-113: mu = 1 the Geman-McClure loss, mu -> infinity the quadratic."""
+
+    @staticmethod
+    def _evaluate_impl(x, radius, mu):
+        return mu * radius * x / (mu * radius + x + RobustLoss._LOSS_EPS)
+
+    @staticmethod
+    def _linearize_impl(x, radius, mu):
+        return (mu * radius) ** 2 / ((mu * radius + x) ** 2 + RobustLoss._LOSS_EPS)
+
+
 class RobustCostFunction(CostFunction):
     """Wraps a cost function: its weighted error / Jacobians are rescaled by sqrt(rho'(|w e|^2) + eps) in the
     linearization and its contribution to the objective is rho(|w e|^2) (robust_cost_function.py:52-135)."""
@@ -772,13 +796,34 @@ class RobustCostFunction(CostFunction):
         we = self.cost_function.weighted_error()
         if self.flatten_dims:
             we = we.reshape(-1, 1)
-        rho = self.loss.evaluate((we ** 2).sum(dim=1, keepdim=True), self.log_loss_radius.tensor)
+        rho = self._evaluate_loss((we ** 2).sum(dim=1, keepdim=True))
         if self.flatten_dims:
             return (rho.reshape(-1, self.dim()) + RobustCostFunction._EPS).sqrt()
         return torch.ones_like(we) * (rho / self.dim() + RobustCostFunction._EPS).sqrt()
 
     def error(self):
         return self.weighted_error()
+
+    def _evaluate_loss(self, squared_norm):
+        return self.loss.evaluate(squared_norm, self.log_loss_radius.tensor)
+
+
+class GNCRobustCostFunction(RobustCostFunction):
+    """robust_cost_function.py:173-222: a RobustCostFunction whose loss takes the graduated-non-convexity control value
+    ``gnc_control_val`` (an auxiliary variable the caller anneals between optimisations)."""
+
+    def __init__(self, cost_function: CostFunction, loss_cls, log_loss_radius: Variable, gnc_control_val: Variable,
+                 flatten_dims: bool = False, name: Optional[str] = None):
+        if not issubclass(loss_cls, GNCRobustLoss):
+            raise RuntimeError(f"{loss_cls} must be GNCRobustLoss type to initialize GNCRobustCostFunction.")
+        super().__init__(cost_function, loss_cls, log_loss_radius, flatten_dims=flatten_dims, name=name)
+        self.gnc_control_val = gnc_control_val
+
+    def aux_vars(self):
+        return super().aux_vars() + [self.gnc_control_val]
+
+    def _evaluate_loss(self, squared_norm):
+        return self.loss.evaluate(squared_norm, self.log_loss_radius.tensor, self.gnc_control_val.tensor)
 
 
 # ------------------------------------------------------------------------------------------------

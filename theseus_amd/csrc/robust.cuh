@@ -1,5 +1,5 @@
 // RobustCostFunction on device (theseus/core/robust_cost_function.py:87-135) with the losses of
-// theseus/core/robust_loss.py:33-62 (Welsch, Huber, Hinge).  x = squared norm of the WEIGHTED error, log_radius as stored by the reference.
+// theseus/core/robust_loss.py:33-62 (Welsch, Huber, Hinge) and :92-113 (Geman-McClure with the GNC control value folded into the radius).  x = squared norm of the WEIGHTED error, log_radius as stored by the reference.
 //   linearisation pass:  (J, e) <- sqrt(rho'(x) + 1e-20) (J, e)
 //   error metric:        |h|^2 = dim * (rho(x) / dim + 1e-20)
 // flatten_dims = True (robust_cost_function.py:89-96,118-133): every residual row is its own term -- x_r = e_r^2, row r of
@@ -19,6 +19,7 @@ __device__ __forceinline__ double loss_linearize(int kind, double x, double log_
   const double r = exp(log_radius);
   if (kind == THX_LOSS_WELSCH) return exp(-x / (r + kLossEps));
   if (kind == THX_LOSS_HINGE) return x > r ? 1.0 / (2.0 * sqrt(x) + kLossEps) : 0.0;   // robust_loss.py:60-62
+  if (kind == THX_LOSS_GEMAN_MCCLURE) return r * r / ((r + x) * (r + x) + kLossEps);     // robust_loss.py:109-113, r = mu * radius
   return sqrt(r / fmax(x, r) + kLossEps);  // Huber
 }
 // rho(x)
@@ -26,6 +27,7 @@ __device__ __forceinline__ double loss_evaluate(int kind, double x, double log_r
   const double r = exp(log_radius);
   if (kind == THX_LOSS_WELSCH) return r - r * exp(-x / (r + kLossEps));
   if (kind == THX_LOSS_HINGE) return x > r ? sqrt(x) - sqrt(r) : kLossEps;   // robust_loss.py:56-58
+  if (kind == THX_LOSS_GEMAN_MCCLURE) return r * x / (r + x + kLossEps);      // robust_loss.py:96-107, r = mu * radius
   return x > r ? 2.0 * sqrt(r * fmax(x, r) + kLossEps) - r : x;  // Huber
 }
 // m = rho'(x) + 1e-20 (the square of the rescale factor) with its partial derivatives w.r.t. x and log_radius
@@ -37,6 +39,12 @@ __device__ __forceinline__ void rescale2_partials(int kind, double x, double log
     m = v + kRobustEps;
     dm_dx = -v / rr;
     dm_dl = v * x / (rr * rr) * r;
+  } else if (kind == THX_LOSS_GEMAN_MCCLURE) {
+    // rho' = r^2 / ((r + x)^2 + eps), r = exp(log_radius) = mu * radius
+    const double sx = r + x, den = sx * sx + kLossEps;
+    m = r * r / den + kRobustEps;
+    dm_dx = -2.0 * r * r * sx / (den * den);
+    dm_dl = (2.0 * r * den - r * r * 2.0 * sx) / (den * den) * r;
   } else if (kind == THX_LOSS_HINGE) {
     // rho' = 1 / (2 sqrt(x) + eps) beyond the radius, 0 inside: the radius enters through the branch only (no gradient, as in
     // the reference's torch.where)
@@ -80,7 +88,8 @@ __device__ __forceinline__ int loss_code(int role_code, const int32_t* __restric
   return per_cost ? per_cost[entity] : role_code;
 }
 __host__ __device__ __forceinline__ bool loss_code_valid(int code) {
-  return code >= 0 && (code & ~THX_LOSS_FLATTEN) <= THX_LOSS_HINGE && code != THX_LOSS_FLATTEN;
+  const int kind = code & ~THX_LOSS_FLATTEN;
+  return code >= 0 && (kind <= THX_LOSS_HINGE || kind == THX_LOSS_GEMAN_MCCLURE) && code != THX_LOSS_FLATTEN;
 }
 // what the cost contributes to 2 * error_metric
 template <int DIM>

@@ -126,19 +126,42 @@ def _weight_diag(w, dof: int) -> torch.Tensor:
                                "There is no CPU/eager fallback.")
 
 
-_LOSS_KIND = {"WelschLoss": _lib.LOSS_WELSCH, "HuberLoss": _lib.LOSS_HUBER, "HingeLoss": _lib.LOSS_HINGE}
+_LOSS_KIND = {"WelschLoss": _lib.LOSS_WELSCH, "HuberLoss": _lib.LOSS_HUBER, "HingeLoss": _lib.LOSS_HINGE,
+              "GemanMcClureLoss": _lib.LOSS_GEMAN_MCCLURE}
+
+
+class _GNCRadius:
+    """The radius entry of a GNCRobustCostFunction (robust_cost_function.py:173-222) as the kernels take it: log(mu * radius) =
+    log_loss_radius + log(gnc_control_val) -- Geman-McClure depends on the two only through their product (robust_loss.py:96-113).
+    Built with torch ops at packing time, so gradients reach both variables; ``vars`` are what the packers track for edits."""
+
+    def __init__(self, log_radius, mu):
+        self.vars = (log_radius, mu)
+
+    @property
+    def tensor(self):
+        lr, mu = self.vars[0].tensor, self.vars[1].tensor
+        return lr.reshape(lr.shape[0], -1)[:, :1] + mu.reshape(mu.shape[0], -1)[:, :1].log()
+
+
+def _radius_vars(r):
+    """the Variables behind a radius entry (None | Variable | _GNCRadius)"""
+    return () if r is None else (r.vars if isinstance(r, _GNCRadius) else (r,))
 
 
 def _unwrap_robust(c):
-    """cost -> (base cost, loss code, log_loss_radius variable | None); code = _lib.LOSS_* | _lib.LOSS_FLATTEN for
-    ``flatten_dims=True``  (theseus/core/robust_cost_function.py:52-85)."""
+    """cost -> (base cost, loss code, log_loss_radius variable [_GNCRadius for a GNC cost] | None); code = _lib.LOSS_* |
+    _lib.LOSS_FLATTEN for ``flatten_dims=True``  (theseus/core/robust_cost_function.py:52-85, 173-222)."""
     if "RobustCostFunction" not in {k.__name__ for k in type(c).__mro__}:
         return c, _lib.LOSS_NONE, None
     kind = _LOSS_KIND.get(type(c.loss).__name__)
     if kind is None:
-        raise UnsupportedObjective(f"HIP backend fuses WelschLoss / HuberLoss / HingeLoss; got {type(c.loss).__name__} ({c.name}). "
-                                   "There is no CPU/eager fallback.")
-    return c.cost_function, kind | (_lib.LOSS_FLATTEN if c.flatten_dims else 0), c.log_loss_radius
+        raise UnsupportedObjective(f"HIP backend fuses WelschLoss / HuberLoss / HingeLoss / GemanMcClureLoss; got "
+                                   f"{type(c.loss).__name__} ({c.name}).  There is no CPU/eager fallback.")
+    radius = c.log_loss_radius
+    if kind == _lib.LOSS_GEMAN_MCCLURE:
+        radius = _GNCRadius(c.log_loss_radius, c.gnc_control_val)
+    return c.cost_function, kind | (_lib.LOSS_FLATTEN if c.flatten_dims else 0), radius
 
 
 def _role_codes(codes):
@@ -245,8 +268,7 @@ class PackedPoseGraph:
             yield c.target
             yield from _aux_vars(c.weight)
         for r in self.edge_radius + self.prior_radius:
-            if r is not None:
-                yield r
+            yield from _radius_vars(r)
 
     def tracked_list(self):
         """Every variable the packed buffers are built from, each ONCE (a cost weight shared by 1024 edges is one entry), the
@@ -619,7 +641,9 @@ class PackedPoseGraph:
             welsch = r - r * torch.exp(-x / (r + 1e-20))
             huber = torch.where(x > r, 2 * torch.sqrt(r * torch.maximum(x, r) + 1e-20) - r, x)
             hinge = torch.where(x > r, x.sqrt() - r.sqrt(), torch.full_like(x, 1e-20))
-            rho = torch.where(kind == _lib.LOSS_WELSCH, welsch, torch.where(kind == _lib.LOSS_HINGE, hinge, huber))
+            gm = r * x / (r + x + 1e-20)
+            rho = torch.where(kind == _lib.LOSS_WELSCH, welsch, torch.where(kind == _lib.LOSS_HINGE, hinge,
+                                                                         torch.where(kind == _lib.LOSS_GEMAN_MCCLURE, gm, huber)))
             h = torch.where(flat, (rho + 1e-20).sqrt(), (rho / e.shape[-1] + 1e-20).sqrt())
             return torch.where(kind == _lib.LOSS_NONE, e, h)
         eb = robust_error(eb, t.robust_between, t.log_radius_between, t.loss_between)
