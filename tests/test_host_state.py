@@ -211,3 +211,33 @@ def test_check_singular_zeroes_the_singular_items():
     plain = th.HipCholeskySolver(obj, linearization_kwargs=dict(kernels=OracleKernels()))
     plain.linearization.linearize()
     np.testing.assert_allclose(plain.solve(damping=0.1, ellipsoidal_damping=False)[[0, 1, 3]].numpy(), delta[[0, 1, 3]].numpy())
+
+
+def test_update_skips_the_variable_walk_only_when_batch_and_device_are_unchanged():
+    """Objective.update(input_tensors) re-resolves the batch size (a pass over every variable) unless every new tensor keeps its
+    variable's batch size and device and nothing else was edited since the last resolve (theseus/core/objective.py:708-811)."""
+    import theseus_amd as th
+    dt = torch.float64
+    obj = th.Objective(dtype=dt)
+    a = th.Vector(tensor=torch.zeros(2, 3, dtype=dt), name="a")
+    b = th.Vector(tensor=torch.zeros(1, 3, dtype=dt), name="b")
+    obj.add(th.Difference(a, b, th.ScaleCostWeight(torch.ones(1, dtype=dt)), name="d"))
+    calls = {"n": 0}
+    walk = obj._resolve_batch_size
+
+    def counted():
+        calls["n"] += 1
+        return walk()
+    obj._resolve_batch_size = counted
+    obj.update({"a": torch.ones(2, 3, dtype=dt)})
+    assert obj.batch_size == 2 and calls["n"] == 1                      # first update: resolved
+    obj.update({"a": torch.full((2, 3), 2.0, dtype=dt)})
+    assert obj.batch_size == 2 and calls["n"] == 1                      # same shapes: the walk is skipped
+    assert float(a.tensor[0, 0]) == 2.0
+    obj.update({"a": torch.ones(5, 3, dtype=dt)})
+    assert obj.batch_size == 5 and calls["n"] == 2                      # another batch size: resolved again
+    b.update(torch.ones(1, 3, dtype=dt))                                 # an edit outside update(): the next update() walks again
+    obj.update({"a": torch.zeros(5, 3, dtype=dt)})
+    assert obj.batch_size == 5 and calls["n"] == 3
+    with pytest.raises(ValueError):
+        obj.update({"a": torch.zeros(5, 3, dtype=dt), "b": torch.zeros(4, 3, dtype=dt)})   # 5 vs 4: not broadcastable
