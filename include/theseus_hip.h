@@ -222,6 +222,11 @@ typedef struct {
   const int32_t* tile_ptr;
   const int32_t* piece_blk;
   const int32_t* piece_rc;
+  int32_t max_tile_pieces; /* the largest number of pieces of one OFF-DIAGONAL tile (host: max of tile_ptr[t + 1] - tile_ptr[t] over
+                            * i > j), 0 = unknown.  The factorisations pick how an off-diagonal tile takes its pieces of H by it: up
+                            * to 64 (pose graphs: ~15 blocks per tile) they are ADDED to the tile's Schur update by the matrix cores
+                            * (a rank-bd MFMA per piece, one barrier); above (a bundle adjustment's reduced camera system: up to
+                            * 21 x 21 blocks per tile) or unknown they are gathered through LDS.  Same results either way. */
 } thx_hblock_layout;
 int thx_pg_assemble_blocks(const thx_pg_structure* s, const thx_pg_data* d, const thx_hblock_layout* layout, void* Hc,
                            int64_t bstride, void* g, int dtype, const thx_lie_eps* eps, void* stream);
@@ -299,11 +304,16 @@ int thx_se3_retract(const void* poses, const void* delta, int64_t ldd, double st
  *          one workgroup per tile of the trailing matrix, each a single 128^3 product -- instead of the left-looking one whose
  *          serial K-loops leave the chip empty at 8 ... 64 problems (the reference's published batch range,
  *          evaluations/pose_graph_synthetic.sh:7).  Another summation order: the factor agrees with the left-looking one to
- *          rounding, not bit for bit.  0 = never; < 0: the default (32, or THX_CHOL_RL_MAX_BATCH). */
+ *          rounding, not bit for bit.  0 = never; < 0: the default (32, or THX_CHOL_RL_MAX_BATCH).
+ *        hb_scatter_max_pieces: block-compact H (thx_hblock_layout) whose off-diagonal tiles hold at most this many pieces
+ *          (layout.max_tile_pieces) has them ADDED to the tile's Schur update by the matrix cores; above, they are gathered through
+ *          LDS (see thx_hblock_layout.max_tile_pieces; the same bits either way).  0 = always gather; < 0: the default (64, or
+ *          THX_HB_SCATTER_MAX_PIECES). */
 typedef struct {
   int32_t split_diag_min_batch;
   int32_t column_pairs;
   int32_t right_looking_max_batch;
+  int32_t hb_scatter_max_pieces;
 } thx_chol_schedule;
 
 /* ---- tile-sparse Cholesky for LARGE pose graphs -- the functional analogue of BaspachoSparseSolver

@@ -336,6 +336,32 @@ def test_schur_block_list_equals_the_dense_frame(name):
     assert ((w0 - w1).abs().max() / w0.abs().max()).item() < tol
 
 
+@pytest.mark.parametrize("name", ["ba_mid_f64_lm", "ba_mid_f32_lm"])
+def test_dense_tiles_through_the_matrix_core_scatter_equal_the_gather(name):
+    """A reduced camera system's tiles hold up to 21 x 21 blocks and take the LDS gather by default; forced through the matrix-core
+    path (thx_chol_schedule.hb_scatter_max_pieces: hb_add's overflow chunks of 64 pieces, several per tile) the level-scheduled
+    factorisation must give the same bits -- both ways add the same values to the same sums."""
+    import theseus_amd as th
+    g = load_golden(name)
+    got = []
+    for limit in (-1, 1 << 20):
+        obj, _, _ = build_ba_objective(th, g, "cuda")
+        opt = th.LevenbergMarquardt(obj, max_iterations=1, linear_solver_kwargs=dict(ordering="nd"))
+        solver, lin = opt.linear_solver, opt.linear_solver.linearization
+        obj.update()
+        lin.linearize()
+        prev = solver.K.chol_hb_scatter_max_pieces(limit)
+        try:
+            lam = torch.full((lin.g.shape[0],), 0.02, dtype=lin.g.dtype, device="cuda")
+            got.append(solver.solve(damping=lam, ellipsoidal_damping=True, damping_eps=1e-8).clone())
+        finally:
+            solver.K.chol_hb_scatter_max_pieces(prev)
+        assert solver.levels
+        pieces = solver._level_layout.c.max_tile_pieces
+    assert pieces > 64, pieces     # (the default is the gather here)
+    assert torch.equal(got[0], got[1])
+
+
 @pytest.mark.parametrize("ordering", ["natural", "nd", "md"])
 def test_ba_full_size_first_solve_under_every_camera_order(ordering):
     """The reference's first linear solve at 512 / 8192 / 32768 (tests/golden/ba_full_f64_lm) under the cameras' own order

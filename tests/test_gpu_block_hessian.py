@@ -56,16 +56,28 @@ def test_block_assembly_is_bit_identical_to_the_dense_frame(K, name):
     np.testing.assert_array_equal(hb.expand(Hc.cpu().numpy(), ld) * tiles.cpu().numpy(), (He * tiles).cpu().numpy())
 
 
+# how an off-diagonal tile takes its pieces of H (thx_chol_schedule.hb_scatter_max_pieces): "mfma" -- added by the matrix cores, the
+# default for a pose graph's few blocks per tile (tiles with more than the 21 blocks the registers hold take hb_add's overflow chunks:
+# tests/test_gpu_ba.py forces a reduced camera system through them); "lds" -- the gather rounds (a bundle adjustment's dense tiles).
+# Both bit-identical to the dense frame.
+GATHER = {"mfma": -1, "lds": 0}
+
+
+@pytest.mark.parametrize("gather", list(GATHER))
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("name,ellipsoidal", [("pg_full_f32_lm", False), ("pg_full_f64_lm", True), ("pg_f64_lm", False)])
-def test_factor_from_blocks_is_bit_identical(K, name, ellipsoidal, split):
+def test_factor_from_blocks_is_bit_identical(K, name, ellipsoidal, split, gather):
     """thx_chol_factor_hblocks against thx_chol_factor_forward on the dense frame of the same H: (0 - L L^T) + H and H - L L^T
-    round identically, so L, the panels, y and info agree bit for bit -- fused and split diagonal phase, 12-tile and 1-tile n."""
+    round identically, so L, the panels, y and info agree bit for bit -- fused and split diagonal phase, 12-tile and 1-tile n,
+    pieces added by the matrix cores (hb_scatter) and gathered through LDS."""
     s, hb, dhb, H, gv, Hc, g2, n, ld = _assembled(K, name)
     B = H.shape[0]
     nt = (n + 127) // 128
+    if nt > 1:   # the default really is the matrix-core path here
+        assert 1 <= dhb.c.max_tile_pieces <= 64
     lam = torch.full((B,), 1e-3, dtype=H.dtype, device="cuda")
     prev = K.chol_split_diag_min_batch(0 if split else 2 ** 31 - 1)
+    prev_g = K.chol_hb_scatter_max_pieces(GATHER[gather])
     try:
         out = []
         for compact in (False, True):
@@ -80,6 +92,7 @@ def test_factor_from_blocks_is_bit_identical(K, name, ellipsoidal, split):
             out.append((torch.tril(L[:, :n, :n]), panels, y, info))
     finally:
         K.chol_split_diag_min_batch(prev)
+        K.chol_hb_scatter_max_pieces(prev_g)
     (La, Pa, ya, ia), (Lb, Pb, yb, ib) = out
     assert int(ia.abs().sum()) == 0 and int(ib.abs().sum()) == 0
     assert torch.equal(La, Lb) and torch.equal(ya, yb)
@@ -88,15 +101,17 @@ def test_factor_from_blocks_is_bit_identical(K, name, ellipsoidal, split):
             assert torch.equal(Pa[:, :, 32 * u:32 * u + 32, 32 * v:32 * v + 32], Pb[:, :, 32 * u:32 * u + 32, 32 * v:32 * v + 32])
 
 
+@pytest.mark.parametrize("gather", list(GATHER))
 @pytest.mark.parametrize("split", [False, True])
-def test_factor_from_blocks_in_column_pairs_is_bit_identical(K, split):
-    """thx_chol_factor_hblocks, fp32, 12 tile columns: the column-pair schedule (both H tiles of a workgroup gathered from the
+def test_factor_from_blocks_in_column_pairs_is_bit_identical(K, split, gather):
+    """thx_chol_factor_hblocks, fp32, 12 tile columns: the column-pair schedule (both H tiles of a workgroup taken from the
     block list) against the column-by-column one -- L, panels, y bit for bit."""
     s, hb, dhb, H, gv, Hc, g2, n, ld = _assembled(K, "pg_full_f32_lm")
     B = H.shape[0]
     nt = (n + 127) // 128
     lam = torch.full((B,), 1e-3, dtype=H.dtype, device="cuda")
     prev_split = K.chol_split_diag_min_batch(0 if split else 2 ** 31 - 1)
+    prev_g = K.chol_hb_scatter_max_pieces(GATHER[gather])
     out = []
     try:
         for pairs in (True, False):
@@ -112,6 +127,7 @@ def test_factor_from_blocks_in_column_pairs_is_bit_identical(K, split):
                 K.chol_column_pairs(prev)
     finally:
         K.chol_split_diag_min_batch(prev_split)
+        K.chol_hb_scatter_max_pieces(prev_g)
     (La, Pa, ya, ia), (Lb, Pb, yb, ib) = out
     assert int(ia.abs().sum()) == 0 and int(ib.abs().sum()) == 0
     assert torch.equal(La, Lb) and torch.equal(ya, yb)

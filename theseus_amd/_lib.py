@@ -21,7 +21,7 @@ THX_BA_ERR_CHUNKS = 256
 LOSS_NONE, LOSS_WELSCH, LOSS_HUBER, LOSS_HINGE = 0, 1, 2, 3  # THX_LOSS_* (theseus/core/robust_loss.py:33-62)
 LOSS_FLATTEN = 4  # THX_LOSS_FLATTEN: RobustCostFunction(flatten_dims=True), or-ed into a loss code
 LOSS_GEMAN_MCCLURE = 8  # THX_LOSS_GEMAN_MCCLURE (robust_loss.py:92-113; the radius entry carries log(mu * radius))
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 
 class LieEps(Structure):
@@ -63,7 +63,8 @@ class TilePattern(Structure):  # thx_tile_pattern: tile-level symbolic factorisa
 
 
 class CholSchedule(Structure):  # thx_chol_schedule: per-call schedule of the factorisations (negative = the library default)
-    _fields_ = [("split_diag_min_batch", c_int32), ("column_pairs", c_int32), ("right_looking_max_batch", c_int32)]
+    _fields_ = [("split_diag_min_batch", c_int32), ("column_pairs", c_int32), ("right_looking_max_batch", c_int32),
+                ("hb_scatter_max_pieces", c_int32)]
 
 
 class LevelSchedule(Structure):  # thx_level_schedule: elimination-tree levels of a tile pattern (2 host + 2 device int32 tables)
@@ -73,7 +74,19 @@ class LevelSchedule(Structure):  # thx_level_schedule: elimination-tree levels o
 
 class HBlockLayout(Structure):  # thx_hblock_layout: block-compact Hessian (device int32 tables)
     _fields_ = [(k, c_int32) for k in ("nblocks", "bd", "nvars", "ntiles")] + [
-        (k, c_void_p) for k in ("diag_blk", "inc_blk", "tile_ptr", "piece_blk", "piece_rc")]
+        (k, c_void_p) for k in ("diag_blk", "inc_blk", "tile_ptr", "piece_blk", "piece_rc")] + [("max_tile_pieces", c_int32)]
+
+
+def max_offdiag_tile_pieces(tile_ptr, ntiles: int) -> int:
+    """thx_hblock_layout.max_tile_pieces: the largest piece count of a lower tile t = i (i + 1) / 2 + j with i > j (0: none)."""
+    import numpy as np
+    cnt = np.diff(np.asarray(tile_ptr, dtype=np.int64))
+    if cnt.size < ntiles * (ntiles + 1) // 2 or ntiles < 2:
+        return 0
+    off = np.ones(ntiles * (ntiles + 1) // 2, bool)
+    i = np.arange(ntiles)
+    off[i * (i + 1) // 2 + i] = False
+    return int(cnt[: off.size][off].max())
 
 
 class SE2Eps(Structure):  # thx_se2_eps (theseus/global_params.py:46-59)

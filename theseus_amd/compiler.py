@@ -230,4 +230,5 @@ class DeviceHessianBlocks:
         c.nblocks, c.bd, c.nvars, c.ntiles = hb.nblocks, hb.bd, hb.nvars, hb.ntiles
         for f in self._FIELDS:
             setattr(c, f, self.t[f].data_ptr())
+        c.max_tile_pieces = _lib.max_offdiag_tile_pieces(hb.tile_ptr, hb.ntiles)
         self.c = c

@@ -1244,6 +1244,7 @@ struct HBlk {
   const int32_t* piece_blk;
   const int32_t* piece_rc;
   const int32_t* diag_blk;   // (nvars) block id of variable v's diagonal block (the right-looking schedule's damping pass; may be null)
+  int max_tile_pieces;       // thx_hblock_layout.max_tile_pieces (host side: picks the off-diagonal kernels' HB mode); 0: unknown
 };
 
 // The pieces of lower tile (ti, tj) of problem b -- f(r, c, value), (r, c) relative to the tile origin and inside the tile; the
@@ -1256,13 +1257,31 @@ struct HBPre {
   T v[NPRE];
   int rc[NPRE];   // (r << 8) | c inside the tile, -1: nothing
   int p0, cnt;
+  int wmeta;      // lane l of every wave: piece_rc of the tile's piece l (hb_scatter: readlane)
+  __device__ __forceinline__ void empty() {   // (timing experiments)
+    p0 = cnt = wmeta = 0;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      rc[k] = -1;
+      v[k] = T(0);
+    }
+  }
+  // the tile's elements, in list order, -> LDS (element idx of the tile's run at list[idx]; the caller publishes them with a barrier)
+  __device__ __forceinline__ void to_list(T* list, int tid) const {
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k)
+      if (tid + 256 * k < cnt) list[tid + 256 * k] = v[k];   // (k < NPRE: what the registers hold)
+  }
   // BRANCH-FREE (round 5): the loads of all NPRE elements are independent of each other -- with an ``if (idx < cnt)`` around each
   // element hipcc emitted  table load, s_waitcnt vmcnt(0), table load, s_waitcnt vmcnt(0), value load  once per element, i.e.
   // 2 NPRE exposed round trips at the head of every workgroup (6 per off-diagonal tile, 14 per SYRK workgroup).  Now: both tables
   // of all elements in one batch, one wait, all values in one batch whose wait is the first use (after the K-loop).  A lane
   // without an element reads element 0 of the tile's first piece and discards it.
-  __device__ __forceinline__ void load(const HBlk& hb, int b, int ti, int tj, int tid) {
-    const T* base = static_cast<const T*>(hb.blocks) + (int64_t)b * hb.bstride;
+  // (Round 6 measured the chain in TWO PHASES -- tile_ptr -> piece_rc / piece_blk at the kernel's very top, the values behind the
+  //  first k-chunk's loads: no gain in fp64, 0.4 of 43.5 ms SLOWER in fp32, profiles/r6/ab_.  load() keeps both in one place; the
+  //  split stays as two functions.)
+  int tw[NPRE], tblk[NPRE];   // (live between the phases only)
+  __device__ __forceinline__ void load_tables(const HBlk& hb, int ti, int tj, int tid) {
     const int bd = hb.bd, bb = bd * bd, t = ti * (ti + 1) / 2 + tj;
     p0 = hb.tile_ptr[t];
     cnt = (hb.tile_ptr[t + 1] - p0) * bb;
@@ -1270,29 +1289,41 @@ struct HBPre {
     for (int k = 0; k < NPRE; ++k) {
       rc[k] = -1;
       v[k] = T(0);
+      tw[k] = tblk[k] = 0;
     }
+    wmeta = 0;
     if (cnt <= 0) return;   // (workgroup uniform; p0 may be the END of the piece list)
-    int w[NPRE], blk[NPRE], e[NPRE];
-    bool ok[NPRE];
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
       const int idx = tid + 256 * k;
-      ok[k] = idx < cnt;
-      const int idc = ok[k] ? idx : 0;
-      const int pc = p0 + idc / bb;
-      e[k] = idc % bb;
-      w[k] = hb.piece_rc[pc];
-      blk[k] = hb.piece_blk[pc];
+      const int pc = p0 + (idx < cnt ? idx : 0) / bb;
+      tw[k] = hb.piece_rc[pc];
+      tblk[k] = hb.piece_blk[pc];
     }
+    wmeta = hb.piece_rc[p0 + min(tid & 63, cnt / bb - 1)];
+  }
+  // BRANCH-FREE (round 5): the loads of all NPRE elements are independent of each other -- all values in one batch whose wait is
+  // the first use (after the K-loop).  A lane without an element reads element 0 of the tile's first piece and discards it.
+  __device__ __forceinline__ void load_values(const HBlk& hb, int b, int tid) {
+    if (cnt <= 0) return;
+    const T* base = static_cast<const T*>(hb.blocks) + (int64_t)b * hb.bstride;
+    const int bd = hb.bd, bb = bd * bd;
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int r = (int)(short)(w[k] >> 16) + e[k] / bd, c = (int)(short)(w[k] & 0xffff) + e[k] % bd;
-      const T val = base[(int64_t)blk[k] * bb + e[k]];
-      if (ok[k] && r >= 0 && r < TILE && c >= 0 && c < TILE) {
+      const int idx = tid + 256 * k;
+      const bool ok = idx < cnt;
+      const int e = (ok ? idx : 0) % bb;
+      const int r = (int)(short)(tw[k] >> 16) + e / bd, c = (int)(short)(tw[k] & 0xffff) + e % bd;
+      const T val = base[(int64_t)tblk[k] * bb + e];
+      if (ok && r >= 0 && r < TILE && c >= 0 && c < TILE) {
         rc[k] = (r << 8) | c;
         v[k] = val;
       }
     }
+  }
+  __device__ __forceinline__ void load(const HBlk& hb, int b, int ti, int tj, int tid) {
+    load_tables(hb, ti, tj, tid);
+    load_values(hb, b, tid);
   }
   template <typename F>
   __device__ __forceinline__ void foreach(const HBlk& hb, int b, int tid, F&& f) const {
@@ -1349,8 +1380,22 @@ struct HBPre2 {
   T v[NPRE];
   int rc[NPRE];
   int p0, p1, cnt;   // first piece of tile 0 / of tile 1, elements of both
-  __device__ __forceinline__ void load(const HBlk& hb, int b, int ti, int tj, int tid) {
-    const T* base = static_cast<const T*>(hb.blocks) + (int64_t)b * hb.bstride;
+  int wmeta;         // (HBPre: lane l holds piece_rc of piece l of the run)
+  __device__ __forceinline__ void empty() {   // (timing experiments)
+    p0 = p1 = cnt = wmeta = 0;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      rc[k] = -1;
+      v[k] = T(0);
+    }
+  }
+  __device__ __forceinline__ void to_list(T* list, int tid) const {
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k)
+      if (tid + 256 * k < cnt) list[tid + 256 * k] = v[k];   // (k < NPRE: what the registers hold)
+  }
+  int tw[NPRE], tblk[NPRE], tpc[NPRE];   // (HBPre: the two phases)
+  __device__ __forceinline__ void load_tables(const HBlk& hb, int ti, int tj, int tid) {
     const int bd = hb.bd, bb = bd * bd, t = ti * (ti + 1) / 2 + tj;
     p0 = hb.tile_ptr[t];
     p1 = hb.tile_ptr[t + 1];
@@ -1359,29 +1404,39 @@ struct HBPre2 {
     for (int k = 0; k < NPRE; ++k) {
       rc[k] = -1;
       v[k] = T(0);
+      tw[k] = tblk[k] = tpc[k] = 0;
     }
+    wmeta = 0;
     if (cnt <= 0) return;   // (workgroup uniform)
-    int w[NPRE], blk[NPRE], e[NPRE], pcs[NPRE];
-    bool ok[NPRE];
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
       const int idx = tid + 256 * k;
-      ok[k] = idx < cnt;
-      const int idc = ok[k] ? idx : 0;
-      pcs[k] = p0 + idc / bb;
-      e[k] = idc % bb;
-      w[k] = hb.piece_rc[pcs[k]];
-      blk[k] = hb.piece_blk[pcs[k]];
+      tpc[k] = p0 + (idx < cnt ? idx : 0) / bb;
+      tw[k] = hb.piece_rc[tpc[k]];
+      tblk[k] = hb.piece_blk[tpc[k]];
     }
+    wmeta = hb.piece_rc[p0 + min(tid & 63, cnt / bb - 1)];
+  }
+  __device__ __forceinline__ void load_values(const HBlk& hb, int b, int tid) {
+    if (cnt <= 0) return;
+    const T* base = static_cast<const T*>(hb.blocks) + (int64_t)b * hb.bstride;
+    const int bd = hb.bd, bb = bd * bd;
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int r = (int)(short)(w[k] >> 16) + e[k] / bd, c = (int)(short)(w[k] & 0xffff) + e[k] % bd;
-      const T val = base[(int64_t)blk[k] * bb + e[k]];
-      if (ok[k] && r >= 0 && r < TILE && c >= 0 && c < TILE) {
-        rc[k] = ((pcs[k] >= p1 ? 1 : 0) << 16) | (r << 8) | c;
+      const int idx = tid + 256 * k;
+      const bool ok = idx < cnt;
+      const int e = (ok ? idx : 0) % bb;
+      const int r = (int)(short)(tw[k] >> 16) + e / bd, c = (int)(short)(tw[k] & 0xffff) + e % bd;
+      const T val = base[(int64_t)tblk[k] * bb + e];
+      if (ok && r >= 0 && r < TILE && c >= 0 && c < TILE) {
+        rc[k] = ((tpc[k] >= p1 ? 1 : 0) << 16) | (r << 8) | c;
         v[k] = val;
       }
     }
+  }
+  __device__ __forceinline__ void load(const HBlk& hb, int b, int ti, int tj, int tid) {
+    load_tables(hb, ti, tj, tid);
+    load_values(hb, b, tid);
   }
   // f(r, c, value) for the pieces of tile ``sel`` (0 / 1)
   template <typename F>
@@ -1403,6 +1458,116 @@ struct HBPre2 {
   }
 };
 constexpr int HB_NPRE_DIAG = 7;   // diagonal tiles: ~21 diagonal blocks + their chain / loop-closure neighbours (~49 pieces)
+
+// ---- H_ij's pieces ADDED to the accumulators by the matrix cores (round 6) ----
+// The gather rounds above (zero half a tile of LDS, scatter, barrier, read it back in the accumulator layout, barrier -- 2 rounds
+// in fp32, 4 in fp64, 7 / 13 barriers) cost 17 k (fp32) / 40 k (fp64) cycles per tile while the partner workgroup is in its
+// K-loop: 2.4 of 44 ms and 5.7 of 93 ms of the headline factorisations (profiles/r6: the same launches with a register-only fake
+// of the gather).  A pose graph's off-diagonal tile holds <= ~20 blocks of 6 x 6: 720 values for 16384 accumulators.  So:
+// P = -P in registers, the tile's values as ONE contiguous list in LDS (one barrier), and per piece a rank-bd update on the matrix
+// cores, acc(tile column c, tile row r) += sum_k [c == c0 + k] V[r - r0][k]: operand A is a 0/1 selector computed from the lane
+// index, operand B the piece's values of this lane's row, the accumulator block is picked by wave-uniform branches (the piece's
+// origin comes from lane p of ``wmeta`` by readlane).  One exact product v * 1 per element, every other term 0 * x = 0: the result
+// is the bit pattern of  v - sum  as before (up to the sign of a zero).
+// fp32, v_mfma_f32_32x32x2: lane (rr = lane & 31, g = lane >> 5) supplies A[i = rr][k = g], B[k = g][j = rr]; acc.v[cb][v] is
+// D[i = 8 (v / 4) + 4 g + v % 4][j = rr] = tile (row 32 wave + rr, column 32 cb + i)
+__device__ __forceinline__ void hb_scatter(Engine<float>::Acc& P, const float* list, int wmeta, int pa, int pb, int bd, int wave,
+                                           int lane) {
+  const int rr = lane & 31, g = lane >> 5, bb = bd * bd, rw0 = 32 * wave;
+  // lane l looks at piece l: does it touch this wave's rows / block cb's columns?  One ballot per accumulator block, then a loop
+  // over the set bits -- every loop updates ONE accumulator block (one loop over the pieces with a branch per block made hipcc
+  // shuffle the accumulators between registers and spill)
+  const int r0l = (int)(short)(wmeta >> 16), c0l = (int)(short)(wmeta & 0xffff);
+  const bool rowhit = lane >= pa && lane < pb && r0l + bd > rw0 && r0l < rw0 + 32;
+  static_for<4>([&](auto icb) __attribute__((always_inline)) {
+    constexpr int cb = decltype(icb)::value;
+    unsigned long long mask = __builtin_amdgcn_ballot_w64(rowhit && c0l + bd > 32 * cb && c0l < 32 * cb + 32);
+    while (mask) {
+      const int p = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int w = __builtin_amdgcn_readlane(wmeta, p);
+      const int r0 = (int)(short)(w >> 16), c0 = (int)(short)(w & 0xffff);
+      const int dr = rw0 + rr - r0;
+      const bool rin = dr >= 0 && dr < bd;
+      const float* src = list + p * bb + (rin ? dr : 0) * bd;
+      const int t = c0 + g - rr - 32 * cb;   // A[i = rr][k = g], step m: 32 cb + rr == c0 + 2 m + g
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const int kc = 2 * m + g;
+        const float x = src[min(kc, bd - 1)];
+        if (2 * m < bd)
+          P.v[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(t + 2 * m == 0 ? 1.f : 0.f, rin && kc < bd ? x : 0.f, P.v[cb], 0, 0, 0);
+      }
+    }
+  });
+}
+// fp64, v_mfma_f64_16x16x4: lane (rl = lane & 15, kq = lane >> 4) supplies A[i = rl][k = kq], B[k = kq][j = rl]; acc.v[h][cb][v] is
+// D[i = 4 v + kq][j = rl] = tile (row 32 wave + 16 h + rl, column 16 cb + i)
+__device__ __forceinline__ void hb_scatter(Engine<double>::Acc& P, const double* list, int wmeta, int pa, int pb, int bd, int wave,
+                                           int lane) {
+  const int rl = lane & 15, kq = lane >> 4, bb = bd * bd, rw0 = 32 * wave;
+  const int r0l = (int)(short)(wmeta >> 16), c0l = (int)(short)(wmeta & 0xffff);
+  const bool mine = lane >= pa && lane < pb;
+  static_for<2>([&](auto ih) __attribute__((always_inline)) {
+    constexpr int h = decltype(ih)::value;
+    const int rh0 = rw0 + 16 * h;
+    const bool rowhit = mine && r0l + bd > rh0 && r0l < rh0 + 16;
+    static_for<8>([&](auto icb) __attribute__((always_inline)) {
+      constexpr int cb = decltype(icb)::value;
+      unsigned long long mask = __builtin_amdgcn_ballot_w64(rowhit && c0l + bd > 16 * cb && c0l < 16 * cb + 16);
+      while (mask) {
+        const int p = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int w = __builtin_amdgcn_readlane(wmeta, p);
+        const int r0 = (int)(short)(w >> 16), c0 = (int)(short)(w & 0xffff);
+        const int dr = rh0 + rl - r0;
+        const bool rin = dr >= 0 && dr < bd;
+        const double* src = list + p * bb + (rin ? dr : 0) * bd;
+        const int t = c0 + kq - rl - 16 * cb;   // A[i = rl][k = kq], step m: 16 cb + rl == c0 + 4 m + kq
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int kc = 4 * m + kq;
+          const double x = src[min(kc, bd - 1)];
+          if (4 * m < bd)
+            P.v[h][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(t + 4 * m == 0 ? 1.0 : 0.0, rin && kc < bd ? x : 0.0, P.v[h][cb], 0, 0, 0);
+        }
+      }
+    });
+  });
+}
+
+// acc += the pieces [lo, hi) of the run ``pre`` describes (HBPre: the tile's, HBPre2: both tiles').  Chunk 0 -- the pieces that sit in
+// the registers whole, at most 64 (wmeta) -- goes through ``list`` (written here when ``write_list``: once per run, the caller
+// guarantees the buffer is free); a tile with more pieces (rare in a pose graph: > 21 blocks of 6 x 6 in one 128 x 128 tile) takes
+// further chunks of 64 straight from memory into ``list + LIST0`` -- two dependent loads and two barriers each, exposed.
+// Workgroup uniform control flow; LDS use: LIST0 + 64 bd^2 elements.
+constexpr int HB_MODE_SCATTER = 1, HB_MODE_ROUNDS = 2;   // the kernels' HB template argument (0: dense H)
+template <typename T, typename Acc, typename Pre, int LIST0>
+__device__ __forceinline__ void hb_add(Acc& P, const Pre& pre, const HBlk& hb, int b, T* list, int lo, int hi, bool write_list,
+                                       int tid) {
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int bd = hb.bd, bb = bd * bd;
+  const int nreg = min(min(pre.cnt / bb, LIST0 / bb), 64);
+  if (write_list) {
+    pre.to_list(list, tid);
+#ifndef THX_EXP_NO_HBBARRIER   // (timing experiment, WRONG results)
+    __syncthreads();
+#endif
+  }
+  hb_scatter(P, list, pre.wmeta, lo, min(hi, nreg), bd, wave, lane);
+  if (hi > nreg) {   // (workgroup uniform)
+    const T* base = static_cast<const T*>(hb.blocks) + (int64_t)b * hb.bstride;
+    T* over = list + LIST0;
+    for (int q0 = max(lo, nreg); q0 < hi; q0 += 64) {
+      const int nq = min(64, hi - q0);
+      __syncthreads();   // the previous chunk has been read
+      for (int idx = tid; idx < nq * bb; idx += 256) over[idx] = base[(int64_t)hb.piece_blk[pre.p0 + q0 + idx / bb] * bb + idx % bb];
+      const int wm = hb.piece_rc[pre.p0 + q0 + min(lane, nq - 1)];
+      __syncthreads();
+      hb_scatter(P, over, wm, 0, nq, bd, wave, lane);
+    }
+  }
+}
 
 template <typename T>
 struct DiagSmem {
@@ -1927,7 +2092,7 @@ __device__ __forceinline__ void sub_mma_sw(const float* Pc, const Engine<float>:
   }
 }
 
-template <bool HB>
+template <int HB>   // 0: dense H; HB_MODE_SCATTER / HB_MODE_ROUNDS: block-compact H, how a tile's pieces reach the accumulators
 __global__ void __launch_bounds__(256, 2)
 chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, const float* __restrict__ panel, int n,
                         int64_t ld, int jarg, int ntiles, int i_first, int nrow_tiles, int B, TilePat pat, HBlk hb) {
@@ -1995,7 +2160,11 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   float4 hr[4][4];
   HBPre<float, HB ? HB_NPRE_OFF : 1> hbp;
   auto prologue = [&]() __attribute__((always_inline)) {
+#ifdef THX_EXP_NO_HBLOAD   // timing experiment (WRONG results): the off-diagonal tiles without their table / value loads
+    if constexpr (HB) hbp.empty();
+#else
     if constexpr (HB) hbp.load(hb, b, i, j, tid);
+#endif
     if constexpr (!HB) {
       const float* Hrow = H + mat + (int64_t)(row0 + (rvalid ? r : 0)) * ld + col0 + 4 * g;
 #pragma unroll
@@ -2048,6 +2217,25 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
     constexpr int LDH = 132;
     static_assert(64 * LDH <= OFF32_STAGE_FLOATS, "half an H tile must fit in the staging buffers");
     __syncthreads();   // the K-loop's last chunk has been consumed
+    // P = -sum first, H_ij's pieces are ADDED
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) P.v[cb][q] = -P.v[cb][q];
+#ifdef THX_EXP_NO_HBLOAD
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {   // (full-entropy mantissas: a constant pattern draws less power under the cap)
+        const unsigned hsh = (unsigned)(tid * 64 + cb * 16 + q + 4099 * blockIdx.x) * 2654435761u;
+        P.v[cb][q] += ((lane & 1) ? 1e-3f : -1e-3f) * (1.f + (float)(hsh >> 8) * (1.f / 16777216.f));
+      }
+#endif
+    if constexpr (HB == HB_MODE_SCATTER) {
+      // a few pieces per tile (pose graphs): added by the matrix cores, see hb_scatter.  (hb_add's barrier also publishes the
+      // panel copy -- also when the K-loop had no iterations)
+      hb_add<float, Engine<float>::Acc, decltype(hbp), 256 * HB_NPRE_OFF>(P, hbp, hb, b, smem, 0, hbp.cnt / (hb.bd * hb.bd), true, tid);
+    } else {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       for (int k = tid; k < 64 * LDH / 4; k += 256) reinterpret_cast<float4*>(smem)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2063,13 +2251,14 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float4 h = *reinterpret_cast<const float4*>(hrow + 32 * cb + 8 * q);
-            P.v[cb][4 * q + 0] = h.x - P.v[cb][4 * q + 0];
-            P.v[cb][4 * q + 1] = h.y - P.v[cb][4 * q + 1];
-            P.v[cb][4 * q + 2] = h.z - P.v[cb][4 * q + 2];
-            P.v[cb][4 * q + 3] = h.w - P.v[cb][4 * q + 3];
+            P.v[cb][4 * q + 0] = h.x + P.v[cb][4 * q + 0];   // (P holds -sum already)
+            P.v[cb][4 * q + 1] = h.y + P.v[cb][4 * q + 1];
+            P.v[cb][4 * q + 2] = h.z + P.v[cb][4 * q + 2];
+            P.v[cb][4 * q + 3] = h.w + P.v[cb][4 * q + 3];
           }
       }
       __syncthreads();
+    }
     }
   } else {
     // P = H_ij - sum (rows outside the matrix: zero)
@@ -2198,7 +2387,7 @@ static_assert(64 * 132 <= OFF2_PANEL_OFF, "the H gather (half a tile) must not t
 static_assert(2 * 128 * 36 <= OFF2_PANEL_OFF, "staging buffers 0 and 1 must not touch the panel copy");
 static_assert(OFF2_SMEM >= 3 * 128 * 36 * 4 && 2 * OFF2_SMEM <= 160 * 1024, "three staging buffers; two workgroups per CU");
 
-template <bool HB>
+template <int HB>   // (as chol_offdiag_f32_kernel)
 __global__ void __launch_bounds__(256, 2)
 chol_offdiag2_f32_kernel(const float* __restrict__ H, float* __restrict__ L, const float* __restrict__ panel, int n,
                          int64_t ld, int j, int ntiles, int i_first, int nrow_tiles, int B, HBlk hb) {
@@ -2260,7 +2449,11 @@ chol_offdiag2_f32_kernel(const float* __restrict__ H, float* __restrict__ L, con
   Engine<float>::zero(P1);
   const int nk = 4 * j;
   if (nk > 0) gload3(0);
+#ifdef THX_EXP_NO_HBLOAD
+  if constexpr (HB) hb2.empty();
+#else
   if constexpr (HB) hb2.load(hb, b, i, j, tid);
+#endif
   const float* sBw = sB + 32 * wave * 36;
   for (int kc = 0; kc < nk; ++kc) {
     __syncthreads();
@@ -2316,6 +2509,30 @@ chol_offdiag2_f32_kernel(const float* __restrict__ H, float* __restrict__ L, con
   auto h_minus = [&](Engine<float>::Acc& P, int sel, int jj) __attribute__((always_inline)) {
     if constexpr (HB) {
       constexpr int LDH = 132;
+      // P = -sum first, H's pieces are ADDED
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) P.v[cb][q] = -P.v[cb][q];
+#ifdef THX_EXP_NO_HBLOAD
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const unsigned hsh = (unsigned)(tid * 64 + cb * 16 + q + 4099 * blockIdx.x + 77 * sel) * 2654435761u;
+          P.v[cb][q] += ((lane & 1) ? 1e-3f : -1e-3f) * (1.f + (float)(hsh >> 8) * (1.f / 16777216.f));
+        }
+#endif
+      if constexpr (HB == HB_MODE_SCATTER) {
+        // a few pieces per tile (pose graphs): added by the matrix cores, see hb_scatter.  Both tiles' values go to staging
+        // buffer 0 as ONE list before tile (i, j)'s pieces are applied (the caller's barrier before panel_dma(j): the K-loop is
+        // done with the buffers); nothing writes that buffer until tile (i, j + 1)'s turn (column j's share of it is staged in
+        // buffer 1): no second copy, no second barrier
+        const int n0 = hb2.p1 - hb2.p0, ntot = hb2.cnt / (hb.bd * hb.bd);
+        static_assert(256 * 2 * HB_NPRE_OFF + 64 * 36 <= 128 * 36, "list + overflow chunk inside staging buffer 0");
+        hb_add<float, Engine<float>::Acc, decltype(hb2), 256 * 2 * HB_NPRE_OFF>(P, hb2, hb, b, smem, sel == 0 ? 0 : n0, sel == 0 ? n0 : ntot,
+                                                                               sel == 0, tid);
+      } else {
       __syncthreads();   // whatever read the staging buffers last is done
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
@@ -2332,13 +2549,14 @@ chol_offdiag2_f32_kernel(const float* __restrict__ H, float* __restrict__ L, con
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const float4 h = *reinterpret_cast<const float4*>(hrow + 32 * cb + 8 * q);
-              P.v[cb][4 * q + 0] = h.x - P.v[cb][4 * q + 0];
-              P.v[cb][4 * q + 1] = h.y - P.v[cb][4 * q + 1];
-              P.v[cb][4 * q + 2] = h.z - P.v[cb][4 * q + 2];
-              P.v[cb][4 * q + 3] = h.w - P.v[cb][4 * q + 3];
+              P.v[cb][4 * q + 0] = h.x + P.v[cb][4 * q + 0];   // (P holds -sum already)
+              P.v[cb][4 * q + 1] = h.y + P.v[cb][4 * q + 1];
+              P.v[cb][4 * q + 2] = h.z + P.v[cb][4 * q + 2];
+              P.v[cb][4 * q + 3] = h.w + P.v[cb][4 * q + 3];
             }
         }
         __syncthreads();
+      }
       }
     } else {
       const float* Hrow = H + mat + (int64_t)(row0 + (rvalid ? r : 0)) * ld + jj * TILE + 4 * g;
@@ -2461,7 +2679,7 @@ __device__ __forceinline__ void sub_mma64(const double* blk, const Engine<double
   }
 }
 
-template <bool HB, bool RL = false>   // (RL: the right-looking schedule's modes, TilePat.rl / rl_y -- an instance of its own: in the
+template <int HB, bool RL = false>    // (HB: as chol_offdiag_f32_kernel; RL: the right-looking schedule's modes, TilePat.rl / rl_y -- an instance of its own: in the
                                       //  left-looking instance the extra live values spilled 268 - 700 B per lane through scratch)
 __global__ void __launch_bounds__(256, 2)
 chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, const double* __restrict__ panel, int n,
@@ -2519,7 +2737,11 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   E::Acc P;
   E::zero(P);
   HBPre<double, HB ? HB_NPRE_OFF : 1> hbp;
+#ifdef THX_EXP_NO_HBLOAD
+  if constexpr (HB) hbp.empty();
+#else
   if constexpr (HB) hbp.load(hb, b, i, j, tid);
+#endif
   // panel sub-block q (row-major list of the lower triangle): block row SB[q], block column TB[q]
   const double* Pn = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
   double* const smemE = smem + OFF64_STAGE / 8;
@@ -2579,6 +2801,33 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
     static_assert(32 * LDH * 8 <= OFF64_STAGE, "a quarter of an H tile must fit in the staging buffers");
     __syncthreads();
     THX_ST64(8);    // (sub-stamps 8..11: the first barrier -- the K-loop's last MFMAs drained --, then the gather rounds 1..3 begin)
+    // P = -sum first, H_ij's pieces are ADDED
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) P.v[h][cb][rho] = -P.v[h][cb][rho];
+#ifdef THX_EXP_NO_HBLOAD
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) {
+          const unsigned hsh = (unsigned)(tid * 64 + h * 32 + cb * 4 + rho + 4099 * blockIdx.x) * 2654435761u;
+          const unsigned h2 = hsh * 2246822519u + 1u;
+          P.v[h][cb][rho] += ((lane & 1) ? 1e-3 : -1e-3) * (1.0 + ((double)hsh * 4294967296.0 + (double)h2) * (1.0 / 18446744073709551616.0));
+        }
+#endif
+    if constexpr (HB == HB_MODE_SCATTER) {
+      // a few pieces per tile (pose graphs): added by the matrix cores, see hb_scatter
+      static_assert((256 * HB_NPRE_OFF + 64 * 36) * 8 <= OFF64_STAGE, "list + overflow chunk inside the staging buffers");
+      hb_add<double, E::Acc, decltype(hbp), 256 * HB_NPRE_OFF>(P, hbp, hb, b, smem, 0, hbp.cnt / (hb.bd * hb.bd), true, tid);
+#ifndef THX_EXP_NO_HBBARRIER   // (timing experiment, WRONG results)
+      __syncthreads();   // the list has been read: panel sub-blocks 5..8 may take the staging buffers
+#endif
+    } else {
 #pragma unroll
     for (int rd = 0; rd < 4; ++rd) {
       if (rd == 1) THX_ST64(9);
@@ -2597,10 +2846,11 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
 #pragma unroll
           for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
-            for (int rho = 0; rho < 4; ++rho) P.v[h][cb][rho] = hrow[16 * cb + 4 * rho] - P.v[h][cb][rho];
+            for (int rho = 0; rho < 4; ++rho) P.v[h][cb][rho] = hrow[16 * cb + 4 * rho] + P.v[h][cb][rho];   // (P holds -sum already)
         }
       }
       __syncthreads();
+    }
     }
   } else {
   // ---- P = H_ij - sum, H straight from global memory in the native layout (rows outside the matrix: zero) ----
@@ -3121,6 +3371,14 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
                        const thx_chol_schedule* sched = nullptr) {
   const bool use_hb = hbp != nullptr;
   const HBlk hb = use_hb ? *hbp : HBlk{nullptr, 0, 0, nullptr, nullptr, nullptr};
+  // how an off-diagonal tile takes its pieces of H: a few per tile (pose graphs) -> added by the matrix cores (hb_scatter); many (a
+  // bundle adjustment's reduced camera system: up to 21 x 21 blocks per tile) or unknown -> gathered through LDS in rounds
+  static const int hb_scatter_max_default = [] {
+    const char* e = getenv("THX_HB_SCATTER_MAX_PIECES");   // (0: always the gather rounds)
+    return e ? atoi(e) : 64;
+  }();
+  const int hb_scatter_max = (sched && sched->hb_scatter_max_pieces >= 0) ? sched->hb_scatter_max_pieces : hb_scatter_max_default;
+  const bool hb_sc = use_hb && hb.bd <= 6 && hb.max_tile_pieces > 0 && hb.max_tile_pieces <= hb_scatter_max;
   const int ntiles = (n + TILE - 1) / TILE;
   TilePat pat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
   // ld == 0: L is the TILE-PACKED factor (B, nslots, TILE, TILE) of the pattern
@@ -3184,21 +3442,29 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     ds.attr_syrk[ti][use_hb] = dsm;
   }
   if (!ds.attr_off) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f32_kernel<false>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f32_kernel<0>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF32_SMEM);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f32_kernel<true>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f32_kernel<1>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF32_SMEM);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag2_f32_kernel<false>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f32_kernel<2>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, OFF32_SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag2_f32_kernel<0>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF2_SMEM);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag2_f32_kernel<true>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag2_f32_kernel<1>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF2_SMEM);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<false>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag2_f32_kernel<2>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, OFF2_SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<0>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<true>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<1>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<false, true>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<2>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<true, true>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<0, true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<1, true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<2, true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
     ds.attr_off = true;
   }
@@ -3249,25 +3515,23 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     if (use_hb) x.blocks = static_cast<const T*>(hb.blocks) + (int64_t)h.b0 * hb.bstride;
     return x;
   };
+  const int hbm = !use_hb ? 0 : (hb_sc ? HB_MODE_SCATTER : HB_MODE_ROUNDS);   // the off-diagonal kernels' HB template argument
   auto launch_off = [&](const Half& h, int j, int i_first, int nrt) {
     const int Bpad = (h.nb + 7) / 8 * 8;
     const int64_t mo = (int64_t)h.b0 * lstride, po = (int64_t)h.b0 * ntiles * TILE * TILE;
     const T* Hh = use_hb ? nullptr : (const T*)H + (int64_t)h.b0 * hstride;
-    if constexpr (sizeof(T) == 4) {
-      if (use_hb)
-        hipLaunchKernelGGL(chol_offdiag_f32_kernel<true>, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, h.s, Hh, (float*)L + mo,
+    auto go = [&](auto mode) {
+      constexpr int M = decltype(mode)::value;
+      if constexpr (sizeof(T) == 4)
+        hipLaunchKernelGGL(chol_offdiag_f32_kernel<M>, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, h.s, (const float*)Hh, (float*)L + mo,
                            (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));
       else
-        hipLaunchKernelGGL(chol_offdiag_f32_kernel<false>, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, h.s, Hh, (float*)L + mo,
-                           (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));
-    } else {
-      if (use_hb)
-        hipLaunchKernelGGL(chol_offdiag_f64_kernel<true>, dim3(Bpad * nrt), dim3(256), OFF64_SMEM, h.s, Hh, (double*)L + mo,
+        hipLaunchKernelGGL(chol_offdiag_f64_kernel<M>, dim3(Bpad * nrt), dim3(256), OFF64_SMEM, h.s, (const double*)Hh, (double*)L + mo,
                            (const double*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));
-      else
-        hipLaunchKernelGGL(chol_offdiag_f64_kernel<false>, dim3(Bpad * nrt), dim3(256), OFF64_SMEM, h.s, Hh, (double*)L + mo,
-                           (const double*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));
-    }
+    };
+    if (hbm == 0) go(std::integral_constant<int, 0>{});
+    else if (hbm == HB_MODE_SCATTER) go(std::integral_constant<int, HB_MODE_SCATTER>{});
+    else go(std::integral_constant<int, HB_MODE_ROUNDS>{});
   };
   // tiles (i, j) and (i, j + 1) of row tiles [i_first, i_first + nrt) in one workgroup each (chol_offdiag2_f32_kernel)
   auto launch_pair = [&](const Half& h, int j, int i_first, int nrt) {
@@ -3275,12 +3539,14 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       const int Bpad = (h.nb + 7) / 8 * 8;
       const int64_t mo = (int64_t)h.b0 * lstride, po = (int64_t)h.b0 * ntiles * TILE * TILE;
       const float* Hh = use_hb ? nullptr : (const float*)H + (int64_t)h.b0 * hstride;
-      if (use_hb)
-        hipLaunchKernelGGL(chol_offdiag2_f32_kernel<true>, dim3(Bpad * nrt), dim3(256), OFF2_SMEM, h.s, Hh, (float*)L + mo,
+      auto go = [&](auto mode) {
+        constexpr int M = decltype(mode)::value;
+        hipLaunchKernelGGL(chol_offdiag2_f32_kernel<M>, dim3(Bpad * nrt), dim3(256), OFF2_SMEM, h.s, Hh, (float*)L + mo,
                            (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, hb_of(h));
-      else
-        hipLaunchKernelGGL(chol_offdiag2_f32_kernel<false>, dim3(Bpad * nrt), dim3(256), OFF2_SMEM, h.s, Hh, (float*)L + mo,
-                           (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, hb_of(h));
+      };
+      if (hbm == 0) go(std::integral_constant<int, 0>{});
+      else if (hbm == HB_MODE_SCATTER) go(std::integral_constant<int, HB_MODE_SCATTER>{});
+      else go(std::integral_constant<int, HB_MODE_ROUNDS>{});
     }
   };
   // (nc > 1: the level schedule -- block columns [j, j + nc) in one launch, blockIdx.y the column; `fused` / `smem`: which of the
@@ -3509,28 +3775,26 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
         p0.rl_y = p1.rl_y = y;
         p0.rl_ldv = p1.rl_ldv = ldv;
       }
-      const HBlk nohb{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr};
+      const HBlk nohb{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0};
       const T* Lc = (const T*)L;
       const T* yc = fwd_fused ? (const T*)y : nullptr;
       const size_t dsm0 = DiagSmem<T>::bytes(0);
       // one chol_offdiag launch: nrt workgroup slots per problem (row tiles / update tiles), H from the block list, the dense H
       // frame or the L frame
       auto off = [&](bool hbsrc, const T* Hsrc, int jarg, int i_first, int nrt, const TilePat& pp) {
-        if constexpr (sizeof(T) == 4) {
-          if (hbsrc)
-            hipLaunchKernelGGL(chol_offdiag_f32_kernel<true>, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, st, (const float*)nullptr, (float*)L,
-                               (const float*)panel, n, ld, jarg, ntiles, i_first, nrt, B, pp, hb);
+        auto go = [&](auto mode) {
+          constexpr int M = decltype(mode)::value;
+          if constexpr (sizeof(T) == 4)
+            hipLaunchKernelGGL(chol_offdiag_f32_kernel<M>, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, st, (const float*)(M ? nullptr : Hsrc),
+                               (float*)L, (const float*)panel, n, ld, jarg, ntiles, i_first, nrt, B, pp, M ? hb : nohb);
           else
-            hipLaunchKernelGGL(chol_offdiag_f32_kernel<false>, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, st, (const float*)Hsrc, (float*)L,
-                               (const float*)panel, n, ld, jarg, ntiles, i_first, nrt, B, pp, nohb);
-        } else {
-          if (hbsrc)
-            hipLaunchKernelGGL((chol_offdiag_f64_kernel<true, true>), dim3(Bpad * nrt), dim3(256), OFF64_SMEM, st, (const double*)nullptr, (double*)L,
-                               (const double*)panel, n, ld, jarg, ntiles, i_first, nrt, B, pp, hb);
-          else
-            hipLaunchKernelGGL((chol_offdiag_f64_kernel<false, true>), dim3(Bpad * nrt), dim3(256), OFF64_SMEM, st, (const double*)Hsrc, (double*)L,
-                               (const double*)panel, n, ld, jarg, ntiles, i_first, nrt, B, pp, nohb);
-        }
+            hipLaunchKernelGGL((chol_offdiag_f64_kernel<M, true>), dim3(Bpad * nrt), dim3(256), OFF64_SMEM, st,
+                               (const double*)(M ? nullptr : Hsrc), (double*)L, (const double*)panel, n, ld, jarg, ntiles, i_first, nrt, B,
+                               pp, M ? hb : nohb);
+        };
+        if (!hbsrc) go(std::integral_constant<int, 0>{});
+        else if (hbm == HB_MODE_SCATTER) go(std::integral_constant<int, HB_MODE_SCATTER>{});
+        else go(std::integral_constant<int, HB_MODE_ROUNDS>{});
       };
       auto upd = [&](int jc, bool first) {
         const int m = ntiles - 1 - jc;
@@ -3795,7 +4059,7 @@ int thx_chol_factor_hblocks(const thx_hblock_layout* layout, const void* Hc, int
     return fail("thx_chol_factor_hblocks: incomplete tile pattern");
   if ((rhs == nullptr) != (y == nullptr) || (rhs && ldv < n)) return fail("thx_chol_factor_hblocks: rhs / y / ldv");
   if (rhs && rhs == y) return fail("thx_chol_factor_hblocks: y must not alias rhs");
-  const HBlk hb{Hc, bstride, layout->bd, layout->tile_ptr, layout->piece_blk, layout->piece_rc, layout->diag_blk};
+  const HBlk hb{Hc, bstride, layout->bd, layout->tile_ptr, layout->piece_blk, layout->piece_rc, layout->diag_blk, layout->max_tile_pieces};
   THX_DISPATCH(dtype,
                return factor_then_forward<float>(nullptr, ld, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
                                          as_stream(stream), pattern, &hb, nullptr, schedule),
@@ -3833,7 +4097,7 @@ int thx_chol_factor_levels(const thx_hblock_layout* layout, const void* Hc, int6
   const int n = pattern->ntiles * TILE;   // (the padded order: every tile is whole, tile_valid says how much of it is matrix)
   if ((rhs == nullptr) != (y == nullptr) || (rhs && ldv < n)) return fail("thx_chol_factor_levels: rhs / y are vectors of the PADDED order (ldv >= ntiles * THX_TILE)");
   if (rhs && rhs == y) return fail("thx_chol_factor_levels: y must not alias rhs");
-  const HBlk hb{Hc, bstride, layout->bd, layout->tile_ptr, layout->piece_blk, layout->piece_rc};
+  const HBlk hb{Hc, bstride, layout->bd, layout->tile_ptr, layout->piece_blk, layout->piece_rc, nullptr, layout->max_tile_pieces};
   THX_DISPATCH(dtype,
                return factor_impl<float>(nullptr, 0, n, B, damping, ellipsoidal, damping_eps, L, Winv, info, rhs, y, ldv,
                                          as_stream(stream), pattern, &hb, schedule, chol_schedule),

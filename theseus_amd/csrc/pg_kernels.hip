@@ -542,7 +542,7 @@ using namespace thx;
 extern "C" {
 
 const char* thx_last_error(void) { return last_error().c_str(); }
-int thx_abi_version(void) { return 23; }
+int thx_abi_version(void) { return 24; }
 
 int thx_copy_where(const uint8_t* mask, const void* src, void* dst, int64_t N, int32_t B, int32_t record_bytes, void* stream) {
   if (!mask || !src || !dst || N < 0 || B <= 0 || record_bytes <= 0 || (record_bytes & 3))

@@ -233,7 +233,7 @@ class HipKernels:
         self.lib = _lib.load()
         # per-call schedule of the factorisations (include/theseus_hip.h: thx_chol_schedule), handed to every thx_chol_factor* call
         # of THIS kernels object: -1 = the library default.  The library itself keeps no schedule state.
-        self.chol_schedule = _lib.CholSchedule(-1, -1, -1)
+        self.chol_schedule = _lib.CholSchedule(-1, -1, -1, -1)
 
     def _sched(self):
         import ctypes
@@ -760,6 +760,14 @@ class HipKernels:
         setting."""
         prev = int(self.chol_schedule.right_looking_max_batch)
         self.chol_schedule.right_looking_max_batch = int(max_batch)
+        return prev
+
+    def chol_hb_scatter_max_pieces(self, max_pieces: int) -> int:
+        """Schedule of THIS kernels object's factorisations from a block-compact H (thx_chol_schedule.hb_scatter_max_pieces): layouts
+        whose off-diagonal tiles hold at most ``max_pieces`` blocks have them added by the matrix cores, others gathered through LDS
+        -- the same bits either way (0 always gather, -1 the library default).  Returns the previous setting."""
+        prev = int(self.chol_schedule.hb_scatter_max_pieces)
+        self.chol_schedule.hb_scatter_max_pieces = int(max_pieces)
         return prev
 
     def chol_solve(self, L, n, panels, rhs, x):

@@ -675,6 +675,7 @@ class _LevelLayout:
         c.diag_blk, c.inc_blk = base.t["diag_blk"].data_ptr(), base.t["inc_blk"].data_ptr()
         for k, v in self.t.items():
             setattr(c, k, v.data_ptr())
+        c.max_tile_pieces = _lib.max_offdiag_tile_pieces(tile_ptr, pattern.ntiles)
         self.c, self._base = c, base
 
 
