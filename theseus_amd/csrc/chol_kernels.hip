@@ -3830,6 +3830,47 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     return e ? atoi(e) : 128;
   }();
   const bool colpair = column_pairs != 0 && sizeof(T) == 4 && !tp && !packed && B >= pair_min_batch;
+  // STAGGERED PIPELINE (THX_CHOL_LAG_COLS=<columns>, THX_CHOL_PIPE=<parts per stream>; experiment, default off): the batch in
+  // 2 x PIPE parts, even parts one after the other on the caller's stream, odd parts on the auxiliary stream which starts LAG
+  // block columns behind -- so that one stream's early columns (short K-loops: substitution / store bound, 0.4 - 0.7 of peak per
+  // executed flop in fp64) share the CUs with the other stream's late columns (long K-loops: matrix-core bound) instead of with
+  // each other.  MEASURED, NOT A WIN (profiles/r6/ad_ab_staggered_streams.txt: fp64 91.7 ms -> 91.8 ... 94.7, fp32 43.7 -> 43.9 ... 45.9
+  // over LAG 4 / 6 / 8 x PIPE 1 / 2 / 4): two streams' kernels do not interleave on a CU finely enough.
+  static const int lag_cols = [] {
+    const char* e = getenv("THX_CHOL_LAG_COLS");
+    return e ? atoi(e) : 0;
+  }();
+  static const int pipe_parts = [] {
+    const char* e = getenv("THX_CHOL_PIPE");
+    const int v = e ? atoi(e) : 2;
+    return v < 1 ? 1 : (v > 8 ? 8 : v);
+  }();
+  if (split && nparts == 2 && lag_cols > 0 && lag_cols < ntiles && !tp) {
+    const int nq = 2 * pipe_parts;
+    const int per = min(((B + nq - 1) / nq + 7) / 8 * 8, B);
+    for (int q = 0; q < nq; ++q) {
+      const int b0 = q * per, nb = min(per, B - b0);
+      if (nb <= 0) break;
+      const Half h{(q & 1) ? ds.aux[0] : st, b0, nb};
+      if (q == 1) hipStreamWaitEvent(h.s, ds.ev_lag[0], 0);
+      for (int j = 0; j < ntiles;) {
+        const bool pair = colpair && j + 2 < ntiles;
+        launch_diag(h, j);
+        if (pair) {
+          launch_off(h, j, j + 1, 1);
+          launch_diag(h, j + 1);
+          launch_pair(h, j, j + 2, ntiles - 2 - j);
+        } else if (ntiles - 1 - j > 0) {
+          launch_off(h, j, j + 1, ntiles - 1 - j);
+        }
+        j += pair ? 2 : 1;
+        if (q == 0 && j >= lag_cols && j - (pair ? 2 : 1) < lag_cols) hipEventRecord(ds.ev_lag[0], h.s);
+      }
+    }
+    hipEventRecord(ds.ev_join[0], ds.aux[0]);
+    hipStreamWaitEvent(st, ds.ev_join[0], 0);
+    return check_launch("thx_chol_factor");
+  }
   for (int j = 0; j < ntiles;) {
     const bool pair = colpair && j + 2 < ntiles;
     for (int k = 0; k < nparts; ++k) {
