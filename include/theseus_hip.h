@@ -308,12 +308,17 @@ int thx_se3_retract(const void* poses, const void* delta, int64_t ldd, double st
  *        hb_scatter_max_pieces: block-compact H (thx_hblock_layout) whose off-diagonal tiles hold at most this many pieces
  *          (layout.max_tile_pieces) has them ADDED to the tile's Schur update by the matrix cores; above, they are gathered through
  *          LDS (see thx_hblock_layout.max_tile_pieces; the same bits either way).  0 = always gather; < 0: the default (64, or
- *          THX_HB_SCATTER_MAX_PIECES). */
+ *          THX_HB_SCATTER_MAX_PIECES).
+ *        f64_wide_max_ktiles: fp64 factorisations on the column-by-column schedule: the off-diagonal tiles of the first this many
+ *          block columns (K-loops shorter than that many tiles) are produced by EIGHT-wave workgroups (16 rows of the tile per
+ *          wave, four waves per SIMD) instead of four-wave ones -- the same arithmetic in the same order, bit-identical.  0 =
+ *          never; < 0: the default (every column, or THX_F64_WIDE_MAX_KTILES). */
 typedef struct {
   int32_t split_diag_min_batch;
   int32_t column_pairs;
   int32_t right_looking_max_batch;
   int32_t hb_scatter_max_pieces;
+  int32_t f64_wide_max_ktiles;
 } thx_chol_schedule;
 
 /* ---- tile-sparse Cholesky for LARGE pose graphs -- the functional analogue of BaspachoSparseSolver

@@ -161,3 +161,32 @@ def test_lm_with_block_hessian_equals_dense_frame(name, solver):
     assert lina._H is None                      # the dense frame was never materialised ...
     AtA = lina.AtA                              # ... until somebody reads AtA (thx_hblocks_expand)
     assert torch.equal(AtA, linb.AtA)
+
+
+@pytest.mark.parametrize("compact", [True, False])
+def test_fp64_eight_wave_offdiag_kernel_is_bit_identical(K, compact):
+    """thx_chol_schedule.f64_wide_max_ktiles: the off-diagonal tiles of the first block columns from eight-wave workgroups (16 rows
+    of the tile per wave) -- the same MFMAs in the same order as the four-wave kernel: L, the panels, y bit for bit, for the
+    block-compact H (matrix-core scatter) and the dense frame, every setting from "no column" to "all of them"."""
+    s, hb, dhb, H, gv, Hc, g2, n, ld = _assembled(K, "pg_full_f64_lm")
+    B = H.shape[0]
+    nt = (n + 127) // 128
+    lam = torch.full((B,), 1e-3, dtype=H.dtype, device="cuda")
+    out = []
+    for wide in (0, 1, 3, nt):
+        prev = K.chol_f64_wide_max_ktiles(wide)
+        try:
+            L = torch.zeros_like(H)
+            panels = torch.zeros(B, nt, 128, 128, dtype=H.dtype, device="cuda")
+            info = torch.empty(B, dtype=torch.int32, device="cuda")
+            y = torch.empty_like(gv)
+            if compact:
+                K.chol_factor_hblocks(dhb, Hc, n, lam, True, 1e-8, L, panels, info, rhs=gv, y=y)
+            else:
+                K.chol_factor(H, n, lam, True, 1e-8, L, panels, info, rhs=gv, y=y)
+            out.append((torch.tril(L[:, :n, :n]), y, info))
+        finally:
+            K.chol_f64_wide_max_ktiles(prev)
+    for La, ya, ia in out:
+        assert int(ia.abs().sum()) == 0
+        assert torch.equal(La, out[0][0]) and torch.equal(ya, out[0][1])

@@ -656,7 +656,7 @@ struct NoHook {
 // ``ksa`` / ``ksb`` (tile-packed factor): per K-list element the SLOT of the A / B operand tile; Arows / Brows then point at the
 // problem's packed buffer, ``ld`` is TILE and ``packed_elems`` the buffer's extent (rows of a tile beyond the matrix are zero in
 // the buffer itself, never written).
-template <typename T, bool SAME, bool GEMV, int LDT, bool SPLIT16 = false, typename Compute, typename Hook = NoHook>
+template <typename T, bool SAME, bool GEMV, int LDT, bool SPLIT16 = false, int NT = 256, typename Compute, typename Hook = NoHook>
 __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA, const T* __restrict__ Brows,
                                         int validB, int64_t ld, int K, T* sA, T* sB, int tid, const T* gemv_y,
                                         T* gemv_part, Compute&& compute, Hook&& after_issue = NoHook{},
@@ -668,7 +668,8 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   using C = CT<T>;
   using V = typename C::V;
   constexpr int TPR = C::KB / C::VEC;   // threads per staged row (16 bytes each)
-  constexpr int RPP = 256 / TPR;        // rows per pass of the 256 threads
+  static_assert(!GEMV || NT == 256, "the fused GEMV pairs the 256 threads with the 128 rows");
+  constexpr int RPP = NT / TPR;         // rows per pass of the NT (256; the 8-wave fp64 off-diagonal kernel: 512) threads
   constexpr int NP = TILE / RPP;        // passes: fp32 4 x 32 rows, fp64 8 x 16 rows
   const int lrow = tid / TPR, lc = tid % TPR;
   // element offset of this thread's 16-byte piece inside a staged row (set)
@@ -1252,8 +1253,9 @@ struct HBlk {
 // the first NPRE x 256 elements of the tile go global -> registers in the kernel's prologue (two
 // dependent loads each -- table, then value: ~2 us if left to the epilogue, measured as +1.3 ms per factorisation), the K-loop
 // hides them; ``foreach`` then replays them from registers (and walks whatever is beyond NPRE x 256 from memory).
-template <typename T, int NPRE>
+template <typename T, int NPRE, int NT = 256>   // (NT: threads of the workgroup)
 struct HBPre {
+  static constexpr int CAP = NT * NPRE;   // elements the registers hold
   T v[NPRE];
   int rc[NPRE];   // (r << 8) | c inside the tile, -1: nothing
   int p0, cnt;
@@ -1270,7 +1272,7 @@ struct HBPre {
   __device__ __forceinline__ void to_list(T* list, int tid) const {
 #pragma unroll
     for (int k = 0; k < NPRE; ++k)
-      if (tid + 256 * k < cnt) list[tid + 256 * k] = v[k];   // (k < NPRE: what the registers hold)
+      if (tid + NT * k < cnt) list[tid + NT * k] = v[k];   // (k < NPRE: what the registers hold)
   }
   // BRANCH-FREE (round 5): the loads of all NPRE elements are independent of each other -- with an ``if (idx < cnt)`` around each
   // element hipcc emitted  table load, s_waitcnt vmcnt(0), table load, s_waitcnt vmcnt(0), value load  once per element, i.e.
@@ -1295,7 +1297,7 @@ struct HBPre {
     if (cnt <= 0) return;   // (workgroup uniform; p0 may be the END of the piece list)
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int idx = tid + 256 * k;
+      const int idx = tid + NT * k;
       const int pc = p0 + (idx < cnt ? idx : 0) / bb;
       tw[k] = hb.piece_rc[pc];
       tblk[k] = hb.piece_blk[pc];
@@ -1310,7 +1312,7 @@ struct HBPre {
     const int bd = hb.bd, bb = bd * bd;
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int idx = tid + 256 * k;
+      const int idx = tid + NT * k;
       const bool ok = idx < cnt;
       const int e = (ok ? idx : 0) % bb;
       const int r = (int)(short)(tw[k] >> 16) + e / bd, c = (int)(short)(tw[k] & 0xffff) + e % bd;
@@ -1330,7 +1332,7 @@ struct HBPre {
 #pragma unroll
     for (int k = 0; k < NPRE; ++k)
       if (rc[k] >= 0) f(rc[k] >> 8, rc[k] & 255, v[k]);
-    if (cnt > 256 * NPRE) {   // a tile with more pieces than the registers hold
+    if (cnt > NT * NPRE) {   // a tile with more pieces than the registers hold
       const T* base = static_cast<const T*>(hb.blocks) + (int64_t)b * hb.bstride;
       const int bd = hb.bd, bb = bd * bd;
       if (bd == 6) {
@@ -1340,8 +1342,8 @@ struct HBPre {
         // element 256 NPRE of the tile's run is split with the register part above.
         constexpr int VEC = 16 / sizeof(T), NV = 12 / VEC;
         typedef T TV __attribute__((ext_vector_type(VEC)));
-        const int pb = (256 * NPRE) / 36, eb = (256 * NPRE) % 36, np = cnt / 36;
-        for (int q = pb + tid; q < np; q += 256) {
+        const int pb = (NT * NPRE) / 36, eb = (NT * NPRE) % 36, np = cnt / 36;
+        for (int q = pb + tid; q < np; q += NT) {
           const int w = hb.piece_rc[p0 + q];
           const int r0 = (int)(short)(w >> 16), c0 = (int)(short)(w & 0xffff);
           const TV* src = reinterpret_cast<const TV*>(base + (int64_t)hb.piece_blk[p0 + q] * 36);
@@ -1360,7 +1362,7 @@ struct HBPre {
           }
         }
       } else {
-        for (int idx = tid + 256 * NPRE; idx < cnt; idx += 256) {
+        for (int idx = tid + NT * NPRE; idx < cnt; idx += NT) {
           const int pc = p0 + idx / bb, e = idx % bb;
           const int w = hb.piece_rc[pc];
           const int r = (int)(short)(w >> 16) + e / bd, c = (int)(short)(w & 0xffff) + e % bd;
@@ -1536,13 +1538,44 @@ __device__ __forceinline__ void hb_scatter(Engine<double>::Acc& P, const double*
   });
 }
 
+// (the 8-wave fp64 off-diagonal kernel: a wave owns 16 rows of the tile -- acc.v[cb][v] = tile (row 16 wave + rl, column 16 cb + 4 v + kq))
+struct Acc16 {
+  f64x4 v[8];
+};
+__device__ __forceinline__ void hb_scatter(Acc16& P, const double* list, int wmeta, int pa, int pb, int bd, int wave, int lane) {
+  const int rl = lane & 15, kq = lane >> 4, bb = bd * bd, rh0 = 16 * wave;
+  const int r0l = (int)(short)(wmeta >> 16), c0l = (int)(short)(wmeta & 0xffff);
+  const bool rowhit = lane >= pa && lane < pb && r0l + bd > rh0 && r0l < rh0 + 16;
+  static_for<8>([&](auto icb) __attribute__((always_inline)) {
+    constexpr int cb = decltype(icb)::value;
+    unsigned long long mask = __builtin_amdgcn_ballot_w64(rowhit && c0l + bd > 16 * cb && c0l < 16 * cb + 16);
+    while (mask) {
+      const int p = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int w = __builtin_amdgcn_readlane(wmeta, p);
+      const int r0 = (int)(short)(w >> 16), c0 = (int)(short)(w & 0xffff);
+      const int dr = rh0 + rl - r0;
+      const bool rin = dr >= 0 && dr < bd;
+      const double* src = list + p * bb + (rin ? dr : 0) * bd;
+      const int t = c0 + kq - rl - 16 * cb;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int kc = 4 * m + kq;
+        const double x = src[min(kc, bd - 1)];
+        if (4 * m < bd)
+          P.v[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(t + 4 * m == 0 ? 1.0 : 0.0, rin && kc < bd ? x : 0.0, P.v[cb], 0, 0, 0);
+      }
+    }
+  });
+}
+
 // acc += the pieces [lo, hi) of the run ``pre`` describes (HBPre: the tile's, HBPre2: both tiles').  Chunk 0 -- the pieces that sit in
 // the registers whole, at most 64 (wmeta) -- goes through ``list`` (written here when ``write_list``: once per run, the caller
 // guarantees the buffer is free); a tile with more pieces (rare in a pose graph: > 21 blocks of 6 x 6 in one 128 x 128 tile) takes
 // further chunks of 64 straight from memory into ``list + LIST0`` -- two dependent loads and two barriers each, exposed.
 // Workgroup uniform control flow; LDS use: LIST0 + 64 bd^2 elements.
 constexpr int HB_MODE_SCATTER = 1, HB_MODE_ROUNDS = 2;   // the kernels' HB template argument (0: dense H)
-template <typename T, typename Acc, typename Pre, int LIST0>
+template <typename T, typename Acc, typename Pre, int LIST0, int NT = 256>
 __device__ __forceinline__ void hb_add(Acc& P, const Pre& pre, const HBlk& hb, int b, T* list, int lo, int hi, bool write_list,
                                        int tid) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -1561,7 +1594,7 @@ __device__ __forceinline__ void hb_add(Acc& P, const Pre& pre, const HBlk& hb, i
     for (int q0 = max(lo, nreg); q0 < hi; q0 += 64) {
       const int nq = min(64, hi - q0);
       __syncthreads();   // the previous chunk has been read
-      for (int idx = tid; idx < nq * bb; idx += 256) over[idx] = base[(int64_t)hb.piece_blk[pre.p0 + q0 + idx / bb] * bb + idx % bb];
+      for (int idx = tid; idx < nq * bb; idx += NT) over[idx] = base[(int64_t)hb.piece_blk[pre.p0 + q0 + idx / bb] * bb + idx % bb];
       const int wm = hb.piece_rc[pre.p0 + q0 + min(lane, nq - 1)];
       __syncthreads();
       hb_scatter(P, over, wm, 0, nq, bd, wave, lane);
@@ -2993,6 +3026,187 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// chol_offdiag, fp64, EIGHT waves per workgroup (round 6): the same tile, staging, panel plan and arithmetic -- element by element
+// the same sequence of MFMAs, bit-identical results -- with a wave owning 16 rows x 128 columns instead of 32 x 128: 64 accumulator
+// VGPRs, <= 128 in all, two workgroups = FOUR waves per SIMD.  Why: the 4-wave kernel is two waves per SIMD (256 VGPRs); with
+// K-loops of zero to three tiles -- block columns 0 ... 3, 27 of the 95 ms -- a tile's time is its serial epilogue (H pieces, ten
+// dependent block products of the substitution, 128 KB of stores), which one other wave per SIMD cannot cover: 0.39 ... 0.71 of
+// the peak per executed flop (profiles/r5/x_).  Half the epilogue per wave and twice the waves to interleave.  MEASURED
+// (profiles/r6/ae_): the early columns gain NOTHING (their tiles are serial phases -- pieces, panel waits, ten dependent block
+// products, stores -- that more waves of the SAME tile do not overlap; it takes more TILES per CU), the late ones 0.1 - 0.3 ms
+// each: 91.5 -> 90.4 ms with every column on this kernel, which is the default.  Left-looking column schedule only (no TilePat.rl
+// modes, no tile pattern); block-compact H through the matrix-core scatter or a dense H frame (HB_MODE_ROUNDS: the 4-wave kernel).
+// ------------------------------------------------------------------------------------------------
+template <int S, int Tt>
+__device__ __forceinline__ void sub_mma64_16(const double* blk, const Acc16& Bs, f64x4& D0, f64x4& D1, int lane) {
+  const int rl = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+    for (int cbh = 0; cbh < 2; ++cbh)
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) {
+        const int r = 16 * ch + rl, c = 16 * cbh + 4 * rho + kq;
+        const double a = blk[r * 32 + (c ^ (2 * rl))];
+        auto& d = ch == 0 ? D0 : D1;
+        d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs.v[2 * Tt + cbh][rho], d, 0, 0, 0);
+      }
+}
+
+template <int HB>
+__global__ void __launch_bounds__(512, 4)   // (second argument: waves per SIMD -- two workgroups of eight per CU)
+chol_offdiag_f64w8_kernel(const double* __restrict__ H, double* __restrict__ L, const double* __restrict__ panel, int n,
+                          int64_t ld, int jarg, int ntiles, int i_first, int nrow_tiles, int B, TilePat pat, HBlk hb) {
+  static_assert(HB != HB_MODE_ROUNDS, "dense tiles of H: the 4-wave kernel");
+  constexpr int NT = 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* smem = reinterpret_cast<double*>(smem_raw);
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int b8 = gridDim.x / (8 * nrow_tiles);       // (the two block maps: chol_offdiag_f32_kernel)
+  const int b = pat.lpt ? (slot % b8) * 8 + xcd : (slot / nrow_tiles) * 8 + xcd;
+  const int rslot = pat.lpt ? slot / b8 : slot % nrow_tiles;
+  const int ent = pat.col_row ? (pat.ent_col ? 0 : pat.col_ptr[jarg]) + i_first + rslot : 0;
+  const int j = pat.ent_col ? pat.ent_col[ent] : jarg;
+  const int i = pat.col_row ? pat.col_row[ent] : i_first + rslot;
+  const int32_t* klist = pat.col_row ? pat.tile_k + pat.tile_kptr[ent] : nullptr;
+  const int Kspan = pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE;
+  if (b >= B) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rl = lane & 15, kq = lane >> 4;
+  const LFrame lf = lframe(pat, ld);
+  const int64_t mat = (int64_t)b * ld * ld;
+  const int64_t lmat = (int64_t)b * lf.pstride;
+  const int64_t ldt = lf.ld;
+  double* const Lij = L + lmat + lf.tile(i, j, ntiles + ent);
+  const int32_t* ksa = lf.packed ? pat.tile_sa + pat.tile_kptr[ent] : nullptr;
+  const int32_t* ksb = lf.packed ? pat.tile_sb + pat.tile_kptr[ent] : nullptr;
+  const int col0 = j * TILE, row0 = i * TILE;
+  const int validB = tile_rows(pat, n, i);
+  double* sA = smem;
+  double* sB = smem + 128 * CT<double>::LDT;
+  Acc16 P;
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) P.v[cb][k] = 0.0;
+  HBPre<double, HB ? 2 : 1, NT> hbp;
+  if constexpr (HB != 0) hbp.load(hb, b, i, j, tid);
+  const double* Pn = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
+  double* const smemE = smem + OFF64_STAGE / 8;
+  // one panel sub-block (block row sbr, block column sbc) -> LDS at dst, LDS-direct, in sub_mma64's swizzled layout: thread U
+  // writes the 16-byte unit U of the block (row r = U / 16, unit U % 16) and fetches the unit (U % 16) ^ (r & 15) of that row
+  auto panel_dma = [&](int sbr, int sbc, double* dst) __attribute__((always_inline)) {
+    const int U = tid, r = U >> 4, up = U & 15;
+    const double* src = Pn + (32 * sbr + r) * TILE + 32 * sbc + 2 * (up ^ (r & 15));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(dst + (64 * wave) * 2), 16, 0, 0);
+  };
+  auto prefetch_panel = [&]() __attribute__((always_inline)) {   // sub-blocks 0..4 -> E (chol_offdiag_f64_kernel)
+    panel_dma(0, 0, smemE + 0 * 1024);
+    panel_dma(1, 0, smemE + 1 * 1024);
+    panel_dma(1, 1, smemE + 2 * 1024);
+    panel_dma(2, 0, smemE + 3 * 1024);
+    panel_dma(2, 1, smemE + 4 * 1024);
+  };
+  {
+    const double* sBw = sB + 16 * wave * CT<double>::LDT;
+    kloop_f<double, false, false, CT<double>::LDT, false, NT>(
+        L + lmat + (lf.packed ? 0 : (int64_t)col0 * ld), TILE, L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld), validB, ldt, Kspan, sA,
+        sB, tid, nullptr, nullptr,
+        [&]() __attribute__((always_inline)) {
+          constexpr int LDT = CT<double>::LDT;
+#pragma unroll
+          for (int ks = 0; ks < CT<double>::KB / 8; ++ks) {
+            const double2 fb = *reinterpret_cast<const double2*>(sBw + rl * LDT + 8 * ks + 2 * kq);
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+              const double2 fa = *reinterpret_cast<const double2*>(sA + (16 * cb + rl) * LDT + 8 * ks + 2 * kq);
+              P.v[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa.x, fb.x, P.v[cb], 0, 0, 0);
+              P.v[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa.y, fb.y, P.v[cb], 0, 0, 0);
+            }
+          }
+        },
+        prefetch_panel, klist, ksa, ksb, lf.pstride);
+  }
+  const int r = 16 * wave + rl;   // this lane's tile row
+  if constexpr (HB == 0) {
+    // dense H: sub-blocks 5..8 straight into the staging buffers (after a barrier: a slower wave may still read its fragments)
+    __syncthreads();
+    panel_dma(2, 2, smem + 0 * 1024);
+    panel_dma(3, 0, smem + 1 * 1024);
+    panel_dma(3, 1, smem + 2 * 1024);
+    panel_dma(3, 2, smem + 3 * 1024);
+    const bool rv = r < validB;
+    const double* Hrow = H + mat + (int64_t)(row0 + (rv ? r : 0)) * ld + col0 + kq;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) {
+        const double hv = Hrow[16 * cb + 4 * rho];
+        P.v[cb][rho] = (rv ? hv : 0.0) - P.v[cb][rho];
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // E and the staging buffers complete and visible to every wave
+  } else {
+    __syncthreads();   // the K-loop's last chunk has been consumed: the staging buffers are free
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) P.v[cb][rho] = -P.v[cb][rho];
+    static_assert((NT * 2 + 64 * 36) * 8 <= OFF64_STAGE, "list + overflow chunk inside the staging buffers");
+    hb_add<double, Acc16, decltype(hbp), NT * 2, NT>(P, hbp, hb, b, smem, 0, hbp.cnt / (hb.bd * hb.bd), true, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of E (requested in the prologue) have landed
+    __syncthreads();   // the list has been read; E visible to every wave (also when the K-loop was empty)
+    panel_dma(2, 2, smem + 0 * 1024);   // sub-blocks 5..8: they land under the first five block products, which read E
+    panel_dma(3, 0, smem + 1 * 1024);
+    panel_dma(3, 1, smem + 2 * 1024);
+    panel_dma(3, 2, smem + 3 * 1024);
+  }
+  // ---- in-place substitution (chol_offdiag_f64_kernel's, on 16 rows) ----
+  auto solve_diag = [&](auto is, const double* Wss) __attribute__((always_inline)) {
+    constexpr int sb = decltype(is)::value;
+    f64x4 T0, T1;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) { T0[r4] = 0.0; T1[r4] = 0.0; }
+    sub_mma64_16<sb, sb>(Wss, P, T0, T1, lane);  // X_s = W_ss P_s
+    P.v[2 * sb] = T0;
+    P.v[2 * sb + 1] = T1;
+  };
+  auto update = [&](auto is, auto it, const double* Mst) __attribute__((always_inline)) {
+    constexpr int sb = decltype(is)::value, tb = decltype(it)::value;
+    sub_mma64_16<sb, tb>(Mst, P, P.v[2 * sb], P.v[2 * sb + 1], lane);  // P_s += (-L_st) X_t
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  solve_diag(I0{}, smemE + 0 * 1024);
+  update(I1{}, I0{}, smemE + 1 * 1024);
+  solve_diag(I1{}, smemE + 2 * 1024);
+  update(I2{}, I0{}, smemE + 3 * 1024);
+  update(I2{}, I1{}, smemE + 4 * 1024);
+  if constexpr (HB != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // sub-blocks 5..8 have landed
+  __syncthreads();                       // every wave is done with E (block-compact H: and sees sub-blocks 5..8)
+  panel_dma(3, 3, smemE + 0 * 1024);     // W_33 takes sub-block 0's place, lands under the next four block products
+  solve_diag(I2{}, smem + 0 * 1024);
+  update(I3{}, I0{}, smem + 1 * 1024);
+  update(I3{}, I1{}, smem + 2 * 1024);
+  update(I3{}, I2{}, smem + 3 * 1024);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                       // W_33 in place
+  solve_diag(I3{}, smemE + 0 * 1024);
+  // ---- store X ----
+  if (r < validB) {
+    double* Lrow = Lij + (int64_t)r * ldt + kq;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) Lrow[16 * cb + 4 * rho] = P.v[cb][rho];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // triangular solves with one right-hand side per problem, one workgroup per problem, HBM bound
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -3379,6 +3593,15 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   }();
   const int hb_scatter_max = (sched && sched->hb_scatter_max_pieces >= 0) ? sched->hb_scatter_max_pieces : hb_scatter_max_default;
   const bool hb_sc = use_hb && hb.bd <= 6 && hb.max_tile_pieces > 0 && hb.max_tile_pieces <= hb_scatter_max;
+  // fp64: the first f64_wide_max block columns (K-loops shorter than that many tiles) take the 8-wave off-diagonal kernel
+  // (chol_offdiag_f64w8_kernel).  Default: ALL of them -- measured +1.0 ... 1.3 % at batch 256 / 1024 / 4096 (n = 1536), growing with
+  // the number of columns that use it (profiles/r6/ae_): four waves per SIMD serve the K-loop better than two; the early columns,
+  // for which the kernel was written, gain nothing.
+  static const int f64_wide_default = [] {
+    const char* e = getenv("THX_F64_WIDE_MAX_KTILES");   // (0: never)
+    return e ? atoi(e) : (1 << 30);
+  }();
+  const int f64_wide_max = (sched && sched->f64_wide_max_ktiles >= 0) ? sched->f64_wide_max_ktiles : f64_wide_default;
   const int ntiles = (n + TILE - 1) / TILE;
   TilePat pat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
   // ld == 0: L is the TILE-PACKED factor (B, nslots, TILE, TILE) of the pattern
@@ -3466,6 +3689,10 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<2, true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64w8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        OFF64_SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64w8_kernel<HB_MODE_SCATTER>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
     ds.attr_off = true;
   }
   hipMemsetAsync(info, 0, sizeof(int32_t) * (size_t)B, st);
@@ -3522,12 +3749,20 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     const T* Hh = use_hb ? nullptr : (const T*)H + (int64_t)h.b0 * hstride;
     auto go = [&](auto mode) {
       constexpr int M = decltype(mode)::value;
-      if constexpr (sizeof(T) == 4)
+      if constexpr (sizeof(T) == 4) {
         hipLaunchKernelGGL(chol_offdiag_f32_kernel<M>, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, h.s, (const float*)Hh, (float*)L + mo,
                            (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));
-      else
+      } else {
+        if constexpr (M != HB_MODE_ROUNDS) {
+          if (!tp && j < f64_wide_max) {   // (dense schedule: column j's K-loops are j tiles long)
+            hipLaunchKernelGGL(chol_offdiag_f64w8_kernel<M>, dim3(Bpad * nrt), dim3(512), OFF64_SMEM, h.s, (const double*)Hh,
+                               (double*)L + mo, (const double*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));
+            return;
+          }
+        }
         hipLaunchKernelGGL(chol_offdiag_f64_kernel<M>, dim3(Bpad * nrt), dim3(256), OFF64_SMEM, h.s, (const double*)Hh, (double*)L + mo,
                            (const double*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));
+      }
     };
     if (hbm == 0) go(std::integral_constant<int, 0>{});
     else if (hbm == HB_MODE_SCATTER) go(std::integral_constant<int, HB_MODE_SCATTER>{});
