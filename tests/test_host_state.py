@@ -241,3 +241,38 @@ def test_update_skips_the_variable_walk_only_when_batch_and_device_are_unchanged
     assert obj.batch_size == 5 and calls["n"] == 3
     with pytest.raises(ValueError):
         obj.update({"a": torch.zeros(5, 3, dtype=dt), "b": torch.zeros(4, 3, dtype=dt)})   # 5 vs 4: not broadcastable
+
+
+def test_one_repointing_per_forward_and_the_inputs_are_never_written():
+    """The optimizer's first sync packs the caller's tensors into a PRIVATE state buffer and leaves the variables on the tensors they
+    hold; they are re-pointed ONCE, to views of the final state, when the loop is done (PackedPoseGraph.sync, ``_defer_repoint``) --
+    re-pointing them to the packed copy first was 5 ms of host time per forward at 4096 poses.  The caller's tensors keep their
+    values; an end_iter_callback still sees the current iterate (the loop flushes before anybody can look)."""
+    th, g, obj, opt, layer = _layer(iters=3)
+    packed = opt.linear_solver.linearization.packed
+    start = {k: v.tensor.clone() for k, v in obj.optim_vars.items()}
+    layer.forward(None, optimizer_kwargs=dict(damping=1e-3))           # (first call: packs, builds the structure)
+    calls = {"n": 0}
+    orig = packed._repoint_variables
+
+    def counted():
+        calls["n"] += 1
+        return orig()
+    packed._repoint_variables = counted
+    inputs = {k: v.clone() for k, v in start.items()}
+    sol, _ = layer.forward(inputs, optimizer_kwargs=dict(damping=1e-3))
+    assert calls["n"] == 1
+    for k, v in inputs.items():
+        assert torch.equal(v, start[k])                                  # never written into
+        assert not torch.equal(sol[k], start[k])                         # (the loop moved)
+        assert sol[k] is obj.optim_vars[k].tensor
+    assert packed.buffer_of([v.tensor for v in packed.pose_vars]) is not None   # the variables view ONE buffer: the final state
+    # with a callback: the variables show the iterate of each iteration (one re-pointing per look)
+    seen = []
+    calls["n"] = 0
+    sol2, _ = layer.forward({k: v.clone() for k, v in start.items()}, optimizer_kwargs=dict(
+        damping=1e-3, end_iter_callback=lambda o, i, d, it: seen.append({k: v.tensor.clone() for k, v in o.objective.optim_vars.items()})))
+    assert len(seen) == 3 and calls["n"] >= 3
+    for k in sol:
+        assert torch.equal(sol2[k], sol[k]) and torch.equal(seen[-1][k], sol[k])
+        assert not torch.equal(seen[0][k], seen[-1][k])

@@ -260,7 +260,11 @@ class NonlinearLeastSquares(abc.ABC):
         # (only THEN may a no_grad re-pack leave the variables on their own graph-carrying tensors instead of views of the packed state)
         packed._keep_graph_tensors = init_tensors is not None
         with torch.no_grad():
-            packed.sync(deep=True)   # once per optimize(): also catches in-place edits of the variables' tensors
+            packed._defer_repoint = True   # (PackedPoseGraph.sync: the variables are re-pointed once, when the loop is done)
+            try:
+                packed.sync(deep=True)   # once per optimize(): also catches in-place edits of the variables' tensors
+            finally:
+                packed._defer_repoint = False
         self.reset(**kwargs, backward_mode=backward_mode)
         tail_iters = 0
         if implicit:

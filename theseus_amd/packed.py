@@ -240,6 +240,7 @@ class PackedPoseGraph:
         self._deep_stamp = None
         self._aux_stamp = _AuxDeepStamp()
         self._keep_graph_tensors = False   # set by the optimizer around an optimize() that differentiates from the initial tensors
+        self._defer_repoint = False        # set by the optimizer around its first sync (see sync)
         self._global_stamp = -1
         self._vars_stale = False
         self._state_exposed = False
@@ -390,6 +391,15 @@ class PackedPoseGraph:
             self._stamp = stamp
             self._global_stamp = Variable._global_updates
             self._vars_stale = False
+            self._state_exposed = False
+        elif self._defer_repoint and self._own_variables:
+            # the optimizer's sync at the start of optimize(): the loop is about to continue on a PRIVATE state buffer and re-points
+            # the variables when it is done (or before anybody can look: callbacks, exceptions -- flush_variables) -- re-pointing
+            # them to views of THIS buffer first was 5 ms of host time per optimize() at 4096 poses in front of the first kernel,
+            # for views nobody ever read.  The variables keep the tensors they hold (the same values) until then.
+            self._stamp = stamp
+            self._global_stamp = Variable._global_updates
+            self._vars_stale = True
             self._state_exposed = False
         else:
             self._repoint_variables()
