@@ -165,3 +165,31 @@ def test_hessian_block_layout_round_trip():
         # the blocks of a tile form one contiguous run (top-left ownership): ids ascend tile by tile
         own = [(d * a // 128, d * b // 128) for a, b in hb.blocks.tolist()]
         assert own == sorted(own)
+
+
+def test_max_tile_pieces_and_schedule_structs_follow_the_header():
+    """thx_hblock_layout.max_tile_pieces (host-computed: picks how the off-diagonal Cholesky kernels take their pieces of H) and the
+    ctypes mirrors of the two structs that grew this round: the field lists are the header's, in order."""
+    import re
+    import numpy as np
+    from theseus_amd import _lib
+    from theseus_amd.compiler import PoseGraphStructure
+    from theseus_amd.utils.synthetic import pose_graph_topology
+    # the largest piece count over the OFF-diagonal lower tiles t = i (i + 1) / 2 + j, i > j
+    tile_ptr = np.cumsum([0, 50, 3, 60, 7, 9, 70])          # tiles (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+    assert _lib.max_offdiag_tile_pieces(tile_ptr, 3) == 9
+    assert _lib.max_offdiag_tile_pieces(np.array([0, 5]), 1) == 0     # one tile: no off-diagonal tile
+    # the headline graph: a few tens of blocks per tile at most -> the matrix-core scatter (<= 64); equals a direct count
+    s = PoseGraphStructure.build(256, pose_graph_topology(256, 1024, 0), [0], dof=6)
+    hb = s.hessian_blocks()
+    cnt = np.diff(hb.tile_ptr)
+    off = [int(cnt[i * (i + 1) // 2 + j]) for i in range(hb.ntiles) for j in range(i)]
+    assert _lib.max_offdiag_tile_pieces(hb.tile_ptr, hb.ntiles) == max(off) and 1 <= max(off) <= 64
+    header = open(os.path.join(ROOT, "include", "theseus_hip.h")).read()
+
+    def fields(name):
+        body = re.search(r"typedef struct \{([^}]*)\} " + name + ";", header).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        return [re.findall(r"\w+", piece)[-1] for decl in body.split(";") if decl.strip() for piece in decl.split(",")]
+    assert fields("thx_chol_schedule") == [f for f, _ in _lib.CholSchedule._fields_]
+    assert fields("thx_hblock_layout") == [f for f, _ in _lib.HBlockLayout._fields_]
