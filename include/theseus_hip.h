@@ -312,13 +312,18 @@ int thx_se3_retract(const void* poses, const void* delta, int64_t ldd, double st
  *        f64_wide_max_ktiles: fp64 factorisations on the column-by-column schedule: the off-diagonal tiles of the first this many
  *          block columns (K-loops shorter than that many tiles) are produced by EIGHT-wave workgroups (16 rows of the tile per
  *          wave, four waves per SIMD) instead of four-wave ones -- the same arithmetic in the same order, bit-identical.  0 =
- *          never; < 0: the default (every column, or THX_F64_WIDE_MAX_KTILES). */
+ *          never; < 0: the default (every column, or THX_F64_WIDE_MAX_KTILES).
+ *        f64_half_max_ktiles: fp64, column-by-column schedule on a dense factor frame: the off-diagonal tiles of the first this many
+ *          block columns are produced as two HALF tiles (64 rows each) by four-wave workgroups that need 37 KB of LDS and 128
+ *          VGPRs -- four per CU instead of two; takes precedence over f64_wide_max_ktiles for those columns.  Bit-identical.
+ *          0 = never; < 0: the default (8, or THX_F64_HALF_MAX_KTILES). */
 typedef struct {
   int32_t split_diag_min_batch;
   int32_t column_pairs;
   int32_t right_looking_max_batch;
   int32_t hb_scatter_max_pieces;
   int32_t f64_wide_max_ktiles;
+  int32_t f64_half_max_ktiles;
 } thx_chol_schedule;
 
 /* ---- tile-sparse Cholesky for LARGE pose graphs -- the functional analogue of BaspachoSparseSolver

@@ -63,7 +63,7 @@ def test_bad_arguments_are_rejected_without_a_gpu(lib_path):
     assert rc != 0 and b"bad args" in lib.thx_last_error()
     rc = lib.thx_chol_factor_levels(None, one, 36, 2, None, 0, 1e-8, one, one, one, None, None, 0, None, None, 0, None, None)
     assert rc != 0 and b"block layout" in lib.thx_last_error()
-    sched = _lib.CholSchedule(-1, -1, -1, -1, -1)                               # (a schedule does not rescue bad arguments)
+    sched = _lib.CholSchedule(-1, -1, -1, -1, -1, -1)                               # (a schedule does not rescue bad arguments)
     rc = lib.thx_chol_factor(one, 33, 6, 1, None, 0, 1e-8, one, one, one, 0, None, ctypes.byref(sched))
     assert rc != 0 and b"ld" in lib.thx_last_error()
 

@@ -164,17 +164,19 @@ def test_lm_with_block_hessian_equals_dense_frame(name, solver):
 
 
 @pytest.mark.parametrize("compact", [True, False])
-def test_fp64_eight_wave_offdiag_kernel_is_bit_identical(K, compact):
-    """thx_chol_schedule.f64_wide_max_ktiles: the off-diagonal tiles of the first block columns from eight-wave workgroups (16 rows
-    of the tile per wave) -- the same MFMAs in the same order as the four-wave kernel: L, the panels, y bit for bit, for the
-    block-compact H (matrix-core scatter) and the dense frame, every setting from "no column" to "all of them"."""
+def test_fp64_eight_wave_and_half_tile_offdiag_kernels_are_bit_identical(K, compact):
+    """thx_chol_schedule.f64_wide_max_ktiles / f64_half_max_ktiles: the off-diagonal tiles of the first block columns from eight-wave
+    workgroups (16 rows of the tile per wave) or as two half tiles from four-wave workgroups (four per CU) -- the same MFMAs in the
+    same order as the four-wave kernel: L, y bit for bit, for the block-compact H (matrix-core scatter) and the dense frame, every
+    setting from "no column" to "all of them", and the defaults."""
     s, hb, dhb, H, gv, Hc, g2, n, ld = _assembled(K, "pg_full_f64_lm")
     B = H.shape[0]
     nt = (n + 127) // 128
     lam = torch.full((B,), 1e-3, dtype=H.dtype, device="cuda")
     out = []
-    for wide in (0, 1, 3, nt):
+    for wide, half in ((0, 0), (1, 0), (3, 0), (nt, 0), (0, 1), (0, 5), (0, nt), (nt, 4), (-1, -1)):
         prev = K.chol_f64_wide_max_ktiles(wide)
+        prev_h = K.chol_f64_half_max_ktiles(half)
         try:
             L = torch.zeros_like(H)
             panels = torch.zeros(B, nt, 128, 128, dtype=H.dtype, device="cuda")
@@ -187,6 +189,7 @@ def test_fp64_eight_wave_offdiag_kernel_is_bit_identical(K, compact):
             out.append((torch.tril(L[:, :n, :n]), y, info))
         finally:
             K.chol_f64_wide_max_ktiles(prev)
+            K.chol_f64_half_max_ktiles(prev_h)
     for La, ya, ia in out:
         assert int(ia.abs().sum()) == 0
         assert torch.equal(La, out[0][0]) and torch.equal(ya, out[0][1])

@@ -64,7 +64,8 @@ class TilePattern(Structure):  # thx_tile_pattern: tile-level symbolic factorisa
 
 class CholSchedule(Structure):  # thx_chol_schedule: per-call schedule of the factorisations (negative = the library default)
     _fields_ = [("split_diag_min_batch", c_int32), ("column_pairs", c_int32), ("right_looking_max_batch", c_int32),
-                ("hb_scatter_max_pieces", c_int32), ("f64_wide_max_ktiles", c_int32)]
+                ("hb_scatter_max_pieces", c_int32), ("f64_wide_max_ktiles", c_int32),
+                ("f64_half_max_ktiles", c_int32)]
 
 
 class LevelSchedule(Structure):  # thx_level_schedule: elimination-tree levels of a tile pattern (2 host + 2 device int32 tables)

@@ -656,7 +656,8 @@ struct NoHook {
 // ``ksa`` / ``ksb`` (tile-packed factor): per K-list element the SLOT of the A / B operand tile; Arows / Brows then point at the
 // problem's packed buffer, ``ld`` is TILE and ``packed_elems`` the buffer's extent (rows of a tile beyond the matrix are zero in
 // the buffer itself, never written).
-template <typename T, bool SAME, bool GEMV, int LDT, bool SPLIT16 = false, int NT = 256, typename Compute, typename Hook = NoHook>
+template <typename T, bool SAME, bool GEMV, int LDT, bool SPLIT16 = false, int NT = 256, int AHEAD_OVR = 0, int BROWS = TILE,
+          typename Compute, typename Hook = NoHook>
 __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA, const T* __restrict__ Brows,
                                         int validB, int64_t ld, int K, T* sA, T* sB, int tid, const T* gemv_y,
                                         T* gemv_part, Compute&& compute, Hook&& after_issue = NoHook{},
@@ -671,6 +672,8 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   static_assert(!GEMV || NT == 256, "the fused GEMV pairs the 256 threads with the 128 rows");
   constexpr int RPP = NT / TPR;         // rows per pass of the NT (256; the 8-wave fp64 off-diagonal kernel: 512) threads
   constexpr int NP = TILE / RPP;        // passes: fp32 4 x 32 rows, fp64 8 x 16 rows
+  constexpr int NPB = BROWS / RPP;      // (operand B of the fp64 half-tile kernel: 64 rows -- the other passes are neither loaded nor staged)
+  static_assert(BROWS % RPP == 0 && NPB >= 1 && NPB <= NP, "B rows: whole passes");
   const int lrow = tid / TPR, lc = tid % TPR;
   // element offset of this thread's 16-byte piece inside a staged row (set)
   const int scol = SPLIT16 ? ((lc * C::VEC) >> 4) * 128 * LDT + ((lc * C::VEC) & 15) : lc * C::VEC;
@@ -690,7 +693,7 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
   // Register prefetch, AHEAD k-chunks deep: 128 bytes per staged row in flight.  fp32: one 32-column chunk (a second register
   // set measured no gain: 47.3-47.7 ms either way); fp64: two 16-column chunks -- a 16-column chunk is half the MFMA time of an
   // fp32 one, one chunk ahead does not cover the load latency (factor -2.9 %).
-  constexpr int AHEAD = C::KB * (int)sizeof(T) <= 128 ? 2 : 1;
+  constexpr int AHEAD = AHEAD_OVR ? AHEAD_OVR : (C::KB * (int)sizeof(T) <= 128 ? 2 : 1);   // (AHEAD_OVR: the fp64 half-tile kernel, 128 VGPRs)
   uint4 ra[AHEAD][NP], rb[AHEAD][NP];
   // (so.x / so.y: scalar byte offsets of the chunk inside the A / B operand buffers; the same unless the factor is tile-packed)
   auto gload = [&](uint4 (&xa)[NP], uint4 (&xb)[NP], int2 so) __attribute__((always_inline)) {
@@ -698,7 +701,7 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
     for (int u = 0; u < NP; ++u) {
       const u32x4 va = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[u], so.x, 0);
       xa[u] = make_uint4(va.x, va.y, va.z, va.w);
-      if (!SAME) {
+      if (!SAME && u < NPB) {
         const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rsB, voff[u], so.y, 0);
         xb[u] = make_uint4(vb.x, vb.y, vb.z, vb.w);
       }
@@ -756,7 +759,7 @@ __device__ __forceinline__ void kloop_f(const T* __restrict__ Arows, int validA,
     for (int u = 0; u < NP; ++u) {
       const int row = lrow + RPP * u;
       *reinterpret_cast<uint4*>(sA + row * LDT + scol) = xa[u];
-      if (!SAME) *reinterpret_cast<uint4*>(sB + row * LDT + scol) = xb[u];
+      if (!SAME && u < NPB) *reinterpret_cast<uint4*>(sB + row * LDT + scol) = xb[u];
     }
     __syncthreads();
 #endif
@@ -3207,6 +3210,181 @@ chol_offdiag_f64w8_kernel(const double* __restrict__ H, double* __restrict__ L, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// chol_offdiag, fp64, HALF TILES (round 6): a workgroup of four waves produces 64 rows x 128 columns of the tile (16 rows
+// per wave, Acc16), with 36.8 KB of LDS -- the K-loop's staging buffers and nothing else -- and <= 128 VGPRs: FOUR workgroups per CU
+// instead of two.  For the block columns with K-loops of zero to three tiles, whose tiles are chains of latency-bound phases (pieces
+// of H, panel waits, ten dependent block products, stores) that two resident workgroups cannot overlap.  The price: each half
+// stages the whole column panel L_j (1.5x the operand traffic per tile product), the solve panel is not prefetched under the K-loop
+// but fetched afterwards, four sub-blocks at a time into the free staging buffers (three exposed round trips), one k-chunk in
+// flight instead of two.  Same MFMAs in the same order per element: bit-identical (tools/cmp_f64_half.py, tests/test_gpu_block_hessian.py).
+// MEASURED (profiles/r6/af_): n = 1536, batch 4096: 90.0 -> 88.5 ms with the first 6 - 8 block columns on this kernel (0.700 -> 0.711),
+// every further column gives 0.1 ms back (the K-loop with one chunk in flight and 1.5x the staging loses to the 8-wave kernel from
+// ~8 tiles on): thx_chol_schedule.f64_half_max_ktiles, default 8.
+// ------------------------------------------------------------------------------------------------
+#ifndef THX_F64H_AHEAD
+#define THX_F64H_AHEAD 1   // k-chunks in flight (2: 142 VGPRs wanted, spills -- see the header comment)
+#endif
+template <int HB>
+__global__ void __launch_bounds__(256, 4)
+chol_offdiag_f64h_kernel(const double* __restrict__ H, double* __restrict__ L, const double* __restrict__ panel, int n,
+                         int64_t ld, int jarg, int ntiles, int i_first, int nrow_tiles, int B, TilePat pat, HBlk hb) {
+  static_assert(HB != HB_MODE_ROUNDS, "dense tiles of H: the 4-wave full-tile kernel");
+  constexpr int NT = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* smem = reinterpret_cast<double*>(smem_raw);
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int nslots = 2 * nrow_tiles;                 // (two halves per row tile, adjacent slots)
+  const int b = (slot / nslots) * 8 + xcd;
+  const int hslot = slot % nslots;
+  const int half = hslot & 1, rslot = hslot >> 1;
+  const int j = jarg, i = i_first + rslot;
+  const int Kspan = j * TILE;
+  if (b >= B) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rl = lane & 15, kq = lane >> 4;
+  const int64_t mat = (int64_t)b * ld * ld;
+  const int col0 = j * TILE, row0 = i * TILE + 64 * half;
+  const int validB = min(64, tile_rows(pat, n, i) - 64 * half);   // rows of this half inside the matrix
+  if (validB <= 0) return;
+  double* const Lij = L + mat + (int64_t)row0 * ld + col0;
+  double* sA = smem;
+  double* sB = smem + 128 * CT<double>::LDT;
+  Acc16 P;
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) P.v[cb][k] = 0.0;
+  HBPre<double, HB ? HB_NPRE_OFF : 1, NT> hbp;
+  if constexpr (HB != 0) hbp.load(hb, b, i, j, tid);
+  const double* Pn = panel + ((int64_t)b * ntiles + j) * TILE * TILE;
+  {
+    const double* sBw = sB + 16 * wave * CT<double>::LDT;
+    kloop_f<double, false, false, CT<double>::LDT, false, NT, THX_F64H_AHEAD, 64>(
+        L + mat + (int64_t)col0 * ld, TILE, L + mat + (int64_t)row0 * ld, validB, ld, Kspan, sA, sB, tid, nullptr, nullptr,
+        [&]() __attribute__((always_inline)) {
+          constexpr int LDT = CT<double>::LDT;
+#pragma unroll
+          for (int ks = 0; ks < CT<double>::KB / 8; ++ks) {
+            const double2 fb = *reinterpret_cast<const double2*>(sBw + rl * LDT + 8 * ks + 2 * kq);
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+              const double2 fa = *reinterpret_cast<const double2*>(sA + (16 * cb + rl) * LDT + 8 * ks + 2 * kq);
+              P.v[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa.x, fb.x, P.v[cb], 0, 0, 0);
+              P.v[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa.y, fb.y, P.v[cb], 0, 0, 0);
+            }
+          }
+        });
+  }
+  const int r = 16 * wave + rl;   // this lane's row inside the half
+  __syncthreads();                // the K-loop's last chunk has been consumed: the staging buffers are free
+  if constexpr (HB == 0) {
+    const bool rv = r < validB;
+    const double* Hrow = H + mat + (int64_t)(row0 + (rv ? r : 0)) * ld + col0 + kq;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) {
+        const double hv = Hrow[16 * cb + 4 * rho];
+        P.v[cb][rho] = (rv ? hv : 0.0) - P.v[cb][rho];
+      }
+  } else {
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) P.v[cb][rho] = -P.v[cb][rho];
+    static_assert((NT * HB_NPRE_OFF + 64 * 36) * 8 <= OFF64_STAGE, "list + overflow chunk inside the staging buffers");
+    // (hb_scatter's "wave" names the 16-row block of the TILE: 4 half + wave)
+    {
+      const int bd = hb.bd, bb = bd * bd;
+      const int nreg = min(min(hbp.cnt / bb, NT * HB_NPRE_OFF / bb), 64), np = hbp.cnt / bb;
+      const int wv = __builtin_amdgcn_readfirstlane(4 * half + wave);
+      hbp.to_list(smem, tid);
+      __syncthreads();
+      hb_scatter(P, smem, hbp.wmeta, 0, nreg, bd, wv, lane);
+      if (np > nreg) {   // (workgroup uniform) crowded tile: further chunks of 64 pieces from memory (hb_add)
+        const double* base = static_cast<const double*>(hb.blocks) + (int64_t)b * hb.bstride;
+        double* over = smem + NT * HB_NPRE_OFF;
+        for (int q0 = nreg; q0 < np; q0 += 64) {
+          const int nq = min(64, np - q0);
+          __syncthreads();
+          for (int idx = tid; idx < nq * bb; idx += NT) over[idx] = base[(int64_t)hb.piece_blk[hbp.p0 + q0 + idx / bb] * bb + idx % bb];
+          const int wm = hb.piece_rc[hbp.p0 + q0 + min(lane, nq - 1)];
+          __syncthreads();
+          hb_scatter(P, over, wm, 0, nq, bd, wv, lane);
+        }
+      }
+    }
+    __syncthreads();   // the list has been read: the panel may take the staging buffers
+  }
+  // one panel sub-block -> LDS slot, LDS-direct, in sub_mma64's swizzled layout (two passes of the 256 threads)
+  auto panel_dma = [&](int sbr, int sbc, double* dst) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int U = 256 * u + tid, rr = U >> 4, up = U & 15;
+      const double* src = Pn + (32 * sbr + rr) * TILE + 32 * sbc + 2 * (up ^ (rr & 15));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + (256 * u + 64 * wave) * 2), 16, 0, 0);
+    }
+  };
+  auto landed = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  auto solve_diag = [&](auto is, const double* Wss) __attribute__((always_inline)) {
+    constexpr int sb = decltype(is)::value;
+    f64x4 T0, T1;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) { T0[r4] = 0.0; T1[r4] = 0.0; }
+    sub_mma64_16<sb, sb>(Wss, P, T0, T1, lane);
+    P.v[2 * sb] = T0;
+    P.v[2 * sb + 1] = T1;
+  };
+  auto update = [&](auto is, auto it, const double* Mst) __attribute__((always_inline)) {
+    constexpr int sb = decltype(is)::value, tb = decltype(it)::value;
+    sub_mma64_16<sb, tb>(Mst, P, P.v[2 * sb], P.v[2 * sb + 1], lane);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  // ---- the substitution in three panel phases of four / four / two sub-blocks through the staging buffers ----
+  panel_dma(0, 0, smem + 0 * 1024);
+  panel_dma(1, 0, smem + 1 * 1024);
+  panel_dma(1, 1, smem + 2 * 1024);
+  panel_dma(2, 0, smem + 3 * 1024);
+  landed();
+  solve_diag(I0{}, smem + 0 * 1024);
+  update(I1{}, I0{}, smem + 1 * 1024);
+  solve_diag(I1{}, smem + 2 * 1024);
+  update(I2{}, I0{}, smem + 3 * 1024);
+  __syncthreads();   // every wave is done with the four slots
+  panel_dma(2, 1, smem + 0 * 1024);
+  panel_dma(2, 2, smem + 1 * 1024);
+  panel_dma(3, 0, smem + 2 * 1024);
+  panel_dma(3, 1, smem + 3 * 1024);
+  landed();
+  update(I2{}, I1{}, smem + 0 * 1024);
+  solve_diag(I2{}, smem + 1 * 1024);
+  update(I3{}, I0{}, smem + 2 * 1024);
+  update(I3{}, I1{}, smem + 3 * 1024);
+  __syncthreads();
+  panel_dma(3, 2, smem + 0 * 1024);
+  panel_dma(3, 3, smem + 1 * 1024);
+  landed();
+  update(I3{}, I2{}, smem + 0 * 1024);
+  solve_diag(I3{}, smem + 1 * 1024);
+  // ---- store X ----
+  if (r < validB) {
+    double* Lrow = Lij + (int64_t)r * ld + kq;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho) Lrow[16 * cb + 4 * rho] = P.v[cb][rho];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // triangular solves with one right-hand side per problem, one workgroup per problem, HBM bound
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -3602,6 +3780,13 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
     return e ? atoi(e) : (1 << 30);
   }();
   const int f64_wide_max = (sched && sched->f64_wide_max_ktiles >= 0) ? sched->f64_wide_max_ktiles : f64_wide_default;
+  // ... and the first f64_half_max of them (K-loops shorter than that many tiles) the HALF-TILE kernel (chol_offdiag_f64h_kernel, four
+  // workgroups per CU): measured optimum 6 ... 8 at n = 1536 / batch 4096 (profiles/r6/af_: 90.0 -> 88.5 ms; all twelve columns 89.0)
+  static const int f64_half_default = [] {
+    const char* e = getenv("THX_F64_HALF_MAX_KTILES");   // (0: never)
+    return e ? atoi(e) : 8;
+  }();
+  const int f64_half_max = (sched && sched->f64_half_max_ktiles >= 0) ? sched->f64_half_max_ktiles : f64_half_default;
   const int ntiles = (n + TILE - 1) / TILE;
   TilePat pat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
   // ld == 0: L is the TILE-PACKED factor (B, nslots, TILE, TILE) of the pattern
@@ -3689,6 +3874,10 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64_kernel<2, true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64h_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        OFF64_STAGE);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64h_kernel<HB_MODE_SCATTER>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, OFF64_STAGE);
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64w8_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         OFF64_SMEM);
     hipFuncSetAttribute(reinterpret_cast<const void*>(chol_offdiag_f64w8_kernel<HB_MODE_SCATTER>),
@@ -3754,6 +3943,11 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
                            (const float*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));
       } else {
         if constexpr (M != HB_MODE_ROUNDS) {
+          if (!tp && !packed && j < f64_half_max) {   // (half tiles, four workgroups per CU, for the short K-loops)
+            hipLaunchKernelGGL(chol_offdiag_f64h_kernel<M>, dim3(Bpad * nrt * 2), dim3(256), OFF64_STAGE, h.s, (const double*)Hh,
+                               (double*)L + mo, (const double*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));
+            return;
+          }
           if (!tp && j < f64_wide_max) {   // (dense schedule: column j's K-loops are j tiles long)
             hipLaunchKernelGGL(chol_offdiag_f64w8_kernel<M>, dim3(Bpad * nrt), dim3(512), OFF64_SMEM, h.s, (const double*)Hh,
                                (double*)L + mo, (const double*)panel + po, n, ld, j, ntiles, i_first, nrt, h.nb, pat, hb_of(h));

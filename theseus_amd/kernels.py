@@ -233,7 +233,7 @@ class HipKernels:
         self.lib = _lib.load()
         # per-call schedule of the factorisations (include/theseus_hip.h: thx_chol_schedule), handed to every thx_chol_factor* call
         # of THIS kernels object: -1 = the library default.  The library itself keeps no schedule state.
-        self.chol_schedule = _lib.CholSchedule(-1, -1, -1, -1, -1)
+        self.chol_schedule = _lib.CholSchedule(-1, -1, -1, -1, -1, -1)
 
     def _sched(self):
         import ctypes
@@ -776,6 +776,14 @@ class HipKernels:
         -1 the library default).  Returns the previous setting."""
         prev = int(self.chol_schedule.f64_wide_max_ktiles)
         self.chol_schedule.f64_wide_max_ktiles = int(max_ktiles)
+        return prev
+
+    def chol_f64_half_max_ktiles(self, max_ktiles: int) -> int:
+        """Schedule of THIS kernels object's fp64 factorisations (thx_chol_schedule.f64_half_max_ktiles): the off-diagonal tiles of
+        the first ``max_ktiles`` block columns as half tiles from four-wave workgroups, four per CU -- bit-identical (0 never, -1
+        the library default).  Returns the previous setting."""
+        prev = int(self.chol_schedule.f64_half_max_ktiles)
+        self.chol_schedule.f64_half_max_ktiles = int(max_ktiles)
         return prev
 
     def chol_solve(self, L, n, panels, rhs, x):
