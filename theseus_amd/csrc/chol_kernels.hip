@@ -3348,7 +3348,9 @@ chol_offdiag_f64h_kernel(const double* __restrict__ H, double* __restrict__ L, c
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
-  // ---- the substitution in three panel phases of four / four / two sub-blocks through the staging buffers ----
+#ifndef THX_F64H_RING
+  // ---- the substitution in three panel phases of four / four / two sub-blocks through the staging buffers (each an exposed round
+  //      trip, covered by the other three workgroups of the CU) ----
   panel_dma(0, 0, smem + 0 * 1024);
   panel_dma(1, 0, smem + 1 * 1024);
   panel_dma(1, 1, smem + 2 * 1024);
@@ -3374,6 +3376,54 @@ chol_offdiag_f64h_kernel(const double* __restrict__ H, double* __restrict__ L, c
   landed();
   update(I3{}, I2{}, smem + 0 * 1024);
   solve_diag(I3{}, smem + 1 * 1024);
+#else
+  // (-DTHX_F64H_RING, measured EQUAL: 87.99 / 88.03 against 87.92 / 88.13 ms, profiles/r6/af_ -- not the default: ten barriers for nothing)
+  // ---- the substitution with the panel's ten sub-blocks through a RING of four slots in the staging buffers: sub-block m lives in
+  //      slot m % 4; the first four are requested here, sub-block k + 3 at step k >= 1 -- right behind the barrier that proves every
+  //      wave has finished product k - 1, the previous tenant of that slot -- so a request has three products' time to land.  The
+  //      waits count instructions: loads return in order, two LDS-direct loads per thread and sub-block, and behind sub-block k
+  //      at most k + 1, k + 2 are in flight.  One exposed round trip instead of three. ----
+  panel_dma(0, 0, smem + 0 * 1024);
+  panel_dma(1, 0, smem + 1 * 1024);
+  panel_dma(1, 1, smem + 2 * 1024);
+  panel_dma(2, 0, smem + 3 * 1024);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __syncthreads();
+  solve_diag(I0{}, smem + 0 * 1024);                 // product 0: (0,0)
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __syncthreads();
+  panel_dma(2, 1, smem + 0 * 1024);                  // sub-block 4 -> slot 0
+  update(I1{}, I0{}, smem + 1 * 1024);               // product 1: (1,0)
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __syncthreads();
+  panel_dma(2, 2, smem + 1 * 1024);                  // 5 -> slot 1
+  solve_diag(I1{}, smem + 2 * 1024);                 // product 2: (1,1)
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __syncthreads();
+  panel_dma(3, 0, smem + 2 * 1024);                  // 6 -> slot 2
+  update(I2{}, I0{}, smem + 3 * 1024);               // product 3: (2,0)
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __syncthreads();
+  panel_dma(3, 1, smem + 3 * 1024);                  // 7 -> slot 3
+  update(I2{}, I1{}, smem + 0 * 1024);               // product 4: (2,1)
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __syncthreads();
+  panel_dma(3, 2, smem + 0 * 1024);                  // 8 -> slot 0
+  solve_diag(I2{}, smem + 1 * 1024);                 // product 5: (2,2)
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __syncthreads();
+  panel_dma(3, 3, smem + 1 * 1024);                  // 9 -> slot 1
+  update(I3{}, I0{}, smem + 2 * 1024);               // product 6: (3,0)
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __syncthreads();
+  update(I3{}, I1{}, smem + 3 * 1024);               // product 7: (3,1)
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  __syncthreads();
+  update(I3{}, I2{}, smem + 0 * 1024);               // product 8: (3,2)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  solve_diag(I3{}, smem + 1 * 1024);                 // product 9: (3,3)
+#endif
   // ---- store X ----
   if (r < validB) {
     double* Lrow = Lij + (int64_t)r * ld + kq;
