@@ -1908,8 +1908,16 @@ struct SyrkSmem {
   static size_t bytes(int ypad) { return (size_t)Engine<T>::SYRK_STAGE * sizeof(T) + (size_t)ypad * sizeof(T); }
 };
 
+#ifndef THX_SYRK32_WAVES
+#define THX_SYRK32_WAVES 3
+#endif
+#ifndef THX_SYRK64_WAVES
+#define THX_SYRK64_WAVES 3   // waves per SIMD the fp64 block-compact SYRK is compiled for: 3 (168 VGPRs + 20 B of scratch) instead of 2
+                             // (200 VGPRs) takes 0.7 ms off the headline factorisation (87.9 / 88.0 -> 87.2 / 87.3 ms: its short
+                             // K-loops want a third workgroup per CU); 4 (128 VGPRs, 168 B of scratch) costs 2.7 ms (profiles/r6/ag_)
+#endif
 template <typename T, bool HB>
-__global__ void __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2)
+__global__ void __launch_bounds__(256, sizeof(T) == 4 ? (HB ? THX_SYRK32_WAVES : 3) : (HB ? THX_SYRK64_WAVES : 2))
 chol_syrk_kernel(const T* __restrict__ H, T* __restrict__ L, const T* __restrict__ damping, int ellipsoidal, T damping_eps,
                  int n, int64_t ld, int j0, const T* __restrict__ rhs, T* __restrict__ yout, int64_t ldv, TilePat pat, HBlk hb) {
   using E = Engine<T>;
