@@ -970,6 +970,8 @@ __device__ __forceinline__ void inv32(const T* Lss, A (&w)[32], int lane) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// (The scheme of rounds 2-6, kept for A/B under -DTHX_POTRF_BLOCKED; the default is potrf_inv32_lanes below: 7 us less per tile,
+//  profiles/r6/ah_.)
 // One 32x32 diagonal sub-block, blocked 16 + 16 (executed by ONE wave): the in-register factorisation and the
 // substitution for the inverse cost ~N^2 dependent readlane/FMA steps each, so halving N and doing the coupling
 // with 16x16x16 MFMA products on the LDS block halves the serial chain of chol_diag:
@@ -1155,6 +1157,63 @@ __device__ __forceinline__ int potrf_inv32_blocked(T* Dss, T* Lg, int64_t ld, in
     }
   }
   return bad;
+}
+
+// The same contract as potrf_inv32_blocked with the inverse for FREE: lanes 0..31 hold the rows of S_ss, lanes 32..63 the rows
+// of the identity, and the factorisation's column operations (column c scaled by 1/sqrt(pivot), column q -= column c * L[q][c])
+// run over all 64 lanes in the same instructions.  S -> L = S U with U = L^-T, so the identity becomes U: lane 32 + r ends with
+// a[q] = U[r][q] = W[q][r], exact zeros for q < r -- column r of W = L^-1, what inv_tri produced with a second N^2 / 2 chain of
+// dependent FMAs, two LDS round trips and five 16 x 16 MFMA couplings around it.  One wave issues in order, so the chain's cost
+// is its instruction count: 32 steps of (pivot broadcast, rsqrt, scale) + 496 (readlane, fma) pairs.
+template <typename T>
+__device__ __forceinline__ int potrf_inv32_lanes(T* Dss, T* Lg, int64_t ld, int rows_valid, int lane) {
+  using C = CT<T>;
+  using V = typename C::V;
+  constexpr int LDB = C::LDB;
+  const int r = lane & 31;
+  const bool upper = lane >= 32;
+  T a[32];
+  {
+    const V* rp = reinterpret_cast<const V*>(Dss + r * LDB);
+#pragma unroll
+    for (int q = 0; q < 32 / C::VEC; ++q) {
+      const V v = rp[q];
+      if constexpr (sizeof(T) == 4) {
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+      } else {
+        a[2 * q] = v.x; a[2 * q + 1] = v.y;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) a[q] = upper ? (q == r ? T(1) : T(0)) : a[q];
+  }
+  __builtin_amdgcn_wave_barrier();   // (every lane has read its row before column r of W overwrites the block)
+  const int bad = potrf_reg<T, 32>(a);
+  if (!upper) {   // L_ss -> global memory: one 32-element row per lane, zeros above the diagonal
+    if (r < rows_valid) {
+      V* gp = reinterpret_cast<V*>(Lg + (int64_t)r * ld);
+#pragma unroll
+      for (int q = 0; q < 32 / C::VEC; ++q) {
+        if constexpr (sizeof(T) == 4)
+          gp[q] = make_float4(4 * q <= r ? a[4 * q] : 0.f, 4 * q + 1 <= r ? a[4 * q + 1] : 0.f, 4 * q + 2 <= r ? a[4 * q + 2] : 0.f,
+                              4 * q + 3 <= r ? a[4 * q + 3] : 0.f);
+        else
+          gp[q] = make_double2(2 * q <= r ? a[2 * q] : 0.0, 2 * q + 1 <= r ? a[2 * q + 1] : 0.0);
+      }
+    }
+  } else {        // W_ss -> the LDS block, row-major: W[q][r] (zero above the diagonal by construction)
+#pragma unroll
+    for (int q = 0; q < 32; ++q) Dss[q * LDB + r] = a[q];
+  }
+  return bad;
+}
+template <typename T>
+__device__ __forceinline__ int potrf_inv32(T* Dss, T* Lg, int64_t ld, int rows_valid, int lane) {
+#ifdef THX_POTRF_BLOCKED
+  return potrf_inv32_blocked<T>(Dss, Lg, ld, rows_valid, lane);
+#else
+  return potrf_inv32_lanes<T>(Dss, Lg, ld, rows_valid, lane);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1742,7 +1801,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 #ifndef THX_POTRF_FLAT
     if (wave == sw) {
       THX_STAMP();
-      const int bad = potrf_inv32_blocked<T>(Dss, Ljj + (int64_t)(32 * sb) * ldt + 32 * sb, ldt, valid - 32 * sb, lane);
+      const int bad = potrf_inv32<T>(Dss, Ljj + (int64_t)(32 * sb) * ldt + 32 * sb, ldt, valid - 32 * sb, lane);
       if (bad != 0 && lane == 0 && info[b] == 0) info[b] = row0 + 32 * sb + bad;
       THX_STAMP();
     }
@@ -1898,7 +1957,7 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
 //   chol_potrf_kernel: the serial half, ONE WAVE per tile.  The tile's ten lower 32x32 sub-blocks live in that wave's registers in
 //                      the MFMA C/D layout (160 VGPRs in fp32); the sub-block TRSMs and trailing updates are register x register
 //                      MFMAs (Engine::blk_mma_rr: no LDS traffic at all), only the 32x32 diagonal sub-block being factorised and
-//                      inverted passes through a 4.6 KB LDS block (potrf_inv32_blocked).  5 KB of LDS and <= 256 VGPRs per tile:
+//                      inverted passes through a 4.6 KB LDS block (potrf_inv32).  5 KB of LDS and <= 256 VGPRs per tile:
 //                      EIGHT tiles per CU are in their latency-bound pivot chains at once, against three with chol_diag -- whose
 //                      workgroup pinned 53 KB of LDS and three idle waves' registers for the 126 k cycles of its chain, i.e. kept
 //                      a third of a CU from anything else.
@@ -2025,7 +2084,7 @@ chol_potrf_kernel(T* __restrict__ L, T* __restrict__ panel, int32_t* __restrict_
   __shared__ __attribute__((aligned(16))) T Dss[32 * C::LDB];   // the diagonal sub-block being factorised / inverted
   __shared__ __attribute__((aligned(16))) T vvec[TILE];         // right-hand side / solution of the fused forward substitution
   // fp32, two waves per SIMD (256 VGPRs): while the FIRST diagonal sub-block is factorised -- nine other sub-blocks live next to
-  // the temporaries of potrf_inv32_blocked -- the last block row waits in LDS instead of in spilled registers
+  // the temporaries of potrf_inv32 -- the last block row waits in LDS instead of in spilled registers
   constexpr int PARK = sizeof(T) == 4 ? 3 : 0;
   __shared__ __attribute__((aligned(16))) T park[PARK > 0 ? PARK * 32 * C::LDB : 4];
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -2061,7 +2120,7 @@ chol_potrf_kernel(T* __restrict__ L, T* __restrict__ panel, int32_t* __restrict_
       });
     }
     wave_lds_fence();
-    const int bad = potrf_inv32_blocked<T>(Dss, Lt + (int64_t)(32 * sb) * ld + 32 * sb, ld, valid - 32 * sb, lane);
+    const int bad = potrf_inv32<T>(Dss, Lt + (int64_t)(32 * sb) * ld + 32 * sb, ld, valid - 32 * sb, lane);
     if (bad != 0 && lane == 0 && info[b] == 0) info[b] = row0 + 32 * sb + bad;
     wave_lds_fence();
     E::blk_load(Tb[bidx(sb, sb)], Dss, lane);   // W_ss (full 32 x 32, zero above the diagonal)
