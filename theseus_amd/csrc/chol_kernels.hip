@@ -4239,12 +4239,21 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   // bundle-adjustment config (3072 columns, batch 256, 158 of 300 tiles) 6.82 -> 6.60 ms; DENSE frames do not gain (n = 1536:
   // batch 256 3.5 ms either way, batch 512 6.2 -> 6.4 ms; n = 3072 batch 256 21.6 -> 21.8 ms: REST(j) of a dense column is most
   // of the launch, the dispatcher does not run the two queues side by side) -- so: tile-sparse only.
-  const bool lookahead = lookahead_cfg && !split && ntiles > 2 && tp && tp->col_head_host != nullptr;
+  // DENSE frames between the right-looking schedule's batches and THX_CHOL_LOOKAHEAD_DENSE_MAX_BATCH problems (experiment, default
+  // 0 = off): the launches of a block column do not fill the chip there either (batch 64: diag(j) is 64 workgroups, REST(j)
+  // 64 (10 - j)).  MEASURED, NOT A WIN (profiles/r6/ai_: batch 64 1.66 -> 1.88 ms, 128 2.18 -> 2.22, 256 3.16 -> 3.27): the whole
+  // off-diagonal launch is one round of workgroups, HEAD(j) alone takes as long -- the chain is the serial K-loops.
+  static const int dense_la_max = [] {
+    const char* e = getenv("THX_CHOL_LOOKAHEAD_DENSE_MAX_BATCH");
+    return e ? atoi(e) : 0;
+  }();
+  const bool dense_la = !tp && !packed && B > rl_max_batch && B <= dense_la_max;
+  const bool lookahead = lookahead_cfg && !split && ntiles > 2 && ((tp && tp->col_head_host != nullptr) || dense_la);
   static const bool lpt_cfg = [] {
     const char* e = getenv("THX_CHOL_LPT");
     return e ? atoi(e) != 0 : true;
   }();
-  pat.lpt = (lookahead && lpt_cfg) ? 1 : 0;
+  pat.lpt = (lookahead && lpt_cfg && tp) ? 1 : 0;
   if (lookahead) {
     if (!ds.ev_fork) hipEventCreateWithFlags(&ds.ev_fork, hipEventDisableTiming);
     if (!ds.ev_diag) {
