@@ -1248,6 +1248,10 @@ struct TilePat {
   // turns block j into y_j in place, every substitution tile (i, j) then takes  L_ij y_j  off block i (chol_offdiag, rl == 1)
   void* rl_y;
   int64_t rl_ldv;
+  // right-looking schedule with LOOK-AHEAD (rl == 1, chol_diag only): the diagonal tile takes the previous block column's update
+  // itself -- a K-loop over the ONE tile L_j,j-1 -- and the trailing update of column j - 1 leaves tile (j, j) out: diag(j) starts
+  // as soon as the substitutions of column j - 1 are done, next to that column's trailing update instead of behind it
+  int32_t rl_la;
 };
 
 // rows (= columns) of diagonal tile j that belong to the matrix
@@ -1710,7 +1714,8 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   // SYRK on the 36 lower 16x16 blocks of the tile, nine per wave (Engine<T>::syrk36)
   // tile-sparse: only the block columns k < j in which row panel j is non-zero
   const int32_t* klist = pat.diag_k ? pat.diag_k + pat.diag_kptr[j] : nullptr;
-  const int Kspan = pat.rl ? 0 : (pat.diag_k ? (pat.diag_kptr[j + 1] - pat.diag_kptr[j]) * TILE : row0);
+  const int Kspan = pat.rl ? (pat.rl_la ? TILE : 0) : (pat.diag_k ? (pat.diag_kptr[j + 1] - pat.diag_kptr[j]) * TILE : row0);
+  const int kcol0 = (pat.rl && pat.rl_la) ? (j - 1) * TILE : 0;   // (right-looking look-ahead: the K-loop is the one tile L_j,j-1)
   const bool ycompact = pat.ent_col != nullptr;   // (level schedule: ybuf holds the K-list's blocks of y only)
   typename E::Sy acc[9];
 #pragma unroll
@@ -1748,8 +1753,8 @@ chol_diag_kernel(const T* __restrict__ H, T* __restrict__ L, T* __restrict__ pan
   prologue();
 #endif
   kloop_f<T, true, true, E::SYRK_LDT, (sizeof(T) == 8 && CT<T>::KB == 32)>(
-      L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld), valid, nullptr, 0, ldt, Kspan, tile, nullptr, tid,
-      fwd ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
+      L + lmat + (lf.packed ? 0 : (int64_t)row0 * ld) + kcol0, valid, nullptr, 0, ldt, Kspan, tile, nullptr, tid,
+      (fwd && !pat.rl) ? ybuf : nullptr, &tpart, [&]() __attribute__((always_inline)) {
     if (wave == 0) E::template syrk36<0>(tile, acc, lane);
     else if (wave == 1) E::template syrk36<1>(tile, acc, lane);
     else if (wave == 2) E::template syrk36<2>(tile, acc, lane);
@@ -2221,11 +2226,12 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   const bool upd = pat.rl >= 2;
   const int jc = pat.rl - 2;
   int ui = 0, uk = 0;
-  if (upd) {
-    ui = (int)((__builtin_sqrtf(8.f * (float)rslot + 1.f) - 1.f) * 0.5f);
-    while ((ui + 1) * (ui + 2) / 2 <= rslot) ++ui;
-    while (ui * (ui + 1) / 2 > rslot) --ui;
-    uk = rslot - ui * (ui + 1) / 2;
+  if (upd) {   // (i_first: the launch's first slot -- 1 leaves tile (jc + 1, jc + 1) to the next diagonal phase, TilePat.rl_la)
+    const int us = rslot + i_first;
+    ui = (int)((__builtin_sqrtf(8.f * (float)us + 1.f) - 1.f) * 0.5f);
+    while ((ui + 1) * (ui + 2) / 2 <= us) ++ui;
+    while (ui * (ui + 1) / 2 > us) --ui;
+    uk = us - ui * (ui + 1) / 2;
   }
   const int j = upd ? jc + 1 + uk : (pat.ent_col ? pat.ent_col[ent] : jarg);
   const int i = upd ? jc + 1 + ui : (pat.col_row ? pat.col_row[ent] : i_first + rslot);
@@ -2802,11 +2808,12 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   const bool upd = RL && pat.rl >= 2;
   const int jc = pat.rl - 2;
   int ui = 0, uk = 0;
-  if (RL && upd) {
-    ui = (int)((__builtin_sqrtf(8.f * (float)rslot + 1.f) - 1.f) * 0.5f);
-    while ((ui + 1) * (ui + 2) / 2 <= rslot) ++ui;
-    while (ui * (ui + 1) / 2 > rslot) --ui;
-    uk = rslot - ui * (ui + 1) / 2;
+  if (RL && upd) {   // (i_first: the launch's first slot, see chol_offdiag_f32_kernel)
+    const int us = rslot + i_first;
+    ui = (int)((__builtin_sqrtf(8.f * (float)us + 1.f) - 1.f) * 0.5f);
+    while ((ui + 1) * (ui + 2) / 2 <= us) ++ui;
+    while (ui * (ui + 1) / 2 > us) --ui;
+    uk = us - ui * (ui + 1) / 2;
   }
   const int j = upd ? jc + 1 + uk : (pat.ent_col ? pat.ent_col[ent] : jarg);
   const int i = upd ? jc + 1 + ui : (pat.col_row ? pat.col_row[ent] : i_first + rslot);
@@ -4336,14 +4343,15 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       const size_t dsm0 = DiagSmem<T>::bytes(0);
       // one chol_offdiag launch: nrt workgroup slots per problem (row tiles / update tiles), H from the block list, the dense H
       // frame or the L frame
-      auto off = [&](bool hbsrc, const T* Hsrc, int jarg, int i_first, int nrt, const TilePat& pp) {
+      auto off = [&](bool hbsrc, const T* Hsrc, int jarg, int i_first, int nrt, const TilePat& pp, hipStream_t so = nullptr) {
+        if (!so) so = st;
         auto go = [&](auto mode) {
           constexpr int M = decltype(mode)::value;
           if constexpr (sizeof(T) == 4)
-            hipLaunchKernelGGL(chol_offdiag_f32_kernel<M>, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, st, (const float*)(M ? nullptr : Hsrc),
+            hipLaunchKernelGGL(chol_offdiag_f32_kernel<M>, dim3(Bpad * nrt), dim3(256), OFF32_SMEM, so, (const float*)(M ? nullptr : Hsrc),
                                (float*)L, (const float*)panel, n, ld, jarg, ntiles, i_first, nrt, B, pp, M ? hb : nohb);
           else
-            hipLaunchKernelGGL((chol_offdiag_f64_kernel<M, true>), dim3(Bpad * nrt), dim3(256), OFF64_SMEM, st,
+            hipLaunchKernelGGL((chol_offdiag_f64_kernel<M, true>), dim3(Bpad * nrt), dim3(256), OFF64_SMEM, so,
                                (const double*)(M ? nullptr : Hsrc), (double*)L, (const double*)panel, n, ld, jarg, ntiles, i_first, nrt, B,
                                pp, M ? hb : nohb);
         };
@@ -4364,14 +4372,62 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       if (damping)
         hipLaunchKernelGGL(rl_damp_kernel<T>, dim3((n - TILE + 255) / 256, B), dim3(256), 0, st, (T*)L, ld, (const T*)H, ld, hb,
                            (const T*)damping, ellipsoidal, (T)eps, TILE, n);
+      // LOOK-AHEAD (fp64 by default, see below): from block column 2 on, the diagonal phase takes the previous column's
+      // update of ITS tile itself (TilePat.rl_la: a K-loop over the one tile L_j,j-1) and that column's trailing update leaves the
+      // tile out -- diag(j) then needs only the substitutions of column j - 1 and runs NEXT TO update(j - 1), which goes to the
+      // library's second stream:   st:  diag(j) -> [update(j - 1) done] -> subst(j) -> diag(j + 1) ...      aux:  update(j) after subst(j).
+      // The chain per block column loses the update launch (15 - 44 us of ~75 at batch 8).  Another summation order for the
+      // diagonal tiles' last update (the SYRK's 16 x 16 x 4 products instead of the tile kernel's): to rounding, as the schedule itself.
+      // MEASURED (profiles/r6/ao_, same box, two rounds, n = 1536): fp64 factor + forward 1.54 -> 1.34 ms at batch 8, 1.78 -> 1.60 at
+      // 16, 2.41 -> 2.19 at 32; fp32 0.74 -> 0.76, 0.86 -> 0.86, 1.10 -> 1.08 -- an fp32 update launch is as short as the two event
+      // hops that replace it.  Default: fp64 only (THX_CHOL_RL_LOOKAHEAD=1 / 0 forces it on / off for both).
+      static const int rl_la_cfg = [] {
+        const char* e = getenv("THX_CHOL_RL_LOOKAHEAD");
+        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+      }();
+      const bool la = rl_la_cfg < 0 ? sizeof(T) == 8 : rl_la_cfg != 0;
+      hipStream_t sa = st;
+      if (la) {
+        if (!ds.ev_diag) {
+          hipEventCreateWithFlags(&ds.ev_diag, hipEventDisableTiming);
+          hipEventCreateWithFlags(&ds.ev_rest, hipEventDisableTiming);
+        }
+        if (!ds.aux[0]) {
+          hipStreamCreateWithFlags(&ds.aux[0], hipStreamNonBlocking);
+          hipEventCreateWithFlags(&ds.ev_lag[0], hipEventDisableTiming);
+          hipEventCreateWithFlags(&ds.ev_join[0], hipEventDisableTiming);
+        }
+        sa = ds.aux[0];
+      }
+      TilePat pd = p1;
+      pd.rl_la = 1;
+      bool upd_pending = false;   // an update launch on the second stream that the caller's stream has not waited for yet
       for (int j = 1; j < ntiles; ++j) {
         hipLaunchKernelGGL((chol_diag_kernel<T, false>), dim3(B, 1), dim3(256), fwd_fused ? dsm : dsm0, st, Lc, (T*)L,
                            (T*)panel, (const T*)nullptr, 0, T(0), info, n, ld, j, ntiles, yc, (T*)(fwd_fused ? y : nullptr), ldv,
-                           p1, nohb);
+                           (la && j >= 2) ? pd : p1, nohb);
         if (j + 1 == ntiles) break;
+        if (upd_pending) {   // the substitutions read the tiles update(j - 1) wrote
+          hipStreamWaitEvent(st, ds.ev_rest, 0);
+          upd_pending = false;
+        }
         off(false, Lc, j, j + 1, ntiles - 1 - j, p1);
-        upd(j, false);
+        if (!la) {
+          upd(j, false);
+          continue;
+        }
+        const int m = ntiles - 1 - j, nslots = m * (m + 1) / 2 - 1;   // (slot 0 = tile (j + 1, j + 1): left to diag(j + 1))
+        if (nslots > 0) {
+          hipEventRecord(ds.ev_diag, st);
+          hipStreamWaitEvent(sa, ds.ev_diag, 0);
+          TilePat pu = pat;
+          pu.rl = 2 + j;
+          off(false, Lc, j, 1, nslots, pu, sa);
+          hipEventRecord(ds.ev_rest, sa);
+          upd_pending = true;
+        }
       }
+      if (upd_pending) hipStreamWaitEvent(st, ds.ev_rest, 0);
       if (int r = check_launch("thx_chol_factor (right-looking)")) return r;
       return (rhs && !fwd_fused) ? FACTOR_NEEDS_FORWARD : 0;   // (the caller runs the forward substitution as its own kernel)
     }
