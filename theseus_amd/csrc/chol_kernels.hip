@@ -1248,10 +1248,14 @@ struct TilePat {
   // turns block j into y_j in place, every substitution tile (i, j) then takes  L_ij y_j  off block i (chol_offdiag, rl == 1)
   void* rl_y;
   int64_t rl_ldv;
-  // right-looking schedule with LOOK-AHEAD (rl == 1, chol_diag only): the diagonal tile takes the previous block column's update
-  // itself -- a K-loop over the ONE tile L_j,j-1 -- and the trailing update of column j - 1 leaves tile (j, j) out: diag(j) starts
-  // as soon as the substitutions of column j - 1 are done, next to that column's trailing update instead of behind it
+  // right-looking schedule, two launches per block column (rl == 1): the tile takes the PREVIOUS block column's update itself -- a
+  // K-loop over the one tile of column j - 1, the left-looking kernels' own path -- instead of finding it applied: chol_diag(j)
+  // and the substitution tiles (i, j) of chol_offdiag
   int32_t rl_la;
+  // ... and ONE chol_offdiag launch per block column (rl == 1, rl_la == 1, rl_nsub > 0): slots [0, rl_nsub) = the substitution
+  // tiles (i, jarg), each taking column jarg - 1's update of itself first (a K-loop over the one tile of that column); the other
+  // slots = column jarg - 1's trailing update of the tiles (i, k), jarg < k <= i -- which nobody needs before column jarg + 1
+  int32_t rl_nsub;
 };
 
 // rows (= columns) of diagonal tile j that belong to the matrix
@@ -2223,21 +2227,24 @@ chol_offdiag_f32_kernel(const float* __restrict__ H, float* __restrict__ L, cons
   const int ent = pat.col_row ? (pat.ent_col ? 0 : pat.col_ptr[jarg]) + i_first + rslot : 0;
   // right-looking trailing update of block column jc (pat.rl = 2 + jc; dense frames): slot t -> tile (i, k), jc < k <= i,
   // rows of the lower triangle numbered row by row; "j" is the tile's own block column k, the K-loop is the one tile jc
-  const bool upd = pat.rl >= 2;
-  const int jc = pat.rl - 2;
+  const bool combo = pat.rl_nsub > 0;   // (TilePat.rl_nsub: substitution tiles of column jarg + update tiles of column jarg - 1)
+  const bool upd = combo ? rslot >= pat.rl_nsub : pat.rl >= 2;
+  const int jc = combo ? jarg - 1 : pat.rl - 2;
+  const int ub = combo ? jarg + 1 : jc + 1;          // first block row / column of the updated tiles
+  const bool sla = pat.rl == 1 && pat.rl_la != 0;    // substitution tile with the previous column's update as a one-tile K-loop
   int ui = 0, uk = 0;
-  if (upd) {   // (i_first: the launch's first slot -- 1 leaves tile (jc + 1, jc + 1) to the next diagonal phase, TilePat.rl_la)
-    const int us = rslot + i_first;
+  if (upd) {   // (i_first: the launch's first slot)
+    const int us = combo ? rslot - pat.rl_nsub : rslot + i_first;
     ui = (int)((__builtin_sqrtf(8.f * (float)us + 1.f) - 1.f) * 0.5f);
     while ((ui + 1) * (ui + 2) / 2 <= us) ++ui;
     while (ui * (ui + 1) / 2 > us) --ui;
     uk = us - ui * (ui + 1) / 2;
   }
-  const int j = upd ? jc + 1 + uk : (pat.ent_col ? pat.ent_col[ent] : jarg);
-  const int i = upd ? jc + 1 + ui : (pat.col_row ? pat.col_row[ent] : i_first + rslot);
+  const int j = upd ? ub + uk : (pat.ent_col ? pat.ent_col[ent] : jarg);
+  const int i = upd ? ub + ui : (pat.col_row ? pat.col_row[ent] : i_first + rslot);
   const int32_t* klist = pat.col_row ? pat.tile_k + pat.tile_kptr[ent] : nullptr;
-  const int Kspan = pat.rl ? (upd ? TILE : 0) : (pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE);
-  const int kcol0 = upd ? jc * TILE : 0;               // first column of the K-loop inside the row panels
+  const int Kspan = pat.rl ? ((upd || sla) ? TILE : 0) : (pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE);
+  const int kcol0 = upd ? jc * TILE : (sla ? (jarg - 1) * TILE : 0);   // first column of the K-loop inside the row panels
   if (b >= B) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const LFrame lf = lframe(pat, ld);
@@ -2805,21 +2812,24 @@ chol_offdiag_f64_kernel(const double* __restrict__ H, double* __restrict__ L, co
   //  names its block column)
   const int ent = pat.col_row ? (pat.ent_col ? 0 : pat.col_ptr[jarg]) + i_first + rslot : 0;
   // (right-looking schedule, TilePat.rl: see chol_offdiag_f32_kernel)
-  const bool upd = RL && pat.rl >= 2;
-  const int jc = pat.rl - 2;
+  const bool combo = RL && pat.rl_nsub > 0;
+  const bool upd = RL && (combo ? rslot >= pat.rl_nsub : pat.rl >= 2);
+  const int jc = combo ? jarg - 1 : pat.rl - 2;
+  const int ub = combo ? jarg + 1 : jc + 1;
+  const bool sla = RL && pat.rl == 1 && pat.rl_la != 0;
   int ui = 0, uk = 0;
   if (RL && upd) {   // (i_first: the launch's first slot, see chol_offdiag_f32_kernel)
-    const int us = rslot + i_first;
+    const int us = combo ? rslot - pat.rl_nsub : rslot + i_first;
     ui = (int)((__builtin_sqrtf(8.f * (float)us + 1.f) - 1.f) * 0.5f);
     while ((ui + 1) * (ui + 2) / 2 <= us) ++ui;
     while (ui * (ui + 1) / 2 > us) --ui;
     uk = us - ui * (ui + 1) / 2;
   }
-  const int j = upd ? jc + 1 + uk : (pat.ent_col ? pat.ent_col[ent] : jarg);
-  const int i = upd ? jc + 1 + ui : (pat.col_row ? pat.col_row[ent] : i_first + rslot);
+  const int j = upd ? ub + uk : (pat.ent_col ? pat.ent_col[ent] : jarg);
+  const int i = upd ? ub + ui : (pat.col_row ? pat.col_row[ent] : i_first + rslot);
   const int32_t* klist = pat.col_row ? pat.tile_k + pat.tile_kptr[ent] : nullptr;
-  const int Kspan = (RL && pat.rl) ? (upd ? TILE : 0) : (pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE);
-  const int kcol0 = upd ? jc * TILE : 0;
+  const int Kspan = (RL && pat.rl) ? ((upd || sla) ? TILE : 0) : (pat.col_row ? (pat.tile_kptr[ent + 1] - pat.tile_kptr[ent]) * TILE : j * TILE);
+  const int kcol0 = upd ? jc * TILE : (sla ? (jarg - 1) * TILE : 0);
   if (b >= B) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int rl = lane & 15, kq = lane >> 4;
@@ -4372,22 +4382,28 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       if (damping)
         hipLaunchKernelGGL(rl_damp_kernel<T>, dim3((n - TILE + 255) / 256, B), dim3(256), 0, st, (T*)L, ld, (const T*)H, ld, hb,
                            (const T*)damping, ellipsoidal, (T)eps, TILE, n);
-      // LOOK-AHEAD (fp64 by default, see below): from block column 2 on, the diagonal phase takes the previous column's
-      // update of ITS tile itself (TilePat.rl_la: a K-loop over the one tile L_j,j-1) and that column's trailing update leaves the
-      // tile out -- diag(j) then needs only the substitutions of column j - 1 and runs NEXT TO update(j - 1), which goes to the
-      // library's second stream:   st:  diag(j) -> [update(j - 1) done] -> subst(j) -> diag(j + 1) ...      aux:  update(j) after subst(j).
-      // The chain per block column loses the update launch (15 - 44 us of ~75 at batch 8).  Another summation order for the
-      // diagonal tiles' last update (the SYRK's 16 x 16 x 4 products instead of the tile kernel's): to rounding, as the schedule itself.
-      // MEASURED (profiles/r6/ao_, same box, two rounds, n = 1536): fp64 factor + forward 1.54 -> 1.34 ms at batch 8, 1.78 -> 1.60 at
-      // 16, 2.41 -> 2.19 at 32; fp32 0.74 -> 0.76, 0.86 -> 0.86, 1.10 -> 1.08 -- an fp32 update launch is as short as the two event
-      // hops that replace it.  Default: fp64 only (THX_CHOL_RL_LOOKAHEAD=1 / 0 forces it on / off for both).
+      // MODE 1, TWO LAUNCHES PER BLOCK COLUMN (TilePat.rl_la / rl_nsub; fp32's default; mode 0: the three launches of the plain schedule).
+      // The chain per column was diag -> substitutions -> trailing update, although the next diagonal phase and the next
+      // substitutions need only ONE block column of that update.  From block column 2 on every tile of column j takes column
+      // j - 1's update ITSELF -- chol_diag(j) and the substitution tiles (i, j) run a K-loop over the one tile of column j - 1, the
+      // left-looking kernels' own path -- and the rest of that update (tiles (i, k), j < k <= i: needed from column j + 1 on) rides
+      // in the SAME chol_offdiag launch as column j's substitutions, as extra workgroup slots:
+      //   diag(j) [own update]  ->  { substitutions (i, j) [own update]  +  update of column j - 1 on the tiles right of column j }
+      // No second stream, no events.  Another summation order for the tiles' last update (one K-loop product added before the
+      // substitution instead of a read-modify-write before it): to rounding, as the schedule itself.
+      // MODE 2, the second stream (fp64's default): only chol_diag(j) takes its own update; update(j - 1) is launched without tile
+      // (j, j) (first slot skipped) on the library's second stream and runs BESIDE diag(j); the substitutions of column j wait for
+      // both.  Hides the whole update instead of the part the substitutions cover, for two event hops per column.
+      // MEASURED (profiles/r6/ao_, n = 1536, factor + forward, plain / mode 1 / mode 2): fp32 batch 8 0.742 / 0.724 / 0.756 ms, 16:
+      // 0.856 / 0.828 / 0.855, 32: 1.10 / 1.05 / 1.08; fp64 batch 8 1.53 / 1.42 / 1.34, 16: 1.77 / 1.66 / 1.60, 32: 2.41 / 2.28 / 2.19
+      // -- an fp32 update launch is as short as the event hops, an fp64 one twice as long.  THX_CHOL_RL_LOOKAHEAD = 0 | 1 | 2 forces a mode.
       static const int rl_la_cfg = [] {
         const char* e = getenv("THX_CHOL_RL_LOOKAHEAD");
-        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+        return e ? atoi(e) : -1;
       }();
-      const bool la = rl_la_cfg < 0 ? sizeof(T) == 8 : rl_la_cfg != 0;
+      const int la = rl_la_cfg < 0 ? (sizeof(T) == 8 ? 2 : 1) : (rl_la_cfg > 2 ? 1 : rl_la_cfg);
       hipStream_t sa = st;
-      if (la) {
+      if (la == 2) {
         if (!ds.ev_diag) {
           hipEventCreateWithFlags(&ds.ev_diag, hipEventDisableTiming);
           hipEventCreateWithFlags(&ds.ev_rest, hipEventDisableTiming);
@@ -4401,30 +4417,40 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       }
       TilePat pd = p1;
       pd.rl_la = 1;
-      bool upd_pending = false;   // an update launch on the second stream that the caller's stream has not waited for yet
+      bool upd_pending = false;   // (mode 2) an update launch on the second stream that the caller's stream has not waited for yet
       for (int j = 1; j < ntiles; ++j) {
         hipLaunchKernelGGL((chol_diag_kernel<T, false>), dim3(B, 1), dim3(256), fwd_fused ? dsm : dsm0, st, Lc, (T*)L,
                            (T*)panel, (const T*)nullptr, 0, T(0), info, n, ld, j, ntiles, yc, (T*)(fwd_fused ? y : nullptr), ldv,
                            (la && j >= 2) ? pd : p1, nohb);
         if (j + 1 == ntiles) break;
-        if (upd_pending) {   // the substitutions read the tiles update(j - 1) wrote
-          hipStreamWaitEvent(st, ds.ev_rest, 0);
-          upd_pending = false;
-        }
-        off(false, Lc, j, j + 1, ntiles - 1 - j, p1);
-        if (!la) {
+        if (la == 0) {
+          off(false, Lc, j, j + 1, ntiles - 1 - j, p1);
           upd(j, false);
-          continue;
-        }
-        const int m = ntiles - 1 - j, nslots = m * (m + 1) / 2 - 1;   // (slot 0 = tile (j + 1, j + 1): left to diag(j + 1))
-        if (nslots > 0) {
-          hipEventRecord(ds.ev_diag, st);
-          hipStreamWaitEvent(sa, ds.ev_diag, 0);
-          TilePat pu = pat;
-          pu.rl = 2 + j;
-          off(false, Lc, j, 1, nslots, pu, sa);
-          hipEventRecord(ds.ev_rest, sa);
-          upd_pending = true;
+        } else if (la == 1) {
+          if (j == 1) {   // (column 1's tiles carry column 0's update already; its own update is folded into column 2's launches)
+            off(false, Lc, 1, 2, ntiles - 2, p1);
+          } else {
+            const int nsub = ntiles - 1 - j;
+            TilePat pc = pd;
+            pc.rl_nsub = nsub;
+            off(false, Lc, j, j + 1, nsub + nsub * (nsub + 1) / 2, pc);
+          }
+        } else {
+          if (upd_pending) {   // the substitutions read the tiles update(j - 1) wrote
+            hipStreamWaitEvent(st, ds.ev_rest, 0);
+            upd_pending = false;
+          }
+          off(false, Lc, j, j + 1, ntiles - 1 - j, p1);
+          const int m = ntiles - 1 - j, nslots = m * (m + 1) / 2 - 1;   // (slot 0 = tile (j + 1, j + 1): left to diag(j + 1))
+          if (nslots > 0) {
+            hipEventRecord(ds.ev_diag, st);
+            hipStreamWaitEvent(sa, ds.ev_diag, 0);
+            TilePat pu = pat;
+            pu.rl = 2 + j;
+            off(false, Lc, j, 1, nslots, pu, sa);
+            hipEventRecord(ds.ev_rest, sa);
+            upd_pending = true;
+          }
         }
       }
       if (upd_pending) hipStreamWaitEvent(st, ds.ev_rest, 0);
