@@ -856,7 +856,7 @@ def small_batch_run(cfg, ctx):
         fac = ph.get("chol_factor_hblocks") or ph.get("chol_factor") or {"avg_ms": float("nan")}
         tf = B * n ** 3 / 3.0 / (fac["avg_ms"] * 1e-3) / 1e12
         rl_max = int(opt.linear_solver.K.chol_schedule.right_looking_max_batch)
-        rl_max = 32 if rl_max < 0 else rl_max      # (include/theseus_hip.h: thx_chol_schedule.right_looking_max_batch, default 32)
+        rl_max = 64 if rl_max < 0 else rl_max      # (include/theseus_hip.h: thx_chol_schedule.right_looking_max_batch; default at 12 block columns, fp32: 64)
         points[f"b{B}"] = {"value": B * info.iters_done / dt, "ms_per_step": dt / info.iters_done * 1e3, "factor_ms": fac["avg_ms"],
                            "factor_TFLOPs": tf, "factor_frac_of_peak": tf / PEAK["f32"],
                            "schedule": "right-looking (one workgroup per tile product)" if B <= rl_max else "left-looking",

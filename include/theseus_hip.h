@@ -304,7 +304,9 @@ int thx_se3_retract(const void* poses, const void* delta, int64_t ldd, double st
  *          one workgroup per tile of the trailing matrix, each a single 128^3 product -- instead of the left-looking one whose
  *          serial K-loops leave the chip empty at 8 ... 64 problems (the reference's published batch range,
  *          evaluations/pose_graph_synthetic.sh:7).  Another summation order: the factor agrees with the left-looking one to
- *          rounding, not bit for bit.  0 = never; < 0: the default (32, or THX_CHOL_RL_MAX_BATCH).
+ *          rounding, not bit for bit.  0 = never; < 0: the default (THX_CHOL_RL_MAX_BATCH, else by dtype and size: fp32 64 problems and
+ *          fp64 40 up to 12 block columns, shrinking to 32 from 24 block columns on -- min(64, max(32, 768 / ntiles)) resp.
+ *          min(40, max(32, 480 / ntiles))).
  *        hb_scatter_max_pieces: block-compact H (thx_hblock_layout) whose off-diagonal tiles hold at most this many pieces
  *          (layout.max_tile_pieces) has them ADDED to the tile's Schur update by the matrix cores; above, they are gathered through
  *          LDS (see thx_hblock_layout.max_tile_pieces; the same bits either way).  0 = always gather; < 0: the default (64, or

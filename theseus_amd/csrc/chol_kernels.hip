@@ -3868,7 +3868,7 @@ static const int g_column_pairs_default = [] {
 }();
 static const int g_right_looking_max_default = [] {
   const char* e = getenv("THX_CHOL_RL_MAX_BATCH");
-  return e ? atoi(e) : 32;
+  return e ? atoi(e) : -1;   // (-1: by dtype and size, factor_impl)
 }();
 
 // Launch-side state is kept PER DEVICE (a process may drive several GPUs, from several threads): the dynamic-LDS limits
@@ -3942,7 +3942,12 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
   // launch per column costs more than the chain there), else the fused chol_diag_kernel
   const int split_diag_min = (sched && sched->split_diag_min_batch >= 0) ? sched->split_diag_min_batch : g_split_diag_min_default;
   const int column_pairs = (sched && sched->column_pairs >= 0) ? sched->column_pairs : g_column_pairs_default;
-  const int rl_max_batch = (sched && sched->right_looking_max_batch >= 0) ? sched->right_looking_max_batch : g_right_looking_max_default;
+  // (default hand-over to the left-looking schedule, measured at 12 block columns with two launches per column, profiles/r6/ar_:
+  //  fp32 right-looking wins through 64 problems -- batch 40 1.49 -> 1.16 ms, 64 1.66 -> 1.58 --, fp64 through 40; the update
+  //  launches grow with the SQUARE of the block columns, so the limit shrinks with them, down to round 6's first 32)
+  const int rl_auto = sizeof(T) == 4 ? min(64, max(32, 768 / max(ntiles, 1))) : min(40, max(32, 480 / max(ntiles, 1)));
+  const int rl_max_batch = (sched && sched->right_looking_max_batch >= 0) ? sched->right_looking_max_batch
+                           : (g_right_looking_max_default >= 0 ? g_right_looking_max_default : rl_auto);
   const bool fused_diag = B < split_diag_min;
   const size_t dsm = fused_diag ? DiagSmem<T>::bytes(rhs ? ntiles * TILE : 0) : SyrkSmem<T>::bytes(rhs ? ntiles * TILE : 0);
   if (dsm > LDS_LIMIT) return fail("thx_chol_factor: n too large for the fused forward substitution (LDS)");

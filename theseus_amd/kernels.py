@@ -756,8 +756,8 @@ class HipKernels:
 
     def chol_right_looking_max_batch(self, max_batch: int) -> int:
         """Schedule of THIS kernels object's fp32 dense-frame factorisations (thx_chol_schedule.right_looking_max_batch): batches of
-        at most ``max_batch`` problems take the right-looking schedule (0 never, -1 the library default).  Returns the previous
-        setting."""
+        at most ``max_batch`` problems take the right-looking schedule (0 never, -1 the library default: by dtype and size -- fp32 64 /
+        fp64 40 problems up to 12 block columns, 32 from 24 on).  Returns the previous setting."""
         prev = int(self.chol_schedule.right_looking_max_batch)
         self.chol_schedule.right_looking_max_batch = int(max_batch)
         return prev

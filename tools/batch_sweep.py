@@ -44,7 +44,7 @@ for B in batches:
         torch.cuda.synchronize()
         fac = ev0.elapsed_time(ev1) / 5
     tf = B * n ** 3 / 3.0 / (fac * 1e-3) / 1e12
-    sched = "right-looking" if B <= 32 else ("left-looking" if B < 128 else ("left-looking, column pairs" if B < 1024 else
+    sched = "right-looking" if B <= int(os.environ.get("THX_CHOL_RL_MAX_BATCH", "64")) else ("left-looking" if B < 128 else ("left-looking, column pairs" if B < 1024 else
                                                                             "left-looking, column pairs, two half-batch streams"))
     print(f"{B:6d} {best:16.3f} {B / best * 1e3:15.0f} {fac:10.3f} {tf:8.1f} {tf / 157.3:8.3f}  {sched}", flush=True)
     del sol, info, layer, opt, obj, inputs
