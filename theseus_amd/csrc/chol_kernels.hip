@@ -4380,13 +4380,45 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
         pu.rl = 2 + jc;
         off(first && use_hb, first ? (const T*)H : Lc, jc, 0, m * (m + 1) / 2, pu);
       };
+      static const int rl_la_cfg = [] {
+        const char* e = getenv("THX_CHOL_RL_LOOKAHEAD");
+        return e ? atoi(e) : -1;
+      }();
+      const int la = rl_la_cfg < 0 ? (sizeof(T) == 8 ? 2 : 1) : (rl_la_cfg > 2 ? 1 : rl_la_cfg);
       // block column 0: the kernels as they are (no earlier columns), reading H
       launch_diag_n(h, 0, 1, true, dsm);   // (with a right-hand side: y_0 = W_00 g_0 -- kept when the forward substitution is fused)
       off(use_hb, (const T*)H, 0, 1, ntiles - 1, p0);
-      upd(0, true);
-      if (damping)
-        hipLaunchKernelGGL(rl_damp_kernel<T>, dim3((n - TILE + 255) / 256, B), dim3(256), 0, st, (T*)L, ld, (const T*)H, ld, hb,
-                           (const T*)damping, ellipsoidal, (T)eps, TILE, n);
+      int jstart = 1;
+      if (la == 1) {
+        // (mode 1) block column 1 the same way, straight from H: chol_diag(1) and the substitution tiles (i, 1) read their tile of H
+        // (block list or dense frame; the diagonal tile with its damping) and take column 0's update through the one-tile K-loop;
+        // column 0's update of the tiles right of column 1 -- which moves H into the L frame -- rides with the substitutions.
+        // (The plain schedule's update(0) is 66 tiles per problem at 12 block columns: 528 workgroups at batch 8, 16 more than one round.)
+        TilePat pd1 = p0;
+        pd1.rl = 1;
+        pd1.rl_la = 1;
+        if (use_hb)
+          hipLaunchKernelGGL((chol_diag_kernel<T, true>), dim3(B, 1), dim3(256), fwd_fused ? dsm : dsm0, st, (const T*)nullptr, (T*)L,
+                             (T*)panel, (const T*)damping, ellipsoidal, (T)eps, info, n, ld, 1, ntiles, yc, (T*)(fwd_fused ? y : nullptr),
+                             ldv, pd1, hb);
+        else
+          hipLaunchKernelGGL((chol_diag_kernel<T, false>), dim3(B, 1), dim3(256), fwd_fused ? dsm : dsm0, st, (const T*)H, (T*)L,
+                             (T*)panel, (const T*)damping, ellipsoidal, (T)eps, info, n, ld, 1, ntiles, yc, (T*)(fwd_fused ? y : nullptr),
+                             ldv, pd1, nohb);
+        const int nsub = ntiles - 2;
+        TilePat pc1 = pd1;
+        pc1.rl_nsub = nsub;
+        off(use_hb, (const T*)H, 1, 2, nsub + nsub * (nsub + 1) / 2, pc1);
+        if (damping && n > 2 * TILE)
+          hipLaunchKernelGGL(rl_damp_kernel<T>, dim3((n - 2 * TILE + 255) / 256, B), dim3(256), 0, st, (T*)L, ld, (const T*)H, ld, hb,
+                             (const T*)damping, ellipsoidal, (T)eps, 2 * TILE, n);
+        jstart = 2;
+      } else {
+        upd(0, true);
+        if (damping)
+          hipLaunchKernelGGL(rl_damp_kernel<T>, dim3((n - TILE + 255) / 256, B), dim3(256), 0, st, (T*)L, ld, (const T*)H, ld, hb,
+                             (const T*)damping, ellipsoidal, (T)eps, TILE, n);
+      }
       // MODE 1, TWO LAUNCHES PER BLOCK COLUMN (TilePat.rl_la / rl_nsub; fp32's default; mode 0: the three launches of the plain schedule).
       // The chain per column was diag -> substitutions -> trailing update, although the next diagonal phase and the next
       // substitutions need only ONE block column of that update.  From block column 2 on every tile of column j takes column
@@ -4402,11 +4434,6 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       // MEASURED (profiles/r6/ao_, n = 1536, factor + forward, plain / mode 1 / mode 2): fp32 batch 8 0.742 / 0.724 / 0.756 ms, 16:
       // 0.856 / 0.828 / 0.855, 32: 1.10 / 1.05 / 1.08; fp64 batch 8 1.53 / 1.42 / 1.34, 16: 1.77 / 1.66 / 1.60, 32: 2.41 / 2.28 / 2.19
       // -- an fp32 update launch is as short as the event hops, an fp64 one twice as long.  THX_CHOL_RL_LOOKAHEAD = 0 | 1 | 2 forces a mode.
-      static const int rl_la_cfg = [] {
-        const char* e = getenv("THX_CHOL_RL_LOOKAHEAD");
-        return e ? atoi(e) : -1;
-      }();
-      const int la = rl_la_cfg < 0 ? (sizeof(T) == 8 ? 2 : 1) : (rl_la_cfg > 2 ? 1 : rl_la_cfg);
       hipStream_t sa = st;
       if (la == 2) {
         if (!ds.ev_diag) {
@@ -4423,7 +4450,7 @@ static int factor_impl(const void* H, int64_t ld, int n, int B, const void* damp
       TilePat pd = p1;
       pd.rl_la = 1;
       bool upd_pending = false;   // (mode 2) an update launch on the second stream that the caller's stream has not waited for yet
-      for (int j = 1; j < ntiles; ++j) {
+      for (int j = jstart; j < ntiles; ++j) {
         hipLaunchKernelGGL((chol_diag_kernel<T, false>), dim3(B, 1), dim3(256), fwd_fused ? dsm : dsm0, st, Lc, (T*)L,
                            (T*)panel, (const T*)nullptr, 0, T(0), info, n, ld, j, ntiles, yc, (T*)(fwd_fused ? y : nullptr), ldv,
                            (la && j >= 2) ? pd : p1, nohb);
